@@ -1,0 +1,487 @@
+/*
+ * tce_oracle.c -- CPU ORACLE for the quantized-matmul hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is a plain-C restatement of the arithmetic of TinyChatEngine's
+ * kernels/matmul.h surface (reference @ 2024_08_07).  It is the checker the GPU
+ * parity tests compare against.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load it; the product path
+ * (tinychatengine_amd/) never links, imports or calls anything in oracle/.
+ *
+ * Parity pin: every function here is checked bit-for-bit (fp32 / int8 paths) or
+ * exactly (software-fp16 path) against the reference's own sources compiled
+ * from /root/reference into oracle/_ref/libtce_ref.so (see oracle/Makefile and
+ * tests/test_oracle_vs_ref.py) and against the committed vectors in
+ * tests/golden/ that were produced by that library (tests/golden/make_golden.py).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math  (NO -Ofast, NO -mfma: the
+ * int8 epilogue must round the multiply and the add separately -- SURVEY App. B).
+ *
+ * Each function cites the reference file:line it restates.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------- */
+/* IEEE binary16 helpers (round-to-nearest-even), independent of any library */
+/* ------------------------------------------------------------------------- */
+
+/* double -> binary16 with a single correct RNE rounding (no double rounding). */
+ORC_API uint16_t orc_f64_to_f16(double v) {
+    uint64_t bits;
+    memcpy(&bits, &v, 8);
+    uint16_t sign = (uint16_t)((bits >> 48) & 0x8000u);
+    int64_t exp = (int64_t)((bits >> 52) & 0x7FF);
+    uint64_t man = bits & 0xFFFFFFFFFFFFFull;
+    if (exp == 0x7FF) { /* inf / nan */
+        return (uint16_t)(sign | 0x7C00u | (man ? 0x200u : 0));
+    }
+    if (exp == 0 && man == 0) return sign;
+    int64_t e = exp - 1023; /* unbiased */
+    if (e > 15) return (uint16_t)(sign | 0x7C00u);
+    /* significand with hidden bit, 53 bits */
+    uint64_t sig = (exp ? (1ull << 52) : 0) | man;
+    int shift; /* how many low bits of sig are dropped */
+    int64_t he; /* half biased exponent field */
+    if (e >= -14) {
+        shift = 42; /* keep 11 bits (1 hidden + 10) */
+        he = e + 15;
+    } else {
+        /* subnormal half: value = m * 2^-24, m in [0,1023] */
+        shift = (int)(42 + (-14 - e));
+        he = 0;
+        if (shift > 63) return sign; /* underflow to zero (|v| < 2^-35) */
+    }
+    uint64_t kept = sig >> shift;
+    uint64_t rem = sig & ((1ull << shift) - 1);
+    uint64_t half = 1ull << (shift - 1);
+    if (rem > half || (rem == half && (kept & 1))) kept++;
+    uint32_t out;
+    if (he == 0) {
+        out = (uint32_t)kept; /* may carry into exponent field = smallest normal, correct */
+    } else {
+        out = (uint32_t)(((uint64_t)he << 10) + (kept - 1024)); /* carry propagates into exponent */
+    }
+    if (out >= 0x7C00u) out = 0x7C00u;
+    return (uint16_t)(sign | out);
+}
+
+ORC_API uint16_t orc_f32_to_f16(float v) { return orc_f64_to_f16((double)v); }
+
+ORC_API float orc_f16_to_f32(uint16_t h) {
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1F;
+    uint32_t man = h & 0x3FF;
+    uint32_t out;
+    if (exp == 0) {
+        if (man == 0) {
+            out = sign;
+        } else {
+            int e = -1;
+            do { man <<= 1; e++; } while (!(man & 0x400));
+            man &= 0x3FF;
+            out = sign | (uint32_t)((127 - 15 - e) << 23) | (man << 13);
+        }
+    } else if (exp == 31) {
+        out = sign | 0x7F800000u | (man << 13);
+    } else {
+        out = sign | ((exp + 127 - 15) << 23) | (man << 13);
+    }
+    float f;
+    memcpy(&f, &out, 4);
+    return f;
+}
+
+ORC_API void orc_f32_to_f16_array(const float *src, uint16_t *dst, int64_t n) {
+    for (int64_t i = 0; i < n; i++) dst[i] = orc_f32_to_f16(src[i]);
+}
+ORC_API void orc_f16_to_f32_array(const uint16_t *src, float *dst, int64_t n) {
+    for (int64_t i = 0; i < n; i++) dst[i] = orc_f16_to_f32(src[i]);
+}
+
+/* ------------------------------------------------------------------------- */
+/* Weight-format spec: group quantizer + the three packings used on the path  */
+/* ------------------------------------------------------------------------- */
+
+/* llm/tools/quantize_methods.py:9-21 (python) == llm/src/nn_modules/cuda/utils.cu:162-178 */
+ORC_API int orc_zeros_width(int in_features, int group_size) {
+    int mult;
+    if (group_size >= 128) mult = 1;
+    else if (group_size == 64) mult = 2;
+    else if (group_size == 32) mult = 4;
+    else return -1;
+    int w = (in_features / group_size + 7) / 8;
+    return ((w + mult - 1) / mult) * mult;
+}
+
+/*
+ * Group quantizer shared by quantize_row_q4_5 / q4_6 (quantize_methods.py:323-339,
+ * 392-411): per group of G consecutive values along IC (the flat array is
+ * reshaped (nb, G)), d = x[argmax|x|] / -8 (signed), id = 1/d (0 if d == 0),
+ * code = trunc(clip(x*id + 8.5, 0, 15)).  All arithmetic in float32 like numpy.
+ * codes: uint8 [N*K] (one code per byte), d_out: float32 [N*K/G].
+ */
+ORC_API void orc_group_quantize(const float *w, int64_t n_elems, int G, uint8_t *codes, float *d_out) {
+    int64_t nb = n_elems / G;
+    for (int64_t b = 0; b < nb; b++) {
+        const float *x = w + b * G;
+        int imax = 0;
+        float amax = fabsf(x[0]);
+        for (int i = 1; i < G; i++) { /* np.argmax: first maximal element */
+            float a = fabsf(x[i]);
+            if (a > amax) { amax = a; imax = i; }
+        }
+        float d = x[imax] / -8.0f;
+        float id = (d == 0.0f) ? 0.0f : 1.0f / d;
+        d_out[b] = d;
+        for (int i = 0; i < G; i++) {
+            float t = x[i] * id;
+            t = t + 8.5f;
+            if (t < 0.0f) t = 0.0f;
+            if (t > 15.0f) t = 15.0f;
+            codes[b * G + i] = (uint8_t)(int32_t)t; /* astype(int32): truncation */
+        }
+    }
+}
+
+/*
+ * q4_6 packing = what Linear_half_int4 loads (quantize_methods.py:413-440,
+ * llm/include/ops/linear.h:188-210).
+ *   qweight  uint32 [N][K/8]   nibble i of word j = code[n][8j+i]
+ *   scales   fp16   [N][zw*8]  first K/G valid, rest 0
+ *   zeros    uint32 [N][zw]    every nibble = 8
+ */
+ORC_API void orc_pack_q4_6(const uint8_t *codes, const float *d, int N, int K, int G, uint32_t *qweight,
+                           uint16_t *scales, uint32_t *zeros) {
+    int zw = orc_zeros_width(K, G);
+    int sfw = zw * 8;
+    int ng = K / G;
+    for (int n = 0; n < N; n++) {
+        for (int j = 0; j < K / 8; j++) {
+            uint32_t word = 0;
+            for (int i = 0; i < 8; i++) word |= (uint32_t)(codes[(int64_t)n * K + 8 * j + i] & 0xF) << (4 * i);
+            qweight[(int64_t)n * (K / 8) + j] = word;
+        }
+        for (int g = 0; g < sfw; g++)
+            scales[(int64_t)n * sfw + g] = (g < ng) ? orc_f32_to_f16(d[(int64_t)n * ng + g]) : 0;
+        for (int z = 0; z < zw; z++) zeros[(int64_t)n * zw + z] = 0x88888888u;
+    }
+}
+
+/*
+ * q4_5 packing = AWQ GEMM layout consumed by naive_mat_mul_fp16_int4
+ * (quantize_methods.py:341-366, kernels/cuda/matmul_int4.cu:19-39).
+ *   qweight uint32 [K][N/8]  nibbles 0..7 of word j hold n = 8j + {0,2,4,6,1,3,5,7}
+ *   scales  fp16   [K/G][N]
+ *   zeros   uint32 [K/G][N/8] = 0x88888888
+ */
+ORC_API void orc_pack_q4_5(const uint8_t *codes, const float *d, int N, int K, int G, uint32_t *qweight,
+                           uint16_t *scales, uint32_t *zeros) {
+    static const int order[8] = {0, 2, 4, 6, 1, 3, 5, 7};
+    int ng = K / G;
+    for (int k = 0; k < K; k++)
+        for (int j = 0; j < N / 8; j++) {
+            uint32_t word = 0;
+            for (int i = 0; i < 8; i++)
+                word |= (uint32_t)(codes[(int64_t)(8 * j + order[i]) * K + k] & 0xF) << (4 * i);
+            qweight[(int64_t)k * (N / 8) + j] = word;
+        }
+    for (int g = 0; g < ng; g++)
+        for (int n = 0; n < N; n++) scales[(int64_t)g * N + n] = orc_f32_to_f16(d[(int64_t)n * ng + g]);
+    for (int64_t i = 0; i < (int64_t)ng * (N / 8); i++) zeros[i] = 0x88888888u;
+}
+
+/* sequential packing (q4_0 style, quantize_methods.py:28-76 / kernels/matmul_int4.cc:116-120):
+ *   uint8 [N][K/2], byte b of a row = code[2b] | code[2b+1] << 4 */
+ORC_API void orc_pack_sequential(const uint8_t *codes, int N, int K, uint8_t *packed) {
+    for (int64_t i = 0; i < (int64_t)N * K / 2; i++) packed[i] = (uint8_t)((codes[2 * i] & 0xF) | (codes[2 * i + 1] << 4));
+}
+
+/* inverse of the q4_6 weight packing: uint32 [N][K/8] -> one code per byte [N][K] */
+ORC_API void orc_unpack_q4_6(const uint32_t *qweight, int N, int K, uint8_t *codes) {
+    for (int64_t w = 0; w < (int64_t)N * (K / 8); w++) {
+        uint32_t word = qweight[w];
+        for (int i = 0; i < 8; i++) codes[w * 8 + i] = (uint8_t)((word >> (4 * i)) & 0xF);
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* W4 paths                                                                   */
+/* ------------------------------------------------------------------------- */
+
+/*
+ * MatmulOperator::naive_mat_mul_int4, generic (#else) branch --
+ * kernels/matmul_int4.cc:105-127.  A f32 [M][K]; B uint8 [N][K/2] sequential
+ * nibbles; scales f32 [N][K/G]; one float zero point; strictly sequential fp32
+ * accumulation over k; (q - z) * s is rounded once, then a*deq, then the add.
+ */
+ORC_API void orc_naive_mat_mul_int4(int M, int N, int K, int G, const float *A, const uint8_t *B, const float *scales,
+                                    float zero_point, float *C) {
+    for (int i = 0; i < M; i++)
+        for (int j = 0; j < N; j++) {
+            float acc = 0.0f;
+            for (int k = 0; k < K; k += G) {
+                float s = scales[((int64_t)j * K + k) / G];
+                const float *a = A + (int64_t)i * K + k;
+                const uint8_t *b = B + (int64_t)j * (K / 2) + k / 2;
+                for (int q = 0; q < G / 2; q++) {
+                    uint8_t p = b[q];
+                    float d0 = ((float)(p & 0x0F) - zero_point) * s;
+                    float d1 = ((float)(p >> 4) - zero_point) * s;
+                    float t0 = a[2 * q] * d0;
+                    acc = acc + t0;
+                    float t1 = a[2 * q + 1] * d1;
+                    acc = acc + t1;
+                }
+            }
+            C[(int64_t)i * N + j] = acc;
+        }
+}
+
+/* naive_mat_mul_int4_with_offset -- kernels/matmul_int4.cc:133-165 (deq = (q-z)*s + o). */
+ORC_API void orc_naive_mat_mul_int4_with_offset(int M, int N, int K, int G, const float *A, const uint8_t *B,
+                                                const float *scales, const float *offset, float zero_point, float *C) {
+    for (int i = 0; i < M; i++)
+        for (int j = 0; j < N; j++) {
+            float acc = 0.0f;
+            for (int k = 0; k < K; k += G) {
+                float s = scales[((int64_t)j * K + k) / G];
+                float o = offset[((int64_t)j * K + k) / G];
+                const float *a = A + (int64_t)i * K + k;
+                const uint8_t *b = B + (int64_t)j * (K / 2) + k / 2;
+                for (int q = 0; q < G / 2; q++) {
+                    uint8_t p = b[q];
+                    float m0 = ((float)(p & 0x0F) - zero_point) * s;
+                    float d0 = m0 + o;
+                    float m1 = ((float)(p >> 4) - zero_point) * s;
+                    float d1 = m1 + o;
+                    float t0 = a[2 * q] * d0;
+                    acc = acc + t0;
+                    float t1 = a[2 * q + 1] * d1;
+                    acc = acc + t1;
+                }
+            }
+            C[(int64_t)i * N + j] = acc;
+        }
+}
+
+/* mat_mul_accelerator_int4_fast (ref backend) -- kernels/ref/matmul_ref_int4.cc:11-38:
+ * deq = q*s + o (no zero point), block 32 only. */
+ORC_API int orc_ref_int4_fast(int M, int N, int K, int G, const float *A, const uint8_t *B, const float *scales,
+                              const float *offset, float *C) {
+    if (G != 32) return -1;
+    for (int i = 0; i < M; i++)
+        for (int j = 0; j < N; j++) {
+            float acc = 0.0f;
+            for (int k = 0; k < K; k += G) {
+                float s = scales[(int64_t)j * (K / 32) + k / 32];
+                float o = offset[(int64_t)j * (K / 32) + k / 32];
+                const uint8_t *b = B + (int64_t)j * (K / 2) + k / 2;
+                const float *a = A + (int64_t)i * K + k;
+                for (int q = 0; q < G / 2; q++) {
+                    uint8_t p = b[q];
+                    float m0 = (float)(p & 0x0F) * s;
+                    float d0 = m0 + o;
+                    float m1 = (float)(p >> 4) * s;
+                    float d1 = m1 + o;
+                    float t0 = a[2 * q] * d0;
+                    acc = acc + t0;
+                    float t1 = a[2 * q + 1] * d1;
+                    acc = acc + t1;
+                }
+            }
+            C[(int64_t)i * N + j] = acc;
+        }
+    return 0;
+}
+
+/*
+ * W4A16 GEMV on the q4_6 layout -- the math of gemv_kernel_g128 / g64
+ * (kernels/cuda/gemv_cuda.cu:140-194, 68-123) restated with the accumulation
+ * order of the kernels/ref-class oracle (naive_mat_mul_int4): inputs and scales
+ * are fp16 promoted to fp32, the zero point is READ per group from the packed
+ * zeros (gemv_cuda.cu:159,166), deq = s * (q - z) in fp32, accumulate in fp32
+ * sequentially over k, final result stored both as fp32 and as __float2half (RNE,
+ * gemv_cuda.cu:192).  With all zero nibbles == 8 the fp32 result is bit-identical
+ * to orc_naive_mat_mul_int4 on the unpacked codes (tests pin this).
+ * zeros row stride = orc_zeros_width(K,G); scales row stride = 8x that.
+ */
+ORC_API void orc_w4a16_gemv_q4_6(int M, int N, int K, int G, const uint16_t *A, const uint32_t *qweight,
+                                 const uint16_t *scales, const uint32_t *zeros, float *C32, uint16_t *C16) {
+    int zw = orc_zeros_width(K, G);
+    int sfw = zw * 8;
+    for (int i = 0; i < M; i++)
+        for (int j = 0; j < N; j++) {
+            float acc = 0.0f;
+            for (int k = 0; k < K; k += G) {
+                int g = k / G;
+                float s = orc_f16_to_f32(scales[(int64_t)j * sfw + g]);
+                float z = (float)((zeros[(int64_t)j * zw + g / 8] >> (4 * (g % 8))) & 0xF);
+                for (int kk = k; kk < k + G; kk++) {
+                    uint32_t word = qweight[(int64_t)j * (K / 8) + kk / 8];
+                    float q = (float)((word >> (4 * (kk % 8))) & 0xF);
+                    float deq = (q - z) * s;
+                    float t = orc_f16_to_f32(A[(int64_t)i * K + kk]) * deq;
+                    acc = acc + t;
+                }
+            }
+            if (C32) C32[(int64_t)i * N + j] = acc;
+            if (C16) C16[(int64_t)i * N + j] = orc_f32_to_f16(acc);
+        }
+}
+
+/*
+ * MatmulOperator::naive_mat_mul_fp16_int4 -- kernels/cuda/matmul_int4.cu:8-48.
+ * AWQ GEMM layout (q4_5), zero point fixed 8, EVERY operation in software
+ * binary16 with RNE per operation (half_float 2.2.0 without
+ * HALF_ARITHMETIC_TYPE: llm/half-2.2.0/include/half.hpp:296,386-387):
+ *   weight = h( h(q - 8) * s );  acc = h( acc + h(input * weight) ).
+ * Products of two halfs are exact in double; sums of two halfs are exact in
+ * double; so one orc_f64_to_f16 per op reproduces the correctly rounded result.
+ */
+ORC_API void orc_naive_mat_mul_fp16_int4(int M, int N, int K, int G, const uint16_t *A, const uint32_t *qweight,
+                                         const uint16_t *scales, uint16_t *C) {
+    static const int shift_of[8] = {0, 16, 4, 20, 8, 24, 12, 28}; /* j%8 -> bit offset (order 0 2 4 6 1 3 5 7) */
+    for (int i = 0; i < M; i++)
+        for (int j = 0; j < N; j++) {
+            uint16_t acc = 0;
+            for (int k = 0; k < K; k++) {
+                double s = (double)orc_f16_to_f32(scales[(int64_t)(k / G) * N + j]);
+                double in = (double)orc_f16_to_f32(A[(int64_t)i * K + k]);
+                uint32_t word = qweight[(int64_t)k * (N / 8) + j / 8];
+                double q = (double)((word >> shift_of[j % 8]) & 0xF);
+                uint16_t qz = orc_f64_to_f16(q - 8.0);
+                uint16_t wgt = orc_f64_to_f16((double)orc_f16_to_f32(qz) * s);
+                uint16_t prod = orc_f64_to_f16(in * (double)orc_f16_to_f32(wgt));
+                acc = orc_f64_to_f16((double)orc_f16_to_f32(acc) + (double)orc_f16_to_f32(prod));
+            }
+            C[(int64_t)i * N + j] = acc;
+        }
+}
+
+/* ------------------------------------------------------------------------- */
+/* W8A8 (SmoothQuant) paths -- kernels/ref/matmul_ref_int8.cc                */
+/* ------------------------------------------------------------------------- */
+
+static inline int32_t orc_dot_i8(const int8_t *a, const int8_t *b, int k) {
+    int32_t acc = 0;
+    for (int t = 0; t < k; t++) acc += (int32_t)a[t] * (int32_t)b[t];
+    return acc;
+}
+
+static inline int8_t orc_requant(float v, int qmin, int qmax) {
+    /* (int32_t)std::round(v); MAX(.,q_min); MIN(.,q_max); (int8_t) -- matmul_ref_int8.cc:29-32 */
+    int32_t r = (int32_t)roundf(v);
+    if (r < qmin) r = qmin;
+    if (r > qmax) r = qmax;
+    return (int8_t)r;
+}
+
+/* int8_ref_matmul -- matmul_ref_int8.cc:11-35: int8 bias, alpha, beta; B is [N][K]. */
+ORC_API void orc_int8_matmul_bias_i8(int M, int N, int K, const int8_t *A, const int8_t *B, const int8_t *bias,
+                                     float alpha, float beta, int qmin, int qmax, int8_t *C) {
+    for (int i = 0; i < M; i++)
+        for (int j = 0; j < N; j++) {
+            int32_t acc = orc_dot_i8(A + (int64_t)i * K, B + (int64_t)j * K, K);
+            float t = (float)acc * alpha;
+            float u = (float)bias[j] * beta;
+            float v = t + u;
+            C[(int64_t)i * N + j] = orc_requant(v, qmin, qmax);
+        }
+}
+
+/* int8_ref_matmul_nobias -- matmul_ref_int8.cc:37-61 */
+ORC_API void orc_int8_matmul_nobias_i8(int M, int N, int K, const int8_t *A, const int8_t *B, float alpha, int qmin,
+                                       int qmax, int8_t *C) {
+    for (int i = 0; i < M; i++)
+        for (int j = 0; j < N; j++) {
+            int32_t acc = orc_dot_i8(A + (int64_t)i * K, B + (int64_t)j * K, K);
+            float t = (float)acc * alpha;
+            C[(int64_t)i * N + j] = orc_requant(t, qmin, qmax);
+        }
+}
+
+/* int8_ref_matmul_nobias_batch -- matmul_ref_int8.cc:63-87: row i of A uses its own B[i] ([M][N][K]). */
+ORC_API void orc_int8_matmul_nobias_batch_i8(int M, int N, int K, const int8_t *A, const int8_t *B, float alpha,
+                                             int qmin, int qmax, int8_t *C) {
+    for (int i = 0; i < M; i++)
+        for (int j = 0; j < N; j++) {
+            int32_t acc = orc_dot_i8(A + (int64_t)i * K, B + ((int64_t)i * N + j) * K, K);
+            float t = (float)acc * alpha;
+            C[(int64_t)i * N + j] = orc_requant(t, qmin, qmax);
+        }
+}
+
+/* int8_ref_matmul_bfp32_ofp32 -- matmul_ref_int8.cc:89-111: fp32 bias added after the alpha scale. */
+ORC_API void orc_int8_matmul_bias_f32(int M, int N, int K, const int8_t *A, const int8_t *B, const float *bias,
+                                      float alpha, float *C) {
+    for (int i = 0; i < M; i++)
+        for (int j = 0; j < N; j++) {
+            int32_t acc = orc_dot_i8(A + (int64_t)i * K, B + (int64_t)j * K, K);
+            float t = (float)acc * alpha;
+            C[(int64_t)i * N + j] = t + bias[j];
+        }
+}
+
+/* int8_ref_matmul_nobias_ofp32 -- matmul_ref_int8.cc:113-135 */
+ORC_API void orc_int8_matmul_nobias_f32(int M, int N, int K, const int8_t *A, const int8_t *B, float alpha, float *C) {
+    for (int i = 0; i < M; i++)
+        for (int j = 0; j < N; j++) {
+            int32_t acc = orc_dot_i8(A + (int64_t)i * K, B + (int64_t)j * K, K);
+            C[(int64_t)i * N + j] = (float)acc * alpha;
+        }
+}
+
+/* int8_ref_matmul_nobias_ofp32_batch -- matmul_ref_int8.cc:137-159 */
+ORC_API void orc_int8_matmul_nobias_batch_f32(int M, int N, int K, const int8_t *A, const int8_t *B, float alpha,
+                                              float *C) {
+    for (int i = 0; i < M; i++)
+        for (int j = 0; j < N; j++) {
+            int32_t acc = orc_dot_i8(A + (int64_t)i * K, B + ((int64_t)i * N + j) * K, K);
+            C[(int64_t)i * N + j] = (float)acc * alpha;
+        }
+}
+
+/*
+ * MatmulOperator::naive_mat_mul_int8 -- kernels/matmul_int8.cc:8-30.  Zero-point
+ * form, B UNtransposed [K][N], truncating cast of acc * (A_sc*B_sc/C_sc).
+ */
+ORC_API void orc_naive_mat_mul_int8(int M, int N, int K, const int8_t *A, const int8_t *B, int32_t A_zp, int32_t C_zp,
+                                    float A_sc, float B_sc, float C_sc, int qmin, int qmax, int8_t *C) {
+    float t0 = A_sc * B_sc;
+    float eff = t0 / C_sc;
+    for (int i = 0; i < M; i++)
+        for (int j = 0; j < N; j++) {
+            int32_t acc = 0;
+            for (int k = 0; k < K; k++) acc += ((int32_t)A[(int64_t)i * K + k] - A_zp) * (int32_t)B[(int64_t)k * N + j];
+            float f = (float)acc * eff;
+            int32_t r = (int32_t)f;
+            r -= C_zp;
+            if (r < qmin) r = qmin;
+            if (r > qmax) r = qmax;
+            C[(int64_t)i * N + j] = (int8_t)r;
+        }
+}
+
+/* ------------------------------------------------------------------------- */
+/* fp32 helpers on the same operator surface                                  */
+/* ------------------------------------------------------------------------- */
+
+/* mat_mul_transposed (kernels/matmul_imp.cc:23-35) == fp32_ref_matmul (kernels/ref/matmul_ref_fp32.cc:11-30):
+ * C = A . B^T, B [N][K], sequential fp32 accumulate.  bias may be NULL
+ * (…_fastover_column_bias, kernels/avx/matmul_avx_fp32.cc:93-117 adds bias[j] after the sum). */
+ORC_API void orc_fp32_matmul_transposed(int M, int N, int K, const float *A, const float *B, const float *bias, float *C) {
+    for (int i = 0; i < M; i++)
+        for (int j = 0; j < N; j++) {
+            float acc = 0.0f;
+            for (int k = 0; k < K; k++) {
+                float t = A[(int64_t)i * K + k] * B[(int64_t)j * K + k];
+                acc = acc + t;
+            }
+            if (bias) acc = acc + bias[j];
+            C[(int64_t)i * N + j] = acc;
+        }
+}
