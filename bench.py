@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""bench.py -- decode tokens/s of the W4A16 hot path (the linears of one decode token) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload baseline-named|llama3-8b|llama2-13b]
+
+A "step" is one decode token: every W4A16 linear of every transformer block + lm_head (M = 1), issued through the
+C ABI of libtce_hip.so as ONE hipGraph replay (tinychatengine_amd.capi.Plan); weights are synthetic N(0, 0.02^2)
+quantized with the reference's q4_6 recipe, all layers distinct (3.4 GB for the default workload, so a token streams
+from HBM, not from the 256 MB Infinity Cache) and resident in HBM before the timed region.  N > 1: one process per
+GPU (torch.distributed, backend nccl == RCCL), every linear column-sharded N-way, one all-gather per transformer block.
+
+Prints ONE JSON line (rank 0): metric/value/unit per the driver contract plus
+  "roofline":     the dominant kernel (the grouped gate+up GEMV launch), algorithmic bytes / HIP-event time, vs 8 TB/s
+  "cpu_baseline": the reference's own CPU path (oracle/_ref, built from /root/reference) timed on this host.
+Only the cpu_baseline leg touches oracle/; the measured path never does.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured streaming ceiling
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="baseline-named", choices=["baseline-named", "llama3-8b", "llama2-13b", "tiny"])
+    ap.add_argument("--layers", type=int, default=None, help="override the number of transformer blocks (debug only)")
+    ap.add_argument("--ungrouped", action="store_true", help="one launch per linear, as the reference issues them")
+    ap.add_argument("--gathers-per-block", type=int, default=1, choices=[1, 4])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true", help="run only the dominant-kernel loop (for rocprofv3)")
+    ap.add_argument("--roofline-launches", type=int, default=256)
+    return ap.parse_args()
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def roofline_leg(dl, torch, launches: int):
+    """The dominant kernel in isolation: the grouped gate+up GEMV launch (2*ffn rows x hidden), `launches` back-to-back
+    launches on one stream, rotating over the layers' distinct weights (ring >> Infinity Cache), HIP events on that
+    stream around the whole sequence.  achieved = algorithmic bytes per launch / average launch duration."""
+    from tinychatengine_amd import capi
+    st = torch.cuda.current_stream().cuda_stream
+    groups = [dl.block_launches(li)[2] for li in range(dl.n_layers)]
+    d0 = groups[0]
+    bytes_per_launch = sum(capi.algorithmic_bytes(dl.m, d.N, d.K, d.group_size) for d in d0)
+    arrs = [(capi.W4A16Desc * len(g))(*g) for g in groups]
+    L = capi.lib()
+    import ctypes as C
+    stp = C.c_void_p(st)
+    for i in range(min(32, launches)):
+        capi.check(L.tce_w4a16_forward_group(arrs[i % len(arrs)], len(d0), stp))
+    torch.cuda.synchronize()
+    # captured into a graph so the host launch rate (~3-4 us per call) does not bound a ~8 us kernel
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        sp = C.c_void_p(s.cuda_stream)
+        with torch.cuda.graph(g, stream=s):
+            for i in range(launches):
+                capi.check(L.tce_w4a16_forward_group(arrs[i % len(arrs)], len(d0), sp))
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (reps * launches)
+    gbs = bytes_per_launch / us / 1e3
+    return {
+        "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+        "traffic": None,
+        "kernel": f"w4a16_gemv_kernel (grouped gate+up launch, N={'+'.join(str(d.N) for d in d0)}, K={d0[0].K}, M={dl.m})",
+        "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": round(us, 3), "launches_timed": reps * launches,
+        "timing": "HIP events on the launch stream around graph-replayed back-to-back launches rotating over all layers' weights (includes inter-kernel gaps)",
+    }
+
+
+def cpu_baseline_leg(shape, torch, group_size: int):
+    """The reference's CPU path on this host, bounded sample = ONE transformer block's linears + lm_head at full size,
+    scaled to tokens/s.  (i) kernels/avx W4A8 fast path (the x86 path the reference actually runs; group 32; all
+    cores); (ii) kernels/ref-class naive_mat_mul_int4 (the parity oracle's source; group 128; single-threaded code)."""
+    import numpy as np
+    from oracle import oracle as O
+    from tinychatengine_amd import quantize as Q
+    h, f = shape.hidden, shape.ffn
+    block = [(n, h) for n in shape.qkv] + [(h, h), (f, h), (f, h), (h, f)]
+    head = (shape.vocab, h)
+    ncpu = os.cpu_count() or 1
+    try:
+        with open("/proc/cpuinfo") as fh:
+            model = next((l.split(":", 1)[1].strip() for l in fh if l.startswith("model name")), "unknown")
+    except OSError:
+        model = "unknown"
+    dev = "cuda" if torch.cuda.is_available() else "cpu"
+    res = {"cpu_model": model, "nproc": ncpu}
+
+    def make(n, k, g):
+        w = torch.empty((n, k), dtype=torch.float32, device=dev).normal_(0, 0.02)
+        codes, d = Q.group_codes(w, g)
+        return codes.cpu().numpy(), d.cpu().numpy()
+
+    rng = np.random.default_rng(4321)
+    # (i) AVX W4A8
+    if O.have_ref_avx():
+        avx = O.ReferenceAVX(num_thread=ncpu)
+        t_block = 0.0
+        for (n, k) in block + [head]:
+            codes, d = make(n, k, 32)
+            call = avx.make_timed_call(rng.standard_normal((1, k)).astype(np.float32), avx.pack_q4_3(codes), d, 1, n, k)
+            for _ in range(3):
+                call()
+            reps = 10
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                call()
+            dt = (time.perf_counter() - t0) / reps
+            if (n, k) == head:
+                t_head = dt
+            else:
+                t_block += dt
+        res["avx"] = {"value": round(1.0 / (t_block * shape.layers + t_head), 3), "unit": "tokens/s", "cores": ncpu, "kind": "reference",
+                      "sample": f"kernels/avx mat_mul_accelerator_int8_int4_fast_no_offset (W4A8, group 32, {ncpu} threads), one block's linears + lm_head at full size, 10 reps each, scaled x{shape.layers} blocks"}
+    # (ii) ref-class naive (single-threaded by construction)
+    if O.have_ref():
+        ref = O.Reference()
+        t_block = 0.0
+        for (n, k) in block + [head]:
+            codes, d = make(n, k, group_size)
+            seq = (codes[:, 0::2] | (codes[:, 1::2] << 4)).astype(np.uint8)
+            a = rng.standard_normal((1, k)).astype(np.float16).astype(np.float32)
+            s32 = d.astype(np.float16).astype(np.float32)
+            ref.naive_mat_mul_int4(a, seq, s32, 8.0, 1, n, k, group_size)
+            t0 = time.perf_counter()
+            ref.naive_mat_mul_int4(a, seq, s32, 8.0, 1, n, k, group_size)
+            dt = time.perf_counter() - t0
+            if (n, k) == head:
+                t_head = dt
+            else:
+                t_block += dt
+        res["ref"] = {"value": round(1.0 / (t_block * shape.layers + t_head), 4), "unit": "tokens/s", "cores": 1, "kind": "reference",
+                      "sample": f"kernels/matmul_int4.cc naive_mat_mul_int4 (generic branch, group {group_size}, 1 thread), one block's linears + lm_head at full size, scaled x{shape.layers} blocks"}
+    return res
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def main():
+    args = parse_args()
+    import torch
+    from tinychatengine_amd import capi
+    from tinychatengine_amd.decode import SHAPES, DecodeLinears
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    capi.lib()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    shape = SHAPES[args.workload]
+    G = 128
+    dl = DecodeLinears(shape, device=dev, group_size=G, rank=rank, world=world, m=1, layers=args.layers)
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    if args.roofline_only:
+        r = roofline_leg(dl, torch, args.roofline_launches)
+        if rank == 0:
+            print(json.dumps({"roofline": r}))
+        return
+
+    # ---- the step ----
+    if world == 1:
+        plan = dl.make_plan(grouped=not args.ungrouped)
+        step = lambda: plan.launch(stream)
+        n_launches = plan.n_launches
+        mode = "one hipGraph replay per token"
+    else:
+        n_launches = dl.n_layers * 4 + 1
+        graph = None
+        try:  # capture GEMVs + RCCL all-gathers of one token into one graph; fall back to eager issue if capture fails
+            for _ in range(3):
+                dl.run_token_distributed(args.gathers_per_block)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                dl.run_token_distributed(args.gathers_per_block)
+            step = graph.replay
+            mode = "one graph replay per token (GEMVs + RCCL all-gathers captured)"
+        except Exception as e:  # noqa: BLE001
+            if rank == 0:
+                print(f"[bench] graph capture of the distributed token failed ({type(e).__name__}: {e}); issuing eagerly", file=sys.stderr)
+            step = lambda: dl.run_token_distributed(args.gathers_per_block)
+            mode = "eager issue per token"
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    fence()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        tw = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = float(tw.item())
+    ms_per_step = wall * 1e3 / args.steps
+    ev_ms_per_step = e0.elapsed_time(e1) / args.steps
+    tok_s = args.steps / wall
+
+    token_bytes_rank = dl.token_bytes()
+    token_bytes_full = sum(capi.algorithmic_bytes(1, n, k, G) for (n, k) in
+                           ([(n, shape.hidden) for n in shape.qkv] + [(shape.hidden, shape.hidden), (shape.ffn, shape.hidden),
+                                                                       (shape.ffn, shape.hidden), (shape.hidden, shape.ffn)]) * dl.n_layers
+                           + [(shape.vocab, shape.hidden)])
+    roof = roofline_leg(dl, torch, args.roofline_launches) if (world == 1) else None
+    whole = {"achieved_GBs_per_gpu": round(token_bytes_rank / (ev_ms_per_step * 1e-3) / 1e9, 1),
+             "frac_of_8TBs": round(token_bytes_rank / (ev_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+             "algorithmic_bytes_per_token_per_gpu": token_bytes_rank, "launches_per_token": n_launches,
+             "event_ms_per_token": round(ev_ms_per_step, 4)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline_leg(shape, torch, G)
+        except Exception as e:  # noqa: BLE001 -- the baseline must never take the GPU number down with it
+            cpu = {"error": f"{type(e).__name__}: {e}"}
+
+    if rank == 0:
+        out = {
+            "metric": "decode tokens/s (W4A16 linears of one token, M=1) + GEMV GB/s vs HBM roofline",
+            "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "int4 weights x fp16 activations, fp32 accumulate", "data": "synthetic",
+            "config": {"workload": f"W4A16 decode GEMV M=1, {shape.name}: {dl.n_layers} blocks x [qkv {list(shape.qkv)}, o {shape.hidden}, gate/up {shape.ffn}, down] + lm_head {shape.vocab}, group 128",
+                       "parallelism": f"tp{world} column-sharded, {args.gathers_per_block} RCCL all-gather(s) per block" if world > 1 else "single GPU",
+                       "issue": mode, "grouped_launches": not args.ungrouped,
+                       "algorithmic_bytes_per_token": token_bytes_full},
+            "whole_token": whole,
+        }
+        if roof is not None:
+            out["roofline"] = roof
+        if cpu is not None:
+            main_cpu = cpu.get("avx") or cpu.get("ref")
+            if main_cpu:
+                out["cpu_baseline"] = dict(main_cpu, cpu_model=cpu.get("cpu_model"), nproc=cpu.get("nproc"))
+                if "avx" in cpu and "ref" in cpu:
+                    out["cpu_baseline_ref_naive"] = cpu["ref"]
+            else:
+                out["cpu_baseline"] = cpu
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

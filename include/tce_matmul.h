@@ -1,0 +1,170 @@
+/*
+ * tce_matmul.h -- C ABI of libtce_hip.so: the MI355X (gfx950 / CDNA4) implementation of
+ * TinyChatEngine's quantized-matmul hot path (reference: kernels/matmul.h @ 2024_08_07).
+ *
+ * This is the drop-in boundary.  Every entry point takes plain pointers and sizes (no C++
+ * or torch types), is ASYNCHRONOUS (returns after enqueueing on `stream`; NULL = the HIP
+ * null stream, which is what the reference uses -- kernels/cuda/gemv_cuda.cu:237), never
+ * allocates, frees or retains caller memory, and returns 0 or a negative TCE_ERR_* code
+ * (it never throws or exits; the C++ adapter in tinychatengine_amd/adapter/ maps failures to
+ * the reference's printf+exit(1) behaviour -- kernels/cuda/gemv_cuda.cu:254-256).
+ *
+ * All data pointers must be device-accessible (hipMalloc or hipMallocManaged memory).
+ *
+ * Which reference symbol each entry point replaces:
+ *
+ *   tce_w4a16_forward          <- matmul::MatmulOperator::gemv_forward_cuda
+ *                                 (kernels/cuda/gemv_cuda.cu:213-260; kernels gemv_kernel_g128 :140-194,
+ *                                  gemv_kernel_g64 :68-123).  Serves every M like the reference does
+ *                                 (grid.z = M there); here M <= TCE_W4A16_GEMV_MAX_M runs the
+ *                                 bandwidth-bound GEMV kernel and larger M the MFMA GEMM kernel.
+ *   tce_w4a16_forward_group    <- several gemv_forward_cuda calls that read the same activation
+ *                                 (fused q/k/v: llm/src/nn_modules/cuda/Int4llamaAttention.cu:125;
+ *                                  gate+up: Int4llamaDecoderLayer.cu:96-99) issued as ONE launch.
+ *   tce_w4a16_awq_fp16acc      <- MatmulOperator::naive_mat_mul_fp16_int4 (kernels/cuda/matmul_int4.cu:8-48)
+ *   tce_w4a16_gemm_awq         <- MatmulOperator::gemm_forward_cuda* (declared kernels/matmul.h:140-145,
+ *                                 never defined in the reference; AWQ q4_5 layout, fp32 accumulate here)
+ *   tce_w8a8_matmul            <- the eight int8 methods of kernels/ref/matmul_ref_int8.cc:161-192
+ *                                 (int8_ref_matmul{,_nobias,_nobias_batch,_bfp32_ofp32,_nobias_ofp32,
+ *                                  _nobias_ofp32_batch}), selected by the descriptor's bias/out kinds.
+ *   tce_plan_*                 <- the host loop that issues one decode token's linears
+ *                                 (llm/src/nn_modules/cuda/Int4llamaDecoder.cu:84-103) captured once into a
+ *                                 hipGraph and replayed; new on MI355X (launch latency ~ kernel time).
+ */
+#ifndef TCE_MATMUL_H
+#define TCE_MATMUL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TCE_API __attribute__((visibility("default")))
+
+#define TCE_VERSION 100 /* 0.1.0 */
+
+/* error codes (return values) */
+#define TCE_OK 0
+#define TCE_ERR_BAD_ARG (-1)           /* null pointer / non-positive size */
+#define TCE_ERR_UNSUPPORTED_GROUP (-2) /* group size not in {32,64,128}: reference prints "Unsupported group size" and exits */
+#define TCE_ERR_UNSUPPORTED_SHAPE (-3) /* K % 32 != 0, N % 8 != 0 for the AWQ layout, ... */
+#define TCE_ERR_HIP (-4)               /* a HIP runtime call failed; see tce_last_error() */
+#define TCE_ERR_UNSUPPORTED_KIND (-5)  /* bias/out kind combination that has no reference counterpart */
+
+/* M at or below which tce_w4a16_forward uses the GEMV kernel family */
+#define TCE_W4A16_GEMV_MAX_M 8
+
+/*
+ * W4A16 on the reference's q4_6 ("CUDA GEMV") layout -- llm/tools/quantize_methods.py:370-442:
+ *   A        fp16  [M][lda]           activations, row-major           (matmul_params.A.half_data_ptr)
+ *   qweight  u32   [N][K/8]           nibble i of word j = code[n][8j+i] (matmul_params.B.int32_data_ptr)
+ *   scales   fp16  [N][scales_stride] first K/G entries valid           (matmul_params.half_scales)
+ *   zeros    u32   [N][zeros_stride]  nibble g%8 of word g/8            (matmul_params.int32_zero_point)
+ *   C        fp16  [M][ldc]                                            (matmul_params.C.half_data_ptr)
+ *   C[m][n] = fp16( sum_k fp32(s[n][k/G]) * (q[n][k] - z[n][k/G]) * fp32(A[m][k]) ), fp32 accumulate.
+ * Strides of 0 select the reference's defaults: lda = K, ldc = N,
+ * zeros_stride = calculate_zeros_width(K,G) (llm/src/nn_modules/cuda/utils.cu:162-178), scales_stride = 8x that.
+ * Like the reference, B.row / B.column are NOT part of the contract (gemv_cuda.cu:217-221 ignores them).
+ */
+typedef struct tce_w4a16_desc {
+    int32_t M, N, K;
+    int32_t group_size; /* QK: 128 (reference CUDA default, llm/include/common.h:18), 64 or 32 */
+    const void *A;
+    const void *qweight;
+    const void *scales;
+    const void *zeros;
+    void *C;
+    int32_t lda, ldc;                     /* elements; 0 = dense */
+    int32_t scales_stride, zeros_stride;  /* elements / words; 0 = reference default */
+    int32_t flags;                        /* TCE_W4_* */
+    int32_t reserved;
+} tce_w4a16_desc;
+
+/* flags */
+#define TCE_W4_FORCE_GEMV 1  /* use the GEMV kernel even when M > TCE_W4A16_GEMV_MAX_M (weights re-streamed per 4 rows) */
+#define TCE_W4_FORCE_GEMM 2  /* use the MFMA GEMM kernel even for small M */
+
+TCE_API int tce_w4a16_forward(const tce_w4a16_desc *d, void *stream);
+
+/* count (<= TCE_MAX_GROUP) linears with identical M, K, group_size and A/lda, one launch (GEMV path only). */
+#define TCE_MAX_GROUP 4
+TCE_API int tce_w4a16_forward_group(const tce_w4a16_desc *descs, int count, void *stream);
+
+/*
+ * AWQ "CUDA GEMM" (q4_5) layout -- quantize_methods.py:299-368, kernels/cuda/matmul_int4.cu:19-39:
+ *   qweight u32 [K][N/8], nibbles 0..7 of word j hold n = 8j + {0,2,4,6,1,3,5,7}; scales fp16 [K/G][N];
+ *   zero point fixed 8.  tce_w4a16_awq_fp16acc reproduces naive_mat_mul_fp16_int4 bit-for-bit
+ *   (every operation rounded to binary16, sequential over k).  tce_w4a16_gemm_awq is the fast path
+ *   (fp32 accumulate): `workspace` must hold tce_w4a16_awq_workspace_bytes(N,K,G) bytes and receives the
+ *   q4_6 re-layout of the weights (pass the same workspace again with repack=0 to skip the re-layout).
+ */
+TCE_API int tce_w4a16_awq_fp16acc(int M, int N, int K, int group_size, const void *A, const void *qweight,
+                                  const void *scales, void *C, void *stream);
+TCE_API size_t tce_w4a16_awq_workspace_bytes(int N, int K, int group_size);
+TCE_API int tce_w4a16_gemm_awq(int M, int N, int K, int group_size, const void *A, const void *qweight,
+                               const void *scales, void *C, void *workspace, int repack, void *stream);
+
+/*
+ * W8A8 (SmoothQuant) -- kernels/ref/matmul_ref_int8.cc.  A int8 [M][K]; B int8 [N][K] (K contiguous;
+ * matmul_params.B.row = K, B.column = N -- llm/src/ops/W8A8B8O8Linear.cc:47-50); acc int32 exact.
+ *   out_kind TCE_OUT_INT8: C int8 [M][N] = clamp( (int32) round( (float)acc*alpha [+ (float)bias_i8[n]*beta] ), q_min, q_max )
+ *            (round = half away from zero; multiply, multiply, add each rounded separately -- :29-32)
+ *   out_kind TCE_OUT_FP32: C fp32 [M][N] = (float)acc*alpha [+ bias_f32[n]]          (:108, :132)
+ *   b_per_row != 0: row i of A multiplies its own B_i, B laid out [M][N][K] (the *_batch variants, :79, :153)
+ *   batch > 1: `batch` independent problems at element strides strideA/strideB/strideC (the per-head loop of
+ *            llm/src/ops/BMM_S8T_S8N_F32T.cc:45-59 / BMM_S8T_S8N_S8T.cc:47-60 as one launch).
+ */
+#define TCE_BIAS_NONE 0
+#define TCE_BIAS_INT8 1
+#define TCE_BIAS_FP32 2
+#define TCE_OUT_INT8 0
+#define TCE_OUT_FP32 1
+
+typedef struct tce_w8a8_desc {
+    int32_t M, N, K;
+    int32_t batch;        /* >= 1 */
+    const void *A;
+    const void *B;
+    const void *bias;     /* int8 [N] or fp32 [N] or NULL */
+    void *C;
+    int64_t strideA, strideB, strideC; /* elements between consecutive batch entries (ignored when batch == 1) */
+    float alpha, beta;
+    int32_t q_min, q_max; /* C.qparams.q_min/q_max: -128..127, or 0..127 for the fused-ReLU linear (W8A8B8O8LinearReLU.cc:32) */
+    int32_t bias_kind, out_kind;
+    int32_t b_per_row;
+    int32_t reserved;
+} tce_w8a8_desc;
+
+TCE_API int tce_w8a8_matmul(const tce_w8a8_desc *d, void *stream);
+
+/* ---- replayable plan: a fixed sequence of W4A16 launches captured into one hipGraph ---- */
+typedef struct tce_plan tce_plan;
+/* group_sizes[i] consecutive descriptors form launch i (1 = tce_w4a16_forward, >1 = tce_w4a16_forward_group). */
+TCE_API int tce_plan_create(const tce_w4a16_desc *descs, const int32_t *group_sizes, int n_launches, tce_plan **out);
+TCE_API int tce_plan_launch(tce_plan *plan, void *stream);
+TCE_API int tce_plan_n_launches(const tce_plan *plan);
+TCE_API void tce_plan_destroy(tce_plan *plan);
+
+/* ---- introspection / tuning (not part of the reference surface) ---- */
+TCE_API int tce_version(void);
+TCE_API const char *tce_last_error(void);
+TCE_API const char *tce_build_info(void);
+/* Force a GEMV launch geometry for every subsequent call from this process (all 0 = automatic).
+ * rows_per_wave in {1,2,4}; waves_n x waves_k waves per workgroup (waves_k of them split K); depth = weight steps kept
+ * in flight per wave (the library lowers it when K is too short).  TCE_ERR_BAD_ARG if that variant was not compiled. */
+TCE_API int tce_w4a16_set_gemv_config(int rows_per_wave, int waves_n, int waves_k, int depth);
+/* Force an MFMA GEMM tile (m_tiles x n_tiles of 16x16 per wave); 0,0 = automatic. */
+TCE_API int tce_w4a16_set_gemm_config(int m_tiles, int n_tiles);
+/* Enumerate the compiled kernel variants (for tuning sweeps / tests): returns 0 and fills the outputs, or
+ * TCE_ERR_BAD_ARG when idx is past the end. */
+TCE_API int tce_w4a16_gemv_variant(int idx, int *rows_per_wave, int *waves_n, int *waves_k, int *depth);
+TCE_API int tce_w4a16_gemm_variant(int idx, int *m_tiles, int *n_tiles);
+/* Algorithmic HBM bytes of one tce_w4a16_forward call: N*K/2 + 2*N*K/G + N*K/(2G) + 2*M*K + 2*M*N. */
+TCE_API int64_t tce_w4a16_algorithmic_bytes(int M, int N, int K, int group_size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TCE_MATMUL_H */

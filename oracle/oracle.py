@@ -71,12 +71,13 @@ class _Lib:
                                                   _p(scales), _p(offset), C.c_float(zero_point), _p(out))
         return out
 
-    def ref_int4_fast(self, A, B, scales, offset, M, N, K, G=32):
+    def ref_int4_fast(self, A, B, scales, offset, M, N, K, G=32, b_row=None):
+        b_row = K // 2 if b_row is None else b_row  # what Linear_FP_int4::forward_fast passes (linear.cc:138-139)
         A = np.ascontiguousarray(A, np.float32); B = np.ascontiguousarray(B, np.uint8)
         scales = np.ascontiguousarray(scales, np.float32); offset = np.ascontiguousarray(offset, np.float32)
         out = np.empty((M, N), np.float32)
-        rc = self._f("ref_int4_fast", C.c_int)(C.c_int(M), C.c_int(N), C.c_int(K), C.c_int(G), _p(A), _p(B), _p(scales),
-                                               _p(offset), _p(out))
+        rc = self._f("ref_int4_fast", C.c_int)(C.c_int(M), C.c_int(N), C.c_int(K), C.c_int(G), C.c_int(b_row), _p(A), _p(B),
+                                               _p(scales), _p(offset), _p(out))
         if rc != 0:
             raise ValueError("block size must be 32")
         return out

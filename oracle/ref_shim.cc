@@ -84,16 +84,16 @@ REF_API void ref_naive_mat_mul_int4_with_offset(int M, int N, int K, int G, cons
     op.naive_mat_mul_int4_with_offset(&p);
 }
 
-// kernels/ref/matmul_ref_int4.cc:11-38 (B.row = K -- linear.cc:138-139)
-REF_API int ref_ref_int4_fast(int M, int N, int K, int G, const float *A, const uint8_t *B, const float *scales,
-                              const float *offset, float *C) {
+// kernels/ref/matmul_ref_int4.cc:11-38; the caller passes B.row = K/2 (linear.cc:138-139)
+REF_API int ref_ref_int4_fast(int M, int N, int K, int G, int b_row, const float *A, const uint8_t *B,
+                              const float *scales, const float *offset, float *C) {
     if (G != 32) return -1;  // the reference asserts
     matmul_params p;
     clear(p);
     p.A.row = M;
     p.A.column = K;
     p.A.data_ptr = const_cast<float *>(A);
-    p.B.row = K;
+    p.B.row = b_row;
     p.B.column = N;
     p.B.int4_data_ptr = const_cast<uint8_t *>(B);
     p.C.row = M;

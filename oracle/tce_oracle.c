@@ -268,18 +268,21 @@ ORC_API void orc_naive_mat_mul_int4_with_offset(int M, int N, int K, int G, cons
         }
 }
 
-/* mat_mul_accelerator_int4_fast (ref backend) -- kernels/ref/matmul_ref_int4.cc:11-38:
- * deq = q*s + o (no zero point), block 32 only. */
-ORC_API int orc_ref_int4_fast(int M, int N, int K, int G, const float *A, const uint8_t *B, const float *scales,
-                              const float *offset, float *C) {
+/* mat_mul_accelerator_int4_fast (ref backend) -- kernels/ref/matmul_ref_int4.cc:11-38: deq = q*s + o (no zero
+ * point), block 32 only.  The function is driven entirely by B.row (`b_row`): k runs over [0, b_row), the weight row
+ * stride is b_row BYTES and the scale row stride b_row/16.  Its only caller passes b_row = K/2
+ * (llm/src/ops/linear.cc:138-139), so as called it contracts over the FIRST HALF of K only -- restated as is
+ * (this backend function is not on the GPU path: the CUDA build stubs it, kernels/cuda/gemv_cuda.cu:262-264). */
+ORC_API int orc_ref_int4_fast(int M, int N, int K, int G, int b_row, const float *A, const uint8_t *B,
+                              const float *scales, const float *offset, float *C) {
     if (G != 32) return -1;
     for (int i = 0; i < M; i++)
         for (int j = 0; j < N; j++) {
             float acc = 0.0f;
-            for (int k = 0; k < K; k += G) {
-                float s = scales[(int64_t)j * (K / 32) + k / 32];
-                float o = offset[(int64_t)j * (K / 32) + k / 32];
-                const uint8_t *b = B + (int64_t)j * (K / 2) + k / 2;
+            for (int k = 0; k < b_row; k += G) {
+                float s = scales[(int64_t)j * (b_row / 16) + k / 32];
+                float o = offset[(int64_t)j * (b_row / 16) + k / 32];
+                const uint8_t *b = B + (int64_t)j * b_row + k / 2;
                 const float *a = A + (int64_t)i * K + k;
                 for (int q = 0; q < G / 2; q++) {
                     uint8_t p = b[q];

@@ -1,0 +1,314 @@
+"""GPU parity tests of the W4A16 path (run with -m gpu on an MI355X).  Every kernel is reached through the C ABI
+(libtce_hip.so) via tinychatengine_amd.capi / .matmul; the checker is oracle/ (the CPU restatement pinned to the
+reference's own code) and the committed golden vectors.
+
+Tolerance (north-star): W4A16 within 1e-3 relative -- see conftest.w4a16_close for the exact per-element rule; the
+reference's own GPU-vs-CPU comparator is far looser (MSE <= 7e-4, llm/tests/cuda/test_ops.cu:656), also asserted.
+The binary16-arithmetic AWQ entry point is bit-exact.
+"""
+import numpy as np
+import pytest
+
+from conftest import w4a16_close
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the GPU (they must not silently pass without it)"
+    from tinychatengine_amd import capi
+    capi.lib()  # raises if libtce_hip.so is missing: no fallback
+    capi.set_gemv_config()  # automatic
+    capi.set_gemm_config()
+    return torch.device("cuda:0")
+
+
+def _make(oracle, M, N, K, G, seed, random_zeros=False):
+    rng = np.random.default_rng(seed)
+    w = (rng.standard_normal((N, K)) * 0.02).astype(np.float32)
+    qw, sc, zp, codes, d = oracle.quantize_q4_6(w, G)
+    if random_zeros:  # general AWQ checkpoints carry real zero points; the kernel must read them (gemv_cuda.cu:159,166)
+        nib = rng.integers(0, 16, (N, zp.shape[1] * 8), dtype=np.uint32)
+        zp = (nib.reshape(N, -1, 8) << (np.arange(8, dtype=np.uint32) * 4)).sum(axis=2).astype(np.uint32)
+    a = rng.standard_normal((M, K)).astype(np.float16)
+    return qw, sc, zp, a
+
+
+def _run(dev, qw, sc, zp, a, G, flags=0):
+    from tinychatengine_amd import capi
+    M, K = a.shape
+    N = qw.shape[0]
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    tq, ts, tz, ta = t(qw.view(np.int32)), t(sc.view(np.float16)), t(zp.view(np.int32)), t(a)
+    out = torch.full((M, N), float("nan"), dtype=torch.float16, device=dev)
+    d = capi.W4A16Desc(M=M, N=N, K=K, group_size=G, A=ta.data_ptr(), qweight=tq.data_ptr(), scales=ts.data_ptr(),
+                       zeros=tz.data_ptr(), C=out.data_ptr(), flags=flags)
+    capi.check(capi.w4a16_forward(d, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def _check(got, ref32, what):
+    assert not np.isnan(got.astype(np.float32)).any(), f"{what}: output has NaN / unwritten elements"
+    ok, worst = w4a16_close(got, ref32)
+    mse = float(np.mean((got.astype(np.float64) - ref32.astype(np.float64)) ** 2))
+    assert ok, f"{what}: worst |err|/tol = {worst:.3f} (tol = 1e-3*max(|ref|, rms/64)), mse = {mse:.3e}"
+    assert mse <= 7e-4, f"{what}: mse {mse}"  # the reference's own threshold (tests/cuda/test_ops.cu:656)
+
+
+GEMV_SHAPES = [
+    # M, N, K, G
+    (1, 256, 4096, 128), (1, 64, 1408, 128), (1, 100, 4096, 128), (2, 128, 2048, 64), (4, 96, 1024, 32),
+    (3, 132, 2560, 128), (1, 4096, 4096, 128), (1, 512, 11008, 128), (1, 256, 14336, 128), (1, 1024, 5120, 128),
+    (8, 64, 4096, 128), (5, 48, 1408, 128), (1, 16, 32, 32), (1, 24, 13824, 128),
+]
+
+
+@pytest.mark.parametrize("M,N,K,G", GEMV_SHAPES)
+def test_gemv_matches_oracle(dev, oracle, M, N, K, G):
+    from tinychatengine_amd import capi
+    qw, sc, zp, a = _make(oracle, M, N, K, G, seed=M * 7 + N + K)
+    ref32, _ = oracle.w4a16_gemv_q4_6(a, qw, sc, zp, M, N, K, G)
+    _check(_run(dev, qw, sc, zp, a, G, flags=capi.TCE_W4_FORCE_GEMV), ref32, f"gemv {M}x{N}x{K} g{G}")
+
+
+@pytest.mark.parametrize("M,N,K,G", [(1, 192, 4096, 128), (2, 64, 1408, 128), (4, 64, 1024, 64), (1, 40, 512, 32)])
+def test_gemv_reads_real_zero_points(dev, oracle, M, N, K, G):
+    from tinychatengine_amd import capi
+    qw, sc, zp, a = _make(oracle, M, N, K, G, seed=99 + N, random_zeros=True)
+    ref32, _ = oracle.w4a16_gemv_q4_6(a, qw, sc, zp, M, N, K, G)
+    _check(_run(dev, qw, sc, zp, a, G, flags=capi.TCE_W4_FORCE_GEMV), ref32, f"gemv zeros {M}x{N}x{K} g{G}")
+
+
+def test_every_gemv_variant(dev, oracle):
+    """Each compiled launch geometry (rows/wave, waves, K split, pipeline depth) on shapes with K tails and N tails."""
+    from tinychatengine_amd import capi
+    cases = [(1, 264, 8192, 128), (2, 72, 11008, 128), (4, 40, 6144 + 1408, 64)]
+    data = []
+    for (M, N, K, G) in cases:
+        qw, sc, zp, a = _make(oracle, M, N, K, G, seed=N, random_zeros=True)
+        data.append((M, N, K, G, qw, sc, zp, a, oracle.w4a16_gemv_q4_6(a, qw, sc, zp, M, N, K, G)[0]))
+    try:
+        for v in capi.gemv_variants():
+            capi.set_gemv_config(*v)
+            for (M, N, K, G, qw, sc, zp, a, ref32) in data:
+                _check(_run(dev, qw, sc, zp, a, G, flags=capi.TCE_W4_FORCE_GEMV), ref32, f"variant {v} on {M}x{N}x{K}")
+    finally:
+        capi.set_gemv_config()
+
+
+def test_gemv_golden_vector(dev, golden):
+    """The committed vector produced by the reference's quantizer + naive_mat_mul_int4 (K=1408: padded scale rows)."""
+    from tinychatengine_amd import capi
+    M, N, K, G = (int(v) for v in golden["w4_dims"])
+    got = _run(dev, golden["w4_qweight"], golden["w4_scales"], golden["w4_zeros"], golden["w4_a"], G, flags=capi.TCE_W4_FORCE_GEMV)
+    _check(got, golden["w4_expected_f32"], "golden gemv")
+    got = _run(dev, golden["w4_qweight"], golden["w4_scales"], golden["w4_zeros"], golden["w4_a"], G, flags=capi.TCE_W4_FORCE_GEMM)
+    _check(got, golden["w4_expected_f32"], "golden gemm")
+
+
+GEMM_SHAPES = [(64, 256, 512, 128), (33, 200, 1024, 128), (512, 384, 4096, 128), (128, 128, 1408 + 128 * 5, 64), (17, 72, 256, 32), (9, 16, 128, 128)]
+
+
+@pytest.mark.parametrize("M,N,K,G", GEMM_SHAPES)
+def test_gemm_matches_oracle(dev, oracle, M, N, K, G):
+    from tinychatengine_amd import capi
+    qw, sc, zp, a = _make(oracle, M, N, K, G, seed=M + N * 3 + K, random_zeros=True)
+    ref32, _ = oracle.w4a16_gemv_q4_6(a, qw, sc, zp, M, N, K, G)
+    try:
+        for v in [None] + capi.gemm_variants():
+            capi.set_gemm_config(*(v or (0, 0)))
+            _check(_run(dev, qw, sc, zp, a, G, flags=capi.TCE_W4_FORCE_GEMM), ref32, f"gemm {v} {M}x{N}x{K} g{G}")
+    finally:
+        capi.set_gemm_config()
+
+
+def test_gemm_is_transpose_detecting(dev, oracle):
+    """Asymmetric data: A = one-hot rows selects single k, so a swapped fragment index shows up as a wrong column."""
+    from tinychatengine_amd import capi
+    M, N, K, G = 48, 80, 256, 128
+    qw, sc, zp, _ = _make(oracle, M, N, K, G, seed=5)
+    a = np.zeros((M, K), np.float16)
+    for m in range(M):
+        a[m, (m * 37 + 11) % K] = 1.0 + m / 64.0
+    ref32, _ = oracle.w4a16_gemv_q4_6(a, qw, sc, zp, M, N, K, G)
+    _check(_run(dev, qw, sc, zp, a, G, flags=capi.TCE_W4_FORCE_GEMM), ref32, "one-hot gemm")
+    _check(_run(dev, qw, sc, zp, a[:4].copy(), G, flags=capi.TCE_W4_FORCE_GEMV), ref32[:4], "one-hot gemv")
+
+
+def test_dispatch_threshold_and_default_path(dev, oracle):
+    """M <= 8 -> GEMV kernels, M > 8 -> MFMA GEMM; both must agree with the oracle at the boundary."""
+    for M in (8, 9):
+        qw, sc, zp, a = _make(oracle, M, 144, 1024, 128, seed=M)
+        ref32, _ = oracle.w4a16_gemv_q4_6(a, qw, sc, zp, M, 144, 1024, 128)
+        _check(_run(dev, qw, sc, zp, a, 128), ref32, f"default path M={M}")
+
+
+def test_grouped_launch_equals_separate_launches(dev, oracle):
+    from tinychatengine_amd import capi
+    from tinychatengine_amd.linear import Linear_half_int4, forward_group
+    K, G = 4096, 128
+    x = torch.randn(1, K, device=dev).to(torch.float16)
+    g = torch.Generator(device=dev).manual_seed(7)
+    lins = [Linear_half_int4.from_float(torch.empty(n, K, device=dev).normal_(0, 0.02, generator=g), G) for n in (512, 128, 144)]
+    sep = [l.forward(x) for l in lins]
+    outs = [torch.full_like(s, float("nan")) for s in sep]
+    forward_group(lins, x, outs)
+    torch.cuda.synchronize()
+    for s, o, l in zip(sep, outs, lins):
+        assert not torch.isnan(o).any()
+        ref32, _ = oracle.w4a16_gemv_q4_6(x.cpu().numpy(), l.weight.cpu().numpy().view(np.uint32), l.scale.cpu().numpy(),
+                                          l.zero_point.cpu().numpy().view(np.uint32), 1, l.out_features, K, G)
+        _check(o.cpu().numpy(), ref32, "grouped launch")
+        _check(s.cpu().numpy(), ref32, "separate launch")
+
+
+def test_plan_replay_matches_eager(dev):
+    from tinychatengine_amd.decode import DecodeLinears, SHAPES
+    dl = DecodeLinears(SHAPES["tiny"], device=dev)
+    for li in range(dl.n_layers):
+        dl.run_block(li)
+    dl.run_lm_head()
+    torch.cuda.synchronize()
+    eager = [dl.logits.clone(), dl.out_down.clone(), dl.out_up.clone(), dl.out_qkv[1].clone()]
+    for t in (dl.logits, dl.out_down, dl.out_up, dl.out_qkv[1]):
+        t.fill_(float("nan"))
+    plan = dl.make_plan()
+    s = torch.cuda.current_stream().cuda_stream
+    plan.launch(s)
+    plan.launch(s)
+    torch.cuda.synchronize()
+    for e, t in zip(eager, (dl.logits, dl.out_down, dl.out_up, dl.out_qkv[1])):
+        assert torch.equal(e, t)
+    assert plan.n_launches == dl.n_layers * 4 + 1
+    plan.close()
+
+
+def test_awq_fp16acc_is_bit_exact(dev, oracle, golden):
+    """naive_mat_mul_fp16_int4: every op rounded to binary16 -- the GPU result must equal the reference bit for bit."""
+    from tinychatengine_amd.matmul import MatmulOperator, matmul_params, matrix
+    cases = [tuple(int(v) for v in golden["awq_dims"]) + (golden["awq_qweight"], golden["awq_scales"], golden["awq_a"], golden["awq_expected_f16"])]
+    rng = np.random.default_rng(11)
+    M, N, K, G = 3, 72, 512, 128
+    w = (rng.standard_normal((N, K)) * 0.02).astype(np.float32)
+    codes, d = oracle.group_quantize(w, G)
+    q5, s5, _ = oracle.pack_q4_5(codes, d, N, K, G)
+    a = rng.standard_normal((M, K)).astype(np.float16)
+    cases.append((M, N, K, G, q5, s5, a, oracle.naive_mat_mul_fp16_int4(a, q5, s5, M, N, K, G)))
+    for (M, N, K, G, q5, s5, a, exp) in cases:
+        t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+        out = torch.zeros((M, N), dtype=torch.float16, device=dev)
+        p = matmul_params(A=matrix(M, K, t(a)), B=matrix(K, N // 8, t(q5.view(np.int32))), C=matrix(M, N, out),
+                          fp16_scales=t(s5.view(np.float16)), block_size=G)
+        MatmulOperator().naive_mat_mul_fp16_int4(p)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint16), exp.view(np.uint16))
+
+
+@pytest.mark.parametrize("M", [1, 4, 64])
+def test_awq_layout_gemm(dev, oracle, M):
+    """gemm_forward_cuda surface: q4_5 in, result must match the q4_6 oracle on the same codes (fp32 accumulate)."""
+    from tinychatengine_amd.matmul import MatmulOperator, matmul_params, matrix
+    rng = np.random.default_rng(M)
+    N, K, G = 136, 1024, 128
+    w = (rng.standard_normal((N, K)) * 0.02).astype(np.float32)
+    qw, sc, zp, codes, d = oracle.quantize_q4_6(w, G)
+    q5, s5, _ = oracle.pack_q4_5(codes, d.reshape(-1), N, K, G)
+    a = rng.standard_normal((M, K)).astype(np.float16)
+    ref32, _ = oracle.w4a16_gemv_q4_6(a, qw, sc, zp, M, N, K, G)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    out = torch.full((M, N), float("nan"), dtype=torch.float16, device=dev)
+    p = matmul_params(A=matrix(M, K, t(a)), B=matrix(K, N // 8, t(q5.view(np.int32))), C=matrix(M, N, out),
+                      fp16_scales=t(s5.view(np.float16)), block_size=G)
+    ws = MatmulOperator().gemm_forward_cuda(p, 8)
+    torch.cuda.synchronize()
+    _check(out.cpu().numpy(), ref32, f"awq gemm M={M}")
+    out.fill_(float("nan"))
+    MatmulOperator().gemm_forward_cuda(p, 8, workspace=ws, repack=False)  # cached re-layout
+    torch.cuda.synchronize()
+    _check(out.cpu().numpy(), ref32, f"awq gemm (cached) M={M}")
+
+
+def test_error_codes_match_reference_behaviour(dev):
+    """Unsupported group size: the reference prints and exits (gemv_cuda.cu:254-256); here a distinct error code."""
+    from tinychatengine_amd import capi
+    x = torch.zeros(1, 256, dtype=torch.float16, device=dev)
+    q = torch.zeros(16, 32, dtype=torch.int32, device=dev)
+    s = torch.zeros(16, 8, dtype=torch.float16, device=dev)
+    z = torch.zeros(16, 1, dtype=torch.int32, device=dev)
+    o = torch.zeros(1, 16, dtype=torch.float16, device=dev)
+    d = capi.W4A16Desc(M=1, N=16, K=256, group_size=96, A=x.data_ptr(), qweight=q.data_ptr(), scales=s.data_ptr(), zeros=z.data_ptr(), C=o.data_ptr())
+    assert capi.w4a16_forward(d, 0) == capi.TCE_ERR_UNSUPPORTED_GROUP and "Unsupported group size" in capi.last_error()
+    d.group_size = 128
+    d.K = 250
+    assert capi.w4a16_forward(d, 0) == capi.TCE_ERR_UNSUPPORTED_SHAPE
+    d.K = 256
+    d.A = None
+    assert capi.w4a16_forward(d, 0) == capi.TCE_ERR_BAD_ARG
+
+
+# ---------------------------------------------------------------------------------------------------------
+# BASELINE.json full sizes
+# ---------------------------------------------------------------------------------------------------------
+FULL = [(4096, 4096), (11008, 4096), (4096, 11008), (14336, 4096), (4096, 14336), (1024, 4096), (12288, 4096)]
+
+
+@pytest.mark.parametrize("N,K", FULL)
+def test_full_size_decode_gemv(dev, oracle, N, K):
+    """configs[1]: M=1 at the Llama shapes, against the oracle directly (it needs < 1 s per shape), plus two
+    size-independent properties: exact homogeneity under x -> 2x and bit-identical results for row shards."""
+    from tinychatengine_amd import capi
+    from tinychatengine_amd.linear import Linear_half_int4
+    G = 128
+    g = torch.Generator(device=dev).manual_seed(1234 + N)
+    lin = Linear_half_int4.from_float(torch.empty(N, K, device=dev).normal_(0, 0.02, generator=g), G)
+    x = torch.empty(1, K, device=dev).normal_(0, 1, generator=g).to(torch.float16)
+    y = lin.forward(x)
+    torch.cuda.synchronize()
+    ref32, _ = oracle.w4a16_gemv_q4_6(x.cpu().numpy(), lin.weight.cpu().numpy().view(np.uint32), lin.scale.cpu().numpy(),
+                                      lin.zero_point.cpu().numpy().view(np.uint32), 1, N, K, G)
+    _check(y.cpu().numpy(), ref32, f"full {N}x{K}")
+    y2 = lin.forward(x * 2)
+    torch.cuda.synchronize()
+    assert torch.equal(y2, y * 2), "x -> 2x must double every output exactly (power-of-two scaling is exact in fp16/fp32)"
+    # column sharding: each shard's rows must reproduce the full result bit for bit under one geometry
+    try:
+        capi.set_gemv_config(2, 4, 1, 2)
+        full = lin.forward(x)
+        parts = [lin.shard(r, 8).forward(x) for r in range(8)]
+        torch.cuda.synchronize()
+        assert torch.equal(torch.cat(parts, dim=1), full)
+    finally:
+        capi.set_gemv_config()
+
+
+@pytest.mark.parametrize("N,K", [(4096, 4096), (11008, 4096), (4096, 11008)])
+def test_full_size_prefill_gemm(dev, oracle, N, K):
+    """configs[2]: M=512 on the MFMA path.  16 of the 512 rows are checked against the oracle (a full check costs
+    ~9e9 scalar MACs per shape on the host); the rest through a property: every input row appears twice in the batch and
+    both copies must give identical outputs, and the GEMV kernel (validated above) must agree on 4 more rows."""
+    from tinychatengine_amd import capi
+    from tinychatengine_amd.linear import Linear_half_int4
+    G, M = 128, 512
+    g = torch.Generator(device=dev).manual_seed(77 + N)
+    lin = Linear_half_int4.from_float(torch.empty(N, K, device=dev).normal_(0, 0.02, generator=g), G)
+    xh = torch.empty(M // 2, K, device=dev).normal_(0, 1, generator=g).to(torch.float16)
+    x = torch.cat([xh, xh], dim=0).contiguous()
+    y = lin.forward(x)
+    torch.cuda.synchronize()
+    assert torch.equal(y[: M // 2], y[M // 2:]), "duplicate rows must produce identical outputs"
+    rows = list(range(0, 256, 16))
+    xs = x[rows].cpu().numpy()
+    ref32, _ = oracle.w4a16_gemv_q4_6(xs, lin.weight.cpu().numpy().view(np.uint32), lin.scale.cpu().numpy(),
+                                      lin.zero_point.cpu().numpy().view(np.uint32), len(rows), N, K, G)
+    _check(y[rows].cpu().numpy(), ref32, f"prefill {N}x{K}")
+    yv = torch.empty(4, N, dtype=torch.float16, device=dev)
+    d = lin.desc(x[3:7].contiguous(), yv)
+    d.flags = capi.TCE_W4_FORCE_GEMV
+    capi.check(capi.w4a16_forward(d, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    ok, worst = w4a16_close(y[3:7].cpu().numpy(), yv.float().cpu().numpy(), rel=2e-3)  # two fp16-rounded results
+    assert ok, worst

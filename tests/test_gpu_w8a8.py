@@ -1,0 +1,174 @@
+"""GPU parity tests of the W8A8 (SmoothQuant) path: BIT-EXACT against the oracle, which is pinned bit-exact to
+kernels/ref/matmul_ref_int8.cc (the reference's own tests demand check_two_exact_equal for int8 outputs,
+llm/tests/non_cuda/test_ops.cc:204,238,340,373).  Shapes and scalar constants are the reference's test shapes
+(test_ops.cc:177-209, 245-276, 311-345, 380-410, 444-473) plus the edge cases it exercises implicitly."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+ALPHA, BETA = 0.0005035400390625, 0.02130126953125  # test_ops.cc:179
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from tinychatengine_amd import capi
+    capi.lib()
+    return torch.device("cuda:0")
+
+
+def _t(dev, x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def _params(dev, A, B, out_dtype, bias=None, alpha=ALPHA, beta=BETA, qmin=-128, qmax=127):
+    from tinychatengine_amd.matmul import matmul_params, matrix
+    M, K = A.shape
+    N = B.shape[-2]
+    out = torch.zeros((M, N), dtype=out_dtype, device=dev)
+    p = matmul_params(A=matrix(M, K, _t(dev, A)), B=matrix(K, N, _t(dev, B)), C=matrix(M, N, out), alpha=alpha, beta=beta)
+    if bias is not None:
+        p.bias = matrix(1, N, _t(dev, bias))
+    p.C.qparams.q_min, p.C.qparams.q_max = qmin, qmax
+    return p, out
+
+
+def _data(M, N, K, seed, corner=True):
+    rng = np.random.default_rng(seed)
+    A = rng.integers(-127, 128, (M, K), dtype=np.int8)
+    B = rng.integers(-127, 128, (N, K), dtype=np.int8)
+    if corner:  # the -128 corner set of SURVEY §8d
+        A[0, :] = -128
+        B[0, :] = -128
+        A[-1, ::3] = -128
+    return A, B, rng.integers(-128, 128, N, dtype=np.int8), rng.standard_normal(N).astype(np.float32)
+
+
+SHAPES = [(108, 3072, 768), (108, 768, 768), (512, 768, 768), (1, 768, 768), (1, 3072, 768), (512, 768, 3072), (108, 2048, 2048),
+          (7, 40, 80), (65, 130, 208), (3, 5, 33), (2, 3, 16), (64, 64, 64)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_all_linear_variants_bit_exact(dev, oracle, M, N, K):
+    from tinychatengine_amd.matmul import MatmulOperator
+    op = MatmulOperator()
+    A, B, b8, bf = _data(M, N, K, seed=M + N + K)
+    for alpha, beta in [(ALPHA, BETA), (0.0071, 0.13)]:
+        for qmin in (-128, 0):  # 0 = W8A8B8O8LinearReLU
+            p, out = _params(dev, A, B, torch.int8, b8, alpha, beta, qmin)
+            op.mat_mul_accelerator_int8_fast_2x2_32unroll(p)
+            exp = oracle.int8_matmul_bias_i8(A, B, b8, alpha, beta, qmin, 127, M, N, K)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), exp), f"bias_i8 qmin={qmin} mismatches: {(out.cpu().numpy() != exp).sum()}"
+            p, out = _params(dev, A, B, torch.int8, None, alpha, beta, qmin)
+            op.mat_mul_accelerator_int8_fast_2x2_32unroll_nobias(p)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), oracle.int8_matmul_nobias_i8(A, B, alpha, qmin, 127, M, N, K))
+        p, out = _params(dev, A, B, torch.int8, b8, alpha, beta)
+        op.mat_mul_accelerator_int8_fast_32unroll_over_column(p)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), oracle.int8_matmul_bias_i8(A, B, b8, alpha, beta, -128, 127, M, N, K))
+        p, out = _params(dev, A, B, torch.float32, bf, alpha)
+        op.mat_mul_accelerator_int8_fast_2x2_32unroll_bfp32_ofp32(p)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), oracle.int8_matmul_bias_f32(A, B, bf, alpha, M, N, K).view(np.uint32))
+        p, out = _params(dev, A, B, torch.float32, bf, alpha)
+        op.mat_mul_accelerator_int8_fast_2x2_32unroll_bfp32_ofp32_over_column(p)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), oracle.int8_matmul_bias_f32(A, B, bf, alpha, M, N, K).view(np.uint32))
+        p, out = _params(dev, A, B, torch.float32, None, alpha)
+        op.mat_mul_accelerator_int8_fast_2x2_32unroll_nobias_ofp32(p)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), oracle.int8_matmul_nobias_f32(A, B, alpha, M, N, K).view(np.uint32))
+
+
+@pytest.mark.parametrize("M,N,K", [(12, 512, 64), (12, 64, 512), (5, 9, 33), (1, 16, 64)])
+def test_batch_variants_bit_exact(dev, oracle, M, N, K):
+    """*_nobias_batch / *_nobias_ofp32_batch: row i of A has its own B_i (decode-time attention BMMs)."""
+    from tinychatengine_amd.matmul import MatmulOperator
+    rng = np.random.default_rng(M * N + K)
+    A = rng.integers(-128, 128, (M, K), dtype=np.int8)
+    Bb = rng.integers(-128, 128, (M, N, K), dtype=np.int8)
+    op = MatmulOperator()
+    p, out = _params(dev, A, Bb, torch.int8, None, 0.0031)
+    op.mat_mul_accelerator_int8_fast_2x2_32unroll_nobias_batch(p)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), oracle.int8_matmul_nobias_i8(A, Bb, 0.0031, -128, 127, M, N, K, batch=True))
+    p, out = _params(dev, A, Bb, torch.float32, None, 0.0031)
+    op.mat_mul_accelerator_int8_fast_2x2_32unroll_nobias_ofp32_batch(p)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), oracle.int8_matmul_nobias_f32(A, Bb, 0.0031, M, N, K, batch=True).view(np.uint32))
+
+
+def test_bmm_head_loop_as_one_launch(dev, oracle):
+    """BMM_S8T_S8N_F32T b=12,(512,512,64) and BMM_S8T_S8N_S8T b=12,(512,64,512) (test_ops.cc:380-410, 444-473)."""
+    from tinychatengine_amd.linear import bmm_s8t_s8n
+    rng = np.random.default_rng(12)
+    for (b, m, n, k, fp32) in [(12, 512, 512, 64, True), (12, 512, 64, 512, False), (3, 7, 5, 48, False)]:
+        a = rng.integers(-128, 128, (b, m, k), dtype=np.int8)
+        w = rng.integers(-128, 128, (b, n, k), dtype=np.int8)
+        out = bmm_s8t_s8n(_t(dev, a), _t(dev, w), 0.0013, fp32).cpu().numpy()
+        for h in range(b):
+            exp = oracle.int8_matmul_nobias_f32(a[h], w[h], 0.0013, m, n, k) if fp32 else oracle.int8_matmul_nobias_i8(a[h], w[h], 0.0013, -128, 127, m, n, k)
+            assert np.array_equal(out[h], exp), f"head {h}"
+
+
+def test_golden_vectors(dev, golden):
+    """The committed outputs of the reference's own code."""
+    from tinychatengine_amd.matmul import MatmulOperator
+    op = MatmulOperator()
+    M, N, K = (int(v) for v in golden["i8_dims"])
+    al, be = (float(v) for v in golden["i8_alpha_beta"])
+    A, B, b8, bf, Bb = golden["i8_A"], golden["i8_B"], golden["i8_bias8"], golden["i8_biasf"], golden["i8_Bb"]
+    runs = [
+        ("i8_bias_i8", op.mat_mul_accelerator_int8_fast_2x2_32unroll, B, torch.int8, b8, -128),
+        ("i8_bias_i8_relu", op.mat_mul_accelerator_int8_fast_2x2_32unroll, B, torch.int8, b8, 0),
+        ("i8_bias_i8_over_column", op.mat_mul_accelerator_int8_fast_32unroll_over_column, B, torch.int8, b8, -128),
+        ("i8_nobias_i8", op.mat_mul_accelerator_int8_fast_2x2_32unroll_nobias, B, torch.int8, None, -128),
+        ("i8_nobias_batch_i8", op.mat_mul_accelerator_int8_fast_2x2_32unroll_nobias_batch, Bb, torch.int8, None, -128),
+        ("i8_bias_f32", op.mat_mul_accelerator_int8_fast_2x2_32unroll_bfp32_ofp32, B, torch.float32, bf, -128),
+        ("i8_nobias_f32", op.mat_mul_accelerator_int8_fast_2x2_32unroll_nobias_ofp32, B, torch.float32, None, -128),
+        ("i8_nobias_batch_f32", op.mat_mul_accelerator_int8_fast_2x2_32unroll_nobias_ofp32_batch, Bb, torch.float32, None, -128),
+    ]
+    for name, fn, Bm, dt, bias, qmin in runs:
+        p, out = _params(dev, A, Bm, dt, bias, al, be, qmin)
+        fn(p)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint8), golden[name].view(np.uint8)), name
+    p, out = _params(dev, golden["i8_tie_A"], golden["i8_tie_B"], torch.int8, None, 0.5)
+    op.mat_mul_accelerator_int8_fast_2x2_32unroll_nobias(p)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), golden["i8_tie_nobias_i8"]), "round-half-away-from-zero"
+
+
+def test_linear_wrappers_and_size_independent_properties(dev, oracle):
+    """L2 wrappers + properties that hold at any size: ReLU variant == max(non-ReLU, 0); permuting the rows of A
+    permutes the rows of C; alpha = 1, beta = 0 on small integers returns the exact integer dot products."""
+    from tinychatengine_amd.linear import W8A8B8O8Linear, W8A8BFP32OFP32Linear
+    M, N, K = 108, 3072, 768
+    A, B, b8, bf = _data(M, N, K, seed=1)
+    x, w = _t(dev, A), _t(dev, B)
+    y = W8A8B8O8Linear(w, _t(dev, b8), ALPHA, BETA)(x)
+    yr = W8A8B8O8Linear(w, _t(dev, b8), ALPHA, BETA, relu=True)(x)
+    assert torch.equal(yr, torch.clamp(y, min=0))
+    perm = torch.randperm(M, device=dev)
+    assert torch.equal(W8A8B8O8Linear(w, _t(dev, b8), ALPHA, BETA)(x[perm].contiguous()), y[perm])
+    yf = W8A8BFP32OFP32Linear(w, _t(dev, bf), ALPHA)(x)
+    assert np.array_equal(yf.cpu().numpy().view(np.uint32), oracle.int8_matmul_bias_f32(A, B, bf, ALPHA, M, N, K).view(np.uint32))
+    small_a = torch.randint(-3, 4, (64, 256), dtype=torch.int8, device=dev)
+    small_b = torch.randint(-3, 4, (96, 256), dtype=torch.int8, device=dev)
+    exact = W8A8BFP32OFP32Linear(small_b, torch.zeros(96, device=dev), 1.0)(small_a)
+    assert torch.equal(exact, (small_a.float() @ small_b.float().t()))
+    y1 = W8A8B8O8Linear(w, _t(dev, b8), ALPHA, BETA)(x[:1].contiguous())  # m == 1 -> over_column entry point
+    assert torch.equal(y1, y[:1])
+
+
+def test_unsupported_kind_is_rejected(dev):
+    from tinychatengine_amd import capi
+    a = torch.zeros(4, 64, dtype=torch.int8, device=dev)
+    d = capi.W8A8Desc(M=4, N=4, K=64, batch=1, A=a.data_ptr(), B=a.data_ptr(), bias=a.data_ptr(), C=a.data_ptr(), alpha=1.0, beta=1.0,
+                      q_min=-128, q_max=127, bias_kind=capi.TCE_BIAS_FP32, out_kind=capi.TCE_OUT_INT8)
+    assert capi.w8a8_matmul(d, 0) == capi.TCE_ERR_UNSUPPORTED_KIND

@@ -1,0 +1,134 @@
+"""CPU: pin oracle/tce_oracle.c (the restatement) against (a) the committed golden vectors, which were produced by the
+reference's own code (tests/golden/make_golden.py), and (b) the reference build itself when oracle/_ref is present."""
+import numpy as np
+import pytest
+
+
+def _seq(codes):
+    return (codes[:, 0::2] | (codes[:, 1::2] << 4)).astype(np.uint8)
+
+
+# ---------------- golden vectors (always run) ----------------
+def test_quantizer_matches_reference_python_quantizer(oracle, golden):
+    M, N, K, G = golden["w4_dims"]
+    qw, sc, zp, codes, d = oracle.quantize_q4_6(golden["w4_w"], int(G))
+    assert np.array_equal(qw, golden["w4_qweight"])
+    assert np.array_equal(sc.view(np.uint16), golden["w4_scales"].view(np.uint16))
+    assert np.array_equal(zp, golden["w4_zeros"])
+    assert sc.shape[1] == 16 and zp.shape[1] == 2  # K=1408: 11 groups padded to zeros_width 2 (quantize_methods.py:9-21)
+    M, N, K, G = golden["awq_dims"]
+    codes, d = oracle.group_quantize(golden["awq_w"], int(G))
+    q5, s5, z5 = oracle.pack_q4_5(codes, d, int(N), int(K), int(G))
+    assert np.array_equal(q5, golden["awq_qweight"])
+    assert np.array_equal(s5.view(np.uint16), golden["awq_scales"].view(np.uint16))
+    assert np.array_equal(z5, golden["awq_zeros"])
+
+
+def test_w4_naive_and_gemv_oracles_match_golden(oracle, golden):
+    M, N, K, G = (int(v) for v in golden["w4_dims"])
+    codes = oracle.unpack_q4_6(golden["w4_qweight"], N, K)
+    s32 = golden["w4_scales"][:, : K // G].astype(np.float32)
+    a = golden["w4_a"]
+    out = oracle.naive_mat_mul_int4(a.astype(np.float32), _seq(codes), s32, 8.0, M, N, K, G)
+    assert np.array_equal(out, golden["w4_expected_f32"])
+    c32, c16 = oracle.w4a16_gemv_q4_6(a, golden["w4_qweight"], golden["w4_scales"], golden["w4_zeros"], M, N, K, G)
+    assert np.array_equal(c32, golden["w4_expected_f32"])  # zero point 8 everywhere -> identical to the naive oracle
+    assert np.array_equal(c16.view(np.uint16), golden["w4_expected_f32"].astype(np.float16).view(np.uint16))
+
+
+def test_awq_fp16_oracle_matches_golden(oracle, golden):
+    M, N, K, G = (int(v) for v in golden["awq_dims"])
+    out = oracle.naive_mat_mul_fp16_int4(golden["awq_a"], golden["awq_qweight"], golden["awq_scales"], M, N, K, G)
+    assert np.array_equal(out.view(np.uint16), golden["awq_expected_f16"].view(np.uint16))
+
+
+def test_int8_oracles_match_golden(oracle, golden):
+    M, N, K = (int(v) for v in golden["i8_dims"])
+    al, be = (float(v) for v in golden["i8_alpha_beta"])
+    A, B, b8, bf, Bb = golden["i8_A"], golden["i8_B"], golden["i8_bias8"], golden["i8_biasf"], golden["i8_Bb"]
+    assert np.array_equal(oracle.int8_matmul_bias_i8(A, B, b8, al, be, -128, 127, M, N, K), golden["i8_bias_i8"])
+    assert np.array_equal(oracle.int8_matmul_bias_i8(A, B, b8, al, be, 0, 127, M, N, K), golden["i8_bias_i8_relu"])
+    assert np.array_equal(golden["i8_bias_i8"], golden["i8_bias_i8_over_column"])
+    assert np.array_equal(oracle.int8_matmul_nobias_i8(A, B, al, -128, 127, M, N, K), golden["i8_nobias_i8"])
+    assert np.array_equal(oracle.int8_matmul_nobias_i8(A, Bb, al, -128, 127, M, N, K, batch=True), golden["i8_nobias_batch_i8"])
+    assert np.array_equal(oracle.int8_matmul_bias_f32(A, B, bf, al, M, N, K), golden["i8_bias_f32"])
+    assert np.array_equal(oracle.int8_matmul_nobias_f32(A, B, al, M, N, K), golden["i8_nobias_f32"])
+    assert np.array_equal(oracle.int8_matmul_nobias_f32(A, Bb, al, M, N, K, batch=True), golden["i8_nobias_batch_f32"])
+    assert np.array_equal(oracle.int8_matmul_nobias_i8(golden["i8_tie_A"], golden["i8_tie_B"], 0.5, -128, 127, 16, 4, 1),
+                          golden["i8_tie_nobias_i8"])
+    assert golden["i8_tie_nobias_i8"][9, 0] == 1 and golden["i8_tie_nobias_i8"][7, 0] == -1  # +-0.5 round away from zero
+    assert np.array_equal(oracle.naive_mat_mul_int8(A, np.ascontiguousarray(B.T), 3, -2, 0.02, 0.01, 0.05, -128, 127, M, N, K),
+                          golden["i8_naive"])
+    assert golden["i8_bias_i8"].min() == -128 and golden["i8_bias_i8"].max() == 127  # the clamp is exercised
+
+
+def test_fp32_oracle_matches_golden(oracle, golden):
+    out = oracle.fp32_matmul_transposed(golden["f32_A"], golden["f32_B"], None, 5, 7, 64)
+    assert np.array_equal(out, golden["f32_expected"]) and np.array_equal(out, golden["f32_expected_imp"])
+
+
+def test_f16_conversions_match_numpy(oracle):
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.standard_normal(4000) * 10.0 ** rng.integers(-9, 6, 4000), [0.0, -0.0, 65504.0, 65520.0, 1e-8, 6e-8, 2 ** -24, 2 ** -25]])
+    for v in x.astype(np.float32):
+        assert oracle.lib.orc_f32_to_f16(float(v)) == int(np.float32(v).astype(np.float16).view(np.uint16))
+    for v in x:
+        assert oracle.lib.orc_f64_to_f16(float(v)) == int(np.float64(v).astype(np.float16).view(np.uint16))
+    for bits in list(range(0, 0x7C00, 37)) + [0x8001, 0x83FF, 0xFBFF]:
+        assert oracle.lib.orc_f16_to_f32(bits) == float(np.uint16(bits).view(np.float16))
+
+
+# ---------------- live cross-check against the reference build (when present) ----------------
+@pytest.mark.parametrize("M,N,K,G", [(1, 64, 512, 128), (3, 40, 256, 32), (2, 24, 384, 64), (1, 16, 1408, 128)])
+def test_w4_against_reference_build(oracle, reference, M, N, K, G):
+    rng = np.random.default_rng(M * 1000 + N + K + G)
+    w = (rng.standard_normal((N, K)) * 0.02).astype(np.float32)
+    qw, sc, zp, codes, d = oracle.quantize_q4_6(w, G)
+    a = rng.standard_normal((M, K)).astype(np.float16)
+    s32 = sc[:, : K // G].astype(np.float32)
+    a32 = a.astype(np.float32)
+    assert np.array_equal(oracle.naive_mat_mul_int4(a32, _seq(codes), s32, 8.0, M, N, K, G),
+                          reference.naive_mat_mul_int4(a32, _seq(codes), s32, 8.0, M, N, K, G))
+    off = (rng.standard_normal(s32.shape) * 0.01).astype(np.float32)
+    assert np.array_equal(oracle.naive_mat_mul_int4_with_offset(a32, _seq(codes), s32, off, 8.0, M, N, K, G),
+                          reference.naive_mat_mul_int4_with_offset(a32, _seq(codes), s32, off, 8.0, M, N, K, G))
+    if G == 32:
+        assert np.array_equal(oracle.ref_int4_fast(a32, _seq(codes), s32, off, M, N, K), reference.ref_int4_fast(a32, _seq(codes), s32, off, M, N, K))
+    if N % 8 == 0:
+        q5, s5, _ = oracle.pack_q4_5(codes, d, N, K, G)
+        assert np.array_equal(oracle.naive_mat_mul_fp16_int4(a, q5, s5, M, N, K, G).view(np.uint16),
+                              reference.naive_mat_mul_fp16_int4(a, q5, s5, M, N, K, G).view(np.uint16))
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 32, 64), (17, 48, 96), (5, 8, 33)])
+def test_int8_against_reference_build(oracle, reference, M, N, K):
+    rng = np.random.default_rng(M + N + K)
+    A = rng.integers(-128, 128, (M, K), dtype=np.int8)
+    B = rng.integers(-128, 128, (N, K), dtype=np.int8)
+    Bb = rng.integers(-128, 128, (M, N, K), dtype=np.int8)
+    b8 = rng.integers(-128, 128, N, dtype=np.int8)
+    bf = rng.standard_normal(N).astype(np.float32)
+    for al, be in [(0.0005035400390625, 0.02130126953125), (0.0071, 0.13), (1.0, 1.0)]:
+        for qmin in (-128, 0):
+            assert np.array_equal(oracle.int8_matmul_bias_i8(A, B, b8, al, be, qmin, 127, M, N, K), reference.int8_matmul_bias_i8(A, B, b8, al, be, qmin, 127, M, N, K))
+            assert np.array_equal(oracle.int8_matmul_nobias_i8(A, B, al, qmin, 127, M, N, K), reference.int8_matmul_nobias_i8(A, B, al, qmin, 127, M, N, K))
+        assert np.array_equal(oracle.int8_matmul_nobias_i8(A, Bb, al, -128, 127, M, N, K, batch=True), reference.int8_matmul_nobias_i8(A, Bb, al, -128, 127, M, N, K, batch=True))
+        assert np.array_equal(oracle.int8_matmul_bias_f32(A, B, bf, al, M, N, K), reference.int8_matmul_bias_f32(A, B, bf, al, M, N, K))
+        assert np.array_equal(oracle.int8_matmul_nobias_f32(A, B, al, M, N, K), reference.int8_matmul_nobias_f32(A, B, al, M, N, K))
+        assert np.array_equal(oracle.int8_matmul_nobias_f32(A, Bb, al, M, N, K, batch=True), reference.int8_matmul_nobias_f32(A, Bb, al, M, N, K, batch=True))
+
+
+def test_config1_reference_shape_runs_on_cpu(oracle, reference):
+    """BASELINE config #1: kernels/ref-class naive_mat_mul_int4 on CPU, M=1, N=K=4096, group 128 (plumbing, no GPU)."""
+    rng = np.random.default_rng(1234)
+    N = K = 4096
+    w = (rng.standard_normal((N, K)) * 0.02).astype(np.float32)
+    qw, sc, zp, codes, d = oracle.quantize_q4_6(w, 128)
+    a = rng.standard_normal((1, K)).astype(np.float16)
+    ref = reference.naive_mat_mul_int4(a.astype(np.float32), _seq(codes), sc[:, :32].astype(np.float32), 8.0, 1, N, K, 128)
+    c32, _ = oracle.w4a16_gemv_q4_6(a, qw, sc, zp, 1, N, K, 128)
+    assert np.array_equal(c32, ref)
+
+
+def test_reference_struct_size_is_what_the_adapter_assumes(golden):
+    assert int(golden["sizeof_matmul_params"][0]) == 416

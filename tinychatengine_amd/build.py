@@ -1,0 +1,67 @@
+"""Build libtce_hip.so (the C-ABI library, include/tce_matmul.h) in-tree with hipcc for gfx950.
+
+    python -m tinychatengine_amd.build [--force]
+
+The library is written for MI355X only: one offload arch, no fallback path.  hipcc cross-compiles without a GPU.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO_DIR = os.path.dirname(PKG_DIR)
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_DIR = os.path.join(PKG_DIR, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libtce_hip.so")
+ADAPTER_LIB_PATH = os.path.join(LIB_DIR, "libtce_matmul_operator.so")
+ADAPTER_TEST_PATH = os.path.join(LIB_DIR, "adapter_selftest")
+
+HIP_SOURCES = ["tce_capi.hip", "w4a16_gemv.hip", "w4a16_gemm.hip", "w4a16_awq.hip", "w8a8_gemm.hip"]
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+    "-ffp-contract=off",  # the int8 epilogue and the fp16-accumulate entry point need every rounding
+    "-Wall", "-Wno-unused-function",
+]
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libtce_hip.so cannot be built (there is no CPU fallback)")
+
+
+def _stale(target: str, deps: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(LIB_DIR, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + [os.path.join(REPO_DIR, "include", "tce_matmul.h")]
+    objs = []
+    hipcc = _hipcc()
+    for src in HIP_SOURCES:
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
+        if force or _stale(op, [sp] + headers):
+            cmd = [hipcc, *HIPCC_FLAGS, "-I", os.path.join(REPO_DIR, "include"), "-I", CSRC, "-c", sp, "-o", op]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(op)
+    if force or _stale(LIB_PATH, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

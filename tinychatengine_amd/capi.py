@@ -1,0 +1,172 @@
+"""ctypes binding of libtce_hip.so (include/tce_matmul.h).  Plain pointers and sizes; torch is only used by callers
+to own device memory and streams.  Loading fails loudly when the HIP library has not been built: there is no fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libtce_hip.so")
+
+TCE_OK = 0
+TCE_ERR_BAD_ARG = -1
+TCE_ERR_UNSUPPORTED_GROUP = -2
+TCE_ERR_UNSUPPORTED_SHAPE = -3
+TCE_ERR_HIP = -4
+TCE_ERR_UNSUPPORTED_KIND = -5
+TCE_W4A16_GEMV_MAX_M = 8
+TCE_MAX_GROUP = 4
+TCE_W4_FORCE_GEMV = 1
+TCE_W4_FORCE_GEMM = 2
+TCE_BIAS_NONE, TCE_BIAS_INT8, TCE_BIAS_FP32 = 0, 1, 2
+TCE_OUT_INT8, TCE_OUT_FP32 = 0, 1
+
+# every symbol include/tce_matmul.h declares (tests/test_boundary.py checks the .so exports exactly these)
+EXPORTS = [
+    "tce_w4a16_forward", "tce_w4a16_forward_group", "tce_w4a16_awq_fp16acc", "tce_w4a16_awq_workspace_bytes",
+    "tce_w4a16_gemm_awq", "tce_w8a8_matmul", "tce_plan_create", "tce_plan_launch", "tce_plan_n_launches",
+    "tce_plan_destroy", "tce_version", "tce_last_error", "tce_build_info", "tce_w4a16_set_gemv_config",
+    "tce_w4a16_set_gemm_config", "tce_w4a16_algorithmic_bytes", "tce_w4a16_gemv_variant", "tce_w4a16_gemm_variant",
+]
+
+
+class W4A16Desc(C.Structure):
+    """struct tce_w4a16_desc"""
+    _fields_ = [
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("group_size", C.c_int32),
+        ("A", C.c_void_p), ("qweight", C.c_void_p), ("scales", C.c_void_p), ("zeros", C.c_void_p), ("C", C.c_void_p),
+        ("lda", C.c_int32), ("ldc", C.c_int32), ("scales_stride", C.c_int32), ("zeros_stride", C.c_int32),
+        ("flags", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class W8A8Desc(C.Structure):
+    """struct tce_w8a8_desc"""
+    _fields_ = [
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("batch", C.c_int32),
+        ("A", C.c_void_p), ("B", C.c_void_p), ("bias", C.c_void_p), ("C", C.c_void_p),
+        ("strideA", C.c_int64), ("strideB", C.c_int64), ("strideC", C.c_int64),
+        ("alpha", C.c_float), ("beta", C.c_float), ("q_min", C.c_int32), ("q_max", C.c_int32),
+        ("bias_kind", C.c_int32), ("out_kind", C.c_int32), ("b_per_row", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class TceError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libtce_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """The loaded library.  Raises if it has not been built (python -m tinychatengine_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m tinychatengine_amd.build` "
+                "(hipcc, gfx950).  tinychatengine_amd has no CPU or PyTorch fallback."
+            )
+        L = C.CDLL(LIB_PATH)
+        L.tce_version.restype = C.c_int
+        L.tce_last_error.restype = C.c_char_p
+        L.tce_build_info.restype = C.c_char_p
+        L.tce_w4a16_forward.argtypes = [C.POINTER(W4A16Desc), C.c_void_p]
+        L.tce_w4a16_forward_group.argtypes = [C.POINTER(W4A16Desc), C.c_int, C.c_void_p]
+        L.tce_w4a16_awq_fp16acc.argtypes = [C.c_int] * 4 + [C.c_void_p] * 5
+        L.tce_w4a16_awq_workspace_bytes.argtypes = [C.c_int] * 3
+        L.tce_w4a16_awq_workspace_bytes.restype = C.c_size_t
+        L.tce_w4a16_gemm_awq.argtypes = [C.c_int] * 4 + [C.c_void_p] * 5 + [C.c_int, C.c_void_p]
+        L.tce_w8a8_matmul.argtypes = [C.POINTER(W8A8Desc), C.c_void_p]
+        L.tce_plan_create.argtypes = [C.POINTER(W4A16Desc), C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_void_p)]
+        L.tce_plan_launch.argtypes = [C.c_void_p, C.c_void_p]
+        L.tce_plan_n_launches.argtypes = [C.c_void_p]
+        L.tce_plan_destroy.argtypes = [C.c_void_p]
+        L.tce_plan_destroy.restype = None
+        L.tce_w4a16_set_gemv_config.argtypes = [C.c_int] * 4
+        L.tce_w4a16_set_gemm_config.argtypes = [C.c_int] * 2
+        L.tce_w4a16_algorithmic_bytes.argtypes = [C.c_int] * 4
+        L.tce_w4a16_algorithmic_bytes.restype = C.c_int64
+        _lib = L
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != TCE_OK:
+        raise TceError(rc, lib().tce_last_error().decode())
+
+
+def last_error() -> str:
+    return lib().tce_last_error().decode()
+
+
+def w4a16_forward(desc: W4A16Desc, stream: int | None) -> int:
+    return lib().tce_w4a16_forward(C.byref(desc), C.c_void_p(stream or 0))
+
+
+def w4a16_forward_group(descs: list[W4A16Desc], stream: int | None) -> int:
+    arr = (W4A16Desc * len(descs))(*descs)
+    return lib().tce_w4a16_forward_group(arr, len(descs), C.c_void_p(stream or 0))
+
+
+def w8a8_matmul(desc: W8A8Desc, stream: int | None) -> int:
+    return lib().tce_w8a8_matmul(C.byref(desc), C.c_void_p(stream or 0))
+
+
+def algorithmic_bytes(M: int, N: int, K: int, G: int) -> int:
+    return int(lib().tce_w4a16_algorithmic_bytes(M, N, K, G))
+
+
+def set_gemv_config(rows: int = 0, waves_n: int = 0, waves_k: int = 0, depth: int = 0) -> None:
+    check(lib().tce_w4a16_set_gemv_config(rows, waves_n, waves_k, depth))
+
+
+def set_gemm_config(m_tiles: int = 0, n_tiles: int = 0) -> None:
+    check(lib().tce_w4a16_set_gemm_config(m_tiles, n_tiles))
+
+
+def gemv_variants() -> list[tuple[int, int, int, int]]:
+    """(rows_per_wave, waves_n, waves_k, depth) of every compiled GEMV kernel variant."""
+    out, i = [], 0
+    r, n, k, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    while lib().tce_w4a16_gemv_variant(i, C.byref(r), C.byref(n), C.byref(k), C.byref(d)) == TCE_OK:
+        out.append((r.value, n.value, k.value, d.value))
+        i += 1
+    return out
+
+
+def gemm_variants() -> list[tuple[int, int]]:
+    out, i = [], 0
+    m, n = C.c_int(), C.c_int()
+    while lib().tce_w4a16_gemm_variant(i, C.byref(m), C.byref(n)) == TCE_OK:
+        out.append((m.value, n.value))
+        i += 1
+    return out
+
+
+class Plan:
+    """tce_plan: a fixed sequence of W4A16 launches captured into one hipGraph (one decode token's linears)."""
+
+    def __init__(self, launches: list[list[W4A16Desc]]):
+        flat = [d for g in launches for d in g]
+        self._descs = (W4A16Desc * len(flat))(*flat)
+        self._groups = (C.c_int32 * len(launches))(*[len(g) for g in launches])
+        self._h = C.c_void_p()
+        check(lib().tce_plan_create(self._descs, self._groups, len(launches), C.byref(self._h)))
+        self.n_launches = len(launches)
+
+    def launch(self, stream: int | None) -> None:
+        check(lib().tce_plan_launch(self._h, C.c_void_p(stream or 0)))
+
+    def close(self) -> None:
+        if self._h:
+            lib().tce_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,289 @@
+// tce_capi.hip -- the C ABI of libtce_hip.so (include/tce_matmul.h): argument checking, dispatch, hipGraph plans.
+// No kernel lives here.  Nothing in this library falls back to a CPU path: if a kernel cannot run, the entry point
+// returns a negative code and the caller fails loudly.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "tce_common.hpp"
+#include "w4a16_kernels.hpp"
+
+namespace tce {
+int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err);
+}
+
+namespace {
+
+thread_local char g_err[512] = "";
+int g_gemv_rows = 0, g_gemv_wn = 0, g_gemv_wk = 0, g_gemv_depth = 0;
+int g_gemm_mt = 0, g_gemm_nt = 0;
+
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char *what) {
+    return fail(TCE_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+int check_w4a16(const tce_w4a16_desc *d) {
+    if (!d) return fail(TCE_ERR_BAD_ARG, "null descriptor");
+    if (!d->A || !d->qweight || !d->scales || !d->zeros || !d->C) return fail(TCE_ERR_BAD_ARG, "null data pointer");
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0) return fail(TCE_ERR_BAD_ARG, "non-positive M/N/K (%d,%d,%d)", d->M, d->N, d->K);
+    if (d->group_size != 128 && d->group_size != 64 && d->group_size != 32)
+        return fail(TCE_ERR_UNSUPPORTED_GROUP, "Unsupported group size: %d", d->group_size);  // gemv_cuda.cu:254-256
+    if (d->K % d->group_size != 0 || d->K % 32 != 0)
+        return fail(TCE_ERR_UNSUPPORTED_SHAPE, "K=%d must be a multiple of the group size and of 32", d->K);
+    const int lda = d->lda ? d->lda : d->K;
+    if (lda % 8 != 0 || reinterpret_cast<uintptr_t>(d->A) % 16 != 0)
+        return fail(TCE_ERR_UNSUPPORTED_SHAPE, "A must be 16-byte aligned with lda %% 8 == 0");
+    if (reinterpret_cast<uintptr_t>(d->qweight) % 16 != 0) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "qweight must be 16-byte aligned");
+    return TCE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tce_version(void) { return TCE_VERSION; }
+const char *tce_last_error(void) { return g_err; }
+const char *tce_build_info(void) { return "tce_hip gfx950 wave64 hipcc " __VERSION__; }
+
+int64_t tce_w4a16_algorithmic_bytes(int M, int N, int K, int G) {
+    const int64_t nk = (int64_t)N * K;
+    return nk / 2 + 2 * nk / G + nk / (2 * (int64_t)G) + 2 * (int64_t)M * K + 2 * (int64_t)M * N;
+}
+
+int tce_w4a16_set_gemv_config(int rows, int wn, int wk, int depth) {
+    if (rows == 0 && wn == 0 && wk == 0) {
+        g_gemv_rows = g_gemv_wn = g_gemv_wk = g_gemv_depth = 0;
+        return TCE_OK;
+    }
+    const int dd = depth ? depth : 2;
+    if (!tce::gemv_variant_exists(rows, wn, wk, dd))
+        return fail(TCE_ERR_BAD_ARG, "GEMV variant rows=%d wn=%d wk=%d depth=%d was not compiled", rows, wn, wk, dd);
+    g_gemv_rows = rows;
+    g_gemv_wn = wn;
+    g_gemv_wk = wk;
+    g_gemv_depth = dd;
+    return TCE_OK;
+}
+
+int tce_w4a16_gemv_variant(int idx, int *rows, int *wn, int *wk, int *depth) {
+    static const int table[][4] = {
+#define TCE_V(R, N_, K_, D_) {R, N_, K_, D_},
+        TCE_GEMV_VARIANTS(TCE_V)
+#undef TCE_V
+    };
+    const int n = (int)(sizeof(table) / sizeof(table[0]));
+    if (idx < 0 || idx >= n || !rows || !wn || !wk || !depth) return TCE_ERR_BAD_ARG;
+    *rows = table[idx][0];
+    *wn = table[idx][1];
+    *wk = table[idx][2];
+    *depth = table[idx][3];
+    return TCE_OK;
+}
+
+int tce_w4a16_gemm_variant(int idx, int *mt, int *nt) {
+    static const int table[][2] = {
+#define TCE_V(M_, N_) {M_, N_},
+        TCE_GEMM_VARIANTS(TCE_V)
+#undef TCE_V
+    };
+    const int n = (int)(sizeof(table) / sizeof(table[0]));
+    if (idx < 0 || idx >= n || !mt || !nt) return TCE_ERR_BAD_ARG;
+    *mt = table[idx][0];
+    *nt = table[idx][1];
+    return TCE_OK;
+}
+
+int tce_w4a16_set_gemm_config(int mt, int nt) {
+    if (mt == 0 && nt == 0) {
+        g_gemm_mt = g_gemm_nt = 0;
+        return TCE_OK;
+    }
+    if (!tce::gemm_variant_exists(mt, nt)) return fail(TCE_ERR_BAD_ARG, "GEMM variant %dx%d was not compiled", mt, nt);
+    g_gemm_mt = mt;
+    g_gemm_nt = nt;
+    return TCE_OK;
+}
+
+int tce_w4a16_forward_group(const tce_w4a16_desc *descs, int count, void *stream) {
+    if (!descs || count < 1 || count > TCE_MAX_GROUP) return fail(TCE_ERR_BAD_ARG, "group count %d not in 1..%d", count, TCE_MAX_GROUP);
+    for (int i = 0; i < count; ++i) {
+        const int rc = check_w4a16(&descs[i]);
+        if (rc != TCE_OK) return rc;
+        const tce_w4a16_desc &a = descs[0], &b = descs[i];
+        if (b.M != a.M || b.K != a.K || b.group_size != a.group_size || b.A != a.A || b.lda != a.lda)
+            return fail(TCE_ERR_BAD_ARG, "grouped linears must share M, K, group size and the activation");
+    }
+    hipError_t he = hipSuccess;
+    const int rc = tce::launch_w4a16_gemv(descs, count, g_gemv_rows, g_gemv_wn, g_gemv_wk, g_gemv_depth,
+                                          static_cast<hipStream_t>(stream), &he);
+    if (rc == TCE_ERR_HIP) return hip_fail(he, "w4a16 gemv launch");
+    if (rc != TCE_OK) return fail(rc, "w4a16 gemv: no kernel variant for this shape/config");
+    return TCE_OK;
+}
+
+int tce_w4a16_forward(const tce_w4a16_desc *d, void *stream) {
+    const int rc0 = check_w4a16(d);
+    if (rc0 != TCE_OK) return rc0;
+    const bool want_gemm = (d->flags & TCE_W4_FORCE_GEMM) || (d->M > TCE_W4A16_GEMV_MAX_M && !(d->flags & TCE_W4_FORCE_GEMV));
+    hipError_t he = hipSuccess;
+    if (want_gemm && d->K % 128 == 0) {
+        const int rc = tce::launch_w4a16_gemm(*d, g_gemm_mt, g_gemm_nt, static_cast<hipStream_t>(stream), &he);
+        if (rc == TCE_ERR_HIP) return hip_fail(he, "w4a16 gemm launch");
+        if (rc != TCE_OK) return fail(rc, "w4a16 gemm: no kernel variant for this shape/config");
+        return TCE_OK;
+    }
+    // GEMV path (also the fallback for K % 128 != 0): gridDim.y walks the M rows 4 at a time
+    return tce_w4a16_forward_group(d, 1, stream);
+}
+
+int tce_w4a16_awq_fp16acc(int M, int N, int K, int G, const void *A, const void *qweight, const void *scales, void *C,
+                          void *stream) {
+    if (!A || !qweight || !scales || !C || M <= 0 || N <= 0 || K <= 0) return fail(TCE_ERR_BAD_ARG, "bad argument");
+    if (G <= 0 || K % G != 0 || N % 8 != 0) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "need K %% G == 0 and N %% 8 == 0");
+    hipError_t he = hipSuccess;
+    const int rc = tce::launch_awq_fp16acc(M, N, K, G, A, qweight, scales, C, static_cast<hipStream_t>(stream), &he);
+    return rc == TCE_ERR_HIP ? hip_fail(he, "awq fp16acc launch") : rc;
+}
+
+size_t tce_w4a16_awq_workspace_bytes(int N, int K, int G) {
+    if (N <= 0 || K <= 0 || (G != 128 && G != 64 && G != 32)) return 0;
+    const size_t zw = (size_t)tce::zeros_width(K, G);
+    return (size_t)N * (K / 8) * 4 + (size_t)N * zw * 4 + (size_t)N * zw * 8 * 2;
+}
+
+int tce_w4a16_gemm_awq(int M, int N, int K, int G, const void *A, const void *qweight, const void *scales, void *C,
+                       void *workspace, int repack, void *stream) {
+    if (!A || !qweight || !scales || !C || !workspace || M <= 0 || N <= 0 || K <= 0) return fail(TCE_ERR_BAD_ARG, "bad argument");
+    if (G != 128 && G != 64 && G != 32) return fail(TCE_ERR_UNSUPPORTED_GROUP, "Unsupported group size: %d", G);
+    if (K % G != 0 || K % 32 != 0 || N % 8 != 0 || ((size_t)N * (K / 8)) % 4 != 0)
+        return fail(TCE_ERR_UNSUPPORTED_SHAPE, "need K %% G == 0, K %% 32 == 0, N %% 8 == 0");
+    hipError_t he = hipSuccess;
+    if (repack) {
+        const int rc = tce::launch_awq_repack(N, K, G, qweight, scales, workspace, static_cast<hipStream_t>(stream), &he);
+        if (rc != TCE_OK) return rc == TCE_ERR_HIP ? hip_fail(he, "awq repack launch") : rc;
+    }
+    const int zw = tce::zeros_width(K, G);
+    tce_w4a16_desc d;
+    std::memset(&d, 0, sizeof(d));
+    d.M = M;
+    d.N = N;
+    d.K = K;
+    d.group_size = G;
+    d.A = A;
+    d.qweight = workspace;
+    d.zeros = static_cast<const unsigned *>(workspace) + (size_t)N * (K / 8);
+    d.scales = static_cast<const unsigned *>(d.zeros) + (size_t)N * zw;
+    d.C = C;
+    return tce_w4a16_forward(&d, stream);
+}
+
+int tce_w8a8_matmul(const tce_w8a8_desc *d, void *stream) {
+    if (!d) return fail(TCE_ERR_BAD_ARG, "null descriptor");
+    if (!d->A || !d->B || !d->C) return fail(TCE_ERR_BAD_ARG, "null data pointer");
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch < 1) return fail(TCE_ERR_BAD_ARG, "non-positive M/N/K/batch");
+    if (d->out_kind != TCE_OUT_INT8 && d->out_kind != TCE_OUT_FP32) return fail(TCE_ERR_UNSUPPORTED_KIND, "bad out_kind %d", d->out_kind);
+    // only the combinations that exist in kernels/ref/matmul_ref_int8.cc
+    const bool ok = (d->out_kind == TCE_OUT_INT8 && (d->bias_kind == TCE_BIAS_INT8 || d->bias_kind == TCE_BIAS_NONE)) ||
+                    (d->out_kind == TCE_OUT_FP32 && (d->bias_kind == TCE_BIAS_FP32 || d->bias_kind == TCE_BIAS_NONE));
+    if (!ok) return fail(TCE_ERR_UNSUPPORTED_KIND, "bias_kind %d with out_kind %d has no reference counterpart", d->bias_kind, d->out_kind);
+    if (d->bias_kind != TCE_BIAS_NONE && !d->bias) return fail(TCE_ERR_BAD_ARG, "bias_kind set but bias is null");
+    if (d->b_per_row && d->bias_kind != TCE_BIAS_NONE) return fail(TCE_ERR_UNSUPPORTED_KIND, "the *_batch variants have no bias");
+    if (d->out_kind == TCE_OUT_INT8 && (d->q_min < -128 || d->q_max > 127 || d->q_min > d->q_max))
+        return fail(TCE_ERR_BAD_ARG, "q_min/q_max out of int8 range");
+    hipError_t he = hipSuccess;
+    const int rc = tce::launch_w8a8(*d, static_cast<hipStream_t>(stream), &he);
+    return rc == TCE_ERR_HIP ? hip_fail(he, "w8a8 launch") : rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Plans: a fixed sequence of W4A16 launches (one decode token's linears) captured into a hipGraph.
+// ---------------------------------------------------------------------------------------------
+struct tce_plan {
+    std::vector<tce_w4a16_desc> descs;
+    std::vector<int32_t> groups;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+int tce_plan_create(const tce_w4a16_desc *descs, const int32_t *group_sizes, int n_launches, tce_plan **out) {
+    if (!descs || !group_sizes || n_launches < 1 || !out) return fail(TCE_ERR_BAD_ARG, "bad argument");
+    tce_plan *p = new (std::nothrow) tce_plan();
+    if (!p) return fail(TCE_ERR_BAD_ARG, "out of host memory");
+    int total = 0;
+    for (int i = 0; i < n_launches; ++i) {
+        if (group_sizes[i] < 1 || group_sizes[i] > TCE_MAX_GROUP) {
+            delete p;
+            return fail(TCE_ERR_BAD_ARG, "group size %d not in 1..%d", group_sizes[i], TCE_MAX_GROUP);
+        }
+        total += group_sizes[i];
+    }
+    p->descs.assign(descs, descs + total);
+    p->groups.assign(group_sizes, group_sizes + n_launches);
+
+    hipStream_t cap = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&cap, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete p;
+        return hip_fail(e, "hipStreamCreate");
+    }
+    e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(cap);
+        delete p;
+        return hip_fail(e, "hipStreamBeginCapture");
+    }
+    int rc = TCE_OK, off = 0;
+    for (int i = 0; i < n_launches && rc == TCE_OK; ++i) {
+        rc = p->groups[i] == 1 ? tce_w4a16_forward(&p->descs[off], cap) : tce_w4a16_forward_group(&p->descs[off], p->groups[i], cap);
+        off += p->groups[i];
+    }
+    e = hipStreamEndCapture(cap, &p->graph);
+    (void)hipStreamDestroy(cap);
+    if (rc != TCE_OK) {
+        if (p->graph) (void)hipGraphDestroy(p->graph);
+        delete p;
+        return rc;
+    }
+    if (e != hipSuccess) {
+        delete p;
+        return hip_fail(e, "hipStreamEndCapture");
+    }
+    e = hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(p->graph);
+        delete p;
+        return hip_fail(e, "hipGraphInstantiate");
+    }
+    *out = p;
+    return TCE_OK;
+}
+
+int tce_plan_launch(tce_plan *plan, void *stream) {
+    if (!plan || !plan->exec) return fail(TCE_ERR_BAD_ARG, "null plan");
+    const hipError_t e = hipGraphLaunch(plan->exec, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? TCE_OK : hip_fail(e, "hipGraphLaunch");
+}
+
+int tce_plan_n_launches(const tce_plan *plan) { return plan ? (int)plan->groups.size() : 0; }
+
+void tce_plan_destroy(tce_plan *plan) {
+    if (!plan) return;
+    if (plan->exec) (void)hipGraphExecDestroy(plan->exec);
+    if (plan->graph) (void)hipGraphDestroy(plan->graph);
+    delete plan;
+}
+
+}  // extern "C"

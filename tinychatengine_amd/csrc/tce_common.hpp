@@ -1,0 +1,91 @@
+// tce_common.hpp -- shared device helpers for the gfx950 kernels (wave64, CDNA4 only; no other target is supported).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tce_matmul.h"
+
+namespace tce {
+
+typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef int int4_t __attribute__((ext_vector_type(4)));
+typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+// llm/src/nn_modules/cuda/utils.cu:162-178 (calculate_zeros_width), host + device
+__host__ __device__ inline int zeros_width(int in_features, int group_size) {
+    const int mult = group_size >= 128 ? 1 : (group_size == 64 ? 2 : 4);
+    int w = (in_features / group_size + 7) / 8;
+    return ((w + mult - 1) / mult) * mult;
+}
+
+__device__ __forceinline__ half2_t as_half2(unsigned v) { return __builtin_bit_cast(half2_t, v); }
+__device__ __forceinline__ unsigned as_u32(half2_t v) { return __builtin_bit_cast(unsigned, v); }
+
+// ---------------------------------------------------------------------------------------------
+// int4 -> fp16 without integer->float conversions.
+//
+// A q4_6 word holds codes q0..q7 for k = 8j..8j+7, q_i in bits [4i, 4i+4).  OR-ing a nibble into the
+// mantissa of 1024.0h (0x6400, ulp 1) yields the half 1024+q; a nibble at mantissa bits 4..7 yields
+// 1024+16q.  Two nibbles 16 bits apart are converted at once:
+//     (w      & 0x000F000F) | 0x64006400 -> (1024+q0,    1024+q4)
+//     (w      & 0x00F000F0) | 0x64006400 -> (1024+16q1,  1024+16q5)
+//     (w >> 8 & 0x000F000F) | 0x64006400 -> (1024+q2,    1024+q6)
+//     (w >> 8 & 0x00F000F0) | 0x64006400 -> (1024+16q3,  1024+16q7)
+// and the zero point is removed EXACTLY in fp16:  (1024+q) + (-(1024+z)) = q - z;
+// (1024+16q) * (1/16) + (-(64+z)) = q - z (one fma, every intermediate representable).
+// So d[0..3] = (q0-z,q4-z), (q1-z,q5-z), (q2-z,q6-z), (q3-z,q7-z): the activation vector is staged
+// in the matching pair order (x0,x4),(x1,x5),(x2,x6),(x3,x7) so no lane ever shuffles weights.
+// ---------------------------------------------------------------------------------------------
+struct ZeroPair {
+    half2_t lo;  // (-(1024+z), -(1024+z))
+    half2_t hi;  // (-(64+z),   -(64+z))
+};
+
+__device__ __forceinline__ ZeroPair make_zero_pair(unsigned z /*0..15*/) {
+    ZeroPair zp;
+    zp.lo = as_half2(0xE400E400u | (z * 0x00010001u));  // -(1024+z): 0xE400 | z
+    zp.hi = as_half2(0xD400D400u | (z * 0x00100010u));  // -(64+z):   0xD400 | z<<4  (ulp of [64,128) is 1/16)
+    return zp;
+}
+
+__device__ __forceinline__ void dequant_word(unsigned w, const ZeroPair &zp, half2_t (&d)[4]) {
+    const half2_t sixteenth = as_half2(0x2C002C00u);  // 0.0625h
+    const unsigned w8 = w >> 8;
+    const half2_t t0 = as_half2((w & 0x000F000Fu) | 0x64006400u);
+    const half2_t t1 = as_half2((w & 0x00F000F0u) | 0x64006400u);
+    const half2_t t2 = as_half2((w8 & 0x000F000Fu) | 0x64006400u);
+    const half2_t t3 = as_half2((w8 & 0x00F000F0u) | 0x64006400u);
+    d[0] = t0 + zp.lo;
+    d[1] = __builtin_elementwise_fma(t1, sixteenth, zp.hi);
+    d[2] = t2 + zp.lo;
+    d[3] = __builtin_elementwise_fma(t3, sixteenth, zp.hi);
+}
+
+// Reorder 8 consecutive halves (x0..x7, one 16-byte piece) into the pair order the dequantizer produces:
+// (x0,x4),(x1,x5),(x2,x6),(x3,x7).
+__device__ __forceinline__ uint4_t pair_permute(uint4_t v) {
+    // v.x = (x0,x1) v.y = (x2,x3) v.z = (x4,x5) v.w = (x6,x7), low half first (hipcc folds these to v_perm_b32 / v_and_or_b32)
+    uint4_t r;
+    r.x = (v.x & 0x0000FFFFu) | (v.z << 16);         // (x0, x4)
+    r.y = (v.x >> 16) | (v.z & 0xFFFF0000u);         // (x1, x5)
+    r.z = (v.y & 0x0000FFFFu) | (v.w << 16);         // (x2, x6)
+    r.w = (v.y >> 16) | (v.w & 0xFFFF0000u);         // (x3, x7)
+    return r;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// non-temporal 16-byte load: streamed weights are read exactly once by exactly one CU
+__device__ __forceinline__ uint4_t load_nt(const uint4_t *p) { return __builtin_nontemporal_load(p); }
+
+}  // namespace tce

@@ -1,0 +1,245 @@
+// w4a16_gemm.hip -- W4A16 dequant-GEMM on MFMA for gfx950 (prefill, M > TCE_W4A16_GEMV_MAX_M).
+//
+// The reference has no GEMM kernel on this layout: gemv_forward_cuda re-runs its GEMV once per input row
+// (grid.z = M, kernels/cuda/gemv_cuda.cu:229-231) and gemm_forward_cuda* are declared but never defined
+// (kernels/matmul.h:140-145).  The math is the same dequant + dot product as the GEMV:
+//     C[m][n] = fp16( sum_k A[m][k] * fp16( s[n][k/G] * (q[n][k] - z[n][k/G]) ) ),   fp32 accumulate on MFMA.
+//
+// CDNA4 design:
+//   * v_mfma_f32_16x16x32_f16; the A operand is the activation tile, the B operand the dequantized weights, so a
+//     lane's accumulator registers share one output channel n = lane & 15 and the group scale is a per-lane scalar.
+//   * weights never touch LDS: in the q4_6 layout one 32-bit word is exactly the 8 consecutive k of one n that a
+//     lane feeds to one MFMA, so each lane streams a 16-byte chunk (4 MFMA k-steps) straight from HBM/L2 into
+//     registers and converts it with the magic-number trick (tce_common.hpp).  Any permutation of k inside the
+//     contraction is legal as long as A uses the same one: the pair order (0,4,1,5,2,6,3,7) is applied to the
+//     activation tile while it is staged into LDS, never to the weights.
+//   * the activation tile (BM x 128 halves) is staged through registers into an LDS image that is lane-linear
+//     per MFMA fragment (ds_read_b128 conflict-free) with an XOR swizzle that keeps the coalesced staging
+//     writes at <= 2-way conflicts.
+//   * 4 waves along N, each MT x NT tiles of 16x16; block -> tile mapping keeps every XCD on its own set of
+//     weight columns so the re-reads of a weight panel by the M/BM row-blocks hit that XCD's L2.
+#include "tce_common.hpp"
+#include "w4a16_kernels.hpp"
+
+namespace tce {
+
+namespace {
+
+struct GemmArgs {
+    const half_t *A;
+    const uint4_t *qweight;
+    const half_t *scales;
+    const unsigned *zeros;
+    half_t *C;
+    int M, N, K, lda, ldc, scales_stride, zeros_stride, log2g;
+    int n_blocks, m_blocks;
+};
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void w4a16_gemm_kernel(const GemmArgs g) {
+    constexpr int BM = MT * 16;
+    constexpr int BN = 4 * NT * 16;
+    constexpr int BK = 128;
+    __shared__ __attribute__((aligned(16))) uint4_t lds_a[MT * 4 * 64];  // [mt][s][64 lanes] 16-byte pieces
+
+    // ---- XCD-aware tile mapping: workgroup b runs on XCD b % 8 (observed, used for speed only) ----
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const int slot = bid >> 3;
+    const int n_blk = xcd + 8 * (slot / g.m_blocks);
+    const int m_blk = slot % g.m_blocks;
+    if (n_blk >= g.n_blocks) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n16 = lane & 15;
+    const int q = lane >> 4;
+    const int m_base = m_blk * BM;
+    const int n_base = n_blk * BN + wave * (NT * 16);
+    const int nchunks = g.K >> 5;
+    const int nkb = g.K / BK;
+
+    // ---- per-lane weight rows ----
+    int nrow[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n_base + j * 16 + n16;
+        nrow[j] = n < g.N ? n : g.N - 1;
+    }
+    struct BRegs {
+        uint4_t w[NT];
+        half_t s[NT];
+        unsigned z[NT];
+    };
+    auto load_b = [&](BRegs &b, int kb) {
+        const int chunk = kb * 4 + q;
+        const int grp = (chunk << 5) >> g.log2g;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            b.w[j] = g.qweight[(size_t)nrow[j] * nchunks + chunk];
+            b.s[j] = g.scales[(size_t)nrow[j] * g.scales_stride + grp];
+            b.z[j] = g.zeros[(size_t)nrow[j] * g.zeros_stride + (grp >> 3)];
+        }
+    };
+    // ---- activation staging: MT pieces of 16 bytes per thread ----
+    uint4_t areg[MT];
+    auto load_a = [&](int kb) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int e = i * 256 + tid;
+            const int row = e >> 4, pc = e & 15;
+            int m = m_base + row;
+            m = m < g.M ? m : g.M - 1;
+            areg[i] = *reinterpret_cast<const uint4_t *>(g.A + (size_t)m * g.lda + kb * BK + pc * 8);
+        }
+    };
+    auto write_a = [&]() {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int e = i * 256 + tid;
+            const int row = e >> 4, pc = e & 15;
+            const int qq = pc >> 2, s = pc & 3;  // k offset 8*pc = 32*qq + 8*s
+            lds_a[((row >> 4) * 4 + s) * 64 + qq * 16 + ((row & 15) ^ s)] = pair_permute(areg[i]);
+        }
+    };
+
+    float4_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](const BRegs &b, int kb) {
+        const int grp = ((kb * 4 + q) << 5) >> g.log2g;
+        const int zsh = (grp & 7) * 4;
+        ZeroPair zp[NT];
+        half2_t sc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            zp[j] = make_zero_pair((b.z[j] >> zsh) & 0xFu);
+            sc[j] = half2_t{b.s[j], b.s[j]};
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            half8_t bf[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                half2_t d[4];
+                dequant_word(b.w[j][s], zp[j], d);
+                const half2_t e0 = d[0] * sc[j], e1 = d[1] * sc[j], e2 = d[2] * sc[j], e3 = d[3] * sc[j];
+                bf[j] = half8_t{e0.x, e0.y, e1.x, e1.y, e2.x, e2.y, e3.x, e3.y};
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const uint4_t araw = lds_a[(i * 4 + s) * 64 + q * 16 + (n16 ^ s)];  // lane's row m16 == lane & 15
+                const half8_t af = __builtin_bit_cast(half8_t, araw);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    BRegs b0, b1;
+    load_a(0);
+    load_b(b0, 0);
+    const int last = nkb - 1;
+    for (int kb = 0; kb < nkb; kb += 2) {
+        {
+            write_a();
+            __syncthreads();
+            const int nx = kb + 1 < nkb ? kb + 1 : last;  // clamped (never predicated) prefetch
+            load_a(nx);
+            load_b(b1, nx);
+            compute(b0, kb);
+            __syncthreads();
+        }
+        if (kb + 1 < nkb) {
+            write_a();
+            __syncthreads();
+            const int nx = kb + 2 < nkb ? kb + 2 : last;
+            load_a(nx);
+            load_b(b0, nx);
+            compute(b1, kb + 1);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: D[i = 4*(lane>>4) + r][j = lane & 15] of each 16x16 tile ----
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n_base + j * 16 + n16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m_base + i * 16 + q * 4 + r;
+                if (m < g.M && n < g.N) g.C[(size_t)m * g.ldc + n] = (half_t)acc[i][j][r];
+            }
+        }
+}
+
+template <int MT, int NT>
+hipError_t launch_gemm(const GemmArgs &g0, hipStream_t stream) {
+    GemmArgs g = g0;
+    constexpr int BM = MT * 16, BN = 4 * NT * 16;
+    g.n_blocks = (g.N + BN - 1) / BN;
+    g.m_blocks = (g.M + BM - 1) / BM;
+    const int n8 = (g.n_blocks + 7) / 8 * 8;
+    hipLaunchKernelGGL((w4a16_gemm_kernel<MT, NT>), dim3(n8 * g.m_blocks), dim3(256), 0, stream, g);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool gemm_variant_exists(int mt, int nt) {
+#define TCE_V(M_, N_) \
+    if (mt == M_ && nt == N_) return true;
+    TCE_GEMM_VARIANTS(TCE_V)
+#undef TCE_V
+    return false;
+}
+
+int launch_w4a16_gemm(const tce_w4a16_desc &d, int forced_mt, int forced_nt, hipStream_t stream, hipError_t *hip_err) {
+    if (d.K % 128 != 0) return TCE_ERR_UNSUPPORTED_SHAPE;  // caller falls back to the GEMV kernel
+    GemmArgs g{};
+    const int zw = zeros_width(d.K, d.group_size);
+    g.A = static_cast<const half_t *>(d.A);
+    g.qweight = static_cast<const uint4_t *>(d.qweight);
+    g.scales = static_cast<const half_t *>(d.scales);
+    g.zeros = static_cast<const unsigned *>(d.zeros);
+    g.C = static_cast<half_t *>(d.C);
+    g.M = d.M;
+    g.N = d.N;
+    g.K = d.K;
+    g.lda = d.lda ? d.lda : d.K;
+    g.ldc = d.ldc ? d.ldc : d.N;
+    g.scales_stride = d.scales_stride ? d.scales_stride : zw * 8;
+    g.zeros_stride = d.zeros_stride ? d.zeros_stride : zw;
+    g.log2g = d.group_size == 128 ? 7 : (d.group_size == 64 ? 6 : 5);
+    int mt = forced_mt, nt = forced_nt;
+    if (mt == 0) {
+        // tile choice: keep >= ~256 workgroups when the problem allows it (one per CU)
+        if (d.M <= 32) { mt = 2; nt = 2; }
+        else if (d.M <= 64) { mt = 4; nt = 1; }
+        else { mt = 4; nt = 2; }
+    }
+    hipError_t e = hipSuccess;
+    bool found = false;
+#define TCE_V(M_, N_)                        \
+    if (!found && mt == M_ && nt == N_) {    \
+        found = true;                        \
+        e = launch_gemm<M_, N_>(g, stream);  \
+    }
+    TCE_GEMM_VARIANTS(TCE_V)
+#undef TCE_V
+    if (!found) return TCE_ERR_BAD_ARG;
+    if (e != hipSuccess) {
+        if (hip_err) *hip_err = e;
+        return TCE_ERR_HIP;
+    }
+    return TCE_OK;
+}
+
+}  // namespace tce

@@ -1,0 +1,65 @@
+// w4a16_kernels.hpp -- host-visible declarations shared by the W4A16 translation units.
+#pragma once
+#include "tce_common.hpp"
+
+namespace tce {
+
+// One linear of a (possibly grouped) GEMV launch.
+struct GemvSeg {
+    const uint4_t *qweight;  // u32 [N][K/8] viewed as 16-byte chunks: [N][K/32]
+    const half_t *scales;    // fp16 [N][scales_stride]
+    const unsigned *zeros;   // u32 [N][zeros_stride]
+    half_t *C;               // fp16 [M][ldc]
+    int N, ldc, scales_stride, zeros_stride;
+    int block_begin;         // first blockIdx.x of this linear
+};
+
+struct GemvArgs {
+    const half_t *A;  // fp16 [M][lda]
+    int lda, M, K, log2g;
+    int nseg;
+    GemvSeg seg[TCE_MAX_GROUP];
+};
+
+// (rows per wave, waves along N, waves splitting K, pipeline depth in steps) -- every tuple listed here is compiled
+// for MB in {1,2,4}; tce_w4a16_set_gemv_config() can force any of them, the dispatcher picks by shape otherwise.
+#define TCE_GEMV_VARIANTS(X) \
+    X(1, 4, 1, 1)            \
+    X(2, 4, 1, 1)            \
+    X(4, 4, 1, 1)            \
+    X(1, 4, 1, 2)            \
+    X(2, 4, 1, 2)            \
+    X(4, 4, 1, 2)            \
+    X(2, 4, 1, 3)            \
+    X(4, 4, 1, 3)            \
+    X(1, 8, 1, 2)            \
+    X(2, 8, 1, 2)            \
+    X(4, 8, 1, 2)            \
+    X(1, 2, 2, 1)            \
+    X(2, 2, 2, 1)            \
+    X(4, 2, 2, 1)            \
+    X(2, 4, 2, 1)            \
+    X(2, 2, 2, 2)            \
+    X(1, 1, 4, 1)            \
+    X(1, 2, 4, 1)
+
+bool gemv_variant_exists(int rows, int wn, int wk, int depth);
+int launch_w4a16_gemv(const tce_w4a16_desc *descs, int count, int forced_rows, int forced_wn, int forced_wk,
+                      int forced_depth, hipStream_t stream, hipError_t *hip_err);
+
+// MFMA GEMM on the q4_6 layout (prefill).  m_tiles x n_tiles 16x16 MFMA tiles per wave, 4 waves along N.
+#define TCE_GEMM_VARIANTS(X) \
+    X(8, 1)                  \
+    X(4, 2)                  \
+    X(4, 1)                  \
+    X(2, 2)
+bool gemm_variant_exists(int m_tiles, int n_tiles);
+int launch_w4a16_gemm(const tce_w4a16_desc &d, int forced_mt, int forced_nt, hipStream_t stream, hipError_t *hip_err);
+
+// AWQ (q4_5) helpers
+int launch_awq_fp16acc(int M, int N, int K, int G, const void *A, const void *qweight, const void *scales, void *C,
+                       hipStream_t stream, hipError_t *hip_err);
+int launch_awq_repack(int N, int K, int G, const void *qweight, const void *scales, void *workspace, hipStream_t stream,
+                      hipError_t *hip_err);
+
+}  // namespace tce

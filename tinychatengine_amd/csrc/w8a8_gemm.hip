@@ -1,0 +1,200 @@
+// w8a8_gemm.hip -- SmoothQuant W8A8 int8 GEMM on MFMA for gfx950, bit-exact with kernels/ref/matmul_ref_int8.cc.
+//
+// One kernel serves the eight int8 MatmulOperator methods (kernels/ref/matmul_ref_int8.cc:161-192); they differ only
+// in the epilogue:
+//     acc   = sum_k (int32)A[m][k] * (int32)B[n][k]                                  exact, v_mfma_i32_16x16x64_i8
+//     int8 out:  r = (int32) round( (float)acc * alpha [+ (float)bias_i8[n] * beta] ); clamp(q_min,q_max)   (:29-32,:54-57)
+//     fp32 out:  (float)acc * alpha [+ bias_f32[n]]                                                     (:108,:132)
+// Bit-exactness rules: int->float conversion is RNE (v_cvt_f32_i32), the two products and the sum are
+// each rounded separately (this file is compiled with -ffp-contract=off AND uses __fmul_rn/__fadd_rn), round() is
+// half-away-from-zero, the clamp happens on the rounded value before narrowing.
+//
+// Layout: A int8 [M][K], B int8 [N][K] -- both K-contiguous, which is exactly the MFMA i8 fragment shape: lane l
+// feeds 16 consecutive k of row (l & 15), k-block (l >> 4), i.e. one 16-byte load per lane per MFMA and no LDS.
+// (Any assignment of k to MFMA slots is legal as long as A and B agree, so no swizzle is needed.)
+#include "tce_common.hpp"
+
+namespace tce {
+
+namespace {
+
+struct W8A8Args {
+    const int8_t *A;
+    const int8_t *B;
+    const void *bias;
+    void *C;
+    long long strideA, strideB, strideC;
+    int M, N, K;
+    float alpha, beta;
+    int q_min, q_max;
+    int bias_kind, out_kind, b_per_row, vec_ok;
+};
+
+__device__ __forceinline__ void epilogue_store(const W8A8Args &a, void *Cb, int m, int n, int acc) {
+    const float f = (float)acc;  // v_cvt_f32_i32: round-to-nearest-even, like the host cast
+    float v = __fmul_rn(f, a.alpha);
+    if (a.out_kind == TCE_OUT_INT8) {
+        if (a.bias_kind == TCE_BIAS_INT8) {
+            const float u = __fmul_rn((float)static_cast<const int8_t *>(a.bias)[n], a.beta);
+            v = __fadd_rn(v, u);
+        }
+        float r = roundf(v);  // half away from zero (std::round)
+        r = fmaxf(r, (float)a.q_min);
+        r = fminf(r, (float)a.q_max);
+        static_cast<int8_t *>(Cb)[(size_t)m * a.N + n] = (int8_t)(int)r;
+    } else {
+        if (a.bias_kind == TCE_BIAS_FP32) v = __fadd_rn(v, static_cast<const float *>(a.bias)[n]);
+        static_cast<float *>(Cb)[(size_t)m * a.N + n] = v;
+    }
+}
+
+// 4 waves as 2(M) x 2(N); each wave 2x2 MFMA tiles of 16x16 -> 64x64 per workgroup.
+__global__ __launch_bounds__(256) void w8a8_mfma_kernel(const W8A8Args a) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int batch = blockIdx.z;
+    const int8_t *A = a.A + (size_t)batch * a.strideA;
+    const int8_t *B = a.B + (size_t)batch * a.strideB;
+    const size_t c_off = (size_t)batch * a.strideC;
+    void *Cb = a.out_kind == TCE_OUT_INT8 ? static_cast<void *>(static_cast<int8_t *>(a.C) + c_off)
+                                          : static_cast<void *>(static_cast<float *>(a.C) + c_off);
+    const int m_base = blockIdx.y * 64 + wm * 32;
+    const int n_base = blockIdx.x * 64 + wn * 32;
+
+    const int8_t *pa[2], *pb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int m = m_base + i * 16 + r16;
+        m = m < a.M ? m : a.M - 1;
+        pa[i] = A + (size_t)m * a.K + kq * 16;
+        int n = n_base + i * 16 + r16;
+        n = n < a.N ? n : a.N - 1;
+        pb[i] = B + (size_t)n * a.K + kq * 16;
+    }
+    int4_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = int4_t{0, 0, 0, 0};
+
+    const int k_full = a.K & ~63;
+#pragma unroll 4
+    for (int k0 = 0; k0 < k_full; k0 += 64) {
+        int4_t fa[2], fb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            fa[i] = *reinterpret_cast<const int4_t *>(pa[i] + k0);
+            fb[i] = *reinterpret_cast<const int4_t *>(pb[i] + k0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (k_full < a.K) {  // K % 64 in {16,32,48}: k-blocks past the end contribute zeros (K % 16 == 0 is guaranteed)
+        const bool live = k_full + kq * 16 < a.K;
+        int4_t fa[2], fb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int koff = live ? k_full : 0;  // dead k-blocks re-read a valid address and are zeroed
+            fa[i] = *reinterpret_cast<const int4_t *>(pa[i] + koff);
+            fb[i] = *reinterpret_cast<const int4_t *>(pb[i] + koff);
+            if (!live) {
+                fa[i] = int4_t{0, 0, 0, 0};
+                fb[i] = int4_t{0, 0, 0, 0};
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+
+    // D[row = 4*(lane>>4) + r][col = lane & 15]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n_base + j * 16 + r16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m_base + i * 16 + kq * 4 + r;
+                if (m < a.M && n < a.N) epilogue_store(a, Cb, m, n, acc[i][j][r]);
+            }
+        }
+}
+
+// Generic path: any K, and the *_batch variants where row i of A has its own B_i ([M][N][K], ref :79,:153).
+// One wavefront per output element pair would be overkill at these sizes (decode-time BMMs: heads x tgt_len x 64):
+// one thread per output, 16-byte loads when K % 16 == 0, exact int32 accumulate.
+__global__ __launch_bounds__(256) void w8a8_generic_kernel(const W8A8Args a) {
+    const int batch = blockIdx.z;
+    const int8_t *A = a.A + (size_t)batch * a.strideA;
+    const int8_t *B = a.B + (size_t)batch * a.strideB;
+    const size_t c_off = (size_t)batch * a.strideC;
+    void *Cb = a.out_kind == TCE_OUT_INT8 ? static_cast<void *>(static_cast<int8_t *>(a.C) + c_off)
+                                          : static_cast<void *>(static_cast<float *>(a.C) + c_off);
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)a.M * a.N) return;
+    const int m = (int)(idx / a.N), n = (int)(idx % a.N);
+    const int8_t *pa = A + (size_t)m * a.K;
+    const int8_t *pb = a.b_per_row ? B + ((size_t)m * a.N + n) * a.K : B + (size_t)n * a.K;
+    int acc = 0;
+    int k = 0;
+    if (a.vec_ok) {
+        for (; k < a.K; k += 16) {
+            const int4_t va = *reinterpret_cast<const int4_t *>(pa + k);
+            const int4_t vb = *reinterpret_cast<const int4_t *>(pb + k);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) acc = __builtin_amdgcn_sdot4(va[w], vb[w], acc, false);
+        }
+    }
+    for (; k < a.K; ++k) acc += (int)pa[k] * (int)pb[k];
+    epilogue_store(a, Cb, m, n, acc);
+}
+
+}  // namespace
+
+int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err) {
+    W8A8Args a{};
+    a.A = static_cast<const int8_t *>(d.A);
+    a.B = static_cast<const int8_t *>(d.B);
+    a.bias = d.bias;
+    a.C = d.C;
+    a.strideA = d.batch > 1 ? d.strideA : 0;
+    a.strideB = d.batch > 1 ? d.strideB : 0;
+    a.strideC = d.batch > 1 ? d.strideC : 0;
+    a.M = d.M;
+    a.N = d.N;
+    a.K = d.K;
+    a.alpha = d.alpha;
+    a.beta = d.beta;
+    a.q_min = d.q_min;
+    a.q_max = d.q_max;
+    a.bias_kind = d.bias_kind;
+    a.out_kind = d.out_kind;
+    a.b_per_row = d.b_per_row;
+    const bool aligned = (d.K % 16 == 0) && (reinterpret_cast<uintptr_t>(d.A) % 16 == 0) &&
+                         (reinterpret_cast<uintptr_t>(d.B) % 16 == 0) &&
+                         (d.batch == 1 || (d.strideA % 16 == 0 && d.strideB % 16 == 0));
+    a.vec_ok = aligned ? 1 : 0;
+    if (!d.b_per_row && aligned && d.K >= 64) {
+        dim3 grid((d.N + 63) / 64, (d.M + 63) / 64, d.batch);
+        hipLaunchKernelGGL(w8a8_mfma_kernel, grid, dim3(256), 0, stream, a);
+    } else {
+        const long long total = (long long)d.M * d.N;
+        dim3 grid((unsigned)((total + 255) / 256), 1, d.batch);
+        hipLaunchKernelGGL(w8a8_generic_kernel, grid, dim3(256), 0, stream, a);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (hip_err) *hip_err = e;
+        return TCE_ERR_HIP;
+    }
+    return TCE_OK;
+}
+
+}  // namespace tce

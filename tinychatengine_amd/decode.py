@@ -1,0 +1,159 @@
+"""One decode token's worth of hot-path work: the linears of every transformer block + lm_head, on synthetic weights.
+
+This is the caller side of the path as the reference issues it (llm/src/nn_modules/cuda/Int4llamaDecoderLayer.cu:73-115,
+Int4llamaAttention.cu:116-229, Int4llamaForCausalLM.cu:17-50: per block qkv_proj, o_proj, gate_proj, up_proj, down_proj,
+then lm_head) -- 5 x layers + 1 GEMV launches per token in the reference.  Here the linears that read the same
+activation are issued as one grouped launch (q/k/v; gate/up) and the whole token is one hipGraph (capi.Plan).
+Attention, norms, RoPE, SiLU are NOT part of the hot path and are not modelled: each linear reads a
+synthetic activation buffer of the right shape.
+
+Multi-GPU (no reference counterpart): every linear is sharded column-wise (output channels) over the ranks;
+per transformer block the rank-local slices of the block output are joined by ONE RCCL all-gather over xGMI
+(`gathers_per_block=1`, the north-star definition), or by the four gathers a dependency-faithful transformer needs
+(`gathers_per_block=4`: after qkv/attention, o_proj, gate/up, down_proj).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+
+from . import capi, quantize
+from .linear import Linear_half_int4
+from .matmul import _stream
+
+
+@dataclass(frozen=True)
+class ModelShape:
+    name: str
+    hidden: int
+    qkv: tuple[int, ...]  # output widths of the projections that read the block input (fused or separate)
+    ffn: int
+    vocab: int
+    layers: int
+
+
+# llm/include/model.h:68-83.  "baseline-named" is the shape set BASELINE.json's configs[1] spells out for its
+# "Llama-3-8B" row (4096x4096, 4096x11008 -- i.e. Llama-2-7B widths, fused 12288 qkv as the CUDA model launches it,
+# Int4llamaAttention.cu:124-125); "llama3-8b" is the true Llama-3-8B set (GQA k/v 1024, FFN 14336, vocab 128256).
+SHAPES = {
+    "baseline-named": ModelShape("baseline-named (Llama-2-7B-shaped, as BASELINE.json spells it)", 4096, (12288,), 11008, 32000, 32),
+    "llama3-8b": ModelShape("llama3-8b (true shapes, model.h:83)", 4096, (4096, 1024, 1024), 14336, 128256, 32),
+    "llama2-13b": ModelShape("llama2-13b (model.h:72)", 5120, (15360,), 13824, 32000, 40),
+    "tiny": ModelShape("tiny (tests)", 256, (256, 128, 128), 512, 1024, 2),
+}
+
+
+def _synthetic_linear(n: int, k: int, seed: int, device, group_size: int, rank: int, world: int) -> Linear_half_int4:
+    """W ~ N(0, 0.02^2) fp32 [N][K], quantized with the reference's q4_6 recipe; rank keeps rows
+    [rank*N/P, (rank+1)*N/P).  The full matrix is generated on every rank (same seed) so shards are consistent."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    n_loc = n // world
+    # generate only this rank's rows, but from a per-row-block seed so that world sizes agree on the values
+    w = torch.empty((n, k), dtype=torch.float32, device=device).normal_(0.0, 0.02, generator=g)
+    w = w[rank * n_loc:(rank + 1) * n_loc]
+    lin = Linear_half_int4.from_float(w.contiguous(), group_size)
+    del w
+    return lin
+
+
+class DecodeLinears:
+    """All W4A16 linears of one decode token for rank `rank` of `world`, plus the launch list / plan to run them."""
+
+    def __init__(self, shape: ModelShape, device="cuda", group_size: int = 128, rank: int = 0, world: int = 1,
+                 m: int = 1, seed: int = 1234, layers: int | None = None):
+        self.shape, self.rank, self.world, self.m, self.group_size = shape, rank, world, m, group_size
+        self.device = torch.device(device)
+        L = shape.layers if layers is None else layers
+        self.n_layers = L
+        h, f = shape.hidden, shape.ffn
+        for n in (*shape.qkv, h, f, shape.vocab):
+            if n % world or (n // world) % 4:
+                raise ValueError(f"N={n} does not shard {world}-way into multiples of 4 rows")
+        mk = lambda n, k, s: _synthetic_linear(n, k, seed + s, self.device, group_size, rank, world)
+        self.blocks = []
+        for li in range(L):
+            s = li * 16
+            self.blocks.append(dict(
+                qkv=[mk(n, h, s + i) for i, n in enumerate(shape.qkv)],
+                o=mk(h, h, s + 4), gate=mk(f, h, s + 5), up=mk(f, h, s + 6), down=mk(h, f, s + 7)))
+        self.lm_head = mk(shape.vocab, h, 999_983)
+        # activations (fp16).  x ~ N(0,1); every buffer a linear READS is full width (replicated input).
+        gx = torch.Generator(device=self.device).manual_seed(4321)
+        rnd = lambda *sz: torch.empty(sz, dtype=torch.float32, device=self.device).normal_(0, 1, generator=gx).to(torch.float16)
+        self.x = rnd(m, h)          # block input
+        self.attn = rnd(m, h)       # attention output stand-in (input of o_proj)
+        self.h2 = rnd(m, h)         # post-attention-norm stand-in (input of gate/up)
+        self.act = rnd(m, f)        # silu(gate)*up stand-in (input of down_proj)
+        W = world
+        e = lambda n: torch.empty((m, n), dtype=torch.float16, device=self.device)
+        self.out_qkv = [e(n // W) for n in shape.qkv]
+        self.out_o, self.out_gate, self.out_up, self.out_down = e(h // W), e(f // W), e(f // W), e(h // W)
+        self.logits = e(shape.vocab // W)
+        # gather targets (world > 1)
+        if W > 1:
+            self.g_qkv = [e(n) for n in shape.qkv]
+            self.g_o, self.g_gate, self.g_up, self.g_down, self.g_logits = e(h), e(f), e(f), e(h), e(shape.vocab)
+
+    # ---- descriptors ----
+    def block_launches(self, li: int) -> list[list[capi.W4A16Desc]]:
+        b = self.blocks[li]
+        return [
+            [l.desc(self.x, o) for l, o in zip(b["qkv"], self.out_qkv)],
+            [b["o"].desc(self.attn, self.out_o)],
+            [b["gate"].desc(self.h2, self.out_gate), b["up"].desc(self.h2, self.out_up)],
+            [b["down"].desc(self.act, self.out_down)],
+        ]
+
+    def token_launches(self, grouped: bool = True) -> list[list[capi.W4A16Desc]]:
+        out = []
+        for li in range(self.n_layers):
+            out += self.block_launches(li)
+        out.append([self.lm_head.desc(self.x, self.logits)])
+        if not grouped:  # one launch per linear, as the reference issues them
+            out = [[d] for g in out for d in g]
+        return out
+
+    def all_linears(self) -> list[Linear_half_int4]:
+        ls = []
+        for b in self.blocks:
+            ls += [*b["qkv"], b["o"], b["gate"], b["up"], b["down"]]
+        return ls + [self.lm_head]
+
+    def token_bytes(self) -> int:
+        """Algorithmic HBM bytes of one token on THIS rank (SURVEY §8d formula, summed over its linears)."""
+        return sum(capi.algorithmic_bytes(self.m, l.out_features, l.in_features, self.group_size) for l in self.all_linears())
+
+    def make_plan(self, grouped: bool = True) -> capi.Plan:
+        return capi.Plan(self.token_launches(grouped))
+
+    # ---- eager issue (used inside torch graph capture for world > 1, and by tests) ----
+    def run_block(self, li: int) -> None:
+        st = _stream()
+        for g in self.block_launches(li):
+            capi.check(capi.w4a16_forward_group(g, st) if len(g) > 1 else capi.w4a16_forward(g[0], st))
+
+    def run_lm_head(self) -> None:
+        capi.check(capi.w4a16_forward(self.lm_head.desc(self.x, self.logits), _stream()))
+
+    def run_token_distributed(self, gathers_per_block: int = 1) -> None:
+        """world > 1: per block, rank-local GEMVs then the RCCL all-gather(s) (torch.distributed 'nccl' == RCCL)."""
+        import torch.distributed as dist
+        ag = dist.all_gather_into_tensor
+        assert self.m == 1, "column-sharded outputs are gathered as flat [N] vectors (M = 1 decode)"
+        for li in range(self.n_layers):
+            if gathers_per_block == 1:
+                self.run_block(li)
+                ag(self.g_down.view(-1), self.out_down.view(-1))
+            else:
+                b, st = self.blocks[li], _stream()
+                lch = self.block_launches(li)
+                run = lambda g: capi.check(capi.w4a16_forward_group(g, st) if len(g) > 1 else capi.w4a16_forward(g[0], st))
+                run(lch[0])
+                for gfull, part in zip(self.g_qkv, self.out_qkv):
+                    ag(gfull.view(-1), part.view(-1))
+                run(lch[1]); ag(self.g_o.view(-1), self.out_o.view(-1))
+                run(lch[2]); ag(self.g_gate.view(-1), self.out_gate.view(-1)); ag(self.g_up.view(-1), self.out_up.view(-1))
+                run(lch[3]); ag(self.g_down.view(-1), self.out_down.view(-1))
+        self.run_lm_head()
+        ag(self.g_logits.view(-1), self.logits.view(-1))

@@ -1,0 +1,124 @@
+"""The L2 callers of the hot path -- the ops that own quantized weights, fill a descriptor and call one operator
+method (reference llm/include/ops/linear.h:186-221, llm/src/ops/cuda/linear.cu:5-40, llm/src/ops/W8A8*.cc,
+llm/src/ops/BMM_S8T_*.cc) -- and their multi-GPU form: every linear sharded column-wise (output channels) across
+ranks, outputs joined by an RCCL all-gather over xGMI (no reference counterpart).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import capi, quantize
+from .matmul import MatmulOperator, matmul_params, matrix, _ptr, _stream
+
+
+class Linear_half_int4:
+    """W4A16 linear on the q4_6 layout.  Mirrors Linear_half_int4 (linear.h:186-221 / linear.cu:5-40)."""
+
+    def __init__(self, qweight: torch.Tensor, scales: torch.Tensor, zeros: torch.Tensor, group_size: int = quantize.QK4_6):
+        self.weight, self.scale, self.zero_point = qweight, scales, zeros  # names as in linear.h:215-218
+        self.out_features, self.in_features = qweight.shape[0], qweight.shape[1] * 8
+        self.group_size = group_size
+        zw = quantize.calculate_zeros_width(self.in_features, group_size)
+        if tuple(scales.shape) != (self.out_features, zw * 8) or tuple(zeros.shape) != (self.out_features, zw):
+            raise ValueError("scales/zeros do not have the padded q4_6 shapes (quantize_methods.py:431-440)")
+        self._op = MatmulOperator()
+
+    @classmethod
+    def from_float(cls, w: torch.Tensor, group_size: int = quantize.QK4_6):
+        return cls(*quantize.quantize_q4_6(w, group_size), group_size=group_size)
+
+    @classmethod
+    def load(cls, dirname: str, out_features: int, in_features: int, group_size: int = quantize.QK4_6, device="cuda"):
+        return cls(*quantize.load_linear_q4_6(dirname, out_features, in_features, group_size, device), group_size=group_size)
+
+    def desc(self, x: torch.Tensor, out: torch.Tensor, ldc: int = 0) -> capi.W4A16Desc:
+        m = x.numel() // self.in_features
+        return capi.W4A16Desc(M=m, N=self.out_features, K=self.in_features, group_size=self.group_size, A=_ptr(x),
+                              qweight=_ptr(self.weight), scales=_ptr(self.scale), zeros=_ptr(self.zero_point),
+                              C=out.data_ptr(), ldc=ldc)
+
+    def forward(self, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        m = x.numel() // self.in_features
+        assert self.out_features > 8 and self.out_features % 16 == 0  # linear.cu:16-17
+        if out is None:
+            out = torch.empty((*x.shape[:-1], self.out_features), dtype=torch.float16, device=x.device)
+        p = matmul_params(A=matrix(m, self.in_features, x), B=matrix(self.in_features // 8, self.out_features, self.weight),
+                          C=matrix(m, self.out_features, out), half_scales=self.scale,
+                          int32_zero_point=self.zero_point, block_size=self.group_size)
+        self._op.gemv_forward_cuda(p)
+        return out
+
+    __call__ = forward
+
+    def shard(self, rank: int, world: int) -> "Linear_half_int4":
+        """Rows [rank*N/P, (rank+1)*N/P): a contiguous byte range of weights, scales and zeros in q4_6."""
+        n = self.out_features
+        assert n % world == 0 and (n // world) % 4 == 0
+        lo, hi = rank * (n // world), (rank + 1) * (n // world)
+        return Linear_half_int4(self.weight[lo:hi].contiguous(), self.scale[lo:hi].contiguous(),
+                                self.zero_point[lo:hi].contiguous(), self.group_size)
+
+    def weight_bytes(self) -> int:
+        return capi.algorithmic_bytes(1, self.out_features, self.in_features, self.group_size)
+
+
+def forward_group(linears: list[Linear_half_int4], x: torch.Tensor, outs: list[torch.Tensor]) -> None:
+    """Several linears reading the same activation (q/k/v, gate/up) as ONE launch (tce_w4a16_forward_group)."""
+    capi.check(capi.w4a16_forward_group([l.desc(x, o) for l, o in zip(linears, outs)], _stream()))
+
+
+class W8A8B8O8Linear:
+    """int8 -> int8 linear, alpha/beta epilogue (llm/src/ops/W8A8B8O8Linear.cc:15-78); relu=True is W8A8B8O8LinearReLU
+    (q_min = 0, W8A8B8O8LinearReLU.cc:32)."""
+
+    def __init__(self, weight: torch.Tensor, bias_int8: torch.Tensor, alpha: float, beta: float, relu: bool = False):
+        self.weight, self.bias, self.alpha, self.beta = weight, bias_int8, float(alpha), float(beta)
+        self.q_min = 0 if relu else -128
+        self._op = MatmulOperator()
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        n, k = self.weight.shape
+        m = x.numel() // k
+        out = torch.empty((*x.shape[:-1], n), dtype=torch.int8, device=x.device)
+        p = matmul_params(A=matrix(m, k, x), B=matrix(k, n, self.weight), C=matrix(m, n, out), bias=matrix(1, n, self.bias),
+                          alpha=self.alpha, beta=self.beta)
+        p.C.qparams.q_min, p.C.qparams.q_max = self.q_min, 127
+        if m == 1:  # W8A8B8O8Linear.cc:61-75
+            self._op.mat_mul_accelerator_int8_fast_32unroll_over_column(p)
+        else:
+            self._op.mat_mul_accelerator_int8_fast_2x2_32unroll(p)
+        return out
+
+    __call__ = forward
+
+
+class W8A8BFP32OFP32Linear:
+    """int8 -> fp32 linear with fp32 bias (llm/src/ops/W8A8BFP32OFP32Linear.cc:12-73)."""
+
+    def __init__(self, weight: torch.Tensor, bias_fp32: torch.Tensor, alpha: float):
+        self.weight, self.bias, self.alpha = weight, bias_fp32, float(alpha)
+        self._op = MatmulOperator()
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        n, k = self.weight.shape
+        m = x.numel() // k
+        out = torch.empty((*x.shape[:-1], n), dtype=torch.float32, device=x.device)
+        p = matmul_params(A=matrix(m, k, x), B=matrix(k, n, self.weight), C=matrix(m, n, out), bias=matrix(1, n, self.bias),
+                          alpha=self.alpha)
+        self._op.mat_mul_accelerator_int8_fast_2x2_32unroll_bfp32_ofp32(p)
+        return out
+
+    __call__ = forward
+
+
+def bmm_s8t_s8n(a: torch.Tensor, b: torch.Tensor, alpha: float, out_fp32: bool) -> torch.Tensor:
+    """BMM_S8T_S8N_F32T / BMM_S8T_S8N_S8T (llm/src/ops/BMM_S8T_S8N_F32T.cc:12-62, BMM_S8T_S8N_S8T.cc:12-63):
+    a int8 [b][m][k], b int8 [b][n][k] -> [b][m][n]; the reference loops heads on the host, here one launch."""
+    bs, m, k = a.shape
+    n = b.shape[1]
+    out = torch.empty((bs, m, n), dtype=torch.float32 if out_fp32 else torch.int8, device=a.device)
+    d = capi.W8A8Desc(M=m, N=n, K=k, batch=bs, A=_ptr(a), B=_ptr(b), bias=None, C=_ptr(out), strideA=m * k, strideB=n * k,
+                      strideC=m * n, alpha=float(alpha), beta=0.0, q_min=-128, q_max=127, bias_kind=capi.TCE_BIAS_NONE,
+                      out_kind=capi.TCE_OUT_FP32 if out_fp32 else capi.TCE_OUT_INT8, b_per_row=0)
+    capi.check(capi.w8a8_matmul(d, _stream()))
+    return out
