@@ -147,6 +147,20 @@ TCE_API int tce_plan_launch(tce_plan *plan, void *stream);
 TCE_API int tce_plan_n_launches(const tce_plan *plan);
 TCE_API void tce_plan_destroy(tce_plan *plan);
 
+/* ---- memory / sync helpers: what the L2 wrappers need from the runtime ----
+ * tce_malloc(managed=1) / tce_free replace allocate_aligned_memory_gpu / free_aligned_memory_gpu
+ * (llm/src/nn_modules/cuda/utils.cu:92-103, cudaMallocManaged there: model files are read straight into that memory,
+ * llm/include/common.h:111-120).  managed=0 gives plain device memory (preferred on MI355X; fill it with tce_memcpy).
+ * tce_synchronize(NULL) is the per-forward device sync (Int4llamaForCausalLM.cu:40-44 / tests' cudaDeviceSynchronize). */
+#define TCE_MEMCPY_H2D 0
+#define TCE_MEMCPY_D2H 1
+#define TCE_MEMCPY_D2D 2
+TCE_API int tce_malloc(void **ptr, size_t bytes, int managed);
+TCE_API int tce_free(void *ptr);
+TCE_API int tce_memcpy(void *dst, const void *src, size_t bytes, int kind, void *stream);
+TCE_API int tce_synchronize(void *stream);
+TCE_API int tce_device_count(void);
+
 /* ---- introspection / tuning (not part of the reference surface) ---- */
 TCE_API int tce_version(void);
 TCE_API const char *tce_last_error(void);
@@ -155,6 +169,10 @@ TCE_API const char *tce_build_info(void);
  * rows_per_wave in {1,2,4}; waves_n x waves_k waves per workgroup (waves_k of them split K); depth = weight steps kept
  * in flight per wave (the library lowers it when K is too short).  TCE_ERR_BAD_ARG if that variant was not compiled. */
 TCE_API int tce_w4a16_set_gemv_config(int rows_per_wave, int waves_n, int waves_k, int depth);
+/* Roofline diagnostics for the GEMV kernel (scripts/tune.py): 0 = normal; 1 = stream the weights only (no dequant/dot);
+ * 2 = skip the scale/zero-point loads; 3 = plain instead of non-temporal weight loads.  Outputs are meaningless for
+ * mode != 0; available for M = 1 and three geometries only (TCE_ERR_BAD_ARG from the launch otherwise). */
+TCE_API int tce_w4a16_set_debug_mode(int mode);
 /* Force an MFMA GEMM tile (m_tiles x n_tiles of 16x16 per wave); 0,0 = automatic. */
 TCE_API int tce_w4a16_set_gemm_config(int m_tiles, int n_tiles);
 /* Enumerate the compiled kernel variants (for tuning sweeps / tests): returns 0 and fills the outputs, or

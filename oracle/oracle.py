@@ -229,6 +229,21 @@ def have_ref_avx() -> bool:
         return False
 
 
+def _aligned(shape, dtype, align: int = 64) -> np.ndarray:
+    """The reference allocates every operand with posix_memalign (llm/src/utils.cc allocate_aligned_memory) and its AVX
+    kernels use aligned 256-bit loads; numpy only guarantees 16 bytes."""
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    raw = np.empty(n + align, np.uint8)
+    off = (-raw.ctypes.data) % align
+    return raw[off:off + n].view(dtype).reshape(shape)
+
+
+def _aligned_copy(a: np.ndarray, dtype) -> np.ndarray:
+    out = _aligned(a.shape, dtype)
+    out[...] = a
+    return out
+
+
 class ReferenceAVX:
     """Timed CPU baseline: the reference's W4A8 (group 32, QM_x86 layout) fast path.  Not a parity oracle."""
 
@@ -244,27 +259,26 @@ class ReferenceAVX:
         c = codes.reshape(N, K // 64, 2, 32)
         return np.ascontiguousarray((c[:, :, 0, :] | (c[:, :, 1, :] << 4)).astype(np.uint8).reshape(N, K // 2))
 
-    def w4a8(self, A_f32, B_q4_3, scales_f32, M, N, K):
-        A = np.ascontiguousarray(A_f32, np.float32).copy()
-        off = np.zeros_like(scales_f32, dtype=np.float32)
-        a8 = np.empty(M * K, np.int8); asc = np.empty(M * K // 32, np.float32)
-        out = np.empty((M, N), np.float32)
-        rc = self.lib.ref_avx_w4a8_g32(C.c_int(M), C.c_int(N), C.c_int(K), C.c_int(self.num_thread), _p(A), _p(B_q4_3),
-                                       _p(np.ascontiguousarray(scales_f32, np.float32)), _p(off), _p(a8), _p(asc), _p(out))
-        if rc != 0:
-            raise ValueError("K must be a multiple of 64")
-        return out
-
     def make_timed_call(self, A_f32, B_q4_3, scales_f32, M, N, K):
-        """Returns a zero-argument callable with all buffers pre-bound (for timing loops)."""
-        A = np.ascontiguousarray(A_f32, np.float32).copy(); B = np.ascontiguousarray(B_q4_3, np.uint8)
-        sc = np.ascontiguousarray(scales_f32, np.float32); off = np.zeros_like(sc)
-        a8 = np.empty(M * K, np.int8); asc = np.empty(M * K // 32, np.float32); out = np.empty((M, N), np.float32)
+        """Returns a zero-argument callable with all (64-byte aligned) buffers pre-bound, for timing loops."""
+        A = _aligned_copy(np.asarray(A_f32, np.float32), np.float32)
+        B = _aligned_copy(np.asarray(B_q4_3, np.uint8), np.uint8)
+        sc = _aligned_copy(np.asarray(scales_f32, np.float32), np.float32)
+        off = _aligned(sc.shape, np.float32)
+        off[...] = 0
+        a8 = _aligned((M * K,), np.int8)
+        asc = _aligned((M * K // 32,), np.float32)
+        out = _aligned((M, N), np.float32)
         args = (C.c_int(M), C.c_int(N), C.c_int(K), C.c_int(self.num_thread), _p(A), _p(B), _p(sc), _p(off), _p(a8), _p(asc), _p(out))
         keep = (A, B, sc, off, a8, asc, out)
         fn = self.lib.ref_avx_w4a8_g32
 
         def call(_keep=keep):
-            fn(*args)
+            rc = fn(*args)
+            if rc != 0:
+                raise ValueError("K must be a multiple of 64")
             return out
         return call
+
+    def w4a8(self, A_f32, B_q4_3, scales_f32, M, N, K):
+        return self.make_timed_call(A_f32, B_q4_3, scales_f32, M, N, K)().copy()

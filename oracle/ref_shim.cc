@@ -238,3 +238,30 @@ REF_API void ref_fp32_matmul_transposed(int M, int N, int K, const float *A, con
     else
         op.mat_mul_transposed(&p);
 }
+
+// Layout of the reference's descriptor (same index convention as tce_adapter_layout in
+// tinychatengine_amd/adapter/matmul_operator_hip.cc); tests/test_boundary.py compares the two tables.
+#include <cstddef>
+REF_API long ref_layout(int idx) {
+    switch (idx) {
+        case 0: return (long)sizeof(matmul_params);
+        case 1: return (long)sizeof(matrix);
+        case 2: return (long)offsetof(matmul_params, B);
+        case 3: return (long)offsetof(matmul_params, C);
+        case 4: return (long)offsetof(matmul_params, bias);
+        case 5: return (long)offsetof(matmul_params, opt_params);
+        case 6: return (long)offsetof(matmul_params, alpha);
+        case 7: return (long)offsetof(matmul_params, beta);
+        case 8: return (long)offsetof(matmul_params, half_scales);
+        case 9: return (long)offsetof(matmul_params, fp16_scales);
+        case 10: return (long)offsetof(matmul_params, int32_zero_point);
+        case 11: return (long)offsetof(matmul_params, block_size);
+        case 12: return (long)offsetof(matrix, half_data_ptr);
+        case 13: return (long)offsetof(matrix, int32_data_ptr);
+        case 14: return (long)offsetof(matrix, int8_data_ptr);
+        case 15: return (long)offsetof(matrix, qparams);
+        case 16: return (long)(offsetof(matrix, qparams) + offsetof(quantization_params, q_min));
+        case 17: return (long)offsetof(matmul_params, A_scales);
+        default: return -1;
+    }
+}

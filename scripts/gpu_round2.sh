@@ -1,0 +1,12 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+TAG=${1:-r1b}
+timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -60 > gpurun_out/${TAG}_pytest.log
+echo "pytest exit ${PIPESTATUS[0]}" >> gpurun_out/${TAG}_pytest.log
+timeout 900 python bench.py --steps 100 --warmup 10 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+timeout 600 python scripts/tune.py --only experiments > gpurun_out/${TAG}_exp.jsonl 2> gpurun_out/${TAG}_exp.err
+timeout 600 python scripts/tune.py --only gemm > gpurun_out/${TAG}_gemm.jsonl 2>> gpurun_out/${TAG}_exp.err
+bash scripts/profile.sh ${TAG} > gpurun_out/${TAG}_profile.log 2>&1
+tail -4 gpurun_out/${TAG}_pytest.log; tail -2 gpurun_out/${TAG}_bench.json | cut -c1-1500; tail -3 gpurun_out/${TAG}_bench.err

@@ -92,6 +92,54 @@ def sweep_gemv(shapes, variants, M=1, G=128, launches=128):
         del rings, arrs
 
 
+def experiments():
+    """Where does the time go?  The same launch with pieces of the kernel removed (tce_w4a16_set_debug_mode)."""
+    L = capi.lib()
+    shapes = [("gate+up grouped 2x11008x4096", [11008, 11008], 4096), ("lm_head 128256x4096", [128256], 4096),
+              ("o_proj 4096x4096", [4096], 4096), ("down 4096x11008", [4096], 11008)]
+    names = {0: "normal", 1: "stream-only", 2: "no scale/zero loads", 3: "plain (not nt) loads"}
+    for mode in (0, 1, 2, 3):
+        capi.check(L.tce_w4a16_set_debug_mode(mode))
+        try:
+            for (name, segs, K) in shapes:
+                rings = [ring(n, K, 128, min_bytes=1.2e9 / len(segs)) for n in segs]
+                nset = min(len(r) for r in rings)
+                x = torch.randn(1, K, device=dev).to(torch.float16)
+                outs = [torch.empty(1, n, dtype=torch.float16, device=dev) for n in segs]
+                arrs = []
+                for i in range(nset):
+                    ds = [capi.W4A16Desc(M=1, N=n, K=K, group_size=128, A=x.data_ptr(), qweight=rings[j][i][0].data_ptr(),
+                                         scales=rings[j][i][1].data_ptr(), zeros=rings[j][i][2].data_ptr(), C=outs[j].data_ptr())
+                          for j, n in enumerate(segs)]
+                    arrs.append((capi.W4A16Desc * len(ds))(*ds))
+                nbytes = sum(capi.algorithmic_bytes(1, n, K, 128) for n in segs)
+                for v in [(4, 4, 1, 1), (4, 4, 1, 2), (2, 4, 1, 2)]:
+                    capi.set_gemv_config(*v)
+                    try:
+                        us = time_graph(lambda i, sp: capi.check(L.tce_w4a16_forward_group(arrs[i % nset], len(segs), sp)), 128)
+                    except Exception as e:  # noqa: BLE001
+                        print(json.dumps({"kind": "exp", "mode": names[mode], "shape": name, "variant": v, "error": str(e)}), flush=True)
+                        continue
+                    print(json.dumps({"kind": "exp", "mode": names[mode], "shape": name, "variant": v, "us": round(us, 3),
+                                      "GBs": round(nbytes / us / 1e3, 1)}), flush=True)
+                del rings, arrs
+        finally:
+            capi.set_gemv_config()
+            L.tce_w4a16_set_debug_mode(0)
+    # a plain device-to-device read ceiling for reference: torch sum over 1.2 GB of int32 (reads only)
+    big = torch.randint(0, 100, (300_000_000,), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for fn, label in ((lambda: big.sum(), "torch int32 sum (read 1.2 GB)"), (lambda: big.clone(), "torch clone (read+write 1.2 GB each)")):
+        fn(); torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        print(json.dumps({"kind": "ceiling", "what": label, "ms": round(ms, 4), "GBs_read": round(1.2e9 / ms / 1e6, 1)}), flush=True)
+
+
 def sweep_gemm(shapes, M=512, G=128):
     L = capi.lib()
     for (N, K) in shapes:
@@ -155,6 +203,8 @@ def main():
         sweep_gemv(shapes, variants)
         sweep_gemv([("M=2 4096x4096", [4096], 4096), ("M=4 gate+up", [11008, 11008], 4096), ("M=8 4096x4096", [4096], 4096)][:1 if args.quick else 3],
                    [(2, 4, 1, 2), (4, 4, 1, 2), (1, 4, 1, 2)], M=2)
+    if args.only == "experiments":
+        experiments()
     if args.only in ("", "gemm"):
         sweep_gemm([(4096, 4096), (11008, 4096), (4096, 11008)])
     if args.only in ("", "w8a8"):

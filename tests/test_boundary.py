@@ -1,0 +1,147 @@
+"""CPU (no GPU): the drop-in boundary itself.
+
+* libtce_hip.so loads and exports every symbol include/tce_matmul.h declares;
+* descriptor structs have the sizes the header implies; argument validation returns the documented codes before any
+  HIP call (so it is testable without a GPU);
+* the C++ adapter's matmul_params has the reference's exact layout (compared with the reference build's own offsets);
+* the product package never imports, links or opens anything under oracle/ and has no CPU fallback.
+"""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    from tinychatengine_amd import build as B
+    B.build()
+    B.build_adapter()
+    from tinychatengine_amd import capi
+    return capi
+
+
+def _declared_symbols():
+    src = open(os.path.join(REPO, "include", "tce_matmul.h")).read()
+    return sorted(set(re.findall(r"TCE_API\s+[\w\s\*]+?\b(tce_\w+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    assert sorted(built.EXPORTS) == declared, "capi.EXPORTS must list exactly what the header declares"
+    out = subprocess.check_output(["nm", "-D", "--defined-only", built.LIB_PATH], text=True)
+    exported = set(re.findall(r"\bT (tce_\w+)", out))
+    assert set(declared) <= exported, f"missing from the .so: {set(declared) - exported}"
+    lib = built.lib()
+    for s in declared:
+        assert hasattr(lib, s)
+    assert lib.tce_version() == 100
+    assert b"gfx950" in lib.tce_build_info()
+
+
+def test_library_contains_gfx950_code_objects_only(built):
+    blob = open(built.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    for other in (b"gfx942", b"gfx90a", b"gfx1100", b"sm_80"):
+        assert other not in blob
+
+
+def test_descriptor_sizes(built):
+    assert C.sizeof(built.W4A16Desc) == 80 and C.sizeof(built.W8A8Desc) == 104
+
+
+def test_argument_validation_needs_no_gpu(built):
+    capi = built
+    buf = (C.c_char * 4096)()
+    p = C.addressof(buf)
+    p16 = (p + 15) & ~15
+    d = capi.W4A16Desc(M=1, N=16, K=256, group_size=100, A=p16, qweight=p16, scales=p16, zeros=p16, C=p16)
+    assert capi.w4a16_forward(d, None) == capi.TCE_ERR_UNSUPPORTED_GROUP
+    assert "Unsupported group size: 100" in capi.last_error()  # the reference's message (gemv_cuda.cu:255)
+    d.group_size = 128
+    d.K = 200
+    assert capi.w4a16_forward(d, None) == capi.TCE_ERR_UNSUPPORTED_SHAPE
+    d.K = 256
+    d.A = p16 + 2
+    assert capi.w4a16_forward(d, None) == capi.TCE_ERR_UNSUPPORTED_SHAPE
+    d.A = p16
+    d.M = 0
+    assert capi.w4a16_forward(d, None) == capi.TCE_ERR_BAD_ARG
+    d.M = 1
+    d.C = None
+    assert capi.w4a16_forward(d, None) == capi.TCE_ERR_BAD_ARG
+    assert capi.lib().tce_w4a16_forward_group(None, 1, None) == capi.TCE_ERR_BAD_ARG
+    w = capi.W8A8Desc(M=1, N=1, K=1, batch=1, A=p16, B=p16, bias=None, C=p16, bias_kind=capi.TCE_BIAS_INT8, out_kind=capi.TCE_OUT_FP32)
+    assert capi.w8a8_matmul(w, None) == capi.TCE_ERR_UNSUPPORTED_KIND
+    w.bias_kind, w.out_kind = capi.TCE_BIAS_INT8, capi.TCE_OUT_INT8
+    assert capi.w8a8_matmul(w, None) == capi.TCE_ERR_BAD_ARG  # bias_kind set, bias null
+    w.bias_kind, w.q_min, w.q_max = capi.TCE_BIAS_NONE, 5, 3
+    assert capi.w8a8_matmul(w, None) == capi.TCE_ERR_BAD_ARG
+    assert capi.algorithmic_bytes(1, 4096, 4096, 128) == 8_732_672
+    assert capi.algorithmic_bytes(1, 11008, 4096, 128) == 23_455_232
+    assert capi.lib().tce_w4a16_awq_workspace_bytes(64, 256, 128) == 64 * 32 * 4 + 64 * 4 + 64 * 8 * 2
+    with pytest.raises(capi.TceError):
+        capi.set_gemv_config(3, 3, 3, 3)
+    assert (4, 4, 1, 2) in capi.gemv_variants() and (4, 2) in capi.gemm_variants()
+
+
+def test_adapter_exports_the_reference_member_functions(built):
+    from tinychatengine_amd import build as B
+    out = subprocess.check_output(["nm", "-D", "--defined-only", "-C", B.ADAPTER_LIB_PATH], text=True)
+    for m in ["gemv_forward_cuda(matmul_params const*)", "naive_mat_mul_fp16_int4(matmul_params const*)",
+              "gemm_forward_cuda(matmul_params const*, int)", "mat_mul_accelerator_int8_fast_2x2_32unroll(matmul_params const*)",
+              "mat_mul_accelerator_int8_fast_32unroll_over_column(matmul_params const*)",
+              "mat_mul_accelerator_int8_fast_2x2_32unroll_nobias(matmul_params const*)",
+              "mat_mul_accelerator_int8_fast_2x2_32unroll_nobias_batch(matmul_params const*)",
+              "mat_mul_accelerator_int8_fast_2x2_32unroll_nobias_ofp32(matmul_params const*)",
+              "mat_mul_accelerator_int8_fast_2x2_32unroll_nobias_ofp32_batch(matmul_params const*)",
+              "mat_mul_accelerator_int8_fast_2x2_32unroll_bfp32_ofp32(matmul_params const*)",
+              "mat_mul_accelerator_int8_fast_2x2_32unroll_bfp32_ofp32_over_column(matmul_params const*)",
+              "mat_mul_accelerator_int4_fast(matmul_params const*)", "mat_mul_accelerator_int4_fast_no_offset(matmul_params const*)"]:
+        assert f"matmul::MatmulOperator::{m}" in out, m
+
+
+def test_adapter_descriptor_layout_is_the_references(built):
+    """Same names, same offsets: the adapter's matmul_params is binary-compatible with kernels/matmul.h:52-92."""
+    from tinychatengine_amd import build as B
+    a = C.CDLL(B.ADAPTER_LIB_PATH)
+    a.tce_adapter_layout.restype = C.c_long
+    mine = [a.tce_adapter_layout(i) for i in range(18)]
+    assert mine[0] == 416 and mine[1] == 80
+    expected = [416, 80, 80, 160, 240, 320, 328, 332, 368, 376, 384, 392, 16, 32, 40, 64, 76, 400]  # from the reference build
+    assert mine == expected
+    from oracle import oracle as O
+    if O.have_ref():
+        r = C.CDLL(O.REF_SO)
+        if hasattr(r, "ref_layout"):
+            r.ref_layout.restype = C.c_long
+            assert [r.ref_layout(i) for i in range(18)] == mine
+
+
+def test_product_never_touches_the_oracle_and_has_no_cpu_fallback():
+    pkg = os.path.join(REPO, "tinychatengine_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cc")):
+                text = open(os.path.join(root, f), errors="ignore").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f"{f} imports oracle"
+                assert "libtce_oracle" not in text and "libtce_ref" not in text, f"{f} opens an oracle library"
+    bench = open(os.path.join(REPO, "bench.py")).read()
+    oracle_imports = [m.start() for m in re.finditer(r"from oracle import|import oracle", bench)]
+    assert oracle_imports, "bench.py's cpu_baseline leg uses the oracle"
+    leg = bench.index("def cpu_baseline_worker")
+    nxt = bench.index("\ndef main", leg)
+    assert all(leg < pos < nxt for pos in oracle_imports), "oracle may only be imported inside the cpu_baseline functions"
+
+
+def test_missing_library_fails_loudly(built, monkeypatch):
+    capi = built
+    monkeypatch.setattr(capi, "_lib", None)
+    monkeypatch.setattr(capi, "LIB_PATH", "/nonexistent/libtce_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU or PyTorch fallback"):
+        capi.lib()

@@ -1,0 +1,39 @@
+"""GPU: the C++ drop-in boundary end to end -- adapter_selftest fills a (poisoned) matmul_params like the reference's L2
+wrappers, calls matmul::MatmulOperator members, and compares with expected values computed here by the oracle."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cpp_adapter_selftest(oracle, tmp_path):
+    import torch
+    assert torch.cuda.is_available()
+    from tinychatengine_amd import build as B
+    B.build_adapter()
+    rng = np.random.default_rng(2024)
+    # case 1: FP16Linear_int4 (test_ops.cu:671-724 uses m=1, n=32000, k=4096; here n=2048 keeps the oracle instant)
+    M, N, K, G = 1, 2048, 4096, 128
+    w = (rng.standard_normal((N, K)) * 0.02).astype(np.float32)
+    qw, sc, zp, _, _ = oracle.quantize_q4_6(w, G)
+    x = rng.standard_normal((M, K)).astype(np.float16)
+    ref32, _ = oracle.w4a16_gemv_q4_6(x, qw, sc, zp, M, N, K, G)
+    blob = struct.pack("5i", M, N, K, G, zp.shape[1]) + qw.tobytes() + sc.tobytes() + zp.tobytes() + x.tobytes() + ref32.tobytes()
+    # case 2: W8A8B8O8LinearReLU 108x768x3072 with the reference's alpha/beta (test_ops.cc:177-209)
+    M, N, K = 108, 3072, 768
+    al, be = 0.0005035400390625, 0.02130126953125
+    A = rng.integers(-128, 128, (M, K), dtype=np.int8)
+    Bm = rng.integers(-128, 128, (N, K), dtype=np.int8)
+    bias = rng.integers(-128, 128, N, dtype=np.int8)
+    exp = oracle.int8_matmul_bias_i8(A, Bm, bias, al, be, 0, 127, M, N, K)
+    blob += struct.pack("3i2f", M, N, K, al, be) + A.tobytes() + Bm.tobytes() + bias.tobytes() + exp.tobytes()
+    path = tmp_path / "vectors.bin"
+    path.write_bytes(blob)
+    r = subprocess.run([B.ADAPTER_TEST_PATH, str(path)], capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("Passed!") == 3 and "Fail!" not in r.stdout

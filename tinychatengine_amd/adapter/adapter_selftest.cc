@@ -1,0 +1,183 @@
+// adapter_selftest.cc -- drives the C++ boundary exactly the way the reference's L2 wrappers and op tests do.
+//
+// Mirrors llm/tests/cuda/test_ops.cu:test_FP16Linear_int4 (:671-724) and llm/tests/non_cuda/test_ops.cc
+// (W8A8 tests :177-209, :245-276): managed allocations like allocate_aligned_memory_gpu (utils.cu:92-96), a
+// `matmul_params` on the stack whose unused fields are deliberately poisoned (the reference leaves them
+// uninitialised, linear.cu:19-33), `matmul::MatmulOperator op; op.gemv_forward_cuda(&params);`, one device sync,
+// compare.  Inputs and expected outputs come from a binary file written by tests/test_gpu_adapter.py (expected
+// values computed by oracle/); prints the reference's "-------- Test of X: Passed! --------" lines and returns
+// non-zero on any failure (the reference's tests do not propagate exit codes; this one does).
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "tce_matmul.h"
+#include "tce_matmul_operator.h"
+
+namespace {
+
+struct Blob {
+    std::vector<unsigned char> bytes;
+    size_t pos = 0;
+    template <typename T>
+    T get() {
+        T v;
+        std::memcpy(&v, bytes.data() + pos, sizeof(T));
+        pos += sizeof(T);
+        return v;
+    }
+    const unsigned char *take(size_t n) {
+        const unsigned char *p = bytes.data() + pos;
+        pos += n;
+        return p;
+    }
+};
+
+template <typename T>
+T *managed_copy(const unsigned char *src, size_t n_elems) {
+    void *p = nullptr;
+    if (tce_malloc(&p, n_elems * sizeof(T), /*managed=*/1) != TCE_OK) {
+        std::printf("allocation failed: %s\n", tce_last_error());
+        std::exit(2);
+    }
+    if (src) std::memcpy(p, src, n_elems * sizeof(T));  // like ifstream::read straight into managed memory (common.h:111-120)
+    else std::memset(p, 0xEE, n_elems * sizeof(T));
+    return static_cast<T *>(p);
+}
+
+float half_to_float(uint16_t h) {
+    const uint32_t s = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1F, m = h & 0x3FF;
+    uint32_t o;
+    if (e == 0) {
+        if (!m) o = s;
+        else {
+            int sh = 0;
+            uint32_t mm = m;
+            while (!(mm & 0x400)) { mm <<= 1; ++sh; }
+            o = s | ((uint32_t)(113 - sh) << 23) | ((mm & 0x3FF) << 13);
+        }
+    } else if (e == 31) o = s | 0x7F800000u | (m << 13);
+    else o = s | ((e + 112) << 23) | (m << 13);
+    float f;
+    std::memcpy(&f, &o, 4);
+    return f;
+}
+
+void poison(matmul_params &p) { std::memset(static_cast<void *>(&p), 0xA5, sizeof(p)); }
+
+bool report(const char *name, bool ok) {
+    std::printf("-------- Test of %s: %s --------\n", name, ok ? "Passed!" : "Fail!");
+    return ok;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    if (argc < 2) {
+        std::printf("usage: %s <vectors.bin>\n", argv[0]);
+        return 2;
+    }
+    Blob b;
+    {
+        FILE *f = std::fopen(argv[1], "rb");
+        if (!f) return 2;
+        std::fseek(f, 0, SEEK_END);
+        const long n = std::ftell(f);
+        std::fseek(f, 0, SEEK_SET);
+        b.bytes.resize(n);
+        if (std::fread(b.bytes.data(), 1, n, f) != (size_t)n) return 2;
+        std::fclose(f);
+    }
+    bool all_ok = true;
+
+    // ---- case 1: Linear_half_int4::forward (linear.cu:5-40) ----
+    {
+        const int M = b.get<int>(), N = b.get<int>(), K = b.get<int>(), G = b.get<int>(), zw = b.get<int>();
+        auto *w = managed_copy<int32_t>(b.take((size_t)N * (K / 8) * 4), (size_t)N * (K / 8));
+        auto *sc = managed_copy<float16_t>(b.take((size_t)N * zw * 8 * 2), (size_t)N * zw * 8);
+        auto *zp = managed_copy<int>(b.take((size_t)N * zw * 4), (size_t)N * zw);
+        auto *x = managed_copy<float16_t>(b.take((size_t)M * K * 2), (size_t)M * K);
+        const float *expect = reinterpret_cast<const float *>(b.take((size_t)M * N * 4));
+        auto *out = managed_copy<float16_t>(nullptr, (size_t)M * N);
+
+        struct matmul_params params;
+        poison(params);  // everything the wrapper does not set is garbage
+        params.A.row = M;
+        params.A.column = K;
+        params.A.half_data_ptr = x;
+        params.B.row = K / 8;  // "k"  (linear.cu:23; never read by the kernel)
+        params.B.column = N;   // "n"
+        params.B.int32_data_ptr = w;
+        params.C.row = M;
+        params.C.column = N;
+        params.C.half_data_ptr = out;
+        params.opt_params.num_thread = 8;
+        params.half_scales = sc;
+        params.int32_zero_point = zp;
+        params.block_size = G;
+
+        matmul::MatmulOperator op = matmul::MatmulOperator();
+        op.gemv_forward_cuda(&params);
+        tce_synchronize(nullptr);
+
+        double rms = 0;
+        for (int i = 0; i < M * N; ++i) rms += (double)expect[i] * expect[i];
+        rms = std::sqrt(rms / (M * N));
+        bool ok = true;
+        double worst = 0;
+        for (int i = 0; i < M * N; ++i) {
+            const double got = half_to_float(out[i].bits), ref = expect[i];
+            const double tol = 1e-3 * std::fmax(std::fabs(ref), rms / 64.0);
+            const double r = std::fabs(got - ref) / tol;
+            if (!(r <= 1.0)) ok = false;
+            if (r > worst) worst = r;
+        }
+        std::printf("FP16Linear_int4: M=%d N=%d K=%d G=%d worst |err|/tol = %.3f\n", M, N, K, G, worst);
+        all_ok &= report("FP16Linear_int4 (gemv_forward_cuda via matmul::MatmulOperator)", ok);
+        tce_free(w); tce_free(sc); tce_free(zp); tce_free(x); tce_free(out);
+    }
+
+    // ---- case 2: W8A8B8O8LinearReLU::forward (W8A8B8O8LinearReLU.cc:40-78), persistent params like the reference ----
+    {
+        const int M = b.get<int>(), N = b.get<int>(), K = b.get<int>();
+        const float alpha = b.get<float>(), beta = b.get<float>();
+        auto *A = managed_copy<int8_t>(b.take((size_t)M * K), (size_t)M * K);
+        auto *B = managed_copy<int8_t>(b.take((size_t)N * K), (size_t)N * K);
+        auto *bias = managed_copy<int8_t>(b.take(N), N);
+        const int8_t *expect = reinterpret_cast<const int8_t *>(b.take((size_t)M * N));
+        auto *out = managed_copy<int8_t>(nullptr, (size_t)M * N);
+
+        struct matmul_params params;
+        poison(params);
+        params.A.row = M;
+        params.A.column = K;
+        params.A.int8_data_ptr = A;
+        params.B.row = K;
+        params.B.column = N;
+        params.B.int8_data_ptr = B;
+        params.C.row = M;
+        params.C.column = N;
+        params.C.int8_data_ptr = out;
+        params.C.qparams.q_min = 0;  // ReLU by clamping (W8A8B8O8LinearReLU.cc:32)
+        params.C.qparams.q_max = 127;
+        params.bias.int8_data_ptr = bias;
+        params.alpha = alpha;
+        params.beta = beta;
+        matmul::MatmulOperator op = matmul::MatmulOperator();
+        op.mat_mul_accelerator_int8_fast_2x2_32unroll(&params);
+        tce_synchronize(nullptr);
+        long bad = 0;
+        for (long i = 0; i < (long)M * N; ++i) bad += out[i] != expect[i];
+        std::printf("W8A8B8O8LinearReLU: M=%d N=%d K=%d mismatches = %ld\n", M, N, K, bad);
+        all_ok &= report("W8A8B8O8LinearReLU (check_two_exact_equal)", bad == 0);
+        tce_free(A); tce_free(B); tce_free(bias); tce_free(out);
+    }
+
+    // ---- layout: this build's matmul_params must be the reference's (416 bytes, kernels/matmul.h:78-92) ----
+    all_ok &= report("matmul_params layout", tce_adapter_layout(0) == 416);
+    return all_ok ? 0 : 1;
+}

@@ -1,0 +1,193 @@
+// matmul_operator_hip.cc -- matmul::MatmulOperator members for a QM_HIP build of TinyChatEngine, on top of the C ABI
+// of libtce_hip.so (include/tce_matmul.h).  This is the only C++-mangled layer; it is plain host code (g++ or hipcc).
+//
+// Behavioural contract kept from the reference:
+//   * each member reads ONLY the matmul_params fields the corresponding reference member reads (the L2 wrappers leave
+//     the rest of the struct uninitialised -- llm/src/ops/cuda/linear.cu:19-33);
+//   * work is enqueued on the null stream and the call returns without synchronising
+//     (kernels/cuda/gemv_cuda.cu:237-251; the only sync is once per forward, Int4llamaForCausalLM.cu:40-44);
+//   * failures print a message and exit(1), which is what the reference does for an unsupported group size
+//     (gemv_cuda.cu:254-256); its asserts become the same exit path.
+#include "tce_matmul_operator.h"
+
+#include <cstddef>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "tce_matmul.h"
+
+namespace {
+
+[[noreturn]] void die(const char *who, int rc) {
+    std::printf("%s: %s (tce error %d)\n", who, tce_last_error(), rc);
+    std::exit(1);
+}
+
+// workspace for the AWQ-layout GEMM surface: the re-laid-out weights are cached per weight pointer (the operator
+// itself is stateless in the reference; ownership of model buffers stays with the caller -- SURVEY §8b)
+struct AwqCache {
+    const void *qweight = nullptr;
+    void *workspace = nullptr;
+    size_t bytes = 0;
+};
+AwqCache g_awq[64];
+
+void int8_call(const char *who, const struct matmul_params *p, int bias_kind, int out_kind, int b_per_row) {
+    const struct matrix *A = &p->A, *B = &p->B, *C = &p->C;
+    if (A->column != B->row || C->row != A->row || C->column != B->column) {  // kernels/ref/matmul_ref_int8.cc:19-21
+        std::printf("%s: assertion failed: A.column == B.row && C.row == A.row && C.column == B.column\n", who);
+        std::exit(1);
+    }
+    tce_w8a8_desc d;
+    std::memset(&d, 0, sizeof(d));
+    d.M = A->row;
+    d.N = B->column;
+    d.K = A->column;
+    d.batch = 1;
+    d.A = A->int8_data_ptr;
+    d.B = B->int8_data_ptr;
+    d.bias = bias_kind == TCE_BIAS_INT8 ? static_cast<const void *>(p->bias.int8_data_ptr)
+                                        : (bias_kind == TCE_BIAS_FP32 ? static_cast<const void *>(p->bias.data_ptr) : nullptr);
+    d.C = out_kind == TCE_OUT_INT8 ? static_cast<void *>(C->int8_data_ptr) : static_cast<void *>(C->data_ptr);
+    d.alpha = p->alpha;
+    d.beta = p->beta;
+    d.q_min = C->qparams.q_min;
+    d.q_max = C->qparams.q_max;
+    d.bias_kind = bias_kind;
+    d.out_kind = out_kind;
+    d.b_per_row = b_per_row;
+    const int rc = tce_w8a8_matmul(&d, nullptr);
+    if (rc != TCE_OK) die(who, rc);
+}
+
+}  // namespace
+
+namespace matmul {
+
+// kernels/cuda/gemv_cuda.cu:213-260.  IC = A.column, OC = C.column, M = C.row; B.row / B.column are not read.
+void MatmulOperator::gemv_forward_cuda(const struct matmul_params *params) {
+    tce_w4a16_desc d;
+    std::memset(&d, 0, sizeof(d));
+    d.M = params->C.row;
+    d.N = params->C.column;
+    d.K = params->A.column;
+    d.group_size = params->block_size;  // QK
+    d.A = params->A.half_data_ptr;
+    d.qweight = params->B.int32_data_ptr;
+    d.scales = params->half_scales;
+    d.zeros = params->int32_zero_point;
+    d.C = params->C.half_data_ptr;
+    const int rc = tce_w4a16_forward(&d, nullptr);
+    if (rc == TCE_ERR_UNSUPPORTED_GROUP) {
+        std::printf("Unsupported group size: %d\n", params->block_size);  // the reference's own message
+        std::exit(1);
+    }
+    if (rc != TCE_OK) die("gemv_forward_cuda", rc);
+}
+
+// kernels/cuda/matmul_int4.cu:8-48: AWQ layout, binary16 arithmetic, B.row = K.
+void MatmulOperator::naive_mat_mul_fp16_int4(const struct matmul_params *params) {
+    const int rc = tce_w4a16_awq_fp16acc(params->C.row, params->C.column, params->B.row, params->block_size,
+                                         params->A.fp16_data_ptr, params->B.int32_data_ptr, params->fp16_scales,
+                                         params->C.fp16_data_ptr, nullptr);
+    if (rc != TCE_OK) die("naive_mat_mul_fp16_int4", rc);
+}
+
+// Declared in kernels/matmul.h:142-145, never defined in the reference: AWQ (q4_5) layout GEMM.  split_k_iters is
+// accepted for signature compatibility; the HIP kernels accumulate the whole K in fp32 and need no split-K merge.
+void MatmulOperator::gemm_forward_cuda(const struct matmul_params *params, int /*split_k_iters*/) {
+    const int M = params->C.row, N = params->C.column, K = params->B.row, G = params->block_size;
+    const void *qw = params->B.int32_data_ptr;
+    AwqCache *slot = nullptr;
+    for (auto &c : g_awq)
+        if (c.qweight == qw) slot = &c;
+    int repack = 0;
+    if (!slot) {
+        for (auto &c : g_awq)
+            if (!c.qweight) {
+                slot = &c;
+                break;
+            }
+        if (!slot) slot = &g_awq[0];  // table full: recycle
+        const size_t need = tce_w4a16_awq_workspace_bytes(N, K, G);
+        if (need == 0) die("gemm_forward_cuda", TCE_ERR_UNSUPPORTED_GROUP);
+        if (slot->bytes < need) {
+            if (slot->workspace) tce_free(slot->workspace);
+            slot->workspace = nullptr;
+            const int arc = tce_malloc(&slot->workspace, need, /*managed=*/0);
+            if (arc != TCE_OK) die("gemm_forward_cuda (workspace)", arc);
+            slot->bytes = need;
+        }
+        slot->qweight = qw;
+        repack = 1;
+    }
+    const int rc = tce_w4a16_gemm_awq(M, N, K, G, params->A.half_data_ptr, qw, params->half_scales, params->C.half_data_ptr,
+                                      slot->workspace, repack, nullptr);
+    if (rc != TCE_OK) die("gemm_forward_cuda", rc);
+}
+void MatmulOperator::gemm_forward_cuda_8splits(const struct matmul_params *params, float16_t * /*split_8_buffer*/) {
+    gemm_forward_cuda(params, 8);
+}
+void MatmulOperator::gemm_forward_cuda_half(const struct matmul_params *params, int split_k_iters) {
+    gemm_forward_cuda(params, split_k_iters);
+}
+void MatmulOperator::gemm_forward_cuda_half_test(const struct matmul_params *params, int split_k_iters) {
+    gemm_forward_cuda(params, split_k_iters);
+}
+
+// kernels/ref/matmul_ref_int8.cc:161-192
+void MatmulOperator::mat_mul_accelerator_int8_fast_2x2_32unroll(const struct matmul_params *p) {
+    int8_call("mat_mul_accelerator_int8_fast_2x2_32unroll", p, TCE_BIAS_INT8, TCE_OUT_INT8, 0);
+}
+void MatmulOperator::mat_mul_accelerator_int8_fast_32unroll_over_column(const struct matmul_params *p) {
+    int8_call("mat_mul_accelerator_int8_fast_32unroll_over_column", p, TCE_BIAS_INT8, TCE_OUT_INT8, 0);
+}
+void MatmulOperator::mat_mul_accelerator_int8_fast_2x2_32unroll_nobias(const struct matmul_params *p) {
+    int8_call("mat_mul_accelerator_int8_fast_2x2_32unroll_nobias", p, TCE_BIAS_NONE, TCE_OUT_INT8, 0);
+}
+void MatmulOperator::mat_mul_accelerator_int8_fast_2x2_32unroll_nobias_batch(const struct matmul_params *p) {
+    int8_call("mat_mul_accelerator_int8_fast_2x2_32unroll_nobias_batch", p, TCE_BIAS_NONE, TCE_OUT_INT8, 1);
+}
+void MatmulOperator::mat_mul_accelerator_int8_fast_2x2_32unroll_bfp32_ofp32(const struct matmul_params *p) {
+    int8_call("mat_mul_accelerator_int8_fast_2x2_32unroll_bfp32_ofp32", p, TCE_BIAS_FP32, TCE_OUT_FP32, 0);
+}
+void MatmulOperator::mat_mul_accelerator_int8_fast_2x2_32unroll_bfp32_ofp32_over_column(const struct matmul_params *p) {
+    int8_call("mat_mul_accelerator_int8_fast_2x2_32unroll_bfp32_ofp32_over_column", p, TCE_BIAS_FP32, TCE_OUT_FP32, 0);
+}
+void MatmulOperator::mat_mul_accelerator_int8_fast_2x2_32unroll_nobias_ofp32(const struct matmul_params *p) {
+    int8_call("mat_mul_accelerator_int8_fast_2x2_32unroll_nobias_ofp32", p, TCE_BIAS_NONE, TCE_OUT_FP32, 0);
+}
+void MatmulOperator::mat_mul_accelerator_int8_fast_2x2_32unroll_nobias_ofp32_batch(const struct matmul_params *p) {
+    int8_call("mat_mul_accelerator_int8_fast_2x2_32unroll_nobias_ofp32_batch", p, TCE_BIAS_NONE, TCE_OUT_FP32, 1);
+}
+
+// kernels/cuda/gemv_cuda.cu:262-268: empty in the GPU build
+void MatmulOperator::mat_mul_accelerator_int4_fast(const struct matmul_params *) {}
+void MatmulOperator::mat_mul_accelerator_int4_fast_no_offset(const struct matmul_params *) {}
+
+}  // namespace matmul
+
+extern "C" long tce_adapter_layout(int idx) {
+    switch (idx) {
+        case 0: return (long)sizeof(matmul_params);
+        case 1: return (long)sizeof(matrix);
+        case 2: return (long)offsetof(matmul_params, B);
+        case 3: return (long)offsetof(matmul_params, C);
+        case 4: return (long)offsetof(matmul_params, bias);
+        case 5: return (long)offsetof(matmul_params, opt_params);
+        case 6: return (long)offsetof(matmul_params, alpha);
+        case 7: return (long)offsetof(matmul_params, beta);
+        case 8: return (long)offsetof(matmul_params, half_scales);
+        case 9: return (long)offsetof(matmul_params, fp16_scales);
+        case 10: return (long)offsetof(matmul_params, int32_zero_point);
+        case 11: return (long)offsetof(matmul_params, block_size);
+        case 12: return (long)offsetof(matrix, half_data_ptr);
+        case 13: return (long)offsetof(matrix, int32_data_ptr);
+        case 14: return (long)offsetof(matrix, int8_data_ptr);
+        case 15: return (long)offsetof(matrix, qparams);
+        case 16: return (long)(offsetof(matrix, qparams) + offsetof(quantization_params, q_min));
+        case 17: return (long)offsetof(matmul_params, A_scales);
+        default: return -1;
+    }
+}

@@ -63,5 +63,30 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def build_adapter(force: bool = False, verbose: bool = False) -> str:
+    """libtce_matmul_operator.so (the C++ matmul::MatmulOperator members, plain host code) + adapter_selftest."""
+    build(force=False, verbose=verbose)
+    adir = os.path.join(PKG_DIR, "adapter")
+    src = os.path.join(adir, "matmul_operator_hip.cc")
+    hdrs = [os.path.join(adir, "tce_matmul_operator.h"), os.path.join(REPO_DIR, "include", "tce_matmul.h")]
+    inc = ["-I", os.path.join(REPO_DIR, "include"), "-I", adir]
+    rpath = "-Wl,-rpath,$ORIGIN"
+    if force or _stale(ADAPTER_LIB_PATH, [src, LIB_PATH] + hdrs):
+        cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", *inc, src, "-o", ADAPTER_LIB_PATH,
+               "-L", LIB_DIR, "-ltce_hip", rpath]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    test_src = os.path.join(adir, "adapter_selftest.cc")
+    if force or _stale(ADAPTER_TEST_PATH, [test_src, ADAPTER_LIB_PATH] + hdrs):
+        cmd = ["g++", "-std=c++17", "-O2", "-Wall", *inc, test_src, "-o", ADAPTER_TEST_PATH, "-L", LIB_DIR,
+               "-ltce_matmul_operator", "-ltce_hip", rpath]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return ADAPTER_LIB_PATH
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_adapter(force="--force" in sys.argv, verbose=True))

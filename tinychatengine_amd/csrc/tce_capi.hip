@@ -78,6 +78,41 @@ int tce_w4a16_set_gemv_config(int rows, int wn, int wk, int depth) {
     return TCE_OK;
 }
 
+int tce_w4a16_set_debug_mode(int mode) {
+    if (mode < 0 || mode > 3) return fail(TCE_ERR_BAD_ARG, "debug mode %d", mode);
+    tce::set_gemv_debug_mode(mode);
+    return TCE_OK;
+}
+
+int tce_malloc(void **ptr, size_t bytes, int managed) {
+    if (!ptr || bytes == 0) return fail(TCE_ERR_BAD_ARG, "tce_malloc: bad argument");
+    const hipError_t e = managed ? hipMallocManaged(ptr, bytes, hipMemAttachGlobal) : hipMalloc(ptr, bytes);
+    return e == hipSuccess ? TCE_OK : hip_fail(e, managed ? "hipMallocManaged" : "hipMalloc");
+}
+
+int tce_free(void *ptr) {
+    if (!ptr) return TCE_OK;
+    const hipError_t e = hipFree(ptr);
+    return e == hipSuccess ? TCE_OK : hip_fail(e, "hipFree");
+}
+
+int tce_memcpy(void *dst, const void *src, size_t bytes, int kind, void *stream) {
+    if (!dst || !src) return fail(TCE_ERR_BAD_ARG, "tce_memcpy: null pointer");
+    const hipMemcpyKind k = kind == TCE_MEMCPY_H2D ? hipMemcpyHostToDevice : (kind == TCE_MEMCPY_D2H ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice);
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, k, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? TCE_OK : hip_fail(e, "hipMemcpyAsync");
+}
+
+int tce_synchronize(void *stream) {
+    const hipError_t e = stream ? hipStreamSynchronize(static_cast<hipStream_t>(stream)) : hipDeviceSynchronize();
+    return e == hipSuccess ? TCE_OK : hip_fail(e, "synchronize");
+}
+
+int tce_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 int tce_w4a16_gemv_variant(int idx, int *rows, int *wn, int *wk, int *depth) {
     static const int table[][4] = {
 #define TCE_V(R, N_, K_, D_) {R, N_, K_, D_},
@@ -139,13 +174,13 @@ int tce_w4a16_forward(const tce_w4a16_desc *d, void *stream) {
     if (rc0 != TCE_OK) return rc0;
     const bool want_gemm = (d->flags & TCE_W4_FORCE_GEMM) || (d->M > TCE_W4A16_GEMV_MAX_M && !(d->flags & TCE_W4_FORCE_GEMV));
     hipError_t he = hipSuccess;
-    if (want_gemm && d->K % 128 == 0) {
+    if (want_gemm && d->K % 128 == 0 && d->group_size == 128) {  // other group sizes: GEMV kernel, 4 rows per pass
         const int rc = tce::launch_w4a16_gemm(*d, g_gemm_mt, g_gemm_nt, static_cast<hipStream_t>(stream), &he);
         if (rc == TCE_ERR_HIP) return hip_fail(he, "w4a16 gemm launch");
         if (rc != TCE_OK) return fail(rc, "w4a16 gemm: no kernel variant for this shape/config");
         return TCE_OK;
     }
-    // GEMV path (also the fallback for K % 128 != 0): gridDim.y walks the M rows 4 at a time
+    // GEMV path (also the fallback for K % 128 != 0 or G != 128): gridDim.y walks the M rows 4 at a time
     return tce_w4a16_forward_group(d, 1, stream);
 }
 

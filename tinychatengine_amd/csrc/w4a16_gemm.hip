@@ -3,7 +3,7 @@
 // The reference has no GEMM kernel on this layout: gemv_forward_cuda re-runs its GEMV once per input row
 // (grid.z = M, kernels/cuda/gemv_cuda.cu:229-231) and gemm_forward_cuda* are declared but never defined
 // (kernels/matmul.h:140-145).  The math is the same dequant + dot product as the GEMV:
-//     C[m][n] = fp16( sum_k A[m][k] * fp16( s[n][k/G] * (q[n][k] - z[n][k/G]) ) ),   fp32 accumulate on MFMA.
+//     C[m][n] = fp16( sum_g fp32(s[n][g]) * sum_{k in g} A[m][k] * (q[n][k] - z[n][g]) ),   fp32 accumulate on MFMA.
 //
 // CDNA4 design:
 //   * v_mfma_f32_16x16x32_f16; the A operand is the activation tile, the B operand the dequantized weights, so a
@@ -110,16 +110,22 @@ __global__ __launch_bounds__(256) void w4a16_gemm_kernel(const GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
 
+    // One k-block (128 k) is exactly one quantization group (the kernel is only dispatched for G == 128), so the
+    // MFMAs of a block contract EXACT integers (q - z) with the fp16 activations in fp32, and the fp16 group scale is
+    // applied once per block in fp32: acc += s * acc_block -- the same precision class as the GEMV kernel and the
+    // oracle (rounding the scaled weight to fp16 first costs ~2^-12 relative per weight, which breaks 1e-3 on outputs
+    // that are small by cancellation).
     auto compute = [&](const BRegs &b, int kb) {
         const int grp = ((kb * 4 + q) << 5) >> g.log2g;
         const int zsh = (grp & 7) * 4;
         ZeroPair zp[NT];
-        half2_t sc[NT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            zp[j] = make_zero_pair((b.z[j] >> zsh) & 0xFu);
-            sc[j] = half2_t{b.s[j], b.s[j]};
-        }
+        for (int j = 0; j < NT; ++j) zp[j] = make_zero_pair((b.z[j] >> zsh) & 0xFu);
+        float4_t blk[MT][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) blk[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             half8_t bf[NT];
@@ -127,8 +133,7 @@ __global__ __launch_bounds__(256) void w4a16_gemm_kernel(const GemmArgs g) {
             for (int j = 0; j < NT; ++j) {
                 half2_t d[4];
                 dequant_word(b.w[j][s], zp[j], d);
-                const half2_t e0 = d[0] * sc[j], e1 = d[1] * sc[j], e2 = d[2] * sc[j], e3 = d[3] * sc[j];
-                bf[j] = half8_t{e0.x, e0.y, e1.x, e1.y, e2.x, e2.y, e3.x, e3.y};
+                bf[j] = half8_t{d[0].x, d[0].y, d[1].x, d[1].y, d[2].x, d[2].y, d[3].x, d[3].y};
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
@@ -136,8 +141,16 @@ __global__ __launch_bounds__(256) void w4a16_gemm_kernel(const GemmArgs g) {
                 const half8_t af = __builtin_bit_cast(half8_t, araw);
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0);
+                    blk[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], blk[i][j], 0, 0, 0);
             }
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const float sc = (float)b.s[j];  // lane's output channel n = lane & 15 is the same for its 4 registers
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = __builtin_fmaf(sc, blk[i][j][r], acc[i][j][r]);
         }
     };
 
@@ -202,7 +215,7 @@ bool gemm_variant_exists(int mt, int nt) {
 }
 
 int launch_w4a16_gemm(const tce_w4a16_desc &d, int forced_mt, int forced_nt, hipStream_t stream, hipError_t *hip_err) {
-    if (d.K % 128 != 0) return TCE_ERR_UNSUPPORTED_SHAPE;  // caller falls back to the GEMV kernel
+    if (d.K % 128 != 0 || d.group_size != 128) return TCE_ERR_UNSUPPORTED_SHAPE;  // caller falls back to the GEMV kernel
     GemmArgs g{};
     const int zw = zeros_width(d.K, d.group_size);
     g.A = static_cast<const half_t *>(d.A);
@@ -220,10 +233,15 @@ int launch_w4a16_gemm(const tce_w4a16_desc &d, int forced_mt, int forced_nt, hip
     g.log2g = d.group_size == 128 ? 7 : (d.group_size == 64 ? 6 : 5);
     int mt = forced_mt, nt = forced_nt;
     if (mt == 0) {
-        // tile choice: keep >= ~256 workgroups when the problem allows it (one per CU)
+        // tile choice (measured on MI355X, profiles/): small M -> small row tiles; otherwise 128x64 tiles when that
+        // still yields >= 2 workgroups per CU, else 64x64
         if (d.M <= 32) { mt = 2; nt = 2; }
         else if (d.M <= 64) { mt = 4; nt = 1; }
-        else { mt = 4; nt = 2; }
+        else {
+            const long blocks_81 = (long)((d.M + 127) / 128) * ((d.N + 63) / 64);
+            if (blocks_81 >= 512) { mt = 8; nt = 1; }
+            else { mt = 4; nt = 1; }
+        }
     }
     hipError_t e = hipSuccess;
     bool found = false;

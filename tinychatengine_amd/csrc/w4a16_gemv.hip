@@ -24,7 +24,9 @@ namespace tce {
 
 namespace {
 
-template <int MB, int ROWS, int WN, int WK, int DEPTH>
+// MODE is a diagnostics switch for roofline experiments (scripts/tune.py); only MODE 0 computes the GEMV.
+//   1: stream only (weights loaded, no dequant / dot)   2: no scale / zero-point loads   3: plain instead of non-temporal loads
+template <int MB, int ROWS, int WN, int WK, int DEPTH, int MODE = 0>
 __global__ __launch_bounds__(64 * WN * WK) void w4a16_gemv_kernel(const GemvArgs args) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NTHREADS = 64 * WN * WK;
@@ -95,9 +97,16 @@ __global__ __launch_bounds__(64 * WN * WK) void w4a16_gemv_kernel(const GemvArgs
         st.g = g;
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) {
-            st.w[i] = load_nt(seg.qweight + (size_t)rows[i] * nchunks + cc);
-            st.s[i] = seg.scales[(size_t)rows[i] * seg.scales_stride + g];
-            st.z[i] = seg.zeros[(size_t)rows[i] * seg.zeros_stride + (g >> 3)];
+            const uint4_t *wp = seg.qweight + (size_t)rows[i] * nchunks + cc;
+            if constexpr (MODE == 3) st.w[i] = *wp;
+            else st.w[i] = load_nt(wp);
+            if constexpr (MODE == 1 || MODE == 2) {
+                st.s[i] = (half_t)0.01f;
+                st.z[i] = 0x88888888u;
+            } else {
+                st.s[i] = seg.scales[(size_t)rows[i] * seg.scales_stride + g];
+                st.z[i] = seg.zeros[(size_t)rows[i] * seg.zeros_stride + (g >> 3)];
+            }
         }
     };
     // Prologue: DEPTH steps issued unconditionally (the host only picks variants with DEPTH <= T), so every wait
@@ -137,6 +146,11 @@ __global__ __launch_bounds__(64 * WN * WK) void w4a16_gemv_kernel(const GemvArgs
         for (int m = 0; m < MB; ++m) acc[i][m] = 0.f;
 
     auto compute = [&](const Step &st, int t) {
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < ROWS; ++i) acc[i][0] += (float)((st.w[i].x ^ st.w[i].y ^ st.w[i].z ^ st.w[i].w) & 0xFFu);
+            return;
+        }
         uint4_t x[MB][4];
 #pragma unroll
         for (int m = 0; m < MB; ++m)
@@ -239,7 +253,9 @@ struct Variant {
     int rows, wn, wk, depth;
 };
 
-template <int MB, int ROWS, int WN, int WK, int DEPTH>
+int g_debug_mode = 0;
+
+template <int MB, int ROWS, int WN, int WK, int DEPTH, int MODE = 0>
 hipError_t launch_variant(const GemvArgs &a, int total_blocks, int m_blocks, hipStream_t stream) {
     const int nchunks = a.K >> 5;
     const int LS = 64 * WK;
@@ -247,7 +263,7 @@ hipError_t launch_variant(const GemvArgs &a, int total_blocks, int m_blocks, hip
     size_t lds = (size_t)MB * T * LS * 64 + (size_t)64 * WN * WK * 16;  // x image + trash slots
     const size_t red = (size_t)WN * WK * ROWS * MB * sizeof(float);
     if (lds < red) lds = red;
-    auto kfn = w4a16_gemv_kernel<MB, ROWS, WN, WK, DEPTH>;
+    auto kfn = w4a16_gemv_kernel<MB, ROWS, WN, WK, DEPTH, MODE>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -259,6 +275,22 @@ hipError_t launch_variant(const GemvArgs &a, int total_blocks, int m_blocks, hip
 template <int MB>
 hipError_t launch_mb(const Variant &v, const GemvArgs &a, int total_blocks, int m_blocks, hipStream_t s, bool &found) {
     found = true;
+    if constexpr (MB == 1) {
+        if (g_debug_mode != 0) {  // diagnostics builds exist for three geometries only
+#define TCE_DBG(R, N_, K_, D_)                                                                                   \
+    if (v.rows == R && v.wn == N_ && v.wk == K_ && v.depth == D_) {                                              \
+        if (g_debug_mode == 1) return launch_variant<1, R, N_, K_, D_, 1>(a, total_blocks, m_blocks, s);          \
+        if (g_debug_mode == 2) return launch_variant<1, R, N_, K_, D_, 2>(a, total_blocks, m_blocks, s);          \
+        if (g_debug_mode == 3) return launch_variant<1, R, N_, K_, D_, 3>(a, total_blocks, m_blocks, s);          \
+    }
+            TCE_DBG(4, 4, 1, 1)
+            TCE_DBG(4, 4, 1, 2)
+            TCE_DBG(2, 4, 1, 2)
+#undef TCE_DBG
+            found = false;
+            return hipSuccess;
+        }
+    }
 #define TCE_V(R, N_, K_, D_) \
     if (v.rows == R && v.wn == N_ && v.wk == K_ && v.depth == D_) \
         return launch_variant<MB, R, N_, K_, D_>(a, total_blocks, m_blocks, s);
@@ -269,6 +301,8 @@ hipError_t launch_mb(const Variant &v, const GemvArgs &a, int total_blocks, int 
 }
 
 }  // namespace
+
+void set_gemv_debug_mode(int mode) { g_debug_mode = mode; }
 
 bool gemv_variant_exists(int rows, int wn, int wk, int depth) {
 #define TCE_V(R, N_, K_, D_) \

@@ -44,6 +44,7 @@ struct GemvArgs {
     X(1, 2, 4, 1)
 
 bool gemv_variant_exists(int rows, int wn, int wk, int depth);
+void set_gemv_debug_mode(int mode);
 int launch_w4a16_gemv(const tce_w4a16_desc *descs, int count, int forced_rows, int forced_wn, int forced_wk,
                       int forced_depth, hipStream_t stream, hipError_t *hip_err);
 
