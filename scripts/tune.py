@@ -97,8 +97,8 @@ def experiments():
     L = capi.lib()
     shapes = [("gate+up grouped 2x11008x4096", [11008, 11008], 4096), ("lm_head 128256x4096", [128256], 4096),
               ("o_proj 4096x4096", [4096], 4096), ("down 4096x11008", [4096], 11008)]
-    names = {0: "normal", 1: "stream-only", 2: "no scale/zero loads", 3: "plain (not nt) loads"}
-    for mode in (0, 1, 2, 3):
+    names = {0: "normal", 1: "stream-only", 2: "no scale/zero loads", 3: "plain (not nt) loads", 4: "dot2c on VALU"}
+    for mode in (0, 4, 1, 2, 3):
         capi.check(L.tce_w4a16_set_debug_mode(mode))
         try:
             for (name, segs, K) in shapes:

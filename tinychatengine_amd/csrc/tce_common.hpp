@@ -9,6 +9,7 @@ namespace tce {
 
 typedef _Float16 half_t;
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef float float4_t __attribute__((ext_vector_type(4)));
 typedef int int4_t __attribute__((ext_vector_type(4)));
@@ -54,13 +55,26 @@ __device__ __forceinline__ ZeroPair make_zero_pair(unsigned z /*0..15*/) {
     return zp;
 }
 
-__device__ __forceinline__ void dequant_word(unsigned w, const ZeroPair &zp, half2_t (&d)[4]) {
+// The two nibble masks live in VGPRs: gfx9 VOP3 instructions may read only ONE scalar/literal operand, so with both
+// the mask and the magic constant as literals hipcc splits every (w & mask) | magic into v_and + v_or; with the mask
+// in a VGPR it is a single v_and_or_b32 (mask VGPR, magic SGPR).  The empty asm makes the values opaque to the
+// constant folder.
+struct NibbleMasks {
+    unsigned lo, hi;
+};
+__device__ __forceinline__ NibbleMasks make_nibble_masks() {
+    NibbleMasks m;
+    asm volatile("v_mov_b32 %0, 0x000F000F\n\tv_mov_b32 %1, 0x00F000F0" : "=v"(m.lo), "=v"(m.hi));
+    return m;
+}
+
+__device__ __forceinline__ void dequant_word(unsigned w, const ZeroPair &zp, const NibbleMasks &nm, half2_t (&d)[4]) {
     const half2_t sixteenth = as_half2(0x2C002C00u);  // 0.0625h
     const unsigned w8 = w >> 8;
-    const half2_t t0 = as_half2((w & 0x000F000Fu) | 0x64006400u);
-    const half2_t t1 = as_half2((w & 0x00F000F0u) | 0x64006400u);
-    const half2_t t2 = as_half2((w8 & 0x000F000Fu) | 0x64006400u);
-    const half2_t t3 = as_half2((w8 & 0x00F000F0u) | 0x64006400u);
+    const half2_t t0 = as_half2((w & nm.lo) | 0x64006400u);
+    const half2_t t1 = as_half2((w & nm.hi) | 0x64006400u);
+    const half2_t t2 = as_half2((w8 & nm.lo) | 0x64006400u);
+    const half2_t t3 = as_half2((w8 & nm.hi) | 0x64006400u);
     d[0] = t0 + zp.lo;
     d[1] = __builtin_elementwise_fma(t1, sixteenth, zp.hi);
     d[2] = t2 + zp.lo;

@@ -104,6 +104,7 @@ __global__ __launch_bounds__(256) void w4a16_gemm_kernel(const GemmArgs g) {
         }
     };
 
+    const NibbleMasks nmask = make_nibble_masks();
     float4_t acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void w4a16_gemm_kernel(const GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 half2_t d[4];
-                dequant_word(b.w[j][s], zp[j], d);
+                dequant_word(b.w[j][s], zp[j], nmask, d);
                 bf[j] = half8_t{d[0].x, d[0].y, d[1].x, d[1].y, d[2].x, d[2].y, d[3].x, d[3].y};
             }
 #pragma unroll

@@ -26,6 +26,7 @@ namespace {
 
 // MODE is a diagnostics switch for roofline experiments (scripts/tune.py); only MODE 0 computes the GEMV.
 //   1: stream only (weights loaded, no dequant / dot)   2: no scale / zero-point loads   3: plain instead of non-temporal loads
+//   4: dot products on the VALU (v_dot2c_f32_f16) instead of the matrix pipe -- a correct GEMV, kept for A/B measurements
 template <int MB, int ROWS, int WN, int WK, int DEPTH, int MODE = 0>
 __global__ __launch_bounds__(64 * WN * WK) void w4a16_gemv_kernel(const GemvArgs args) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -139,16 +140,27 @@ __global__ __launch_bounds__(64 * WN * WK) void w4a16_gemv_kernel(const GemvArgs
     }
     __syncthreads();
 
-    float acc[ROWS][MB];
+    // Dot products.  MODE 4 uses v_dot2c_f32_f16 on the VALU.  The default puts them on the otherwise idle matrix
+    // pipe: v_mfma_f32_4x4x4_16b_f16 computes, for each group of 4 lanes, D[i][j] = sum_k A_i[k] * B_j[k] over the 4
+    // halves each lane supplies; with A = a lane's dequantized weights and B = the same lane's activations, the
+    // DIAGONAL element D[l%4][l%4] is exactly that lane's own 4-term dot product, accumulated in fp32 across calls
+    // (the 12 off-diagonal cross terms per group are discarded).  That removes 4 of the 13 VALU instructions per 8
+    // weights -- measured: the kernel was VALU-issue-bound, not HBM-bound (profiles/).
+    constexpr bool kMfma = (MODE != 4);
+    constexpr int ACCW = kMfma ? 4 : 1;
+    float acc[ROWS][MB][ACCW];
 #pragma unroll
     for (int i = 0; i < ROWS; ++i)
 #pragma unroll
-        for (int m = 0; m < MB; ++m) acc[i][m] = 0.f;
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int r = 0; r < ACCW; ++r) acc[i][m][r] = 0.f;
+    const NibbleMasks nmask = make_nibble_masks();
 
     auto compute = [&](const Step &st, int t) {
         if constexpr (MODE == 1) {
 #pragma unroll
-            for (int i = 0; i < ROWS; ++i) acc[i][0] += (float)((st.w[i].x ^ st.w[i].y ^ st.w[i].z ^ st.w[i].w) & 0xFFu);
+            for (int i = 0; i < ROWS; ++i) acc[i][0][0] += (float)((st.w[i].x ^ st.w[i].y ^ st.w[i].z ^ st.w[i].w) & 0xFFu);
             return;
         }
         uint4_t x[MB][4];
@@ -160,24 +172,50 @@ __global__ __launch_bounds__(64 * WN * WK) void w4a16_gemv_kernel(const GemvArgs
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) {
             const ZeroPair zp = make_zero_pair((st.z[i] >> zsh) & 0xFu);
-            float p[MB];
-#pragma unroll
-            for (int m = 0; m < MB; ++m) p[m] = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                half2_t d[4];
-                dequant_word(st.w[i][j], zp, d);
-#pragma unroll
-                for (int m = 0; m < MB; ++m) {
-                    p[m] = __builtin_amdgcn_fdot2(d[0], as_half2(x[m][j].x), p[m], false);
-                    p[m] = __builtin_amdgcn_fdot2(d[1], as_half2(x[m][j].y), p[m], false);
-                    p[m] = __builtin_amdgcn_fdot2(d[2], as_half2(x[m][j].z), p[m], false);
-                    p[m] = __builtin_amdgcn_fdot2(d[3], as_half2(x[m][j].w), p[m], false);
-                }
-            }
             const float s = (float)st.s[i];
+            if constexpr (kMfma) {
+                float4_t blk[MB];
 #pragma unroll
-            for (int m = 0; m < MB; ++m) acc[i][m] = __builtin_fmaf(s, p[m], acc[i][m]);
+                for (int m = 0; m < MB; ++m) blk[m] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    half2_t d[4];
+                    dequant_word(st.w[i][j], zp, nmask, d);
+                    const half4_t a0 = __builtin_bit_cast(half4_t, uint2_t{as_u32(d[0]), as_u32(d[1])});
+                    const half4_t a1 = __builtin_bit_cast(half4_t, uint2_t{as_u32(d[2]), as_u32(d[3])});
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) {
+                        const half4_t b0 = __builtin_bit_cast(half4_t, uint2_t{x[m][j].x, x[m][j].y});
+                        const half4_t b1 = __builtin_bit_cast(half4_t, uint2_t{x[m][j].z, x[m][j].w});
+                        blk[m] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, b0, blk[m], 0, 0, 0);
+                        blk[m] = __builtin_amdgcn_mfma_f32_4x4x4f16(a1, b1, blk[m], 0, 0, 0);
+                    }
+                }
+                // lanes 4b..4b+3 share a quantization group (32 weights per lane, groups of >= 32), so scaling all four
+                // accumulator registers by this lane's scale is consistent; the diagonal is picked once, at the end
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][m][r] = __builtin_fmaf(s, blk[m][r], acc[i][m][r]);
+            } else {
+                float p[MB];
+#pragma unroll
+                for (int m = 0; m < MB; ++m) p[m] = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    half2_t d[4];
+                    dequant_word(st.w[i][j], zp, nmask, d);
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) {
+                        p[m] = __builtin_amdgcn_fdot2(d[0], as_half2(x[m][j].x), p[m], false);
+                        p[m] = __builtin_amdgcn_fdot2(d[1], as_half2(x[m][j].y), p[m], false);
+                        p[m] = __builtin_amdgcn_fdot2(d[2], as_half2(x[m][j].z), p[m], false);
+                        p[m] = __builtin_amdgcn_fdot2(d[3], as_half2(x[m][j].w), p[m], false);
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < MB; ++m) acc[i][m][0] = __builtin_fmaf(s, p[m], acc[i][m][0]);
+            }
         }
     };
 
@@ -210,20 +248,35 @@ __global__ __launch_bounds__(64 * WN * WK) void w4a16_gemv_kernel(const GemvArgs
     if constexpr (DEPTH > 2) { if (r == 2) tail(std::integral_constant<int, 2>{}); }
     static_assert(DEPTH <= 3, "add tail cases");
 
-    // ---- K reduction: 64-lane shuffle tree, then across the WK waves through LDS ----
+    // ---- K reduction: pick the lane's diagonal accumulator, 64-lane shuffle tree, then across the WK waves via LDS ----
+    float diag[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) diag[r] = (lane & 3) == r ? 1.0f : 0.0f;  // off-diagonal terms are finite, so x0 is exact
+    float red[ROWS][MB];
 #pragma unroll
     for (int i = 0; i < ROWS; ++i)
 #pragma unroll
-        for (int m = 0; m < MB; ++m) acc[i][m] = wave_sum(acc[i][m]);
+        for (int m = 0; m < MB; ++m) {
+            float v = acc[i][m][0];
+            if constexpr (kMfma) {
+                // diagonal pick as a multiply-add with a one-hot lane mask: a select chain on (lane & 3) is turned by
+                // hipcc into a dynamically indexed private array, i.e. scratch memory traffic
+                v = acc[i][m][0] * diag[0];
+                v = __builtin_fmaf(acc[i][m][1], diag[1], v);
+                v = __builtin_fmaf(acc[i][m][2], diag[2], v);
+                v = __builtin_fmaf(acc[i][m][3], diag[3], v);
+            }
+            red[i][m] = wave_sum(v);
+        }
 
     if constexpr (WK > 1) {
         __syncthreads();  // everyone is done reading the x image; reuse the front of LDS
-        float *red = reinterpret_cast<float *>(smem);  // [WN][WK][ROWS*MB]
+        float *redbuf = reinterpret_cast<float *>(smem);  // [WN][WK][ROWS*MB]
         if (lane == 0) {
 #pragma unroll
             for (int i = 0; i < ROWS; ++i)
 #pragma unroll
-                for (int m = 0; m < MB; ++m) red[((wn * WK + wk) * ROWS + i) * MB + m] = acc[i][m];
+                for (int m = 0; m < MB; ++m) redbuf[((wn * WK + wk) * ROWS + i) * MB + m] = red[i][m];
         }
         __syncthreads();
         if (wk != 0) return;
@@ -233,8 +286,8 @@ __global__ __launch_bounds__(64 * WN * WK) void w4a16_gemv_kernel(const GemvArgs
             for (int m = 0; m < MB; ++m) {
                 float v = 0.f;
 #pragma unroll
-                for (int k2 = 0; k2 < WK; ++k2) v += red[((wn * WK + k2) * ROWS + i) * MB + m];
-                acc[i][m] = v;
+                for (int k2 = 0; k2 < WK; ++k2) v += redbuf[((wn * WK + k2) * ROWS + i) * MB + m];
+                red[i][m] = v;
             }
     }
 
@@ -244,7 +297,7 @@ __global__ __launch_bounds__(64 * WN * WK) void w4a16_gemv_kernel(const GemvArgs
             if (m0 + m >= args.M) continue;
 #pragma unroll
             for (int i = 0; i < ROWS; ++i)
-                if (row_base + i < seg.N) seg.C[(size_t)(m0 + m) * seg.ldc + row_base + i] = (half_t)acc[i][m];
+                if (row_base + i < seg.N) seg.C[(size_t)(m0 + m) * seg.ldc + row_base + i] = (half_t)red[i][m];
         }
     }
 }
@@ -282,6 +335,7 @@ hipError_t launch_mb(const Variant &v, const GemvArgs &a, int total_blocks, int 
         if (g_debug_mode == 1) return launch_variant<1, R, N_, K_, D_, 1>(a, total_blocks, m_blocks, s);          \
         if (g_debug_mode == 2) return launch_variant<1, R, N_, K_, D_, 2>(a, total_blocks, m_blocks, s);          \
         if (g_debug_mode == 3) return launch_variant<1, R, N_, K_, D_, 3>(a, total_blocks, m_blocks, s);          \
+        if (g_debug_mode == 4) return launch_variant<1, R, N_, K_, D_, 4>(a, total_blocks, m_blocks, s);          \
     }
             TCE_DBG(4, 4, 1, 1)
             TCE_DBG(4, 4, 1, 2)
