@@ -169,9 +169,8 @@ TCE_API const char *tce_build_info(void);
  * rows_per_wave in {1,2,4}; waves_n x waves_k waves per workgroup (waves_k of them split K); depth = weight steps kept
  * in flight per wave (the library lowers it when K is too short).  TCE_ERR_BAD_ARG if that variant was not compiled. */
 TCE_API int tce_w4a16_set_gemv_config(int rows_per_wave, int waves_n, int waves_k, int depth);
-/* Roofline diagnostics for the GEMV kernel (scripts/tune.py): 0 = normal; 1 = stream the weights only (no dequant/dot);
- * 2 = skip the scale/zero-point loads; 3 = plain instead of non-temporal weight loads.  Outputs are meaningless for
- * mode != 0; available for M = 1 and three geometries only (TCE_ERR_BAD_ARG from the launch otherwise). */
+/* Roofline diagnostics for the GEMV kernel (scripts/tune.py): 0 = normal; 1 = stream the weights only (no unpack, no
+ * dot products) to measure the memory-side ceiling of the access pattern.  Outputs are meaningless for mode 1; M = 1 only. */
 TCE_API int tce_w4a16_set_debug_mode(int mode);
 /* Force an MFMA GEMM tile (m_tiles x n_tiles of 16x16 per wave); 0,0 = automatic. */
 TCE_API int tce_w4a16_set_gemm_config(int m_tiles, int n_tiles);

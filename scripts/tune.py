@@ -97,8 +97,8 @@ def experiments():
     L = capi.lib()
     shapes = [("gate+up grouped 2x11008x4096", [11008, 11008], 4096), ("lm_head 128256x4096", [128256], 4096),
               ("o_proj 4096x4096", [4096], 4096), ("down 4096x11008", [4096], 11008)]
-    names = {0: "normal", 1: "stream-only", 2: "no scale/zero loads", 3: "plain (not nt) loads", 4: "dot2c on VALU"}
-    for mode in (0, 4, 1, 2, 3):
+    names = {0: "normal", 1: "stream-only"}
+    for mode in (0, 1):
         capi.check(L.tce_w4a16_set_debug_mode(mode))
         try:
             for (name, segs, K) in shapes:
@@ -113,7 +113,7 @@ def experiments():
                           for j, n in enumerate(segs)]
                     arrs.append((capi.W4A16Desc * len(ds))(*ds))
                 nbytes = sum(capi.algorithmic_bytes(1, n, K, 128) for n in segs)
-                for v in [(4, 4, 1, 1), (4, 4, 1, 2), (2, 4, 1, 2)]:
+                for v in [(4, 4, 1, 1), (4, 4, 1, 2), (2, 4, 1, 2), (2, 8, 1, 2), (4, 8, 1, 1)]:
                     capi.set_gemv_config(*v)
                     try:
                         us = time_graph(lambda i, sp: capi.check(L.tce_w4a16_forward_group(arrs[i % nset], len(segs), sp)), 128)

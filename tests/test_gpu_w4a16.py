@@ -100,21 +100,6 @@ def test_every_gemv_variant(dev, oracle):
         capi.set_gemv_config()
 
 
-def test_valu_dot_path_matches_too(dev, oracle):
-    """The v_dot2c (VALU) formulation kept for A/B measurements must agree with the oracle like the MFMA one."""
-    from tinychatengine_amd import capi
-    qw, sc, zp, a = _make(oracle, 1, 264, 8192, 128, seed=3, random_zeros=True)
-    ref32, _ = oracle.w4a16_gemv_q4_6(a, qw, sc, zp, 1, 264, 8192, 128)
-    try:
-        capi.check(capi.lib().tce_w4a16_set_debug_mode(4))
-        for v in [(4, 4, 1, 1), (4, 4, 1, 2), (2, 4, 1, 2)]:
-            capi.set_gemv_config(*v)
-            _check(_run(dev, qw, sc, zp, a, 128, flags=capi.TCE_W4_FORCE_GEMV), ref32, f"dot2c path {v}")
-    finally:
-        capi.lib().tce_w4a16_set_debug_mode(0)
-        capi.set_gemv_config()
-
-
 def test_gemv_golden_vector(dev, golden):
     """The committed vector produced by the reference's quantizer + naive_mat_mul_int4 (K=1408: padded scale rows)."""
     from tinychatengine_amd import capi

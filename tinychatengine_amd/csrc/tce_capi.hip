@@ -79,7 +79,7 @@ int tce_w4a16_set_gemv_config(int rows, int wn, int wk, int depth) {
 }
 
 int tce_w4a16_set_debug_mode(int mode) {
-    if (mode < 0 || mode > 4) return fail(TCE_ERR_BAD_ARG, "debug mode %d", mode);
+    if (mode < 0 || mode > 1) return fail(TCE_ERR_BAD_ARG, "debug mode %d", mode);
     tce::set_gemv_debug_mode(mode);
     return TCE_OK;
 }

@@ -1,20 +1,36 @@
-// w4a16_gemv.hip -- bandwidth-bound W4A16 dequant-GEMV for gfx950 (MI355X), M <= a few rows.
+// w4a16_gemv.hip -- W4A16 dequant-GEMV for gfx950 (MI355X), M <= a few rows: the per-token decode kernel.
 //
 // Replaces gemv_kernel_g128 / gemv_kernel_g64 (reference kernels/cuda/gemv_cuda.cu:140-194, 68-123) behind
 // MatmulOperator::gemv_forward_cuda.  Same data layout (q4_6), same math
 //     C[m][n] = fp16( sum_k fp32(s[n][k/G]) * (q[n][k] - z[n][k/G]) * fp32(A[m][k]) )      (fp32 accumulate)
-// but designed for CDNA4 rather than translated:
-//   * one 64-lane wavefront streams ROWS weight rows at a time; lane l of step t owns the 16-byte chunk
-//     c = t*64*WK + wk*64 + l of each row (32 int4 weights), so every global_load_dwordx4 of a wave covers
-//     1 KiB of consecutive HBM bytes; loads are non-temporal (each byte is read once by one CU) and
-//     2*ROWS of them are in flight per lane (double-buffered steps) to cover HBM latency;
-//   * the activation vector is staged once per workgroup into LDS, pre-permuted into the pair order that the
-//     magic-number int4->fp16 conversion yields (tce_common.hpp), in a lane-linear image so every ds_read_b128
-//     is bank-conflict free; one read feeds ROWS rows;
-//   * (q - z) is formed exactly in packed fp16, multiplied with the activations by v_dot2c_f32_f16 (fp32
-//     accumulate), and the fp16 group scale is applied once per 32 weights in fp32;
-//   * the K reduction is a 64-lane shuffle tree (+ an LDS hop when WK waves split K);
-//   * up to TCE_MAX_GROUP linears that share the activation (q/k/v, gate/up) run as ONE launch.
+// designed for CDNA4 rather than translated.  Measurements (profiles/) showed the first version of this kernel was
+// bound by VALU ISSUE, not by HBM: a wave64 VALU instruction occupies its SIMD for 4 cycles, which caps a CU at one
+// vector instruction per cycle, i.e. ~85 instructions per KiB of weights at 6.5 TB/s.  So the design minimises vector
+// instructions per weight and moves everything it can to other pipes:
+//
+//   * STREAM   one wavefront streams ROWS weight rows at a time; lane l of step t owns the 16-byte chunk
+//              c = t*64*WK + wk*64 + l of each row (32 int4 weights), so every buffer_load_dwordx4 of a wave covers
+//              1 KiB of consecutive HBM bytes.  Loads are non-temporal (each byte is read once by one CU), addressed
+//              through buffer descriptors (row offset in an SGPR, chunk offset in one VGPR shared by all rows: no
+//              per-load 64-bit address arithmetic), and DEPTH steps are kept in flight per wave.
+//   * X        the activation vector is staged once per workgroup into LDS, permuted into the pair order the int4
+//              extraction yields, in a lane-linear image (every ds_read_b128 is bank-conflict free); one read
+//              feeds ROWS rows.
+//   * UNPACK   7 VALU instructions per 8 weights: each nibble pair is moved to mantissa bits 4..7 of the half
+//              1024.0 (3 shifts + 4 v_and_or_b32 with the mask in a VGPR -- gfx9 VOP3 reads one scalar only), giving the
+//              halves 1024 + 16q.  The zero point is NOT removed per element:
+//                  sum_k (q_k - z) x_k = ( sum_k (1024 + 16 q_k) x_k  -  (1024 + 16 z) * sum_k x_k ) / 16
+//              where sum_k x_k per 32-weight chunk is row independent (computed once per step, on the matrix pipe).
+//              The bias is only ~14x the signal at this nibble position, so the fp32 accumulation noise it adds is
+//              ~2e-6 of the output rms (DESIGN.md "GEMV numerics"), three orders below the 1e-3 budget.
+//   * DOT      on the otherwise idle matrix pipe: v_mfma_f32_4x4x4_16b_f16 computes, per group of 4 lanes,
+//              D[i][j] = sum_k A_i[k] B_j[k] over the 4 halves each lane supplies; with A = a lane's weights and
+//              B = the same lane's activations the DIAGONAL D[l%4][l%4] is that lane's own dot product, accumulated
+//              in fp32 across calls (the off-diagonal cross terms are discarded at the end with a one-hot multiply).
+//   * SCALE    the fp16 group scale is applied in fp32 once per 32 weights (4 fma for the accumulator, 2 for the
+//              zero-point term).
+//   * REDUCE   64-lane shuffle tree (+ an LDS hop when WK waves split K).
+//   * GROUP    up to TCE_MAX_GROUP linears that share the activation (q/k/v, gate/up) run as ONE launch.
 #include "tce_common.hpp"
 #include "w4a16_kernels.hpp"
 
@@ -24,11 +40,11 @@ namespace tce {
 
 namespace {
 
-// MODE is a diagnostics switch for roofline experiments (scripts/tune.py); only MODE 0 computes the GEMV.
-//   1: stream only (weights loaded, no dequant / dot)   2: no scale / zero-point loads   3: plain instead of non-temporal loads
-//   4: dot products on the VALU (v_dot2c_f32_f16) instead of the matrix pipe -- a correct GEMV, kept for A/B measurements
-template <int MB, int ROWS, int WN, int WK, int DEPTH, int MODE = 0>
-__global__ __launch_bounds__(64 * WN * WK) void w4a16_gemv_kernel(const GemvArgs args) {
+// MODE: 0 = the GEMV.  1 = diagnostics: stream the weights only (no unpack / dot) -- roofline experiments, output unused.
+// The second __launch_bounds__ argument (minimum waves per SIMD) caps the register allocation: left alone, hipcc hoists
+// every row's unpack ahead of the MFMAs and spends > 256 VGPRs, i.e. one wave per SIMD and nothing to hide HBM latency.
+template <int MB, int ROWS, int WN, int WK, int DEPTH, int XB, int MODE = 0>
+__global__ __launch_bounds__(64 * WN * WK, (MB * ROWS * DEPTH >= 8 ? 2 : (MB * ROWS * DEPTH >= 4 ? 3 : 4))) void w4a16_gemv_kernel(const GemvArgs args) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NTHREADS = 64 * WN * WK;
     constexpr int LS = 64 * WK;  // lanes that split K
@@ -39,9 +55,9 @@ __global__ __launch_bounds__(64 * WN * WK) void w4a16_gemv_kernel(const GemvArgs
     const int wn = wave / WK;
 
     const int K = args.K;
-    const int nchunks = K >> 5;                // 16-byte chunks per weight row
-    const int T = (nchunks + LS - 1) / LS;     // steps
-    const int gshift = args.log2g - 5;         // chunk -> group
+    const int nchunks = K >> 5;             // 16-byte chunks per weight row
+    const int T = (nchunks + LS - 1) / LS;  // steps
+    const int gshift = args.log2g - 5;      // chunk -> group
     const int m0 = blockIdx.y * MB;
 
     // ---- which linear of the group does this workgroup belong to? (wave-uniform) ----
@@ -57,37 +73,41 @@ __global__ __launch_bounds__(64 * WN * WK) void w4a16_gemv_kernel(const GemvArgs
     const int total_pieces = MB * pieces_per_m;
 
     // ---- activation staging, part 1: issue the first batch of x loads (addresses clamped, never predicated) ----
-    constexpr int XB = 8;  // pieces per thread per batch
     const half_t *A = args.A;
     auto x_src = [&](int p, bool &valid) -> const uint4_t * {
-        // LDS piece index p -> (m, t, wk', j, l): image is lane-linear for the readers
+        // LDS piece index p -> (m, t*WK + wk', j, l): the image is lane-linear for the readers
         const int pc = p < total_pieces ? p : 0;
         const int m = MB == 1 ? 0 : pc / pieces_per_m;
         const int r = pc - m * pieces_per_m;
-        const int l = r & 63;
+        const int c = (r >> 8) * 64 + (r & 63);
         const int j = (r >> 6) & 3;
-        const int tw = r >> 8;  // t*WK + wk'
-        const int c = tw * 64 + l;
-        const int mrow = (m0 + m) < args.M ? (m0 + m) : (args.M - 1);
+        int mrow = m0 + m;
+        mrow = mrow < args.M ? mrow : args.M - 1;
         valid = (p < total_pieces) && (c < nchunks);
         const int cc = c < nchunks ? c : 0;
-        return reinterpret_cast<const uint4_t *>(A + (size_t)mrow * args.lda + (size_t)cc * 32 + j * 8);
+        return reinterpret_cast<const uint4_t *>(A + (size_t)mrow * args.lda + (cc * 32 + j * 8));
     };
     uint4_t xv[XB];
     bool xok[XB];
 #pragma unroll
     for (int i = 0; i < XB; ++i) xv[i] = *x_src(tid + i * NTHREADS, xok[i]);
 
-    // ---- weight stream ----
-    int rows[ROWS];
+    // ---- weight stream: buffer descriptors + scalar row offsets ----
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4_t *>(seg.qweight), 0, seg.bytes_w, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(seg.scales), 0, seg.bytes_s, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(seg.zeros), 0, seg.bytes_z, 0x00020000);
+    int so_w[ROWS], so_s[ROWS], so_z[ROWS];
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) {
-        const int r = row_base + i;
-        rows[i] = r < seg.N ? r : seg.N - 1;  // clamped; stores are masked
+        int r = row_base + i;
+        r = r < seg.N ? r : seg.N - 1;  // clamped; stores are masked
+        so_w[i] = r * (nchunks * 16);
+        so_s[i] = r * (seg.scales_stride * 2);
+        so_z[i] = r * (seg.zeros_stride * 4);
     }
     struct Step {
         uint4_t w[ROWS];
-        half_t s[ROWS];
+        unsigned short s[ROWS];
         unsigned z[ROWS];
         int g;
     };
@@ -98,29 +118,27 @@ __global__ __launch_bounds__(64 * WN * WK) void w4a16_gemv_kernel(const GemvArgs
         st.g = g;
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) {
-            const uint4_t *wp = seg.qweight + (size_t)rows[i] * nchunks + cc;
-            if constexpr (MODE == 3) st.w[i] = *wp;
-            else st.w[i] = load_nt(wp);
-            if constexpr (MODE == 1 || MODE == 2) {
-                st.s[i] = (half_t)0.01f;
+            st.w[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, cc * 16, so_w[i], /*nt*/ 2);
+            if constexpr (MODE == 1) {
+                st.s[i] = 0x2000;
                 st.z[i] = 0x88888888u;
             } else {
-                st.s[i] = seg.scales[(size_t)rows[i] * seg.scales_stride + g];
-                st.z[i] = seg.zeros[(size_t)rows[i] * seg.zeros_stride + (g >> 3)];
+                st.s[i] = __builtin_amdgcn_raw_buffer_load_b16(rs_s, g * 2, so_s[i], 0);
+                st.z[i] = __builtin_amdgcn_raw_buffer_load_b32(rs_z, (g >> 3) * 4, so_z[i], 0);
             }
         }
     };
-    // Prologue: DEPTH steps issued unconditionally (the host only picks variants with DEPTH <= T), so every wait
-    // the compiler places is an exact counted vmcnt.
+    // Prologue: DEPTH steps issued unconditionally (the host only picks variants with DEPTH <= T), so every wait the
+    // compiler places is an exact counted vmcnt.
     Step st[DEPTH];
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) issue(st[d], d);
-    // pin the issue order: x loads, then the weight stream, and only then the first use of x -- so the wait in
-    // front of the LDS writes is a counted vmcnt that leaves every weight load in flight
+    // pin the issue order: x loads, then the weight stream, and only then the first use of x -- so the wait in front
+    // of the LDS writes is a counted vmcnt that leaves every weight load in flight
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- activation staging, part 2: permute + write.  Batch 0 is straight-line code so that its wait is a
-    // counted vmcnt covering only the x loads (they were issued first; the weight loads stay in flight). ----
+    // ---- activation staging, part 2: permute + write.  Batch 0 is straight-line code (counted waits); XB is chosen by
+    // the host so that one batch covers the whole image whenever a compiled XB is large enough. ----
     auto x_write = [&](int base) {
 #pragma unroll
         for (int i = 0; i < XB; ++i) {
@@ -140,22 +158,21 @@ __global__ __launch_bounds__(64 * WN * WK) void w4a16_gemv_kernel(const GemvArgs
     }
     __syncthreads();
 
-    // Dot products.  MODE 4 uses v_dot2c_f32_f16 on the VALU.  The default puts them on the otherwise idle matrix
-    // pipe: v_mfma_f32_4x4x4_16b_f16 computes, for each group of 4 lanes, D[i][j] = sum_k A_i[k] * B_j[k] over the 4
-    // halves each lane supplies; with A = a lane's dequantized weights and B = the same lane's activations, the
-    // DIAGONAL element D[l%4][l%4] is exactly that lane's own 4-term dot product, accumulated in fp32 across calls
-    // (the 12 off-diagonal cross terms per group are discarded).  That removes 4 of the 13 VALU instructions per 8
-    // weights -- measured: the kernel was VALU-issue-bound, not HBM-bound (profiles/).
-    constexpr bool kMfma = (MODE != 4);
-    constexpr int ACCW = kMfma ? 4 : 1;
-    float acc[ROWS][MB][ACCW];
+    float acc[ROWS][MB][4];  // the 4 accumulator registers of the 4x4x4 MFMA; the lane's own dot product is [lane & 3]
+    float corr[ROWS][MB];    // sum over chunks of s * (1024 + 16 z) * sum_k x_k
 #pragma unroll
     for (int i = 0; i < ROWS; ++i)
 #pragma unroll
-        for (int m = 0; m < MB; ++m)
+        for (int m = 0; m < MB; ++m) {
+            corr[i][m] = 0.f;
 #pragma unroll
-            for (int r = 0; r < ACCW; ++r) acc[i][m][r] = 0.f;
-    const NibbleMasks nmask = make_nibble_masks();
+            for (int r = 0; r < 4; ++r) acc[i][m][r] = 0.f;
+        }
+    // nibble mask in a VGPR (see tce_common.hpp: one scalar operand per VOP3 on gfx9)
+    unsigned mask_hi;
+    asm volatile("v_mov_b32 %0, 0x00F000F0" : "=v"(mask_hi));
+    const unsigned magic = 0x64006400u;  // (1024.0h, 1024.0h)
+    const half4_t ones = half4_t{(half_t)1.0f, (half_t)1.0f, (half_t)1.0f, (half_t)1.0f};
 
     auto compute = [&](const Step &st, int t) {
         if constexpr (MODE == 1) {
@@ -163,58 +180,56 @@ __global__ __launch_bounds__(64 * WN * WK) void w4a16_gemv_kernel(const GemvArgs
             for (int i = 0; i < ROWS; ++i) acc[i][0][0] += (float)((st.w[i].x ^ st.w[i].y ^ st.w[i].z ^ st.w[i].w) & 0xFFu);
             return;
         }
-        uint4_t x[MB][4];
+        // activations of this lane's chunk, as MFMA B operands, and their sum (A = ones) on the matrix pipe
+        half4_t xb[MB][8];
+        float xsum[MB];
 #pragma unroll
-        for (int m = 0; m < MB; ++m)
+        for (int m = 0; m < MB; ++m) {
+            float4_t xs4 = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) x[m][j] = xs[(((m * T + t) * WK + wk) * 4 + j) * 64 + lane];
+            for (int j = 0; j < 4; ++j) {
+                const uint4_t xp = xs[(((m * T + t) * WK + wk) * 4 + j) * 64 + lane];
+                xb[m][2 * j] = __builtin_bit_cast(half4_t, uint2_t{xp.x, xp.y});      // (x0,x4,x1,x5) of word j
+                xb[m][2 * j + 1] = __builtin_bit_cast(half4_t, uint2_t{xp.z, xp.w});  // (x2,x6,x3,x7)
+                xs4 = __builtin_amdgcn_mfma_f32_4x4x4f16(ones, xb[m][2 * j], xs4, 0, 0, 0);
+                xs4 = __builtin_amdgcn_mfma_f32_4x4x4f16(ones, xb[m][2 * j + 1], xs4, 0, 0, 0);
+            }
+            xsum[m] = xs4[0];  // D[i][j] = sum_k B_j[k] for every i: all four registers hold this lane's sum
+        }
         const int zsh = (st.g & 7) * 4;
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) {
-            const ZeroPair zp = make_zero_pair((st.z[i] >> zsh) & 0xFu);
-            const float s = (float)st.s[i];
-            if constexpr (kMfma) {
-                float4_t blk[MB];
+            // keep each row's unpack -> MFMA -> scale sequence together: without the fence the scheduler hoists all
+            // rows' unpacks ahead of the first MFMA and the register allocation explodes
+            __builtin_amdgcn_sched_barrier(0);
+            float4_t blk[MB];
 #pragma unroll
-                for (int m = 0; m < MB; ++m) blk[m] = float4_t{0.f, 0.f, 0.f, 0.f};
+            for (int m = 0; m < MB; ++m) blk[m] = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    half2_t d[4];
-                    dequant_word(st.w[i][j], zp, nmask, d);
-                    const half4_t a0 = __builtin_bit_cast(half4_t, uint2_t{as_u32(d[0]), as_u32(d[1])});
-                    const half4_t a1 = __builtin_bit_cast(half4_t, uint2_t{as_u32(d[2]), as_u32(d[3])});
+            for (int j = 0; j < 4; ++j) {
+                const unsigned w = st.w[i][j];
+                const unsigned t0 = ((w << 4) & mask_hi) | magic;  // (1024+16 q0, 1024+16 q4)
+                const unsigned t1 = (w & mask_hi) | magic;         // (q1, q5)
+                const unsigned t2 = ((w >> 4) & mask_hi) | magic;  // (q2, q6)
+                const unsigned t3 = ((w >> 8) & mask_hi) | magic;  // (q3, q7)
+                const half4_t a0 = __builtin_bit_cast(half4_t, uint2_t{t0, t1});
+                const half4_t a1 = __builtin_bit_cast(half4_t, uint2_t{t2, t3});
 #pragma unroll
-                    for (int m = 0; m < MB; ++m) {
-                        const half4_t b0 = __builtin_bit_cast(half4_t, uint2_t{x[m][j].x, x[m][j].y});
-                        const half4_t b1 = __builtin_bit_cast(half4_t, uint2_t{x[m][j].z, x[m][j].w});
-                        blk[m] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, b0, blk[m], 0, 0, 0);
-                        blk[m] = __builtin_amdgcn_mfma_f32_4x4x4f16(a1, b1, blk[m], 0, 0, 0);
-                    }
+                for (int m = 0; m < MB; ++m) {
+                    blk[m] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, xb[m][2 * j], blk[m], 0, 0, 0);
+                    blk[m] = __builtin_amdgcn_mfma_f32_4x4x4f16(a1, xb[m][2 * j + 1], blk[m], 0, 0, 0);
                 }
-                // lanes 4b..4b+3 share a quantization group (32 weights per lane, groups of >= 32), so scaling all four
-                // accumulator registers by this lane's scale is consistent; the diagonal is picked once, at the end
+            }
+            // lanes 4b..4b+3 share a quantization group (32 weights per lane, groups of >= 32), so scaling all four
+            // accumulator registers by this lane's scale is consistent; the diagonal is picked once, at the end
+            const float s = (float)__builtin_bit_cast(half_t, st.s[i]);
+            const float cz = __builtin_fmaf((float)((st.z[i] >> zsh) & 0xFu), 16.0f, 1024.0f);  // 1024 + 16 z
+            const float scz = s * cz;
 #pragma unroll
-                for (int m = 0; m < MB; ++m)
+            for (int m = 0; m < MB; ++m) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[i][m][r] = __builtin_fmaf(s, blk[m][r], acc[i][m][r]);
-            } else {
-                float p[MB];
-#pragma unroll
-                for (int m = 0; m < MB; ++m) p[m] = 0.f;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    half2_t d[4];
-                    dequant_word(st.w[i][j], zp, nmask, d);
-#pragma unroll
-                    for (int m = 0; m < MB; ++m) {
-                        p[m] = __builtin_amdgcn_fdot2(d[0], as_half2(x[m][j].x), p[m], false);
-                        p[m] = __builtin_amdgcn_fdot2(d[1], as_half2(x[m][j].y), p[m], false);
-                        p[m] = __builtin_amdgcn_fdot2(d[2], as_half2(x[m][j].z), p[m], false);
-                        p[m] = __builtin_amdgcn_fdot2(d[3], as_half2(x[m][j].w), p[m], false);
-                    }
-                }
-#pragma unroll
-                for (int m = 0; m < MB; ++m) acc[i][m][0] = __builtin_fmaf(s, p[m], acc[i][m][0]);
+                for (int r = 0; r < 4; ++r) acc[i][m][r] = __builtin_fmaf(s, blk[m][r], acc[i][m][r]);
+                corr[i][m] = __builtin_fmaf(scz, xsum[m], corr[i][m]);
             }
         }
     };
@@ -251,21 +266,20 @@ __global__ __launch_bounds__(64 * WN * WK) void w4a16_gemv_kernel(const GemvArgs
     // ---- K reduction: pick the lane's diagonal accumulator, 64-lane shuffle tree, then across the WK waves via LDS ----
     float diag[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) diag[r] = (lane & 3) == r ? 1.0f : 0.0f;  // off-diagonal terms are finite, so x0 is exact
+    for (int q = 0; q < 4; ++q) diag[q] = (lane & 3) == q ? 0.0625f : 0.0f;  // one-hot pick and the final /16 in one factor
     float red[ROWS][MB];
 #pragma unroll
     for (int i = 0; i < ROWS; ++i)
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
-            float v = acc[i][m][0];
-            if constexpr (kMfma) {
-                // diagonal pick as a multiply-add with a one-hot lane mask: a select chain on (lane & 3) is turned by
-                // hipcc into a dynamically indexed private array, i.e. scratch memory traffic
-                v = acc[i][m][0] * diag[0];
-                v = __builtin_fmaf(acc[i][m][1], diag[1], v);
-                v = __builtin_fmaf(acc[i][m][2], diag[2], v);
-                v = __builtin_fmaf(acc[i][m][3], diag[3], v);
-            }
+            // diagonal pick as multiply-adds with a one-hot lane mask: a select chain on (lane & 3) is turned by hipcc
+            // into a dynamically indexed private array, i.e. scratch memory traffic (off-diagonal terms are finite)
+            float v = corr[i][m] * -0.0625f;
+            v = __builtin_fmaf(acc[i][m][0], diag[0], v);
+            v = __builtin_fmaf(acc[i][m][1], diag[1], v);
+            v = __builtin_fmaf(acc[i][m][2], diag[2], v);
+            v = __builtin_fmaf(acc[i][m][3], diag[3], v);
+            if constexpr (MODE == 1) v = acc[i][m][0];
             red[i][m] = wave_sum(v);
         }
 
@@ -308,15 +322,15 @@ struct Variant {
 
 int g_debug_mode = 0;
 
-template <int MB, int ROWS, int WN, int WK, int DEPTH, int MODE = 0>
-hipError_t launch_variant(const GemvArgs &a, int total_blocks, int m_blocks, hipStream_t stream) {
+template <int MB, int ROWS, int WN, int WK, int DEPTH, int XB, int MODE = 0>
+hipError_t launch_one(const GemvArgs &a, int total_blocks, int m_blocks, hipStream_t stream) {
     const int nchunks = a.K >> 5;
     const int LS = 64 * WK;
     const int T = (nchunks + LS - 1) / LS;
     size_t lds = (size_t)MB * T * LS * 64 + (size_t)64 * WN * WK * 16;  // x image + trash slots
     const size_t red = (size_t)WN * WK * ROWS * MB * sizeof(float);
     if (lds < red) lds = red;
-    auto kfn = w4a16_gemv_kernel<MB, ROWS, WN, WK, DEPTH, MODE>;
+    auto kfn = w4a16_gemv_kernel<MB, ROWS, WN, WK, DEPTH, XB, MODE>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -325,26 +339,28 @@ hipError_t launch_variant(const GemvArgs &a, int total_blocks, int m_blocks, hip
     return hipGetLastError();
 }
 
+template <int MB, int ROWS, int WN, int WK, int DEPTH>
+hipError_t launch_variant(const GemvArgs &a, int total_blocks, int m_blocks, hipStream_t stream) {
+    // x pieces per thread: MB * T * 4 / WN; one straight-line batch when it fits a compiled batch size
+    const int nchunks = a.K >> 5;
+    const int T = (nchunks + 64 * WK - 1) / (64 * WK);
+    const int need = (MB * T * 4 + WN - 1) / WN;
+    // register budget: the widest batches run with a shallower pipeline instead of spilling
+    if constexpr (MB * ROWS * DEPTH > 16 && DEPTH > 1) {
+        return launch_variant<MB, ROWS, WN, WK, DEPTH - 1>(a, total_blocks, m_blocks, stream);
+    } else {
+        if constexpr (MB == 1) {
+            if (g_debug_mode == 1) return launch_one<1, ROWS, WN, WK, DEPTH, 8, 1>(a, total_blocks, m_blocks, stream);
+        }
+        if (need <= 2) return launch_one<MB, ROWS, WN, WK, DEPTH, 2>(a, total_blocks, m_blocks, stream);
+        if (need <= 4) return launch_one<MB, ROWS, WN, WK, DEPTH, 4>(a, total_blocks, m_blocks, stream);
+        return launch_one<MB, ROWS, WN, WK, DEPTH, 8>(a, total_blocks, m_blocks, stream);
+    }
+}
+
 template <int MB>
 hipError_t launch_mb(const Variant &v, const GemvArgs &a, int total_blocks, int m_blocks, hipStream_t s, bool &found) {
     found = true;
-    if constexpr (MB == 1) {
-        if (g_debug_mode != 0) {  // diagnostics builds exist for three geometries only
-#define TCE_DBG(R, N_, K_, D_)                                                                                   \
-    if (v.rows == R && v.wn == N_ && v.wk == K_ && v.depth == D_) {                                              \
-        if (g_debug_mode == 1) return launch_variant<1, R, N_, K_, D_, 1>(a, total_blocks, m_blocks, s);          \
-        if (g_debug_mode == 2) return launch_variant<1, R, N_, K_, D_, 2>(a, total_blocks, m_blocks, s);          \
-        if (g_debug_mode == 3) return launch_variant<1, R, N_, K_, D_, 3>(a, total_blocks, m_blocks, s);          \
-        if (g_debug_mode == 4) return launch_variant<1, R, N_, K_, D_, 4>(a, total_blocks, m_blocks, s);          \
-    }
-            TCE_DBG(4, 4, 1, 1)
-            TCE_DBG(4, 4, 1, 2)
-            TCE_DBG(2, 4, 1, 2)
-#undef TCE_DBG
-            found = false;
-            return hipSuccess;
-        }
-    }
 #define TCE_V(R, N_, K_, D_) \
     if (v.rows == R && v.wn == N_ && v.wk == K_ && v.depth == D_) \
         return launch_variant<MB, R, N_, K_, D_>(a, total_blocks, m_blocks, s);
@@ -366,7 +382,7 @@ bool gemv_variant_exists(int rows, int wn, int wk, int depth) {
     return false;
 }
 
-// Host-side launch: fills GemvArgs, picks MB and the geometry, launches.  `forced` may be {0,0,0}.
+// Host-side launch: fills GemvArgs, picks MB and the geometry, launches.  `forced_*` may be 0.
 int launch_w4a16_gemv(const tce_w4a16_desc *descs, int count, int forced_rows, int forced_wn, int forced_wk,
                       int forced_depth, hipStream_t stream, hipError_t *hip_err) {
     const tce_w4a16_desc &d0 = descs[0];
@@ -378,12 +394,8 @@ int launch_w4a16_gemv(const tce_w4a16_desc *descs, int count, int forced_rows, i
     a.log2g = d0.group_size == 128 ? 7 : (d0.group_size == 64 ? 6 : 5);
     a.nseg = count;
 
-    // ---- geometry: enough workgroups to cover 256 CUs several times, enough bytes in flight per CU ----
-    int total_n = 0, min_n = 1 << 30;
-    for (int i = 0; i < count; ++i) {
-        total_n += descs[i].N;
-        if (descs[i].N < min_n) min_n = descs[i].N;
-    }
+    int total_n = 0;
+    for (int i = 0; i < count; ++i) total_n += descs[i].N;
     Variant v{forced_rows, forced_wn, forced_wk, forced_depth};
     const int nchunks = d0.K >> 5;
     if (v.rows == 0) {
@@ -415,6 +427,12 @@ int launch_w4a16_gemv(const tce_w4a16_desc *descs, int count, int forced_rows, i
         s.ldc = d.ldc ? d.ldc : d.N;
         s.scales_stride = d.scales_stride ? d.scales_stride : zw * 8;
         s.zeros_stride = d.zeros_stride ? d.zeros_stride : zw;
+        // buffer descriptors address 32-bit byte offsets
+        const long long bw = (long long)d.N * (d.K / 2), bs = (long long)d.N * s.scales_stride * 2, bz = (long long)d.N * s.zeros_stride * 4;
+        if (bw >= (1LL << 31) || bs >= (1LL << 31) || bz >= (1LL << 31)) return TCE_ERR_UNSUPPORTED_SHAPE;
+        s.bytes_w = (int)bw;
+        s.bytes_s = (int)bs;
+        s.bytes_z = (int)bz;
         s.block_begin = blocks;
         blocks += (d.N + rows_per_block - 1) / rows_per_block;
     }

@@ -11,6 +11,7 @@ struct GemvSeg {
     const unsigned *zeros;   // u32 [N][zeros_stride]
     half_t *C;               // fp16 [M][ldc]
     int N, ldc, scales_stride, zeros_stride;
+    int bytes_w, bytes_s, bytes_z;  // extents for the buffer descriptors (each < 2 GiB)
     int block_begin;         // first blockIdx.x of this linear
 };
 
@@ -31,16 +32,11 @@ struct GemvArgs {
     X(2, 4, 1, 2)            \
     X(4, 4, 1, 2)            \
     X(2, 4, 1, 3)            \
-    X(4, 4, 1, 3)            \
-    X(1, 8, 1, 2)            \
     X(2, 8, 1, 2)            \
-    X(4, 8, 1, 2)            \
+    X(4, 8, 1, 1)            \
     X(1, 2, 2, 1)            \
     X(2, 2, 2, 1)            \
-    X(4, 2, 2, 1)            \
-    X(2, 4, 2, 1)            \
     X(2, 2, 2, 2)            \
-    X(1, 1, 4, 1)            \
     X(1, 2, 4, 1)
 
 bool gemv_variant_exists(int rows, int wn, int wk, int depth);
