@@ -273,7 +273,11 @@ def test_full_size_decode_gemv(dev, oracle, N, K):
     _check(y.cpu().numpy(), ref32, f"full {N}x{K}")
     y2 = lin.forward(x * 2)
     torch.cuda.synchronize()
-    assert torch.equal(y2, y * 2), "x -> 2x must double every output exactly (power-of-two scaling is exact in fp16/fp32)"
+    # power-of-two scaling is exact in fp16/fp32 -- except where the fp16 OUTPUT is subnormal (|y| < 2^-14), where
+    # fp16(2v) and 2*fp16(v) may differ by one subnormal ulp (2^-24)
+    normal = y.abs() >= 2.0 ** -13
+    assert torch.equal(y2[normal], (y * 2)[normal]), "x -> 2x must double every (normal) output exactly"
+    assert (y2.float() - 2 * y.float()).abs().max().item() <= 2.0 ** -23
     # column sharding: each shard's rows must reproduce the full result bit for bit under one geometry
     try:
         capi.set_gemv_config(2, 4, 1, 2)

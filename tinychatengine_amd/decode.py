@@ -128,32 +128,41 @@ class DecodeLinears:
         return capi.Plan(self.token_launches(grouped))
 
     # ---- eager issue (used inside torch graph capture for world > 1, and by tests) ----
-    def run_block(self, li: int) -> None:
+    @staticmethod
+    def _hip_launch(group: list[capi.W4A16Desc]) -> None:
         st = _stream()
+        capi.check(capi.w4a16_forward_group(group, st) if len(group) > 1 else capi.w4a16_forward(group[0], st))
+
+    def run_block(self, li: int, launch=None) -> None:
+        launch = launch or self._hip_launch
         for g in self.block_launches(li):
-            capi.check(capi.w4a16_forward_group(g, st) if len(g) > 1 else capi.w4a16_forward(g[0], st))
+            launch(g)
 
-    def run_lm_head(self) -> None:
-        capi.check(capi.w4a16_forward(self.lm_head.desc(self.x, self.logits), _stream()))
+    def run_lm_head(self, launch=None) -> None:
+        (launch or self._hip_launch)([self.lm_head.desc(self.x, self.logits)])
 
-    def run_token_distributed(self, gathers_per_block: int = 1) -> None:
-        """world > 1: per block, rank-local GEMVs then the RCCL all-gather(s) (torch.distributed 'nccl' == RCCL)."""
+    def run_token_distributed(self, gathers_per_block: int = 1, launch=None) -> None:
+        """world > 1: per block, the rank-local GEMVs on N/P shards, then the all-gather(s) of the fp16 output slices
+        (torch.distributed: backend 'nccl' == RCCL over xGMI on the GPU box; 'gloo' in the CPU tests, where `launch`
+        is a CPU stand-in for the kernel launch).  gathers_per_block = 1 is the north-star definition (all five linears
+        of a block from replicated inputs, one gather of the block output); 4 is the dependency-faithful variant
+        (SURVEY §8e)."""
         import torch.distributed as dist
         ag = dist.all_gather_into_tensor
+        launch = launch or self._hip_launch
         assert self.m == 1, "column-sharded outputs are gathered as flat [N] vectors (M = 1 decode)"
         for li in range(self.n_layers):
+            lch = self.block_launches(li)
             if gathers_per_block == 1:
-                self.run_block(li)
+                for g in lch:
+                    launch(g)
                 ag(self.g_down.view(-1), self.out_down.view(-1))
             else:
-                b, st = self.blocks[li], _stream()
-                lch = self.block_launches(li)
-                run = lambda g: capi.check(capi.w4a16_forward_group(g, st) if len(g) > 1 else capi.w4a16_forward(g[0], st))
-                run(lch[0])
+                launch(lch[0])
                 for gfull, part in zip(self.g_qkv, self.out_qkv):
                     ag(gfull.view(-1), part.view(-1))
-                run(lch[1]); ag(self.g_o.view(-1), self.out_o.view(-1))
-                run(lch[2]); ag(self.g_gate.view(-1), self.out_gate.view(-1)); ag(self.g_up.view(-1), self.out_up.view(-1))
-                run(lch[3]); ag(self.g_down.view(-1), self.out_down.view(-1))
-        self.run_lm_head()
+                launch(lch[1]); ag(self.g_o.view(-1), self.out_o.view(-1))
+                launch(lch[2]); ag(self.g_gate.view(-1), self.out_gate.view(-1)); ag(self.g_up.view(-1), self.out_up.view(-1))
+                launch(lch[3]); ag(self.g_down.view(-1), self.out_down.view(-1))
+        launch([self.lm_head.desc(self.x, self.logits)])
         ag(self.g_logits.view(-1), self.logits.view(-1))

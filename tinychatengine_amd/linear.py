@@ -33,8 +33,10 @@ class Linear_half_int4:
 
     def desc(self, x: torch.Tensor, out: torch.Tensor, ldc: int = 0) -> capi.W4A16Desc:
         m = x.numel() // self.in_features
-        return capi.W4A16Desc(M=m, N=self.out_features, K=self.in_features, group_size=self.group_size, A=_ptr(x),
-                              qweight=_ptr(self.weight), scales=_ptr(self.scale), zeros=_ptr(self.zero_point),
+        # plain data_ptr(): descriptors are also built for host tensors by the CPU-side tests of the sharding logic;
+        # the C ABI itself only ever receives device pointers on the product path (MatmulOperator checks is_cuda)
+        return capi.W4A16Desc(M=m, N=self.out_features, K=self.in_features, group_size=self.group_size, A=x.data_ptr(),
+                              qweight=self.weight.data_ptr(), scales=self.scale.data_ptr(), zeros=self.zero_point.data_ptr(),
                               C=out.data_ptr(), ldc=ldc)
 
     def forward(self, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
