@@ -165,13 +165,19 @@ TCE_API int tce_device_count(void);
 TCE_API int tce_version(void);
 TCE_API const char *tce_last_error(void);
 TCE_API const char *tce_build_info(void);
-/* Force a GEMV launch geometry for every subsequent call from this process (all 0 = automatic).
- * rows_per_wave in {1,2,4}; waves_n x waves_k waves per workgroup (waves_k of them split K); depth = weight steps kept
- * in flight per wave (the library lowers it when K is too short).  TCE_ERR_BAD_ARG if that variant was not compiled. */
+/* Force a GEMV kernel + launch geometry for every subsequent call from this process (all 0 = automatic).
+ *   waves_k >= 1: the workgroup-per-row-block kernel: rows_per_wave in {1,2,4}, waves_n x waves_k waves per workgroup
+ *                 (waves_k of them split K), depth = weight steps kept in flight per wave;
+ *   waves_k == 0: the persistent stream kernel: rows_per_wave in {1,2} rows per unit, waves_n (1..16) waves per
+ *                 workgroup (one workgroup per CU), depth in {0 = auto, 2, 3} units in flight.
+ * TCE_ERR_BAD_ARG if that variant was not compiled. */
 TCE_API int tce_w4a16_set_gemv_config(int rows_per_wave, int waves_n, int waves_k, int depth);
 /* Roofline diagnostics for the GEMV kernel (scripts/tune.py): 0 = normal; 1 = stream the weights only (no unpack, no
- * dot products) to measure the memory-side ceiling of the access pattern.  Outputs are meaningless for mode 1; M = 1 only. */
+ * dot products) to measure the memory-side ceiling of the access pattern (outputs meaningless); 2 = normal math plus
+ * per-wave timestamps into the debug buffer.  M = 1 only. */
 TCE_API int tce_w4a16_set_debug_mode(int mode);
+/* mode 2: every wave writes {start, x staged, math done, end} (100 MHz wall clock, 4 x u64 per wave) to this device buffer */
+TCE_API int tce_w4a16_set_debug_buffer(void *device_buffer);
 /* Force an MFMA GEMM tile (m_tiles x n_tiles of 16x16 per wave); 0,0 = automatic. */
 TCE_API int tce_w4a16_set_gemm_config(int m_tiles, int n_tiles);
 /* Enumerate the compiled kernel variants (for tuning sweeps / tests): returns 0 and fills the outputs, or

@@ -96,7 +96,8 @@ def experiments():
     """Where does the time go?  The same launch with pieces of the kernel removed (tce_w4a16_set_debug_mode)."""
     L = capi.lib()
     shapes = [("gate+up grouped 2x11008x4096", [11008, 11008], 4096), ("lm_head 128256x4096", [128256], 4096),
-              ("o_proj 4096x4096", [4096], 4096), ("down 4096x11008", [4096], 11008)]
+              ("o_proj 4096x4096", [4096], 4096), ("down 4096x11008", [4096], 11008), ("qkv 12288x4096", [12288], 4096),
+              ("lm_head 32000x4096", [32000], 4096), ("L3 gate+up 2x14336x4096", [14336, 14336], 4096)]
     names = {0: "normal", 1: "stream-only"}
     for mode in (0, 1):
         capi.check(L.tce_w4a16_set_debug_mode(mode))
@@ -113,7 +114,9 @@ def experiments():
                           for j, n in enumerate(segs)]
                     arrs.append((capi.W4A16Desc * len(ds))(*ds))
                 nbytes = sum(capi.algorithmic_bytes(1, n, K, 128) for n in segs)
-                for v in [(4, 4, 1, 1), (4, 4, 1, 2), (2, 4, 1, 2), (2, 8, 1, 2), (4, 8, 1, 1)]:
+                for v in [(4, 4, 1, 1), (2, 4, 1, 2), (4, 8, 1, 1), (2, 16, 0, 2), (2, 15, 0, 2), (2, 16, 0, 3), (2, 15, 0, 3), (1, 16, 0, 3), (1, 16, 0, 2), (2, 12, 0, 3), (2, 8, 0, 3), (1, 12, 0, 3)]:
+                    if mode != 0 and v[2] == 0:
+                        continue
                     capi.set_gemv_config(*v)
                     try:
                         us = time_graph(lambda i, sp: capi.check(L.tce_w4a16_forward_group(arrs[i % nset], len(segs), sp)), 128)
@@ -122,6 +125,10 @@ def experiments():
                         continue
                     print(json.dumps({"kind": "exp", "mode": names[mode], "shape": name, "variant": v, "us": round(us, 3),
                                       "GBs": round(nbytes / us / 1e3, 1)}), flush=True)
+                capi.set_gemv_config()
+                us = time_graph(lambda i, sp: capi.check(L.tce_w4a16_forward_group(arrs[i % nset], len(segs), sp)), 128)
+                print(json.dumps({"kind": "exp", "mode": names[mode], "shape": name, "variant": (0, 0, 0, 0), "us": round(us, 3),
+                                  "GBs": round(nbytes / us / 1e3, 1)}), flush=True)
                 del rings, arrs
         finally:
             capi.set_gemv_config()

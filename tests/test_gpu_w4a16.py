@@ -100,6 +100,33 @@ def test_every_gemv_variant(dev, oracle):
         capi.set_gemv_config()
 
 
+STREAM_CFGS = [(2, 16, 2), (2, 15, 3), (1, 16, 3), (1, 9, 2), (2, 4, 2), (1, 1, 2)]
+
+
+@pytest.mark.parametrize("M", [1, 2])
+def test_stream_kernel_every_config(dev, oracle, M):
+    """The persistent stream kernel: rows per unit x waves per workgroup x ring depth, on grouped launches with odd N
+    (row-group tails), K tails (K % 2048 != 0), more row groups than waves and fewer row groups than waves."""
+    from tinychatengine_amd import capi
+    from tinychatengine_amd.linear import Linear_half_int4, forward_group
+    g = torch.Generator(device=dev).manual_seed(31 + M)
+    for (K, Ns) in [(4096, [9001, 520, 72]), (1408, [24]), (11008, [4104])]:
+        x = torch.empty(M, K, device=dev).normal_(0, 1, generator=g).to(torch.float16)
+        lins = [Linear_half_int4.from_float(torch.empty(n, K, device=dev).normal_(0, 0.02, generator=g), 128) for n in Ns]
+        refs = [oracle.w4a16_gemv_q4_6(x.cpu().numpy(), l.weight.cpu().numpy().view(np.uint32), l.scale.cpu().numpy(),
+                                       l.zero_point.cpu().numpy().view(np.uint32), M, l.out_features, K, 128)[0] for l in lins]
+        try:
+            for cfg in STREAM_CFGS:
+                capi.set_gemv_config(cfg[0], cfg[1], 0, cfg[2])
+                outs = [torch.full((M, n), float("nan"), dtype=torch.float16, device=dev) for n in Ns]
+                forward_group(lins, x, outs)
+                torch.cuda.synchronize()
+                for o, r, n in zip(outs, refs, Ns):
+                    _check(o.cpu().numpy(), r, f"stream cfg {cfg} K={K} N={n} M={M}")
+        finally:
+            capi.set_gemv_config()
+
+
 def test_gemv_golden_vector(dev, golden):
     """The committed vector produced by the reference's quantizer + naive_mat_mul_int4 (K=1408: padded scale rows)."""
     from tinychatengine_amd import capi

@@ -27,7 +27,7 @@ EXPORTS = [
     "tce_w4a16_gemm_awq", "tce_w8a8_matmul", "tce_plan_create", "tce_plan_launch", "tce_plan_n_launches",
     "tce_plan_destroy", "tce_version", "tce_last_error", "tce_build_info", "tce_w4a16_set_gemv_config",
     "tce_w4a16_set_gemm_config", "tce_w4a16_algorithmic_bytes", "tce_w4a16_gemv_variant", "tce_w4a16_gemm_variant",
-    "tce_w4a16_set_debug_mode", "tce_malloc", "tce_free", "tce_memcpy", "tce_synchronize", "tce_device_count",
+    "tce_w4a16_set_debug_mode", "tce_w4a16_set_debug_buffer", "tce_malloc", "tce_free", "tce_memcpy", "tce_synchronize", "tce_device_count",
 ]
 
 

@@ -21,6 +21,7 @@ namespace {
 thread_local char g_err[512] = "";
 int g_gemv_rows = 0, g_gemv_wn = 0, g_gemv_wk = 0, g_gemv_depth = 0;
 int g_gemm_mt = 0, g_gemm_nt = 0;
+int g_debug_mode_capi = 0;
 
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 int fail(int code, const char *fmt, ...) {
@@ -63,9 +64,20 @@ int64_t tce_w4a16_algorithmic_bytes(int M, int N, int K, int G) {
     return nk / 2 + 2 * nk / G + nk / (2 * (int64_t)G) + 2 * (int64_t)M * K + 2 * (int64_t)M * N;
 }
 
+int g_gemv_kernel = 0;  // 0 automatic, 1 workgroup-per-row-block kernel forced, 2 persistent stream kernel forced
+
 int tce_w4a16_set_gemv_config(int rows, int wn, int wk, int depth) {
     if (rows == 0 && wn == 0 && wk == 0) {
         g_gemv_rows = g_gemv_wn = g_gemv_wk = g_gemv_depth = 0;
+        g_gemv_kernel = 0;
+        tce::set_gemv_stream_config(0, 0, 0);
+        return TCE_OK;
+    }
+    if (wk == 0) {  // persistent stream kernel: rows per unit, waves per workgroup, units in flight
+        if ((rows != 1 && rows != 2) || wn < 1 || wn > 16 || (depth != 0 && depth != 2 && depth != 3))
+            return fail(TCE_ERR_BAD_ARG, "stream GEMV config rows=%d waves=%d depth=%d is not available", rows, wn, depth);
+        tce::set_gemv_stream_config(rows, wn, depth);
+        g_gemv_kernel = 2;
         return TCE_OK;
     }
     const int dd = depth ? depth : 2;
@@ -75,12 +87,19 @@ int tce_w4a16_set_gemv_config(int rows, int wn, int wk, int depth) {
     g_gemv_wn = wn;
     g_gemv_wk = wk;
     g_gemv_depth = dd;
+    g_gemv_kernel = 1;
     return TCE_OK;
 }
 
 int tce_w4a16_set_debug_mode(int mode) {
-    if (mode < 0 || mode > 1) return fail(TCE_ERR_BAD_ARG, "debug mode %d", mode);
+    if (mode < 0 || mode > 2) return fail(TCE_ERR_BAD_ARG, "debug mode %d", mode);
     tce::set_gemv_debug_mode(mode);
+    g_debug_mode_capi = mode;
+    return TCE_OK;
+}
+
+int tce_w4a16_set_debug_buffer(void *buf) {
+    tce::set_gemv_debug_buffer(buf);
     return TCE_OK;
 }
 
@@ -162,6 +181,16 @@ int tce_w4a16_forward_group(const tce_w4a16_desc *descs, int count, void *stream
             return fail(TCE_ERR_BAD_ARG, "grouped linears must share M, K, group size and the activation");
     }
     hipError_t he = hipSuccess;
+    // Kernel choice: the workgroup-per-row-block kernel unless the persistent stream kernel is forced through
+    // tce_w4a16_set_gemv_config(rows, waves, 0, depth).  The stream kernel is correct and tested, but on MI355X it
+    // measured slower or equal on every decode shape (profiles/r1/stream_vs_rowblock.jsonl), so it is opt-in.
+    const bool use_stream = g_debug_mode_capi == 0 && g_gemv_kernel == 2;
+    if (use_stream) {
+        const int rc = tce::launch_w4a16_gemv_stream(descs, count, static_cast<hipStream_t>(stream), &he);
+        if (rc == TCE_OK) return TCE_OK;
+        if (rc == TCE_ERR_HIP) return hip_fail(he, "w4a16 stream gemv launch");
+        if (rc != TCE_ERR_UNSUPPORTED_SHAPE || g_gemv_kernel == 2) return fail(rc, "w4a16 stream gemv: unsupported configuration");
+    }
     const int rc = tce::launch_w4a16_gemv(descs, count, g_gemv_rows, g_gemv_wn, g_gemv_wk, g_gemv_depth,
                                           static_cast<hipStream_t>(stream), &he);
     if (rc == TCE_ERR_HIP) return hip_fail(he, "w4a16 gemv launch");

@@ -48,6 +48,8 @@ __global__ __launch_bounds__(64 * WN * WK, (MB * ROWS * DEPTH >= 8 ? 2 : (MB * R
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NTHREADS = 64 * WN * WK;
     constexpr int LS = 64 * WK;  // lanes that split K
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+    if constexpr (MODE == 2) ts0 = wall_clock64();  // 100 MHz
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -157,6 +159,7 @@ __global__ __launch_bounds__(64 * WN * WK, (MB * ROWS * DEPTH >= 8 ? 2 : (MB * R
         x_write(base);
     }
     __syncthreads();
+    if constexpr (MODE == 2) ts1 = wall_clock64();
 
     float acc[ROWS][MB][4];  // the 4 accumulator registers of the 4x4x4 MFMA; the lane's own dot product is [lane & 3]
     float corr[ROWS][MB];    // sum over chunks of s * (1024 + 16 z) * sum_k x_k
@@ -263,6 +266,7 @@ __global__ __launch_bounds__(64 * WN * WK, (MB * ROWS * DEPTH >= 8 ? 2 : (MB * R
     if constexpr (DEPTH > 2) { if (r == 2) tail(std::integral_constant<int, 2>{}); }
     static_assert(DEPTH <= 3, "add tail cases");
 
+    if constexpr (MODE == 2) ts2 = wall_clock64();
     // ---- K reduction: pick the lane's diagonal accumulator, 64-lane shuffle tree, then across the WK waves via LDS ----
     float diag[4];
 #pragma unroll
@@ -305,6 +309,12 @@ __global__ __launch_bounds__(64 * WN * WK, (MB * ROWS * DEPTH >= 8 ? 2 : (MB * R
             }
     }
 
+    if constexpr (MODE == 2) {
+        if (lane == 0 && args.dbg) {
+            unsigned long long *d = args.dbg + ((size_t)blockIdx.x * (WN * WK) + wave) * 4;
+            d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = wall_clock64();
+        }
+    }
     if (lane == 0) {
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
@@ -321,6 +331,7 @@ struct Variant {
 };
 
 int g_debug_mode = 0;
+unsigned long long *g_debug_buf = nullptr;
 
 template <int MB, int ROWS, int WN, int WK, int DEPTH, int XB, int MODE = 0>
 hipError_t launch_one(const GemvArgs &a, int total_blocks, int m_blocks, hipStream_t stream) {
@@ -351,6 +362,7 @@ hipError_t launch_variant(const GemvArgs &a, int total_blocks, int m_blocks, hip
     } else {
         if constexpr (MB == 1) {
             if (g_debug_mode == 1) return launch_one<1, ROWS, WN, WK, DEPTH, 8, 1>(a, total_blocks, m_blocks, stream);
+            if (g_debug_mode == 2) return launch_one<1, ROWS, WN, WK, DEPTH, 2, 2>(a, total_blocks, m_blocks, stream);
         }
         if (need <= 2) return launch_one<MB, ROWS, WN, WK, DEPTH, 2>(a, total_blocks, m_blocks, stream);
         if (need <= 4) return launch_one<MB, ROWS, WN, WK, DEPTH, 4>(a, total_blocks, m_blocks, stream);
@@ -373,6 +385,7 @@ hipError_t launch_mb(const Variant &v, const GemvArgs &a, int total_blocks, int 
 }  // namespace
 
 void set_gemv_debug_mode(int mode) { g_debug_mode = mode; }
+void set_gemv_debug_buffer(void *p) { g_debug_buf = static_cast<unsigned long long *>(p); }
 
 bool gemv_variant_exists(int rows, int wn, int wk, int depth) {
 #define TCE_V(R, N_, K_, D_) \
@@ -393,6 +406,7 @@ int launch_w4a16_gemv(const tce_w4a16_desc *descs, int count, int forced_rows, i
     a.K = d0.K;
     a.log2g = d0.group_size == 128 ? 7 : (d0.group_size == 64 ? 6 : 5);
     a.nseg = count;
+    a.dbg = g_debug_buf;
 
     int total_n = 0;
     for (int i = 0; i < count; ++i) total_n += descs[i].N;
@@ -401,7 +415,8 @@ int launch_w4a16_gemv(const tce_w4a16_desc *descs, int count, int forced_rows, i
     if (v.rows == 0) {
         // Enough workgroups to cover 256 CUs a few times; split K across waves only when there are too few rows to
         // fill the chip and K is long enough.  (Tuned on MI355X; see DESIGN.md "GEMV geometry".)
-        if (total_n >= 8192) v = {4, 8, 1, 1};
+        if (total_n >= 24000) v = {4, 8, 1, 1};
+        else if (total_n >= 8192) v = {4, 4, 1, 1};
         else if (total_n >= 3072) v = {2, 4, 1, 2};
         else if (total_n >= 1536) v = {1, 4, 1, 2};
         else if (nchunks >= 128) v = {1, 2, 2, 1};

@@ -19,6 +19,7 @@ struct GemvArgs {
     const half_t *A;  // fp16 [M][lda]
     int lda, M, K, log2g;
     int nseg;
+    unsigned long long *dbg;  // MODE 2 (timestamps) only
     GemvSeg seg[TCE_MAX_GROUP];
 };
 
@@ -41,6 +42,11 @@ struct GemvArgs {
 
 bool gemv_variant_exists(int rows, int wn, int wk, int depth);
 void set_gemv_debug_mode(int mode);
+void set_gemv_debug_buffer(void *p);
+
+// persistent ("streaming") form, w4a16_gemv_stream.hip
+void set_gemv_stream_config(int rows, int nw, int depth);
+int launch_w4a16_gemv_stream(const tce_w4a16_desc *descs, int count, hipStream_t stream, hipError_t *hip_err);
 int launch_w4a16_gemv(const tce_w4a16_desc *descs, int count, int forced_rows, int forced_wn, int forced_wk,
                       int forced_depth, hipStream_t stream, hipError_t *hip_err);
 
