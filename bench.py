@@ -42,6 +42,7 @@ def parse_args():
     ap.add_argument("--roofline-only", action="store_true", help="run only the dominant-kernel loop (for rocprofv3)")
     ap.add_argument("--roofline-launches", type=int, default=256)
     ap.add_argument("--roofline-eager", action="store_true", help="roofline leg without graph capture (for rocprofv3 PMC passes)")
+    ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (RCCL init, gathers, graph capture) even with one rank")
     ap.add_argument("--cpu-worker", default="", choices=["", "avx", "ref"], help=argparse.SUPPRESS)
     ap.add_argument("--threads", type=int, default=8, help=argparse.SUPPRESS)
     return ap.parse_args()
@@ -209,13 +210,16 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     shape = SHAPES[args.workload]
     G = 128
+    if args.force_dist:
+        os.environ["TCE_FORCE_GATHER_BUFFERS"] = "1"
     dl = DecodeLinears(shape, device=dev, group_size=G, rank=rank, world=world, m=1, layers=args.layers)
     torch.cuda.synchronize()
     stream = torch.cuda.current_stream().cuda_stream
@@ -227,7 +231,7 @@ def main():
         return
 
     # ---- the step ----
-    if world == 1:
+    if dist is None:
         plan = dl.make_plan(grouped=not args.ungrouped)
         step = lambda: plan.launch(stream)
         n_launches = plan.n_launches

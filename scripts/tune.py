@@ -98,8 +98,8 @@ def experiments():
     shapes = [("gate+up grouped 2x11008x4096", [11008, 11008], 4096), ("lm_head 128256x4096", [128256], 4096),
               ("o_proj 4096x4096", [4096], 4096), ("down 4096x11008", [4096], 11008), ("qkv 12288x4096", [12288], 4096),
               ("lm_head 32000x4096", [32000], 4096), ("L3 gate+up 2x14336x4096", [14336, 14336], 4096)]
-    names = {0: "normal", 1: "stream-only"}
-    for mode in (0, 1):
+    names = {0: "normal", 1: "stream-only", 3: "x-first"}
+    for mode in (0, 3, 1):
         capi.check(L.tce_w4a16_set_debug_mode(mode))
         try:
             for (name, segs, K) in shapes:

@@ -92,7 +92,7 @@ int tce_w4a16_set_gemv_config(int rows, int wn, int wk, int depth) {
 }
 
 int tce_w4a16_set_debug_mode(int mode) {
-    if (mode < 0 || mode > 2) return fail(TCE_ERR_BAD_ARG, "debug mode %d", mode);
+    if (mode < 0 || mode > 3) return fail(TCE_ERR_BAD_ARG, "debug mode %d", mode);
     tce::set_gemv_debug_mode(mode);
     g_debug_mode_capi = mode;
     return TCE_OK;

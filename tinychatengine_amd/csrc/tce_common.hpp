@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "tce_matmul.h"
 
 namespace tce {
@@ -96,6 +98,25 @@ __device__ __forceinline__ uint4_t pair_permute(uint4_t v) {
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// 64-lane sum on the VALU with DPP cross-lane operands: six dependent adds of ~8 cycles each, against six ds_bpermute
+// round trips through the LDS crossbar (~100+ cycles each) for the shuffle tree above.  The total ends up in LANE 63
+// only (rows 1..3 accumulate the rows before them).
+__device__ __forceinline__ float wave_sum_dpp_lane63(float v) {
+    auto dpp = [](float x, auto ctrl, auto row_mask) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value,
+                                                                     decltype(row_mask)::value, 0xF, false));
+    };
+    using I = std::integral_constant<int, 0>;
+    (void)sizeof(I);
+    v += dpp(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xF>{});   // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xF>{});   // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xF>{});  // row_half_mirror
+    v += dpp(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xF>{});  // row_mirror: every lane of a row = row sum
+    v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});  // row_bcast15 into rows 1 and 3
+    v += dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{});  // row_bcast31 into rows 2 and 3
     return v;
 }
 

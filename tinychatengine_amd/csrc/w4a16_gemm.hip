@@ -36,11 +36,11 @@ struct GemmArgs {
 };
 
 template <int MT, int NT>
-__global__ __launch_bounds__(256) void w4a16_gemm_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(256, (MT * NT >= 16 ? 1 : 2)) void w4a16_gemm_kernel(const GemmArgs g) {
     constexpr int BM = MT * 16;
     constexpr int BN = 4 * NT * 16;
     constexpr int BK = 128;
-    __shared__ __attribute__((aligned(16))) uint4_t lds_a[MT * 4 * 64];  // [mt][s][64 lanes] 16-byte pieces
+    __shared__ __attribute__((aligned(16))) uint4_t lds_a[2][MT * 4 * 64];  // double buffer x [mt][s][64 lanes] 16-byte pieces
 
     // ---- XCD-aware tile mapping: workgroup b runs on XCD b % 8 (observed, used for speed only) ----
     const int bid = blockIdx.x;
@@ -94,13 +94,13 @@ __global__ __launch_bounds__(256) void w4a16_gemm_kernel(const GemmArgs g) {
             areg[i] = *reinterpret_cast<const uint4_t *>(g.A + (size_t)m * g.lda + kb * BK + pc * 8);
         }
     };
-    auto write_a = [&]() {
+    auto write_a = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int e = i * 256 + tid;
             const int row = e >> 4, pc = e & 15;
             const int qq = pc >> 2, s = pc & 3;  // k offset 8*pc = 32*qq + 8*s
-            lds_a[((row >> 4) * 4 + s) * 64 + qq * 16 + ((row & 15) ^ s)] = pair_permute(areg[i]);
+            lds_a[buf][((row >> 4) * 4 + s) * 64 + qq * 16 + ((row & 15) ^ s)] = pair_permute(areg[i]);
         }
     };
 
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void w4a16_gemm_kernel(const GemmArgs g) {
     // applied once per block in fp32: acc += s * acc_block -- the same precision class as the GEMV kernel and the
     // oracle (rounding the scaled weight to fp16 first costs ~2^-12 relative per weight, which breaks 1e-3 on outputs
     // that are small by cancellation).
-    auto compute = [&](const BRegs &b, int kb) {
+    auto compute = [&](const BRegs &b, int kb, int buf) {
         const int grp = ((kb * 4 + q) << 5) >> g.log2g;
         const int zsh = (grp & 7) * 4;
         ZeroPair zp[NT];
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void w4a16_gemm_kernel(const GemmArgs g) {
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                const uint4_t araw = lds_a[(i * 4 + s) * 64 + q * 16 + (n16 ^ s)];  // lane's row m16 == lane & 15
+                const uint4_t araw = lds_a[buf][(i * 4 + s) * 64 + q * 16 + (n16 ^ s)];  // lane's row m16 == lane & 15
                 const half8_t af = __builtin_bit_cast(half8_t, araw);
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
@@ -155,27 +155,29 @@ __global__ __launch_bounds__(256) void w4a16_gemm_kernel(const GemmArgs g) {
         }
     };
 
+    // Double-buffered LDS, one barrier per k-block: while block kb is contracted out of lds_a[kb & 1], the registers
+    // prefetch block kb+1 (activations and weights); the activations are written to the other buffer after the MFMAs.
     BRegs b0, b1;
     load_a(0);
     load_b(b0, 0);
+    write_a(0);
+    __syncthreads();
     const int last = nkb - 1;
     for (int kb = 0; kb < nkb; kb += 2) {
         {
-            write_a();
-            __syncthreads();
             const int nx = kb + 1 < nkb ? kb + 1 : last;  // clamped (never predicated) prefetch
             load_a(nx);
             load_b(b1, nx);
-            compute(b0, kb);
+            compute(b0, kb, 0);
+            write_a(1);
             __syncthreads();
         }
         if (kb + 1 < nkb) {
-            write_a();
-            __syncthreads();
             const int nx = kb + 2 < nkb ? kb + 2 : last;
             load_a(nx);
             load_b(b0, nx);
-            compute(b1, kb + 1);
+            compute(b1, kb + 1, 1);
+            write_a(0);
             __syncthreads();
         }
     }
@@ -239,8 +241,10 @@ int launch_w4a16_gemm(const tce_w4a16_desc &d, int forced_mt, int forced_nt, hip
         if (d.M <= 32) { mt = 2; nt = 2; }
         else if (d.M <= 64) { mt = 4; nt = 1; }
         else {
-            const long blocks_81 = (long)((d.M + 127) / 128) * ((d.N + 63) / 64);
-            if (blocks_81 >= 512) { mt = 8; nt = 1; }
+            // 64x128 tiles (each wave 4x2 MFMA tiles: the dequantized fragment feeds 8 MFMAs) once they still give
+            // >= 2 workgroups per CU, else 64x64 (measured, profiles/r1/gemm_m512_sweep.jsonl)
+            const long blocks_42 = (long)((d.M + 63) / 64) * ((d.N + 127) / 128);
+            if (blocks_42 >= 512) { mt = 4; nt = 2; }
             else { mt = 4; nt = 1; }
         }
     }

@@ -40,11 +40,11 @@ namespace tce {
 
 namespace {
 
-// MODE: 0 = the GEMV.  1 = diagnostics: stream the weights only (no unpack / dot) -- roofline experiments, output unused.
+// MODE: 0 = the GEMV.  3 = the GEMV with x staged before the weight stream starts.  2 = 0 + per-wave timestamps.  1 = diagnostics: stream the weights only (no unpack / dot) -- roofline experiments, output unused.
 // The second __launch_bounds__ argument (minimum waves per SIMD) caps the register allocation: left alone, hipcc hoists
 // every row's unpack ahead of the MFMAs and spends > 256 VGPRs, i.e. one wave per SIMD and nothing to hide HBM latency.
 template <int MB, int ROWS, int WN, int WK, int DEPTH, int XB, int MODE = 0>
-__global__ __launch_bounds__(64 * WN * WK, (MB * ROWS * DEPTH >= 8 ? 2 : (MB * ROWS * DEPTH >= 4 ? 3 : 4))) void w4a16_gemv_kernel(const GemvArgs args) {
+__global__ __launch_bounds__(64 * WN * WK, (MB * ROWS * DEPTH >= 8 ? 2 : (MB * ROWS * DEPTH >= 4 ? (MB == 1 && ROWS == 4 && DEPTH == 1 ? 5 : 3) : 4))) void w4a16_gemv_kernel(const GemvArgs args) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NTHREADS = 64 * WN * WK;
     constexpr int LS = 64 * WK;  // lanes that split K
@@ -133,8 +133,11 @@ __global__ __launch_bounds__(64 * WN * WK, (MB * ROWS * DEPTH >= 8 ? 2 : (MB * R
     // Prologue: DEPTH steps issued unconditionally (the host only picks variants with DEPTH <= T), so every wait the
     // compiler places is an exact counted vmcnt.
     Step st[DEPTH];
+    constexpr bool XFIRST = (MODE == 3);  // stage x completely before the first weight load is issued (see launch_variant)
+    if constexpr (!XFIRST) {
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) issue(st[d], d);
+        for (int d = 0; d < DEPTH; ++d) issue(st[d], d);
+    }
     // pin the issue order: x loads, then the weight stream, and only then the first use of x -- so the wait in front
     // of the LDS writes is a counted vmcnt that leaves every weight load in flight
     __builtin_amdgcn_sched_barrier(0);
@@ -159,6 +162,10 @@ __global__ __launch_bounds__(64 * WN * WK, (MB * ROWS * DEPTH >= 8 ? 2 : (MB * R
         x_write(base);
     }
     __syncthreads();
+    if constexpr (XFIRST) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) issue(st[d], d);
+    }
     if constexpr (MODE == 2) ts1 = wall_clock64();
 
     float acc[ROWS][MB][4];  // the 4 accumulator registers of the 4x4x4 MFMA; the lane's own dot product is [lane & 3]
@@ -284,13 +291,13 @@ __global__ __launch_bounds__(64 * WN * WK, (MB * ROWS * DEPTH >= 8 ? 2 : (MB * R
             v = __builtin_fmaf(acc[i][m][2], diag[2], v);
             v = __builtin_fmaf(acc[i][m][3], diag[3], v);
             if constexpr (MODE == 1) v = acc[i][m][0];
-            red[i][m] = wave_sum(v);
+            red[i][m] = wave_sum_dpp_lane63(v);  // total in lane 63
         }
 
     if constexpr (WK > 1) {
         __syncthreads();  // everyone is done reading the x image; reuse the front of LDS
         float *redbuf = reinterpret_cast<float *>(smem);  // [WN][WK][ROWS*MB]
-        if (lane == 0) {
+        if (lane == 63) {
 #pragma unroll
             for (int i = 0; i < ROWS; ++i)
 #pragma unroll
@@ -310,12 +317,12 @@ __global__ __launch_bounds__(64 * WN * WK, (MB * ROWS * DEPTH >= 8 ? 2 : (MB * R
     }
 
     if constexpr (MODE == 2) {
-        if (lane == 0 && args.dbg) {
+        if (lane == 63 && args.dbg) {
             unsigned long long *d = args.dbg + ((size_t)blockIdx.x * (WN * WK) + wave) * 4;
             d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = wall_clock64();
         }
     }
-    if (lane == 0) {
+    if (lane == 63) {
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
             if (m0 + m >= args.M) continue;
@@ -363,6 +370,20 @@ hipError_t launch_variant(const GemvArgs &a, int total_blocks, int m_blocks, hip
         if constexpr (MB == 1) {
             if (g_debug_mode == 1) return launch_one<1, ROWS, WN, WK, DEPTH, 8, 1>(a, total_blocks, m_blocks, stream);
             if (g_debug_mode == 2) return launch_one<1, ROWS, WN, WK, DEPTH, 2, 2>(a, total_blocks, m_blocks, stream);
+            if (g_debug_mode == 3) return launch_one<1, ROWS, WN, WK, DEPTH, 2, 3>(a, total_blocks, m_blocks, stream);
+        }
+        // MODE 3 = "x first": the workgroup stages x completely before it issues its first weight load.  When the whole
+        // grid is resident at once (one generation of workgroups) this keeps the x loads from queueing behind HBM-bound
+        // weight loads in the CU's miss queue (median wave start -> barrier 2.5 us otherwise, profiles/r1/timeline*.jsonl);
+        // with several generations the late workgroups queue anyway and the delayed weight issue only costs.
+        if constexpr (MB == 1) {
+            const int waves_per_simd = (ROWS == 4 && DEPTH == 1) ? 5 : (ROWS * DEPTH <= 2 ? 8 : 4);
+            const int capacity = 256 * (4 * waves_per_simd / (WN * WK));
+            if (g_debug_mode == 0 && total_blocks <= capacity) {
+                if (need <= 2) return launch_one<MB, ROWS, WN, WK, DEPTH, 2, 3>(a, total_blocks, m_blocks, stream);
+                if (need <= 4) return launch_one<MB, ROWS, WN, WK, DEPTH, 4, 3>(a, total_blocks, m_blocks, stream);
+                return launch_one<MB, ROWS, WN, WK, DEPTH, 8, 3>(a, total_blocks, m_blocks, stream);
+            }
         }
         if (need <= 2) return launch_one<MB, ROWS, WN, WK, DEPTH, 2>(a, total_blocks, m_blocks, stream);
         if (need <= 4) return launch_one<MB, ROWS, WN, WK, DEPTH, 4>(a, total_blocks, m_blocks, stream);

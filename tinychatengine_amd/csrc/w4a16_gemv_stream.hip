@@ -188,17 +188,6 @@ __global__ __launch_bounds__(1024) void w4a16_gemv_stream_kernel(const StreamArg
 #pragma unroll
     for (int q = 0; q < 4; ++q) diag[q] = (lane & 3) == q ? 0.0625f : 0.0f;
 
-    // butterfly addresses for the 64-lane sum, computed once (ds_bpermute takes a byte address per lane)
-    int bperm[6];
-#pragma unroll
-    for (int b = 0; b < 6; ++b) bperm[b] = (lane ^ (1 << b)) << 2;
-    auto wave_sum_pre = [&](float v) {
-#pragma unroll
-        for (int b = 5; b >= 0; --b)
-            v += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bperm[b], __builtin_bit_cast(int, v)));
-        return v;
-    };
-
     auto compute = [&](const Step &st) {
         const int t = st.t;
         half4_t xb[MB][8];
@@ -263,8 +252,8 @@ __global__ __launch_bounds__(1024) void w4a16_gemv_stream_kernel(const StreamArg
                     v = __builtin_fmaf(acc[i][m][1], diag[1], v);
                     v = __builtin_fmaf(acc[i][m][2], diag[2], v);
                     v = __builtin_fmaf(acc[i][m][3], diag[3], v);
-                    v = wave_sum_pre(v);
-                    if (lane == 0 && live && row0 + i < segN && m0 + m < args.M) Cp[(size_t)(m0 + m) * ldc + row0 + i] = (half_t)v;
+                    v = wave_sum_dpp_lane63(v);  // total in lane 63
+                    if (lane == 63 && live && row0 + i < segN && m0 + m < args.M) Cp[(size_t)(m0 + m) * ldc + row0 + i] = (half_t)v;
                     corr[i][m] = 0.f;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[i][m][r] = 0.f;

@@ -53,6 +53,7 @@ int launch_w4a16_gemv(const tce_w4a16_desc *descs, int count, int forced_rows, i
 // MFMA GEMM on the q4_6 layout (prefill).  m_tiles x n_tiles 16x16 MFMA tiles per wave, 4 waves along N.
 #define TCE_GEMM_VARIANTS(X) \
     X(8, 1)                  \
+    X(8, 2)                  \
     X(4, 2)                  \
     X(4, 1)                  \
     X(2, 2)

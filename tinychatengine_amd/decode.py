@@ -14,6 +14,7 @@ per transformer block the rank-local slices of the block output are joined by ON
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 
 import torch
@@ -91,7 +92,7 @@ class DecodeLinears:
         self.out_o, self.out_gate, self.out_up, self.out_down = e(h // W), e(f // W), e(f // W), e(h // W)
         self.logits = e(shape.vocab // W)
         # gather targets (world > 1)
-        if W > 1:
+        if W > 1 or os.environ.get("TCE_FORCE_GATHER_BUFFERS"):
             self.g_qkv = [e(n) for n in shape.qkv]
             self.g_o, self.g_gate, self.g_up, self.g_down, self.g_logits = e(h), e(f), e(f), e(h), e(shape.vocab)
 
