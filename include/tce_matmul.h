@@ -85,8 +85,15 @@ typedef struct tce_w4a16_desc {
 /* flags */
 #define TCE_W4_FORCE_GEMV 1  /* use the GEMV kernel even when M > TCE_W4A16_GEMV_MAX_M (weights re-streamed per 4 rows) */
 #define TCE_W4_FORCE_GEMM 2  /* use the MFMA GEMM kernel even for small M */
+#define TCE_W4_ZERO_POINT_IS_8 4 /* the caller vouches that every 4-bit zero point of this linear is 8 (`zeros` all
+                                    0x88888888 -- what the reference quantizer always writes, quantize_methods.py:436-440):
+                                    the GEMV then does not stream the zeros.  Results are identical when the promise holds. */
 
 TCE_API int tce_w4a16_forward(const tce_w4a16_desc *d, void *stream);
+
+/* Load-time helper for TCE_W4_ZERO_POINT_IS_8: returns 1 if all `n_words` packed zero-point words are 0x88888888, 0 if
+ * not, negative on error.  Synchronous; call it once per weight tensor (weights are immutable after loading). */
+TCE_API int tce_w4a16_check_zero_point_8(const void *zeros, long long n_words);
 
 /* count (<= TCE_MAX_GROUP) linears with identical M, K, group_size and A/lda, one launch (GEMV path only). */
 #define TCE_MAX_GROUP 4

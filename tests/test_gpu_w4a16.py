@@ -127,6 +127,22 @@ def test_stream_kernel_every_config(dev, oracle, M):
             capi.set_gemv_config()
 
 
+def test_zero_point_8_fast_path_is_bit_identical(dev, oracle):
+    """TCE_W4_ZERO_POINT_IS_8 skips the zeros stream; with all-8 zero points the output bits must not change."""
+    from tinychatengine_amd import capi
+    for (M, N, K) in [(1, 4096, 4096), (1, 520, 11008), (2, 264, 4096)]:
+        qw, sc, zp, a = _make(oracle, M, N, K, 128, seed=N)
+        assert capi.lib().tce_w4a16_check_zero_point_8(torch.from_numpy(zp.view(np.int32)).to(dev).data_ptr(), zp.size) == 1
+        plain = _run(dev, qw, sc, zp, a, 128, flags=capi.TCE_W4_FORCE_GEMV)
+        fast = _run(dev, qw, sc, zp, a, 128, flags=capi.TCE_W4_FORCE_GEMV | capi.TCE_W4_ZERO_POINT_IS_8)
+        assert np.array_equal(plain.view(np.uint16), fast.view(np.uint16))
+        ref32, _ = oracle.w4a16_gemv_q4_6(a, qw, sc, zp, M, N, K, 128)
+        _check(fast, ref32, f"zero8 fast path {M}x{N}x{K}")
+    zp2 = zp.copy()
+    zp2[3, 0] ^= 0x10
+    assert capi.lib().tce_w4a16_check_zero_point_8(torch.from_numpy(zp2.view(np.int32)).to(dev).data_ptr(), zp2.size) == 0
+
+
 def test_gemv_golden_vector(dev, golden):
     """The committed vector produced by the reference's quantizer + naive_mat_mul_int4 (K=1408: padded scale rows)."""
     from tinychatengine_amd import capi

@@ -33,6 +33,30 @@ struct AwqCache {
 };
 AwqCache g_awq[64];
 
+// TCE_W4_ZERO_POINT_IS_8 fast path: checked once per zero-point tensor (model weights are immutable after loading)
+struct ZeroCache {
+    const void *zeros = nullptr;
+    long long words = 0;
+    int is8 = 0;
+};
+ZeroCache g_zero[512];
+
+int zeros_are_8(const void *zeros, long long words) {
+    ZeroCache *free_slot = nullptr;
+    for (auto &c : g_zero) {
+        if (c.zeros == zeros && c.words == words) return c.is8;
+        if (!c.zeros && !free_slot) free_slot = &c;
+    }
+    const int r = tce_w4a16_check_zero_point_8(zeros, words);
+    if (r < 0) return 0;
+    if (free_slot) {
+        free_slot->zeros = zeros;
+        free_slot->words = words;
+        free_slot->is8 = r;
+    }
+    return r;
+}
+
 void int8_call(const char *who, const struct matmul_params *p, int bias_kind, int out_kind, int b_per_row) {
     const struct matrix *A = &p->A, *B = &p->B, *C = &p->C;
     if (A->column != B->row || C->row != A->row || C->column != B->column) {  // kernels/ref/matmul_ref_int8.cc:19-21
@@ -78,6 +102,12 @@ void MatmulOperator::gemv_forward_cuda(const struct matmul_params *params) {
     d.scales = params->half_scales;
     d.zeros = params->int32_zero_point;
     d.C = params->C.half_data_ptr;
+    if (d.group_size == 128 || d.group_size == 64 || d.group_size == 32) {
+        // rows of packed zero points: calculate_zeros_width (llm/src/nn_modules/cuda/utils.cu:162-178)
+        const int mult = d.group_size >= 128 ? 1 : (d.group_size == 64 ? 2 : 4);
+        const int zw = (((d.K / d.group_size + 7) / 8) + mult - 1) / mult * mult;
+        if (d.zeros && zeros_are_8(d.zeros, (long long)d.N * zw)) d.flags |= TCE_W4_ZERO_POINT_IS_8;
+    }
     const int rc = tce_w4a16_forward(&d, nullptr);
     if (rc == TCE_ERR_UNSUPPORTED_GROUP) {
         std::printf("Unsupported group size: %d\n", params->block_size);  // the reference's own message

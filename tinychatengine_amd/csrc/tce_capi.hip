@@ -213,6 +213,13 @@ int tce_w4a16_forward(const tce_w4a16_desc *d, void *stream) {
     return tce_w4a16_forward_group(d, 1, stream);
 }
 
+int tce_w4a16_check_zero_point_8(const void *zeros, long long n_words) {
+    if (!zeros || n_words <= 0) return fail(TCE_ERR_BAD_ARG, "tce_w4a16_check_zero_point_8: bad argument");
+    hipError_t he = hipSuccess;
+    const int rc = tce::check_zero_point_8(zeros, n_words, &he);
+    return rc == TCE_ERR_HIP ? hip_fail(he, "zero-point check") : rc;
+}
+
 int tce_w4a16_awq_fp16acc(int M, int N, int K, int G, const void *A, const void *qweight, const void *scales, void *C,
                           void *stream) {
     if (!A || !qweight || !scales || !C || M <= 0 || N <= 0 || K <= 0) return fail(TCE_ERR_BAD_ARG, "bad argument");

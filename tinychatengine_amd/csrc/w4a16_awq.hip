@@ -69,7 +69,32 @@ __global__ __launch_bounds__(256) void awq_repack_kernel(int N, int K, int G, in
     if (idx < (long long)N * zw) z6[idx] = 0x88888888u;
 }
 
+__device__ int g_zero_mismatch;
+
+__global__ __launch_bounds__(256) void zeros_check_kernel(const unsigned *__restrict__ z, long long n_words) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_words && z[i] != 0x88888888u) g_zero_mismatch = 1;
+}
+
 }  // namespace
+
+// 1 if every packed zero-point word is 0x88888888, 0 if not, negative on a HIP error.  Synchronous (used once per
+// weight tensor, at load time).
+int check_zero_point_8(const void *zeros, long long n_words, hipError_t *hip_err) {
+    int zero = 0, out = 0;
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_zero_mismatch), &zero, sizeof(int));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(zeros_check_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, nullptr,
+                           static_cast<const unsigned *>(zeros), n_words);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(&out, HIP_SYMBOL(g_zero_mismatch), sizeof(int));
+    if (e != hipSuccess) {
+        if (hip_err) *hip_err = e;
+        return TCE_ERR_HIP;
+    }
+    return out ? 0 : 1;
+}
 
 int launch_awq_fp16acc(int M, int N, int K, int G, const void *A, const void *qweight, const void *scales, void *C,
                        hipStream_t stream, hipError_t *hip_err) {

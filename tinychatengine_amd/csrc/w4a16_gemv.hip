@@ -43,7 +43,7 @@ namespace {
 // MODE: 0 = the GEMV.  3 = the GEMV with x staged before the weight stream starts.  2 = 0 + per-wave timestamps.  1 = diagnostics: stream the weights only (no unpack / dot) -- roofline experiments, output unused.
 // The second __launch_bounds__ argument (minimum waves per SIMD) caps the register allocation: left alone, hipcc hoists
 // every row's unpack ahead of the MFMAs and spends > 256 VGPRs, i.e. one wave per SIMD and nothing to hide HBM latency.
-template <int MB, int ROWS, int WN, int WK, int DEPTH, int XB, int MODE = 0>
+template <int MB, int ROWS, int WN, int WK, int DEPTH, int XB, int MODE = 0, bool Z8 = false>
 __global__ __launch_bounds__(64 * WN * WK, (MB * ROWS * DEPTH >= 8 ? 2 : (MB * ROWS * DEPTH >= 4 ? (MB == 1 && ROWS == 4 && DEPTH == 1 ? 5 : 3) : 4))) void w4a16_gemv_kernel(const GemvArgs args) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NTHREADS = 64 * WN * WK;
@@ -126,7 +126,10 @@ __global__ __launch_bounds__(64 * WN * WK, (MB * ROWS * DEPTH >= 8 ? 2 : (MB * R
                 st.z[i] = 0x88888888u;
             } else {
                 st.s[i] = __builtin_amdgcn_raw_buffer_load_b16(rs_s, g * 2, so_s[i], 0);
-                st.z[i] = __builtin_amdgcn_raw_buffer_load_b32(rs_z, (g >> 3) * 4, so_z[i], 0);
+                // Z8: the caller vouches (TCE_W4_ZERO_POINT_IS_8) that every zero point is 8 -- what the reference
+                // quantizer always writes (quantize_methods.py:436-440) -- so the packed zeros are not streamed at all
+                if constexpr (Z8) st.z[i] = 0x88888888u;
+                else st.z[i] = __builtin_amdgcn_raw_buffer_load_b32(rs_z, (g >> 3) * 4, so_z[i], 0);
             }
         }
     };
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(64 * WN * WK, (MB * ROWS * DEPTH >= 8 ? 2 : (MB * R
             // lanes 4b..4b+3 share a quantization group (32 weights per lane, groups of >= 32), so scaling all four
             // accumulator registers by this lane's scale is consistent; the diagonal is picked once, at the end
             const float s = (float)__builtin_bit_cast(half_t, st.s[i]);
-            const float cz = __builtin_fmaf((float)((st.z[i] >> zsh) & 0xFu), 16.0f, 1024.0f);  // 1024 + 16 z
+            const float cz = Z8 ? 1152.0f : __builtin_fmaf((float)((st.z[i] >> zsh) & 0xFu), 16.0f, 1024.0f);  // 1024 + 16 z
             const float scz = s * cz;
 #pragma unroll
             for (int m = 0; m < MB; ++m) {
@@ -340,7 +343,7 @@ struct Variant {
 int g_debug_mode = 0;
 unsigned long long *g_debug_buf = nullptr;
 
-template <int MB, int ROWS, int WN, int WK, int DEPTH, int XB, int MODE = 0>
+template <int MB, int ROWS, int WN, int WK, int DEPTH, int XB, int MODE = 0, bool Z8 = false>
 hipError_t launch_one(const GemvArgs &a, int total_blocks, int m_blocks, hipStream_t stream) {
     const int nchunks = a.K >> 5;
     const int LS = 64 * WK;
@@ -348,7 +351,7 @@ hipError_t launch_one(const GemvArgs &a, int total_blocks, int m_blocks, hipStre
     size_t lds = (size_t)MB * T * LS * 64 + (size_t)64 * WN * WK * 16;  // x image + trash slots
     const size_t red = (size_t)WN * WK * ROWS * MB * sizeof(float);
     if (lds < red) lds = red;
-    auto kfn = w4a16_gemv_kernel<MB, ROWS, WN, WK, DEPTH, XB, MODE>;
+    auto kfn = w4a16_gemv_kernel<MB, ROWS, WN, WK, DEPTH, XB, MODE, Z8>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -380,9 +383,19 @@ hipError_t launch_variant(const GemvArgs &a, int total_blocks, int m_blocks, hip
             const int waves_per_simd = (ROWS == 4 && DEPTH == 1) ? 5 : (ROWS * DEPTH <= 2 ? 8 : 4);
             const int capacity = 256 * (4 * waves_per_simd / (WN * WK));
             if (g_debug_mode == 0 && total_blocks <= capacity) {
+                if (a.zeros_are_8) {
+                    if (need <= 2) return launch_one<MB, ROWS, WN, WK, DEPTH, 2, 3, true>(a, total_blocks, m_blocks, stream);
+                    if (need <= 4) return launch_one<MB, ROWS, WN, WK, DEPTH, 4, 3, true>(a, total_blocks, m_blocks, stream);
+                    return launch_one<MB, ROWS, WN, WK, DEPTH, 8, 3, true>(a, total_blocks, m_blocks, stream);
+                }
                 if (need <= 2) return launch_one<MB, ROWS, WN, WK, DEPTH, 2, 3>(a, total_blocks, m_blocks, stream);
                 if (need <= 4) return launch_one<MB, ROWS, WN, WK, DEPTH, 4, 3>(a, total_blocks, m_blocks, stream);
                 return launch_one<MB, ROWS, WN, WK, DEPTH, 8, 3>(a, total_blocks, m_blocks, stream);
+            }
+            if (g_debug_mode == 0 && a.zeros_are_8) {
+                if (need <= 2) return launch_one<MB, ROWS, WN, WK, DEPTH, 2, 0, true>(a, total_blocks, m_blocks, stream);
+                if (need <= 4) return launch_one<MB, ROWS, WN, WK, DEPTH, 4, 0, true>(a, total_blocks, m_blocks, stream);
+                return launch_one<MB, ROWS, WN, WK, DEPTH, 8, 0, true>(a, total_blocks, m_blocks, stream);
             }
         }
         if (need <= 2) return launch_one<MB, ROWS, WN, WK, DEPTH, 2>(a, total_blocks, m_blocks, stream);
@@ -428,6 +441,9 @@ int launch_w4a16_gemv(const tce_w4a16_desc *descs, int count, int forced_rows, i
     a.log2g = d0.group_size == 128 ? 7 : (d0.group_size == 64 ? 6 : 5);
     a.nseg = count;
     a.dbg = g_debug_buf;
+    a.zeros_are_8 = 1;
+    for (int i = 0; i < count; ++i)
+        if (!(descs[i].flags & TCE_W4_ZERO_POINT_IS_8)) a.zeros_are_8 = 0;
 
     int total_n = 0;
     for (int i = 0; i < count; ++i) total_n += descs[i].N;

@@ -20,6 +20,7 @@ struct GemvArgs {
     int lda, M, K, log2g;
     int nseg;
     unsigned long long *dbg;  // MODE 2 (timestamps) only
+    int zeros_are_8;          // every linear of the launch carries TCE_W4_ZERO_POINT_IS_8
     GemvSeg seg[TCE_MAX_GROUP];
 };
 
@@ -59,6 +60,8 @@ int launch_w4a16_gemv(const tce_w4a16_desc *descs, int count, int forced_rows, i
     X(2, 2)
 bool gemm_variant_exists(int m_tiles, int n_tiles);
 int launch_w4a16_gemm(const tce_w4a16_desc &d, int forced_mt, int forced_nt, hipStream_t stream, hipError_t *hip_err);
+
+int check_zero_point_8(const void *zeros, long long n_words, hipError_t *hip_err);
 
 // AWQ (q4_5) helpers
 int launch_awq_fp16acc(int M, int N, int K, int G, const void *A, const void *qweight, const void *scales, void *C,

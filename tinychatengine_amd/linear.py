@@ -21,6 +21,8 @@ class Linear_half_int4:
         zw = quantize.calculate_zeros_width(self.in_features, group_size)
         if tuple(scales.shape) != (self.out_features, zw * 8) or tuple(zeros.shape) != (self.out_features, zw):
             raise ValueError("scales/zeros do not have the padded q4_6 shapes (quantize_methods.py:431-440)")
+        # the reference quantizer writes zero point 8 everywhere; verified once here so the GEMV can skip the zeros stream
+        self.zeros_are_8 = bool((zeros == -2004318072).all().item())
         self._op = MatmulOperator()
 
     @classmethod
@@ -37,7 +39,7 @@ class Linear_half_int4:
         # the C ABI itself only ever receives device pointers on the product path (MatmulOperator checks is_cuda)
         return capi.W4A16Desc(M=m, N=self.out_features, K=self.in_features, group_size=self.group_size, A=x.data_ptr(),
                               qweight=self.weight.data_ptr(), scales=self.scale.data_ptr(), zeros=self.zero_point.data_ptr(),
-                              C=out.data_ptr(), ldc=ldc)
+                              C=out.data_ptr(), ldc=ldc, flags=capi.TCE_W4_ZERO_POINT_IS_8 if self.zeros_are_8 else 0)
 
     def forward(self, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
         m = x.numel() // self.in_features
