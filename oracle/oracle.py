@@ -23,6 +23,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(_HERE, "libtce_oracle.so")
 REF_SO = os.path.join(_HERE, "_ref", "libtce_ref.so")
 REF_AVX_SO = os.path.join(_HERE, "_ref", "libtce_ref_avx.so")
+REF_X86NAIVE_SO = os.path.join(_HERE, "_ref", "libtce_ref_x86naive.so")
 
 
 def build(with_ref: bool | None = None) -> None:
@@ -212,6 +213,14 @@ class Reference(_Lib):
         out = np.empty((M, N), np.float32)
         self.lib.ref_fp32_matmul_transposed(C.c_int(M), C.c_int(N), C.c_int(K), _p(A), _p(B), _p(out), C.c_int(int(use_ref_backend)))
         return out
+
+
+def naive_mat_mul_int4_x86(lib, prefix, A, B_q4_3, scales, M, N, K, G=32):
+    """QM_x86 branch of naive_mat_mul_int4 through either library (lib = CDLL, prefix 'orc_' or 'ref_')."""
+    A = np.ascontiguousarray(A, np.float32); B = np.ascontiguousarray(B_q4_3, np.uint8); sc = np.ascontiguousarray(scales, np.float32)
+    out = np.empty((M, N), np.float32)
+    getattr(lib, prefix + "naive_mat_mul_int4_x86")(C.c_int(M), C.c_int(N), C.c_int(K), C.c_int(G), _p(A), _p(B), _p(sc), _p(out))
+    return out
 
 
 def have_ref() -> bool:

@@ -241,6 +241,39 @@ ORC_API void orc_naive_mat_mul_int4(int M, int N, int K, int G, const float *A, 
         }
 }
 
+/*
+ * MatmulOperator::naive_mat_mul_int4, QM_x86 branch -- kernels/matmul_int4.cc:78-104.  Weights in the x86 interleave
+ * (quantize_row_q4_3, llm/tools/quantize_methods.py:232-240): per 64 weights, byte e holds code[e] in the low and
+ * code[32+e] in the high nibble; zero point hard-coded 8; the accumulation alternates x[e]*w[e], x[32+e]*w[32+e].
+ * Only meaningful for block_size == 32 (the branch steps k by 2*block_size but consumes block_size bytes).
+ * This is the reference the AVX W4A8 fast path is compared with in the reference's own test (test_ops.cc:648-653).
+ */
+ORC_API int orc_naive_mat_mul_int4_x86(int M, int N, int K, int G, const float *A, const uint8_t *B, const float *scales,
+                                       float *C) {
+    if (G != 32 || K % 64 != 0) return -1;
+    for (int i = 0; i < M; i++)
+        for (int j = 0; j < N; j++) {
+            float acc = 0.0f;
+            for (int k = 0; k < K; k += 2 * G) {
+                float s = scales[((int64_t)j * K + k) / G];
+                float s1 = scales[((int64_t)j * K + k) / G + 1];
+                const uint8_t *b = B + (int64_t)j * (K / 2) + k / 2;
+                const float *x = A + (int64_t)i * K + k;
+                for (int e = 0; e < 32; e++) {
+                    uint8_t p = b[e];
+                    float d0 = (float)((double)(p & 0x0F) - 8.0) * s;
+                    float d1 = (float)((double)(p >> 4) - 8.0) * s1;
+                    float t0 = x[e] * d0;
+                    acc = acc + t0;
+                    float t1 = x[32 + e] * d1;
+                    acc = acc + t1;
+                }
+            }
+            C[(int64_t)i * N + j] = acc;
+        }
+    return 0;
+}
+
 /* naive_mat_mul_int4_with_offset -- kernels/matmul_int4.cc:133-165 (deq = (q-z)*s + o). */
 ORC_API void orc_naive_mat_mul_int4_with_offset(int M, int N, int K, int G, const float *A, const uint8_t *B,
                                                 const float *scales, const float *offset, float zero_point, float *C) {

@@ -132,3 +132,29 @@ def test_config1_reference_shape_runs_on_cpu(oracle, reference):
 
 def test_reference_struct_size_is_what_the_adapter_assumes(golden):
     assert int(golden["sizeof_matmul_params"][0]) == 416
+
+
+def test_x86_interleave_branch_and_avx_baseline_sanity(oracle):
+    """kernels/matmul_int4.cc:78-104 (QM_x86 nibble order) restated and pinned; and the AVX W4A8 fast path that
+    bench.py times as the CPU baseline agrees with it to the reference's own tolerance (test_ops.cc:648-653, MSE 7e-4),
+    which also proves the q4_3 packing used for the timing is the one the AVX kernel expects."""
+    import ctypes as C
+    import os
+    from oracle import oracle as O
+    if not os.path.exists(O.REF_X86NAIVE_SO):
+        pytest.skip("oracle/_ref/libtce_ref_x86naive.so not built")
+    ref = C.CDLL(O.REF_X86NAIVE_SO)
+    rng = np.random.default_rng(7)
+    M, N, K = 2, 48, 512
+    w = (rng.standard_normal((N, K)) * 0.02).astype(np.float32)
+    codes, d = oracle.group_quantize(w, 32)
+    B = O.ReferenceAVX.pack_q4_3(codes)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    mine = O.naive_mat_mul_int4_x86(oracle.lib, "orc_", A, B, d, M, N, K)
+    theirs = O.naive_mat_mul_int4_x86(ref, "ref_", A, B, d, M, N, K)
+    assert np.array_equal(mine, theirs)
+    generic = oracle.naive_mat_mul_int4(A, oracle.pack_sequential(codes, N, K), d.reshape(N, -1), 8.0, M, N, K, 32)
+    assert np.abs(mine - generic).max() < 1e-5  # same math, different summation order
+    if O.have_ref_avx():
+        avx = O.ReferenceAVX(num_thread=4).w4a8(A[:1], B, d.reshape(N, -1), 1, N, K)
+        assert float(np.mean((avx - mine[:1]) ** 2)) <= 7e-4
