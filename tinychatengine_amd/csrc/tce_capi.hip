@@ -22,6 +22,7 @@ thread_local char g_err[512] = "";
 int g_gemv_rows = 0, g_gemv_wn = 0, g_gemv_wk = 0, g_gemv_depth = 0;
 int g_gemm_mt = 0, g_gemm_nt = 0;
 int g_debug_mode_capi = 0;
+void *g_dbg_buf_capi = nullptr;
 
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 int fail(int code, const char *fmt, ...) {
@@ -94,12 +95,15 @@ int tce_w4a16_set_gemv_config(int rows, int wn, int wk, int depth) {
 int tce_w4a16_set_debug_mode(int mode) {
     if (mode < 0 || mode > 3) return fail(TCE_ERR_BAD_ARG, "debug mode %d", mode);
     tce::set_gemv_debug_mode(mode);
+    tce::set_gemv_stream_debug(mode, g_dbg_buf_capi);
     g_debug_mode_capi = mode;
     return TCE_OK;
 }
 
 int tce_w4a16_set_debug_buffer(void *buf) {
     tce::set_gemv_debug_buffer(buf);
+    g_dbg_buf_capi = buf;
+    tce::set_gemv_stream_debug(g_debug_mode_capi, buf);
     return TCE_OK;
 }
 
@@ -184,7 +188,7 @@ int tce_w4a16_forward_group(const tce_w4a16_desc *descs, int count, void *stream
     // Kernel choice: the workgroup-per-row-block kernel unless the persistent stream kernel is forced through
     // tce_w4a16_set_gemv_config(rows, waves, 0, depth).  The stream kernel is correct and tested, but on MI355X it
     // measured slower or equal on every decode shape (profiles/r1/stream_vs_rowblock.jsonl), so it is opt-in.
-    const bool use_stream = g_debug_mode_capi == 0 && g_gemv_kernel == 2;
+    const bool use_stream = g_gemv_kernel == 2;
     if (use_stream) {
         const int rc = tce::launch_w4a16_gemv_stream(descs, count, static_cast<hipStream_t>(stream), &he);
         if (rc == TCE_OK) return TCE_OK;

@@ -26,6 +26,7 @@ struct StreamArgs {
     int lda, M, K, log2g;
     int nseg;
     int n_rg;  // total row groups over all segments
+    unsigned long long *dbg;  // MODE 2 only
     GemvSeg seg[TCE_MAX_GROUP];  // block_begin = first row group of the segment
 };
 
@@ -34,8 +35,10 @@ __device__ __forceinline__ T pick4(int i, T a, T b, T c, T d) {
     return i == 0 ? a : (i == 1 ? b : (i == 2 ? c : d));
 }
 
-template <int MB, int ROWS, int DEPTH>
+template <int MB, int ROWS, int DEPTH, int MODE = 0>
 __global__ __launch_bounds__(1024) void w4a16_gemv_stream_kernel(const StreamArgs args) {
+    unsigned long long ts0 = 0, ts1 = 0;
+    if constexpr (MODE == 2) ts0 = wall_clock64();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int nthreads = blockDim.x;
@@ -133,42 +136,33 @@ __global__ __launch_bounds__(1024) void w4a16_gemv_stream_kernel(const StreamArg
         }
     };
 
-    // ---- prologue: weight stream first, then the one-time x staging ----
+    // ---- prologue: the one-time x staging FIRST (with empty memory queues it takes ~1 us; issued behind the first
+    // weight units its data cannot be consumed before theirs -- vmcnt retires in order -- and every wave idled 3.3-5 us,
+    // profiles/r1/timeline_stream.jsonl), then the weight stream ----
     Step st[DEPTH];
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) issue(st[d]);
 
     uint4_t *xs = reinterpret_cast<uint4_t *>(smem);  // [MB][T][4][64] pieces of 16 bytes (pair-permuted, lane-linear)
     {
         const int pieces_per_m = T * 256;
         const int total_pieces = MB * pieces_per_m;
-        for (int base = 0; base < total_pieces; base += 4 * nthreads) {
-            uint4_t v[4];
-            bool ok[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int p = base + tid + i * nthreads;
-                const int pc = p < total_pieces ? p : 0;
-                const int m = MB == 1 ? 0 : pc / pieces_per_m;
-                const int r = pc - m * pieces_per_m;
-                const int c = (r >> 8) * 64 + (r & 63);
-                const int j = (r >> 6) & 3;
-                int mrow = m0 + m;
-                mrow = mrow < args.M ? mrow : args.M - 1;
-                ok[i] = c < nchunks;
-                const int cc = c < nchunks ? c : 0;
-                v[i] = *reinterpret_cast<const uint4_t *>(args.A + (size_t)mrow * args.lda + (cc * 32 + j * 8));
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int p = base + tid + i * nthreads;
-                uint4_t q = pair_permute(v[i]);
-                if (!ok[i]) q = uint4_t{0u, 0u, 0u, 0u};
-                xs[p < total_pieces ? p : total_pieces + tid] = q;  // surplus pieces go to a trash slot behind the image
-            }
+        // one piece per thread per round; threads without a piece load nothing (clamping surplus threads onto piece 0,
+        // as the row-block kernel does for its counted waits, made 3584 of 4096 threads hammer one L2 line here)
+        for (int p = tid; p < total_pieces; p += nthreads) {
+            const int m = MB == 1 ? 0 : p / pieces_per_m;
+            const int r = p - m * pieces_per_m;
+            const int c = (r >> 8) * 64 + (r & 63);
+            const int j = (r >> 6) & 3;
+            int mrow = m0 + m;
+            mrow = mrow < args.M ? mrow : args.M - 1;
+            uint4_t q = uint4_t{0u, 0u, 0u, 0u};
+            if (c < nchunks) q = pair_permute(*reinterpret_cast<const uint4_t *>(args.A + (size_t)mrow * args.lda + (c * 32 + j * 8)));
+            xs[p] = q;
         }
     }
     __syncthreads();
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) issue(st[d]);
+    if constexpr (MODE == 2) ts1 = wall_clock64();
 
     float acc[ROWS][MB][4];
     float corr[ROWS][MB];
@@ -189,6 +183,12 @@ __global__ __launch_bounds__(1024) void w4a16_gemv_stream_kernel(const StreamArg
     for (int q = 0; q < 4; ++q) diag[q] = (lane & 3) == q ? 0.0625f : 0.0f;
 
     auto compute = [&](const Step &st) {
+        if constexpr (MODE == 1) {  // diagnostics: consume the loads, skip the math
+#pragma unroll
+            for (int i = 0; i < ROWS; ++i) acc[i][0][0] += (float)((st.w[i].x ^ st.w[i].y ^ st.w[i].z ^ st.w[i].w ^ st.s[i] ^ st.z[i]) & 0xFFu);
+            if (st.t == T - 1 && st.live && lane == 63) st.C[st.row0] = (half_t)acc[0][0][0];
+            return;
+        }
         const int t = st.t;
         half4_t xb[MB][8];
         float xsum[MB];
@@ -271,14 +271,20 @@ __global__ __launch_bounds__(1024) void w4a16_gemv_stream_kernel(const StreamArg
             issue(st[d]);                       // past the end: padding (no memory traffic)
         }
     }
+    if constexpr (MODE == 2) {
+        if (lane == 63 && args.dbg) {
+            unsigned long long *d = args.dbg + (size_t)gw * 4;
+            d[0] = ts0; d[1] = ts1; d[2] = wall_clock64(); d[3] = d[2];
+        }
+    }
 }
 
-template <int MB, int ROWS, int DEPTH>
+template <int MB, int ROWS, int DEPTH, int MODE = 0>
 hipError_t launch_stream(const StreamArgs &a, int blocks, int nw, int m_blocks, hipStream_t stream) {
     const int nchunks = a.K >> 5;
     const int T = (nchunks + 63) / 64;
     const size_t lds = (size_t)MB * T * 4096 + (size_t)64 * nw * 16;
-    auto kfn = w4a16_gemv_stream_kernel<MB, ROWS, DEPTH>;
+    auto kfn = w4a16_gemv_stream_kernel<MB, ROWS, DEPTH, MODE>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -289,8 +295,15 @@ hipError_t launch_stream(const StreamArgs &a, int blocks, int nw, int m_blocks, 
 
 int g_num_cus = 0;
 int g_stream_rows = 0, g_stream_nw = 0, g_stream_depth = 0;  // forced geometry (0 = automatic)
+int g_stream_mode = 0;
+unsigned long long *g_stream_dbg = nullptr;
 
 }  // namespace
+
+void set_gemv_stream_debug(int mode, void *buf) {
+    g_stream_mode = mode;
+    g_stream_dbg = static_cast<unsigned long long *>(buf);
+}
 
 void set_gemv_stream_config(int rows, int nw, int depth) {
     g_stream_rows = rows;
@@ -366,6 +379,7 @@ int launch_w4a16_gemv_stream(const tce_w4a16_desc *descs, int count, hipStream_t
     }
     for (int i = count; i < TCE_MAX_GROUP; ++i) a.seg[i] = a.seg[0];
     a.n_rg = n_rg;
+    a.dbg = g_stream_dbg;
     const size_t lds = (size_t)mb * T * 4096 + (size_t)64 * nw * 16;
     if (lds > 160 * 1024) return TCE_ERR_UNSUPPORTED_SHAPE;
     int blocks = g_num_cus;
@@ -374,6 +388,13 @@ int launch_w4a16_gemv_stream(const tce_w4a16_desc *descs, int count, hipStream_t
 
     hipError_t e = hipSuccess;
     bool found = true;
+    if (mb == 1 && g_stream_mode != 0) {
+        if (rows == 2 && depth == 2) e = g_stream_mode == 1 ? launch_stream<1, 2, 2, 1>(a, blocks, nw, m_blocks, stream) : launch_stream<1, 2, 2, 2>(a, blocks, nw, m_blocks, stream);
+        else if (rows == 2 && depth == 3) e = g_stream_mode == 1 ? launch_stream<1, 2, 3, 1>(a, blocks, nw, m_blocks, stream) : launch_stream<1, 2, 3, 2>(a, blocks, nw, m_blocks, stream);
+        else return TCE_ERR_BAD_ARG;
+        if (e != hipSuccess) { if (hip_err) *hip_err = e; return TCE_ERR_HIP; }
+        return TCE_OK;
+    }
 #define TCE_S(MB_, R_, D_) \
     if (mb == MB_ && rows == R_ && depth == D_) e = launch_stream<MB_, R_, D_>(a, blocks, nw, m_blocks, stream); else
     TCE_S(1, 1, 2) TCE_S(1, 1, 3) TCE_S(1, 2, 2) TCE_S(1, 2, 3) TCE_S(2, 1, 2) TCE_S(2, 1, 3) TCE_S(2, 2, 2)

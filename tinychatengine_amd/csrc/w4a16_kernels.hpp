@@ -47,6 +47,7 @@ void set_gemv_debug_buffer(void *p);
 
 // persistent ("streaming") form, w4a16_gemv_stream.hip
 void set_gemv_stream_config(int rows, int nw, int depth);
+void set_gemv_stream_debug(int mode, void *buf);
 int launch_w4a16_gemv_stream(const tce_w4a16_desc *descs, int count, hipStream_t stream, hipError_t *hip_err);
 int launch_w4a16_gemv(const tce_w4a16_desc *descs, int count, int forced_rows, int forced_wn, int forced_wk,
                       int forced_depth, hipStream_t stream, hipError_t *hip_err);
