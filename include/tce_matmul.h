@@ -150,6 +150,20 @@ TCE_API int tce_w8a8_matmul(const tce_w8a8_desc *d, void *stream);
 typedef struct tce_plan tce_plan;
 /* group_sizes[i] consecutive descriptors form launch i (1 = tce_w4a16_forward, >1 = tce_w4a16_forward_group). */
 TCE_API int tce_plan_create(const tce_w4a16_desc *descs, const int32_t *group_sizes, int n_launches, tce_plan **out);
+/* TCE_PLAN_CHAINED: the launches keep their order and their data dependences (launch i+1 reads its activations and
+ * writes its outputs only after launch i has published all of its outputs), but ONE persistent kernel walks the whole
+ * list and a device-wide barrier replaces each kernel boundary: a workgroup that is done with launch i already has the
+ * first weight tiles of launch i+1 in registers while it waits, so launch ramp and first-byte HBM latency disappear
+ * from the token's critical path.  Needs every launch to be an M = 1 GEMV the persistent kernel takes; otherwise the
+ * plan is built stream-ordered (tce_plan_is_chained tells).  tce_plan_status synchronises the device and returns
+ * TCE_ERR_HIP if a barrier wait ever timed out (~2 s; cannot happen unless the device is shared with a kernel that
+ * never ends).  tce_plan_geometry reports what the token kernel runs with (rows per row group, ring depth, waves per
+ * workgroup, workgroups). */
+#define TCE_PLAN_CHAINED 1
+TCE_API int tce_plan_create_ex(const tce_w4a16_desc *descs, const int32_t *group_sizes, int n_launches, int flags, tce_plan **out);
+TCE_API int tce_plan_is_chained(const tce_plan *plan);
+TCE_API int tce_plan_geometry(const tce_plan *plan, int *rows, int *depth, int *waves, int *workgroups);
+TCE_API int tce_plan_status(tce_plan *plan);
 TCE_API int tce_plan_launch(tce_plan *plan, void *stream);
 TCE_API int tce_plan_n_launches(const tce_plan *plan);
 TCE_API void tce_plan_destroy(tce_plan *plan);

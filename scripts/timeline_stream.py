@@ -28,11 +28,11 @@ def timeit(sets, nseg, launches=64):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); [g.replay() for _ in range(3)]; e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / (3 * launches)
-for (segs, K) in [([11008, 11008], 4096), ([128256], 4096), ([12288], 4096)]:
+for (segs, K) in [([11008, 11008], 4096), ([4096], 11008)]:
     sets = mk(segs, K, reps=24 if sum(segs) < 100000 else 5)
-    for cfg in [(2, 16, 2), (2, 15, 2), (2, 16, 3)]:
+    for cfg in [(2, 16, 2), (2, 8, 2)]:
         capi.set_gemv_config(cfg[0], cfg[1], 0, cfg[2])
-        for mode, name in ((0, "normal"), (1, "stream-only")):
+        for mode, name in ((0, "normal"), (1, "stream-only"), (4, "compute-only")):
             capi.check(L.tce_w4a16_set_debug_mode(mode))
             us = timeit(sets, len(segs))
             print(json.dumps({"segs": segs, "cfg": cfg, "mode": name, "us": round(us, 2)}), flush=True)
@@ -41,8 +41,10 @@ for (segs, K) in [([11008, 11008], 4096), ([128256], 4096), ([12288], 4096)]:
         capi.check(L.tce_w4a16_set_debug_buffer(C.c_void_p(buf.data_ptr()))); capi.check(L.tce_w4a16_set_debug_mode(2))
         for i in range(4): capi.check(L.tce_w4a16_forward_group(sets[i][0], len(segs), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         torch.cuda.synchronize()
-        t = buf.cpu().numpy().reshape(nw, 4).astype(np.float64) * 10.0; t = t[t[:, 0] > 0]; t -= t[:, 0].min()
+        raw = buf.cpu().numpy().reshape(nw, 4).astype(np.float64); raw = raw[raw[:, 0] > 0]
+        ghz = float(np.median(raw[:, 3] / ((raw[:, 2] - raw[:, 0]) * 10.0)))
+        t = raw * 10.0; t -= t[:, 0].min()
         q = lambda a: [round(float(np.percentile(a, p)) / 1e3, 2) for p in (0, 10, 50, 90, 100)]
-        print(json.dumps({"segs": segs, "cfg": cfg, "waves": len(t), "start_us": q(t[:, 0]), "x_ready_us": q(t[:, 1]), "end_us": q(t[:, 2])}), flush=True)
+        print(json.dumps({"segs": segs, "cfg": cfg, "waves": len(t), "start_us": q(t[:, 0]), "x_ready_us": q(t[:, 1]), "end_us": q(t[:, 2]), "shader_GHz": round(ghz, 3)}), flush=True)
         L.tce_w4a16_set_debug_mode(0); L.tce_w4a16_set_debug_buffer(None)
 capi.set_gemv_config()

@@ -18,6 +18,7 @@ TCE_W4A16_GEMV_MAX_M = 8
 TCE_MAX_GROUP = 4
 TCE_W4_FORCE_GEMV = 1
 TCE_W4_FORCE_GEMM = 2
+TCE_PLAN_CHAINED = 1
 TCE_W4_ZERO_POINT_IS_8 = 4
 TCE_BIAS_NONE, TCE_BIAS_INT8, TCE_BIAS_FP32 = 0, 1, 2
 TCE_OUT_INT8, TCE_OUT_FP32 = 0, 1
@@ -25,7 +26,7 @@ TCE_OUT_INT8, TCE_OUT_FP32 = 0, 1
 # every symbol include/tce_matmul.h declares (tests/test_boundary.py checks the .so exports exactly these)
 EXPORTS = [
     "tce_w4a16_forward", "tce_w4a16_forward_group", "tce_w4a16_check_zero_point_8", "tce_w4a16_awq_fp16acc", "tce_w4a16_awq_workspace_bytes",
-    "tce_w4a16_gemm_awq", "tce_w8a8_matmul", "tce_plan_create", "tce_plan_launch", "tce_plan_n_launches",
+    "tce_w4a16_gemm_awq", "tce_w8a8_matmul", "tce_plan_create", "tce_plan_create_ex", "tce_plan_is_chained", "tce_plan_geometry", "tce_plan_status", "tce_plan_launch", "tce_plan_n_launches",
     "tce_plan_destroy", "tce_version", "tce_last_error", "tce_build_info", "tce_w4a16_set_gemv_config",
     "tce_w4a16_set_gemm_config", "tce_w4a16_algorithmic_bytes", "tce_w4a16_gemv_variant", "tce_w4a16_gemm_variant",
     "tce_w4a16_set_debug_mode", "tce_w4a16_set_debug_buffer", "tce_malloc", "tce_free", "tce_memcpy", "tce_synchronize", "tce_device_count",
@@ -84,6 +85,10 @@ def lib() -> C.CDLL:
         L.tce_w4a16_gemm_awq.argtypes = [C.c_int] * 4 + [C.c_void_p] * 5 + [C.c_int, C.c_void_p]
         L.tce_w8a8_matmul.argtypes = [C.POINTER(W8A8Desc), C.c_void_p]
         L.tce_plan_create.argtypes = [C.POINTER(W4A16Desc), C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_void_p)]
+        L.tce_plan_create_ex.argtypes = [C.POINTER(W4A16Desc), C.POINTER(C.c_int32), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.tce_plan_is_chained.argtypes = [C.c_void_p]
+        L.tce_plan_status.argtypes = [C.c_void_p]
+        L.tce_plan_geometry.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 4
         L.tce_plan_launch.argtypes = [C.c_void_p, C.c_void_p]
         L.tce_plan_n_launches.argtypes = [C.c_void_p]
         L.tce_plan_destroy.argtypes = [C.c_void_p]
@@ -152,16 +157,29 @@ def gemm_variants() -> list[tuple[int, int]]:
 class Plan:
     """tce_plan: a fixed sequence of W4A16 launches captured into one hipGraph (one decode token's linears)."""
 
-    def __init__(self, launches: list[list[W4A16Desc]]):
+    def __init__(self, launches: list[list[W4A16Desc]], chained: bool = False):
+        """chained: TCE_PLAN_CHAINED -- same order and data dependences, but one persistent kernel walks the list with
+        device-wide barriers instead of kernel boundaries (include/tce_matmul.h)."""
         flat = [d for g in launches for d in g]
         self._descs = (W4A16Desc * len(flat))(*flat)
         self._groups = (C.c_int32 * len(launches))(*[len(g) for g in launches])
         self._h = C.c_void_p()
-        check(lib().tce_plan_create(self._descs, self._groups, len(launches), C.byref(self._h)))
+        check(lib().tce_plan_create_ex(self._descs, self._groups, len(launches), TCE_PLAN_CHAINED if chained else 0, C.byref(self._h)))
         self.n_launches = len(launches)
+        self.chained = bool(lib().tce_plan_is_chained(self._h))
 
     def launch(self, stream: int | None) -> None:
         check(lib().tce_plan_launch(self._h, C.c_void_p(stream or 0)))
+
+    def geometry(self) -> dict:
+        """Chained plans: what the token kernel runs with."""
+        v = [C.c_int() for _ in range(4)]
+        check(lib().tce_plan_geometry(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("rows", "depth", "waves", "workgroups"), (x.value for x in v)))
+
+    def status(self) -> None:
+        """Synchronise and raise if a chained launch ever gave up waiting for its predecessor."""
+        check(lib().tce_plan_status(self._h))
 
     def close(self) -> None:
         if self._h:

@@ -75,7 +75,7 @@ int tce_w4a16_set_gemv_config(int rows, int wn, int wk, int depth) {
         return TCE_OK;
     }
     if (wk == 0) {  // persistent stream kernel: rows per unit, waves per workgroup, units in flight
-        if ((rows != 1 && rows != 2) || wn < 1 || wn > 16 || (depth != 0 && depth != 2 && depth != 3))
+        if ((rows % 10 != 0 && rows % 10 != 1 && rows % 10 != 2 && rows % 10 != 4) || rows < 0 || rows >= 90 || wn < 1 || wn > 16 || (depth != 0 && depth != 2 && depth != 3))
             return fail(TCE_ERR_BAD_ARG, "stream GEMV config rows=%d waves=%d depth=%d is not available", rows, wn, depth);
         tce::set_gemv_stream_config(rows, wn, depth);
         g_gemv_kernel = 2;
@@ -93,7 +93,7 @@ int tce_w4a16_set_gemv_config(int rows, int wn, int wk, int depth) {
 }
 
 int tce_w4a16_set_debug_mode(int mode) {
-    if (mode < 0 || mode > 3) return fail(TCE_ERR_BAD_ARG, "debug mode %d", mode);
+    if (mode < 0 || mode > 4) return fail(TCE_ERR_BAD_ARG, "debug mode %d", mode);
     tce::set_gemv_debug_mode(mode);
     tce::set_gemv_stream_debug(mode, g_dbg_buf_capi);
     g_debug_mode_capi = mode;
@@ -185,10 +185,13 @@ int tce_w4a16_forward_group(const tce_w4a16_desc *descs, int count, void *stream
             return fail(TCE_ERR_BAD_ARG, "grouped linears must share M, K, group size and the activation");
     }
     hipError_t he = hipSuccess;
-    // Kernel choice: the workgroup-per-row-block kernel unless the persistent stream kernel is forced through
-    // tce_w4a16_set_gemv_config(rows, waves, 0, depth).  The stream kernel is correct and tested, but on MI355X it
-    // measured slower or equal on every decode shape (profiles/r1/stream_vs_rowblock.jsonl), so it is opt-in.
-    const bool use_stream = g_gemv_kernel == 2;
+    // Kernel choice: the workgroup-per-row-block kernel or the persistent one (w4a16_gemv_stream.hip); either can be
+    // forced through tce_w4a16_set_gemv_config (waves_k == 0 selects the persistent kernel).
+    // Automatic choice (measured, profiles/r1/stream_sweep.jsonl): the persistent kernel wins from ~100M weights per
+    // launch up (Llama-3 gate+up 14.5 vs 16.4 us, the 128k-row lm_head 50 vs 57 us) and loses 5-10 % below that.
+    long long weights = 0;
+    for (int i = 0; i < count; ++i) weights += (long long)descs[i].N * descs[i].K;
+    const bool use_stream = g_gemv_kernel == 2 || (g_gemv_kernel == 0 && descs[0].M == 1 && weights >= 100000000LL && g_debug_mode_capi == 0);
     if (use_stream) {
         const int rc = tce::launch_w4a16_gemv_stream(descs, count, static_cast<hipStream_t>(stream), &he);
         if (rc == TCE_OK) return TCE_OK;
@@ -291,10 +294,20 @@ struct tce_plan {
     std::vector<int32_t> groups;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    tce::TokenPlan *token = nullptr;  // chained plans: the device-side launch list of the token kernel
 };
 
-int tce_plan_create(const tce_w4a16_desc *descs, const int32_t *group_sizes, int n_launches, tce_plan **out) {
+static void plan_free(tce_plan *p) {
+    if (!p) return;
+    if (p->exec) (void)hipGraphExecDestroy(p->exec);
+    if (p->graph) (void)hipGraphDestroy(p->graph);
+    tce::token_plan_destroy(p->token);
+    delete p;
+}
+
+int tce_plan_create_ex(const tce_w4a16_desc *descs, const int32_t *group_sizes, int n_launches, int flags, tce_plan **out) {
     if (!descs || !group_sizes || n_launches < 1 || !out) return fail(TCE_ERR_BAD_ARG, "bad argument");
+    if (flags & ~TCE_PLAN_CHAINED) return fail(TCE_ERR_BAD_ARG, "unknown plan flags 0x%x", flags);
     tce_plan *p = new (std::nothrow) tce_plan();
     if (!p) return fail(TCE_ERR_BAD_ARG, "out of host memory");
     int total = 0;
@@ -308,42 +321,84 @@ int tce_plan_create(const tce_w4a16_desc *descs, const int32_t *group_sizes, int
     p->descs.assign(descs, descs + total);
     p->groups.assign(group_sizes, group_sizes + n_launches);
 
+    // Chained form: only if every launch is a valid GEMV group the persistent kernel takes (same checks as the
+    // unchained entry points), and there is something to overlap.
+    bool chained = (flags & TCE_PLAN_CHAINED) && n_launches > 1 && g_gemv_kernel != 1;
+    for (int i = 0, off = 0; i < n_launches && chained; off += p->groups[i], ++i)
+        for (int j = 0; j < p->groups[i] && chained; ++j) {
+            const tce_w4a16_desc &a = p->descs[off], &b = p->descs[off + j];
+            if (check_w4a16(&b) != TCE_OK || b.M != a.M || b.K != a.K || b.group_size != a.group_size || b.A != a.A || b.lda != a.lda ||
+                (b.flags & TCE_W4_FORCE_GEMM))
+                chained = false;
+        }
+    hipError_t he = hipSuccess;
+    if (chained) {
+        const int rc = tce::token_plan_create(p->descs.data(), p->groups.data(), n_launches, &p->token, &he);
+        if (rc == TCE_ERR_HIP) {
+            plan_free(p);
+            return hip_fail(he, "token plan");
+        }
+        if (rc != TCE_OK) p->token = nullptr;  // a launch the token kernel does not take: stream-ordered plan
+    }
+
     hipStream_t cap = nullptr;
     hipError_t e = hipStreamCreateWithFlags(&cap, hipStreamNonBlocking);
     if (e != hipSuccess) {
-        delete p;
+        plan_free(p);
         return hip_fail(e, "hipStreamCreate");
     }
     e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
     if (e != hipSuccess) {
         (void)hipStreamDestroy(cap);
-        delete p;
+        plan_free(p);
         return hip_fail(e, "hipStreamBeginCapture");
     }
-    int rc = TCE_OK, off = 0;
-    for (int i = 0; i < n_launches && rc == TCE_OK; ++i) {
-        rc = p->groups[i] == 1 ? tce_w4a16_forward(&p->descs[off], cap) : tce_w4a16_forward_group(&p->descs[off], p->groups[i], cap);
-        off += p->groups[i];
+    int rc = TCE_OK;
+    if (p->token) {
+        rc = tce::token_plan_enqueue(p->token, cap, &he);
+    } else {
+        for (int i = 0, off = 0; i < n_launches && rc == TCE_OK; off += p->groups[i], ++i)
+            rc = p->groups[i] == 1 ? tce_w4a16_forward(&p->descs[off], cap) : tce_w4a16_forward_group(&p->descs[off], p->groups[i], cap);
     }
     e = hipStreamEndCapture(cap, &p->graph);
     (void)hipStreamDestroy(cap);
     if (rc != TCE_OK) {
-        if (p->graph) (void)hipGraphDestroy(p->graph);
-        delete p;
-        return rc;
+        plan_free(p);
+        return rc == TCE_ERR_HIP && he != hipSuccess ? hip_fail(he, "token kernel launch") : rc;
     }
     if (e != hipSuccess) {
-        delete p;
+        plan_free(p);
         return hip_fail(e, "hipStreamEndCapture");
     }
     e = hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0);
     if (e != hipSuccess) {
-        (void)hipGraphDestroy(p->graph);
-        delete p;
+        plan_free(p);
         return hip_fail(e, "hipGraphInstantiate");
     }
     *out = p;
     return TCE_OK;
+}
+
+int tce_plan_create(const tce_w4a16_desc *descs, const int32_t *group_sizes, int n_launches, tce_plan **out) {
+    return tce_plan_create_ex(descs, group_sizes, n_launches, 0, out);
+}
+
+int tce_plan_is_chained(const tce_plan *plan) { return plan && plan->token ? 1 : 0; }
+
+int tce_plan_geometry(const tce_plan *plan, int *rows, int *depth, int *waves, int *workgroups) {
+    if (!plan || !plan->token || !rows || !depth || !waves || !workgroups) return fail(TCE_ERR_BAD_ARG, "not a chained plan");
+    tce::token_plan_geometry(plan->token, rows, depth, waves, workgroups);
+    return TCE_OK;
+}
+
+int tce_plan_status(tce_plan *plan) {
+    if (!plan) return fail(TCE_ERR_BAD_ARG, "null plan");
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return hip_fail(e, "hipDeviceSynchronize");
+    if (!plan->token) return TCE_OK;
+    unsigned status = 0;
+    if (tce::token_plan_status(plan->token, &status, &e) != TCE_OK) return hip_fail(e, "hipMemcpy");
+    return status == 0 ? TCE_OK : fail(TCE_ERR_HIP, "chained plan: a device-wide barrier timed out");
 }
 
 int tce_plan_launch(tce_plan *plan, void *stream) {
@@ -354,11 +409,6 @@ int tce_plan_launch(tce_plan *plan, void *stream) {
 
 int tce_plan_n_launches(const tce_plan *plan) { return plan ? (int)plan->groups.size() : 0; }
 
-void tce_plan_destroy(tce_plan *plan) {
-    if (!plan) return;
-    if (plan->exec) (void)hipGraphExecDestroy(plan->exec);
-    if (plan->graph) (void)hipGraphDestroy(plan->graph);
-    delete plan;
-}
+void tce_plan_destroy(tce_plan *plan) { plan_free(plan); }
 
 }  // extern "C"

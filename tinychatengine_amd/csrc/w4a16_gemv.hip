@@ -120,6 +120,14 @@ __global__ __launch_bounds__(64 * WN * WK, (MB * ROWS * DEPTH >= 8 ? 2 : (MB * R
         st.g = g;
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) {
+            if constexpr (MODE == 4) {  // diagnostics: no weight traffic, the unpack/MFMA work runs on synthetic registers
+                const unsigned v = (unsigned)(cc * 16 + so_w[i]) * 2654435761u;
+                st.w[i] = uint4_t{v, v ^ 0x9E3779B9u, v * 3u, v * 5u};
+                st.s[i] = (unsigned short)0x2000;
+                st.z[i] = 0x88888888u;
+                asm volatile("" : "+v"(st.w[i]));
+                continue;
+            }
             st.w[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, cc * 16, so_w[i], /*nt*/ 2);
             if constexpr (MODE == 1) {
                 st.s[i] = 0x2000;
@@ -374,6 +382,7 @@ hipError_t launch_variant(const GemvArgs &a, int total_blocks, int m_blocks, hip
             if (g_debug_mode == 1) return launch_one<1, ROWS, WN, WK, DEPTH, 8, 1>(a, total_blocks, m_blocks, stream);
             if (g_debug_mode == 2) return launch_one<1, ROWS, WN, WK, DEPTH, 2, 2>(a, total_blocks, m_blocks, stream);
             if (g_debug_mode == 3) return launch_one<1, ROWS, WN, WK, DEPTH, 2, 3>(a, total_blocks, m_blocks, stream);
+            if (g_debug_mode == 4) return launch_one<1, ROWS, WN, WK, DEPTH, 2, 4>(a, total_blocks, m_blocks, stream);
         }
         // MODE 3 = "x first": the workgroup stages x completely before it issues its first weight load.  When the whole
         // grid is resident at once (one generation of workgroups) this keeps the x loads from queueing behind HBM-bound

@@ -1,361 +1,418 @@
-// w4a16_gemv_stream.hip -- the persistent ("streaming") form of the W4A16 decode GEMV for gfx950.
+// w4a16_gemv_stream.hip -- persistent W4A16 dequant-GEMV for gfx950 (MI355X), M = 1.
 //
-// Same math, layout and unpack/dot scheme as w4a16_gemv.hip (read its header first); what changes is the work
-// distribution, because per-wave timestamps of that kernel (DESIGN.md "GEMV timeline", profiles/r1/timeline.jsonl)
-// showed where a large launch loses its time:
-//   * resident capacity is 4 waves/SIMD = 1024 four-wave workgroups; 1376 workgroups therefore run as a full first
-//     generation and a 34 %-full second one that still costs a whole workgroup lifetime (~5 us);
-//   * every workgroup re-stages the activation vector, and those x loads queue behind the weight loads already in the
-//     CU's memory pipeline: median 1.7 us (p90 4.6 us) from wave start to the barrier.
-// Here ONE workgroup per CU (up to 16 waves) stages x once, then each wave walks its own sequence of row groups
-//     rg = gw, gw + W, gw + 2W, ...        (gw = global wave index, W = waves in the grid)
-// with a ring of DEPTH units (one unit = ROWS rows x one 1-KiB step) always in flight, so loads, unpack and MFMAs of
-// different units overlap inside a wave and across the 4 waves of a SIMD.  The host picks ROWS in {1,2} and the wave
-// count per workgroup (<= 16) that make ceil(n_rg / W) * W closest to n_rg.  Units past the end of a wave's list are
-// issued with an out-of-range buffer offset -- the hardware returns zeros without touching memory -- so the loop body
-// has no divergent or conditional loads and every s_waitcnt the compiler places is an exact count.
+// Same math and data layout as w4a16_gemv.hip (reference kernels/cuda/gemv_cuda.cu:140-194 behind
+// MatmulOperator::gemv_forward_cuda; read that file's header for the unpack / MFMA-diagonal scheme), different work
+// distribution:
+//
+//   * ONE GENERATION   the grid is at most (CUs x workgroups-per-CU) workgroups, all resident at once.  Wave `gw` of
+//                      the launch owns row groups gw, gw+W, gw+2W, ... (a row group = ROWS consecutive output rows of
+//                      one linear of the group; W = waves in the launch), so consecutive waves stream consecutive rows,
+//                      every wave gets the same number of row groups +-1, and there is no second, nearly empty
+//                      generation of workgroups (the 2-3 us tail of the workgroup-per-row-block kernel).
+//   * ONE X IMAGE      the activation vector is staged into LDS once per workgroup (not once per 32 rows), together
+//                      with the per-lane sums sum_k x_k of every 32-weight chunk that the zero-point correction needs
+//                      (computed once on the matrix pipe instead of 8 MFMAs per step).
+//   * RING             a wave keeps DEPTH steps (ROWS x 1 KiB of weights + scales/zeros each) in flight across row-group
+//                      boundaries; the issue side and the compute side each walk their own (row group, step) cursor with
+//                      "sticky" per-linear state in SGPRs, so nothing but the loaded registers travels through the ring.
+//   * TOKEN KERNEL     (w4a16_gemv_token_kernel, chained plans) ONE launch of the same workgroups walks a whole list of
+//                      GEMV launches -- a decode token's linears.  Between two launches of the list there is a
+//                      device-wide barrier instead of a kernel boundary: a workgroup that has finished launch j issues
+//                      the first DEPTH steps of launch j+1's WEIGHTS (they depend on nothing), then waits until every
+//                      workgroup has published its outputs of launch j, and only then reads its activations.  Launch
+//                      ramp and first-byte HBM latency vanish from the token's critical path; the data dependence is
+//                      exactly the stream-ordered one.  All workgroups are resident at once (the host checks the
+//                      occupancy), so the barrier cannot deadlock; a wait that lasts ~2 s gives up and flags the plan.
 #include "tce_common.hpp"
 #include "w4a16_kernels.hpp"
+
+#include <new>
+#include <vector>
 
 namespace tce {
 
 namespace {
 
 struct StreamArgs {
-    const half_t *A;
-    int lda, M, K, log2g;
-    int nseg;
-    int n_rg;  // total row groups over all segments
+    StreamLaunch launch;
     unsigned long long *dbg;  // MODE 2 only
-    GemvSeg seg[TCE_MAX_GROUP];  // block_begin = first row group of the segment
 };
 
-template <typename T>
-__device__ __forceinline__ T pick4(int i, T a, T b, T c, T d) {
-    return i == 0 ? a : (i == 1 ? b : (i == 2 ? c : d));
-}
+struct TokenArgs {
+    const StreamLaunch *launches;  // device memory
+    int n_launches;
+    unsigned *arrive;  // [n_launches] workgroup arrival counters, zero before the kernel starts
+    unsigned *status;  // set to 1 if a barrier wait timed out
+};
 
-template <int MB, int ROWS, int DEPTH, int MODE = 0>
-__global__ __launch_bounds__(1024) void w4a16_gemv_stream_kernel(const StreamArgs args) {
-    unsigned long long ts0 = 0, ts1 = 0;
-    if constexpr (MODE == 2) ts0 = wall_clock64();
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// How one launch of the list is ordered against its predecessor.
+struct Barrier {
+    unsigned *arrive_prev;  // null: first launch / single launch (activations first, nothing to wait for)
+    unsigned *arrive_here;  // null: nobody comes after this launch
+    unsigned *status;
+};
+
+// One GEMV launch, executed by all waves of the (persistent) grid.  MODE: 0 = the GEMV.  Diagnostics
+// (tce_w4a16_set_debug_mode): 1 = stream the weights only, 2 = GEMV + per-wave timestamps, 4 = unpack/MFMA only.
+template <int ROWS, int DEPTH, bool Z8, int MODE>
+__device__ __forceinline__ void gemv_launch_body(const StreamLaunch &L, const Barrier bar, unsigned char *smem, unsigned long long *ts_x_ready) {
     const int tid = threadIdx.x;
     const int nthreads = blockDim.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NW = nthreads >> 6;
-    const int gw = blockIdx.x * NW + wave;  // global wave index
+    const int gw = blockIdx.x * NW + wave;  // wave index in the grid
     const int W = gridDim.x * NW;
 
-    const int K = args.K;
-    const int nchunks = K >> 5;
-    const int T = (nchunks + 63) >> 6;
-    const int gshift = args.log2g - 5;
-    const int m0 = blockIdx.y * MB;
+    const int K = L.K;
+    const int nseg = L.nseg;
+    const int nchunks = K >> 5;           // 16-byte chunks per weight row
+    const int T = (nchunks + 63) >> 6;    // steps per row group
+    const int gshift = L.log2g - 5;       // chunk -> quantization group
     const int rowbytes = nchunks * 16;
+    const int n_rg = L.n_rg;
+    const int U = gw < n_rg ? ((n_rg - gw + W - 1) / W) * T : 0;  // steps of this wave
+    const half_t *A = L.A;
 
-    // ---- cursors (all wave-uniform) ----
-    struct Cursor {
-        int rg, t;
-    };
-    Cursor ci{gw, 0};  // next unit to issue
-
+    // ---------------------------------------------------------------------------------------------------------------
+    // issue side
+    // ---------------------------------------------------------------------------------------------------------------
     struct Step {
         uint4_t w[ROWS];
         unsigned short s[ROWS];
         unsigned z[ROWS];
-        int g;       // per lane: quantization group of the lane's chunk
-        // wave-uniform bookkeeping of the unit (lives in SGPRs)
-        int t;       // step within the row group
-        bool live;   // false: a padding unit past the end of this wave's list (loads were answered with zeros)
-        half_t *C;   // output pointer / extent of the unit's segment, needed when the row group completes
-        int segN, ldc, row0;
     };
-    // "Sticky" segment state: the descriptors of the linear the issue cursor is in.  A wave's row groups only move
-    // forward, so this is re-read from the kernel arguments a handful of times per launch, not per unit (re-deriving it
-    // per unit cost ~175 scalar instructions and two dozen branches per unit in the first version of this kernel).
-    int cur_si = 0;
-    int cur_end = args.nseg > 1 ? args.seg[1].block_begin : args.n_rg;  // first row group past the current segment
-    const uint4_t *cur_qw = args.seg[0].qweight;
-    const half_t *cur_sc = args.seg[0].scales;
-    const unsigned *cur_zp = args.seg[0].zeros;
-    half_t *cur_C = args.seg[0].C;
-    int cur_N = args.seg[0].N, cur_ldc = args.seg[0].ldc, cur_sstr = args.seg[0].scales_stride * 2,
-        cur_zstr = args.seg[0].zeros_stride * 4, cur_rgb = 0;
-    auto issue = [&](Step &st) {
-        const int rg = ci.rg, t = ci.t;
-        const bool live = rg < args.n_rg;
-        if (live && rg >= cur_end) {  // uniform, rare: advance to the segment that contains rg
-            do {
-                ++cur_si;
-                cur_end = cur_si + 1 < args.nseg ? args.seg[cur_si + 1].block_begin : args.n_rg;
-            } while (rg >= cur_end);
-            const GemvSeg &sg = args.seg[cur_si];
-            cur_qw = sg.qweight;
-            cur_sc = sg.scales;
-            cur_zp = sg.zeros;
-            cur_C = sg.C;
-            cur_N = sg.N;
-            cur_ldc = sg.ldc;
-            cur_sstr = sg.scales_stride * 2;
-            cur_zstr = sg.zeros_stride * 4;
-            cur_rgb = sg.block_begin;
+    int i_rg = gw, i_t = 0;            // cursor: next step to issue
+    int i_si = 0, i_begin = 0;         // sticky: the linear that contains i_rg
+    int i_end = nseg > 1 ? L.seg[1].block_begin : n_rg;
+    int i_N = L.seg[0].N, i_sstr = L.seg[0].scales_stride * 2, i_zstr = L.seg[0].zeros_stride * 4;
+    // num_records is a constant just below 2 GiB: real extents were checked on the host, and a padding step uses an
+    // offset above it, which the buffer unit answers with zeros and no memory request
+    __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4_t *>(L.seg[0].qweight), 0, 0x7FFFFFF0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(L.seg[0].scales), 0, 0x7FFFFFF0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(L.seg[0].zeros), 0, 0x7FFFFFF0, 0x00020000);
+    int so_w[ROWS], so_s[ROWS], so_z[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) so_w[i] = so_s[i] = so_z[i] = 0;
+
+    auto issue = [&](Step &st, int u) {
+        const bool live = u < U;  // wave-uniform; past the end: padding (no memory traffic)
+        if (live && i_t == 0) {   // a new row group: row offsets into SGPRs, once per T steps
+            if (i_rg >= i_end) {  // rare: the row group belongs to a later linear of the group
+                do {
+                    ++i_si;
+                    i_begin = i_end;
+                    i_end = i_si + 1 < nseg ? L.seg[i_si + 1].block_begin : n_rg;
+                } while (i_rg >= i_end);
+                const GemvSeg &sg = L.seg[i_si];
+                i_N = sg.N;
+                i_sstr = sg.scales_stride * 2;
+                i_zstr = sg.zeros_stride * 4;
+                rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4_t *>(sg.qweight), 0, 0x7FFFFFF0, 0x00020000);
+                rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(sg.scales), 0, 0x7FFFFFF0, 0x00020000);
+                rs_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(sg.zeros), 0, 0x7FFFFFF0, 0x00020000);
+            }
+#pragma unroll
+            for (int i = 0; i < ROWS; ++i) {
+                int r = (i_rg - i_begin) * ROWS + i;
+                r = r < i_N ? r : i_N - 1;  // clamped; the store is masked
+                so_w[i] = r * rowbytes;
+                so_s[i] = r * i_sstr;
+                so_z[i] = r * i_zstr;
+            }
         }
-        // num_records is a constant just below 2 GiB: real extents were checked on the host, and a padding unit uses an
-        // offset above it, which the buffer unit answers with zeros and no memory request
-        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4_t *>(cur_qw), 0, 0x7FFFFFF0, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(cur_sc), 0, 0x7FFFFFF0, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(cur_zp), 0, 0x7FFFFFF0, 0x00020000);
-        const int c = t * 64 + lane;
+        const int c = i_t * 64 + lane;
         const int cc = c < nchunks ? c : nchunks - 1;  // tail lanes re-read the last chunk; their x image is zero
         const int g = cc >> gshift;
-        st.g = g;
-        st.t = t;
-        st.live = live;
-        st.C = cur_C;
-        st.segN = cur_N;
-        st.ldc = cur_ldc;
-        const int row0 = live ? (rg - cur_rgb) * ROWS : 0;
-        st.row0 = row0;
         const int oob = live ? 0 : (int)0x7FFFFFF0;
         const int vo_w = cc * 16 + oob, vo_s = g * 2 + oob, vo_z = (g >> 3) * 4 + oob;
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) {
-            int r = row0 + i;
-            r = r < cur_N ? r : cur_N - 1;  // clamped; the store is masked
-            st.w[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, vo_w, r * rowbytes, /*nt*/ 2);
-            st.s[i] = __builtin_amdgcn_raw_buffer_load_b16(rs_s, vo_s, r * cur_sstr, 0);
-            st.z[i] = __builtin_amdgcn_raw_buffer_load_b32(rs_z, vo_z, r * cur_zstr, 0);
+            if constexpr (MODE == 4) {  // no weight traffic: the unpack/MFMA work runs on synthetic registers
+                const unsigned v = (unsigned)(vo_w + so_w[i]) * 2654435761u;
+                st.w[i] = uint4_t{v, v ^ 0x9E3779B9u, v * 3u, v * 5u};
+                st.s[i] = (unsigned short)0x2000;
+                st.z[i] = 0x88888888u;
+                asm volatile("" : "+v"(st.w[i]));
+                continue;
+            }
+            st.w[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, vo_w, so_w[i], /*nt*/ 2);
+            st.s[i] = __builtin_amdgcn_raw_buffer_load_b16(rs_s, vo_s, so_s[i], 0);
+            // Z8: the caller vouches (TCE_W4_ZERO_POINT_IS_8) that every zero point is 8 -- what the reference quantizer
+            // always writes (quantize_methods.py:436-440) -- so the packed zeros are not streamed at all
+            if constexpr (Z8) st.z[i] = 0x88888888u;
+            else st.z[i] = __builtin_amdgcn_raw_buffer_load_b32(rs_z, vo_z, so_z[i], 0);
         }
-        // advance
-        ci.t = t + 1;
-        if (ci.t == T) {
-            ci.t = 0;
-            ci.rg = rg + W;
+        if (live) {
+            if (++i_t == T) {
+                i_t = 0;
+                i_rg += W;
+            }
         }
     };
 
-    // ---- prologue: the one-time x staging FIRST (with empty memory queues it takes ~1 us; issued behind the first
-    // weight units its data cannot be consumed before theirs -- vmcnt retires in order -- and every wave idled 3.3-5 us,
-    // profiles/r1/timeline_stream.jsonl), then the weight stream ----
+    // ---------------------------------------------------------------------------------------------------------------
+    // prologue.  Behind a device-wide barrier: weights first (they do not depend on the predecessor), then the wait,
+    // then the activations.  Otherwise activations first: with empty memory queues the x image is ready in ~1 us;
+    // queued behind the first weight steps it took 3-5 us.
+    // ---------------------------------------------------------------------------------------------------------------
     Step st[DEPTH];
+    const bool behind_barrier = bar.arrive_prev != nullptr;  // grid-uniform
+    if (behind_barrier) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) issue(st[d], d);
+        __builtin_amdgcn_sched_barrier(0);
+        if (tid == 0) {
+            // ~1 us per probe; give up after ~2 s instead of hanging the device (and at once if another workgroup did)
+            const unsigned nblocks = gridDim.x;
+            int probes = 0;
+            while (__hip_atomic_load(bar.arrive_prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nblocks) {
+                __builtin_amdgcn_s_sleep(4);
+                if ((++probes & 1023) == 0) {
+                    if (__hip_atomic_load(bar.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                    if (probes > (1 << 21)) {
+                        __hip_atomic_store(bar.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // no cache-wide acquire here (a buffer_inv per wave made every barrier cost ~40 us): the activations are read
+        // with device-coherent loads below, and nothing else the predecessor wrote is read by this launch
+    }
 
-    uint4_t *xs = reinterpret_cast<uint4_t *>(smem);  // [MB][T][4][64] pieces of 16 bytes (pair-permuted, lane-linear)
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(A), 0, 0x7FFFFFF0, 0x00020000);
+    uint4_t *xs = reinterpret_cast<uint4_t *>(smem);                  // [T][4][64] pieces of 16 bytes (pair-permuted, lane-linear)
+    float *xsl = reinterpret_cast<float *>(smem + (size_t)T * 4096);  // [T][64]: sum of the 32 activations of (step, lane)
     {
-        const int pieces_per_m = T * 256;
-        const int total_pieces = MB * pieces_per_m;
-        // one piece per thread per round; threads without a piece load nothing (clamping surplus threads onto piece 0,
-        // as the row-block kernel does for its counted waits, made 3584 of 4096 threads hammer one L2 line here)
+        const int total_pieces = T * 256;
+        // one piece per thread per round; threads without a piece load nothing
         for (int p = tid; p < total_pieces; p += nthreads) {
-            const int m = MB == 1 ? 0 : p / pieces_per_m;
-            const int r = p - m * pieces_per_m;
-            const int c = (r >> 8) * 64 + (r & 63);
-            const int j = (r >> 6) & 3;
-            int mrow = m0 + m;
-            mrow = mrow < args.M ? mrow : args.M - 1;
+            const int c = (p >> 8) * 64 + (p & 63);
+            const int j = (p >> 6) & 3;
             uint4_t q = uint4_t{0u, 0u, 0u, 0u};
-            if (c < nchunks) q = pair_permute(*reinterpret_cast<const uint4_t *>(args.A + (size_t)mrow * args.lda + (c * 32 + j * 8)));
+            // sc0 sc1: device-coherent read -- the vector was written by other CUs (other XCDs, other L2s) moments ago,
+            // and this CU / this L2 may still hold the previous token's lines of the same buffer
+            if (c < nchunks) q = pair_permute(__builtin_amdgcn_raw_buffer_load_b128(rs_a, (c * 32 + j * 8) * 2, 0, /*sc0|sc1*/ 17));
             xs[p] = q;
         }
     }
     __syncthreads();
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) issue(st[d]);
-    if constexpr (MODE == 2) ts1 = wall_clock64();
-
-    float acc[ROWS][MB][4];
-    float corr[ROWS][MB];
-#pragma unroll
-    for (int i = 0; i < ROWS; ++i)
-#pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            corr[i][m] = 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[i][m][r] = 0.f;
-        }
-    unsigned mask_hi;
-    asm volatile("v_mov_b32 %0, 0x00F000F0" : "=v"(mask_hi));
-    const unsigned magic = 0x64006400u;
-    const half4_t ones = half4_t{(half_t)1.0f, (half_t)1.0f, (half_t)1.0f, (half_t)1.0f};
-    float diag[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) diag[q] = (lane & 3) == q ? 0.0625f : 0.0f;
-
-    auto compute = [&](const Step &st) {
-        if constexpr (MODE == 1) {  // diagnostics: consume the loads, skip the math
-#pragma unroll
-            for (int i = 0; i < ROWS; ++i) acc[i][0][0] += (float)((st.w[i].x ^ st.w[i].y ^ st.w[i].z ^ st.w[i].w ^ st.s[i] ^ st.z[i]) & 0xFFu);
-            if (st.t == T - 1 && st.live && lane == 63) st.C[st.row0] = (half_t)acc[0][0][0];
-            return;
-        }
-        const int t = st.t;
-        half4_t xb[MB][8];
-        float xsum[MB];
-#pragma unroll
-        for (int m = 0; m < MB; ++m) {
+    {
+        // D[i][j] = sum_k A_i[k] B_j[k] with A = ones: every accumulator register of a lane holds that lane's own sum
+        const half4_t ones = half4_t{(half_t)1.0f, (half_t)1.0f, (half_t)1.0f, (half_t)1.0f};
+        for (int t = wave; t < T; t += NW) {
             float4_t xs4 = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const uint4_t xp = xs[((m * T + t) * 4 + j) * 64 + lane];
-                xb[m][2 * j] = __builtin_bit_cast(half4_t, uint2_t{xp.x, xp.y});
-                xb[m][2 * j + 1] = __builtin_bit_cast(half4_t, uint2_t{xp.z, xp.w});
-                xs4 = __builtin_amdgcn_mfma_f32_4x4x4f16(ones, xb[m][2 * j], xs4, 0, 0, 0);
-                xs4 = __builtin_amdgcn_mfma_f32_4x4x4f16(ones, xb[m][2 * j + 1], xs4, 0, 0, 0);
+                const uint4_t xp = xs[(t * 4 + j) * 64 + lane];
+                xs4 = __builtin_amdgcn_mfma_f32_4x4x4f16(ones, __builtin_bit_cast(half4_t, uint2_t{xp.x, xp.y}), xs4, 0, 0, 0);
+                xs4 = __builtin_amdgcn_mfma_f32_4x4x4f16(ones, __builtin_bit_cast(half4_t, uint2_t{xp.z, xp.w}), xs4, 0, 0, 0);
             }
-            xsum[m] = xs4[0];
-        }
-        const int zsh = (st.g & 7) * 4;
-#pragma unroll
-        for (int i = 0; i < ROWS; ++i) {
-            __builtin_amdgcn_sched_barrier(0);
-            float4_t blk[MB];
-#pragma unroll
-            for (int m = 0; m < MB; ++m) blk[m] = float4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned w = st.w[i][j];
-                const unsigned t0 = ((w << 4) & mask_hi) | magic;
-                const unsigned t1 = (w & mask_hi) | magic;
-                const unsigned t2 = ((w >> 4) & mask_hi) | magic;
-                const unsigned t3 = ((w >> 8) & mask_hi) | magic;
-                const half4_t a0 = __builtin_bit_cast(half4_t, uint2_t{t0, t1});
-                const half4_t a1 = __builtin_bit_cast(half4_t, uint2_t{t2, t3});
-#pragma unroll
-                for (int m = 0; m < MB; ++m) {
-                    blk[m] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, xb[m][2 * j], blk[m], 0, 0, 0);
-                    blk[m] = __builtin_amdgcn_mfma_f32_4x4x4f16(a1, xb[m][2 * j + 1], blk[m], 0, 0, 0);
-                }
-            }
-            // a padding unit must contribute nothing even if an out-of-range load were not answered with zeros
-            const float s = st.live ? (float)__builtin_bit_cast(half_t, st.s[i]) : 0.0f;
-            const float cz = __builtin_fmaf((float)((st.z[i] >> zsh) & 0xFu), 16.0f, 1024.0f);
-            const float scz = s * cz;
-#pragma unroll
-            for (int m = 0; m < MB; ++m) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][m][r] = __builtin_fmaf(s, blk[m][r], acc[i][m][r]);
-                corr[i][m] = __builtin_fmaf(scz, xsum[m], corr[i][m]);
-            }
-        }
-        // ---- end of a row group: reduce over the 64 lanes, store, reset (wave-uniform branch) ----
-        if (t == T - 1) {
-            const bool live = st.live;
-            half_t *Cp = st.C;
-            const int segN = st.segN, ldc = st.ldc, row0 = st.row0;
-#pragma unroll
-            for (int i = 0; i < ROWS; ++i)
-#pragma unroll
-                for (int m = 0; m < MB; ++m) {
-                    float v = corr[i][m] * -0.0625f;
-                    v = __builtin_fmaf(acc[i][m][0], diag[0], v);
-                    v = __builtin_fmaf(acc[i][m][1], diag[1], v);
-                    v = __builtin_fmaf(acc[i][m][2], diag[2], v);
-                    v = __builtin_fmaf(acc[i][m][3], diag[3], v);
-                    v = wave_sum_dpp_lane63(v);  // total in lane 63
-                    if (lane == 63 && live && row0 + i < segN && m0 + m < args.M) Cp[(size_t)(m0 + m) * ldc + row0 + i] = (half_t)v;
-                    corr[i][m] = 0.f;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[i][m][r] = 0.f;
-                }
-        }
-    };
-
-    // ---- the stream: every wave runs the same number of ring rounds; units past its list are zero-traffic padding ----
-    const int iters = (args.n_rg + W - 1) / W;             // row groups per wave (last one may be padding)
-    const int units = iters * T;
-    for (int u = 0; u < units; u += DEPTH) {
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-            if (u + d < units) compute(st[d]);  // uniform
-            issue(st[d]);                       // past the end: padding (no memory traffic)
+            xsl[t * 64 + lane] = xs4[0];
         }
     }
+    __syncthreads();
+    if (!behind_barrier) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) issue(st[d], d);
+    }
+    if constexpr (MODE == 2) *ts_x_ready = wall_clock64();
+
+    // ---------------------------------------------------------------------------------------------------------------
+    // compute side
+    // ---------------------------------------------------------------------------------------------------------------
+    float acc[ROWS][4];  // the 4 accumulator registers of the 4x4x4 MFMA; the lane's own dot product is [lane & 3]
+    float corr[ROWS];    // sum over chunks of s * (1024 + 16 z) * sum_k x_k
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        corr[i] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+    }
+    unsigned mask_hi;  // nibble mask in a VGPR (tce_common.hpp: one scalar operand per VOP3 on gfx9)
+    asm volatile("v_mov_b32 %0, 0x00F000F0" : "=v"(mask_hi));
+    const unsigned magic = 0x64006400u;  // (1024.0h, 1024.0h)
+    float diag[4];                       // one-hot pick of the lane's diagonal accumulator and the final /16 in one factor
+#pragma unroll
+    for (int q = 0; q < 4; ++q) diag[q] = (lane & 3) == q ? 0.0625f : 0.0f;
+
+    int c_rg = gw, c_t = 0;  // cursor: next step to compute
+    int c_si = 0, c_begin = 0;
+    int c_end = nseg > 1 ? L.seg[1].block_begin : n_rg;
+    half_t *c_C = L.seg[0].C;
+    int c_N = L.seg[0].N;
+
+    auto compute = [&](const Step &st) {
+        const int t = c_t;
+        if constexpr (MODE == 1) {  // consume the loads, skip the math
+#pragma unroll
+            for (int i = 0; i < ROWS; ++i) acc[i][0] += (float)((st.w[i].x ^ st.w[i].y ^ st.w[i].z ^ st.w[i].w ^ st.s[i] ^ st.z[i]) & 0xFFu);
+        } else {
+            half4_t xb[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint4_t xp = xs[(t * 4 + j) * 64 + lane];
+                xb[2 * j] = __builtin_bit_cast(half4_t, uint2_t{xp.x, xp.y});      // (x0,x4,x1,x5) of word j
+                xb[2 * j + 1] = __builtin_bit_cast(half4_t, uint2_t{xp.z, xp.w});  // (x2,x6,x3,x7)
+            }
+            const float xsum = xsl[t * 64 + lane];
+            int zsh = 0;
+            if constexpr (!Z8) {
+                const int c = t * 64 + lane;
+                const int cc = c < nchunks ? c : nchunks - 1;
+                zsh = ((cc >> gshift) & 7) * 4;
+            }
+#pragma unroll
+            for (int i = 0; i < ROWS; ++i) {
+                // keep each row's unpack -> MFMA -> scale sequence together: without the fence the scheduler hoists all
+                // rows' unpacks ahead of the first MFMA and the register allocation explodes
+                __builtin_amdgcn_sched_barrier(0);
+                float4_t blk = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned w = st.w[i][j];
+                    const unsigned t0 = ((w << 4) & mask_hi) | magic;  // (1024+16 q0, 1024+16 q4)
+                    const unsigned t1 = (w & mask_hi) | magic;         // (q1, q5)
+                    const unsigned t2 = ((w >> 4) & mask_hi) | magic;  // (q2, q6)
+                    const unsigned t3 = ((w >> 8) & mask_hi) | magic;  // (q3, q7)
+                    blk = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(half4_t, uint2_t{t0, t1}), xb[2 * j], blk, 0, 0, 0);
+                    blk = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(half4_t, uint2_t{t2, t3}), xb[2 * j + 1], blk, 0, 0, 0);
+                }
+                // lanes 4b..4b+3 share a quantization group (32 weights per lane, groups of >= 32), so scaling all four
+                // accumulator registers by this lane's scale is consistent; the diagonal is picked at the row group's end
+                const float s = (float)__builtin_bit_cast(half_t, st.s[i]);
+                const float cz = Z8 ? 1152.0f : __builtin_fmaf((float)((st.z[i] >> zsh) & 0xFu), 16.0f, 1024.0f);  // 1024 + 16 z
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][r] = __builtin_fmaf(s, blk[r], acc[i][r]);
+                corr[i] = __builtin_fmaf(s * cz, xsum, corr[i]);
+            }
+        }
+        if (t != T - 1) {
+            c_t = t + 1;
+            return;
+        }
+        // ---- end of a row group: reduce over the 64 lanes, store, reset (wave-uniform branch) ----
+        if (c_rg >= c_end) {
+            do {
+                ++c_si;
+                c_begin = c_end;
+                c_end = c_si + 1 < nseg ? L.seg[c_si + 1].block_begin : n_rg;
+            } while (c_rg >= c_end);
+            c_C = L.seg[c_si].C;
+            c_N = L.seg[c_si].N;
+        }
+        const int row0 = (c_rg - c_begin) * ROWS;
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) {
+            float v = corr[i] * -0.0625f;
+            v = __builtin_fmaf(acc[i][0], diag[0], v);
+            v = __builtin_fmaf(acc[i][1], diag[1], v);
+            v = __builtin_fmaf(acc[i][2], diag[2], v);
+            v = __builtin_fmaf(acc[i][3], diag[3], v);
+            if constexpr (MODE == 1) v = acc[i][0];
+            v = wave_sum_dpp_lane63(v);  // total in lane 63
+            // device-scope (write-through) store: visible to the next launch's coherent reads without a cache flush
+            if (lane == 63 && row0 + i < c_N)
+                __hip_atomic_store(reinterpret_cast<unsigned short *>(c_C + row0 + i), __builtin_bit_cast(unsigned short, (half_t)v),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            corr[i] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+        }
+        c_t = 0;
+        c_rg += W;
+    };
+
+    // ---- the ring: slot d holds steps d, d+DEPTH, ...; the last round refills with padding ----
+    for (int u = 0; u < U; u += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            if (u + d < U) compute(st[d]);  // wave-uniform
+            issue(st[d], u + d + DEPTH);
+        }
+    }
+
+    if (bar.arrive_here) {
+        // every wave waits for its own write-through stores to be acknowledged, then the workgroup arrives.  No
+        // cache-wide release (buffer_wbl2): the outputs are the only data the next launch reads, and they went through.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // (also: everyone is done with the x image)
+        if (tid == 0) __hip_atomic_fetch_add(bar.arrive_here, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int ROWS, int DEPTH, bool Z8, int MODE = 0>
+__global__ __launch_bounds__(1024) void w4a16_gemv_stream_kernel(const StreamArgs args) {
+    unsigned long long ts0 = 0, ts1 = 0, cy0 = 0;
     if constexpr (MODE == 2) {
-        if (lane == 63 && args.dbg) {
-            unsigned long long *d = args.dbg + (size_t)gw * 4;
-            d[0] = ts0; d[1] = ts1; d[2] = wall_clock64(); d[3] = d[2];
+        ts0 = wall_clock64();
+        cy0 = clock64();
+    }
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    gemv_launch_body<ROWS, DEPTH, Z8, MODE>(args.launch, Barrier{nullptr, nullptr, nullptr}, smem, &ts1);
+    if constexpr (MODE == 2) {
+        if ((threadIdx.x & 63) == 63 && args.dbg) {
+            unsigned long long *d = args.dbg + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4;
+            d[0] = ts0; d[1] = ts1; d[2] = wall_clock64(); d[3] = clock64() - cy0;  // shader cycles, for the clock rate
         }
     }
 }
 
-template <int MB, int ROWS, int DEPTH, int MODE = 0>
-hipError_t launch_stream(const StreamArgs &a, int blocks, int nw, int m_blocks, hipStream_t stream) {
-    const int nchunks = a.K >> 5;
-    const int T = (nchunks + 63) / 64;
-    const size_t lds = (size_t)MB * T * 4096 + (size_t)64 * nw * 16;
-    auto kfn = w4a16_gemv_stream_kernel<MB, ROWS, DEPTH, MODE>;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
+// A whole list of launches (a decode token's linears) in one kernel; see the header.
+template <int ROWS, int DEPTH, bool Z8>
+__global__ __launch_bounds__(1024) void w4a16_gemv_token_kernel(const TokenArgs args) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = args.n_launches;
+    for (int j = 0; j < n; ++j) {
+        Barrier bar;
+        bar.arrive_prev = j > 0 ? args.arrive + (j - 1) : nullptr;
+        bar.arrive_here = j + 1 < n ? args.arrive + j : nullptr;
+        bar.status = args.status;
+        gemv_launch_body<ROWS, DEPTH, Z8, 0>(args.launches[j], bar, smem, nullptr);
     }
-    hipLaunchKernelGGL(kfn, dim3(blocks, m_blocks, 1), dim3(64 * nw, 1, 1), lds, stream, a);
-    return hipGetLastError();
 }
 
 int g_num_cus = 0;
-int g_stream_rows = 0, g_stream_nw = 0, g_stream_depth = 0;  // forced geometry (0 = automatic)
+int g_stream_rows = 0, g_stream_nw = 0, g_stream_depth = 0, g_stream_bpc = 0;  // forced geometry (0 = automatic)
 int g_stream_mode = 0;
 unsigned long long *g_stream_dbg = nullptr;
 
-}  // namespace
-
-void set_gemv_stream_debug(int mode, void *buf) {
-    g_stream_mode = mode;
-    g_stream_dbg = static_cast<unsigned long long *>(buf);
-}
-
-void set_gemv_stream_config(int rows, int nw, int depth) {
-    g_stream_rows = rows;
-    g_stream_nw = nw;
-    g_stream_depth = depth;
-}
-
-// Returns TCE_ERR_UNSUPPORTED_SHAPE when the persistent form does not apply (the caller then uses the workgroup-per-
-// row-block kernel of w4a16_gemv.hip).
-int launch_w4a16_gemv_stream(const tce_w4a16_desc *descs, int count, hipStream_t stream, hipError_t *hip_err) {
-    const tce_w4a16_desc &d0 = descs[0];
+int num_cus() {
     if (g_num_cus == 0) {
         int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return TCE_ERR_HIP;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
         g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    long total_n = 0;
-    for (int i = 0; i < count; ++i) total_n += descs[i].N;
-    const int nchunks = d0.K >> 5;
-    const int T = (nchunks + 63) / 64;
-    const int mb = d0.M >= 4 ? 4 : (d0.M >= 2 ? 2 : 1);
-    if (mb == 4) return TCE_ERR_UNSUPPORTED_SHAPE;  // 4 activation rows per pass do not fit 128 VGPRs here: row-block kernel
+    return g_num_cus;
+}
 
-    // ---- geometry: ROWS in {1,2}, nw waves per workgroup (one workgroup per CU), DEPTH units in flight ----
-    int rows = g_stream_rows, nw = g_stream_nw, depth = g_stream_depth;
-    if (rows == 0) {
-        double best = -1.0;
-        for (int r = 2; r >= 1; --r) {
-            long n_rg = 0;
-            for (int i = 0; i < count; ++i) n_rg += (descs[i].N + r - 1) / r;
-            for (int w = 16; w >= 8; --w) {
-                const long Wt = (long)g_num_cus * w;
-                const long it = (n_rg + Wt - 1) / Wt;
-                // balance x a mild preference for more waves (latency hiding) and for 2 rows per unit (x reuse)
-                const double eff = (double)n_rg / (double)(Wt * it) * (0.90 + 0.10 * w / 16.0) * (r == 2 ? 1.0 : 0.97);
-                if (eff > best) {
-                    best = eff;
-                    rows = r;
-                    nw = w;
-                }
-            }
-        }
-    }
-    if (depth == 0 || (mb * rows >= 4 && depth == 3)) depth = (mb * rows >= 4) ? 2 : 3;
-    if (rows != 1 && rows != 2) return TCE_ERR_BAD_ARG;
-    if (nw < 1 || nw > 16 || depth < 2 || depth > 3) return TCE_ERR_BAD_ARG;
+size_t lds_bytes(int K) { return (size_t)(((K >> 5) + 63) / 64) * (4096 + 256); }
 
-    StreamArgs a{};
+template <typename KFn>
+hipError_t set_lds(KFn kfn, size_t lds) {
+    if (lds <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+template <int ROWS, int DEPTH, bool Z8, int MODE = 0>
+hipError_t launch_stream(const StreamArgs &a, int blocks, int nw, hipStream_t stream) {
+    const size_t lds = lds_bytes(a.launch.K);
+    auto kfn = w4a16_gemv_stream_kernel<ROWS, DEPTH, Z8, MODE>;
+    hipError_t e = set_lds(kfn, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kfn, dim3(blocks, 1, 1), dim3(64 * nw, 1, 1), lds, stream, a);
+    return hipGetLastError();
+}
+
+// Fills one launch record; returns false if a linear does not fit the 2 GiB buffer-descriptor window.
+bool fill_launch(const tce_w4a16_desc *descs, int count, int rows, StreamLaunch *out, bool *z8) {
+    const tce_w4a16_desc &d0 = descs[0];
+    StreamLaunch &a = *out;
+    a = StreamLaunch{};
     a.A = static_cast<const half_t *>(d0.A);
-    a.lda = d0.lda ? d0.lda : d0.K;
-    a.M = d0.M;
     a.K = d0.K;
     a.log2g = d0.group_size == 128 ? 7 : (d0.group_size == 64 ? 6 : 5);
     a.nseg = count;
@@ -372,40 +429,233 @@ int launch_w4a16_gemv_stream(const tce_w4a16_desc *descs, int count, hipStream_t
         s.ldc = d.ldc ? d.ldc : d.N;
         s.scales_stride = d.scales_stride ? d.scales_stride : zw * 8;
         s.zeros_stride = d.zeros_stride ? d.zeros_stride : zw;
-        const long long bw = (long long)d.N * (d.K / 2), bs = (long long)d.N * s.scales_stride * 2, bz = (long long)d.N * s.zeros_stride * 4;
-        if (bw >= 0x7FFFFFF0LL || bs >= 0x7FFFFFF0LL || bz >= 0x7FFFFFF0LL) return TCE_ERR_UNSUPPORTED_SHAPE;
+        if ((long long)d.N * (d.K / 2) >= 0x7FFFFFF0LL || (long long)d.N * s.scales_stride * 2 >= 0x7FFFFFF0LL ||
+            (long long)d.N * s.zeros_stride * 4 >= 0x7FFFFFF0LL)
+            return false;
         s.block_begin = n_rg;
         n_rg += (d.N + rows - 1) / rows;
+        if (!(d.flags & TCE_W4_ZERO_POINT_IS_8)) *z8 = false;
     }
     for (int i = count; i < TCE_MAX_GROUP; ++i) a.seg[i] = a.seg[0];
     a.n_rg = n_rg;
+    return true;
+}
+
+// rows per row group: balance (every wave runs ceil(n_rg / W) row groups, the last one maybe empty) x a preference for
+// wide row groups (one x read and one set of addresses per ROWS rows), weighted by the bytes of each launch
+int pick_rows(const tce_w4a16_desc *descs, const int32_t *groups, int n_launches, long waves) {
+    double best = -1.0;
+    int rows = 2;
+    for (int r = 4; r >= 1; r >>= 1) {
+        double num = 0.0, den = 0.0;
+        for (int l = 0, off = 0; l < n_launches; off += groups[l], ++l) {
+            long n_rg = 0, n = 0;
+            for (int i = 0; i < groups[l]; ++i) {
+                n_rg += (descs[off + i].N + r - 1) / r;
+                n += descs[off + i].N;
+            }
+            const long it = (n_rg + waves - 1) / waves;
+            const double bytes = (double)n * descs[off].K;
+            num += bytes;
+            den += bytes * (double)(waves * it) / (double)n_rg;
+        }
+        const double eff = num / den * (r == 4 ? 1.0 : (r == 2 ? 0.94 : 0.85));
+        if (eff > best) {
+            best = eff;
+            rows = r;
+        }
+    }
+    return rows;
+}
+
+}  // namespace
+
+void set_gemv_stream_debug(int mode, void *buf) {
+    g_stream_mode = mode;
+    g_stream_dbg = static_cast<unsigned long long *>(buf);
+}
+
+void set_gemv_stream_config(int rows, int nw, int depth) {
+    g_stream_bpc = rows >= 10 ? rows / 10 : 0;  // tuning: rows = 10 * workgroups-per-CU + rows-per-row-group
+    g_stream_rows = rows % 10;
+    g_stream_nw = nw;
+    g_stream_depth = depth;
+}
+
+bool gemv_stream_supports(const tce_w4a16_desc *descs, int count) {
+    if (descs[0].M != 1) return false;
+    if (lds_bytes(descs[0].K) > 80 * 1024) return false;
+    StreamLaunch tmp;
+    bool z8 = true;
+    return fill_launch(descs, count, 1, &tmp, &z8);
+}
+
+// Returns TCE_ERR_UNSUPPORTED_SHAPE when the persistent form does not apply (the caller then uses the workgroup-per-
+// row-block kernel of w4a16_gemv.hip).
+int launch_w4a16_gemv_stream(const tce_w4a16_desc *descs, int count, hipStream_t stream, hipError_t *hip_err) {
+    if (!gemv_stream_supports(descs, count)) return TCE_ERR_UNSUPPORTED_SHAPE;
+    const int cus = num_cus();
+    if (cus == 0) return TCE_ERR_HIP;
+
+    // ---- geometry: two workgroups of 8 waves per CU (measured better than one of 16: the two run out of phase) ----
+    int rows = g_stream_rows, nw = g_stream_nw ? g_stream_nw : 8, depth = g_stream_depth;
+    int bpc = g_stream_bpc ? g_stream_bpc : 2;
+    if (bpc * nw > 32) bpc = 32 / nw > 0 ? 32 / nw : 1;  // 8 waves per SIMD at most
+    const int32_t one_group = count;
+    if (rows == 0) rows = pick_rows(descs, &one_group, 1, (long)cus * bpc * nw);
+    if (rows != 1 && rows != 2 && rows != 4) return TCE_ERR_BAD_ARG;
+    if (depth == 0) depth = rows == 1 ? 3 : 2;  // deeper rings measured slower: the memory system is oversubscribed as it is
+    if (rows == 4 && depth > 2) depth = 2;
+    if (nw < 1 || nw > 16 || depth < 2 || depth > 3) return TCE_ERR_BAD_ARG;
+
+    StreamArgs a{};
+    bool z8 = true;
+    if (!fill_launch(descs, count, rows, &a.launch, &z8)) return TCE_ERR_UNSUPPORTED_SHAPE;
     a.dbg = g_stream_dbg;
-    const size_t lds = (size_t)mb * T * 4096 + (size_t)64 * nw * 16;
-    if (lds > 160 * 1024) return TCE_ERR_UNSUPPORTED_SHAPE;
-    int blocks = g_num_cus;
-    if ((long)blocks * nw > n_rg) blocks = (n_rg + nw - 1) / nw;  // fewer row groups than waves
-    const int m_blocks = (d0.M + mb - 1) / mb;
+    int blocks = cus * bpc;
+    if ((long)blocks * nw > a.launch.n_rg) blocks = (a.launch.n_rg + nw - 1) / nw;  // fewer row groups than waves
 
     hipError_t e = hipSuccess;
     bool found = true;
-    if (mb == 1 && g_stream_mode != 0) {
-        if (rows == 2 && depth == 2) e = g_stream_mode == 1 ? launch_stream<1, 2, 2, 1>(a, blocks, nw, m_blocks, stream) : launch_stream<1, 2, 2, 2>(a, blocks, nw, m_blocks, stream);
-        else if (rows == 2 && depth == 3) e = g_stream_mode == 1 ? launch_stream<1, 2, 3, 1>(a, blocks, nw, m_blocks, stream) : launch_stream<1, 2, 3, 2>(a, blocks, nw, m_blocks, stream);
+    if (g_stream_mode != 0) {
+        const int md = g_stream_mode;
+        if (rows == 2 && depth == 2) e = md == 1 ? launch_stream<2, 2, false, 1>(a, blocks, nw, stream) : (md == 4 ? launch_stream<2, 2, false, 4>(a, blocks, nw, stream) : launch_stream<2, 2, false, 2>(a, blocks, nw, stream));
+        else if (rows == 4 && depth == 2) e = md == 1 ? launch_stream<4, 2, false, 1>(a, blocks, nw, stream) : (md == 4 ? launch_stream<4, 2, false, 4>(a, blocks, nw, stream) : launch_stream<4, 2, false, 2>(a, blocks, nw, stream));
         else return TCE_ERR_BAD_ARG;
-        if (e != hipSuccess) { if (hip_err) *hip_err = e; return TCE_ERR_HIP; }
-        return TCE_OK;
-    }
-#define TCE_S(MB_, R_, D_) \
-    if (mb == MB_ && rows == R_ && depth == D_) e = launch_stream<MB_, R_, D_>(a, blocks, nw, m_blocks, stream); else
-    TCE_S(1, 1, 2) TCE_S(1, 1, 3) TCE_S(1, 2, 2) TCE_S(1, 2, 3) TCE_S(2, 1, 2) TCE_S(2, 1, 3) TCE_S(2, 2, 2)
-    found = false;
+    } else {
+#define TCE_S(R_, D_) \
+    if (rows == R_ && depth == D_) e = z8 ? launch_stream<R_, D_, true>(a, blocks, nw, stream) : launch_stream<R_, D_, false>(a, blocks, nw, stream); else
+        TCE_S(1, 2) TCE_S(1, 3) TCE_S(2, 2) TCE_S(2, 3) TCE_S(4, 2)
+        found = false;
 #undef TCE_S
+    }
     if (!found) return TCE_ERR_BAD_ARG;
     if (e != hipSuccess) {
         if (hip_err) *hip_err = e;
         return TCE_ERR_HIP;
     }
     return TCE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Token plans: the launch list lives in device memory; one kernel walks it.
+// ---------------------------------------------------------------------------------------------------------------------
+struct TokenPlan {
+    StreamLaunch *launches = nullptr;  // device
+    unsigned *sync = nullptr;          // device: [n] arrival counters, [1] status
+    int n = 0, rows = 0, depth = 0, nw = 0, blocks = 0;
+    bool z8 = false;
+    size_t lds = 0;
+};
+
+void token_plan_destroy(TokenPlan *tp) {
+    if (!tp) return;
+    if (tp->launches) (void)hipFree(tp->launches);
+    if (tp->sync) (void)hipFree(tp->sync);
+    delete tp;
+}
+
+namespace {
+template <int ROWS, int DEPTH, bool Z8>
+hipError_t token_setup(const TokenPlan &tp, int *max_blocks_per_cu) {
+    auto kfn = w4a16_gemv_token_kernel<ROWS, DEPTH, Z8>;
+    hipError_t e = set_lds(kfn, tp.lds);
+    if (e != hipSuccess) return e;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(max_blocks_per_cu, kfn, 64 * tp.nw, tp.lds);
+}
+template <int ROWS, int DEPTH, bool Z8>
+hipError_t token_launch(const TokenPlan &tp, hipStream_t stream) {
+    TokenArgs a;
+    a.launches = tp.launches;
+    a.n_launches = tp.n;
+    a.arrive = tp.sync;
+    a.status = tp.sync + tp.n;
+    hipLaunchKernelGGL((w4a16_gemv_token_kernel<ROWS, DEPTH, Z8>), dim3(tp.blocks, 1, 1), dim3(64 * tp.nw, 1, 1), tp.lds, stream, a);
+    return hipGetLastError();
+}
+#define TCE_TOKEN_DISPATCH(FN, ...)                                                                 \
+    (tp.rows == 1 ? (tp.z8 ? FN<1, 3, true>(__VA_ARGS__) : FN<1, 3, false>(__VA_ARGS__))            \
+     : tp.rows == 2 ? (tp.depth == 3 ? (tp.z8 ? FN<2, 3, true>(__VA_ARGS__) : FN<2, 3, false>(__VA_ARGS__)) \
+                                     : (tp.z8 ? FN<2, 2, true>(__VA_ARGS__) : FN<2, 2, false>(__VA_ARGS__)))  \
+                    : (tp.z8 ? FN<4, 2, true>(__VA_ARGS__) : FN<4, 2, false>(__VA_ARGS__)))
+}  // namespace
+
+// Builds the device-side launch list.  Returns TCE_ERR_UNSUPPORTED_SHAPE if a launch is not an M = 1 GEMV this kernel takes.
+int token_plan_create(const tce_w4a16_desc *descs, const int32_t *groups, int n_launches, TokenPlan **out, hipError_t *hip_err) {
+    const int cus = num_cus();
+    if (cus == 0) return TCE_ERR_HIP;
+    int maxK = 0;
+    for (int l = 0, off = 0; l < n_launches; off += groups[l], ++l) {
+        if (!gemv_stream_supports(descs + off, groups[l])) return TCE_ERR_UNSUPPORTED_SHAPE;
+        if (descs[off].K > maxK) maxK = descs[off].K;
+    }
+    TokenPlan *tpp = new (std::nothrow) TokenPlan();
+    if (!tpp) return TCE_ERR_BAD_ARG;
+    TokenPlan &tp = *tpp;
+    tp.n = n_launches;
+    tp.nw = g_stream_nw ? g_stream_nw : 16;
+    int bpc = g_stream_bpc ? g_stream_bpc : 1;
+    if (bpc * tp.nw > 16) bpc = 16 / tp.nw > 0 ? 16 / tp.nw : 1;
+    tp.rows = g_stream_rows ? g_stream_rows : pick_rows(descs, groups, n_launches, (long)cus * bpc * tp.nw);
+    tp.depth = g_stream_depth ? g_stream_depth : (tp.rows == 4 ? 2 : 3);
+    if (tp.rows == 4) tp.depth = 2;
+    if (tp.rows == 1) tp.depth = 3;
+    tp.lds = lds_bytes(maxK);
+    tp.z8 = true;
+    std::vector<StreamLaunch> host(n_launches);
+    for (int l = 0, off = 0; l < n_launches; off += groups[l], ++l)
+        if (!fill_launch(descs + off, groups[l], tp.rows, &host[l], &tp.z8)) {
+            token_plan_destroy(tpp);
+            return TCE_ERR_UNSUPPORTED_SHAPE;
+        }
+    // every workgroup must be resident at once: the barrier between launches spins
+    int per_cu = 0;
+    hipError_t e = TCE_TOKEN_DISPATCH(token_setup, tp, &per_cu);
+    if (e == hipSuccess && per_cu < 1) {
+        token_plan_destroy(tpp);
+        return TCE_ERR_UNSUPPORTED_SHAPE;
+    }
+    if (per_cu < bpc) bpc = per_cu;
+    tp.blocks = cus * bpc;
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&tp.launches), sizeof(StreamLaunch) * n_launches);
+    if (e == hipSuccess) e = hipMemcpy(tp.launches, host.data(), sizeof(StreamLaunch) * n_launches, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&tp.sync), sizeof(unsigned) * (n_launches + 1));
+    if (e == hipSuccess) e = hipMemset(tp.sync, 0, sizeof(unsigned) * (n_launches + 1));
+    if (e != hipSuccess) {
+        if (hip_err) *hip_err = e;
+        token_plan_destroy(tpp);
+        return TCE_ERR_HIP;
+    }
+    *out = tpp;
+    return TCE_OK;
+}
+
+// Enqueues the token: the arrival counters are cleared, then one kernel runs the whole list.
+int token_plan_enqueue(TokenPlan *tpp, hipStream_t stream, hipError_t *hip_err) {
+    const TokenPlan &tp = *tpp;
+    hipError_t e = hipMemsetAsync(tp.sync, 0, sizeof(unsigned) * tp.n, stream);
+    if (e == hipSuccess) e = TCE_TOKEN_DISPATCH(token_launch, tp, stream);
+    if (e != hipSuccess) {
+        if (hip_err) *hip_err = e;
+        return TCE_ERR_HIP;
+    }
+    return TCE_OK;
+}
+
+int token_plan_status(TokenPlan *tp, unsigned *status, hipError_t *hip_err) {
+    const hipError_t e = hipMemcpy(status, tp->sync + tp->n, sizeof(unsigned), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+        if (hip_err) *hip_err = e;
+        return TCE_ERR_HIP;
+    }
+    return TCE_OK;
+}
+
+void token_plan_geometry(const TokenPlan *tp, int *rows, int *depth, int *waves, int *blocks) {
+    *rows = tp->rows;
+    *depth = tp->depth;
+    *waves = tp->nw;
+    *blocks = tp->blocks;
 }
 
 }  // namespace tce

@@ -45,10 +45,26 @@ bool gemv_variant_exists(int rows, int wn, int wk, int depth);
 void set_gemv_debug_mode(int mode);
 void set_gemv_debug_buffer(void *p);
 
-// persistent ("streaming") form, w4a16_gemv_stream.hip
+// persistent form, w4a16_gemv_stream.hip
+// One GEMV launch (up to TCE_MAX_GROUP linears sharing the activation) as the persistent kernels read it.
+struct StreamLaunch {
+    const half_t *A;  // fp16 [K]
+    int K, log2g;
+    int nseg;
+    int n_rg;                    // row groups over all linears of the launch
+    GemvSeg seg[TCE_MAX_GROUP];  // block_begin = first row group of the linear
+};
 void set_gemv_stream_config(int rows, int nw, int depth);
 void set_gemv_stream_debug(int mode, void *buf);
+bool gemv_stream_supports(const tce_w4a16_desc *descs, int count);
 int launch_w4a16_gemv_stream(const tce_w4a16_desc *descs, int count, hipStream_t stream, hipError_t *hip_err);
+// token plans: a list of launches walked by ONE persistent kernel with device-wide barriers in between
+struct TokenPlan;
+int token_plan_create(const tce_w4a16_desc *descs, const int32_t *groups, int n_launches, TokenPlan **out, hipError_t *hip_err);
+int token_plan_enqueue(TokenPlan *tp, hipStream_t stream, hipError_t *hip_err);
+int token_plan_status(TokenPlan *tp, unsigned *status, hipError_t *hip_err);
+void token_plan_geometry(const TokenPlan *tp, int *rows, int *depth, int *waves, int *blocks);
+void token_plan_destroy(TokenPlan *tp);
 int launch_w4a16_gemv(const tce_w4a16_desc *descs, int count, int forced_rows, int forced_wn, int forced_wk,
                       int forced_depth, hipStream_t stream, hipError_t *hip_err);
 
