@@ -4,12 +4,12 @@ import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from overlap_exp import mk, timeit, L, capi
 def main():
-    for (segs, K) in [([11008, 11008], 4096), ([12288], 4096), ([4096], 11008), ([14336, 14336], 4096)]:
+    for (segs, K) in [([11008, 11008], 4096), ([12288], 4096), ([4096], 4096), ([4096], 11008), ([14336, 14336], 4096), ([128256], 4096)]:
         sets = mk(segs, K, reps=24 if sum(segs) < 100000 else 5)
         row = {"segs": segs, "K": K}
         capi.set_gemv_config(); row["rowblock"] = round(timeit(sets, len(segs), 1), 2)
         best = None
-        for bpc, nw in ((1, 16), (2, 12), (3, 8), (2, 10), (4, 8), (2, 16), (3, 10), (4, 6), (5, 4), (6, 4), (8, 4)):
+        for bpc, nw in ((1, 16), (2, 8), (2, 12), (3, 8), (1, 12), (2, 16)):
             for rows in (1, 2):
                 for depth in (2, 3):
                     if rows == 4 and depth == 3: continue

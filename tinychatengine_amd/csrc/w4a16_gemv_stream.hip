@@ -4,11 +4,15 @@
 // MatmulOperator::gemv_forward_cuda; read that file's header for the unpack / MFMA-diagonal scheme), different work
 // distribution:
 //
-//   * ONE GENERATION   the grid is at most (CUs x workgroups-per-CU) workgroups, all resident at once.  Wave `gw` of
-//                      the launch owns row groups gw, gw+W, gw+2W, ... (a row group = ROWS consecutive output rows of
-//                      one linear of the group; W = waves in the launch), so consecutive waves stream consecutive rows,
-//                      every wave gets the same number of row groups +-1, and there is no second, nearly empty
-//                      generation of workgroups (the 2-3 us tail of the workgroup-per-row-block kernel).
+//   * ONE GENERATION   the grid is at most (CUs x workgroups-per-CU) workgroups, all resident at once: there is no
+//                      second, nearly empty generation of workgroups (the 2-3 us tail of the workgroup-per-row-block
+//                      kernel).  Workgroup b owns row groups b, b+G, b+2G, ... (a row group = ROWS consecutive output
+//                      rows of one linear of the group; G = workgroups in the launch).
+//   * WAVES PULL WORK  the waves of a workgroup take the workgroup's row groups from a counter in LDS, one at a time.
+//                      A static split starves the young waves: the SIMD arbiter favours the oldest wave, so with equal
+//                      shares wave slots 0-3 of a 16-wave workgroup finished at 34 us and slots 12-15 at 51 us on the
+//                      128k-row lm_head (profiles/r1/timeline_stream.jsonl) -- the launch ended with one wave per SIMD
+//                      and nothing to overlap its HBM latency with.
 //   * ONE X IMAGE      the activation vector is staged into LDS once per workgroup (not once per 32 rows), together
 //                      with the per-lane sums sum_k x_k of every 32-weight chunk that the zero-point correction needs
 //                      (computed once on the matrix pipe instead of 8 MFMAs per step).
@@ -61,8 +65,7 @@ __device__ __forceinline__ void gemv_launch_body(const StreamLaunch &L, const Ba
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NW = nthreads >> 6;
-    const int gw = blockIdx.x * NW + wave;  // wave index in the grid
-    const int W = gridDim.x * NW;
+    const int G = gridDim.x;
 
     const int K = L.K;
     const int nseg = L.nseg;
@@ -71,8 +74,18 @@ __device__ __forceinline__ void gemv_launch_body(const StreamLaunch &L, const Ba
     const int gshift = L.log2g - 5;       // chunk -> quantization group
     const int rowbytes = nchunks * 16;
     const int n_rg = L.n_rg;
-    const int U = gw < n_rg ? ((n_rg - gw + W - 1) / W) * T : 0;  // steps of this wave
     const half_t *A = L.A;
+    // LDS: x image [T][4][64] x 16 B, chunk sums [T][64] floats, the workgroup's row-group counter
+    int *rg_counter = reinterpret_cast<int *>(smem + (size_t)T * (4096 + 256));  // [64]; word 0 is the counter
+    if (tid == 0) *rg_counter = 0;
+    __syncthreads();
+    // The ticket is lane 0's atomic on word 0; the value is read (readfirstlane) one row group later.  All 64 lanes
+    // execute the instruction, lanes 1..63 adding 0 to words of their own (64 banks, one LDS pass): a `lane == 0` branch
+    // around it makes hipcc treat every cursor variable behind the join as divergent (descriptors in VGPRs, waterfall
+    // loops around each buffer load: +40 VGPRs).
+    auto grab = [&]() -> int {
+        return __hip_atomic_fetch_add(rg_counter + lane, lane == 0 ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
 
     // ---------------------------------------------------------------------------------------------------------------
     // issue side
@@ -81,8 +94,11 @@ __device__ __forceinline__ void gemv_launch_body(const StreamLaunch &L, const Ba
         uint4_t w[ROWS];
         unsigned short s[ROWS];
         unsigned z[ROWS];
+        int rg;  // wave-uniform: the row group of the step, -1 = padding past the end of the work
     };
-    int i_rg = gw, i_t = 0;            // cursor: next step to issue
+    int i_rg = 0, i_t = 0;             // cursor: next step to issue
+    bool i_done = false;               // the workgroup's row groups are used up
+    int v_next = grab();               // the next row group's ticket (in lane 0), in flight
     int i_si = 0, i_begin = 0;         // sticky: the linear that contains i_rg
     int i_end = nseg > 1 ? L.seg[1].block_begin : n_rg;
     int i_N = L.seg[0].N, i_sstr = L.seg[0].scales_stride * 2, i_zstr = L.seg[0].zeros_stride * 4;
@@ -95,9 +111,15 @@ __device__ __forceinline__ void gemv_launch_body(const StreamLaunch &L, const Ba
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) so_w[i] = so_s[i] = so_z[i] = 0;
 
-    auto issue = [&](Step &st, int u) {
-        const bool live = u < U;  // wave-uniform; past the end: padding (no memory traffic)
-        if (live && i_t == 0) {   // a new row group: row offsets into SGPRs, once per T steps
+    auto issue = [&](Step &st) {
+        if (!i_done && i_t == 0) {  // a new row group: take the ticket, ask for the next one, row offsets into SGPRs
+            i_rg = blockIdx.x + __builtin_amdgcn_readfirstlane(v_next) * G;
+            if (i_rg >= n_rg) i_done = true;
+            else v_next = grab();
+        }
+        const bool live = !i_done;  // wave-uniform; past the end: padding (no memory traffic)
+        st.rg = live ? i_rg : -1;
+        if (live && i_t == 0) {
             if (i_rg >= i_end) {  // rare: the row group belongs to a later linear of the group
                 do {
                     ++i_si;
@@ -144,10 +166,7 @@ __device__ __forceinline__ void gemv_launch_body(const StreamLaunch &L, const Ba
             else st.z[i] = __builtin_amdgcn_raw_buffer_load_b32(rs_z, vo_z, so_z[i], 0);
         }
         if (live) {
-            if (++i_t == T) {
-                i_t = 0;
-                i_rg += W;
-            }
+            if (++i_t == T) i_t = 0;
         }
     };
 
@@ -160,7 +179,7 @@ __device__ __forceinline__ void gemv_launch_body(const StreamLaunch &L, const Ba
     const bool behind_barrier = bar.arrive_prev != nullptr;  // grid-uniform
     if (behind_barrier) {
 #pragma unroll
-        for (int d = 0; d < DEPTH; ++d) issue(st[d], d);
+        for (int d = 0; d < DEPTH; ++d) issue(st[d]);
         __builtin_amdgcn_sched_barrier(0);
         if (tid == 0) {
             // ~1 us per probe; give up after ~2 s instead of hanging the device (and at once if another workgroup did)
@@ -216,7 +235,7 @@ __device__ __forceinline__ void gemv_launch_body(const StreamLaunch &L, const Ba
     __syncthreads();
     if (!behind_barrier) {
 #pragma unroll
-        for (int d = 0; d < DEPTH; ++d) issue(st[d], d);
+        for (int d = 0; d < DEPTH; ++d) issue(st[d]);
     }
     if constexpr (MODE == 2) *ts_x_ready = wall_clock64();
 
@@ -238,7 +257,7 @@ __device__ __forceinline__ void gemv_launch_body(const StreamLaunch &L, const Ba
 #pragma unroll
     for (int q = 0; q < 4; ++q) diag[q] = (lane & 3) == q ? 0.0625f : 0.0f;
 
-    int c_rg = gw, c_t = 0;  // cursor: next step to compute
+    int c_t = 0;  // cursor: step within the row group being computed
     int c_si = 0, c_begin = 0;
     int c_end = nseg > 1 ? L.seg[1].block_begin : n_rg;
     half_t *c_C = L.seg[0].C;
@@ -294,6 +313,7 @@ __device__ __forceinline__ void gemv_launch_body(const StreamLaunch &L, const Ba
             return;
         }
         // ---- end of a row group: reduce over the 64 lanes, store, reset (wave-uniform branch) ----
+        const int c_rg = st.rg;  // a wave's row groups only move forward, so the per-linear state is sticky here too
         if (c_rg >= c_end) {
             do {
                 ++c_si;
@@ -322,17 +342,22 @@ __device__ __forceinline__ void gemv_launch_body(const StreamLaunch &L, const Ba
             for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
         }
         c_t = 0;
-        c_rg += W;
     };
 
-    // ---- the ring: slot d holds steps d, d+DEPTH, ...; the last round refills with padding ----
-    for (int u = 0; u < U; u += DEPTH) {
+    // ---- the ring: consume slot d, refill it; once the work is used up the refills are padding, and the loop ends
+    // after the first round that found nothing to consume ----
+    bool any;
+    do {
+        any = false;
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
-            if (u + d < U) compute(st[d]);  // wave-uniform
-            issue(st[d], u + d + DEPTH);
+            if (st[d].rg >= 0) {  // wave-uniform
+                compute(st[d]);
+                any = true;
+            }
+            issue(st[d]);
         }
-    }
+    } while (any);
 
     if (bar.arrive_here) {
         // every wave waits for its own write-through stores to be acknowledged, then the workgroup arrives.  No
@@ -389,7 +414,7 @@ int num_cus() {
     return g_num_cus;
 }
 
-size_t lds_bytes(int K) { return (size_t)(((K >> 5) + 63) / 64) * (4096 + 256); }
+size_t lds_bytes(int K) { return (size_t)(((K >> 5) + 63) / 64) * (4096 + 256) + 256; }
 
 template <typename KFn>
 hipError_t set_lds(KFn kfn, size_t lds) {
@@ -441,31 +466,17 @@ bool fill_launch(const tce_w4a16_desc *descs, int count, int rows, StreamLaunch 
     return true;
 }
 
-// rows per row group: balance (every wave runs ceil(n_rg / W) row groups, the last one maybe empty) x a preference for
-// wide row groups (one x read and one set of addresses per ROWS rows), weighted by the bytes of each launch
+// rows per row group: 2 (one x read and one set of addresses per two rows) once every wave still gets several row
+// groups to pull, else 1 (measured: profiles/r1/stream_sweep.jsonl)
 int pick_rows(const tce_w4a16_desc *descs, const int32_t *groups, int n_launches, long waves) {
-    double best = -1.0;
-    int rows = 2;
-    for (int r = 4; r >= 1; r >>= 1) {
-        double num = 0.0, den = 0.0;
-        for (int l = 0, off = 0; l < n_launches; off += groups[l], ++l) {
-            long n_rg = 0, n = 0;
-            for (int i = 0; i < groups[l]; ++i) {
-                n_rg += (descs[off + i].N + r - 1) / r;
-                n += descs[off + i].N;
-            }
-            const long it = (n_rg + waves - 1) / waves;
-            const double bytes = (double)n * descs[off].K;
-            num += bytes;
-            den += bytes * (double)(waves * it) / (double)n_rg;
-        }
-        const double eff = num / den * (r == 4 ? 1.0 : (r == 2 ? 0.94 : 0.85));
-        if (eff > best) {
-            best = eff;
-            rows = r;
-        }
+    double rows = 0.0, bytes = 0.0;
+    for (int l = 0, off = 0; l < n_launches; off += groups[l], ++l) {
+        long n = 0;
+        for (int i = 0; i < groups[l]; ++i) n += descs[off + i].N;
+        rows += (double)n * n * descs[off].K;  // byte-weighted mean of the launches' row counts
+        bytes += (double)n * descs[off].K;
     }
-    return rows;
+    return rows / bytes >= 4.0 * (double)waves ? 2 : 1;
 }
 
 }  // namespace
@@ -497,9 +508,9 @@ int launch_w4a16_gemv_stream(const tce_w4a16_desc *descs, int count, hipStream_t
     const int cus = num_cus();
     if (cus == 0) return TCE_ERR_HIP;
 
-    // ---- geometry: two workgroups of 8 waves per CU (measured better than one of 16: the two run out of phase) ----
-    int rows = g_stream_rows, nw = g_stream_nw ? g_stream_nw : 8, depth = g_stream_depth;
-    int bpc = g_stream_bpc ? g_stream_bpc : 2;
+    // ---- geometry: one workgroup of 16 waves per CU, two rows per row group for large launches ----
+    int rows = g_stream_rows, nw = g_stream_nw ? g_stream_nw : 16, depth = g_stream_depth;
+    int bpc = g_stream_bpc ? g_stream_bpc : 1;
     if (bpc * nw > 32) bpc = 32 / nw > 0 ? 32 / nw : 1;  // 8 waves per SIMD at most
     const int32_t one_group = count;
     if (rows == 0) rows = pick_rows(descs, &one_group, 1, (long)cus * bpc * nw);

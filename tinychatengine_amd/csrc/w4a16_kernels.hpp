@@ -74,7 +74,9 @@ int launch_w4a16_gemv(const tce_w4a16_desc *descs, int count, int forced_rows, i
     X(8, 2)                  \
     X(4, 2)                  \
     X(4, 1)                  \
-    X(2, 2)
+    X(2, 2)                  \
+    X(4, 4)                  \
+    X(2, 4)
 bool gemm_variant_exists(int m_tiles, int n_tiles);
 int launch_w4a16_gemm(const tce_w4a16_desc &d, int forced_mt, int forced_nt, hipStream_t stream, hipError_t *hip_err);
 
