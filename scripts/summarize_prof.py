@@ -1,5 +1,11 @@
 #!/usr/bin/env python3
-"""Condense rocprofv3 CSV output (kernel-trace stats + PMC passes) into a short text summary."""
+"""Condense rocprofv3 CSV output (kernel-trace stats + separate PMC passes) into a short text summary of this
+library's kernels (names starting with tce::), with the derived figures DESIGN.md quotes.
+
+rocprofv3 prints FETCH_SIZE / WRITE_SIZE in KiB, and on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide
+coalesced streaming read (/opt/skills/guides/MI355X_MICROARCH.md, "HBM"): bytes = value * 1024 * 2.  The same
+correction reproduces the algorithmic bytes of the GEMV to 0.5 %; WRITE_SIZE is uncalibrated (shown with the same
+factor, for scale only)."""
 import csv
 import glob
 import os
@@ -7,39 +13,65 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
+MINE = "tce::"
 
 
 def short(name):
-    return name.split("(")[0][-90:]
+    i = name.find(MINE)
+    return name[i:i + 110] if i >= 0 else name[:110]
 
 
+avg_ns = {}
 for f in sorted(glob.glob(os.path.join(root, "kt", "**", "*kernel_stats.csv"), recursive=True)):
-    print("== kernel stats:", os.path.relpath(f, root))
-    for row in list(csv.DictReader(open(f)))[:8]:
-        print("  ", short(row.get("Name", "")), "| calls", row.get("Calls"), "| avg ns", row.get("AverageNs"), "| total ns", row.get("TotalDurationNs"),
-              "| %", row.get("Percentage"))
+    print("== kernel stats (rocprofv3 --kernel-trace --stats):", os.path.relpath(f, root))
+    for row in csv.DictReader(open(f)):
+        if MINE in row.get("Name", ""):
+            avg_ns[short(row["Name"])] = float(row["AverageNs"])
+            print("  ", short(row["Name"]), "| calls", row.get("Calls"), "| avg ns", row.get("AverageNs"), "| min", row.get("MinNs"), "| max", row.get("MaxNs"),
+                  "| stddev", row.get("StdDev"))
 for f in sorted(glob.glob(os.path.join(root, "kt", "**", "*kernel_trace.csv"), recursive=True)):
-    rows = list(csv.DictReader(open(f)))
+    rows = [r for r in csv.DictReader(open(f)) if MINE in r["Kernel_Name"]]
     by = defaultdict(list)
     for r in rows:
         by[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r))
-    print("== kernel trace:", os.path.relpath(f, root), len(rows), "dispatches")
-    for k, v in sorted(by.items(), key=lambda kv: -sum(e - s for s, e, _ in kv[1]))[:4]:
+    print("== kernel trace:", os.path.relpath(f, root), len(rows), "dispatches of this library")
+    for k, v in sorted(by.items(), key=lambda kv: -sum(e - s for s, e, _ in kv[1])):
         d = sorted(e - s for s, e, _ in v)
-        v.sort()
+        v.sort(key=lambda t: t[0])
         gaps = sorted(v[i + 1][0] - v[i][1] for i in range(len(v) - 1))
         r0 = v[0][2]
         print(f"   {short(k)}\n      n={len(d)} dur ns min/med/mean/max = {d[0]}/{d[len(d)//2]}/{sum(d)//len(d)}/{d[-1]}  gap ns med = {gaps[len(gaps)//2] if gaps else None}"
               f"  grid={r0.get('Grid_Size_X', r0.get('Grid_Size'))} wg={r0.get('Workgroup_Size_X', r0.get('Workgroup_Size'))} vgpr={r0.get('VGPR_Count')} sgpr={r0.get('SGPR_Count')} lds={r0.get('LDS_Block_Size')}")
+med = defaultdict(dict)
 for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
     for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
-        rows = list(csv.DictReader(open(f)))
         acc = defaultdict(lambda: defaultdict(list))
-        for r in rows:
-            acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-        print("== pmc:", os.path.relpath(f, root), len(rows), "rows")
-        for k, cs in sorted(acc.items(), key=lambda kv: -len(next(iter(kv[1].values()))))[:2]:
-            print("   ", short(k))
+        n = 0
+        for r in csv.DictReader(open(f)):
+            if MINE in r["Kernel_Name"]:
+                acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                n += 1
+        print("== pmc:", os.path.relpath(f, root), n, "rows of this library")
+        for k, cs in acc.items():
+            print("   ", k)
             for c, vals in cs.items():
                 vals.sort()
-                print(f"       {c}: n={len(vals)} median={vals[len(vals)//2]:.4g} mean={sum(vals)/len(vals):.4g}")
+                med[k][c] = vals[len(vals) // 2]
+                print(f"       {c}: n={len(vals)} median={vals[len(vals)//2]:.5g} mean={sum(vals)/len(vals):.5g}")
+print("== derived (per launch, medians)")
+for k, m in med.items():
+    out = []
+    if "FETCH_SIZE" in m:
+        out.append(f"HBM read traffic = FETCH_SIZE*1024*2 = {m['FETCH_SIZE'] * 2048 / 1e6:.2f} MB")
+    if "WRITE_SIZE" in m:
+        out.append(f"HBM write traffic = {m['WRITE_SIZE'] * 2048 / 1e6:.3f} MB")
+    if "SQ_INSTS_VALU" in m and "SQ_WAVES" in m:
+        out.append(f"VALU instructions per wave = {m['SQ_INSTS_VALU'] / m['SQ_WAVES']:.0f}")
+    if "SQ_WAIT_ANY" in m and "SQ_WAVE_CYCLES" in m:
+        out.append(f"wave-cycles parked on s_waitcnt/barrier = {m['SQ_WAIT_ANY'] / m['SQ_WAVE_CYCLES']:.2f}, stalled at issue = {m.get('SQ_WAIT_INST_ANY', 0) / m['SQ_WAVE_CYCLES']:.2f}, "
+                   f"issuing = {m.get('SQ_ACTIVE_INST_ANY', 0) / m['SQ_WAVE_CYCLES']:.2f}")
+    if k in avg_ns and "FETCH_SIZE" in m:
+        out.append(f"traffic / avg duration = {m['FETCH_SIZE'] * 2048 / avg_ns[k]:.0f} GB/s")
+    print("   ", k)
+    for o in out:
+        print("       " + o)

@@ -105,8 +105,9 @@ STREAM_CFGS = [(2, 16, 2), (2, 15, 3), (1, 16, 3), (1, 9, 2), (2, 4, 2), (1, 1, 
 
 @pytest.mark.parametrize("M", [1, 2])
 def test_stream_kernel_every_config(dev, oracle, M):
-    """The persistent stream kernel: rows per unit x waves per workgroup x ring depth, on grouped launches with odd N
-    (row-group tails), K tails (K % 2048 != 0), more row groups than waves and fewer row groups than waves."""
+    """The persistent kernel: rows per row group x waves per workgroup x ring depth, on grouped launches with odd N
+    (row-group tails), K tails (K % 2048 != 0), more row groups than waves and fewer row groups than waves.  M = 2 is
+    not a shape it takes: the forced configuration must then fall through to the row-block kernel, not fail."""
     from tinychatengine_amd import capi
     from tinychatengine_amd.linear import Linear_half_int4, forward_group
     g = torch.Generator(device=dev).manual_seed(31 + M)

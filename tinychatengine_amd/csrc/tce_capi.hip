@@ -187,16 +187,17 @@ int tce_w4a16_forward_group(const tce_w4a16_desc *descs, int count, void *stream
     hipError_t he = hipSuccess;
     // Kernel choice: the workgroup-per-row-block kernel or the persistent one (w4a16_gemv_stream.hip); either can be
     // forced through tce_w4a16_set_gemv_config (waves_k == 0 selects the persistent kernel).
-    // Automatic choice (measured, profiles/r1/stream_sweep.jsonl): the persistent kernel wins from ~100M weights per
-    // launch up (Llama-3 gate+up 14.5 vs 16.4 us, the 128k-row lm_head 50 vs 57 us) and loses 5-10 % below that.
+    // Automatic choice (measured, profiles/r1/gemv_experiments.jsonl): the persistent kernel wins on very large launches
+    // (the 128k-row lm_head: 47 vs 50.5 us) and loses 5-10 % on per-layer shapes, where a launch is 2-3 waves of work.
     long long weights = 0;
     for (int i = 0; i < count; ++i) weights += (long long)descs[i].N * descs[i].K;
-    const bool use_stream = g_gemv_kernel == 2 || (g_gemv_kernel == 0 && descs[0].M == 1 && weights >= 100000000LL && g_debug_mode_capi == 0);
+    const bool use_stream = g_gemv_kernel == 2 || (g_gemv_kernel == 0 && descs[0].M == 1 && weights >= 200000000LL && g_debug_mode_capi == 0);
     if (use_stream) {
         const int rc = tce::launch_w4a16_gemv_stream(descs, count, static_cast<hipStream_t>(stream), &he);
         if (rc == TCE_OK) return TCE_OK;
         if (rc == TCE_ERR_HIP) return hip_fail(he, "w4a16 stream gemv launch");
-        if (rc != TCE_ERR_UNSUPPORTED_SHAPE || g_gemv_kernel == 2) return fail(rc, "w4a16 stream gemv: unsupported configuration");
+        if (rc != TCE_ERR_UNSUPPORTED_SHAPE) return fail(rc, "w4a16 persistent gemv: unsupported configuration");
+        // M > 1 or an over-long K: the workgroup-per-row-block kernel takes it
     }
     const int rc = tce::launch_w4a16_gemv(descs, count, g_gemv_rows, g_gemv_wn, g_gemv_wk, g_gemv_depth,
                                           static_cast<hipStream_t>(stream), &he);

@@ -461,7 +461,7 @@ int launch_w4a16_gemv(const tce_w4a16_desc *descs, int count, int forced_rows, i
     if (v.rows == 0) {
         // Enough workgroups to cover 256 CUs a few times; split K across waves only when there are too few rows to
         // fill the chip and K is long enough.  (Tuned on MI355X; see DESIGN.md "GEMV geometry".)
-        if (total_n >= 24000) v = {4, 8, 1, 1};
+        if (total_n >= 30000) v = {4, 8, 1, 1};
         else if (total_n >= 8192) v = {4, 4, 1, 1};
         else if (total_n >= 3072) v = {2, 4, 1, 2};
         else if (total_n >= 1536) v = {1, 4, 1, 2};

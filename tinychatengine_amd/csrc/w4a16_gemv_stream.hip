@@ -177,6 +177,21 @@ __device__ __forceinline__ void gemv_launch_body(const StreamLaunch &L, const Ba
     // ---------------------------------------------------------------------------------------------------------------
     Step st[DEPTH];
     const bool behind_barrier = bar.arrive_prev != nullptr;  // grid-uniform
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(A), 0, 0x7FFFFFF0, 0x00020000);
+    uint4_t *xs = reinterpret_cast<uint4_t *>(smem);                  // [T][4][64] pieces of 16 bytes (pair-permuted, lane-linear)
+    float *xsl = reinterpret_cast<float *>(smem + (size_t)T * 4096);  // [T][64]: sum of the 32 activations of (step, lane)
+    const int total_pieces = T * 256;
+    // x piece p -> 16 bytes of the vector.  sc0 sc1: device-coherent read -- behind a barrier the vector was written by
+    // other CUs (other XCDs, other L2s) moments ago, and this CU / this L2 may still hold the previous token's lines.
+    auto x_piece = [&](int p) -> uint4_t {
+        const int c = (p >> 8) * 64 + (p & 63);
+        const int j = (p >> 6) & 3;
+        uint4_t q = uint4_t{0u, 0u, 0u, 0u};
+        if (p < total_pieces && c < nchunks) q = __builtin_amdgcn_raw_buffer_load_b128(rs_a, (c * 32 + j * 8) * 2, 0, /*sc0|sc1*/ 17);
+        return q;
+    };
+    constexpr int XR = 4;  // pieces per thread held in registers across the weight prologue (covers K <= 8192 x waves/16)
+    uint4_t xr[XR];
     if (behind_barrier) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) issue(st[d]);
@@ -198,25 +213,25 @@ __device__ __forceinline__ void gemv_launch_body(const StreamLaunch &L, const Ba
         }
         __syncthreads();
         // no cache-wide acquire here (a buffer_inv per wave made every barrier cost ~40 us): the activations are read
-        // with device-coherent loads below, and nothing else the predecessor wrote is read by this launch
+        // with device-coherent loads, and nothing else the predecessor wrote is read by this launch
+#pragma unroll
+        for (int i = 0; i < XR; ++i) xr[i] = x_piece(tid + i * nthreads);
+    } else {
+        // x loads first, the weight prologue right behind them, and only then the first use of x: the x data returns
+        // first (in-order), and the weights are already in flight while the image is written and summed
+#pragma unroll
+        for (int i = 0; i < XR; ++i) xr[i] = x_piece(tid + i * nthreads);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) issue(st[d]);
+        __builtin_amdgcn_sched_barrier(0);
     }
-
-    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(A), 0, 0x7FFFFFF0, 0x00020000);
-    uint4_t *xs = reinterpret_cast<uint4_t *>(smem);                  // [T][4][64] pieces of 16 bytes (pair-permuted, lane-linear)
-    float *xsl = reinterpret_cast<float *>(smem + (size_t)T * 4096);  // [T][64]: sum of the 32 activations of (step, lane)
-    {
-        const int total_pieces = T * 256;
-        // one piece per thread per round; threads without a piece load nothing
-        for (int p = tid; p < total_pieces; p += nthreads) {
-            const int c = (p >> 8) * 64 + (p & 63);
-            const int j = (p >> 6) & 3;
-            uint4_t q = uint4_t{0u, 0u, 0u, 0u};
-            // sc0 sc1: device-coherent read -- the vector was written by other CUs (other XCDs, other L2s) moments ago,
-            // and this CU / this L2 may still hold the previous token's lines of the same buffer
-            if (c < nchunks) q = pair_permute(__builtin_amdgcn_raw_buffer_load_b128(rs_a, (c * 32 + j * 8) * 2, 0, /*sc0|sc1*/ 17));
-            xs[p] = q;
-        }
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+        const int p = tid + i * nthreads;
+        if (p < total_pieces) xs[p] = pair_permute(xr[i]);
     }
+    for (int p = tid + XR * nthreads; p < total_pieces; p += nthreads) xs[p] = pair_permute(x_piece(p));  // long K only
     __syncthreads();
     {
         // D[i][j] = sum_k A_i[k] B_j[k] with A = ones: every accumulator register of a lane holds that lane's own sum
@@ -233,10 +248,6 @@ __device__ __forceinline__ void gemv_launch_body(const StreamLaunch &L, const Ba
         }
     }
     __syncthreads();
-    if (!behind_barrier) {
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d) issue(st[d]);
-    }
     if constexpr (MODE == 2) *ts_x_ready = wall_clock64();
 
     // ---------------------------------------------------------------------------------------------------------------
