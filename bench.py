@@ -97,11 +97,32 @@ def roofline_leg(dl, torch, launches: int, eager: bool = False):
     gbs = bytes_per_launch / us / 1e3
     return {
         "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-        "traffic": None,
+        **_pmc_traffic(bytes_per_launch),
         "kernel": f"w4a16_gemv_kernel (grouped gate+up launch, N={'+'.join(str(d.N) for d in d0)}, K={d0[0].K}, M={dl.m})",
         "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": round(us, 3), "launches_timed": reps * launches,
         "timing": "HIP events on the launch stream around graph-replayed back-to-back launches rotating over all layers' weights (includes inter-kernel gaps)",
     }
+
+
+def _pmc_traffic(bytes_per_launch):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 --pmc FETCH_SIZE pass of this same roofline command
+    (scripts/profile.sh; corrected as the MI355X guide prescribes: KiB x 1024 x 2 on gfx950).  The counters cannot be
+    collected from inside the timed process, so the figure comes from the newest committed profiles/*/traffic.json and
+    is only reported if that pass ran on the same launch (same algorithmic bytes); otherwise null."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*", "traffic.json"))):
+        try:
+            t = json.load(open(f))
+        except Exception:  # noqa: BLE001
+            continue
+        if t.get("algorithmic_bytes_per_launch") == bytes_per_launch:
+            best = (t, f)
+    if not best:
+        return {"traffic": None}
+    t, f = best
+    return {"traffic": t["hbm_read_bytes_per_launch"],
+            "traffic_source": f"rocprofv3 --pmc FETCH_SIZE (x1024x2), median of {t['dispatches']} dispatches, {os.path.relpath(f, os.path.dirname(os.path.abspath(__file__)))}"}
 
 
 def cpu_baseline_worker(args):

@@ -9,4 +9,6 @@ timeout 900 python bench.py --steps 100 --warmup 10 > gpurun_out/${TAG}_bench.js
 timeout 600 python scripts/tune.py --only experiments > gpurun_out/${TAG}_exp.jsonl 2> gpurun_out/${TAG}_exp.err
 timeout 600 python scripts/tune.py --only gemm > gpurun_out/${TAG}_gemm.jsonl 2>> gpurun_out/${TAG}_exp.err
 bash scripts/profile.sh ${TAG} > gpurun_out/${TAG}_profile.log 2>&1
+timeout 200 python scripts/timeline_stream.py > gpurun_out/${TAG}_timeline_stream.jsonl 2>> gpurun_out/${TAG}_exp.err
+timeout 200 python scripts/chain_exp.py > gpurun_out/${TAG}_chain.jsonl 2>> gpurun_out/${TAG}_exp.err
 tail -4 gpurun_out/${TAG}_pytest.log; tail -2 gpurun_out/${TAG}_bench.json | cut -c1-1500; tail -3 gpurun_out/${TAG}_bench.err

@@ -75,3 +75,16 @@ for k, m in med.items():
     print("   ", k)
     for o in out:
         print("       " + o)
+
+# machine-readable traffic figure for bench.py's roofline.traffic (dominant GEMV kernel only)
+import json
+for k, m in med.items():
+    if "w4a16_gemv" in k and "FETCH_SIZE" in m:
+        n = 0
+        for d in glob.glob(os.path.join(root, "pmc_fetch", "**", "*counter_collection.csv"), recursive=True):
+            n += sum(1 for r in csv.DictReader(open(d)) if MINE in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE")
+        json.dump({"kernel": k, "hbm_read_bytes_per_launch": int(m["FETCH_SIZE"] * 2048), "fetch_size_kib_median": m["FETCH_SIZE"],
+                   "dispatches": n, "algorithmic_bytes_per_launch": int(os.environ.get("TCE_ALGO_BYTES", "46910464")),
+                   "correction": "FETCH_SIZE [KiB] x 1024 x 2 (gfx950 reports half of a wide coalesced streaming read)"},
+                  open(os.path.join(root, "traffic.json"), "w"), indent=1)
+        break
