@@ -168,6 +168,9 @@ __global__ __launch_bounds__(256, (MT * NT >= 16 ? 1 : 2)) void w4a16_gemm_kerne
             const int nx = kb + 1 < nkb ? kb + 1 : last;  // clamped (never predicated) prefetch
             load_a(nx);
             load_b(b1, nx);
+            // pin the prefetch in front of the MFMAs: left alone, the scheduler sinks these loads to the end of the
+            // iteration, right in front of the next iteration's wait for them (one exposed L2/HBM latency per k-block)
+            __builtin_amdgcn_sched_barrier(0);
             compute(b0, kb, 0);
             write_a(1);
             __syncthreads();
@@ -176,6 +179,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 16 ? 1 : 2)) void w4a16_gemm_kerne
             const int nx = kb + 2 < nkb ? kb + 2 : last;
             load_a(nx);
             load_b(b0, nx);
+            __builtin_amdgcn_sched_barrier(0);
             compute(b1, kb + 1, 1);
             write_a(0);
             __syncthreads();
