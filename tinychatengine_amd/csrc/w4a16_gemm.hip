@@ -14,8 +14,8 @@
 //     contraction is legal as long as A uses the same one: the pair order (0,4,1,5,2,6,3,7) is applied to the
 //     activation tile while it is staged into LDS, never to the weights.
 //   * the activation tile (BM x 128 halves) is staged through registers into an LDS image that is lane-linear
-//     per MFMA fragment (ds_read_b128 conflict-free) with an XOR swizzle that keeps the coalesced staging
-//     writes at <= 2-way conflicts.
+//     per MFMA fragment (ds_read_b128 conflict-free) with an XOR swizzle (row ^ k-step ^ 4*k-quarter) that
+//     spreads a wave's coalesced staging writes over all 16 bank groups (row ^ k-step alone used 4 of them).
 //   * 4 waves along N, each MT x NT tiles of 16x16; block -> tile mapping keeps every XCD on its own set of
 //     weight columns so the re-reads of a weight panel by the M/BM row-blocks hit that XCD's L2.
 #include "tce_common.hpp"
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 16 ? 1 : 2)) void w4a16_gemm_kerne
             const int e = i * 256 + tid;
             const int row = e >> 4, pc = e & 15;
             const int qq = pc >> 2, s = pc & 3;  // k offset 8*pc = 32*qq + 8*s
-            lds_a[buf][((row >> 4) * 4 + s) * 64 + qq * 16 + ((row & 15) ^ s)] = pair_permute(areg[i]);
+            lds_a[buf][((row >> 4) * 4 + s) * 64 + qq * 16 + ((row & 15) ^ s ^ (qq << 2))] = pair_permute(areg[i]);
         }
     };
 
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 16 ? 1 : 2)) void w4a16_gemm_kerne
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                const uint4_t araw = lds_a[buf][(i * 4 + s) * 64 + q * 16 + (n16 ^ s)];  // lane's row m16 == lane & 15
+                const uint4_t araw = lds_a[buf][(i * 4 + s) * 64 + q * 16 + (n16 ^ s ^ (q << 2))];  // lane's row m16 == lane & 15
                 const half8_t af = __builtin_bit_cast(half8_t, araw);
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
