@@ -153,7 +153,7 @@ int tce_w4a16_gemv_variant(int idx, int *rows, int *wn, int *wk, int *depth) {
 
 int tce_w4a16_gemm_variant(int idx, int *mt, int *nt) {
     static const int table[][2] = {
-#define TCE_V(M_, N_) {M_, N_},
+#define TCE_V(M_, N_) {M_, N_}, {100 + M_, N_},
         TCE_GEMM_VARIANTS(TCE_V)
 #undef TCE_V
     };

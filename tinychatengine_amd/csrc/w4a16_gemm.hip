@@ -200,6 +200,195 @@ __global__ __launch_bounds__(256, (MT * NT >= 16 ? 1 : 2)) void w4a16_gemm_kerne
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Variant (C-ABI tile ids 100 + m_tiles): the PACKED weights go through LDS too, 4 KiB per 64 rows and k-block.  Not to
+// share them but because of how an MFMA operand fragment is read: it puts output column n = lane % 16 and k-slice
+// lane / 16 in a lane, so a fragment loaded straight from a K-contiguous matrix makes the 16 lanes of every
+// quarter-wave read 16 different rows (64 cache-line look-ups per wave load instead of 8).  Here a thread loads 16 bytes
+// such that 4 consecutive lanes read one row's 64 bytes, the tile is written to LDS with an XOR swizzle
+// (slot = row*4 + (chunk ^ (row/4 % 4)): fragment reads touch all 16 bank groups), each lane reads its fragment word
+// with one ds_read_b128, and the scales and packed zeros of the workgroup's rows are staged into LDS once.
+// Measured (profiles/r1/gemm_pipeline_attempts.md): faster than the direct form for 32-row tiles (426 vs 380 TF at
+// M=512, 4096^2), slower for the 64-row tiles the dispatcher prefers (449 vs 512-536 TF) -- the look-up count is not
+// what bounds this loop either.  Kept as a selectable variant; the dispatcher uses the direct form.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int MT, int NT>
+__global__ __launch_bounds__(256, (MT * NT >= 16 ? 1 : 2)) void w4a16_gemm_lds_kernel(const GemmArgs g) {
+    constexpr int BM = MT * 16;
+    constexpr int BN = 4 * NT * 16;
+    constexpr int BK = 128;
+    constexpr int ABUF = MT * 4 * 64;  // 16-byte pieces of one activation tile image
+    constexpr int WBUF = BN * 4;       // 16-byte pieces of one packed weight tile (64 bytes per row)
+    extern __shared__ __attribute__((aligned(16))) uint4_t lds_dyn[];
+    uint4_t *lds_a = lds_dyn;                  // [2][ABUF]
+    uint4_t *lds_w = lds_dyn + 2 * ABUF;       // [2][WBUF]
+    const int nkb = g.K / BK;
+    const int zw = g.zeros_stride;
+    unsigned *lds_z = reinterpret_cast<unsigned *>(lds_w + 2 * WBUF);  // [BN][zw]
+    half_t *lds_s = reinterpret_cast<half_t *>(lds_z + BN * zw);       // [BN][nkb]
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const int slot = bid >> 3;
+    const int n_blk = xcd + 8 * (slot / g.m_blocks);
+    const int m_blk = slot % g.m_blocks;
+    if (n_blk >= g.n_blocks) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n16 = lane & 15;
+    const int q = lane >> 4;
+    const int m_base = m_blk * BM;
+    const int nb0 = n_blk * BN;  // first weight row of the workgroup
+    const int nchunks = g.K >> 5;
+
+    // ---- scales and zeros of the workgroup's rows, all k-blocks, once ----
+    for (int idx = tid; idx < BN * nkb; idx += 256) {
+        const int row = idx / nkb, gi = idx - row * nkb;
+        int n = nb0 + row;
+        n = n < g.N ? n : g.N - 1;
+        lds_s[idx] = g.scales[(size_t)n * g.scales_stride + gi];
+    }
+    for (int idx = tid; idx < BN * zw; idx += 256) {
+        const int row = idx / zw, wi = idx - row * zw;
+        int n = nb0 + row;
+        n = n < g.N ? n : g.N - 1;
+        lds_z[idx] = g.zeros[(size_t)n * g.zeros_stride + wi];
+    }
+
+    // ---- staging registers: MT activation pieces and NT weight pieces of 16 bytes per thread ----
+    uint4_t areg[MT], wreg[NT];
+    auto load_tiles = [&](int kb) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int p = i * 256 + tid;  // piece: row p/4 of the workgroup, 16-byte chunk p%4 of the k-block
+            int n = nb0 + (p >> 2);
+            n = n < g.N ? n : g.N - 1;
+            wreg[i] = g.qweight[(size_t)n * nchunks + kb * 4 + (p & 3)];
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int e = i * 256 + tid;
+            const int row = e >> 4, pc = e & 15;
+            int m = m_base + row;
+            m = m < g.M ? m : g.M - 1;
+            areg[i] = *reinterpret_cast<const uint4_t *>(g.A + (size_t)m * g.lda + kb * BK + pc * 8);
+        }
+    };
+    auto write_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int p = i * 256 + tid;
+            const int row = p >> 2, c = p & 3;
+            lds_w[buf * WBUF + row * 4 + (c ^ ((row >> 2) & 3))] = wreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int e = i * 256 + tid;
+            const int row = e >> 4, pc = e & 15;
+            const int qq = pc >> 2, s = pc & 3;  // k offset 8*pc = 32*qq + 8*s
+            lds_a[buf * ABUF + ((row >> 4) * 4 + s) * 64 + qq * 16 + ((row & 15) ^ s ^ (qq << 2))] = pair_permute(areg[i]);
+        }
+    };
+
+    const NibbleMasks nmask = make_nibble_masks();
+    float4_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int kb, int buf) {
+        uint4_t bw[NT];
+        ZeroPair zp[NT];
+        float sc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int row = (wave * NT + j) * 16 + n16;  // the lane's weight row within the workgroup
+            bw[j] = lds_w[buf * WBUF + row * 4 + (q ^ ((row >> 2) & 3))];
+            zp[j] = make_zero_pair((lds_z[row * zw + (kb >> 3)] >> ((kb & 7) * 4)) & 0xFu);
+            sc[j] = (float)lds_s[row * nkb + kb];
+        }
+        float4_t blk[MT][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) blk[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            half8_t bf[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                half2_t d[4];
+                dequant_word(bw[j][s], zp[j], nmask, d);
+                bf[j] = half8_t{d[0].x, d[0].y, d[1].x, d[1].y, d[2].x, d[2].y, d[3].x, d[3].y};
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const uint4_t araw = lds_a[buf * ABUF + (i * 4 + s) * 64 + q * 16 + (n16 ^ s ^ (q << 2))];
+                const half8_t af = __builtin_bit_cast(half8_t, araw);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    blk[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], blk[i][j], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = __builtin_fmaf(sc[j], blk[i][j][r], acc[i][j][r]);
+    };
+
+    // double-buffered LDS, one barrier per k-block; the next block's tiles are requested at the top of the iteration
+    // (fenced there) and written to the other buffer after the MFMAs
+    const int last = nkb - 1;
+    load_tiles(0);
+    write_tiles(0);
+    __syncthreads();
+    for (int kb = 0; kb < nkb; ++kb) {
+        load_tiles(kb + 1 < nkb ? kb + 1 : last);  // clamped, never predicated
+        __builtin_amdgcn_sched_barrier(0);
+        compute(kb, kb & 1);
+        write_tiles((kb + 1) & 1);
+        __syncthreads();
+    }
+
+    const int n_base = nb0 + wave * (NT * 16);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n_base + j * 16 + n16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m_base + i * 16 + q * 4 + r;
+                if (m < g.M && n < g.N) g.C[(size_t)m * g.ldc + n] = (half_t)acc[i][j][r];
+            }
+        }
+}
+
+template <int MT, int NT>
+hipError_t launch_gemm_lds(const GemmArgs &g0, hipStream_t stream) {
+    GemmArgs g = g0;
+    constexpr int BM = MT * 16, BN = 4 * NT * 16;
+    g.n_blocks = (g.N + BN - 1) / BN;
+    g.m_blocks = (g.M + BM - 1) / BM;
+    const int n8 = (g.n_blocks + 7) / 8 * 8;
+    const int nkb = g.K / 128;
+    size_t lds = (size_t)(2 * MT * 4 * 64 + 2 * BN * 4) * 16 + (size_t)BN * g.zeros_stride * 4 + (size_t)BN * nkb * 2;
+    lds = (lds + 15) & ~(size_t)15;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    auto kfn = w4a16_gemm_lds_kernel<MT, NT>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kfn, dim3(n8 * g.m_blocks), dim3(256), lds, stream, g);
+    return hipGetLastError();
+}
+
 template <int MT, int NT>
 hipError_t launch_gemm(const GemmArgs &g0, hipStream_t stream) {
     GemmArgs g = g0;
@@ -215,7 +404,7 @@ hipError_t launch_gemm(const GemmArgs &g0, hipStream_t stream) {
 
 bool gemm_variant_exists(int mt, int nt) {
 #define TCE_V(M_, N_) \
-    if (mt == M_ && nt == N_) return true;
+    if ((mt == M_ || mt == 100 + M_) && nt == N_) return true;  // 100 + m_tiles: packed weights staged through LDS
     TCE_GEMM_VARIANTS(TCE_V)
 #undef TCE_V
     return false;
@@ -254,10 +443,10 @@ int launch_w4a16_gemm(const tce_w4a16_desc &d, int forced_mt, int forced_nt, hip
     }
     hipError_t e = hipSuccess;
     bool found = false;
-#define TCE_V(M_, N_)                        \
-    if (!found && mt == M_ && nt == N_) {    \
-        found = true;                        \
-        e = launch_gemm<M_, N_>(g, stream);  \
+#define TCE_V(M_, N_)                                                                     \
+    if (!found && (mt == M_ || mt == 100 + M_) && nt == N_) {                              \
+        found = true;                                                                     \
+        e = mt >= 100 ? launch_gemm_lds<M_, N_>(g, stream) : launch_gemm<M_, N_>(g, stream); \
     }
     TCE_GEMM_VARIANTS(TCE_V)
 #undef TCE_V
