@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 counters for the prefill GEMM (M=512, 4096x4096): SQ, TA, TCP, TCC passes (each its own run).
+# rocprofv3 counters for the prefill GEMM (M=512, 4096x4096): kernel trace + two SQ passes (each its own run).
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=$REPO/gpurun_out/prof_gemm
 mkdir -p $OUT
@@ -26,9 +26,7 @@ run() { name=$1; shift; timeout 200 rocprofv3 "$@" --output-format csv -d $OUT/$
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python /tmp/gemm_once.py > $OUT/kt.log 2>&1
 run pmc_sq --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
 run pmc_sq2 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS
-run pmc_ta --pmc TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_ADDR_STALLED_BY_TD_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum TA_TOTAL_WAVEFRONTS_sum
-run pmc_tcp --pmc TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TA_TCP_STATE_READ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum
-run pmc_tcp2 --pmc TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_REQUEST_sum TCP_UTCL1_STALL_MULTI_MISS_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+# (TA_* / TCP_* / TCC_* passes abort in rocprofv3 on this image -- signal 6 after the timeout -- and are not run)
 python $REPO/scripts/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 find $OUT -name "*.csv" -size +1M -delete
-cat $OUT/summary.txt | tail -150; for f in $OUT/pmc_ta.log $OUT/pmc_tcp.log $OUT/pmc_tcp2.log; do tail -2 $f; done
+cat $OUT/summary.txt | tail -100
