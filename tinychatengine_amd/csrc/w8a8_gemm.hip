@@ -55,12 +55,25 @@ __device__ __forceinline__ void epilogue_store(const W8A8Args &a, void *Cb, int 
 }
 
 // 4 waves as 2(M) x 2(N); each wave 2x2 MFMA tiles of 16x16 -> 64x64 per workgroup.
+//
+// Operand fragments: the MFMA wants row (lane % 16) and k-slice (lane / 16) in a lane.  Loading that straight from a
+// K-contiguous matrix makes the 16 lanes of every quarter-wave read 16 different rows -- 64 cache-line look-ups per wave
+// load, and the texture-address unit, not HBM or the matrix pipe, bounded the kernel (512x3072x768: 15.7 us; with a
+// coalesced but wrong lane mapping 7.9 us).  So a lane loads row (lane / 4), chunk (lane % 4) -- 4 consecutive lanes read
+// one row's 64 bytes -- and the 16x64-byte fragment is transposed through a per-wave 1 KiB LDS slot: lane-linear
+// ds_write_b128 with an XOR swizzle (slot = row*4 + (chunk ^ (row/4 % 4))), one ds_read_b128 back in MFMA order
+// (conflict-free both ways).  A wave's LDS operations complete in order, so one slot per fragment is enough and no
+// barrier is involved.
 __global__ __launch_bounds__(256) void w8a8_mfma_kernel(const W8A8Args a) {
+    __shared__ __attribute__((aligned(16))) int4_t lds_t[4][4][64];  // [wave][fragment: A0 A1 B0 B1][slot]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int r16 = lane & 15, kq = lane >> 4;
+    const int r16 = lane & 15, kq = lane >> 4;   // MFMA view of the lane
+    const int lrow = lane >> 2, lchunk = lane & 3;  // load view of the lane
+    const int wslot = lrow * 4 + (lchunk ^ ((lrow >> 2) & 3));
+    const int rslot = r16 * 4 + (kq ^ ((r16 >> 2) & 3));
     const int batch = blockIdx.z;
     const int8_t *A = a.A + (size_t)batch * a.strideA;
     const int8_t *B = a.B + (size_t)batch * a.strideB;
@@ -73,12 +86,12 @@ __global__ __launch_bounds__(256) void w8a8_mfma_kernel(const W8A8Args a) {
     const int8_t *pa[2], *pb[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        int m = m_base + i * 16 + r16;
+        int m = m_base + i * 16 + lrow;
         m = m < a.M ? m : a.M - 1;
-        pa[i] = A + (size_t)m * a.K + kq * 16;
-        int n = n_base + i * 16 + r16;
+        pa[i] = A + (size_t)m * a.K + lchunk * 16;
+        int n = n_base + i * 16 + lrow;
         n = n < a.N ? n : a.N - 1;
-        pb[i] = B + (size_t)n * a.K + kq * 16;
+        pb[i] = B + (size_t)n * a.K + lchunk * 16;
     }
     int4_t acc[2][2];
 #pragma unroll
@@ -92,39 +105,62 @@ __global__ __launch_bounds__(256) void w8a8_mfma_kernel(const W8A8Args a) {
         bterm[j] = bias_term(a, n < a.N ? n : a.N - 1);
     }
 
-    const int k_full = a.K & ~63;
-    // (A 4-deep register ring with counted waits measured 15-20 % SLOWER than this plain loop on the OPT shapes --
-    // 18.9 vs 15.7 us at 512x3072x768: more fragments in flight per wave is not what these launches lack.)
-#pragma unroll 4
-    for (int k0 = 0; k0 < k_full; k0 += 64) {
+    // one k-step (64 k): raw fragments -> LDS -> MFMA order -> 4 MFMAs
+    auto contract = [&](const int4_t (&ra)[2], const int4_t (&rb)[2]) {
         int4_t fa[2], fb[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            fa[i] = *reinterpret_cast<const int4_t *>(pa[i] + k0);
-            fb[i] = *reinterpret_cast<const int4_t *>(pb[i] + k0);
+            lds_t[wave][i][wslot] = ra[i];
+            lds_t[wave][2 + i][wslot] = rb[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            fa[i] = lds_t[wave][i][rslot];
+            fb[i] = lds_t[wave][2 + i][rslot];
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    }
-    if (k_full < a.K) {  // K % 64 in {16,32,48}: k-blocks past the end contribute zeros (K % 16 == 0 is guaranteed)
-        const bool live = k_full + kq * 16 < a.K;
-        int4_t fa[2], fb[2];
+    };
+
+    const int k_full = a.K & ~63;
+    // the next k-step's raw fragments are requested before the current one goes through LDS and the MFMAs (two static
+    // register sets; requests past the end are clamped re-reads)
+    auto load_raw = [&](int4_t (&ra)[2], int4_t (&rb)[2], int k0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int koff = live ? k_full : 0;  // dead k-blocks re-read a valid address and are zeroed
-            fa[i] = *reinterpret_cast<const int4_t *>(pa[i] + koff);
-            fb[i] = *reinterpret_cast<const int4_t *>(pb[i] + koff);
-            if (!live) {
-                fa[i] = int4_t{0, 0, 0, 0};
-                fb[i] = int4_t{0, 0, 0, 0};
+            ra[i] = *reinterpret_cast<const int4_t *>(pa[i] + k0);
+            rb[i] = *reinterpret_cast<const int4_t *>(pb[i] + k0);
+        }
+    };
+    if (k_full > 0) {
+        const int k_last = k_full - 64;
+        int4_t ra0[2], rb0[2], ra1[2], rb1[2];
+        load_raw(ra0, rb0, 0);
+        for (int k0 = 0; k0 < k_full; k0 += 128) {
+            load_raw(ra1, rb1, k0 + 64 <= k_last ? k0 + 64 : k_last);
+            contract(ra0, rb0);
+            if (k0 + 64 < k_full) {
+                load_raw(ra0, rb0, k0 + 128 <= k_last ? k0 + 128 : k_last);
+                contract(ra1, rb1);
             }
         }
+    }
+    if (k_full < a.K) {  // K % 64 in {16,32,48}: chunks past the end contribute zeros (K % 16 == 0 is guaranteed)
+        const bool live = k_full + lchunk * 16 < a.K;
+        int4_t ra[2], rb[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 2; ++i) {
+            const int koff = live ? k_full : 0;  // dead chunks re-read a valid address and are zeroed
+            ra[i] = *reinterpret_cast<const int4_t *>(pa[i] + koff);
+            rb[i] = *reinterpret_cast<const int4_t *>(pb[i] + koff);
+            if (!live) {
+                ra[i] = int4_t{0, 0, 0, 0};
+                rb[i] = int4_t{0, 0, 0, 0};
+            }
+        }
+        contract(ra, rb);
     }
 
     // D[row = 4*(lane>>4) + r][col = lane & 15]
