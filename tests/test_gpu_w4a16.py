@@ -360,3 +360,22 @@ def test_full_size_prefill_gemm(dev, oracle, N, K):
     torch.cuda.synchronize()
     ok, worst = w4a16_close(y[3:7].cpu().numpy(), yv.float().cpu().numpy(), rel=2e-3)  # two fp16-rounded results
     assert ok, worst
+
+
+def test_randomized_shapes_match_oracle(dev, oracle):
+    """Seeded random (M, N, K, G, zero points): every dispatch path (row-block GEMV with and without a K split, M-row
+    batches, the GEMV fallback of non-128 groups at M > 8, the MFMA GEMM) against the oracle."""
+    from tinychatengine_amd import capi
+    rng = np.random.default_rng(20240807)
+    for case in range(24):
+        G = int(rng.choice([32, 64, 128]))
+        K = G * int(rng.integers(1, 40))
+        if K % 32:
+            K = (K // 32 + 1) * 32
+        while K % G:
+            K += 32
+        N = int(rng.integers(1, 700))
+        M = int(rng.choice([1, 1, 1, 2, 3, 5, 8, 9, 17, 70]))
+        qw, sc, zp, a = _make(oracle, M, N, K, G, seed=1000 + case, random_zeros=bool(case % 2))
+        ref32, _ = oracle.w4a16_gemv_q4_6(a, qw, sc, zp, M, N, K, G)
+        _check(_run(dev, qw, sc, zp, a, G), ref32, f"random case {case}: {M}x{N}x{K} g{G}")
