@@ -89,7 +89,26 @@ typedef struct tce_w4a16_desc {
                                     0x88888888 -- what the reference quantizer always writes, quantize_methods.py:436-440):
                                     the GEMV then does not stream the zeros.  Results are identical when the promise holds. */
 
+/* Fused decode epilogues: the element-wise kernels the reference launches right behind these linears,
+ * with the same fp16 arithmetic, applied while the result is still in registers.
+ *   TCE_W4_SILU_MUL_PAIRS  replaces gate_proj + up_proj + SiLuMul_half (Int4llamaDecoderLayer.cu:20-30, 96-102): the
+ *       linear holds the two projections' rows INTERLEAVED (row 2n = gate row n, row 2n+1 = up row n; a load-time row
+ *       permutation, like the reference's offline qkv merge), N is even, and
+ *           C[m][n] = hmul( hmul(g, hdiv(1, hadd(1, hexp(hneg(g))))), u ),  g = fp16(y[m][2n]), u = fp16(y[m][2n+1])
+ *       with every operation rounded to fp16 as in the reference kernel.  C is [M][N/2] (ldc 0 = N/2).  M <= 8 path.
+ *   TCE_W4_ADD_TO_C        replaces o_proj / down_proj + add_half (Int4llamaDecoderLayer.cu:12-18, 86-88, 107-108):
+ *           C[m][n] = hadd(C[m][n], fp16(y[m][n]))   (C holds the residual on entry, like residual_add there). */
+#define TCE_W4_SILU_MUL_PAIRS 8
+#define TCE_W4_ADD_TO_C 16
+
 TCE_API int tce_w4a16_forward(const tce_w4a16_desc *d, void *stream);
+
+/* The same two element-wise operations as stand-alone kernels (for hosts that keep the reference's launch structure):
+ *   tce_add_half:       c[i] = hadd(a[i], b[i])                                   (add_half, Int4llamaDecoderLayer.cu:12-18)
+ *   tce_silu_mul_half:  a[i] = hmul(hmul(a[i], hdiv(1, hadd(1, hexp(-a[i])))), b[i])  (SiLuMul_half, :20-30)
+ * n halves; pointers 16-byte aligned; c may alias a or b. */
+TCE_API int tce_add_half(const void *a, const void *b, void *c, long long n, void *stream);
+TCE_API int tce_silu_mul_half(void *a, const void *b, long long n, void *stream);
 
 /* Load-time helper for TCE_W4_ZERO_POINT_IS_8: returns 1 if all `n_words` packed zero-point words are 0x88888888, 0 if
  * not, negative on error.  Synchronous; call it once per weight tensor (weights are immutable after loading). */

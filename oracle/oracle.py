@@ -190,6 +190,18 @@ class Oracle(_Lib):
         self.lib.orc_w4a16_gemv_q4_6(C.c_int(M), C.c_int(N), C.c_int(K), C.c_int(G), _p(A), _p(q), _p(s), _p(z), _p(c32), _p(c16))
         return c32, c16.view(np.float16)
 
+    def add_half(self, a_f16, b_f16):
+        a = np.ascontiguousarray(a_f16, np.float16).view(np.uint16); b = np.ascontiguousarray(b_f16, np.float16).view(np.uint16)
+        out = np.empty(a.shape, np.uint16)
+        self.lib.orc_add_half(_p(a), _p(b), _p(out), C.c_int64(a.size))
+        return out.view(np.float16)
+
+    def silu_mul_half(self, gate_f16, up_f16):
+        a = np.ascontiguousarray(gate_f16, np.float16).view(np.uint16); b = np.ascontiguousarray(up_f16, np.float16).view(np.uint16)
+        out = np.empty(a.shape, np.uint16)
+        self.lib.orc_silu_mul_half(_p(a), _p(b), _p(out), C.c_int64(a.size))
+        return out.view(np.float16)
+
     def fp32_matmul_transposed(self, A, B, bias, M, N, K):
         A = np.ascontiguousarray(A, np.float32); B = np.ascontiguousarray(B, np.float32)
         bias = None if bias is None else np.ascontiguousarray(bias, np.float32)

@@ -521,3 +521,30 @@ ORC_API void orc_fp32_matmul_transposed(int M, int N, int K, const float *A, con
             C[(int64_t)i * N + j] = acc;
         }
 }
+
+/* ------------------------------------------------------------------------- */
+/* element-wise glue behind the W4A16 linears of a decoder layer */
+/* ------------------------------------------------------------------------- */
+
+/* add_half (llm/src/nn_modules/cuda/Int4llamaDecoderLayer.cu:12-18): c[i] = __hadd(a[i], b[i]), one binary16 rounding
+ * (the float sum of two halves is exact). */
+ORC_API void orc_add_half(const uint16_t *a, const uint16_t *b, uint16_t *c, int64_t n) {
+    for (int64_t i = 0; i < n; i++) c[i] = orc_f32_to_f16(orc_f16_to_f32(a[i]) + orc_f16_to_f32(b[i]));
+}
+
+/* SiLuMul_half (Int4llamaDecoderLayer.cu:20-30): a[i] = __hmul(__hmul(v, __hdiv(1, __hadd(1, hexp(__hneg(v))))), b[i]),
+ * every operation rounded to binary16.  The float product / sum of two halves is exact, so each is one rounding; the
+ * quotient is formed in double (no double-rounding case for an 11-bit result).  hexp: CUDA documents round-to-nearest
+ * of the exponential; restated as the C library's expf rounded to half.  A device exponential that differs from expf
+ * in the last float bit changes the half result only when that float sits on a rounding boundary (~1 element in 4000,
+ * by one half ulp of e, which moves the final product by at most one ulp): the GPU test allows exactly that. */
+ORC_API void orc_silu_mul_half(const uint16_t *a, const uint16_t *b, uint16_t *out, int64_t n) {
+    for (int64_t i = 0; i < n; i++) {
+        const float v = orc_f16_to_f32(a[i]);
+        const uint16_t e = orc_f32_to_f16(expf(-v));
+        const uint16_t d = orc_f32_to_f16(1.0f + orc_f16_to_f32(e));
+        const uint16_t r = orc_f64_to_f16(1.0 / (double)orc_f16_to_f32(d));
+        const uint16_t sv = orc_f32_to_f16(v * orc_f16_to_f32(r));
+        out[i] = orc_f32_to_f16(orc_f16_to_f32(sv) * orc_f16_to_f32(b[i]));
+    }
+}

@@ -182,6 +182,45 @@ def sweep_w8a8():
         print(json.dumps({"kind": "w8a8", "M": M, "N": N, "K": K, "us": round(us, 2), "TOPs": round(tops, 2)}), flush=True)
 
 
+def mlp_block():
+    """One decoder layer's post-attention half (o_proj, +residual, gate/up, SiLU*mul, down_proj, +residual): the
+    reference's launch structure on this library's kernels against the fused epilogues, one hipGraph each."""
+    from tinychatengine_amd.linear import Linear_half_int4
+    L = capi.lib()
+    for (name, h, f) in [("baseline-named 4096/11008", 4096, 11008), ("llama3-8b 4096/14336", 4096, 14336)]:
+        reps = 12  # distinct weight sets so that every launch streams from HBM
+        sets = []
+        for r in range(reps):
+            mk = lambda n, k: Linear_half_int4(torch.randint(-2**31, 2**31 - 1, (n, k // 8), dtype=torch.int32, device=dev),
+                                               (torch.rand((n, quantize.calculate_zeros_width(k, 128) * 8), device=dev) * 0.01).to(torch.float16),
+                                               torch.full((n, quantize.calculate_zeros_width(k, 128)), -2004318072, dtype=torch.int32, device=dev))
+            sets.append({"o": mk(h, h), "gate": mk(f, h), "up": mk(f, h), "gu": None, "down": mk(h, f)})
+            sets[-1]["gu"] = Linear_half_int4.interleave(sets[-1]["gate"], sets[-1]["up"])
+        x = torch.randn(1, h, device=dev).to(torch.float16); res = torch.randn(1, h, device=dev).to(torch.float16)
+        t_o = torch.empty(1, h, dtype=torch.float16, device=dev); t_g = torch.empty(1, f, dtype=torch.float16, device=dev)
+        t_u = torch.empty(1, f, dtype=torch.float16, device=dev); t_d = torch.empty(1, h, dtype=torch.float16, device=dev)
+
+        def unfused(i, sp):
+            w = sets[i % reps]
+            capi.check(capi.w4a16_forward(w["o"].desc(x, t_o), sp.value))
+            capi.check(L.tce_add_half(res.data_ptr(), t_o.data_ptr(), res.data_ptr(), h, sp))
+            capi.check(capi.w4a16_forward_group([w["gate"].desc(res, t_g), w["up"].desc(res, t_u)], sp.value))
+            capi.check(L.tce_silu_mul_half(t_g.data_ptr(), t_u.data_ptr(), f, sp))
+            capi.check(capi.w4a16_forward(w["down"].desc(t_g, t_d), sp.value))
+            capi.check(L.tce_add_half(res.data_ptr(), t_d.data_ptr(), res.data_ptr(), h, sp))
+
+        def fused(i, sp):
+            w = sets[i % reps]
+            capi.check(capi.w4a16_forward(w["o"].desc(x, res, flags=capi.TCE_W4_ADD_TO_C), sp.value))
+            capi.check(capi.w4a16_forward(w["gu"].desc(res, t_g, flags=capi.TCE_W4_SILU_MUL_PAIRS), sp.value))
+            capi.check(capi.w4a16_forward(w["down"].desc(t_g, res, flags=capi.TCE_W4_ADD_TO_C), sp.value))
+
+        for nm, fn, launches in (("reference launch structure (6 launches)", unfused, 6), ("fused epilogues (3 launches)", fused, 3)):
+            us = time_graph(fn, 24)
+            print(json.dumps({"kind": "mlp_block", "shape": name, "form": nm, "us_per_block": round(us, 2)}), flush=True)
+        del sets
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
@@ -216,6 +255,8 @@ def main():
         sweep_gemm([(4096, 4096), (11008, 4096), (4096, 11008)])
     if args.only in ("", "w8a8"):
         sweep_w8a8()
+    if args.only in ("", "mlp"):
+        mlp_block()
 
 
 if __name__ == "__main__":

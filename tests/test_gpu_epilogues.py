@@ -1,0 +1,120 @@
+"""GPU tests of the fused decode epilogues: gate_proj + up_proj + SiLuMul_half as one launch
+(TCE_W4_SILU_MUL_PAIRS) and o_proj / down_proj + add_half as one launch (TCE_W4_ADD_TO_C).
+
+The element-wise arithmetic is binary16 as in the reference kernels (Int4llamaDecoderLayer.cu:12-30) and restated in
+the oracle (orc_silu_mul_half / orc_add_half).  The fused launch must equal the oracle ops applied to the UNFUSED
+kernel's own fp16 outputs: bit for bit for the add, and within one half ulp-step for SiLU*mul (the device exponential
+may differ from the C library's in the last float bit; see the oracle's comment)."""
+import numpy as np
+import pytest
+
+from conftest import w4a16_close
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from tinychatengine_amd import capi
+    capi.lib()
+    capi.set_gemv_config()
+    return torch.device("cuda:0")
+
+
+def _ulps(a, b):
+    """Distance in binary16 steps between two half arrays (same sign assumed near zero handled by the bit trick)."""
+    ia = a.view(np.int16).astype(np.int32)
+    ib = b.view(np.int16).astype(np.int32)
+    ia = np.where(ia < 0, -32768 - ia, ia)
+    ib = np.where(ib < 0, -32768 - ib, ib)
+    return np.abs(ia - ib)
+
+
+CASES = [(1, 11008, 4096), (1, 344, 4096), (1, 72, 1408), (2, 520, 2048), (4, 256, 4096), (1, 14336, 4096), (12, 96, 1024)]
+
+
+@pytest.mark.parametrize("M,H,K", CASES)
+def test_gate_up_silu_mul_fused(dev, oracle, M, H, K):
+    from tinychatengine_amd import capi
+    from tinychatengine_amd.linear import Linear_half_int4
+    g = torch.Generator(device=dev).manual_seed(H + K + M)
+    gate = Linear_half_int4.from_float(torch.empty(H, K, device=dev).normal_(0, 0.05, generator=g))
+    up = Linear_half_int4.from_float(torch.empty(H, K, device=dev).normal_(0, 0.05, generator=g))
+    gu = Linear_half_int4.interleave(gate, up)
+    x = torch.empty(M, K, device=dev).normal_(0, 1, generator=g).to(torch.float16)
+    configs = [None] if M > 1 or H > 2000 else [None, (2, 4, 1, 1), (4, 4, 1, 1), (2, 2, 2, 1), (2, 8, 0, 2), (4, 16, 0, 2)]
+    try:
+        for cfg in configs:
+            capi.set_gemv_config(*(cfg or (0, 0, 0, 0)))
+            y = torch.empty(M, 2 * H, dtype=torch.float16, device=dev)
+            capi.check(capi.w4a16_forward(gu.desc(x, y, flags=capi.TCE_W4_FORCE_GEMV), torch.cuda.current_stream().cuda_stream))
+            fused = gu.forward_silu_mul(x)
+            torch.cuda.synchronize()
+            yn = y.cpu().numpy()
+            want = oracle.silu_mul_half(yn[:, 0::2], yn[:, 1::2])
+            got = fused.cpu().numpy()
+            assert got.shape == (M, H)
+            d = _ulps(got, want)
+            assert d.max() <= 1, f"cfg {cfg}: {int((d > 1).sum())} outputs differ by more than one half step (max {int(d.max())})"
+            assert (d > 0).mean() < 2e-3, f"cfg {cfg}: {float((d > 0).mean()):.4f} of the outputs differ from the oracle"
+    finally:
+        capi.set_gemv_config()
+    # and the unfused outputs themselves are the two projections (row 2n = gate n, row 2n+1 = up n)
+    if M == 1:
+        a = x.cpu().numpy()
+        ref_g, _ = oracle.w4a16_gemv_q4_6(a, gate.weight.cpu().numpy().view(np.uint32), gate.scale.cpu().numpy(),
+                                          gate.zero_point.cpu().numpy().view(np.uint32), M, H, K, 128)
+        ok, worst = w4a16_close(yn[:, 0::2], ref_g)
+        assert ok, f"interleaved gate rows: worst |err|/tol = {worst:.3f}"
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (1, 4096, 11008), (3, 264, 2048), (1, 100, 1408), (64, 256, 1024), (100, 200, 512)])
+def test_projection_plus_residual_fused(dev, oracle, M, N, K):
+    from tinychatengine_amd import capi
+    from tinychatengine_amd.linear import Linear_half_int4
+    g = torch.Generator(device=dev).manual_seed(N + K + M)
+    lin = Linear_half_int4.from_float(torch.empty(N, K, device=dev).normal_(0, 0.05, generator=g))
+    x = torch.empty(M, K, device=dev).normal_(0, 1, generator=g).to(torch.float16)
+    res = torch.empty(M, N, device=dev).normal_(0, 2, generator=g).to(torch.float16)
+    y = torch.empty(M, N, dtype=torch.float16, device=dev)
+    capi.check(capi.w4a16_forward(lin.desc(x, y), torch.cuda.current_stream().cuda_stream))
+    inout = res.clone()
+    lin.forward_add(x, inout)
+    torch.cuda.synchronize()
+    want = oracle.add_half(res.cpu().numpy(), y.cpu().numpy())
+    assert np.array_equal(inout.cpu().numpy().view(np.uint16), want.view(np.uint16))
+
+
+def test_pair_epilogue_rejects_bad_descriptors(dev, oracle):
+    from tinychatengine_amd import capi
+    from tinychatengine_amd.linear import Linear_half_int4
+    lin = Linear_half_int4.from_float(torch.randn(48, 256, device=dev) * 0.05)
+    odd = Linear_half_int4(lin.weight[:47].contiguous(), lin.scale[:47].contiguous(), lin.zero_point[:47].contiguous())
+    x = torch.randn(1, 256, device=dev).to(torch.float16)
+    out = torch.empty(1, 24, dtype=torch.float16, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    assert capi.w4a16_forward(odd.desc(x, out, flags=capi.TCE_W4_SILU_MUL_PAIRS), s) == capi.TCE_ERR_UNSUPPORTED_SHAPE
+    assert capi.w4a16_forward(lin.desc(x, out, flags=capi.TCE_W4_SILU_MUL_PAIRS | capi.TCE_W4_ADD_TO_C), s) == capi.TCE_ERR_BAD_ARG
+
+
+@pytest.mark.parametrize("n", [8, 4096, 11008, 11008 * 3 + 8, 4099 * 8])
+def test_standalone_glue_kernels(dev, oracle, n):
+    """tce_add_half bit-exact, tce_silu_mul_half within one half step of the oracle (same caveat as the fused form)."""
+    import ctypes as C
+    from tinychatengine_amd import capi
+    g = torch.Generator(device=dev).manual_seed(n)
+    a = (torch.empty(n, device=dev).normal_(0, 3, generator=g)).to(torch.float16)
+    b = (torch.empty(n, device=dev).normal_(0, 3, generator=g)).to(torch.float16)
+    c = torch.empty_like(a)
+    L, s = capi.lib(), C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    capi.check(L.tce_add_half(a.data_ptr(), b.data_ptr(), c.data_ptr(), n, s))
+    torch.cuda.synchronize()
+    assert np.array_equal(c.cpu().numpy().view(np.uint16), oracle.add_half(a.cpu().numpy(), b.cpu().numpy()).view(np.uint16))
+    want = oracle.silu_mul_half(a.cpu().numpy(), b.cpu().numpy())
+    capi.check(L.tce_silu_mul_half(a.data_ptr(), b.data_ptr(), n, s))
+    torch.cuda.synchronize()
+    d = _ulps(a.cpu().numpy(), want)
+    assert d.max() <= 1 and (d > 0).mean() < 2e-3

@@ -158,3 +158,19 @@ def test_x86_interleave_branch_and_avx_baseline_sanity(oracle):
     if O.have_ref_avx():
         avx = O.ReferenceAVX(num_thread=4).w4a8(A[:1], B, d.reshape(N, -1), 1, N, K)
         assert float(np.mean((avx - mine[:1]) ** 2)) <= 7e-4
+
+
+def test_glue_ops_are_binary16_arithmetic(oracle):
+    """orc_add_half / orc_silu_mul_half (Int4llamaDecoderLayer.cu:12-30) against numpy's float16 arithmetic, which rounds
+    every operation to binary16 like __hadd / __hmul / __hdiv; exp is the float exponential rounded to half."""
+    rng = np.random.default_rng(8)
+    a = (rng.standard_normal(20000) * 4).astype(np.float16)
+    b = (rng.standard_normal(20000) * 4).astype(np.float16)
+    a[:8] = np.array([0.0, -0.0, 65504, -65504, 6e-8, -6e-8, 11.09, -17.0], np.float16)
+    assert np.array_equal(oracle.add_half(a, b).view(np.uint16), (a + b).view(np.uint16))
+    one = np.float16(1)
+    with np.errstate(over="ignore"):
+        e = np.exp((-a).astype(np.float32)).astype(np.float16)
+        want = (a * (one / (one + e))) * b
+    got = oracle.silu_mul_half(a, b)
+    assert np.array_equal(got.view(np.uint16), want.view(np.uint16))

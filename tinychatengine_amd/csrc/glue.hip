@@ -1,0 +1,61 @@
+// glue.hip -- the two element-wise kernels the reference launches around the W4A16 linears of a decoder layer
+// (llm/src/nn_modules/cuda/Int4llamaDecoderLayer.cu:12-30), for hosts that do not use the fused epilogues
+// (TCE_W4_ADD_TO_C / TCE_W4_SILU_MUL_PAIRS) and as the unfused side of the fusion measurements.  Same binary16
+// arithmetic; 8 halves (16 bytes) per thread, HBM-bound.
+#include "tce_common.hpp"
+#include "w4a16_kernels.hpp"
+
+namespace tce {
+
+namespace {
+
+__global__ __launch_bounds__(256) void add_half_kernel(const half_t *a, const half_t *b, half_t *c, long long n) {
+    const long long i8 = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i8 + 8 <= n) {
+        const half8_t va = *reinterpret_cast<const half8_t *>(a + i8), vb = *reinterpret_cast<const half8_t *>(b + i8);
+        *reinterpret_cast<half8_t *>(c + i8) = va + vb;  // element-wise binary16 adds (-ffp-contract=off)
+    } else {
+        for (long long i = i8; i < n; ++i) c[i] = a[i] + b[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void silu_mul_half_kernel(half_t *a, const half_t *b, long long n) {
+    const long long i8 = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i8 + 8 <= n) {
+        half8_t va = *reinterpret_cast<const half8_t *>(a + i8);
+        const half8_t vb = *reinterpret_cast<const half8_t *>(b + i8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) va[j] = silu_mul_half(va[j], vb[j]);
+        *reinterpret_cast<half8_t *>(a + i8) = va;
+    } else {
+        for (long long i = i8; i < n; ++i) a[i] = silu_mul_half(a[i], b[i]);
+    }
+}
+
+}  // namespace
+
+int launch_add_half(const void *a, const void *b, void *c, long long n, hipStream_t stream, hipError_t *hip_err) {
+    const long long blocks = (n + 2047) / 2048;
+    hipLaunchKernelGGL(add_half_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<const half_t *>(a),
+                       static_cast<const half_t *>(b), static_cast<half_t *>(c), n);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (hip_err) *hip_err = e;
+        return TCE_ERR_HIP;
+    }
+    return TCE_OK;
+}
+
+int launch_silu_mul_half(void *a, const void *b, long long n, hipStream_t stream, hipError_t *hip_err) {
+    const long long blocks = (n + 2047) / 2048;
+    hipLaunchKernelGGL(silu_mul_half_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<half_t *>(a),
+                       static_cast<const half_t *>(b), n);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (hip_err) *hip_err = e;
+        return TCE_ERR_HIP;
+    }
+    return TCE_OK;
+}
+
+}  // namespace tce

@@ -49,6 +49,10 @@ int check_w4a16(const tce_w4a16_desc *d) {
     if (lda % 8 != 0 || reinterpret_cast<uintptr_t>(d->A) % 16 != 0)
         return fail(TCE_ERR_UNSUPPORTED_SHAPE, "A must be 16-byte aligned with lda %% 8 == 0");
     if (reinterpret_cast<uintptr_t>(d->qweight) % 16 != 0) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "qweight must be 16-byte aligned");
+    if (d->flags & TCE_W4_SILU_MUL_PAIRS) {
+        if (d->N % 2 != 0) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "TCE_W4_SILU_MUL_PAIRS needs an even N (interleaved gate/up rows), got %d", d->N);
+        if (d->flags & (TCE_W4_ADD_TO_C | TCE_W4_FORCE_GEMM)) return fail(TCE_ERR_BAD_ARG, "TCE_W4_SILU_MUL_PAIRS cannot be combined with ADD_TO_C / FORCE_GEMM");
+    }
     return TCE_OK;
 }
 
@@ -209,7 +213,9 @@ int tce_w4a16_forward_group(const tce_w4a16_desc *descs, int count, void *stream
 int tce_w4a16_forward(const tce_w4a16_desc *d, void *stream) {
     const int rc0 = check_w4a16(d);
     if (rc0 != TCE_OK) return rc0;
-    const bool want_gemm = (d->flags & TCE_W4_FORCE_GEMM) || (d->M > TCE_W4A16_GEMV_MAX_M && !(d->flags & TCE_W4_FORCE_GEMV));
+    // (the pair epilogue lives in the GEMV kernels: for M > 8 it runs there too, 4 activation rows per pass)
+    const bool want_gemm = (d->flags & TCE_W4_FORCE_GEMM) ||
+                           (d->M > TCE_W4A16_GEMV_MAX_M && !(d->flags & (TCE_W4_FORCE_GEMV | TCE_W4_SILU_MUL_PAIRS)));
     hipError_t he = hipSuccess;
     if (want_gemm && d->K % 128 == 0 && d->group_size == 128) {  // other group sizes: GEMV kernel, 4 rows per pass
         const int rc = tce::launch_w4a16_gemm(*d, g_gemm_mt, g_gemm_nt, static_cast<hipStream_t>(stream), &he);
@@ -267,6 +273,24 @@ int tce_w4a16_gemm_awq(int M, int N, int K, int G, const void *A, const void *qw
     d.scales = static_cast<const unsigned *>(d.zeros) + (size_t)N * zw;
     d.C = C;
     return tce_w4a16_forward(&d, stream);
+}
+
+int tce_add_half(const void *a, const void *b, void *c, long long n, void *stream) {
+    if (!a || !b || !c || n <= 0) return fail(TCE_ERR_BAD_ARG, "tce_add_half: bad argument");
+    if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) % 16 != 0)
+        return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_add_half: pointers must be 16-byte aligned");
+    hipError_t he = hipSuccess;
+    const int rc = tce::launch_add_half(a, b, c, n, static_cast<hipStream_t>(stream), &he);
+    return rc == TCE_ERR_HIP ? hip_fail(he, "add_half launch") : rc;
+}
+
+int tce_silu_mul_half(void *a, const void *b, long long n, void *stream) {
+    if (!a || !b || n <= 0) return fail(TCE_ERR_BAD_ARG, "tce_silu_mul_half: bad argument");
+    if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) % 16 != 0)
+        return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_silu_mul_half: pointers must be 16-byte aligned");
+    hipError_t he = hipSuccess;
+    const int rc = tce::launch_silu_mul_half(a, b, n, static_cast<hipStream_t>(stream), &he);
+    return rc == TCE_ERR_HIP ? hip_fail(he, "silu_mul_half launch") : rc;
 }
 
 int tce_w8a8_matmul(const tce_w8a8_desc *d, void *stream) {

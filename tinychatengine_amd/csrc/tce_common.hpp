@@ -120,6 +120,17 @@ __device__ __forceinline__ float wave_sum_dpp_lane63(float v) {
     return v;
 }
 
+// SiLuMul_half (llm/src/nn_modules/cuda/Int4llamaDecoderLayer.cu:20-30): v * (1 / (1 + hexp(-v))) * u with every operation
+// rounded to binary16 (hexp = the float exponential rounded to nearest half).
+__device__ __forceinline__ half_t silu_mul_half(half_t g, half_t u) {
+    const half_t one = (half_t)1.0f;
+    const half_t e = (half_t)expf((float)(-g));  // see oracle/tce_oracle.c orc_silu_mul_half for the 1-ulp caveat
+    const half_t d = one + e;
+    const half_t r = one / d;
+    const half_t sv = g * r;
+    return sv * u;
+}
+
 // non-temporal 16-byte load: streamed weights are read exactly once by exactly one CU
 __device__ __forceinline__ uint4_t load_nt(const uint4_t *p) { return __builtin_nontemporal_load(p); }
 

@@ -33,6 +33,7 @@ struct GemmArgs {
     half_t *C;
     int M, N, K, lda, ldc, scales_stride, zeros_stride, log2g;
     int n_blocks, m_blocks;
+    int add_to_c;  // TCE_W4_ADD_TO_C
 };
 
 template <int MT, int NT>
@@ -195,7 +196,10 @@ __global__ __launch_bounds__(256, (MT * NT >= 16 ? 1 : 2)) void w4a16_gemm_kerne
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m_base + i * 16 + q * 4 + r;
-                if (m < g.M && n < g.N) g.C[(size_t)m * g.ldc + n] = (half_t)acc[i][j][r];
+                if (m < g.M && n < g.N) {
+                    half_t *c = g.C + (size_t)m * g.ldc + n;
+                    *c = g.add_to_c ? (half_t)(*c + (half_t)acc[i][j][r]) : (half_t)acc[i][j][r];
+                }
             }
         }
 }
@@ -383,7 +387,10 @@ __global__ __launch_bounds__(256, (MT * NT >= 16 ? 1 : 2)) void w4a16_gemm_lds_k
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m_base + i * 16 + q * 4 + r;
-                if (m < g.M && n < g.N) g.C[(size_t)m * g.ldc + n] = (half_t)acc[i][j][r];
+                if (m < g.M && n < g.N) {
+                    half_t *c = g.C + (size_t)m * g.ldc + n;
+                    *c = g.add_to_c ? (half_t)(*c + (half_t)acc[i][j][r]) : (half_t)acc[i][j][r];
+                }
             }
         }
 }
@@ -443,6 +450,7 @@ int launch_w4a16_gemm(const tce_w4a16_desc &d, int forced_mt, int forced_nt, hip
     g.K = d.K;
     g.lda = d.lda ? d.lda : d.K;
     g.ldc = d.ldc ? d.ldc : d.N;
+    g.add_to_c = (d.flags & TCE_W4_ADD_TO_C) ? 1 : 0;
     g.scales_stride = d.scales_stride ? d.scales_stride : zw * 8;
     g.zeros_stride = d.zeros_stride ? d.zeros_stride : zw;
     g.log2g = d.group_size == 128 ? 7 : (d.group_size == 64 ? 6 : 5);

@@ -337,9 +337,22 @@ __global__ __launch_bounds__(64 * WN * WK, (MB * ROWS * DEPTH >= 8 ? 2 : (MB * R
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
             if (m0 + m >= args.M) continue;
+            half_t *crow = seg.C + (size_t)(m0 + m) * seg.ldc;
+            if (seg.epilogue & TCE_W4_SILU_MUL_PAIRS) {  // rows (2n, 2n+1) = (gate n, up n); the host picked an even ROWS
+                if constexpr (ROWS % 2 == 0) {
 #pragma unroll
-            for (int i = 0; i < ROWS; ++i)
-                if (row_base + i < seg.N) seg.C[(size_t)(m0 + m) * seg.ldc + row_base + i] = (half_t)red[i][m];
+                    for (int i = 0; i < ROWS; i += 2)
+                        if (row_base + i + 1 < seg.N) crow[(row_base + i) >> 1] = silu_mul_half((half_t)red[i][m], (half_t)red[i + 1][m]);
+                }
+            } else if (seg.epilogue & TCE_W4_ADD_TO_C) {
+#pragma unroll
+                for (int i = 0; i < ROWS; ++i)
+                    if (row_base + i < seg.N) crow[row_base + i] = crow[row_base + i] + (half_t)red[i][m];
+            } else {
+#pragma unroll
+                for (int i = 0; i < ROWS; ++i)
+                    if (row_base + i < seg.N) crow[row_base + i] = (half_t)red[i][m];
+            }
         }
     }
 }
@@ -468,6 +481,14 @@ int launch_w4a16_gemv(const tce_w4a16_desc *descs, int count, int forced_rows, i
         else if (nchunks >= 128) v = {1, 2, 2, 1};
         else v = {1, 4, 1, 1};
     }
+    bool pairs = false;
+    for (int i = 0; i < count; ++i) pairs = pairs || (descs[i].flags & TCE_W4_SILU_MUL_PAIRS);
+    if (pairs && (v.rows & 1)) {  // a (gate, up) row pair must sit in one wave: the 2-row sibling of the chosen geometry
+        v.rows = 2;
+        if (v.wk == 4) v.wk = 2;
+        if (!gemv_variant_exists(v.rows, v.wn, v.wk, v.depth)) v.depth = 1;
+        if (!gemv_variant_exists(v.rows, v.wn, v.wk, v.depth)) v = {2, 4, 1, 1};
+    }
     {
         // the kernel's prologue needs DEPTH <= T; shrink the pipeline for short K
         const int T = (nchunks + 64 * v.wk - 1) / (64 * v.wk);
@@ -485,7 +506,8 @@ int launch_w4a16_gemv(const tce_w4a16_desc *descs, int count, int forced_rows, i
         s.zeros = static_cast<const unsigned *>(d.zeros);
         s.C = static_cast<half_t *>(d.C);
         s.N = d.N;
-        s.ldc = d.ldc ? d.ldc : d.N;
+        s.epilogue = d.flags & (TCE_W4_SILU_MUL_PAIRS | TCE_W4_ADD_TO_C);
+        s.ldc = d.ldc ? d.ldc : ((s.epilogue & TCE_W4_SILU_MUL_PAIRS) ? d.N / 2 : d.N);
         s.scales_stride = d.scales_stride ? d.scales_stride : zw * 8;
         s.zeros_stride = d.zeros_stride ? d.zeros_stride : zw;
         // buffer descriptors address 32-bit byte offsets

@@ -273,6 +273,7 @@ __device__ __forceinline__ void gemv_launch_body(const StreamLaunch &L, const Ba
     int c_end = nseg > 1 ? L.seg[1].block_begin : n_rg;
     half_t *c_C = L.seg[0].C;
     int c_N = L.seg[0].N;
+    int c_epi = L.seg[0].epilogue;
 
     auto compute = [&](const Step &st) {
         const int t = c_t;
@@ -333,8 +334,10 @@ __device__ __forceinline__ void gemv_launch_body(const StreamLaunch &L, const Ba
             } while (c_rg >= c_end);
             c_C = L.seg[c_si].C;
             c_N = L.seg[c_si].N;
+            c_epi = L.seg[c_si].epilogue;
         }
         const int row0 = (c_rg - c_begin) * ROWS;
+        half_t outv[ROWS];
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) {
             float v = corr[i] * -0.0625f;
@@ -344,13 +347,32 @@ __device__ __forceinline__ void gemv_launch_body(const StreamLaunch &L, const Ba
             v = __builtin_fmaf(acc[i][3], diag[3], v);
             if constexpr (MODE == 1) v = acc[i][0];
             v = wave_sum_dpp_lane63(v);  // total in lane 63
-            // device-scope (write-through) store: visible to the next launch's coherent reads without a cache flush
-            if (lane == 63 && row0 + i < c_N)
-                __hip_atomic_store(reinterpret_cast<unsigned short *>(c_C + row0 + i), __builtin_bit_cast(unsigned short, (half_t)v),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            outv[i] = (half_t)v;
             corr[i] = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+        }
+        // device-scope (write-through) stores: visible to the next launch's coherent reads without a cache flush
+        auto put = [&](int idx, half_t h) {
+            __hip_atomic_store(reinterpret_cast<unsigned short *>(c_C + idx), __builtin_bit_cast(unsigned short, h), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        };
+        if (lane == 63) {
+            if (c_epi & TCE_W4_SILU_MUL_PAIRS) {  // rows (2n, 2n+1) = (gate n, up n); the host picked an even ROWS
+                if constexpr (ROWS % 2 == 0) {
+#pragma unroll
+                    for (int i = 0; i < ROWS; i += 2)
+                        if (row0 + i + 1 < c_N) put((row0 + i) >> 1, silu_mul_half(outv[i], outv[i + 1]));
+                }
+            } else if (c_epi & TCE_W4_ADD_TO_C) {
+#pragma unroll
+                for (int i = 0; i < ROWS; ++i)
+                    if (row0 + i < c_N) put(row0 + i, c_C[row0 + i] + outv[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < ROWS; ++i)
+                    if (row0 + i < c_N) put(row0 + i, outv[i]);
+            }
         }
         c_t = 0;
     };
@@ -462,6 +484,7 @@ bool fill_launch(const tce_w4a16_desc *descs, int count, int rows, StreamLaunch 
         s.zeros = static_cast<const unsigned *>(d.zeros);
         s.C = static_cast<half_t *>(d.C);
         s.N = d.N;
+        s.epilogue = d.flags & (TCE_W4_SILU_MUL_PAIRS | TCE_W4_ADD_TO_C);
         s.ldc = d.ldc ? d.ldc : d.N;
         s.scales_stride = d.scales_stride ? d.scales_stride : zw * 8;
         s.zeros_stride = d.zeros_stride ? d.zeros_stride : zw;
@@ -525,6 +548,8 @@ int launch_w4a16_gemv_stream(const tce_w4a16_desc *descs, int count, hipStream_t
     if (bpc * nw > 32) bpc = 32 / nw > 0 ? 32 / nw : 1;  // 8 waves per SIMD at most
     const int32_t one_group = count;
     if (rows == 0) rows = pick_rows(descs, &one_group, 1, (long)cus * bpc * nw);
+    for (int i = 0; i < count; ++i)
+        if ((descs[i].flags & TCE_W4_SILU_MUL_PAIRS) && rows == 1) rows = 2;  // a (gate, up) row pair sits in one row group
     if (rows != 1 && rows != 2 && rows != 4) return TCE_ERR_BAD_ARG;
     if (depth == 0) depth = rows == 1 ? 3 : 2;  // deeper rings measured slower: the memory system is oversubscribed as it is
     if (rows == 4 && depth > 2) depth = 2;
@@ -619,6 +644,12 @@ int token_plan_create(const tce_w4a16_desc *descs, const int32_t *groups, int n_
     int bpc = g_stream_bpc ? g_stream_bpc : 1;
     if (bpc * tp.nw > 16) bpc = 16 / tp.nw > 0 ? 16 / tp.nw : 1;
     tp.rows = g_stream_rows ? g_stream_rows : pick_rows(descs, groups, n_launches, (long)cus * bpc * tp.nw);
+    {
+        int total = 0;
+        for (int l = 0; l < n_launches; ++l) total += groups[l];
+        for (int i = 0; i < total; ++i)
+            if ((descs[i].flags & TCE_W4_SILU_MUL_PAIRS) && tp.rows == 1) tp.rows = 2;
+    }
     tp.depth = g_stream_depth ? g_stream_depth : (tp.rows == 4 ? 2 : 3);
     if (tp.rows == 4) tp.depth = 2;
     if (tp.rows == 1) tp.depth = 3;

@@ -13,6 +13,7 @@ struct GemvSeg {
     int N, ldc, scales_stride, zeros_stride;
     int bytes_w, bytes_s, bytes_z;  // extents for the buffer descriptors (each < 2 GiB)
     int block_begin;         // first blockIdx.x of this linear
+    int epilogue;            // TCE_W4_SILU_MUL_PAIRS / TCE_W4_ADD_TO_C bits of the descriptor
 };
 
 struct GemvArgs {
@@ -87,5 +88,9 @@ int launch_awq_fp16acc(int M, int N, int K, int G, const void *A, const void *qw
                        hipStream_t stream, hipError_t *hip_err);
 int launch_awq_repack(int N, int K, int G, const void *qweight, const void *scales, void *workspace, hipStream_t stream,
                       hipError_t *hip_err);
+
+// element-wise glue of the decoder layer (glue.hip)
+int launch_add_half(const void *a, const void *b, void *c, long long n, hipStream_t stream, hipError_t *hip_err);
+int launch_silu_mul_half(void *a, const void *b, long long n, hipStream_t stream, hipError_t *hip_err);
 
 }  // namespace tce

@@ -33,13 +33,36 @@ class Linear_half_int4:
     def load(cls, dirname: str, out_features: int, in_features: int, group_size: int = quantize.QK4_6, device="cuda"):
         return cls(*quantize.load_linear_q4_6(dirname, out_features, in_features, group_size, device), group_size=group_size)
 
-    def desc(self, x: torch.Tensor, out: torch.Tensor, ldc: int = 0) -> capi.W4A16Desc:
+    def desc(self, x: torch.Tensor, out: torch.Tensor, ldc: int = 0, flags: int = 0) -> capi.W4A16Desc:
         m = x.numel() // self.in_features
         # plain data_ptr(): descriptors are also built for host tensors by the CPU-side tests of the sharding logic;
         # the C ABI itself only ever receives device pointers on the product path (MatmulOperator checks is_cuda)
         return capi.W4A16Desc(M=m, N=self.out_features, K=self.in_features, group_size=self.group_size, A=x.data_ptr(),
                               qweight=self.weight.data_ptr(), scales=self.scale.data_ptr(), zeros=self.zero_point.data_ptr(),
-                              C=out.data_ptr(), ldc=ldc, flags=capi.TCE_W4_ZERO_POINT_IS_8 if self.zeros_are_8 else 0)
+                              C=out.data_ptr(), ldc=ldc, flags=flags | (capi.TCE_W4_ZERO_POINT_IS_8 if self.zeros_are_8 else 0))
+
+    @classmethod
+    def interleave(cls, gate: "Linear_half_int4", up: "Linear_half_int4") -> "Linear_half_int4":
+        """One linear whose row 2n is gate's row n and row 2n+1 up's row n: the load-time layout of the fused
+        gate_proj + up_proj + SiLuMul launch (TCE_W4_SILU_MUL_PAIRS).  A pure row permutation of the three q4_6 arrays,
+        like the reference's offline qkv merge (llm/tools/llama_qkv_merger.py:27-48)."""
+        assert gate.weight.shape == up.weight.shape and gate.group_size == up.group_size
+        il = lambda a, b: torch.stack((a, b), dim=1).reshape(2 * a.shape[0], *a.shape[1:]).contiguous()
+        return cls(il(gate.weight, up.weight), il(gate.scale, up.scale), il(gate.zero_point, up.zero_point), gate.group_size)
+
+    def forward_silu_mul(self, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        """silu(gate(x)) * up(x) for an interleaved gate/up linear, fp16 arithmetic of SiLuMul_half
+        (Int4llamaDecoderLayer.cu:20-30, 96-102); one launch, output [..., out_features / 2]."""
+        if out is None:
+            out = torch.empty((*x.shape[:-1], self.out_features // 2), dtype=torch.float16, device=x.device)
+        capi.check(capi.w4a16_forward(self.desc(x, out, flags=capi.TCE_W4_SILU_MUL_PAIRS), _stream()))
+        return out
+
+    def forward_add(self, x: torch.Tensor, residual_inout: torch.Tensor) -> torch.Tensor:
+        """residual_inout = hadd(residual_inout, self(x)): o_proj / down_proj with the add_half behind it
+        (Int4llamaDecoderLayer.cu:12-18, 86-88, 107-108) as one launch."""
+        capi.check(capi.w4a16_forward(self.desc(x, residual_inout, flags=capi.TCE_W4_ADD_TO_C), _stream()))
+        return residual_inout
 
     def forward(self, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
         m = x.numel() // self.in_features
