@@ -108,6 +108,14 @@ TCE_API int tce_w4a16_forward(const tce_w4a16_desc *d, void *stream);
  *   tce_silu_mul_half:  a[i] = hmul(hmul(a[i], hdiv(1, hadd(1, hexp(-a[i])))), b[i])  (SiLuMul_half, :20-30)
  * n halves; pointers 16-byte aligned; c may alias a or b. */
 TCE_API int tce_add_half(const void *a, const void *b, void *c, long long n, void *stream);
+/* RMSNorm as the reference's CUDA build computes it (generalT5LayerNorm, llm/src/ops/cuda/LlamaRMSNorm.cu:68-115):
+ *   out[r][i] = half( clamp( (float(x[r][i]) * rs_r) * gamma[i] ) ),  rs_r = 1 / sqrt(mean_i x[r][i]^2 + eps), fp32,
+ *   clamp to +-(65504 - 1000).  x, out fp16 [m][n]; gamma fp32 [n]; n % 8 == 0.
+ * tce_w4a16_forward_group_rmsnorm is tce_w4a16_forward_group with that normalisation applied to the (un-normalised)
+ * activation while it is staged -- input_layernorm + q/k/v, post_attention_layernorm + gate/up
+ * (Int4llamaDecoderLayer.cu:78, 92-99) as one launch each.  M = 1 (decode) only. */
+TCE_API int tce_rmsnorm_half(const void *x, const float *gamma, void *out, int m, int n, float eps, void *stream);
+TCE_API int tce_w4a16_forward_group_rmsnorm(const tce_w4a16_desc *descs, int count, const float *gamma, float eps, void *stream);
 TCE_API int tce_silu_mul_half(void *a, const void *b, long long n, void *stream);
 
 /* Load-time helper for TCE_W4_ZERO_POINT_IS_8: returns 1 if all `n_words` packed zero-point words are 0x88888888, 0 if

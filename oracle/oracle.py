@@ -202,6 +202,13 @@ class Oracle(_Lib):
         self.lib.orc_silu_mul_half(_p(a), _p(b), _p(out), C.c_int64(a.size))
         return out.view(np.float16)
 
+    def rmsnorm_half(self, x_f16, gamma_f32, eps):
+        x = np.ascontiguousarray(x_f16, np.float16); g = np.ascontiguousarray(gamma_f32, np.float32)
+        m, n = x.reshape(-1, x.shape[-1]).shape
+        out = np.empty(x.shape, np.uint16)
+        self.lib.orc_rmsnorm_half(_p(x.view(np.uint16)), _p(g), _p(out), C.c_int(m), C.c_int(n), C.c_float(eps))
+        return out.view(np.float16)
+
     def fp32_matmul_transposed(self, A, B, bias, M, N, K):
         A = np.ascontiguousarray(A, np.float32); B = np.ascontiguousarray(B, np.float32)
         bias = None if bias is None else np.ascontiguousarray(bias, np.float32)

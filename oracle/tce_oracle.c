@@ -548,3 +548,55 @@ ORC_API void orc_silu_mul_half(const uint16_t *a, const uint16_t *b, uint16_t *o
         out[i] = orc_f32_to_f16(orc_f16_to_f32(sv) * orc_f16_to_f32(b[i]));
     }
 }
+
+/* generalT5LayerNorm, the kernel LlamaRMSNorm_cuda::forward launches (llm/src/ops/cuda/LlamaRMSNorm.cu:68-115):
+ *   out[i] = half( clamp( (float(x[i]) * rsqrtf(sum_j x[j]^2 / n + eps)) * gamma[i] ) ),  clamp to +-(65504 - 1000)
+ * (clamp_inf_for_half, llm/include/ops/cuda/reduction.cuh:76-81).  The sum is formed as the reference forms it: blockDim
+ * = min(n, 1024) / 2 threads (1024 / 2 when n % 32 != 0), thread t adds its elements t, t + blockDim, ... in order, then
+ * the butterfly of warpReduceSum over the 32 lanes of each warp and once more over the warps (reduction.cuh:38-67).
+ * rsqrtf is an approximate instruction there (2 ulp); 1 / sqrtf is used here and on the GPU side of the tests. */
+ORC_API void orc_rmsnorm_half(const uint16_t *x, const float *gamma, uint16_t *out, int m, int n, float eps) {
+    int bd = (n < 1024 ? n : 1024);
+    if (n % 32 != 0) bd = 1024;
+    bd /= 2;
+    if (bd < 1) bd = 1;
+    for (int r = 0; r < m; r++) {
+        const uint16_t *xr = x + (int64_t)r * n;
+        float part[1024];
+        for (int t = 0; t < 1024; t++) part[t] = 0.0f;
+        for (int t = 0; t < bd; t++) {
+            float s = 0.0f;
+            for (int i = t; i < n; i += bd) {
+                const float d = orc_f16_to_f32(xr[i]);
+                s = s + d * d;
+            }
+            part[t] = s;
+        }
+        const int nwarp = (bd + 31) / 32;
+        float shared[32];
+        for (int w = 0; w < 32; w++) shared[w] = 0.0f;
+        for (int w = 0; w < nwarp; w++) {  /* warpReduceSum: val += shfl_xor(val, mask) for mask = 16, 8, 4, 2, 1 */
+            float v[32];
+            for (int l = 0; l < 32; l++) v[l] = (w * 32 + l < bd) ? part[w * 32 + l] : 0.0f;
+            for (int mask = 16; mask > 0; mask >>= 1) {
+                float nv[32];
+                for (int l = 0; l < 32; l++) nv[l] = v[l] + v[l ^ mask];
+                for (int l = 0; l < 32; l++) v[l] = nv[l];
+            }
+            shared[w] = v[0];
+        }
+        float v[32];
+        for (int l = 0; l < 32; l++) v[l] = ((float)l < (float)bd / 32.f) ? shared[l] : 0.0f;
+        for (int mask = 16; mask > 0; mask >>= 1) {
+            float nv[32];
+            for (int l = 0; l < 32; l++) nv[l] = v[l] + v[l ^ mask];
+            for (int l = 0; l < 32; l++) v[l] = nv[l];
+        }
+        const float rs = 1.0f / sqrtf(v[0] / (float)n + eps);
+        for (int i = 0; i < n; i++) {
+            float f = (orc_f16_to_f32(xr[i]) * rs) * gamma[i];
+            f = f > 0.0f ? (f < 65504.F - 1000 ? f : 65504.F - 1000) : (f > -65504.F + 1000 ? f : -65504.F + 1000);
+            out[(int64_t)r * n + i] = orc_f32_to_f16(f);
+        }
+    }
+}

@@ -182,42 +182,55 @@ def sweep_w8a8():
         print(json.dumps({"kind": "w8a8", "M": M, "N": N, "K": K, "us": round(us, 2), "TOPs": round(tops, 2)}), flush=True)
 
 
-def mlp_block():
-    """One decoder layer's post-attention half (o_proj, +residual, gate/up, SiLU*mul, down_proj, +residual): the
-    reference's launch structure on this library's kernels against the fused epilogues, one hipGraph each."""
+def layer_glue():
+    """One decoder layer's linears with the element-wise operations around them (attention itself excluded): the
+    reference's launch structure -- RMSNorm, q/k/v, o_proj, add, RMSNorm, gate/up, SiLU*mul, down_proj, add = 9 launches --
+    on this library's kernels, against the fused prologues/epilogues (4 launches).  One hipGraph of 24 layers each."""
+    import ctypes as Ct
     from tinychatengine_amd.linear import Linear_half_int4
     L = capi.lib()
-    for (name, h, f) in [("baseline-named 4096/11008", 4096, 11008), ("llama3-8b 4096/14336", 4096, 14336)]:
-        reps = 12  # distinct weight sets so that every launch streams from HBM
+    for (name, h, f, qkv) in [("baseline-named 4096/11008", 4096, 11008, 12288), ("llama3-8b 4096/14336 (GQA)", 4096, 14336, 6144)]:
+        reps = 8  # distinct weight sets so that every launch streams from HBM
+        zw = lambda k: quantize.calculate_zeros_width(k, 128)
+        mk = lambda n, k: Linear_half_int4(torch.randint(-2**31, 2**31 - 1, (n, k // 8), dtype=torch.int32, device=dev),
+                                           (torch.rand((n, zw(k) * 8), device=dev) * 0.01).to(torch.float16),
+                                           torch.full((n, zw(k)), -2004318072, dtype=torch.int32, device=dev))
         sets = []
         for r in range(reps):
-            mk = lambda n, k: Linear_half_int4(torch.randint(-2**31, 2**31 - 1, (n, k // 8), dtype=torch.int32, device=dev),
-                                               (torch.rand((n, quantize.calculate_zeros_width(k, 128) * 8), device=dev) * 0.01).to(torch.float16),
-                                               torch.full((n, quantize.calculate_zeros_width(k, 128)), -2004318072, dtype=torch.int32, device=dev))
-            sets.append({"o": mk(h, h), "gate": mk(f, h), "up": mk(f, h), "gu": None, "down": mk(h, f)})
-            sets[-1]["gu"] = Linear_half_int4.interleave(sets[-1]["gate"], sets[-1]["up"])
-        x = torch.randn(1, h, device=dev).to(torch.float16); res = torch.randn(1, h, device=dev).to(torch.float16)
+            w = {"qkv": mk(qkv, h), "o": mk(h, h), "gate": mk(f, h), "up": mk(f, h), "down": mk(h, f)}
+            w["gu"] = Linear_half_int4.interleave(w["gate"], w["up"])
+            sets.append(w)
+        gamma = torch.ones(h, device=dev)
+        hid = torch.randn(1, h, device=dev).to(torch.float16); xn = torch.empty_like(hid)
+        t_qkv = torch.empty(1, qkv, dtype=torch.float16, device=dev); attn = torch.randn(1, h, device=dev).to(torch.float16)
         t_o = torch.empty(1, h, dtype=torch.float16, device=dev); t_g = torch.empty(1, f, dtype=torch.float16, device=dev)
         t_u = torch.empty(1, f, dtype=torch.float16, device=dev); t_d = torch.empty(1, h, dtype=torch.float16, device=dev)
 
+        def one(d):
+            return (capi.W4A16Desc * 1)(d)
+
         def unfused(i, sp):
             w = sets[i % reps]
-            capi.check(capi.w4a16_forward(w["o"].desc(x, t_o), sp.value))
-            capi.check(L.tce_add_half(res.data_ptr(), t_o.data_ptr(), res.data_ptr(), h, sp))
-            capi.check(capi.w4a16_forward_group([w["gate"].desc(res, t_g), w["up"].desc(res, t_u)], sp.value))
+            capi.check(L.tce_rmsnorm_half(hid.data_ptr(), gamma.data_ptr(), xn.data_ptr(), 1, h, 1e-6, sp))
+            capi.check(capi.w4a16_forward(w["qkv"].desc(xn, t_qkv), sp.value))
+            capi.check(capi.w4a16_forward(w["o"].desc(attn, t_o), sp.value))
+            capi.check(L.tce_add_half(hid.data_ptr(), t_o.data_ptr(), hid.data_ptr(), h, sp))
+            capi.check(L.tce_rmsnorm_half(hid.data_ptr(), gamma.data_ptr(), xn.data_ptr(), 1, h, 1e-6, sp))
+            capi.check(capi.w4a16_forward_group([w["gate"].desc(xn, t_g), w["up"].desc(xn, t_u)], sp.value))
             capi.check(L.tce_silu_mul_half(t_g.data_ptr(), t_u.data_ptr(), f, sp))
             capi.check(capi.w4a16_forward(w["down"].desc(t_g, t_d), sp.value))
-            capi.check(L.tce_add_half(res.data_ptr(), t_d.data_ptr(), res.data_ptr(), h, sp))
+            capi.check(L.tce_add_half(hid.data_ptr(), t_d.data_ptr(), hid.data_ptr(), h, sp))
 
         def fused(i, sp):
             w = sets[i % reps]
-            capi.check(capi.w4a16_forward(w["o"].desc(x, res, flags=capi.TCE_W4_ADD_TO_C), sp.value))
-            capi.check(capi.w4a16_forward(w["gu"].desc(res, t_g, flags=capi.TCE_W4_SILU_MUL_PAIRS), sp.value))
-            capi.check(capi.w4a16_forward(w["down"].desc(t_g, res, flags=capi.TCE_W4_ADD_TO_C), sp.value))
+            capi.check(L.tce_w4a16_forward_group_rmsnorm(one(w["qkv"].desc(hid, t_qkv)), 1, gamma.data_ptr(), 1e-6, sp))
+            capi.check(capi.w4a16_forward(w["o"].desc(attn, hid, flags=capi.TCE_W4_ADD_TO_C), sp.value))
+            capi.check(L.tce_w4a16_forward_group_rmsnorm(one(w["gu"].desc(hid, t_g, flags=capi.TCE_W4_SILU_MUL_PAIRS)), 1, gamma.data_ptr(), 1e-6, sp))
+            capi.check(capi.w4a16_forward(w["down"].desc(t_g, hid, flags=capi.TCE_W4_ADD_TO_C), sp.value))
 
-        for nm, fn, launches in (("reference launch structure (6 launches)", unfused, 6), ("fused epilogues (3 launches)", fused, 3)):
+        for nm, fn in (("reference launch structure (9 launches)", unfused), ("fused prologues/epilogues (4 launches)", fused)):
             us = time_graph(fn, 24)
-            print(json.dumps({"kind": "mlp_block", "shape": name, "form": nm, "us_per_block": round(us, 2)}), flush=True)
+            print(json.dumps({"kind": "layer_glue", "shape": name, "form": nm, "us_per_layer": round(us, 2)}), flush=True)
         del sets
 
 
@@ -255,8 +268,8 @@ def main():
         sweep_gemm([(4096, 4096), (11008, 4096), (4096, 11008)])
     if args.only in ("", "w8a8"):
         sweep_w8a8()
-    if args.only in ("", "mlp"):
-        mlp_block()
+    if args.only in ("", "glue"):
+        layer_glue()
 
 
 if __name__ == "__main__":

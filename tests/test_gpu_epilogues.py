@@ -118,3 +118,59 @@ def test_standalone_glue_kernels(dev, oracle, n):
     torch.cuda.synchronize()
     d = _ulps(a.cpu().numpy(), want)
     assert d.max() <= 1 and (d > 0).mean() < 2e-3
+
+
+@pytest.mark.parametrize("m,n", [(1, 4096), (3, 11008), (1, 520), (2, 14336), (5, 64)])
+def test_rmsnorm_kernel_matches_oracle(dev, oracle, m, n):
+    from tinychatengine_amd.linear import rmsnorm_half
+    g = torch.Generator(device=dev).manual_seed(m * 31 + n)
+    x = torch.empty(m, n, device=dev).normal_(0, 2.5, generator=g).to(torch.float16)
+    gamma = (1 + 0.2 * torch.empty(n, device=dev).normal_(0, 1, generator=g)).float()
+    got = rmsnorm_half(x, gamma, 1e-6).cpu().numpy()
+    want = oracle.rmsnorm_half(x.cpu().numpy(), gamma.cpu().numpy(), 1e-6)
+    d = _ulps(got, want)
+    # the sum of squares is associated differently from the reference's block reduction: the common factor rs may differ in
+    # its last bit, which moves at most a few per cent of the outputs by one binary16 step
+    assert d.max() <= 1 and (d > 0).mean() < 0.08, f"max {int(d.max())} steps, {float((d > 0).mean()):.4f} differ"
+
+
+@pytest.mark.parametrize("Ns,K", [([4096, 4096, 4096], 4096), ([11008, 11008], 4096), ([72], 1408), ([520, 264], 11008), ([4096], 4096)])
+def test_rmsnorm_prologue_fused(dev, oracle, Ns, K):
+    """input_layernorm + q/k/v (or post_attention_layernorm + gate/up) as one launch: against the oracle's RMSNorm followed
+    by the oracle's GEMV, and against this library's own two-launch form."""
+    from tinychatengine_amd import capi
+    from tinychatengine_amd.linear import Linear_half_int4, forward_group, forward_group_rmsnorm, rmsnorm_half
+    g = torch.Generator(device=dev).manual_seed(sum(Ns) + K)
+    lins = [Linear_half_int4.from_float(torch.empty(n, K, device=dev).normal_(0, 0.05, generator=g)) for n in Ns]
+    x = torch.empty(1, K, device=dev).normal_(0, 3, generator=g).to(torch.float16)
+    gamma = (1 + 0.2 * torch.empty(K, device=dev).normal_(0, 1, generator=g)).float()
+    xn_ref = oracle.rmsnorm_half(x.cpu().numpy(), gamma.cpu().numpy(), 1e-6)
+    # automatic, row-block geometries, persistent geometries (waves_k = 0)
+    cfgs = [None, (4, 4, 1, 1), (2, 16, 0, 2)] if sum(Ns) > 9000 else [None, (2, 4, 1, 2), (4, 4, 1, 1), (1, 2, 2, 1), (2, 2, 2, 2), (1, 2, 4, 1), (2, 8, 0, 2), (1, 16, 0, 3), (4, 16, 0, 2)]
+    try:
+        for cfg in cfgs:
+            capi.set_gemv_config(*(cfg or (0, 0, 0, 0)))
+            fused = [torch.full((1, n), float("nan"), dtype=torch.float16, device=dev) for n in Ns]
+            forward_group_rmsnorm(lins, x, fused, gamma, 1e-6)
+            two = [torch.empty(1, n, dtype=torch.float16, device=dev) for n in Ns]
+            forward_group(lins, rmsnorm_half(x, gamma, 1e-6), two)
+            torch.cuda.synchronize()
+            xn_gpu = rmsnorm_half(x, gamma, 1e-6).cpu().numpy()
+            d = _ulps(xn_gpu, xn_ref)
+            assert d.max() <= 1 and (d > 0).mean() < 0.08
+            for l, f, t, n in zip(lins, fused, two, Ns):
+                fo = f.cpu().numpy()
+                assert not np.isnan(fo.astype(np.float32)).any()
+                # the fused launch stages exactly the vector the stand-alone kernel writes (same wave-level sum): identical bits
+                assert np.array_equal(fo.view(np.uint16), t.cpu().numpy().view(np.uint16)), f"cfg {cfg} N={n}: fused != two launches"
+                # and the GEMV on that vector is the oracle's GEMV on it
+                ref32, _ = oracle.w4a16_gemv_q4_6(xn_gpu, l.weight.cpu().numpy().view(np.uint32), l.scale.cpu().numpy(),
+                                                  l.zero_point.cpu().numpy().view(np.uint32), 1, n, K, 128)
+                ok, worst = w4a16_close(fo, ref32)
+                assert ok, f"cfg {cfg} N={n}: worst |err|/tol = {worst:.3f}"
+    finally:
+        capi.set_gemv_config()
+    # M > 1 is not a decode shape
+    x2 = torch.randn(2, K, device=dev).to(torch.float16)
+    with pytest.raises(capi.TceError):
+        forward_group_rmsnorm(lins[:1], x2, [torch.empty(2, Ns[0], dtype=torch.float16, device=dev)], gamma, 1e-6)

@@ -174,3 +174,23 @@ def test_glue_ops_are_binary16_arithmetic(oracle):
         want = (a * (one / (one + e))) * b
     got = oracle.silu_mul_half(a, b)
     assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
+
+
+def test_rmsnorm_restatement_against_float64(oracle):
+    """orc_rmsnorm_half (generalT5LayerNorm, LlamaRMSNorm.cu:68-93): the reference's summation order in fp32 stays within
+    a few fp32 ulps of the exact sum, so at most a handful of outputs may sit one binary16 step away from the float64
+    evaluation; the clamp keeps huge products finite."""
+    rng = np.random.default_rng(9)
+    for n in (4096, 11008, 520, 100):
+        x = (rng.standard_normal((3, n)) * 3).astype(np.float16)
+        g = (1 + 0.1 * rng.standard_normal(n)).astype(np.float32)
+        got = oracle.rmsnorm_half(x, g, 1e-6)
+        xd = x.astype(np.float64)
+        rs = 1.0 / np.sqrt((xd * xd).mean(axis=1, keepdims=True) + 1e-6)
+        want = (xd * rs * g).astype(np.float16)
+        bad = got.view(np.uint16) != want.view(np.uint16)
+        assert bad.mean() < 5e-3
+        assert np.allclose(got.astype(np.float32), want.astype(np.float32), rtol=2e-3, atol=1e-6)
+    big = np.full((1, 64), 60000.0, np.float16); big[0, 1:] = 0
+    out = oracle.rmsnorm_half(big, np.full(64, 1e4, np.float32), 1e-6)
+    assert np.isfinite(out.astype(np.float32)).all() and float(out[0, 0]) == float(np.float16(64504.0))

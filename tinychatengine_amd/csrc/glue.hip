@@ -32,7 +32,38 @@ __global__ __launch_bounds__(256) void silu_mul_half_kernel(half_t *a, const hal
     }
 }
 
+// generalT5LayerNorm (LlamaRMSNorm.cu:68-93): one workgroup of 512 threads per row; rs = 1 / sqrt(mean(x^2) + eps) by
+// rmsnorm_rs_block (same bits as the fused GEMV prologue), then half(clamp((x * rs) * gamma)) in 16-byte pieces.  n % 8 == 0.
+__global__ __launch_bounds__(512) void rmsnorm_half_kernel(const half_t *x, const float *gamma, half_t *out, int n, float eps) {
+    __shared__ float part[16 * 64];
+    const int tid = threadIdx.x;
+    const half_t *xr = x + (size_t)blockIdx.x * n;
+    half_t *orow = out + (size_t)blockIdx.x * n;
+    const float rs = rmsnorm_rs_block(xr, n, eps, tid >> 6, 8, tid & 63, part);
+    for (int p = tid; p < (n >> 3); p += 512) {
+        const half8_t v = *reinterpret_cast<const half8_t *>(xr + p * 8);
+        const float4_t g0 = *reinterpret_cast<const float4_t *>(gamma + p * 8), g1 = *reinterpret_cast<const float4_t *>(gamma + p * 8 + 4);
+        half8_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[j] = rmsnorm_out(v[j], rs, g0[j]);
+            o[4 + j] = rmsnorm_out(v[4 + j], rs, g1[j]);
+        }
+        *reinterpret_cast<half8_t *>(orow + p * 8) = o;
+    }
+}
+
 }  // namespace
+
+int launch_rmsnorm_half(const void *x, const float *gamma, void *out, int m, int n, float eps, hipStream_t stream, hipError_t *hip_err) {
+    hipLaunchKernelGGL(rmsnorm_half_kernel, dim3(m), dim3(512), 0, stream, static_cast<const half_t *>(x), gamma, static_cast<half_t *>(out), n, eps);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (hip_err) *hip_err = e;
+        return TCE_ERR_HIP;
+    }
+    return TCE_OK;
+}
 
 int launch_add_half(const void *a, const void *b, void *c, long long n, hipStream_t stream, hipError_t *hip_err) {
     const long long blocks = (n + 2047) / 2048;

@@ -275,6 +275,46 @@ int tce_w4a16_gemm_awq(int M, int N, int K, int G, const void *A, const void *qw
     return tce_w4a16_forward(&d, stream);
 }
 
+int tce_rmsnorm_half(const void *x, const float *gamma, void *out, int m, int n, float eps, void *stream) {
+    if (!x || !gamma || !out || m <= 0 || n <= 0) return fail(TCE_ERR_BAD_ARG, "tce_rmsnorm_half: bad argument");
+    if (n % 8 != 0 || (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(gamma)) % 16 != 0)
+        return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_rmsnorm_half: n %% 8 == 0 and 16-byte aligned pointers");
+    hipError_t he = hipSuccess;
+    const int rc = tce::launch_rmsnorm_half(x, gamma, out, m, n, eps, static_cast<hipStream_t>(stream), &he);
+    return rc == TCE_ERR_HIP ? hip_fail(he, "rmsnorm launch") : rc;
+}
+
+int tce_w4a16_forward_group_rmsnorm(const tce_w4a16_desc *descs, int count, const float *gamma, float eps, void *stream) {
+    if (!descs || count < 1 || count > TCE_MAX_GROUP) return fail(TCE_ERR_BAD_ARG, "group count %d not in 1..%d", count, TCE_MAX_GROUP);
+    if (!gamma || reinterpret_cast<uintptr_t>(gamma) % 16 != 0) return fail(TCE_ERR_BAD_ARG, "gamma must be a 16-byte aligned fp32 [K] vector");
+    for (int i = 0; i < count; ++i) {
+        const int rc = check_w4a16(&descs[i]);
+        if (rc != TCE_OK) return rc;
+        const tce_w4a16_desc &a = descs[0], &b = descs[i];
+        if (b.M != a.M || b.K != a.K || b.group_size != a.group_size || b.A != a.A || b.lda != a.lda)
+            return fail(TCE_ERR_BAD_ARG, "grouped linears must share M, K, group size and the activation");
+    }
+    if (descs[0].M != 1) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "the fused RMSNorm prologue is a decode (M = 1) path; use tce_rmsnorm_half for M = %d", descs[0].M);
+    hipError_t he = hipSuccess;
+    // The prologue costs a workgroup one extra pass over x plus 4 bytes of gamma per element: 256 persistent workgroups
+    // pay that once each, thousands of row-block workgroups do not amortise it (Llama-3 gate+up: no gain over two
+    // launches).  So the persistent kernel takes the fused form from ~8k rows up; the row-block kernel below that.
+    long long rows = 0;
+    for (int i = 0; i < count; ++i) rows += descs[i].N;
+    if (g_gemv_kernel == 2 || (g_gemv_kernel == 0 && rows >= 8192)) {
+        const int rc = tce::launch_w4a16_gemv_stream(descs, count, static_cast<hipStream_t>(stream), &he, gamma, eps);
+        if (rc == TCE_OK) return TCE_OK;
+        if (rc == TCE_ERR_HIP) return hip_fail(he, "w4a16 persistent gemv launch");
+        if (rc != TCE_ERR_UNSUPPORTED_SHAPE) return fail(rc, "w4a16 persistent gemv: unsupported configuration");
+    }
+    const int rc = tce::launch_w4a16_gemv(descs, count, g_gemv_kernel == 1 ? g_gemv_rows : 0, g_gemv_kernel == 1 ? g_gemv_wn : 0,
+                                          g_gemv_kernel == 1 ? g_gemv_wk : 0, g_gemv_kernel == 1 ? g_gemv_depth : 0,
+                                          static_cast<hipStream_t>(stream), &he, gamma, eps);
+    if (rc == TCE_ERR_HIP) return hip_fail(he, "w4a16 gemv launch");
+    if (rc != TCE_OK) return fail(rc, "w4a16 gemv (rmsnorm prologue): no kernel variant for this shape/config");
+    return TCE_OK;
+}
+
 int tce_add_half(const void *a, const void *b, void *c, long long n, void *stream) {
     if (!a || !b || !c || n <= 0) return fail(TCE_ERR_BAD_ARG, "tce_add_half: bad argument");
     if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) % 16 != 0)

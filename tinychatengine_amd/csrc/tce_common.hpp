@@ -131,6 +131,43 @@ __device__ __forceinline__ half_t silu_mul_half(half_t g, half_t u) {
     return sv * u;
 }
 
+// One output of generalT5LayerNorm (llm/src/ops/cuda/LlamaRMSNorm.cu:89-92): half(clamp((x * rs) * gamma)), the clamp of
+// clamp_inf_for_half (reduction.cuh:76-81).
+__device__ __forceinline__ half_t rmsnorm_out(half_t x, float rs, float gamma) {
+    float f = ((float)x * rs) * gamma;
+    f = f > 0.0f ? fminf(f, 65504.f - 1000.f) : fmaxf(f, -65504.f + 1000.f);
+    return (half_t)f;
+}
+
+// rs = 1 / sqrt(mean(x^2) + eps) of one fp16 row of n (n % 8 == 0) elements, formed by a whole workgroup in an order that
+// does not depend on the workgroup's shape, so the fused GEMV prologue and the stand-alone kernel produce identical bits:
+// the row's 16-byte pieces are cut into 16 chunks (of a multiple of 64 pieces); within a chunk lane l accumulates pieces
+// l, l + 64, ... in order (fmaf, fp32); wave w takes chunks w, w + nwaves, ...; the [16][64] partial sums meet in LDS, each
+// lane adds its 16 in chunk order, and the 64 lane sums go through the fixed DPP tree.  `part` = 4 KiB of LDS; contains
+// two barriers (the second one frees `part` for reuse).
+__device__ __forceinline__ float rmsnorm_rs_block(const half_t *x, int n, float eps, int wave, int nwaves, int lane, float *part) {
+    const int pieces = n >> 3;
+    const int chunk = ((pieces + 15) / 16 + 63) & ~63;
+    for (int c = wave; c < 16; c += nwaves) {
+        float ss = 0.f;
+        const int end = (c + 1) * chunk < pieces ? (c + 1) * chunk : pieces;
+        for (int p = c * chunk + lane; p < end; p += 64) {
+            const half8_t v = *reinterpret_cast<const half8_t *>(x + p * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss = __builtin_fmaf((float)v[e], (float)v[e], ss);
+        }
+        part[c * 64 + lane] = ss;
+    }
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) tot += part[c * 64 + lane];
+    tot = wave_sum_dpp_lane63(tot);
+    tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), 63));
+    __syncthreads();
+    return 1.0f / sqrtf(tot / (float)n + eps);
+}
+
 // non-temporal 16-byte load: streamed weights are read exactly once by exactly one CU
 __device__ __forceinline__ uint4_t load_nt(const uint4_t *p) { return __builtin_nontemporal_load(p); }
 

@@ -43,7 +43,9 @@ namespace {
 // MODE: 0 = the GEMV.  3 = the GEMV with x staged before the weight stream starts.  2 = 0 + per-wave timestamps.  1 = diagnostics: stream the weights only (no unpack / dot) -- roofline experiments, output unused.
 // The second __launch_bounds__ argument (minimum waves per SIMD) caps the register allocation: left alone, hipcc hoists
 // every row's unpack ahead of the MFMAs and spends > 256 VGPRs, i.e. one wave per SIMD and nothing to hide HBM latency.
-template <int MB, int ROWS, int WN, int WK, int DEPTH, int XB, int MODE = 0, bool Z8 = false>
+// NORM: the activation staging applies generalT5LayerNorm (LlamaRMSNorm.cu:68-93) on the fly -- the workgroup reads the
+// un-normalised hidden state, sums its squares, and writes half(clamp((x * rs) * gamma)) into the x image (MB = 1).
+template <int MB, int ROWS, int WN, int WK, int DEPTH, int XB, int MODE = 0, bool Z8 = false, bool NORM = false>
 __global__ __launch_bounds__(64 * WN * WK, (MB * ROWS * DEPTH >= 8 ? 2 : (MB * ROWS * DEPTH >= 4 ? (MB == 1 && ROWS == 4 && DEPTH == 1 ? 5 : 3) : 4))) void w4a16_gemv_kernel(const GemvArgs args) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NTHREADS = 64 * WN * WK;
@@ -91,8 +93,10 @@ __global__ __launch_bounds__(64 * WN * WK, (MB * ROWS * DEPTH >= 8 ? 2 : (MB * R
     };
     uint4_t xv[XB];
     bool xok[XB];
+    if constexpr (!NORM) {
 #pragma unroll
-    for (int i = 0; i < XB; ++i) xv[i] = *x_src(tid + i * NTHREADS, xok[i]);
+        for (int i = 0; i < XB; ++i) xv[i] = *x_src(tid + i * NTHREADS, xok[i]);
+    }
 
     // ---- weight stream: buffer descriptors + scalar row offsets ----
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4_t *>(seg.qweight), 0, seg.bytes_w, 0x00020000);
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(64 * WN * WK, (MB * ROWS * DEPTH >= 8 ? 2 : (MB * R
     // Prologue: DEPTH steps issued unconditionally (the host only picks variants with DEPTH <= T), so every wait the
     // compiler places is an exact counted vmcnt.
     Step st[DEPTH];
-    constexpr bool XFIRST = (MODE == 3);  // stage x completely before the first weight load is issued (see launch_variant)
+    constexpr bool XFIRST = (MODE == 3) && !NORM;  // stage x completely before the first weight load is issued (see launch_variant)
     if constexpr (!XFIRST) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) issue(st[d], d);
@@ -166,11 +170,37 @@ __global__ __launch_bounds__(64 * WN * WK, (MB * ROWS * DEPTH >= 8 ? 2 : (MB * R
             xs[p < total_pieces ? p : total_pieces + tid] = v;
         }
     };
-    x_write(0);
-    for (int base = XB * NTHREADS; base < total_pieces; base += XB * NTHREADS) {  // only for long K and/or MB > 1
+    if constexpr (NORM) {
+        static_assert(MB == 1, "the fused RMSNorm prologue is a decode (M = 1) feature");
+        // rs by the whole workgroup, in the shape-independent order of rmsnorm_rs_block (same bits as tce_rmsnorm_half);
+        // its 4 KiB of partial sums live in the trash-slot area behind the image
+        static_assert(NTHREADS >= 256, "the trash-slot area must hold 16 x 64 floats");
+        const float rs = rmsnorm_rs_block(A, K, args.eps, wave, WN * WK, lane, reinterpret_cast<float *>(smem + (size_t)total_pieces * 16));
+        // normalise, permute, write the image (the row is re-read: L1/L2 hits)
+        for (int p = tid; p < total_pieces; p += NTHREADS) {
+            const int c = (p >> 8) * 64 + (p & 63), j = (p >> 6) & 3;
+            uint4_t o = uint4_t{0u, 0u, 0u, 0u};
+            if (c < nchunks) {
+                const int k0 = c * 32 + j * 8;
+                const half8_t v = *reinterpret_cast<const half8_t *>(A + k0);
+                const float4_t g0 = *reinterpret_cast<const float4_t *>(args.gamma + k0), g1 = *reinterpret_cast<const float4_t *>(args.gamma + k0 + 4);
+                half8_t y;
 #pragma unroll
-        for (int i = 0; i < XB; ++i) xv[i] = *x_src(base + tid + i * NTHREADS, xok[i]);
-        x_write(base);
+                for (int e = 0; e < 4; ++e) {
+                    y[e] = rmsnorm_out(v[e], rs, g0[e]);
+                    y[4 + e] = rmsnorm_out(v[4 + e], rs, g1[e]);
+                }
+                o = pair_permute(__builtin_bit_cast(uint4_t, y));
+            }
+            xs[p] = o;
+        }
+    } else {
+        x_write(0);
+        for (int base = XB * NTHREADS; base < total_pieces; base += XB * NTHREADS) {  // only for long K and/or MB > 1
+#pragma unroll
+            for (int i = 0; i < XB; ++i) xv[i] = *x_src(base + tid + i * NTHREADS, xok[i]);
+            x_write(base);
+        }
     }
     __syncthreads();
     if constexpr (XFIRST) {
@@ -364,7 +394,7 @@ struct Variant {
 int g_debug_mode = 0;
 unsigned long long *g_debug_buf = nullptr;
 
-template <int MB, int ROWS, int WN, int WK, int DEPTH, int XB, int MODE = 0, bool Z8 = false>
+template <int MB, int ROWS, int WN, int WK, int DEPTH, int XB, int MODE = 0, bool Z8 = false, bool NORM = false>
 hipError_t launch_one(const GemvArgs &a, int total_blocks, int m_blocks, hipStream_t stream) {
     const int nchunks = a.K >> 5;
     const int LS = 64 * WK;
@@ -372,7 +402,7 @@ hipError_t launch_one(const GemvArgs &a, int total_blocks, int m_blocks, hipStre
     size_t lds = (size_t)MB * T * LS * 64 + (size_t)64 * WN * WK * 16;  // x image + trash slots
     const size_t red = (size_t)WN * WK * ROWS * MB * sizeof(float);
     if (lds < red) lds = red;
-    auto kfn = w4a16_gemv_kernel<MB, ROWS, WN, WK, DEPTH, XB, MODE, Z8>;
+    auto kfn = w4a16_gemv_kernel<MB, ROWS, WN, WK, DEPTH, XB, MODE, Z8, NORM>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -392,6 +422,10 @@ hipError_t launch_variant(const GemvArgs &a, int total_blocks, int m_blocks, hip
         return launch_variant<MB, ROWS, WN, WK, DEPTH - 1>(a, total_blocks, m_blocks, stream);
     } else {
         if constexpr (MB == 1) {
+            if (a.gamma) {
+                return a.zeros_are_8 ? launch_one<1, ROWS, WN, WK, DEPTH, 2, 0, true, true>(a, total_blocks, m_blocks, stream)
+                                     : launch_one<1, ROWS, WN, WK, DEPTH, 2, 0, false, true>(a, total_blocks, m_blocks, stream);
+            }
             if (g_debug_mode == 1) return launch_one<1, ROWS, WN, WK, DEPTH, 8, 1>(a, total_blocks, m_blocks, stream);
             if (g_debug_mode == 2) return launch_one<1, ROWS, WN, WK, DEPTH, 2, 2>(a, total_blocks, m_blocks, stream);
             if (g_debug_mode == 3) return launch_one<1, ROWS, WN, WK, DEPTH, 2, 3>(a, total_blocks, m_blocks, stream);
@@ -453,9 +487,12 @@ bool gemv_variant_exists(int rows, int wn, int wk, int depth) {
 
 // Host-side launch: fills GemvArgs, picks MB and the geometry, launches.  `forced_*` may be 0.
 int launch_w4a16_gemv(const tce_w4a16_desc *descs, int count, int forced_rows, int forced_wn, int forced_wk,
-                      int forced_depth, hipStream_t stream, hipError_t *hip_err) {
+                      int forced_depth, hipStream_t stream, hipError_t *hip_err, const float *gamma, float eps) {
     const tce_w4a16_desc &d0 = descs[0];
+    if (gamma && d0.M != 1) return TCE_ERR_UNSUPPORTED_SHAPE;
     GemvArgs a{};
+    a.gamma = gamma;
+    a.eps = eps;
     a.A = static_cast<const half_t *>(d0.A);
     a.lda = d0.lda ? d0.lda : d0.K;
     a.M = d0.M;

@@ -226,12 +226,35 @@ __device__ __forceinline__ void gemv_launch_body(const StreamLaunch &L, const Ba
         for (int d = 0; d < DEPTH; ++d) issue(st[d]);
         __builtin_amdgcn_sched_barrier(0);
     }
+    if (L.gamma) {
+        // fused RMSNorm prologue (generalT5LayerNorm, LlamaRMSNorm.cu:68-93): rs by the workgroup in the shape-independent
+        // order of rmsnorm_rs_block, then half(clamp((x * rs) * gamma)) goes into the image instead of x
+        const float rs = rmsnorm_rs_block(A, K, L.eps, wave, NW, lane, reinterpret_cast<float *>(smem + (size_t)T * (4096 + 256) + 256));
+        for (int p = tid; p < total_pieces; p += nthreads) {
+            const int c = (p >> 8) * 64 + (p & 63), j = (p >> 6) & 3;
+            uint4_t o = uint4_t{0u, 0u, 0u, 0u};
+            if (c < nchunks) {
+                const int k0 = c * 32 + j * 8;
+                const half8_t v = __builtin_bit_cast(half8_t, x_piece(p));
+                const float4_t g0 = *reinterpret_cast<const float4_t *>(L.gamma + k0), g1 = *reinterpret_cast<const float4_t *>(L.gamma + k0 + 4);
+                half8_t y;
 #pragma unroll
-    for (int i = 0; i < XR; ++i) {
-        const int p = tid + i * nthreads;
-        if (p < total_pieces) xs[p] = pair_permute(xr[i]);
+                for (int e = 0; e < 4; ++e) {
+                    y[e] = rmsnorm_out(v[e], rs, g0[e]);
+                    y[4 + e] = rmsnorm_out(v[4 + e], rs, g1[e]);
+                }
+                o = pair_permute(__builtin_bit_cast(uint4_t, y));
+            }
+            xs[p] = o;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < XR; ++i) {
+            const int p = tid + i * nthreads;
+            if (p < total_pieces) xs[p] = pair_permute(xr[i]);
+        }
+        for (int p = tid + XR * nthreads; p < total_pieces; p += nthreads) xs[p] = pair_permute(x_piece(p));  // long K only
     }
-    for (int p = tid + XR * nthreads; p < total_pieces; p += nthreads) xs[p] = pair_permute(x_piece(p));  // long K only
     __syncthreads();
     {
         // D[i][j] = sum_k A_i[k] B_j[k] with A = ones: every accumulator register of a lane holds that lane's own sum
@@ -447,7 +470,7 @@ int num_cus() {
     return g_num_cus;
 }
 
-size_t lds_bytes(int K) { return (size_t)(((K >> 5) + 63) / 64) * (4096 + 256) + 256; }
+size_t lds_bytes(int K) { return (size_t)(((K >> 5) + 63) / 64) * (4096 + 256) + 256 + 4096; }  // x image, chunk sums, ticket words, RMSNorm partials
 
 template <typename KFn>
 hipError_t set_lds(KFn kfn, size_t lds) {
@@ -529,7 +552,7 @@ void set_gemv_stream_config(int rows, int nw, int depth) {
 
 bool gemv_stream_supports(const tce_w4a16_desc *descs, int count) {
     if (descs[0].M != 1) return false;
-    if (lds_bytes(descs[0].K) > 80 * 1024) return false;
+    if (lds_bytes(descs[0].K) > 84 * 1024) return false;
     StreamLaunch tmp;
     bool z8 = true;
     return fill_launch(descs, count, 1, &tmp, &z8);
@@ -537,7 +560,7 @@ bool gemv_stream_supports(const tce_w4a16_desc *descs, int count) {
 
 // Returns TCE_ERR_UNSUPPORTED_SHAPE when the persistent form does not apply (the caller then uses the workgroup-per-
 // row-block kernel of w4a16_gemv.hip).
-int launch_w4a16_gemv_stream(const tce_w4a16_desc *descs, int count, hipStream_t stream, hipError_t *hip_err) {
+int launch_w4a16_gemv_stream(const tce_w4a16_desc *descs, int count, hipStream_t stream, hipError_t *hip_err, const float *gamma, float eps) {
     if (!gemv_stream_supports(descs, count)) return TCE_ERR_UNSUPPORTED_SHAPE;
     const int cus = num_cus();
     if (cus == 0) return TCE_ERR_HIP;
@@ -559,6 +582,8 @@ int launch_w4a16_gemv_stream(const tce_w4a16_desc *descs, int count, hipStream_t
     bool z8 = true;
     if (!fill_launch(descs, count, rows, &a.launch, &z8)) return TCE_ERR_UNSUPPORTED_SHAPE;
     a.dbg = g_stream_dbg;
+    a.launch.gamma = gamma;
+    a.launch.eps = eps;
     int blocks = cus * bpc;
     if ((long)blocks * nw > a.launch.n_rg) blocks = (a.launch.n_rg + nw - 1) / nw;  // fewer row groups than waves
 

@@ -22,6 +22,8 @@ struct GemvArgs {
     int nseg;
     unsigned long long *dbg;  // MODE 2 (timestamps) only
     int zeros_are_8;          // every linear of the launch carries TCE_W4_ZERO_POINT_IS_8
+    const float *gamma;       // non-null: stage RMSNorm(A) * gamma instead of A (fused prologue, M = 1)
+    float eps;
     GemvSeg seg[TCE_MAX_GROUP];
 };
 
@@ -54,11 +56,14 @@ struct StreamLaunch {
     int nseg;
     int n_rg;                    // row groups over all linears of the launch
     GemvSeg seg[TCE_MAX_GROUP];  // block_begin = first row group of the linear
+    const float *gamma;          // non-null: stage RMSNorm(A) * gamma instead of A (generalT5LayerNorm arithmetic)
+    float eps;
 };
 void set_gemv_stream_config(int rows, int nw, int depth);
 void set_gemv_stream_debug(int mode, void *buf);
 bool gemv_stream_supports(const tce_w4a16_desc *descs, int count);
-int launch_w4a16_gemv_stream(const tce_w4a16_desc *descs, int count, hipStream_t stream, hipError_t *hip_err);
+int launch_w4a16_gemv_stream(const tce_w4a16_desc *descs, int count, hipStream_t stream, hipError_t *hip_err,
+                             const float *gamma = nullptr, float eps = 0.f);
 // token plans: a list of launches walked by ONE persistent kernel with device-wide barriers in between
 struct TokenPlan;
 int token_plan_create(const tce_w4a16_desc *descs, const int32_t *groups, int n_launches, TokenPlan **out, hipError_t *hip_err);
@@ -67,7 +72,7 @@ int token_plan_status(TokenPlan *tp, unsigned *status, hipError_t *hip_err);
 void token_plan_geometry(const TokenPlan *tp, int *rows, int *depth, int *waves, int *blocks);
 void token_plan_destroy(TokenPlan *tp);
 int launch_w4a16_gemv(const tce_w4a16_desc *descs, int count, int forced_rows, int forced_wn, int forced_wk,
-                      int forced_depth, hipStream_t stream, hipError_t *hip_err);
+                      int forced_depth, hipStream_t stream, hipError_t *hip_err, const float *gamma = nullptr, float eps = 0.f);
 
 // MFMA GEMM on the q4_6 layout (prefill).  m_tiles x n_tiles 16x16 MFMA tiles per wave, 4 waves along N.
 #define TCE_GEMM_VARIANTS(X) \
@@ -90,6 +95,7 @@ int launch_awq_repack(int N, int K, int G, const void *qweight, const void *scal
                       hipError_t *hip_err);
 
 // element-wise glue of the decoder layer (glue.hip)
+int launch_rmsnorm_half(const void *x, const float *gamma, void *out, int m, int n, float eps, hipStream_t stream, hipError_t *hip_err);
 int launch_add_half(const void *a, const void *b, void *c, long long n, hipStream_t stream, hipError_t *hip_err);
 int launch_silu_mul_half(void *a, const void *b, long long n, hipStream_t stream, hipError_t *hip_err);
 

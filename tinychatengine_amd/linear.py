@@ -94,6 +94,24 @@ def forward_group(linears: list[Linear_half_int4], x: torch.Tensor, outs: list[t
     capi.check(capi.w4a16_forward_group([l.desc(x, o) for l, o in zip(linears, outs)], _stream()))
 
 
+def rmsnorm_half(x: torch.Tensor, gamma: torch.Tensor, eps: float, out: torch.Tensor | None = None) -> torch.Tensor:
+    """LlamaRMSNorm_cuda::forward (generalT5LayerNorm, llm/src/ops/cuda/LlamaRMSNorm.cu:68-115): x fp16 [..., n], gamma fp32 [n]."""
+    if out is None:
+        out = torch.empty_like(x)
+    n = x.shape[-1]
+    capi.check(capi.lib().tce_rmsnorm_half(x.data_ptr(), gamma.data_ptr(), out.data_ptr(), x.numel() // n, n, float(eps), _stream()))
+    return out
+
+
+def forward_group_rmsnorm(linears: list[Linear_half_int4], x: torch.Tensor, outs: list[torch.Tensor], gamma: torch.Tensor, eps: float) -> None:
+    """RMSNorm(x) * gamma fed to several linears (q/k/v after input_layernorm, gate/up after post_attention_layernorm,
+    Int4llamaDecoderLayer.cu:78, 92-99) as ONE launch: the normalisation happens while x is staged (decode, M = 1)."""
+    import ctypes as C
+    descs = [l.desc(x, o) for l, o in zip(linears, outs)]
+    arr = (capi.W4A16Desc * len(descs))(*descs)
+    capi.check(capi.lib().tce_w4a16_forward_group_rmsnorm(arr, len(descs), gamma.data_ptr(), float(eps), C.c_void_p(_stream() or 0)))
+
+
 class W8A8B8O8Linear:
     """int8 -> int8 linear, alpha/beta epilogue (llm/src/ops/W8A8B8O8Linear.cc:15-78); relu=True is W8A8B8O8LinearReLU
     (q_min = 0, W8A8B8O8LinearReLU.cc:32)."""
