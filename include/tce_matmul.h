@@ -80,6 +80,10 @@ typedef struct tce_w4a16_desc {
     int32_t scales_stride, zeros_stride;  /* elements / words; 0 = reference default */
     int32_t flags;                        /* TCE_W4_* */
     int32_t reserved;
+    const void *rmsnorm_gamma;            /* NULL = none.  fp32 [K]: A is the UN-normalised hidden state and the kernel stages
+                                             RMSNorm(A) * gamma (generalT5LayerNorm arithmetic, see tce_rmsnorm_half); M = 1 */
+    float rmsnorm_eps;
+    int32_t reserved2;
 } tce_w4a16_desc;
 
 /* flags */
@@ -111,9 +115,11 @@ TCE_API int tce_add_half(const void *a, const void *b, void *c, long long n, voi
 /* RMSNorm as the reference's CUDA build computes it (generalT5LayerNorm, llm/src/ops/cuda/LlamaRMSNorm.cu:68-115):
  *   out[r][i] = half( clamp( (float(x[r][i]) * rs_r) * gamma[i] ) ),  rs_r = 1 / sqrt(mean_i x[r][i]^2 + eps), fp32,
  *   clamp to +-(65504 - 1000).  x, out fp16 [m][n]; gamma fp32 [n]; n % 8 == 0.
- * tce_w4a16_forward_group_rmsnorm is tce_w4a16_forward_group with that normalisation applied to the (un-normalised)
- * activation while it is staged -- input_layernorm + q/k/v, post_attention_layernorm + gate/up
- * (Int4llamaDecoderLayer.cu:78, 92-99) as one launch each.  M = 1 (decode) only. */
+ * A descriptor with rmsnorm_gamma set has that normalisation applied to its (un-normalised) activation while it is staged
+ * -- input_layernorm + q/k/v, post_attention_layernorm + gate/up (Int4llamaDecoderLayer.cu:78, 92-99) as one launch each;
+ * M = 1 (decode) only; the linears of a group share gamma and eps like they share A.  Works in tce_w4a16_forward,
+ * tce_w4a16_forward_group and plans.  tce_w4a16_forward_group_rmsnorm is the same call with gamma / eps passed separately
+ * (the descriptors' own rmsnorm fields are ignored). */
 TCE_API int tce_rmsnorm_half(const void *x, const float *gamma, void *out, int m, int n, float eps, void *stream);
 TCE_API int tce_w4a16_forward_group_rmsnorm(const tce_w4a16_desc *descs, int count, const float *gamma, float eps, void *stream);
 TCE_API int tce_silu_mul_half(void *a, const void *b, long long n, void *stream);

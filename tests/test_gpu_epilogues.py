@@ -174,3 +174,66 @@ def test_rmsnorm_prologue_fused(dev, oracle, Ns, K):
     x2 = torch.randn(2, K, device=dev).to(torch.float16)
     with pytest.raises(capi.TceError):
         forward_group_rmsnorm(lins[:1], x2, [torch.empty(2, Ns[0], dtype=torch.float16, device=dev)], gamma, 1e-6)
+
+
+def test_decoder_layer_linears_fused_in_plans(dev, oracle):
+    """A decoder layer's linears with their glue (attention replaced by a fixed vector): the reference's 9-launch
+    structure on the stand-alone kernels against 4 fused launches, issued directly, as a stream-ordered plan and as a
+    chained (token-kernel) plan.  Same device arithmetic everywhere, so the hidden state must come out bit-identical."""
+    import ctypes as C
+    from tinychatengine_amd import capi
+    from tinychatengine_amd.linear import Linear_half_int4, forward_group, rmsnorm_half
+    h, f, eps = 1024, 2816, 1e-5
+    g = torch.Generator(device=dev).manual_seed(77)
+    mk = lambda n, k: Linear_half_int4.from_float(torch.empty(n, k, device=dev).normal_(0, 1.0 / np.sqrt(k), generator=g))
+    qkv, o, gate, up, down = mk(3 * h, h), mk(h, h), mk(f, h), mk(f, h), mk(h, f)
+    gu = Linear_half_int4.interleave(gate, up)
+    gam1 = (1 + 0.1 * torch.empty(h, device=dev).normal_(0, 1, generator=g)).float()
+    gam2 = (1 + 0.1 * torch.empty(h, device=dev).normal_(0, 1, generator=g)).float()
+    hid0 = torch.empty(1, h, device=dev).normal_(0, 1, generator=g).to(torch.float16)
+    attn = torch.empty(1, h, device=dev).normal_(0, 1, generator=g).to(torch.float16)
+    L, s = capi.lib(), torch.cuda.current_stream().cuda_stream
+    sp = C.c_void_p(s)
+
+    # --- reference launch structure ---
+    hid = hid0.clone()
+    xn = rmsnorm_half(hid, gam1, eps)
+    t_qkv = qkv(xn)
+    t_o = o(attn)
+    capi.check(L.tce_add_half(hid.data_ptr(), t_o.data_ptr(), hid.data_ptr(), h, sp))
+    xn = rmsnorm_half(hid, gam2, eps)
+    t_g, t_u = torch.empty(1, f, dtype=torch.float16, device=dev), torch.empty(1, f, dtype=torch.float16, device=dev)
+    forward_group([gate, up], xn, [t_g, t_u])
+    capi.check(L.tce_silu_mul_half(t_g.data_ptr(), t_u.data_ptr(), f, sp))
+    t_d = down(t_g)
+    capi.check(L.tce_add_half(hid.data_ptr(), t_d.data_ptr(), hid.data_ptr(), h, sp))
+    torch.cuda.synchronize()
+    want_hid, want_qkv = hid.cpu().numpy().copy(), t_qkv.cpu().numpy().copy()
+
+    # --- fused: 4 launches ---
+    hid_f = torch.empty_like(hid0)
+    q_f = torch.empty(1, 3 * h, dtype=torch.float16, device=dev)
+    act = torch.empty(1, f, dtype=torch.float16, device=dev)
+    launches = [[qkv.desc(hid_f, q_f, gamma=gam1, eps=eps)],
+                [o.desc(attn, hid_f, flags=capi.TCE_W4_ADD_TO_C)],
+                [gu.desc(hid_f, act, flags=capi.TCE_W4_SILU_MUL_PAIRS, gamma=gam2, eps=eps)],
+                [down.desc(act, hid_f, flags=capi.TCE_W4_ADD_TO_C)]]
+
+    def check(what):
+        torch.cuda.synchronize()
+        assert np.array_equal(q_f.cpu().numpy().view(np.uint16), want_qkv.view(np.uint16)), f"{what}: q/k/v"
+        assert np.array_equal(hid_f.cpu().numpy().view(np.uint16), want_hid.view(np.uint16)), f"{what}: hidden state"
+
+    hid_f.copy_(hid0)
+    for d in launches:
+        capi.check(capi.w4a16_forward(d[0], s))
+    check("direct")
+    for chained in (False, True):
+        plan = capi.Plan(launches, chained=chained)
+        assert plan.chained == chained
+        for _ in range(3):
+            hid_f.copy_(hid0); q_f.zero_(); act.zero_()
+            plan.launch(s)
+            plan.status()
+            check(f"plan chained={chained}")
+        plan.close()

@@ -42,6 +42,7 @@ class W4A16Desc(C.Structure):
         ("A", C.c_void_p), ("qweight", C.c_void_p), ("scales", C.c_void_p), ("zeros", C.c_void_p), ("C", C.c_void_p),
         ("lda", C.c_int32), ("ldc", C.c_int32), ("scales_stride", C.c_int32), ("zeros_stride", C.c_int32),
         ("flags", C.c_int32), ("reserved", C.c_int32),
+        ("rmsnorm_gamma", C.c_void_p), ("rmsnorm_eps", C.c_float), ("reserved2", C.c_int32),
     ]
 
 

@@ -179,6 +179,37 @@ int tce_w4a16_set_gemm_config(int mt, int nt) {
     return TCE_OK;
 }
 
+static int forward_group_norm(const tce_w4a16_desc *descs, int count, const float *gamma, float eps, void *stream) {
+    if (!descs || count < 1 || count > TCE_MAX_GROUP) return fail(TCE_ERR_BAD_ARG, "group count %d not in 1..%d", count, TCE_MAX_GROUP);
+    if (!gamma || reinterpret_cast<uintptr_t>(gamma) % 16 != 0) return fail(TCE_ERR_BAD_ARG, "gamma must be a 16-byte aligned fp32 [K] vector");
+    for (int i = 0; i < count; ++i) {
+        const int rc = check_w4a16(&descs[i]);
+        if (rc != TCE_OK) return rc;
+        const tce_w4a16_desc &a = descs[0], &b = descs[i];
+        if (b.M != a.M || b.K != a.K || b.group_size != a.group_size || b.A != a.A || b.lda != a.lda)
+            return fail(TCE_ERR_BAD_ARG, "grouped linears must share M, K, group size and the activation");
+    }
+    if (descs[0].M != 1) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "the fused RMSNorm prologue is a decode (M = 1) path; use tce_rmsnorm_half for M = %d", descs[0].M);
+    hipError_t he = hipSuccess;
+    // The prologue costs a workgroup one extra pass over x plus 4 bytes of gamma per element: 256 persistent workgroups
+    // pay that once each, thousands of row-block workgroups do not amortise it (Llama-3 gate+up: no gain over two
+    // launches).  So the persistent kernel takes the fused form from ~8k rows up; the row-block kernel below that.
+    long long rows = 0;
+    for (int i = 0; i < count; ++i) rows += descs[i].N;
+    if (g_gemv_kernel == 2 || (g_gemv_kernel == 0 && rows >= 8192)) {
+        const int rc = tce::launch_w4a16_gemv_stream(descs, count, static_cast<hipStream_t>(stream), &he, gamma, eps);
+        if (rc == TCE_OK) return TCE_OK;
+        if (rc == TCE_ERR_HIP) return hip_fail(he, "w4a16 persistent gemv launch");
+        if (rc != TCE_ERR_UNSUPPORTED_SHAPE) return fail(rc, "w4a16 persistent gemv: unsupported configuration");
+    }
+    const int rc = tce::launch_w4a16_gemv(descs, count, g_gemv_kernel == 1 ? g_gemv_rows : 0, g_gemv_kernel == 1 ? g_gemv_wn : 0,
+                                          g_gemv_kernel == 1 ? g_gemv_wk : 0, g_gemv_kernel == 1 ? g_gemv_depth : 0,
+                                          static_cast<hipStream_t>(stream), &he, gamma, eps);
+    if (rc == TCE_ERR_HIP) return hip_fail(he, "w4a16 gemv launch");
+    if (rc != TCE_OK) return fail(rc, "w4a16 gemv (rmsnorm prologue): no kernel variant for this shape/config");
+    return TCE_OK;
+}
+
 int tce_w4a16_forward_group(const tce_w4a16_desc *descs, int count, void *stream) {
     if (!descs || count < 1 || count > TCE_MAX_GROUP) return fail(TCE_ERR_BAD_ARG, "group count %d not in 1..%d", count, TCE_MAX_GROUP);
     for (int i = 0; i < count; ++i) {
@@ -187,7 +218,10 @@ int tce_w4a16_forward_group(const tce_w4a16_desc *descs, int count, void *stream
         const tce_w4a16_desc &a = descs[0], &b = descs[i];
         if (b.M != a.M || b.K != a.K || b.group_size != a.group_size || b.A != a.A || b.lda != a.lda)
             return fail(TCE_ERR_BAD_ARG, "grouped linears must share M, K, group size and the activation");
+        if (b.rmsnorm_gamma != a.rmsnorm_gamma || (a.rmsnorm_gamma && b.rmsnorm_eps != a.rmsnorm_eps))
+            return fail(TCE_ERR_BAD_ARG, "grouped linears must share the RMSNorm prologue (gamma, eps)");
     }
+    if (descs[0].rmsnorm_gamma) return forward_group_norm(descs, count, static_cast<const float *>(descs[0].rmsnorm_gamma), descs[0].rmsnorm_eps, stream);
     hipError_t he = hipSuccess;
     // Kernel choice: the workgroup-per-row-block kernel or the persistent one (w4a16_gemv_stream.hip); either can be
     // forced through tce_w4a16_set_gemv_config (waves_k == 0 selects the persistent kernel).
@@ -217,6 +251,7 @@ int tce_w4a16_forward(const tce_w4a16_desc *d, void *stream) {
     const bool want_gemm = (d->flags & TCE_W4_FORCE_GEMM) ||
                            (d->M > TCE_W4A16_GEMV_MAX_M && !(d->flags & (TCE_W4_FORCE_GEMV | TCE_W4_SILU_MUL_PAIRS)));
     hipError_t he = hipSuccess;
+    if (d->rmsnorm_gamma && d->M != 1) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "the fused RMSNorm prologue is a decode (M = 1) path; use tce_rmsnorm_half for M = %d", d->M);
     if (want_gemm && d->K % 128 == 0 && d->group_size == 128) {  // other group sizes: GEMV kernel, 4 rows per pass
         const int rc = tce::launch_w4a16_gemm(*d, g_gemm_mt, g_gemm_nt, static_cast<hipStream_t>(stream), &he);
         if (rc == TCE_ERR_HIP) return hip_fail(he, "w4a16 gemm launch");
@@ -285,34 +320,7 @@ int tce_rmsnorm_half(const void *x, const float *gamma, void *out, int m, int n,
 }
 
 int tce_w4a16_forward_group_rmsnorm(const tce_w4a16_desc *descs, int count, const float *gamma, float eps, void *stream) {
-    if (!descs || count < 1 || count > TCE_MAX_GROUP) return fail(TCE_ERR_BAD_ARG, "group count %d not in 1..%d", count, TCE_MAX_GROUP);
-    if (!gamma || reinterpret_cast<uintptr_t>(gamma) % 16 != 0) return fail(TCE_ERR_BAD_ARG, "gamma must be a 16-byte aligned fp32 [K] vector");
-    for (int i = 0; i < count; ++i) {
-        const int rc = check_w4a16(&descs[i]);
-        if (rc != TCE_OK) return rc;
-        const tce_w4a16_desc &a = descs[0], &b = descs[i];
-        if (b.M != a.M || b.K != a.K || b.group_size != a.group_size || b.A != a.A || b.lda != a.lda)
-            return fail(TCE_ERR_BAD_ARG, "grouped linears must share M, K, group size and the activation");
-    }
-    if (descs[0].M != 1) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "the fused RMSNorm prologue is a decode (M = 1) path; use tce_rmsnorm_half for M = %d", descs[0].M);
-    hipError_t he = hipSuccess;
-    // The prologue costs a workgroup one extra pass over x plus 4 bytes of gamma per element: 256 persistent workgroups
-    // pay that once each, thousands of row-block workgroups do not amortise it (Llama-3 gate+up: no gain over two
-    // launches).  So the persistent kernel takes the fused form from ~8k rows up; the row-block kernel below that.
-    long long rows = 0;
-    for (int i = 0; i < count; ++i) rows += descs[i].N;
-    if (g_gemv_kernel == 2 || (g_gemv_kernel == 0 && rows >= 8192)) {
-        const int rc = tce::launch_w4a16_gemv_stream(descs, count, static_cast<hipStream_t>(stream), &he, gamma, eps);
-        if (rc == TCE_OK) return TCE_OK;
-        if (rc == TCE_ERR_HIP) return hip_fail(he, "w4a16 persistent gemv launch");
-        if (rc != TCE_ERR_UNSUPPORTED_SHAPE) return fail(rc, "w4a16 persistent gemv: unsupported configuration");
-    }
-    const int rc = tce::launch_w4a16_gemv(descs, count, g_gemv_kernel == 1 ? g_gemv_rows : 0, g_gemv_kernel == 1 ? g_gemv_wn : 0,
-                                          g_gemv_kernel == 1 ? g_gemv_wk : 0, g_gemv_kernel == 1 ? g_gemv_depth : 0,
-                                          static_cast<hipStream_t>(stream), &he, gamma, eps);
-    if (rc == TCE_ERR_HIP) return hip_fail(he, "w4a16 gemv launch");
-    if (rc != TCE_OK) return fail(rc, "w4a16 gemv (rmsnorm prologue): no kernel variant for this shape/config");
-    return TCE_OK;
+    return forward_group_norm(descs, count, gamma, eps, stream);
 }
 
 int tce_add_half(const void *a, const void *b, void *c, long long n, void *stream) {
@@ -393,6 +401,7 @@ int tce_plan_create_ex(const tce_w4a16_desc *descs, const int32_t *group_sizes, 
         for (int j = 0; j < p->groups[i] && chained; ++j) {
             const tce_w4a16_desc &a = p->descs[off], &b = p->descs[off + j];
             if (check_w4a16(&b) != TCE_OK || b.M != a.M || b.K != a.K || b.group_size != a.group_size || b.A != a.A || b.lda != a.lda ||
+                b.rmsnorm_gamma != a.rmsnorm_gamma || (a.rmsnorm_gamma && b.rmsnorm_eps != a.rmsnorm_eps) ||
                 (b.flags & TCE_W4_FORCE_GEMM))
                 chained = false;
         }

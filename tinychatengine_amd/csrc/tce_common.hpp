@@ -145,14 +145,16 @@ __device__ __forceinline__ half_t rmsnorm_out(half_t x, float rs, float gamma) {
 // l, l + 64, ... in order (fmaf, fp32); wave w takes chunks w, w + nwaves, ...; the [16][64] partial sums meet in LDS, each
 // lane adds its 16 in chunk order, and the 64 lane sums go through the fixed DPP tree.  `part` = 4 KiB of LDS; contains
 // two barriers (the second one frees `part` for reuse).
-__device__ __forceinline__ float rmsnorm_rs_block(const half_t *x, int n, float eps, int wave, int nwaves, int lane, float *part) {
+// `load_piece(p)` returns the row's p-th 16-byte piece as 8 halves.
+template <typename LoadPiece>
+__device__ __forceinline__ float rmsnorm_rs_block(LoadPiece load_piece, int n, float eps, int wave, int nwaves, int lane, float *part) {
     const int pieces = n >> 3;
     const int chunk = ((pieces + 15) / 16 + 63) & ~63;
     for (int c = wave; c < 16; c += nwaves) {
         float ss = 0.f;
         const int end = (c + 1) * chunk < pieces ? (c + 1) * chunk : pieces;
         for (int p = c * chunk + lane; p < end; p += 64) {
-            const half8_t v = *reinterpret_cast<const half8_t *>(x + p * 8);
+            const half8_t v = load_piece(p);
 #pragma unroll
             for (int e = 0; e < 8; ++e) ss = __builtin_fmaf((float)v[e], (float)v[e], ss);
         }
@@ -166,6 +168,9 @@ __device__ __forceinline__ float rmsnorm_rs_block(const half_t *x, int n, float 
     tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), 63));
     __syncthreads();
     return 1.0f / sqrtf(tot / (float)n + eps);
+}
+__device__ __forceinline__ float rmsnorm_rs_block(const half_t *x, int n, float eps, int wave, int nwaves, int lane, float *part) {
+    return rmsnorm_rs_block([&](int p) { return *reinterpret_cast<const half8_t *>(x + p * 8); }, n, eps, wave, nwaves, lane, part);
 }
 
 // non-temporal 16-byte load: streamed weights are read exactly once by exactly one CU

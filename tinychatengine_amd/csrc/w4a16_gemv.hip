@@ -489,6 +489,10 @@ bool gemv_variant_exists(int rows, int wn, int wk, int depth) {
 int launch_w4a16_gemv(const tce_w4a16_desc *descs, int count, int forced_rows, int forced_wn, int forced_wk,
                       int forced_depth, hipStream_t stream, hipError_t *hip_err, const float *gamma, float eps) {
     const tce_w4a16_desc &d0 = descs[0];
+    if (!gamma && d0.rmsnorm_gamma) {
+        gamma = static_cast<const float *>(d0.rmsnorm_gamma);
+        eps = d0.rmsnorm_eps;
+    }
     if (gamma && d0.M != 1) return TCE_ERR_UNSUPPORTED_SHAPE;
     GemvArgs a{};
     a.gamma = gamma;

@@ -229,7 +229,9 @@ __device__ __forceinline__ void gemv_launch_body(const StreamLaunch &L, const Ba
     if (L.gamma) {
         // fused RMSNorm prologue (generalT5LayerNorm, LlamaRMSNorm.cu:68-93): rs by the workgroup in the shape-independent
         // order of rmsnorm_rs_block, then half(clamp((x * rs) * gamma)) goes into the image instead of x
-        const float rs = rmsnorm_rs_block(A, K, L.eps, wave, NW, lane, reinterpret_cast<float *>(smem + (size_t)T * (4096 + 256) + 256));
+        // (coherent reads, like the image's: behind a barrier the row was written by other CUs moments ago)
+        const float rs = rmsnorm_rs_block([&](int p) { return __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_a, p * 16, 0, /*sc0|sc1*/ 17)); },
+                                          K, L.eps, wave, NW, lane, reinterpret_cast<float *>(smem + (size_t)T * (4096 + 256) + 256));
         for (int p = tid; p < total_pieces; p += nthreads) {
             const int c = (p >> 8) * 64 + (p & 63), j = (p >> 6) & 3;
             uint4_t o = uint4_t{0u, 0u, 0u, 0u};
@@ -390,7 +392,11 @@ __device__ __forceinline__ void gemv_launch_body(const StreamLaunch &L, const Ba
             } else if (c_epi & TCE_W4_ADD_TO_C) {
 #pragma unroll
                 for (int i = 0; i < ROWS; ++i)
-                    if (row0 + i < c_N) put(row0 + i, c_C[row0 + i] + outv[i]);
+                    if (row0 + i < c_N) {
+                        // device-scope read: inside a token kernel the residual may have been written by another CU
+                        const unsigned short old = __hip_atomic_load(reinterpret_cast<unsigned short *>(c_C + row0 + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        put(row0 + i, __builtin_bit_cast(half_t, old) + outv[i]);
+                    }
             } else {
 #pragma unroll
                 for (int i = 0; i < ROWS; ++i)
@@ -497,6 +503,8 @@ bool fill_launch(const tce_w4a16_desc *descs, int count, int rows, StreamLaunch 
     a.K = d0.K;
     a.log2g = d0.group_size == 128 ? 7 : (d0.group_size == 64 ? 6 : 5);
     a.nseg = count;
+    a.gamma = static_cast<const float *>(d0.rmsnorm_gamma);
+    a.eps = d0.rmsnorm_eps;
     int n_rg = 0;
     for (int i = 0; i < count; ++i) {
         const tce_w4a16_desc &d = descs[i];
@@ -582,8 +590,10 @@ int launch_w4a16_gemv_stream(const tce_w4a16_desc *descs, int count, hipStream_t
     bool z8 = true;
     if (!fill_launch(descs, count, rows, &a.launch, &z8)) return TCE_ERR_UNSUPPORTED_SHAPE;
     a.dbg = g_stream_dbg;
-    a.launch.gamma = gamma;
-    a.launch.eps = eps;
+    if (gamma) {
+        a.launch.gamma = gamma;
+        a.launch.eps = eps;
+    }
     int blocks = cus * bpc;
     if ((long)blocks * nw > a.launch.n_rg) blocks = (a.launch.n_rg + nw - 1) / nw;  // fewer row groups than waves
 

@@ -33,13 +33,14 @@ class Linear_half_int4:
     def load(cls, dirname: str, out_features: int, in_features: int, group_size: int = quantize.QK4_6, device="cuda"):
         return cls(*quantize.load_linear_q4_6(dirname, out_features, in_features, group_size, device), group_size=group_size)
 
-    def desc(self, x: torch.Tensor, out: torch.Tensor, ldc: int = 0, flags: int = 0) -> capi.W4A16Desc:
+    def desc(self, x: torch.Tensor, out: torch.Tensor, ldc: int = 0, flags: int = 0, gamma: torch.Tensor | None = None, eps: float = 0.0) -> capi.W4A16Desc:
         m = x.numel() // self.in_features
         # plain data_ptr(): descriptors are also built for host tensors by the CPU-side tests of the sharding logic;
         # the C ABI itself only ever receives device pointers on the product path (MatmulOperator checks is_cuda)
         return capi.W4A16Desc(M=m, N=self.out_features, K=self.in_features, group_size=self.group_size, A=x.data_ptr(),
                               qweight=self.weight.data_ptr(), scales=self.scale.data_ptr(), zeros=self.zero_point.data_ptr(),
-                              C=out.data_ptr(), ldc=ldc, flags=flags | (capi.TCE_W4_ZERO_POINT_IS_8 if self.zeros_are_8 else 0))
+                              C=out.data_ptr(), ldc=ldc, flags=flags | (capi.TCE_W4_ZERO_POINT_IS_8 if self.zeros_are_8 else 0),
+                              rmsnorm_gamma=gamma.data_ptr() if gamma is not None else None, rmsnorm_eps=float(eps))
 
     @classmethod
     def interleave(cls, gate: "Linear_half_int4", up: "Linear_half_int4") -> "Linear_half_int4":
