@@ -179,6 +179,11 @@ typedef struct tce_w8a8_desc {
 
 TCE_API int tce_w8a8_matmul(const tce_w8a8_desc *d, void *stream);
 
+/* LayerNormQ::forward (llm/src/ops/LayerNormQ.cc:12-52), the op in front of the W8A8 linears: x fp32 [m][n],
+ * weight / bias fp32 [n], out int8 [m][n] = (int8) round((x - mean) / sqrt(var + 1e-5) * weight + bias), sums sequential
+ * in fp32 exactly like the reference loop: BIT-EXACT.  n % 4 == 0. */
+TCE_API int tce_layernorm_q(const float *x, const float *weight, const float *bias, void *out, int m, int n, void *stream);
+
 /* ---- replayable plan: a fixed sequence of W4A16 launches captured into one hipGraph ---- */
 typedef struct tce_plan tce_plan;
 /* group_sizes[i] consecutive descriptors form launch i (1 = tce_w4a16_forward, >1 = tce_w4a16_forward_group). */

@@ -202,6 +202,13 @@ class Oracle(_Lib):
         self.lib.orc_silu_mul_half(_p(a), _p(b), _p(out), C.c_int64(a.size))
         return out.view(np.float16)
 
+    def layernorm_q(self, x_f32, w_f32, b_f32):
+        x = np.ascontiguousarray(x_f32, np.float32); w = np.ascontiguousarray(w_f32, np.float32); b = np.ascontiguousarray(b_f32, np.float32)
+        m, n = x.reshape(-1, x.shape[-1]).shape
+        out = np.empty(x.shape, np.int8)
+        self.lib.orc_layernorm_q(_p(x), _p(w), _p(b), _p(out), C.c_int(m), C.c_int(n))
+        return out
+
     def rmsnorm_half(self, x_f16, gamma_f32, eps):
         x = np.ascontiguousarray(x_f16, np.float16); g = np.ascontiguousarray(gamma_f32, np.float32)
         m, n = x.reshape(-1, x.shape[-1]).shape

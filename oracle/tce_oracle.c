@@ -600,3 +600,31 @@ ORC_API void orc_rmsnorm_half(const uint16_t *x, const float *gamma, uint16_t *o
         }
     }
 }
+
+/* LayerNormQ::forward (llm/src/ops/LayerNormQ.cc:12-52), the op in front of every W8A8 linear of the OPT path: fp32 in,
+ * int8 out, eps = 1e-5, every sum sequential in fp32, out = (int8) round( (v - mean) / std * w + b ) (std::round: half
+ * away from zero; no clamp in the reference -- values are assumed to fit).  The narrowing is done through int32 here,
+ * which is what the reference's static_cast does for in-range values. */
+ORC_API void orc_layernorm_q(const float *x, const float *w, const float *b, int8_t *out, int m, int n) {
+    const float eps = 0.00001;
+    for (int r = 0; r < m; r++) {
+        const float *xr = x + (int64_t)r * n;
+        float mean = 0;
+        for (int k = 0; k < n; k++) mean += xr[k];
+        mean /= (float)n;
+        float sq = 0;
+        for (int k = 0; k < n; k++) {
+            const float d = xr[k] - mean;
+            const float p = d * d;
+            sq += p;
+        }
+        const float var = sq / (float)n;
+        const float std_dev = sqrtf(var + eps);
+        for (int k = 0; k < n; k++) {
+            const float t = (xr[k] - mean) / std_dev;
+            const float u = t * w[k];
+            const float f = u + b[k];
+            out[(int64_t)r * n + k] = (int8_t)(int32_t)roundf(f);
+        }
+    }
+}

@@ -180,6 +180,11 @@ def sweep_w8a8():
         us = time_graph(lambda i, sp: capi.check(L.tce_w8a8_matmul(C.byref(d), sp)), 64)
         tops = 2.0 * M * N * K / us / 1e6
         print(json.dumps({"kind": "w8a8", "M": M, "N": N, "K": K, "us": round(us, 2), "TOPs": round(tops, 2)}), flush=True)
+    for (M, N) in [(512, 768), (108, 768), (1, 768)]:  # LayerNormQ in front of the int8 linears (bit-exact, one thread per row)
+        x = torch.randn(M, N, device=dev); w = torch.randn(N, device=dev); b = torch.randn(N, device=dev)
+        out = torch.empty((M, N), dtype=torch.int8, device=dev)
+        us = time_graph(lambda i, sp: capi.check(L.tce_layernorm_q(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, sp)), 64)
+        print(json.dumps({"kind": "layernorm_q", "M": M, "N": N, "us": round(us, 2)}), flush=True)
 
 
 def layer_glue():

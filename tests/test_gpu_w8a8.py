@@ -173,3 +173,21 @@ def test_unsupported_kind_is_rejected(dev):
     d = capi.W8A8Desc(M=4, N=4, K=64, batch=1, A=a.data_ptr(), B=a.data_ptr(), bias=a.data_ptr(), C=a.data_ptr(), alpha=1.0, beta=1.0,
                       q_min=-128, q_max=127, bias_kind=capi.TCE_BIAS_FP32, out_kind=capi.TCE_OUT_INT8)
     assert capi.w8a8_matmul(d, 0) == capi.TCE_ERR_UNSUPPORTED_KIND
+
+
+@pytest.mark.parametrize("m,n", [(108, 768), (1, 768), (512, 768), (65, 1024), (3, 2048), (7, 20)])
+def test_layernorm_q_bit_exact(dev, oracle, m, n):
+    """tce_layernorm_q against the oracle's restatement of LayerNormQ::forward (LayerNormQ.cc:12-52): bit for bit."""
+    import ctypes as C
+    from tinychatengine_amd import capi
+    rng = np.random.default_rng(m * 1000 + n)
+    x = (rng.standard_normal((m, n)) * 3 + rng.standard_normal((m, 1))).astype(np.float32)
+    w = (8 + 4 * rng.standard_normal(n)).astype(np.float32)
+    b = (rng.standard_normal(n) * 2).astype(np.float32)
+    out = torch.zeros((m, n), dtype=torch.int8, device=dev)
+    tx, tw, tb = _t(dev, x), _t(dev, w), _t(dev, b)
+    capi.check(capi.lib().tce_layernorm_q(tx.data_ptr(), tw.data_ptr(), tb.data_ptr(), out.data_ptr(), m, n, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    want = oracle.layernorm_q(x, w, b)
+    got = out.cpu().numpy()
+    assert np.array_equal(got, want), f"{(got != want).sum()} of {got.size} int8 outputs differ"

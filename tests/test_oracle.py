@@ -194,3 +194,22 @@ def test_rmsnorm_restatement_against_float64(oracle):
     big = np.full((1, 64), 60000.0, np.float16); big[0, 1:] = 0
     out = oracle.rmsnorm_half(big, np.full(64, 1e4, np.float32), 1e-6)
     assert np.isfinite(out.astype(np.float32)).all() and float(out[0, 0]) == float(np.float16(64504.0))
+
+
+def test_layernorm_q_restatement(oracle):
+    """orc_layernorm_q (LayerNormQ.cc:12-52) against an independent numpy float32 evaluation with sequential sums."""
+    rng = np.random.default_rng(12)
+    x = (rng.standard_normal((5, 96)) * 2).astype(np.float32); w = (6 + rng.standard_normal(96)).astype(np.float32); b = rng.standard_normal(96).astype(np.float32)
+    got = oracle.layernorm_q(x, w, b)
+    want = np.empty_like(got)
+    for r in range(5):
+        mean = np.float32(0)
+        for v in x[r]: mean = np.float32(mean + v)
+        mean = np.float32(mean / np.float32(96))
+        sq = np.float32(0)
+        for v in x[r]:
+            d = np.float32(v - mean); sq = np.float32(sq + np.float32(d * d))
+        std = np.float32(np.sqrt(np.float32(np.float32(sq / np.float32(96)) + np.float32(0.00001))))
+        f = ((x[r] - mean) / std * w + b).astype(np.float32)
+        want[r] = np.where(f >= 0, np.floor(f + np.float32(0.5)), np.ceil(f - np.float32(0.5))).astype(np.int8)
+    assert np.array_equal(got, want)

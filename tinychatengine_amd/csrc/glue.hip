@@ -53,7 +53,58 @@ __global__ __launch_bounds__(512) void rmsnorm_half_kernel(const half_t *x, cons
     }
 }
 
+// LayerNormQ::forward (llm/src/ops/LayerNormQ.cc:12-52): fp32 in, int8 out, in front of the W8A8 linears.  Bit-exact
+// with the reference's CPU loop, which fixes the design: both row sums are SEQUENTIAL fp32 additions, so one thread
+// walks one row (three passes, 16-byte loads; the division, multiply and add are separate roundings:
+// -ffp-contract=off).  OPT rows are 768-1024 elements; the launch is latency-sized like the int8 GEMMs around it.
+__global__ __launch_bounds__(64) void layernorm_q_kernel(const float *x, const float *w, const float *b, int8_t *out, int m, int n) {
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= m) return;
+    const float *xr = x + (size_t)r * n;
+    int8_t *orow = out + (size_t)r * n;
+    const int n4 = n & ~3;
+    float mean = 0.f;
+    for (int k = 0; k < n4; k += 4) {
+        const float4_t v = *reinterpret_cast<const float4_t *>(xr + k);
+        mean += v[0];
+        mean += v[1];
+        mean += v[2];
+        mean += v[3];
+    }
+    for (int k = n4; k < n; ++k) mean += xr[k];
+    mean /= (float)n;
+    float sq = 0.f;
+    for (int k = 0; k < n4; k += 4) {
+        const float4_t v = *reinterpret_cast<const float4_t *>(xr + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = v[e] - mean;
+            sq += __fmul_rn(d, d);
+        }
+    }
+    for (int k = n4; k < n; ++k) {
+        const float d = xr[k] - mean;
+        sq += __fmul_rn(d, d);
+    }
+    const float std_dev = sqrtf(sq / (float)n + 0.00001f);
+    for (int k = 0; k < n; ++k) {
+        const float t = __fdiv_rn(xr[k] - mean, std_dev);
+        const float f = __fadd_rn(__fmul_rn(t, w[k]), b[k]);
+        orow[k] = (int8_t)(int)roundf(f);
+    }
+}
+
 }  // namespace
+
+int launch_layernorm_q(const float *x, const float *w, const float *b, void *out, int m, int n, hipStream_t stream, hipError_t *hip_err) {
+    hipLaunchKernelGGL(layernorm_q_kernel, dim3((m + 63) / 64), dim3(64), 0, stream, x, w, b, static_cast<int8_t *>(out), m, n);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (hip_err) *hip_err = e;
+        return TCE_ERR_HIP;
+    }
+    return TCE_OK;
+}
 
 int launch_rmsnorm_half(const void *x, const float *gamma, void *out, int m, int n, float eps, hipStream_t stream, hipError_t *hip_err) {
     hipLaunchKernelGGL(rmsnorm_half_kernel, dim3(m), dim3(512), 0, stream, static_cast<const half_t *>(x), gamma, static_cast<half_t *>(out), n, eps);

@@ -95,6 +95,7 @@ int launch_awq_repack(int N, int K, int G, const void *qweight, const void *scal
                       hipError_t *hip_err);
 
 // element-wise glue of the decoder layer (glue.hip)
+int launch_layernorm_q(const float *x, const float *w, const float *b, void *out, int m, int n, hipStream_t stream, hipError_t *hip_err);
 int launch_rmsnorm_half(const void *x, const float *gamma, void *out, int m, int n, float eps, hipStream_t stream, hipError_t *hip_err);
 int launch_add_half(const void *a, const void *b, void *c, long long n, hipStream_t stream, hipError_t *hip_err);
 int launch_silu_mul_half(void *a, const void *b, long long n, hipStream_t stream, hipError_t *hip_err);
