@@ -181,7 +181,7 @@ TCE_API int tce_w8a8_matmul(const tce_w8a8_desc *d, void *stream);
 
 /* LayerNormQ::forward (llm/src/ops/LayerNormQ.cc:12-52), the op in front of the W8A8 linears: x fp32 [m][n],
  * weight / bias fp32 [n], out int8 [m][n] = (int8) round((x - mean) / sqrt(var + 1e-5) * weight + bias), sums sequential
- * in fp32 exactly like the reference loop: BIT-EXACT.  n % 4 == 0. */
+ * in fp32 exactly like the reference loop: BIT-EXACT.  n % 4 == 0, n <= 8192. */
 TCE_API int tce_layernorm_q(const float *x, const float *weight, const float *bias, void *out, int m, int n, void *stream);
 
 /* ---- replayable plan: a fixed sequence of W4A16 launches captured into one hipGraph ---- */

@@ -54,41 +54,45 @@ __global__ __launch_bounds__(512) void rmsnorm_half_kernel(const half_t *x, cons
 }
 
 // LayerNormQ::forward (llm/src/ops/LayerNormQ.cc:12-52): fp32 in, int8 out, in front of the W8A8 linears.  Bit-exact
-// with the reference's CPU loop, which fixes the design: both row sums are SEQUENTIAL fp32 additions, so one thread
-// walks one row (three passes, 16-byte loads; the division, multiply and add are separate roundings:
-// -ffp-contract=off).  OPT rows are 768-1024 elements; the launch is latency-sized like the int8 GEMMs around it.
+// with the reference's CPU loop, which fixes the design: both row sums are SEQUENTIAL fp32 additions.  One wavefront per
+// row: the row is loaded coalesced into LDS, lane 0 walks it for the two sums (16-byte LDS reads, the additions are the
+// critical path: ~2 x n dependent adds), then all lanes produce outputs in parallel (the division, multiply and add are
+// separate roundings: -ffp-contract=off).  n <= 8192.
 __global__ __launch_bounds__(64) void layernorm_q_kernel(const float *x, const float *w, const float *b, int8_t *out, int m, int n) {
-    const int r = blockIdx.x * 64 + threadIdx.x;
-    if (r >= m) return;
-    const float *xr = x + (size_t)r * n;
-    int8_t *orow = out + (size_t)r * n;
-    const int n4 = n & ~3;
-    float mean = 0.f;
-    for (int k = 0; k < n4; k += 4) {
-        const float4_t v = *reinterpret_cast<const float4_t *>(xr + k);
-        mean += v[0];
-        mean += v[1];
-        mean += v[2];
-        mean += v[3];
-    }
-    for (int k = n4; k < n; ++k) mean += xr[k];
-    mean /= (float)n;
-    float sq = 0.f;
-    for (int k = 0; k < n4; k += 4) {
-        const float4_t v = *reinterpret_cast<const float4_t *>(xr + k);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float d = v[e] - mean;
-            sq += __fmul_rn(d, d);
+    extern __shared__ __attribute__((aligned(16))) float row[];
+    const int lane = threadIdx.x;
+    const float *xr = x + (size_t)blockIdx.x * n;
+    int8_t *orow = out + (size_t)blockIdx.x * n;
+    const int n4 = n >> 2;  // n % 4 == 0
+    for (int p = lane; p < n4; p += 64) reinterpret_cast<float4_t *>(row)[p] = reinterpret_cast<const float4_t *>(xr)[p];
+    __syncthreads();
+    float mean = 0.f, std_dev = 0.f;
+    if (lane == 0) {
+#pragma unroll 8
+        for (int p = 0; p < n4; ++p) {
+            const float4_t v = reinterpret_cast<const float4_t *>(row)[p];
+            mean += v[0];
+            mean += v[1];
+            mean += v[2];
+            mean += v[3];
         }
+        mean /= (float)n;
+        float sq = 0.f;
+#pragma unroll 8
+        for (int p = 0; p < n4; ++p) {
+            const float4_t v = reinterpret_cast<const float4_t *>(row)[p];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[e] - mean;
+                sq += __fmul_rn(d, d);
+            }
+        }
+        std_dev = sqrtf(sq / (float)n + 0.00001f);
     }
-    for (int k = n4; k < n; ++k) {
-        const float d = xr[k] - mean;
-        sq += __fmul_rn(d, d);
-    }
-    const float std_dev = sqrtf(sq / (float)n + 0.00001f);
-    for (int k = 0; k < n; ++k) {
-        const float t = __fdiv_rn(xr[k] - mean, std_dev);
+    mean = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, mean)));
+    std_dev = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, std_dev)));
+    for (int k = lane; k < n; k += 64) {
+        const float t = __fdiv_rn(row[k] - mean, std_dev);
         const float f = __fadd_rn(__fmul_rn(t, w[k]), b[k]);
         orow[k] = (int8_t)(int)roundf(f);
     }
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(64) void layernorm_q_kernel(const float *x, const f
 }  // namespace
 
 int launch_layernorm_q(const float *x, const float *w, const float *b, void *out, int m, int n, hipStream_t stream, hipError_t *hip_err) {
-    hipLaunchKernelGGL(layernorm_q_kernel, dim3((m + 63) / 64), dim3(64), 0, stream, x, w, b, static_cast<int8_t *>(out), m, n);
+    hipLaunchKernelGGL(layernorm_q_kernel, dim3(m), dim3(64), (size_t)n * sizeof(float), stream, x, w, b, static_cast<int8_t *>(out), m, n);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         if (hip_err) *hip_err = e;

@@ -312,7 +312,8 @@ int tce_w4a16_gemm_awq(int M, int N, int K, int G, const void *A, const void *qw
 
 int tce_layernorm_q(const float *x, const float *weight, const float *bias, void *out, int m, int n, void *stream) {
     if (!x || !weight || !bias || !out || m <= 0 || n <= 0) return fail(TCE_ERR_BAD_ARG, "tce_layernorm_q: bad argument");
-    if (n % 4 != 0 || reinterpret_cast<uintptr_t>(x) % 16 != 0) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_layernorm_q: n %% 4 == 0 and x 16-byte aligned");
+    if (n % 4 != 0 || n > 8192 || reinterpret_cast<uintptr_t>(x) % 16 != 0)
+        return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_layernorm_q: n %% 4 == 0, n <= 8192 and x 16-byte aligned");
     hipError_t he = hipSuccess;
     const int rc = tce::launch_layernorm_q(x, weight, bias, out, m, n, static_cast<hipStream_t>(stream), &he);
     return rc == TCE_ERR_HIP ? hip_fail(he, "layernorm_q launch") : rc;
