@@ -44,17 +44,24 @@ def _stale(target: str, deps: list[str]) -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIB_DIR, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + [os.path.join(REPO_DIR, "include", "tce_matmul.h")]
-    objs = []
+    objs, jobs = [], []
     hipcc = _hipcc()
     for src in HIP_SOURCES:
         sp = os.path.join(CSRC, src)
         op = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
         if force or _stale(op, [sp] + headers):
-            cmd = [hipcc, *HIPCC_FLAGS, "-I", os.path.join(REPO_DIR, "include"), "-I", CSRC, "-c", sp, "-o", op]
+            jobs.append([hipcc, *HIPCC_FLAGS, "-I", os.path.join(REPO_DIR, "include"), "-I", CSRC, "-c", sp, "-o", op])
+        objs.append(op)
+    if jobs:  # the translation units are independent: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
-        objs.append(op)
+
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
+            list(pool.map(run, jobs))
     if force or _stale(LIB_PATH, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs]
         if verbose:
