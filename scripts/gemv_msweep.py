@@ -14,6 +14,10 @@ def main():
             ds = [capi.W4A16Desc(M=M, N=N, K=K, group_size=128, A=x.data_ptr(), qweight=s[0].data_ptr(), scales=s[1].data_ptr(), zeros=s[2].data_ptr(), C=out.data_ptr()) for s in sets]
             us = time_graph(lambda i, sp: capi.check(L.tce_w4a16_forward(C.byref(ds[i % len(ds)]), sp)), 64)
             row[f"M={M}"] = round(us, 2)
+            if 2 <= M <= 16:  # the paths the small-batch kernel replaced (GEMV with repeated MFMAs up to 8, GEMM above)
+                capi.check(L.tce_w4a16_set_debug_mode(29))
+                row[f"M={M} old"] = round(time_graph(lambda i, sp: capi.check(L.tce_w4a16_forward(C.byref(ds[i % len(ds)]), sp)), 64), 2)
+                capi.check(L.tce_w4a16_set_debug_mode(20))
         print(json.dumps(row), flush=True)
 if __name__ == "__main__":
     main()

@@ -50,7 +50,7 @@ def test_gate_up_silu_mul_fused(dev, oracle, M, H, K):
         for cfg in configs:
             capi.set_gemv_config(*(cfg or (0, 0, 0, 0)))
             y = torch.empty(M, 2 * H, dtype=torch.float16, device=dev)
-            capi.check(capi.w4a16_forward(gu.desc(x, y, flags=capi.TCE_W4_FORCE_GEMV), torch.cuda.current_stream().cuda_stream))
+            capi.check(capi.w4a16_forward(gu.desc(x, y), torch.cuda.current_stream().cuda_stream))  # same kernel as the fused call
             fused = gu.forward_silu_mul(x)
             torch.cuda.synchronize()
             yn = y.cpu().numpy()

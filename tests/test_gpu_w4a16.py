@@ -379,3 +379,30 @@ def test_randomized_shapes_match_oracle(dev, oracle):
         qw, sc, zp, a = _make(oracle, M, N, K, G, seed=1000 + case, random_zeros=bool(case % 2))
         ref32, _ = oracle.w4a16_gemv_q4_6(a, qw, sc, zp, M, N, K, G)
         _check(_run(dev, qw, sc, zp, a, G), ref32, f"random case {case}: {M}x{N}x{K} g{G}")
+
+
+SKINNY_SHAPES = [(2, 4096, 4096), (16, 4096, 4096), (3, 100, 1408), (8, 264, 11008), (16, 17, 128), (5, 40, 256), (9, 2050, 2048), (13, 31, 14336)]
+
+
+@pytest.mark.parametrize("M,N,K", SKINNY_SHAPES)
+def test_small_batch_kernel_matches_oracle(dev, oracle, M, N, K):
+    """w4a16_skinny.hip (3 <= M <= 16; M = 2 stays on the GEMV kernel): automatic and every forced K split, plain and random zero points, with the
+    zero-point-8 promise, N tails (N % 16 != 0), a single k-block, rows past M."""
+    from tinychatengine_amd import capi
+    L = capi.lib()
+    try:
+        for rz in (False, True):
+            qw, sc, zp, a = _make(oracle, M, N, K, 128, seed=M * 13 + N + K, random_zeros=rz)
+            ref32, _ = oracle.w4a16_gemv_q4_6(a, qw, sc, zp, M, N, K, 128)
+            for mode in (20, 21, 22, 24, 28):
+                if mode > 20 and (mode - 20) > K // 128:
+                    continue
+                capi.check(L.tce_w4a16_set_debug_mode(mode))
+                _check(_run(dev, qw, sc, zp, a, 128), ref32, f"skinny ks-mode {mode} {M}x{N}x{K} random_zeros={rz}")
+                if not rz:
+                    _check(_run(dev, qw, sc, zp, a, 128, flags=capi.TCE_W4_ZERO_POINT_IS_8), ref32, f"skinny z8 ks-mode {mode} {M}x{N}x{K}")
+        # and the older paths still answer when the small-batch kernel is switched off
+        capi.check(L.tce_w4a16_set_debug_mode(29))
+        _check(_run(dev, qw, sc, zp, a, 128), ref32, f"skinny off {M}x{N}x{K}")
+    finally:
+        L.tce_w4a16_set_debug_mode(20)

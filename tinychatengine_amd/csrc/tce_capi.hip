@@ -70,6 +70,7 @@ int64_t tce_w4a16_algorithmic_bytes(int M, int N, int K, int G) {
 }
 
 int g_gemv_kernel = 0;  // 0 automatic, 1 workgroup-per-row-block kernel forced, 2 persistent stream kernel forced
+int g_skinny_enabled = 1;  // tuning: tce_w4a16_set_debug_mode(29) routes 3 <= M <= 16 to the GEMV / GEMM kernels again
 
 int tce_w4a16_set_gemv_config(int rows, int wn, int wk, int depth) {
     if (rows == 0 && wn == 0 && wk == 0) {
@@ -97,6 +98,11 @@ int tce_w4a16_set_gemv_config(int rows, int wn, int wk, int depth) {
 }
 
 int tce_w4a16_set_debug_mode(int mode) {
+    if (mode >= 20 && mode <= 29) {  // small-batch kernel tuning: 20 automatic, 21/22/24/28 = waves per tile, 29 = off
+        g_skinny_enabled = mode != 29;
+        tce::set_skinny_config(mode == 29 ? 0 : mode - 20);
+        return TCE_OK;
+    }
     if (mode < 0 || mode > 4) return fail(TCE_ERR_BAD_ARG, "debug mode %d", mode);
     tce::set_gemv_debug_mode(mode);
     tce::set_gemv_stream_debug(mode, g_dbg_buf_capi);
@@ -223,6 +229,18 @@ int tce_w4a16_forward_group(const tce_w4a16_desc *descs, int count, void *stream
     }
     if (descs[0].rmsnorm_gamma) return forward_group_norm(descs, count, static_cast<const float *>(descs[0].rmsnorm_gamma), descs[0].rmsnorm_eps, stream);
     hipError_t he = hipSuccess;
+    if (g_skinny_enabled && descs[0].M >= 3) {  // small batches: one skinny launch per linear (they stream the weights once each)
+        bool all = true;
+        for (int i = 0; i < count; ++i) all = all && !(descs[i].flags & (TCE_W4_FORCE_GEMV | TCE_W4_FORCE_GEMM)) && tce::skinny_supports(descs[i]);
+        if (all) {
+            for (int i = 0; i < count; ++i) {
+                const int rc = tce::launch_w4a16_skinny(descs[i], static_cast<hipStream_t>(stream), &he);
+                if (rc == TCE_ERR_HIP) return hip_fail(he, "w4a16 skinny launch");
+                if (rc != TCE_OK) return fail(rc, "w4a16 skinny: unsupported configuration");
+            }
+            return TCE_OK;
+        }
+    }
     // Kernel choice: the workgroup-per-row-block kernel or the persistent one (w4a16_gemv_stream.hip); either can be
     // forced through tce_w4a16_set_gemv_config (waves_k == 0 selects the persistent kernel).
     // Automatic choice (measured, profiles/r1/gemv_experiments.jsonl): the persistent kernel wins on very large launches
@@ -251,6 +269,13 @@ int tce_w4a16_forward(const tce_w4a16_desc *d, void *stream) {
     const bool want_gemm = (d->flags & TCE_W4_FORCE_GEMM) ||
                            (d->M > TCE_W4A16_GEMV_MAX_M && !(d->flags & (TCE_W4_FORCE_GEMV | TCE_W4_SILU_MUL_PAIRS)));
     hipError_t he = hipSuccess;
+    // small batches: weights streamed once, all M <= 16 rows on one MFMA tile (w4a16_skinny.hip)
+    if (g_skinny_enabled && !(d->flags & (TCE_W4_FORCE_GEMV | TCE_W4_FORCE_GEMM)) && tce::skinny_supports(*d)) {
+        const int rc = tce::launch_w4a16_skinny(*d, static_cast<hipStream_t>(stream), &he);
+        if (rc == TCE_OK) return TCE_OK;
+        if (rc == TCE_ERR_HIP) return hip_fail(he, "w4a16 skinny launch");
+        if (rc != TCE_ERR_UNSUPPORTED_SHAPE) return fail(rc, "w4a16 skinny: unsupported configuration");
+    }
     if (d->rmsnorm_gamma && d->M != 1) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "the fused RMSNorm prologue is a decode (M = 1) path; use tce_rmsnorm_half for M = %d", d->M);
     if (want_gemm && d->K % 128 == 0 && d->group_size == 128) {  // other group sizes: GEMV kernel, 4 rows per pass
         const int rc = tce::launch_w4a16_gemm(*d, g_gemm_mt, g_gemm_nt, static_cast<hipStream_t>(stream), &he);

@@ -94,6 +94,11 @@ int launch_awq_fp16acc(int M, int N, int K, int G, const void *A, const void *qw
 int launch_awq_repack(int N, int K, int G, const void *qweight, const void *scales, void *workspace, hipStream_t stream,
                       hipError_t *hip_err);
 
+// small batches, 2 <= M <= 16 (w4a16_skinny.hip)
+bool skinny_supports(const tce_w4a16_desc &d);
+void set_skinny_config(int ks);  // tuning: waves per 16-row tile, 0 = automatic
+int launch_w4a16_skinny(const tce_w4a16_desc &d, hipStream_t stream, hipError_t *hip_err);
+
 // element-wise glue of the decoder layer (glue.hip)
 int launch_layernorm_q(const float *x, const float *w, const float *b, void *out, int m, int n, hipStream_t stream, hipError_t *hip_err);
 int launch_rmsnorm_half(const void *x, const float *gamma, void *out, int m, int n, float eps, hipStream_t stream, hipError_t *hip_err);
