@@ -16,8 +16,10 @@
  *   tce_w4a16_forward          <- matmul::MatmulOperator::gemv_forward_cuda
  *                                 (kernels/cuda/gemv_cuda.cu:213-260; kernels gemv_kernel_g128 :140-194,
  *                                  gemv_kernel_g64 :68-123).  Serves every M like the reference does
- *                                 (grid.z = M there); here M <= TCE_W4A16_GEMV_MAX_M runs the
- *                                 bandwidth-bound GEMV kernel and larger M the MFMA GEMM kernel.
+ *                                 (grid.z = M there); here M <= 2 runs the bandwidth-bound GEMV kernels,
+ *                                 3 <= M <= 16 (group 128) the small-batch kernel that streams the weights once for
+ *                                 all rows, larger M the MFMA GEMM kernel; M <= TCE_W4A16_GEMV_MAX_M with another
+ *                                 group size stays on the GEMV kernels.
  *   tce_w4a16_forward_group    <- several gemv_forward_cuda calls that read the same activation
  *                                 (fused q/k/v: llm/src/nn_modules/cuda/Int4llamaAttention.cu:125;
  *                                  gate+up: Int4llamaDecoderLayer.cu:96-99) issued as ONE launch.
@@ -53,7 +55,7 @@ extern "C" {
 #define TCE_ERR_HIP (-4)               /* a HIP runtime call failed; see tce_last_error() */
 #define TCE_ERR_UNSUPPORTED_KIND (-5)  /* bias/out kind combination that has no reference counterpart */
 
-/* M at or below which tce_w4a16_forward uses the GEMV kernel family */
+/* M at or below which tce_w4a16_forward never uses the prefill GEMM (GEMV or small-batch kernels) */
 #define TCE_W4A16_GEMV_MAX_M 8
 
 /*
