@@ -381,7 +381,7 @@ def test_randomized_shapes_match_oracle(dev, oracle):
         _check(_run(dev, qw, sc, zp, a, G), ref32, f"random case {case}: {M}x{N}x{K} g{G}")
 
 
-SKINNY_SHAPES = [(2, 4096, 4096), (16, 4096, 4096), (3, 100, 1408), (8, 264, 11008), (16, 17, 128), (5, 40, 256), (9, 2050, 2048), (13, 31, 14336)]
+SKINNY_SHAPES = [(2, 4096, 4096), (16, 4096, 4096), (3, 100, 1408), (8, 264, 11008), (16, 17, 128), (5, 40, 256), (9, 2050, 2048), (13, 31, 14336), (7, 16400, 512)]
 
 
 @pytest.mark.parametrize("M,N,K", SKINNY_SHAPES)
@@ -394,8 +394,8 @@ def test_small_batch_kernel_matches_oracle(dev, oracle, M, N, K):
         for rz in (False, True):
             qw, sc, zp, a = _make(oracle, M, N, K, 128, seed=M * 13 + N + K, random_zeros=rz)
             ref32, _ = oracle.w4a16_gemv_q4_6(a, qw, sc, zp, M, N, K, 128)
-            for mode in (20, 21, 22, 24, 28):
-                if mode > 20 and (mode - 20) > K // 128:
+            for mode in (20, 21, 22, 24, 28, 30):  # 30: workgroups of 8 tiles sharing the activation blocks (K % 256 == 0, else it falls back)
+                if 20 < mode < 30 and (mode - 20) > K // 128:
                     continue
                 capi.check(L.tce_w4a16_set_debug_mode(mode))
                 _check(_run(dev, qw, sc, zp, a, 128), ref32, f"skinny ks-mode {mode} {M}x{N}x{K} random_zeros={rz}")

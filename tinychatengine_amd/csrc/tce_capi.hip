@@ -98,9 +98,9 @@ int tce_w4a16_set_gemv_config(int rows, int wn, int wk, int depth) {
 }
 
 int tce_w4a16_set_debug_mode(int mode) {
-    if (mode >= 20 && mode <= 29) {  // small-batch kernel tuning: 20 automatic, 21/22/24/28 = waves per tile, 29 = off
+    if (mode >= 20 && mode <= 30) {  // small-batch kernel tuning: 20 automatic, 21/22/24/28 = waves per tile, 30 = shared-x form, 29 = off
         g_skinny_enabled = mode != 29;
-        tce::set_skinny_config(mode == 29 ? 0 : mode - 20);
+        tce::set_skinny_config(mode == 29 ? 0 : (mode == 30 ? 9 : mode - 20));
         return TCE_OK;
     }
     if (mode < 0 || mode > 4) return fail(TCE_ERR_BAD_ARG, "debug mode %d", mode);

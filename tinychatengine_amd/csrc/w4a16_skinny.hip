@@ -195,6 +195,156 @@ __global__ __launch_bounds__(512) void w4a16_skinny_kernel(const SkinnyArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Large N: every wave of the kernel above fetches its own 4 KiB activation block per KiB of weights through L1, which caps
+// it at 2-2.4 TB/s once there are enough tiles to fill the chip without a K split (22016 x 4096: 19.5-24 us).  Here the 8
+// waves of a workgroup take 8 neighbouring weight tiles over the WHOLE K range and share the activation blocks: the
+// workgroup stages two k-blocks (16 rows x 256 k = 8 KiB, one 16-byte piece per thread, permuted once) into a
+// double-buffered LDS image per barrier; weights, tables and arithmetic are as above.  K % 256 == 0.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kSharedWaves = 8;
+
+template <bool Z8>
+__global__ __launch_bounds__(512) void w4a16_skinny_shared_kernel(const SkinnyArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nkb = a.K >> 7;
+    const int nst = nkb >> 1;  // stages of two k-blocks
+    const int tiles = (a.N + 15) >> 4;
+    int tile = blockIdx.x * kSharedWaves + wave;
+    const bool idle = tile >= tiles;  // a wave past the last tile walks the barriers on a clamped tile and stores nothing
+    tile = idle ? tiles - 1 : tile;
+    const int n0 = tile * 16;
+    const int nchunks = a.K >> 5;
+
+    // LDS: [2][2 x 256] activation pieces, then per wave: two weight blocks (2 KiB) and tables [nkb_pad][16] x 2 halves.
+    // The tables are padded to a multiple of 8 k-blocks with scale 0: the stage loop below runs in groups of four stages on
+    // clamped addresses and the surplus stages of the last group add exactly 0.
+    const int nkb_pad = (nkb + 7) & ~7;
+    uint4_t *lds_x = reinterpret_cast<uint4_t *>(smem);
+    unsigned char *wv = smem + 2 * 2 * kXBuf + (size_t)wave * (2 * kWBuf + (size_t)nkb_pad * 64);
+    uint4_t *lds_w = reinterpret_cast<uint4_t *>(wv);
+    half_t *tab_s = reinterpret_cast<half_t *>(wv + 2 * kWBuf);
+    half_t *tab_c = tab_s + nkb_pad * 16;
+    for (int idx = lane; idx < nkb_pad * 16; idx += 64) {
+        const int g = idx >> 4, r = idx & 15;
+        int n = n0 + r;
+        n = n < a.N ? n : a.N - 1;
+        const int gc = g < nkb ? g : nkb - 1;
+        const half_t sv = a.scales[(size_t)n * a.scales_stride + gc];
+        tab_s[idx] = g < nkb ? sv : (half_t)0.f;
+        unsigned z = 8u;
+        if constexpr (!Z8) z = (a.zeros[(size_t)n * a.zeros_stride + (gc >> 3)] >> ((gc & 7) * 4)) & 0xFu;
+        tab_c[idx] = (half_t)(float)(1024u + 16u * z);
+    }
+
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int lrow = lane >> 2, lchunk = lane & 3;
+    int wrow = n0 + lrow;
+    wrow = wrow < a.N ? wrow : a.N - 1;
+    const uint4_t *wsrc = a.qweight + (size_t)wrow * nchunks + lchunk;
+    const int w_wslot = lrow * 4 + (lchunk ^ ((lrow >> 2) & 3));
+    const int w_rslot = r16 * 4 + (kq ^ ((r16 >> 2) & 3));
+    // activation stage: thread t owns piece t of 512: k-block h = t / 256 of the stage, batch row (t % 256) / 16, piece t % 16
+    const int xh = tid >> 8, xm = (tid & 255) >> 4, xpc = tid & 15;
+    const half_t *xsrc = a.A + (size_t)(xm < a.M ? xm : a.M - 1) * a.lda + xh * 128 + xpc * 8;
+    const int x_wslot = xh * 256 + xpc * 16 + (xm ^ xpc);
+
+    float4_t acc = float4_t{0.f, 0.f, 0.f, 0.f};
+    unsigned mask_hi;
+    asm volatile("v_mov_b32 %0, 0x00F000F0" : "=v"(mask_hi));
+    const unsigned magic = 0x64006400u;
+    const half8_t ones = half8_t{(half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f};
+
+    // one stage: both k-blocks' weights through the wave's LDS slots, then four independent MFMA chains
+    auto stage = [&](const uint4_t *xi, int g) {
+        const uint4_t wq0 = lds_w[w_rslot], wq1 = lds_w[64 + w_rslot];
+        float4_t blk0 = float4_t{0.f, 0.f, 0.f, 0.f}, xs0 = blk0, blk1 = blk0, xs1 = blk0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int pc = kq * 4 + s;
+            const half8_t xb0 = __builtin_bit_cast(half8_t, xi[pc * 16 + (r16 ^ pc)]);
+            const half8_t xb1 = __builtin_bit_cast(half8_t, xi[256 + pc * 16 + (r16 ^ pc)]);
+            const unsigned w = wq0[s], v = wq1[s];
+            const half8_t a0 = __builtin_bit_cast(half8_t, uint4_t{((w << 4) & mask_hi) | magic, (w & mask_hi) | magic, ((w >> 4) & mask_hi) | magic, ((w >> 8) & mask_hi) | magic});
+            const half8_t a1 = __builtin_bit_cast(half8_t, uint4_t{((v << 4) & mask_hi) | magic, (v & mask_hi) | magic, ((v >> 4) & mask_hi) | magic, ((v >> 8) & mask_hi) | magic});
+            blk0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, xb0, blk0, 0, 0, 0);
+            blk1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, xb1, blk1, 0, 0, 0);
+            xs0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, xb0, xs0, 0, 0, 0);
+            xs1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, xb1, xs1, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const half4_t s40 = *reinterpret_cast<const half4_t *>(tab_s + g * 16 + 4 * kq);
+        const half4_t c40 = *reinterpret_cast<const half4_t *>(tab_c + g * 16 + 4 * kq);
+        const half4_t s41 = *reinterpret_cast<const half4_t *>(tab_s + g * 16 + 16 + 4 * kq);
+        const half4_t c41 = *reinterpret_cast<const half4_t *>(tab_c + g * 16 + 16 + 4 * kq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {  // k-block order, as the autonomous kernel
+            const float t0 = __builtin_fmaf(-(float)c40[i], xs0[i], blk0[i]);
+            acc[i] = __builtin_fmaf((float)s40[i], t0, acc[i]);
+            const float t1 = __builtin_fmaf(-(float)c41[i], xs1[i], blk1[i]);
+            acc[i] = __builtin_fmaf((float)s41[i], t1, acc[i]);
+        }
+    };
+
+    // stage s = k-blocks 2 s, 2 s + 1.  Weights are requested four stages ahead (register ring W), activations two stages
+    // ahead (ring X) and written to the LDS image one stage ahead; every address is clamped, nothing is predicated.
+    const int last = nst - 1;
+    auto xload = [&](int s) { return *reinterpret_cast<const uint4_t *>(xsrc + (s < last ? s : last) * 256); };
+    uint4_t W[4][2], X[2];
+    X[0] = xload(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int s = j < last ? j : last;
+        W[j][0] = wsrc[(2 * s) * 4];
+        W[j][1] = wsrc[(2 * s + 1) * 4];
+        if (j == 0) X[1] = xload(1);
+    }
+    lds_x[x_wslot] = pair_permute(X[0]);
+    __syncthreads();
+    for (int s4 = 0; s4 < nst; s4 += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int s = s4 + j;
+            // the ring registers are dead once their block sits in LDS, so the next request can land in the same registers
+            // (requesting first would leave old and new values live together and cost copies, i.e. vmcnt(0), at the back edge)
+            lds_w[w_wslot] = W[j][0];
+            lds_w[64 + w_wslot] = W[j][1];
+            __builtin_amdgcn_sched_barrier(0);
+            X[j & 1] = xload(s + 2);
+            const int sn = s + 4 < last ? s + 4 : last;
+            W[j][0] = wsrc[(2 * sn) * 4];
+            W[j][1] = wsrc[(2 * sn + 1) * 4];
+            __builtin_amdgcn_sched_barrier(0);
+            stage(lds_x + (j & 1) * 512, 2 * s);
+            lds_x[((j + 1) & 1) * 512 + x_wslot] = pair_permute(X[(j + 1) & 1]);
+            __syncthreads();
+        }
+    }
+
+    const int m = r16;
+    if (idle || m >= a.M) return;
+    const int nb = n0 + 4 * kq;
+    half_t outv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) outv[i] = (half_t)(acc[i] * 0.0625f);
+    half_t *crow = a.C + (size_t)m * a.ldc;
+    if (a.epilogue & TCE_W4_SILU_MUL_PAIRS) {
+        if (nb + 1 < a.N) crow[nb >> 1] = silu_mul_half(outv[0], outv[1]);
+        if (nb + 3 < a.N) crow[(nb >> 1) + 1] = silu_mul_half(outv[2], outv[3]);
+    } else if (a.epilogue & TCE_W4_ADD_TO_C) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (nb + i < a.N) crow[nb + i] = crow[nb + i] + outv[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (nb + i < a.N) crow[nb + i] = outv[i];
+    }
+}
+
 int g_skinny_ks = 0;  // forced K split (tuning), 0 = automatic
 
 }  // namespace
@@ -226,8 +376,32 @@ int launch_w4a16_skinny(const tce_w4a16_desc &d, hipStream_t stream, hipError_t 
     a.zeros_stride = d.zeros_stride ? d.zeros_stride : zw;
     const int nkb = d.K / 128;
     const int tiles = (d.N + 15) / 16;
+    const bool z8 = (d.flags & TCE_W4_ZERO_POINT_IS_8) != 0;
+    // enough tiles to fill the chip without a K split: workgroups of 8 tiles sharing the activation blocks (ks == 9 forces
+    // this form, any other forced ks the autonomous one)
+    if ((g_skinny_ks == 9 || (g_skinny_ks == 0 && tiles >= 1024)) && d.K % 256 == 0) {
+        const size_t lds = (size_t)2 * 2 * kXBuf + (size_t)kSharedWaves * (2 * kWBuf + (size_t)((nkb + 7) & ~7) * 64);
+        if (lds <= 160 * 1024) {
+            a.groups_per_wave = nkb;
+            auto kfn = z8 ? w4a16_skinny_shared_kernel<true> : w4a16_skinny_shared_kernel<false>;
+            if (lds > 64 * 1024) {
+                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) {
+                    if (hip_err) *hip_err = e;
+                    return TCE_ERR_HIP;
+                }
+            }
+            hipLaunchKernelGGL(kfn, dim3((tiles + kSharedWaves - 1) / kSharedWaves), dim3(64 * kSharedWaves), lds, stream, a);
+            const hipError_t e = hipGetLastError();
+            if (e != hipSuccess) {
+                if (hip_err) *hip_err = e;
+                return TCE_ERR_HIP;
+            }
+            return TCE_OK;
+        }
+    }
     // waves per tile: enough waves in the launch to cover the chip a few times, each with at least two k-blocks
-    int ks = g_skinny_ks;
+    int ks = g_skinny_ks == 9 ? 0 : g_skinny_ks;
     if (ks == 0) {
         ks = 1;
         while (ks < 8 && (long)tiles * ks < 3072 && nkb / (ks * 2) >= 2) ks *= 2;
@@ -238,7 +412,6 @@ int launch_w4a16_skinny(const tce_w4a16_desc &d, hipStream_t stream, hipError_t 
     size_t lds = (size_t)ks * (kWBuf + kXBuf + (size_t)a.groups_per_wave * 64);
     if (lds < (size_t)ks * 1024) lds = (size_t)ks * 1024;
     if (lds > 160 * 1024) return TCE_ERR_UNSUPPORTED_SHAPE;
-    const bool z8 = (d.flags & TCE_W4_ZERO_POINT_IS_8) != 0;
     auto kfn = z8 ? w4a16_skinny_kernel<true> : w4a16_skinny_kernel<false>;
     if (lds > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
