@@ -170,6 +170,34 @@ def test_gemm_matches_oracle(dev, oracle, M, N, K, G):
         capi.set_gemm_config()
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 256, 512), (33, 200, 1024), (130, 132, 256)])
+def test_gemm_add_to_c_every_variant(dev, oracle, M, N, K):
+    """TCE_W4_ADD_TO_C on the GEMM kernels: C = half(C + half(gemm)), bit for bit against the same variant without the flag, for row tails
+    (M % 16 != 0), column tails that end inside a 16-byte piece (N % 8 != 0) and an unaligned leading dimension (the scalar store path)."""
+    from tinychatengine_amd import capi
+    qw, sc, zp, a = _make(oracle, M, N, K, 128, seed=M + N + K, random_zeros=True)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    tq, ts, tz, ta = t(qw.view(np.int32)), t(sc.view(np.float16)), t(zp.view(np.int32)), t(a)
+    c0 = (torch.randn(M, N + 3, device=dev) * 0.5).to(torch.float16)
+    try:
+        for v in [None] + capi.gemm_variants():
+            capi.set_gemm_config(*(v or (0, 0)))
+            for ldc in (N, N + 3):
+                plain = torch.zeros(M, ldc, dtype=torch.float16, device=dev)
+                acc = c0[:, :ldc].clone().contiguous()
+                for out, flags in ((plain, capi.TCE_W4_FORCE_GEMM), (acc, capi.TCE_W4_FORCE_GEMM | capi.TCE_W4_ADD_TO_C)):
+                    d = capi.W4A16Desc(M=M, N=N, K=K, group_size=128, A=ta.data_ptr(), qweight=tq.data_ptr(), scales=ts.data_ptr(),
+                                       zeros=tz.data_ptr(), C=out.data_ptr(), ldc=ldc, flags=flags)
+                    capi.check(capi.w4a16_forward(d, torch.cuda.current_stream().cuda_stream))
+                torch.cuda.synchronize()
+                want = (c0[:, :N] + plain[:, :N])
+                assert torch.equal(acc[:, :N], want), f"variant {v} ldc {ldc}: add-to-C differs"
+                if ldc > N:
+                    assert torch.equal(acc[:, N:], c0[:, N:ldc]) and not plain[:, N:].any(), f"variant {v}: wrote past column N"
+    finally:
+        capi.set_gemm_config()
+
+
 def test_gemm_is_transpose_detecting(dev, oracle):
     """Asymmetric data: A = one-hot rows selects single k, so a swapped fragment index shows up as a wrong column."""
     from tinychatengine_amd import capi

@@ -98,6 +98,15 @@ int tce_w4a16_set_gemv_config(int rows, int wn, int wk, int depth) {
 }
 
 int tce_w4a16_set_debug_mode(int mode) {
+    if (mode >= 50 && mode <= 65) {  // DMA GEMM timing experiments (wrong results by design)
+        tce::set_gemm_dma_mode(mode - 50);
+        return TCE_OK;
+    }
+    if (mode == 41 || mode == 42 || mode == 44 || mode == 48) {  // GEMM: XCD grid rows
+        tce::set_gemm_xcd_rows(mode - 40);
+        tce::set_gemm_dma_xcd_rows(mode - 40);
+        return TCE_OK;
+    }
     if (mode >= 20 && mode <= 30) {  // small-batch kernel tuning: 20 automatic, 21/22/24/28 = waves per tile, 30 = shared-x form, 29 = off
         g_skinny_enabled = mode != 29;
         tce::set_skinny_config(mode == 29 ? 0 : (mode == 30 ? 9 : mode - 20));
@@ -163,7 +172,7 @@ int tce_w4a16_gemv_variant(int idx, int *rows, int *wn, int *wk, int *depth) {
 
 int tce_w4a16_gemm_variant(int idx, int *mt, int *nt) {
     static const int table[][2] = {
-#define TCE_V(M_, N_) {M_, N_}, {100 + M_, N_},
+#define TCE_V(M_, N_) {M_, N_}, {100 + M_, N_}, {200 + M_, N_},
         TCE_GEMM_VARIANTS(TCE_V)
 #undef TCE_V
     };
@@ -179,7 +188,7 @@ int tce_w4a16_set_gemm_config(int mt, int nt) {
         g_gemm_mt = g_gemm_nt = 0;
         return TCE_OK;
     }
-    if (!tce::gemm_variant_exists(mt, nt)) return fail(TCE_ERR_BAD_ARG, "GEMM variant %dx%d was not compiled", mt, nt);
+    if (!tce::gemm_variant_exists(mt >= 200 ? mt - 200 : mt, nt)) return fail(TCE_ERR_BAD_ARG, "GEMM variant %dx%d was not compiled", mt, nt);
     g_gemm_mt = mt;
     g_gemm_nt = nt;
     return TCE_OK;
@@ -278,7 +287,13 @@ int tce_w4a16_forward(const tce_w4a16_desc *d, void *stream) {
     }
     if (d->rmsnorm_gamma && d->M != 1) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "the fused RMSNorm prologue is a decode (M = 1) path; use tce_rmsnorm_half for M = %d", d->M);
     if (want_gemm && d->K % 128 == 0 && d->group_size == 128) {  // other group sizes: GEMV kernel, 4 rows per pass
-        const int rc = tce::launch_w4a16_gemm(*d, g_gemm_mt, g_gemm_nt, static_cast<hipStream_t>(stream), &he);
+        if (g_gemm_mt >= 200 || g_gemm_mt == 0) {  // the LDS-DMA kernel (w4a16_gemm_dma.hip): the default, or forced by tile ids 200 + m_tiles
+            const int rc = tce::launch_w4a16_gemm_dma(*d, g_gemm_mt ? g_gemm_mt - 200 : 0, g_gemm_mt ? g_gemm_nt : 0, static_cast<hipStream_t>(stream), &he);
+            if (rc == TCE_OK) return TCE_OK;
+            if (rc == TCE_ERR_HIP) return hip_fail(he, "w4a16 gemm (dma) launch");
+            if (rc != TCE_ERR_UNSUPPORTED_SHAPE) return fail(rc, "w4a16 gemm (dma): no kernel variant for this config");
+        }
+        const int rc = tce::launch_w4a16_gemm(*d, g_gemm_mt >= 200 ? g_gemm_mt - 200 : g_gemm_mt, g_gemm_nt, static_cast<hipStream_t>(stream), &he);
         if (rc == TCE_ERR_HIP) return hip_fail(he, "w4a16 gemm launch");
         if (rc != TCE_OK) return fail(rc, "w4a16 gemm: no kernel variant for this shape/config");
         return TCE_OK;

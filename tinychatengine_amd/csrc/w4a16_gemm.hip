@@ -34,7 +34,10 @@ struct GemmArgs {
     int M, N, K, lda, ldc, scales_stride, zeros_stride, log2g;
     int n_blocks, m_blocks;
     int add_to_c;  // TCE_W4_ADD_TO_C
+    int xm, m_per, n_per;  // XCD grid: xm x (8 / xm) XCDs over (row blocks x column blocks), contiguous slices of m_per x n_per blocks
 };
+
+int g_gemm_xm = 1;
 
 template <int MT, int NT>
 __global__ __launch_bounds__(256, (MT * NT >= 16 ? 1 : 2)) void w4a16_gemm_kernel(const GemmArgs g) {
@@ -47,9 +50,9 @@ __global__ __launch_bounds__(256, (MT * NT >= 16 ? 1 : 2)) void w4a16_gemm_kerne
     const int bid = blockIdx.x;
     const int xcd = bid & 7;
     const int slot = bid >> 3;
-    const int n_blk = xcd + 8 * (slot / g.m_blocks);
-    const int m_blk = slot % g.m_blocks;
-    if (n_blk >= g.n_blocks) return;
+    const int m_blk = (xcd % g.xm) * g.m_per + slot % g.m_per;
+    const int n_blk = (xcd / g.xm) * g.n_per + slot / g.m_per;
+    if (n_blk >= g.n_blocks || m_blk >= g.m_blocks) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -234,9 +237,9 @@ __global__ __launch_bounds__(256, (MT * NT >= 16 ? 1 : 2)) void w4a16_gemm_lds_k
     const int bid = blockIdx.x;
     const int xcd = bid & 7;
     const int slot = bid >> 3;
-    const int n_blk = xcd + 8 * (slot / g.m_blocks);
-    const int m_blk = slot % g.m_blocks;
-    if (n_blk >= g.n_blocks) return;
+    const int m_blk = (xcd % g.xm) * g.m_per + slot % g.m_per;
+    const int n_blk = (xcd / g.xm) * g.n_per + slot / g.m_per;
+    if (n_blk >= g.n_blocks || m_blk >= g.m_blocks) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -395,13 +398,19 @@ __global__ __launch_bounds__(256, (MT * NT >= 16 ? 1 : 2)) void w4a16_gemm_lds_k
         }
 }
 
+void set_xcd_grid(GemmArgs &g) {
+    g.xm = g_gemm_xm;
+    g.m_per = (g.m_blocks + g.xm - 1) / g.xm;
+    const int xn = 8 / g.xm;
+    g.n_per = (g.n_blocks + xn - 1) / xn;
+}
+
 template <int MT, int NT>
 hipError_t launch_gemm_lds(const GemmArgs &g0, hipStream_t stream) {
     GemmArgs g = g0;
     constexpr int BM = MT * 16, BN = 4 * NT * 16;
     g.n_blocks = (g.N + BN - 1) / BN;
     g.m_blocks = (g.M + BM - 1) / BM;
-    const int n8 = (g.n_blocks + 7) / 8 * 8;
     const int nkb = g.K / 128;
     size_t lds = (size_t)(2 * MT * 4 * 64 + 2 * BN * 4) * 16 + (size_t)BN * g.zeros_stride * 4 + (size_t)BN * nkb * 2;
     lds = (lds + 15) & ~(size_t)15;
@@ -411,7 +420,8 @@ hipError_t launch_gemm_lds(const GemmArgs &g0, hipStream_t stream) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kfn, dim3(n8 * g.m_blocks), dim3(256), lds, stream, g);
+    set_xcd_grid(g);
+    hipLaunchKernelGGL(kfn, dim3(8 * g.m_per * g.n_per), dim3(256), lds, stream, g);
     return hipGetLastError();
 }
 
@@ -421,12 +431,14 @@ hipError_t launch_gemm(const GemmArgs &g0, hipStream_t stream) {
     constexpr int BM = MT * 16, BN = 4 * NT * 16;
     g.n_blocks = (g.N + BN - 1) / BN;
     g.m_blocks = (g.M + BM - 1) / BM;
-    const int n8 = (g.n_blocks + 7) / 8 * 8;
-    hipLaunchKernelGGL((w4a16_gemm_kernel<MT, NT>), dim3(n8 * g.m_blocks), dim3(256), 0, stream, g);
+    set_xcd_grid(g);
+    hipLaunchKernelGGL((w4a16_gemm_kernel<MT, NT>), dim3(8 * g.m_per * g.n_per), dim3(256), 0, stream, g);
     return hipGetLastError();
 }
 
 }  // namespace
+
+void set_gemm_xcd_rows(int xm) { g_gemm_xm = (xm == 2 || xm == 4 || xm == 8) ? xm : 1; }
 
 bool gemm_variant_exists(int mt, int nt) {
 #define TCE_V(M_, N_) \

@@ -1,0 +1,383 @@
+// w4a16_gemm_dma.hip -- W4A16 dequant-GEMM for gfx950 whose tiles reach LDS by DMA (global_load_lds_dwordx4).
+//
+// Same math, layout and precision class as w4a16_gemm.hip (exact integers (q - z) contracted with fp16 activations in
+// fp32 on v_mfma_f32_16x16x32_f16, the fp16 group scale applied per 128-wide k-block in fp32).  What differs is how a
+// k-block's operands get to the MFMAs.  The bottom-up probe of the older loop (profiles/r1/gemm_bottom_up_probe.jsonl)
+// gives 1.7-2.2 PFLOP/s for MFMAs + activation-fragment LDS reads, 1.0-1.4 with unpack, scaling and weight loads added, and
+// 0.5-0.9 once the activation tile is staged global -> registers -> permute -> ds_write -> barrier: that staging chain,
+// serial with the MFMAs of every k-block, is what holds the older kernel at 0.5-0.65 PFLOP/s.  Here
+//   * the activation tile (BM x 128 halves) and the packed weight tile (BN x 64 bytes) of a k-block are fetched with
+//     LDS-DMA loads: no staging registers, no ds_write pass, no VALU.  A DMA writes lane-linear (wave-uniform base +
+//     lane * 16), so the bank swizzle sits on the SOURCE side: the lane that fills position p of row r fetches the row's
+//     piece p ^ (r % 16) (activations, 16 pieces of 16 bytes per row) or chunk p ^ (r / 4 % 4) (weights, 4 chunks per
+//     row), and the fragment reads apply the same involution -- every ds_read_b128 touches all 16 slots of a bank row,
+//     and every DMA instruction still reads whole contiguous rows (4 x 256 bytes / 16 x 64 bytes);
+//   * three stages in LDS: the DMAs of block kb+2 are issued before the MFMAs of block kb, the wait at the end of a step
+//     is a COUNTED vmcnt that leaves them in flight, and the barrier is a bare s_barrier (a __syncthreads would drain the
+//     queue: vmcnt(0));
+//   * since the activation image is now the plain row-major tile, the pair order the one-instruction nibble masks produce
+//     ((k, k+4) in one register) no longer fits; the weights are unpacked in natural order instead: byte r of a word
+//     holds k = 2r (low nibble) and 2r+1 (high nibble); v_perm copies it to bytes 0 and 2, one v_and_or leaves
+//     (1024 + q_lo, 1024 + 16 q_hi), one packed fma with per-half constants (1, 1/16) and (-(1024+z), -(64+z)) gives
+//     (q_lo - z, q_hi - z) exactly: 12 VALU per word against 9, paid for by the activation permute that is gone;
+//   * the group scales and packed zeros of the workgroup's rows are staged into LDS once, so the k loop contains no
+//     register-returning global load at all (hipcc answers one of those with vmcnt(0) while a DMA is in flight).
+#include "tce_common.hpp"
+#include "w4a16_kernels.hpp"
+
+namespace tce {
+
+namespace {
+
+struct DmaGemmArgs {
+    const half_t *A;
+    const uint4_t *qweight;
+    const half_t *scales;
+    const unsigned *zeros;
+    half_t *C;
+    int M, N, K, lda, ldc, scales_stride, zeros_stride;
+    int n_blocks, m_blocks;
+    int add_to_c;
+    int xm, m_per, n_per;
+    int mode;  // timing experiments (wrong results): 1 constant group constants, 2 fragment reads always from stage 0, 4 no DMA, 8 no stores
+};
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void global_void_t;
+
+__device__ __forceinline__ void dma16(const void *src, void *lds_dst_wave_uniform) {
+    __builtin_amdgcn_global_load_lds((global_void_t *)src, (lds_void_t *)lds_dst_wave_uniform, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256, (MT * NT >= 16 ? 1 : 2)) void w4a16_gemm_dma_kernel(const DmaGemmArgs g) {
+    constexpr int BM = MT * 16;
+    constexpr int BN = 4 * NT * 16;
+    constexpr int A_BYTES = BM * 256;  // one stage of activations: BM rows x 128 halves
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nkb = g.K >> 7;
+    const int zw = g.zeros_stride;
+    unsigned *lds_z = reinterpret_cast<unsigned *>(smem + 3 * A_BYTES);  // [BN][zw]
+    half_t *lds_s = reinterpret_cast<half_t *>(lds_z + BN * zw);       // [BN][nkb]
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const int slot = bid >> 3;
+    const int m_blk = (xcd % g.xm) * g.m_per + slot % g.m_per;
+    const int n_blk = (xcd / g.xm) * g.n_per + slot / g.m_per;
+    if (n_blk >= g.n_blocks || m_blk >= g.m_blocks) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n16 = lane & 15;
+    const int q = lane >> 4;
+    const int m_base = m_blk * BM;
+    const int nb0 = n_blk * BN;
+    const int nchunks = g.K >> 5;
+
+    // ---- scales and zeros of the workgroup's rows, all k-blocks, once: batches of 8 independent loads per thread (a
+    // load -> store loop pays one memory latency per trip, 16 trips for K = 4096) ----
+    for (int base = tid; base < BN * nkb; base += 256 * 8) {
+        half_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * 256;
+            const int row = idx / nkb, gi = idx - row * nkb;
+            int n = nb0 + row;
+            n = n < g.N ? n : g.N - 1;
+            v[u] = idx < BN * nkb ? g.scales[(size_t)n * g.scales_stride + gi] : (half_t)0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * 256;
+            if (idx < BN * nkb) lds_s[idx] = v[u];
+        }
+    }
+    for (int base = tid; base < BN * zw; base += 256 * 4) {
+        unsigned v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * 256;
+            const int row = idx / zw, wi = idx - row * zw;
+            int n = nb0 + row;
+            n = n < g.N ? n : g.N - 1;
+            v[u] = idx < BN * zw ? g.zeros[(size_t)n * g.zeros_stride + wi] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * 256;
+            if (idx < BN * zw) lds_z[idx] = v[u];
+        }
+    }
+    __syncthreads();  // before the first DMA is in flight: from here on only bare barriers and counted waits
+
+    // ---- DMA sources: instruction i of this wave fills the 1 KiB piece (i * 4 + wave) of a stage ----
+    const char *a_src[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int row = (i * 4 + wave) * 4 + (lane >> 4);  // 4 rows of 256 bytes per instruction
+        const int p = lane & 15;
+        int m = m_base + row;
+        m = m < g.M ? m : g.M - 1;  // rows past M repeat the last row; their outputs are not stored
+        const int x = p ^ (row & 15);                              // = s ^ h(q) of the piece that belongs at position p
+        const int pc = 4 * ((0x78 >> (2 * (x >> 2))) & 3) + (x & 3);  // h^-1: 0 -> 0, 12 -> 1, 4 -> 2, 8 -> 3
+        a_src[i] = reinterpret_cast<const char *>(g.A + (size_t)m * g.lda) + (pc << 4);
+    }
+    auto issue = [&](int stage, int kb) {
+        unsigned char *st = smem + stage * A_BYTES;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) dma16(a_src[i] + (size_t)kb * 256, st + (i * 4 + wave) * 1024);
+    };
+    // ---- the lane's weight rows: one 16-byte chunk (its 4 MFMA steps) per column tile and k-block, straight to registers ----
+    const uint4_t *w_src[NT];
+    int t_row[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        t_row[j] = (wave * NT + j) * 16 + n16;  // row within the workgroup (index into the LDS tables)
+        int n = nb0 + t_row[j];
+        n = n < g.N ? n : g.N - 1;
+        w_src[j] = g.qweight + (size_t)n * nchunks + q;
+    }
+    // ---- fragment read offsets (bytes within a stage): row i*16 + n16, piece 4q + s at position n16 ^ s ^ h(q) with
+    // h = (0, 12, 4, 8).  A ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...
+    // (MI355X_MICROARCH.md), which mix two q: the groups hit 16 distinct 16-byte columns iff h(0) ^ h(1) and h(2) ^ h(3)
+    // set both or neither of bits 2 and 3.  The plain (4q + s) ^ n16 (h = 4q) is 2-way conflicted on every read. ----
+    int a_off[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a_off[s] = n16 * 256 + ((n16 ^ s ^ ((0x84C0 >> (4 * q)) & 15)) << 4);
+
+    unsigned nib_mask;
+    asm volatile("v_mov_b32 %0, 0x00F0000F" : "=v"(nib_mask));
+    const half2_t mulc = as_half2(0x2C003C00u);  // (1, 1/16)
+    float4_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+    // group constants of a k-block: the zero-point pair (-(1024 + z), -(64 + z)) and the fp32 scale.  Read one step ahead
+    // so that the first unpack of a step does not start behind an LDS round trip plus a dependent VALU chain.
+    struct GroupConst {
+        half2_t zc[NT];
+        float sc[NT];
+    };
+    auto read_group = [&](GroupConst &o, int kb) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const unsigned z = (lds_z[t_row[j] * zw + (kb >> 3)] >> ((kb & 7) * 4)) & 0xFu;
+            o.zc[j] = as_half2((0xD400u | (z << 4)) << 16 | (0xE400u | z));
+            o.sc[j] = (float)lds_s[t_row[j] * nkb + kb];
+        }
+    };
+    auto compute = [&](const uint4_t (&bw)[NT], const GroupConst &gc, int stage) {
+        const unsigned char *st = smem + stage * A_BYTES;
+        const half2_t(&zc)[NT] = gc.zc;
+        const float(&sc)[NT] = gc.sc;
+        float4_t blk[MT][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) blk[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+        // Fragments are double-buffered by hand and the regions fenced: left alone, hipcc reads every fragment into the same
+        // four registers right in front of its MFMAs -- 16 exposed LDS round trips per k-block with one wave per SIMD.
+        // Region s holds the LDS reads and the unpack of step s+1 next to the MFMAs of step s.
+        half8_t af[2][MT], bf[2][NT];
+        auto read_a = [&](half8_t (&dst)[MT], int step) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) dst[i] = *reinterpret_cast<const half8_t *>(st + a_off[step] + i * 4096);
+        };
+        auto unpack = [&](half8_t (&dst)[NT], int step) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const unsigned w = bw[j][step];
+                half2_t d[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned rep = __builtin_amdgcn_perm(w, w, 0x01010101u * (unsigned)r);  // byte r in every byte
+                    d[r] = __builtin_elementwise_fma(as_half2((rep & nib_mask) | 0x64006400u), mulc, zc[j]);
+                }
+                dst[j] = half8_t{d[0].x, d[0].y, d[1].x, d[1].y, d[2].x, d[2].y, d[3].x, d[3].y};
+            }
+        };
+        read_a(af[0], 0);
+        unpack(bf[0], 0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (s < 3) {
+                read_a(af[(s + 1) & 1], s + 1);
+                unpack(bf[(s + 1) & 1], s + 1);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) blk[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s & 1][i], bf[s & 1][j], blk[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = __builtin_fmaf(sc[j], blk[i][j][r], acc[i][j][r]);
+    };
+
+    // Stage kb % 3 holds the activations of block kb.  In step kb the weight words of block kb+1 are requested first, then
+    // the DMAs of block kb+2; the counted wait at the end of the step leaves exactly those MT DMAs in flight (in-order
+    // counter: the weights of kb+1 and this wave's part of stage kb+1 have landed), the bare barrier extends that to the
+    // whole workgroup and also orders step kb's fragment reads before stage kb % 3 is refilled in step kb+1.
+    const int last = nkb - 1;
+    uint4_t wreg[NT], wnext[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) wreg[j] = w_src[j][0];
+    issue(0, 0);
+    issue(1, nkb > 1 ? 1 : 0);
+    wait_vmcnt<MT>();
+    __builtin_amdgcn_s_barrier();
+    int stage = 0;
+    GroupConst gcur, gnext;
+    read_group(gcur, 0);
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int n1 = kb + 1 < nkb ? kb + 1 : last;  // clamped, never predicated
+        const int n2 = kb + 2 < nkb ? kb + 2 : last;
+        // The weight loads are inline asm: left to hipcc they sink to the end of the step and are answered with vmcnt(0)
+        // (one exposed memory latency per k-block, and the DMAs of block kb+2 drained with them).
+#pragma unroll
+        for (int j = 0; j < NT; ++j) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wnext[j]) : "v"(w_src[j] + n1 * 4) : "memory");
+        if (!(g.mode & 4)) issue(stage >= 1 ? stage - 1 : 2, n2);
+        if (!(g.mode & 1)) read_group(gnext, n1);
+        compute(wreg, gcur, (g.mode & 2) ? 0 : stage);
+        if (!(g.mode & 1)) gcur = gnext;
+        wait_vmcnt<MT>();
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            asm volatile("" : "+v"(wnext[j]));  // the registers are valid from here on, not before
+            wreg[j] = wnext[j];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+    wait_vmcnt<0>();
+    __syncthreads();  // every wave's last (clamped, redundant) DMAs have landed: the stages may be overwritten
+    if (g.mode & 8) return;
+
+    // ---- epilogue: the tile goes through LDS (the stages are free after the last barrier) so that rows leave as 16-byte
+    // pieces.  Straight from the accumulator layout (lane = column n16, registers = 4 consecutive rows) every store is a
+    // 2-byte element of a 32-byte run: 4.4 us of a 37 us launch at M = 512, 4096 x 4096. ----
+    half_t *lds_c = reinterpret_cast<half_t *>(smem);  // [BM][BN]
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lds_c[(i * 16 + q * 4 + r) * BN + (wave * NT + j) * 16 + n16] = (half_t)acc[i][j][r];
+    __syncthreads();
+    const bool vec_ok = (g.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0;
+    constexpr int PIECES_PER_ROW = BN / 8;
+    for (int e = tid; e < BM * PIECES_PER_ROW; e += 256) {
+        const int row = e / PIECES_PER_ROW, pc = e - row * PIECES_PER_ROW;
+        const int m = m_base + row, n = nb0 + pc * 8;
+        if (m >= g.M || n >= g.N) continue;
+        const half8_t v = *reinterpret_cast<const half8_t *>(lds_c + row * BN + pc * 8);
+        half_t *c = g.C + (size_t)m * g.ldc + n;
+        if (vec_ok && n + 8 <= g.N) {
+            half8_t o = v;
+            if (g.add_to_c) {
+                const half8_t old = *reinterpret_cast<const half8_t *>(c);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) o[u] = (half_t)(old[u] + v[u]);
+            }
+            *reinterpret_cast<half8_t *>(c) = o;
+        } else {
+            for (int u = 0; u < 8 && n + u < g.N; ++u) c[u] = g.add_to_c ? (half_t)(c[u] + v[u]) : v[u];
+        }
+    }
+}
+
+int g_dma_xm = 8;
+int g_dma_mode = 0;
+
+template <int MT, int NT>
+hipError_t launch(const DmaGemmArgs &g0, hipStream_t stream) {
+    DmaGemmArgs g = g0;
+    constexpr int BM = MT * 16, BN = 4 * NT * 16;
+    g.n_blocks = (g.N + BN - 1) / BN;
+    g.m_blocks = (g.M + BM - 1) / BM;
+    g.xm = g_dma_xm;
+    g.mode = g_dma_mode;
+    g.m_per = (g.m_blocks + g.xm - 1) / g.xm;
+    const int xn = 8 / g.xm;
+    g.n_per = (g.n_blocks + xn - 1) / xn;
+    const int nkb = g.K / 128;
+    size_t lds = (size_t)3 * (BM * 256) + (size_t)BN * g.zeros_stride * 4 + (size_t)BN * nkb * 2;
+    lds = (lds + 15) & ~(size_t)15;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    auto kfn = w4a16_gemm_dma_kernel<MT, NT>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kfn, dim3(8 * g.m_per * g.n_per), dim3(256), lds, stream, g);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+void set_gemm_dma_mode(int mode) { g_dma_mode = mode; }
+void set_gemm_dma_xcd_rows(int xm) { g_dma_xm = (xm == 1 || xm == 2 || xm == 4) ? xm : 8; }
+
+int launch_w4a16_gemm_dma(const tce_w4a16_desc &d, int mt, int nt, hipStream_t stream, hipError_t *hip_err) {
+    if (d.K % 128 != 0 || d.group_size != 128) return TCE_ERR_UNSUPPORTED_SHAPE;
+    DmaGemmArgs g{};
+    const int zw = zeros_width(d.K, d.group_size);
+    g.A = static_cast<const half_t *>(d.A);
+    g.qweight = static_cast<const uint4_t *>(d.qweight);
+    g.scales = static_cast<const half_t *>(d.scales);
+    g.zeros = static_cast<const unsigned *>(d.zeros);
+    g.C = static_cast<half_t *>(d.C);
+    g.M = d.M;
+    g.N = d.N;
+    g.K = d.K;
+    g.lda = d.lda ? d.lda : d.K;
+    g.ldc = d.ldc ? d.ldc : d.N;
+    g.add_to_c = (d.flags & TCE_W4_ADD_TO_C) ? 1 : 0;
+    g.scales_stride = d.scales_stride ? d.scales_stride : zw * 8;
+    g.zeros_stride = d.zeros_stride ? d.zeros_stride : zw;
+    if ((g.lda * 2) % 16 != 0 || (reinterpret_cast<uintptr_t>(d.A) & 15)) return TCE_ERR_UNSUPPORTED_SHAPE;  // 16-byte DMA pieces
+    if (mt == 0) {
+        // tile choice as in w4a16_gemm.hip (measured on MI355X, profiles/r1/gemm_dma_sweep.jsonl): small M -> small row
+        // tiles; 64x128 tiles once they still give >= 2 workgroups per CU, else 64x64
+        if (d.M <= 32) { mt = 2; nt = 2; }
+        else if (d.M <= 64) { mt = 4; nt = 1; }
+        else {
+            const long blocks_42 = (long)((d.M + 63) / 64) * ((d.N + 127) / 128);
+            mt = 4;
+            nt = blocks_42 >= 512 ? 2 : 1;
+        }
+    }
+    hipError_t e = hipSuccess;
+    bool found = false;
+#define TCE_V(M_, N_)                      \
+    if (!found && mt == M_ && nt == N_) { \
+        found = true;                     \
+        e = launch<M_, N_>(g, stream);    \
+    }
+    TCE_GEMM_VARIANTS(TCE_V)
+#undef TCE_V
+    if (!found) return TCE_ERR_BAD_ARG;
+    if (e == hipErrorInvalidValue) return TCE_ERR_UNSUPPORTED_SHAPE;  // tables do not fit LDS: the caller uses the older kernel
+    if (e != hipSuccess) {
+        if (hip_err) *hip_err = e;
+        return TCE_ERR_HIP;
+    }
+    return TCE_OK;
+}
+
+}  // namespace tce

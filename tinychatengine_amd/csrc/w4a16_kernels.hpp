@@ -84,6 +84,12 @@ int launch_w4a16_gemv(const tce_w4a16_desc *descs, int count, int forced_rows, i
     X(4, 4)                  \
     X(2, 4)
 bool gemm_variant_exists(int m_tiles, int n_tiles);
+void set_gemm_xcd_rows(int xm);
+void set_gemm_dma_xcd_rows(int xm);
+void set_gemm_dma_mode(int mode);  // timing experiments, see w4a16_gemm_dma.hip
+// w4a16_gemm_dma.hip: same contract as launch_w4a16_gemm with an explicit tile; TCE_ERR_UNSUPPORTED_SHAPE when the shape
+// (alignment, table size) does not fit, so the caller can fall back
+int launch_w4a16_gemm_dma(const tce_w4a16_desc &d, int m_tiles, int n_tiles, hipStream_t stream, hipError_t *hip_err);  // tuning: XCD grid of xm x (8 / xm) over (row blocks x column blocks)
 int launch_w4a16_gemm(const tce_w4a16_desc &d, int forced_mt, int forced_nt, hipStream_t stream, hipError_t *hip_err);
 
 int check_zero_point_8(const void *zeros, long long n_words, hipError_t *hip_err);
