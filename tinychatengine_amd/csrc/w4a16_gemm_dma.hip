@@ -39,7 +39,6 @@ struct DmaGemmArgs {
     int n_blocks, m_blocks;
     int add_to_c;
     int xm, m_per, n_per;
-    int mode;  // timing experiments (wrong results): 1 constant group constants, 2 fragment reads always from stage 0, 4 no DMA, 8 no stores
 };
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -54,15 +53,19 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int MT, int NT>
-__global__ __launch_bounds__(256, (MT * NT >= 16 ? 1 : 2)) void w4a16_gemm_dma_kernel(const DmaGemmArgs g) {
+// KS = 2: eight waves on the same tile, the k-blocks alternating between the two wave quartets (each with its own three
+// stages); the quartets' fp32 accumulators meet in LDS at the end (quartet 0 + quartet 1, a fixed order).  One wave per SIMD
+// executes a k-block as the SUM of its VALU, MFMA and LDS time; two interleave them.
+template <int MT, int NT, int KS>
+__global__ __launch_bounds__(256 * KS, (KS == 2 || MT * NT >= 16 ? 1 : 2)) void w4a16_gemm_dma_kernel(const DmaGemmArgs g) {
+    constexpr int NTHREADS = 256 * KS;
     constexpr int BM = MT * 16;
     constexpr int BN = 4 * NT * 16;
     constexpr int A_BYTES = BM * 256;  // one stage of activations: BM rows x 128 halves
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nkb = g.K >> 7;
     const int zw = g.zeros_stride;
-    unsigned *lds_z = reinterpret_cast<unsigned *>(smem + 3 * A_BYTES);  // [BN][zw]
+    unsigned *lds_z = reinterpret_cast<unsigned *>(smem + KS * 3 * A_BYTES);  // [BN][zw]
     half_t *lds_s = reinterpret_cast<half_t *>(lds_z + BN * zw);       // [BN][nkb]
 
     const int bid = blockIdx.x;
@@ -74,7 +77,10 @@ __global__ __launch_bounds__(256, (MT * NT >= 16 ? 1 : 2)) void w4a16_gemm_dma_k
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave8 & 3;                    // role within the quartet: its 16 * NT columns, its quarter of the DMAs
+    const int grp = KS == 2 ? wave8 >> 2 : 0;      // quartet: k-blocks grp, grp + KS, ...
+    unsigned char *const stages = smem + grp * 3 * A_BYTES;
     const int n16 = lane & 15;
     const int q = lane >> 4;
     const int m_base = m_blk * BM;
@@ -83,11 +89,11 @@ __global__ __launch_bounds__(256, (MT * NT >= 16 ? 1 : 2)) void w4a16_gemm_dma_k
 
     // ---- scales and zeros of the workgroup's rows, all k-blocks, once: batches of 8 independent loads per thread (a
     // load -> store loop pays one memory latency per trip, 16 trips for K = 4096) ----
-    for (int base = tid; base < BN * nkb; base += 256 * 8) {
+    for (int base = tid; base < BN * nkb; base += NTHREADS * 8) {
         half_t v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int idx = base + u * 256;
+            const int idx = base + u * NTHREADS;
             const int row = idx / nkb, gi = idx - row * nkb;
             int n = nb0 + row;
             n = n < g.N ? n : g.N - 1;
@@ -95,15 +101,15 @@ __global__ __launch_bounds__(256, (MT * NT >= 16 ? 1 : 2)) void w4a16_gemm_dma_k
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int idx = base + u * 256;
+            const int idx = base + u * NTHREADS;
             if (idx < BN * nkb) lds_s[idx] = v[u];
         }
     }
-    for (int base = tid; base < BN * zw; base += 256 * 4) {
+    for (int base = tid; base < BN * zw; base += NTHREADS * 4) {
         unsigned v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int idx = base + u * 256;
+            const int idx = base + u * NTHREADS;
             const int row = idx / zw, wi = idx - row * zw;
             int n = nb0 + row;
             n = n < g.N ? n : g.N - 1;
@@ -111,7 +117,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 16 ? 1 : 2)) void w4a16_gemm_dma_k
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int idx = base + u * 256;
+            const int idx = base + u * NTHREADS;
             if (idx < BN * zw) lds_z[idx] = v[u];
         }
     }
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 16 ? 1 : 2)) void w4a16_gemm_dma_k
         a_src[i] = reinterpret_cast<const char *>(g.A + (size_t)m * g.lda) + (pc << 4);
     }
     auto issue = [&](int stage, int kb) {
-        unsigned char *st = smem + stage * A_BYTES;
+        unsigned char *st = stages + stage * A_BYTES;
 #pragma unroll
         for (int i = 0; i < MT; ++i) dma16(a_src[i] + (size_t)kb * 256, st + (i * 4 + wave) * 1024);
     };
@@ -167,16 +173,17 @@ __global__ __launch_bounds__(256, (MT * NT >= 16 ? 1 : 2)) void w4a16_gemm_dma_k
         half2_t zc[NT];
         float sc[NT];
     };
-    auto read_group = [&](GroupConst &o, int kb) {
+    auto read_group = [&](GroupConst &o, int kb_unclamped) {
+        const int kb = kb_unclamped < nkb ? kb_unclamped : nkb - 1;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const unsigned z = (lds_z[t_row[j] * zw + (kb >> 3)] >> ((kb & 7) * 4)) & 0xFu;
             o.zc[j] = as_half2((0xD400u | (z << 4)) << 16 | (0xE400u | z));
-            o.sc[j] = (float)lds_s[t_row[j] * nkb + kb];
+            o.sc[j] = kb_unclamped < nkb ? (float)lds_s[t_row[j] * nkb + kb] : 0.f;  // a step past K (odd block count, KS = 2) adds 0
         }
     };
     auto compute = [&](const uint4_t (&bw)[NT], const GroupConst &gc, int stage) {
-        const unsigned char *st = smem + stage * A_BYTES;
+        const unsigned char *st = stages + stage * A_BYTES;
         const half2_t(&zc)[NT] = gc.zc;
         const float(&sc)[NT] = gc.sc;
         float4_t blk[MT][NT];
@@ -233,27 +240,28 @@ __global__ __launch_bounds__(256, (MT * NT >= 16 ? 1 : 2)) void w4a16_gemm_dma_k
     // counter: the weights of kb+1 and this wave's part of stage kb+1 have landed), the bare barrier extends that to the
     // whole workgroup and also orders step kb's fragment reads before stage kb % 3 is refilled in step kb+1.
     const int last = nkb - 1;
+    auto clampk = [&](int kb) { return kb < nkb ? kb : last; };  // clamped, never predicated (a step past K is scaled by 0)
     uint4_t wreg[NT], wnext[NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) wreg[j] = w_src[j][0];
-    issue(0, 0);
-    issue(1, nkb > 1 ? 1 : 0);
+    for (int j = 0; j < NT; ++j) wreg[j] = w_src[j][clampk(grp) * 4];
+    issue(0, clampk(grp));
+    issue(1, clampk(grp + KS));
     wait_vmcnt<MT>();
     __builtin_amdgcn_s_barrier();
     int stage = 0;
     GroupConst gcur, gnext;
-    read_group(gcur, 0);
-    for (int kb = 0; kb < nkb; ++kb) {
-        const int n1 = kb + 1 < nkb ? kb + 1 : last;  // clamped, never predicated
-        const int n2 = kb + 2 < nkb ? kb + 2 : last;
+    read_group(gcur, grp);
+    for (int kb = grp; kb < nkb + grp; kb += KS) {  // both quartets take the same number of steps (and barriers)
+        const int n1 = clampk(kb + KS);
+        const int n2 = clampk(kb + 2 * KS);
         // The weight loads are inline asm: left to hipcc they sink to the end of the step and are answered with vmcnt(0)
         // (one exposed memory latency per k-block, and the DMAs of block kb+2 drained with them).
 #pragma unroll
         for (int j = 0; j < NT; ++j) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wnext[j]) : "v"(w_src[j] + n1 * 4) : "memory");
-        if (!(g.mode & 4)) issue(stage >= 1 ? stage - 1 : 2, n2);
-        if (!(g.mode & 1)) read_group(gnext, n1);
-        compute(wreg, gcur, (g.mode & 2) ? 0 : stage);
-        if (!(g.mode & 1)) gcur = gnext;
+        issue(stage >= 1 ? stage - 1 : 2, n2);
+        read_group(gnext, kb + KS);
+        compute(wreg, gcur, stage);
+        gcur = gnext;
         wait_vmcnt<MT>();
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -266,22 +274,46 @@ __global__ __launch_bounds__(256, (MT * NT >= 16 ? 1 : 2)) void w4a16_gemm_dma_k
     }
     wait_vmcnt<0>();
     __syncthreads();  // every wave's last (clamped, redundant) DMAs have landed: the stages may be overwritten
-    if (g.mode & 8) return;
+
+    if constexpr (KS == 2) {  // quartet 1 hands its accumulators over: [register][thread of the quartet] floats
+        float *red = reinterpret_cast<float *>(smem);
+        const int t4 = tid & 255;
+        if (grp == 1) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[((i * NT + j) * 4 + r) * 256 + t4] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] += red[((i * NT + j) * 4 + r) * 256 + t4];
+        }
+        __syncthreads();
+    }
 
     // ---- epilogue: the tile goes through LDS (the stages are free after the last barrier) so that rows leave as 16-byte
     // pieces.  Straight from the accumulator layout (lane = column n16, registers = 4 consecutive rows) every store is a
-    // 2-byte element of a 32-byte run: 4.4 us of a 37 us launch at M = 512, 4096 x 4096. ----
+    // 2-byte element of a 32-byte run. ----
     half_t *lds_c = reinterpret_cast<half_t *>(smem);  // [BM][BN]
+    if (grp == 0) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+            for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) lds_c[(i * 16 + q * 4 + r) * BN + (wave * NT + j) * 16 + n16] = (half_t)acc[i][j][r];
+                for (int r = 0; r < 4; ++r) lds_c[(i * 16 + q * 4 + r) * BN + (wave * NT + j) * 16 + n16] = (half_t)acc[i][j][r];
+    }
     __syncthreads();
     const bool vec_ok = (g.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0;
     constexpr int PIECES_PER_ROW = BN / 8;
-    for (int e = tid; e < BM * PIECES_PER_ROW; e += 256) {
+    for (int e = tid; e < BM * PIECES_PER_ROW; e += NTHREADS) {
         const int row = e / PIECES_PER_ROW, pc = e - row * PIECES_PER_ROW;
         const int m = m_base + row, n = nb0 + pc * 8;
         if (m >= g.M || n >= g.N) continue;
@@ -302,7 +334,25 @@ __global__ __launch_bounds__(256, (MT * NT >= 16 ? 1 : 2)) void w4a16_gemm_dma_k
 }
 
 int g_dma_xm = 8;
-int g_dma_mode = 0;
+
+int g_dma_ks = 0;  // 0: choose, 1 / 2: forced
+
+template <int MT, int NT, int KS>
+hipError_t launch_ks(DmaGemmArgs &g, hipStream_t stream) {
+    constexpr int BM = MT * 16, BN = 4 * NT * 16;
+    const int nkb = g.K / 128;
+    size_t lds = (size_t)KS * 3 * (BM * 256) + (size_t)BN * g.zeros_stride * 4 + (size_t)BN * nkb * 2;
+    if (KS == 2 && lds < (size_t)MT * NT * 4 * 256 * 4 + (size_t)BM * BN * 2) lds = (size_t)MT * NT * 4 * 256 * 4 + (size_t)BM * BN * 2;
+    lds = (lds + 15) & ~(size_t)15;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    auto kfn = w4a16_gemm_dma_kernel<MT, NT, KS>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kfn, dim3(8 * g.m_per * g.n_per), dim3(256 * KS), lds, stream, g);
+    return hipGetLastError();
+}
 
 template <int MT, int NT>
 hipError_t launch(const DmaGemmArgs &g0, hipStream_t stream) {
@@ -311,26 +361,23 @@ hipError_t launch(const DmaGemmArgs &g0, hipStream_t stream) {
     g.n_blocks = (g.N + BN - 1) / BN;
     g.m_blocks = (g.M + BM - 1) / BM;
     g.xm = g_dma_xm;
-    g.mode = g_dma_mode;
     g.m_per = (g.m_blocks + g.xm - 1) / g.xm;
     const int xn = 8 / g.xm;
     g.n_per = (g.n_blocks + xn - 1) / xn;
-    const int nkb = g.K / 128;
-    size_t lds = (size_t)3 * (BM * 256) + (size_t)BN * g.zeros_stride * 4 + (size_t)BN * nkb * 2;
-    lds = (lds + 15) & ~(size_t)15;
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kfn = w4a16_gemm_dma_kernel<MT, NT>;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
+    if constexpr (MT * NT <= 8) {  // the two-quartet form needs <= 256 registers per wave
+        // one workgroup per CU or fewer: a second quartet is the only way to a second wave per SIMD
+        const bool ks2 = g_dma_ks == 2 || (g_dma_ks == 0 && (long)g.m_blocks * g.n_blocks <= 320);
+        if (ks2) {
+            const hipError_t e = launch_ks<MT, NT, 2>(g, stream);
+            if (e != hipErrorInvalidValue) return e;
+        }
     }
-    hipLaunchKernelGGL(kfn, dim3(8 * g.m_per * g.n_per), dim3(256), lds, stream, g);
-    return hipGetLastError();
+    return launch_ks<MT, NT, 1>(g, stream);
 }
 
 }  // namespace
 
-void set_gemm_dma_mode(int mode) { g_dma_mode = mode; }
+void set_gemm_dma_mode(int mode) { g_dma_ks = mode & 3; }
 void set_gemm_dma_xcd_rows(int xm) { g_dma_xm = (xm == 1 || xm == 2 || xm == 4) ? xm : 8; }
 
 int launch_w4a16_gemm_dma(const tce_w4a16_desc &d, int mt, int nt, hipStream_t stream, hipError_t *hip_err) {
@@ -352,15 +399,14 @@ int launch_w4a16_gemm_dma(const tce_w4a16_desc &d, int mt, int nt, hipStream_t s
     g.zeros_stride = d.zeros_stride ? d.zeros_stride : zw;
     if ((g.lda * 2) % 16 != 0 || (reinterpret_cast<uintptr_t>(d.A) & 15)) return TCE_ERR_UNSUPPORTED_SHAPE;  // 16-byte DMA pieces
     if (mt == 0) {
-        // tile choice as in w4a16_gemm.hip (measured on MI355X, profiles/r1/gemm_dma_sweep.jsonl): small M -> small row
-        // tiles; 64x128 tiles once they still give >= 2 workgroups per CU, else 64x64
-        if (d.M <= 32) { mt = 2; nt = 2; }
-        else if (d.M <= 64) { mt = 4; nt = 1; }
-        else {
-            const long blocks_42 = (long)((d.M + 63) / 64) * ((d.N + 127) / 128);
-            mt = 4;
-            nt = blocks_42 >= 512 ? 2 : 1;
-        }
+        // tile choice (measured on MI355X, profiles/r1/gemm_dma_sweep.jsonl, gemm_dma_ksplit.jsonl): 64x128 tiles while they
+        // give >= 2 workgroups per CU; 64x64 in between; at about one workgroup per CU or fewer the two-quartet form of the
+        // 64x128 tile (launch<> picks it from the workgroup count), and 32-row tiles when even that leaves CUs idle
+        const long blocks_42 = (long)((d.M + 63) / 64) * ((d.N + 127) / 128);
+        if (blocks_42 >= 512) { mt = 4; nt = 2; }
+        else if (blocks_42 > 320) { mt = 4; nt = 1; }
+        else if (blocks_42 >= 192) { mt = 4; nt = 2; }
+        else { mt = 2; nt = 2; }
     }
     hipError_t e = hipSuccess;
     bool found = false;
