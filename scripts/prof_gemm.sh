@@ -14,7 +14,7 @@ L = capi.lib()
 M, N, K = 512, 4096, 4096
 sets = ring(N, K, 128, min_bytes=1e8)
 x = torch.randn(M, K, device=dev).to(torch.float16); out = torch.empty(M, N, dtype=torch.float16, device=dev)
-for v in ((104, 1), (4, 1), (104, 2), (4, 2)):
+for v in ((4, 1), (4, 2), (204, 1), (204, 2), (0, 0)):  # older kernel tiles, LDS-DMA tiles (one quartet by default at these ids? no: the launcher picks the form from the tile count), the dispatcher
     capi.set_gemm_config(*v)
     for i in range(12):
         s = sets[i % len(sets)]
