@@ -409,13 +409,15 @@ def test_randomized_shapes_match_oracle(dev, oracle):
         _check(_run(dev, qw, sc, zp, a, G), ref32, f"random case {case}: {M}x{N}x{K} g{G}")
 
 
-SKINNY_SHAPES = [(2, 4096, 4096), (16, 4096, 4096), (3, 100, 1408), (8, 264, 11008), (16, 17, 128), (5, 40, 256), (9, 2050, 2048), (13, 31, 14336), (7, 16400, 512)]
+SKINNY_SHAPES = [(2, 4096, 4096), (16, 4096, 4096), (3, 100, 1408), (8, 264, 11008), (16, 17, 128), (5, 40, 256), (9, 2050, 2048), (13, 31, 14336), (7, 16400, 512),
+                 # M > 16: 16-row slices of the batch on gridDim.y (taken while N is small, see skinny_supports)
+                 (17, 40, 2048), (33, 200, 1024), (100, 264, 1408), (128, 512, 256), (40, 16400, 256)]
 
 
 @pytest.mark.parametrize("M,N,K", SKINNY_SHAPES)
 def test_small_batch_kernel_matches_oracle(dev, oracle, M, N, K):
-    """w4a16_skinny.hip (3 <= M <= 16; M = 2 stays on the GEMV kernel): automatic and every forced K split, plain and random zero points, with the
-    zero-point-8 promise, N tails (N % 16 != 0), a single k-block, rows past M."""
+    """w4a16_skinny.hip (3 <= M <= 128; M = 2 stays on the GEMV kernel): automatic and every forced K split, plain and random zero points, with the
+    zero-point-8 promise, N tails (N % 16 != 0), a single k-block, rows past M, batch slices (M > 16, partial last slice)."""
     from tinychatengine_amd import capi
     L = capi.lib()
     try:

@@ -98,11 +98,15 @@ int tce_w4a16_set_gemv_config(int rows, int wn, int wk, int depth) {
 }
 
 int tce_w4a16_set_debug_mode(int mode) {
+    if (mode >= 1000 && mode <= 1256) {  // small-batch kernel: largest M it takes
+        tce::set_skinny_max_m(mode - 1000);
+        return TCE_OK;
+    }
     if (mode >= 50 && mode <= 65) {  // DMA GEMM timing experiments (wrong results by design)
         tce::set_gemm_dma_mode(mode - 50);
         return TCE_OK;
     }
-    if (mode == 41 || mode == 42 || mode == 44 || mode == 48) {  // GEMM: XCD grid rows
+    if (mode == 40 || mode == 41 || mode == 42 || mode == 44 || mode == 48) {  // GEMM: XCD grid rows (40: automatic for the LDS-DMA kernel)
         tce::set_gemm_xcd_rows(mode - 40);
         tce::set_gemm_dma_xcd_rows(mode - 40);
         return TCE_OK;

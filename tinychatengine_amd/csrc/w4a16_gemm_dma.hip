@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256 * KS, (KS == 2 || MT * NT >= 16 ? 1 : 2)) void 
     }
 }
 
-int g_dma_xm = 8;
+int g_dma_xm = 0;  // 0: choose per launch
 
 int g_dma_ks = 0;  // 0: choose, 1 / 2: forced
 
@@ -355,19 +355,32 @@ hipError_t launch_ks(DmaGemmArgs &g, hipStream_t stream) {
 }
 
 template <int MT, int NT>
-hipError_t launch(const DmaGemmArgs &g0, hipStream_t stream) {
+hipError_t launch(const DmaGemmArgs &g0, int ks, hipStream_t stream) {
     DmaGemmArgs g = g0;
     constexpr int BM = MT * 16, BN = 4 * NT * 16;
     g.n_blocks = (g.N + BN - 1) / BN;
     g.m_blocks = (g.M + BM - 1) / BM;
-    g.xm = g_dma_xm;
+    // XCD grid: xm rows of XCDs over the row blocks (an XCD's L2 then holds only its slice of the activations), 8 / xm
+    // columns over the column blocks -- the split that wastes the fewest workgroup slots (3 row blocks on 8 XCD rows would
+    // leave 5 XCDs idle), larger xm on ties; g_dma_xm != 0 forces one (tuning).
+    int best_xm = 1;
+    long best_grid = -1;
+    for (int xm = 8; xm >= 1; xm >>= 1) {
+        const long grid = 8L * ((g.m_blocks + xm - 1) / xm) * ((g.n_blocks + 8 / xm - 1) / (8 / xm));
+        if (best_grid < 0 || grid < best_grid) {
+            best_grid = grid;
+            best_xm = xm;
+        }
+    }
+    g.xm = g_dma_xm ? g_dma_xm : best_xm;
     g.m_per = (g.m_blocks + g.xm - 1) / g.xm;
     const int xn = 8 / g.xm;
     g.n_per = (g.n_blocks + xn - 1) / xn;
     if constexpr (MT * NT <= 8) {  // the two-quartet form needs <= 256 registers per wave
-        // one workgroup per CU or fewer: a second quartet is the only way to a second wave per SIMD
-        const bool ks2 = g_dma_ks == 2 || (g_dma_ks == 0 && (long)g.m_blocks * g.n_blocks <= 320);
-        if (ks2) {
+        if (g_dma_ks) ks = g_dma_ks;
+        // forced tile without a form: one workgroup per CU or fewer -> a second quartet is the only way to a second wave per SIMD
+        if (ks == 0) ks = (long)g.m_blocks * g.n_blocks <= 320 ? 2 : 1;
+        if (ks == 2) {
             const hipError_t e = launch_ks<MT, NT, 2>(g, stream);
             if (e != hipErrorInvalidValue) return e;
         }
@@ -375,10 +388,33 @@ hipError_t launch(const DmaGemmArgs &g0, hipStream_t stream) {
     return launch_ks<MT, NT, 1>(g, stream);
 }
 
+// Tile and form for a shape.  A workgroup's time is its k-loop, nearly independent of how many others run (latency-bound
+// steps), so a launch costs about rounds x (K / 128) x c with rounds = workgroups / resident slots rounded UP while it is
+// small: 688 workgroups on 512 slots cost two rounds, 344 on 512 one.  c (us per k-block, measured, profiles/r1/
+// gemm_dma_sweep.jsonl / gemm_dma_ksplit.jsonl): 64x128 1.2, 64x64 1.0, 64x128 two quartets 0.92, 32x128 two quartets 0.7,
+// 128x128 1.55; slots per CU: 2, 2, 1, 1, 1.
+void choose_tile(int M, int N, int *mt, int *nt, int *ks) {
+    static const struct { int mt, nt, ks, slots_per_cu; float c; } cand[] = {
+        {4, 2, 1, 2, 1.2f}, {4, 1, 1, 2, 1.0f}, {4, 2, 2, 1, 0.92f}, {2, 2, 2, 1, 0.70f}, {8, 2, 1, 1, 1.55f}};
+    float best = 0.f;
+    for (const auto &c : cand) {
+        const long wgs = (long)((M + c.mt * 16 - 1) / (c.mt * 16)) * ((N + c.nt * 64 - 1) / (c.nt * 64));
+        const float r = (float)wgs / (256.f * c.slots_per_cu);
+        const float rounds = r <= 3.f ? (float)(int)(r + 0.999f) : r + 0.5f;
+        const float cost = rounds * c.c;
+        if (best == 0.f || cost < best) {
+            best = cost;
+            *mt = c.mt;
+            *nt = c.nt;
+            *ks = c.ks;
+        }
+    }
+}
+
 }  // namespace
 
 void set_gemm_dma_mode(int mode) { g_dma_ks = mode & 3; }
-void set_gemm_dma_xcd_rows(int xm) { g_dma_xm = (xm == 1 || xm == 2 || xm == 4) ? xm : 8; }
+void set_gemm_dma_xcd_rows(int xm) { g_dma_xm = (xm == 1 || xm == 2 || xm == 4 || xm == 8) ? xm : 0; }
 
 int launch_w4a16_gemm_dma(const tce_w4a16_desc &d, int mt, int nt, hipStream_t stream, hipError_t *hip_err) {
     if (d.K % 128 != 0 || d.group_size != 128) return TCE_ERR_UNSUPPORTED_SHAPE;
@@ -398,22 +434,14 @@ int launch_w4a16_gemm_dma(const tce_w4a16_desc &d, int mt, int nt, hipStream_t s
     g.scales_stride = d.scales_stride ? d.scales_stride : zw * 8;
     g.zeros_stride = d.zeros_stride ? d.zeros_stride : zw;
     if ((g.lda * 2) % 16 != 0 || (reinterpret_cast<uintptr_t>(d.A) & 15)) return TCE_ERR_UNSUPPORTED_SHAPE;  // 16-byte DMA pieces
-    if (mt == 0) {
-        // tile choice (measured on MI355X, profiles/r1/gemm_dma_sweep.jsonl, gemm_dma_ksplit.jsonl): 64x128 tiles while they
-        // give >= 2 workgroups per CU; 64x64 in between; at about one workgroup per CU or fewer the two-quartet form of the
-        // 64x128 tile (launch<> picks it from the workgroup count), and 32-row tiles when even that leaves CUs idle
-        const long blocks_42 = (long)((d.M + 63) / 64) * ((d.N + 127) / 128);
-        if (blocks_42 >= 512) { mt = 4; nt = 2; }
-        else if (blocks_42 > 320) { mt = 4; nt = 1; }
-        else if (blocks_42 >= 192) { mt = 4; nt = 2; }
-        else { mt = 2; nt = 2; }
-    }
+    int ks = 0;
+    if (mt == 0) choose_tile(d.M, d.N, &mt, &nt, &ks);
     hipError_t e = hipSuccess;
     bool found = false;
 #define TCE_V(M_, N_)                      \
     if (!found && mt == M_ && nt == N_) { \
         found = true;                     \
-        e = launch<M_, N_>(g, stream);    \
+        e = launch<M_, N_>(g, ks, stream); \
     }
     TCE_GEMM_VARIANTS(TCE_V)
 #undef TCE_V

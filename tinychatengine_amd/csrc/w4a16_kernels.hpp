@@ -102,7 +102,8 @@ int launch_awq_repack(int N, int K, int G, const void *qweight, const void *scal
 
 // small batches, 2 <= M <= 16 (w4a16_skinny.hip)
 bool skinny_supports(const tce_w4a16_desc &d);
-void set_skinny_config(int ks);  // tuning: waves per 16-row tile, 0 = automatic
+void set_skinny_config(int ks);
+void set_skinny_max_m(int m);  // largest M the small-batch kernel takes (16-row slices of the batch on gridDim.y)  // tuning: waves per 16-row tile, 0 = automatic
 int launch_w4a16_skinny(const tce_w4a16_desc &d, hipStream_t stream, hipError_t *hip_err);
 
 // element-wise glue of the decoder layer (glue.hip)

@@ -1,4 +1,5 @@
-// w4a16_skinny.hip -- W4A16 for small batches, 3 <= M <= 16 (batched / speculative decoding), gfx950.
+// w4a16_skinny.hip -- W4A16 for small batches, 3 <= M <= 16 (batched / speculative decoding) and, in 16-row slices of the
+// batch on gridDim.y, up to M = 128 while N is small (short prompts), gfx950.
 //
 // Between the decode GEMV (M = 1: dot products on the 4x4x4 MFMA diagonal, one activation vector in LDS) and the prefill
 // GEMM (M >= 17: 64-row activation tiles) the weights must still be streamed ONCE at HBM speed, but every weight now
@@ -50,6 +51,12 @@ __global__ __launch_bounds__(512) void w4a16_skinny_kernel(const SkinnyArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int KS = blockDim.x >> 6;
     const int n0 = blockIdx.x * 16;
+    // batch rows 16 * blockIdx.y .. + 15 (M > 16: the weight tile is streamed once per 16 rows, the repeats out of L2 / MALL)
+    const int m0 = blockIdx.y * 16;
+    const half_t *Am = a.A + (size_t)m0 * a.lda;
+    half_t *Cm = a.C + (size_t)m0 * a.ldc;
+    const int Mloc = a.M - m0 < 16 ? a.M - m0 : 16;
+
     const int nkb = a.K >> 7;
     const int gpw = a.groups_per_wave;                     // k-blocks per wave (the last wave may have fewer)
     const int kb0 = wave * gpw;
@@ -89,8 +96,8 @@ __global__ __launch_bounds__(512) void w4a16_skinny_kernel(const SkinnyArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int xm = 4 * j + (lane >> 4), pc = lane & 15;
-        const int m = xm < a.M ? xm : a.M - 1;  // rows past M repeat the last row; their outputs are not stored
-        xsrc[j] = a.A + (size_t)m * a.lda + pc * 8;
+        const int m = xm < Mloc ? xm : Mloc - 1;  // rows past M repeat the last row; their outputs are not stored
+        xsrc[j] = Am + (size_t)m * a.lda + pc * 8;
         x_wslot[j] = pc * 16 + (xm ^ pc);
     }
 
@@ -175,12 +182,12 @@ __global__ __launch_bounds__(512) void w4a16_skinny_kernel(const SkinnyArgs a) {
         }
     }
     const int m = r16;
-    if (m >= a.M) return;
+    if (m >= Mloc) return;
     const int nb = n0 + 4 * kq;
     half_t outv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) outv[i] = (half_t)(acc[i] * 0.0625f);
-    half_t *crow = a.C + (size_t)m * a.ldc;
+    half_t *crow = Cm + (size_t)m * a.ldc;
     if (a.epilogue & TCE_W4_SILU_MUL_PAIRS) {  // rows (2n, 2n+1) = (gate n, up n); nb is a multiple of 4
         if (nb + 1 < a.N) crow[nb >> 1] = silu_mul_half(outv[0], outv[1]);
         if (nb + 3 < a.N) crow[(nb >> 1) + 1] = silu_mul_half(outv[2], outv[3]);
@@ -212,6 +219,11 @@ __global__ __launch_bounds__(512) void w4a16_skinny_shared_kernel(const SkinnyAr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nkb = a.K >> 7;
     const int nst = nkb >> 1;  // stages of two k-blocks
+    // batch rows 16 * blockIdx.y .. + 15 (M > 16: the weight tile is streamed once per 16 rows, the repeats out of L2 / MALL)
+    const int m0 = blockIdx.y * 16;
+    const half_t *Am = a.A + (size_t)m0 * a.lda;
+    half_t *Cm = a.C + (size_t)m0 * a.ldc;
+    const int Mloc = a.M - m0 < 16 ? a.M - m0 : 16;
     const int tiles = (a.N + 15) >> 4;
     int tile = blockIdx.x * kSharedWaves + wave;
     const bool idle = tile >= tiles;  // a wave past the last tile walks the barriers on a clamped tile and stores nothing
@@ -249,7 +261,7 @@ __global__ __launch_bounds__(512) void w4a16_skinny_shared_kernel(const SkinnyAr
     const int w_rslot = r16 * 4 + (kq ^ ((r16 >> 2) & 3));
     // activation stage: thread t owns piece t of 512: k-block h = t / 256 of the stage, batch row (t % 256) / 16, piece t % 16
     const int xh = tid >> 8, xm = (tid & 255) >> 4, xpc = tid & 15;
-    const half_t *xsrc = a.A + (size_t)(xm < a.M ? xm : a.M - 1) * a.lda + xh * 128 + xpc * 8;
+    const half_t *xsrc = Am + (size_t)(xm < Mloc ? xm : Mloc - 1) * a.lda + xh * 128 + xpc * 8;
     const int x_wslot = xh * 256 + xpc * 16 + (xm ^ xpc);
 
     float4_t acc = float4_t{0.f, 0.f, 0.f, 0.f};
@@ -325,12 +337,12 @@ __global__ __launch_bounds__(512) void w4a16_skinny_shared_kernel(const SkinnyAr
     }
 
     const int m = r16;
-    if (idle || m >= a.M) return;
+    if (idle || m >= Mloc) return;
     const int nb = n0 + 4 * kq;
     half_t outv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) outv[i] = (half_t)(acc[i] * 0.0625f);
-    half_t *crow = a.C + (size_t)m * a.ldc;
+    half_t *crow = Cm + (size_t)m * a.ldc;
     if (a.epilogue & TCE_W4_SILU_MUL_PAIRS) {
         if (nb + 1 < a.N) crow[nb >> 1] = silu_mul_half(outv[0], outv[1]);
         if (nb + 3 < a.N) crow[(nb >> 1) + 1] = silu_mul_half(outv[2], outv[3]);
@@ -346,15 +358,27 @@ __global__ __launch_bounds__(512) void w4a16_skinny_shared_kernel(const SkinnyAr
 }
 
 int g_skinny_ks = 0;  // forced K split (tuning), 0 = automatic
+int g_skinny_max_m = 128;
 
 }  // namespace
 
 void set_skinny_config(int ks) { g_skinny_ks = ks; }
+void set_skinny_max_m(int m) { g_skinny_max_m = m; }
 
 bool skinny_supports(const tce_w4a16_desc &d) {
     // M = 2 stays with the GEMV kernels (5.2 vs 6.5 us at 4096^2, 15.5 vs 20 us at 22016x4096); from 3 rows up this one wins
-    return d.M >= 3 && d.M <= 16 && d.group_size == 128 && d.K % 128 == 0 && !d.rmsnorm_gamma &&
-           (long long)d.N * (d.K / 2) < (1LL << 40);
+    if (!(d.M >= 3 && d.M <= g_skinny_max_m && d.group_size == 128 && d.K % 128 == 0 && !d.rmsnorm_gamma &&
+          (long long)d.N * (d.K / 2) < (1LL << 40)))
+        return false;
+    if (d.M <= 16) return true;
+    // 17 <= M <= 128: 16-row slices of the batch on gridDim.y against the MFMA GEMM, whose 64-row tiles leave most CUs idle
+    // when N is small (4096 x 4096, M = 32: 64 workgroups, 24 us; here 8.8 us) and win once there are enough of them
+    // (22016 x 4096 from M = 24).  Both estimates in us, fitted to profiles/r1/gemv_small_batch_sweep.jsonl (second block).
+    const float scale = (float)d.N / 4096.f * (float)d.K / 4096.f;
+    const float here = (4.0f + 2.3f * (float)((d.M + 15) / 16)) * scale;
+    const long gemm_wgs = (long)((d.M + 63) / 64) * ((d.N + 63) / 64);
+    const float gemm = 1.2f * (float)((gemm_wgs + 511) / 512) * (float)(d.K / 128) * 0.72f;
+    return here < gemm;
 }
 
 int launch_w4a16_skinny(const tce_w4a16_desc &d, hipStream_t stream, hipError_t *hip_err) {
@@ -379,6 +403,7 @@ int launch_w4a16_skinny(const tce_w4a16_desc &d, hipStream_t stream, hipError_t 
     const bool z8 = (d.flags & TCE_W4_ZERO_POINT_IS_8) != 0;
     // enough tiles to fill the chip without a K split: workgroups of 8 tiles sharing the activation blocks (ks == 9 forces
     // this form, any other forced ks the autonomous one)
+    const int mtiles = (d.M + 15) / 16;
     if ((g_skinny_ks == 9 || (g_skinny_ks == 0 && tiles >= 1024)) && d.K % 256 == 0) {
         const size_t lds = (size_t)2 * 2 * kXBuf + (size_t)kSharedWaves * (2 * kWBuf + (size_t)((nkb + 7) & ~7) * 64);
         if (lds <= 160 * 1024) {
@@ -391,7 +416,7 @@ int launch_w4a16_skinny(const tce_w4a16_desc &d, hipStream_t stream, hipError_t 
                     return TCE_ERR_HIP;
                 }
             }
-            hipLaunchKernelGGL(kfn, dim3((tiles + kSharedWaves - 1) / kSharedWaves), dim3(64 * kSharedWaves), lds, stream, a);
+            hipLaunchKernelGGL(kfn, dim3((tiles + kSharedWaves - 1) / kSharedWaves, mtiles), dim3(64 * kSharedWaves), lds, stream, a);
             const hipError_t e = hipGetLastError();
             if (e != hipSuccess) {
                 if (hip_err) *hip_err = e;
@@ -404,7 +429,7 @@ int launch_w4a16_skinny(const tce_w4a16_desc &d, hipStream_t stream, hipError_t 
     int ks = g_skinny_ks == 9 ? 0 : g_skinny_ks;
     if (ks == 0) {
         ks = 1;
-        while (ks < 8 && (long)tiles * ks < 3072 && nkb / (ks * 2) >= 2) ks *= 2;
+        while (ks < 8 && (long)tiles * mtiles * ks < 3072 && nkb / (ks * 2) >= 2) ks *= 2;
     }
     if (ks > nkb) ks = nkb;
     if (ks < 1 || ks > 8) return TCE_ERR_BAD_ARG;
@@ -420,7 +445,7 @@ int launch_w4a16_skinny(const tce_w4a16_desc &d, hipStream_t stream, hipError_t 
             return TCE_ERR_HIP;
         }
     }
-    hipLaunchKernelGGL(kfn, dim3(tiles), dim3(64 * ks), lds, stream, a);
+    hipLaunchKernelGGL(kfn, dim3(tiles, mtiles), dim3(64 * ks), lds, stream, a);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         if (hip_err) *hip_err = e;
