@@ -198,6 +198,29 @@ def test_gemm_add_to_c_every_variant(dev, oracle, M, N, K):
         capi.set_gemm_config()
 
 
+@pytest.mark.parametrize("pad", [8, 24, 4])
+def test_gemm_strided_activations(dev, oracle, pad):
+    """lda != K (rows are 16-byte pieces for the LDS-DMA loads; the ABI requires lda % 8 == 0 and refuses anything else)."""
+    from tinychatengine_amd import capi
+    M, N, K = 200, 264, 1024
+    qw, sc, zp, a = _make(oracle, M, N, K, 128, seed=pad, random_zeros=True)
+    ref32, _ = oracle.w4a16_gemv_q4_6(a, qw, sc, zp, M, N, K, 128)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    tq, ts, tz = t(qw.view(np.int32)), t(sc.view(np.float16)), t(zp.view(np.int32))
+    buf = torch.full((M, K + pad), float("nan"), dtype=torch.float16, device=dev)
+    buf[:, :K] = t(a)
+    out = torch.full((M, N), float("nan"), dtype=torch.float16, device=dev)
+    d = capi.W4A16Desc(M=M, N=N, K=K, group_size=128, A=buf.data_ptr(), lda=K + pad, qweight=tq.data_ptr(), scales=ts.data_ptr(),
+                       zeros=tz.data_ptr(), C=out.data_ptr(), flags=capi.TCE_W4_FORCE_GEMM)
+    rc = capi.w4a16_forward(d, torch.cuda.current_stream().cuda_stream)
+    if pad % 8:
+        assert rc == capi.TCE_ERR_BAD_ARG or rc < 0, "an lda that is not a multiple of 8 halves must be refused"
+        return
+    capi.check(rc)
+    torch.cuda.synchronize()
+    _check(out.cpu().numpy(), ref32, f"gemm lda = K + {pad}")
+
+
 def test_gemm_is_transpose_detecting(dev, oracle):
     """Asymmetric data: A = one-hot rows selects single k, so a swapped fragment index shows up as a wrong column."""
     from tinychatengine_amd import capi
