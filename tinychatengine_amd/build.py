@@ -25,6 +25,8 @@ HIPCC_FLAGS = [
     "-ffp-contract=off",  # the int8 epilogue and the fp16-accumulate entry point need every rounding
     "-Wall", "-Wno-unused-function",
 ]
+# per-file additions (experiments land here first)
+EXTRA_FLAGS: dict[str, list[str]] = {}  # (-fno-slp-vectorize on the GEMM: no packed fp32 fma beside the MFMAs -- measured neutral)
 
 
 def _hipcc() -> str:
@@ -50,7 +52,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         sp = os.path.join(CSRC, src)
         op = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
         if force or _stale(op, [sp] + headers):
-            jobs.append([hipcc, *HIPCC_FLAGS, "-I", os.path.join(REPO_DIR, "include"), "-I", CSRC, "-c", sp, "-o", op])
+            jobs.append([hipcc, *HIPCC_FLAGS, *EXTRA_FLAGS.get(src, []), "-I", os.path.join(REPO_DIR, "include"), "-I", CSRC, "-c", sp, "-o", op])
         objs.append(op)
     if jobs:  # the translation units are independent: compile them side by side
         from concurrent.futures import ThreadPoolExecutor

@@ -391,11 +391,11 @@ hipError_t launch(const DmaGemmArgs &g0, int ks, hipStream_t stream) {
 // Tile and form for a shape.  A workgroup's time is its k-loop, nearly independent of how many others run (latency-bound
 // steps), so a launch costs about rounds x (K / 128) x c with rounds = workgroups / resident slots rounded UP while it is
 // small: 688 workgroups on 512 slots cost two rounds, 344 on 512 one.  c (us per k-block, measured, profiles/r1/
-// gemm_dma_sweep.jsonl / gemm_dma_ksplit.jsonl): 64x128 1.2, 64x64 1.0, 64x128 two quartets 0.92, 32x128 two quartets 0.7,
-// 128x128 1.55; slots per CU: 2, 2, 1, 1, 1.
+// gemm_dma_sweep.jsonl / gemm_dma_ksplit.jsonl): 64x128 1.2, 64x64 1.0, 64x128 two quartets 0.92, 64x64 two quartets 0.6,
+// 32x128 two quartets 0.7, 128x128 1.55; slots per CU: 2, 2, 1, 1, 1, 1.
 void choose_tile(int M, int N, int *mt, int *nt, int *ks) {
     static const struct { int mt, nt, ks, slots_per_cu; float c; } cand[] = {
-        {4, 2, 1, 2, 1.2f}, {4, 1, 1, 2, 1.0f}, {4, 2, 2, 1, 0.92f}, {2, 2, 2, 1, 0.70f}, {8, 2, 1, 1, 1.55f}};
+        {4, 2, 1, 2, 1.2f}, {4, 1, 1, 2, 1.0f}, {4, 2, 2, 1, 0.92f}, {4, 1, 2, 1, 0.6f}, {2, 2, 2, 1, 0.70f}, {8, 2, 1, 1, 1.55f}};
     float best = 0.f;
     for (const auto &c : cand) {
         const long wgs = (long)((M + c.mt * 16 - 1) / (c.mt * 16)) * ((N + c.nt * 64 - 1) / (c.nt * 64));
