@@ -102,6 +102,10 @@ int tce_w4a16_set_debug_mode(int mode) {
         tce::set_skinny_max_m(mode - 1000);
         return TCE_OK;
     }
+    if (mode >= 70 && mode <= 74) {  // W8A8: wave quartets per tile (70 automatic)
+        tce::set_w8a8_ksplit(mode - 70);
+        return TCE_OK;
+    }
     if (mode >= 50 && mode <= 65) {  // DMA GEMM timing experiments (wrong results by design)
         tce::set_gemm_dma_mode(mode - 50);
         return TCE_OK;

@@ -64,11 +64,17 @@ __device__ __forceinline__ void epilogue_store(const W8A8Args &a, void *Cb, int 
 // ds_write_b128 with an XOR swizzle (slot = row*4 + (chunk ^ (row/4 % 4))), one ds_read_b128 back in MFMA order
 // (conflict-free both ways).  A wave's LDS operations complete in order, so one slot per fragment is enough and no
 // barrier is involved.
-__global__ __launch_bounds__(256) void w8a8_mfma_kernel(const W8A8Args a) {
-    __shared__ __attribute__((aligned(16))) int4_t lds_t[4][4][64];  // [wave][fragment: A0 A1 B0 B1][slot]
+// KS > 1: the K range is cut between KS wave quartets of the same 64x64 tile (the OPT shapes give 24-96 tiles, each a serial
+// chain of K/64 steps: 512x768x3072 15.4 us with 96 workgroups).  int32 partial sums are exact, so the quartets' tiles are
+// added through LDS in any order and the epilogue sees the same integers as the unsplit kernel: still bit-exact.
+template <int KS>
+__global__ __launch_bounds__(256 * KS) void w8a8_mfma_kernel(const W8A8Args a) {
+    extern __shared__ __attribute__((aligned(16))) int4_t lds_dyn[];  // [4 * KS waves][fragment: A0 A1 B0 B1][64 slots]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave8 & 3, grp = wave8 >> 2;
+    int4_t(*lds_t)[64] = reinterpret_cast<int4_t(*)[64]>(lds_dyn + (size_t)wave8 * 4 * 64);  // this wave's four slots
     const int wm = wave >> 1, wn = wave & 1;
     const int r16 = lane & 15, kq = lane >> 4;   // MFMA view of the lane
     const int lrow = lane >> 2, lchunk = lane & 3;  // load view of the lane
@@ -110,13 +116,13 @@ __global__ __launch_bounds__(256) void w8a8_mfma_kernel(const W8A8Args a) {
         int4_t fa[2], fb[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            lds_t[wave][i][wslot] = ra[i];
-            lds_t[wave][2 + i][wslot] = rb[i];
+            lds_t[i][wslot] = ra[i];
+            lds_t[2 + i][wslot] = rb[i];
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            fa[i] = lds_t[wave][i][rslot];
-            fb[i] = lds_t[wave][2 + i][rslot];
+            fa[i] = lds_t[i][rslot];
+            fb[i] = lds_t[2 + i][rslot];
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -124,7 +130,11 @@ __global__ __launch_bounds__(256) void w8a8_mfma_kernel(const W8A8Args a) {
             for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
     };
 
-    const int k_full = a.K & ~63;
+    // this quartet's full k-steps: [k_begin, k_end)
+    const int nfull = a.K >> 6;
+    const int spg = (nfull + KS - 1) / KS;
+    const int k_begin = (grp * spg < nfull ? grp * spg : nfull) * 64;
+    const int k_end = ((grp + 1) * spg < nfull ? (grp + 1) * spg : nfull) * 64;
     // the next k-step's raw fragments are requested before the current one goes through LDS and the MFMAs (two static
     // register sets; requests past the end are clamped re-reads)
     auto load_raw = [&](int4_t (&ra)[2], int4_t (&rb)[2], int k0) {
@@ -134,20 +144,23 @@ __global__ __launch_bounds__(256) void w8a8_mfma_kernel(const W8A8Args a) {
             rb[i] = *reinterpret_cast<const int4_t *>(pb[i] + k0);
         }
     };
-    if (k_full > 0) {
-        const int k_last = k_full - 64;
+    if (k_end > k_begin) {
+        // (three steps of loads in flight through four static register sets, unrolled by four, measured SLOWER: hipcc answers
+        // the ring with vmcnt(0) at most uses -- 512x768x3072 with two quartets 10.7 -> 12.5 us)
+        const int k_last = k_end - 64;
         int4_t ra0[2], rb0[2], ra1[2], rb1[2];
-        load_raw(ra0, rb0, 0);
-        for (int k0 = 0; k0 < k_full; k0 += 128) {
+        load_raw(ra0, rb0, k_begin);
+        for (int k0 = k_begin; k0 < k_end; k0 += 128) {
             load_raw(ra1, rb1, k0 + 64 <= k_last ? k0 + 64 : k_last);
             contract(ra0, rb0);
-            if (k0 + 64 < k_full) {
+            if (k0 + 64 < k_end) {
                 load_raw(ra0, rb0, k0 + 128 <= k_last ? k0 + 128 : k_last);
                 contract(ra1, rb1);
             }
         }
     }
-    if (k_full < a.K) {  // K % 64 in {16,32,48}: chunks past the end contribute zeros (K % 16 == 0 is guaranteed)
+    const int k_full = nfull * 64;
+    if (k_full < a.K && grp == KS - 1) {  // K % 64 in {16,32,48}: chunks past the end contribute zeros (K % 16 == 0 is guaranteed)
         const bool live = k_full + lchunk * 16 < a.K;
         int4_t ra[2], rb[2];
 #pragma unroll
@@ -161,6 +174,29 @@ __global__ __launch_bounds__(256) void w8a8_mfma_kernel(const W8A8Args a) {
             }
         }
         contract(ra, rb);
+    }
+
+    if constexpr (KS > 1) {  // quartets 1.. hand their int32 tiles to quartet 0: [quartet - 1][register][thread of the quartet]
+        __syncthreads();  // every wave is done with its transpose slots
+        int4_t *red = lds_dyn;
+        const int t4 = tid & 255;
+        if (grp > 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) red[((grp - 1) * 4 + i * 2 + j) * 256 + t4] = acc[i][j];
+        }
+        __syncthreads();
+        if (grp > 0) return;
+        for (int g2 = 0; g2 < KS - 1; ++g2)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int4_t o = red[(g2 * 4 + i * 2 + j) * 256 + t4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] += o[r];
+                }
     }
 
     // D[row = 4*(lane>>4) + r][col = lane & 15]
@@ -206,7 +242,11 @@ __global__ __launch_bounds__(256) void w8a8_generic_kernel(const W8A8Args a) {
     epilogue_store(a, Cb, m, n, acc, bias_term(a, n));
 }
 
+int g_w8a8_ks = 0;  // forced K split (tuning), 0 = automatic
+
 }  // namespace
+
+void set_w8a8_ksplit(int ks) { g_w8a8_ks = (ks == 1 || ks == 2 || ks == 4) ? ks : 0; }
 
 int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err) {
     W8A8Args a{};
@@ -233,7 +273,17 @@ int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err)
     a.vec_ok = aligned ? 1 : 0;
     if (!d.b_per_row && aligned && d.K >= 64) {
         dim3 grid((d.N + 63) / 64, (d.M + 63) / 64, d.batch);
-        hipLaunchKernelGGL(w8a8_mfma_kernel, grid, dim3(256), 0, stream, a);
+        // wave quartets per tile: while the tiles do not fill the chip and every quartet keeps >= 2 k-steps
+        const long tiles = (long)grid.x * grid.y * grid.z;
+        int ks = g_w8a8_ks;
+        if (ks == 0) {
+            ks = 1;
+            if (tiles < 512 && d.K / 64 >= 4) ks = 2;  // four quartets measured no better than two (profiles/r1/w8a8_ksplit_sweep.jsonl)
+        }
+        const size_t lds = (size_t)ks * 4 * 4 * 64 * 16;  // transpose slots; the reduction ((ks - 1) * 16 KiB) reuses them
+        if (ks == 4) hipLaunchKernelGGL(w8a8_mfma_kernel<4>, grid, dim3(1024), lds, stream, a);
+        else if (ks == 2) hipLaunchKernelGGL(w8a8_mfma_kernel<2>, grid, dim3(512), lds, stream, a);
+        else hipLaunchKernelGGL(w8a8_mfma_kernel<1>, grid, dim3(256), lds, stream, a);
     } else {
         const long long total = (long long)d.M * d.N;
         dim3 grid((unsigned)((total + 255) / 256), 1, d.batch);
