@@ -19,8 +19,9 @@
  *                                 (grid.z = M there); here M <= 2 runs the bandwidth-bound GEMV kernels,
  *                                 3 <= M <= 16 (group 128) the small-batch kernel that streams the weights once for
  *                                 all rows -- also 17 <= M <= 128 in 16-row slices while N is too small to fill the
- *                                 chip with GEMM tiles --, larger M the MFMA GEMM kernels; M <= TCE_W4A16_GEMV_MAX_M
- *                                 with another group size stays on the GEMV kernels.
+ *                                 chip with GEMM tiles --, larger M the MFMA GEMM kernels (groups of 128, and from
+ *                                 M = 17 also 64 and 32 when K % 128 == 0); smaller M with another group size stays
+ *                                 on the GEMV kernels.
  *   tce_w4a16_forward_group    <- several gemv_forward_cuda calls that read the same activation
  *                                 (fused q/k/v: llm/src/nn_modules/cuda/Int4llamaAttention.cu:125;
  *                                  gate+up: Int4llamaDecoderLayer.cu:96-99) issued as ONE launch.

@@ -154,7 +154,9 @@ def test_gemv_golden_vector(dev, golden):
     _check(got, golden["w4_expected_f32"], "golden gemm")
 
 
-GEMM_SHAPES = [(64, 256, 512, 128), (33, 200, 1024, 128), (512, 384, 4096, 128), (128, 128, 1408 + 128 * 5, 64), (17, 72, 256, 32), (9, 16, 128, 128)]
+GEMM_SHAPES = [(64, 256, 512, 128), (33, 200, 1024, 128), (512, 384, 4096, 128), (128, 128, 1408 + 128 * 5, 64), (17, 72, 256, 32), (9, 16, 128, 128),
+               # groups of 64 / 32 on the LDS-DMA GEMM (two / four groups per k-block; one and two quartets), and with a K tail (GEMV fallback)
+               (130, 200, 1024, 64), (70, 136, 512, 32), (300, 2100, 384, 64), (260, 520, 256, 32), (40, 64, 192, 64)]
 
 
 @pytest.mark.parametrize("M,N,K,G", GEMM_SHAPES)

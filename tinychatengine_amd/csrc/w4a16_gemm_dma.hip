@@ -39,6 +39,7 @@ struct DmaGemmArgs {
     int n_blocks, m_blocks;
     int add_to_c;
     int xm, m_per, n_per;
+    int log2g;  // 7 / 6 / 5: group size 128 / 64 / 32
 };
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -56,17 +57,27 @@ __device__ __forceinline__ void wait_vmcnt() {
 // KS = 2: eight waves on the same tile, the k-blocks alternating between the two wave quartets (each with its own three
 // stages); the quartets' fp32 accumulators meet in LDS at the end (quartet 0 + quartet 1, a fixed order).  One wave per SIMD
 // executes a k-block as the SUM of its VALU, MFMA and LDS time; two interleave them.
-template <int MT, int NT, int KS>
+//
+// LG = log2(group size): 7, or 6 / 5 -- two / four quantization groups per 128-wide k-block.  The MFMA sums over its four
+// k-quarters, so for the smaller groups a step must stay inside ONE group: lane quarter q then contracts k = 32 s + 8 q ..
+// (the row's words 4 s + q) in step s instead of 32 q + 8 s (words 4 q + s).  The activation image only needs the other
+// involution (position n16 ^ (4 s + q): conflict-free for the same reason); the lane's 16-byte weight chunk, loaded as
+// before, is re-dealt between the four quarters through a per-wave LDS slot (4 ds_write_b32 + 1 ds_read_b128 per column
+// tile and k-block), and the fp32 scale is applied after every group's steps.
+template <int MT, int NT, int KS, int LG>
 __global__ __launch_bounds__(256 * KS, (KS == 2 || MT * NT >= 16 ? 1 : 2)) void w4a16_gemm_dma_kernel(const DmaGemmArgs g) {
     constexpr int NTHREADS = 256 * KS;
+    constexpr int GPB = 128 >> LG;  // groups per k-block
+    constexpr int SPG = 4 / GPB;    // MFMA steps per group
     constexpr int BM = MT * 16;
     constexpr int BN = 4 * NT * 16;
     constexpr int A_BYTES = BM * 256;  // one stage of activations: BM rows x 128 halves
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nkb = g.K >> 7;
+    const int ngr = nkb * GPB;  // quantization groups along K
     const int zw = g.zeros_stride;
     unsigned *lds_z = reinterpret_cast<unsigned *>(smem + KS * 3 * A_BYTES);  // [BN][zw]
-    half_t *lds_s = reinterpret_cast<half_t *>(lds_z + BN * zw);       // [BN][nkb]
+    half_t *lds_s = reinterpret_cast<half_t *>(lds_z + BN * zw);       // [BN][ngr]
 
     const int bid = blockIdx.x;
     const int xcd = bid & 7;
@@ -89,20 +100,20 @@ __global__ __launch_bounds__(256 * KS, (KS == 2 || MT * NT >= 16 ? 1 : 2)) void 
 
     // ---- scales and zeros of the workgroup's rows, all k-blocks, once: batches of 8 independent loads per thread (a
     // load -> store loop pays one memory latency per trip, 16 trips for K = 4096) ----
-    for (int base = tid; base < BN * nkb; base += NTHREADS * 8) {
+    for (int base = tid; base < BN * ngr; base += NTHREADS * 8) {
         half_t v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int idx = base + u * NTHREADS;
-            const int row = idx / nkb, gi = idx - row * nkb;
+            const int row = idx / ngr, gi = idx - row * ngr;
             int n = nb0 + row;
             n = n < g.N ? n : g.N - 1;
-            v[u] = idx < BN * nkb ? g.scales[(size_t)n * g.scales_stride + gi] : (half_t)0.f;
+            v[u] = idx < BN * ngr ? g.scales[(size_t)n * g.scales_stride + gi] : (half_t)0.f;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int idx = base + u * NTHREADS;
-            if (idx < BN * nkb) lds_s[idx] = v[u];
+            if (idx < BN * ngr) lds_s[idx] = v[u];
         }
     }
     for (int base = tid; base < BN * zw; base += NTHREADS * 4) {
@@ -131,8 +142,8 @@ __global__ __launch_bounds__(256 * KS, (KS == 2 || MT * NT >= 16 ? 1 : 2)) void 
         const int p = lane & 15;
         int m = m_base + row;
         m = m < g.M ? m : g.M - 1;  // rows past M repeat the last row; their outputs are not stored
-        const int x = p ^ (row & 15);                              // = s ^ h(q) of the piece that belongs at position p
-        const int pc = 4 * ((0x78 >> (2 * (x >> 2))) & 3) + (x & 3);  // h^-1: 0 -> 0, 12 -> 1, 4 -> 2, 8 -> 3
+        const int x = p ^ (row & 15);  // LG == 7: = s ^ h(q) of the piece that belongs at position p; else the piece itself
+        const int pc = LG == 7 ? 4 * ((0x78 >> (2 * (x >> 2))) & 3) + (x & 3) : x;  // h^-1: 0 -> 0, 12 -> 1, 4 -> 2, 8 -> 3
         a_src[i] = reinterpret_cast<const char *>(g.A + (size_t)m * g.lda) + (pc << 4);
     }
     auto issue = [&](int stage, int kb) {
@@ -156,7 +167,7 @@ __global__ __launch_bounds__(256 * KS, (KS == 2 || MT * NT >= 16 ? 1 : 2)) void 
     // set both or neither of bits 2 and 3.  The plain (4q + s) ^ n16 (h = 4q) is 2-way conflicted on every read. ----
     int a_off[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) a_off[s] = n16 * 256 + ((n16 ^ s ^ ((0x84C0 >> (4 * q)) & 15)) << 4);
+    for (int s = 0; s < 4; ++s) a_off[s] = n16 * 256 + ((LG == 7 ? n16 ^ s ^ ((0x84C0 >> (4 * q)) & 15) : n16 ^ (4 * s + q)) << 4);
 
     unsigned nib_mask;
     asm volatile("v_mov_b32 %0, 0x00F0000F" : "=v"(nib_mask));
@@ -170,27 +181,40 @@ __global__ __launch_bounds__(256 * KS, (KS == 2 || MT * NT >= 16 ? 1 : 2)) void 
     // group constants of a k-block: the zero-point pair (-(1024 + z), -(64 + z)) and the fp32 scale.  Read one step ahead
     // so that the first unpack of a step does not start behind an LDS round trip plus a dependent VALU chain.
     struct GroupConst {
-        half2_t zc[NT];
-        float sc[NT];
+        half2_t zc[NT][GPB];
+        float sc[NT][GPB];
     };
     auto read_group = [&](GroupConst &o, int kb_unclamped) {
         const int kb = kb_unclamped < nkb ? kb_unclamped : nkb - 1;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const unsigned z = (lds_z[t_row[j] * zw + (kb >> 3)] >> ((kb & 7) * 4)) & 0xFu;
-            o.zc[j] = as_half2((0xD400u | (z << 4)) << 16 | (0xE400u | z));
-            o.sc[j] = kb_unclamped < nkb ? (float)lds_s[t_row[j] * nkb + kb] : 0.f;  // a step past K (odd block count, KS = 2) adds 0
-        }
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int gi = 0; gi < GPB; ++gi) {
+                const int gr = kb * GPB + gi;
+                const unsigned z = (lds_z[t_row[j] * zw + (gr >> 3)] >> ((gr & 7) * 4)) & 0xFu;
+                o.zc[j][gi] = as_half2((0xD400u | (z << 4)) << 16 | (0xE400u | z));
+                o.sc[j][gi] = kb_unclamped < nkb ? (float)lds_s[t_row[j] * ngr + gr] : 0.f;  // a step past K (odd block count, KS = 2) adds 0
+            }
     };
-    auto compute = [&](const uint4_t (&bw)[NT], const GroupConst &gc, int stage) {
+    // per-wave slot for re-dealing the weight words between the k-quarters (LG < 7 only): [column tile][dst quarter][n16][src quarter]
+    unsigned *lds_wt = reinterpret_cast<unsigned *>(lds_s + BN * ngr + ((BN * ngr) & 1)) + wave8 * NT * 256;
+    auto compute = [&](const uint4_t (&bw_in)[NT], const GroupConst &gc, int stage) {
         const unsigned char *st = stages + stage * A_BYTES;
-        const half2_t(&zc)[NT] = gc.zc;
-        const float(&sc)[NT] = gc.sc;
+        uint4_t bw[NT];
+        if constexpr (LG == 7) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bw[j] = bw_in[j];
+        } else {  // lane (n16, q) holds the row's words 4q .. 4q+3 and needs words q, 4+q, 8+q, 12+q
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) lds_wt[j * 256 + (jj * 16 + n16) * 4 + q] = bw_in[j][jj];  // word 4q + jj -> quarter jj, step q
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bw[j] = *reinterpret_cast<const uint4_t *>(lds_wt + j * 256 + (q * 16 + n16) * 4);
+            __builtin_amdgcn_wave_barrier();
+        }
         float4_t blk[MT][NT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) blk[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
         // Fragments are double-buffered by hand and the regions fenced: left alone, hipcc reads every fragment into the same
         // four registers right in front of its MFMAs -- 16 exposed LDS round trips per k-block with one wave per SIMD.
         // Region s holds the LDS reads and the unpack of step s+1 next to the MFMAs of step s.
@@ -203,11 +227,12 @@ __global__ __launch_bounds__(256 * KS, (KS == 2 || MT * NT >= 16 ? 1 : 2)) void 
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const unsigned w = bw[j][step];
+                const half2_t zc = gc.zc[j][step / SPG];
                 half2_t d[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const unsigned rep = __builtin_amdgcn_perm(w, w, 0x01010101u * (unsigned)r);  // byte r in every byte
-                    d[r] = __builtin_elementwise_fma(as_half2((rep & nib_mask) | 0x64006400u), mulc, zc[j]);
+                    d[r] = __builtin_elementwise_fma(as_half2((rep & nib_mask) | 0x64006400u), mulc, zc);
                 }
                 dst[j] = half8_t{d[0].x, d[0].y, d[1].x, d[1].y, d[2].x, d[2].y, d[3].x, d[3].y};
             }
@@ -221,18 +246,26 @@ __global__ __launch_bounds__(256 * KS, (KS == 2 || MT * NT >= 16 ? 1 : 2)) void 
                 read_a(af[(s + 1) & 1], s + 1);
                 unpack(bf[(s + 1) & 1], s + 1);
             }
+            if (s % SPG == 0) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) blk[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) blk[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s & 1][i], bf[s & 1][j], blk[i][j], 0, 0, 0);
+            if (s % SPG == SPG - 1) {  // the group is complete: its fp32 scale
+                if (s == 3) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[i][j][r] = __builtin_fmaf(gc.sc[j][s / SPG], blk[i][j][r], acc[i][j][r]);
+            }
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] = __builtin_fmaf(sc[j], blk[i][j][r], acc[i][j][r]);
     };
 
     // Stage kb % 3 holds the activations of block kb.  In step kb the weight words of block kb+1 are requested first, then
@@ -337,21 +370,33 @@ int g_dma_xm = 0;  // 0: choose per launch
 
 int g_dma_ks = 0;  // 0: choose, 1 / 2: forced
 
-template <int MT, int NT, int KS>
-hipError_t launch_ks(DmaGemmArgs &g, hipStream_t stream) {
+template <int MT, int NT, int KS, int LG>
+hipError_t launch_lg(DmaGemmArgs &g, hipStream_t stream) {
     constexpr int BM = MT * 16, BN = 4 * NT * 16;
-    const int nkb = g.K / 128;
-    size_t lds = (size_t)KS * 3 * (BM * 256) + (size_t)BN * g.zeros_stride * 4 + (size_t)BN * nkb * 2;
+    const int ngr = g.K >> LG;
+    size_t lds = (size_t)KS * 3 * (BM * 256) + (size_t)BN * g.zeros_stride * 4 + (((size_t)BN * ngr * 2 + 3) & ~(size_t)3);
+    if (LG < 7) lds += (size_t)KS * 4 * NT * 1024;  // the waves' weight re-deal slots
     if (KS == 2 && lds < (size_t)MT * NT * 4 * 256 * 4 + (size_t)BM * BN * 2) lds = (size_t)MT * NT * 4 * 256 * 4 + (size_t)BM * BN * 2;
     lds = (lds + 15) & ~(size_t)15;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kfn = w4a16_gemm_dma_kernel<MT, NT, KS>;
+    auto kfn = w4a16_gemm_dma_kernel<MT, NT, KS, LG>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kfn, dim3(8 * g.m_per * g.n_per), dim3(256 * KS), lds, stream, g);
     return hipGetLastError();
+}
+
+template <int MT, int NT, int KS>
+hipError_t launch_ks(DmaGemmArgs &g, hipStream_t stream) {
+    if (g.log2g == 7) return launch_lg<MT, NT, KS, 7>(g, stream);
+    // groups of 64 / 32: compiled for the tiles choose_tile picks
+    if constexpr ((MT == 4 && NT <= 2) || (MT == 2 && NT == 2)) {
+        if (g.log2g == 6) return launch_lg<MT, NT, KS, 6>(g, stream);
+        if (g.log2g == 5) return launch_lg<MT, NT, KS, 5>(g, stream);
+    }
+    return hipErrorInvalidValue;
 }
 
 template <int MT, int NT>
@@ -393,11 +438,12 @@ hipError_t launch(const DmaGemmArgs &g0, int ks, hipStream_t stream) {
 // small: 688 workgroups on 512 slots cost two rounds, 344 on 512 one.  c (us per k-block, measured, profiles/r1/
 // gemm_dma_sweep.jsonl / gemm_dma_ksplit.jsonl): 64x128 1.2, 64x64 1.0, 64x128 two quartets 0.92, 64x64 two quartets 0.6,
 // 32x128 two quartets 0.7, 128x128 1.55; slots per CU: 2, 2, 1, 1, 1, 1.
-void choose_tile(int M, int N, int *mt, int *nt, int *ks) {
+void choose_tile(int M, int N, bool g128, int *mt, int *nt, int *ks) {
     static const struct { int mt, nt, ks, slots_per_cu; float c; } cand[] = {
         {4, 2, 1, 2, 1.2f}, {4, 1, 1, 2, 1.0f}, {4, 2, 2, 1, 0.92f}, {4, 1, 2, 1, 0.6f}, {2, 2, 2, 1, 0.70f}, {8, 2, 1, 1, 1.55f}};
     float best = 0.f;
     for (const auto &c : cand) {
+        if (!g128 && c.mt == 8) continue;  // groups of 64 / 32 are compiled for the 64- and 32-row tiles only
         const long wgs = (long)((M + c.mt * 16 - 1) / (c.mt * 16)) * ((N + c.nt * 64 - 1) / (c.nt * 64));
         const float r = (float)wgs / (256.f * c.slots_per_cu);
         const float rounds = r <= 3.f ? (float)(int)(r + 0.999f) : r + 0.5f;
@@ -417,8 +463,9 @@ void set_gemm_dma_mode(int mode) { g_dma_ks = mode & 3; }
 void set_gemm_dma_xcd_rows(int xm) { g_dma_xm = (xm == 1 || xm == 2 || xm == 4 || xm == 8) ? xm : 0; }
 
 int launch_w4a16_gemm_dma(const tce_w4a16_desc &d, int mt, int nt, hipStream_t stream, hipError_t *hip_err) {
-    if (d.K % 128 != 0 || d.group_size != 128) return TCE_ERR_UNSUPPORTED_SHAPE;
+    if (d.K % 128 != 0 || (d.group_size != 128 && d.group_size != 64 && d.group_size != 32)) return TCE_ERR_UNSUPPORTED_SHAPE;
     DmaGemmArgs g{};
+    g.log2g = d.group_size == 128 ? 7 : (d.group_size == 64 ? 6 : 5);
     const int zw = zeros_width(d.K, d.group_size);
     g.A = static_cast<const half_t *>(d.A);
     g.qweight = static_cast<const uint4_t *>(d.qweight);
@@ -435,7 +482,7 @@ int launch_w4a16_gemm_dma(const tce_w4a16_desc &d, int mt, int nt, hipStream_t s
     g.zeros_stride = d.zeros_stride ? d.zeros_stride : zw;
     if ((g.lda * 2) % 16 != 0 || (reinterpret_cast<uintptr_t>(d.A) & 15)) return TCE_ERR_UNSUPPORTED_SHAPE;  // 16-byte DMA pieces
     int ks = 0;
-    if (mt == 0) choose_tile(d.M, d.N, &mt, &nt, &ks);
+    if (mt == 0) choose_tile(d.M, d.N, d.group_size == 128, &mt, &nt, &ks);
     hipError_t e = hipSuccess;
     bool found = false;
 #define TCE_V(M_, N_)                      \
