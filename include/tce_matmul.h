@@ -115,6 +115,10 @@ TCE_API int tce_w4a16_forward(const tce_w4a16_desc *d, void *stream);
  *   tce_add_half:       c[i] = hadd(a[i], b[i])                                   (add_half, Int4llamaDecoderLayer.cu:12-18)
  *   tce_silu_mul_half:  a[i] = hmul(hmul(a[i], hdiv(1, hadd(1, hexp(-a[i])))), b[i])  (SiLuMul_half, :20-30)
  * n halves; pointers 16-byte aligned; c may alias a or b. */
+/* Reads [ptr, ptr + bytes) with at most `workgroups` workgroups (0 = as many as the range needs) and discards the data: the
+ * range then sits in the memory-side cache (256 MiB) for the launch that needs it.  Meant for a side stream / graph branch
+ * next to the launch BEFORE that one (no reference counterpart: cudaMallocManaged prefetching is the closest idea). */
+TCE_API int tce_prefetch(const void *ptr, long long bytes, int workgroups, void *stream);
 TCE_API int tce_add_half(const void *a, const void *b, void *c, long long n, void *stream);
 /* RMSNorm as the reference's CUDA build computes it (generalT5LayerNorm, llm/src/ops/cuda/LlamaRMSNorm.cu:68-115):
  *   out[r][i] = half( clamp( (float(x[r][i]) * rs_r) * gamma[i] ) ),  rs_r = 1 / sqrt(mean_i x[r][i]^2 + eps), fp32,

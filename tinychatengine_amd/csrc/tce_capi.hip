@@ -386,6 +386,13 @@ int tce_w4a16_forward_group_rmsnorm(const tce_w4a16_desc *descs, int count, cons
     return forward_group_norm(descs, count, gamma, eps, stream);
 }
 
+int tce_prefetch(const void *ptr, long long bytes, int workgroups, void *stream) {
+    if (!ptr || bytes < 0 || (reinterpret_cast<uintptr_t>(ptr) & 15)) return fail(TCE_ERR_BAD_ARG, "tce_prefetch: bad argument (16-byte aligned pointer, bytes >= 0)");
+    hipError_t he = hipSuccess;
+    const int rc = tce::launch_prefetch(ptr, bytes, workgroups, static_cast<hipStream_t>(stream), &he);
+    return rc == TCE_ERR_HIP ? hip_fail(he, "prefetch launch") : rc;
+}
+
 int tce_add_half(const void *a, const void *b, void *c, long long n, void *stream) {
     if (!a || !b || !c || n <= 0) return fail(TCE_ERR_BAD_ARG, "tce_add_half: bad argument");
     if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) % 16 != 0)
