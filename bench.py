@@ -42,10 +42,74 @@ def parse_args():
     ap.add_argument("--roofline-only", action="store_true", help="run only the dominant-kernel loop (for rocprofv3)")
     ap.add_argument("--roofline-launches", type=int, default=256)
     ap.add_argument("--roofline-eager", action="store_true", help="roofline leg without graph capture (for rocprofv3 PMC passes)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the short prefill-GEMM / W8A8 legs (BASELINE configs 3 and 4) reported under \"other_configs\"")
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (RCCL init, gathers, graph capture) even with one rank")
     ap.add_argument("--cpu-worker", default="", choices=["", "avx", "ref"], help=argparse.SUPPRESS)
     ap.add_argument("--threads", type=int, default=8, help=argparse.SUPPRESS)
     return ap.parse_args()
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def other_configs_leg(torch, dev):
+    """BASELINE.json configs 3 and 4, measured live next to the headline metric (they are parity-test cases, not the bench
+    line, but their rates belong beside it): W4A16 prefill GEMM at M = 512 on the three Llama linear shapes (TFLOP/s against
+    the 2.5 PFLOP/s dense fp16 MFMA peak) and the W8A8 int8 GEMM on the OPT-125M shapes.  hipGraph of back-to-back launches
+    rotating over distinct weights, HIP events around the replays; a few seconds in total."""
+    import ctypes as C
+    from tinychatengine_amd import capi
+    from tinychatengine_amd.linear import Linear_half_int4
+    L = capi.lib()
+
+    def time_graph(fn, launches, reps=3):
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            sp = C.c_void_p(s.cuda_stream)
+            with torch.cuda.graph(g, stream=s):
+                for i in range(launches):
+                    fn(i, sp)
+        for _ in range(8):  # burn-in: the first replays after allocating fresh weights run ~10 % slow
+            g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / (reps * launches)
+
+    out = {"w4a16_prefill_gemm_M512": [], "w8a8_opt125m": []}
+    gen = torch.Generator(device=dev).manual_seed(1)
+    for (N, K) in ((4096, 4096), (11008, 4096), (4096, 11008)):
+        M = 512
+        nsets = max(2, int(3e8 // (N * K // 2)))  # > 256 MiB of distinct weights: they come from HBM
+        zw = (K // 128 + 7) // 8
+        sets = []
+        for _ in range(nsets):
+            qw = torch.randint(-2**31, 2**31 - 1, (N, K // 8), dtype=torch.int32, device=dev, generator=gen)
+            sc = (torch.rand((N, zw * 8), device=dev, generator=gen) * 0.01 + 0.001).to(torch.float16)
+            zp = torch.full((N, zw), -2004318072, dtype=torch.int32, device=dev)  # 0x88888888
+            sets.append((qw, sc, zp))
+        x = torch.randn(M, K, device=dev, generator=gen).to(torch.float16)
+        y = torch.empty(M, N, dtype=torch.float16, device=dev)
+        ds = [capi.W4A16Desc(M=M, N=N, K=K, group_size=128, A=x.data_ptr(), qweight=q.data_ptr(), scales=s_.data_ptr(), zeros=z.data_ptr(), C=y.data_ptr())
+              for (q, s_, z) in sets]
+        us = time_graph(lambda i, sp: capi.check(L.tce_w4a16_forward(C.byref(ds[i % len(ds)]), sp)), 16)
+        tf = 2.0 * M * N * K / us / 1e6
+        out["w4a16_prefill_gemm_M512"].append({"N": N, "K": K, "us": round(us, 1), "TFLOPs": round(tf, 1), "frac_of_2500_TFLOPs": round(tf / 2500.0, 3)})
+        del sets, ds
+    for (M, N, K) in ((512, 768, 768), (512, 3072, 768), (512, 768, 3072), (1, 768, 768)):
+        a = torch.randint(-128, 128, (M, K), dtype=torch.int8, device=dev)
+        b = torch.randint(-128, 128, (N, K), dtype=torch.int8, device=dev)
+        bias = torch.randint(-128, 128, (N,), dtype=torch.int8, device=dev)
+        o = torch.empty((M, N), dtype=torch.int8, device=dev)
+        d = capi.W8A8Desc(M=M, N=N, K=K, batch=1, A=a.data_ptr(), B=b.data_ptr(), bias=bias.data_ptr(), C=o.data_ptr(), alpha=0.0005, beta=0.02,
+                          q_min=-128, q_max=127, bias_kind=capi.TCE_BIAS_INT8, out_kind=capi.TCE_OUT_INT8)
+        us = time_graph(lambda i, sp: capi.check(L.tce_w8a8_matmul(C.byref(d), sp)), 64)
+        out["w8a8_opt125m"].append({"M": M, "N": N, "K": K, "us": round(us, 2), "TOPs": round(2.0 * M * N * K / us / 1e6, 1)})
+    torch.cuda.empty_cache()
+    return out
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -310,6 +374,13 @@ def main():
              "algorithmic_bytes_per_token_per_gpu": token_bytes_rank, "launches_per_token": n_launches,
              "event_ms_per_token": round(ev_ms_per_step, 4)}
 
+    extras = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        try:
+            extras = other_configs_leg(torch, dev)
+        except Exception as e:  # noqa: BLE001 -- never takes the headline number down with it
+            extras = {"error": f"{type(e).__name__}: {e}"}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -331,6 +402,8 @@ def main():
         }
         if roof is not None:
             out["roofline"] = roof
+        if extras is not None:
+            out["other_configs"] = extras
         if cpu is not None:
             main_cpu = cpu.get("avx") or cpu.get("ref")
             if main_cpu:
