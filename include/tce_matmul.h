@@ -239,9 +239,16 @@ TCE_API const char *tce_build_info(void);
  *                 workgroup (one workgroup per CU), depth in {0 = auto, 2, 3} units in flight.
  * TCE_ERR_BAD_ARG if that variant was not compiled. */
 TCE_API int tce_w4a16_set_gemv_config(int rows_per_wave, int waves_n, int waves_k, int depth);
-/* Roofline diagnostics for the GEMV kernel (scripts/tune.py): 0 = normal; 1 = stream the weights only (no unpack, no
- * dot products) to measure the memory-side ceiling of the access pattern (outputs meaningless); 2 = normal math plus
- * per-wave timestamps into the debug buffer.  M = 1 only. */
+/* Tuning / diagnostics switch for the sweeps under scripts/ (process-wide, not thread-safe, never needed by a host):
+ *   0..4     GEMV kernels, M = 1: 0 normal; 1 stream the weights only (no unpack, no dot products: the memory-side ceiling
+ *            of the access pattern, outputs meaningless); 2 normal math plus per-wave timestamps into the debug buffer;
+ *            3 / 4 further timing variants of the persistent kernel (w4a16_gemv_stream.hip)
+ *   20..30   small-batch kernel: 20 automatic, 21 / 22 / 24 / 28 waves per tile, 30 shared-activation form, 29 off
+ *   40..48   GEMM XCD grid rows: 40 automatic, 41 / 42 / 44 / 48 forced
+ *   50..52   LDS-DMA GEMM wave quartets per tile: 50 automatic, 51 one, 52 two
+ *   70..74   W8A8 wave quartets per tile: 70 automatic, 71 / 72 / 74 forced
+ *   1000+m   largest M the small-batch kernel takes (default 1128 = 128; 1016 restricts it to M <= 16)
+ * Every setting computes correct results except GEMV modes 1, 3, 4. */
 TCE_API int tce_w4a16_set_debug_mode(int mode);
 /* mode 2: every wave writes {start, x staged, math done, end} (100 MHz wall clock, 4 x u64 per wave) to this device buffer */
 TCE_API int tce_w4a16_set_debug_buffer(void *device_buffer);

@@ -106,7 +106,7 @@ int tce_w4a16_set_debug_mode(int mode) {
         tce::set_w8a8_ksplit(mode - 70);
         return TCE_OK;
     }
-    if (mode >= 50 && mode <= 65) {  // DMA GEMM timing experiments (wrong results by design)
+    if (mode >= 50 && mode <= 52) {  // LDS-DMA GEMM: wave quartets per tile (50 automatic)
         tce::set_gemm_dma_mode(mode - 50);
         return TCE_OK;
     }
