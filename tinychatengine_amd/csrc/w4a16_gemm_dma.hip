@@ -98,41 +98,6 @@ __global__ __launch_bounds__(256 * KS, (KS == 2 || MT * NT >= 16 ? 1 : 2)) void 
     const int nb0 = n_blk * BN;
     const int nchunks = g.K >> 5;
 
-    // ---- scales and zeros of the workgroup's rows, all k-blocks, once: batches of 8 independent loads per thread (a
-    // load -> store loop pays one memory latency per trip, 16 trips for K = 4096) ----
-    for (int base = tid; base < BN * ngr; base += NTHREADS * 8) {
-        half_t v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int idx = base + u * NTHREADS;
-            const int row = idx / ngr, gi = idx - row * ngr;
-            int n = nb0 + row;
-            n = n < g.N ? n : g.N - 1;
-            v[u] = idx < BN * ngr ? g.scales[(size_t)n * g.scales_stride + gi] : (half_t)0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int idx = base + u * NTHREADS;
-            if (idx < BN * ngr) lds_s[idx] = v[u];
-        }
-    }
-    for (int base = tid; base < BN * zw; base += NTHREADS * 4) {
-        unsigned v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int idx = base + u * NTHREADS;
-            const int row = idx / zw, wi = idx - row * zw;
-            int n = nb0 + row;
-            n = n < g.N ? n : g.N - 1;
-            v[u] = idx < BN * zw ? g.zeros[(size_t)n * g.zeros_stride + wi] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int idx = base + u * NTHREADS;
-            if (idx < BN * zw) lds_z[idx] = v[u];
-        }
-    }
-    __syncthreads();  // before the first DMA is in flight: from here on only bare barriers and counted waits
 
     // ---- DMA sources: instruction i of this wave fills the 1 KiB piece (i * 4 + wave) of a stage ----
     const char *a_src[MT];
@@ -279,8 +244,44 @@ __global__ __launch_bounds__(256 * KS, (KS == 2 || MT * NT >= 16 ? 1 : 2)) void 
     for (int j = 0; j < NT; ++j) wreg[j] = w_src[j][clampk(grp) * 4];
     issue(0, clampk(grp));
     issue(1, clampk(grp + KS));
-    wait_vmcnt<MT>();
-    __builtin_amdgcn_s_barrier();
+    // The tables are staged behind the first DMAs and weight loads, not in front of them (one memory latency less per launch).
+    // The __syncthreads below drains the whole queue (vmcnt(0)) -- both stages have landed for everyone, which is more than
+    // needed; from there on only bare barriers and counted waits.
+    // ---- scales and zeros of the workgroup's rows, all k-blocks, once: batches of 8 independent loads per thread (a
+    // load -> store loop pays one memory latency per trip, 16 trips for K = 4096) ----
+    for (int base = tid; base < BN * ngr; base += NTHREADS * 8) {
+        half_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * NTHREADS;
+            const int row = idx / ngr, gi = idx - row * ngr;
+            int n = nb0 + row;
+            n = n < g.N ? n : g.N - 1;
+            v[u] = idx < BN * ngr ? g.scales[(size_t)n * g.scales_stride + gi] : (half_t)0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * NTHREADS;
+            if (idx < BN * ngr) lds_s[idx] = v[u];
+        }
+    }
+    for (int base = tid; base < BN * zw; base += NTHREADS * 4) {
+        unsigned v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * NTHREADS;
+            const int row = idx / zw, wi = idx - row * zw;
+            int n = nb0 + row;
+            n = n < g.N ? n : g.N - 1;
+            v[u] = idx < BN * zw ? g.zeros[(size_t)n * g.zeros_stride + wi] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * NTHREADS;
+            if (idx < BN * zw) lds_z[idx] = v[u];
+        }
+    }
+    __syncthreads();
     int stage = 0;
     GroupConst gcur, gnext;
     read_group(gcur, grp);
