@@ -191,3 +191,24 @@ def test_layernorm_q_bit_exact(dev, oracle, m, n):
     want = oracle.layernorm_q(x, w, b)
     got = out.cpu().numpy()
     assert np.array_equal(got, want), f"{(got != want).sum()} of {got.size} int8 outputs differ"
+
+
+@pytest.mark.parametrize("M,N,K", [(65, 130, 208), (33, 65, 128), (512, 768, 768), (70, 33, 1136), (16, 16, 64)])
+def test_wave_quartets_per_tile_are_bit_exact(dev, oracle, M, N, K):
+    """The K range of a 64x64 tile cut between 1 / 2 / 4 wave quartets (debug modes 71 / 72 / 74) and the automatic choice: int32 partial
+    tiles are exact, so every setting must give the oracle's bytes -- odd step counts, a K tail (K % 64 != 0), fewer steps than quartets."""
+    from tinychatengine_amd import capi
+    from tinychatengine_amd.matmul import MatmulOperator
+    op = MatmulOperator()
+    L = capi.lib()
+    A, B, b8, _ = _data(M, N, K, seed=K + M)
+    exp = oracle.int8_matmul_bias_i8(A, B, b8, ALPHA, BETA, -128, 127, M, N, K)
+    try:
+        for mode in (71, 72, 74, 70):
+            capi.check(L.tce_w4a16_set_debug_mode(mode))
+            p, out = _params(dev, A, B, torch.int8, b8)
+            op.mat_mul_accelerator_int8_fast_2x2_32unroll(p)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), exp), f"mode {mode}: {(out.cpu().numpy() != exp).sum()} mismatches"
+    finally:
+        L.tce_w4a16_set_debug_mode(70)
