@@ -159,11 +159,36 @@ def roofline_leg(dl, torch, launches: int, eager: bool = False):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / (reps * launches)
     gbs = bytes_per_launch / us / 1e3
+    # spread: the same graph replayed 15 more times, each replay timed on its own (median and p10 / p90)
+    per = []
+    for _ in range(15):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); g.replay(); b.record(); torch.cuda.synchronize()
+        per.append(a.elapsed_time(b) * 1e3 / launches)
+    per.sort()
+    # a measured ceiling beside the 8 TB/s spec: plain 16-byte loads over 1 GiB of the same weights (tce_prefetch), nothing else
+    ceiling = None
+    try:
+        span = torch.empty(1 << 30, dtype=torch.uint8, device=torch.device("cuda", torch.cuda.current_device()))
+        for _ in range(2):
+            capi.check(L.tce_prefetch(C.c_void_p(span.data_ptr()), span.numel(), 0, stp))
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(4):
+            capi.check(L.tce_prefetch(C.c_void_p(span.data_ptr()), span.numel(), 0, stp))
+        b.record(); torch.cuda.synchronize()
+        ceiling = round(4 * span.numel() / (a.elapsed_time(b) * 1e-3) / 1e9, 1)
+        del span
+    except Exception:  # noqa: BLE001
+        ceiling = None
     return {
         "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
         **_pmc_traffic(bytes_per_launch),
         "kernel": f"w4a16_gemv_kernel (grouped gate+up launch, N={'+'.join(str(d.N) for d in d0)}, K={d0[0].K}, M={dl.m})",
         "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": round(us, 3), "launches_timed": reps * launches,
+        "launch_us_p10_p50_p90": [round(per[1], 3), round(per[len(per) // 2], 3), round(per[-2], 3)],
+        "measured_streaming_read_GBs": ceiling, "frac_of_measured_streaming_read": (round(gbs / ceiling, 4) if ceiling else None),
         "timing": "HIP events on the launch stream around graph-replayed back-to-back launches rotating over all layers' weights (includes inter-kernel gaps)",
     }
 
