@@ -393,7 +393,14 @@ def main():
                            ([(n, shape.hidden) for n in shape.qkv] + [(shape.hidden, shape.hidden), (shape.ffn, shape.hidden),
                                                                        (shape.ffn, shape.hidden), (shape.hidden, shape.ffn)]) * dl.n_layers
                            + [(shape.vocab, shape.hidden)])
-    roof = roofline_leg(dl, torch, args.roofline_launches) if (world == 1) else None
+    # the dominant kernel in isolation (at N > 1: this rank's row shard of it; purely local, every rank runs it so the ranks
+    # stay in step for the teardown)
+    try:
+        roof = roofline_leg(dl, torch, args.roofline_launches)
+        if world > 1:
+            roof["kernel"] += f", rows sharded {world}-way (this rank's shard)"
+    except Exception as e:  # noqa: BLE001 -- never takes the headline number down with it
+        roof = None if world > 1 else {"error": f"{type(e).__name__}: {e}"}
     whole = {"achieved_GBs_per_gpu": round(token_bytes_rank / (ev_ms_per_step * 1e-3) / 1e9, 1),
              "frac_of_8TBs": round(token_bytes_rank / (ev_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
              "algorithmic_bytes_per_token_per_gpu": token_bytes_rank, "launches_per_token": n_launches,
