@@ -444,9 +444,18 @@ def main():
                     out["cpu_baseline_ref_naive"] = cpu["ref"]
             else:
                 out["cpu_baseline"] = cpu
-        print(json.dumps(out))
+        line = json.dumps(out)
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL's banner sits in the C stdio buffer and would otherwise come out AFTER this line at exit: flush it first,
+        # so that the JSON line is the last line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
