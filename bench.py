@@ -445,17 +445,21 @@ def main():
             else:
                 out["cpu_baseline"] = cpu
         line = json.dumps(out)
+    # RCCL's banner sits in the C stdio buffer and would otherwise come out AFTER the JSON line at exit: every rank flushes
+    # its C streams, the ranks meet, and only then rank 0 prints -- the JSON line is the last line of the job's stdout
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+    sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    if rank == 0:
+        print(line, flush=True)
     if dist is not None:
         dist.destroy_process_group()
-    if rank == 0:
-        # RCCL's banner sits in the C stdio buffer and would otherwise come out AFTER this line at exit: flush it first,
-        # so that the JSON line is the last line of stdout
-        try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except Exception:  # noqa: BLE001
-            pass
-        print(line, flush=True)
 
 
 if __name__ == "__main__":
