@@ -44,6 +44,8 @@ def parse_args():
     ap.add_argument("--roofline-eager", action="store_true", help="roofline leg without graph capture (for rocprofv3 PMC passes)")
     ap.add_argument("--no-extras", action="store_true", help="skip the short prefill-GEMM / W8A8 legs (BASELINE configs 3 and 4) reported under \"other_configs\"")
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (RCCL init, gathers, graph capture) even with one rank")
+    ap.add_argument("--no-graph", action="store_true", help="N > 1: issue the token eagerly instead of capturing GEMVs + gathers into one graph")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (gloo + TCE_BENCH_SINGLE_DEVICE=1: exercise the multi-rank orchestration on one GPU)")
     ap.add_argument("--cpu-worker", default="", choices=["", "avx", "ref"], help=argparse.SUPPRESS)
     ap.add_argument("--threads", type=int, default=8, help=argparse.SUPPRESS)
     return ap.parse_args()
@@ -317,6 +319,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     capi.lib()
+    if os.environ.get("TCE_BENCH_SINGLE_DEVICE") == "1":  # debugging: every rank on GPU 0 (only meaningful with --backend gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -324,7 +328,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     shape = SHAPES[args.workload]
     G = 128
@@ -350,19 +357,29 @@ def main():
         n_launches = dl.n_layers * 4 + 1
         graph = None
         try:  # capture GEMVs + RCCL all-gathers of one token into one graph; fall back to eager issue if capture fails
+            if args.no_graph or args.backend != "nccl":
+                raise RuntimeError("graph capture not requested / not available with this backend")
             for _ in range(3):
                 dl.run_token_distributed(args.gathers_per_block)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):  # the RCCL watchdog thread may call HIP APIs meanwhile
                 dl.run_token_distributed(args.gathers_per_block)
             step = graph.replay
             mode = "one graph replay per token (GEMVs + RCCL all-gathers captured)"
         except Exception as e:  # noqa: BLE001
             if rank == 0:
                 print(f"[bench] graph capture of the distributed token failed ({type(e).__name__}: {e}); issuing eagerly", file=sys.stderr)
+            # a failed capture leaves hipErrorStreamCaptureInvalidated as the runtime's sticky last error, which the next
+            # launch's error check would report as its own: drain it before issuing eagerly
+            # torch.cuda.graph.__exit__ raises out of capture_end() before it restores the current stream: the dead capture
+            # stream would stay current and every eager launch would fail on it
+            torch.cuda.set_stream(torch.cuda.default_stream())
+            capi.lib().tce_reset_last_error()
+            torch.cuda.synchronize()
             step = lambda: dl.run_token_distributed(args.gathers_per_block)
             mode = "eager issue per token"
+
 
     def fence():
         if dist is not None:
@@ -427,7 +444,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "int4 weights x fp16 activations, fp32 accumulate", "data": "synthetic",
             "config": {"workload": f"W4A16 decode GEMV M=1, {shape.name}: {dl.n_layers} blocks x [qkv {list(shape.qkv)}, o {shape.hidden}, gate/up {shape.ffn}, down] + lm_head {shape.vocab}, group 128",
-                       "parallelism": f"tp{world} column-sharded, {args.gathers_per_block} RCCL all-gather(s) per block" if world > 1 else "single GPU",
+                       "parallelism": f"tp{world} column-sharded, {args.gathers_per_block} {'RCCL' if args.backend == 'nccl' else args.backend} all-gather(s) per block" if world > 1 else "single GPU",
                        "issue": mode, "grouped_launches": not args.ungrouped,
                        "algorithmic_bytes_per_token": token_bytes_full},
             "whole_token": whole,

@@ -232,6 +232,10 @@ TCE_API int tce_device_count(void);
 TCE_API int tce_version(void);
 TCE_API const char *tce_last_error(void);
 TCE_API const char *tce_build_info(void);
+/* Drops the HIP runtime's sticky last error (and this library's message).  For a host that recovers from a failure of
+ * its own -- e.g. a stream capture that was invalidated: the runtime keeps reporting hipErrorStreamCaptureInvalidated as the
+ * "last error", and the next launch's check here would return it as TCE_ERR_HIP.  Returns the HIP error code it dropped. */
+TCE_API int tce_reset_last_error(void);
 /* Force a GEMV kernel + launch geometry for every subsequent call from this process (all 0 = automatic).
  *   waves_k >= 1: the workgroup-per-row-block kernel: rows_per_wave in {1,2,4}, waves_n x waves_k waves per workgroup
  *                 (waves_k of them split K), depth = weight steps kept in flight per wave;

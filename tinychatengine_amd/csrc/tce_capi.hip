@@ -134,6 +134,17 @@ int tce_w4a16_set_debug_buffer(void *buf) {
     return TCE_OK;
 }
 
+int tce_reset_last_error(void) {
+    int first = 0;
+    for (int i = 0; i < 8; ++i) {  // hipGetLastError returns and clears; a few rounds in case several are queued
+        const hipError_t e = hipGetLastError();
+        if (e == hipSuccess) break;
+        if (!first) first = (int)e;
+    }
+    fail(TCE_OK, "");
+    return first;
+}
+
 int tce_malloc(void **ptr, size_t bytes, int managed) {
     if (!ptr || bytes == 0) return fail(TCE_ERR_BAD_ARG, "tce_malloc: bad argument");
     const hipError_t e = managed ? hipMallocManaged(ptr, bytes, hipMemAttachGlobal) : hipMalloc(ptr, bytes);
