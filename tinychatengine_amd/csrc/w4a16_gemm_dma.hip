@@ -240,8 +240,13 @@ __global__ __launch_bounds__(256 * KS, (KS == 2 || MT * NT >= 16 ? 1 : 2)) void 
     const int last = nkb - 1;
     auto clampk = [&](int kb) { return kb < nkb ? kb : last; };  // clamped, never predicated (a step past K is scaled by 0)
     uint4_t wreg[NT], wnext[NT];
+    uint4_t wodd[NT], wnext2[NT];  // KS == 1: weights are requested for two k-blocks at a time (see the loop)
 #pragma unroll
     for (int j = 0; j < NT; ++j) wreg[j] = w_src[j][clampk(grp) * 4];
+    if constexpr (KS == 1) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wodd[j] = w_src[j][clampk(1) * 4];
+    }
     issue(0, clampk(grp));
     issue(1, clampk(grp + KS));
     // The tables are staged behind the first DMAs and weight loads, not in front of them (one memory latency less per launch).
@@ -285,26 +290,67 @@ __global__ __launch_bounds__(256 * KS, (KS == 2 || MT * NT >= 16 ? 1 : 2)) void 
     int stage = 0;
     GroupConst gcur, gnext;
     read_group(gcur, grp);
-    for (int kb = grp; kb < nkb + grp; kb += KS) {  // both quartets take the same number of steps (and barriers)
-        const int n1 = clampk(kb + KS);
-        const int n2 = clampk(kb + 2 * KS);
-        // The weight loads are inline asm: left to hipcc they sink to the end of the step and are answered with vmcnt(0)
-        // (one exposed memory latency per k-block, and the DMAs of block kb+2 drained with them).
+    if constexpr (KS == 1) {
+        // One quartet: a row's 64 bytes of one k-block are half a cache line, and by the next step the other half has left
+        // L1 (the step moves 24 KiB through it) -- every weight line would come from L2 twice.  So the words of TWO k-blocks
+        // are requested together at every even step (two back-to-back loads on the same lines); with two quartets the
+        // alternating k-blocks do the same thing by themselves.
+        for (int kb = 0; kb < nkb; kb += 2) {
+            {  // even step kb: wreg = block kb, wodd = block kb+1 are in registers
 #pragma unroll
-        for (int j = 0; j < NT; ++j) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wnext[j]) : "v"(w_src[j] + n1 * 4) : "memory");
-        issue(stage >= 1 ? stage - 1 : 2, n2);
-        read_group(gnext, kb + KS);
-        compute(wreg, gcur, stage);
-        gcur = gnext;
-        wait_vmcnt<MT>();
+                for (int j = 0; j < NT; ++j) {
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wnext[j]) : "v"(w_src[j] + clampk(kb + 2) * 4) : "memory");
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wnext2[j]) : "v"(w_src[j] + clampk(kb + 3) * 4) : "memory");
+                }
+                issue(stage >= 1 ? stage - 1 : 2, clampk(kb + 2));
+                read_group(gnext, kb + 1);
+                compute(wreg, gcur, stage);
+                gcur = gnext;
+                wait_vmcnt<2 * NT + MT>();  // leaves this step's weight pairs and DMAs in flight; stage kb+1 has landed
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                stage = stage == 2 ? 0 : stage + 1;
+            }
+            if (kb + 1 >= nkb) break;
+            {  // odd step kb+1
+                issue(stage >= 1 ? stage - 1 : 2, clampk(kb + 3));
+                read_group(gnext, kb + 2);
+                compute(wodd, gcur, stage);
+                gcur = gnext;
+                wait_vmcnt<MT>();  // everything but the DMAs just issued: the weight pairs and stage kb+2
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            asm volatile("" : "+v"(wnext[j]));  // the registers are valid from here on, not before
-            wreg[j] = wnext[j];
+                for (int j = 0; j < NT; ++j) {
+                    asm volatile("" : "+v"(wnext[j]), "+v"(wnext2[j]));  // valid from here on, not before
+                    wreg[j] = wnext[j];
+                    wodd[j] = wnext2[j];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                stage = stage == 2 ? 0 : stage + 1;
+            }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        stage = stage == 2 ? 0 : stage + 1;
+    } else {
+    for (int kb = grp; kb < nkb + grp; kb += KS) {  // both quartets take the same number of steps (and barriers)
+            const int n1 = clampk(kb + KS);
+            const int n2 = clampk(kb + 2 * KS);
+            // The weight loads are inline asm: left to hipcc they sink to the end of the step and are answered with vmcnt(0)
+            // (one exposed memory latency per k-block, and the DMAs of block kb+2 drained with them).
+    #pragma unroll
+            for (int j = 0; j < NT; ++j) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wnext[j]) : "v"(w_src[j] + n1 * 4) : "memory");
+            issue(stage >= 1 ? stage - 1 : 2, n2);
+            read_group(gnext, kb + KS);
+            compute(wreg, gcur, stage);
+            gcur = gnext;
+            wait_vmcnt<MT>();
+    #pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                asm volatile("" : "+v"(wnext[j]));  // the registers are valid from here on, not before
+                wreg[j] = wnext[j];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            stage = stage == 2 ? 0 : stage + 1;
+        }
     }
     wait_vmcnt<0>();
     __syncthreads();  // every wave's last (clamped, redundant) DMAs have landed: the stages may be overwritten
