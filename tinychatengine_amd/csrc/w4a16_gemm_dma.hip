@@ -6,22 +6,28 @@
 // gives 1.7-2.2 PFLOP/s for MFMAs + activation-fragment LDS reads, 1.0-1.4 with unpack, scaling and weight loads added, and
 // 0.5-0.9 once the activation tile is staged global -> registers -> permute -> ds_write -> barrier: that staging chain,
 // serial with the MFMAs of every k-block, is what holds the older kernel at 0.5-0.65 PFLOP/s.  Here
-//   * the activation tile (BM x 128 halves) and the packed weight tile (BN x 64 bytes) of a k-block are fetched with
-//     LDS-DMA loads: no staging registers, no ds_write pass, no VALU.  A DMA writes lane-linear (wave-uniform base +
-//     lane * 16), so the bank swizzle sits on the SOURCE side: the lane that fills position p of row r fetches the row's
-//     piece p ^ (r % 16) (activations, 16 pieces of 16 bytes per row) or chunk p ^ (r / 4 % 4) (weights, 4 chunks per
-//     row), and the fragment reads apply the same involution -- every ds_read_b128 touches all 16 slots of a bank row,
-//     and every DMA instruction still reads whole contiguous rows (4 x 256 bytes / 16 x 64 bytes);
+//   * the activation tile (BM x 128 halves) of a k-block is fetched with LDS-DMA loads: no staging registers, no ds_write
+//     pass, no VALU.  A DMA writes lane-linear (wave-uniform base + lane * 16), so the bank swizzle sits on the SOURCE
+//     side: the lane that fills position p of row r fetches the piece that belongs there, and the fragment reads apply the
+//     same involution (position n16 ^ s ^ h(q), see the kernel); every DMA instruction still reads whole contiguous rows
+//     (4 x 256 bytes), every ds_read_b128 touches all 16 slots of a bank row;
 //   * three stages in LDS: the DMAs of block kb+2 are issued before the MFMAs of block kb, the wait at the end of a step
 //     is a COUNTED vmcnt that leaves them in flight, and the barrier is a bare s_barrier (a __syncthreads would drain the
 //     queue: vmcnt(0));
+//   * the weight words stay in registers as in the older kernel (a lane's 16-byte chunk = its four MFMA steps), but are
+//     loaded by inline asm one step ahead: left to hipcc the loads sink to the end of the step and are answered with
+//     vmcnt(0), which exposes a memory latency per k-block and drains the DMAs with it (a first version moved the weights
+//     by DMA as well: no faster);
 //   * since the activation image is now the plain row-major tile, the pair order the one-instruction nibble masks produce
 //     ((k, k+4) in one register) no longer fits; the weights are unpacked in natural order instead: byte r of a word
 //     holds k = 2r (low nibble) and 2r+1 (high nibble); v_perm copies it to bytes 0 and 2, one v_and_or leaves
 //     (1024 + q_lo, 1024 + 16 q_hi), one packed fma with per-half constants (1, 1/16) and (-(1024+z), -(64+z)) gives
 //     (q_lo - z, q_hi - z) exactly: 12 VALU per word against 9, paid for by the activation permute that is gone;
-//   * the group scales and packed zeros of the workgroup's rows are staged into LDS once, so the k loop contains no
-//     register-returning global load at all (hipcc answers one of those with vmcnt(0) while a DMA is in flight).
+//   * the group scales and packed zeros of the workgroup's rows are staged into LDS once (behind the first DMAs) and read one
+//     step ahead; fragments are double-buffered by hand between fenced regions; the output tile leaves through LDS as
+//     16-byte row pieces.
+// Forms: one or two wave quartets per tile (KS), group sizes 128 / 64 / 32 (LG); tile, form and XCD grid are chosen per
+// launch (choose_tile, launch<>).
 #include "tce_common.hpp"
 #include "w4a16_kernels.hpp"
 
