@@ -312,7 +312,7 @@ int tce_w4a16_forward(const tce_w4a16_desc *d, void *stream) {
         if (rc != TCE_ERR_UNSUPPORTED_SHAPE) return fail(rc, "w4a16 gemm (dma): no kernel variant for this config");
     }
     if (want_gemm && d->K % 128 == 0 && d->group_size == 128) {  // other group sizes without a GEMM form: GEMV kernel, 4 rows per pass
-        if (g_gemm_mt >= 200 || (g_gemm_mt == 0 && d->M > 128)) {  // (up to 128 rows the table prologue outweighs the gain: 23.7 vs 28.4 us at M = 128)  // the LDS-DMA kernel (w4a16_gemm_dma.hip): the default, or forced by tile ids 200 + m_tiles
+        if (g_gemm_mt >= 200 || g_gemm_mt == 0) {  // the LDS-DMA kernel: the default (every M the GEMV / small-batch kernels leave), or forced by tile ids 200 + m_tiles  // the LDS-DMA kernel (w4a16_gemm_dma.hip): the default, or forced by tile ids 200 + m_tiles
             const int rc = tce::launch_w4a16_gemm_dma(*d, g_gemm_mt ? g_gemm_mt - 200 : 0, g_gemm_mt ? g_gemm_nt : 0, static_cast<hipStream_t>(stream), &he);
             if (rc == TCE_OK) return TCE_OK;
             if (rc == TCE_ERR_HIP) return hip_fail(he, "w4a16 gemm (dma) launch");

@@ -1,6 +1,6 @@
-// w4a16_gemm.hip -- W4A16 dequant-GEMM on MFMA for gfx950: the first, register-staged kernel.  The dispatcher now uses it for
-// 17 <= M <= 128 where the small-batch kernel does not apply and as the fallback of w4a16_gemm_dma.hip (which is 7-27 % faster
-// from M = 129 up and explains why); its tiles stay selectable (tce_w4a16_set_gemm_config) as the baseline of the sweeps.
+// w4a16_gemm.hip -- W4A16 dequant-GEMM on MFMA for gfx950: the first, register-staged kernel.  The dispatcher now uses it only as
+// the fallback of w4a16_gemm_dma.hip (which is 7-30 % faster and explains why); its tiles stay selectable
+// (tce_w4a16_set_gemm_config) as the baseline of the sweeps.
 //
 // The reference has no GEMM kernel on this layout: gemv_forward_cuda re-runs its GEMV once per input row
 // (grid.z = M, kernels/cuda/gemv_cuda.cu:229-231) and gemm_forward_cuda* are declared but never defined

@@ -493,7 +493,7 @@ hipError_t launch(const DmaGemmArgs &g0, int ks, hipStream_t stream) {
 // small: 688 workgroups on 512 slots cost two rounds, 344 on 512 one.  c (us per k-block, measured, profiles/r1/
 // gemm_dma_sweep.jsonl / gemm_dma_ksplit.jsonl): 64x128 1.2, 64x64 1.0, 64x128 two quartets 0.92, 64x64 two quartets 0.6,
 // 32x128 two quartets 0.7, 128x128 1.55; slots per CU: 2, 2, 1, 1, 1, 1.
-void choose_tile(int M, int N, bool g128, int *mt, int *nt, int *ks) {
+float choose_tile(int M, int N, bool g128, int *mt, int *nt, int *ks) {  // returns the winning cost per k-block, us
     static const struct { int mt, nt, ks, slots_per_cu; float c; } cand[] = {
         {4, 2, 1, 2, 1.2f}, {4, 1, 1, 2, 1.0f}, {4, 2, 2, 1, 0.92f}, {4, 1, 2, 1, 0.6f}, {2, 2, 2, 1, 0.70f}, {8, 2, 1, 1, 1.55f}};
     float best = 0.f;
@@ -510,11 +510,17 @@ void choose_tile(int M, int N, bool g128, int *mt, int *nt, int *ks) {
             *ks = c.ks;
         }
     }
+    return best;
 }
 
 }  // namespace
 
 void set_gemm_dma_mode(int mode) { g_dma_ks = mode & 3; }
+
+float gemm_dma_estimate_us(int M, int N, int K) {
+    int mt, nt, ks;
+    return choose_tile(M, N, true, &mt, &nt, &ks) * (float)(K / 128);
+}
 void set_gemm_dma_xcd_rows(int xm) { g_dma_xm = (xm == 1 || xm == 2 || xm == 4 || xm == 8) ? xm : 0; }
 
 int launch_w4a16_gemm_dma(const tce_w4a16_desc &d, int mt, int nt, hipStream_t stream, hipError_t *hip_err) {

@@ -373,11 +373,10 @@ bool skinny_supports(const tce_w4a16_desc &d) {
     if (d.M <= 16) return true;
     // 17 <= M <= 128: 16-row slices of the batch on gridDim.y against the MFMA GEMM, whose 64-row tiles leave most CUs idle
     // when N is small (4096 x 4096, M = 32: 64 workgroups, 24 us; here 8.8 us) and win once there are enough of them
-    // (22016 x 4096 from M = 24).  Both estimates in us, fitted to profiles/r1/gemv_small_batch_sweep.jsonl (second block).
+    // (22016 x 4096 from M = 24).  Both estimates in us, fitted to profiles/r1/m_sweep_17_384.jsonl and gemm_dma_*.jsonl.
     const float scale = (float)d.N / 4096.f * (float)d.K / 4096.f;
     const float here = (4.0f + 2.3f * (float)((d.M + 15) / 16)) * scale;
-    const long gemm_wgs = (long)((d.M + 63) / 64) * ((d.N + 63) / 64);
-    const float gemm = 1.2f * (float)((gemm_wgs + 511) / 512) * (float)(d.K / 128) * 0.72f;
+    const float gemm = gemm_dma_estimate_us(d.M, d.N, d.K);  // (fitted to the same sweeps; 16.6 us measured at M = 128, 4096 x 4096 against 19.2)
     return here < gemm;
 }
 
