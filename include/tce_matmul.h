@@ -115,6 +115,15 @@ TCE_API int tce_w4a16_forward(const tce_w4a16_desc *d, void *stream);
  *   tce_add_half:       c[i] = hadd(a[i], b[i])                                   (add_half, Int4llamaDecoderLayer.cu:12-18)
  *   tce_silu_mul_half:  a[i] = hmul(hmul(a[i], hdiv(1, hadd(1, hexp(-a[i])))), b[i])  (SiLuMul_half, :20-30)
  * n halves; pointers 16-byte aligned; c may alias a or b. */
+/* The two fp16 operators between the q/k/v and the o linears of the reference's Llama attention, with its
+ * arithmetic (see csrc/attention_ops.hip):
+ *   tce_bmm_f16t     <- BMM_F16T::forward / mat_mul_transposed_cuda (llm/src/ops/cuda/BMM_F16T.cu:28-76):
+ *                       A fp16 [batch][M][K], B fp16 [batch][N][K], C fp16 [batch][M][N];
+ *                       C = hmul(alpha, acc), acc = hfma(A[i][k], B[j][k], acc) for k ascending (binary16 accumulation);
+ *                       alpha as binary16 bits (what alpha_half.bin holds)
+ *   tce_softmax_half <- softmax_cuda (llm/src/ops/cuda/softmax.cu:4-40): rows of n binary16 values */
+TCE_API int tce_bmm_f16t(const void *A, const void *B, void *C, int batch, int M, int N, int K, unsigned short alpha_half_bits, void *stream);
+TCE_API int tce_softmax_half(const void *x, void *out, long long rows, int n, void *stream);
 /* Reads [ptr, ptr + bytes) with at most `workgroups` workgroups (0 = as many as the range needs) and discards the data: the
  * range then sits in the memory-side cache (256 MiB) for the launch that needs it.  Meant for a side stream / graph branch
  * next to the launch BEFORE that one (no reference counterpart: cudaMallocManaged prefetching is the closest idea). */

@@ -216,6 +216,32 @@ class Oracle(_Lib):
         self.lib.orc_rmsnorm_half(_p(x.view(np.uint16)), _p(g), _p(out), C.c_int(m), C.c_int(n), C.c_float(eps))
         return out.view(np.float16)
 
+    # ---- attention ops (PARITY UNPINNED: CUDA-only in the reference; see tce_oracle.c) ----
+    def hfma(self, a_bits: int, b_bits: int, c_bits: int) -> int:
+        self.lib.orc_hfma.restype = C.c_uint16
+        self.lib.orc_hfma.argtypes = [C.c_uint16] * 3
+        return int(self.lib.orc_hfma(a_bits, b_bits, c_bits))
+
+    def bmm_f16t(self, A_f16, B_f16, alpha_f16) -> np.ndarray:
+        """A [batch][M][K], B [batch][N][K] -> C [batch][M][N] = hmul(alpha, sequential hfma over k) (BMM_F16T.cu:28-45)."""
+        A = np.ascontiguousarray(A_f16, np.float16); B = np.ascontiguousarray(B_f16, np.float16)
+        batch, M, K = A.shape
+        N = B.shape[1]
+        out = np.empty((batch, M, N), np.uint16)
+        alpha = int(np.array([alpha_f16], np.float16).view(np.uint16)[0])
+        self.lib.orc_bmm_f16t.argtypes = [C.c_int] * 4 + [C.c_void_p] * 3 + [C.c_uint16]
+        self.lib.orc_bmm_f16t(batch, M, N, K, _p(A.view(np.uint16)), _p(B.view(np.uint16)), _p(out), alpha)
+        return out.view(np.float16)
+
+    def softmax_half(self, x_f16) -> np.ndarray:
+        """rows of the last dimension, softmax_cuda's arithmetic (softmax.cu:4-40)."""
+        x = np.ascontiguousarray(x_f16, np.float16)
+        n = x.shape[-1]
+        out = np.empty(x.shape, np.uint16)
+        self.lib.orc_softmax_half.argtypes = [C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+        self.lib.orc_softmax_half(x.size // n, n, _p(x.view(np.uint16)), _p(out))
+        return out.view(np.float16)
+
     def fp32_matmul_transposed(self, A, B, bias, M, N, K):
         A = np.ascontiguousarray(A, np.float32); B = np.ascontiguousarray(B, np.float32)
         bias = None if bias is None else np.ascontiguousarray(bias, np.float32)

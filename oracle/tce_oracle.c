@@ -628,3 +628,116 @@ ORC_API void orc_layernorm_q(const float *x, const float *w, const float *b, int
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* Attention ops either side of the int4 linears.  PARITY UNPINNED: the reference implements these */
+/* only as CUDA kernels (llm/src/ops/cuda/BMM_F16T.cu, softmax.cu), which cannot be built or run here; what follows   */
+/* restates their arithmetic operation by operation.  The binary16 fused multiply-add is exact (integer arithmetic),  */
+/* hexp is modelled as the C library's expf rounded to binary16 (CUDA's hexp is an approximation of its own).         */
+/* ------------------------------------------------------------------------------------------------------------------ */
+
+/* value of a finite binary16 as m * 2^e with integer m (|m| < 2^11) */
+static void orc_half_parts(uint16_t h, int64_t *m, int *e) {
+    const int exp = (h >> 10) & 0x1F;
+    const int64_t man = h & 0x3FF;
+    int64_t mm;
+    int ee;
+    if (exp == 0) { mm = man; ee = -24; }
+    else { mm = man | 0x400; ee = exp - 25; }
+    *m = (h & 0x8000u) ? -mm : mm;
+    *e = ee;
+}
+
+/* round (sign, magnitude * 2^-72) to binary16, nearest even; magnitude is an exact integer */
+static uint16_t orc_round_i128_to_half(int neg, unsigned __int128 mag) {
+    const uint16_t sign = neg ? 0x8000u : 0;
+    if (mag == 0) return sign;
+    int msb = 127;
+    while (!((mag >> msb) & 1)) msb--;
+    /* value = mag * 2^-72; the leading bit has weight 2^(msb - 72) */
+    int e = msb - 72;
+    int drop; /* low bits to drop so that 11 bits (normal) or fewer (subnormal) remain */
+    if (e >= -14) drop = msb - 10;
+    else drop = (-24) + 72; /* subnormal: keep multiples of 2^-24 */
+    unsigned __int128 kept, rem, half;
+    if (drop <= 0) {
+        kept = mag << (-drop);
+        rem = 0;
+        half = 1;
+    } else {
+        kept = mag >> drop;
+        rem = mag & ((((unsigned __int128)1) << drop) - 1);
+        half = ((unsigned __int128)1) << (drop - 1);
+    }
+    if (rem > half || (rem == half && (kept & 1))) kept++;
+    if (e >= -14) {
+        if (kept == 2048) { kept = 1024; e++; }
+        if (e > 15) return (uint16_t)(sign | 0x7C00u);
+        return (uint16_t)(sign | (uint16_t)((e + 15) << 10) | (uint16_t)(kept - 1024));
+    }
+    return (uint16_t)(sign | (uint16_t)kept); /* kept <= 1024: 1024 is the smallest normal, encoded correctly */
+}
+
+/* __hfma(a, b, c): a * b + c with ONE rounding (finite inputs; inf / nan are not produced by the tests' data) */
+ORC_API uint16_t orc_hfma(uint16_t a, uint16_t b, uint16_t c) {
+    int64_t ma, mb, mc;
+    int ea, eb, ec;
+    orc_half_parts(a, &ma, &ea);
+    orc_half_parts(b, &mb, &eb);
+    orc_half_parts(c, &mc, &ec);
+    /* everything in units of 2^-72: products have e >= -48, addends e >= -24, so all shifts are >= 0 and < 104 bits */
+    __int128 p = (__int128)(ma * mb);
+    p = p * ((__int128)1 << (ea + eb + 72));
+    __int128 q = (__int128)mc * ((__int128)1 << (ec + 72));
+    __int128 s = p + q;
+    if (s == 0) {
+        /* exact zero: +0 unless both terms are negative zeros (RNE) */
+        const int pneg = ((a ^ b) & 0x8000u) != 0, cneg = (c & 0x8000u) != 0;
+        return (pneg && cneg) ? 0x8000u : 0;
+    }
+    const int neg = s < 0;
+    return orc_round_i128_to_half(neg, (unsigned __int128)(neg ? -s : s));
+}
+
+static uint16_t orc_hop(double v) { return orc_f64_to_f16(v); } /* one binary16 rounding of an exactly computed double */
+
+/* BMM_F16T::forward -> mat_mul_transposed_cuda (llm/src/ops/cuda/BMM_F16T.cu:28-45): per batch b, C[i][j] =
+ * __hmul(alpha, acc) with acc = 0; acc = __hfma(A[i][k], B[j][k], acc) for k ascending.  A [batch][M][K], B [batch][N][K],
+ * C [batch][M][N], all binary16.  Both attention products of Int4llamaAttention use it (qk with alpha = 1/sqrt(head_dim) as
+ * stored, pv with alpha = 1 on the transposed V: Int4llamaAttention.cu:185, 211). */
+ORC_API void orc_bmm_f16t(int batch, int M, int N, int K, const uint16_t *A, const uint16_t *B, uint16_t *C, uint16_t alpha) {
+    const double al = (double)orc_f16_to_f32(alpha);
+    for (int b = 0; b < batch; b++)
+        for (int i = 0; i < M; i++)
+            for (int j = 0; j < N; j++) {
+                const uint16_t *a = A + ((int64_t)b * M + i) * K;
+                const uint16_t *w = B + ((int64_t)b * N + j) * K;
+                uint16_t acc = 0;
+                for (int k = 0; k < K; k++) acc = orc_hfma(a[k], w[k], acc);
+                C[((int64_t)b * M + i) * N + j] = orc_hop(al * (double)orc_f16_to_f32(acc)); /* 11 x 11 bits: exact in double */
+            }
+}
+
+/* softmax_cuda (llm/src/ops/cuda/softmax.cu:4-40): per row, max by comparison from -65504; sum = __hadd(sum,
+ * hexp(__hsub(x, max))) for k ascending; out = __hdiv(hexp(__hsub(x, max)), sum). */
+ORC_API void orc_softmax_half(int64_t rows, int n, const uint16_t *x, uint16_t *out) {
+    for (int64_t r = 0; r < rows; r++) {
+        const uint16_t *xr = x + r * n;
+        float mx = -65504.0f;
+        for (int k = 0; k < n; k++) {
+            const float v = orc_f16_to_f32(xr[k]);
+            mx = mx > v ? mx : v;
+        }
+        uint16_t sum = 0;
+        for (int k = 0; k < n; k++) {
+            const uint16_t d = orc_hop((double)orc_f16_to_f32(xr[k]) - (double)mx);
+            const uint16_t e = orc_f32_to_f16(expf(orc_f16_to_f32(d)));
+            sum = orc_hop((double)orc_f16_to_f32(sum) + (double)orc_f16_to_f32(e));
+        }
+        for (int k = 0; k < n; k++) {
+            const uint16_t d = orc_hop((double)orc_f16_to_f32(xr[k]) - (double)mx);
+            const uint16_t e = orc_f32_to_f16(expf(orc_f16_to_f32(d)));
+            out[r * n + k] = orc_hop((double)orc_f16_to_f32(e) / (double)orc_f16_to_f32(sum));
+        }
+    }
+}

@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""Decode-time attention operators (32 heads, head_dim 128) at a few context lengths: us per call, hipGraph of 32 calls."""
+import ctypes as C, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import numpy as np, torch
+from tune import dev, time_graph, capi
+L = capi.lib()
+for t in (128, 512, 2048):
+    q = torch.randn(32, 1, 128, device=dev).half(); k = torch.randn(32, t, 128, device=dev).half()
+    s = torch.empty(32, 1, t, dtype=torch.float16, device=dev); p = torch.empty_like(s)
+    vt = torch.randn(32, 128, t, device=dev).half(); o = torch.empty(32, 1, 128, dtype=torch.float16, device=dev)
+    one = int(np.array([1.0], np.float16).view(np.uint16)[0]); al = int(np.array([0.0884], np.float16).view(np.uint16)[0])
+    row = {"context": t}
+    row["qk_us"] = round(time_graph(lambda i, sp: capi.check(L.tce_bmm_f16t(q.data_ptr(), k.data_ptr(), s.data_ptr(), 32, 1, t, 128, al, sp)), 32), 2)
+    row["softmax_us"] = round(time_graph(lambda i, sp: capi.check(L.tce_softmax_half(s.data_ptr(), p.data_ptr(), 32, t, sp)), 32), 2)
+    row["pv_us"] = round(time_graph(lambda i, sp: capi.check(L.tce_bmm_f16t(p.data_ptr(), vt.data_ptr(), o.data_ptr(), 32, 1, 128, t, one, sp)), 32), 2)
+    print(json.dumps(row), flush=True)

@@ -1,0 +1,75 @@
+"""GPU parity of the attention operators around the int4 linears against the oracle's restatement of the reference's CUDA
+arithmetic (PARITY UNPINNED: those kernels exist only as CUDA; the binary16 fma primitive itself is pinned to exact rational arithmetic in
+tests/test_oracle.py).  BMM_F16T: bit-exact.  softmax: exact except where the device exponential and libm differ in the last float bit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from tinychatengine_amd import capi
+    capi.lib()
+    return torch.device("cuda:0")
+
+
+# (batch = heads, M = query rows, N = keys, K = head_dim): decode q k^T, decode p v on the transposed V (K = keys), prefill-like, odd sizes
+BMM_SHAPES = [(32, 1, 777, 128), (32, 1, 128, 777), (4, 9, 9, 128), (3, 5, 70, 96), (2, 3, 11, 13), (1, 1, 1, 1), (2, 17, 300, 64)]
+
+
+@pytest.mark.parametrize("batch,M,N,K", BMM_SHAPES)
+def test_bmm_f16t_bit_exact(dev, oracle, batch, M, N, K):
+    from tinychatengine_amd.attention_ops import BMM_F16T
+    rng = np.random.default_rng(batch * 1000 + M + N + K)
+    A = (rng.standard_normal((batch, M, K)) * 0.7).astype(np.float16)
+    B = (rng.standard_normal((batch, N, K)) * 0.7).astype(np.float16)
+    A[0, 0, : min(K, 3)] = np.float16(6e-5)  # subnormal products on the way
+    for alpha in (0.08838834764831845, 1.0):  # 1/sqrt(128) as alpha_half.bin stores it; the p v product's 1.0
+        want = oracle.bmm_f16t(A, B, np.float16(alpha))
+        c = torch.full((batch, M, N), float("nan"), dtype=torch.float16, device=dev)
+        BMM_F16T(alpha).forward(torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev), c)
+        torch.cuda.synchronize()
+        got = c.cpu().numpy()
+        assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), f"alpha {alpha}: {(got.view(np.uint16) != want.view(np.uint16)).sum()} of {got.size} differ"
+
+
+def test_bmm_f16t_unaligned_rows_take_the_scalar_path(dev, oracle):
+    """K % 8 != 0 or a base that is not 16-byte aligned: same bits through the element-wise loop."""
+    from tinychatengine_amd import capi
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    batch, M, N, K = 2, 3, 40, 72
+    A = (rng.standard_normal((batch, M, K))).astype(np.float16)
+    B = (rng.standard_normal((batch, N, K))).astype(np.float16)
+    want = oracle.bmm_f16t(A, B, np.float16(0.5))
+    bufa = torch.zeros(A.size + 1, dtype=torch.float16, device=dev)
+    bufa[1:] = torch.from_numpy(A.reshape(-1)).to(dev)  # offset by 2 bytes
+    tb = torch.from_numpy(B).to(dev)
+    c = torch.empty((batch, M, N), dtype=torch.float16, device=dev)
+    alpha_bits = int(np.array([0.5], np.float16).view(np.uint16)[0])
+    capi.check(capi.lib().tce_bmm_f16t(C.c_void_p(bufa.data_ptr() + 2), C.c_void_p(tb.data_ptr()), C.c_void_p(c.data_ptr()), batch, M, N, K, alpha_bits, None))
+    torch.cuda.synchronize()
+    assert np.array_equal(c.cpu().numpy().view(np.uint16), want.view(np.uint16))
+
+
+@pytest.mark.parametrize("rows,n", [(32, 777), (32, 1), (5, 64), (3, 2049), (64, 130)])
+def test_softmax_half_matches_oracle(dev, oracle, rows, n):
+    from tinychatengine_amd.attention_ops import softmax
+    rng = np.random.default_rng(rows + n)
+    x = (rng.standard_normal((rows, n)) * 4).astype(np.float16)
+    x[0, :] = x[0, 0]            # a constant row
+    if n > 2:
+        x[-1, 1] = np.float16(-60000.0)  # an entry that underflows to 0
+    want = oracle.softmax_half(x)
+    got = softmax(torch.from_numpy(x).to(dev)).cpu().numpy()
+    assert not np.isnan(got.astype(np.float32)).any()
+    diff = got.view(np.uint16).astype(np.int32) - want.view(np.uint16).astype(np.int32)
+    # expf on the device vs libm: a last-bit difference in float moves the binary16 exponential only when it sits on a rounding boundary; the
+    # sum then moves by at most an ulp and with it every quotient of that row
+    assert np.abs(diff).max() <= 2, f"worst difference {np.abs(diff).max()} binary16 steps"
+    assert (diff != 0).mean() <= 0.35, f"{(diff != 0).mean():.3f} of the elements differ"
+    assert np.abs(got.astype(np.float64).sum(axis=1) - 1.0).max() < 0.05

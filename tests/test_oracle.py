@@ -213,3 +213,73 @@ def test_layernorm_q_restatement(oracle):
         f = ((x[r] - mean) / std * w + b).astype(np.float32)
         want[r] = np.where(f >= 0, np.floor(f + np.float32(0.5)), np.ceil(f - np.float32(0.5))).astype(np.int8)
     assert np.array_equal(got, want)
+
+
+def _round_fraction_to_half_bits(v):
+    """Independent restatement: exact rational -> binary16 bits, round to nearest even (finite range)."""
+    from fractions import Fraction
+    if v == 0:
+        return 0
+    sign = 0x8000 if v < 0 else 0
+    a = abs(v)
+    e = 0
+    while a >= 2:
+        a /= 2; e += 1
+    while a < 1:
+        a *= 2; e -= 1
+    if e < -14:  # subnormal: multiples of 2^-24
+        q = abs(v) / Fraction(1, 2 ** 24)
+        k = int(q)
+        r = q - k
+        if r > Fraction(1, 2) or (r == Fraction(1, 2) and (k & 1)):
+            k += 1
+        return sign | k
+    q = a * 1024  # in [1024, 2048)
+    k = int(q)
+    r = q - k
+    if r > Fraction(1, 2) or (r == Fraction(1, 2) and (k & 1)):
+        k += 1
+    if k == 2048:
+        k = 1024; e += 1
+    if e > 15:
+        return sign | 0x7C00
+    return sign | ((e + 15) << 10) | (k - 1024)
+
+
+def test_hfma_is_one_exact_rounding(oracle):
+    """orc_hfma (the primitive of the attention BMM restatement) against exact rational arithmetic with an independent
+    rounding routine: random finite halves, subnormals, ties, cancellations."""
+    from fractions import Fraction
+    rng = np.random.default_rng(7)
+    def val(bits):
+        return Fraction(float(np.array([bits], np.uint16).view(np.float16)[0]))
+    cases = []
+    for _ in range(3000):
+        a, b, c = (int(x) for x in rng.integers(0, 0x7C00, 3))
+        s = [int(x) << 15 for x in rng.integers(0, 2, 3)]
+        cases.append((a | s[0], b | s[1], c | s[2]))
+    cases += [(0x0001, 0x0001, 0x0001), (0x3C00, 0x3C00, 0xBC00), (0x3C01, 0x3C01, 0xBC02), (0x7BFF, 0x3C00, 0x0001), (0x0400, 0x3800, 0x8200),
+              (0x3555, 0x4200, 0x8001), (0x0001, 0x3C00, 0x8001)]
+    for a, b, c in cases:
+        exact = val(a) * val(b) + val(c)
+        want = _round_fraction_to_half_bits(exact)
+        got = oracle.hfma(a, b, c)
+        if exact == 0:
+            assert got in (0, 0x8000)
+        else:
+            assert got == want, (hex(a), hex(b), hex(c), hex(got), hex(want))
+
+
+def test_attention_ops_against_float64(oracle):
+    """The restated BMM and softmax stay within binary16 accumulation error of a float64 evaluation (sanity of the loops, not parity)."""
+    rng = np.random.default_rng(11)
+    A = (rng.standard_normal((3, 5, 128)) * 0.5).astype(np.float16)
+    B = (rng.standard_normal((3, 40, 128)) * 0.5).astype(np.float16)
+    alpha = np.float16(0.08838)
+    got = oracle.bmm_f16t(A, B, alpha).astype(np.float64)
+    ref = np.einsum("bmk,bnk->bmn", A.astype(np.float64), B.astype(np.float64)) * float(alpha)
+    assert np.abs(got - ref).max() < 0.03
+    x = (rng.standard_normal((6, 333)) * 3).astype(np.float16)
+    p = oracle.softmax_half(x).astype(np.float64)
+    e = np.exp(x.astype(np.float64) - x.astype(np.float64).max(axis=1, keepdims=True))
+    assert np.abs(p - e / e.sum(axis=1, keepdims=True)).max() < 8e-3 and np.abs(p.sum(axis=1) - 1).max() < 0.03  # the sum is a 333-term binary16 chain

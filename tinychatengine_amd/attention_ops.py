@@ -1,0 +1,40 @@
+"""Python mirror of the two fp16 operators between the q/k/v and the o linears of the reference's Llama attention
+(`BMM_F16T`, `softmax`: llm/src/ops/cuda/BMM_F16T.cu, softmax.cu), over the C ABI (`tce_bmm_f16t`, `tce_softmax_half`).
+torch is only the owner of the device buffers."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class BMM_F16T:
+    """`BMM_F16T(alpha)`; `forward(a, weight, c)`: a [batch][M][K], weight [batch][N][K] -> c [batch][M][N] =
+    hmul(alpha, sum over k by binary16 fma) -- BMM_F16T::forward (BMM_F16T.cu:52-76)."""
+
+    def __init__(self, alpha: float = 1.0):
+        self.alpha_bits = int(np.array([alpha], np.float16).view(np.uint16)[0])
+
+    def forward(self, a: torch.Tensor, weight: torch.Tensor, c: torch.Tensor) -> torch.Tensor:
+        assert a.dtype == weight.dtype == c.dtype == torch.float16 and a.is_contiguous() and weight.is_contiguous() and c.is_contiguous()
+        batch, M, K = a.shape
+        assert weight.shape[0] == batch and weight.shape[2] == K and tuple(c.shape) == (batch, M, weight.shape[1])  # BMM_F16T.cu:57-60
+        capi.check(capi.lib().tce_bmm_f16t(C.c_void_p(a.data_ptr()), C.c_void_p(weight.data_ptr()), C.c_void_p(c.data_ptr()), batch, M,
+                                           weight.shape[1], K, self.alpha_bits, C.c_void_p(_stream())))
+        return c
+
+
+def softmax(x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """softmax over the last dimension with softmax_cuda's arithmetic (softmax.cu:4-40)."""
+    assert x.dtype == torch.float16 and x.is_contiguous()
+    out = torch.empty_like(x) if out is None else out
+    n = x.shape[-1]
+    capi.check(capi.lib().tce_softmax_half(C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), x.numel() // n, n, C.c_void_p(_stream())))
+    return out

@@ -1,0 +1,92 @@
+// attention_ops.hip -- the two fp16 operators between the q/k/v and the o linears of the reference's Llama attention
+// (SURVEY 8f rank 4), with the reference's arithmetic:
+//   * BMM_F16T::forward -> mat_mul_transposed_cuda (llm/src/ops/cuda/BMM_F16T.cu:28-45): C[b][i][j] = __hmul(alpha, acc),
+//     acc = __hfma(A[b][i][k], B[b][j][k], acc) for k ascending from acc = 0 -- binary16 accumulation, one rounding per
+//     step.  Used for q k^T (alpha = the stored 1/sqrt(head_dim)) and for p v on the transposed V (alpha = 1):
+//     Int4llamaAttention.cu:185, 211.
+//   * softmax_cuda (llm/src/ops/cuda/softmax.cu:4-40): row maximum from -65504, sum = __hadd(sum, hexp(__hsub(x, max)))
+//     for k ascending, out = __hdiv(hexp(__hsub(x, max)), sum).
+// Both chains are sequential by definition (every step rounds to binary16), so "identical results" means walking them in
+// order; what is parallel is everything around them:
+//   * BMM: one LANE per output element like the reference, but a wave takes 64 consecutive j of one (b, i): the A row is a
+//     wave-uniform broadcast, every lane walks its own B row with 16-byte loads; v_fma_f16 is the IEEE fused operation
+//     (one rounding), fp16 denormals are on by default on gfx9.
+//   * softmax: one wave per row; max and the exponentials are computed by all lanes (order-free / element-wise), staged in
+//     LDS, lane 0 walks the binary16 sum, all lanes divide.
+// hexp: the float exponential rounded to binary16 (the oracle's model of CUDA's hexp; see orc_softmax_half).
+#include "tce_common.hpp"
+#include "w4a16_kernels.hpp"
+
+namespace tce {
+
+namespace {
+
+__global__ __launch_bounds__(256) void bmm_f16t_kernel(const half_t *A, const half_t *B, half_t *C, int batch, int M, int N, int K, half_t alpha) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    const int b = blockIdx.z;
+    if (j >= N) return;
+    const half_t *a = A + ((size_t)b * M + i) * K;
+    const half_t *w = B + ((size_t)b * N + j) * K;
+    half_t acc = (half_t)0.f;
+    int k = 0;
+    if ((K & 7) == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w)) & 15) == 0) {
+        for (; k < K; k += 8) {
+            const half8_t av = *reinterpret_cast<const half8_t *>(a + k);
+            const half8_t wv = *reinterpret_cast<const half8_t *>(w + k);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_fmaf16(av[u], wv[u], acc);
+        }
+    }
+    for (; k < K; ++k) acc = __builtin_fmaf16(a[k], w[k], acc);
+    C[((size_t)b * M + i) * N + j] = alpha * acc;  // __hmul: one rounding
+}
+
+__global__ __launch_bounds__(64) void softmax_half_kernel(const half_t *x, half_t *out, long long rows, int n) {
+    extern __shared__ __attribute__((aligned(16))) half_t e_lds[];  // n halves
+    const long long r = blockIdx.x;
+    const int lane = threadIdx.x;
+    const half_t *xr = x + r * n;
+    float mx = -65504.0f;  // comparisons only: exact in any precision
+    for (int k = lane; k < n; k += 64) mx = fmaxf(mx, (float)xr[k]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    const half_t hmax = (half_t)mx;
+    for (int k = lane; k < n; k += 64) {
+        const half_t d = xr[k] - hmax;                 // __hsub
+        e_lds[k] = (half_t)expf((float)d);             // hexp
+    }
+    __syncthreads();
+    half_t sum = (half_t)0.f;
+    if (lane == 0)
+        for (int k = 0; k < n; ++k) sum = sum + e_lds[k];  // __hadd, in order
+    sum = (half_t)__shfl((float)sum, 0, 64);  // exact round trip through float
+    for (int k = lane; k < n; k += 64) out[r * n + k] = e_lds[k] / sum;  // __hdiv
+}
+
+}  // namespace
+
+int launch_bmm_f16t(const void *A, const void *B, void *C, int batch, int M, int N, int K, unsigned short alpha_bits, hipStream_t stream, hipError_t *hip_err) {
+    half_t alpha;
+    __builtin_memcpy(&alpha, &alpha_bits, 2);
+    dim3 grid((N + 255) / 256, M, batch);
+    hipLaunchKernelGGL(bmm_f16t_kernel, grid, dim3(256), 0, stream, static_cast<const half_t *>(A), static_cast<const half_t *>(B), static_cast<half_t *>(C), batch, M, N, K, alpha);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (hip_err) *hip_err = e;
+        return TCE_ERR_HIP;
+    }
+    return TCE_OK;
+}
+
+int launch_softmax_half(const void *x, void *out, long long rows, int n, hipStream_t stream, hipError_t *hip_err) {
+    hipLaunchKernelGGL(softmax_half_kernel, dim3((unsigned)rows), dim3(64), (size_t)n * 2, stream, static_cast<const half_t *>(x), static_cast<half_t *>(out), rows, n);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (hip_err) *hip_err = e;
+        return TCE_ERR_HIP;
+    }
+    return TCE_OK;
+}
+
+}  // namespace tce

@@ -397,6 +397,22 @@ int tce_w4a16_forward_group_rmsnorm(const tce_w4a16_desc *descs, int count, cons
     return forward_group_norm(descs, count, gamma, eps, stream);
 }
 
+int tce_bmm_f16t(const void *A, const void *B, void *C, int batch, int M, int N, int K, unsigned short alpha_half_bits, void *stream) {
+    if (!A || !B || !C || batch <= 0 || M <= 0 || N <= 0 || K <= 0) return fail(TCE_ERR_BAD_ARG, "tce_bmm_f16t: bad argument");
+    if (M > 65535 || batch > 65535) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_bmm_f16t: M and batch must be <= 65535");
+    hipError_t he = hipSuccess;
+    const int rc = tce::launch_bmm_f16t(A, B, C, batch, M, N, K, alpha_half_bits, static_cast<hipStream_t>(stream), &he);
+    return rc == TCE_ERR_HIP ? hip_fail(he, "bmm_f16t launch") : rc;
+}
+
+int tce_softmax_half(const void *x, void *out, long long rows, int n, void *stream) {
+    if (!x || !out || rows <= 0 || n <= 0) return fail(TCE_ERR_BAD_ARG, "tce_softmax_half: bad argument");
+    if (n > 32768) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_softmax_half: rows of at most 32768 elements (one row in LDS)");
+    hipError_t he = hipSuccess;
+    const int rc = tce::launch_softmax_half(x, out, rows, n, static_cast<hipStream_t>(stream), &he);
+    return rc == TCE_ERR_HIP ? hip_fail(he, "softmax launch") : rc;
+}
+
 int tce_prefetch(const void *ptr, long long bytes, int workgroups, void *stream) {
     if (!ptr || bytes < 0 || (reinterpret_cast<uintptr_t>(ptr) & 15)) return fail(TCE_ERR_BAD_ARG, "tce_prefetch: bad argument (16-byte aligned pointer, bytes >= 0)");
     hipError_t he = hipSuccess;

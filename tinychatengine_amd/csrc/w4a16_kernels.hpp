@@ -111,6 +111,9 @@ int launch_w4a16_skinny(const tce_w4a16_desc &d, hipStream_t stream, hipError_t 
 // element-wise glue of the decoder layer (glue.hip)
 int launch_layernorm_q(const float *x, const float *w, const float *b, void *out, int m, int n, hipStream_t stream, hipError_t *hip_err);
 int launch_rmsnorm_half(const void *x, const float *gamma, void *out, int m, int n, float eps, hipStream_t stream, hipError_t *hip_err);
+// attention_ops.hip
+int launch_bmm_f16t(const void *A, const void *B, void *C, int batch, int M, int N, int K, unsigned short alpha_bits, hipStream_t stream, hipError_t *hip_err);
+int launch_softmax_half(const void *x, void *out, long long rows, int n, hipStream_t stream, hipError_t *hip_err);
 int launch_prefetch(const void *ptr, long long bytes, int workgroups, hipStream_t stream, hipError_t *hip_err);
 int launch_add_half(const void *a, const void *b, void *c, long long n, hipStream_t stream, hipError_t *hip_err);
 int launch_silu_mul_half(void *a, const void *b, long long n, hipStream_t stream, hipError_t *hip_err);
