@@ -31,6 +31,20 @@ __global__ __launch_bounds__(256) void bmm_f16t_kernel(const half_t *A, const ha
     half_t acc = (half_t)0.f;
     int k = 0;
     if ((K & 7) == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w)) & 15) == 0) {
+        // four 16-byte pieces of each row requested before the 32 dependent fmas that consume them: the chain itself cannot be
+        // shortened, but it should not also wait for one load at a time (p v at 2048 keys: 35 -> see attention_ops_decode.jsonl)
+        for (; k + 32 <= K; k += 32) {
+            half8_t av[4], wv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                av[u] = *reinterpret_cast<const half8_t *>(a + k + 8 * u);
+                wv[u] = *reinterpret_cast<const half8_t *>(w + k + 8 * u);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 8; ++v) acc = __builtin_fmaf16(av[u][v], wv[u][v], acc);
+        }
         for (; k < K; k += 8) {
             const half8_t av = *reinterpret_cast<const half8_t *>(a + k);
             const half8_t wv = *reinterpret_cast<const half8_t *>(w + k);
@@ -58,8 +72,19 @@ __global__ __launch_bounds__(64) void softmax_half_kernel(const half_t *x, half_
     }
     __syncthreads();
     half_t sum = (half_t)0.f;
-    if (lane == 0)
-        for (int k = 0; k < n; ++k) sum = sum + e_lds[k];  // __hadd, in order
+    if (lane == 0) {  // __hadd, in order; 16 bytes of exponentials per LDS read, four reads ahead of the adds
+        int k = 0;
+        for (; k + 32 <= n; k += 32) {
+            half8_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const half8_t *>(e_lds + k + 8 * u);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int w = 0; w < 8; ++w) sum = sum + v[u][w];
+        }
+        for (; k < n; ++k) sum = sum + e_lds[k];
+    }
     sum = (half_t)__shfl((float)sum, 0, 64);  // exact round trip through float
     for (int k = lane; k < n; k += 64) out[r * n + k] = e_lds[k] / sum;  // __hdiv
 }
