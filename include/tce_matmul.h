@@ -124,6 +124,12 @@ TCE_API int tce_w4a16_forward(const tce_w4a16_desc *d, void *stream);
  *   tce_softmax_half <- softmax_cuda (llm/src/ops/cuda/softmax.cu:4-40): rows of n binary16 values */
 TCE_API int tce_bmm_f16t(const void *A, const void *B, void *C, int batch, int M, int N, int K, unsigned short alpha_half_bits, void *stream);
 TCE_API int tce_softmax_half(const void *x, void *out, long long rows, int n, void *stream);
+/* One decode step (one query row per head) of Int4llamaAttention's qk_bmm -> batch_Add(mask) -> check_inf_half -> softmax ->
+ * pv_bmm (llm/src/nn_modules/cuda/Int4llamaAttention.cu:184-211) as ONE launch, every operation and every order kept (bit-identical
+ * to tce_bmm_f16t + hadd + tce_softmax_half + tce_bmm_f16t): q fp16 [heads][head_dim], K [heads][keys][head_dim],
+ * Vt [heads][head_dim][keys] (the transposed values the reference also keeps), mask fp16 [keys] or NULL, out [heads][head_dim]. */
+TCE_API int tce_attention_decode_f16(const void *q, const void *K, const void *Vt, const void *mask, void *out, int heads, int keys, int head_dim,
+                                     unsigned short alpha_half_bits, void *stream);
 /* Reads [ptr, ptr + bytes) with at most `workgroups` workgroups (0 = as many as the range needs) and discards the data: the
  * range then sits in the memory-side cache (256 MiB) for the launch that needs it.  Meant for a side stream / graph branch
  * next to the launch BEFORE that one (no reference counterpart: cudaMallocManaged prefetching is the closest idea). */

@@ -15,3 +15,7 @@ for t in (128, 512, 2048):
     row["softmax_us"] = round(time_graph(lambda i, sp: capi.check(L.tce_softmax_half(s.data_ptr(), p.data_ptr(), 32, t, sp)), 32), 2)
     row["pv_us"] = round(time_graph(lambda i, sp: capi.check(L.tce_bmm_f16t(p.data_ptr(), vt.data_ptr(), o.data_ptr(), 32, 1, 128, t, one, sp)), 32), 2)
     print(json.dumps(row), flush=True)
+    row2 = {"context": t}
+    kk = torch.randn(32, t, 128, device=dev).half(); qq = torch.randn(32, 128, device=dev).half(); oo = torch.empty(32, 128, dtype=torch.float16, device=dev)
+    row2["fused_decode_us"] = round(time_graph(lambda i, sp: capi.check(L.tce_attention_decode_f16(qq.data_ptr(), kk.data_ptr(), vt.data_ptr(), None, oo.data_ptr(), 32, t, 128, al, sp)), 32), 2)
+    print(json.dumps(row2), flush=True)

@@ -73,3 +73,37 @@ def test_softmax_half_matches_oracle(dev, oracle, rows, n):
     assert np.abs(diff).max() <= 2, f"worst difference {np.abs(diff).max()} binary16 steps"
     assert (diff != 0).mean() <= 0.35, f"{(diff != 0).mean():.3f} of the elements differ"
     assert np.abs(got.astype(np.float64).sum(axis=1) - 1.0).max() < 0.05
+
+
+@pytest.mark.parametrize("heads,keys,hd,masked", [(32, 777, 128, False), (32, 2048, 128, True), (4, 1, 128, False), (3, 70, 96, True), (2, 33, 20, False)])
+def test_fused_decode_attention_is_the_composition(dev, oracle, heads, keys, hd, masked):
+    """tce_attention_decode_f16 == tce_bmm_f16t -> (+ mask, inf scrub) -> tce_softmax_half -> tce_bmm_f16t bit for bit (same operations, same
+    order, one launch), and its two products equal the oracle's BMM on the same inputs."""
+    from tinychatengine_amd.attention_ops import BMM_F16T, attention_decode, softmax
+    rng = np.random.default_rng(heads * 7 + keys + hd)
+    q = (rng.standard_normal((heads, hd)) * 1.5).astype(np.float16)
+    K = (rng.standard_normal((heads, keys, hd)) * 1.5).astype(np.float16)
+    V = (rng.standard_normal((heads, keys, hd))).astype(np.float16)
+    Vt = np.ascontiguousarray(V.transpose(0, 2, 1))
+    alpha = float(np.float16(1.0 / np.sqrt(hd)))
+    mask = None
+    if masked:
+        mask = np.zeros(keys, np.float16)
+        mask[keys // 3] = np.float16(-65504.0)  # a masked key (what prepare_decoder_attention_mask writes)
+    tq, tK, tVt = (torch.from_numpy(x).to(dev) for x in (q, K, Vt))
+    tm = torch.from_numpy(mask).to(dev) if masked else None
+    fused = attention_decode(tq, tK, tVt, torch.empty((heads, hd), dtype=torch.float16, device=dev), alpha, tm)
+    # the same thing as separate launches
+    s = BMM_F16T(alpha).forward(tq.view(heads, 1, hd), tK, torch.empty((heads, 1, keys), dtype=torch.float16, device=dev))
+    assert np.array_equal(s.cpu().numpy().view(np.uint16), oracle.bmm_f16t(q.reshape(heads, 1, hd), K, np.float16(alpha)).view(np.uint16))
+    if masked:
+        s = s + tm.view(1, 1, keys)  # __hadd
+    s = torch.where(torch.isfinite(s), s, torch.full_like(s, -65504.0))  # check_inf_half
+    p = softmax(s.contiguous())
+    o = BMM_F16T(1.0).forward(p, tVt, torch.empty((heads, 1, hd), dtype=torch.float16, device=dev))
+    torch.cuda.synchronize()
+    assert torch.equal(fused.view(-1), o.view(-1)), f"{(fused.view(-1) != o.view(-1)).sum().item()} of {fused.numel()} outputs differ"
+    want = oracle.bmm_f16t(p.cpu().numpy(), Vt, np.float16(1.0))  # the oracle's product on the device's probabilities
+    assert np.array_equal(fused.cpu().numpy().reshape(-1).view(np.uint16), want.reshape(-1).view(np.uint16))
+    if masked:
+        assert float(p.view(heads, keys)[:, keys // 3].abs().max()) == 0.0

@@ -38,3 +38,17 @@ def softmax(x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
     n = x.shape[-1]
     capi.check(capi.lib().tce_softmax_half(C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), x.numel() // n, n, C.c_void_p(_stream())))
     return out
+
+
+def attention_decode(q: torch.Tensor, K: torch.Tensor, Vt: torch.Tensor, out: torch.Tensor, alpha: float, mask: torch.Tensor | None = None) -> torch.Tensor:
+    """One decode step of all heads as one launch: q [heads][hd], K [heads][keys][hd], Vt [heads][hd][keys], mask [keys] or None ->
+    out [heads][hd]; the reference's qk_bmm -> batch_Add -> check_inf_half -> softmax -> pv_bmm (Int4llamaAttention.cu:184-211)."""
+    heads, hd = q.shape
+    keys = K.shape[1]
+    assert tuple(K.shape) == (heads, keys, hd) and tuple(Vt.shape) == (heads, hd, keys) and tuple(out.shape) == (heads, hd)
+    assert all(x.dtype == torch.float16 and x.is_contiguous() for x in (q, K, Vt, out))
+    alpha_bits = int(np.array([alpha], np.float16).view(np.uint16)[0])
+    capi.check(capi.lib().tce_attention_decode_f16(C.c_void_p(q.data_ptr()), C.c_void_p(K.data_ptr()), C.c_void_p(Vt.data_ptr()),
+                                                   C.c_void_p(mask.data_ptr() if mask is not None else 0), C.c_void_p(out.data_ptr()), heads, keys, hd,
+                                                   alpha_bits, C.c_void_p(_stream())))
+    return out

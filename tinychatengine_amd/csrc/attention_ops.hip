@@ -89,7 +89,132 @@ __global__ __launch_bounds__(64) void softmax_half_kernel(const half_t *x, half_
     for (int k = lane; k < n; k += 64) out[r * n + k] = e_lds[k] / sum;  // __hdiv
 }
 
+// One decode step of one head as ONE workgroup: the reference's sequence qk_bmm -> batch_Add(mask) -> check_inf_half -> softmax
+// -> pv_bmm (Int4llamaAttention.cu:184-211) with every operation and every order kept, only the launches merged:
+//   scores: thread t takes keys t, t + 256, ...: hmul(alpha, chain of hfma over the head dimension), + mask, inf / nan -> -65504;
+//   softmax: maximum by all threads (order-free), exponentials by all threads, the binary16 sum by thread 0 in key order,
+//            quotients by all threads;
+//   p v:    thread j < head_dim walks the keys in order over its row of the TRANSPOSED values (the reference transposes V for
+//           this product too: value_states_transpose, :203-211), probabilities broadcast from LDS.
+// q [heads][hd], K [heads][t][hd], Vt [heads][hd][t], mask [t] or null, out [heads][hd] (= the unshaped [1][heads * hd] row).
+__global__ __launch_bounds__(1024) void attention_decode_kernel(const half_t *q, const half_t *K, const half_t *Vt, const half_t *mask, half_t *out, int t,
+                                                                int hd, half_t alpha) {
+    extern __shared__ __attribute__((aligned(16))) half_t sm[];
+    half_t *sc = sm;                       // [t_pad]: scores, then probabilities
+    half_t *ex = sm + ((t + 7) & ~7);      // [t_pad]: exponentials
+    half_t *qs = ex + ((t + 7) & ~7);      // [hd]
+    __shared__ float red[16];
+    __shared__ half_t sum_sh;
+    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const half_t *qh = q + (size_t)h * hd;
+    for (int i = tid; i < hd; i += 1024) qs[i] = qh[i];
+    __syncthreads();
+    const bool vec = (hd & 7) == 0 && (reinterpret_cast<uintptr_t>(K) & 15) == 0;
+    float mx = -65504.0f;
+    for (int k = tid; k < t; k += 1024) {
+        const half_t *kr = K + ((size_t)h * t + k) * hd;
+        half_t acc = (half_t)0.f;
+        int d = 0;
+        if (vec) {
+            for (; d + 32 <= hd; d += 32) {
+                half8_t kv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) kv[u] = *reinterpret_cast<const half8_t *>(kr + d + 8 * u);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const half8_t qv = *reinterpret_cast<const half8_t *>(qs + d + 8 * u);
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) acc = __builtin_fmaf16(qv[v], kv[u][v], acc);
+                }
+            }
+        }
+        for (; d < hd; ++d) acc = __builtin_fmaf16(qs[d], kr[d], acc);
+        half_t sv = alpha * acc;                       // __hmul
+        if (mask) sv = sv + mask[k];                   // batch_Add_cuda: __hadd
+        const float sf = (float)sv;
+        if (__builtin_isinf(sf) || __builtin_isnan(sf)) sv = (half_t)-65504.0f;  // check_inf_half
+        sc[k] = sv;
+        mx = fmaxf(mx, (float)sv);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) mx = fmaxf(mx, red[w]);
+    const half_t hmax = (half_t)mx;
+    for (int k = tid; k < t; k += 1024) ex[k] = (half_t)expf((float)(half_t)(sc[k] - hmax));  // hexp(__hsub)
+    __syncthreads();
+    if (tid == 0) {
+        half_t sum = (half_t)0.f;
+        int k = 0;
+        for (; k + 32 <= t; k += 32) {
+            half8_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const half8_t *>(ex + k + 8 * u);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int w = 0; w < 8; ++w) sum = sum + v[u][w];
+        }
+        for (; k < t; ++k) sum = sum + ex[k];
+        sum_sh = sum;
+    }
+    __syncthreads();
+    const half_t sum = sum_sh;
+    for (int k = tid; k < t; k += 1024) sc[k] = ex[k] / sum;  // __hdiv
+    __syncthreads();
+    const bool vecv = (t & 7) == 0 && (reinterpret_cast<uintptr_t>(Vt) & 15) == 0;
+    for (int j = tid; j < hd; j += 1024) {
+        const half_t *vr = Vt + ((size_t)h * hd + j) * t;
+        half_t acc = (half_t)0.f;
+        int k = 0;
+        if (vecv) {
+            for (; k + 32 <= t; k += 32) {
+                half8_t vv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) vv[u] = *reinterpret_cast<const half8_t *>(vr + k + 8 * u);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const half8_t pv = *reinterpret_cast<const half8_t *>(sc + k + 8 * u);
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) acc = __builtin_fmaf16(pv[w], vv[u][w], acc);
+                }
+            }
+        }
+        for (; k < t; ++k) acc = __builtin_fmaf16(sc[k], vr[k], acc);
+        out[(size_t)h * hd + j] = acc;  // pv_bmm's alpha is 1: __hmul(1, acc) = acc
+    }
+}
+
 }  // namespace
+
+int launch_attention_decode(const void *q, const void *K, const void *Vt, const void *mask, void *out, int heads, int t, int hd, unsigned short alpha_bits,
+                            hipStream_t stream, hipError_t *hip_err) {
+    half_t alpha;
+    __builtin_memcpy(&alpha, &alpha_bits, 2);
+    const size_t lds = ((size_t)2 * ((t + 7) & ~7) + hd) * 2;
+    if (lds > 150 * 1024) return TCE_ERR_UNSUPPORTED_SHAPE;
+    auto kfn = attention_decode_kernel;
+    static size_t lds_allowed = 64 * 1024;
+    if (lds > lds_allowed) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            if (hip_err) *hip_err = e;
+            return TCE_ERR_HIP;
+        }
+        lds_allowed = lds;
+    }
+    hipLaunchKernelGGL(kfn, dim3(heads), dim3(1024), lds, stream, static_cast<const half_t *>(q), static_cast<const half_t *>(K), static_cast<const half_t *>(Vt),
+                       static_cast<const half_t *>(mask), static_cast<half_t *>(out), t, hd, alpha);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (hip_err) *hip_err = e;
+        return TCE_ERR_HIP;
+    }
+    return TCE_OK;
+}
 
 int launch_bmm_f16t(const void *A, const void *B, void *C, int batch, int M, int N, int K, unsigned short alpha_bits, hipStream_t stream, hipError_t *hip_err) {
     half_t alpha;

@@ -405,6 +405,15 @@ int tce_bmm_f16t(const void *A, const void *B, void *C, int batch, int M, int N,
     return rc == TCE_ERR_HIP ? hip_fail(he, "bmm_f16t launch") : rc;
 }
 
+int tce_attention_decode_f16(const void *q, const void *K, const void *Vt, const void *mask, void *out, int heads, int keys, int head_dim,
+                             unsigned short alpha_half_bits, void *stream) {
+    if (!q || !K || !Vt || !out || heads <= 0 || keys <= 0 || head_dim <= 0) return fail(TCE_ERR_BAD_ARG, "tce_attention_decode_f16: bad argument");
+    hipError_t he = hipSuccess;
+    const int rc = tce::launch_attention_decode(q, K, Vt, mask, out, heads, keys, head_dim, alpha_half_bits, static_cast<hipStream_t>(stream), &he);
+    if (rc == TCE_ERR_UNSUPPORTED_SHAPE) return fail(rc, "tce_attention_decode_f16: %d keys do not fit one workgroup's LDS (use tce_bmm_f16t / tce_softmax_half)", keys);
+    return rc == TCE_ERR_HIP ? hip_fail(he, "attention decode launch") : rc;
+}
+
 int tce_softmax_half(const void *x, void *out, long long rows, int n, void *stream) {
     if (!x || !out || rows <= 0 || n <= 0) return fail(TCE_ERR_BAD_ARG, "tce_softmax_half: bad argument");
     if (n > 32768) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_softmax_half: rows of at most 32768 elements (one row in LDS)");
