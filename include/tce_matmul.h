@@ -124,6 +124,10 @@ TCE_API int tce_w4a16_forward(const tce_w4a16_desc *d, void *stream);
  *   tce_softmax_half <- softmax_cuda (llm/src/ops/cuda/softmax.cu:4-40): rows of n binary16 values */
 TCE_API int tce_bmm_f16t(const void *A, const void *B, void *C, int batch, int M, int N, int K, unsigned short alpha_half_bits, void *stream);
 TCE_API int tce_softmax_half(const void *x, void *out, long long rows, int n, void *stream);
+/* RotaryPosEmb_cuda_forward (llm/src/ops/cuda/RotaryPosEmb.cu:4-34), in place on q and / or k fp16 [heads][len][head_dim] (NULL skips one);
+ * cos / sin tables fp16 [positions][head_dim]; row i uses position i + start_idx:  x'[j] = hfma(x[j], cos[j], hmul(rot[j], sin[j])),
+ * rot = (-x[head_dim/2:], x[:head_dim/2]). */
+TCE_API int tce_rope_half(void *q, void *k, const void *cos_table, const void *sin_table, int heads, int len, int head_dim, int start_idx, void *stream);
 /* One decode step (one query row per head) of Int4llamaAttention's qk_bmm -> batch_Add(mask) -> check_inf_half -> softmax ->
  * pv_bmm (llm/src/nn_modules/cuda/Int4llamaAttention.cu:184-211) as ONE launch, every operation and every order kept (bit-identical
  * to tce_bmm_f16t + hadd + tce_softmax_half + tce_bmm_f16t): q fp16 [heads][head_dim], K [heads][keys][head_dim],

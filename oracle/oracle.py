@@ -242,6 +242,15 @@ class Oracle(_Lib):
         self.lib.orc_softmax_half(x.size // n, n, _p(x.view(np.uint16)), _p(out))
         return out.view(np.float16)
 
+    def rope_half(self, q_f16, k_f16, cos_f16, sin_f16, start_idx: int):
+        """RotaryPosEmb_cuda_forward on copies of q, k [heads][len][hd]; cos / sin [positions][hd] (RotaryPosEmb.cu:4-34)."""
+        q = np.array(q_f16, np.float16, copy=True); k = np.array(k_f16, np.float16, copy=True)
+        heads, ln, hd = q.shape
+        c = np.ascontiguousarray(cos_f16, np.float16); s_ = np.ascontiguousarray(sin_f16, np.float16)
+        self.lib.orc_rope_half.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4
+        self.lib.orc_rope_half(_p(q.view(np.uint16)), _p(k.view(np.uint16)), _p(c.view(np.uint16)), _p(s_.view(np.uint16)), heads, ln, hd, start_idx)
+        return q, k
+
     def fp32_matmul_transposed(self, A, B, bias, M, N, K):
         A = np.ascontiguousarray(A, np.float32); B = np.ascontiguousarray(B, np.float32)
         bias = None if bias is None else np.ascontiguousarray(bias, np.float32)

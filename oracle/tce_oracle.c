@@ -741,3 +741,27 @@ ORC_API void orc_softmax_half(int64_t rows, int n, const uint16_t *x, uint16_t *
         }
     }
 }
+
+/* RotaryPosEmb_cuda_forward (llm/src/ops/cuda/RotaryPosEmb.cu:4-34), in place on q and k [heads][len][hd]; cos / sin
+ * [positions][hd]: x'[j] = __hfma(x[j], cos[p][j], __hmul(rot[j], sin[p][j])) with rot = (-x[hd/2:], x[:hd/2]), p = i +
+ * start_idx.  PARITY UNPINNED like the operators above (CUDA-only in the reference). */
+ORC_API void orc_rope_half(uint16_t *q, uint16_t *k, const uint16_t *cosv, const uint16_t *sinv, int heads, int len, int hd, int start_idx) {
+    uint16_t buf[512];
+    const int hp = hd / 2;
+    for (int t = 0; t < 2; t++) {
+        uint16_t *x = t ? k : q;
+        if (!x) continue;
+        for (int b = 0; b < heads; b++)
+            for (int i = 0; i < len; i++) {
+                uint16_t *r = x + ((int64_t)b * len + i) * hd;
+                const uint16_t *c = cosv + (int64_t)(i + start_idx) * hd, *s = sinv + (int64_t)(i + start_idx) * hd;
+                for (int j = 0; j < hp; j++) buf[j] = (uint16_t)(r[j + hp] ^ 0x8000u); /* __hneg */
+                for (int j = hp; j < hd; j++) buf[j] = r[j - hp];
+                for (int j = 0; j < hd; j++) {
+                    const uint16_t m = orc_hop((double)orc_f16_to_f32(buf[j]) * (double)orc_f16_to_f32(s[j])); /* __hmul: exact product, one rounding */
+                    buf[j] = orc_hfma(r[j], c[j], m);
+                }
+                for (int j = 0; j < hd; j++) r[j] = buf[j];
+            }
+    }
+}

@@ -107,3 +107,19 @@ def test_fused_decode_attention_is_the_composition(dev, oracle, heads, keys, hd,
     assert np.array_equal(fused.cpu().numpy().reshape(-1).view(np.uint16), want.reshape(-1).view(np.uint16))
     if masked:
         assert float(p.view(heads, keys)[:, keys // 3].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("heads,ln,hd,start", [(32, 1, 128, 77), (32, 9, 128, 0), (4, 3, 64, 5), (2, 2, 510, 1)])
+def test_rope_bit_exact(dev, oracle, heads, ln, hd, start):
+    from tinychatengine_amd.attention_ops import rotary_pos_emb
+    rng = np.random.default_rng(heads + ln + hd + start)
+    q = rng.standard_normal((heads, ln, hd)).astype(np.float16)
+    k = rng.standard_normal((heads, ln, hd)).astype(np.float16)
+    pos = np.arange(start + ln + 3)[:, None] * (10000.0 ** (-np.arange(0, hd, 2) / hd))[None, :]
+    cos = np.concatenate([np.cos(pos), np.cos(pos)], axis=1).astype(np.float16)  # the tables the reference precomputes
+    sin = np.concatenate([np.sin(pos), np.sin(pos)], axis=1).astype(np.float16)
+    wq, wk = oracle.rope_half(q, k, cos, sin, start)
+    tq, tk = torch.from_numpy(q).to(dev), torch.from_numpy(k).to(dev)
+    rotary_pos_emb(tq, tk, torch.from_numpy(cos).to(dev), torch.from_numpy(sin).to(dev), start)
+    torch.cuda.synchronize()
+    assert np.array_equal(tq.cpu().numpy().view(np.uint16), wq.view(np.uint16)) and np.array_equal(tk.cpu().numpy().view(np.uint16), wk.view(np.uint16))

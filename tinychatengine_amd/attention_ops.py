@@ -52,3 +52,12 @@ def attention_decode(q: torch.Tensor, K: torch.Tensor, Vt: torch.Tensor, out: to
                                                    C.c_void_p(mask.data_ptr() if mask is not None else 0), C.c_void_p(out.data_ptr()), heads, keys, hd,
                                                    alpha_bits, C.c_void_p(_stream())))
     return out
+
+
+def rotary_pos_emb(q: torch.Tensor | None, k: torch.Tensor | None, cos: torch.Tensor, sin: torch.Tensor, start_idx: int) -> None:
+    """RotaryPosEmb_cuda_forward in place: q, k [heads][len][hd] (either may be None), cos / sin [positions][hd] (RotaryPosEmb.cu:4-34)."""
+    ref = q if q is not None else k
+    heads, ln, hd = ref.shape
+    assert cos.dtype == sin.dtype == torch.float16 and cos.shape[-1] == hd and cos.shape[0] >= start_idx + ln
+    capi.check(capi.lib().tce_rope_half(C.c_void_p(q.data_ptr() if q is not None else 0), C.c_void_p(k.data_ptr() if k is not None else 0),
+                                        C.c_void_p(cos.data_ptr()), C.c_void_p(sin.data_ptr()), heads, ln, hd, start_idx, C.c_void_p(_stream())))

@@ -188,7 +188,38 @@ __global__ __launch_bounds__(1024) void attention_decode_kernel(const half_t *q,
     }
 }
 
+// RotaryPosEmb_cuda_forward (llm/src/ops/cuda/RotaryPosEmb.cu:4-34), in place: x'[j] = hfma(x[j], cos[p][j], hmul(rot[j], sin[p][j])),
+// rot = (-x[hd/2:], x[:hd/2]).  One workgroup per (head, token, q or k); the row is read completely before it is written.
+__global__ __launch_bounds__(256) void rope_half_kernel(half_t *q, half_t *k, const half_t *cosv, const half_t *sinv, int len, int hd, int start_idx) {
+    half_t *x = blockIdx.z ? k : q;
+    if (!x) return;
+    half_t *r = x + ((size_t)blockIdx.x * len + blockIdx.y) * hd;
+    const half_t *c = cosv + (size_t)(blockIdx.y + start_idx) * hd, *s = sinv + (size_t)(blockIdx.y + start_idx) * hd;
+    const int hp = hd / 2;
+    half_t res[2];  // hd <= 512: at most two elements per thread
+    int n = 0;
+    for (int j = threadIdx.x; j < hd; j += 256) {
+        const half_t rot = j < hp ? -r[j + hp] : r[j - hp];
+        const half_t m = rot * s[j];                       // __hmul
+        res[n++] = __builtin_fmaf16(r[j], c[j], m);        // __hfma
+    }
+    __syncthreads();
+    n = 0;
+    for (int j = threadIdx.x; j < hd; j += 256) r[j] = res[n++];
+}
+
 }  // namespace
+
+int launch_rope_half(void *q, void *k, const void *cosv, const void *sinv, int heads, int len, int hd, int start_idx, hipStream_t stream, hipError_t *hip_err) {
+    hipLaunchKernelGGL(rope_half_kernel, dim3(heads, len, 2), dim3(256), 0, stream, static_cast<half_t *>(q), static_cast<half_t *>(k), static_cast<const half_t *>(cosv),
+                       static_cast<const half_t *>(sinv), len, hd, start_idx);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (hip_err) *hip_err = e;
+        return TCE_ERR_HIP;
+    }
+    return TCE_OK;
+}
 
 int launch_attention_decode(const void *q, const void *K, const void *Vt, const void *mask, void *out, int heads, int t, int hd, unsigned short alpha_bits,
                             hipStream_t stream, hipError_t *hip_err) {

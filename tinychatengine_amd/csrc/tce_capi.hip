@@ -414,6 +414,14 @@ int tce_attention_decode_f16(const void *q, const void *K, const void *Vt, const
     return rc == TCE_ERR_HIP ? hip_fail(he, "attention decode launch") : rc;
 }
 
+int tce_rope_half(void *q, void *k, const void *cos_table, const void *sin_table, int heads, int len, int head_dim, int start_idx, void *stream) {
+    if ((!q && !k) || !cos_table || !sin_table || heads <= 0 || len <= 0 || head_dim <= 0 || start_idx < 0) return fail(TCE_ERR_BAD_ARG, "tce_rope_half: bad argument");
+    if ((head_dim & 1) || head_dim > 512 || len > 65535) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_rope_half: even head_dim <= 512, len <= 65535");
+    hipError_t he = hipSuccess;
+    const int rc = tce::launch_rope_half(q, k, cos_table, sin_table, heads, len, head_dim, start_idx, static_cast<hipStream_t>(stream), &he);
+    return rc == TCE_ERR_HIP ? hip_fail(he, "rope launch") : rc;
+}
+
 int tce_softmax_half(const void *x, void *out, long long rows, int n, void *stream) {
     if (!x || !out || rows <= 0 || n <= 0) return fail(TCE_ERR_BAD_ARG, "tce_softmax_half: bad argument");
     if (n > 32768) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_softmax_half: rows of at most 32768 elements (one row in LDS)");
