@@ -1,0 +1,56 @@
+"""Host logic of tce_w4a16_forward: which kernel family / GEMM tile a shape is sent to (tce_w4a16_describe_dispatch: no launch, no HIP call,
+so this runs without a GPU).  The expectations are the measured cross-over points of DESIGN.md section 5 / profiles/r1/m_sweep_17_384.jsonl."""
+import pytest
+
+from tinychatengine_amd import capi
+
+
+def _desc(M, N, K, G=128, flags=0):
+    # pointers are never dereferenced by the query; 16 satisfies the alignment checks
+    return capi.W4A16Desc(M=M, N=N, K=K, group_size=G, A=16, qweight=16, scales=16, zeros=16, C=16, flags=flags)
+
+
+@pytest.mark.parametrize("shape,expect", [
+    ((1, 4096, 4096), "gemv passes=1"),                       # decode
+    ((2, 11008, 4096), "gemv passes=1"),                      # M = 2 stays on the GEMV kernels
+    ((3, 4096, 4096), "small-batch slices=1"),
+    ((16, 22016, 4096), "small-batch slices=1"),
+    ((32, 4096, 4096), "small-batch slices=2"),                # N too small to fill the chip with GEMM tiles
+    ((64, 4096, 11008), "small-batch slices=4"),
+    ((32, 22016, 4096), "gemm-dma tile=32x128 quartets=2 group=128"),   # enough column tiles: the GEMM takes over
+    ((128, 4096, 4096), "gemm-dma tile=64x64 quartets=2 group=128"),
+    ((512, 4096, 4096), "gemm-dma tile=64x128 quartets=2 group=128"),  # one workgroup per CU: two quartets
+    ((512, 11008, 4096), "gemm-dma tile=64x128 quartets=1 group=128"), # 688 workgroups on 512 slots
+    ((4096, 4096, 4096), "gemm-dma tile=64x128 quartets=1 group=128"),
+    ((512, 4096, 4096, 64), "gemm-dma tile=64x128 quartets=2 group=64"),
+    ((9, 4096, 4096, 64), "gemv passes=3"),                   # other group sizes below M = 17: GEMV kernel, 4 rows per pass
+    ((12, 4096, 4096, 128, capi.TCE_W4_FORCE_GEMV), "gemv passes=3"),
+])
+def test_dispatch_of_documented_regimes(shape, expect):
+    assert capi.describe_dispatch(_desc(*shape)) == expect
+
+
+def test_forced_paths_and_errors():
+    assert capi.describe_dispatch(_desc(1, 4096, 4096, 128, capi.TCE_W4_FORCE_GEMM)).startswith("gemm-dma")
+    assert capi.describe_dispatch(_desc(64, 4096, 4096, 128, capi.TCE_W4_FORCE_GEMV)) == "gemv passes=16"
+    with pytest.raises(capi.TceError):
+        capi.describe_dispatch(_desc(4, 4096, 4160))  # K not a multiple of the group size
+    try:
+        capi.set_gemm_config(4, 2)
+        assert capi.describe_dispatch(_desc(512, 4096, 4096)) == "gemm tile=64x128"
+        capi.set_gemm_config(204, 1)
+        assert capi.describe_dispatch(_desc(512, 4096, 4096)).startswith("gemm-dma tile=64x64")
+    finally:
+        capi.set_gemm_config()
+
+
+def test_cost_model_prefers_fewer_rounds():
+    """688 workgroups of 64x128 on 512 slots are two rounds; the dispatcher must not pick a form that needs three."""
+    for M, N in ((512, 11008), (192, 11008), (256, 22016), (2048, 4096)):
+        s = capi.describe_dispatch(_desc(M, N, 4096))
+        assert s.startswith("gemm-dma"), s
+        r, c = (int(v) for v in s.split("tile=")[1].split()[0].split("x"))
+        q = int(s.split("quartets=")[1].split()[0])
+        wgs = -(-M // r) * -(-N // c)
+        slots = 256 * (1 if q == 2 or r >= 128 else 2)
+        assert -(-wgs // slots) <= 4 or wgs / slots > 3, (s, wgs, slots)

@@ -27,7 +27,7 @@ TCE_OUT_INT8, TCE_OUT_FP32 = 0, 1
 
 # every symbol include/tce_matmul.h declares (tests/test_boundary.py checks the .so exports exactly these)
 EXPORTS = [
-    "tce_w4a16_forward", "tce_reset_last_error", "tce_bmm_f16t", "tce_rope_half", "tce_softmax_half", "tce_attention_decode_f16", "tce_prefetch", "tce_add_half", "tce_silu_mul_half", "tce_rmsnorm_half", "tce_w4a16_forward_group_rmsnorm", "tce_w4a16_forward_group", "tce_w4a16_check_zero_point_8", "tce_w4a16_awq_fp16acc", "tce_w4a16_awq_workspace_bytes",
+    "tce_w4a16_forward", "tce_w4a16_describe_dispatch", "tce_reset_last_error", "tce_bmm_f16t", "tce_rope_half", "tce_softmax_half", "tce_attention_decode_f16", "tce_prefetch", "tce_add_half", "tce_silu_mul_half", "tce_rmsnorm_half", "tce_w4a16_forward_group_rmsnorm", "tce_w4a16_forward_group", "tce_w4a16_check_zero_point_8", "tce_w4a16_awq_fp16acc", "tce_w4a16_awq_workspace_bytes",
     "tce_w4a16_gemm_awq", "tce_w8a8_matmul", "tce_layernorm_q", "tce_plan_create", "tce_plan_create_ex", "tce_plan_is_chained", "tce_plan_geometry", "tce_plan_status", "tce_plan_launch", "tce_plan_n_launches",
     "tce_plan_destroy", "tce_version", "tce_last_error", "tce_build_info", "tce_w4a16_set_gemv_config",
     "tce_w4a16_set_gemm_config", "tce_w4a16_algorithmic_bytes", "tce_w4a16_gemv_variant", "tce_w4a16_gemm_variant",
@@ -121,6 +121,12 @@ def check(rc: int) -> None:
 
 def last_error() -> str:
     return lib().tce_last_error().decode()
+
+
+def describe_dispatch(desc: W4A16Desc) -> str:
+    buf = C.create_string_buffer(128)
+    check(lib().tce_w4a16_describe_dispatch(C.byref(desc), buf, 128))
+    return buf.value.decode()
 
 
 def w4a16_forward(desc: W4A16Desc, stream: int | None) -> int:

@@ -327,6 +327,31 @@ int tce_w4a16_forward(const tce_w4a16_desc *d, void *stream) {
     return tce_w4a16_forward_group(d, 1, stream);
 }
 
+// The decision tce_w4a16_forward takes for a descriptor, as text, without launching anything (no HIP call: usable without a GPU).
+int tce_w4a16_describe_dispatch(const tce_w4a16_desc *d, char *buf, int buf_len) {
+    if (!buf || buf_len <= 0) return fail(TCE_ERR_BAD_ARG, "tce_w4a16_describe_dispatch: no buffer");
+    const int rc0 = check_w4a16(d);
+    if (rc0 != TCE_OK) return rc0;
+    const bool want_gemm = (d->flags & TCE_W4_FORCE_GEMM) ||
+                           (d->M > TCE_W4A16_GEMV_MAX_M && !(d->flags & (TCE_W4_FORCE_GEMV | TCE_W4_SILU_MUL_PAIRS)));
+    if (g_skinny_enabled && !(d->flags & (TCE_W4_FORCE_GEMV | TCE_W4_FORCE_GEMM)) && tce::skinny_supports(*d)) {
+        std::snprintf(buf, (size_t)buf_len, "small-batch slices=%d", (d->M + 15) / 16);
+        return TCE_OK;
+    }
+    if (want_gemm && d->K % 128 == 0 && (d->group_size == 128 || (d->M > 16 && g_gemm_mt == 0))) {
+        if (g_gemm_mt == 0 || g_gemm_mt >= 200) {
+            int mt = g_gemm_mt ? g_gemm_mt - 200 : 0, nt = g_gemm_nt, ks = 0;
+            if (mt == 0) tce::gemm_dma_describe(d->M, d->N, d->group_size == 128, &mt, &nt, &ks);
+            std::snprintf(buf, (size_t)buf_len, "gemm-dma tile=%dx%d quartets=%d group=%d", mt * 16, nt * 64, ks, d->group_size);
+        } else {
+            std::snprintf(buf, (size_t)buf_len, "gemm tile=%dx%d", (g_gemm_mt % 100) * 16, g_gemm_nt * 64);
+        }
+        return TCE_OK;
+    }
+    std::snprintf(buf, (size_t)buf_len, "gemv passes=%d", (d->M + 3) / 4);
+    return TCE_OK;
+}
+
 int tce_w4a16_check_zero_point_8(const void *zeros, long long n_words) {
     if (!zeros || n_words <= 0) return fail(TCE_ERR_BAD_ARG, "tce_w4a16_check_zero_point_8: bad argument");
     hipError_t he = hipSuccess;

@@ -517,6 +517,8 @@ float choose_tile(int M, int N, bool g128, int *mt, int *nt, int *ks) {  // retu
 
 void set_gemm_dma_mode(int mode) { g_dma_ks = mode & 3; }
 
+void gemm_dma_describe(int M, int N, bool g128, int *mt, int *nt, int *ks) { choose_tile(M, N, g128, mt, nt, ks); }
+
 float gemm_dma_estimate_us(int M, int N, int K) {
     int mt, nt, ks;
     return choose_tile(M, N, true, &mt, &nt, &ks) * (float)(K / 128);

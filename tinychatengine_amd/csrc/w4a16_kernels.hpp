@@ -86,7 +86,8 @@ int launch_w4a16_gemv(const tce_w4a16_desc *descs, int count, int forced_rows, i
 bool gemm_variant_exists(int m_tiles, int n_tiles);
 void set_gemm_xcd_rows(int xm);
 void set_gemm_dma_xcd_rows(int xm);
-float gemm_dma_estimate_us(int M, int N, int K);  // the GEMM dispatcher's cost model (rounds x k-blocks x us per k-block)
+float gemm_dma_estimate_us(int M, int N, int K);
+void gemm_dma_describe(int M, int N, bool g128, int *mt, int *nt, int *ks);  // the tile and form launch_w4a16_gemm_dma would pick  // the GEMM dispatcher's cost model (rounds x k-blocks x us per k-block)
 void set_gemm_dma_mode(int mode);
 void set_w8a8_ksplit(int ks);  // w8a8_gemm.hip tuning: wave quartets per tile (0 = automatic)  // timing experiments, see w4a16_gemm_dma.hip
 // w4a16_gemm_dma.hip: same contract as launch_w4a16_gemm with an explicit tile; TCE_ERR_UNSUPPORTED_SHAPE when the shape
