@@ -256,7 +256,7 @@ TCE_API const char *tce_build_info(void);
  * "last error", and the next launch's check here would return it as TCE_ERR_HIP.  Returns the HIP error code it dropped. */
 TCE_API int tce_reset_last_error(void);
 /* Which kernel family (and, for the GEMM, which tile and form) tce_w4a16_forward would run for this descriptor, as text:
- * "gemv passes=P" | "small-batch slices=S" | "gemm-dma tile=RxC quartets=Q group=G" | "gemm tile=RxC".  Launches nothing and
+ * "gemv passes=P kernel=row-block|persistent" | "small-batch slices=S" | "gemm-dma tile=RxC quartets=Q group=G" | "gemm tile=RxC".  Launches nothing and
  * makes no HIP call (works without a GPU); a shape the chosen GEMM form cannot hold in LDS still falls back at launch time. */
 TCE_API int tce_w4a16_describe_dispatch(const tce_w4a16_desc *d, char *buf, int buf_len);
 /* Force a GEMV kernel + launch geometry for every subsequent call from this process (all 0 = automatic).

@@ -190,6 +190,26 @@ class Oracle(_Lib):
         self.lib.orc_w4a16_gemv_q4_6(C.c_int(M), C.c_int(N), C.c_int(K), C.c_int(G), _p(A), _p(q), _p(s), _p(z), _p(c32), _p(c16))
         return c32, c16.view(np.float16)
 
+    def w4a16_gemv_q4_6_mt(self, A_f16, qweight, scales_f16, zeros, M, N, K, G, threads: int | None = None):
+        """The same function over row ranges of the weight matrix on several host threads (an output column depends on
+        its own weight row only, so the result is bit-identical to the single call; ctypes releases the GIL)."""
+        from concurrent.futures import ThreadPoolExecutor
+        threads = threads or min(64, os.cpu_count() or 1)
+        A = np.ascontiguousarray(A_f16).view(np.uint16); q = np.ascontiguousarray(qweight).view(np.uint32).reshape(N, K // 8)
+        s = np.ascontiguousarray(scales_f16).view(np.uint16).reshape(N, -1); z = np.ascontiguousarray(zeros).view(np.uint32).reshape(N, -1)
+        step = max(16, -(-N // (threads * 4)))
+        c32 = np.empty((M, N), np.float32)
+
+        def part(n0):
+            n1 = min(N, n0 + step)
+            o = np.empty((M, n1 - n0), np.float32)
+            self.lib.orc_w4a16_gemv_q4_6(C.c_int(M), C.c_int(n1 - n0), C.c_int(K), C.c_int(G), _p(A), _p(q[n0:n1]), _p(s[n0:n1]), _p(z[n0:n1]), _p(o), None)
+            c32[:, n0:n1] = o
+
+        with ThreadPoolExecutor(max_workers=threads) as pool:
+            list(pool.map(part, range(0, N, step)))
+        return c32
+
     def add_half(self, a_f16, b_f16):
         a = np.ascontiguousarray(a_f16, np.float16).view(np.uint16); b = np.ascontiguousarray(b_f16, np.float16).view(np.uint16)
         out = np.empty(a.shape, np.uint16)

@@ -11,8 +11,10 @@ def _desc(M, N, K, G=128, flags=0):
 
 
 @pytest.mark.parametrize("shape,expect", [
-    ((1, 4096, 4096), "gemv passes=1"),                       # decode
-    ((2, 11008, 4096), "gemv passes=1"),                      # M = 2 stays on the GEMV kernels
+    ((1, 4096, 4096), "gemv passes=1 kernel=row-block"),      # decode
+    ((1, 128256, 4096), "gemv passes=1 kernel=persistent"),   # the Llama-3 lm_head: >= 200 M weights -> the persistent kernel
+    ((1, 32000, 4096), "gemv passes=1 kernel=row-block"),
+    ((2, 11008, 4096), "gemv passes=1 kernel=row-block"),                      # M = 2 stays on the GEMV kernels
     ((3, 4096, 4096), "small-batch slices=1"),
     ((16, 22016, 4096), "small-batch slices=1"),
     ((32, 4096, 4096), "small-batch slices=2"),                # N too small to fill the chip with GEMM tiles
@@ -23,8 +25,8 @@ def _desc(M, N, K, G=128, flags=0):
     ((512, 11008, 4096), "gemm-dma tile=64x128 quartets=1 group=128"), # 688 workgroups on 512 slots
     ((4096, 4096, 4096), "gemm-dma tile=64x128 quartets=1 group=128"),
     ((512, 4096, 4096, 64), "gemm-dma tile=64x128 quartets=2 group=64"),
-    ((9, 4096, 4096, 64), "gemv passes=3"),                   # other group sizes below M = 17: GEMV kernel, 4 rows per pass
-    ((12, 4096, 4096, 128, capi.TCE_W4_FORCE_GEMV), "gemv passes=3"),
+    ((9, 4096, 4096, 64), "gemv passes=3 kernel=row-block"),                   # other group sizes below M = 17: GEMV kernel, 4 rows per pass
+    ((12, 4096, 4096, 128, capi.TCE_W4_FORCE_GEMV), "gemv passes=3 kernel=row-block"),
 ])
 def test_dispatch_of_documented_regimes(shape, expect):
     assert capi.describe_dispatch(_desc(*shape)) == expect
@@ -32,7 +34,7 @@ def test_dispatch_of_documented_regimes(shape, expect):
 
 def test_forced_paths_and_errors():
     assert capi.describe_dispatch(_desc(1, 4096, 4096, 128, capi.TCE_W4_FORCE_GEMM)).startswith("gemm-dma")
-    assert capi.describe_dispatch(_desc(64, 4096, 4096, 128, capi.TCE_W4_FORCE_GEMV)) == "gemv passes=16"
+    assert capi.describe_dispatch(_desc(64, 4096, 4096, 128, capi.TCE_W4_FORCE_GEMV)) == "gemv passes=16 kernel=row-block"
     with pytest.raises(capi.TceError):
         capi.describe_dispatch(_desc(4, 4096, 4160))  # K not a multiple of the group size
     try:

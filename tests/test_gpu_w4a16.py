@@ -9,7 +9,7 @@ The binary16-arithmetic AWQ entry point is bit-exact.
 import numpy as np
 import pytest
 
-from conftest import w4a16_close
+from conftest import record_parity, w4a16_close, w4a16_report
 
 pytestmark = pytest.mark.gpu
 
@@ -350,24 +350,45 @@ def test_error_codes_match_reference_behaviour(dev):
 # ---------------------------------------------------------------------------------------------------------
 # BASELINE.json full sizes
 # ---------------------------------------------------------------------------------------------------------
-FULL = [(4096, 4096), (11008, 4096), (4096, 11008), (14336, 4096), (4096, 14336), (1024, 4096), (12288, 4096)]
+FULL = [(4096, 4096), (11008, 4096), (4096, 11008), (14336, 4096), (4096, 14336), (1024, 4096), (12288, 4096),
+        # the two lm_head shapes (Llama-2 / Llama-3 vocabularies); 128256 x 4096 is the launch the dispatcher hands to the persistent kernel
+        (32000, 4096), (128256, 4096),
+        # BASELINE config 5 (cfgD): Llama-2-13B's linears, llm/include/model.h:72 -- fused qkv, o, gate / up, down
+        (15360, 5120), (5120, 5120), (13824, 5120), (5120, 13824)]
+
+
+def _floor_gate(got, ref32, what, limit=0.01):
+    """how much of the pass is owed to the rms/64 floor of w4a16_close?  Recorded for every full-size case
+    (gpurun_out/parity_report.jsonl -> DESIGN.md section 4) and bounded: at most `limit` of the elements may exceed the plain
+    1e-3 * |ref| rule, and none whose |ref| is at least rms/64."""
+    rep = w4a16_report(got, ref32)
+    record_parity(what, rep)
+    assert rep["frac_fail"] == 0.0, (what, rep)
+    assert rep["frac_over_plain"] < limit, (what, rep)
+    assert rep["worst_plain"] <= 1.0, (what, rep)
+    return rep
 
 
 @pytest.mark.parametrize("N,K", FULL)
 def test_full_size_decode_gemv(dev, oracle, N, K):
-    """configs[1]: M=1 at the Llama shapes, against the oracle directly (it needs < 1 s per shape), plus two
-    size-independent properties: exact homogeneity under x -> 2x and bit-identical results for row shards."""
+    """configs[1] and [4]: M=1 at the Llama shapes on the AUTOMATIC dispatch, every output against the oracle (threaded over
+    weight rows on the host), plus two size-independent properties: exact homogeneity under x -> 2x and bit-identical results
+    for 8-way row shards (= the column shards of SURVEY 8e)."""
     from tinychatengine_amd import capi
     from tinychatengine_amd.linear import Linear_half_int4
     G = 128
     g = torch.Generator(device=dev).manual_seed(1234 + N)
     lin = Linear_half_int4.from_float(torch.empty(N, K, device=dev).normal_(0, 0.02, generator=g), G)
     x = torch.empty(1, K, device=dev).normal_(0, 1, generator=g).to(torch.float16)
+    y = torch.full((1, N), float("nan"), dtype=torch.float16, device=dev)
+    want_kernel = "persistent" if N * K >= 200_000_000 else "row-block"
+    assert capi.describe_dispatch(lin.desc(x, y)) == f"gemv passes=1 kernel={want_kernel}"
     y = lin.forward(x)
     torch.cuda.synchronize()
-    ref32, _ = oracle.w4a16_gemv_q4_6(x.cpu().numpy(), lin.weight.cpu().numpy().view(np.uint32), lin.scale.cpu().numpy(),
+    ref32 = oracle.w4a16_gemv_q4_6_mt(x.cpu().numpy(), lin.weight.cpu().numpy().view(np.uint32), lin.scale.cpu().numpy(),
                                       lin.zero_point.cpu().numpy().view(np.uint32), 1, N, K, G)
     _check(y.cpu().numpy(), ref32, f"full {N}x{K}")
+    _floor_gate(y.cpu().numpy(), ref32, f"decode M=1 {N}x{K} ({want_kernel})")
     y2 = lin.forward(x * 2)
     torch.cuda.synchronize()
     # power-of-two scaling is exact in fp16/fp32 -- except where the fp16 OUTPUT is subnormal (|y| < 2^-14), where
@@ -388,9 +409,10 @@ def test_full_size_decode_gemv(dev, oracle, N, K):
 
 @pytest.mark.parametrize("N,K", [(4096, 4096), (11008, 4096), (4096, 11008)])
 def test_full_size_prefill_gemm(dev, oracle, N, K):
-    """configs[2]: M=512 on the MFMA path.  16 of the 512 rows are checked against the oracle (a full check costs
-    ~9e9 scalar MACs per shape on the host); the rest through a property: every input row appears twice in the batch and
-    both copies must give identical outputs, and the GEMV kernel (validated above) must agree on 4 more rows."""
+    """configs[2]: M=512 on the MFMA path.  128 of the 512 rows (every 4th: all 16-row MFMA tiles, all four row positions mod 4
+    over the batch's 64-row blocks) are checked against the oracle, threaded over weight rows on the host (5.8e9 scalar MACs for
+    the widest shape); the other rows through two properties: rows 256.. repeat rows 0..255 and must give identical outputs
+    (row tiles 4..7 against 0..3), and the GEMV kernel (validated above) must agree on 4 more rows."""
     from tinychatengine_amd import capi
     from tinychatengine_amd.linear import Linear_half_int4
     G, M = 128, 512
@@ -401,11 +423,13 @@ def test_full_size_prefill_gemm(dev, oracle, N, K):
     y = lin.forward(x)
     torch.cuda.synchronize()
     assert torch.equal(y[: M // 2], y[M // 2:]), "duplicate rows must produce identical outputs"
-    rows = list(range(0, 256, 16))
+    rows = [r for r in range(0, 512) if (r % 4) == ((r // 64) % 4)]
+    assert len(rows) == 128
     xs = x[rows].cpu().numpy()
-    ref32, _ = oracle.w4a16_gemv_q4_6(xs, lin.weight.cpu().numpy().view(np.uint32), lin.scale.cpu().numpy(),
+    ref32 = oracle.w4a16_gemv_q4_6_mt(xs, lin.weight.cpu().numpy().view(np.uint32), lin.scale.cpu().numpy(),
                                       lin.zero_point.cpu().numpy().view(np.uint32), len(rows), N, K, G)
     _check(y[rows].cpu().numpy(), ref32, f"prefill {N}x{K}")
+    _floor_gate(y[rows].cpu().numpy(), ref32, f"prefill M=512 {N}x{K} (128 rows)")
     yv = torch.empty(4, N, dtype=torch.float16, device=dev)
     d = lin.desc(x[3:7].contiguous(), yv)
     d.flags = capi.TCE_W4_FORCE_GEMV

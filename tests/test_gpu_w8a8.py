@@ -48,6 +48,8 @@ def _data(M, N, K, seed, corner=True):
 
 
 SHAPES = [(108, 3072, 768), (108, 768, 768), (512, 768, 768), (1, 768, 768), (1, 3072, 768), (512, 768, 3072), (108, 2048, 2048),
+          (512, 3072, 768),                      # BASELINE config 4, the fc1 shape bench.py times
+          (108, 8192, 2048), (108, 2048, 8192),  # OPT-1.3B fc1 / fc2 (test_ops.cc)
           (7, 40, 80), (65, 130, 208), (3, 5, 33), (2, 3, 16), (64, 64, 64),
           (5, 17, 96), (70, 33, 112), (130, 66, 176), (33, 65, 128), (16, 16, 192)]  # K % 64 in {32, 48, 0}: the transposed fragment tails
 

@@ -53,6 +53,8 @@ int check_w4a16(const tce_w4a16_desc *d) {
         if (d->N % 2 != 0) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "TCE_W4_SILU_MUL_PAIRS needs an even N (interleaved gate/up rows), got %d", d->N);
         if (d->flags & (TCE_W4_ADD_TO_C | TCE_W4_FORCE_GEMM)) return fail(TCE_ERR_BAD_ARG, "TCE_W4_SILU_MUL_PAIRS cannot be combined with ADD_TO_C / FORCE_GEMM");
     }
+    // the RMSNorm prologue lives in the GEMV kernels only: a forced GEMM would silently contract the un-normalised A
+    if (d->rmsnorm_gamma && (d->flags & TCE_W4_FORCE_GEMM)) return fail(TCE_ERR_BAD_ARG, "rmsnorm_gamma cannot be combined with TCE_W4_FORCE_GEMM");
     return TCE_OK;
 }
 
@@ -348,7 +350,10 @@ int tce_w4a16_describe_dispatch(const tce_w4a16_desc *d, char *buf, int buf_len)
         }
         return TCE_OK;
     }
-    std::snprintf(buf, (size_t)buf_len, "gemv passes=%d", (d->M + 3) / 4);
+    // which GEMV kernel: same rule as tce_w4a16_forward_group (one linear per launch here)
+    const bool persistent = g_gemv_kernel == 2 || (d->rmsnorm_gamma ? (g_gemv_kernel == 0 && d->N >= 8192)
+                                                                     : (g_gemv_kernel == 0 && d->M == 1 && (long long)d->N * d->K >= 200000000LL && g_debug_mode_capi == 0));
+    std::snprintf(buf, (size_t)buf_len, "gemv passes=%d kernel=%s", (d->M + 3) / 4, persistent && d->M == 1 ? "persistent" : "row-block");
     return TCE_OK;
 }
 
