@@ -31,9 +31,33 @@ def test_cpp_adapter_selftest(oracle, tmp_path):
     bias = rng.integers(-128, 128, N, dtype=np.int8)
     exp = oracle.int8_matmul_bias_i8(A, Bm, bias, al, be, 0, 127, M, N, K)
     blob += struct.pack("3i2f", M, N, K, al, be) + A.tobytes() + Bm.tobytes() + bias.tobytes() + exp.tobytes()
+    # case 3: the adapter's tensor cache.  Expected outputs are the library's own through the C ABI (bit-exact comparison in the
+    # self-test: the cached zero-point-8 fast path and the general path must both equal what a direct call returns)
+    from tinychatengine_amd import capi
+    M, N, K, G = 1, 64, 512, 128
+    w = (rng.standard_normal((N, K)) * 0.02).astype(np.float32)
+    qw, sc, zp8, _, _ = oracle.quantize_q4_6(w, G)
+    nib = rng.integers(0, 16, (N, zp8.shape[1] * 8), dtype=np.uint32)
+    zpr = (nib.reshape(N, -1, 8) << (np.arange(8, dtype=np.uint32) * 4)).sum(axis=2).astype(np.uint32)
+    x = rng.standard_normal((M, K)).astype(np.float16)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    outs = []
+    for z in (zp8, zpr):
+        tq, ts, tz, tx = t(qw.view(np.int32)), t(sc.view(np.float16)), t(z.view(np.int32)), t(x)
+        o = torch.zeros((M, N), dtype=torch.float16, device=dev)
+        d = capi.W4A16Desc(M=M, N=N, K=K, group_size=G, A=tx.data_ptr(), qweight=tq.data_ptr(), scales=ts.data_ptr(), zeros=tz.data_ptr(), C=o.data_ptr())
+        capi.check(capi.w4a16_forward(d, torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        ref32, _ = oracle.w4a16_gemv_q4_6(x, qw, sc, z, M, N, K, G)
+        from conftest import w4a16_close
+        assert w4a16_close(o.cpu().numpy(), ref32)[0]
+        outs.append(o.cpu().numpy())
+    assert not np.array_equal(outs[0], outs[1])
+    blob += struct.pack("5i", M, N, K, G, zp8.shape[1]) + qw.tobytes() + sc.tobytes() + zp8.tobytes() + zpr.tobytes() + x.tobytes() + outs[0].tobytes() + outs[1].tobytes()
     path = tmp_path / "vectors.bin"
     path.write_bytes(blob)
     r = subprocess.run([B.ADAPTER_TEST_PATH, str(path)], capture_output=True, text=True, timeout=300)
     print(r.stdout, r.stderr)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("Passed!") == 3 and "Fail!" not in r.stdout
+    assert r.stdout.count("Passed!") == 4 and "Fail!" not in r.stdout

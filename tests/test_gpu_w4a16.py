@@ -319,7 +319,7 @@ def test_awq_layout_gemm(dev, oracle, M):
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
     out = torch.full((M, N), float("nan"), dtype=torch.float16, device=dev)
     p = matmul_params(A=matrix(M, K, t(a)), B=matrix(K, N // 8, t(q5.view(np.int32))), C=matrix(M, N, out),
-                      fp16_scales=t(s5.view(np.float16)), block_size=G)
+                      half_scales=t(s5.view(np.float16)), block_size=G)
     ws = MatmulOperator().gemm_forward_cuda(p, 8)
     torch.cuda.synchronize()
     _check(out.cpu().numpy(), ref32, f"awq gemm M={M}")

@@ -177,6 +177,58 @@ int main(int argc, char **argv) {
         tce_free(A); tce_free(B); tce_free(bias); tce_free(out);
     }
 
+    // ---- case 3: the adapter's per-tensor caches (zero-point-is-8 flag): keyed by (pointer, shape), no capacity cliff, and a
+    //      buffer that is rewritten after tce_adapter_forget() takes the general path ----
+    {
+        const int M = b.get<int>(), N = b.get<int>(), K = b.get<int>(), G = b.get<int>(), zw = b.get<int>();
+        auto *w = managed_copy<int32_t>(b.take((size_t)N * (K / 8) * 4), (size_t)N * (K / 8));
+        auto *sc = managed_copy<float16_t>(b.take((size_t)N * zw * 8 * 2), (size_t)N * zw * 8);
+        const unsigned char *zp8 = b.take((size_t)N * zw * 4), *zpr = b.take((size_t)N * zw * 4);
+        auto *x = managed_copy<float16_t>(b.take((size_t)M * K * 2), (size_t)M * K);
+        const uint16_t *expect8 = reinterpret_cast<const uint16_t *>(b.take((size_t)M * N * 2));
+        const uint16_t *expectr = reinterpret_cast<const uint16_t *>(b.take((size_t)M * N * 2));
+        auto *out = managed_copy<float16_t>(nullptr, (size_t)M * N);
+        // 700 distinct zero-point tensors (more than the 512 slots the first version of the cache had)
+        const int n_tensors = 700;
+        auto *zps = managed_copy<int>(nullptr, (size_t)n_tensors * N * zw);
+        for (int t = 0; t < n_tensors; ++t) std::memcpy(zps + (size_t)t * N * zw, zp8, (size_t)N * zw * 4);
+        tce_adapter_forget_all();
+        struct matmul_params params;
+        poison(params);
+        params.A.row = M;
+        params.A.column = K;
+        params.A.half_data_ptr = x;
+        params.B.int32_data_ptr = w;
+        params.C.row = M;
+        params.C.column = N;
+        params.C.half_data_ptr = out;
+        params.half_scales = sc;
+        params.block_size = G;
+        matmul::MatmulOperator op = matmul::MatmulOperator();
+        bool ok = true;
+        for (int rep = 0; rep < 2; ++rep)
+            for (int t = 0; t < n_tensors; ++t) {
+                params.int32_zero_point = zps + (size_t)t * N * zw;
+                op.gemv_forward_cuda(&params);
+            }
+        tce_synchronize(nullptr);
+        ok &= tce_adapter_cache_entries() == n_tensors;  // every tensor remembered, none evicted, none re-checked
+        ok &= std::memcmp(out, expect8, (size_t)M * N * 2) == 0;
+        // the host rewrites tensor 3 (model reload): forget, then real zero points must be read
+        int *z3 = zps + (size_t)3 * N * zw;
+        tce_adapter_forget(z3);
+        ok &= tce_adapter_cache_entries() == n_tensors - 1;
+        std::memcpy(z3, zpr, (size_t)N * zw * 4);
+        params.int32_zero_point = z3;
+        op.gemv_forward_cuda(&params);
+        tce_synchronize(nullptr);
+        ok &= std::memcmp(out, expectr, (size_t)M * N * 2) == 0;
+        tce_adapter_forget_all();
+        ok &= tce_adapter_cache_entries() == 0;
+        all_ok &= report("adapter tensor cache (700 tensors, forget + rewrite)", ok);
+        tce_free(w); tce_free(sc); tce_free(zps); tce_free(x); tce_free(out);
+    }
+
     // ---- layout: this build's matmul_params must be the reference's (416 bytes, kernels/matmul.h:78-92) ----
     all_ok &= report("matmul_params layout", tce_adapter_layout(0) == 416);
     return all_ok ? 0 : 1;

@@ -14,6 +14,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
+#include <unordered_map>
 
 #include "tce_matmul.h"
 
@@ -24,36 +27,45 @@ namespace {
     std::exit(1);
 }
 
-// workspace for the AWQ-layout GEMM surface: the re-laid-out weights are cached per weight pointer (the operator
-// itself is stateless in the reference; ownership of model buffers stays with the caller -- SURVEY §8b)
-struct AwqCache {
-    const void *qweight = nullptr;
-    void *workspace = nullptr;
+// Per-tensor state the stateless reference operator does not have ("the HIP shim may keep an internal cache keyed
+// by weight pointer").  Both caches are hash maps keyed by the tensor's identity AS THE CALL DESCRIBES IT -- pointer AND shape
+// (a different N / K / group at a recycled address is a different key, never a stale hit) -- guarded by one mutex, with no
+// capacity cliff.  A host that frees or overwrites model buffers tells the adapter: tce_adapter_forget(ptr) (called by the
+// free_aligned_memory_gpu of INTEGRATION.md 2.4) or tce_adapter_forget_all().  Same pointer + same shape + different CONTENTS
+// without that call is the one case the adapter cannot see; model weights are immutable after loading in the reference
+// (Linear_half_int4's constructor is the only writer, llm/include/ops/linear.h:215-240).
+struct TensorKey {
+    const void *ptr;
+    long long a, b, c;  // shape words (zeros: n_words, 0, 0; AWQ weights: N, K, G)
+    bool operator==(const TensorKey &o) const { return ptr == o.ptr && a == o.a && b == o.b && c == o.c; }
+};
+struct TensorKeyHash {
+    size_t operator()(const TensorKey &k) const {
+        size_t h = std::hash<const void *>()(k.ptr);
+        for (long long v : {k.a, k.b, k.c}) h ^= std::hash<long long>()(v) + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+        return h;
+    }
+};
+struct AwqEntry {
+    void *workspace = nullptr;  // q4_6 re-layout of a q4_5 tensor (tce_w4a16_gemm_awq)
     size_t bytes = 0;
 };
-AwqCache g_awq[64];
+std::mutex g_mu;
+std::unordered_map<TensorKey, int, TensorKeyHash> g_zero;       // zero-point tensor -> every packed zero point is 8
+std::unordered_map<TensorKey, AwqEntry, TensorKeyHash> g_awq;   // AWQ weight tensor -> re-laid-out copy
 
-// TCE_W4_ZERO_POINT_IS_8 fast path: checked once per zero-point tensor (model weights are immutable after loading)
-struct ZeroCache {
-    const void *zeros = nullptr;
-    long long words = 0;
-    int is8 = 0;
-};
-ZeroCache g_zero[512];
-
+// TCE_W4_ZERO_POINT_IS_8 fast path: checked once per zero-point tensor
 int zeros_are_8(const void *zeros, long long words) {
-    ZeroCache *free_slot = nullptr;
-    for (auto &c : g_zero) {
-        if (c.zeros == zeros && c.words == words) return c.is8;
-        if (!c.zeros && !free_slot) free_slot = &c;
+    const TensorKey key{zeros, words, 0, 0};
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_zero.find(key);
+        if (it != g_zero.end()) return it->second;
     }
-    const int r = tce_w4a16_check_zero_point_8(zeros, words);
+    const int r = tce_w4a16_check_zero_point_8(zeros, words);  // synchronous, once per tensor
     if (r < 0) return 0;
-    if (free_slot) {
-        free_slot->zeros = zeros;
-        free_slot->words = words;
-        free_slot->is8 = r;
-    }
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_zero[key] = r;
     return r;
 }
 
@@ -129,31 +141,29 @@ void MatmulOperator::naive_mat_mul_fp16_int4(const struct matmul_params *params)
 void MatmulOperator::gemm_forward_cuda(const struct matmul_params *params, int /*split_k_iters*/) {
     const int M = params->C.row, N = params->C.column, K = params->B.row, G = params->block_size;
     const void *qw = params->B.int32_data_ptr;
-    AwqCache *slot = nullptr;
-    for (auto &c : g_awq)
-        if (c.qweight == qw) slot = &c;
+    const size_t need = tce_w4a16_awq_workspace_bytes(N, K, G);
+    if (need == 0) die("gemm_forward_cuda", TCE_ERR_UNSUPPORTED_GROUP);
+    void *ws = nullptr;
     int repack = 0;
-    if (!slot) {
-        for (auto &c : g_awq)
-            if (!c.qweight) {
-                slot = &c;
-                break;
-            }
-        if (!slot) slot = &g_awq[0];  // table full: recycle
-        const size_t need = tce_w4a16_awq_workspace_bytes(N, K, G);
-        if (need == 0) die("gemm_forward_cuda", TCE_ERR_UNSUPPORTED_GROUP);
-        if (slot->bytes < need) {
-            if (slot->workspace) tce_free(slot->workspace);
-            slot->workspace = nullptr;
-            const int arc = tce_malloc(&slot->workspace, need, /*managed=*/0);
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        AwqEntry &e = g_awq[TensorKey{qw, N, K, G}];
+        if (!e.workspace || e.bytes < need) {  // first sight of this (pointer, N, K, G): allocate and re-lay-out
+            if (e.workspace) tce_free(e.workspace);
+            e.workspace = nullptr;
+            e.bytes = 0;
+            const int arc = tce_malloc(&e.workspace, need, /*managed=*/0);
             if (arc != TCE_OK) die("gemm_forward_cuda (workspace)", arc);
-            slot->bytes = need;
+            e.bytes = need;
+            repack = 1;
         }
-        slot->qweight = qw;
-        repack = 1;
+        ws = e.workspace;
     }
-    const int rc = tce_w4a16_gemm_awq(M, N, K, G, params->A.half_data_ptr, qw, params->half_scales, params->C.half_data_ptr,
-                                      slot->workspace, repack, nullptr);
+    // Fields read: the CUDA-typed ones (A / C .half_data_ptr, half_scales) -- gemm_forward_cuda is a device entry point like
+    // gemv_forward_cuda (kernels/matmul.h:140-145 sits in the QM_CUDA block); fp16_scales belongs to the software-half
+    // reference naive_mat_mul_fp16_int4.  The Python mirror (tinychatengine_amd/matmul.py) reads the same fields.
+    const void *scales = params->half_scales;
+    const int rc = tce_w4a16_gemm_awq(M, N, K, G, params->A.half_data_ptr, qw, scales, params->C.half_data_ptr, ws, repack, nullptr);
     if (rc != TCE_OK) die("gemm_forward_cuda", rc);
 }
 void MatmulOperator::gemm_forward_cuda_8splits(const struct matmul_params *params, float16_t * /*split_8_buffer*/) {
@@ -197,6 +207,32 @@ void MatmulOperator::mat_mul_accelerator_int4_fast(const struct matmul_params *)
 void MatmulOperator::mat_mul_accelerator_int4_fast_no_offset(const struct matmul_params *) {}
 
 }  // namespace matmul
+
+// Drops what the adapter remembers about a buffer (any tensor whose data starts at ptr): call it before freeing or
+// rewriting model memory.  tce_adapter_forget_all() drops everything (e.g. on model reload).
+extern "C" void tce_adapter_forget(const void *ptr) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto it = g_zero.begin(); it != g_zero.end();) it = it->first.ptr == ptr ? g_zero.erase(it) : std::next(it);
+    for (auto it = g_awq.begin(); it != g_awq.end();) {
+        if (it->first.ptr == ptr) {
+            if (it->second.workspace) tce_free(it->second.workspace);
+            it = g_awq.erase(it);
+        } else {
+            ++it;
+        }
+    }
+}
+extern "C" void tce_adapter_forget_all(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_zero.clear();
+    for (auto &kv : g_awq)
+        if (kv.second.workspace) tce_free(kv.second.workspace);
+    g_awq.clear();
+}
+extern "C" long tce_adapter_cache_entries(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return (long)(g_zero.size() + g_awq.size());
+}
 
 extern "C" long tce_adapter_layout(int idx) {
     switch (idx) {

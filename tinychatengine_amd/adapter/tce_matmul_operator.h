@@ -5,11 +5,11 @@
 // 110-153); the backend is whichever object file defines those members at link time (llm/Makefile:64-65,86-88).
 // matmul_operator_hip.cc defines them on top of the C ABI (include/tce_matmul.h).
 //
-// In the reference tree the adapter is compiled against the reference's OWN kernels/matmul.h plus the three-line
-// QM_HIP typedef branch shown in INTEGRATION.md.  This header exists so the adapter and its self-test build inside
-// this repository, where the reference sources are not available: it re-declares the descriptor types with the
-// same names, field order and sizes (checked against the reference build by tests/test_boundary.py through
-// tce_adapter_layout()), and the member functions the hot path needs.  float16_t is a 2-byte type in every
+// In the reference tree the adapter is compiled against the reference's OWN kernels/matmul.h (-DTCE_ADAPTER_USE_REFERENCE_HEADER;
+// oracle/Makefile target `l2link` does exactly that and links the result with the reference's unmodified level-2 callers --
+// tests/test_l2_link.py).  The re-declaration below exists so that libtce_matmul_operator.so and its self-test also build on
+// a box without the reference tree (the GPU box): same names, field order and sizes (checked against the reference build by
+// tests/test_boundary.py through tce_adapter_layout()), and the member functions the hot path needs.  float16_t is a 2-byte type in every
 // reference flavour (kernels/matmul.h:12-28), so the layout is backend-independent.
 #ifndef TCE_MATMUL_OPERATOR_H
 #define TCE_MATMUL_OPERATOR_H
@@ -93,6 +93,12 @@ class MatmulOperator {
 #else
 #include "matmul.h"  // the reference's header (with the QM_HIP branch of INTEGRATION.md)
 #endif
+
+// Per-tensor caches of the adapter (zero-point-is-8 flags, AWQ re-layouts; see matmul_operator_hip.cc): forget one buffer
+// (call before freeing / rewriting it) or everything; number of live entries.
+extern "C" void tce_adapter_forget(const void *ptr);
+extern "C" void tce_adapter_forget_all(void);
+extern "C" long tce_adapter_cache_entries(void);
 
 // Layout probe used by the tests: index -> value (0 sizeof(matmul_params), 1 sizeof(matrix), 2.. offsets).
 extern "C" long tce_adapter_layout(int idx);

@@ -228,14 +228,12 @@ int launch_attention_decode(const void *q, const void *K, const void *Vt, const 
     const size_t lds = ((size_t)2 * ((t + 7) & ~7) + hd) * 2;
     if (lds > 150 * 1024) return TCE_ERR_UNSUPPORTED_SHAPE;
     auto kfn = attention_decode_kernel;
-    static size_t lds_allowed = 64 * 1024;
-    if (lds > lds_allowed) {
+    if (lds > 64 * 1024) {  // per launch: the attribute is per device, and a process may drive several (no cached "already raised" flag)
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             if (hip_err) *hip_err = e;
             return TCE_ERR_HIP;
         }
-        lds_allowed = lds;
     }
     hipLaunchKernelGGL(kfn, dim3(heads), dim3(1024), lds, stream, static_cast<const half_t *>(q), static_cast<const half_t *>(K), static_cast<const half_t *>(Vt),
                        static_cast<const half_t *>(mask), static_cast<half_t *>(out), t, hd, alpha);

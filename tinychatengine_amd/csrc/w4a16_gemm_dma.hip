@@ -433,11 +433,9 @@ hipError_t launch_lg(DmaGemmArgs &g, hipStream_t stream) {
     lds = (lds + 15) & ~(size_t)15;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto kfn = w4a16_gemm_dma_kernel<MT, NT, KS, LG>;
-    static size_t lds_allowed = 64 * 1024;  // per instantiation: raise the dynamic-LDS limit once per size, not per launch
-    if (lds > lds_allowed) {
+    if (lds > 64 * 1024) {  // per launch: the attribute is per device, and a process may drive several
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        lds_allowed = lds;
     }
     hipLaunchKernelGGL(kfn, dim3(8 * g.m_per * g.n_per), dim3(256 * KS), lds, stream, g);
     return hipGetLastError();

@@ -563,7 +563,15 @@ int launch_w4a16_gemv(const tce_w4a16_desc *descs, int count, int forced_rows, i
     for (int i = count; i < TCE_MAX_GROUP; ++i) a.seg[i] = a.seg[0];
 
     // M rows are processed MB at a time by gridDim.y; MB in {1,2,4}
-    const int mb = d0.M >= 4 ? 4 : (d0.M >= 2 ? 2 : 1);
+    int mb = d0.M >= 4 ? 4 : (d0.M >= 2 ? 2 : 1);
+    {
+        // the x image of mb rows must fit the CU's 160 KiB of LDS (launch_one's formula): fewer rows per pass for a long K,
+        // and a clear refusal -- not a generic HIP launch error -- when even one row does not fit (K > ~80k)
+        const int LS = 64 * v.wk, T = (nchunks + LS - 1) / LS;
+        auto need = [&](int m) { return (size_t)m * T * LS * 64 + (size_t)64 * v.wn * v.wk * 16; };
+        while (mb > 1 && need(mb) > 160 * 1024) mb >>= 1;
+        if (need(mb) > 160 * 1024) return TCE_ERR_UNSUPPORTED_SHAPE;
+    }
     const int m_blocks = (d0.M + mb - 1) / mb;
     bool found = false;
     hipError_t e;

@@ -46,13 +46,21 @@ SHAPES = {
 
 
 def _synthetic_linear(n: int, k: int, seed: int, device, group_size: int, rank: int, world: int) -> Linear_half_int4:
-    """W ~ N(0, 0.02^2) fp32 [N][K] (SURVEY §8d), quantized with the reference's q4_6 recipe; rank keeps rows
-    [rank*N/P, (rank+1)*N/P).  The full matrix is generated on every rank (same seed) so shards are consistent."""
-    g = torch.Generator(device=device).manual_seed(seed)
+    """W ~ N(0, 0.02^2) fp32 [N][K] (SURVEY section 8d), quantized with the reference's q4_6 recipe; rank keeps rows
+    [rank*N/P, (rank+1)*N/P).  The matrix is defined in eight row blocks, each drawn from its own seed, so a rank generates
+    ONLY the blocks it owns (1/P of the fp32 matrix, not all of it) and every world size in {1, 2, 4, 8} sees the same values."""
     n_loc = n // world
-    # generate only this rank's rows, but from a per-row-block seed so that world sizes agree on the values
-    w = torch.empty((n, k), dtype=torch.float32, device=device).normal_(0.0, 0.02, generator=g)
-    w = w[rank * n_loc:(rank + 1) * n_loc]
+    blocks = 8 if (n % 8 == 0 and 8 % world == 0) else 1
+    if blocks == 1:  # odd sizes (tests): draw everything, keep the slice
+        g = torch.Generator(device=device).manual_seed(seed)
+        w = torch.empty((n, k), dtype=torch.float32, device=device).normal_(0.0, 0.02, generator=g)[rank * n_loc:(rank + 1) * n_loc]
+    else:
+        rows = n // blocks
+        per_rank = blocks // world
+        w = torch.empty((n_loc, k), dtype=torch.float32, device=device)
+        for j in range(per_rank):
+            g = torch.Generator(device=device).manual_seed(seed * 8 + rank * per_rank + j)
+            w[j * rows:(j + 1) * rows].normal_(0.0, 0.02, generator=g)
     lin = Linear_half_int4.from_float(w.contiguous(), group_size)
     del w
     return lin
@@ -65,12 +73,13 @@ class DecodeLinears:
                  m: int = 1, seed: int = 1234, layers: int | None = None):
         self.shape, self.rank, self.world, self.m, self.group_size = shape, rank, world, m, group_size
         self.device = torch.device(device)
+        self._host_ok = self.device.type != "cuda"  # CPU tests of the sharding logic build descriptors for host tensors
         L = shape.layers if layers is None else layers
         self.n_layers = L
         h, f = shape.hidden, shape.ffn
         for n in (*shape.qkv, h, f, shape.vocab):
-            if n % world or (n // world) % 4:
-                raise ValueError(f"N={n} does not shard {world}-way into multiples of 4 rows")
+            if n % world or (n // world) % 16:
+                raise ValueError(f"N={n} does not shard {world}-way into multiples of 16 rows")
         mk = lambda n, k, s: _synthetic_linear(n, k, seed + s, self.device, group_size, rank, world)
         self.blocks = []
         for li in range(L):
@@ -100,17 +109,17 @@ class DecodeLinears:
     def block_launches(self, li: int) -> list[list[capi.W4A16Desc]]:
         b = self.blocks[li]
         return [
-            [l.desc(self.x, o) for l, o in zip(b["qkv"], self.out_qkv)],
-            [b["o"].desc(self.attn, self.out_o)],
-            [b["gate"].desc(self.h2, self.out_gate), b["up"].desc(self.h2, self.out_up)],
-            [b["down"].desc(self.act, self.out_down)],
+            [l.desc(self.x, o, allow_host=self._host_ok) for l, o in zip(b["qkv"], self.out_qkv)],
+            [b["o"].desc(self.attn, self.out_o, allow_host=self._host_ok)],
+            [b["gate"].desc(self.h2, self.out_gate, allow_host=self._host_ok), b["up"].desc(self.h2, self.out_up, allow_host=self._host_ok)],
+            [b["down"].desc(self.act, self.out_down, allow_host=self._host_ok)],
         ]
 
     def token_launches(self, grouped: bool = True) -> list[list[capi.W4A16Desc]]:
         out = []
         for li in range(self.n_layers):
             out += self.block_launches(li)
-        out.append([self.lm_head.desc(self.x, self.logits)])
+        out.append([self.lm_head.desc(self.x, self.logits, allow_host=self._host_ok)])
         if not grouped:  # one launch per linear, as the reference issues them
             out = [[d] for g in out for d in g]
         return out
@@ -140,7 +149,7 @@ class DecodeLinears:
             launch(g)
 
     def run_lm_head(self, launch=None) -> None:
-        (launch or self._hip_launch)([self.lm_head.desc(self.x, self.logits)])
+        (launch or self._hip_launch)([self.lm_head.desc(self.x, self.logits, allow_host=self._host_ok)])
 
     def run_token_distributed(self, gathers_per_block: int = 1, launch=None) -> None:
         """world > 1: per block, the rank-local GEMVs on N/P shards, then the all-gather(s) of the fp16 output slices
@@ -165,5 +174,5 @@ class DecodeLinears:
                 launch(lch[1]); ag(self.g_o.view(-1), self.out_o.view(-1))
                 launch(lch[2]); ag(self.g_gate.view(-1), self.out_gate.view(-1)); ag(self.g_up.view(-1), self.out_up.view(-1))
                 launch(lch[3]); ag(self.g_down.view(-1), self.out_down.view(-1))
-        launch([self.lm_head.desc(self.x, self.logits)])
+        launch([self.lm_head.desc(self.x, self.logits, allow_host=self._host_ok)])
         ag(self.g_logits.view(-1), self.logits.view(-1))

@@ -33,10 +33,30 @@ class Linear_half_int4:
     def load(cls, dirname: str, out_features: int, in_features: int, group_size: int = quantize.QK4_6, device="cuda"):
         return cls(*quantize.load_linear_q4_6(dirname, out_features, in_features, group_size, device), group_size=group_size)
 
-    def desc(self, x: torch.Tensor, out: torch.Tensor, ldc: int = 0, flags: int = 0, gamma: torch.Tensor | None = None, eps: float = 0.0) -> capi.W4A16Desc:
+    def desc(self, x: torch.Tensor, out: torch.Tensor, ldc: int = 0, flags: int = 0, gamma: torch.Tensor | None = None, eps: float = 0.0,
+             allow_host: bool = False) -> capi.W4A16Desc:
+        """The C-ABI descriptor of self(x) -> out.  Everything the kernels assume about the buffers is checked here (device
+        memory, dtype, contiguity, sizes): a sliced / transposed x, an fp16 gamma or a short output would otherwise be a silent
+        out-of-bounds device read.  allow_host=True skips only the is_cuda check (CPU tests of the sharding logic build
+        descriptors for host tensors and never hand them to the library)."""
         m = x.numel() // self.in_features
-        # plain data_ptr(): descriptors are also built for host tensors by the CPU-side tests of the sharding logic;
-        # the C ABI itself only ever receives device pointers on the product path (MatmulOperator checks is_cuda)
+        pairs = bool(flags & capi.TCE_W4_SILU_MUL_PAIRS)
+        n_out = self.out_features // 2 if pairs else self.out_features
+        for name, t, dt in (("x", x, torch.float16), ("out", out, torch.float16), ("gamma", gamma, torch.float32)):
+            if t is None:
+                continue
+            if t.dtype != dt:
+                raise ValueError(f"{name} must be {dt}, got {t.dtype}")
+            if not t.is_contiguous():
+                raise ValueError(f"{name} must be contiguous")
+            if not allow_host and not t.is_cuda:
+                raise ValueError(f"{name} must be a device tensor (no CPU fallback)")
+        if x.numel() != m * self.in_features or m < 1:
+            raise ValueError("x is not [M][in_features]")
+        if out.numel() < (m - 1) * (ldc or n_out) + n_out:
+            raise ValueError("out is too small for [M][N] with this ldc")
+        if gamma is not None and gamma.numel() != self.in_features:
+            raise ValueError("gamma must be fp32 [in_features]")
         return capi.W4A16Desc(M=m, N=self.out_features, K=self.in_features, group_size=self.group_size, A=x.data_ptr(),
                               qweight=self.weight.data_ptr(), scales=self.scale.data_ptr(), zeros=self.zero_point.data_ptr(),
                               C=out.data_ptr(), ldc=ldc, flags=flags | (capi.TCE_W4_ZERO_POINT_IS_8 if self.zeros_are_8 else 0),
@@ -81,7 +101,9 @@ class Linear_half_int4:
     def shard(self, rank: int, world: int) -> "Linear_half_int4":
         """Rows [rank*N/P, (rank+1)*N/P): a contiguous byte range of weights, scales and zeros in q4_6."""
         n = self.out_features
-        assert n % world == 0 and (n // world) % 4 == 0
+        # forward() keeps the reference wrapper's N % 16 == 0 (linear.cu:16-17): a shard must satisfy it too to be runnable
+        if n % world or (n // world) % 16:
+            raise ValueError(f"N={n} does not shard {world}-way into multiples of 16 rows (Linear_half_int4::forward's own requirement)")
         lo, hi = rank * (n // world), (rank + 1) * (n // world)
         return Linear_half_int4(self.weight[lo:hi].contiguous(), self.scale[lo:hi].contiguous(),
                                 self.zero_point[lo:hi].contiguous(), self.group_size)
@@ -100,7 +122,9 @@ def rmsnorm_half(x: torch.Tensor, gamma: torch.Tensor, eps: float, out: torch.Te
     if out is None:
         out = torch.empty_like(x)
     n = x.shape[-1]
-    capi.check(capi.lib().tce_rmsnorm_half(x.data_ptr(), gamma.data_ptr(), out.data_ptr(), x.numel() // n, n, float(eps), _stream()))
+    if x.dtype != torch.float16 or out.dtype != torch.float16 or gamma.dtype != torch.float32 or gamma.numel() != n:
+        raise ValueError("rmsnorm_half: x / out fp16 [..., n], gamma fp32 [n]")
+    capi.check(capi.lib().tce_rmsnorm_half(_ptr(x), _ptr(gamma), _ptr(out), x.numel() // n, n, float(eps), _stream()))
     return out
 
 
@@ -110,7 +134,9 @@ def forward_group_rmsnorm(linears: list[Linear_half_int4], x: torch.Tensor, outs
     import ctypes as C
     descs = [l.desc(x, o) for l, o in zip(linears, outs)]
     arr = (capi.W4A16Desc * len(descs))(*descs)
-    capi.check(capi.lib().tce_w4a16_forward_group_rmsnorm(arr, len(descs), gamma.data_ptr(), float(eps), C.c_void_p(_stream() or 0)))
+    if gamma.dtype != torch.float32 or gamma.numel() != x.shape[-1]:
+        raise ValueError("gamma must be fp32 [in_features]")
+    capi.check(capi.lib().tce_w4a16_forward_group_rmsnorm(arr, len(descs), _ptr(gamma), float(eps), C.c_void_p(_stream() or 0)))
 
 
 class W8A8B8O8Linear:

@@ -89,7 +89,7 @@ class MatmulOperator:
             workspace = torch.empty(need, dtype=torch.uint8, device=A.data.device)
         if workspace.numel() * workspace.element_size() < need:
             raise ValueError("workspace too small")
-        capi.check(capi.lib().tce_w4a16_gemm_awq(Cm.row, N, K, G, _ptr(A.data), _ptr(B.data), _ptr(params.fp16_scales),
+        capi.check(capi.lib().tce_w4a16_gemm_awq(Cm.row, N, K, G, _ptr(A.data), _ptr(B.data), _ptr(params.half_scales),
                                                  _ptr(Cm.data), _ptr(workspace), int(repack), _stream()))
         return workspace
 
