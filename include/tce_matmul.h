@@ -47,7 +47,7 @@ extern "C" {
 
 #define TCE_API __attribute__((visibility("default")))
 
-#define TCE_VERSION 100 /* 0.1.0 */
+#define TCE_VERSION 101 /* 0.1.1: tce_w4a16_desc.prepacked, tce_w4a16_prepack* */
 
 /* error codes (return values) */
 #define TCE_OK 0
@@ -88,6 +88,9 @@ typedef struct tce_w4a16_desc {
                                              RMSNorm(A) * gamma (generalT5LayerNorm arithmetic, see tce_rmsnorm_half); M = 1 */
     float rmsnorm_eps;
     int32_t reserved2;
+    const void *prepacked;                /* NULL = none.  The q4_mfma copy of this linear's weights built by tce_w4a16_prepack
+                                             (same N, K, group size): the prefill GEMM for large M reads it instead of
+                                             qweight / scales / zeros (which must still be valid: every other M uses them) */
 } tce_w4a16_desc;
 
 /* flags */
@@ -154,6 +157,17 @@ TCE_API int tce_silu_mul_half(void *a, const void *b, long long n, void *stream)
 /* Load-time helper for TCE_W4_ZERO_POINT_IS_8: returns 1 if all `n_words` packed zero-point words are 0x88888888, 0 if
  * not, negative on error.  Synchronous; call it once per weight tensor (weights are immutable after loading). */
 TCE_API int tce_w4a16_check_zero_point_8(const void *zeros, long long n_words);
+
+/* Load-time re-layout for the prefill GEMM ("offline pre-swizzle to an MFMA-friendly tile layout"; no reference
+ * counterpart -- the reference re-runs its GEMV M times).  tce_w4a16_prepack reads qweight / scales / zeros (+ strides) of `d`
+ * (q4_6 as loaded from weight_int4.bin / scaling_factor_int4.bin / zero_point_int4.bin; A, C, M are ignored) and writes the
+ * q4_mfma copy (csrc/w4a16_mfma_layout.hpp: 16-row x 128-k tiles in MFMA fragment order, nibbles ordered for a 9-instruction
+ * exact unpack, per-group effective scales and zero-point constants) into `packed`, which must hold
+ * tce_w4a16_prepack_bytes(N, K, group_size) bytes of device memory (0 = shape not supported: K % 128 != 0).  Asynchronous on
+ * `stream`; once per weight tensor.  A descriptor whose `prepacked` points at that copy lets tce_w4a16_forward run the 128-row
+ * MFMA kernel (csrc/w4a16_gemm_pk.hip) for M >= 192; results stay within the W4A16 tolerance of every other path. */
+TCE_API size_t tce_w4a16_prepack_bytes(int N, int K, int group_size);
+TCE_API int tce_w4a16_prepack(const tce_w4a16_desc *d, void *packed, void *stream);
 
 /* count (<= TCE_MAX_GROUP) linears with identical M, K, group_size and A/lda, one launch (GEMV path only). */
 #define TCE_MAX_GROUP 4
@@ -256,7 +270,8 @@ TCE_API const char *tce_build_info(void);
  * "last error", and the next launch's check here would return it as TCE_ERR_HIP.  Returns the HIP error code it dropped. */
 TCE_API int tce_reset_last_error(void);
 /* Which kernel family (and, for the GEMM, which tile and form) tce_w4a16_forward would run for this descriptor, as text:
- * "gemv passes=P kernel=row-block|persistent" | "small-batch slices=S" | "gemm-dma tile=RxC quartets=Q group=G" | "gemm tile=RxC".  Launches nothing and
+ * "gemv passes=P kernel=row-block|persistent" | "small-batch slices=S" | "gemm-pk tile=128xC quartets=Q group=G" |
+ * "gemm-dma tile=RxC quartets=Q group=G" | "gemm tile=RxC".  Launches nothing and
  * makes no HIP call (works without a GPU); a shape the chosen GEMM form cannot hold in LDS still falls back at launch time. */
 TCE_API int tce_w4a16_describe_dispatch(const tce_w4a16_desc *d, char *buf, int buf_len);
 /* Force a GEMV kernel + launch geometry for every subsequent call from this process (all 0 = automatic).
@@ -273,6 +288,9 @@ TCE_API int tce_w4a16_set_gemv_config(int rows_per_wave, int waves_n, int waves_
  *   20..30   small-batch kernel: 20 automatic, 21 / 22 / 24 / 28 waves per tile, 30 shared-activation form, 29 off
  *   40..48   GEMM XCD grid rows: 40 automatic, 41 / 42 / 44 / 48 forced
  *   50..52   LDS-DMA GEMM wave quartets per tile: 50 automatic, 51 one, 52 two
+ *   60..69   pre-packed 128-row GEMM: 60 automatic, 61 / 62 / 63 forced form (128x128 tile with one quartet / two quartets splitting K / 128x256 tile with two quartets side by side; taken for every M), 69 off
+ *   600+a    pre-packed GEMM, one quartet, with parts of its loop switched off (a: 1 rescale, 2 unpack, 4 fragment reads, 8 MFMAs,
+ *            16 activation DMAs, 32 barriers; only the combinations scripts/gemm_pk_ablation.py uses are compiled); outputs meaningless
  *   70..74   W8A8 wave quartets per tile: 70 automatic, 71 / 72 / 74 forced
  *   1000+m   largest M the small-batch kernel takes (default 1128 = 128; 1016 restricts it to M <= 16)
  * Every setting computes correct results except GEMV modes 1, 3, 4. */

@@ -24,6 +24,8 @@ enum Op { AND_OR = 0, FMA_F32 = 1, PK_FMA_F16 = 2, LSHR = 3, PK_ADD_F16 = 4, MFM
 // covered by the 7 other chains for a 2- or 4-cycle issue).
 template <int OP, int VALU_PER_MFMA>
 __global__ __launch_bounds__(1024) void probe(unsigned *out, int iters, unsigned long long *ticks) {
+    extern __shared__ unsigned lds_pad[];  // 100 KiB of dynamic LDS: exactly one workgroup per CU, whatever its size
+    if (iters < 0) lds_pad[threadIdx.x] = 1;
     unsigned r0 = threadIdx.x, r1 = r0 * 3, r2 = r0 * 5, r3 = r0 * 7, r4 = r0 * 11, r5 = r0 * 13, r6 = r0 * 17, r7 = r0 * 19;
     const unsigned m = 0x000F000Fu + blockIdx.x;
     float4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0}, acc3 = {0, 0, 0, 0};
@@ -86,12 +88,13 @@ __global__ __launch_bounds__(1024) void probe(unsigned *out, int iters, unsigned
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
     const unsigned long long w1 = wall_clock64();
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        ticks[0] = t1 - t0;
-        ticks[1] = w1 - w0;
+    // slowest wave of workgroup 0 (the SIMD arbiter favours the oldest wave: wave 0 alone finishes early)
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {
+        atomicMax(&ticks[0], t1 - t0);
+        atomicMax(&ticks[1], w1 - w0);
     }
     const float s = acc0[0] + acc1[1] + acc2[2] + acc3[3];
-    if ((r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7) == 0x12345 && s == 17.25f) out[threadIdx.x] = r0;  // keep everything live
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7) + (unsigned)s;  // unconditional: nothing can be sunk or dropped
 }
 
 template <int OP, int V>
@@ -101,10 +104,13 @@ void run(const char *name, int instr_per_iter, int mfma_per_iter, unsigned *out,
     (void)hipEventCreate(&e1);
     for (int wps : {1, 2, 4}) {  // waves per SIMD: one workgroup of 256 * wps threads per CU
         const int iters = 20000 / wps;
-        hipLaunchKernelGGL((probe<OP, V>), dim3(256), dim3(256 * wps), 0, 0, out, 200, ticks);
+        static bool attr_set = false;
+        if (!attr_set) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(probe<OP, V>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+        hipLaunchKernelGGL((probe<OP, V>), dim3(256), dim3(256 * wps), 100 * 1024, 0, out, 200, ticks);
         (void)hipDeviceSynchronize();
+        (void)hipMemset(ticks, 0, 16);
         (void)hipEventRecord(e0, 0);
-        hipLaunchKernelGGL((probe<OP, V>), dim3(256), dim3(256 * wps), 0, 0, out, iters, ticks);
+        hipLaunchKernelGGL((probe<OP, V>), dim3(256), dim3(256 * wps), 100 * 1024, 0, out, iters, ticks);
         (void)hipEventRecord(e1, 0);
         (void)hipDeviceSynchronize();
         float ms = 0;
@@ -124,7 +130,7 @@ void run(const char *name, int instr_per_iter, int mfma_per_iter, unsigned *out,
 int main() {
     unsigned *out;
     unsigned long long *ticks;
-    (void)hipMalloc(&out, 4096);
+    (void)hipMalloc(&out, 256 * 1024 * 4);
     (void)hipMalloc(&ticks, 64);
     run<AND_OR, 0>("v_and_or_b32 x64", 64, 0, out, ticks);
     run<FMA_F32, 0>("v_fma_f32 x64", 64, 0, out, ticks);

@@ -53,6 +53,28 @@ struct AwqEntry {
 std::mutex g_mu;
 std::unordered_map<TensorKey, int, TensorKeyHash> g_zero;       // zero-point tensor -> every packed zero point is 8
 std::unordered_map<TensorKey, AwqEntry, TensorKeyHash> g_awq;   // AWQ weight tensor -> re-laid-out copy
+std::unordered_map<TensorKey, AwqEntry, TensorKeyHash> g_pack;  // q4_6 weight tensor -> q4_mfma copy (prefill GEMM, M >= kPackMinM)
+constexpr int kPackMinM = 192;
+
+// The q4_mfma copy of a linear, built on first sight of a large batch (the reference's Linear_half_int4 has no load-time hook
+// the adapter could use: its constructor only reads files, llm/include/ops/linear.h:215-240).  Enqueued on the null stream in
+// front of the GEMM that needs it, so no synchronisation; costs one extra copy of the int4 weights in HBM.
+const void *packed_copy(const tce_w4a16_desc &d) {
+    const size_t need = tce_w4a16_prepack_bytes(d.N, d.K, d.group_size);
+    if (need == 0) return nullptr;
+    std::lock_guard<std::mutex> lk(g_mu);
+    AwqEntry &e = g_pack[TensorKey{d.qweight, d.N, d.K, d.group_size}];
+    if (!e.workspace) {
+        if (tce_malloc(&e.workspace, need, /*managed=*/0) != TCE_OK) {  // no memory for the copy: the other GEMM kernels take the call
+            e.workspace = nullptr;
+            return nullptr;
+        }
+        e.bytes = need;
+        const int rc = tce_w4a16_prepack(&d, e.workspace, nullptr);
+        if (rc != TCE_OK) die("gemv_forward_cuda (prepack)", rc);
+    }
+    return e.workspace;
+}
 
 // TCE_W4_ZERO_POINT_IS_8 fast path: checked once per zero-point tensor
 int zeros_are_8(const void *zeros, long long words) {
@@ -120,6 +142,7 @@ void MatmulOperator::gemv_forward_cuda(const struct matmul_params *params) {
         const int zw = (((d.K / d.group_size + 7) / 8) + mult - 1) / mult * mult;
         if (d.zeros && zeros_are_8(d.zeros, (long long)d.N * zw)) d.flags |= TCE_W4_ZERO_POINT_IS_8;
     }
+    if (d.M >= kPackMinM && d.K % 128 == 0 && d.A && d.qweight && d.scales && d.zeros) d.prepacked = packed_copy(d);
     const int rc = tce_w4a16_forward(&d, nullptr);
     if (rc == TCE_ERR_UNSUPPORTED_GROUP) {
         std::printf("Unsupported group size: %d\n", params->block_size);  // the reference's own message
@@ -213,25 +236,28 @@ void MatmulOperator::mat_mul_accelerator_int4_fast_no_offset(const struct matmul
 extern "C" void tce_adapter_forget(const void *ptr) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto it = g_zero.begin(); it != g_zero.end();) it = it->first.ptr == ptr ? g_zero.erase(it) : std::next(it);
-    for (auto it = g_awq.begin(); it != g_awq.end();) {
-        if (it->first.ptr == ptr) {
-            if (it->second.workspace) tce_free(it->second.workspace);
-            it = g_awq.erase(it);
-        } else {
-            ++it;
+    for (auto *m : {&g_awq, &g_pack})
+        for (auto it = m->begin(); it != m->end();) {
+            if (it->first.ptr == ptr) {
+                if (it->second.workspace) tce_free(it->second.workspace);
+                it = m->erase(it);
+            } else {
+                ++it;
+            }
         }
-    }
 }
 extern "C" void tce_adapter_forget_all(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_zero.clear();
-    for (auto &kv : g_awq)
-        if (kv.second.workspace) tce_free(kv.second.workspace);
-    g_awq.clear();
+    for (auto *m : {&g_awq, &g_pack}) {
+        for (auto &kv : *m)
+            if (kv.second.workspace) tce_free(kv.second.workspace);
+        m->clear();
+    }
 }
 extern "C" long tce_adapter_cache_entries(void) {
     std::lock_guard<std::mutex> lk(g_mu);
-    return (long)(g_zero.size() + g_awq.size());
+    return (long)(g_zero.size() + g_awq.size() + g_pack.size());
 }
 
 extern "C" long tce_adapter_layout(int idx) {

@@ -71,6 +71,20 @@ int64_t tce_w4a16_algorithmic_bytes(int M, int N, int K, int G) {
     return nk / 2 + 2 * nk / G + nk / (2 * (int64_t)G) + 2 * (int64_t)M * K + 2 * (int64_t)M * N;
 }
 
+int g_pk_mode = 0;  // 0 automatic, 1 / 2 / 3 forced form (taken whenever a packed copy is given), 9 off
+constexpr int kPkMinM = 192;  // below: the 64-row tiles / the small-batch kernel waste fewer rows
+
+// the pre-packed 128-row GEMM takes the launch when a packed copy came with the descriptor and the batch is large enough
+static bool use_pk(const tce_w4a16_desc *d, bool want_gemm) {
+    if (!d->prepacked || g_pk_mode == 9 || !want_gemm || d->K % 128 != 0 || (d->flags & TCE_W4_SILU_MUL_PAIRS) || d->rmsnorm_gamma) return false;
+    if (g_pk_mode >= 1 && g_pk_mode <= 3) return true;
+    if (d->M < kPkMinM || g_gemm_mt != 0) return false;
+    // both dispatchers' cost models, fitted to the same kind of sweep (the 64-row tiles win while the 128-row tiles are too few
+    // to fill the chip: M = 512 at N = 4096); groups of 64 / 32: the pre-packed kernel needs no LDS re-deal, it takes them
+    if (d->group_size != 128) return true;
+    return tce::gemm_pk_estimate_us(d->M, d->N, d->K, nullptr) < tce::gemm_dma_estimate_us(d->M, d->N, d->K) + 1.5f;
+}
+
 int g_gemv_kernel = 0;  // 0 automatic, 1 workgroup-per-row-block kernel forced, 2 persistent stream kernel forced
 int g_skinny_enabled = 1;  // tuning: tce_w4a16_set_debug_mode(29) routes 3 <= M <= 16 to the GEMV / GEMM kernels again
 
@@ -106,6 +120,18 @@ int tce_w4a16_set_debug_mode(int mode) {
     }
     if (mode >= 70 && mode <= 74) {  // W8A8: wave quartets per tile (70 automatic)
         tce::set_w8a8_ksplit(mode - 70);
+        return TCE_OK;
+    }
+    if (mode >= 600 && mode < 664) {  // pre-packed GEMM with parts of its loop switched off (timing experiments, one quartet)
+        g_pk_mode = mode == 600 ? 0 : 1;
+        tce::set_gemm_pk_mode(mode == 600 ? 0 : 1, 0);
+        tce::set_gemm_pk_ablation(mode - 600);
+        return TCE_OK;
+    }
+    if (mode >= 60 && mode <= 69) {  // pre-packed 128-row GEMM: 60 automatic, 61 / 62 forced quartets, 69 off
+        g_pk_mode = mode - 60;
+        tce::set_gemm_pk_ablation(0);
+        tce::set_gemm_pk_mode(g_pk_mode >= 1 && g_pk_mode <= 3 ? g_pk_mode : 0, 0);
         return TCE_OK;
     }
     if (mode >= 50 && mode <= 52) {  // LDS-DMA GEMM: wave quartets per tile (50 automatic)
@@ -299,6 +325,12 @@ int tce_w4a16_forward(const tce_w4a16_desc *d, void *stream) {
     const bool want_gemm = (d->flags & TCE_W4_FORCE_GEMM) ||
                            (d->M > TCE_W4A16_GEMV_MAX_M && !(d->flags & (TCE_W4_FORCE_GEMV | TCE_W4_SILU_MUL_PAIRS)));
     hipError_t he = hipSuccess;
+    if (use_pk(d, want_gemm)) {  // large batches on a pre-packed copy: 128 rows per wave (w4a16_gemm_pk.hip)
+        const int rc = tce::launch_w4a16_gemm_pk(*d, d->prepacked, static_cast<hipStream_t>(stream), &he);
+        if (rc == TCE_OK) return TCE_OK;
+        if (rc == TCE_ERR_HIP) return hip_fail(he, "w4a16 gemm (pre-packed) launch");
+        if (rc != TCE_ERR_UNSUPPORTED_SHAPE) return fail(rc, "w4a16 gemm (pre-packed): unsupported configuration");
+    }
     // small batches: weights streamed once, all M <= 16 rows on one MFMA tile (w4a16_skinny.hip)
     if (g_skinny_enabled && !(d->flags & (TCE_W4_FORCE_GEMV | TCE_W4_FORCE_GEMM)) && tce::skinny_supports(*d)) {
         const int rc = tce::launch_w4a16_skinny(*d, static_cast<hipStream_t>(stream), &he);
@@ -336,6 +368,12 @@ int tce_w4a16_describe_dispatch(const tce_w4a16_desc *d, char *buf, int buf_len)
     if (rc0 != TCE_OK) return rc0;
     const bool want_gemm = (d->flags & TCE_W4_FORCE_GEMM) ||
                            (d->M > TCE_W4A16_GEMV_MAX_M && !(d->flags & (TCE_W4_FORCE_GEMV | TCE_W4_SILU_MUL_PAIRS)));
+    if (use_pk(d, want_gemm)) {
+        int form = 1;
+        tce::gemm_pk_estimate_us(d->M, d->N, d->K, &form);
+        std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=128x%d quartets=%d group=%d", form == 3 ? 256 : 128, form == 1 ? 1 : 2, d->group_size);
+        return TCE_OK;
+    }
     if (g_skinny_enabled && !(d->flags & (TCE_W4_FORCE_GEMV | TCE_W4_FORCE_GEMM)) && tce::skinny_supports(*d)) {
         std::snprintf(buf, (size_t)buf_len, "small-batch slices=%d", (d->M + 15) / 16);
         return TCE_OK;
@@ -354,6 +392,21 @@ int tce_w4a16_describe_dispatch(const tce_w4a16_desc *d, char *buf, int buf_len)
     const bool persistent = g_gemv_kernel == 2 || (d->rmsnorm_gamma ? (g_gemv_kernel == 0 && d->N >= 8192)
                                                                      : (g_gemv_kernel == 0 && d->M == 1 && (long long)d->N * d->K >= 200000000LL && g_debug_mode_capi == 0));
     std::snprintf(buf, (size_t)buf_len, "gemv passes=%d kernel=%s", (d->M + 3) / 4, persistent && d->M == 1 ? "persistent" : "row-block");
+    return TCE_OK;
+}
+
+size_t tce_w4a16_prepack_bytes(int N, int K, int G) { return tce::prepack_bytes(N, K, G); }
+
+int tce_w4a16_prepack(const tce_w4a16_desc *d, void *packed, void *stream) {
+    if (!d || !packed) return fail(TCE_ERR_BAD_ARG, "tce_w4a16_prepack: null argument");
+    if (!d->qweight || !d->scales || !d->zeros || d->N <= 0 || d->K <= 0) return fail(TCE_ERR_BAD_ARG, "tce_w4a16_prepack: null weights / non-positive N, K");
+    if (d->group_size != 128 && d->group_size != 64 && d->group_size != 32) return fail(TCE_ERR_UNSUPPORTED_GROUP, "Unsupported group size: %d", d->group_size);
+    if (d->K % 128 != 0) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_w4a16_prepack: K=%d must be a multiple of 128", d->K);
+    if (reinterpret_cast<uintptr_t>(packed) % 256 != 0) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_w4a16_prepack: the packed buffer must be 256-byte aligned");
+    hipError_t he = hipSuccess;
+    const int rc = tce::launch_w4a16_prepack(*d, packed, static_cast<hipStream_t>(stream), &he);
+    if (rc == TCE_ERR_HIP) return hip_fail(he, "prepack launch");
+    if (rc != TCE_OK) return fail(rc, "tce_w4a16_prepack: unsupported shape");
     return TCE_OK;
 }
 

@@ -1,0 +1,635 @@
+// w4a16_gemm_pk.hip -- W4A16 prefill GEMM for gfx950 on PRE-PACKED weights: 128 activation rows per wave.
+//
+// Why another GEMM (profiles/r1/rocprofv3_summary_gemm_m512.txt): the LDS-DMA kernel (w4a16_gemm_dma.hip) gives a
+// wave 64 rows x 32 columns, so every weight is dequantized M / 64 times and each MFMA carries 6.6 VALU instructions
+// (12 per weight word in natural nibble order, a per-k-block scale fma on a second accumulator set that also caps the
+// occupancy at one wave per SIMD).  Here
+//   * a wave owns 128 rows x 32 columns (8 x 2 MFMA tiles of 16x16, v_mfma_f32_16x16x32_f16): one unpacked weight fragment
+//     feeds 8 MFMAs, the dequantization work per MFMA halves;
+//   * the weights come from the q4_mfma copy built once per tensor by tce_w4a16_prepack (layout: w4a16_mfma_layout.hpp): a
+//     wave's load of one (column tile, k-block) is one contiguous KiB, a lane's four words are its four MFMA steps of
+//     CONSECUTIVE k (any group size steps inside one group -- no LDS re-deal for groups of 64 / 32), and the nibble order
+//     makes the exact int4 -> fp16 unpack 9 VALU per word;
+//   * ONE accumulator set: the accumulator is kept in units of the current group's scale -- before a group's MFMAs it is
+//     multiplied by e[g-1] / e[g] (e = the fp16 group scale, made non-zero by the prepack), the MFMAs then accumulate the
+//     exact products (q - z) * x straight into it, and e[last] is applied once at the end:
+//         sum_g e_g * blk_g  ==  e_last * ((...(blk_0 * e_0/e_1 + blk_1) * e_1/e_2 + ...) + blk_last)
+//     -- the same number of fp32 roundings per group as `acc += e_g * blk_g` (one), without the second 64 registers, so two
+//     waves per SIMD fit (<= 256 registers);
+//   * the activation tile reaches LDS by DMA (global_load_lds_dwordx4) in HALF-stages of 128 rows x 64 k (16 KiB) in a ring of
+//     four per wave quartet: a half-stage is refilled (two k-blocks ahead) as soon as every wave has read it, so a quartet
+//     needs 64 KiB, two workgroups fit a CU, and the in-order vmcnt that retires a block's weight words has retired both of its
+//     half-stages as well;
+//   * forms: KS = 1 -- 4 waves, two workgroups per CU; KS = 2 -- 8 waves on one 128x128 tile, the k-blocks alternating between
+//     the two quartets (one shared barrier sequence), partial sums joined through LDS in a fixed order (quartet 0 + quartet 1).
+//
+// Numerics: products exact (integers |q - z| <= 15 times fp16 in fp32), fp32 accumulation on the matrix pipe, one fp32
+// multiply per accumulator register and group, fp16 RNE store -- the precision class of the reference GEMV
+// (kernels/cuda/gemv_cuda.cu:181-193); tolerance and oracle as for every W4A16 path (tests/test_gpu_w4a16_pk.py).
+#include "tce_common.hpp"
+#include "w4a16_kernels.hpp"
+#include "w4a16_mfma_layout.hpp"
+
+namespace tce {
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------------------------
+// prepack: q4_6 -> q4_mfma
+// ------------------------------------------------------------------------------------------------------------------------
+struct PrepackArgs {
+    const unsigned *qweight;  // u32 [N][K/8]
+    const half_t *scales;     // fp16 [N][scales_stride]
+    const unsigned *zeros;    // u32 [N][zeros_stride]
+    unsigned *words;          // out
+    uint2_t *consts;          // out: {e as f32 bits, zc}
+    float *last;              // out
+    int N, K, log2g, scales_stride, zeros_stride;
+};
+
+// one 64-thread block per (row tile, k-block): thread = lane (q, n16) writes its four words
+__global__ __launch_bounds__(64) void prepack_words_kernel(const PrepackArgs a) {
+    const int jt = blockIdx.x, kb = blockIdx.y, lane = threadIdx.x;
+    const int q = lane >> 4, n16 = lane & 15;
+    const int n = jt * 16 + n16;
+    const bool live = n < a.N;
+    const int nr = live ? n : a.N - 1;
+    unsigned out[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int k0 = kb * 128 + 32 * s + 8 * q;  // 8 consecutive k = one source word
+        const int g = k0 >> a.log2g;
+        unsigned src = a.qweight[(size_t)nr * (a.K >> 3) + (k0 >> 3)];
+        const unsigned z = (a.zeros[(size_t)nr * a.zeros_stride + (g >> 3)] >> ((g & 7) * 4)) & 0xFu;
+        const unsigned short sb = __builtin_bit_cast(unsigned short, a.scales[(size_t)nr * a.scales_stride + g]);
+        // a group whose scale is +-0 contributes nothing in the reference (s * (q - z) == 0): its codes become the zero point
+        if ((sb & 0x7FFFu) == 0u) src = z * 0x11111111u;
+        if (!live) src = 0x88888888u;
+        unsigned w = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w |= ((src >> (4 * e)) & 0xFu) << (4 * pk::nibble_index(e));
+        out[s] = w;
+    }
+    uint4_t *dst = reinterpret_cast<uint4_t *>(a.words) + ((size_t)jt * (a.K >> 7) + kb) * 64 + lane;
+    *dst = uint4_t{out[0], out[1], out[2], out[3]};
+}
+
+// one thread per row: the effective scales e[g] (sequential over the groups) and the zero-point constants
+__global__ __launch_bounds__(64) void prepack_consts_kernel(const PrepackArgs a) {
+    const int n = blockIdx.x * 64 + threadIdx.x;
+    const int np = pk::nt16(a.N) * 16;
+    if (n >= np) return;
+    const int G = 1 << a.log2g, ng = a.K >> a.log2g;
+    if (n >= a.N) {
+        for (int g = 0; g < ng; ++g) a.consts[pk::const_index(n, g, a.K, G)] = uint2_t{__builtin_bit_cast(unsigned, 1.0f), pk::zc_word(8)};
+        a.last[n] = 0.f;
+        return;
+    }
+    float e = 1.0f;  // effective scale in front of the first group: the first non-zero scale of the row (or 1)
+    for (int g = 0; g < ng; ++g) {
+        const float s = (float)a.scales[(size_t)n * a.scales_stride + g];
+        if (s != 0.f) {
+            e = s;
+            break;
+        }
+    }
+    for (int g = 0; g < ng; ++g) {
+        const float s = (float)a.scales[(size_t)n * a.scales_stride + g];
+        if (s != 0.f) e = s;
+        const unsigned z = (a.zeros[(size_t)n * a.zeros_stride + (g >> 3)] >> ((g & 7) * 4)) & 0xFu;
+        a.consts[pk::const_index(n, g, a.K, G)] = uint2_t{__builtin_bit_cast(unsigned, e), pk::zc_word(z)};
+    }
+    a.last[n] = e;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// the GEMM
+// ------------------------------------------------------------------------------------------------------------------------
+struct PkGemmArgs {
+    const half_t *A;
+    const uint4_t *words;   // [NT16][NKB][64]
+    const uint2_t *consts;  // [NT16][K/G][16]
+    half_t *C;
+    int M, N, K, lda, ldc;
+    int n_blocks, m_blocks;  // 128 x 128 tiles
+    int add_to_c;
+    int xm, m_per, n_per;
+};
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void global_void_t;
+
+__device__ __forceinline__ void pk_dma16(const void *src, void *lds_dst_wave_uniform) {
+    __builtin_amdgcn_global_load_lds((global_void_t *)src, (lds_void_t *)lds_dst_wave_uniform, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void pk_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+template <int MASK, int COUNT>
+__device__ __forceinline__ void sched_group() {
+    __builtin_amdgcn_sched_group_barrier(MASK, COUNT, 0);
+}
+
+constexpr int kMT = 8;  // 16-row MFMA tiles per wave (128 rows)
+constexpr int kNT = 2;  // 16-column MFMA tiles per wave (32 columns); 4 waves side by side = 128 columns
+
+// The compiler allocates v0 .. v231 only; v232 .. v255 belong to the inline asm below (a block's words and constants in flight).
+constexpr int kAsmVgprBase = 232;
+// ABL: timing experiments only (tce_w4a16_set_debug_mode(600 + ABL); results are then meaningless): bit 0 no rescale, 1 no unpack,
+// 2 no fragment reads, 3 no MFMAs, 4 no activation DMAs, 5 no barriers.
+// NS = 2: two wave quartets side by side on a 128 x 256 tile, sharing ONE activation ring (KS = 1 then): the activation bytes a CU
+// pulls through L2 -> LDS per MFMA halve.  That path, not the matrix pipe, bounds the 128 x 128 forms: the activation DMAs of
+// M = 2048, 4096 x 4096 alone take 32 us of the 68 (profiles/r2/gemm_pk_ablation.jsonl; ~64 GB/s per CU), the MFMAs alone 38.
+template <int KS, int LG, int ABL = 0, int NS = 1>
+__global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(232))) void w4a16_gemm_pk_kernel(const PkGemmArgs g) {
+    static_assert(KS == 1 || NS == 1, "two quartets either split K or sit side by side");
+    constexpr int NTHREADS = 256 * KS * NS;
+    constexpr int NWR = 4 * NS;          // waves feeding (and reading) one ring
+    constexpr int DPW = 16 / NWR;        // DMA instructions per wave and half-stage
+    constexpr int BN = 128 * NS;
+    constexpr int GPB = 128 >> LG;  // groups per k-block
+    constexpr int SPG = 4 / GPB;    // MFMA steps per group
+    constexpr int QUARTET_BYTES = 4 * pk::kHalfBytes;  // ring of four half-stages
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int m_blk = (xcd % g.xm) * g.m_per + slot % g.m_per;
+    const int n_blk = (xcd / g.xm) * g.n_per + slot / g.m_per;
+    if (n_blk >= g.n_blocks || m_blk >= g.m_blocks) return;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = KS == 2 ? (wave8 & 3) : wave8;  // index within the ring's waves: DMA share and column position
+    const int grp = KS == 2 ? wave8 >> 2 : 0;
+    unsigned char *const ring = smem + grp * QUARTET_BYTES;
+    const int n16 = lane & 15, q = lane >> 4;
+    const int m_base = m_blk * 128, nb0 = n_blk * BN;
+    const int nkb = g.K >> 7;
+    const int T = (nkb + KS - 1) / KS;  // iterations (own k-blocks, the last one may be past K for quartet 1)
+
+    // ---- DMA sources of a half-stage: instruction ii of this wave fills 8 rows; the lane fetches the piece that belongs at its position ----
+    // (uniform 64-bit base + 32-bit lane offset: the address arithmetic of a refill is scalar; the host checked M * lda * 2 < 4 GiB)
+    unsigned a_voff[DPW];
+#pragma unroll
+    for (int ii = 0; ii < DPW; ++ii) {
+        const int row = pk::dma_row(wave, ii, lane, NWR);
+        int m = m_base + row;
+        m = m < g.M ? m : g.M - 1;  // rows past M repeat the last row; their outputs are not stored
+        a_voff[ii] = (unsigned)m * (unsigned)(g.lda * 2) + (unsigned)(pk::dma_src_piece(row, lane) << 4);
+    }
+    const char *const a_bytes = reinterpret_cast<const char *>(g.A);
+    // own half-block h (0 .. 2T-1): k-block grp + (h >> 1) * KS, half h & 1; clamped, never predicated (the counted waits rely on it)
+    auto issue_half = [&](int h) {
+        if constexpr (ABL & 16) return;
+        int kb = grp + (h >> 1) * KS;
+        kb = kb < nkb ? kb : nkb - 1;
+        const char *src = a_bytes + ((size_t)kb * 256 + (h & 1) * 128);  // wave-uniform
+        unsigned char *st = ring + (h & 3) * pk::kHalfBytes;
+#pragma unroll
+        for (int ii = 0; ii < DPW; ++ii) pk_dma16(src + a_voff[ii], st + pk::dma_lds_base(wave, ii, NWR));
+    };
+    // ---- the lane's weights and constants ----
+    const int jt0 = n_blk * (BN / 16) + wave * kNT;  // first 16-column tile of this wave
+    const int ntiles16 = pk::nt16(g.N);
+    const uint4_t *w_tile[kNT];  // wave-uniform bases; lane offsets lane * 16 / n16 * 8 bytes
+    const uint2_t *c_tile[kNT];
+#pragma unroll
+    for (int j = 0; j < kNT; ++j) {
+        int jt = jt0 + j;
+        jt = jt < ntiles16 ? jt : ntiles16 - 1;  // tiles past N: clamped loads, nothing stored
+        w_tile[j] = g.words + (size_t)jt * nkb * 64;
+        c_tile[j] = g.consts + (size_t)jt * (nkb * GPB) * 16;
+    }
+    const unsigned w_voff = lane * 16, c_voff = n16 * 8;
+    int a_off[2];
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) a_off[sl] = pk::frag_offset(0, n16, q, sl);  // + i * 2048 per m-tile
+
+    unsigned mask_lo;
+    asm volatile("v_mov_b32 %0, 0x000F000F" : "=v"(mask_lo));
+    const unsigned mask_hi = mask_lo << 4;
+    const half2_t sixteenth = as_half2(0x2C002C00u);
+
+    float4_t acc[kMT][kNT];
+#pragma unroll
+    for (int i = 0; i < kMT; ++i)
+#pragma unroll
+        for (int j = 0; j < kNT; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+    float e_prev[kNT];  // effective scale the accumulator is currently expressed in
+#pragma unroll
+    for (int j = 0; j < kNT; ++j) e_prev[j] = 0.f;  // "no group yet": the first ratio is forced to 1
+
+    struct BlockRegs {
+        uint4_t w[kNT];
+        uint2_t c[kNT][GPB];
+    };
+    BlockRegs cur;
+    auto block_of = [&](int t) {
+        const int kb = grp + t * KS;
+        return kb < nkb ? kb : nkb - 1;
+    };
+    // the first block's registers by ordinary loads (the compiler waits for them), everything later by inline asm one block ahead
+    {
+        const int kb = block_of(0);
+#pragma unroll
+        for (int j = 0; j < kNT; ++j) {
+            cur.w[j] = w_tile[j][(size_t)kb * 64 + lane];
+#pragma unroll
+            for (int gi = 0; gi < GPB; ++gi) cur.c[j][gi] = c_tile[j][(size_t)(kb * GPB + gi) * 16 + n16];
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    issue_half(0);
+    issue_half(1);
+    issue_half(2);
+    issue_half(3);
+
+    // ---- pieces of a k-block ----
+    half8_t af[2][kMT], bf[2][kNT];  // fragments of the step being multiplied and of the next one
+    half2_t c1[kNT], c2[kNT];        // (-(1024+z)) x2 and (-(64+z)) x2 of the group being unpacked
+    auto read_a = [&](half8_t (&dst)[kMT], const unsigned char *half_stage, int sl) {
+        const unsigned char *st = half_stage + a_off[sl];
+#pragma unroll
+        for (int i = 0; i < kMT; ++i) dst[i] = *reinterpret_cast<const half8_t *>(st + i * 2048);
+    };
+    auto set_group = [&](const BlockRegs &br, int gi) {
+#pragma unroll
+        for (int j = 0; j < kNT; ++j) {
+            const unsigned zc = br.c[j][gi].y;
+            c1[j] = as_half2(__builtin_amdgcn_perm(zc, zc, 0x01000100u));  // low half twice
+            c2[j] = as_half2(__builtin_amdgcn_perm(zc, zc, 0x03020302u));  // high half twice
+        }
+    };
+    auto unpack = [&](half8_t (&dst)[kNT], const BlockRegs &br, int s) {
+#pragma unroll
+        for (int j = 0; j < kNT; ++j) {
+            const unsigned w = br.w[j][s];
+            const unsigned sh = w >> 8;
+            const half2_t d0 = as_half2((w & mask_lo) | 0x64006400u) + c1[j];
+            const half2_t d1 = __builtin_elementwise_fma(as_half2((w & mask_hi) | 0x64006400u), sixteenth, c2[j]);
+            const half2_t d2 = as_half2((sh & mask_lo) | 0x64006400u) + c1[j];
+            const half2_t d3 = __builtin_elementwise_fma(as_half2((sh & mask_hi) | 0x64006400u), sixteenth, c2[j]);
+            dst[j] = half8_t{d0.x, d0.y, d1.x, d1.y, d2.x, d2.y, d3.x, d3.y};
+        }
+    };
+    auto rescale = [&](const float (&e_new)[kNT]) {  // acc <- acc * e_prev / e_g: the accumulator moves into the units of group g
+#pragma unroll
+        for (int j = 0; j < kNT; ++j) {
+            // e != 0 by construction of the table; 1-ulp reciprocal (an IEEE division is ~10 instructions per group and column tile)
+            const float r = e_prev[j] == 0.f ? 1.0f : e_prev[j] * __builtin_amdgcn_rcpf(e_new[j]);
+            e_prev[j] = e_new[j];
+#pragma unroll
+            for (int i = 0; i < kMT; ++i)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) acc[i][j][rr] *= r;
+        }
+    };
+    // Region s of a block = the 16 MFMAs of step s beside the fragment reads and the unpack of the NEXT step (for s = 3: step 0 of
+    // the next block) and, at the first step of a group, the rescale.  The issue order is pinned: the matrix pipe leaves room
+    // for about two 4-cycle VALU instructions per 16-cycle MFMA (scripts/probes/valu_probe.hip: T = 16 + 4.2 * max(0, v - 2)
+    // cycles per MFMA with v and_or / packed instructions beside it, whatever the number of waves), so the VALU work and the LDS
+    // reads are dealt out between the MFMAs instead of being issued as blocks between MFMA runs.
+    float e_grp[GPB][kNT];  // effective scales of the block being multiplied (kept apart: `cur` moves on before step 3)
+    auto load_e = [&](const BlockRegs &br) {
+#pragma unroll
+        for (int gi = 0; gi < GPB; ++gi)
+#pragma unroll
+            for (int j = 0; j < kNT; ++j) e_grp[gi][j] = __builtin_bit_cast(float, br.c[j][gi].x);
+    };
+    auto region = [&](auto s_c, const BlockRegs &br_next, const unsigned char *half_stage_next) {
+        constexpr int s = decltype(s_c)::value;
+        constexpr int sn = (s + 1) & 3;  // the step whose fragments are fetched here
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (s % SPG == 0 && !(ABL & 1)) rescale(e_grp[s / SPG]);
+        if constexpr (!(ABL & 4)) read_a(af[(s + 1) & 1], half_stage_next, sn & 1);
+        if constexpr (!(ABL & 2)) {
+            if constexpr (sn % SPG == 0) set_group(br_next, sn / SPG);
+            unpack(bf[(s + 1) & 1], br_next, sn);
+        }
+        if constexpr (!(ABL & 8)) {
+#pragma unroll
+            for (int i = 0; i < kMT; ++i)
+#pragma unroll
+                for (int j = 0; j < kNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s & 1][i], bf[s & 1][j], acc[i][j], 0, 0, 0);
+        } else {  // keep what the MFMAs would have consumed alive
+#pragma unroll
+            for (int i = 0; i < kMT; ++i) asm volatile("" ::"v"(af[(s + 1) & 1][i]));
+#pragma unroll
+            for (int j = 0; j < kNT; ++j) asm volatile("" ::"v"(bf[(s + 1) & 1][j]));
+        }
+        if constexpr (ABL == 0) static_for<0, 16>([&](auto u_c) {
+            constexpr int u = decltype(u_c)::value;
+            if constexpr (s % SPG == 0) sched_group<0x002, 2>();   // the tile's two packed multiplies, then its MFMA
+            sched_group<0x008, 1>();                               // MFMA
+            if constexpr (u < 8) sched_group<0x100, 1>();          // DS read
+            sched_group<0x002, (u < 4 ? 2 : 1)>();                 // VALU: unpack of the next step (18 + constants)
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // A block's words and constants are requested TWO blocks ahead by inline asm (hipcc would sink ordinary loads to their use and
+    // answer them with vmcnt(0), draining the DMAs) -- into the registers v232.. that the compiler never allocates
+    // (amdgpu_num_vgpr above) and therefore never sees as values: an asm load's VGPR destination counts as written at the end of
+    // the statement, so hipcc is free to copy it (loop-carried phi, coalescing) before the data has landed; that is what a first
+    // version of this loop did, silently.  (Accumulator registers would do as well, but any AGPR use makes hipcc split the 256
+    // registers 128 / 128 and move the MFMA accumulators behind v_accvgpr copies.)  After the counted wait at the end of a block
+    // the landed words are copied out (12 v_mov per k-block for groups of 128) into ordinary variables, and the same registers
+    // take the next request.
+#define TCE_PK_AGPR_CLOBBERS "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
+    static_assert(kNT == 2, "the request / collect macros below spell out two column tiles");
+#define TCE_PK_REQ_W(J)                                                                                                              \
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 v[%c2:%c3], %0, %1" ::"v"(w_voff), "s"(w_tile[J] + (size_t)kbn * 64), "i"(kAsmVgprBase + 4 * J), "i"(kAsmVgprBase + 4 * J + 3) \
+                 : "memory", TCE_PK_AGPR_CLOBBERS);
+#define TCE_PK_REQ_C(J, GI)                                                                                                          \
+    if constexpr (GI < GPB)                                                                                                          \
+        asm volatile("s_nop 4\n\tglobal_load_dwordx2 v[%c2:%c3], %0, %1" ::"v"(c_voff), "s"(c_tile[J] + (size_t)(kbn * GPB + GI) * 16),   \
+                     "i"(kAsmVgprBase + 4 * kNT + 2 * (J * GPB + GI)), "i"(kAsmVgprBase + 4 * kNT + 2 * (J * GPB + GI) + 1)                                        \
+                     : "memory", TCE_PK_AGPR_CLOBBERS);
+    auto request_block = [&](int t_of_block) {
+        const int kbn = block_of(t_of_block);
+        // (s_nop 4: the scalar base was just computed by SALU instructions, and nothing pads an SGPR hazard inside an asm statement)
+        TCE_PK_REQ_W(0) TCE_PK_REQ_W(1)
+        TCE_PK_REQ_C(0, 0) TCE_PK_REQ_C(0, 1) TCE_PK_REQ_C(0, 2) TCE_PK_REQ_C(0, 3)
+        TCE_PK_REQ_C(1, 0) TCE_PK_REQ_C(1, 1) TCE_PK_REQ_C(1, 2) TCE_PK_REQ_C(1, 3)
+    };
+#define TCE_PK_GET(DST, R)                                                     \
+    {                                                                          \
+        unsigned v_;                                                           \
+        asm volatile("v_mov_b32 %0, v%c1" : "=v"(v_) : "i"(kAsmVgprBase + (R)));      \
+        DST = v_;                                                              \
+    }
+#define TCE_PK_GET_C(J, GI)                                                    \
+    if constexpr (GI < GPB) {                                                  \
+        TCE_PK_GET(dst.c[J][GI].x, 4 * kNT + 2 * (J * GPB + GI))               \
+        TCE_PK_GET(dst.c[J][GI].y, 4 * kNT + 2 * (J * GPB + GI) + 1)           \
+    }
+    auto collect_block = [&](BlockRegs &dst) {  // only behind the counted wait that retires the request
+        TCE_PK_GET(dst.w[0].x, 0) TCE_PK_GET(dst.w[0].y, 1) TCE_PK_GET(dst.w[0].z, 2) TCE_PK_GET(dst.w[0].w, 3)
+        TCE_PK_GET(dst.w[1].x, 4) TCE_PK_GET(dst.w[1].y, 5) TCE_PK_GET(dst.w[1].z, 6) TCE_PK_GET(dst.w[1].w, 7)
+        TCE_PK_GET_C(0, 0) TCE_PK_GET_C(0, 1) TCE_PK_GET_C(0, 2) TCE_PK_GET_C(0, 3)
+        TCE_PK_GET_C(1, 0) TCE_PK_GET_C(1, 1) TCE_PK_GET_C(1, 2) TCE_PK_GET_C(1, 3)
+    };
+    constexpr int NWL = kNT * (1 + GPB);  // VMEM instructions of request_block
+    request_block(1);
+    pk_wait_vmcnt<2 * DPW + NWL>();  // the first block's two half-stages have landed (this wave's part); the barrier makes that the workgroup's
+    if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();
+    // fragments of step 0 of the first block
+    set_group(cur, 0);
+    read_a(af[0], ring, 0);
+    unpack(bf[0], cur, 0);
+    load_e(cur);
+
+    for (int t = 0; t < T; ++t) {
+        const bool live = grp + t * KS < nkb;  // wave-uniform; only quartet 1's last iteration can be past K
+        const unsigned char *st_even = ring + ((2 * t) & 3) * pk::kHalfBytes, *st_odd = ring + ((2 * t + 1) & 3) * pk::kHalfBytes;
+        const unsigned char *st_even_next = ring + ((2 * t + 2) & 3) * pk::kHalfBytes;
+        if (live) {
+            region(std::integral_constant<int, 0>{}, cur, st_even);  // MFMAs of step 0 | fragments of step 1 (even half-stage)
+            region(std::integral_constant<int, 1>{}, cur, st_odd);   // step 1 | step 2 (odd half-stage)
+        }
+        // all waves have taken their last fragment of the even half-stage: it may be refilled (own half-block 2t+4)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();
+        issue_half(2 * t + 4);
+        if (live) region(std::integral_constant<int, 2>{}, cur, st_odd);  // step 2 | step 3
+        // End of the block's LDS reads.  VMEM order since the even half-stage of the NEXT block was requested: [its odd half-stage]
+        // [its words / constants] [half 2t+4].  vmcnt(DPW) leaves only the DMAs of half 2t+4 in flight: both half-stages of
+        // block t+1 and its words have landed (in-order counter); the barrier extends that to the workgroup and orders this
+        // block's reads of the odd half-stage before its refill.
+        pk_wait_vmcnt<DPW>();
+        collect_block(cur);  // `cur` (block t) is used up: step 3's fragments are unpacked
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();
+        issue_half(2 * t + 5);
+        request_block(t + 2);
+        if (live) region(std::integral_constant<int, 3>{}, cur, st_even_next);  // step 3 | step 0 of the next block (`cur` is the next block now)
+        load_e(cur);
+    }
+#undef TCE_PK_AGPR_CLOBBERS
+#undef TCE_PK_REQ_W
+#undef TCE_PK_REQ_C
+#undef TCE_PK_GET
+#undef TCE_PK_GET_C
+    pk_wait_vmcnt<0>();
+    __syncthreads();  // every wave's last (clamped, redundant) DMAs have landed: the ring may be overwritten
+
+    // ---- into true units: e of the quartet's last group ----
+#pragma unroll
+    for (int j = 0; j < kNT; ++j)
+#pragma unroll
+        for (int i = 0; i < kMT; ++i)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) acc[i][j][rr] *= e_prev[j];
+
+    if constexpr (KS == 2) {  // quartet 1 hands its partial sums over: [register][thread of the quartet] floats (64 KiB)
+        float *red = reinterpret_cast<float *>(smem);
+        const int t4 = tid & 255;
+        if (grp == 1) {
+#pragma unroll
+            for (int i = 0; i < kMT; ++i)
+#pragma unroll
+                for (int j = 0; j < kNT; ++j)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) red[((i * kNT + j) * 4 + rr) * 256 + t4] = acc[i][j][rr];
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int i = 0; i < kMT; ++i)
+#pragma unroll
+                for (int j = 0; j < kNT; ++j)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) acc[i][j][rr] += red[((i * kNT + j) * 4 + rr) * 256 + t4];
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: the tile leaves through LDS as 16-byte row pieces (accumulator layout: lane = column n16, registers = 4 consecutive rows) ----
+    half_t *lds_c = reinterpret_cast<half_t *>(smem);  // [128][BN]
+    if (grp == 0) {
+#pragma unroll
+        for (int i = 0; i < kMT; ++i)
+#pragma unroll
+            for (int j = 0; j < kNT; ++j)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) lds_c[(i * 16 + q * 4 + rr) * BN + (wave * kNT + j) * 16 + n16] = (half_t)acc[i][j][rr];
+    }
+    __syncthreads();
+    const bool vec_ok = (g.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0;
+    constexpr int PPR = BN / 8;  // 16-byte pieces per row
+    for (int e = tid; e < 128 * PPR; e += NTHREADS) {
+        const int row = e / PPR, pc = e % PPR;
+        const int m = m_base + row, n = nb0 + pc * 8;
+        if (m >= g.M || n >= g.N) continue;
+        const half8_t v = *reinterpret_cast<const half8_t *>(lds_c + row * BN + pc * 8);
+        half_t *c = g.C + (size_t)m * g.ldc + n;
+        if (vec_ok && n + 8 <= g.N) {
+            half8_t o = v;
+            if (g.add_to_c) {
+                const half8_t old = *reinterpret_cast<const half8_t *>(c);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) o[u] = (half_t)(old[u] + v[u]);
+            }
+            *reinterpret_cast<half8_t *>(c) = o;
+        } else {
+            for (int u = 0; u < 8 && n + u < g.N; ++u) c[u] = g.add_to_c ? (half_t)(c[u] + v[u]) : v[u];
+        }
+    }
+}
+
+int g_pk_ks = 0;  // 0: choose per launch, 1 / 2: forced (tuning)
+int g_pk_xm = 0;
+int g_pk_abl = 0;  // timing experiments: parts of the loop switched off (one quartet, groups of 128 only)
+
+template <int KS, int LG, int ABL = 0, int NS = 1>
+hipError_t launch_pk(PkGemmArgs &g, hipStream_t stream) {
+    size_t lds = (size_t)KS * 4 * pk::kHalfBytes;  // the rings; the quartet exchange (64 KiB) and the output tile (32 / 64 KiB) reuse them
+    auto kfn = w4a16_gemm_pk_kernel<KS, LG, ABL, NS>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kfn, dim3(8 * g.m_per * g.n_per), dim3(256 * KS * NS), lds, stream, g);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+void set_gemm_pk_ablation(int abl) { g_pk_abl = abl; }
+
+void set_gemm_pk_mode(int form, int xm) {
+    g_pk_ks = (form >= 1 && form <= 3) ? form : 0;
+    g_pk_xm = (xm == 1 || xm == 2 || xm == 4 || xm == 8) ? xm : 0;
+}
+
+size_t prepack_bytes(int N, int K, int G) {
+    if (N <= 0 || K <= 0 || K % 128 != 0 || (G != 128 && G != 64 && G != 32)) return 0;
+    return pk::total_bytes(N, K, G);
+}
+
+int launch_w4a16_prepack(const tce_w4a16_desc &d, void *out, hipStream_t stream, hipError_t *hip_err) {
+    if (d.K % 128 != 0) return TCE_ERR_UNSUPPORTED_SHAPE;
+    const int zw = zeros_width(d.K, d.group_size);
+    PrepackArgs a{};
+    a.qweight = static_cast<const unsigned *>(d.qweight);
+    a.scales = static_cast<const half_t *>(d.scales);
+    a.zeros = static_cast<const unsigned *>(d.zeros);
+    unsigned char *base = static_cast<unsigned char *>(out);
+    a.words = reinterpret_cast<unsigned *>(base);
+    a.consts = reinterpret_cast<uint2_t *>(base + pk::consts_offset(d.N, d.K));
+    a.last = reinterpret_cast<float *>(base + pk::last_offset(d.N, d.K, d.group_size));
+    a.N = d.N;
+    a.K = d.K;
+    a.log2g = d.group_size == 128 ? 7 : (d.group_size == 64 ? 6 : 5);
+    a.scales_stride = d.scales_stride ? d.scales_stride : zw * 8;
+    a.zeros_stride = d.zeros_stride ? d.zeros_stride : zw;
+    const int nt = pk::nt16(d.N);
+    hipLaunchKernelGGL(prepack_words_kernel, dim3(nt, d.K >> 7), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL(prepack_consts_kernel, dim3((nt * 16 + 63) / 64), dim3(64), 0, stream, a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (hip_err) *hip_err = e;
+        return TCE_ERR_HIP;
+    }
+    return TCE_OK;
+}
+
+// Which form launch_w4a16_gemm_pk would run -- 1: 128x128 tiles, one quartet, two workgroups per CU; 2: 128x128, two quartets
+// splitting K; 3: 128x256, two quartets side by side on one activation ring -- and a cost estimate in us for the dispatcher.
+// A workgroup's time per k-block c grows with the load on its CU and on the chip (f = resident waves / 2048); fitted to
+// profiles/r2/gemm_pk_sweep.jsonl: form 1 alone on its CU 1.06 us, sharing it 1.25 + 0.73 f; form 2 per PAIR of k-blocks
+// 1.7 + 0.4 f; form 3 (every active CU carries eight waves) 1.55 + 0.4 f; + 3 us of launch, prologue and epilogue.
+float gemm_pk_estimate_us(int M, int N, int K, int *form_out) {
+    const long mt = (M + 127) / 128;
+    const long tiles1 = mt * ((N + 127) / 128), tiles3 = mt * ((N + 255) / 256);
+    const float nkb = (float)(K / 128);
+    auto rounds = [](long tiles, long slots) {
+        const float r = (float)tiles / (float)slots;
+        return r <= 3.f ? (float)(int)(r + 0.999f) : r + 0.5f;
+    };
+    auto load = [](long waves) { return waves >= 2048 ? 1.0f : (float)waves / 2048.f; };
+    const float cost1 = (tiles1 <= 256 ? nkb * 1.06f : rounds(tiles1, 512) * nkb * (1.25f + 0.73f * load(tiles1 * 4))) + 3.0f;
+    const float cost2 = rounds(tiles1, 256) * (nkb * 0.5f) * (1.7f + 0.4f * load(tiles1 * 8)) + 3.0f;
+    const float cost3 = rounds(tiles3, 256) * nkb * (1.55f + 0.4f * load(tiles3 * 8)) + 3.0f;
+    int form = 1;
+    float best = cost1;
+    if (cost2 < best) best = cost2, form = 2;
+    if (cost3 < best) best = cost3, form = 3;
+    if (g_pk_ks) {
+        form = g_pk_ks;
+        best = form == 1 ? cost1 : (form == 2 ? cost2 : cost3);
+    }
+    if (form_out) *form_out = form;
+    return best;
+}
+
+int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_t stream, hipError_t *hip_err) {
+    if (d.K % 128 != 0 || !packed) return TCE_ERR_UNSUPPORTED_SHAPE;
+    const int lda = d.lda ? d.lda : d.K;
+    if ((lda * 2) % 16 != 0 || (reinterpret_cast<uintptr_t>(d.A) & 15)) return TCE_ERR_UNSUPPORTED_SHAPE;  // 16-byte DMA pieces
+    PkGemmArgs g{};
+    const unsigned char *base = static_cast<const unsigned char *>(packed);
+    g.A = static_cast<const half_t *>(d.A);
+    g.words = reinterpret_cast<const uint4_t *>(base);
+    g.consts = reinterpret_cast<const uint2_t *>(base + pk::consts_offset(d.N, d.K));
+    g.C = static_cast<half_t *>(d.C);
+    g.M = d.M;
+    g.N = d.N;
+    g.K = d.K;
+    g.lda = lda;
+    g.ldc = d.ldc ? d.ldc : d.N;
+    g.add_to_c = (d.flags & TCE_W4_ADD_TO_C) ? 1 : 0;
+    int form = 1;
+    gemm_pk_estimate_us(d.M, d.N, d.K, &form);
+    const int bn = form == 3 ? 256 : 128;
+    g.n_blocks = (d.N + bn - 1) / bn;
+    g.m_blocks = (d.M + 127) / 128;
+    int best_xm = 1;
+    long best_grid = -1;
+    for (int xm = 8; xm >= 1; xm >>= 1) {  // the XCD grid that wastes the fewest workgroup slots, larger xm on ties (w4a16_gemm_dma.hip)
+        const long grid = 8L * ((g.m_blocks + xm - 1) / xm) * ((g.n_blocks + 8 / xm - 1) / (8 / xm));
+        if (best_grid < 0 || grid < best_grid) {
+            best_grid = grid;
+            best_xm = xm;
+        }
+    }
+    g.xm = g_pk_xm ? g_pk_xm : best_xm;
+    g.m_per = (g.m_blocks + g.xm - 1) / g.xm;
+    g.n_per = (g.n_blocks + 8 / g.xm - 1) / (8 / g.xm);
+    const int ks = form;
+    hipError_t e;
+    const int lg = d.group_size == 128 ? 7 : (d.group_size == 64 ? 6 : 5);
+    if (g_pk_abl && lg == 7) {
+        switch (g_pk_abl) {
+#define TCE_ABL(X) case X: e = launch_pk<1, 7, X>(g, stream); break;
+            TCE_ABL(1) TCE_ABL(2) TCE_ABL(4) TCE_ABL(8) TCE_ABL(16) TCE_ABL(32) TCE_ABL(6) TCE_ABL(7) TCE_ABL(23) TCE_ABL(55) TCE_ABL(47) TCE_ABL(48)
+#undef TCE_ABL
+            default: return TCE_ERR_BAD_ARG;
+        }
+        if (e != hipSuccess) {
+            if (hip_err) *hip_err = e;
+            return TCE_ERR_HIP;
+        }
+        return TCE_OK;
+    }
+    if (ks == 3) e = lg == 7 ? launch_pk<1, 7, 0, 2>(g, stream) : (lg == 6 ? launch_pk<1, 6, 0, 2>(g, stream) : launch_pk<1, 5, 0, 2>(g, stream));
+    else if (ks == 2) e = lg == 7 ? launch_pk<2, 7>(g, stream) : (lg == 6 ? launch_pk<2, 6>(g, stream) : launch_pk<2, 5>(g, stream));
+    else e = lg == 7 ? launch_pk<1, 7>(g, stream) : (lg == 6 ? launch_pk<1, 6>(g, stream) : launch_pk<1, 5>(g, stream));
+    if (e != hipSuccess) {
+        if (hip_err) *hip_err = e;
+        return TCE_ERR_HIP;
+    }
+    return TCE_OK;
+}
+
+}  // namespace tce

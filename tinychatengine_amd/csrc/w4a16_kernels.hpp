@@ -95,6 +95,14 @@ void set_w8a8_ksplit(int ks);  // w8a8_gemm.hip tuning: wave quartets per tile (
 int launch_w4a16_gemm_dma(const tce_w4a16_desc &d, int m_tiles, int n_tiles, hipStream_t stream, hipError_t *hip_err);  // tuning: XCD grid of xm x (8 / xm) over (row blocks x column blocks)
 int launch_w4a16_gemm(const tce_w4a16_desc &d, int forced_mt, int forced_nt, hipStream_t stream, hipError_t *hip_err);
 
+// w4a16_gemm_pk.hip: the 128-row GEMM on pre-packed weights (q4_mfma, w4a16_mfma_layout.hpp)
+size_t prepack_bytes(int N, int K, int G);
+int launch_w4a16_prepack(const tce_w4a16_desc &d, void *out, hipStream_t stream, hipError_t *hip_err);
+int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_t stream, hipError_t *hip_err);
+float gemm_pk_estimate_us(int M, int N, int K, int *ks_out);
+void set_gemm_pk_mode(int ks, int xm);
+void set_gemm_pk_ablation(int abl);  // timing experiments (results meaningless): see w4a16_gemm_pk_kernel  // tuning: forced wave quartets per tile / XCD rows (0 = automatic)
+
 int check_zero_point_8(const void *zeros, long long n_words, hipError_t *hip_err);
 
 // AWQ (q4_5) helpers

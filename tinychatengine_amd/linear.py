@@ -23,7 +23,24 @@ class Linear_half_int4:
             raise ValueError("scales/zeros do not have the padded q4_6 shapes (quantize_methods.py:431-440)")
         # the reference quantizer writes zero point 8 everywhere; verified once here so the GEMV can skip the zeros stream
         self.zeros_are_8 = bool((zeros == -2004318072).all().item())
+        self.packed = None  # q4_mfma copy for the prefill GEMM (prepack())
         self._op = MatmulOperator()
+
+    def prepack(self) -> "Linear_half_int4":
+        """Builds the q4_mfma copy of the weights once (tce_w4a16_prepack; load-time work like the reference's offline
+        re-layouts, llm/tools/model_quantizer.py): descriptors built afterwards carry it, and tce_w4a16_forward runs the
+        128-row MFMA kernel on it for large batches.  K % 128 != 0: no packed form, nothing changes."""
+        if self.packed is None:
+            need = int(capi.lib().tce_w4a16_prepack_bytes(self.out_features, self.in_features, self.group_size))
+            if need:
+                buf = torch.empty(need + 256, dtype=torch.uint8, device=self.weight.device)
+                off = (-buf.data_ptr()) % 256
+                self._packed_storage = buf
+                self.packed = buf[off:off + need]
+                d = capi.W4A16Desc(M=1, N=self.out_features, K=self.in_features, group_size=self.group_size, qweight=_ptr(self.weight),
+                                   scales=_ptr(self.scale), zeros=_ptr(self.zero_point))
+                capi.check(capi.lib().tce_w4a16_prepack(d, self.packed.data_ptr(), _stream()))
+        return self
 
     @classmethod
     def from_float(cls, w: torch.Tensor, group_size: int = quantize.QK4_6):
@@ -60,7 +77,8 @@ class Linear_half_int4:
         return capi.W4A16Desc(M=m, N=self.out_features, K=self.in_features, group_size=self.group_size, A=x.data_ptr(),
                               qweight=self.weight.data_ptr(), scales=self.scale.data_ptr(), zeros=self.zero_point.data_ptr(),
                               C=out.data_ptr(), ldc=ldc, flags=flags | (capi.TCE_W4_ZERO_POINT_IS_8 if self.zeros_are_8 else 0),
-                              rmsnorm_gamma=gamma.data_ptr() if gamma is not None else None, rmsnorm_eps=float(eps))
+                              rmsnorm_gamma=gamma.data_ptr() if gamma is not None else None, rmsnorm_eps=float(eps),
+                              prepacked=self.packed.data_ptr() if self.packed is not None else None)
 
     @classmethod
     def interleave(cls, gate: "Linear_half_int4", up: "Linear_half_int4") -> "Linear_half_int4":
@@ -90,6 +108,9 @@ class Linear_half_int4:
         assert self.out_features > 8 and self.out_features % 16 == 0  # linear.cu:16-17
         if out is None:
             out = torch.empty((*x.shape[:-1], self.out_features), dtype=torch.float16, device=x.device)
+        if self.packed is not None:  # the descriptor carries the q4_mfma copy (what the C++ adapter does from its tensor cache)
+            capi.check(capi.w4a16_forward(self.desc(x, out), _stream()))
+            return out
         p = matmul_params(A=matrix(m, self.in_features, x), B=matrix(self.in_features // 8, self.out_features, self.weight),
                           C=matrix(m, self.out_features, out), half_scales=self.scale,
                           int32_zero_point=self.zero_point, block_size=self.group_size)
