@@ -137,6 +137,21 @@ TCE_API int tce_rope_half(void *q, void *k, const void *cos_table, const void *s
  * Vt [heads][head_dim][keys] (the transposed values the reference also keeps), mask fp16 [keys] or NULL, out [heads][head_dim]. */
 TCE_API int tce_attention_decode_f16(const void *q, const void *K, const void *Vt, const void *mask, void *out, int heads, int keys, int head_dim,
                                      unsigned short alpha_half_bits, void *stream);
+/* One decode step of the reference's Llama attention block between the fused q/k/v linear and o_proj as ONE bandwidth-bound launch
+ * (csrc/attention_fast.hip): replaces shape_qkv, RotaryPosEmb_cuda_forward, the KV append, qk_bmm, batch_Add, check_inf_half, softmax,
+ * transpose_1_2idx, pv_bmm and unshape (llm/src/nn_modules/cuda/Int4llamaAttention.cu:130-217).
+ *   qkv        fp16 [3][heads][head_dim]   the fused projection's output row (q | k | v, head-major: what qkv_proj.forward writes)
+ *   k_cache, v_cache  fp16 [heads][max_keys][head_dim]   fixed-capacity caches; rows [0, pos) hold the past, row `pos` is WRITTEN by this
+ *              call (the rotated key -- bit-identical to what the reference appends -- and the value)
+ *   cos_table / sin_table  fp16 [positions][head_dim] (RotaryPosEmb's tables) or both NULL: no rotation
+ *   mask       fp16 [pos + 1] additive, or NULL;  alpha as binary16 bits;  out fp16 [heads][head_dim] (= o_proj's input row)
+ *   workspace  tce_attention_decode_workspace_bytes(heads, max_keys, head_dim) bytes, ZEROED once by the caller before the first use
+ * Scores, softmax and the weighted sum run in fp32 over key chunks spread across the chip (the bit-exact binary16-chain form of the
+ * same block is tce_attention_decode_f16): results agree with that form within 2e-3 * max|out| per head.  head_dim == 128. */
+TCE_API size_t tce_attention_decode_workspace_bytes(int heads, int max_keys, int head_dim);
+TCE_API int tce_attention_decode_step_f16(const void *qkv, void *k_cache, void *v_cache, const void *cos_table, const void *sin_table, const void *mask,
+                                          void *out, void *workspace, int heads, int head_dim, int max_keys, int pos, unsigned short alpha_half_bits,
+                                          void *stream);
 /* Reads [ptr, ptr + bytes) with at most `workgroups` workgroups (0 = as many as the range needs) and discards the data: the
  * range then sits in the memory-side cache (256 MiB) for the launch that needs it.  Meant for a side stream / graph branch
  * next to the launch BEFORE that one (no reference counterpart: cudaMallocManaged prefetching is the closest idea). */
@@ -224,6 +239,16 @@ TCE_API int tce_w8a8_matmul(const tce_w8a8_desc *d, void *stream);
  * weight / bias fp32 [n], out int8 [m][n] = (int8) round((x - mean) / sqrt(var + 1e-5) * weight + bias), sums sequential
  * in fp32 exactly like the reference loop: BIT-EXACT.  n % 4 == 0, n <= 8192. */
 TCE_API int tce_layernorm_q(const float *x, const float *weight, const float *bias, void *out, int m, int n, void *stream);
+
+/* LayerNormQ and the int8 linears that read its output as ONE launch, for decode: replaces
+ *   self_attn_layer_norm.forward + q_proj / k_proj / v_proj.forward   (llm/src/nn_modules/Int8OPTAttention.cc:186-201 behind LayerNormQ.cc:12-52)
+ *   final_layer_norm.forward + fc1.forward                             (LayerNormQ + W8A8B8O8LinearReLU)
+ * x fp32 [m][k] (m <= 8), ln_weight / ln_bias fp32 [k]; `linears[i]` (count <= TCE_MAX_GROUP) describe the consumers exactly as for
+ * tce_w8a8_matmul with M = m, K = k, batch = 1, b_per_row = 0 -- their `A` is ignored (it is the normalised row, which never
+ * leaves the chip unless ln_out, int8 [m][k], is given).  BIT-EXACT against tce_layernorm_q followed by tce_w8a8_matmul (and so
+ * against the reference).  k % 16 == 0. */
+TCE_API int tce_layernorm_q_w8a8_group(const float *x, const float *ln_weight, const float *ln_bias, int m, int k, const tce_w8a8_desc *linears,
+                                       int count, void *ln_out, void *stream);
 
 /* ---- replayable plan: a fixed sequence of W4A16 launches captured into one hipGraph ---- */
 typedef struct tce_plan tce_plan;

@@ -19,3 +19,18 @@ for t in (128, 512, 2048):
     kk = torch.randn(32, t, 128, device=dev).half(); qq = torch.randn(32, 128, device=dev).half(); oo = torch.empty(32, 128, dtype=torch.float16, device=dev)
     row2["fused_decode_us"] = round(time_graph(lambda i, sp: capi.check(L.tce_attention_decode_f16(qq.data_ptr(), kk.data_ptr(), vt.data_ptr(), None, oo.data_ptr(), 32, t, 128, al, sp)), 32), 2)
     print(json.dumps(row2), flush=True)
+    # the one-launch fp32 step (RoPE + append + chunked online softmax): a fresh set of caches per graph node would not fit for long
+    # contexts, so the 32 nodes rotate over 4 cache sets (4 x 2 x 32 x t x 128 halves: > the 32 MB of L2 from t = 512 up)
+    from tinychatengine_amd.attention_ops import DecodeAttention
+    cos = torch.randn(t + 1, 128, device=dev).half(); sin = torch.randn(t + 1, 128, device=dev).half()
+    atts = [DecodeAttention(32, 128, t, dev, cos, sin) for _ in range(4)]
+    for a_ in atts:
+        a_.k_cache.normal_(0, 0.8); a_.v_cache.normal_(0, 0.8)
+    qkv = torch.randn(3 * 32 * 128, device=dev).half()
+    def step(i, sp):
+        a_ = atts[i % 4]
+        capi.check(L.tce_attention_decode_step_f16(qkv.data_ptr(), a_.k_cache.data_ptr(), a_.v_cache.data_ptr(), cos.data_ptr(), sin.data_ptr(), None, oo.data_ptr(),
+                                                   a_.workspace.data_ptr(), 32, 128, t, t - 1, al, sp))
+    us = time_graph(step, 32)
+    bytes_ = 2 * 32 * t * 128 * 2
+    print(json.dumps({"context": t, "decode_step_fp32_us": round(us, 2), "kv_bytes": bytes_, "GBs": round(bytes_ / us / 1e3, 1)}), flush=True)

@@ -123,3 +123,85 @@ def test_rope_bit_exact(dev, oracle, heads, ln, hd, start):
     rotary_pos_emb(tq, tk, torch.from_numpy(cos).to(dev), torch.from_numpy(sin).to(dev), start)
     torch.cuda.synchronize()
     assert np.array_equal(tq.cpu().numpy().view(np.uint16), wq.view(np.uint16)) and np.array_equal(tk.cpu().numpy().view(np.uint16), wk.view(np.uint16))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# tce_attention_decode_step_f16: the whole decode step of the attention block as one launch, fp32 arithmetic (csrc/attention_fast.hip)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _rope_tables(positions, hd, seed):
+    rng = np.random.default_rng(seed)  # any table: the kernel applies what it is given (the reference loads cos.bin / sin.bin)
+    ang = rng.uniform(0, 2 * np.pi, (positions, hd))
+    return np.cos(ang).astype(np.float16), np.sin(ang).astype(np.float16)
+
+
+def _attention_reference_f64(q_rot, K, V, alpha, mask):
+    """softmax(alpha * q K^T + mask) V per head in float64 on binary16 inputs; scores outside binary16 range -> -65504 (check_inf_half)."""
+    s = alpha * np.einsum("hd,hkd->hk", q_rot.astype(np.float64), K.astype(np.float64))
+    if mask is not None:
+        s = s + mask.astype(np.float64)[None, :]
+    s = np.where(np.abs(s) <= 65504.0, s, -65504.0)
+    s = s - s.max(axis=1, keepdims=True)
+    p = np.exp(s)
+    p /= p.sum(axis=1, keepdims=True)
+    return np.einsum("hk,hkd->hd", p, V.astype(np.float64))
+
+
+@pytest.mark.parametrize("heads,max_keys,steps,start", [(32, 64, 40, 0), (8, 2048, 3, 2045), (32, 2048, 2, 1000), (4, 300, 5, 250)])
+def test_attention_decode_step_against_float64_and_the_binary16_chain_kernel(dev, oracle, heads, max_keys, steps, start):
+    from tinychatengine_amd.attention_ops import DecodeAttention, attention_decode
+    hd = 128
+    rng = np.random.default_rng(heads + max_keys + start)
+    cos, sin = _rope_tables(max_keys, hd, 5)
+    att = DecodeAttention(heads, hd, max_keys, dev, torch.from_numpy(cos).to(dev), torch.from_numpy(sin).to(dev))
+    # a past of `start` keys already in the caches (rotated keys, as the reference would have appended them)
+    Kc = np.zeros((heads, max_keys, hd), np.float16)
+    Vc = np.zeros((heads, max_keys, hd), np.float16)
+    if start:
+        Kc[:, :start] = (rng.standard_normal((heads, start, hd)) * 0.8).astype(np.float16)
+        Vc[:, :start] = (rng.standard_normal((heads, start, hd)) * 0.8).astype(np.float16)
+        att.k_cache.copy_(torch.from_numpy(Kc))
+        att.v_cache.copy_(torch.from_numpy(Vc))
+    alpha = float(np.float16(1.0 / np.sqrt(hd)))
+    for t in range(steps):
+        pos = start + t
+        qkv = (rng.standard_normal((3, heads, hd)) * 0.9).astype(np.float16)
+        mask = None
+        if t % 2 == 1:  # an additive mask with a few keys switched off, as a padding mask would
+            mask = np.zeros(pos + 1, np.float16)
+            mask[rng.integers(0, pos + 1, size=max(1, (pos + 1) // 7))] = np.float16(-65504.0)
+            mask[pos] = 0
+        out = att.step(torch.from_numpy(qkv.reshape(-1)).to(dev), pos, mask=None if mask is None else torch.from_numpy(mask).to(dev))
+        torch.cuda.synchronize()
+        # the reference's RoPE (binary16 arithmetic) on q and the new key: the oracle's restatement of RotaryPosEmb_cuda_forward
+        q_rot, k_rot = oracle.rope_half(qkv[0][:, None, :], qkv[1][:, None, :], cos, sin, pos)
+        Kc[:, pos] = k_rot[:, 0]
+        Vc[:, pos] = qkv[2]
+        assert np.array_equal(att.k_cache[:, pos].cpu().numpy().view(np.uint16), Kc[:, pos].view(np.uint16)), "appended key differs from the reference's rotated key"
+        assert np.array_equal(att.v_cache[:, pos].cpu().numpy().view(np.uint16), Vc[:, pos].view(np.uint16))
+        ref = _attention_reference_f64(q_rot[:, 0], Kc[:, : pos + 1], Vc[:, : pos + 1], alpha, mask)
+        got = out.cpu().numpy().astype(np.float64)
+        tol = 2e-3 * np.abs(ref).max(axis=1, keepdims=True) + 2.0 ** -11 * np.abs(ref)
+        assert np.all(np.abs(got - ref) <= tol), f"step {t}: worst |err|/tol = {(np.abs(got - ref) / tol).max():.3f}"
+        if t == steps - 1:  # and against the bit-exact (binary16-chain) form of the same block, on the same rotated inputs
+            K_t = torch.from_numpy(np.ascontiguousarray(Kc[:, : pos + 1])).to(dev)
+            Vt_t = torch.from_numpy(np.ascontiguousarray(Vc[:, : pos + 1].transpose(0, 2, 1))).to(dev)
+            exact = torch.empty((heads, hd), dtype=torch.float16, device=dev)
+            attention_decode(torch.from_numpy(np.ascontiguousarray(q_rot[:, 0])).to(dev), K_t, Vt_t, exact, alpha,
+                             mask=None if mask is None else torch.from_numpy(mask).to(dev))
+            torch.cuda.synchronize()
+            e = exact.cpu().numpy().astype(np.float64)
+            # the chain kernel accumulates in binary16 (the reference's arithmetic): its own distance from float64 is the larger one
+            # (binary16 running sums over `keys` terms: ~1 % of the largest output per 1000 keys)
+            tol2 = (2e-2 + 2e-5 * (pos + 1)) * np.abs(ref).max(axis=1, keepdims=True)
+            assert np.all(np.abs(got - e) <= tol2), f"fp32 form vs binary16-chain form: {(np.abs(got - e) / tol2).max():.3f}"
+
+
+def test_attention_decode_step_argument_checks(dev):
+    from tinychatengine_amd import capi
+    L = capi.lib()
+    assert int(L.tce_attention_decode_workspace_bytes(32, 2048, 64)) == 0  # head_dim 128 only
+    z = torch.zeros(4096, dtype=torch.float16, device=dev)
+    ws = torch.zeros(int(L.tce_attention_decode_workspace_bytes(2, 64, 128)), dtype=torch.uint8, device=dev)
+    p = z.data_ptr()
+    assert L.tce_attention_decode_step_f16(p, p, p, None, None, None, p, ws.data_ptr(), 2, 128, 64, 64, 0x3C00, None) == capi.TCE_ERR_BAD_ARG  # pos == max_keys
+    assert L.tce_attention_decode_step_f16(p, p, p, p, None, None, p, ws.data_ptr(), 2, 128, 64, 0, 0x3C00, None) == capi.TCE_ERR_BAD_ARG  # cos without sin

@@ -214,3 +214,57 @@ def test_wave_quartets_per_tile_are_bit_exact(dev, oracle, M, N, K):
             assert np.array_equal(out.cpu().numpy(), exp), f"mode {mode}: {(out.cpu().numpy() != exp).sum()} mismatches"
     finally:
         L.tce_w4a16_set_debug_mode(70)
+
+
+@pytest.mark.parametrize("m,k,ns", [(1, 768, (768, 768, 768)), (1, 768, (3072,)), (3, 2048, (2048, 512)), (8, 96, (40, 24, 16, 8)), (1, 8192, (64,))])
+def test_layernorm_q_fused_with_its_linears_is_bit_exact(dev, oracle, m, k, ns):
+    """tce_layernorm_q_w8a8_group (SURVEY 8f-3): LayerNormQ::forward (LayerNormQ.cc:12-52) + q/k/v (Int8OPTAttention.cc:186-201) or
+    fc1 as ONE launch, against the oracle's LayerNormQ followed by int8_ref_matmul, and against the library's separate launches."""
+    from tinychatengine_amd.linear import W8A8B8O8Linear, W8A8BFP32OFP32Linear, layernorm_q_linears
+    rng = np.random.default_rng(m * 7 + k + len(ns))
+    x = (rng.standard_normal((m, k)) * 3.0 + 0.5).astype(np.float32)
+    x[0, :8] = [0.5, 1.5, 2.5, -0.5, -1.5, 100.0, -100.0, 0.0]  # ties of the final rounding and saturating values
+    lw = (rng.standard_normal(k) * 20.0).astype(np.float32)
+    lb = (rng.standard_normal(k) * 5.0).astype(np.float32)
+    q_ref = oracle.layernorm_q(x, lw, lb)
+    lins, exps = [], []
+    for i, n in enumerate(ns):
+        W = rng.integers(-128, 128, (n, k), dtype=np.int8)
+        if i == 1:  # one fp32-out linear in the group (the out_proj / fc2 kind), the rest int8-out, the last one with ReLU clamping
+            b = rng.standard_normal(n).astype(np.float32)
+            lins.append(W8A8BFP32OFP32Linear(_t(dev, W), _t(dev, b), 0.0031))
+            exps.append(oracle.int8_matmul_bias_f32(q_ref, W, b, 0.0031, m, n, k))
+        else:
+            b = rng.integers(-128, 128, n, dtype=np.int8)
+            relu = i == len(ns) - 1 and len(ns) > 1
+            lins.append(W8A8B8O8Linear(_t(dev, W), _t(dev, b), ALPHA, BETA, relu=relu))
+            exps.append(oracle.int8_matmul_bias_i8(q_ref, W, b, ALPHA, BETA, 0 if relu else -128, 127, m, n, k))
+    xt, lwt, lbt = _t(dev, x), _t(dev, lw), _t(dev, lb)
+    ln_out = torch.zeros((m, k), dtype=torch.int8, device=dev)
+    outs = layernorm_q_linears(xt, lwt, lbt, lins, ln_out=ln_out)
+    torch.cuda.synchronize()
+    assert np.array_equal(ln_out.cpu().numpy(), q_ref), "fused LayerNormQ output differs from the reference's"
+    for o, e in zip(outs, exps):
+        got = o.cpu().numpy()
+        assert np.array_equal(got.view(np.uint8 if got.dtype == np.int8 else np.uint32), e.view(np.uint8 if e.dtype == np.int8 else np.uint32))
+    # and the unfused path of this library
+    from tinychatengine_amd import capi
+    q_sep = torch.zeros((m, k), dtype=torch.int8, device=dev)
+    capi.check(capi.lib().tce_layernorm_q(xt.data_ptr(), lwt.data_ptr(), lbt.data_ptr(), q_sep.data_ptr(), m, k, torch.cuda.current_stream().cuda_stream))
+    for lin, o in zip(lins, outs):
+        assert torch.equal(lin(q_sep), o)
+
+
+def test_layernorm_q_fused_argument_checks(dev):
+    from tinychatengine_amd import capi
+    x = torch.zeros(9, 64, device=dev)
+    w = torch.zeros(64, device=dev)
+    B = torch.zeros(16, 64, dtype=torch.int8, device=dev)
+    o = torch.zeros(9, 16, dtype=torch.int8, device=dev)
+    d = capi.W8A8Desc(M=9, N=16, K=64, batch=1, B=B.data_ptr(), C=o.data_ptr(), alpha=1.0, q_min=-128, q_max=127, bias_kind=capi.TCE_BIAS_NONE, out_kind=capi.TCE_OUT_INT8)
+    arr = (capi.W8A8Desc * 1)(d)
+    L = capi.lib()
+    assert L.tce_layernorm_q_w8a8_group(x.data_ptr(), w.data_ptr(), w.data_ptr(), 9, 64, arr, 1, None, None) == capi.TCE_ERR_UNSUPPORTED_SHAPE  # m > 8
+    arr[0].M = 2
+    assert L.tce_layernorm_q_w8a8_group(x.data_ptr(), w.data_ptr(), w.data_ptr(), 1, 64, arr, 1, None, None) == capi.TCE_ERR_BAD_ARG  # M mismatch
+    assert L.tce_layernorm_q_w8a8_group(x.data_ptr(), w.data_ptr(), w.data_ptr(), 1, 40, arr, 1, None, None) == capi.TCE_ERR_UNSUPPORTED_SHAPE  # k % 16

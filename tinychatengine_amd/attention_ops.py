@@ -61,3 +61,29 @@ def rotary_pos_emb(q: torch.Tensor | None, k: torch.Tensor | None, cos: torch.Te
     assert cos.dtype == sin.dtype == torch.float16 and cos.shape[-1] == hd and cos.shape[0] >= start_idx + ln
     capi.check(capi.lib().tce_rope_half(C.c_void_p(q.data_ptr() if q is not None else 0), C.c_void_p(k.data_ptr() if k is not None else 0),
                                         C.c_void_p(cos.data_ptr()), C.c_void_p(sin.data_ptr()), heads, ln, hd, start_idx, C.c_void_p(_stream())))
+
+
+class DecodeAttention:
+    """One decode step of the Llama attention block between the fused q/k/v linear and o_proj as ONE launch
+    (tce_attention_decode_step_f16; Int4llamaAttention.cu:130-217 without its copies and transposes): fixed-capacity caches
+    [heads][max_keys][hd], RoPE on q and the new key with the reference's binary16 arithmetic, fp32 online softmax over key chunks."""
+
+    def __init__(self, heads: int, head_dim: int, max_keys: int, device, cos: torch.Tensor | None = None, sin: torch.Tensor | None = None):
+        self.heads, self.hd, self.max_keys = heads, head_dim, max_keys
+        self.k_cache = torch.zeros((heads, max_keys, head_dim), dtype=torch.float16, device=device)
+        self.v_cache = torch.zeros((heads, max_keys, head_dim), dtype=torch.float16, device=device)
+        need = int(capi.lib().tce_attention_decode_workspace_bytes(heads, max_keys, head_dim))
+        if need == 0:
+            raise ValueError("unsupported attention shape (head_dim must be 128)")
+        self.workspace = torch.zeros(need, dtype=torch.uint8, device=device)  # zeroed once: the arrival counters
+        self.cos, self.sin = cos, sin
+        self.alpha_bits = int(np.array([1.0 / np.sqrt(head_dim)], np.float16).view(np.uint16)[0])
+
+    def step(self, qkv: torch.Tensor, pos: int, out: torch.Tensor | None = None, mask: torch.Tensor | None = None) -> torch.Tensor:
+        assert qkv.dtype == torch.float16 and qkv.is_contiguous() and qkv.numel() == 3 * self.heads * self.hd and qkv.is_cuda
+        if out is None:
+            out = torch.empty((self.heads, self.hd), dtype=torch.float16, device=qkv.device)
+        p = lambda t: C.c_void_p(t.data_ptr() if t is not None else 0)
+        capi.check(capi.lib().tce_attention_decode_step_f16(p(qkv), p(self.k_cache), p(self.v_cache), p(self.cos), p(self.sin), p(mask), p(out), p(self.workspace),
+                                                            self.heads, self.hd, self.max_keys, int(pos), self.alpha_bits, C.c_void_p(_stream())))
+        return out

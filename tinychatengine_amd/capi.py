@@ -27,8 +27,8 @@ TCE_OUT_INT8, TCE_OUT_FP32 = 0, 1
 
 # every symbol include/tce_matmul.h declares (tests/test_boundary.py checks the .so exports exactly these)
 EXPORTS = [
-    "tce_w4a16_forward", "tce_w4a16_prepack_bytes", "tce_w4a16_prepack", "tce_w4a16_describe_dispatch", "tce_reset_last_error", "tce_bmm_f16t", "tce_rope_half", "tce_softmax_half", "tce_attention_decode_f16", "tce_prefetch", "tce_add_half", "tce_silu_mul_half", "tce_rmsnorm_half", "tce_w4a16_forward_group_rmsnorm", "tce_w4a16_forward_group", "tce_w4a16_check_zero_point_8", "tce_w4a16_awq_fp16acc", "tce_w4a16_awq_workspace_bytes",
-    "tce_w4a16_gemm_awq", "tce_w8a8_matmul", "tce_layernorm_q", "tce_plan_create", "tce_plan_create_ex", "tce_plan_is_chained", "tce_plan_geometry", "tce_plan_status", "tce_plan_launch", "tce_plan_n_launches",
+    "tce_w4a16_forward", "tce_w4a16_prepack_bytes", "tce_w4a16_prepack", "tce_w4a16_describe_dispatch", "tce_reset_last_error", "tce_bmm_f16t", "tce_rope_half", "tce_softmax_half", "tce_attention_decode_f16", "tce_attention_decode_workspace_bytes", "tce_attention_decode_step_f16", "tce_prefetch", "tce_add_half", "tce_silu_mul_half", "tce_rmsnorm_half", "tce_w4a16_forward_group_rmsnorm", "tce_w4a16_forward_group", "tce_w4a16_check_zero_point_8", "tce_w4a16_awq_fp16acc", "tce_w4a16_awq_workspace_bytes",
+    "tce_w4a16_gemm_awq", "tce_w8a8_matmul", "tce_layernorm_q", "tce_layernorm_q_w8a8_group", "tce_plan_create", "tce_plan_create_ex", "tce_plan_is_chained", "tce_plan_geometry", "tce_plan_status", "tce_plan_launch", "tce_plan_n_launches",
     "tce_plan_destroy", "tce_version", "tce_last_error", "tce_build_info", "tce_w4a16_set_gemv_config",
     "tce_w4a16_set_gemm_config", "tce_w4a16_algorithmic_bytes", "tce_w4a16_gemv_variant", "tce_w4a16_gemm_variant",
     "tce_w4a16_set_debug_mode", "tce_w4a16_set_debug_buffer", "tce_malloc", "tce_free", "tce_memcpy", "tce_synchronize", "tce_device_count",
@@ -90,6 +90,9 @@ def lib() -> C.CDLL:
         L.tce_rope_half.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]
         L.tce_softmax_half.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]
         L.tce_attention_decode_f16.argtypes = [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_ushort, C.c_void_p]
+        L.tce_attention_decode_workspace_bytes.argtypes = [C.c_int] * 3
+        L.tce_attention_decode_workspace_bytes.restype = C.c_size_t
+        L.tce_attention_decode_step_f16.argtypes = [C.c_void_p] * 8 + [C.c_int] * 4 + [C.c_ushort, C.c_void_p]
         L.tce_add_half.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]
         L.tce_silu_mul_half.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]
         L.tce_rmsnorm_half.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]
@@ -101,6 +104,7 @@ def lib() -> C.CDLL:
         L.tce_w4a16_gemm_awq.argtypes = [C.c_int] * 4 + [C.c_void_p] * 5 + [C.c_int, C.c_void_p]
         L.tce_w8a8_matmul.argtypes = [C.POINTER(W8A8Desc), C.c_void_p]
         L.tce_layernorm_q.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.tce_layernorm_q_w8a8_group.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(W8A8Desc), C.c_int, C.c_void_p, C.c_void_p]
         L.tce_plan_create.argtypes = [C.POINTER(W4A16Desc), C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_void_p)]
         L.tce_plan_create_ex.argtypes = [C.POINTER(W4A16Desc), C.POINTER(C.c_int32), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.tce_plan_is_chained.argtypes = [C.c_void_p]

@@ -1,0 +1,294 @@
+// attention_fast.hip -- one decode step of the reference's Llama attention block between the fused q/k/v linear and o_proj, as
+// ONE launch, bandwidth-bound in the KV cache ("flash-decoding").
+//
+// What it replaces per token and layer (llm/src/nn_modules/cuda/Int4llamaAttention.cu:116-229):
+//     shape_qkv_cuda (:41-64, 130-136)          the fused projection's row [3 * heads * hd] is read in place (q | k | v, head-major)
+//     RotaryPosEmb_cuda_forward (:157-159)      applied to q and the new k while they are loaded -- the reference's binary16
+//                                               arithmetic hfma(x, cos, hmul(rot, sin)) (llm/src/ops/cuda/RotaryPosEmb.cu:4-34): the
+//                                               key that enters the cache is bit-identical to the reference's
+//     the KV append (:161-181)                  the reference copies the WHOLE past into the layer's other cache buffer every token
+//                                               (4 cudaMemcpyAsync per head, O(t)); here the cache is one fixed-capacity array
+//                                               [heads][max_keys][hd] per K and V and the new row is written at index `pos`
+//     qk_bmm -> batch_Add -> check_inf_half -> softmax -> transpose_1_2idx -> pv_bmm -> unshape (:184-217)
+//                                               scores, online softmax and the weighted sum of V rows in fp32, the key range cut into
+//                                               chunks over workgroups (heads x chunks fills the chip); V is read in the layout it was
+//                                               appended in (no transposed copy); the output row [heads * hd] is o_proj's input
+// The bit-exact form of the same block -- binary16 accumulation chains in the reference's order -- stays available as
+// tce_attention_decode_f16 (attention_ops.hip); that one is what parity is claimed with.  THIS kernel computes the same function
+// in fp32 and is checked against it with a stated tolerance (tests/test_gpu_attention.py): |out - ref| <= 2e-3 * max|ref| per head
+// + one binary16 ulp, i.e. the difference between fp32 and binary16 accumulation, not a different algorithm.
+//
+// Work decomposition: workgroup = (head, chunk of keys), 4 waves; a wave takes 4 keys per step -- lane = (key slot = lane / 16,
+// piece = lane % 16): one 16-byte load per lane covers 4 consecutive cache rows completely (1 KiB contiguous), the dot product is 4
+// v_dot2_f32_f16 per lane plus a 4-step DPP sum over the 16 lanes of a row, every lane of the row then holds the score and
+// rescales its own 8 output dimensions (online softmax state per (wave, key slot)).  The 16 states of a workgroup are merged
+// through LDS, the chunks of a head through a small fp32 workspace by the last workgroup to arrive (write-through stores +
+// device-scope loads: MI355X_MICROARCH.md, inter-workgroup visibility; no cache-wide fence).
+#include "tce_common.hpp"
+#include "w4a16_kernels.hpp"
+
+namespace tce {
+
+namespace {
+
+struct FastAttnArgs {
+    const half_t *qkv;    // [3][heads][hd]
+    half_t *kc, *vc;      // [heads][max_keys][hd]
+    const half_t *cosv, *sinv;  // [positions][hd] or null (no RoPE: q / k used as they are)
+    const half_t *mask;   // [keys] additive or null
+    half_t *out;          // [heads][hd]
+    float *part;          // [heads][chunks][2 + hd]
+    unsigned *cnt;        // [heads], zero between launches
+    int heads, hd, max_keys, pos, keys, chunk, chunks;
+    float alpha;
+};
+
+__device__ __forceinline__ float row16_sum(float v) {  // sum over the 16 lanes of a DPP row, result in every lane of the row
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, false));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x141>{});  // row_half_mirror
+    v += dpp(v, std::integral_constant<int, 0x140>{});  // row_mirror
+    return v;
+}
+
+// RotaryPosEmb_cuda_forward on the 8 elements of `piece` (hd = 128: the partner half is piece ^ 8):
+//   out[j] = hfma(x[j], cos[j], hmul(rot[j], sin[j])),  rot[j] = j < hd/2 ? -x[j + hd/2] : x[j - hd/2]
+__device__ __forceinline__ half8_t rope_piece(const half_t *x, const half_t *cosr, const half_t *sinr, int piece) {
+    const half8_t v = *reinterpret_cast<const half8_t *>(x + piece * 8);
+    if (!cosr) return v;
+    const half8_t p = *reinterpret_cast<const half8_t *>(x + (piece ^ 8) * 8);
+    const half8_t c = *reinterpret_cast<const half8_t *>(cosr + piece * 8), s = *reinterpret_cast<const half8_t *>(sinr + piece * 8);
+    half8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const half_t rot = piece < 8 ? (half_t)(-p[e]) : p[e];
+        const half_t t = rot * s[e];                       // hmul
+        o[e] = __builtin_fmaf16(v[e], c[e], t);            // hfma: v_fma_f16, one rounding (as tce_rope_half, attention_ops.hip)
+    }
+    return o;
+}
+
+constexpr int kHD = 128;
+constexpr float kNegBig = -1.0e30f;
+
+__global__ __launch_bounds__(256) void attn_decode_fast_kernel(const FastAttnArgs a) {
+    __shared__ __attribute__((aligned(16))) float st[16][2 + kHD];  // the 16 (wave, slot) states: m, l, o[hd]
+    __shared__ __attribute__((aligned(16))) half_t newrow[2][kHD];  // the token's own (rotated) key and value
+    __shared__ unsigned last_flag;
+    const int head = blockIdx.x / a.chunks, c = blockIdx.x - head * a.chunks;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slot = lane >> 4, piece = lane & 15;
+    const int key0 = c * a.chunk, key1 = key0 + a.chunk < a.keys ? key0 + a.chunk : a.keys;
+    const half_t *cosr = a.cosv ? a.cosv + (size_t)a.pos * kHD : nullptr, *sinr = a.sinv ? a.sinv + (size_t)a.pos * kHD : nullptr;
+    const size_t hoff = (size_t)head * kHD;
+    // ---- q (rotated), this lane's 8 dimensions, in fp32 ----
+    const half8_t qh = rope_piece(a.qkv + hoff, cosr, sinr, piece);
+    // ---- the new key / value of this head: into LDS for this workgroup's use, into the cache by the workgroup that owns index pos ----
+    if (wave == 0) {
+        const half8_t kh = rope_piece(a.qkv + (size_t)a.heads * kHD + hoff, cosr, sinr, piece);
+        const half8_t vh = *reinterpret_cast<const half8_t *>(a.qkv + (size_t)2 * a.heads * kHD + hoff + piece * 8);
+        if (slot == 0) {
+            *reinterpret_cast<half8_t *>(&newrow[0][piece * 8]) = kh;
+            *reinterpret_cast<half8_t *>(&newrow[1][piece * 8]) = vh;
+            if (a.pos >= key0 && a.pos < key1) {
+                *reinterpret_cast<half8_t *>(a.kc + ((size_t)head * a.max_keys + a.pos) * kHD + piece * 8) = kh;
+                *reinterpret_cast<half8_t *>(a.vc + ((size_t)head * a.max_keys + a.pos) * kHD + piece * 8) = vh;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- this wave's keys: chunk / 4 consecutive ones, 4 per step ----
+    const int per_wave = a.chunk >> 2;
+    const int kw0 = key0 + wave * per_wave;
+    float m = kNegBig, l = 0.f, acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    const half_t *kbase = a.kc + (size_t)head * a.max_keys * kHD, *vbase = a.vc + (size_t)head * a.max_keys * kHD;
+    // blocks of 4 steps (16 keys per wave): the 8 loads of the next block are in flight while this block's scores and
+    // exponentials are computed (the online-softmax state is the only loop-carried dependence; without the explicit double
+    // buffer every step paid a full memory round trip: 20 us at 2048 keys, profiles/r2/attention_decode_step.jsonl)
+    constexpr int BLK = 4;
+    half8_t kbuf[2][BLK], vbuf[2][BLK];
+    auto fetch = [&](half8_t (&kd)[BLK], half8_t (&vd)[BLK], int it0) {
+#pragma unroll
+        for (int u = 0; u < BLK; ++u) {
+            const int key = kw0 + it0 + u * 4 + slot;
+            const int kk = key < key1 ? key : (a.keys - 1);  // clamped: rows past the range are read (harmlessly) and weigh nothing
+            kd[u] = *reinterpret_cast<const half8_t *>(kbase + (size_t)kk * kHD + piece * 8);
+            vd[u] = *reinterpret_cast<const half8_t *>(vbase + (size_t)kk * kHD + piece * 8);
+        }
+    };
+    auto consume = [&](const half8_t (&kd)[BLK], const half8_t (&vd)[BLK], int it0) {
+#pragma unroll
+        for (int u = 0; u < BLK; ++u) {
+            const int key = kw0 + it0 + u * 4 + slot;
+            const bool valid = key < key1;
+            half8_t kv = kd[u], vv = vd[u];
+            if (key == a.pos) {  // the token's own row: not necessarily visible in the cache yet
+                kv = *reinterpret_cast<const half8_t *>(&newrow[0][piece * 8]);
+                vv = *reinterpret_cast<const half8_t *>(&newrow[1][piece * 8]);
+            }
+            float d = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) d = __builtin_amdgcn_fdot2(half2_t{qh[e], qh[e + 1]}, half2_t{kv[e], kv[e + 1]}, d, false);
+            d = row16_sum(d);
+            float s = a.alpha * d;
+            if (a.mask) s += (float)a.mask[valid ? key : a.keys - 1];
+            if (!(__builtin_fabsf(s) <= 65504.0f)) s = -65504.0f;  // check_inf_half (Int4llamaAttention.cu:105-115): inf / nan / beyond binary16 -> -65504
+            if (!valid) s = kNegBig;
+            const float mn = __builtin_fmaxf(m, s);
+            const float sc = __expf(m - mn), p = valid ? __expf(s - mn) : 0.f;
+            m = mn;
+            l = l * sc + p;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = acc[e] * sc + p * (float)vv[e];
+        }
+    };
+    // per_wave is a multiple of 4 (steps); blocks of 4 steps, the last one possibly past the range (clamped loads, zero weights)
+    fetch(kbuf[0], vbuf[0], 0);
+    for (int it = 0; it < per_wave; it += 2 * BLK * 4) {
+        fetch(kbuf[1], vbuf[1], it + BLK * 4);
+        consume(kbuf[0], vbuf[0], it);
+        if (it + BLK * 4 >= per_wave) break;
+        fetch(kbuf[0], vbuf[0], it + 2 * BLK * 4);
+        consume(kbuf[1], vbuf[1], it + BLK * 4);
+    }
+    // ---- merge the workgroup's 16 states ----
+    {
+        float *s_ = st[wave * 4 + slot];
+        if (piece == 0) {
+            s_[0] = m;
+            s_[1] = l;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s_[2 + piece * 8 + e] = acc[e];
+    }
+    __syncthreads();
+    float M = kNegBig, L = 0.f, O = 0.f;  // thread d < 128 owns output dimension d
+    if (tid < kHD) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) M = __builtin_fmaxf(M, st[i][0]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float w = __expf(st[i][0] - M);
+            L += st[i][1] * w;
+            O += st[i][2 + tid] * w;
+        }
+    }
+    if (a.chunks == 1) {
+        if (tid < kHD) a.out[hoff + tid] = (half_t)(O / L);
+        return;
+    }
+    // ---- several chunks per head: partial (M, L, O) to the workspace, the last workgroup to arrive combines ----
+    float *mine = a.part + ((size_t)head * a.chunks + c) * (2 + kHD);
+    if (tid < kHD) {
+        __hip_atomic_store(mine + 2 + tid, O, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through (sc1) stores
+        if (tid == 0) {
+            __hip_atomic_store(mine, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(mine + 1, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores are acknowledged before the workgroup arrives
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(a.cnt + head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = old == (unsigned)a.chunks - 1 ? 1u : 0u;
+        if (last_flag) __hip_atomic_store(a.cnt + head, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    // The partials were stored write-through; they are read back with device-coherent (sc0 sc1) buffer loads -- plain loads as
+    // far as the compiler is concerned, so all of a thread's loads are in flight together (a loop of relaxed atomic loads is a
+    // chain of round trips: 1 us per chunk, measured).  Thread i < chunks fetches (M_i, L_i), every thread d < hd its O_i[d].
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.part + (size_t)head * a.chunks * (2 + kHD), 0, (int)((size_t)a.chunks * (2 + kHD) * 4), 0x00020000);
+    float *ml = &st[0][0];  // [chunks][2], reuses the state area
+    if (tid < a.chunks) {
+        ml[2 * tid] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, tid * (2 + kHD) * 4, 0, /*sc0|sc1*/ 17));
+        ml[2 * tid + 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, tid * (2 + kHD) * 4 + 4, 0, 17));
+    }
+    constexpr int kMaxChunksUnrolled = 16;
+    float oi[kMaxChunksUnrolled];
+    if (tid < kHD) {
+#pragma unroll
+        for (int i = 0; i < kMaxChunksUnrolled; ++i)
+            oi[i] = i < a.chunks ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (i * (2 + kHD) + 2 + tid) * 4, 0, 17)) : 0.f;
+    }
+    __syncthreads();
+    if (tid < kHD) {
+        float Mx = kNegBig;
+        for (int i = 0; i < a.chunks; ++i) Mx = __builtin_fmaxf(Mx, ml[2 * i]);
+        float Lx = 0.f, Ox = 0.f;
+#pragma unroll
+        for (int i = 0; i < kMaxChunksUnrolled; ++i) {
+            if (i < a.chunks) {
+                const float w = __expf(ml[2 * i] - Mx);
+                Lx += ml[2 * i + 1] * w;
+                Ox += oi[i] * w;
+            }
+        }
+        for (int i = kMaxChunksUnrolled; i < a.chunks; ++i) {  // very long contexts: the rest one by one
+            const float w = __expf(ml[2 * i] - Mx);
+            Lx += ml[2 * i + 1] * w;
+            Ox += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (i * (2 + kHD) + 2 + tid) * 4, 0, 17)) * w;
+        }
+        a.out[hoff + tid] = (half_t)(Ox / Lx);
+    }
+}
+
+}  // namespace
+
+// chunk of keys per workgroup: heads x chunks should cover the chip a couple of times; a multiple of 16 (4 waves x 4 keys per step)
+static int pick_chunk(int heads, int keys) {
+    const int target_chunks = heads >= 256 ? 1 : 256 / heads;  // one workgroup per CU: fewer, longer key runs and fewer partials to merge
+    int chunk = (keys + target_chunks - 1) / target_chunks;
+    chunk = (chunk + 15) & ~15;
+    if (chunk < 64) chunk = 64;
+    if (chunk > 1024) chunk = 1024;
+    return chunk;
+}
+
+size_t attention_decode_workspace_bytes(int heads, int max_keys, int hd) {
+    if (heads <= 0 || max_keys <= 0 || hd != kHD) return 0;
+    const int chunk = 64;  // the smallest chunk bounds the number of partials
+    const size_t chunks = (size_t)(max_keys + chunk - 1) / chunk;
+    const size_t cnt_bytes = ((size_t)heads * 4 + 255) & ~(size_t)255;
+    return cnt_bytes + (size_t)heads * chunks * (2 + kHD) * 4;
+}
+
+int launch_attention_decode_fast(const void *qkv, void *kc, void *vc, const void *cosv, const void *sinv, const void *mask, void *out, void *workspace,
+                                 int heads, int hd, int max_keys, int pos, unsigned short alpha_bits, hipStream_t stream, hipError_t *hip_err) {
+    if (hd != kHD) return TCE_ERR_UNSUPPORTED_SHAPE;
+    FastAttnArgs a{};
+    a.qkv = static_cast<const half_t *>(qkv);
+    a.kc = static_cast<half_t *>(kc);
+    a.vc = static_cast<half_t *>(vc);
+    a.cosv = static_cast<const half_t *>(cosv);
+    a.sinv = static_cast<const half_t *>(sinv);
+    a.mask = static_cast<const half_t *>(mask);
+    a.out = static_cast<half_t *>(out);
+    const size_t cnt_bytes = ((size_t)heads * 4 + 255) & ~(size_t)255;
+    a.cnt = static_cast<unsigned *>(workspace);
+    a.part = reinterpret_cast<float *>(static_cast<unsigned char *>(workspace) + cnt_bytes);
+    a.heads = heads;
+    a.hd = hd;
+    a.max_keys = max_keys;
+    a.pos = pos;
+    a.keys = pos + 1;
+    a.chunk = pick_chunk(heads, a.keys);
+    a.chunks = (a.keys + a.chunk - 1) / a.chunk;
+    half_t ah;
+    __builtin_memcpy(&ah, &alpha_bits, 2);
+    a.alpha = (float)ah;
+    hipLaunchKernelGGL(attn_decode_fast_kernel, dim3(heads * a.chunks), dim3(256), 0, stream, a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (hip_err) *hip_err = e;
+        return TCE_ERR_HIP;
+    }
+    return TCE_OK;
+}
+
+}  // namespace tce

@@ -66,29 +66,15 @@ __global__ __launch_bounds__(64) void layernorm_q_kernel(const float *x, const f
     const int n4 = n >> 2;  // n % 4 == 0
     for (int p = lane; p < n4; p += 64) reinterpret_cast<float4_t *>(row)[p] = reinterpret_cast<const float4_t *>(xr)[p];
     __syncthreads();
-    float mean = 0.f, std_dev = 0.f;
-    if (lane == 0) {
-#pragma unroll 8
-        for (int p = 0; p < n4; ++p) {
-            const float4_t v = reinterpret_cast<const float4_t *>(row)[p];
-            mean += v[0];
-            mean += v[1];
-            mean += v[2];
-            mean += v[3];
-        }
-        mean /= (float)n;
-        float sq = 0.f;
-#pragma unroll 8
-        for (int p = 0; p < n4; ++p) {
-            const float4_t v = reinterpret_cast<const float4_t *>(row)[p];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float d = v[e] - mean;
-                sq += __fmul_rn(d, d);
-            }
-        }
-        std_dev = sqrtf(sq / (float)n + 0.00001f);
-    }
+    // the two sums in the reference's order (sequential_sum_lane0: one dependent add per element, tce_common.hpp)
+    float mean = sequential_sum_lane0(row, n, lane, [](float v) { return v; });
+    mean /= (float)n;
+    mean = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, mean)));
+    float sq = sequential_sum_lane0(row, n, lane, [&](float v) {
+        const float d = v - mean;
+        return __fmul_rn(d, d);
+    });
+    float std_dev = sqrtf(sq / (float)n + 0.00001f);
     mean = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, mean)));
     std_dev = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, std_dev)));
     for (int k = lane; k < n; k += 64) {

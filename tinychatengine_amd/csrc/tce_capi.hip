@@ -556,6 +556,46 @@ int tce_w8a8_matmul(const tce_w8a8_desc *d, void *stream) {
     return rc == TCE_ERR_HIP ? hip_fail(he, "w8a8 launch") : rc;
 }
 
+size_t tce_attention_decode_workspace_bytes(int heads, int max_keys, int hd) { return tce::attention_decode_workspace_bytes(heads, max_keys, hd); }
+
+int tce_attention_decode_step_f16(const void *qkv, void *kc, void *vc, const void *cosv, const void *sinv, const void *mask, void *out, void *workspace, int heads,
+                                  int hd, int max_keys, int pos, unsigned short alpha_bits, void *stream) {
+    if (!qkv || !kc || !vc || !out || !workspace) return fail(TCE_ERR_BAD_ARG, "tce_attention_decode_step_f16: null pointer");
+    if ((cosv == nullptr) != (sinv == nullptr)) return fail(TCE_ERR_BAD_ARG, "tce_attention_decode_step_f16: cos and sin tables come together");
+    if (heads <= 0 || max_keys <= 0 || pos < 0 || pos >= max_keys) return fail(TCE_ERR_BAD_ARG, "tce_attention_decode_step_f16: need heads > 0 and 0 <= pos < max_keys");
+    if (hd != 128) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_attention_decode_step_f16: head_dim %d (128 only: Llama's)", hd);
+    for (const void *p : {qkv, (const void *)kc, (const void *)vc, cosv, sinv})
+        if (reinterpret_cast<uintptr_t>(p) & 15) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_attention_decode_step_f16: 16-byte aligned pointers");
+    hipError_t he = hipSuccess;
+    const int rc = tce::launch_attention_decode_fast(qkv, kc, vc, cosv, sinv, mask, out, workspace, heads, hd, max_keys, pos, alpha_bits, static_cast<hipStream_t>(stream), &he);
+    return rc == TCE_ERR_HIP ? hip_fail(he, "attention decode step launch") : rc;
+}
+
+int tce_layernorm_q_w8a8_group(const float *x, const float *ln_weight, const float *ln_bias, int m, int k, const tce_w8a8_desc *lin, int count,
+                               void *ln_out, void *stream) {
+    if (!x || !ln_weight || !ln_bias || !lin) return fail(TCE_ERR_BAD_ARG, "tce_layernorm_q_w8a8_group: null pointer");
+    if (m < 1 || m > 8) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_layernorm_q_w8a8_group is a decode path: 1 <= m <= 8, got %d", m);
+    if (k <= 0 || k % 16 != 0) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_layernorm_q_w8a8_group: k=%d must be a positive multiple of 16", k);
+    if (count < 1 || count > TCE_MAX_GROUP) return fail(TCE_ERR_BAD_ARG, "group count %d not in 1..%d", count, TCE_MAX_GROUP);
+    if ((reinterpret_cast<uintptr_t>(x) & 15)) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "x must be 16-byte aligned");
+    for (int i = 0; i < count; ++i) {
+        const tce_w8a8_desc &d = lin[i];
+        if (!d.B || !d.C || d.N <= 0) return fail(TCE_ERR_BAD_ARG, "linear %d: null B / C or non-positive N", i);
+        if (d.M != m || d.K != k || d.batch != 1 || d.b_per_row) return fail(TCE_ERR_BAD_ARG, "linear %d: M / K must be the normalised rows', batch 1, no per-row B", i);
+        if ((reinterpret_cast<uintptr_t>(d.B) & 15)) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "linear %d: B must be 16-byte aligned", i);
+        const bool ok = (d.out_kind == TCE_OUT_INT8 && (d.bias_kind == TCE_BIAS_INT8 || d.bias_kind == TCE_BIAS_NONE)) ||
+                        (d.out_kind == TCE_OUT_FP32 && (d.bias_kind == TCE_BIAS_FP32 || d.bias_kind == TCE_BIAS_NONE));
+        if (!ok) return fail(TCE_ERR_UNSUPPORTED_KIND, "linear %d: bias_kind %d with out_kind %d has no reference counterpart", i, d.bias_kind, d.out_kind);
+        if (d.bias_kind != TCE_BIAS_NONE && !d.bias) return fail(TCE_ERR_BAD_ARG, "linear %d: bias_kind set but bias is null", i);
+        if (d.out_kind == TCE_OUT_INT8 && (d.q_min < -128 || d.q_max > 127 || d.q_min > d.q_max)) return fail(TCE_ERR_BAD_ARG, "linear %d: q_min/q_max out of int8 range", i);
+    }
+    hipError_t he = hipSuccess;
+    const int rc = tce::launch_lnq_w8a8_group(x, ln_weight, ln_bias, m, k, lin, count, ln_out, static_cast<hipStream_t>(stream), &he);
+    if (rc == TCE_ERR_HIP) return hip_fail(he, "layernorm_q + w8a8 launch");
+    if (rc != TCE_OK) return fail(rc, "tce_layernorm_q_w8a8_group: the rows do not fit the CU's LDS (m * k too large)");
+    return TCE_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Plans: a fixed sequence of W4A16 launches (one decode token's linears) captured into a hipGraph.
 // ---------------------------------------------------------------------------------------------

@@ -173,6 +173,51 @@ __device__ __forceinline__ float rmsnorm_rs_block(const half_t *x, int n, float 
     return rmsnorm_rs_block([&](int p) { return *reinterpret_cast<const half8_t *>(x + p * 8); }, n, eps, wave, nwaves, lane, part);
 }
 
+// Sequential fp32 sum  acc = (((x[0] + x[1]) + x[2]) + ...)  over n values that sit in LDS, in exactly that order --
+// what a scalar host loop `for (k) acc += x[k]` computes (LayerNormQ.cc:27-30) -- at about one dependent v_add per element instead
+// of one LDS round trip per few elements: lanes 0..15 of the wave each fetch one value of a 16-value group (a pipelined
+// ds_read_b32, off the critical path) and lane 0 adds them in order through DPP row shifts (row_shl:j = "read lane i + j"), so
+// the only dependence chain is the accumulator's.  `f` maps a value before it is added (identity, or the squared deviation,
+// computed by the lane that fetched it).  The total is valid in lane 0 (and broadcast by the caller).  All 64 lanes must call.
+template <typename F>
+__device__ __forceinline__ float sequential_sum_lane0(const float *lds_x, int n, int lane, F &&f) {
+    float acc = 0.f;
+    const int l16 = lane & 15;
+    const int n16 = n & ~15;
+    float nxt = n16 ? f(lds_x[l16]) : 0.f;
+    for (int base = 0; base < n16; base += 16) {
+        const float cur = nxt;
+        const int nb = base + 16 < n16 ? base + 16 : base;
+        nxt = f(lds_x[nb + l16]);  // next group's value: in flight while this group is added
+        // One statement, sixteen dependent adds: acc + cur(lane 0), + cur(lane 1), ...  Written as asm because hipcc pads every
+        // DPP instruction that reads a just-written register with s_nop 1 -- the hazard (VALU write -> DPP read: 2 wait states)
+        // concerns the DPP-shifted operand (src0 = cur, written a whole group ago; the s_nop 1 in front covers a late `f`), not
+        // the plain second operand acc -- which doubles the length of the only dependence chain of this kernel.
+        asm volatile(
+            "s_nop 1\n\t"
+            "v_add_f32 %0, %1, %0\n\t"
+            "v_add_f32_dpp %0, %1, %0 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_add_f32_dpp %0, %1, %0 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_add_f32_dpp %0, %1, %0 row_shl:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_add_f32_dpp %0, %1, %0 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_add_f32_dpp %0, %1, %0 row_shl:5 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_add_f32_dpp %0, %1, %0 row_shl:6 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_add_f32_dpp %0, %1, %0 row_shl:7 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_add_f32_dpp %0, %1, %0 row_shl:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_add_f32_dpp %0, %1, %0 row_shl:9 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_add_f32_dpp %0, %1, %0 row_shl:10 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_add_f32_dpp %0, %1, %0 row_shl:11 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_add_f32_dpp %0, %1, %0 row_shl:12 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_add_f32_dpp %0, %1, %0 row_shl:13 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_add_f32_dpp %0, %1, %0 row_shl:14 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_add_f32_dpp %0, %1, %0 row_shl:15 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+            : "+v"(acc)
+            : "v"(cur));
+    }
+    for (int k = n16; k < n; ++k) acc = acc + f(lds_x[k]);  // n % 16 values at the end: plain (every lane, same values)
+    return acc;
+}
+
 // non-temporal 16-byte load: streamed weights are read exactly once by exactly one CU
 __device__ __forceinline__ uint4_t load_nt(const uint4_t *p) { return __builtin_nontemporal_load(p); }
 

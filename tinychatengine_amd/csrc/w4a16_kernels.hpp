@@ -119,11 +119,18 @@ int launch_w4a16_skinny(const tce_w4a16_desc &d, hipStream_t stream, hipError_t 
 
 // element-wise glue of the decoder layer (glue.hip)
 int launch_layernorm_q(const float *x, const float *w, const float *b, void *out, int m, int n, hipStream_t stream, hipError_t *hip_err);
+// w8a8_lnq_fused.hip
+int launch_lnq_w8a8_group(const float *x, const float *ln_w, const float *ln_b, int m, int k, const tce_w8a8_desc *lin, int count, void *ln_out,
+                          hipStream_t stream, hipError_t *hip_err);
 int launch_rmsnorm_half(const void *x, const float *gamma, void *out, int m, int n, float eps, hipStream_t stream, hipError_t *hip_err);
 // attention_ops.hip
 int launch_bmm_f16t(const void *A, const void *B, void *C, int batch, int M, int N, int K, unsigned short alpha_bits, hipStream_t stream, hipError_t *hip_err);
 int launch_attention_decode(const void *q, const void *K, const void *Vt, const void *mask, void *out, int heads, int t, int hd, unsigned short alpha_bits,
                             hipStream_t stream, hipError_t *hip_err);
+// attention_fast.hip
+size_t attention_decode_workspace_bytes(int heads, int max_keys, int hd);
+int launch_attention_decode_fast(const void *qkv, void *kc, void *vc, const void *cosv, const void *sinv, const void *mask, void *out, void *workspace,
+                                 int heads, int hd, int max_keys, int pos, unsigned short alpha_bits, hipStream_t stream, hipError_t *hip_err);
 int launch_rope_half(void *q, void *k, const void *cosv, const void *sinv, int heads, int len, int hd, int start_idx, hipStream_t stream, hipError_t *hip_err);
 int launch_softmax_half(const void *x, void *out, long long rows, int n, hipStream_t stream, hipError_t *hip_err);
 int launch_prefetch(const void *ptr, long long bytes, int workgroups, hipStream_t stream, hipError_t *hip_err);

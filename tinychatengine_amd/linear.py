@@ -185,6 +185,30 @@ class W8A8B8O8Linear:
     __call__ = forward
 
 
+def layernorm_q_linears(x: torch.Tensor, ln_weight: torch.Tensor, ln_bias: torch.Tensor, linears: list, ln_out: torch.Tensor | None = None) -> list[torch.Tensor]:
+    """LayerNormQ::forward (llm/src/ops/LayerNormQ.cc:12-52) and the W8A8 linears that read its output -- q_proj / k_proj / v_proj
+    (Int8OPTAttention.cc:186-201) or fc1 -- as ONE launch for decode (x fp32 [m][k], m <= 8).  `linears`: W8A8B8O8Linear /
+    W8A8BFP32OFP32Linear objects.  Bit-exact against the separate launches."""
+    import ctypes as C
+    k = x.shape[-1]
+    m = x.numel() // k
+    descs, outs = [], []
+    for lin in linears:
+        n = lin.weight.shape[0]
+        fp32 = isinstance(lin, W8A8BFP32OFP32Linear)
+        out = torch.empty((m, n), dtype=torch.float32 if fp32 else torch.int8, device=x.device)
+        outs.append(out)
+        descs.append(capi.W8A8Desc(M=m, N=n, K=k, batch=1, A=None, B=_ptr(lin.weight), bias=_ptr(lin.bias), C=_ptr(out), strideA=0, strideB=0, strideC=0,
+                                   alpha=lin.alpha, beta=0.0 if fp32 else lin.beta, q_min=-128 if fp32 else lin.q_min, q_max=127,
+                                   bias_kind=capi.TCE_BIAS_FP32 if fp32 else capi.TCE_BIAS_INT8, out_kind=capi.TCE_OUT_FP32 if fp32 else capi.TCE_OUT_INT8,
+                                   b_per_row=0))
+    arr = (capi.W8A8Desc * len(descs))(*descs)
+    if x.dtype != torch.float32 or ln_weight.dtype != torch.float32 or ln_bias.dtype != torch.float32:
+        raise ValueError("layernorm_q_linears: x, weight, bias are fp32")
+    capi.check(capi.lib().tce_layernorm_q_w8a8_group(_ptr(x), _ptr(ln_weight), _ptr(ln_bias), m, k, arr, len(descs), _ptr(ln_out), C.c_void_p(_stream() or 0)))
+    return outs
+
+
 class W8A8BFP32OFP32Linear:
     """int8 -> fp32 linear with fp32 bias (llm/src/ops/W8A8BFP32OFP32Linear.cc:12-73)."""
 
