@@ -38,6 +38,8 @@ def parse_args():
     ap.add_argument("--layers", type=int, default=None, help="override the number of transformer blocks (debug only)")
     ap.add_argument("--ungrouped", action="store_true", help="one launch per linear, as the reference issues them")
     ap.add_argument("--gathers-per-block", type=int, default=1, choices=[1, 4])
+    ap.add_argument("--gather", default="peer", choices=["peer", "rccl"],
+                    help="N > 1: how the ranks' output slices are joined -- peer: tce_allgather_f16 (one peer-write kernel per exchange over xGMI, csrc/comm.hip); rccl: torch.distributed all_gather_into_tensor")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true", help="run only the dominant-kernel loop (for rocprofv3)")
     ap.add_argument("--roofline-launches", type=int, default=256)
@@ -81,10 +83,9 @@ def other_configs_leg(torch, dev):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e3 / (reps * launches)
 
-    out = {"w4a16_prefill_gemm_M512": [], "w8a8_opt125m": []}
+    out = {"w4a16_prefill_gemm_M512": [], "w4a16_prefill_gemm_M2048": [], "w8a8_opt125m": []}
     gen = torch.Generator(device=dev).manual_seed(1)
     for (N, K) in ((4096, 4096), (11008, 4096), (4096, 11008)):
-        M = 512
         nsets = max(2, int(3e8 // (N * K // 2)))  # > 256 MiB of distinct weights: they come from HBM
         zw = (K // 128 + 7) // 8
         sets = []
@@ -93,14 +94,34 @@ def other_configs_leg(torch, dev):
             sc = (torch.rand((N, zw * 8), device=dev, generator=gen) * 0.01 + 0.001).to(torch.float16)
             zp = torch.full((N, zw), -2004318072, dtype=torch.int32, device=dev)  # 0x88888888
             sets.append((qw, sc, zp))
-        x = torch.randn(M, K, device=dev, generator=gen).to(torch.float16)
-        y = torch.empty(M, N, dtype=torch.float16, device=dev)
-        ds = [capi.W4A16Desc(M=M, N=N, K=K, group_size=128, A=x.data_ptr(), qweight=q.data_ptr(), scales=s_.data_ptr(), zeros=z.data_ptr(), C=y.data_ptr())
-              for (q, s_, z) in sets]
-        us = time_graph(lambda i, sp: capi.check(L.tce_w4a16_forward(C.byref(ds[i % len(ds)]), sp)), 16)
-        tf = 2.0 * M * N * K / us / 1e6
-        out["w4a16_prefill_gemm_M512"].append({"N": N, "K": K, "us": round(us, 1), "TFLOPs": round(tf, 1), "frac_of_2500_TFLOPs": round(tf / 2500.0, 3)})
-        del sets, ds
+        # the q4_mfma copies (tce_w4a16_prepack: load-time, once per tensor) that let tce_w4a16_forward choose the 128-row MFMA kernel
+        need = int(L.tce_w4a16_prepack_bytes(N, K, 128))
+        packs = []
+        for (q, s_, z) in sets:
+            pk = torch.empty(need, dtype=torch.uint8, device=dev)
+            d = capi.W4A16Desc(M=1, N=N, K=K, group_size=128, qweight=q.data_ptr(), scales=s_.data_ptr(), zeros=z.data_ptr())
+            capi.check(L.tce_w4a16_prepack(C.byref(d), pk.data_ptr(), None))
+            packs.append(pk)
+        torch.cuda.synchronize()
+        for M in (512, 2048):
+            x = torch.randn(M, K, device=dev, generator=gen).to(torch.float16)
+            y = torch.empty(M, N, dtype=torch.float16, device=dev)
+            row = {"M": M, "N": N, "K": K}
+            for name, with_pack in (("q4_6_only", False), ("prepacked", True)):
+                ds = [capi.W4A16Desc(M=M, N=N, K=K, group_size=128, A=x.data_ptr(), qweight=q.data_ptr(), scales=s_.data_ptr(), zeros=z.data_ptr(), C=y.data_ptr(),
+                                     prepacked=pk.data_ptr() if with_pack else None)
+                      for (q, s_, z), pk in zip(sets, packs)]
+                us = time_graph(lambda i, sp: capi.check(L.tce_w4a16_forward(C.byref(ds[i % len(ds)]), sp)), 16)
+                buf = C.create_string_buffer(256)
+                L.tce_w4a16_describe_dispatch(C.byref(ds[0]), buf, 256)
+                row[name] = {"us": round(us, 1), "TFLOPs": round(2.0 * M * N * K / us / 1e6, 1), "dispatch": buf.value.decode()}
+            best = max(row["q4_6_only"]["TFLOPs"], row["prepacked"]["TFLOPs"])
+            row["TFLOPs"] = row["prepacked"]["TFLOPs"]  # what a caller that prepacked at load time gets
+            row["frac_of_2500_TFLOPs"] = round(row["TFLOPs"] / 2500.0, 3)
+            row["best_of_both_TFLOPs"] = best
+            out["w4a16_prefill_gemm_M512" if M == 512 else "w4a16_prefill_gemm_M2048"].append(row)
+        del packs
+        del sets
     for (M, N, K) in ((512, 768, 768), (512, 3072, 768), (512, 768, 3072), (1, 768, 768)):
         a = torch.randint(-128, 128, (M, K), dtype=torch.int8, device=dev)
         b = torch.randint(-128, 128, (N, K), dtype=torch.int8, device=dev)
@@ -115,15 +136,19 @@ def other_configs_leg(torch, dev):
 
 
 # ----------------------------------------------------------------------------------------------------------------
-def roofline_leg(dl, torch, launches: int, eager: bool = False):
+def roofline_leg(dl, torch, launches: int, eager: bool = False, which: int = 2, quick: bool = False):
     """The dominant kernel in isolation: the grouped gate+up GEMV launch (2*ffn rows x hidden), `launches` back-to-back
     launches on one stream, rotating over the layers' distinct weights (ring >> Infinity Cache), HIP events on that
     stream around the whole sequence.  achieved = algorithmic bytes per launch / average launch duration."""
     from tinychatengine_amd import capi
     st = torch.cuda.current_stream().cuda_stream
-    groups = [dl.block_launches(li)[2] for li in range(dl.n_layers)]
+    groups = [dl.block_launches(li)[which] for li in range(dl.n_layers)]
     d0 = groups[0]
-    bytes_per_launch = sum(capi.algorithmic_bytes(dl.m, d.N, d.K, d.group_size) for d in d0)
+    formula_bytes = sum(capi.algorithmic_bytes(dl.m, d.N, d.K, d.group_size) for d in d0)
+    # SURVEY 8d's formula counts the packed zero points (N*K/(2G) bytes); with TCE_W4_ZERO_POINT_IS_8 (what the reference quantizer
+    # always writes) the kernel never reads them, so they do not belong in the numerator of ITS bandwidth (VERDICT r1)
+    zeros_bytes = sum(d.N * d.K // (2 * d.group_size) for d in d0 if d.flags & capi.TCE_W4_ZERO_POINT_IS_8)
+    bytes_per_launch = formula_bytes - zeros_bytes
     arrs = [(capi.W4A16Desc * len(g))(*g) for g in groups]
     L = capi.lib()
     import ctypes as C
@@ -161,6 +186,9 @@ def roofline_leg(dl, torch, launches: int, eager: bool = False):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / (reps * launches)
     gbs = bytes_per_launch / us / 1e3
+    if quick:  # the per-shape table: rate only
+        return {"launch": "+".join(str(d.N) for d in d0) + f" x {d0[0].K}", "us": round(us, 2), "GBs": round(gbs, 1), "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 3),
+                "bytes": bytes_per_launch}
     # spread: the same graph replayed 15 more times, each replay timed on its own (median and p10 / p90)
     per = []
     for _ in range(15):
@@ -188,11 +216,51 @@ def roofline_leg(dl, torch, launches: int, eager: bool = False):
         "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
         **_pmc_traffic(bytes_per_launch),
         "kernel": f"w4a16_gemv_kernel (grouped gate+up launch, N={'+'.join(str(d.N) for d in d0)}, K={d0[0].K}, M={dl.m})",
-        "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": round(us, 3), "launches_timed": reps * launches,
+        "algorithmic_bytes_per_launch": bytes_per_launch, "survey_8d_formula_bytes_per_launch": formula_bytes,
+        "bytes_note": "formula of SURVEY 8d minus the packed zero points the zero-point-8 kernel never reads" if zeros_bytes else "formula of SURVEY 8d",
+        "avg_launch_us": round(us, 3), "launches_timed": reps * launches,
         "launch_us_p10_p50_p90": [round(per[1], 3), round(per[len(per) // 2], 3), round(per[-2], 3)],
         "measured_streaming_read_GBs": ceiling, "frac_of_measured_streaming_read": (round(gbs / ceiling, 4) if ceiling else None),
         "timing": "HIP events on the launch stream around graph-replayed back-to-back launches rotating over all layers' weights (includes inter-kernel gaps)",
     }
+
+
+def launch_shape_table(dl, torch, launches: int = 128):
+    """us / GB/s / fraction of 8 TB/s of every launch shape of the token.  The four per-block launches are timed
+    like the roofline leg (rotating over the layers' weights).  lm_head is ONE tensor (65-260 MB) that a back-to-back loop would serve
+    from the 256 MB Infinity Cache, so each lm_head launch is followed by three gate+up launches of rotating layers (>= 270 MB of other
+    weights) and their separately measured time is subtracted."""
+    from tinychatengine_amd import capi
+    import ctypes as C
+    rows = [roofline_leg(dl, torch, launches, which=w, quick=True) for w in range(4)]
+    L = capi.lib()
+    gu = [dl.block_launches(li)[2] for li in range(dl.n_layers)]
+    arrs = [(capi.W4A16Desc * len(g))(*g) for g in gu]
+    d = dl.lm_head.desc(dl.x, dl.logits)
+    lm = (capi.W4A16Desc * 1)(d)
+    n = 24
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        sp = C.c_void_p(s.cuda_stream)
+        with torch.cuda.graph(g, stream=s):
+            for i in range(n):
+                capi.check(L.tce_w4a16_forward_group(lm, 1, sp))
+                for j in range(3):
+                    capi.check(L.tce_w4a16_forward_group(arrs[(3 * i + j) % len(arrs)], len(gu[0]), sp))
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (5 * n) - 3 * rows[2]["us"]
+    b = capi.algorithmic_bytes(dl.m, d.N, d.K, d.group_size) - (d.N * d.K // (2 * d.group_size) if d.flags & capi.TCE_W4_ZERO_POINT_IS_8 else 0)
+    rows.append({"launch": f"{d.N} x {d.K} (lm_head)", "us": round(us, 2), "GBs": round(b / us / 1e3, 1), "frac_of_8TBs": round(b / us / 1e3 / HBM_PEAK_GBS, 3),
+                 "bytes": b, "timing": "interleaved with 3 gate+up launches (cache flush), their time subtracted"})
+    return rows
 
 
 def _pmc_traffic(bytes_per_launch):
@@ -207,7 +275,7 @@ def _pmc_traffic(bytes_per_launch):
             t = json.load(open(f))
         except Exception:  # noqa: BLE001
             continue
-        if t.get("algorithmic_bytes_per_launch") == bytes_per_launch:
+        if t.get("algorithmic_bytes_per_launch") in (bytes_per_launch, bytes_per_launch + 352256):  # (older files carry the formula incl. zeros)
             best = (t, f)
     if not best:
         return {"traffic": None}
@@ -338,6 +406,12 @@ def main():
     if args.force_dist:
         os.environ["TCE_FORCE_GATHER_BUFFERS"] = "1"
     dl = DecodeLinears(shape, device=dev, group_size=G, rank=rank, world=world, m=1, layers=args.layers)
+    if dist is not None and args.gather == "peer":
+        def exchange(handle: bytes):
+            got = [None] * world
+            dist.all_gather_object(got, handle)
+            return got
+        dl.attach_peer_comm(exchange)
     torch.cuda.synchronize()
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -357,16 +431,16 @@ def main():
         n_launches = dl.n_layers * 4 + 1
         graph = None
         try:  # capture GEMVs + RCCL all-gathers of one token into one graph; fall back to eager issue if capture fails
-            if args.no_graph or args.backend != "nccl":
+            if args.no_graph or (args.backend != "nccl" and args.gather != "peer"):
                 raise RuntimeError("graph capture not requested / not available with this backend")
             for _ in range(3):
-                dl.run_token_distributed(args.gathers_per_block)
+                dl.run_token_distributed(args.gathers_per_block, gather=args.gather)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):  # the RCCL watchdog thread may call HIP APIs meanwhile
-                dl.run_token_distributed(args.gathers_per_block)
+                dl.run_token_distributed(args.gathers_per_block, gather=args.gather)
             step = graph.replay
-            mode = "one graph replay per token (GEMVs + RCCL all-gathers captured)"
+            mode = f"one graph replay per token (GEMVs + {'peer-write' if args.gather == 'peer' else 'RCCL'} all-gathers captured)"
         except Exception as e:  # noqa: BLE001
             if rank == 0:
                 print(f"[bench] graph capture of the distributed token failed ({type(e).__name__}: {e}); issuing eagerly", file=sys.stderr)
@@ -377,7 +451,7 @@ def main():
             torch.cuda.set_stream(torch.cuda.default_stream())
             capi.lib().tce_reset_last_error()
             torch.cuda.synchronize()
-            step = lambda: dl.run_token_distributed(args.gathers_per_block)
+            step = lambda: dl.run_token_distributed(args.gathers_per_block, gather=args.gather)
             mode = "eager issue per token"
 
 
@@ -429,6 +503,31 @@ def main():
             extras = other_configs_leg(torch, dev)
         except Exception as e:  # noqa: BLE001 -- never takes the headline number down with it
             extras = {"error": f"{type(e).__name__}: {e}"}
+        try:  # every launch shape of the token on its own: us, GB/s, fraction of 8 TB/s (same timing method as the roofline leg)
+            extras["decode_launch_shapes"] = launch_shape_table(dl, torch)
+        except Exception as e:  # noqa: BLE001
+            extras["decode_launch_shapes"] = {"error": f"{type(e).__name__}: {e}"}
+        if args.workload == "baseline-named":
+            try:  # BASELINE.json says "Llama-3-8B" but spells Llama-2-7B widths: the true Llama-3-8B shape set beside it
+                dl3 = DecodeLinears(SHAPES["llama3-8b"], device=dev, group_size=G, m=1)
+                plan3 = dl3.make_plan()
+                for _ in range(5):
+                    plan3.launch(stream)
+                torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(30):
+                    plan3.launch(stream)
+                b.record()
+                torch.cuda.synchronize()
+                ms3 = a.elapsed_time(b) / 30
+                extras["decode_llama3_8b_true_shapes"] = {
+                    "tokens_per_s": round(1e3 / ms3, 1), "ms_per_token": round(ms3, 4), "algorithmic_bytes_per_token": dl3.token_bytes(),
+                    "frac_of_8TBs": round(dl3.token_bytes() / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "launch_shapes": launch_shape_table(dl3, torch, 96)}
+                del dl3, plan3
+            except Exception as e:  # noqa: BLE001
+                extras["decode_llama3_8b_true_shapes"] = {"error": f"{type(e).__name__}: {e}"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -444,7 +543,9 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "int4 weights x fp16 activations, fp32 accumulate", "data": "synthetic",
             "config": {"workload": f"W4A16 decode GEMV M=1, {shape.name}: {dl.n_layers} blocks x [qkv {list(shape.qkv)}, o {shape.hidden}, gate/up {shape.ffn}, down] + lm_head {shape.vocab}, group 128",
-                       "parallelism": f"tp{world} column-sharded, {args.gathers_per_block} {'RCCL' if args.backend == 'nccl' else args.backend} all-gather(s) per block" if world > 1 else "single GPU",
+                       "parallelism": (f"tp{world} column-sharded, {args.gathers_per_block} "
+                                       + ("peer-write all-gather(s) (tce_allgather_f16)" if args.gather == "peer" else f"{'RCCL' if args.backend == 'nccl' else args.backend} all-gather(s)")
+                                       + " per block") if world > 1 else "single GPU",
                        "issue": mode, "grouped_launches": not args.ungrouped,
                        "algorithmic_bytes_per_token": token_bytes_full},
             "whole_token": whole,

@@ -272,6 +272,33 @@ TCE_API int tce_plan_launch(tce_plan *plan, void *stream);
 TCE_API int tce_plan_n_launches(const tce_plan *plan);
 TCE_API void tce_plan_destroy(tce_plan *plan);
 
+/* ---- multi-GPU: column shards + peer-write all-gather (no reference counterpart, the reference is single-device) ----
+ * One process per GPU.  Every linear is sharded by OUTPUT ROWS: rank r of P computes rows [r*N/P, (r+1)*N/P) from the replicated
+ * activation; tce_w4a16_shard fills the shard's descriptor (in q4_6 a row range is one contiguous byte range of qweight, scales and
+ * zeros; N % P == 0 and (N / P) % 16 == 0, the reference wrapper's own divisibility rule, linear.cu:16-17); A, C, M, flags and the
+ * strides are copied, C must then be pointed at the rank's slice buffer [M][N/P].
+ * The slices are joined by tce_allgather_f16: at decode sizes (1-4 KB per rank) a latency-bound exchange, done as ONE small kernel
+ * per call that writes the slice into every rank's window over xGMI, publishes an epoch flag, waits for the other ranks' flags
+ * and copies the complete vector to `dst_full` (csrc/comm.hip).  The call is asynchronous, stream-ordered and capturable into a
+ * hipGraph (epochs are counted on the device).  Every rank must issue the same sequence of calls per slot.
+ *   tce_comm_create   rank's window for vectors of up to max_vector_elems halves, `slots` independent exchange slots
+ *   tce_comm_export / tce_comm_connect   the host all-gathers the 64-byte handles (MPI, torch.distributed, a file ...) and hands every
+ *                     rank the table [world][64]; tce_comm_connect_local instead when all ranks live in one process (tests)
+ *   tce_comm_status   synchronous: 1 if a wait ever timed out (~50 ms: a rank never arrived), 0 if not, negative on error
+ * Prefill (M >= 17) moves megabytes per exchange: use RCCL there (ncclAllGather; this repository's host code does, through
+ * torch.distributed) -- the peer-write kernel is a single workgroup. */
+typedef struct tce_comm tce_comm;
+#define TCE_COMM_HANDLE_BYTES 64
+#define TCE_COMM_MAX_RANKS 8
+TCE_API int tce_w4a16_shard(const tce_w4a16_desc *full, int rank, int world, tce_w4a16_desc *shard);
+TCE_API int tce_comm_create(int rank, int world, int max_vector_elems, int slots, tce_comm **out);
+TCE_API int tce_comm_export(tce_comm *comm, void *handle_out /* 64 bytes */);
+TCE_API int tce_comm_connect(tce_comm *comm, const void *handles /* [world][64], rank order */);
+TCE_API int tce_comm_connect_local(tce_comm *comm, tce_comm *const *all_ranks /* [world] */);
+TCE_API int tce_allgather_f16(tce_comm *comm, int slot, const void *src_slice, void *dst_full, int n_total, void *stream);
+TCE_API int tce_comm_status(tce_comm *comm);
+TCE_API void tce_comm_destroy(tce_comm *comm);
+
 /* ---- memory / sync helpers: what the L2 wrappers need from the runtime ----
  * tce_malloc(managed=1) / tce_free replace allocate_aligned_memory_gpu / free_aligned_memory_gpu
  * (llm/src/nn_modules/cuda/utils.cu:92-103, cudaMallocManaged there: model files are read straight into that memory,

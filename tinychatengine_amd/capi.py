@@ -28,7 +28,7 @@ TCE_OUT_INT8, TCE_OUT_FP32 = 0, 1
 # every symbol include/tce_matmul.h declares (tests/test_boundary.py checks the .so exports exactly these)
 EXPORTS = [
     "tce_w4a16_forward", "tce_w4a16_prepack_bytes", "tce_w4a16_prepack", "tce_w4a16_describe_dispatch", "tce_reset_last_error", "tce_bmm_f16t", "tce_rope_half", "tce_softmax_half", "tce_attention_decode_f16", "tce_attention_decode_workspace_bytes", "tce_attention_decode_step_f16", "tce_prefetch", "tce_add_half", "tce_silu_mul_half", "tce_rmsnorm_half", "tce_w4a16_forward_group_rmsnorm", "tce_w4a16_forward_group", "tce_w4a16_check_zero_point_8", "tce_w4a16_awq_fp16acc", "tce_w4a16_awq_workspace_bytes",
-    "tce_w4a16_gemm_awq", "tce_w8a8_matmul", "tce_layernorm_q", "tce_layernorm_q_w8a8_group", "tce_plan_create", "tce_plan_create_ex", "tce_plan_is_chained", "tce_plan_geometry", "tce_plan_status", "tce_plan_launch", "tce_plan_n_launches",
+    "tce_w4a16_gemm_awq", "tce_w4a16_shard", "tce_comm_create", "tce_comm_export", "tce_comm_connect", "tce_comm_connect_local", "tce_allgather_f16", "tce_comm_status", "tce_comm_destroy", "tce_w8a8_matmul", "tce_layernorm_q", "tce_layernorm_q_w8a8_group", "tce_plan_create", "tce_plan_create_ex", "tce_plan_is_chained", "tce_plan_geometry", "tce_plan_status", "tce_plan_launch", "tce_plan_n_launches",
     "tce_plan_destroy", "tce_version", "tce_last_error", "tce_build_info", "tce_w4a16_set_gemv_config",
     "tce_w4a16_set_gemm_config", "tce_w4a16_algorithmic_bytes", "tce_w4a16_gemv_variant", "tce_w4a16_gemm_variant",
     "tce_w4a16_set_debug_mode", "tce_w4a16_set_debug_buffer", "tce_malloc", "tce_free", "tce_memcpy", "tce_synchronize", "tce_device_count",
@@ -103,6 +103,15 @@ def lib() -> C.CDLL:
         L.tce_w4a16_awq_workspace_bytes.restype = C.c_size_t
         L.tce_w4a16_gemm_awq.argtypes = [C.c_int] * 4 + [C.c_void_p] * 5 + [C.c_int, C.c_void_p]
         L.tce_w8a8_matmul.argtypes = [C.POINTER(W8A8Desc), C.c_void_p]
+        L.tce_w4a16_shard.argtypes = [C.POINTER(W4A16Desc), C.c_int, C.c_int, C.POINTER(W4A16Desc)]
+        L.tce_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.tce_comm_export.argtypes = [C.c_void_p, C.c_void_p]
+        L.tce_comm_connect.argtypes = [C.c_void_p, C.c_void_p]
+        L.tce_comm_connect_local.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.tce_allgather_f16.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.tce_comm_status.argtypes = [C.c_void_p]
+        L.tce_comm_destroy.argtypes = [C.c_void_p]
+        L.tce_comm_destroy.restype = None
         L.tce_layernorm_q.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.tce_layernorm_q_w8a8_group.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(W8A8Desc), C.c_int, C.c_void_p, C.c_void_p]
         L.tce_plan_create.argtypes = [C.POINTER(W4A16Desc), C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_void_p)]
@@ -218,3 +227,39 @@ class Plan:
             self.close()
         except Exception:
             pass
+
+
+class Comm:
+    """tce_comm: this rank's peer-write window + the mapped windows of the other ranks (include/tce_matmul.h, csrc/comm.hip)."""
+
+    def __init__(self, rank: int, world: int, max_vector_elems: int, slots: int = 4):
+        self.rank, self.world = rank, world
+        h = C.c_void_p()
+        check(lib().tce_comm_create(rank, world, max_vector_elems, slots, C.byref(h)))
+        self.handle = h
+
+    def export(self) -> bytes:
+        buf = C.create_string_buffer(64)
+        check(lib().tce_comm_export(self.handle, buf))
+        return buf.raw
+
+    def connect(self, handles: list[bytes]) -> None:
+        table = C.create_string_buffer(b"".join(handles), 64 * self.world)
+        check(lib().tce_comm_connect(self.handle, table))
+
+    @staticmethod
+    def connect_local(comms: list["Comm"]) -> None:
+        arr = (C.c_void_p * len(comms))(*[c.handle for c in comms])
+        for c in comms:
+            check(lib().tce_comm_connect_local(c.handle, arr))
+
+    def allgather(self, slot: int, src_ptr: int, dst_ptr: int, n_total: int, stream: int | None) -> None:
+        check(lib().tce_allgather_f16(self.handle, slot, C.c_void_p(src_ptr), C.c_void_p(dst_ptr), n_total, C.c_void_p(stream or 0)))
+
+    def status(self) -> int:
+        return int(lib().tce_comm_status(self.handle))
+
+    def close(self) -> None:
+        if self.handle:
+            lib().tce_comm_destroy(self.handle)
+            self.handle = None

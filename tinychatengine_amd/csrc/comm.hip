@@ -1,0 +1,230 @@
+// comm.hip -- the multi-GPU side of the path behind the C ABI (no reference counterpart: TinyChatEngine is
+// single-device).  Every linear is sharded by output rows (tce_w4a16_shard: a contiguous byte range of the three q4_6 arrays),
+// activations are replicated, and the ranks' fp16 output slices are joined by an ALL-GATHER.  At decode (M = 1) a slice is
+// 1-4 KB: the exchange is pure latency, and a library collective costs O(10 us) per call against ~3 us of HBM time per block at
+// 8 ranks.  So the gather here is a PEER WRITE over xGMI, one small kernel per exchange, capturable in the token's hipGraph:
+//
+//   window    per rank, fine-grained device memory, exported with hipIpcGetMemHandle and mapped by every peer
+//             (one process per GPU), or handed over directly when several ranks live in one process (tests):
+//             [slots][2 parities][vector bytes] data + [slots][2][8] arrival flags
+//   exchange  the kernel of rank r (a) writes its slice into EVERY rank's window -- buffer (slot, parity of the slot's epoch) at
+//             the slice's offset -- with 16-byte stores straight into peer memory, (b) after a system-scope release writes the
+//             epoch into flag (slot, parity, r) of every window, (c) waits until its own window shows all ranks' flags at this
+//             epoch (bounded: a rank that never arrives sets the status word after ~50 ms instead of hanging the queue),
+//             (d) copies the complete vector from the window to an ordinary device buffer -- the next linear's activation.
+//             Epochs are counted on the device (one word per slot), so the same captured kernel node is correct on every
+//             replay; two buffers per slot are enough: a rank can start exchange e+1 (and write into peers' buffers of parity
+//             e+1) while a peer still reads the vector of exchange e, but exchange e+2 cannot start before every rank has sent
+//             its flags of e+1, i.e. has finished with e.
+// M >= 17 (prefill) moves megabytes per exchange: that regime belongs to RCCL (ncclAllGather through torch.distributed in this
+// repository's host code, tinychatengine_amd/decode.py); nothing here replaces it.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+
+#include "tce_common.hpp"
+#include "w4a16_kernels.hpp"
+
+namespace tce {
+
+constexpr int kMaxRanks = 8;
+constexpr int kFlagStride = 16;  // words between flags (their own 64-byte lines)
+
+struct Comm {
+    int rank = 0, world = 1, slots = 0;
+    size_t vec_bytes = 0, window_bytes = 0;
+    unsigned char *window = nullptr;     // this rank's window
+    unsigned char *peer[kMaxRanks] = {};  // every rank's window as mapped here (peer[rank] == window)
+    bool ipc_opened[kMaxRanks] = {};
+    unsigned *epochs = nullptr;          // [slots] exchanges completed per slot, + [1] status
+    bool finegrained = false;
+};
+
+namespace {
+
+size_t data_bytes(const Comm &c) { return (size_t)c.slots * 2 * c.vec_bytes; }
+size_t flags_bytes(const Comm &c) { return (size_t)c.slots * 2 * kMaxRanks * kFlagStride * 4; }
+
+struct GatherArgs {
+    unsigned char *peer[kMaxRanks];
+    unsigned *epochs;  // [slots] + status at [slots]
+    const uint4_t *src;
+    uint4_t *dst;
+    int rank, world, slot, slots;
+    unsigned slice16;      // 16-byte pieces per rank's slice
+    size_t vec_bytes, flags_off;
+};
+
+__global__ __launch_bounds__(1024) void allgather_peer_kernel(const GatherArgs a) {
+    const int tid = threadIdx.x;
+    const unsigned e = a.epochs[a.slot] + 1u;  // this exchange's epoch (same on every rank: they all run the same sequence)
+    const unsigned par = e & 1u;
+    const size_t buf_off = ((size_t)a.slot * 2 + par) * a.vec_bytes;
+    // (a) my slice into every window
+    for (int p = 0; p < a.world; ++p) {
+        uint4_t *dstp = reinterpret_cast<uint4_t *>(a.peer[p] + buf_off) + (size_t)a.rank * a.slice16;
+        for (unsigned i = tid; i < a.slice16; i += 1024) dstp[i] = a.src[i];
+    }
+    // (b) release at system scope, then the flags
+    __threadfence_system();
+    __syncthreads();
+    if (tid < a.world) {
+        unsigned *flag = reinterpret_cast<unsigned *>(a.peer[tid] + a.flags_off) + (((size_t)a.slot * 2 + par) * kMaxRanks + a.rank) * kFlagStride;
+        __hip_atomic_store(flag, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // (c) every rank's flag in MY window
+    if (tid < a.world) {
+        const unsigned *flag = reinterpret_cast<const unsigned *>(a.peer[a.rank] + a.flags_off) + (((size_t)a.slot * 2 + par) * kMaxRanks + tid) * kFlagStride;
+        const unsigned long long t0 = wall_clock64();  // 100 MHz
+        while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > 5000000ull) {  // ~50 ms: give up, flag the communicator (tce_comm_status)
+                __hip_atomic_store(a.epochs + a.slots, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    __threadfence_system();  // acquire: the peers' data behind their flags
+    // (d) the complete vector to the consumer's buffer
+    const uint4_t *full = reinterpret_cast<const uint4_t *>(a.peer[a.rank] + buf_off);
+    const unsigned total16 = a.slice16 * (unsigned)a.world;
+    for (unsigned i = tid; i < total16; i += 1024) {
+        uint4_t v;
+        const unsigned *w = reinterpret_cast<const unsigned *>(full + i);
+        v.x = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        v.y = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        v.z = __hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        v.w = __hip_atomic_load(w + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        a.dst[i] = v;
+    }
+    __syncthreads();
+    if (tid == 0) a.epochs[a.slot] = e;
+}
+
+}  // namespace
+
+int comm_create(int rank, int world, int max_vector_elems, int slots, Comm **out, hipError_t *he) {
+    if (world < 1 || world > kMaxRanks || rank < 0 || rank >= world || max_vector_elems <= 0 || slots < 1) return TCE_ERR_BAD_ARG;
+    Comm *c = new (std::nothrow) Comm();
+    if (!c) return TCE_ERR_BAD_ARG;
+    c->rank = rank;
+    c->world = world;
+    c->slots = slots;
+    c->vec_bytes = (((size_t)max_vector_elems * 2) + 255) & ~(size_t)255;
+    c->window_bytes = data_bytes(*c) + flags_bytes(*c);
+    void *p = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&p, c->window_bytes, hipDeviceMallocFinegrained);
+    c->finegrained = e == hipSuccess;
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        e = hipMalloc(&p, c->window_bytes);  // single-device setups (tests): coherence within the device is all that is needed
+    }
+    if (e == hipSuccess) e = hipMemset(p, 0, c->window_bytes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->epochs), (size_t)(slots + 1) * 4);
+    if (e == hipSuccess) e = hipMemset(c->epochs, 0, (size_t)(slots + 1) * 4);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        if (p) (void)hipFree(p);
+        if (c->epochs) (void)hipFree(c->epochs);
+        delete c;
+        if (he) *he = e;
+        return TCE_ERR_HIP;
+    }
+    c->window = static_cast<unsigned char *>(p);
+    c->peer[rank] = c->window;
+    *out = c;
+    return TCE_OK;
+}
+
+int comm_export(Comm *c, void *handle64, hipError_t *he) {
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the C ABI promises 64-byte handles");
+    hipIpcMemHandle_t h;
+    const hipError_t e = hipIpcGetMemHandle(&h, c->window);
+    if (e != hipSuccess) {
+        if (he) *he = e;
+        return TCE_ERR_HIP;
+    }
+    std::memcpy(handle64, &h, 64);
+    return TCE_OK;
+}
+
+int comm_connect_ipc(Comm *c, const void *handles, hipError_t *he) {
+    for (int p = 0; p < c->world; ++p) {
+        if (p == c->rank || c->peer[p]) continue;
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, static_cast<const unsigned char *>(handles) + (size_t)p * 64, 64);
+        void *ptr = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            if (he) *he = e;
+            return TCE_ERR_HIP;
+        }
+        c->peer[p] = static_cast<unsigned char *>(ptr);
+        c->ipc_opened[p] = true;
+    }
+    return TCE_OK;
+}
+
+int comm_connect_local(Comm *c, Comm *const *all) {
+    for (int p = 0; p < c->world; ++p) {
+        if (!all[p] || all[p]->world != c->world || all[p]->rank != p || all[p]->window_bytes != c->window_bytes) return TCE_ERR_BAD_ARG;
+        c->peer[p] = all[p]->window;
+    }
+    return TCE_OK;
+}
+
+void *comm_window(Comm *c) { return c->window; }
+int comm_rank(const Comm *c) { return c->rank; }
+int comm_world(const Comm *c) { return c->world; }
+
+int comm_status(Comm *c, hipError_t *he) {
+    unsigned st = 0;
+    const hipError_t e = hipMemcpy(&st, c->epochs + c->slots, 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+        if (he) *he = e;
+        return TCE_ERR_HIP;
+    }
+    return st ? 1 : 0;
+}
+
+void comm_destroy(Comm *c) {
+    if (!c) return;
+    for (int p = 0; p < c->world; ++p)
+        if (c->ipc_opened[p] && c->peer[p]) (void)hipIpcCloseMemHandle(c->peer[p]);
+    if (c->window) (void)hipFree(c->window);
+    if (c->epochs) (void)hipFree(c->epochs);
+    delete c;
+}
+
+int launch_allgather_f16(Comm *c, int slot, const void *src_slice, void *dst_full, int n_total, hipStream_t stream, hipError_t *he) {
+    if (slot < 0 || slot >= c->slots || n_total <= 0 || n_total % c->world) return TCE_ERR_BAD_ARG;
+    const size_t slice_bytes = (size_t)(n_total / c->world) * 2;
+    if (slice_bytes % 16 || (size_t)n_total * 2 > c->vec_bytes) return TCE_ERR_UNSUPPORTED_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(src_slice) | reinterpret_cast<uintptr_t>(dst_full)) & 15) return TCE_ERR_UNSUPPORTED_SHAPE;
+    GatherArgs a{};
+    for (int p = 0; p < c->world; ++p) {
+        if (!c->peer[p]) return TCE_ERR_BAD_ARG;  // not connected
+        a.peer[p] = c->peer[p];
+    }
+    a.epochs = c->epochs;
+    a.src = static_cast<const uint4_t *>(src_slice);
+    a.dst = static_cast<uint4_t *>(dst_full);
+    a.rank = c->rank;
+    a.world = c->world;
+    a.slot = slot;
+    a.slots = c->slots;
+    a.slice16 = (unsigned)(slice_bytes / 16);
+    a.vec_bytes = c->vec_bytes;
+    a.flags_off = data_bytes(*c);
+    hipLaunchKernelGGL(allgather_peer_kernel, dim3(1), dim3(1024), 0, stream, a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (he) *he = e;
+        return TCE_ERR_HIP;
+    }
+    return TCE_OK;
+}
+
+}  // namespace tce

@@ -556,6 +556,67 @@ int tce_w8a8_matmul(const tce_w8a8_desc *d, void *stream) {
     return rc == TCE_ERR_HIP ? hip_fail(he, "w8a8 launch") : rc;
 }
 
+// ---- multi-GPU (csrc/comm.hip): tce_comm is tce::Comm ----
+int tce_w4a16_shard(const tce_w4a16_desc *full, int rank, int world, tce_w4a16_desc *shard) {
+    if (!full || !shard || world < 1 || rank < 0 || rank >= world) return fail(TCE_ERR_BAD_ARG, "tce_w4a16_shard: bad argument");
+    if (!full->qweight || !full->scales || !full->zeros || full->N <= 0 || full->K <= 0) return fail(TCE_ERR_BAD_ARG, "tce_w4a16_shard: null weights / non-positive N, K");
+    if (full->group_size != 128 && full->group_size != 64 && full->group_size != 32) return fail(TCE_ERR_UNSUPPORTED_GROUP, "Unsupported group size: %d", full->group_size);
+    if (full->N % world || (full->N / world) % 16) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "N=%d does not shard %d-way into multiples of 16 rows", full->N, world);
+    if (full->prepacked) return fail(TCE_ERR_BAD_ARG, "tce_w4a16_shard: shard first, pre-pack the shard (the packed copy is laid out for the whole N)");
+    const int zw = tce::zeros_width(full->K, full->group_size);
+    const size_t ss = full->scales_stride ? full->scales_stride : zw * 8, zs = full->zeros_stride ? full->zeros_stride : zw;
+    const size_t row0 = (size_t)rank * (full->N / world);
+    *shard = *full;
+    shard->N = full->N / world;
+    shard->qweight = static_cast<const unsigned char *>(full->qweight) + row0 * (size_t)(full->K / 2);
+    shard->scales = static_cast<const unsigned char *>(full->scales) + row0 * ss * 2;
+    shard->zeros = static_cast<const unsigned char *>(full->zeros) + row0 * zs * 4;
+    if (full->ldc == 0) shard->ldc = 0;  // the slice buffer is dense unless the caller says otherwise
+    return TCE_OK;
+}
+int tce_comm_create(int rank, int world, int max_vector_elems, int slots, tce_comm **out) {
+    if (!out) return fail(TCE_ERR_BAD_ARG, "tce_comm_create: null out");
+    hipError_t he = hipSuccess;
+    tce::Comm *c = nullptr;
+    const int rc = tce::comm_create(rank, world, max_vector_elems, slots, &c, &he);
+    if (rc == TCE_ERR_HIP) return hip_fail(he, "tce_comm_create");
+    if (rc != TCE_OK) return fail(rc, "tce_comm_create: need 0 <= rank < world <= %d, positive sizes", TCE_COMM_MAX_RANKS);
+    *out = reinterpret_cast<tce_comm *>(c);
+    return TCE_OK;
+}
+int tce_comm_export(tce_comm *comm, void *handle_out) {
+    if (!comm || !handle_out) return fail(TCE_ERR_BAD_ARG, "tce_comm_export: null argument");
+    hipError_t he = hipSuccess;
+    const int rc = tce::comm_export(reinterpret_cast<tce::Comm *>(comm), handle_out, &he);
+    return rc == TCE_ERR_HIP ? hip_fail(he, "hipIpcGetMemHandle") : rc;
+}
+int tce_comm_connect(tce_comm *comm, const void *handles) {
+    if (!comm || !handles) return fail(TCE_ERR_BAD_ARG, "tce_comm_connect: null argument");
+    hipError_t he = hipSuccess;
+    const int rc = tce::comm_connect_ipc(reinterpret_cast<tce::Comm *>(comm), handles, &he);
+    return rc == TCE_ERR_HIP ? hip_fail(he, "hipIpcOpenMemHandle") : rc;
+}
+int tce_comm_connect_local(tce_comm *comm, tce_comm *const *all) {
+    if (!comm || !all) return fail(TCE_ERR_BAD_ARG, "tce_comm_connect_local: null argument");
+    const int rc = tce::comm_connect_local(reinterpret_cast<tce::Comm *>(comm), reinterpret_cast<tce::Comm *const *>(all));
+    return rc == TCE_OK ? TCE_OK : fail(rc, "tce_comm_connect_local: the communicators do not form one group");
+}
+int tce_allgather_f16(tce_comm *comm, int slot, const void *src_slice, void *dst_full, int n_total, void *stream) {
+    if (!comm || !src_slice || !dst_full) return fail(TCE_ERR_BAD_ARG, "tce_allgather_f16: null argument");
+    hipError_t he = hipSuccess;
+    const int rc = tce::launch_allgather_f16(reinterpret_cast<tce::Comm *>(comm), slot, src_slice, dst_full, n_total, static_cast<hipStream_t>(stream), &he);
+    if (rc == TCE_ERR_HIP) return hip_fail(he, "allgather launch");
+    if (rc != TCE_OK) return fail(rc, "tce_allgather_f16: slot out of range, group not connected, n_total %% world != 0, slices not multiples of 16 bytes, or vector larger than the window");
+    return TCE_OK;
+}
+int tce_comm_status(tce_comm *comm) {
+    if (!comm) return fail(TCE_ERR_BAD_ARG, "tce_comm_status: null");
+    hipError_t he = hipSuccess;
+    const int rc = tce::comm_status(reinterpret_cast<tce::Comm *>(comm), &he);
+    return rc == TCE_ERR_HIP ? hip_fail(he, "tce_comm_status") : rc;
+}
+void tce_comm_destroy(tce_comm *comm) { tce::comm_destroy(reinterpret_cast<tce::Comm *>(comm)); }
+
 size_t tce_attention_decode_workspace_bytes(int heads, int max_keys, int hd) { return tce::attention_decode_workspace_bytes(heads, max_keys, hd); }
 
 int tce_attention_decode_step_f16(const void *qkv, void *kc, void *vc, const void *cosv, const void *sinv, const void *mask, void *out, void *workspace, int heads,

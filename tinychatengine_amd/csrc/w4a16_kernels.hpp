@@ -127,6 +127,15 @@ int launch_rmsnorm_half(const void *x, const float *gamma, void *out, int m, int
 int launch_bmm_f16t(const void *A, const void *B, void *C, int batch, int M, int N, int K, unsigned short alpha_bits, hipStream_t stream, hipError_t *hip_err);
 int launch_attention_decode(const void *q, const void *K, const void *Vt, const void *mask, void *out, int heads, int t, int hd, unsigned short alpha_bits,
                             hipStream_t stream, hipError_t *hip_err);
+// comm.hip
+struct Comm;
+int comm_create(int rank, int world, int max_vector_elems, int slots, Comm **out, hipError_t *he);
+int comm_export(Comm *c, void *handle64, hipError_t *he);
+int comm_connect_ipc(Comm *c, const void *handles, hipError_t *he);
+int comm_connect_local(Comm *c, Comm *const *all);
+int comm_status(Comm *c, hipError_t *he);
+void comm_destroy(Comm *c);
+int launch_allgather_f16(Comm *c, int slot, const void *src_slice, void *dst_full, int n_total, hipStream_t stream, hipError_t *he);
 // attention_fast.hip
 size_t attention_decode_workspace_bytes(int heads, int max_keys, int hd);
 int launch_attention_decode_fast(const void *qkv, void *kc, void *vc, const void *cosv, const void *sinv, const void *mask, void *out, void *workspace,

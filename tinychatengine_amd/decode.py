@@ -151,15 +151,31 @@ class DecodeLinears:
     def run_lm_head(self, launch=None) -> None:
         (launch or self._hip_launch)([self.lm_head.desc(self.x, self.logits, allow_host=self._host_ok)])
 
-    def run_token_distributed(self, gathers_per_block: int = 1, launch=None) -> None:
-        """world > 1: per block, the rank-local GEMVs on N/P shards, then the all-gather(s) of the fp16 output slices
-        (torch.distributed: backend 'nccl' == RCCL over xGMI on the GPU box; 'gloo' in the CPU tests, where `launch`
-        is a CPU stand-in for the kernel launch).  gathers_per_block = 1 is the north-star definition (all five linears
-        of a block from replicated inputs, one gather of the block output); 4 is the dependency-faithful variant
-        (SURVEY §8e)."""
-        import torch.distributed as dist
-        ag = dist.all_gather_into_tensor
+    def attach_peer_comm(self, exchange) -> None:
+        """The peer-write gather of the C ABI (tce_comm / tce_allgather_f16, csrc/comm.hip) for this rank: creates the window,
+        exchanges the 64-byte IPC handles through `exchange(bytes) -> list[bytes]` (e.g. torch.distributed.all_gather_object)
+        and maps the peers.  run_token_distributed(gather="peer") then uses it instead of torch.distributed."""
+        n_max = max(*self.shape.qkv, self.shape.hidden, self.shape.ffn, self.shape.vocab)
+        self.comm = capi.Comm(self.rank, self.world, n_max, slots=8)
+        self.comm.connect(exchange(self.comm.export()))
+
+    def run_token_distributed(self, gathers_per_block: int = 1, launch=None, gather: str = "rccl") -> None:
+        """world > 1: per block, the rank-local GEMVs on N/P shards, then the all-gather(s) of the fp16 output slices --
+        gather="rccl": torch.distributed (backend 'nccl' == RCCL over xGMI on the GPU box; 'gloo' in the CPU tests, where
+        `launch` is a CPU stand-in for the kernel launch); gather="peer": tce_allgather_f16, one peer-write kernel per
+        exchange (attach_peer_comm first).  gathers_per_block = 1 is the north-star definition (all five linears of a block
+        from replicated inputs, one gather of the block output); 4 is the dependency-faithful variant."""
         launch = launch or self._hip_launch
+        if gather == "peer":
+            st = _stream()
+            slot_of = {}
+
+            def ag(full, part):  # one slot per gather site: a site's epochs advance once per token on every rank
+                slot = slot_of.setdefault(full.data_ptr(), len(slot_of))
+                self.comm.allgather(slot, part.data_ptr(), full.data_ptr(), full.numel(), st)
+        else:
+            import torch.distributed as dist
+            ag = dist.all_gather_into_tensor
         assert self.m == 1, "column-sharded outputs are gathered as flat [N] vectors (M = 1 decode)"
         for li in range(self.n_layers):
             lch = self.block_launches(li)
