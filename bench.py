@@ -40,6 +40,9 @@ def parse_args():
     ap.add_argument("--gathers-per-block", type=int, default=1, choices=[1, 4])
     ap.add_argument("--gather", default="peer", choices=["peer", "rccl"],
                     help="N > 1: how the ranks' output slices are joined -- peer: tce_allgather_f16 (one peer-write kernel per exchange over xGMI, csrc/comm.hip); rccl: torch.distributed all_gather_into_tensor")
+    ap.add_argument("--issue", default="auto", choices=["auto", "graph", "token"],
+                    help="N = 1: graph = one hipGraph of 129 launches per token (stream order); token = ONE persistent kernel per token, the linears' data "
+                         "flow ordered by tagged output words (TCE_PLAN_TAGGED); auto = both are verified against each other and timed, the faster one is the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true", help="run only the dominant-kernel loop (for rocprofv3)")
     ap.add_argument("--roofline-launches", type=int, default=256)
@@ -405,7 +408,8 @@ def main():
     G = 128
     if args.force_dist:
         os.environ["TCE_FORCE_GATHER_BUFFERS"] = "1"
-    dl = DecodeLinears(shape, device=dev, group_size=G, rank=rank, world=world, m=1, layers=args.layers)
+    dl = DecodeLinears(shape, device=dev, group_size=G, rank=rank, world=world, m=1, layers=args.layers,
+                       dataflow=(world == 1 and not args.ungrouped and shape.qkv[0] >= shape.hidden))
     if dist is not None and args.gather == "peer":
         def exchange(handle: bytes):
             got = [None] * world
@@ -422,11 +426,61 @@ def main():
         return
 
     # ---- the step ----
+    variants = None
     if dist is None:
         plan = dl.make_plan(grouped=not args.ungrouped)
         step = lambda: plan.launch(stream)
         n_launches = plan.n_launches
-        mode = "one hipGraph replay per token"
+        mode = "one hipGraph replay per token (129 launches in stream order)" if not args.ungrouped else "one hipGraph replay per token"
+        if dl.dataflow and args.issue != "graph":
+            # the same launch list as ONE persistent kernel; what the two forms must agree on, bit for bit: every output of the token
+            tplan = dl.make_plan(tagged=True)
+            outs = [*dl.out_qkv, dl.out_o, dl.out_gate, dl.out_up, dl.out_down, dl.logits]
+            why = None
+            if not tplan.tagged:
+                why = "the library built the plan stream-ordered (tce_plan_is_chained = %d)" % tplan.kind
+            else:
+                plan.launch(stream)
+                torch.cuda.synchronize()
+                want = [o.clone() for o in outs]
+                for rep in range(3):
+                    for o in outs:
+                        o.fill_(float("nan"))
+                    tplan.launch(stream)
+                    tplan.status()
+                    if not all(torch.equal(a.view(torch.int16), b.view(torch.int16)) for a, b in zip(want, outs)):
+                        why = f"outputs differ from the stream-ordered plan (replay {rep})"
+                        break
+                if why is None and not torch.isfinite(dl.logits.float()).all():
+                    why = "non-finite logits"
+            if why is not None:
+                if args.issue == "token":
+                    raise SystemExit(f"--issue token: {why}")
+                print(f"[bench] token kernel not used: {why}", file=sys.stderr)
+                variants = {"token kernel": {"rejected": why}}
+            else:
+                def rate(fn, n):
+                    for _ in range(10):
+                        fn()
+                    torch.cuda.synchronize()
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    for _ in range(n):
+                        fn()
+                    b.record()
+                    torch.cuda.synchronize()
+                    return a.elapsed_time(b) / n
+                tstep = lambda: tplan.launch(stream)
+                ms_g, ms_t = rate(step, max(50, args.steps // 2)), rate(tstep, max(50, args.steps // 2))
+                tplan.status()
+                variants = {"hipGraph of 129 launches (stream order)": {"ms_per_token": round(ms_g, 4), "tokens_per_s": round(1e3 / ms_g, 1)},
+                            "token kernel (TCE_PLAN_TAGGED)": {"ms_per_token": round(ms_t, 4), "tokens_per_s": round(1e3 / ms_t, 1), "geometry": tplan.geometry(),
+                                                                "verified": "all outputs of the token bit-identical to the stream-ordered plan, 3 replays"}}
+                if args.issue == "token" or ms_t < ms_g:
+                    step = tstep
+                    n_launches = 2
+                    mode = ("one persistent kernel per token: the 129 launches walked by the same workgroups, the linears' data flow ordered by tagged "
+                            "output words (TCE_PLAN_TAGGED) + a one-thread kernel that advances the tag")
     else:
         n_launches = dl.n_layers * 4 + 1
         graph = None
@@ -476,6 +530,8 @@ def main():
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
     ms_per_step = wall * 1e3 / args.steps
+    if getattr(dl, "comm", None) is not None and dl.comm.status() != 0:
+        raise SystemExit(f"rank {rank}: tce_comm_status = {dl.comm.status()} (a peer-write gather timed out): the timing is void")
     ev_ms_per_step = e0.elapsed_time(e1) / args.steps
     tok_s = args.steps / wall
 
@@ -546,7 +602,9 @@ def main():
                        "parallelism": (f"tp{world} column-sharded, {args.gathers_per_block} "
                                        + ("peer-write all-gather(s) (tce_allgather_f16)" if args.gather == "peer" else f"{'RCCL' if args.backend == 'nccl' else args.backend} all-gather(s)")
                                        + " per block") if world > 1 else "single GPU",
-                       "issue": mode, "grouped_launches": not args.ungrouped,
+                       "issue": mode, **({"issue_variants": variants} if variants else {}), "grouped_launches": not args.ungrouped,
+                       "activations": ("the linears feed each other as in the decoder (x -> qkv; o reads the q slice; o -> gate/up; gate -> down; down -> next block; "
+                                       "last down -> lm_head); W ~ N(0, 1/K)") if dl.dataflow else "every linear reads its own fixed N(0,1) vector; W ~ N(0, 0.02^2)",
                        "algorithmic_bytes_per_token": token_bytes_full},
             "whole_token": whole,
         }

@@ -254,16 +254,23 @@ TCE_API int tce_layernorm_q_w8a8_group(const float *x, const float *ln_weight, c
 typedef struct tce_plan tce_plan;
 /* group_sizes[i] consecutive descriptors form launch i (1 = tce_w4a16_forward, >1 = tce_w4a16_forward_group). */
 TCE_API int tce_plan_create(const tce_w4a16_desc *descs, const int32_t *group_sizes, int n_launches, tce_plan **out);
-/* TCE_PLAN_CHAINED: the launches keep their order and their data dependences (launch i+1 reads its activations and
- * writes its outputs only after launch i has published all of its outputs), but ONE persistent kernel walks the whole
- * list and a device-wide barrier replaces each kernel boundary: a workgroup that is done with launch i already has the
- * first weight tiles of launch i+1 in registers while it waits, so launch ramp and first-byte HBM latency disappear
- * from the token's critical path.  Needs every launch to be an M = 1 GEMV the persistent kernel takes; otherwise the
- * plan is built stream-ordered (tce_plan_is_chained tells).  tce_plan_status synchronises the device and returns
- * TCE_ERR_HIP if a barrier wait ever timed out (~2 s; cannot happen unless the device is shared with a kernel that
- * never ends).  tce_plan_geometry reports what the token kernel runs with (rows per row group, ring depth, waves per
- * workgroup, workgroups). */
+/* TCE_PLAN_TAGGED (TCE_PLAN_CHAINED is accepted as a synonym): ONE persistent kernel walks the whole launch list -- no kernel
+ * boundaries, no barriers.  Every output of a launch is ALSO written as one 32-bit word (token tag << 16 | fp16 bits,
+ * device-scope store) into a shadow vector the plan owns, and a launch whose activation vector is (a 16-byte-aligned slice
+ * of) an output of an earlier launch of the plan polls those words -- the poll is its activation read; its first weight
+ * tiles are requested before it starts to wait.  A launch whose activations come from outside the plan reads them at once.
+ * What is ordered is therefore the plan's DATA FLOW (and, transitively, everything in front of it), not the launch list as
+ * such: launches that do not feed each other may overlap.  Outputs are bit-identical to the stream-ordered plan.
+ * Not taken (the plan is then built stream-ordered; tce_plan_is_chained tells: 0 stream-ordered, 2 token kernel): a launch that
+ * is not an M = 1 GEMV the persistent kernel takes, a launch with the fused RMSNorm prologue, an activation vector that
+ * straddles two outputs or starts at an odd 16-byte offset.  tce_plan_status synchronises the device and returns TCE_ERR_HIP
+ * if a wait ever timed out (~0.3 s; cannot happen unless the device is shared with a kernel that never ends).
+ * tce_plan_geometry reports what the token kernel runs with (rows per row group, ring depth, waves per workgroup, workgroups).
+ * Measured (MI355X, Llama-2-7B-shaped token): the primitive is cheap -- 1.8 us per bare hand-off against 2.0 us for a kernel
+ * boundary and 5.0 us for round 1's arrival-counter barrier (scripts/probes/handoff_probe.hip) -- but the token is NOT faster
+ * than the stream-ordered graph (1.40 vs 0.995 ms): opt-in, and bench.py picks whichever is faster. */
 #define TCE_PLAN_CHAINED 1
+#define TCE_PLAN_TAGGED 2
 TCE_API int tce_plan_create_ex(const tce_w4a16_desc *descs, const int32_t *group_sizes, int n_launches, int flags, tce_plan **out);
 TCE_API int tce_plan_is_chained(const tce_plan *plan);
 TCE_API int tce_plan_geometry(const tce_plan *plan, int *rows, int *depth, int *waves, int *workgroups);

@@ -1,5 +1,5 @@
-"""GPU tests of the persistent GEMV kernel (w4a16_gemv_stream.hip) and of chained plans (TCE_PLAN_CHAINED: one token
-kernel walks the launch list, device-wide barriers instead of kernel boundaries).
+"""GPU tests of the persistent GEMV kernel (w4a16_gemv_stream.hip) and of token plans (TCE_PLAN_TAGGED: one token
+kernel walks the launch list, consumers poll tagged output words instead of waiting at kernel boundaries).
 
 Parity: the persistent kernel against the oracle on the same inputs (every geometry it compiles), and -- because a
 row's arithmetic does not depend on which wave computes it -- bit-identical to the workgroup-per-row-block kernel.
@@ -131,15 +131,17 @@ def _mlp_chain(dev, oracle, dims, G, seed):
     return launches, bufs, keep, wts
 
 
-def test_chained_plan_keeps_the_data_dependences(dev, oracle):
+@pytest.mark.parametrize("tagged", [False, True])
+def test_chained_plan_keeps_the_data_dependences(dev, oracle, tagged):
+    """Both spellings of the flag (TCE_PLAN_CHAINED is a synonym of TCE_PLAN_TAGGED since round 2)."""
     from tinychatengine_amd import capi
     dims = [4096, 11008, 4096, 1024, 4096, 256, 2048]
     launches, bufs, keep, wts = _mlp_chain(dev, oracle, dims, 128, seed=11)
     capi.set_gemv_config(2, 8, 0, 2)  # the stream-ordered plan on the persistent kernel too: outputs must be bit-identical
     plain = capi.Plan(launches)
     capi.set_gemv_config()
-    chained = capi.Plan(launches, chained=True)
-    assert chained.chained and not plain.chained
+    chained = capi.Plan(launches, chained=not tagged, tagged=tagged)
+    assert chained.tagged and not plain.chained
     s = torch.cuda.current_stream().cuda_stream
     rng = np.random.default_rng(3)
     for it in range(40):
@@ -172,6 +174,76 @@ def test_chained_plan_keeps_the_data_dependences(dev, oracle):
     assert np.array_equal(bufs[-1].cpu().numpy().view(np.uint16), want.view(np.uint16))
     plain.close()
     chained.close()
+
+
+def test_tagged_plan_decoder_block_dataflow(dev, oracle):
+    """A tagged plan over the launch shapes of two decoder blocks, wired the way the linears feed each other (the attention between
+    qkv and o is not part of the path: o reads the q slice): grouped launches (q / k / v as three linears; gate + up), a consumer
+    that reads a SLICE of a producer's output, the SiLU-mul pair epilogue, the residual-add epilogue, an input that comes from
+    outside the plan, buffers reused from block to block (the latest writer is the producer), and 70 000 back-to-back replays
+    (the 16-bit token tag wraps at 65 535).  Bit-identical to the stream-ordered plan throughout."""
+    from tinychatengine_amd import capi
+    from tinychatengine_amd.linear import Linear_half_int4
+    h, f, G = 1024, 2816, 128
+    g = torch.Generator(device=dev).manual_seed(5)
+    mk = lambda n, k: Linear_half_int4.from_float(torch.empty(n, k, device=dev).normal_(0, 1.0 / np.sqrt(k), generator=g), G)
+    e = lambda n: torch.zeros((1, n), dtype=torch.float16, device=dev)
+    x, qkv, o_out, act = e(h), e(3 * h), e(h), e(f)
+    launches, keep = [], []
+    for blk in range(2):
+        q, k, v, o, down = mk(h, h), mk(h, h), mk(h, h), mk(h, h), mk(h, f)
+        gu = Linear_half_int4.interleave(mk(f, h), mk(f, h))
+        keep += [q, k, v, o, down, gu]
+        launches.append([q.desc(x, qkv[:, :h]), k.desc(x, qkv[:, h:2 * h]), v.desc(x, qkv[:, 2 * h:])])  # block 0: x from outside the plan
+        launches.append([o.desc(qkv[:, :h], o_out)])                                                   # a slice of launch 0's first output
+        launches.append([gu.desc(o_out, act, flags=capi.TCE_W4_SILU_MUL_PAIRS)])
+        launches.append([down.desc(act, x, flags=capi.TCE_W4_ADD_TO_C)])                               # x += down(act): next block's input
+    capi.set_gemv_config(2, 8, 0, 2)
+    plain = capi.Plan(launches)
+    capi.set_gemv_config()
+    tagged = capi.Plan(launches, tagged=True)
+    assert tagged.tagged and not plain.chained
+    s = torch.cuda.current_stream().cuda_stream
+    bufs = [qkv, o_out, act, x]
+    for it in range(25):
+        x0 = torch.empty((1, h), device=dev).normal_(0, 1, generator=g).to(torch.float16)
+        results = []
+        for plan in (plain, tagged):
+            for b in bufs:
+                b.fill_(float("nan"))
+            x.copy_(x0)
+            plan.launch(s)
+            plan.status()
+            results.append([b.cpu().numpy().copy() for b in bufs])
+        for name, a, b in zip(("qkv", "o", "act", "x"), *results):
+            assert not np.isnan(b.astype(np.float32)).any(), f"replay {it}: {name} has unwritten / poisoned values"
+            assert np.array_equal(a.view(np.uint16), b.view(np.uint16)), f"replay {it}: {name} differs from the stream-ordered plan"
+    # tag wrap-around: x is an input AND an output, so 70 000 replays are a 140 000-block-deep recurrence; restart it now and then
+    x0 = torch.empty((1, h), device=dev).normal_(0, 1, generator=g).to(torch.float16)
+    for r in range(70):
+        for _ in range(999):
+            tagged.launch(s)
+        x.copy_(x0)
+        tagged.launch(s)
+    tagged.status()
+    got = x.cpu().numpy().copy()
+    x.copy_(x0)
+    plain.launch(s)
+    torch.cuda.synchronize()
+    assert np.array_equal(got.view(np.uint16), x.cpu().numpy().view(np.uint16))
+    plain.close()
+    tagged.close()
+
+
+def test_tagged_plan_falls_back_for_the_fused_rmsnorm_prologue(dev, oracle):
+    from tinychatengine_amd import capi
+    launches, bufs, keep, wts = _mlp_chain(dev, oracle, [1024, 512, 256], 128, seed=4)
+    gamma = torch.ones(512, dtype=torch.float32, device=dev)
+    launches[1][0].rmsnorm_gamma = gamma.data_ptr()
+    launches[1][0].rmsnorm_eps = 1e-6
+    plan = capi.Plan(launches, tagged=True)
+    assert not plan.chained
+    plan.close()
 
 
 def test_chained_plan_falls_back_when_a_launch_is_not_a_decode_gemv(dev, oracle):

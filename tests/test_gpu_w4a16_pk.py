@@ -109,7 +109,7 @@ def test_pk_gemm_matches_oracle(dev, oracle, M, N, K, G):
                 capi.check(L.tce_w4a16_set_debug_mode(mode))
                 out = torch.full((M, N), float("nan"), dtype=torch.float16, device=dev)
                 d = lin.desc(x, out)
-                if mode != 60 or M >= 192:  # the automatic rule leaves smaller batches to the 64-row tiles / the small-batch kernel
+                if mode != 60:  # (60 = automatic: the cost models of the two GEMMs decide, test_pk_dispatch_rules)
                     assert capi.describe_dispatch(d).startswith("gemm-pk"), capi.describe_dispatch(d)
                 capi.check(capi.w4a16_forward(d, torch.cuda.current_stream().cuda_stream))
                 torch.cuda.synchronize()
@@ -146,7 +146,8 @@ def test_pk_gemm_add_to_c_and_strides(dev, oracle):
 
 
 def test_pk_dispatch_rules(dev, oracle):
-    """No packed copy -> the other kernels; M < 192 -> the other kernels; K % 128 != 0 -> no packed form at all."""
+    """No packed copy -> the other kernels; M < 192 -> the other kernels; in between the two GEMMs' cost models decide (the 64-row
+    tiles keep M = 512 at N = 4096, where 128-row tiles are too few to fill 256 CUs); K % 128 != 0 -> no packed form at all."""
     from tinychatengine_amd import capi
     qw, sc, zp = _quant(oracle, 256, 512, 128, seed=1, random_zeros=False)
     lin = _lin(dev, qw, sc, zp, 128)
@@ -154,8 +155,19 @@ def test_pk_dispatch_rules(dev, oracle):
     out = torch.zeros(512, 256, dtype=torch.float16, device=dev)
     assert capi.describe_dispatch(lin.desc(x, out)).startswith("gemm-dma")
     lin.prepack()
-    assert capi.describe_dispatch(lin.desc(x, out)).startswith("gemm-pk tile=128x")
+    try:
+        capi.check(capi.lib().tce_w4a16_set_debug_mode(61))
+        assert capi.describe_dispatch(lin.desc(x, out)).startswith("gemm-pk tile=128x")
+    finally:
+        capi.lib().tce_w4a16_set_debug_mode(60)
     assert not capi.describe_dispatch(lin.desc(x[:64], out[:64])).startswith("gemm-pk")
+    # describe_dispatch only reads the descriptor: the full-size decisions without full-size tensors
+    def decision(M, N, K):
+        d = lin.desc(x, out)
+        d.M, d.N, d.K, d.lda, d.ldc = M, N, K, K, N
+        return capi.describe_dispatch(d).split()[0]
+    assert decision(2048, 4096, 4096) == decision(512, 11008, 4096) == decision(4096, 4096, 11008) == "gemm-pk"
+    assert decision(512, 4096, 4096) == "gemm-dma" and decision(128, 11008, 4096) != "gemm-pk"
     assert capi.describe_dispatch(lin.desc(x[:1], out[:1])).startswith("gemv")
     assert int(capi.lib().tce_w4a16_prepack_bytes(256, 1440, 32)) == 0
 
@@ -172,9 +184,13 @@ def test_full_size_prefill_on_the_packed_kernel(dev, oracle, N, K):
     xh = torch.empty(M // 2, K, device=dev).normal_(0, 1, generator=g).to(torch.float16)
     x = torch.cat([xh, xh], dim=0).contiguous()
     y = torch.full((M, N), float("nan"), dtype=torch.float16, device=dev)
-    assert capi.describe_dispatch(lin.desc(x, y)).startswith("gemm-pk")
-    lin.forward(x, y)
-    torch.cuda.synchronize()
+    try:  # the automatic rule keeps the 64-row tiles for M = 512 at N = 4096: the packed kernel is asked for by name
+        capi.check(capi.lib().tce_w4a16_set_debug_mode(61 if N == 4096 else 60))
+        assert capi.describe_dispatch(lin.desc(x, y)).startswith("gemm-pk")
+        lin.forward(x, y)
+        torch.cuda.synchronize()
+    finally:
+        capi.lib().tce_w4a16_set_debug_mode(60)
     assert torch.equal(y[: M // 2], y[M // 2:]), "duplicate rows must produce identical outputs"
     rows = [r for r in range(0, 512) if (r % 4) == ((r // 64) % 4)]
     ref32 = oracle.w4a16_gemv_q4_6_mt(x[rows].cpu().numpy(), lin.weight.cpu().numpy().view(np.uint32), lin.scale.cpu().numpy(),

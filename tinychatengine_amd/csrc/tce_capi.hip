@@ -678,7 +678,7 @@ static void plan_free(tce_plan *p) {
 
 int tce_plan_create_ex(const tce_w4a16_desc *descs, const int32_t *group_sizes, int n_launches, int flags, tce_plan **out) {
     if (!descs || !group_sizes || n_launches < 1 || !out) return fail(TCE_ERR_BAD_ARG, "bad argument");
-    if (flags & ~TCE_PLAN_CHAINED) return fail(TCE_ERR_BAD_ARG, "unknown plan flags 0x%x", flags);
+    if (flags & ~(TCE_PLAN_CHAINED | TCE_PLAN_TAGGED)) return fail(TCE_ERR_BAD_ARG, "unknown plan flags 0x%x", flags);
     tce_plan *p = new (std::nothrow) tce_plan();
     if (!p) return fail(TCE_ERR_BAD_ARG, "out of host memory");
     int total = 0;
@@ -694,7 +694,7 @@ int tce_plan_create_ex(const tce_w4a16_desc *descs, const int32_t *group_sizes, 
 
     // Chained form: only if every launch is a valid GEMV group the persistent kernel takes (same checks as the
     // unchained entry points), and there is something to overlap.
-    bool chained = (flags & TCE_PLAN_CHAINED) && n_launches > 1 && g_gemv_kernel != 1;
+    bool chained = (flags & (TCE_PLAN_CHAINED | TCE_PLAN_TAGGED)) && n_launches > 1 && g_gemv_kernel != 1;
     for (int i = 0, off = 0; i < n_launches && chained; off += p->groups[i], ++i)
         for (int j = 0; j < p->groups[i] && chained; ++j) {
             const tce_w4a16_desc &a = p->descs[off], &b = p->descs[off + j];
@@ -755,7 +755,7 @@ int tce_plan_create(const tce_w4a16_desc *descs, const int32_t *group_sizes, int
     return tce_plan_create_ex(descs, group_sizes, n_launches, 0, out);
 }
 
-int tce_plan_is_chained(const tce_plan *plan) { return plan && plan->token ? 1 : 0; }
+int tce_plan_is_chained(const tce_plan *plan) { return plan && plan->token ? 2 : 0; }
 
 int tce_plan_geometry(const tce_plan *plan, int *rows, int *depth, int *waves, int *workgroups) {
     if (!plan || !plan->token || !rows || !depth || !waves || !workgroups) return fail(TCE_ERR_BAD_ARG, "not a chained plan");

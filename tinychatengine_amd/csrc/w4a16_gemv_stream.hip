@@ -19,14 +19,19 @@
 //   * RING             a wave keeps DEPTH steps (ROWS x 1 KiB of weights + scales/zeros each) in flight across row-group
 //                      boundaries; the issue side and the compute side each walk their own (row group, step) cursor with
 //                      "sticky" per-linear state in SGPRs, so nothing but the loaded registers travels through the ring.
-//   * TOKEN KERNEL     (w4a16_gemv_token_kernel, chained plans) ONE launch of the same workgroups walks a whole list of
-//                      GEMV launches -- a decode token's linears.  Between two launches of the list there is a
-//                      device-wide barrier instead of a kernel boundary: a workgroup that has finished launch j issues
-//                      the first DEPTH steps of launch j+1's WEIGHTS (they depend on nothing), then waits until every
-//                      workgroup has published its outputs of launch j, and only then reads its activations.  Launch
-//                      ramp and first-byte HBM latency vanish from the token's critical path; the data dependence is
-//                      exactly the stream-ordered one.  All workgroups are resident at once (the host checks the
-//                      occupancy), so the barrier cannot deadlock; a wait that lasts ~2 s gives up and flags the plan.
+//   * TOKEN KERNEL     (w4a16_gemv_token_kernel, TCE_PLAN_TAGGED / TCE_PLAN_CHAINED plans) ONE launch of the same workgroups
+//                      walks a whole list of GEMV launches -- a decode token's linears -- and there is NO barrier between
+//                      them.  Every output is ALSO written as one 32-bit word (token tag << 16 | fp16 bits) with a
+//                      device-scope store into a per-launch shadow vector the plan owns; the launch that consumes it
+//                      first issues the first DEPTH steps of its WEIGHTS (they depend on nothing) and then polls THE
+//                      DATA with coherent 16-byte loads until all tags of a piece match -- the poll is the activation read,
+//                      and no store acknowledgement, arrival counter or second round trip is on the path.  All workgroups
+//                      are resident at once (the host checks the occupancy), so the wait cannot deadlock; a wait that lasts
+//                      ~0.3 s gives up and flags the plan.  Round 1's form (arrival counter per launch, one polling lane,
+//                      then the coherent read) cost 5.0 us per bare hand-off against 1.8 us for this one and 2.0 us for a
+//                      kernel boundary (scripts/probes/handoff_probe.hip, profiles/r2/handoff_probe.jsonl) and is gone.
+//                      Status: correct (bit-identical to the stream-ordered plan), NOT faster for a Llama-7B token -- 1.40
+//                      vs 0.995 ms: DESIGN.md 3.1b has the per-launch timeline (profiles/r2/token_kernel_timeline.jsonl).
 #include "tce_common.hpp"
 #include "w4a16_kernels.hpp"
 
@@ -44,21 +49,24 @@ struct StreamArgs {
 
 struct TokenArgs {
     const StreamLaunch *launches;  // device memory
+    unsigned long long *dbg;       // diagnostics: [workgroup][launch][8] wall-clock stamps (100 MHz), null normally
     int n_launches;
-    unsigned *arrive;  // [n_launches] workgroup arrival counters, zero before the kernel starts
-    unsigned *status;  // set to 1 if a barrier wait timed out
+    unsigned *status;  // set to 1 if a wait timed out
+    const unsigned *epoch;  // the token's tag (1..65535), advanced by a one-thread kernel behind this one
 };
 
-// How one launch of the list is ordered against its predecessor.
+// What a launch of a token kernel needs beside its own record.
 struct Barrier {
-    unsigned *arrive_prev;  // null: first launch / single launch (activations first, nothing to wait for)
-    unsigned *arrive_here;  // null: nobody comes after this launch
     unsigned *status;
+    unsigned tag;  // this token's tag, already shifted into the upper half
+    unsigned long long *stamps;  // diagnostics (null normally): thread 0 writes {entered, activations in registers, image staged, own wave done, workgroup done}
 };
 
 // One GEMV launch, executed by all waves of the (persistent) grid.  MODE: 0 = the GEMV.  Diagnostics
 // (tce_w4a16_set_debug_mode): 1 = stream the weights only, 2 = GEMV + per-wave timestamps, 4 = unpack/MFMA only.
-template <int ROWS, int DEPTH, bool Z8, int MODE>
+// CHAIN: 0 = a launch of its own, 2 = a launch inside the token kernel (tagged hand-off).  (1 was round 1's arrival-counter
+// barrier: 5.0 us per bare hand-off against 1.8 us tagged -- scripts/probes/handoff_probe.hip -- and removed.)
+template <int ROWS, int DEPTH, bool Z8, int MODE, int CHAIN = 0>
 __device__ __forceinline__ void gemv_launch_body(const StreamLaunch &L, const Barrier bar, unsigned char *smem, unsigned long long *ts_x_ready) {
     const int tid = threadIdx.x;
     const int nthreads = blockDim.x;
@@ -77,6 +85,12 @@ __device__ __forceinline__ void gemv_launch_body(const StreamLaunch &L, const Ba
     const half_t *A = L.A;
     // LDS: x image [T][4][64] x 16 B, chunk sums [T][64] floats, the workgroup's row-group counter
     int *rg_counter = reinterpret_cast<int *>(smem + (size_t)T * (4096 + 256));  // [64]; word 0 is the counter
+    auto stamp = [&](int i) {
+        if constexpr (CHAIN != 0) {
+            if (bar.stamps && tid == 0) bar.stamps[i] = wall_clock64();
+        }
+    };
+    stamp(0);
     if (tid == 0) *rg_counter = 0;
     __syncthreads();
     // The ticket is lane 0's atomic on word 0; the value is read (readfirstlane) one row group later.  All 64 lanes
@@ -176,46 +190,82 @@ __device__ __forceinline__ void gemv_launch_body(const StreamLaunch &L, const Ba
     // queued behind the first weight steps it took 3-5 us.
     // ---------------------------------------------------------------------------------------------------------------
     Step st[DEPTH];
-    const bool behind_barrier = bar.arrive_prev != nullptr;  // grid-uniform
+    const bool tagged_in = CHAIN == 2 && L.A_tag != nullptr;                               // grid-uniform: x is polled, not read
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(A), 0, 0x7FFFFFF0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_t =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(tagged_in ? L.A_tag : reinterpret_cast<const unsigned *>(A)), 0, 0x7FFFFFF0, 0x00020000);
     uint4_t *xs = reinterpret_cast<uint4_t *>(smem);                  // [T][4][64] pieces of 16 bytes (pair-permuted, lane-linear)
     float *xsl = reinterpret_cast<float *>(smem + (size_t)T * 4096);  // [T][64]: sum of the 32 activations of (step, lane)
     const int total_pieces = T * 256;
     // x piece p -> 16 bytes of the vector.  sc0 sc1: device-coherent read -- behind a barrier the vector was written by
     // other CUs (other XCDs, other L2s) moments ago, and this CU / this L2 may still hold the previous token's lines.
-    auto x_piece = [&](int p) -> uint4_t {
+    auto piece_halves = [&](int p) -> int {  // first activation of image piece p, -1 = padding
         const int c = (p >> 8) * 64 + (p & 63);
         const int j = (p >> 6) & 3;
+        return p < total_pieces && c < nchunks ? c * 32 + j * 8 : -1;
+    };
+    auto x_piece = [&](int p) -> uint4_t {
+        const int k0 = piece_halves(p);
         uint4_t q = uint4_t{0u, 0u, 0u, 0u};
-        if (p < total_pieces && c < nchunks) q = __builtin_amdgcn_raw_buffer_load_b128(rs_a, (c * 32 + j * 8) * 2, 0, /*sc0|sc1*/ 17);
+        if (k0 >= 0) q = __builtin_amdgcn_raw_buffer_load_b128(rs_a, k0 * 2, 0, /*sc0|sc1*/ 17);
         return q;
     };
-    constexpr int XR = 4;  // pieces per thread held in registers across the weight prologue (covers K <= 8192 x waves/16)
-    uint4_t xr[XR];
-    if (behind_barrier) {
+    // Tagged form: NP pieces of this thread at once -- all requests go out, then the tags are checked, and only the pieces that
+    // were not there yet are asked for again (one round trip when the producers are done, which is the common case at the
+    // slower workgroups; the 32-bit words are single-copy atomic, a piece is complete when its eight tags match).
+    auto poll_pieces = [&](auto np_tag, const int *k0, uint4_t *out) {
+        constexpr int NP = decltype(np_tag)::value;
+        const unsigned tag = bar.tag;
+        bool need[NP];
+        uint4_t lo[NP], hi[NP];
 #pragma unroll
-        for (int d = 0; d < DEPTH; ++d) issue(st[d]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (tid == 0) {
-            // ~1 us per probe; give up after ~2 s instead of hanging the device (and at once if another workgroup did)
-            const unsigned nblocks = gridDim.x;
-            int probes = 0;
-            while (__hip_atomic_load(bar.arrive_prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nblocks) {
-                __builtin_amdgcn_s_sleep(4);
-                if ((++probes & 1023) == 0) {
-                    if (__hip_atomic_load(bar.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-                    if (probes > (1 << 21)) {
-                        __hip_atomic_store(bar.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
-                    }
+        for (int i = 0; i < NP; ++i) {
+            need[i] = k0[i] >= 0;
+            lo[i] = hi[i] = uint4_t{tag, tag, tag, tag};
+        }
+        int tries = 0;
+        for (;;) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i)
+                if (need[i]) {
+                    lo[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_t, k0[i] * 4, 0, /*sc0|sc1*/ 17);
+                    hi[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_t, k0[i] * 4 + 16, 0, /*sc0|sc1*/ 17);
+                }
+            bool again = false;
+#pragma unroll
+            for (int i = 0; i < NP; ++i)
+                if (need[i]) {
+                    const unsigned bad = ((lo[i].x ^ tag) | (lo[i].y ^ tag) | (lo[i].z ^ tag) | (lo[i].w ^ tag) | (hi[i].x ^ tag) | (hi[i].y ^ tag) |
+                                          (hi[i].z ^ tag) | (hi[i].w ^ tag)) >> 16;
+                    need[i] = bad != 0u;
+                    again |= need[i];
+                }
+            if (!again) break;
+            __builtin_amdgcn_s_sleep(1);
+            if ((++tries & 255) == 0) {  // ~0.3 ms: has anybody given up?  ~0.3 s: give up (the plan's status word says so)
+                if (__hip_atomic_load(bar.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                if (tries > (1 << 18)) {
+                    __hip_atomic_store(bar.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
                 }
             }
         }
-        __syncthreads();
-        // no cache-wide acquire here (a buffer_inv per wave made every barrier cost ~40 us): the activations are read
-        // with device-coherent loads, and nothing else the predecessor wrote is read by this launch
 #pragma unroll
-        for (int i = 0; i < XR; ++i) xr[i] = x_piece(tid + i * nthreads);
+        for (int i = 0; i < NP; ++i)
+            out[i] = k0[i] >= 0 ? uint4_t{(lo[i].x & 0xFFFFu) | (lo[i].y << 16), (lo[i].z & 0xFFFFu) | (lo[i].w << 16), (hi[i].x & 0xFFFFu) | (hi[i].y << 16),
+                                          (hi[i].z & 0xFFFFu) | (hi[i].w << 16)}
+                                : uint4_t{0u, 0u, 0u, 0u};
+    };
+    constexpr int XR = 4;  // pieces per thread held in registers across the weight prologue (covers K <= 8192 x waves/16)
+    uint4_t xr[XR];
+    if (tagged_in) {  // weights first (they depend on nothing), then the wait
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) issue(st[d]);
+        __builtin_amdgcn_sched_barrier(0);
+        int k0[XR];
+#pragma unroll
+        for (int i = 0; i < XR; ++i) k0[i] = piece_halves(tid + i * nthreads);
+        poll_pieces(std::integral_constant<int, XR>{}, k0, xr);
     } else {
         // x loads first, the weight prologue right behind them, and only then the first use of x: the x data returns
         // first (in-order), and the weights are already in flight while the image is written and summed
@@ -226,6 +276,7 @@ __device__ __forceinline__ void gemv_launch_body(const StreamLaunch &L, const Ba
         for (int d = 0; d < DEPTH; ++d) issue(st[d]);
         __builtin_amdgcn_sched_barrier(0);
     }
+    stamp(1);
     if (L.gamma) {
         // fused RMSNorm prologue (generalT5LayerNorm, LlamaRMSNorm.cu:68-93): rs by the workgroup in the shape-independent
         // order of rmsnorm_rs_block, then half(clamp((x * rs) * gamma)) goes into the image instead of x
@@ -255,7 +306,16 @@ __device__ __forceinline__ void gemv_launch_body(const StreamLaunch &L, const Ba
             const int p = tid + i * nthreads;
             if (p < total_pieces) xs[p] = pair_permute(xr[i]);
         }
-        for (int p = tid + XR * nthreads; p < total_pieces; p += nthreads) xs[p] = pair_permute(x_piece(p));  // long K only
+        for (int p = tid + XR * nthreads; p < total_pieces; p += nthreads) {  // long K only
+            if (tagged_in) {
+                const int k1[1] = {piece_halves(p)};
+                uint4_t one[1];
+                poll_pieces(std::integral_constant<int, 1>{}, k1, one);
+                xs[p] = pair_permute(one[0]);
+            } else {
+                xs[p] = pair_permute(x_piece(p));
+            }
+        }
     }
     __syncthreads();
     {
@@ -274,6 +334,7 @@ __device__ __forceinline__ void gemv_launch_body(const StreamLaunch &L, const Ba
     }
     __syncthreads();
     if constexpr (MODE == 2) *ts_x_ready = wall_clock64();
+    stamp(2);
 
     // ---------------------------------------------------------------------------------------------------------------
     // compute side
@@ -297,6 +358,7 @@ __device__ __forceinline__ void gemv_launch_body(const StreamLaunch &L, const Ba
     int c_si = 0, c_begin = 0;
     int c_end = nseg > 1 ? L.seg[1].block_begin : n_rg;
     half_t *c_C = L.seg[0].C;
+    unsigned *c_T = CHAIN == 2 ? L.C_tag[0] : nullptr;  // the same outputs as (tag << 16 | bits) words for the launches behind this one
     int c_N = L.seg[0].N;
     int c_epi = L.seg[0].epilogue;
 
@@ -358,6 +420,7 @@ __device__ __forceinline__ void gemv_launch_body(const StreamLaunch &L, const Ba
                 c_end = c_si + 1 < nseg ? L.seg[c_si + 1].block_begin : n_rg;
             } while (c_rg >= c_end);
             c_C = L.seg[c_si].C;
+            if constexpr (CHAIN == 2) c_T = L.C_tag[c_si];
             c_N = L.seg[c_si].N;
             c_epi = L.seg[c_si].epilogue;
         }
@@ -381,6 +444,10 @@ __device__ __forceinline__ void gemv_launch_body(const StreamLaunch &L, const Ba
         auto put = [&](int idx, half_t h) {
             __hip_atomic_store(reinterpret_cast<unsigned short *>(c_C + idx), __builtin_bit_cast(unsigned short, h), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
+            if constexpr (CHAIN == 2) {
+                if (c_T)  // the hand-off itself: value and "it is there" in ONE word; nothing waits for the store to be acknowledged
+                    __hip_atomic_store(c_T + idx, bar.tag | (unsigned)__builtin_bit_cast(unsigned short, h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         };
         if (lane == 63) {
             if (c_epi & TCE_W4_SILU_MUL_PAIRS) {  // rows (2n, 2n+1) = (gate n, up n); the host picked an even ROWS
@@ -420,14 +487,10 @@ __device__ __forceinline__ void gemv_launch_body(const StreamLaunch &L, const Ba
             issue(st[d]);
         }
     } while (any);
+    stamp(3);
 
-    if (bar.arrive_here) {
-        // every wave waits for its own write-through stores to be acknowledged, then the workgroup arrives.  No
-        // cache-wide release (buffer_wbl2): the outputs are the only data the next launch reads, and they went through.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // (also: everyone is done with the x image)
-        if (tid == 0) __hip_atomic_fetch_add(bar.arrive_here, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if constexpr (CHAIN == 2) __syncthreads();  // everyone is done with the x image and the ticket counter; the stores are on their way, nobody waits for them
+    stamp(4);
 }
 
 template <int ROWS, int DEPTH, bool Z8, int MODE = 0>
@@ -438,7 +501,7 @@ __global__ __launch_bounds__(1024) void w4a16_gemv_stream_kernel(const StreamArg
         cy0 = clock64();
     }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    gemv_launch_body<ROWS, DEPTH, Z8, MODE>(args.launch, Barrier{nullptr, nullptr, nullptr}, smem, &ts1);
+    gemv_launch_body<ROWS, DEPTH, Z8, MODE>(args.launch, Barrier{nullptr, 0u, nullptr}, smem, &ts1);
     if constexpr (MODE == 2) {
         if ((threadIdx.x & 63) == 63 && args.dbg) {
             unsigned long long *d = args.dbg + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4;
@@ -448,18 +511,23 @@ __global__ __launch_bounds__(1024) void w4a16_gemv_stream_kernel(const StreamArg
 }
 
 // A whole list of launches (a decode token's linears) in one kernel; see the header.
-template <int ROWS, int DEPTH, bool Z8>
+template <int ROWS, int DEPTH, bool Z8, int CHAIN>
 __global__ __launch_bounds__(1024) void w4a16_gemv_token_kernel(const TokenArgs args) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n = args.n_launches;
+    unsigned tag = 0;
+    if constexpr (CHAIN == 2) tag = __builtin_amdgcn_readfirstlane(__hip_atomic_load(args.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) << 16;
     for (int j = 0; j < n; ++j) {
         Barrier bar;
-        bar.arrive_prev = j > 0 ? args.arrive + (j - 1) : nullptr;
-        bar.arrive_here = j + 1 < n ? args.arrive + j : nullptr;
         bar.status = args.status;
-        gemv_launch_body<ROWS, DEPTH, Z8, 0>(args.launches[j], bar, smem, nullptr);
+        bar.tag = tag;
+        bar.stamps = args.dbg ? args.dbg + ((size_t)blockIdx.x * n + j) * 8 : nullptr;
+        gemv_launch_body<ROWS, DEPTH, Z8, 0, CHAIN>(args.launches[j], bar, smem, nullptr);
     }
 }
+
+// the token's tag for the NEXT replay: 1, 2, ..., 65535, 1, ... (0 is what freshly allocated shadow vectors hold)
+__global__ void token_epoch_kernel(unsigned *epoch) { *epoch = *epoch % 65535u + 1u; }
 
 int g_num_cus = 0;
 int g_stream_rows = 0, g_stream_nw = 0, g_stream_depth = 0, g_stream_bpc = 0;  // forced geometry (0 = automatic)
@@ -624,7 +692,8 @@ int launch_w4a16_gemv_stream(const tce_w4a16_desc *descs, int count, hipStream_t
 // ---------------------------------------------------------------------------------------------------------------------
 struct TokenPlan {
     StreamLaunch *launches = nullptr;  // device
-    unsigned *sync = nullptr;          // device: [n] arrival counters, [1] status
+    unsigned *sync = nullptr;          // device: [0] status, [1] the next token's tag
+    unsigned *shadow = nullptr;        // device: every launch's outputs as (tag << 16 | fp16 bits) words
     int n = 0, rows = 0, depth = 0, nw = 0, blocks = 0;
     bool z8 = false;
     size_t lds = 0;
@@ -634,25 +703,31 @@ void token_plan_destroy(TokenPlan *tp) {
     if (!tp) return;
     if (tp->launches) (void)hipFree(tp->launches);
     if (tp->sync) (void)hipFree(tp->sync);
+    if (tp->shadow) (void)hipFree(tp->shadow);
     delete tp;
 }
+
 
 namespace {
 template <int ROWS, int DEPTH, bool Z8>
 hipError_t token_setup(const TokenPlan &tp, int *max_blocks_per_cu) {
-    auto kfn = w4a16_gemv_token_kernel<ROWS, DEPTH, Z8>;
-    hipError_t e = set_lds(kfn, tp.lds);
-    if (e != hipSuccess) return e;
+    const void *kfn = reinterpret_cast<const void *>(w4a16_gemv_token_kernel<ROWS, DEPTH, Z8, 2>);
+    if (tp.lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tp.lds);
+        if (e != hipSuccess) return e;
+    }
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(max_blocks_per_cu, kfn, 64 * tp.nw, tp.lds);
 }
 template <int ROWS, int DEPTH, bool Z8>
 hipError_t token_launch(const TokenPlan &tp, hipStream_t stream) {
     TokenArgs a;
+    a.dbg = g_stream_mode == 2 ? g_stream_dbg : nullptr;  // captured when the plan is built
     a.launches = tp.launches;
     a.n_launches = tp.n;
-    a.arrive = tp.sync;
-    a.status = tp.sync + tp.n;
-    hipLaunchKernelGGL((w4a16_gemv_token_kernel<ROWS, DEPTH, Z8>), dim3(tp.blocks, 1, 1), dim3(64 * tp.nw, 1, 1), tp.lds, stream, a);
+    a.status = tp.sync;
+    a.epoch = tp.sync + 1;
+    hipLaunchKernelGGL((w4a16_gemv_token_kernel<ROWS, DEPTH, Z8, 2>), dim3(tp.blocks, 1, 1), dim3(64 * tp.nw, 1, 1), tp.lds, stream, a);
+    hipLaunchKernelGGL(token_epoch_kernel, dim3(1), dim3(1), 0, stream, tp.sync + 1);
     return hipGetLastError();
 }
 #define TCE_TOKEN_DISPATCH(FN, ...)                                                                 \
@@ -669,6 +744,7 @@ int token_plan_create(const tce_w4a16_desc *descs, const int32_t *groups, int n_
     int maxK = 0;
     for (int l = 0, off = 0; l < n_launches; off += groups[l], ++l) {
         if (!gemv_stream_supports(descs + off, groups[l])) return TCE_ERR_UNSUPPORTED_SHAPE;
+        if (descs[off].rmsnorm_gamma) return TCE_ERR_UNSUPPORTED_SHAPE;  // (the fused RMSNorm prologue reads x twice: not wired to the polled form)
         if (descs[off].K > maxK) maxK = descs[off].K;
     }
     TokenPlan *tpp = new (std::nothrow) TokenPlan();
@@ -696,7 +772,7 @@ int token_plan_create(const tce_w4a16_desc *descs, const int32_t *groups, int n_
             token_plan_destroy(tpp);
             return TCE_ERR_UNSUPPORTED_SHAPE;
         }
-    // every workgroup must be resident at once: the barrier between launches spins
+    // every workgroup must be resident at once: a launch spins until its producers have delivered
     int per_cu = 0;
     hipError_t e = TCE_TOKEN_DISPATCH(token_setup, tp, &per_cu);
     if (e == hipSuccess && per_cu < 1) {
@@ -705,10 +781,51 @@ int token_plan_create(const tce_w4a16_desc *descs, const int32_t *groups, int n_
     }
     if (per_cu < bpc) bpc = per_cu;
     tp.blocks = cus * bpc;
+    if (e == hipSuccess) {
+        // Who produces what: launch l's activation vector is looked up among the outputs of the launches in front of it, latest
+        // first (buffers are reused from layer to layer; the latest writer is the one stream order would have made visible).
+        // Found: the launch polls that producer's shadow words.  Not found: the vector comes from outside the plan and is simply read.
+        size_t words = 0;
+        std::vector<size_t> base(n_launches * TCE_MAX_GROUP, 0);
+        for (int l = 0; l < n_launches; ++l)
+            for (int i = 0; i < host[l].nseg; ++i) {
+                base[l * TCE_MAX_GROUP + i] = words;
+                const int n_out = (host[l].seg[i].epilogue & TCE_W4_SILU_MUL_PAIRS) ? host[l].seg[i].N / 2 : host[l].seg[i].N;
+                words += ((size_t)n_out + 63) & ~(size_t)63;
+            }
+        e = hipMalloc(reinterpret_cast<void **>(&tp.shadow), words * sizeof(unsigned));
+        if (e == hipSuccess) e = hipMemset(tp.shadow, 0, words * sizeof(unsigned));
+        for (int l = 0; l < n_launches && e == hipSuccess; ++l) {
+            StreamLaunch &L = host[l];
+            for (int i = 0; i < TCE_MAX_GROUP; ++i) L.C_tag[i] = i < L.nseg ? tp.shadow + base[l * TCE_MAX_GROUP + i] : nullptr;
+            L.A_tag = nullptr;
+            const char *a0 = reinterpret_cast<const char *>(L.A), *a1 = a0 + (size_t)L.K * 2;
+            for (int q = l - 1; q >= 0 && !L.A_tag; --q)
+                for (int i = 0; i < host[q].nseg; ++i) {
+                    const int n_out = (host[q].seg[i].epilogue & TCE_W4_SILU_MUL_PAIRS) ? host[q].seg[i].N / 2 : host[q].seg[i].N;
+                    const char *c0 = reinterpret_cast<const char *>(host[q].seg[i].C), *c1 = c0 + (size_t)n_out * 2;
+                    if (a0 >= c0 && a1 <= c1) {  // the whole vector lies inside this output (a prefix / slice of it is fine)
+                        if ((a0 - c0) % 16 != 0) {  // pieces of 8 values must stay 32-byte aligned in the shadow
+                            token_plan_destroy(tpp);
+                            return TCE_ERR_UNSUPPORTED_SHAPE;
+                        }
+                        L.A_tag = host[q].C_tag[i] + (a0 - c0) / 2;
+                        break;
+                    }
+                    if (a0 < c1 && a1 > c0) {  // straddles an output: produced in pieces, not something a poll of one shadow can wait for
+                        token_plan_destroy(tpp);
+                        return TCE_ERR_UNSUPPORTED_SHAPE;
+                    }
+                }
+        }
+    }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&tp.launches), sizeof(StreamLaunch) * n_launches);
     if (e == hipSuccess) e = hipMemcpy(tp.launches, host.data(), sizeof(StreamLaunch) * n_launches, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&tp.sync), sizeof(unsigned) * (n_launches + 1));
-    if (e == hipSuccess) e = hipMemset(tp.sync, 0, sizeof(unsigned) * (n_launches + 1));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&tp.sync), sizeof(unsigned) * 2);
+    if (e == hipSuccess) {
+        const unsigned init[2] = {0u, 1u};  // status clear; the first token's tag
+        e = hipMemcpy(tp.sync, init, sizeof(init), hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) {
         if (hip_err) *hip_err = e;
         token_plan_destroy(tpp);
@@ -718,11 +835,10 @@ int token_plan_create(const tce_w4a16_desc *descs, const int32_t *groups, int n_
     return TCE_OK;
 }
 
-// Enqueues the token: the arrival counters are cleared, then one kernel runs the whole list.
+// Enqueues the token: one kernel runs the whole list, a one-thread kernel behind it advances the tag.
 int token_plan_enqueue(TokenPlan *tpp, hipStream_t stream, hipError_t *hip_err) {
     const TokenPlan &tp = *tpp;
-    hipError_t e = hipMemsetAsync(tp.sync, 0, sizeof(unsigned) * tp.n, stream);
-    if (e == hipSuccess) e = TCE_TOKEN_DISPATCH(token_launch, tp, stream);
+    hipError_t e = TCE_TOKEN_DISPATCH(token_launch, tp, stream);
     if (e != hipSuccess) {
         if (hip_err) *hip_err = e;
         return TCE_ERR_HIP;
@@ -731,7 +847,7 @@ int token_plan_enqueue(TokenPlan *tpp, hipStream_t stream, hipError_t *hip_err) 
 }
 
 int token_plan_status(TokenPlan *tp, unsigned *status, hipError_t *hip_err) {
-    const hipError_t e = hipMemcpy(status, tp->sync + tp->n, sizeof(unsigned), hipMemcpyDeviceToHost);
+    const hipError_t e = hipMemcpy(status, tp->sync, sizeof(unsigned), hipMemcpyDeviceToHost);
     if (e != hipSuccess) {
         if (hip_err) *hip_err = e;
         return TCE_ERR_HIP;

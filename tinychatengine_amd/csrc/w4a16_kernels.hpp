@@ -58,13 +58,18 @@ struct StreamLaunch {
     GemvSeg seg[TCE_MAX_GROUP];  // block_begin = first row group of the linear
     const float *gamma;          // non-null: stage RMSNorm(A) * gamma instead of A (generalT5LayerNorm arithmetic)
     float eps;
+    // tagged token plans only (w4a16_gemv_stream.hip): the activation as (tag << 16 | fp16 bits) words written by the launch of
+    // the same plan that produces it (null: A comes from outside the plan, read at once), and where this launch's outputs go in
+    // that form (per linear; null: nobody inside the plan reads them)
+    const unsigned *A_tag;
+    unsigned *C_tag[TCE_MAX_GROUP];
 };
 void set_gemv_stream_config(int rows, int nw, int depth);
 void set_gemv_stream_debug(int mode, void *buf);
 bool gemv_stream_supports(const tce_w4a16_desc *descs, int count);
 int launch_w4a16_gemv_stream(const tce_w4a16_desc *descs, int count, hipStream_t stream, hipError_t *hip_err,
                              const float *gamma = nullptr, float eps = 0.f);
-// token plans: a list of launches walked by ONE persistent kernel with device-wide barriers in between
+// token plans: a list of launches walked by ONE persistent kernel, the data flow between them ordered by tagged output words
 struct TokenPlan;
 int token_plan_create(const tce_w4a16_desc *descs, const int32_t *groups, int n_launches, TokenPlan **out, hipError_t *hip_err);
 int token_plan_enqueue(TokenPlan *tp, hipStream_t stream, hipError_t *hip_err);

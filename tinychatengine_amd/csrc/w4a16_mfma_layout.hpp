@@ -15,15 +15,19 @@
 //                                            nibble order inside a word: [e0 e2 e4 e6 e1 e3 e5 e7], so that the four mask
 //                                            extractions  w & 0x000F000F, w & 0x00F000F0, (w>>8) & 0x000F000F, (w>>8) & 0x00F000F0
 //                                            yield the halves (e0,e1), (e2,e3), (e4,e5), (e6,e7): natural k order, 9 VALU per word
-//   consts  {f32 ratio, u32 zc} [NT16][K/G][16]   per (row, group): ratio = e[g-1] / e[g] with e[g] the EFFECTIVE scale of group
-//                                            g (the fp16 scale, or -- for a group whose scale is 0 -- the previous effective
-//                                            scale; such a group's codes are rewritten to its zero point, so it contributes
-//                                            exactly 0 either way); zc = packed halves (-(1024 + z), -(64 + z)): the exact
-//                                            zero-point removal constants of the two nibble positions
-//   last    f32 [NT16][16]                   e[last group]: the kernel keeps its accumulator in units of the CURRENT group's
-//                                            scale (acc <- acc * ratio before a group's MFMAs accumulate into it) and multiplies
-//                                            by `last` once at the end:  sum_g s_g * blk_g  ==  e_last * (((blk_0 r_1 + blk_1) r_2 + ...)
-//   rows past N (N % 16 != 0) are zero-filled tiles rows: codes = 8, zc for z = 8, ratio 1, last 0.
+//   consts  {f32 e, u32 zc} [NT16][K/G][16]  per (row, group): e = the EFFECTIVE scale of group g (the fp16 scale as fp32, or -- for a
+//                                            group whose scale is 0 -- the previous group's effective scale (for leading zero-scale
+//                                            groups: the row's first non-zero scale; 1.0 for an all-zero row);
+//                                            such a group's codes are rewritten to its zero point, so it contributes exactly 0
+//                                            either way); zc = packed halves (-(1024 + z), -(64 + z)): the exact zero-point removal
+//                                            constants of the two nibble positions.
+//                                            The kernel keeps its accumulator in units of the CURRENT group's scale: before a group's
+//                                            MFMAs accumulate into it, acc <- acc * (e_prev / e_g) (one v_rcp-free fp32 divide per
+//                                            group per lane, computed from two consecutive consts), and multiplies by e of the last
+//                                            group once at the end:  sum_g s_g * blk_g  ==  e_last * (((blk_0 r_1 + blk_1) r_2 + ...)
+//   last    f32 [NT16][16]                   e of the row's last group (written by the prepack for tools and tests; the kernel carries
+//                                            the value it needs in a register: a k-split wave quartet ends on ITS last group)
+//   rows past N (N % 16 != 0) are zero-filled tile rows: codes = 8, zc for z = 8, e = 1, last = 0.
 #pragma once
 #include <stddef.h>
 #include <stdint.h>

@@ -9,9 +9,11 @@
 // each rounded separately (this file is compiled with -ffp-contract=off AND uses __fmul_rn/__fadd_rn), round() is
 // half-away-from-zero, the clamp happens on the rounded value before narrowing.
 //
-// Layout: A int8 [M][K], B int8 [N][K] -- both K-contiguous, which is exactly the MFMA i8 fragment shape: lane l
-// feeds 16 consecutive k of row (l & 15), k-block (l >> 4), i.e. one 16-byte load per lane per MFMA and no LDS.
-// (Any assignment of k to MFMA slots is legal as long as A and B agree, so no swizzle is needed.)
+// Layout: A int8 [M][K], B int8 [N][K] -- both K-contiguous, which is the MFMA i8 fragment shape: lane l feeds 16
+// consecutive k of row (l & 15), k-block (l >> 4).  (Any assignment of k to MFMA slots is legal as long as A and B agree,
+// so no swizzle of the DATA is needed.)  The MFMA kernel below nevertheless loads row-major 64-byte row pieces (four
+// lanes per row: full cache lines) and transposes them to fragment order through a per-wave 1 KiB LDS slot; the
+// direct fragment-shaped load (16 bytes per lane, 16 rows x 4 k-blocks apart) touched 16 cache lines per request.
 #include "tce_common.hpp"
 
 namespace tce {
@@ -45,6 +47,8 @@ __device__ __forceinline__ void epilogue_store(const W8A8Args &a, void *Cb, int 
     if (a.out_kind == TCE_OUT_INT8) {
         if (a.bias_kind == TCE_BIAS_INT8) v = __fadd_rn(v, u);
         float r = roundf(v);  // half away from zero (std::round)
+        // the reference narrows to int32 first and clamps the integer (matmul_ref_int8.cc:32-34); clamping the rounded float and
+        // narrowing afterwards gives the same int8 for every |v| < 2^31 -- beyond that the reference's float -> int32 cast is UB
         r = fmaxf(r, (float)a.q_min);
         r = fminf(r, (float)a.q_max);
         static_cast<int8_t *>(Cb)[(size_t)m * a.N + n] = (int8_t)(int)r;

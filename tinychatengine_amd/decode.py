@@ -45,22 +45,22 @@ SHAPES = {
 }
 
 
-def _synthetic_linear(n: int, k: int, seed: int, device, group_size: int, rank: int, world: int) -> Linear_half_int4:
-    """W ~ N(0, 0.02^2) fp32 [N][K], quantized with the reference's q4_6 recipe; rank keeps rows
+def _synthetic_linear(n: int, k: int, seed: int, device, group_size: int, rank: int, world: int, std: float = 0.02) -> Linear_half_int4:
+    """W ~ N(0, std^2) fp32 [N][K] (std = 0.02: SURVEY section 8d), quantized with the reference's q4_6 recipe; rank keeps rows
     [rank*N/P, (rank+1)*N/P).  The matrix is defined in eight row blocks, each drawn from its own seed, so a rank generates
     ONLY the blocks it owns (1/P of the fp32 matrix, not all of it) and every world size in {1, 2, 4, 8} sees the same values."""
     n_loc = n // world
     blocks = 8 if (n % 8 == 0 and 8 % world == 0) else 1
     if blocks == 1:  # odd sizes (tests): draw everything, keep the slice
         g = torch.Generator(device=device).manual_seed(seed)
-        w = torch.empty((n, k), dtype=torch.float32, device=device).normal_(0.0, 0.02, generator=g)[rank * n_loc:(rank + 1) * n_loc]
+        w = torch.empty((n, k), dtype=torch.float32, device=device).normal_(0.0, std, generator=g)[rank * n_loc:(rank + 1) * n_loc]
     else:
         rows = n // blocks
         per_rank = blocks // world
         w = torch.empty((n_loc, k), dtype=torch.float32, device=device)
         for j in range(per_rank):
             g = torch.Generator(device=device).manual_seed(seed * 8 + rank * per_rank + j)
-            w[j * rows:(j + 1) * rows].normal_(0.0, 0.02, generator=g)
+            w[j * rows:(j + 1) * rows].normal_(0.0, std, generator=g)
     lin = Linear_half_int4.from_float(w.contiguous(), group_size)
     del w
     return lin
@@ -70,8 +70,17 @@ class DecodeLinears:
     """All W4A16 linears of one decode token for rank `rank` of `world`, plus the launch list / plan to run them."""
 
     def __init__(self, shape: ModelShape, device="cuda", group_size: int = 128, rank: int = 0, world: int = 1,
-                 m: int = 1, seed: int = 1234, layers: int | None = None):
+                 m: int = 1, seed: int = 1234, layers: int | None = None, dataflow: bool = False):
+        """dataflow = False: every linear reads its own fixed synthetic activation vector (the launches are ordered by the
+        stream only).  dataflow = True (world 1, M = 1): the linears FEED each other the way they do in the decoder --
+        x -> qkv; o reads the q slice of qkv's output (the attention between them is not part of this path and same-sized);
+        o -> gate, up; gate's output -> down (standing in for silu(gate) * up, same size); down -> the next block's qkv;
+        the last down -> lm_head.  Same shapes, same bytes, same launch list; W ~ N(0, 1/K) instead of N(0, 0.02^2) so that the
+        activations stay O(1) down the 129-linear chain.  This is the form TCE_PLAN_TAGGED needs: it orders the data flow."""
         self.shape, self.rank, self.world, self.m, self.group_size = shape, rank, world, m, group_size
+        self.dataflow = dataflow
+        if dataflow and (world != 1 or m != 1 or shape.qkv[0] < shape.hidden):
+            raise ValueError("dataflow wiring: world 1, M = 1, and a first qkv linear at least `hidden` wide")
         self.device = torch.device(device)
         self._host_ok = self.device.type != "cuda"  # CPU tests of the sharding logic build descriptors for host tensors
         L = shape.layers if layers is None else layers
@@ -80,7 +89,7 @@ class DecodeLinears:
         for n in (*shape.qkv, h, f, shape.vocab):
             if n % world or (n // world) % 16:
                 raise ValueError(f"N={n} does not shard {world}-way into multiples of 16 rows")
-        mk = lambda n, k, s: _synthetic_linear(n, k, seed + s, self.device, group_size, rank, world)
+        mk = lambda n, k, s: _synthetic_linear(n, k, seed + s, self.device, group_size, rank, world, std=(k ** -0.5 if dataflow else 0.02))
         self.blocks = []
         for li in range(L):
             s = li * 16
@@ -100,6 +109,8 @@ class DecodeLinears:
         self.out_qkv = [e(n // W) for n in shape.qkv]
         self.out_o, self.out_gate, self.out_up, self.out_down = e(h // W), e(f // W), e(f // W), e(h // W)
         self.logits = e(shape.vocab // W)
+        if dataflow:
+            self.attn, self.h2, self.act = self.out_qkv[0][:, :h], self.out_o, self.out_gate
         # gather targets (world > 1)
         if W > 1 or os.environ.get("TCE_FORCE_GATHER_BUFFERS"):
             self.g_qkv = [e(n) for n in shape.qkv]
@@ -108,8 +119,9 @@ class DecodeLinears:
     # ---- descriptors ----
     def block_launches(self, li: int) -> list[list[capi.W4A16Desc]]:
         b = self.blocks[li]
+        x = self.out_down if self.dataflow and li > 0 else self.x  # dataflow: the previous block's down_proj output
         return [
-            [l.desc(self.x, o, allow_host=self._host_ok) for l, o in zip(b["qkv"], self.out_qkv)],
+            [l.desc(x, o, allow_host=self._host_ok) for l, o in zip(b["qkv"], self.out_qkv)],
             [b["o"].desc(self.attn, self.out_o, allow_host=self._host_ok)],
             [b["gate"].desc(self.h2, self.out_gate, allow_host=self._host_ok), b["up"].desc(self.h2, self.out_up, allow_host=self._host_ok)],
             [b["down"].desc(self.act, self.out_down, allow_host=self._host_ok)],
@@ -119,7 +131,7 @@ class DecodeLinears:
         out = []
         for li in range(self.n_layers):
             out += self.block_launches(li)
-        out.append([self.lm_head.desc(self.x, self.logits, allow_host=self._host_ok)])
+        out.append([self.lm_head.desc(self.out_down if self.dataflow else self.x, self.logits, allow_host=self._host_ok)])
         if not grouped:  # one launch per linear, as the reference issues them
             out = [[d] for g in out for d in g]
         return out
@@ -134,8 +146,8 @@ class DecodeLinears:
         """Algorithmic HBM bytes of one token on THIS rank (SURVEY §8d formula, summed over its linears)."""
         return sum(capi.algorithmic_bytes(self.m, l.out_features, l.in_features, self.group_size) for l in self.all_linears())
 
-    def make_plan(self, grouped: bool = True) -> capi.Plan:
-        return capi.Plan(self.token_launches(grouped))
+    def make_plan(self, grouped: bool = True, tagged: bool = False) -> capi.Plan:
+        return capi.Plan(self.token_launches(grouped), tagged=tagged)
 
     # ---- eager issue (used inside torch graph capture for world > 1, and by tests) ----
     @staticmethod
