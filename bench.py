@@ -411,11 +411,48 @@ def main():
     dl = DecodeLinears(shape, device=dev, group_size=G, rank=rank, world=world, m=1, layers=args.layers,
                        dataflow=(world == 1 and not args.ungrouped and shape.qkv[0] >= shape.hidden))
     if dist is not None and args.gather == "peer":
-        def exchange(handle: bytes):
-            got = [None] * world
-            dist.all_gather_object(got, handle)
-            return got
-        dl.attach_peer_comm(exchange)
+        # The peer-write gather needs every rank's window mapped into every other rank (hipIpc) and one exchange to come back right.
+        # Every step is agreed on by ALL ranks (a rank that failed alone would leave the others waiting); otherwise: RCCL.
+        def agree(ok: bool) -> bool:
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item())
+        comm, handle, why = None, b"", ""
+        try:
+            n_max = max(*shape.qkv, shape.hidden, shape.ffn, shape.vocab)
+            comm = capi.Comm(rank, world, n_max, slots=8)
+            handle = comm.export()
+        except Exception as e:  # noqa: BLE001
+            why = f"window: {type(e).__name__}: {e}"
+        got = [None] * world
+        dist.all_gather_object(got, handle)
+        ok = comm is not None and all(h for h in got)
+        if ok:
+            try:
+                comm.connect(got)
+            except Exception as e:  # noqa: BLE001
+                ok, why = False, f"connect: {type(e).__name__}: {e}"
+        if agree(ok):
+            try:  # slot 7, a known pattern: rank r contributes r + 1
+                part = dl.out_down.view(-1)
+                part.fill_(float(rank + 1))
+                comm.allgather(7, part.data_ptr(), dl.g_down.data_ptr(), dl.g_down.numel(), torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+                want = torch.arange(1, world + 1, device=dev).repeat_interleave(part.numel()).to(torch.float16)
+                ok = comm.status() == 0 and torch.equal(dl.g_down.view(-1), want)
+                if not ok:
+                    why = f"test exchange: status {comm.status()}"
+            except Exception as e:  # noqa: BLE001
+                ok, why = False, f"test exchange: {type(e).__name__}: {e}"
+            ok = agree(ok)
+        if ok:
+            dl.comm = comm
+        else:
+            if why:
+                print(f"[bench] rank {rank}: peer-write gather not available ({why}); using RCCL all-gathers", file=sys.stderr)
+            elif rank == 0:
+                print("[bench] peer-write gather not available on another rank; using RCCL all-gathers", file=sys.stderr)
+            args.gather = "rccl"
     torch.cuda.synchronize()
     stream = torch.cuda.current_stream().cuda_stream
 

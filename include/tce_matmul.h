@@ -262,8 +262,10 @@ TCE_API int tce_plan_create(const tce_w4a16_desc *descs, const int32_t *group_si
  * What is ordered is therefore the plan's DATA FLOW (and, transitively, everything in front of it), not the launch list as
  * such: launches that do not feed each other may overlap.  Outputs are bit-identical to the stream-ordered plan.
  * Not taken (the plan is then built stream-ordered; tce_plan_is_chained tells: 0 stream-ordered, 2 token kernel): a launch that
- * is not an M = 1 GEMV the persistent kernel takes, a launch with the fused RMSNorm prologue, an activation vector that
- * straddles two outputs or starts at an odd 16-byte offset.  tce_plan_status synchronises the device and returns TCE_ERR_HIP
+ * is not an M = 1 GEMV the persistent kernel takes; an activation vector that straddles two outputs or starts at an odd
+ * 16-byte offset; a launch list in which a launch overwrites memory that an earlier launch reads un-tagged (activations from
+ * outside the plan, the old value of TCE_W4_ADD_TO_C) or also writes WITHOUT being downstream of that launch in the data
+ * flow -- stream order would protect such a hazard by position, polls do not.  tce_plan_status synchronises the device and returns TCE_ERR_HIP
  * if a wait ever timed out (~0.3 s; cannot happen unless the device is shared with a kernel that never ends).
  * tce_plan_geometry reports what the token kernel runs with (rows per row group, ring depth, waves per workgroup, workgroups).
  * Measured (MI355X, Llama-2-7B-shaped token): the primitive is cheap -- 1.8 us per bare hand-off against 2.0 us for a kernel

@@ -235,14 +235,57 @@ def test_tagged_plan_decoder_block_dataflow(dev, oracle):
     tagged.close()
 
 
-def test_tagged_plan_falls_back_for_the_fused_rmsnorm_prologue(dev, oracle):
+def test_tagged_plan_with_the_fused_rmsnorm_prologue(dev, oracle):
+    """A consumer whose activations go through the fused RMSNorm prologue (two passes over x: both from the polled copy in LDS)."""
     from tinychatengine_amd import capi
-    launches, bufs, keep, wts = _mlp_chain(dev, oracle, [1024, 512, 256], 128, seed=4)
-    gamma = torch.ones(512, dtype=torch.float32, device=dev)
-    launches[1][0].rmsnorm_gamma = gamma.data_ptr()
-    launches[1][0].rmsnorm_eps = 1e-6
+    launches, bufs, keep, wts = _mlp_chain(dev, oracle, [1024, 512, 11008, 256], 128, seed=4)
+    gammas = [(1 + 0.1 * torch.randn(d, device=dev)).float() for d in (512, 11008)]
+    for l, g in zip(launches[1:], gammas):
+        l[0].rmsnorm_gamma = g.data_ptr()
+        l[0].rmsnorm_eps = 1e-6
+    capi.set_gemv_config(2, 8, 0, 2)
+    plain = capi.Plan(launches)
+    capi.set_gemv_config()
     plan = capi.Plan(launches, tagged=True)
+    assert plan.tagged and not plain.chained
+    s = torch.cuda.current_stream().cuda_stream
+    for it in range(10):
+        x0 = torch.randn((1, 1024), device=dev).to(torch.float16)
+        res = []
+        for p in (plain, plan):
+            for b in bufs[1:]:
+                b.fill_(float("nan"))
+            bufs[0].copy_(x0)
+            p.launch(s)
+            p.status()
+            res.append([b.cpu().numpy().copy() for b in bufs[1:]])
+        for a, b in zip(*res):
+            assert not np.isnan(b.astype(np.float32)).any()
+            assert np.array_equal(a.view(np.uint16), b.view(np.uint16)), f"replay {it}"
+    plain.close()
+    plan.close()
+
+
+def test_tagged_plan_is_not_taken_when_a_hazard_is_protected_by_position_only(dev, oracle):
+    """Launch 1 overwrites the vector launch 0 reads from outside the plan, and nothing makes launch 1 wait for launch 0 (its own
+    input is external too): stream order protects that, polls would not -- the plan must come out stream-ordered.  Same for an
+    output written twice by launches that do not feed each other."""
+    from tinychatengine_amd import capi
+    descs, outs, refs, keep = _group(dev, oracle, [256, 256], 256, 128, seed=9)
+    a, b = descs
+    other = torch.randn((1, 256), device=dev).to(torch.float16)
+    b.A = other.data_ptr()
+    b.C = a.A                                   # WAR: launch 1 writes what launch 0 reads
+    plan = capi.Plan([[a], [b]], tagged=True)
     assert not plan.chained
+    plan.close()
+    b.C = a.C                                   # WAW: both write the same output, neither feeds the other
+    plan = capi.Plan([[a], [b]], tagged=True)
+    assert not plan.chained
+    plan.close()
+    b.A, b.C = a.C, outs[1].data_ptr()          # and the plain chain is taken
+    plan = capi.Plan([[a], [b]], tagged=True)
+    assert plan.tagged
     plan.close()
 
 

@@ -228,12 +228,32 @@ def test_decoder_layer_linears_fused_in_plans(dev, oracle):
     for d in launches:
         capi.check(capi.w4a16_forward(d[0], s))
     check("direct")
-    for chained in (False, True):
-        plan = capi.Plan(launches, chained=chained)
-        assert plan.chained == chained
+    for tagged in (False, True):
+        # the token-kernel form is NOT taken for this list: o_proj (fixed `attn`, nothing to wait for) overwrites the hidden state
+        # that the q/k/v launch reads from outside the plan -- stream order protects that by position, tagged polls would not
+        plan = capi.Plan(launches, tagged=tagged)
+        assert not plan.chained
         for _ in range(3):
             hid_f.copy_(hid0); q_f.zero_(); act.zero_()
             plan.launch(s)
             plan.status()
-            check(f"plan chained={chained}")
+            check(f"plan tagged={tagged}")
         plan.close()
+
+    # --- the same four fused launches with o_proj fed by the q slice of the q/k/v output (in the model the attention sits between
+    #     them): now every hazard is downstream in the data flow, and the token kernel takes the list -- fused RMSNorm prologues,
+    #     SiLU-mul pairs and residual adds included.  Bit-identical to the launches issued one by one.
+    launches[1] = [o.desc(q_f[:, :h], hid_f, flags=capi.TCE_W4_ADD_TO_C)]
+    hid_f.copy_(hid0)
+    for d in launches:
+        capi.check(capi.w4a16_forward(d[0], s))
+    torch.cuda.synchronize()
+    want_hid, want_qkv = hid_f.cpu().numpy().copy(), q_f.cpu().numpy().copy()
+    plan = capi.Plan(launches, tagged=True)
+    assert plan.tagged
+    for it in range(5):
+        hid_f.copy_(hid0); q_f.fill_(float("nan")); act.fill_(float("nan"))
+        plan.launch(s)
+        plan.status()
+        check(f"token kernel, replay {it}")
+    plan.close()

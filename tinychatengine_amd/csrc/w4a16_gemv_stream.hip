@@ -279,16 +279,37 @@ __device__ __forceinline__ void gemv_launch_body(const StreamLaunch &L, const Ba
     stamp(1);
     if (L.gamma) {
         // fused RMSNorm prologue (generalT5LayerNorm, LlamaRMSNorm.cu:68-93): rs by the workgroup in the shape-independent
-        // order of rmsnorm_rs_block, then half(clamp((x * rs) * gamma)) goes into the image instead of x
-        // (coherent reads, like the image's: behind a barrier the row was written by other CUs moments ago)
-        const float rs = rmsnorm_rs_block([&](int p) { return __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_a, p * 16, 0, /*sc0|sc1*/ 17)); },
-                                          K, L.eps, wave, NW, lane, reinterpret_cast<float *>(smem + (size_t)T * (4096 + 256) + 256));
+        // order of rmsnorm_rs_block, then half(clamp((x * rs) * gamma)) goes into the image instead of x.
+        // Token kernel: the polled pieces are parked RAW in their own image slots first (a slot is written and later rewritten
+        // by the same thread), and both passes read them from there instead of from memory.
+        if (tagged_in) {
+#pragma unroll
+            for (int i = 0; i < XR; ++i) {
+                const int p = tid + i * nthreads;
+                if (p < total_pieces) xs[p] = xr[i];
+            }
+            for (int p = tid + XR * nthreads; p < total_pieces; p += nthreads) {  // long K only
+                const int k1[1] = {piece_halves(p)};
+                uint4_t one[1];
+                poll_pieces(std::integral_constant<int, 1>{}, k1, one);
+                xs[p] = one[0];
+            }
+            __syncthreads();
+        }
+        auto raw_piece = [&](int lin) -> half8_t {  // 8 activations k = 8 lin ..: image slot of (chunk lin / 4, quarter lin % 4)
+            if (tagged_in) {
+                const int c = lin >> 2, j = lin & 3;
+                return __builtin_bit_cast(half8_t, xs[(c >> 6) * 256 + j * 64 + (c & 63)]);
+            }
+            return __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_a, lin * 16, 0, /*sc0|sc1*/ 17));
+        };
+        const float rs = rmsnorm_rs_block(raw_piece, K, L.eps, wave, NW, lane, reinterpret_cast<float *>(smem + (size_t)T * (4096 + 256) + 256));
         for (int p = tid; p < total_pieces; p += nthreads) {
             const int c = (p >> 8) * 64 + (p & 63), j = (p >> 6) & 3;
             uint4_t o = uint4_t{0u, 0u, 0u, 0u};
             if (c < nchunks) {
                 const int k0 = c * 32 + j * 8;
-                const half8_t v = __builtin_bit_cast(half8_t, x_piece(p));
+                const half8_t v = __builtin_bit_cast(half8_t, tagged_in ? xs[p] : x_piece(p));
                 const float4_t g0 = *reinterpret_cast<const float4_t *>(L.gamma + k0), g1 = *reinterpret_cast<const float4_t *>(L.gamma + k0 + 4);
                 half8_t y;
 #pragma unroll
@@ -744,7 +765,6 @@ int token_plan_create(const tce_w4a16_desc *descs, const int32_t *groups, int n_
     int maxK = 0;
     for (int l = 0, off = 0; l < n_launches; off += groups[l], ++l) {
         if (!gemv_stream_supports(descs + off, groups[l])) return TCE_ERR_UNSUPPORTED_SHAPE;
-        if (descs[off].rmsnorm_gamma) return TCE_ERR_UNSUPPORTED_SHAPE;  // (the fused RMSNorm prologue reads x twice: not wired to the polled form)
         if (descs[off].K > maxK) maxK = descs[off].K;
     }
     TokenPlan *tpp = new (std::nothrow) TokenPlan();
@@ -795,6 +815,7 @@ int token_plan_create(const tce_w4a16_desc *descs, const int32_t *groups, int n_
             }
         e = hipMalloc(reinterpret_cast<void **>(&tp.shadow), words * sizeof(unsigned));
         if (e == hipSuccess) e = hipMemset(tp.shadow, 0, words * sizeof(unsigned));
+        std::vector<int> producer(n_launches, -1);
         for (int l = 0; l < n_launches && e == hipSuccess; ++l) {
             StreamLaunch &L = host[l];
             for (int i = 0; i < TCE_MAX_GROUP; ++i) L.C_tag[i] = i < L.nseg ? tp.shadow + base[l * TCE_MAX_GROUP + i] : nullptr;
@@ -810,6 +831,7 @@ int token_plan_create(const tce_w4a16_desc *descs, const int32_t *groups, int n_
                             return TCE_ERR_UNSUPPORTED_SHAPE;
                         }
                         L.A_tag = host[q].C_tag[i] + (a0 - c0) / 2;
+                        producer[l] = q;
                         break;
                     }
                     if (a0 < c1 && a1 > c0) {  // straddles an output: produced in pieces, not something a poll of one shadow can wait for
@@ -818,6 +840,39 @@ int token_plan_create(const tce_w4a16_desc *descs, const int32_t *groups, int n_
                     }
                 }
         }
+        // What the polls do NOT order: anti- and output dependences on the plain buffers.  A launch that writes memory which an
+        // earlier launch reads un-tagged (an activation vector from outside the plan; the old value of a residual add) or also
+        // writes must come after that launch THROUGH THE DATA FLOW -- a launch starts to compute when all of its producer's rows
+        // are there, every one of which was computed after that producer's own input was complete, and so on up the chain.
+        // A launch list whose stream order protects such a hazard by position only is not taken (built stream-ordered instead).
+        const size_t nw64 = ((size_t)n_launches + 63) / 64;
+        std::vector<uint64_t> anc((size_t)n_launches * nw64, 0);  // anc[l]: bit q = launch q is an ancestor of l in the data flow
+        for (int l = 0; l < n_launches; ++l)
+            if (producer[l] >= 0) {
+                const int q = producer[l];
+                for (size_t w = 0; w < nw64; ++w) anc[l * nw64 + w] = anc[q * nw64 + w];
+                anc[l * nw64 + (size_t)q / 64] |= 1ull << (q % 64);
+            }
+        auto n_out_of = [&](const StreamLaunch &L, int i) { return (L.seg[i].epilogue & TCE_W4_SILU_MUL_PAIRS) ? L.seg[i].N / 2 : L.seg[i].N; };
+        for (int l = 1; l < n_launches && e == hipSuccess; ++l)
+            for (int i = 0; i < host[l].nseg; ++i) {
+                const char *w0 = reinterpret_cast<const char *>(host[l].seg[i].C), *w1 = w0 + (size_t)n_out_of(host[l], i) * 2;
+                for (int q = 0; q < l; ++q) {
+                    bool touches = false;
+                    if (producer[q] < 0) {  // q read its activations un-tagged
+                        const char *r0 = reinterpret_cast<const char *>(host[q].A), *r1 = r0 + (size_t)host[q].K * 2;
+                        touches = r0 < w1 && r1 > w0;
+                    }
+                    for (int k = 0; k < host[q].nseg && !touches; ++k) {
+                        const char *c0 = reinterpret_cast<const char *>(host[q].seg[k].C), *c1 = c0 + (size_t)n_out_of(host[q], k) * 2;
+                        touches = c0 < w1 && c1 > w0;
+                    }
+                    if (touches && !((anc[l * nw64 + (size_t)q / 64] >> (q % 64)) & 1ull)) {
+                        token_plan_destroy(tpp);
+                        return TCE_ERR_UNSUPPORTED_SHAPE;
+                    }
+                }
+            }
     }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&tp.launches), sizeof(StreamLaunch) * n_launches);
     if (e == hipSuccess) e = hipMemcpy(tp.launches, host.data(), sizeof(StreamLaunch) * n_launches, hipMemcpyHostToDevice);
