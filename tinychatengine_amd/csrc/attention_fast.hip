@@ -241,8 +241,16 @@ __global__ __launch_bounds__(256) void attn_decode_fast_kernel(const FastAttnArg
 }  // namespace
 
 // chunk of keys per workgroup: heads x chunks should cover the chip a couple of times; a multiple of 16 (4 waves x 4 keys per step)
+static int g_attn_target_wgs = 256;  // tuning: tce_w4a16_set_debug_mode(3000 + workgroups)
+void set_attention_fast_target(int wgs) { g_attn_target_wgs = wgs >= 32 && wgs <= 8192 ? wgs : 256; }
+
+// Measured (scripts/attention_step_sweep.py, profiles/r2/attention_step_sweep.jsonl; caches rotating through > 256 MB so the keys come
+// from HBM): one workgroup per CU is the best cut at every context -- 2048 keys 12.0 us with 256 workgroups, 12.5 with 128, 14.8 with 512
+// (more partials to merge and shorter key runs per wave cost more than the extra loads in flight bring).  A combine without the
+// acknowledged-store -> atomic -> coherent-read chain (the head's last workgroup polling (value, tag) pairs) was tried and was
+// SLOWER (13.2 us): a poll is a full memory round trip, and the chain it replaces is three of them only on the LAST workgroup.
 static int pick_chunk(int heads, int keys) {
-    const int target_chunks = heads >= 256 ? 1 : 256 / heads;  // one workgroup per CU: fewer, longer key runs and fewer partials to merge
+    const int target_chunks = heads >= g_attn_target_wgs ? 1 : g_attn_target_wgs / heads;  // fewer, longer key runs and fewer partials to merge
     int chunk = (keys + target_chunks - 1) / target_chunks;
     chunk = (chunk + 15) & ~15;
     if (chunk < 64) chunk = 64;

@@ -114,6 +114,10 @@ int tce_w4a16_set_gemv_config(int rows, int wn, int wk, int depth) {
 }
 
 int tce_w4a16_set_debug_mode(int mode) {
+    if (mode >= 3000 && mode <= 3000 + 8192) {  // fast attention step: workgroups the key range is cut for (default 256)
+        tce::set_attention_fast_target(mode - 3000);
+        return TCE_OK;
+    }
     if (mode >= 1000 && mode <= 1256) {  // small-batch kernel: largest M it takes
         tce::set_skinny_max_m(mode - 1000);
         return TCE_OK;
