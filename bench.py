@@ -87,6 +87,7 @@ def other_configs_leg(torch, dev):
         return e0.elapsed_time(e1) * 1e3 / (reps * launches)
 
     out = {"w4a16_prefill_gemm_M512": [], "w4a16_prefill_gemm_M2048": [], "w8a8_opt125m": []}
+    scratch = torch.zeros(int(L.tce_w4a16_gemm_scratch_bytes()), dtype=torch.uint8, device=dev)  # lets the pre-packed GEMM split K across workgroups
     gen = torch.Generator(device=dev).manual_seed(1)
     for (N, K) in ((4096, 4096), (11008, 4096), (4096, 11008)):
         nsets = max(2, int(3e8 // (N * K // 2)))  # > 256 MiB of distinct weights: they come from HBM
@@ -112,7 +113,7 @@ def other_configs_leg(torch, dev):
             row = {"M": M, "N": N, "K": K}
             for name, with_pack in (("q4_6_only", False), ("prepacked", True)):
                 ds = [capi.W4A16Desc(M=M, N=N, K=K, group_size=128, A=x.data_ptr(), qweight=q.data_ptr(), scales=s_.data_ptr(), zeros=z.data_ptr(), C=y.data_ptr(),
-                                     prepacked=pk.data_ptr() if with_pack else None)
+                                     prepacked=pk.data_ptr() if with_pack else None, scratch=scratch.data_ptr() if with_pack else None)
                       for (q, s_, z), pk in zip(sets, packs)]
                 us = time_graph(lambda i, sp: capi.check(L.tce_w4a16_forward(C.byref(ds[i % len(ds)]), sp)), 16)
                 buf = C.create_string_buffer(256)

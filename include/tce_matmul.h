@@ -47,7 +47,7 @@ extern "C" {
 
 #define TCE_API __attribute__((visibility("default")))
 
-#define TCE_VERSION 101 /* 0.1.1: tce_w4a16_desc.prepacked, tce_w4a16_prepack* */
+#define TCE_VERSION 102 /* 0.1.2: tce_w4a16_desc.scratch (0.1.1: .prepacked, tce_w4a16_prepack*) */
 
 /* error codes (return values) */
 #define TCE_OK 0
@@ -91,6 +91,11 @@ typedef struct tce_w4a16_desc {
     const void *prepacked;                /* NULL = none.  The q4_mfma copy of this linear's weights built by tce_w4a16_prepack
                                              (same N, K, group size): the prefill GEMM for large M reads it instead of
                                              qweight / scales / zeros (which must still be valid: every other M uses them) */
+    void *scratch;                        /* NULL = none.  tce_w4a16_gemm_scratch_bytes() bytes of device memory, 256-byte aligned, its first 4096
+                                             bytes ZEROED once by the caller (every call leaves them zero): lets the pre-packed GEMM cut the k range of
+                                             a launch with few tiles (M = 512 at N = 4096 is 128 tiles for 256 CUs) across workgroups
+                                             and add the partial tiles in a fixed order.  One scratch area per stream that runs such
+                                             calls concurrently; calls on one stream may share it. */
 } tce_w4a16_desc;
 
 /* flags */
@@ -182,6 +187,7 @@ TCE_API int tce_w4a16_check_zero_point_8(const void *zeros, long long n_words);
  * `stream`; once per weight tensor.  A descriptor whose `prepacked` points at that copy lets tce_w4a16_forward run the 128-row
  * MFMA kernel (csrc/w4a16_gemm_pk.hip) for M >= 192; results stay within the W4A16 tolerance of every other path. */
 TCE_API size_t tce_w4a16_prepack_bytes(int N, int K, int group_size);
+TCE_API size_t tce_w4a16_gemm_scratch_bytes(void); /* size of tce_w4a16_desc.scratch (about 18 MiB) */
 TCE_API int tce_w4a16_prepack(const tce_w4a16_desc *d, void *packed, void *stream);
 
 /* count (<= TCE_MAX_GROUP) linears with identical M, K, group_size and A/lda, one launch (GEMV path only). */
@@ -349,7 +355,7 @@ TCE_API int tce_w4a16_set_gemv_config(int rows_per_wave, int waves_n, int waves_
  *   20..30   small-batch kernel: 20 automatic, 21 / 22 / 24 / 28 waves per tile, 30 shared-activation form, 29 off
  *   40..48   GEMM XCD grid rows: 40 automatic, 41 / 42 / 44 / 48 forced
  *   50..52   LDS-DMA GEMM wave quartets per tile: 50 automatic, 51 one, 52 two
- *   60..69   pre-packed 128-row GEMM: 60 automatic, 61 / 62 / 63 forced form (128x128 tile with one quartet / two quartets splitting K / 128x256 tile with two quartets side by side; taken for every M), 69 off
+ *   60..69   pre-packed 128-row GEMM: 60 automatic, 61 / 62 / 63 / 64 forced form (128x128 tile with one quartet / two quartets splitting K / 128x256 tile with two quartets side by side / 128x128 with the k range cut across workgroups when a scratch area is given; taken for every M), 69 off
  *   600+a    pre-packed GEMM, one quartet, with parts of its loop switched off (a: 1 rescale, 2 unpack, 4 fragment reads, 8 MFMAs,
  *            16 activation DMAs, 32 barriers; only the combinations scripts/gemm_pk_ablation.py uses are compiled); outputs meaningless
  *   70..74   W8A8 wave quartets per tile: 70 automatic, 71 / 72 / 74 forced

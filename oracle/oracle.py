@@ -33,6 +33,11 @@ def build(with_ref: bool | None = None) -> None:
         with_ref = os.path.isdir("/root/reference/kernels")
     if with_ref:
         subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+        # the reference's own level-2 callers linked against this repository's adapter (oracle/_ref/l2_harness; tests/test_l2_link.py);
+        # needs libtce_hip.so, i.e. tinychatengine_amd.build first -- skipped quietly when that has not run yet
+        lib = os.path.join(_HERE, "..", "tinychatengine_amd", "lib", "libtce_hip.so")
+        if os.path.exists(lib) and os.path.isdir("/root/reference/llm/src/ops"):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "l2link"])
 
 
 def _p(a: np.ndarray | None):

@@ -47,12 +47,12 @@ for (N, K) in shapes:
             it[0] += 1
 
         row = {"M": M, "N": N, "K": K}
-        for name, mode in (("dma", 69), ("pk1", 61), ("pk2", 62), ("pk3", 63), ("auto", 60)):
+        for name, mode in (("dma", 69), ("pk1", 61), ("pk2", 62), ("pk3", 63), ("pk4", 64), ("auto", 60)):
             L.tce_w4a16_set_debug_mode(mode)
             us, med = timed(run)
             row[name + "_us"] = round(us, 2)
             row[name + "_TF"] = round(2.0 * M * N * K / us / 1e6, 1)
-            if name == "auto":
-                row["auto_dispatch"] = capi.describe_dispatch(descs[0])
+            if name in ("auto", "pk4"):
+                row[name + "_dispatch"] = capi.describe_dispatch(descs[0])
         L.tce_w4a16_set_debug_mode(60)
         print(json.dumps(row), flush=True)

@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(built):
     lib = built.lib()
     for s in declared:
         assert hasattr(lib, s)
-    assert lib.tce_version() == 101
+    assert lib.tce_version() == 102
     assert b"gfx950" in lib.tce_build_info()
 
 
@@ -52,7 +52,7 @@ def test_library_contains_gfx950_code_objects_only(built):
 
 
 def test_descriptor_sizes(built):
-    assert C.sizeof(built.W4A16Desc) == 104 and C.sizeof(built.W8A8Desc) == 104
+    assert C.sizeof(built.W4A16Desc) == 112 and C.sizeof(built.W8A8Desc) == 104
 
 
 def test_argument_validation_needs_no_gpu(built):

@@ -88,6 +88,7 @@ PK_SHAPES = [
     # M, N, K, G
     (256, 256, 512, 128), (200, 136, 384, 128), (513, 2100, 256, 128), (128, 128, 128, 128), (300, 264, 1024, 64), (192, 200, 512, 32),
     (384, 520, 1408 + 128 * 5, 128),
+    (260, 300, 1408, 64), (700, 392, 3072, 32),  # uneven runs when the k range is cut across workgroups (11 k-blocks in 2; 24 in 3 / 4), groups of 64 / 32
 ]
 
 
@@ -105,7 +106,7 @@ def test_pk_gemm_matches_oracle(dev, oracle, M, N, K, G):
         lin = _lin(dev, qw, sc, zp, G).prepack()
         x = torch.from_numpy(a).to(dev)
         try:
-            for mode in (61, 62, 63, 60):
+            for mode in (61, 62, 63, 64, 60):  # 64: the k range cut across workgroups (needs the scratch area desc() attaches)
                 capi.check(L.tce_w4a16_set_debug_mode(mode))
                 out = torch.full((M, N), float("nan"), dtype=torch.float16, device=dev)
                 d = lin.desc(x, out)
@@ -167,7 +168,16 @@ def test_pk_dispatch_rules(dev, oracle):
         d.M, d.N, d.K, d.lda, d.ldc = M, N, K, K, N
         return capi.describe_dispatch(d).split()[0]
     assert decision(2048, 4096, 4096) == decision(512, 11008, 4096) == decision(4096, 4096, 11008) == "gemm-pk"
-    assert decision(512, 4096, 4096) == "gemm-dma" and decision(128, 11008, 4096) != "gemm-pk"
+    assert decision(128, 11008, 4096) != "gemm-pk"
+    # few tiles (M = 512 at N = 4096: 128 tiles for 256 CUs): with a scratch area the k range is cut across workgroups, without one the
+    # 64-row kernel keeps the launch
+    d = lin.desc(x, out)
+    d.M, d.N, d.K, d.lda, d.ldc = 512, 4096, 4096, 4096, 4096
+    assert d.scratch and "ksplit=2" in capi.describe_dispatch(d), capi.describe_dispatch(d)
+    d.K = d.lda = 11008
+    assert "ksplit=2" in capi.describe_dispatch(d)
+    d.scratch = None
+    assert capi.describe_dispatch(d).startswith("gemm-dma")
     assert capi.describe_dispatch(lin.desc(x[:1], out[:1])).startswith("gemv")
     assert int(capi.lib().tce_w4a16_prepack_bytes(256, 1440, 32)) == 0
 
@@ -184,13 +194,17 @@ def test_full_size_prefill_on_the_packed_kernel(dev, oracle, N, K):
     xh = torch.empty(M // 2, K, device=dev).normal_(0, 1, generator=g).to(torch.float16)
     x = torch.cat([xh, xh], dim=0).contiguous()
     y = torch.full((M, N), float("nan"), dtype=torch.float16, device=dev)
-    try:  # the automatic rule keeps the 64-row tiles for M = 512 at N = 4096: the packed kernel is asked for by name
-        capi.check(capi.lib().tce_w4a16_set_debug_mode(61 if N == 4096 else 60))
-        assert capi.describe_dispatch(lin.desc(x, y)).startswith("gemm-pk")
+    what = capi.describe_dispatch(lin.desc(x, y))
+    assert what.startswith("gemm-pk") and (("ksplit=2" in what) == (N == 4096)), what  # N = 4096: 128 tiles, k range cut across workgroups
+    for rep in range(3):  # (the scratch counters must be back to zero after every call)
+        y.fill_(float("nan"))
         lin.forward(x, y)
         torch.cuda.synchronize()
-    finally:
-        capi.lib().tce_w4a16_set_debug_mode(60)
+        if rep:
+            assert torch.equal(y, y_first)
+        y_first = y.clone()
+    from tinychatengine_amd.linear import gemm_scratch
+    assert int(gemm_scratch(dev)[:4096].to(torch.int32).sum().item()) == 0
     assert torch.equal(y[: M // 2], y[M // 2:]), "duplicate rows must produce identical outputs"
     rows = [r for r in range(0, 512) if (r % 4) == ((r // 64) % 4)]
     ref32 = oracle.w4a16_gemv_q4_6_mt(x[rows].cpu().numpy(), lin.weight.cpu().numpy().view(np.uint32), lin.scale.cpu().numpy(),

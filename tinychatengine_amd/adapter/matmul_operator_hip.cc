@@ -76,6 +76,25 @@ const void *packed_copy(const tce_w4a16_desc &d) {
     return e.workspace;
 }
 
+// tce_w4a16_desc.scratch: one area for the process (the adapter launches on the null stream, so its calls are ordered), its counter
+// words zeroed once
+void *gemm_scratch() {
+    static void *area = nullptr;
+    static bool tried = false;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!tried) {
+        tried = true;
+        const size_t need = tce_w4a16_gemm_scratch_bytes();
+        void *p = nullptr;
+        if (need && tce_malloc(&p, need, /*managed=*/0) == TCE_OK) {
+            static const unsigned char zeros[4096] = {};
+            if (tce_memcpy(p, zeros, sizeof(zeros), TCE_MEMCPY_H2D, nullptr) == TCE_OK && tce_synchronize(nullptr) == TCE_OK) area = p;
+            else tce_free(p);
+        }
+    }
+    return area;
+}
+
 // TCE_W4_ZERO_POINT_IS_8 fast path: checked once per zero-point tensor
 int zeros_are_8(const void *zeros, long long words) {
     const TensorKey key{zeros, words, 0, 0};
@@ -142,7 +161,10 @@ void MatmulOperator::gemv_forward_cuda(const struct matmul_params *params) {
         const int zw = (((d.K / d.group_size + 7) / 8) + mult - 1) / mult * mult;
         if (d.zeros && zeros_are_8(d.zeros, (long long)d.N * zw)) d.flags |= TCE_W4_ZERO_POINT_IS_8;
     }
-    if (d.M >= kPackMinM && d.K % 128 == 0 && d.A && d.qweight && d.scales && d.zeros) d.prepacked = packed_copy(d);
+    if (d.M >= kPackMinM && d.K % 128 == 0 && d.A && d.qweight && d.scales && d.zeros) {
+        d.prepacked = packed_copy(d);
+        if (d.prepacked) d.scratch = gemm_scratch();
+    }
     const int rc = tce_w4a16_forward(&d, nullptr);
     if (rc == TCE_ERR_UNSUPPORTED_GROUP) {
         std::printf("Unsupported group size: %d\n", params->block_size);  // the reference's own message

@@ -77,12 +77,13 @@ constexpr int kPkMinM = 192;  // below: the 64-row tiles / the small-batch kerne
 // the pre-packed 128-row GEMM takes the launch when a packed copy came with the descriptor and the batch is large enough
 static bool use_pk(const tce_w4a16_desc *d, bool want_gemm) {
     if (!d->prepacked || g_pk_mode == 9 || !want_gemm || d->K % 128 != 0 || (d->flags & TCE_W4_SILU_MUL_PAIRS) || d->rmsnorm_gamma) return false;
-    if (g_pk_mode >= 1 && g_pk_mode <= 3) return true;
+    if (g_pk_mode >= 1 && g_pk_mode <= 4) return true;
     if (d->M < kPkMinM || g_gemm_mt != 0) return false;
     // both dispatchers' cost models, fitted to the same kind of sweep (the 64-row tiles win while the 128-row tiles are too few
     // to fill the chip: M = 512 at N = 4096); groups of 64 / 32: the pre-packed kernel needs no LDS re-deal, it takes them
     if (d->group_size != 128) return true;
-    return tce::gemm_pk_estimate_us(d->M, d->N, d->K, nullptr) < tce::gemm_dma_estimate_us(d->M, d->N, d->K) + 1.5f;
+    const bool has_scratch = d->scratch != nullptr && (reinterpret_cast<uintptr_t>(d->scratch) & 255) == 0;
+    return tce::gemm_pk_estimate_us(d->M, d->N, d->K, nullptr, has_scratch) < tce::gemm_dma_estimate_us(d->M, d->N, d->K) + 1.5f;
 }
 
 int g_gemv_kernel = 0;  // 0 automatic, 1 workgroup-per-row-block kernel forced, 2 persistent stream kernel forced
@@ -135,7 +136,7 @@ int tce_w4a16_set_debug_mode(int mode) {
     if (mode >= 60 && mode <= 69) {  // pre-packed 128-row GEMM: 60 automatic, 61 / 62 forced quartets, 69 off
         g_pk_mode = mode - 60;
         tce::set_gemm_pk_ablation(0);
-        tce::set_gemm_pk_mode(g_pk_mode >= 1 && g_pk_mode <= 3 ? g_pk_mode : 0, 0);
+        tce::set_gemm_pk_mode(g_pk_mode >= 1 && g_pk_mode <= 4 ? g_pk_mode : 0, 0);
         return TCE_OK;
     }
     if (mode >= 50 && mode <= 52) {  // LDS-DMA GEMM: wave quartets per tile (50 automatic)
@@ -373,9 +374,10 @@ int tce_w4a16_describe_dispatch(const tce_w4a16_desc *d, char *buf, int buf_len)
     const bool want_gemm = (d->flags & TCE_W4_FORCE_GEMM) ||
                            (d->M > TCE_W4A16_GEMV_MAX_M && !(d->flags & (TCE_W4_FORCE_GEMV | TCE_W4_SILU_MUL_PAIRS)));
     if (use_pk(d, want_gemm)) {
-        int form = 1;
-        tce::gemm_pk_estimate_us(d->M, d->N, d->K, &form);
-        std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=128x%d quartets=%d group=%d", form == 3 ? 256 : 128, form == 1 ? 1 : 2, d->group_size);
+        int form = 1, split = 1;
+        tce::gemm_pk_estimate_us(d->M, d->N, d->K, &form, d->scratch != nullptr && (reinterpret_cast<uintptr_t>(d->scratch) & 255) == 0, &split);
+        if (form == 4) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=128x128 quartets=1 ksplit=%d group=%d", split, d->group_size);
+        else std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=128x%d quartets=%d group=%d", form == 3 ? 256 : 128, form == 1 ? 1 : 2, d->group_size);
         return TCE_OK;
     }
     if (g_skinny_enabled && !(d->flags & (TCE_W4_FORCE_GEMV | TCE_W4_FORCE_GEMM)) && tce::skinny_supports(*d)) {
@@ -400,6 +402,8 @@ int tce_w4a16_describe_dispatch(const tce_w4a16_desc *d, char *buf, int buf_len)
 }
 
 size_t tce_w4a16_prepack_bytes(int N, int K, int G) { return tce::prepack_bytes(N, K, G); }
+
+size_t tce_w4a16_gemm_scratch_bytes(void) { return tce::gemm_pk_scratch_bytes(); }
 
 int tce_w4a16_prepack(const tce_w4a16_desc *d, void *packed, void *stream) {
     if (!d || !packed) return fail(TCE_ERR_BAD_ARG, "tce_w4a16_prepack: null argument");

@@ -114,6 +114,9 @@ struct PkGemmArgs {
     int n_blocks, m_blocks;  // 128 x 128 tiles
     int add_to_c;
     int xm, m_per, n_per;
+    int split_s;          // > 1: every tile's k-blocks are cut into split_s runs, one workgroup each (one quartet, 128 x 128 tiles only)
+    unsigned *counters;   // [tiles], zero between launches (scratch)
+    float4_t *partials;   // [tiles][split_s][16 accumulators][256 threads] fp32 x 4 (scratch)
 };
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -161,7 +164,14 @@ __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(23
     constexpr int QUARTET_BYTES = 4 * pk::kHalfBytes;  // ring of four half-stages
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const int bid = blockIdx.x;
+    // K split across workgroups: part p of a tile is workgroup p * (grid / split_s) + (the tile's index): bid % 8 -- the XCD the
+    // hardware puts a workgroup on -- stays what the tile mapping below assumes
+    int bid = blockIdx.x, part = 0;
+    if (KS == 1 && NS == 1 && g.split_s > 1) {
+        const int per = 8 * g.m_per * g.n_per;
+        part = bid / per;
+        bid -= part * per;
+    }
     const int xcd = bid & 7, slot = bid >> 3;
     const int m_blk = (xcd % g.xm) * g.m_per + slot % g.m_per;
     const int n_blk = (xcd / g.xm) * g.n_per + slot / g.m_per;
@@ -175,7 +185,9 @@ __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(23
     const int n16 = lane & 15, q = lane >> 4;
     const int m_base = m_blk * 128, nb0 = n_blk * BN;
     const int nkb = g.K >> 7;
-    const int T = (nkb + KS - 1) / KS;  // iterations (own k-blocks, the last one may be past K for quartet 1)
+    const int split = (KS == 1 && NS == 1 && g.split_s > 1) ? g.split_s : 1;
+    const int kb_lo = part * nkb / split, nloc = (part + 1) * nkb / split - kb_lo;  // this workgroup's run of k-blocks
+    const int T = (nloc + KS - 1) / KS;  // iterations (own k-blocks, the last one may be past the run for quartet 1)
 
     // ---- DMA sources of a half-stage: instruction ii of this wave fills 8 rows; the lane fetches the piece that belongs at its position ----
     // (uniform 64-bit base + 32-bit lane offset: the address arithmetic of a refill is scalar; the host checked M * lda * 2 < 4 GiB)
@@ -192,7 +204,7 @@ __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(23
     auto issue_half = [&](int h) {
         if constexpr (ABL & 16) return;
         int kb = grp + (h >> 1) * KS;
-        kb = kb < nkb ? kb : nkb - 1;
+        kb = kb_lo + (kb < nloc ? kb : nloc - 1);
         const char *src = a_bytes + ((size_t)kb * 256 + (h & 1) * 128);  // wave-uniform
         unsigned char *st = ring + (h & 3) * pk::kHalfBytes;
 #pragma unroll
@@ -236,7 +248,7 @@ __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(23
     BlockRegs cur;
     auto block_of = [&](int t) {
         const int kb = grp + t * KS;
-        return kb < nkb ? kb : nkb - 1;
+        return kb_lo + (kb < nloc ? kb : nloc - 1);
     };
     // the first block's registers by ordinary loads (the compiler waits for them), everything later by inline asm one block ahead
     {
@@ -390,7 +402,7 @@ __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(23
     load_e(cur);
 
     for (int t = 0; t < T; ++t) {
-        const bool live = grp + t * KS < nkb;  // wave-uniform; only quartet 1's last iteration can be past K
+        const bool live = grp + t * KS < nloc;  // wave-uniform; only quartet 1's last iteration can be past the run
         const unsigned char *st_even = ring + ((2 * t) & 3) * pk::kHalfBytes, *st_odd = ring + ((2 * t + 1) & 3) * pk::kHalfBytes;
         const unsigned char *st_even_next = ring + ((2 * t + 2) & 3) * pk::kHalfBytes;
         if (live) {
@@ -454,6 +466,61 @@ __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(23
         __syncthreads();
     }
 
+    if (KS == 1 && NS == 1 && split > 1) {
+        // ---- K split across workgroups: the run's partial tile (true units, fp32) goes to the scratch area with write-through stores;
+        //      the workgroup that arrives LAST at the tile's counter adds the split_s partials in run order -- so the sum does not
+        //      depend on who was last -- and stores the tile.  (Same visibility
+        //      rules as the fast attention step's chunk merge: acknowledged device-scope stores, then the counter, then coherent loads.)
+        const int tile_lin = n_blk * g.m_blocks + m_blk;
+        float4_t *mine = g.partials + ((size_t)tile_lin * split + part) * (kMT * kNT * 256);
+        const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(g.partials + (size_t)tile_lin * split * (kMT * kNT * 256), 0,
+                                                                               split * kMT * kNT * 256 * 16, 0x00020000);
+        (void)mine;
+#pragma unroll
+        for (int i = 0; i < kMT; ++i)
+#pragma unroll
+            for (int j = 0; j < kNT; ++j)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, acc[i][j]), rs_p, ((part * kMT * kNT + i * kNT + j) * 256 + tid) * 16, 0, /*sc0|sc1*/ 17);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned *flag = reinterpret_cast<unsigned *>(smem);
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(g.counters + tile_lin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned last = old == (unsigned)split - 1 ? 1u : 0u;
+            if (last) __hip_atomic_store(g.counters + tile_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+            *flag = last;
+        }
+        __syncthreads();
+        if (*flag == 0u) return;
+        __syncthreads();  // (the flag word is part of the output tile's LDS image below)
+        // the sum in run order 0, 1, ..., split_s - 1 whoever computes it: the other runs' partials from memory, its own from its registers
+        // (the same values it stored)
+        float4_t own[kMT][kNT];
+#pragma unroll
+        for (int i = 0; i < kMT; ++i)
+#pragma unroll
+            for (int j = 0; j < kNT; ++j) {
+                own[i][j] = acc[i][j];
+                acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+            }
+        for (int p = 0; p < split; ++p) {
+            if (p == part) {  // workgroup-uniform
+#pragma unroll
+                for (int i = 0; i < kMT; ++i)
+#pragma unroll
+                    for (int j = 0; j < kNT; ++j) acc[i][j] += own[i][j];
+                continue;
+            }
+            uint4_t t4[kMT * kNT];
+#pragma unroll
+            for (int r = 0; r < kMT * kNT; ++r) t4[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_p, ((p * kMT * kNT + r) * 256 + tid) * 16, 0, /*sc0|sc1*/ 17);
+#pragma unroll
+            for (int i = 0; i < kMT; ++i)
+#pragma unroll
+                for (int j = 0; j < kNT; ++j) acc[i][j] += __builtin_bit_cast(float4_t, t4[i * kNT + j]);
+        }
+    }
+
     // ---- epilogue: the tile leaves through LDS as 16-byte row pieces (accumulator layout: lane = column n16, registers = 4 consecutive rows) ----
     half_t *lds_c = reinterpret_cast<half_t *>(smem);  // [128][BN]
     if (grp == 0) {
@@ -499,7 +566,7 @@ hipError_t launch_pk(PkGemmArgs &g, hipStream_t stream) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kfn, dim3(8 * g.m_per * g.n_per), dim3(256 * KS * NS), lds, stream, g);
+    hipLaunchKernelGGL(kfn, dim3(8 * g.m_per * g.n_per * (g.split_s > 1 ? g.split_s : 1)), dim3(256 * KS * NS), lds, stream, g);
     return hipGetLastError();
 }
 
@@ -508,7 +575,7 @@ hipError_t launch_pk(PkGemmArgs &g, hipStream_t stream) {
 void set_gemm_pk_ablation(int abl) { g_pk_abl = abl; }
 
 void set_gemm_pk_mode(int form, int xm) {
-    g_pk_ks = (form >= 1 && form <= 3) ? form : 0;
+    g_pk_ks = (form >= 1 && form <= 4) ? form : 0;
     g_pk_xm = (xm == 1 || xm == 2 || xm == 4 || xm == 8) ? xm : 0;
 }
 
@@ -549,7 +616,32 @@ int launch_w4a16_prepack(const tce_w4a16_desc &d, void *out, hipStream_t stream,
 // A workgroup's time per k-block c grows with the load on its CU and on the chip (f = resident waves / 2048); fitted to
 // profiles/r2/gemm_pk_sweep.jsonl: form 1 alone on its CU 1.06 us, sharing it 1.25 + 0.73 f; form 2 per PAIR of k-blocks
 // 1.7 + 0.4 f; form 3 (every active CU carries eight waves) 1.55 + 0.4 f; + 3 us of launch, prologue and epilogue.
-float gemm_pk_estimate_us(int M, int N, int K, int *form_out) {
+// Scratch for the K split across workgroups (form 4): [4 KiB of tile counters][kPkSplitMaxUnits partial tiles of 64 KiB].
+constexpr int kPkSplitMaxUnits = 288;
+size_t gemm_pk_scratch_bytes() { return 4096 + (size_t)kPkSplitMaxUnits * 65536; }
+
+// form 4 = form 1 with every tile's k-blocks cut into s runs on s workgroups (partial tiles added through the scratch area in a fixed
+// order): for launches whose 128 x 128 tiles are too few for 256 CUs -- M = 512 at N = 4096 is 128 tiles.  One quartet alone on a CU
+// walks a k-block in 1.06 us; the exchange costs what a dozen k-blocks cost, so the form pays from K ~ 6000 up (4096 x 11008 at
+// M = 512: 69 -> 56 us) and is a tie at K = 4096.
+static int pk_split_factor(long tiles1, int nkb, bool has_scratch, float *cost_out) {
+    int best_s = 1;
+    float best = 1e30f;
+    if (has_scratch && tiles1 <= 1024)
+        for (int s = 2; s <= 4; ++s) {
+            if (tiles1 * s > kPkSplitMaxUnits || nkb / s < 4) continue;
+            // fitted to profiles/r2/gemm_pk_ksplit_sweep.jsonl: a run of k-blocks at the lone-quartet rate (units that have to share a CU:
+            // two runs back to back) + 3 us of launch / prologue / epilogue + 5 + 1.3 s us for the exchange (64 KiB per unit written
+            // through to memory -- 16 MB per launch --, the counter, the other partials read back)
+            const float run = (float)((nkb + s - 1) / s);
+            const float c = (tiles1 * s <= 256 ? run * 1.06f : 2.0f * run) + 8.0f + 1.3f * (float)s;
+            if (c < best) best = c, best_s = s;
+        }
+    if (cost_out) *cost_out = best;
+    return best_s;
+}
+
+float gemm_pk_estimate_us(int M, int N, int K, int *form_out, bool has_scratch, int *split_out) {
     const long mt = (M + 127) / 128;
     const long tiles1 = mt * ((N + 127) / 128), tiles3 = mt * ((N + 255) / 256);
     const float nkb = (float)(K / 128);
@@ -561,15 +653,19 @@ float gemm_pk_estimate_us(int M, int N, int K, int *form_out) {
     const float cost1 = (tiles1 <= 256 ? nkb * 1.06f : rounds(tiles1, 512) * nkb * (1.25f + 0.73f * load(tiles1 * 4))) + 3.0f;
     const float cost2 = rounds(tiles1, 256) * (nkb * 0.5f) * (1.7f + 0.4f * load(tiles1 * 8)) + 3.0f;
     const float cost3 = rounds(tiles3, 256) * nkb * (1.55f + 0.4f * load(tiles3 * 8)) + 3.0f;
+    float cost4 = 1e30f;
+    const int split = pk_split_factor(tiles1, (int)nkb, has_scratch, &cost4);
     int form = 1;
     float best = cost1;
     if (cost2 < best) best = cost2, form = 2;
     if (cost3 < best) best = cost3, form = 3;
+    if (cost4 < best) best = cost4, form = 4;
     if (g_pk_ks) {
-        form = g_pk_ks;
-        best = form == 1 ? cost1 : (form == 2 ? cost2 : cost3);
+        form = g_pk_ks == 4 && split == 1 ? 1 : g_pk_ks;
+        best = form == 1 ? cost1 : (form == 2 ? cost2 : (form == 3 ? cost3 : cost4));
     }
     if (form_out) *form_out = form;
+    if (split_out) *split_out = form == 4 ? split : 1;
     return best;
 }
 
@@ -589,8 +685,17 @@ int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_
     g.lda = lda;
     g.ldc = d.ldc ? d.ldc : d.N;
     g.add_to_c = (d.flags & TCE_W4_ADD_TO_C) ? 1 : 0;
-    int form = 1;
-    gemm_pk_estimate_us(d.M, d.N, d.K, &form);
+    int form = 1, split = 1;
+    const bool has_scratch = d.scratch != nullptr && (reinterpret_cast<uintptr_t>(d.scratch) & 255) == 0;
+    gemm_pk_estimate_us(d.M, d.N, d.K, &form, has_scratch, &split);
+    if (form == 4) {
+        form = 1;
+        g.split_s = split;
+        g.counters = static_cast<unsigned *>(d.scratch);
+        g.partials = reinterpret_cast<float4_t *>(static_cast<unsigned char *>(d.scratch) + 4096);
+    } else {
+        g.split_s = 1;
+    }
     const int bn = form == 3 ? 256 : 128;
     g.n_blocks = (d.N + bn - 1) / bn;
     g.m_blocks = (d.M + 127) / 128;

@@ -11,6 +11,18 @@ from . import capi, quantize
 from .matmul import MatmulOperator, matmul_params, matrix, _ptr, _stream
 
 
+_gemm_scratch: dict = {}
+
+
+def gemm_scratch(device) -> torch.Tensor:
+    """tce_w4a16_desc.scratch for `device`: one zeroed area shared by every linear (their calls are ordered by the stream the harness
+    uses; a host that runs prefill GEMMs on several streams at once gives each stream its own)."""
+    key = str(device)
+    if key not in _gemm_scratch:
+        _gemm_scratch[key] = torch.zeros(int(capi.lib().tce_w4a16_gemm_scratch_bytes()), dtype=torch.uint8, device=device)
+    return _gemm_scratch[key]
+
+
 class Linear_half_int4:
     """W4A16 linear on the q4_6 layout.  Mirrors Linear_half_int4 (linear.h:186-221 / linear.cu:5-40)."""
 
@@ -78,7 +90,8 @@ class Linear_half_int4:
                               qweight=self.weight.data_ptr(), scales=self.scale.data_ptr(), zeros=self.zero_point.data_ptr(),
                               C=out.data_ptr(), ldc=ldc, flags=flags | (capi.TCE_W4_ZERO_POINT_IS_8 if self.zeros_are_8 else 0),
                               rmsnorm_gamma=gamma.data_ptr() if gamma is not None else None, rmsnorm_eps=float(eps),
-                              prepacked=self.packed.data_ptr() if self.packed is not None else None)
+                              prepacked=self.packed.data_ptr() if self.packed is not None else None,
+                              scratch=gemm_scratch(self.weight.device).data_ptr() if self.packed is not None and m >= 192 else None)
 
     @classmethod
     def interleave(cls, gate: "Linear_half_int4", up: "Linear_half_int4") -> "Linear_half_int4":
