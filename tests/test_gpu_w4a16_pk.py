@@ -146,6 +146,50 @@ def test_pk_gemm_add_to_c_and_strides(dev, oracle):
     assert w4a16_close(plain.cpu().numpy(), ref32)[0]
 
 
+def test_pk_gemm_with_the_tail_tiles_cut(dev, oracle):
+    """More than 256 tiles: the first 256 run whole, the k-blocks of the others as short runs beside them (partials through the
+    scratch area, fixed order).  260 tiles here; every row of two row blocks against the oracle, all rows against the one-quartet form."""
+    from tinychatengine_amd import capi
+    M, N, K, G = 640, 6656, 1024, 128
+    qw, sc, zp = _quant(oracle, N, K, G, seed=77, random_zeros=True, zero_scale_groups=3)
+    lin = _lin(dev, qw, sc, zp, G).prepack()
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal((M, K)).astype(np.float16)
+    x = torch.from_numpy(a).to(dev)
+    out = torch.full((M, N), float("nan"), dtype=torch.float16, device=dev)
+    d = lin.desc(x, out)
+    st = torch.cuda.current_stream().cuda_stream
+    try:
+        capi.check(capi.lib().tce_w4a16_set_debug_mode(64))  # "cut the k range" by name (the automatic rule decides by its cost model)
+        assert "of-the-tiles-past-256" in capi.describe_dispatch(d), capi.describe_dispatch(d)
+        for rep in range(3):
+            out.fill_(float("nan"))
+            capi.check(capi.w4a16_forward(d, st))
+            torch.cuda.synchronize()
+            got = out.cpu().numpy()
+            assert not np.isnan(got.astype(np.float32)).any()
+            if rep:
+                assert np.array_equal(got.view(np.uint16), first.view(np.uint16)), "the sum must not depend on which workgroup arrives last"
+            first = got
+    finally:
+        capi.lib().tce_w4a16_set_debug_mode(60)
+    rows = list(range(0, 128)) + list(range(512, 640))
+    ref32 = oracle.w4a16_gemv_q4_6_mt(a[rows], qw, sc, zp, len(rows), N, K, G)
+    ok, worst = w4a16_close(got[rows], ref32)
+    assert ok, worst
+    try:  # the whole-tile form on the same inputs: the cut tiles differ from it by fp32 reassociation only
+        capi.check(capi.lib().tce_w4a16_set_debug_mode(61))
+        out2 = torch.empty_like(out)
+        capi.check(capi.w4a16_forward(lin.desc(x, out2), st))
+        torch.cuda.synchronize()
+    finally:
+        capi.lib().tce_w4a16_set_debug_mode(60)
+    whole = out2.cpu().numpy().astype(np.float32)
+    assert np.abs(got.astype(np.float32) - whole).max() <= 2e-3 * np.abs(whole).max()
+    from tinychatengine_amd.linear import gemm_scratch
+    assert int(gemm_scratch(dev)[:4096].to(torch.int32).sum().item()) == 0
+
+
 def test_pk_dispatch_rules(dev, oracle):
     """No packed copy -> the other kernels; M < 192 -> the other kernels; in between the two GEMMs' cost models decide (the 64-row
     tiles keep M = 512 at N = 4096, where 128-row tiles are too few to fill 256 CUs); K % 128 != 0 -> no packed form at all."""
@@ -195,7 +239,8 @@ def test_full_size_prefill_on_the_packed_kernel(dev, oracle, N, K):
     x = torch.cat([xh, xh], dim=0).contiguous()
     y = torch.full((M, N), float("nan"), dtype=torch.float16, device=dev)
     what = capi.describe_dispatch(lin.desc(x, y))
-    assert what.startswith("gemm-pk") and (("ksplit=2" in what) == (N == 4096)), what  # N = 4096: 128 tiles, k range cut across workgroups
+    # N = 4096: 128 tiles, every tile's k range cut in two; N = 11008: 344 tiles, the 88 past the first 256 cut in two (one run per CU at most)
+    assert what.startswith("gemm-pk") and ("ksplit=2 " in what if N == 4096 else "ksplit=2-of-the-tiles-past-256" in what), what
     for rep in range(3):  # (the scratch counters must be back to zero after every call)
         y.fill_(float("nan"))
         lin.forward(x, y)

@@ -127,6 +127,13 @@ int tce_w4a16_set_debug_mode(int mode) {
         tce::set_w8a8_ksplit(mode - 70);
         return TCE_OK;
     }
+    if (mode >= 640 && mode <= 644) {  // pre-packed GEMM, k range cut across workgroups: runs per cut tile forced (640: the cost model's choice)
+        g_pk_mode = 4;
+        tce::set_gemm_pk_ablation(0);
+        tce::set_gemm_pk_mode(4, 0);
+        tce::set_gemm_pk_split(mode - 640);
+        return TCE_OK;
+    }
     if (mode >= 600 && mode < 664) {  // pre-packed GEMM with parts of its loop switched off (timing experiments, one quartet)
         g_pk_mode = mode == 600 ? 0 : 1;
         tce::set_gemm_pk_mode(mode == 600 ? 0 : 1, 0);
@@ -135,6 +142,7 @@ int tce_w4a16_set_debug_mode(int mode) {
     }
     if (mode >= 60 && mode <= 69) {  // pre-packed 128-row GEMM: 60 automatic, 61 / 62 forced quartets, 69 off
         g_pk_mode = mode - 60;
+        tce::set_gemm_pk_split(0);
         tce::set_gemm_pk_ablation(0);
         tce::set_gemm_pk_mode(g_pk_mode >= 1 && g_pk_mode <= 4 ? g_pk_mode : 0, 0);
         return TCE_OK;
@@ -377,6 +385,7 @@ int tce_w4a16_describe_dispatch(const tce_w4a16_desc *d, char *buf, int buf_len)
         int form = 1, split = 1;
         tce::gemm_pk_estimate_us(d->M, d->N, d->K, &form, d->scratch != nullptr && (reinterpret_cast<uintptr_t>(d->scratch) & 255) == 0, &split);
         if (form == 4) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=128x128 quartets=1 ksplit=%d group=%d", split, d->group_size);
+        else if (form == 5) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=128x128 quartets=1 ksplit=%d-of-the-tiles-past-256 group=%d", split, d->group_size);
         else std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=128x%d quartets=%d group=%d", form == 3 ? 256 : 128, form == 1 ? 1 : 2, d->group_size);
         return TCE_OK;
     }

@@ -114,9 +114,10 @@ struct PkGemmArgs {
     int n_blocks, m_blocks;  // 128 x 128 tiles
     int add_to_c;
     int xm, m_per, n_per;
-    int split_s;          // > 1: every tile's k-blocks are cut into split_s runs, one workgroup each (one quartet, 128 x 128 tiles only)
-    unsigned *counters;   // [tiles], zero between launches (scratch)
-    float4_t *partials;   // [tiles][split_s][16 accumulators][256 threads] fp32 x 4 (scratch)
+    int split_s;          // > 1: the k-blocks of the tiles in slots >= full_slots are cut into split_s runs, one workgroup each (one quartet,
+    int full_slots;       //      128 x 128 tiles only); slot = workgroup index / 8 of the tile's first run.  0: every tile is cut
+    unsigned *counters;   // [cut tiles], zero between launches (scratch)
+    float4_t *partials;   // [cut tiles][split_s][16 accumulators][256 threads] fp32 x 4 (scratch)
 };
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -166,11 +167,17 @@ __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(23
 
     // K split across workgroups: part p of a tile is workgroup p * (grid / split_s) + (the tile's index): bid % 8 -- the XCD the
     // hardware puts a workgroup on -- stays what the tile mapping below assumes
+    // Which tiles are cut: those in slots >= full_slots, i.e. the ones whose first runs are dispatched LAST -- a launch of 344 tiles
+    // runs 256 whole tiles (one per CU) and the k-blocks of the other 88 as 3 x 88 short runs beside them, instead of two whole tiles
+    // on 88 CUs and one on the rest.
     int bid = blockIdx.x, part = 0;
     if (KS == 1 && NS == 1 && g.split_s > 1) {
         const int per = 8 * g.m_per * g.n_per;
-        part = bid / per;
-        bid -= part * per;
+        if (bid >= per) {
+            const int tail_wgs = per - 8 * g.full_slots, e = bid - per;
+            part = 1 + e / tail_wgs;
+            bid = 8 * g.full_slots + (e - (part - 1) * tail_wgs);
+        }
     }
     const int xcd = bid & 7, slot = bid >> 3;
     const int m_blk = (xcd % g.xm) * g.m_per + slot % g.m_per;
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(23
     const int n16 = lane & 15, q = lane >> 4;
     const int m_base = m_blk * 128, nb0 = n_blk * BN;
     const int nkb = g.K >> 7;
-    const int split = (KS == 1 && NS == 1 && g.split_s > 1) ? g.split_s : 1;
+    const int split = (KS == 1 && NS == 1 && g.split_s > 1 && slot >= g.full_slots) ? g.split_s : 1;
     const int kb_lo = part * nkb / split, nloc = (part + 1) * nkb / split - kb_lo;  // this workgroup's run of k-blocks
     const int T = (nloc + KS - 1) / KS;  // iterations (own k-blocks, the last one may be past the run for quartet 1)
 
@@ -471,7 +478,7 @@ __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(23
         //      the workgroup that arrives LAST at the tile's counter adds the split_s partials in run order -- so the sum does not
         //      depend on who was last -- and stores the tile.  (Same visibility
         //      rules as the fast attention step's chunk merge: acknowledged device-scope stores, then the counter, then coherent loads.)
-        const int tile_lin = n_blk * g.m_blocks + m_blk;
+        const int tile_lin = bid - 8 * g.full_slots;  // index among the cut tiles (holes of the grid included)
         float4_t *mine = g.partials + ((size_t)tile_lin * split + part) * (kMT * kNT * 256);
         const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(g.partials + (size_t)tile_lin * split * (kMT * kNT * 256), 0,
                                                                                split * kMT * kNT * 256 * 16, 0x00020000);
@@ -557,6 +564,7 @@ __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(23
 int g_pk_ks = 0;  // 0: choose per launch, 1 / 2: forced (tuning)
 int g_pk_xm = 0;
 int g_pk_abl = 0;  // timing experiments: parts of the loop switched off (one quartet, groups of 128 only)
+int g_pk_split_force = 0;  // tuning: the number of runs a cut tile's k range is divided into (0: the cost model's choice)
 
 template <int KS, int LG, int ABL = 0, int NS = 1>
 hipError_t launch_pk(PkGemmArgs &g, hipStream_t stream) {
@@ -566,13 +574,15 @@ hipError_t launch_pk(PkGemmArgs &g, hipStream_t stream) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kfn, dim3(8 * g.m_per * g.n_per * (g.split_s > 1 ? g.split_s : 1)), dim3(256 * KS * NS), lds, stream, g);
+    const int per = 8 * g.m_per * g.n_per;
+    hipLaunchKernelGGL(kfn, dim3(g.split_s > 1 ? per + (per - 8 * g.full_slots) * (g.split_s - 1) : per), dim3(256 * KS * NS), lds, stream, g);
     return hipGetLastError();
 }
 
 }  // namespace
 
 void set_gemm_pk_ablation(int abl) { g_pk_abl = abl; }
+void set_gemm_pk_split(int s) { g_pk_split_force = s >= 2 && s <= 4 ? s : 0; }
 
 void set_gemm_pk_mode(int form, int xm) {
     g_pk_ks = (form >= 1 && form <= 4) ? form : 0;
@@ -654,18 +664,35 @@ float gemm_pk_estimate_us(int M, int N, int K, int *form_out, bool has_scratch, 
     const float cost2 = rounds(tiles1, 256) * (nkb * 0.5f) * (1.7f + 0.4f * load(tiles1 * 8)) + 3.0f;
     const float cost3 = rounds(tiles3, 256) * nkb * (1.55f + 0.4f * load(tiles3 * 8)) + 3.0f;
     float cost4 = 1e30f;
-    const int split = pk_split_factor(tiles1, (int)nkb, has_scratch, &cost4);
+    int split = pk_split_factor(tiles1, (int)nkb, has_scratch, &cost4);
+    // form 5: 256 whole tiles, one per CU, and the k-blocks of the other tiles1 - 256 as s short runs beside them (each CU: a whole tile
+    // and ~one run).  While a run shares the CU both quartets walk a k-block in ~1.9 us, afterwards the whole tile is alone again (1.06).
+    float cost5 = 1e30f;
+    int split5 = 1;
+    if (has_scratch && tiles1 > 256 && tiles1 <= 256 + kPkSplitMaxUnits / 2) {
+        const long tail = tiles1 - 256;
+        for (int s5 = 2; s5 <= 4; ++s5) {
+            // at most one run per CU: 344 tiles cut in 3 (264 runs, 520 workgroups for 512 slots) measured 60 us against 53 us cut in 2
+            // and 56 us whole, while 320 and 336 tiles cut in 3 (192 / 240 runs) run 45-46 us (profiles/r2/gemm_pk_tail_cut_probe.jsonl)
+            if ((tail + 7) / 8 * 8 * s5 > 256 || (int)nkb / s5 < 4 || (g_pk_split_force && s5 != g_pk_split_force)) continue;
+            const float run = (float)(((int)nkb + s5 - 1) / s5);  // k-blocks during which a CU carries a run beside its whole tile
+            const float c = run * 1.9f + (nkb - run) * 1.06f + 4.0f;
+            if (c < cost5) cost5 = c, split5 = s5;
+        }
+    }
     int form = 1;
     float best = cost1;
     if (cost2 < best) best = cost2, form = 2;
     if (cost3 < best) best = cost3, form = 3;
     if (cost4 < best) best = cost4, form = 4;
+    if (cost5 < best) best = cost5, form = 5;
     if (g_pk_ks) {
-        form = g_pk_ks == 4 && split == 1 ? 1 : g_pk_ks;
-        best = form == 1 ? cost1 : (form == 2 ? cost2 : (form == 3 ? cost3 : cost4));
+        form = g_pk_ks;
+        if (form == 4 && split == 1) form = split5 > 1 ? 5 : 1;  // "cut the k range": whichever of the two cut forms applies
+        best = form == 1 ? cost1 : (form == 2 ? cost2 : (form == 3 ? cost3 : (form == 4 ? cost4 : cost5)));
     }
     if (form_out) *form_out = form;
-    if (split_out) *split_out = form == 4 ? split : 1;
+    if (split_out) *split_out = form == 4 ? split : (form == 5 ? split5 : 1);
     return best;
 }
 
@@ -688,7 +715,8 @@ int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_
     int form = 1, split = 1;
     const bool has_scratch = d.scratch != nullptr && (reinterpret_cast<uintptr_t>(d.scratch) & 255) == 0;
     gemm_pk_estimate_us(d.M, d.N, d.K, &form, has_scratch, &split);
-    if (form == 4) {
+    const bool cut_tail_only = form == 5;
+    if (form == 4 || form == 5) {
         form = 1;
         g.split_s = split;
         g.counters = static_cast<unsigned *>(d.scratch);
@@ -711,6 +739,11 @@ int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_
     g.xm = g_pk_xm ? g_pk_xm : best_xm;
     g.m_per = (g.m_blocks + g.xm - 1) / g.xm;
     g.n_per = (g.n_blocks + 8 / g.xm - 1) / (8 / g.xm);
+    if (g.split_s > 1) {
+        g.full_slots = cut_tail_only ? 32 : 0;  // 32 slots x 8 XCDs = the first 256 workgroups
+        const int cut_wgs = 8 * (g.m_per * g.n_per - g.full_slots);
+        if (cut_wgs <= 0 || (long)cut_wgs * g.split_s > kPkSplitMaxUnits || cut_wgs > 1024) g.split_s = 1;  // does not fit the scratch area: whole tiles
+    }
     const int ks = form;
     hipError_t e;
     const int lg = d.group_size == 128 ? 7 : (d.group_size == 64 ? 6 : 5);

@@ -106,6 +106,7 @@ int launch_w4a16_prepack(const tce_w4a16_desc &d, void *out, hipStream_t stream,
 int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_t stream, hipError_t *hip_err);
 float gemm_pk_estimate_us(int M, int N, int K, int *form_out, bool has_scratch = false, int *split_out = nullptr);
 size_t gemm_pk_scratch_bytes();
+void set_gemm_pk_split(int s);
 void set_gemm_pk_mode(int ks, int xm);
 void set_gemm_pk_ablation(int abl);  // timing experiments (results meaningless): see w4a16_gemm_pk_kernel  // tuning: forced wave quartets per tile / XCD rows (0 = automatic)
 
