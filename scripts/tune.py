@@ -22,6 +22,9 @@ from tinychatengine_amd import capi, quantize  # noqa: E402
 dev = torch.device("cuda:0")
 
 
+Z8_FLAG = capi.TCE_W4_ZERO_POINT_IS_8 if os.environ.get("TCE_TUNE_Z8", "1") != "0" else 0
+
+
 def ring(N, K, G, min_bytes=1.2e9, max_sets=256):
     per = N * K // 2
     n = int(max(4, min(max_sets, -(-min_bytes // per))))
@@ -64,12 +67,14 @@ def sweep_gemv(shapes, variants, M=1, G=128, launches=128):
         arrs = []
         for i in range(nset):
             ds = [capi.W4A16Desc(M=M, N=n, K=K, group_size=G, A=x.data_ptr(), qweight=rings[j][i][0].data_ptr(),
-                                 scales=rings[j][i][1].data_ptr(), zeros=rings[j][i][2].data_ptr(), C=outs[j].data_ptr())
+                                 scales=rings[j][i][1].data_ptr(), zeros=rings[j][i][2].data_ptr(), C=outs[j].data_ptr(),
+                                 flags=Z8_FLAG)  # the flag the adapter / bench set after tce_w4a16_check_zero_point_8 (TCE_TUNE_Z8=0: without)
                   for j, n in enumerate(segs)]
             arrs.append((capi.W4A16Desc * len(ds))(*ds))
         nbytes = sum(capi.algorithmic_bytes(M, n, K, G) for n in segs)
         best = None
-        for v in [None] + variants:
+        # "auto" first AND last: the first timing after allocating a ring runs up to 10 % slow; persistent geometries (waves_k = 0) too
+        for v in [None] + variants + [(2, 16, 0, 2), (4, 16, 0, 2), (1, 16, 0, 3)] + [None]:
             try:
                 capi.set_gemv_config(*(v or (0, 0, 0, 0)))
                 rc = L.tce_w4a16_forward_group(arrs[0], len(segs), C.c_void_p(torch.cuda.current_stream().cuda_stream))
@@ -110,7 +115,8 @@ def experiments():
                 arrs = []
                 for i in range(nset):
                     ds = [capi.W4A16Desc(M=1, N=n, K=K, group_size=128, A=x.data_ptr(), qweight=rings[j][i][0].data_ptr(),
-                                         scales=rings[j][i][1].data_ptr(), zeros=rings[j][i][2].data_ptr(), C=outs[j].data_ptr())
+                                         scales=rings[j][i][1].data_ptr(), zeros=rings[j][i][2].data_ptr(), C=outs[j].data_ptr(),
+                                 flags=Z8_FLAG)  # the flag the adapter / bench set after tce_w4a16_check_zero_point_8 (TCE_TUNE_Z8=0: without)
                           for j, n in enumerate(segs)]
                     arrs.append((capi.W4A16Desc * len(ds))(*ds))
                 nbytes = sum(capi.algorithmic_bytes(1, n, K, 128) for n in segs)

@@ -163,6 +163,14 @@ int comm_connect_ipc(Comm *c, const void *handles, hipError_t *he) {
         }
         c->peer[p] = static_cast<unsigned char *>(ptr);
         c->ipc_opened[p] = true;
+        // the mapping must be usable from THIS device before a kernel stores through it (a bad mapping inside the gather kernel would
+        // be a GPU memory fault, i.e. the end of the process; a failed copy is an error code): read one flag word of the peer's window
+        unsigned probe = 0;
+        const hipError_t e2 = hipMemcpy(&probe, c->peer[p] + data_bytes(*c), sizeof(probe), hipMemcpyDeviceToHost);
+        if (e2 != hipSuccess) {
+            if (he) *he = e2;
+            return TCE_ERR_HIP;
+        }
     }
     return TCE_OK;
 }

@@ -86,6 +86,11 @@ static bool use_pk(const tce_w4a16_desc *d, bool want_gemm) {
     return tce::gemm_pk_estimate_us(d->M, d->N, d->K, nullptr, has_scratch) < tce::gemm_dma_estimate_us(d->M, d->N, d->K) + 1.5f;
 }
 
+// Plain (no fused prologue) launches: the persistent kernel is no longer chosen automatically -- with four rows per wave and four waves
+// per workgroup the row-block kernel runs lm_head 128256 x 4096 in 45.5-46.1 us against 46.7 us (round 2 sweep,
+// profiles/r2/gemv_geometry_sweep.jsonl; round 1 compared against the eight-wave geometry: 50.5-57 us).  It stays available through tce_w4a16_set_gemv_config(rows, waves, 0, depth), carries the fused
+// RMSNorm prologue from 8k rows up, and is the body of the token kernel.
+constexpr long long kPersistentMinWeights = 1LL << 62;
 int g_gemv_kernel = 0;  // 0 automatic, 1 workgroup-per-row-block kernel forced, 2 persistent stream kernel forced
 int g_skinny_enabled = 1;  // tuning: tce_w4a16_set_debug_mode(29) routes 3 <= M <= 16 to the GEMV / GEMM kernels again
 
@@ -316,7 +321,7 @@ int tce_w4a16_forward_group(const tce_w4a16_desc *descs, int count, void *stream
     // (the 128k-row lm_head: 47 vs 50.5 us) and loses 5-10 % on per-layer shapes, where a launch is 2-3 waves of work.
     long long weights = 0;
     for (int i = 0; i < count; ++i) weights += (long long)descs[i].N * descs[i].K;
-    const bool use_stream = g_gemv_kernel == 2 || (g_gemv_kernel == 0 && descs[0].M == 1 && weights >= 200000000LL && g_debug_mode_capi == 0);
+    const bool use_stream = g_gemv_kernel == 2 || (g_gemv_kernel == 0 && descs[0].M == 1 && weights >= kPersistentMinWeights && g_debug_mode_capi == 0);
     if (use_stream) {
         const int rc = tce::launch_w4a16_gemv_stream(descs, count, static_cast<hipStream_t>(stream), &he);
         if (rc == TCE_OK) return TCE_OK;
@@ -405,7 +410,7 @@ int tce_w4a16_describe_dispatch(const tce_w4a16_desc *d, char *buf, int buf_len)
     }
     // which GEMV kernel: same rule as tce_w4a16_forward_group (one linear per launch here)
     const bool persistent = g_gemv_kernel == 2 || (d->rmsnorm_gamma ? (g_gemv_kernel == 0 && d->N >= 8192)
-                                                                     : (g_gemv_kernel == 0 && d->M == 1 && (long long)d->N * d->K >= 200000000LL && g_debug_mode_capi == 0));
+                                                                     : (g_gemv_kernel == 0 && d->M == 1 && (long long)d->N * d->K >= kPersistentMinWeights && g_debug_mode_capi == 0));
     std::snprintf(buf, (size_t)buf_len, "gemv passes=%d kernel=%s", (d->M + 3) / 4, persistent && d->M == 1 ? "persistent" : "row-block");
     return TCE_OK;
 }

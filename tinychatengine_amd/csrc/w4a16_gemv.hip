@@ -515,10 +515,16 @@ int launch_w4a16_gemv(const tce_w4a16_desc *descs, int count, int forced_rows, i
     if (v.rows == 0) {
         // Enough workgroups to cover 256 CUs a few times; split K across waves only when there are too few rows to
         // fill the chip and K is long enough.  (Tuned on MI355X; see DESIGN.md "GEMV geometry".)
-        if (total_n >= 30000) v = {4, 8, 1, 1};
-        else if (total_n >= 8192) v = {4, 4, 1, 1};
+        // Re-fitted in round 2 (scripts/tune.py --only gemv with the zero-point-8 kernels the bench and the adapter run,
+        // profiles/r2/gemv_geometry_sweep.jsonl; run-to-run noise is ~3 %): two rows per wave instead of four between 8k and 24k rows
+        // (gate+up 2 x 11008: 10.9-11.3 vs 11.7 us; qkv 12288: a tie), four rows and FOUR waves per workgroup from 24k rows up (lm_head
+        // 32000: 14.0-14.2 vs 14.6 us with eight waves; 128256: 45.5-46.1 us, level with the persistent kernel's 46.7), and few rows
+        // over a long K split K four ways (512 x 11008: 3.9 vs 4.3 us).
+        if (total_n >= 24000) v = {4, 4, 1, 1};
+        else if (total_n >= 8192) v = {2, 4, 1, 1};
         else if (total_n >= 3072) v = {2, 4, 1, 2};
         else if (total_n >= 1536) v = {1, 4, 1, 2};
+        else if (nchunks >= 256 && d0.M == 1) v = {1, 2, 4, 1};
         else if (nchunks >= 128) v = {1, 2, 2, 1};
         else v = {1, 4, 1, 1};
     }
