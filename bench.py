@@ -179,10 +179,11 @@ def roofline_leg(dl, torch, launches: int, eager: bool = False, which: int = 2, 
         with torch.cuda.graph(g, stream=s):
             for i in range(launches):
                 capi.check(L.tce_w4a16_forward_group(arrs[i % len(arrs)], len(d0), sp))
-    g.replay()
+    for _ in range(8):  # burn-in, as in the other legs: the first replays after the device sat idle for the host-side set-up run up to 8 % slow
+        g.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 5
+    reps = 10
     e0.record()
     for _ in range(reps):
         g.replay()
