@@ -526,6 +526,10 @@ def main():
         try:  # capture GEMVs + RCCL all-gathers of one token into one graph; fall back to eager issue if capture fails
             if args.no_graph or (args.backend != "nccl" and args.gather != "peer"):
                 raise RuntimeError("graph capture not requested / not available with this backend")
+            # the ranks meet before anything that exchanges data runs: a peer-write gather waits ~0.4 s for the other ranks' slices and then
+            # flags the communicator, and building the shards / capturing the graph takes the ranks seconds, not all the same number
+            dist.barrier()
+            torch.cuda.synchronize()
             for _ in range(3):
                 dl.run_token_distributed(args.gathers_per_block, gather=args.gather)
             torch.cuda.synchronize()
@@ -553,6 +557,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    fence()  # (N > 1: the ranks start their first replay together, see above)
     for _ in range(args.warmup):
         step()
     fence()

@@ -10,7 +10,7 @@
 //   exchange  the kernel of rank r (a) writes its slice into EVERY rank's window -- buffer (slot, parity of the slot's epoch) at
 //             the slice's offset -- with 16-byte stores straight into peer memory, (b) after a system-scope release writes the
 //             epoch into flag (slot, parity, r) of every window, (c) waits until its own window shows all ranks' flags at this
-//             epoch (bounded: a rank that never arrives sets the status word after ~50 ms instead of hanging the queue),
+//             epoch (bounded: a rank that never arrives sets the status word after ~0.4 s instead of hanging the queue),
 //             (d) copies the complete vector from the window to an ordinary device buffer -- the next linear's activation.
 //             Epochs are counted on the device (one word per slot), so the same captured kernel node is correct on every
 //             replay; two buffers per slot are enough: a rank can start exchange e+1 (and write into peers' buffers of parity
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(1024) void allgather_peer_kernel(const GatherArgs a
         const unsigned long long t0 = wall_clock64();  // 100 MHz
         while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
             __builtin_amdgcn_s_sleep(8);
-            if (wall_clock64() - t0 > 5000000ull) {  // ~50 ms: give up, flag the communicator (tce_comm_status)
+            if (wall_clock64() - t0 > 40000000ull) {  // ~0.4 s (100 MHz clock; a first launch may trail its peers by a code-object load): give up, flag the communicator (tce_comm_status)
                 __hip_atomic_store(a.epochs + a.slots, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
