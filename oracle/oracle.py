@@ -38,6 +38,9 @@ def build(with_ref: bool | None = None) -> None:
         lib = os.path.join(_HERE, "..", "tinychatengine_amd", "lib", "libtce_hip.so")
         if os.path.exists(lib) and os.path.isdir("/root/reference/llm/src/ops"):
             subprocess.check_call(["make", "-s", "-C", _HERE, "l2link"])
+        # the reference's CUDA glue kernels run on the CPU through oracle/cuda_emul (oracle/_ref/glue_harness; tests/test_oracle_glue.py)
+        if os.path.isdir("/root/reference/llm/src/ops/cuda"):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "glue"])
 
 
 def _p(a: np.ndarray | None):
@@ -241,7 +244,7 @@ class Oracle(_Lib):
         self.lib.orc_rmsnorm_half(_p(x.view(np.uint16)), _p(g), _p(out), C.c_int(m), C.c_int(n), C.c_float(eps))
         return out.view(np.float16)
 
-    # ---- attention ops (PARITY UNPINNED: CUDA-only in the reference; see tce_oracle.c) ----
+    # ---- attention ops (CUDA-only in the reference; pinned against its kernel sources run through oracle/cuda_emul: tests/test_oracle_glue.py) ----
     def hfma(self, a_bits: int, b_bits: int, c_bits: int) -> int:
         self.lib.orc_hfma.restype = C.c_uint16
         self.lib.orc_hfma.argtypes = [C.c_uint16] * 3

@@ -527,7 +527,8 @@ ORC_API void orc_fp32_matmul_transposed(int M, int N, int K, const float *A, con
 /* ------------------------------------------------------------------------- */
 
 /* add_half (llm/src/nn_modules/cuda/Int4llamaDecoderLayer.cu:12-18): c[i] = __hadd(a[i], b[i]), one binary16 rounding
- * (the float sum of two halves is exact). */
+ * (the float sum of two halves is exact).  add_half and SiLuMul_half are pinned against the reference's kernel sources run
+ * through oracle/cuda_emul/ (tests/test_oracle_glue.py); orc_rmsnorm_half below is NOT (its kernel needs warp shuffles). */
 ORC_API void orc_add_half(const uint16_t *a, const uint16_t *b, uint16_t *c, int64_t n) {
     for (int64_t i = 0; i < n; i++) c[i] = orc_f32_to_f16(orc_f16_to_f32(a[i]) + orc_f16_to_f32(b[i]));
 }
@@ -630,10 +631,13 @@ ORC_API void orc_layernorm_q(const float *x, const float *w, const float *b, int
 }
 
 /* ------------------------------------------------------------------------------------------------------------------ */
-/* Attention ops either side of the int4 linears.  PARITY UNPINNED: the reference implements these */
-/* only as CUDA kernels (llm/src/ops/cuda/BMM_F16T.cu, softmax.cu), which cannot be built or run here; what follows   */
-/* restates their arithmetic operation by operation.  The binary16 fused multiply-add is exact (integer arithmetic),  */
-/* hexp is modelled as the C library's expf rounded to binary16 (CUDA's hexp is an approximation of its own).         */
+/* Attention ops either side of the int4 linears.  The reference implements these only as CUDA      */
+/* kernels (llm/src/ops/cuda/BMM_F16T.cu, softmax.cu, RotaryPosEmb.cu), which cannot run on a device here; what       */
+/* follows restates their arithmetic operation by operation.  PINNED (round 2) against those kernel SOURCES executed  */
+/* on the CPU through the host emulation in oracle/cuda_emul/ (`make glue`, tests/test_oracle_glue.py: bit for bit) -- */
+/* which fixes structure and order of operations; the binary16 primitives are this file's (the fused multiply-add is  */
+/* exact integer arithmetic, checked against exact rational arithmetic in tests/test_oracle.py), and hexp is modelled */
+/* on BOTH sides as the C library's expf rounded to binary16 (CUDA's hexp is an approximation of its own).            */
 /* ------------------------------------------------------------------------------------------------------------------ */
 
 /* value of a finite binary16 as m * 2^e with integer m (|m| < 2^11) */

@@ -1,0 +1,81 @@
+"""Pins the oracle's restatements of the ops either side of the W4A16 linears against the REFERENCE's own
+CUDA kernel sources, run on the CPU.
+
+The reference has these ops only as CUDA kernels -- llm/src/ops/cuda/softmax.cu:4-40, BMM_F16T.cu:28-78, RotaryPosEmb.cu:4-34, and
+add_half / SiLuMul_half in llm/src/nn_modules/cuda/Int4llamaDecoderLayer.cu:12-30 -- which cannot be run here on a device.  They are
+plain per-thread loops (no shared memory, no barriers, no shuffles), so `make -C oracle glue` compiles those very sources against the
+host emulation in oracle/cuda_emul/ (threads one after the other, binary16 intrinsics as single correctly rounded operations) into
+oracle/_ref/glue_harness, and this file compares orc_* with what they compute, bit for bit.  What is pinned is the kernels' structure
+and order of operations; hexp is the same model on both sides (C library expf rounded to binary16), as tce_oracle.c says.
+generalT5LayerNorm (warp shuffles, __syncthreads) cannot be emulated this way: orc_rmsnorm_half stays unpinned."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HARNESS = os.path.join(REPO, "oracle", "_ref", "glue_harness")
+
+pytestmark = pytest.mark.skipif(not os.path.exists(HARNESS), reason="oracle/_ref/glue_harness not built (needs /root/reference at build time)")
+
+
+def _run(tmp_path, op, ints, inputs, n_out):
+    paths = []
+    for i, a in enumerate(inputs):
+        p = tmp_path / f"in{i}.bin"
+        np.ascontiguousarray(a, np.float16).tofile(p)
+        paths.append(str(p))
+    outs = [str(tmp_path / f"out{i}.bin") for i in range(n_out)]
+    r = subprocess.run([HARNESS, op, *[str(v) for v in ints], *paths, *outs], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, f"glue_harness {op}: rc={r.returncode}\n{r.stdout}\n{r.stderr}"
+    return [np.fromfile(o, np.float16) for o in outs]
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float16).view(np.uint16)
+
+
+def _halves(rng, shape, scale=1.0):
+    return (rng.standard_normal(shape) * scale).astype(np.float16)
+
+
+@pytest.mark.parametrize("n", [1, 1023, 4096, 11008 + 5])
+def test_add_half_and_silu_mul_against_the_reference_kernels(tmp_path, oracle, n):
+    rng = np.random.default_rng(n)
+    a, b = _halves(rng, n, 3.0), _halves(rng, n, 3.0)
+    a[: min(n, 4)] = np.array([65504, -65504, 6e-8, 0], np.float16)[: min(n, 4)]  # overflow to inf, a subnormal, zero
+    (ref,) = _run(tmp_path, "add", [n], [a, b], 1)
+    assert np.array_equal(_bits(ref), _bits(oracle.add_half(a, b)))
+    (ref,) = _run(tmp_path, "silu", [n], [a, b], 1)
+    assert np.array_equal(_bits(ref), _bits(oracle.silu_mul_half(a, b)))
+
+
+@pytest.mark.parametrize("x,y,z", [(32, 1, 129), (3, 5, 64), (2, 17, 1), (1, 1, 2048)])
+def test_softmax_against_the_reference_kernel(tmp_path, oracle, x, y, z):
+    rng = np.random.default_rng(x * 100 + y * 10 + z)
+    s = _halves(rng, (x, y, z), 4.0)
+    s[0, 0, : min(z, 3)] = np.array([-65504, 11.0, -30.0], np.float16)[: min(z, 3)]  # a masked key, a dominant one, an underflowing one
+    (ref,) = _run(tmp_path, "softmax", [x, y, z], [s], 1)
+    assert np.array_equal(_bits(ref), _bits(oracle.softmax_half(s)).ravel())
+
+
+@pytest.mark.parametrize("batch,m,n,k", [(32, 1, 200, 128), (4, 7, 33, 64), (2, 3, 5, 300), (32, 1, 128, 257)])
+def test_bmm_f16t_against_the_reference_operator(tmp_path, oracle, batch, m, n, k):
+    rng = np.random.default_rng(batch + m + n + k)
+    a, w = _halves(rng, (batch, m, k)), _halves(rng, (batch, n, k))
+    a[0, 0, :2] = np.array([6e-5, 6e-8], np.float16)  # products in the subnormal range
+    alpha = np.float16(0.0884)
+    (ref,) = _run(tmp_path, "bmm", [batch, m, n, k, int(np.array([alpha]).view(np.uint16)[0])], [a, w], 1)
+    assert np.array_equal(_bits(ref), _bits(oracle.bmm_f16t(a, w, alpha)).ravel())
+
+
+@pytest.mark.parametrize("heads,ln,hd,start", [(32, 1, 128, 77), (4, 9, 128, 0), (2, 3, 64, 5)])
+def test_rope_against_the_reference_kernel(tmp_path, oracle, heads, ln, hd, start):
+    rng = np.random.default_rng(heads + ln + hd + start)
+    positions = start + ln + 2
+    q, k = _halves(rng, (heads, ln, hd)), _halves(rng, (heads, ln, hd))
+    cos, sin = _halves(rng, (positions, hd)), _halves(rng, (positions, hd))
+    rq, rk = _run(tmp_path, "rope", [heads, ln, hd, start, positions], [q, k, cos, sin], 2)
+    oq, ok = oracle.rope_half(q, k, cos, sin, start)
+    assert np.array_equal(_bits(rq), _bits(oq).ravel()) and np.array_equal(_bits(rk), _bits(ok).ravel())
