@@ -2,8 +2,10 @@
  * reference's own kernel SOURCES -- llm/src/ops/cuda/{softmax,BMM_F16T,RotaryPosEmb}.cu and the add_half / SiLuMul_half kernels
  * of llm/src/nn_modules/cuda/Int4llamaDecoderLayer.cu -- run on the CPU, thread by thread, and pin the restatements in
  * oracle/tce_oracle.c (orc_softmax_half, orc_bmm_f16t, orc_rope_half, orc_add_half, orc_silu_mul_half).  The reference has these
- * ops only as CUDA kernels; none of them uses shared memory, __syncthreads or warp shuffles, so running the threads of a launch one
- * after the other is what the device does.  (generalT5LayerNorm does use them and stays unpinned.)
+ * ops only as CUDA kernels; none of those five uses shared memory, __syncthreads or warp shuffles, so running the threads of a launch
+ * one after the other is what the device does.  generalT5LayerNorm (llm/src/ops/cuda/LlamaRMSNorm.cu:68-115, orc_rmsnorm_half) does:
+ * its blocks run through launch_concurrent(), the threads of a block as OS threads with pthread barriers for __syncthreads and for
+ * each warp's __shfl_xor_sync.
  *   __global__ kernels are plain functions; blockIdx / threadIdx / blockDim / gridDim are thread-local variables that
  *   tce_emul::launch() steps through; `kernel<<<grid, block>>>(args)` in a host wrapper is rewritten by the build recipe
  *   (oracle/Makefile, target `glue`: a sed pass into oracle/_ref/gen/, nothing is copied into the repository) to
@@ -20,6 +22,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef __cplusplus
+#include <algorithm>
+#include <type_traits>
+using std::max;
+using std::min;
+#endif
 
 #define __global__
 #define __device__
@@ -28,12 +36,29 @@
 #define __restrict
 #define __CUDA_ARCH__ 800 /* the device path of softmax.cu:17-23 (pre-8.6: __hgt) */
 #define __launch_bounds__(...)
-/* kernels that use shared memory or barriers are NOT run by this emulation (threads run one after the other); the names exist so that
- * the translation units that also contain such kernels compile -- calling one aborts */
+/* __shared__ is an empty word here: `static __shared__ T v[..]` (reduction.cuh) is then a function-local static, one object for all
+ * threads, which is what a block needs as long as blocks run one after the other (they do); a NON-static `__shared__ T v;` inside a
+ * kernel is rewritten to `static T v;` by the build recipe's sed pass.  __syncthreads / __shfl_xor_sync need the threads of a block to
+ * run concurrently: tce_emul::launch_concurrent() below runs each thread of a block as an OS thread; under the sequential launch()
+ * they abort. */
 #define __shared__
+#include <pthread.h>
+namespace tce_emul {
+struct block_state {
+    pthread_barrier_t all;            /* __syncthreads */
+    pthread_barrier_t warp[64];       /* one per warp of the block */
+    double slot[64][32];              /* values exchanged by a warp's shuffle */
+    unsigned warp_lanes[64];          /* active lanes of each warp */
+    unsigned threads;
+};
+extern block_state *g_block;          /* null under the sequential launch() */
+}  // namespace tce_emul
 static inline void __syncthreads() {
-    fprintf(stderr, "cuda_emul: __syncthreads() -- a kernel that needs real thread concurrency was called\n");
-    abort();
+    if (!tce_emul::g_block) {
+        fprintf(stderr, "cuda_emul: __syncthreads() under the sequential launcher -- this kernel needs launch_concurrent()\n");
+        abort();
+    }
+    pthread_barrier_wait(&tce_emul::g_block->all);
 }
 
 typedef int cudaError_t;
@@ -69,6 +94,25 @@ struct tce_emul_idx {
 extern thread_local tce_emul_idx blockIdx, threadIdx;
 extern thread_local dim3 blockDim, gridDim;
 
+/* __shfl_xor_sync(mask, v, lane_mask, width = 32): every active lane of the warp publishes v, the warp meets, every lane reads its
+ * partner's value (its own if the partner lane does not exist), the warp meets again before the slots are reused.  One-dimensional
+ * blocks only (what the reference's reductions use). */
+template <typename T>
+static inline T __shfl_xor_sync(unsigned, T v, int lane_mask, int = 32) {
+    tce_emul::block_state *b = tce_emul::g_block;
+    if (!b) {
+        fprintf(stderr, "cuda_emul: __shfl_xor_sync() under the sequential launcher\n");
+        abort();
+    }
+    const unsigned w = threadIdx.x >> 5, lane = threadIdx.x & 31, partner = lane ^ (unsigned)lane_mask;
+    b->slot[w][lane] = (double)v;
+    pthread_barrier_wait(&b->warp[w]);
+    const T got = partner < b->warp_lanes[w] ? (T)b->slot[w][partner] : v;
+    pthread_barrier_wait(&b->warp[w]);
+    return got;
+}
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); } /* the device's is a 2-ulp approximation: same model as orc_rmsnorm_half */
+
 namespace tce_emul {
 struct config {
     dim3 grid, block;
@@ -77,6 +121,9 @@ inline config cfg(dim3 g, dim3 b, size_t = 0, cudaStream_t = nullptr) { return c
 inline config cfg(unsigned g, unsigned b, size_t = 0, cudaStream_t = nullptr) { return config{dim3(g), dim3(b)}; }
 inline config cfg(dim3 g, unsigned b, size_t = 0, cudaStream_t = nullptr) { return config{g, dim3(b)}; }
 inline config cfg(unsigned g, dim3 b, size_t = 0, cudaStream_t = nullptr) { return config{dim3(g), b}; }
+/* blocks one after the other, the threads of a block as concurrent OS threads (blockDim.x <= 2048, y = z = 1) */
+template <typename F>
+inline void launch_concurrent(const config &c, F &&body);
 /* every thread of every block, one after the other: valid for kernels without __syncthreads / shared memory / shuffles */
 template <typename F>
 inline void launch(const config &c, F &&body) {
@@ -92,6 +139,62 @@ inline void launch(const config &c, F &&body) {
                             threadIdx = tce_emul_idx{tx, ty, tz};
                             body();
                         }
+}
+template <typename F>
+struct thread_arg {
+    F *body;
+    tce_emul_idx bidx, tidx;
+    dim3 bdim, gdim;
+};
+template <typename F>
+void *thread_main(void *p) {
+    thread_arg<F> *a = static_cast<thread_arg<F> *>(p);
+    blockIdx = a->bidx;
+    threadIdx = a->tidx;
+    blockDim = a->bdim;
+    gridDim = a->gdim;
+    (*a->body)();
+    return nullptr;
+}
+template <typename F>
+inline void launch_concurrent(const config &c, F &&body) {
+    const unsigned nt = c.block.x;
+    if (c.block.y != 1 || c.block.z != 1 || nt == 0 || nt > 2048) {
+        fprintf(stderr, "cuda_emul: launch_concurrent wants a one-dimensional block of at most 2048 threads\n");
+        abort();
+    }
+    static block_state st;
+    st.threads = nt;
+    const unsigned nwarps = (nt + 31) / 32;
+    for (unsigned bz = 0; bz < c.grid.z; ++bz)
+        for (unsigned by = 0; by < c.grid.y; ++by)
+            for (unsigned bx = 0; bx < c.grid.x; ++bx) {
+                pthread_barrier_init(&st.all, nullptr, nt);
+                for (unsigned w = 0; w < nwarps; ++w) {
+                    st.warp_lanes[w] = nt - w * 32 < 32 ? nt - w * 32 : 32;
+                    pthread_barrier_init(&st.warp[w], nullptr, st.warp_lanes[w]);
+                }
+                g_block = &st;
+                thread_arg<typename std::remove_reference<F>::type> *args = new thread_arg<typename std::remove_reference<F>::type>[nt];
+                pthread_t *th = new pthread_t[nt];
+                pthread_attr_t attr;
+                pthread_attr_init(&attr);
+                pthread_attr_setstacksize(&attr, 256 * 1024);
+                for (unsigned t = 0; t < nt; ++t) {
+                    args[t] = {&body, tce_emul_idx{bx, by, bz}, tce_emul_idx{t, 0, 0}, c.block, c.grid};
+                    if (pthread_create(&th[t], &attr, thread_main<typename std::remove_reference<F>::type>, &args[t]) != 0) {
+                        fprintf(stderr, "cuda_emul: pthread_create failed\n");
+                        abort();
+                    }
+                }
+                for (unsigned t = 0; t < nt; ++t) pthread_join(th[t], nullptr);
+                pthread_attr_destroy(&attr);
+                delete[] th;
+                delete[] args;
+                g_block = nullptr;
+                pthread_barrier_destroy(&st.all);
+                for (unsigned w = 0; w < nwarps; ++w) pthread_barrier_destroy(&st.warp[w]);
+            }
 }
 }  // namespace tce_emul
 #endif

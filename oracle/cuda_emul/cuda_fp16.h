@@ -38,6 +38,7 @@ static inline half __hfma(half a, half b, half c) { return tce_emul_bits(orc_hfm
 static inline bool __hgt(half a, half b) { return __half2float(a) > __half2float(b); }
 static inline bool __hlt(half a, half b) { return __half2float(a) < __half2float(b); }
 static inline half __hmax(half a, half b) { return __hgt(a, b) ? a : b; }
+static inline half2 __hadd2(half2 a, half2 b) { return half2{__hadd(a.x, b.x), __hadd(a.y, b.y)}; }
 static inline half hexp(half a) { return half(expf(__half2float(a))); }
 template <typename T> static inline T __ldg(const T *p) { return *p; }
 #endif

@@ -10,6 +10,8 @@
 //   glue_harness softmax x y z in.bin out.bin
 //   glue_harness bmm   batch m n k alpha_bits a.bin w.bin out.bin
 //   glue_harness rope  heads len hd start positions q.bin k.bin cos.bin sin.bin q_out.bin k_out.bin
+//   glue_harness rmsnorm m n eps x.bin gamma_f32.bin out.bin     (LlamaRMSNorm_cuda::forward -> generalT5LayerNorm: warp shuffles and
+//                                                                 __syncthreads, so its block runs as concurrent OS threads)
 // Nothing of this is part of the product.
 #include <cstdio>
 #include <cstdlib>
@@ -21,6 +23,7 @@
 
 thread_local tce_emul_idx blockIdx, threadIdx;
 thread_local dim3 blockDim, gridDim;
+tce_emul::block_state *tce_emul::g_block = nullptr;
 
 // the reference's kernels (defined in the sources named above; no header declares them)
 __global__ void softmax_cuda(Matrix3D<half> input, Matrix3D<half> output);
@@ -98,6 +101,21 @@ int main(int argc, char **argv) {
         tce_emul::launch(tce_emul::cfg(dim3(heads, 1, 1), dim3(len, 1, 1)), [&] { RotaryPosEmb_cuda_forward(Q, K, Cs, Sn, start, len); });
         wr(argv[11], q);
         wr(argv[12], k);
+        return 0;
+    }
+    if (op == "rmsnorm" && argc == 8) {  // LlamaRMSNorm_cuda::forward (LlamaRMSNorm.cu:96-115), its own grid / block
+        const int m = I(2), n = I(3);
+        const float eps = (float)atof(argv[4]);
+        auto x = rd(argv[5], (size_t)m * n);
+        std::vector<float> gamma(n);
+        FILE *f = fopen(argv[6], "rb");
+        if (!f || fread(gamma.data(), 4, n, f) != (size_t)n) return 2;
+        fclose(f);
+        std::vector<half> out((size_t)m * n);
+        Matrix3D<half> X(x.data(), 1, m, n), O(out.data(), 1, m, n);
+        LlamaRMSNorm_cuda norm(Matrix3D<float>(gamma.data(), 1, 1, n));
+        norm.forward(X, O, eps);
+        wr(argv[7], out);
         return 0;
     }
     fprintf(stderr, "glue_harness: bad arguments\n");

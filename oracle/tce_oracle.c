@@ -528,7 +528,8 @@ ORC_API void orc_fp32_matmul_transposed(int M, int N, int K, const float *A, con
 
 /* add_half (llm/src/nn_modules/cuda/Int4llamaDecoderLayer.cu:12-18): c[i] = __hadd(a[i], b[i]), one binary16 rounding
  * (the float sum of two halves is exact).  add_half and SiLuMul_half are pinned against the reference's kernel sources run
- * through oracle/cuda_emul/ (tests/test_oracle_glue.py); orc_rmsnorm_half below is NOT (its kernel needs warp shuffles). */
+ * through oracle/cuda_emul/ (tests/test_oracle_glue.py), and so is orc_rmsnorm_half below (its kernel needs warp shuffles and
+ * __syncthreads: the emulation runs that block's threads concurrently). */
 ORC_API void orc_add_half(const uint16_t *a, const uint16_t *b, uint16_t *c, int64_t n) {
     for (int64_t i = 0; i < n; i++) c[i] = orc_f32_to_f16(orc_f16_to_f32(a[i]) + orc_f16_to_f32(b[i]));
 }

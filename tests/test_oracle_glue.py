@@ -7,7 +7,9 @@ plain per-thread loops (no shared memory, no barriers, no shuffles), so `make -C
 host emulation in oracle/cuda_emul/ (threads one after the other, binary16 intrinsics as single correctly rounded operations) into
 oracle/_ref/glue_harness, and this file compares orc_* with what they compute, bit for bit.  What is pinned is the kernels' structure
 and order of operations; hexp is the same model on both sides (C library expf rounded to binary16), as tce_oracle.c says.
-generalT5LayerNorm (warp shuffles, __syncthreads) cannot be emulated this way: orc_rmsnorm_half stays unpinned."""
+generalT5LayerNorm (LlamaRMSNorm.cu:68-115) DOES use warp shuffles, a shared variable and __syncthreads: for it the emulation runs the
+threads of a block as concurrent OS threads (tce_emul::launch_concurrent: pthread barriers for __syncthreads and for each warp's
+shuffle), and orc_rmsnorm_half -- the hand-restated reduction tree -- is compared with it as well.  rsqrtf is 1 / sqrtf on both sides."""
 import os
 import subprocess
 
@@ -79,3 +81,23 @@ def test_rope_against_the_reference_kernel(tmp_path, oracle, heads, ln, hd, star
     rq, rk = _run(tmp_path, "rope", [heads, ln, hd, start, positions], [q, k, cos, sin], 2)
     oq, ok = oracle.rope_half(q, k, cos, sin, start)
     assert np.array_equal(_bits(rq), _bits(oq).ravel()) and np.array_equal(_bits(rk), _bits(ok).ravel())
+
+
+@pytest.mark.parametrize("m,n", [(1, 4096), (3, 1024), (2, 520), (1, 11008), (2, 64)])
+def test_rmsnorm_against_the_reference_kernel(tmp_path, oracle, m, n):
+    """LlamaRMSNorm_cuda::forward with its own grid / block (min(n, 1024) / 2 threads; 512 when n % 32 != 0): thread-strided partial sums,
+    the butterfly over each warp, the second butterfly over the warps' sums, the clamp, the fp16 store."""
+    rng = np.random.default_rng(m * 7 + n)
+    x = _halves(rng, (m, n), 2.5)
+    x[0, :2] = np.array([60000, -60000], np.float16)  # large values: the clamp
+    gamma = (1 + 0.2 * rng.standard_normal(n)).astype(np.float32)
+    eps = 1e-6
+    gpath = tmp_path / "gamma.bin"
+    gamma.tofile(gpath)
+    xin = tmp_path / "x.bin"
+    x.tofile(xin)
+    out = tmp_path / "out.bin"
+    r = subprocess.run([HARNESS, "rmsnorm", str(m), str(n), repr(eps), str(xin), str(gpath), str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    ref = np.fromfile(out, np.float16)
+    assert np.array_equal(_bits(ref), _bits(oracle.rmsnorm_half(x, gamma, eps)).ravel())
