@@ -10,6 +10,8 @@
 //   glue_harness softmax x y z in.bin out.bin
 //   glue_harness bmm   batch m n k alpha_bits a.bin w.bin out.bin
 //   glue_harness rope  heads len hd start positions q.bin k.bin cos.bin sin.bin q_out.bin k_out.bin
+//   glue_harness lnq   m n x_f32.bin w_f32.bin b_f32.bin out_i8.bin   (LayerNormQ::forward, llm/src/ops/LayerNormQ.cc:12-52 -- host code in the
+//                                                                 reference, compiled as it is: pins orc_layernorm_q)
 //   glue_harness rmsnorm m n eps x.bin gamma_f32.bin out.bin     (LlamaRMSNorm_cuda::forward -> generalT5LayerNorm: warp shuffles and
 //                                                                 __syncthreads, so its block runs as concurrent OS threads)
 // Nothing of this is part of the product.
@@ -101,6 +103,29 @@ int main(int argc, char **argv) {
         tce_emul::launch(tce_emul::cfg(dim3(heads, 1, 1), dim3(len, 1, 1)), [&] { RotaryPosEmb_cuda_forward(Q, K, Cs, Sn, start, len); });
         wr(argv[11], q);
         wr(argv[12], k);
+        return 0;
+    }
+    if (op == "lnq" && argc == 8) {
+        const int m = I(2), n = I(3);
+        auto rdf = [&](const char *path, size_t cnt) {
+            std::vector<float> v(cnt);
+            FILE *f = fopen(path, "rb");
+            if (!f || fread(v.data(), 4, cnt, f) != cnt) exit(2);
+            fclose(f);
+            return v;
+        };
+        auto x = rdf(argv[4], (size_t)m * n), w = rdf(argv[5], n), b = rdf(argv[6], n);
+        std::vector<int8_t> out((size_t)m * n);
+        LayerNormQ_params params;
+        params.weight = Matrix3D<float>(w.data(), 1, 1, n);
+        params.bias = Matrix3D<float>(b.data(), 1, 1, n);
+        LayerNormQ ln(params);
+        Matrix3D<float> X(x.data(), 1, m, n);
+        Matrix3D<int8_t> O(out.data(), 1, m, n);
+        ln.forward(X, O);
+        FILE *f = fopen(argv[7], "wb");
+        if (!f || fwrite(out.data(), 1, out.size(), f) != out.size()) return 2;
+        fclose(f);
         return 0;
     }
     if (op == "rmsnorm" && argc == 8) {  // LlamaRMSNorm_cuda::forward (LlamaRMSNorm.cu:96-115), its own grid / block

@@ -606,7 +606,8 @@ ORC_API void orc_rmsnorm_half(const uint16_t *x, const float *gamma, uint16_t *o
 /* LayerNormQ::forward (llm/src/ops/LayerNormQ.cc:12-52), the op in front of every W8A8 linear of the OPT path: fp32 in,
  * int8 out, eps = 1e-5, every sum sequential in fp32, out = (int8) round( (v - mean) / std * w + b ) (std::round: half
  * away from zero; no clamp in the reference -- values are assumed to fit).  The narrowing is done through int32 here,
- * which is what the reference's static_cast does for in-range values. */
+ * which is what the reference's static_cast does for in-range values.  Pinned against the reference's own LayerNormQ.cc compiled
+ * into oracle/_ref/glue_harness (tests/test_oracle_glue.py). */
 ORC_API void orc_layernorm_q(const float *x, const float *w, const float *b, int8_t *out, int m, int n) {
     const float eps = 0.00001;
     for (int r = 0; r < m; r++) {

@@ -101,3 +101,23 @@ def test_rmsnorm_against_the_reference_kernel(tmp_path, oracle, m, n):
     assert r.returncode == 0, r.stderr
     ref = np.fromfile(out, np.float16)
     assert np.array_equal(_bits(ref), _bits(oracle.rmsnorm_half(x, gamma, eps)).ravel())
+
+
+@pytest.mark.parametrize("m,n", [(1, 768), (5, 768), (2, 2048), (3, 100)])
+def test_layernorm_q_against_the_reference_source(tmp_path, oracle, m, n):
+    """LayerNormQ::forward (llm/src/ops/LayerNormQ.cc:12-52) is host C++ in the reference: compiled as it is (-ffp-contract=off) and
+    compared with orc_layernorm_q -- sequential fp32 sums, separate roundings, std::round."""
+    rng = np.random.default_rng(m + n)
+    x = (rng.standard_normal((m, n)) * 3).astype(np.float32)
+    w = (rng.standard_normal(n) * 20).astype(np.float32)
+    b = (rng.standard_normal(n) * 5).astype(np.float32)
+    paths = []
+    for name, a in (("x", x), ("w", w), ("b", b)):
+        p = tmp_path / f"{name}.bin"
+        a.tofile(p)
+        paths.append(str(p))
+    out = tmp_path / "out.bin"
+    r = subprocess.run([HARNESS, "lnq", str(m), str(n), *paths, str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    ref = np.fromfile(out, np.int8).reshape(m, n)
+    assert np.array_equal(ref, oracle.layernorm_q(x, w, b).reshape(m, n))
