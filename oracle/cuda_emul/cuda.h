@@ -8,8 +8,8 @@
  * each warp's __shfl_xor_sync.
  *   __global__ kernels are plain functions; blockIdx / threadIdx / blockDim / gridDim are thread-local variables that
  *   tce_emul::launch() steps through; `kernel<<<grid, block>>>(args)` in a host wrapper is rewritten by the build recipe
- *   (oracle/Makefile, target `glue`: a sed pass into oracle/_ref/gen/, nothing is copied into the repository) to
- *   tce_emul::launch(tce_emul::cfg(grid, block), [&] { kernel(args); }).
+ *   (oracle/Makefile, target `glue`: oracle/cuda_emul/rewrite_launches.py into oracle/_ref/gen/, nothing is copied into the repository)
+ *   to tce_emul::launch(tce_emul::cfg(grid, block), [&] { kernel(args); }) -- launch_concurrent for kernels that need it.
  *   `half` arithmetic: every intrinsic is ONE correctly rounded binary16 operation (the reference's definition of __hadd, __hmul,
  *   __hfma, __hdiv); the rounding and the exact fused multiply-add come from libtce_oracle.so (orc_f64_to_f16, orc_hfma -- pinned
  *   against exact rational arithmetic in tests/test_oracle.py).  hexp is the C library's expf rounded to binary16, the same
@@ -104,13 +104,33 @@ static inline T __shfl_xor_sync(unsigned, T v, int lane_mask, int = 32) {
         fprintf(stderr, "cuda_emul: __shfl_xor_sync() under the sequential launcher\n");
         abort();
     }
-    const unsigned w = threadIdx.x >> 5, lane = threadIdx.x & 31, partner = lane ^ (unsigned)lane_mask;
+    const unsigned lin = threadIdx.x + threadIdx.y * blockDim.x;  /* warps are formed over the linear thread index */
+    const unsigned w = lin >> 5, lane = lin & 31, partner = lane ^ (unsigned)lane_mask;
     b->slot[w][lane] = (double)v;
     pthread_barrier_wait(&b->warp[w]);
     const T got = partner < b->warp_lanes[w] ? (T)b->slot[w][partner] : v;
     pthread_barrier_wait(&b->warp[w]);
     return got;
 }
+/* __shfl_down_sync(mask, v, delta): lane l reads lane l + delta; lanes whose source does not exist keep their own value */
+template <typename T>
+static inline T __shfl_down_sync(unsigned, T v, unsigned delta, int = 32) {
+    tce_emul::block_state *b = tce_emul::g_block;
+    if (!b) {
+        fprintf(stderr, "cuda_emul: __shfl_down_sync() under the sequential launcher\n");
+        abort();
+    }
+    const unsigned lin = threadIdx.x + threadIdx.y * blockDim.x;
+    const unsigned w = lin >> 5, lane = lin & 31, src = lane + delta;
+    b->slot[w][lane] = (double)v;
+    pthread_barrier_wait(&b->warp[w]);
+    const T got = src < b->warp_lanes[w] ? (T)b->slot[w][src] : v;
+    pthread_barrier_wait(&b->warp[w]);
+    return got;
+}
+struct float4 {
+    float x, y, z, w;
+};
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); } /* the device's is a 2-ulp approximation: same model as orc_rmsnorm_half */
 
 namespace tce_emul {
@@ -121,7 +141,7 @@ inline config cfg(dim3 g, dim3 b, size_t = 0, cudaStream_t = nullptr) { return c
 inline config cfg(unsigned g, unsigned b, size_t = 0, cudaStream_t = nullptr) { return config{dim3(g), dim3(b)}; }
 inline config cfg(dim3 g, unsigned b, size_t = 0, cudaStream_t = nullptr) { return config{g, dim3(b)}; }
 inline config cfg(unsigned g, dim3 b, size_t = 0, cudaStream_t = nullptr) { return config{dim3(g), b}; }
-/* blocks one after the other, the threads of a block as concurrent OS threads (blockDim.x <= 2048, y = z = 1) */
+/* blocks one after the other, the threads of a block as concurrent OS threads (at most 2048 per block, z = 1) */
 template <typename F>
 inline void launch_concurrent(const config &c, F &&body);
 /* every thread of every block, one after the other: valid for kernels without __syncthreads / shared memory / shuffles */
@@ -158,9 +178,9 @@ void *thread_main(void *p) {
 }
 template <typename F>
 inline void launch_concurrent(const config &c, F &&body) {
-    const unsigned nt = c.block.x;
-    if (c.block.y != 1 || c.block.z != 1 || nt == 0 || nt > 2048) {
-        fprintf(stderr, "cuda_emul: launch_concurrent wants a one-dimensional block of at most 2048 threads\n");
+    const unsigned nt = c.block.x * c.block.y;
+    if (c.block.z != 1 || nt == 0 || nt > 2048) {
+        fprintf(stderr, "cuda_emul: launch_concurrent wants a one- or two-dimensional block of at most 2048 threads\n");
         abort();
     }
     static block_state st;
@@ -181,7 +201,7 @@ inline void launch_concurrent(const config &c, F &&body) {
                 pthread_attr_init(&attr);
                 pthread_attr_setstacksize(&attr, 256 * 1024);
                 for (unsigned t = 0; t < nt; ++t) {
-                    args[t] = {&body, tce_emul_idx{bx, by, bz}, tce_emul_idx{t, 0, 0}, c.block, c.grid};
+                    args[t] = {&body, tce_emul_idx{bx, by, bz}, tce_emul_idx{t % c.block.x, t / c.block.x, 0}, c.block, c.grid};
                     if (pthread_create(&th[t], &attr, thread_main<typename std::remove_reference<F>::type>, &args[t]) != 0) {
                         fprintf(stderr, "cuda_emul: pthread_create failed\n");
                         abort();

@@ -10,6 +10,9 @@
 //   glue_harness softmax x y z in.bin out.bin
 //   glue_harness bmm   batch m n k alpha_bits a.bin w.bin out.bin
 //   glue_harness rope  heads len hd start positions q.bin k.bin cos.bin sin.bin q_out.bin k_out.bin
+//   glue_harness gemv  m n k x.bin qweight.bin scales.bin zeros.bin out.bin   (matmul::MatmulOperator::gemv_forward_cuda -> gemv_kernel_g128,
+//                                                                 kernels/cuda/gemv_cuda.cu:140-260 -- THE hot-path kernel of the reference, from its
+//                                                                 own source, block (32, 4) as concurrent threads, __shfl_down_sync warp reduction)
 //   glue_harness lnq   m n x_f32.bin w_f32.bin b_f32.bin out_i8.bin   (LayerNormQ::forward, llm/src/ops/LayerNormQ.cc:12-52 -- host code in the
 //                                                                 reference, compiled as it is: pins orc_layernorm_q)
 //   glue_harness rmsnorm m n eps x.bin gamma_f32.bin out.bin     (LlamaRMSNorm_cuda::forward -> generalT5LayerNorm: warp shuffles and
@@ -103,6 +106,36 @@ int main(int argc, char **argv) {
         tce_emul::launch(tce_emul::cfg(dim3(heads, 1, 1), dim3(len, 1, 1)), [&] { RotaryPosEmb_cuda_forward(Q, K, Cs, Sn, start, len); });
         wr(argv[11], q);
         wr(argv[12], k);
+        return 0;
+    }
+    if (op == "gemv" && argc == 10) {
+        const int m = I(2), n = I(3), k = I(4);
+        const int zw = (k / 128 + 7) / 8;  // calculate_zeros_width (llm/src/nn_modules/cuda/utils.cu:162-178)
+        auto x = rd(argv[5], (size_t)m * k);
+        std::vector<uint32_t> qw((size_t)n * (k / 8)), zp((size_t)n * zw);
+        auto rdw = [&](const char *path, void *dst, size_t bytes) {
+            FILE *f = fopen(path, "rb");
+            if (!f || fread(dst, 1, bytes, f) != bytes) {
+                fprintf(stderr, "glue_harness: cannot read %zu bytes from %s\n", bytes, path);
+                exit(2);
+            }
+            fclose(f);
+        };
+        rdw(argv[6], qw.data(), qw.size() * 4);
+        auto sc = rd(argv[7], (size_t)n * zw * 8);
+        rdw(argv[8], zp.data(), zp.size() * 4);
+        std::vector<half> out((size_t)m * n);
+        struct matmul_params p;
+        memset(&p, 0, sizeof(p));
+        p.A.row = m; p.A.column = k; p.A.half_data_ptr = x.data();
+        p.B.row = k; p.B.column = n; p.B.int32_data_ptr = reinterpret_cast<int32_t *>(qw.data());
+        p.C.row = m; p.C.column = n; p.C.half_data_ptr = out.data();
+        p.half_scales = sc.data();
+        p.int32_zero_point = reinterpret_cast<int *>(zp.data());
+        p.block_size = 128;
+        matmul::MatmulOperator opr;
+        opr.gemv_forward_cuda(&p);
+        wr(argv[9], out);
         return 0;
     }
     if (op == "lnq" && argc == 8) {

@@ -496,3 +496,46 @@ def test_small_batch_kernel_matches_oracle(dev, oracle, M, N, K):
         _check(_run(dev, qw, sc, zp, a, 128), ref32, f"skinny off {M}x{N}x{K}")
     finally:
         L.tce_w4a16_set_debug_mode(20)
+
+
+
+def _cuda_gemv_golden():
+    import importlib.util
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_cuda_gemv_golden", os.path.join(here, "golden", "make_cuda_gemv_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod, np.load(os.path.join(here, "golden", "cuda_gemv_golden.npz"))
+
+
+@pytest.mark.parametrize("idx", range(7))
+def test_decode_against_the_reference_cuda_kernel_itself(dev, oracle, idx):
+    """The HIP path against OUTPUTS OF THE REFERENCE'S OWN CUDA GEMV KERNEL (gemv_forward_cuda -> gemv_kernel_g128, kernels/cuda/gemv_cuda.cu:
+    140-260) at the BASELINE decode shapes: tests/golden/cuda_gemv_golden.npz was produced by running that kernel's unmodified source through
+    the host emulation in oracle/cuda_emul/ (tests/golden/make_cuda_gemv_golden.py); the inputs are regenerated from the recorded seeds.
+    Tolerance: the north star's 1e-3 (with the floor for outputs that are tiny by cancellation, like everywhere)."""
+    from tinychatengine_amd import capi
+    from tinychatengine_amd.linear import Linear_half_int4
+    mod, gold = _cuda_gemv_golden()
+    M, N, K, seed = (int(v) for v in gold["cases"][idx])
+    a, qw, sc, zp = mod.gemv_case(oracle, M, N, K, seed)
+    want = gold[f"out_{M}_{N}_{K}"]
+    lin = Linear_half_int4(torch.from_numpy(qw.view(np.int32)).to(dev), torch.from_numpy(sc).to(dev), torch.from_numpy(zp.view(np.int32)).to(dev), 128)
+    x = torch.from_numpy(a).to(dev)
+    for cfg in (None, (2, 16, 0, 2)):  # the automatic choice (row-block kernel) and the persistent kernel
+        try:
+            capi.set_gemv_config(*(cfg or (0, 0, 0, 0)))
+            y = lin.forward(x)
+            torch.cuda.synchronize()
+        finally:
+            capi.set_gemv_config()
+        got = y.cpu().numpy()
+        ok, worst = w4a16_close(got, want.astype(np.float32))
+        assert ok, f"{M}x{N}x{K} cfg {cfg}: worst |err|/tol against the reference CUDA kernel = {worst:.3f}"
+        if cfg is None:
+            same = float((got.view(np.uint16) == want.view(np.uint16)).mean())
+            rep = w4a16_report(got, want.astype(np.float32))
+            rep["bit_identical_to_the_reference_cuda_kernel"] = round(same, 4)
+            record_parity(f"decode M={M} {N}x{K} vs the reference CUDA kernel's own output", rep)
+            assert same >= 0.80, same  # both round an fp32 sum to binary16: most outputs are the same half
