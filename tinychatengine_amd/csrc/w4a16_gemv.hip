@@ -520,8 +520,12 @@ int launch_w4a16_gemv(const tce_w4a16_desc *descs, int count, int forced_rows, i
         // (gate+up 2 x 11008: 10.9-11.3 vs 11.7 us; qkv 12288: a tie), four rows and FOUR waves per workgroup from 24k rows up (lm_head
         // 32000: 14.0-14.2 vs 14.6 us with eight waves; 128256: 45.5-46.1 us, level with the persistent kernel's 46.7), and few rows
         // over a long K split K four ways (512 x 11008: 3.9 vs 4.3 us).
+        // A/B in one process (scripts/gemv_ab.py, profiles/r2/gemv_geometry_ab.jsonl; best / median of 7 rounds): gate+up 22016 rows:
+        // (2 rows, 4 waves, depth 2) 11.35 / 11.40 us, (2, 4, 1) 11.48 / 12.68 (bimodal), (4, 4, 1) 11.94 / 12.10; qkv 12288 rows: (4, 4, 1)
+        // 7.02 / 7.09, (2, 4, 1) 7.16 / 7.17; Llama-3 gate+up 28672 rows: (4, 4, 1) 13.18, (2, 4, 2) 13.64.
         if (total_n >= 24000) v = {4, 4, 1, 1};
-        else if (total_n >= 8192) v = {2, 4, 1, 1};
+        else if (total_n >= 16384) v = {2, 4, 1, 2};
+        else if (total_n >= 8192) v = {4, 4, 1, 1};
         else if (total_n >= 3072) v = nchunks >= 256 && d0.M == 1 ? Variant{2, 8, 1, 2} : Variant{2, 4, 1, 2};  // long K (down_proj): 7.5 vs 7.8 us, 8.2 vs 8.5
         else if (total_n >= 1536) v = {1, 4, 1, 2};
         else if (nchunks >= 256 && d0.M == 1) v = {1, 2, 4, 1};
