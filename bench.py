@@ -472,54 +472,69 @@ def main():
         n_launches = plan.n_launches
         mode = "one hipGraph replay per token (129 launches in stream order)" if not args.ungrouped else "one hipGraph replay per token"
         if dl.dataflow and args.issue != "graph":
-            # the same launch list as ONE persistent kernel; what the two forms must agree on, bit for bit: every output of the token
-            tplan = dl.make_plan(tagged=True)
-            outs = [*dl.out_qkv, dl.out_o, dl.out_gate, dl.out_up, dl.out_down, dl.logits]
-            why = None
-            if not tplan.tagged:
-                why = "the library built the plan stream-ordered (tce_plan_is_chained = %d)" % tplan.kind
-            else:
-                plan.launch(stream)
-                torch.cuda.synchronize()
-                want = [o.clone() for o in outs]
-                for rep in range(3):
-                    for o in outs:
-                        o.fill_(float("nan"))
-                    tplan.launch(stream)
+            try:  # the token-kernel variant never takes the bench line down with it: any failure leaves the stream-ordered graph as the step
+                # the same launch list as ONE persistent kernel; what the two forms must agree on, bit for bit: every output of the token
+                tplan = dl.make_plan(tagged=True)
+                outs = [*dl.out_qkv, dl.out_o, dl.out_gate, dl.out_up, dl.out_down, dl.logits]
+                why = None
+                if not tplan.tagged:
+                    why = "the library built the plan stream-ordered (tce_plan_is_chained = %d)" % tplan.kind
+                else:
+                    plan.launch(stream)
+                    torch.cuda.synchronize()
+                    want = [o.clone() for o in outs]
+                    for rep in range(3):
+                        for o in outs:
+                            o.fill_(float("nan"))
+                        tplan.launch(stream)
+                        tplan.status()
+                        if not all(torch.equal(a.view(torch.int16), b.view(torch.int16)) for a, b in zip(want, outs)):
+                            why = f"outputs differ from the stream-ordered plan (replay {rep})"
+                            break
+                    if why is None and not torch.isfinite(dl.logits.float()).all():
+                        why = "non-finite logits"
+                if why is not None:
+                    if args.issue == "token":
+                        raise SystemExit(f"--issue token: {why}")
+                    print(f"[bench] token kernel not used: {why}", file=sys.stderr)
+                    variants = {"token kernel": {"rejected": why}}
+                else:
+                    def rate(fn, n):
+                        for _ in range(10):
+                            fn()
+                        torch.cuda.synchronize()
+                        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        a.record()
+                        for _ in range(n):
+                            fn()
+                        b.record()
+                        torch.cuda.synchronize()
+                        return a.elapsed_time(b) / n
+                    tstep = lambda: tplan.launch(stream)
+                    ms_g, ms_t = rate(step, max(50, args.steps // 2)), rate(tstep, max(50, args.steps // 2))
                     tplan.status()
-                    if not all(torch.equal(a.view(torch.int16), b.view(torch.int16)) for a, b in zip(want, outs)):
-                        why = f"outputs differ from the stream-ordered plan (replay {rep})"
-                        break
-                if why is None and not torch.isfinite(dl.logits.float()).all():
-                    why = "non-finite logits"
-            if why is not None:
+                    variants = {"hipGraph of 129 launches (stream order)": {"ms_per_token": round(ms_g, 4), "tokens_per_s": round(1e3 / ms_g, 1)},
+                                "token kernel (TCE_PLAN_TAGGED)": {"ms_per_token": round(ms_t, 4), "tokens_per_s": round(1e3 / ms_t, 1), "geometry": tplan.geometry(),
+                                                                    "verified": "all outputs of the token bit-identical to the stream-ordered plan, 3 replays"}}
+                    if args.issue == "token" or ms_t < ms_g:
+                        step = tstep
+                        n_launches = 2
+                        mode = ("one persistent kernel per token: the 129 launches walked by the same workgroups, the linears' data flow ordered by tagged "
+                                "output words (TCE_PLAN_TAGGED) + a one-thread kernel that advances the tag")
+            except SystemExit:
+                raise
+            except Exception as e:  # noqa: BLE001
                 if args.issue == "token":
-                    raise SystemExit(f"--issue token: {why}")
-                print(f"[bench] token kernel not used: {why}", file=sys.stderr)
-                variants = {"token kernel": {"rejected": why}}
-            else:
-                def rate(fn, n):
-                    for _ in range(10):
-                        fn()
+                    raise
+                print(f"[bench] token kernel not used: {type(e).__name__}: {e}", file=sys.stderr)
+                variants = {"token kernel": {"rejected": f"{type(e).__name__}: {e}"}}
+                step = lambda: plan.launch(stream)
+                n_launches = plan.n_launches
+                try:
+                    capi.lib().tce_reset_last_error()
                     torch.cuda.synchronize()
-                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    a.record()
-                    for _ in range(n):
-                        fn()
-                    b.record()
-                    torch.cuda.synchronize()
-                    return a.elapsed_time(b) / n
-                tstep = lambda: tplan.launch(stream)
-                ms_g, ms_t = rate(step, max(50, args.steps // 2)), rate(tstep, max(50, args.steps // 2))
-                tplan.status()
-                variants = {"hipGraph of 129 launches (stream order)": {"ms_per_token": round(ms_g, 4), "tokens_per_s": round(1e3 / ms_g, 1)},
-                            "token kernel (TCE_PLAN_TAGGED)": {"ms_per_token": round(ms_t, 4), "tokens_per_s": round(1e3 / ms_t, 1), "geometry": tplan.geometry(),
-                                                                "verified": "all outputs of the token bit-identical to the stream-ordered plan, 3 replays"}}
-                if args.issue == "token" or ms_t < ms_g:
-                    step = tstep
-                    n_launches = 2
-                    mode = ("one persistent kernel per token: the 129 launches walked by the same workgroups, the linears' data flow ordered by tagged "
-                            "output words (TCE_PLAN_TAGGED) + a one-thread kernel that advances the tag")
+                except Exception:  # noqa: BLE001
+                    pass
     else:
         n_launches = dl.n_layers * 4 + 1
         graph = None
