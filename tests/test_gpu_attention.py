@@ -196,6 +196,40 @@ def test_attention_decode_step_against_float64_and_the_binary16_chain_kernel(dev
             assert np.all(np.abs(got - e) <= tol2), f"fp32 form vs binary16-chain form: {(np.abs(got - e) / tol2).max():.3f}"
 
 
+def test_attention_decode_step_chunk_merge_under_repetition(dev, oracle):
+    """The chunk merge crosses XCDs (the workgroups of a head sit on different L2s): partial results are stored write-through, a counter
+    elects the last workgroup, which reads them back with coherent loads.  200 back-to-back steps on ONE workspace, the values of every
+    past key and of q changing between steps, no host synchronisation inside a batch of 25: a partial that was read before it landed, or a
+    stale one from the previous step, would show up as a wrong head (the float64 reference is recomputed per step)."""
+    from tinychatengine_amd.attention_ops import DecodeAttention
+    heads, hd, max_keys = 32, 128, 2048
+    rng = np.random.default_rng(99)
+    att = DecodeAttention(heads, hd, max_keys, dev, None, None)  # no rotation: the reference below is then plain numpy
+    alpha = float(np.float16(1.0 / np.sqrt(hd)))
+    pos = max_keys - 1
+    for batch in range(8):
+        cases = []
+        for i in range(25):
+            K = (rng.standard_normal((heads, max_keys, hd)) * 0.8).astype(np.float16)
+            V = (rng.standard_normal((heads, max_keys, hd)) * 0.8).astype(np.float16)
+            qkv = (rng.standard_normal((3, heads, hd)) * 0.9).astype(np.float16)
+            cases.append((K, V, qkv))
+        outs = []
+        for (K, V, qkv) in cases:  # enqueue everything, synchronise once
+            att.k_cache.copy_(torch.from_numpy(K).to(dev), non_blocking=True)
+            att.v_cache.copy_(torch.from_numpy(V).to(dev), non_blocking=True)
+            outs.append(att.step(torch.from_numpy(qkv.reshape(-1)).to(dev), pos).clone())
+        torch.cuda.synchronize()
+        for i, ((K, V, qkv), out) in enumerate(zip(cases, outs)):
+            K = K.copy(); V = V.copy()
+            K[:, pos] = qkv[1]
+            V[:, pos] = qkv[2]
+            ref = _attention_reference_f64(qkv[0], K, V, alpha, None)
+            got = out.cpu().numpy().astype(np.float64)
+            tol = 2e-3 * np.abs(ref).max(axis=1, keepdims=True) + 2.0 ** -11 * np.abs(ref)
+            assert np.all(np.abs(got - ref) <= tol), f"batch {batch} step {i}: worst |err|/tol = {(np.abs(got - ref) / tol).max():.3f}"
+
+
 def test_attention_decode_step_argument_checks(dev):
     from tinychatengine_amd import capi
     L = capi.lib()

@@ -190,6 +190,35 @@ def test_pk_gemm_with_the_tail_tiles_cut(dev, oracle):
     assert int(gemm_scratch(dev)[:4096].to(torch.int32).sum().item()) == 0
 
 
+def test_pk_gemm_k_split_exchange_under_repetition(dev, oracle):
+    """The partial tiles of a k range cut across workgroups travel through the scratch area (write-through stores, a counter, coherent
+    loads): 150 back-to-back launches on ONE scratch area with the activations changing between launches and no host synchronisation in
+    between -- a partial read before it landed, or a stale one from the launch before, shows up against the whole-tile form."""
+    from tinychatengine_amd import capi
+    M, N, K, G = 256, 1024, 2048, 128  # 16 tiles, cut in 4 (the rule's choice when forced): 64 workgroups, 48 partial tiles per launch
+    qw, sc, zp = _quant(oracle, N, K, G, seed=123, random_zeros=True)
+    lin = _lin(dev, qw, sc, zp, G).prepack()
+    g = torch.Generator(device=dev).manual_seed(9)
+    xs = [torch.empty(M, K, device=dev).normal_(0, 1, generator=g).to(torch.float16) for _ in range(150)]
+    outs = [torch.empty(M, N, dtype=torch.float16, device=dev) for _ in range(150)]
+    st = torch.cuda.current_stream().cuda_stream
+    try:
+        capi.check(capi.lib().tce_w4a16_set_debug_mode(64))
+        assert "ksplit=" in capi.describe_dispatch(lin.desc(xs[0], outs[0]))
+        for x, o in zip(xs, outs):
+            capi.check(capi.w4a16_forward(lin.desc(x, o), st))
+        torch.cuda.synchronize()
+        capi.check(capi.lib().tce_w4a16_set_debug_mode(61))
+        whole = torch.empty(M, N, dtype=torch.float16, device=dev)
+        for i, (x, o) in enumerate(zip(xs, outs)):
+            capi.check(capi.w4a16_forward(lin.desc(x, whole), st))
+            torch.cuda.synchronize()
+            w = whole.float()
+            assert (o.float() - w).abs().max().item() <= 2e-3 * w.abs().max().item(), f"launch {i}"
+    finally:
+        capi.lib().tce_w4a16_set_debug_mode(60)
+
+
 def test_pk_dispatch_rules(dev, oracle):
     """No packed copy -> the other kernels; M < 192 -> the other kernels; in between the two GEMMs' cost models decide (the 64-row
     tiles keep M = 512 at N = 4096, where 128-row tiles are too few to fill 256 CUs); K % 128 != 0 -> no packed form at all."""
