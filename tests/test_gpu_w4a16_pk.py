@@ -215,6 +215,14 @@ def test_pk_gemm_k_split_exchange_under_repetition(dev, oracle):
             torch.cuda.synchronize()
             w = whole.float()
             assert (o.float() - w).abs().max().item() <= 2e-3 * w.abs().max().item(), f"launch {i}"
+        # the residual-add epilogue behind the exchange: C = hadd(C, y) with y the summed tile
+        res = torch.empty(M, N, device=dev).normal_(0, 2, generator=g).to(torch.float16)
+        got = res.clone()
+        capi.check(capi.lib().tce_w4a16_set_debug_mode(64))
+        capi.check(capi.w4a16_forward(lin.desc(xs[0], got, flags=capi.TCE_W4_ADD_TO_C), st))
+        torch.cuda.synchronize()
+        want = (res.float() + outs[0].float()).to(torch.float16)  # hadd of two halves = one rounding of the exact sum
+        assert torch.equal(got, want)
     finally:
         capi.lib().tce_w4a16_set_debug_mode(60)
 
