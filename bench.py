@@ -268,6 +268,58 @@ def launch_shape_table(dl, torch, launches: int = 128):
     return rows
 
 
+def whole_token_leg(torch, dev, shape, dl):
+    """One decode token through 32 complete decoder layers on this library's calls (tinychatengine_amd/decoder_block.py): per layer
+    [RMSNorm + q/k/v] [RoPE + KV append + attention, one launch] [o_proj + residual] [RMSNorm + gate/up + SiLU*mul] [down_proj + residual],
+    then lm_head -- 161 launches where the reference issues ~650 -- captured in one graph per context length.  Synthetic weights and
+    caches; the KV caches (2 x 32 x ctx x 128 halves per layer) are distinct per layer, so they stream from HBM like the weights."""
+    import numpy as np
+    from tinychatengine_amd import capi
+    from tinychatengine_amd.decoder_block import DecoderBlock
+    heads, hd, ctx_max = shape.hidden // 128, 128, 2048
+    ang = np.random.default_rng(0).uniform(0, 2 * np.pi, (ctx_max, hd // 2))
+    cos = torch.from_numpy(np.concatenate([np.cos(ang), np.cos(ang)], axis=1).astype(np.float16)).to(dev)
+    sin = torch.from_numpy(np.concatenate([np.sin(ang), np.sin(ang)], axis=1).astype(np.float16)).to(dev)
+    blocks = [DecoderBlock(shape.hidden, heads, shape.ffn, ctx_max, dev, cos, sin, seed=100 + i) for i in range(shape.layers)]
+    for b in blocks:
+        b.attention.k_cache.normal_(0, 0.8)
+        b.attention.v_cache.normal_(0, 0.8)
+    hid = torch.randn(1, shape.hidden, device=dev).to(torch.float16)
+    hid0 = hid.clone()
+    out = {"launches_per_token": shape.layers * DecoderBlock.LAUNCHES + 1, "layers": shape.layers}
+    for ctx in (512, 2048):
+        pos = ctx - 1
+        def token():
+            hid.copy_(hid0)
+            for b in blocks:
+                b.step(hid, pos)
+            capi.check(capi.w4a16_forward(dl.lm_head.desc(hid, dl.logits), torch.cuda.current_stream().cuda_stream))
+        token()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            token()
+        for _ in range(5):
+            g.replay()
+        torch.cuda.synchronize()
+        a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(50):
+            g.replay()
+        b_.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b_) / 50
+        kv = 2 * heads * ctx * hd * 2 * shape.layers
+        wb = sum(b.linear_bytes() for b in blocks)
+        out[f"context_{ctx}"] = {"tokens_per_s": round(1e3 / ms, 1), "ms_per_token": round(ms, 4), "kv_cache_bytes_read": kv,
+                                 "frac_of_8TBs": round((wb + kv) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "finite": bool(torch.isfinite(hid.float()).all().item())}
+        del g
+    del blocks
+    torch.cuda.empty_cache()
+    return out
+
+
 def _pmc_traffic(bytes_per_launch):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 --pmc FETCH_SIZE pass of this same roofline command
     (scripts/profile.sh; corrected as the MI355X guide prescribes: KiB x 1024 x 2 on gfx950).  The counters cannot be
@@ -623,6 +675,10 @@ def main():
         except Exception as e:  # noqa: BLE001
             extras["decode_launch_shapes"] = {"error": f"{type(e).__name__}: {e}"}
         if args.workload == "baseline-named":
+            try:  # the callers either side of the path: a WHOLE decode token -- norms, RoPE, KV append, attention, residuals -- in 5 launches per layer
+                extras["decode_with_attention"] = whole_token_leg(torch, dev, shape, dl)
+            except Exception as e:  # noqa: BLE001
+                extras["decode_with_attention"] = {"error": f"{type(e).__name__}: {e}"}
             try:  # BASELINE.json says "Llama-3-8B" but spells Llama-2-7B widths: the true Llama-3-8B shape set beside it
                 dl3 = DecodeLinears(SHAPES["llama3-8b"], device=dev, group_size=G, m=1)
                 plan3 = dl3.make_plan()

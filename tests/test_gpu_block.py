@@ -1,0 +1,66 @@
+"""A whole decoder block on this library's calls (tinychatengine_amd/decoder_block.py: 5 launches per layer -- fused RMSNorm + q/k/v, the
+one-launch attention step, o_proj + residual, fused RMSNorm + gate/up + SiLU*mul, down_proj + residual) against a float64 evaluation
+of Int4llamaDecoderLayer::forward's mathematics (Int4llamaDecoderLayer.cu:73-115, Int4llamaAttention.cu:116-229) on the dequantized
+weights, token after token with a growing KV cache.  This checks the COMPOSITION -- layouts handed from one call to the next (q | k | v
+rows, head-major; interleaved gate / up rows; the cache the attention step appends to; the residual stream updated in place) -- each
+call's own arithmetic is held to the oracle elsewhere.  Tolerance: binary16 intermediates, 2 % of the largest activation."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _rmsnorm(x, gamma, eps):
+    return x / np.sqrt(np.mean(x * x) + eps) * gamma
+
+
+def _rope(v, cos, sin):  # v [heads][128]; RotaryPosEmb_cuda_forward: v * cos + rotate_half(v) * sin
+    half = v.shape[-1] // 2
+    rot = np.concatenate([-v[:, half:], v[:, :half]], axis=1)
+    return v * cos[None, :] + rot * sin[None, :]
+
+
+@pytest.mark.parametrize("hidden,heads,ffn,layers,tokens", [(256, 2, 512, 2, 6), (512, 4, 1408, 1, 3)])
+def test_decoder_blocks_against_float64(hidden, heads, ffn, layers, tokens):
+    from tinychatengine_amd import capi
+    from tinychatengine_amd.decoder_block import DecoderBlock, dequantize
+    assert torch.cuda.is_available()
+    capi.lib()
+    dev = torch.device("cuda:0")
+    max_keys, hd = 64, 128
+    rng = np.random.default_rng(hidden + ffn)
+    ang = rng.uniform(0, 2 * np.pi, (max_keys, hd // 2))
+    cos = np.concatenate([np.cos(ang), np.cos(ang)], axis=1).astype(np.float16)  # the reference's tables repeat the half (RotaryPosEmb.cc)
+    sin = np.concatenate([np.sin(ang), np.sin(ang)], axis=1).astype(np.float16)
+    blocks = [DecoderBlock(hidden, heads, ffn, max_keys, dev, torch.from_numpy(cos).to(dev), torch.from_numpy(sin).to(dev), seed=10 + i) for i in range(layers)]
+    W = [{k: dequantize(getattr(b, k)) for k in ("qkv", "o", "gate", "up", "down")} for b in blocks]
+    G = [(b.gamma1.cpu().numpy().astype(np.float64), b.gamma2.cpu().numpy().astype(np.float64)) for b in blocks]
+    Kc = [np.zeros((heads, 0, hd)) for _ in blocks]
+    Vc = [np.zeros((heads, 0, hd)) for _ in blocks]
+    alpha = float(np.float16(1.0 / np.sqrt(hd)))
+    for pos in range(tokens):
+        x0 = rng.standard_normal(hidden).astype(np.float16)
+        h_gpu = torch.from_numpy(x0.reshape(1, -1).copy()).to(dev)
+        for b in blocks:
+            b.step(h_gpu, pos)
+        torch.cuda.synchronize()
+        h = x0.astype(np.float64)
+        c, s = cos[pos].astype(np.float64), sin[pos].astype(np.float64)
+        for li in range(layers):
+            qkv = W[li]["qkv"] @ _rmsnorm(h, G[li][0], 1e-6)
+            q, k, v = (qkv[i * hidden:(i + 1) * hidden].reshape(heads, hd) for i in range(3))
+            q, k = _rope(q, c, s), _rope(k, c, s)
+            Kc[li] = np.concatenate([Kc[li], k[:, None, :]], axis=1)
+            Vc[li] = np.concatenate([Vc[li], v[:, None, :]], axis=1)
+            sc = alpha * np.einsum("hd,hkd->hk", q, Kc[li])
+            p = np.exp(sc - sc.max(axis=1, keepdims=True))
+            p /= p.sum(axis=1, keepdims=True)
+            attn = np.einsum("hk,hkd->hd", p, Vc[li]).reshape(-1)
+            h = h + W[li]["o"] @ attn
+            hn = _rmsnorm(h, G[li][1], 1e-6)
+            gate, up = W[li]["gate"] @ hn, W[li]["up"] @ hn
+            h = h + W[li]["down"] @ (gate / (1.0 + np.exp(-gate)) * up)
+        got = h_gpu.cpu().numpy().astype(np.float64).reshape(-1)
+        tol = 2e-2 * np.abs(h).max()
+        assert np.abs(got - h).max() <= tol, f"token {pos}: max |err| {np.abs(got - h).max():.4f} vs tol {tol:.4f}"

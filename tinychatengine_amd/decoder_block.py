@@ -1,0 +1,72 @@
+"""One decode token through whole decoder blocks -- the caller side of the hot path and of its "next" rows, on this
+library's calls only.
+
+The reference's Int4llamaDecoderLayer::forward (llm/src/nn_modules/cuda/Int4llamaDecoderLayer.cu:73-115) with
+Int4llamaAttention::forward inside it (Int4llamaAttention.cu:116-229) issues, per layer and token, ~20 kernel launches and 4 memcpys
+per head: two RMSNorms, qkv_proj, shape_qkv, RoPE, the KV copies, qk_bmm, batch_Add, check_inf, softmax, transpose, pv_bmm, unshape,
+o_proj, add, gate_proj, up_proj, SiLuMul, down_proj, add.  Here a layer is FIVE launches:
+
+    1  input_layernorm + q/k/v projection        tce_w4a16_forward, descriptor with rmsnorm_gamma            
+    2  RoPE + KV append + attention              tce_attention_decode_step_f16                                
+    3  o_proj + residual add                     tce_w4a16_forward, TCE_W4_ADD_TO_C
+    4  post_attention_layernorm + gate/up + SiLU*mul   tce_w4a16_forward, rmsnorm_gamma + TCE_W4_SILU_MUL_PAIRS (gate / up rows interleaved)
+    5  down_proj + residual add                  tce_w4a16_forward, TCE_W4_ADD_TO_C
+
+Used by tests/test_gpu_block.py (against a float64 evaluation of the same layer on the dequantized weights) and by bench.py's
+`other_configs.decode_with_attention` leg.  Synthetic weights; nothing here loads a checkpoint.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import capi
+from .attention_ops import DecodeAttention
+from .linear import Linear_half_int4, _stream
+
+
+class DecoderBlock:
+    def __init__(self, hidden: int, heads: int, ffn: int, max_keys: int, device, cos: torch.Tensor, sin: torch.Tensor, seed: int = 0,
+                 group_size: int = 128, eps: float = 1e-6):
+        assert hidden % heads == 0 and hidden // heads == 128, "the attention step is built for head_dim 128 (Llama)"
+        self.hidden, self.heads, self.ffn, self.eps = hidden, heads, ffn, eps
+        g = torch.Generator(device=device).manual_seed(seed)
+        rnd = lambda n, k: torch.empty(n, k, device=device).normal_(0.0, k ** -0.5, generator=g)
+        self.qkv = Linear_half_int4.from_float(rnd(3 * hidden, hidden), group_size)   # rows: q | k | v, head-major (llama_qkv_merger.py:27-48)
+        self.o = Linear_half_int4.from_float(rnd(hidden, hidden), group_size)
+        self.gate = Linear_half_int4.from_float(rnd(ffn, hidden), group_size)
+        self.up = Linear_half_int4.from_float(rnd(ffn, hidden), group_size)
+        self.gate_up = Linear_half_int4.interleave(self.gate, self.up)                  # row 2n = gate n, row 2n + 1 = up n
+        self.down = Linear_half_int4.from_float(rnd(hidden, ffn), group_size)
+        self.gamma1 = (1.0 + 0.1 * torch.empty(hidden, device=device).normal_(0, 1, generator=g)).float()
+        self.gamma2 = (1.0 + 0.1 * torch.empty(hidden, device=device).normal_(0, 1, generator=g)).float()
+        self.attention = DecodeAttention(heads, 128, max_keys, device, cos, sin)
+        e = lambda n: torch.empty((1, n), dtype=torch.float16, device=device)
+        self.qkv_out, self.attn_out, self.act = e(3 * hidden), e(hidden), e(ffn)
+
+    def step(self, hidden_state: torch.Tensor, pos: int) -> None:
+        """hidden_state fp16 [1][hidden], updated in place (it is the residual stream)."""
+        st = _stream()
+        capi.check(capi.w4a16_forward(self.qkv.desc(hidden_state, self.qkv_out, gamma=self.gamma1, eps=self.eps), st))
+        self.attention.step(self.qkv_out.view(-1), pos, out=self.attn_out.view(self.heads, 128))
+        capi.check(capi.w4a16_forward(self.o.desc(self.attn_out, hidden_state, flags=capi.TCE_W4_ADD_TO_C), st))
+        capi.check(capi.w4a16_forward(self.gate_up.desc(hidden_state, self.act, flags=capi.TCE_W4_SILU_MUL_PAIRS, gamma=self.gamma2, eps=self.eps), st))
+        capi.check(capi.w4a16_forward(self.down.desc(self.act, hidden_state, flags=capi.TCE_W4_ADD_TO_C), st))
+
+    LAUNCHES = 5
+
+    def linear_bytes(self) -> int:
+        return sum(capi.algorithmic_bytes(1, l.out_features, l.in_features, l.group_size) for l in (self.qkv, self.o, self.gate_up, self.down))
+
+
+def dequantize(lin: Linear_half_int4) -> np.ndarray:
+    """fp64 [N][K] = scale * (code - zero point) of a q4_6 linear (for the float64 reference of the tests)."""
+    qw = lin.weight.cpu().numpy().view(np.uint32)
+    n, k8 = qw.shape
+    codes = ((qw[:, :, None] >> (np.arange(8, dtype=np.uint32) * 4)) & 0xF).reshape(n, k8 * 8).astype(np.float64)
+    g = lin.group_size
+    ng = k8 * 8 // g
+    sc = lin.scale.cpu().numpy().astype(np.float64)[:, :ng]
+    zp = lin.zero_point.cpu().numpy().view(np.uint32)
+    z = ((zp[:, :, None] >> (np.arange(8, dtype=np.uint32) * 4)) & 0xF).reshape(n, -1)[:, :ng].astype(np.float64)
+    return (codes.reshape(n, ng, g) - z[:, :, None]).reshape(n, -1) * np.repeat(sc, g, axis=1)
