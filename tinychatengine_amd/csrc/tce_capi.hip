@@ -91,6 +91,7 @@ static bool use_pk(const tce_w4a16_desc *d, bool want_gemm) {
 // profiles/r2/gemv_geometry_sweep.jsonl; round 1 compared against the eight-wave geometry: 50.5-57 us).  It stays available through tce_w4a16_set_gemv_config(rows, waves, 0, depth), carries the fused
 // RMSNorm prologue from 8k rows up, and is the body of the token kernel.
 constexpr long long kPersistentMinWeights = 1LL << 62;
+constexpr long long kFusedNormPersistentRows = 16384;  // fused RMSNorm prologue: rows from which the persistent kernel carries it
 int g_gemv_kernel = 0;  // 0 automatic, 1 workgroup-per-row-block kernel forced, 2 persistent stream kernel forced
 int g_skinny_enabled = 1;  // tuning: tce_w4a16_set_debug_mode(29) routes 3 <= M <= 16 to the GEMV / GEMM kernels again
 
@@ -273,10 +274,12 @@ static int forward_group_norm(const tce_w4a16_desc *descs, int count, const floa
     hipError_t he = hipSuccess;
     // The prologue costs a workgroup one extra pass over x plus 4 bytes of gamma per element: 256 persistent workgroups
     // pay that once each, thousands of row-block workgroups do not amortise it (Llama-3 gate+up: no gain over two
-    // launches).  So the persistent kernel takes the fused form from ~8k rows up; the row-block kernel below that.
+    // launches).  So the persistent kernel takes the fused form from ~16k rows up; the row-block kernel below that
+    // (in-process A/B, scripts/fused_launch_ab.py, profiles/r2/fused_launch_ab.jsonl: norm + q/k/v 12288 rows 9.6 us row-block (4 rows,
+    // 4 waves) vs 10.9 persistent; norm + gate/up 22016 rows 13.4 us persistent vs 15.8 row-block).
     long long rows = 0;
     for (int i = 0; i < count; ++i) rows += descs[i].N;
-    if (g_gemv_kernel == 2 || (g_gemv_kernel == 0 && rows >= 8192)) {
+    if (g_gemv_kernel == 2 || (g_gemv_kernel == 0 && rows >= kFusedNormPersistentRows)) {
         const int rc = tce::launch_w4a16_gemv_stream(descs, count, static_cast<hipStream_t>(stream), &he, gamma, eps);
         if (rc == TCE_OK) return TCE_OK;
         if (rc == TCE_ERR_HIP) return hip_fail(he, "w4a16 persistent gemv launch");
@@ -409,7 +412,7 @@ int tce_w4a16_describe_dispatch(const tce_w4a16_desc *d, char *buf, int buf_len)
         return TCE_OK;
     }
     // which GEMV kernel: same rule as tce_w4a16_forward_group (one linear per launch here)
-    const bool persistent = g_gemv_kernel == 2 || (d->rmsnorm_gamma ? (g_gemv_kernel == 0 && d->N >= 8192)
+    const bool persistent = g_gemv_kernel == 2 || (d->rmsnorm_gamma ? (g_gemv_kernel == 0 && d->N >= kFusedNormPersistentRows)
                                                                      : (g_gemv_kernel == 0 && d->M == 1 && (long long)d->N * d->K >= kPersistentMinWeights && g_debug_mode_capi == 0));
     std::snprintf(buf, (size_t)buf_len, "gemv passes=%d kernel=%s", (d->M + 3) / 4, persistent && d->M == 1 ? "persistent" : "row-block");
     return TCE_OK;

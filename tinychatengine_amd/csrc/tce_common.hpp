@@ -140,26 +140,23 @@ __device__ __forceinline__ half_t rmsnorm_out(half_t x, float rs, float gamma) {
 }
 
 // rs = 1 / sqrt(mean(x^2) + eps) of one fp16 row of n (n % 8 == 0) elements, formed by a whole workgroup in an order that
-// does not depend on the workgroup's shape, so the fused GEMV prologue and the stand-alone kernel produce identical bits:
-// the row's 16-byte pieces are cut into 16 chunks (of a multiple of 64 pieces); within a chunk lane l accumulates pieces
-// l, l + 64, ... in order (fmaf, fp32); wave w takes chunks w, w + nwaves, ...; the [16][64] partial sums meet in LDS, each
-// lane adds its 16 in chunk order, and the 64 lane sums go through the fixed DPP tree.  `part` = 4 KiB of LDS; contains
-// two barriers (the second one frees `part` for reuse).
-// `load_piece(p)` returns the row's p-th 16-byte piece as 8 halves.
-template <typename LoadPiece>
-__device__ __forceinline__ float rmsnorm_rs_block(LoadPiece load_piece, int n, float eps, int wave, int nwaves, int lane, float *part) {
-    const int pieces = n >> 3;
-    const int chunk = ((pieces + 15) / 16 + 63) & ~63;
-    for (int c = wave; c < 16; c += nwaves) {
-        float ss = 0.f;
-        const int end = (c + 1) * chunk < pieces ? (c + 1) * chunk : pieces;
-        for (int p = c * chunk + lane; p < end; p += 64) {
-            const half8_t v = load_piece(p);
+// does not depend on the workgroup's shape, so the fused GEMV prologues and the stand-alone kernel produce identical bits.
+// THE ORDER (round 2; for n <= 8192 the same bits as round 1's):
+//   s_p     of the row's p-th 16-byte piece: s = 0, then s = fmaf(v_e, v_e, s) for its 8 values in order;
+//   slot[q] for q = 0 .. 1023: s_q + s_{q + 1024} + s_{q + 2048} + ... in that order (0 where the row has no such piece);
+//   t_l     for lane l = 0 .. 63: slot[l] + slot[64 + l] + ... + slot[960 + l] in that order;
+//   tot     = the fixed DPP tree over the 64 t_l (wave_sum_dpp_lane63);  rs = 1 / sqrtf(tot / n + eps).
+// A piece's s_p needs nothing but the piece, so a kernel that already holds the row in registers (w4a16_gemv.hip) forms the slots
+// from there -- rmsnorm_slots_finish() below is the part from `slot[]` on; rmsnorm_rs_block() is the whole thing for callers that
+// read the row through `load_piece(p)` (the row's p-th piece as 8 halves): wave w fills slots 64 c + lane for c = w, w + nwaves, ...
+// `part` = 4 KiB of LDS holding slot[]; both contain two barriers (the second one frees `part` for reuse).
+__device__ __forceinline__ float rmsnorm_piece_sum(half8_t v) {
+    float s = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) ss = __builtin_fmaf((float)v[e], (float)v[e], ss);
-        }
-        part[c * 64 + lane] = ss;
-    }
+    for (int e = 0; e < 8; ++e) s = __builtin_fmaf((float)v[e], (float)v[e], s);
+    return s;
+}
+__device__ __forceinline__ float rmsnorm_slots_finish(const float *part, int n, float eps, int lane) {
     __syncthreads();
     float tot = 0.f;
 #pragma unroll
@@ -168,6 +165,16 @@ __device__ __forceinline__ float rmsnorm_rs_block(LoadPiece load_piece, int n, f
     tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), 63));
     __syncthreads();
     return 1.0f / sqrtf(tot / (float)n + eps);
+}
+template <typename LoadPiece>
+__device__ __forceinline__ float rmsnorm_rs_block(LoadPiece load_piece, int n, float eps, int wave, int nwaves, int lane, float *part) {
+    const int pieces = n >> 3;
+    for (int c = wave; c < 16; c += nwaves) {
+        float slot = 0.f;
+        for (int p = c * 64 + lane; p < pieces; p += 1024) slot += rmsnorm_piece_sum(load_piece(p));
+        part[c * 64 + lane] = slot;
+    }
+    return rmsnorm_slots_finish(part, n, eps, lane);
 }
 __device__ __forceinline__ float rmsnorm_rs_block(const half_t *x, int n, float eps, int wave, int nwaves, int lane, float *part) {
     return rmsnorm_rs_block([&](int p) { return *reinterpret_cast<const half8_t *>(x + p * 8); }, n, eps, wave, nwaves, lane, part);

@@ -93,9 +93,17 @@ __global__ __launch_bounds__(64 * WN * WK, (MB * ROWS * DEPTH >= 8 ? 2 : (MB * R
     };
     uint4_t xv[XB];
     bool xok[XB];
-    if constexpr (!NORM) {
 #pragma unroll
-        for (int i = 0; i < XB; ++i) xv[i] = *x_src(tid + i * NTHREADS, xok[i]);
+    for (int i = 0; i < XB; ++i) xv[i] = *x_src(tid + i * NTHREADS, xok[i]);
+    // fused RMSNorm prologue: gamma of the same 8 columns, requested now (their latency overlaps the weight prologue below)
+    float4_t gv[NORM ? XB : 1][2];
+    if constexpr (NORM) {
+#pragma unroll
+        for (int i = 0; i < XB; ++i) {
+            const float *gp = args.gamma + (reinterpret_cast<const half_t *>(x_src(tid + i * NTHREADS, xok[i])) - A);  // same column offset as the x piece (M = 1)
+            gv[i][0] = *reinterpret_cast<const float4_t *>(gp);
+            gv[i][1] = *reinterpret_cast<const float4_t *>(gp + 4);
+        }
     }
 
     // ---- weight stream: buffer descriptors + scalar row offsets ----
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(64 * WN * WK, (MB * ROWS * DEPTH >= 8 ? 2 : (MB * R
     // Prologue: DEPTH steps issued unconditionally (the host only picks variants with DEPTH <= T), so every wait the
     // compiler places is an exact counted vmcnt.
     Step st[DEPTH];
-    constexpr bool XFIRST = (MODE == 3) && !NORM;  // stage x completely before the first weight load is issued (see launch_variant)
+    constexpr bool XFIRST = MODE == 3;  // stage x completely before the first weight load is issued (see launch_variant)
     if constexpr (!XFIRST) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) issue(st[d], d);
@@ -172,26 +180,61 @@ __global__ __launch_bounds__(64 * WN * WK, (MB * ROWS * DEPTH >= 8 ? 2 : (MB * R
     };
     if constexpr (NORM) {
         static_assert(MB == 1, "the fused RMSNorm prologue is a decode (M = 1) feature");
-        // rs by the whole workgroup, in the shape-independent order of rmsnorm_rs_block (same bits as tce_rmsnorm_half);
-        // its 4 KiB of partial sums live in the trash-slot area behind the image
-        static_assert(NTHREADS >= 256, "the trash-slot area must hold 16 x 64 floats");
-        const float rs = rmsnorm_rs_block(A, K, args.eps, wave, WN * WK, lane, reinterpret_cast<float *>(smem + (size_t)total_pieces * 16));
-        // normalise, permute, write the image (the row is re-read: L1/L2 hits)
-        for (int p = tid; p < total_pieces; p += NTHREADS) {
-            const int c = (p >> 8) * 64 + (p & 63), j = (p >> 6) & 3;
-            uint4_t o = uint4_t{0u, 0u, 0u, 0u};
-            if (c < nchunks) {
-                const int k0 = c * 32 + j * 8;
-                const half8_t v = *reinterpret_cast<const half8_t *>(A + k0);
-                const float4_t g0 = *reinterpret_cast<const float4_t *>(args.gamma + k0), g1 = *reinterpret_cast<const float4_t *>(args.gamma + k0 + 4);
-                half8_t y;
+        // rs in the shape-independent order of tce_common.hpp (same bits as tce_rmsnorm_half and as the persistent kernel's prologue), formed
+        // from the pieces this thread ALREADY holds: piece sums -> the 1024 slots (4 KiB in the trash-slot area behind the image) -> the
+        // fixed lane / DPP tree.  Image piece p' is row piece lin(p') = 4 * ((p' >> 8) * 64 + (p' & 63)) + ((p' >> 6) & 3), a permutation
+        // inside every run of 256, so thread tid's pieces p' = tid + i * NTHREADS fall into slots lin(tid + r * NTHREADS), r = i mod R,
+        // in increasing row order -- and the threads' R slots each cover all 1024 exactly once.
+        static_assert(NTHREADS >= 256 && 1024 % NTHREADS == 0, "the trash-slot area must hold 16 x 64 floats; slots are dealt out per thread");
+        constexpr int R = 1024 / NTHREADS;
+        float *part = reinterpret_cast<float *>(smem + (size_t)total_pieces * 16);
+        float sl[R];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    y[e] = rmsnorm_out(v[e], rs, g0[e]);
-                    y[4 + e] = rmsnorm_out(v[4 + e], rs, g1[e]);
-                }
-                o = pair_permute(__builtin_bit_cast(uint4_t, y));
+        for (int r = 0; r < R; ++r) sl[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < XB; ++i) sl[i % R] += xok[i] ? rmsnorm_piece_sum(__builtin_bit_cast(half8_t, xv[i])) : 0.f;
+        for (int base = XB * NTHREADS, b = 1; base < total_pieces; base += XB * NTHREADS, ++b) {  // long K only: the rest of the row
+#pragma unroll
+            for (int i = 0; i < XB; ++i) {
+                bool ok;
+                const uint4_t v = *x_src(base + tid + i * NTHREADS, ok);
+                const float sp = ok ? rmsnorm_piece_sum(__builtin_bit_cast(half8_t, v)) : 0.f;
+                const int r = (XB * b + i) & (R - 1);
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr)
+                    if (rr == r) sl[rr] += sp;
             }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int pp = tid + r * NTHREADS;
+            part[(((pp >> 8) * 64 + (pp & 63)) << 2) + ((pp >> 6) & 3)] = sl[r];
+        }
+        const float rs = rmsnorm_slots_finish(part, K, args.eps, lane);
+        // normalise, permute, write the image: the first batch from registers, the rest of a long row re-read (L1 / L2 hits)
+        auto norm_piece = [&](uint4_t raw, const float4_t &g0, const float4_t &g1) -> uint4_t {
+            const half8_t v = __builtin_bit_cast(half8_t, raw);
+            half8_t y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[e] = rmsnorm_out(v[e], rs, g0[e]);
+                y[4 + e] = rmsnorm_out(v[4 + e], rs, g1[e]);
+            }
+            return pair_permute(__builtin_bit_cast(uint4_t, y));
+        };
+#pragma unroll
+        for (int i = 0; i < XB; ++i) {
+            const int p = tid + i * NTHREADS;
+            uint4_t o = norm_piece(xv[i], gv[i][0], gv[i][1]);
+            if (!xok[i]) o = uint4_t{0u, 0u, 0u, 0u};
+            xs[p < total_pieces ? p : total_pieces + tid] = o;
+        }
+        for (int p = XB * NTHREADS + tid; p < total_pieces; p += NTHREADS) {
+            bool ok;
+            const uint4_t *src = x_src(p, ok);
+            const float *gp = args.gamma + (reinterpret_cast<const half_t *>(src) - A);
+            uint4_t o = norm_piece(*src, *reinterpret_cast<const float4_t *>(gp), *reinterpret_cast<const float4_t *>(gp + 4));
+            if (!ok) o = uint4_t{0u, 0u, 0u, 0u};
             xs[p] = o;
         }
     } else {
@@ -423,6 +466,12 @@ hipError_t launch_variant(const GemvArgs &a, int total_blocks, int m_blocks, hip
     } else {
         if constexpr (MB == 1) {
             if (a.gamma) {
+                // like the plain launches below: "x first" when the whole grid is one generation of workgroups -- round 2 found the fused
+                // prologue 2.6 us slower than the plain launch for exactly this reason (its x loads queued behind every wave's weights)
+                const int wps = (ROWS == 4 && DEPTH == 1) ? 5 : (ROWS * DEPTH <= 2 ? 8 : 4);
+                if (total_blocks <= 256 * (4 * wps / (WN * WK)))
+                    return a.zeros_are_8 ? launch_one<1, ROWS, WN, WK, DEPTH, 2, 3, true, true>(a, total_blocks, m_blocks, stream)
+                                         : launch_one<1, ROWS, WN, WK, DEPTH, 2, 3, false, true>(a, total_blocks, m_blocks, stream);
                 return a.zeros_are_8 ? launch_one<1, ROWS, WN, WK, DEPTH, 2, 0, true, true>(a, total_blocks, m_blocks, stream)
                                      : launch_one<1, ROWS, WN, WK, DEPTH, 2, 0, false, true>(a, total_blocks, m_blocks, stream);
             }
