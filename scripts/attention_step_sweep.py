@@ -11,7 +11,7 @@ L = capi.lib()
 al = int(np.array([0.0884], np.float16).view(np.uint16)[0])
 qkv = torch.randn(3 * 32 * 128, device=dev).half()
 oo = torch.empty(32, 128, dtype=torch.float16, device=dev)
-for t in (128, 512, 2048, 8192):
+for t in (128, 256, 512, 1024, 2048, 4096, 8192):
     bytes_ = 2 * 32 * t * 128 * 2
     nsets = min(96, max(4, int(3.2e8 // bytes_) + 1))
     cos = torch.randn(t + 1, 128, device=dev).half(); sin = torch.randn(t + 1, 128, device=dev).half()
@@ -23,10 +23,11 @@ for t in (128, 512, 2048, 8192):
         capi.check(L.tce_attention_decode_step_f16(qkv.data_ptr(), a_.k_cache.data_ptr(), a_.v_cache.data_ptr(), cos.data_ptr(), sin.data_ptr(), None, oo.data_ptr(),
                                                    a_.workspace.data_ptr(), 32, 128, t, t - 1, al, sp))
     row = {"context": t, "kv_MB": round(bytes_ / 1e6, 1), "cache_sets": nsets}
-    for wgs in (128, 256, 384, 512, 768, 1024, 2048):
+    for wgs in (32, 64, 128, 192, 256, 384, 512, 1024):
         capi.check(L.tce_w4a16_set_debug_mode(3000 + wgs))
         us = time_graph(step, max(32, nsets))
         row[f"wgs{wgs}_us"] = round(us, 2)
-    capi.check(L.tce_w4a16_set_debug_mode(3000 + 256))
+    capi.check(L.tce_w4a16_set_debug_mode(3000))  # back to the fitted rule
+    row["rule_us"] = round(time_graph(step, max(32, nsets)), 2)
     print(json.dumps(row), flush=True)
     del atts

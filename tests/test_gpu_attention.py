@@ -146,8 +146,21 @@ def _attention_reference_f64(q_rot, K, V, alpha, mask):
     return np.einsum("hk,hkd->hd", p, V.astype(np.float64))
 
 
-@pytest.mark.parametrize("heads,max_keys,steps,start", [(32, 64, 40, 0), (8, 2048, 3, 2045), (32, 2048, 2, 1000), (4, 300, 5, 250)])
-def test_attention_decode_step_against_float64_and_the_binary16_chain_kernel(dev, oracle, heads, max_keys, steps, start):
+@pytest.mark.parametrize("heads,max_keys,steps,start,cut", [(32, 64, 40, 0, 0), (8, 2048, 3, 2045, 0), (8, 2048, 3, 2045, 1024), (32, 2048, 2, 1000, 0),
+                                                             (4, 300, 5, 250, 0), (32, 700, 3, 600, 0), (4, 300, 3, 100, 64)])
+def test_attention_decode_step_against_float64_and_the_binary16_chain_kernel(dev, oracle, heads, max_keys, steps, start, cut):
+    """cut = 0: the fitted rule picks the chunks (one per head up to 320 keys, four up to 1024, eight beyond); otherwise the key range is cut
+    for that many workgroups (8 heads, 1024 workgroups: 32 chunks, the combine's one-by-one tail past 16 chunks)."""
+    from tinychatengine_amd.attention_ops import DecodeAttention, attention_decode
+    from tinychatengine_amd import capi
+    capi.check(capi.lib().tce_w4a16_set_debug_mode(3000 + cut))
+    try:
+        _attention_step_case(dev, oracle, heads, max_keys, steps, start)
+    finally:
+        capi.check(capi.lib().tce_w4a16_set_debug_mode(3000))
+
+
+def _attention_step_case(dev, oracle, heads, max_keys, steps, start):
     from tinychatengine_amd.attention_ops import DecodeAttention, attention_decode
     hd = 128
     rng = np.random.default_rng(heads + max_keys + start)

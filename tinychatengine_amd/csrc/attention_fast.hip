@@ -56,11 +56,8 @@ __device__ __forceinline__ float row16_sum(float v) {  // sum over the 16 lanes 
 
 // RotaryPosEmb_cuda_forward on the 8 elements of `piece` (hd = 128: the partner half is piece ^ 8):
 //   out[j] = hfma(x[j], cos[j], hmul(rot[j], sin[j])),  rot[j] = j < hd/2 ? -x[j + hd/2] : x[j - hd/2]
-__device__ __forceinline__ half8_t rope_piece(const half_t *x, const half_t *cosr, const half_t *sinr, int piece) {
-    const half8_t v = *reinterpret_cast<const half8_t *>(x + piece * 8);
-    if (!cosr) return v;
-    const half8_t p = *reinterpret_cast<const half8_t *>(x + (piece ^ 8) * 8);
-    const half8_t c = *reinterpret_cast<const half8_t *>(cosr + piece * 8), s = *reinterpret_cast<const half8_t *>(sinr + piece * 8);
+// v = the piece, p = the partner piece, c / s = the cos / sin pieces (all loaded by the caller, in one batch)
+__device__ __forceinline__ half8_t rope_apply(const half8_t v, const half8_t p, const half8_t c, const half8_t s, int piece) {
     half8_t o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -74,6 +71,8 @@ __device__ __forceinline__ half8_t rope_piece(const half_t *x, const half_t *cos
 constexpr int kHD = 128;
 constexpr float kNegBig = -1.0e30f;
 
+// MASK: the caller gave a mask row (a compile-time form: a branch inside the fetch block makes hipcc drain the load queue at the loop head)
+template <bool MASK>
 __global__ __launch_bounds__(256) void attn_decode_fast_kernel(const FastAttnArgs a) {
     __shared__ __attribute__((aligned(16))) float st[16][2 + kHD];  // the 16 (wave, slot) states: m, l, o[hd]
     __shared__ __attribute__((aligned(16))) half_t newrow[2][kHD];  // the token's own (rotated) key and value
@@ -84,12 +83,47 @@ __global__ __launch_bounds__(256) void attn_decode_fast_kernel(const FastAttnArg
     const int key0 = c * a.chunk, key1 = key0 + a.chunk < a.keys ? key0 + a.chunk : a.keys;
     const half_t *cosr = a.cosv ? a.cosv + (size_t)a.pos * kHD : nullptr, *sinr = a.sinv ? a.sinv + (size_t)a.pos * kHD : nullptr;
     const size_t hoff = (size_t)head * kHD;
-    // ---- q (rotated), this lane's 8 dimensions, in fp32 ----
-    const half8_t qh = rope_piece(a.qkv + hoff, cosr, sinr, piece);
+    // ---- this wave's keys: chunk / 4 consecutive ones, 4 per step.  Their addresses depend on nothing but the arguments, so the
+    //      first block of cache rows is requested BEFORE q / cos / sin: one memory round trip per launch instead of two (the
+    //      same rule as the GEMV's "weights right behind x") ----
+    const int per_wave = a.chunk >> 2;
+    const int kw0 = key0 + wave * per_wave;
+    const int kw1 = kw0 + per_wave < key1 ? kw0 + per_wave : key1;  // a block is 16 keys, a wave's run any multiple of 4: the rest weighs nothing
+    const half_t *kbase = a.kc + (size_t)head * a.max_keys * kHD, *vbase = a.vc + (size_t)head * a.max_keys * kHD;
+    // blocks of 4 steps (16 keys per wave): the 8 loads of the next block are in flight while this block's scores and
+    // exponentials are computed (the online-softmax state is the only loop-carried dependence; without the explicit double
+    // buffer every step paid a full memory round trip: 20 us at 2048 keys, profiles/r2/attention_decode_step.jsonl)
+    constexpr int BLK = 4;
+    half8_t kbuf[2][BLK], vbuf[2][BLK];
+    half_t mbuf[2][BLK];  // the keys' mask values travel with their rows (a load per step inside consume() drained the queue)
+    auto fetch = [&](half8_t (&kd)[BLK], half8_t (&vd)[BLK], half_t (&md)[BLK], int it0) {
+#pragma unroll
+        for (int u = 0; u < BLK; ++u) {
+            const int key = kw0 + it0 + u * 4 + slot;
+            const int kk = key < kw1 ? key : (a.keys - 1);  // clamped: rows past the range are read (harmlessly) and weigh nothing
+            kd[u] = *reinterpret_cast<const half8_t *>(kbase + (size_t)kk * kHD + piece * 8);
+            vd[u] = *reinterpret_cast<const half8_t *>(vbase + (size_t)kk * kHD + piece * 8);
+            if constexpr (MASK) md[u] = a.mask[kk];
+            else md[u] = (half_t)0;
+        }
+    };
+    fetch(kbuf[0], vbuf[0], mbuf[0], 0);  // (the row at index pos may not be in the cache yet: consume() takes it from LDS)
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- every piece the prologue needs, requested together behind them: q, k (with their partner halves), v, cos, sin.  All four
+    //      waves fetch the k / v pieces (L2 hits, 3 instructions) so that nobody waits for a second batch; wave 0 uses them ----
+    const bool rope = cosr != nullptr;
+    const half_t *xq = a.qkv + hoff, *xk = a.qkv + (size_t)a.heads * kHD + hoff, *xv = a.qkv + (size_t)2 * a.heads * kHD + hoff;
+    const half_t *cp = rope ? cosr : xq, *sp = rope ? sinr : xq;  // no rotation: harmless repeats of the q piece, not used
+    auto ld8 = [](const half_t *ptr) { return *reinterpret_cast<const half8_t *>(ptr); };
+    const half8_t q_v = ld8(xq + piece * 8), q_p = ld8(xq + (piece ^ 8) * 8), cc = ld8(cp + piece * 8), ss = ld8(sp + piece * 8);
+    const half8_t k_v = ld8(xk + piece * 8), k_p = ld8(xk + (piece ^ 8) * 8), v_v = ld8(xv + piece * 8);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- q (rotated), this lane's 8 dimensions ----
+    const half8_t qh = rope ? rope_apply(q_v, q_p, cc, ss, piece) : q_v;
     // ---- the new key / value of this head: into LDS for this workgroup's use, into the cache by the workgroup that owns index pos ----
     if (wave == 0) {
-        const half8_t kh = rope_piece(a.qkv + (size_t)a.heads * kHD + hoff, cosr, sinr, piece);
-        const half8_t vh = *reinterpret_cast<const half8_t *>(a.qkv + (size_t)2 * a.heads * kHD + hoff + piece * 8);
+        const half8_t kh = rope ? rope_apply(k_v, k_p, cc, ss, piece) : k_v;
+        const half8_t vh = v_v;
         if (slot == 0) {
             *reinterpret_cast<half8_t *>(&newrow[0][piece * 8]) = kh;
             *reinterpret_cast<half8_t *>(&newrow[1][piece * 8]) = vh;
@@ -100,32 +134,14 @@ __global__ __launch_bounds__(256) void attn_decode_fast_kernel(const FastAttnArg
         }
     }
     __syncthreads();
-    // ---- this wave's keys: chunk / 4 consecutive ones, 4 per step ----
-    const int per_wave = a.chunk >> 2;
-    const int kw0 = key0 + wave * per_wave;
     float m = kNegBig, l = 0.f, acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    const half_t *kbase = a.kc + (size_t)head * a.max_keys * kHD, *vbase = a.vc + (size_t)head * a.max_keys * kHD;
-    // blocks of 4 steps (16 keys per wave): the 8 loads of the next block are in flight while this block's scores and
-    // exponentials are computed (the online-softmax state is the only loop-carried dependence; without the explicit double
-    // buffer every step paid a full memory round trip: 20 us at 2048 keys, profiles/r2/attention_decode_step.jsonl)
-    constexpr int BLK = 4;
-    half8_t kbuf[2][BLK], vbuf[2][BLK];
-    auto fetch = [&](half8_t (&kd)[BLK], half8_t (&vd)[BLK], int it0) {
+    auto consume = [&](const half8_t (&kd)[BLK], const half8_t (&vd)[BLK], const half_t (&md)[BLK], int it0) {
 #pragma unroll
         for (int u = 0; u < BLK; ++u) {
             const int key = kw0 + it0 + u * 4 + slot;
-            const int kk = key < key1 ? key : (a.keys - 1);  // clamped: rows past the range are read (harmlessly) and weigh nothing
-            kd[u] = *reinterpret_cast<const half8_t *>(kbase + (size_t)kk * kHD + piece * 8);
-            vd[u] = *reinterpret_cast<const half8_t *>(vbase + (size_t)kk * kHD + piece * 8);
-        }
-    };
-    auto consume = [&](const half8_t (&kd)[BLK], const half8_t (&vd)[BLK], int it0) {
-#pragma unroll
-        for (int u = 0; u < BLK; ++u) {
-            const int key = kw0 + it0 + u * 4 + slot;
-            const bool valid = key < key1;
+            const bool valid = key < kw1;
             half8_t kv = kd[u], vv = vd[u];
             if (key == a.pos) {  // the token's own row: not necessarily visible in the cache yet
                 kv = *reinterpret_cast<const half8_t *>(&newrow[0][piece * 8]);
@@ -136,7 +152,7 @@ __global__ __launch_bounds__(256) void attn_decode_fast_kernel(const FastAttnArg
             for (int e = 0; e < 8; e += 2) d = __builtin_amdgcn_fdot2(half2_t{qh[e], qh[e + 1]}, half2_t{kv[e], kv[e + 1]}, d, false);
             d = row16_sum(d);
             float s = a.alpha * d;
-            if (a.mask) s += (float)a.mask[valid ? key : a.keys - 1];
+            if constexpr (MASK) s += (float)md[u];
             if (!(__builtin_fabsf(s) <= 65504.0f)) s = -65504.0f;  // check_inf_half (Int4llamaAttention.cu:105-115): inf / nan / beyond binary16 -> -65504
             if (!valid) s = kNegBig;
             const float mn = __builtin_fmaxf(m, s);
@@ -148,13 +164,12 @@ __global__ __launch_bounds__(256) void attn_decode_fast_kernel(const FastAttnArg
         }
     };
     // per_wave is a multiple of 4 (steps); blocks of 4 steps, the last one possibly past the range (clamped loads, zero weights)
-    fetch(kbuf[0], vbuf[0], 0);
     for (int it = 0; it < per_wave; it += 2 * BLK * 4) {
-        fetch(kbuf[1], vbuf[1], it + BLK * 4);
-        consume(kbuf[0], vbuf[0], it);
+        fetch(kbuf[1], vbuf[1], mbuf[1], it + BLK * 4);
+        consume(kbuf[0], vbuf[0], mbuf[0], it);
         if (it + BLK * 4 >= per_wave) break;
-        fetch(kbuf[0], vbuf[0], it + 2 * BLK * 4);
-        consume(kbuf[1], vbuf[1], it + BLK * 4);
+        fetch(kbuf[0], vbuf[0], mbuf[0], it + 2 * BLK * 4);
+        consume(kbuf[1], vbuf[1], mbuf[1], it + BLK * 4);
     }
     // ---- merge the workgroup's 16 states ----
     {
@@ -241,19 +256,38 @@ __global__ __launch_bounds__(256) void attn_decode_fast_kernel(const FastAttnArg
 }  // namespace
 
 // chunk of keys per workgroup: heads x chunks should cover the chip a couple of times; a multiple of 16 (4 waves x 4 keys per step)
-static int g_attn_target_wgs = 256;  // tuning: tce_w4a16_set_debug_mode(3000 + workgroups)
-void set_attention_fast_target(int wgs) { g_attn_target_wgs = wgs >= 32 && wgs <= 8192 ? wgs : 256; }
+static int g_attn_target_wgs = 0;  // 0: the fitted rule below; tuning: tce_w4a16_set_debug_mode(3000 + workgroups)
+void set_attention_fast_target(int wgs) { g_attn_target_wgs = wgs >= 32 && wgs <= 8192 ? wgs : 0; }
 
-// Measured (scripts/attention_step_sweep.py, profiles/r2/attention_step_sweep.jsonl; caches rotating through > 256 MB so the keys come
-// from HBM): one workgroup per CU is the best cut at every context -- 2048 keys 12.0 us with 256 workgroups, 12.5 with 128, 14.8 with 512
-// (more partials to merge and shorter key runs per wave cost more than the extra loads in flight bring).  A combine without the
-// acknowledged-store -> atomic -> coherent-read chain (the head's last workgroup polling (value, tag) pairs) was tried and was
-// SLOWER (13.2 us): a poll is a full memory round trip, and the chain it replaces is three of them only on the LAST workgroup.
+// Measured (scripts/attention_step_sweep.py, profiles/r2/attention_step_sweep.jsonl; 32 heads, caches rotating through > 256 MB so the
+// keys come from HBM).  Two costs pull against each other: a workgroup streams its keys at ~60 GB/s (2.2 us per 256 keys), and
+// combining the chunks of a head costs ~2 us whatever their number (the acknowledged-store -> counter -> coherent-read chain):
+//   128 keys: one chunk 4.5 us, two 6.0          256: one chunk 6.5, two or four 7.0        512: 8.9 / 8.6 / 7.6 / 8.5 for 1 / 2 / 4 / 8 chunks
+//   1024: 9.0 with 4 chunks, 9.3 with 8, 12.5 with 16      2048: 12.0 / 11.8 / 13.7 with 4 / 8 / 16      4096: 18.6 / 16.7 / 18.3
+//   8192: 30.0 / 28.9 / 33.4 with 8 / 16 / 32
+// Rule: up to 320 keys one chunk per head and no combine; up to 1024 four chunks; beyond, eight chunks of at most 512 keys.
+// A combine without the acknowledged-store -> counter -> coherent-read chain (the head's last workgroup polling (value, tag) pairs)
+// was tried and was SLOWER (13.2 us at 2048 keys): a poll is a full memory round trip, and the chain it replaces is three of them
+// only on the LAST workgroup.  So was the hybrid -- (value, tag) pairs stored without waiting for acknowledgements, the counter only
+// electing who combines, the elected workgroup re-reading the pairs whose tag is not there yet: 7.1-8.0 / 10.5-11.4 / 13.7-14.6 us at
+// 128 / 512 / 2048 keys against 6.0 / 8.6 / 11.8 (profiles/r2/attention_merge_variants.jsonl): a write-through store takes longer to
+// become visible to another XCD than the counter's round trip, so the first read pass misses and every further pass is a round
+// trip of its own.
 static int pick_chunk(int heads, int keys) {
-    const int target_chunks = heads >= g_attn_target_wgs ? 1 : g_attn_target_wgs / heads;  // fewer, longer key runs and fewer partials to merge
-    int chunk = (keys + target_chunks - 1) / target_chunks;
-    chunk = (chunk + 15) & ~15;
-    if (chunk < 64) chunk = 64;
+    int chunk;
+    if (g_attn_target_wgs > 0) {
+        const int target_chunks = heads >= g_attn_target_wgs ? 1 : g_attn_target_wgs / heads;
+        chunk = (keys + target_chunks - 1) / target_chunks;
+        chunk = (chunk + 15) & ~15;
+        if (chunk < 64) chunk = 64;
+    } else if (keys <= 320) {
+        chunk = (keys + 15) & ~15;
+    } else if (keys <= 1024) {
+        chunk = (((keys + 3) >> 2) + 15) & ~15;
+    } else {
+        chunk = (((keys + 7) >> 3) + 15) & ~15;
+        if (chunk > 512) chunk = 512;
+    }
     if (chunk > 1024) chunk = 1024;
     return chunk;
 }
@@ -290,7 +324,8 @@ int launch_attention_decode_fast(const void *qkv, void *kc, void *vc, const void
     half_t ah;
     __builtin_memcpy(&ah, &alpha_bits, 2);
     a.alpha = (float)ah;
-    hipLaunchKernelGGL(attn_decode_fast_kernel, dim3(heads * a.chunks), dim3(256), 0, stream, a);
+    if (a.mask) hipLaunchKernelGGL(attn_decode_fast_kernel<true>, dim3(heads * a.chunks), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(attn_decode_fast_kernel<false>, dim3(heads * a.chunks), dim3(256), 0, stream, a);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         if (hip_err) *hip_err = e;

@@ -121,7 +121,7 @@ int tce_w4a16_set_gemv_config(int rows, int wn, int wk, int depth) {
 }
 
 int tce_w4a16_set_debug_mode(int mode) {
-    if (mode >= 3000 && mode <= 3000 + 8192) {  // fast attention step: workgroups the key range is cut for (default 256)
+    if (mode >= 3000 && mode <= 3000 + 8192) {  // fast attention step: workgroups the key range is cut for (3000: the fitted rule, the default)
         tce::set_attention_fast_target(mode - 3000);
         return TCE_OK;
     }
