@@ -23,10 +23,12 @@ for t in (128, 256, 512, 1024, 2048, 4096, 8192):
         capi.check(L.tce_attention_decode_step_f16(qkv.data_ptr(), a_.k_cache.data_ptr(), a_.v_cache.data_ptr(), cos.data_ptr(), sin.data_ptr(), None, oo.data_ptr(),
                                                    a_.workspace.data_ptr(), 32, 128, t, t - 1, al, sp))
     row = {"context": t, "kv_MB": round(bytes_ / 1e6, 1), "cache_sets": nsets}
-    for wgs in (32, 64, 128, 192, 256, 384, 512, 1024):
-        capi.check(L.tce_w4a16_set_debug_mode(3000 + wgs))
-        us = time_graph(step, max(32, nsets))
-        row[f"wgs{wgs}_us"] = round(us, 2)
+    for nw in (4, 8, 16):
+        capi.check(L.tce_w4a16_set_debug_mode(2900 + nw))
+        for wgs in (32, 64, 128, 256, 512):
+            capi.check(L.tce_w4a16_set_debug_mode(3000 + wgs))
+            row[f"wgs{wgs}_waves{nw}_us"] = round(time_graph(step, max(32, nsets)), 2)
+    capi.check(L.tce_w4a16_set_debug_mode(2900))
     capi.check(L.tce_w4a16_set_debug_mode(3000))  # back to the fitted rule
     row["rule_us"] = round(time_graph(step, max(32, nsets)), 2)
     print(json.dumps(row), flush=True)

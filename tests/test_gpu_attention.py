@@ -160,6 +160,18 @@ def test_attention_decode_step_against_float64_and_the_binary16_chain_kernel(dev
         capi.check(capi.lib().tce_w4a16_set_debug_mode(3000))
 
 
+@pytest.mark.parametrize("waves", [8, 16])
+def test_attention_decode_step_wider_workgroups(dev, oracle, waves):
+    """The 8- and 16-wave forms of the step kernel (kept for the sweep that ruled them out) compute the same thing."""
+    from tinychatengine_amd import capi
+    capi.check(capi.lib().tce_w4a16_set_debug_mode(2900 + waves))
+    try:
+        _attention_step_case(dev, oracle, 32, 700, 2, 600)
+        _attention_step_case(dev, oracle, 4, 300, 2, 100)
+    finally:
+        capi.check(capi.lib().tce_w4a16_set_debug_mode(2900))
+
+
 def _attention_step_case(dev, oracle, heads, max_keys, steps, start):
     from tinychatengine_amd.attention_ops import DecodeAttention, attention_decode
     hd = 128

@@ -72,9 +72,11 @@ constexpr int kHD = 128;
 constexpr float kNegBig = -1.0e30f;
 
 // MASK: the caller gave a mask row (a compile-time form: a branch inside the fetch block makes hipcc drain the load queue at the loop head)
-template <bool MASK>
-__global__ __launch_bounds__(256) void attn_decode_fast_kernel(const FastAttnArgs a) {
-    __shared__ __attribute__((aligned(16))) float st[16][2 + kHD];  // the 16 (wave, slot) states: m, l, o[hd]
+// NW: waves per workgroup (4; 8 and 16 exist for the sweep that ruled them out, see pick_chunk).
+template <bool MASK, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_decode_fast_kernel(const FastAttnArgs a) {
+    constexpr int NT = 64 * NW, NS = 4 * NW;
+    __shared__ __attribute__((aligned(16))) float st[NS][2 + kHD];  // the (wave, slot) states: m, l, o[hd]
     __shared__ __attribute__((aligned(16))) half_t newrow[2][kHD];  // the token's own (rotated) key and value
     __shared__ unsigned last_flag;
     const int head = blockIdx.x / a.chunks, c = blockIdx.x - head * a.chunks;
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(256) void attn_decode_fast_kernel(const FastAttnArg
     // ---- this wave's keys: chunk / 4 consecutive ones, 4 per step.  Their addresses depend on nothing but the arguments, so the
     //      first block of cache rows is requested BEFORE q / cos / sin: one memory round trip per launch instead of two (the
     //      same rule as the GEMV's "weights right behind x") ----
-    const int per_wave = a.chunk >> 2;
+    const int per_wave = a.chunk / NW;  // (the host made the chunk a multiple of 4 * NW)
     const int kw0 = key0 + wave * per_wave;
     const int kw1 = kw0 + per_wave < key1 ? kw0 + per_wave : key1;  // a block is 16 keys, a wave's run any multiple of 4: the rest weighs nothing
     const half_t *kbase = a.kc + (size_t)head * a.max_keys * kHD, *vbase = a.vc + (size_t)head * a.max_keys * kHD;
@@ -185,9 +187,9 @@ __global__ __launch_bounds__(256) void attn_decode_fast_kernel(const FastAttnArg
     float M = kNegBig, L = 0.f, O = 0.f;  // thread d < 128 owns output dimension d
     if (tid < kHD) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) M = __builtin_fmaxf(M, st[i][0]);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < NS; ++i) M = __builtin_fmaxf(M, st[i][0]);
+#pragma unroll 16
+        for (int i = 0; i < NS; ++i) {
             const float w = __expf(st[i][0] - M);
             L += st[i][1] * w;
             O += st[i][2 + tid] * w;
@@ -220,9 +222,9 @@ __global__ __launch_bounds__(256) void attn_decode_fast_kernel(const FastAttnArg
     // chain of round trips: 1 us per chunk, measured).  Thread i < chunks fetches (M_i, L_i), every thread d < hd its O_i[d].
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.part + (size_t)head * a.chunks * (2 + kHD), 0, (int)((size_t)a.chunks * (2 + kHD) * 4), 0x00020000);
     float *ml = &st[0][0];  // [chunks][2], reuses the state area
-    if (tid < a.chunks) {
-        ml[2 * tid] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, tid * (2 + kHD) * 4, 0, /*sc0|sc1*/ 17));
-        ml[2 * tid + 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, tid * (2 + kHD) * 4 + 4, 0, 17));
+    for (int i = tid; i < a.chunks; i += NT) {
+        ml[2 * i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, i * (2 + kHD) * 4, 0, /*sc0|sc1*/ 17));
+        ml[2 * i + 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, i * (2 + kHD) * 4 + 4, 0, 17));
     }
     constexpr int kMaxChunksUnrolled = 16;
     float oi[kMaxChunksUnrolled];
@@ -273,23 +275,33 @@ void set_attention_fast_target(int wgs) { g_attn_target_wgs = wgs >= 32 && wgs <
 // 128 / 512 / 2048 keys against 6.0 / 8.6 / 11.8 (profiles/r2/attention_merge_variants.jsonl): a write-through store takes longer to
 // become visible to another XCD than the counter's round trip, so the first read pass misses and every further pass is a round
 // trip of its own.
-static int pick_chunk(int heads, int keys) {
+static int g_attn_waves = 0;  // 0: by the chunk's length; tuning: tce_w4a16_set_debug_mode(2900 + 4 / 8 / 16)
+void set_attention_fast_waves(int nw) { g_attn_waves = (nw == 4 || nw == 8 || nw == 16) ? nw : 0; }
+
+static void pick_chunk(int heads, int keys, int *chunk_out, int *waves_out) {
     int chunk;
     if (g_attn_target_wgs > 0) {
         const int target_chunks = heads >= g_attn_target_wgs ? 1 : g_attn_target_wgs / heads;
         chunk = (keys + target_chunks - 1) / target_chunks;
-        chunk = (chunk + 15) & ~15;
         if (chunk < 64) chunk = 64;
     } else if (keys <= 320) {
-        chunk = (keys + 15) & ~15;
+        chunk = keys;
     } else if (keys <= 1024) {
-        chunk = (((keys + 3) >> 2) + 15) & ~15;
+        chunk = (keys + 3) >> 2;
     } else {
-        chunk = (((keys + 7) >> 3) + 15) & ~15;
+        chunk = (keys + 7) >> 3;
         if (chunk > 512) chunk = 512;
     }
     if (chunk > 1024) chunk = 1024;
-    return chunk;
+    // Waves per workgroup: 4.  More waves on the same chunk (a shorter chain of 16-key blocks per wave, no extra partials) measured
+    // SLOWER at every context -- 128 keys 4.5 / 5.2 / 7.4 us with 4 / 8 / 16 waves, 2048 keys 11.7 / 12.1 / 14.4
+    // (profiles/r2/attention_step_waves_sweep.jsonl): the launch is at the floor of a dependent load -> compute -> store launch
+    // (4.5 us; the 8 MiB GEMV's is 4.1) plus ~2 us for the combine plus the keys at 6.4 TB/s, and wider workgroups only add to the
+    // fixed part (prologue loads per wave, barriers, the workgroup's own merge over 4 x waves states).
+    int nw = g_attn_waves ? g_attn_waves : 4;
+    chunk = (chunk + 4 * nw - 1) / (4 * nw) * (4 * nw);
+    *chunk_out = chunk;
+    *waves_out = nw;
 }
 
 size_t attention_decode_workspace_bytes(int heads, int max_keys, int hd) {
@@ -319,13 +331,22 @@ int launch_attention_decode_fast(const void *qkv, void *kc, void *vc, const void
     a.max_keys = max_keys;
     a.pos = pos;
     a.keys = pos + 1;
-    a.chunk = pick_chunk(heads, a.keys);
+    int nw = 4;
+    pick_chunk(heads, a.keys, &a.chunk, &nw);
     a.chunks = (a.keys + a.chunk - 1) / a.chunk;
+    if (a.chunks > 1024) return TCE_ERR_UNSUPPORTED_SHAPE;  // (the combine's LDS image; unreachable with the fitted rule below 500k keys)
     half_t ah;
     __builtin_memcpy(&ah, &alpha_bits, 2);
     a.alpha = (float)ah;
-    if (a.mask) hipLaunchKernelGGL(attn_decode_fast_kernel<true>, dim3(heads * a.chunks), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(attn_decode_fast_kernel<false>, dim3(heads * a.chunks), dim3(256), 0, stream, a);
+    const dim3 grid(heads * a.chunks);
+    auto go = [&](auto has_mask) {
+        constexpr bool MK = decltype(has_mask)::value;
+        if (nw == 16) hipLaunchKernelGGL((attn_decode_fast_kernel<MK, 16>), grid, dim3(1024), 0, stream, a);
+        else if (nw == 8) hipLaunchKernelGGL((attn_decode_fast_kernel<MK, 8>), grid, dim3(512), 0, stream, a);
+        else hipLaunchKernelGGL((attn_decode_fast_kernel<MK, 4>), grid, dim3(256), 0, stream, a);
+    };
+    if (a.mask) go(std::true_type{});
+    else go(std::false_type{});
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         if (hip_err) *hip_err = e;

@@ -121,6 +121,10 @@ int tce_w4a16_set_gemv_config(int rows, int wn, int wk, int depth) {
 }
 
 int tce_w4a16_set_debug_mode(int mode) {
+    if (mode >= 2900 && mode <= 2916) {  // fast attention step: waves per workgroup (2900: by the chunk length, the default; 2904 / 2908 / 2916)
+        tce::set_attention_fast_waves(mode - 2900);
+        return TCE_OK;
+    }
     if (mode >= 3000 && mode <= 3000 + 8192) {  // fast attention step: workgroups the key range is cut for (3000: the fitted rule, the default)
         tce::set_attention_fast_target(mode - 3000);
         return TCE_OK;
