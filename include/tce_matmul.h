@@ -360,6 +360,9 @@ TCE_API int tce_w4a16_set_gemv_config(int rows_per_wave, int waves_n, int waves_
  *            16 activation DMAs, 32 barriers; only the combinations scripts/gemm_pk_ablation.py uses are compiled); outputs meaningless
  *   70..74   W8A8 wave quartets per tile: 70 automatic, 71 / 72 / 74 forced
  *   1000+m   largest M the small-batch kernel takes (default 1128 = 128; 1016 restricts it to M <= 16)
+ *   640..644 pre-packed GEMM with the k range cut across workgroups: runs per cut tile forced (640: the cost model's choice)
+ *   2900+w   fast attention step: waves per workgroup, w in {4, 8, 16} (2900: the default, 4)
+ *   3000+g   fast attention step: workgroups the key range is cut for (3000: the fitted per-context rule, the default)
  * Every setting computes correct results except GEMV modes 1, 3, 4. */
 TCE_API int tce_w4a16_set_debug_mode(int mode);
 /* mode 2: every wave writes {start, x staged, math done, end} (100 MHz wall clock, 4 x u64 per wave) to this device buffer */
