@@ -77,7 +77,9 @@ __global__ __launch_bounds__(1024) void allgather_peer_kernel(const GatherArgs a
     if (tid < a.world) {
         const unsigned *flag = reinterpret_cast<const unsigned *>(a.peer[a.rank] + a.flags_off) + (((size_t)a.slot * 2 + par) * kMaxRanks + tid) * kFlagStride;
         const unsigned long long t0 = wall_clock64();  // 100 MHz
-        while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
+        // a communicator that is already flagged does not wait again: one lost exchange costs ~0.4 s, not 0.4 s per exchange after it
+        const bool dead = __hip_atomic_load(a.epochs + a.slots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        while (!dead && (int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
             __builtin_amdgcn_s_sleep(8);
             if (wall_clock64() - t0 > 40000000ull) {  // ~0.4 s (100 MHz clock; a first launch may trail its peers by a code-object load): give up, flag the communicator (tce_comm_status)
                 __hip_atomic_store(a.epochs + a.slots, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
