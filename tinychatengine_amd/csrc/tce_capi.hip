@@ -144,7 +144,7 @@ int tce_w4a16_set_debug_mode(int mode) {
         tce::set_gemm_pk_split(mode - 640);
         return TCE_OK;
     }
-    if (mode >= 600 && mode < 664) {  // pre-packed GEMM with parts of its loop switched off (timing experiments, one quartet)
+    if (mode >= 600 && mode <= 664) {  // pre-packed GEMM with parts of its loop switched off (timing experiments, one quartet)
         g_pk_mode = mode == 600 ? 0 : 1;
         tce::set_gemm_pk_mode(mode == 600 ? 0 : 1, 0);
         tce::set_gemm_pk_ablation(mode - 600);

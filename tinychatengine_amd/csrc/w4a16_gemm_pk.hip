@@ -105,6 +105,7 @@ __global__ __launch_bounds__(64) void prepack_consts_kernel(const PrepackArgs a)
 // ------------------------------------------------------------------------------------------------------------------------
 // the GEMM
 // ------------------------------------------------------------------------------------------------------------------------
+typedef float float2_t __attribute__((ext_vector_type(2)));
 struct PkGemmArgs {
     const half_t *A;
     const uint4_t *words;   // [NT16][NKB][64]
@@ -157,6 +158,7 @@ template <int KS, int LG, int ABL = 0, int NS = 1>
 __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(232))) void w4a16_gemm_pk_kernel(const PkGemmArgs g) {
     static_assert(KS == 1 || NS == 1, "two quartets either split K or sit side by side");
     constexpr int NTHREADS = 256 * KS * NS;
+    constexpr int AB = ABL & 63;         // loop parts switched off; bit 6 (64): the rescale as four scalar multiplies per tile (this round's first form, for the A/B)
     constexpr int NWR = 4 * NS;          // waves feeding (and reading) one ring
     constexpr int DPW = 16 / NWR;        // DMA instructions per wave and half-stage
     constexpr int BN = 128 * NS;
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(23
     const char *const a_bytes = reinterpret_cast<const char *>(g.A);
     // own half-block h (0 .. 2T-1): k-block grp + (h >> 1) * KS, half h & 1; clamped, never predicated (the counted waits rely on it)
     auto issue_half = [&](int h) {
-        if constexpr (ABL & 16) return;
+        if constexpr (AB & 16) return;
         int kb = grp + (h >> 1) * KS;
         kb = kb_lo + (kb < nloc ? kb : nloc - 1);
         const char *src = a_bytes + ((size_t)kb * 256 + (h & 1) * 128);  // wave-uniform
@@ -307,10 +309,21 @@ __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(23
             // e != 0 by construction of the table; 1-ulp reciprocal (an IEEE division is ~10 instructions per group and column tile)
             const float r = e_prev[j] == 0.f ? 1.0f : e_prev[j] * __builtin_amdgcn_rcpf(e_new[j]);
             e_prev[j] = e_new[j];
+            // as two-element vector products: v_pk_mul_f32, two per accumulator tile (left to itself hipcc emits four v_mul_f32 here --
+            // 64 instead of 32 VALU instructions per group beside the MFMAs -- while it packs the same loop after the k-loop)
+            if constexpr (ABL & 64) {
 #pragma unroll
-            for (int i = 0; i < kMT; ++i)
+                for (int i = 0; i < kMT; ++i)
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) acc[i][j][rr] *= r;
+                    for (int rr = 0; rr < 4; ++rr) acc[i][j][rr] *= r;
+            } else {
+                const float2_t r2{r, r};
+#pragma unroll
+                for (int i = 0; i < kMT; ++i) {
+                    const float2_t lo = float2_t{acc[i][j][0], acc[i][j][1]} * r2, hi = float2_t{acc[i][j][2], acc[i][j][3]} * r2;
+                    acc[i][j] = float4_t{lo.x, lo.y, hi.x, hi.y};
+                }
+            }
         }
     };
     // Region s of a block = the 16 MFMAs of step s beside the fragment reads and the unpack of the NEXT step (for s = 3: step 0 of
@@ -329,13 +342,13 @@ __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(23
         constexpr int s = decltype(s_c)::value;
         constexpr int sn = (s + 1) & 3;  // the step whose fragments are fetched here
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (s % SPG == 0 && !(ABL & 1)) rescale(e_grp[s / SPG]);
-        if constexpr (!(ABL & 4)) read_a(af[(s + 1) & 1], half_stage_next, sn & 1);
-        if constexpr (!(ABL & 2)) {
+        if constexpr (s % SPG == 0 && !(AB & 1)) rescale(e_grp[s / SPG]);
+        if constexpr (!(AB & 4)) read_a(af[(s + 1) & 1], half_stage_next, sn & 1);
+        if constexpr (!(AB & 2)) {
             if constexpr (sn % SPG == 0) set_group(br_next, sn / SPG);
             unpack(bf[(s + 1) & 1], br_next, sn);
         }
-        if constexpr (!(ABL & 8)) {
+        if constexpr (!(AB & 8)) {
 #pragma unroll
             for (int i = 0; i < kMT; ++i)
 #pragma unroll
@@ -346,9 +359,9 @@ __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(23
 #pragma unroll
             for (int j = 0; j < kNT; ++j) asm volatile("" ::"v"(bf[(s + 1) & 1][j]));
         }
-        if constexpr (ABL == 0) static_for<0, 16>([&](auto u_c) {
+        if constexpr (AB == 0) static_for<0, 16>([&](auto u_c) {
             constexpr int u = decltype(u_c)::value;
-            if constexpr (s % SPG == 0) sched_group<0x002, 2>();   // the tile's two packed multiplies, then its MFMA
+            if constexpr (s % SPG == 0) sched_group<0x002, (ABL & 64) ? 4 : 2>();   // the tile's two packed multiplies, then its MFMA
             sched_group<0x008, 1>();                               // MFMA
             if constexpr (u < 8) sched_group<0x100, 1>();          // DS read
             sched_group<0x002, (u < 4 ? 2 : 1)>();                 // VALU: unpack of the next step (18 + constants)
@@ -401,7 +414,7 @@ __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(23
     constexpr int NWL = kNT * (1 + GPB);  // VMEM instructions of request_block
     request_block(1);
     pk_wait_vmcnt<2 * DPW + NWL>();  // the first block's two half-stages have landed (this wave's part); the barrier makes that the workgroup's
-    if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();
+    if constexpr (!(AB & 32)) __builtin_amdgcn_s_barrier();
     // fragments of step 0 of the first block
     set_group(cur, 0);
     read_a(af[0], ring, 0);
@@ -418,7 +431,7 @@ __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(23
         }
         // all waves have taken their last fragment of the even half-stage: it may be refilled (own half-block 2t+4)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();
+        if constexpr (!(AB & 32)) __builtin_amdgcn_s_barrier();
         issue_half(2 * t + 4);
         if (live) region(std::integral_constant<int, 2>{}, cur, st_odd);  // step 2 | step 3
         // End of the block's LDS reads.  VMEM order since the even half-stage of the NEXT block was requested: [its odd half-stage]
@@ -428,7 +441,7 @@ __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(23
         pk_wait_vmcnt<DPW>();
         collect_block(cur);  // `cur` (block t) is used up: step 3's fragments are unpacked
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();
+        if constexpr (!(AB & 32)) __builtin_amdgcn_s_barrier();
         issue_half(2 * t + 5);
         request_block(t + 2);
         if (live) region(std::integral_constant<int, 3>{}, cur, st_even_next);  // step 3 | step 0 of the next block (`cur` is the next block now)
@@ -750,7 +763,7 @@ int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_
     if (g_pk_abl && lg == 7) {
         switch (g_pk_abl) {
 #define TCE_ABL(X) case X: e = launch_pk<1, 7, X>(g, stream); break;
-            TCE_ABL(1) TCE_ABL(2) TCE_ABL(4) TCE_ABL(8) TCE_ABL(16) TCE_ABL(32) TCE_ABL(6) TCE_ABL(7) TCE_ABL(23) TCE_ABL(55) TCE_ABL(47) TCE_ABL(48)
+            TCE_ABL(1) TCE_ABL(2) TCE_ABL(4) TCE_ABL(8) TCE_ABL(16) TCE_ABL(32) TCE_ABL(6) TCE_ABL(7) TCE_ABL(23) TCE_ABL(55) TCE_ABL(47) TCE_ABL(48) TCE_ABL(64)
 #undef TCE_ABL
             default: return TCE_ERR_BAD_ARG;
         }
