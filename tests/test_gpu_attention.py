@@ -255,6 +255,50 @@ def test_attention_decode_step_chunk_merge_under_repetition(dev, oracle):
             assert np.all(np.abs(got - ref) <= tol), f"batch {batch} step {i}: worst |err|/tol = {(np.abs(got - ref) / tol).max():.3f}"
 
 
+def test_attention_decode_step_random_contexts(dev, oracle):
+    """Forty random (heads, capacity, position, mask) cases, one step each on a cache filled up to the position: every chunk rule, key runs
+    that are no multiple of anything, the token's own row at the end of a chunk, at its start and alone (position 0)."""
+    from tinychatengine_amd.attention_ops import DecodeAttention
+    hd = 128
+    rng = np.random.default_rng(2024)
+    cases = [(32, 321, 320), (32, 322, 321), (32, 1025, 1024), (32, 1026, 1025), (5, 1, 0), (1, 17, 16), (40, 4100, 4099)]
+    while len(cases) < 40:
+        heads = int(rng.choice([1, 3, 8, 32, 40]))
+        max_keys = int(rng.integers(1, 3000))
+        cases.append((heads, max_keys, int(rng.integers(0, max_keys))))
+    for (heads, max_keys, pos) in cases:
+        cos, sin = _rope_tables(max_keys, hd, 7)
+        att = DecodeAttention(heads, hd, max_keys, dev, torch.from_numpy(cos).to(dev), torch.from_numpy(sin).to(dev))
+        Kc = np.zeros((heads, max_keys, hd), np.float16)
+        Vc = np.zeros((heads, max_keys, hd), np.float16)
+        Kc[:, :pos] = (rng.standard_normal((heads, pos, hd)) * 0.8).astype(np.float16)
+        Vc[:, :pos] = (rng.standard_normal((heads, pos, hd)) * 0.8).astype(np.float16)
+        # rows past the position hold garbage the kernel must not look at
+        Kc[:, pos:] = np.float16(300.0)
+        Vc[:, pos:] = np.float16(-300.0)
+        att.k_cache.copy_(torch.from_numpy(Kc))
+        att.v_cache.copy_(torch.from_numpy(Vc))
+        qkv = (rng.standard_normal((3, heads, hd)) * 0.9).astype(np.float16)
+        mask = None
+        if rng.integers(0, 2):
+            mask = np.zeros(pos + 1, np.float16)
+            mask[rng.integers(0, pos + 1, size=max(1, (pos + 1) // 5))] = np.float16(-65504.0)
+            mask[pos] = 0
+        alpha = float(np.float16(1.0 / np.sqrt(hd)))
+        out = att.step(torch.from_numpy(qkv.reshape(-1)).to(dev), pos, mask=None if mask is None else torch.from_numpy(mask).to(dev))
+        torch.cuda.synchronize()
+        q_rot, k_rot = oracle.rope_half(qkv[0][:, None, :], qkv[1][:, None, :], cos, sin, pos)
+        Kc[:, pos] = k_rot[:, 0]
+        Vc[:, pos] = qkv[2]
+        assert np.array_equal(att.k_cache[:, pos].cpu().numpy().view(np.uint16), Kc[:, pos].view(np.uint16)), (heads, max_keys, pos)
+        if pos + 1 < max_keys:  # nothing behind the position was written
+            assert float(att.k_cache[:, pos + 1:].float().min()) == 300.0 and float(att.v_cache[:, pos + 1:].float().max()) == -300.0, (heads, max_keys, pos)
+        ref = _attention_reference_f64(q_rot[:, 0], Kc[:, : pos + 1], Vc[:, : pos + 1], alpha, mask)
+        got = out.cpu().numpy().astype(np.float64)
+        tol = 2e-3 * np.abs(ref).max(axis=1, keepdims=True) + 2.0 ** -11 * np.abs(ref)
+        assert np.all(np.abs(got - ref) <= tol), f"heads {heads} capacity {max_keys} position {pos} mask {mask is not None}: worst |err|/tol = {(np.abs(got - ref) / tol).max():.3f}"
+
+
 def test_attention_decode_step_argument_checks(dev):
     from tinychatengine_amd import capi
     L = capi.lib()
