@@ -638,7 +638,7 @@ int launch_w4a16_prepack(const tce_w4a16_desc &d, void *out, hipStream_t stream,
 // splitting K; 3: 128x256, two quartets side by side on one activation ring -- and a cost estimate in us for the dispatcher.
 // A workgroup's time per k-block c grows with the load on its CU and on the chip (f = resident waves / 2048); fitted to
 // profiles/r2/gemm_pk_sweep.jsonl: form 1 alone on its CU 1.06 us, sharing it 1.25 + 0.73 f; form 2 per PAIR of k-blocks
-// 1.7 + 0.4 f; form 3 (every active CU carries eight waves) 1.55 + 0.4 f; + 3 us of launch, prologue and epilogue.
+// 1.7 + 0.4 f; form 3 (every active CU carries eight waves) 1.5 + 0.4 f; + 3 us of launch, prologue and epilogue.
 // Scratch for the K split across workgroups (form 4): [4 KiB of tile counters][kPkSplitMaxUnits partial tiles of 64 KiB].
 constexpr int kPkSplitMaxUnits = 288;
 size_t gemm_pk_scratch_bytes() { return 4096 + (size_t)kPkSplitMaxUnits * 65536; }
@@ -673,9 +673,11 @@ float gemm_pk_estimate_us(int M, int N, int K, int *form_out, bool has_scratch, 
         return r <= 3.f ? (float)(int)(r + 0.999f) : r + 0.5f;
     };
     auto load = [](long waves) { return waves >= 2048 ? 1.0f : (float)waves / 2048.f; };
-    const float cost1 = (tiles1 <= 256 ? nkb * 1.06f : rounds(tiles1, 512) * nkb * (1.25f + 0.73f * load(tiles1 * 4))) + 3.0f;
+    // form 1 past one tile per CU: a CU walks its ceil(tiles / 256) tiles two at a time (688 tiles: three per CU = 1.5 pair-walks, measured
+    // 93 us where "two rounds of 512" predicted 130 and sent 1024 x 11008 x 4096 to form 2 at 99; profiles/r2/gemm_pk_narrow_tile_sweep.jsonl)
+    const float cost1 = (tiles1 <= 256 ? nkb * 1.06f : 0.5f * rounds(tiles1, 256) * nkb * (1.25f + 0.73f * load(tiles1 * 4))) + 3.0f;
     const float cost2 = rounds(tiles1, 256) * (nkb * 0.5f) * (1.7f + 0.4f * load(tiles1 * 8)) + 3.0f;
-    const float cost3 = rounds(tiles3, 256) * nkb * (1.55f + 0.4f * load(tiles3 * 8)) + 3.0f;
+    const float cost3 = rounds(tiles3, 256) * nkb * (1.5f + 0.4f * load(tiles3 * 8)) + 3.0f;
     float cost4 = 1e30f;
     int split = pk_split_factor(tiles1, (int)nkb, has_scratch, &cost4);
     // form 5: 256 whole tiles, one per CU, and the k-blocks of the other tiles1 - 256 as s short runs beside them (each CU: a whole tile
