@@ -299,7 +299,8 @@ TCE_API void tce_plan_destroy(tce_plan *plan);
  *   tce_comm_create   rank's window for vectors of up to max_vector_elems halves, `slots` independent exchange slots
  *   tce_comm_export / tce_comm_connect   the host all-gathers the 64-byte handles (MPI, torch.distributed, a file ...) and hands every
  *                     rank the table [world][64]; tce_comm_connect_local instead when all ranks live in one process (tests)
- *   tce_comm_status   synchronous: 1 if a wait ever timed out (~0.4 s: a rank never arrived), 0 if not, negative on error
+ *   tce_comm_status   synchronous: 1 if a wait ever timed out (~0.4 s: a rank never arrived), 0 if not, negative on error; a flagged
+ *                     communicator's later exchanges do not wait any more (their outputs are void): one lost exchange costs 0.4 s, not 0.4 s each
  * Prefill (M >= 17) moves megabytes per exchange: use RCCL there (ncclAllGather; this repository's host code does, through
  * torch.distributed) -- the peer-write kernel is a single workgroup. */
 typedef struct tce_comm tce_comm;
