@@ -154,6 +154,10 @@ TCE_API int tce_attention_decode_f16(const void *q, const void *K, const void *V
  * Scores, softmax and the weighted sum run in fp32 over key chunks spread across the chip (the bit-exact binary16-chain form of the
  * same block is tce_attention_decode_f16): results agree with that form within 2e-3 * max|out| per head.  head_dim == 128. */
 TCE_API size_t tce_attention_decode_workspace_bytes(int heads, int max_keys, int head_dim);
+/* How tce_attention_decode_step_f16 would cut a context of `keys` keys (= pos + 1), as text: "chunks=C keys-per-chunk=K waves=W workgroups=G
+ * combine=yes|no" -- one chunk per head and no combine up to 320 keys, four chunks up to 1024, then eight chunks of at most 512 keys.
+ * Launches nothing, makes no HIP call. */
+TCE_API int tce_attention_decode_describe(int heads, int keys, char *buf, int buf_len);
 TCE_API int tce_attention_decode_step_f16(const void *qkv, void *k_cache, void *v_cache, const void *cos_table, const void *sin_table, const void *mask,
                                           void *out, void *workspace, int heads, int head_dim, int max_keys, int pos, unsigned short alpha_half_bits,
                                           void *stream);

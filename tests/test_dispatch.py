@@ -56,3 +56,26 @@ def test_cost_model_prefers_fewer_rounds():
         wgs = -(-M // r) * -(-N // c)
         slots = 256 * (1 if q == 2 or r >= 128 else 2)
         assert -(-wgs // slots) <= 4 or wgs / slots > 3, (s, wgs, slots)
+
+
+def test_attention_step_cut_rule():
+    """The fitted rule of the fast attention step: one chunk per head and no combine up to 320 keys, four chunks up to 1024,
+    eight chunks of at most 512 keys beyond; every chunk a multiple of 16 keys (four waves x four keys per step), all keys covered,
+    never more chunks than the workspace was sized for (64-key chunks)."""
+    from tinychatengine_amd import capi
+    for heads in (1, 8, 32, 40):
+        for keys in list(range(1, 700)) + [1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096, 4097, 8192, 16384, 100000]:
+            d = capi.describe_attention_step(heads, keys)
+            chunk, chunks = d["keys-per-chunk"], d["chunks"]
+            assert chunk % 16 == 0 and chunk <= 1024 and d["waves"] == 4, (heads, keys, d)
+            assert chunks * chunk >= keys > (chunks - 1) * chunk, (heads, keys, d)
+            assert chunks <= (keys + 63) // 64 or chunks == 1, (heads, keys, d)
+            assert d["workgroups"] == heads * chunks and d["combine"] == ("yes" if chunks > 1 else "no")
+            if keys <= 320:
+                assert chunks == 1
+            elif keys <= 1024:
+                assert chunks in (3, 4), (keys, d)  # (ceil(keys / 4) rounded up to 16 keys can leave the fourth chunk empty: 321..336 keys)
+            elif keys <= 4096:
+                assert chunks in (7, 8), (keys, d)
+            else:
+                assert chunk == 512

@@ -304,6 +304,12 @@ static void pick_chunk(int heads, int keys, int *chunk_out, int *waves_out) {
     *waves_out = nw;
 }
 
+// the cut launch_attention_decode_fast would use for `keys` keys (no HIP call)
+void describe_attention_decode_fast(int heads, int keys, int *chunk, int *chunks, int *waves) {
+    pick_chunk(heads, keys, chunk, waves);
+    *chunks = (keys + *chunk - 1) / *chunk;
+}
+
 size_t attention_decode_workspace_bytes(int heads, int max_keys, int hd) {
     if (heads <= 0 || max_keys <= 0 || hd != kHD) return 0;
     const int chunk = 64;  // the smallest chunk bounds the number of partials

@@ -648,6 +648,14 @@ void tce_comm_destroy(tce_comm *comm) { tce::comm_destroy(reinterpret_cast<tce::
 
 size_t tce_attention_decode_workspace_bytes(int heads, int max_keys, int hd) { return tce::attention_decode_workspace_bytes(heads, max_keys, hd); }
 
+int tce_attention_decode_describe(int heads, int keys, char *buf, int buf_len) {
+    if (!buf || buf_len <= 0 || heads <= 0 || keys <= 0) return fail(TCE_ERR_BAD_ARG, "tce_attention_decode_describe: bad argument");
+    int chunk = 0, chunks = 0, waves = 0;
+    tce::describe_attention_decode_fast(heads, keys, &chunk, &chunks, &waves);
+    std::snprintf(buf, (size_t)buf_len, "chunks=%d keys-per-chunk=%d waves=%d workgroups=%d combine=%s", chunks, chunk, waves, heads * chunks, chunks > 1 ? "yes" : "no");
+    return TCE_OK;
+}
+
 int tce_attention_decode_step_f16(const void *qkv, void *kc, void *vc, const void *cosv, const void *sinv, const void *mask, void *out, void *workspace, int heads,
                                   int hd, int max_keys, int pos, unsigned short alpha_bits, void *stream) {
     if (!qkv || !kc || !vc || !out || !workspace) return fail(TCE_ERR_BAD_ARG, "tce_attention_decode_step_f16: null pointer");
