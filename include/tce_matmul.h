@@ -357,6 +357,8 @@ TCE_API int tce_w4a16_set_gemv_config(int rows_per_wave, int waves_n, int waves_
  *   0..4     GEMV kernels, M = 1: 0 normal; 1 stream the weights only (no unpack, no dot products: the memory-side ceiling
  *            of the access pattern, outputs meaningless); 2 normal math plus per-wave timestamps into the debug buffer;
  *            3 / 4 further timing variants of the persistent kernel (w4a16_gemv_stream.hip)
+ *   10..12   row-block GEMV, M = 1, issue order: 10 the rule (activations first when the grid is one generation of workgroups, weights
+ *            first otherwise), 11 activations first always, 12 weights first always (scripts/gemv_order_ab.py)
  *   20..30   small-batch kernel: 20 automatic, 21 / 22 / 24 / 28 waves per tile, 30 shared-activation form, 29 off
  *   40..48   GEMM XCD grid rows: 40 automatic, 41 / 42 / 44 / 48 forced
  *   50..52   LDS-DMA GEMM wave quartets per tile: 50 automatic, 51 one, 52 two

@@ -171,6 +171,10 @@ int tce_w4a16_set_debug_mode(int mode) {
         tce::set_skinny_config(mode == 29 ? 0 : (mode == 30 ? 9 : mode - 20));
         return TCE_OK;
     }
+    if (mode >= 10 && mode <= 12) {  // row-block GEMV, M = 1: 10 the rule (x first when the grid is one generation), 11 x first always, 12 weights first always
+        tce::set_gemv_order(mode - 10);
+        return TCE_OK;
+    }
     if (mode < 0 || mode > 4) return fail(TCE_ERR_BAD_ARG, "debug mode %d", mode);
     tce::set_gemv_debug_mode(mode);
     tce::set_gemv_stream_debug(mode, g_dbg_buf_capi);

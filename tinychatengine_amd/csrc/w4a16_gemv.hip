@@ -435,6 +435,7 @@ struct Variant {
 };
 
 int g_debug_mode = 0;
+int g_order_force = 0;  // tuning (tce_w4a16_set_debug_mode 10 / 11 / 12): 0 the rule in launch_variant, 1 x first always, 2 weights first always
 unsigned long long *g_debug_buf = nullptr;
 
 template <int MB, int ROWS, int WN, int WK, int DEPTH, int XB, int MODE = 0, bool Z8 = false, bool NORM = false>
@@ -487,7 +488,7 @@ hipError_t launch_variant(const GemvArgs &a, int total_blocks, int m_blocks, hip
         if constexpr (MB == 1) {
             const int waves_per_simd = (ROWS == 4 && DEPTH == 1) ? 5 : (ROWS * DEPTH <= 2 ? 8 : 4);
             const int capacity = 256 * (4 * waves_per_simd / (WN * WK));
-            if (g_debug_mode == 0 && total_blocks <= capacity) {
+            if (g_debug_mode == 0 && (g_order_force == 1 || (g_order_force == 0 && total_blocks <= capacity))) {
                 if (a.zeros_are_8) {
                     if (need <= 2) return launch_one<MB, ROWS, WN, WK, DEPTH, 2, 3, true>(a, total_blocks, m_blocks, stream);
                     if (need <= 4) return launch_one<MB, ROWS, WN, WK, DEPTH, 4, 3, true>(a, total_blocks, m_blocks, stream);
@@ -524,6 +525,7 @@ hipError_t launch_mb(const Variant &v, const GemvArgs &a, int total_blocks, int 
 }  // namespace
 
 void set_gemv_debug_mode(int mode) { g_debug_mode = mode; }
+void set_gemv_order(int force) { g_order_force = force >= 0 && force <= 2 ? force : 0; }
 void set_gemv_debug_buffer(void *p) { g_debug_buf = static_cast<unsigned long long *>(p); }
 
 bool gemv_variant_exists(int rows, int wn, int wk, int depth) {

@@ -46,6 +46,7 @@ struct GemvArgs {
 
 bool gemv_variant_exists(int rows, int wn, int wk, int depth);
 void set_gemv_debug_mode(int mode);
+void set_gemv_order(int force);
 void set_gemv_debug_buffer(void *p);
 
 // persistent form, w4a16_gemv_stream.hip
