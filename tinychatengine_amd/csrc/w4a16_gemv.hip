@@ -106,24 +106,6 @@ __global__ __launch_bounds__(64 * WN * WK, (MB * ROWS * DEPTH >= 8 ? 2 : (MB * R
         }
     }
 
-    // ---- the residual rows a TCE_W4_ADD_TO_C launch adds to: requested here, behind the x loads and in front of the weights, so
-    //      they are back long before the epilogue needs them (read in the epilogue they were one more memory round trip at the very
-    //      end of the launch: o + add 4.6 us against 4.2 for the plain o_proj).  Every launch reads them (one broadcast load per
-    //      row, clamped): a branch here would split the straight-line prologue whose counted waits keep the weights in flight. ----
-    half_t c_old[ROWS][MB];
-#pragma unroll
-    for (int i = 0; i < ROWS; ++i) {
-        int r = row_base + i;
-        r = r < seg.N ? r : seg.N - 1;
-#pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            int mr = m0 + m;
-            mr = mr < args.M ? mr : args.M - 1;
-            const int rc = (seg.epilogue & TCE_W4_SILU_MUL_PAIRS) ? (r >> 1) : r;  // (a pair launch's C has N / 2 columns: stay inside it)
-            c_old[i][m] = seg.C[(size_t)mr * seg.ldc + rc];
-        }
-    }
-
     // ---- weight stream: buffer descriptors + scalar row offsets ----
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4_t *>(seg.qweight), 0, seg.bytes_w, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(seg.scales), 0, seg.bytes_s, 0x00020000);
@@ -438,7 +420,7 @@ __global__ __launch_bounds__(64 * WN * WK, (MB * ROWS * DEPTH >= 8 ? 2 : (MB * R
             } else if (seg.epilogue & TCE_W4_ADD_TO_C) {
 #pragma unroll
                 for (int i = 0; i < ROWS; ++i)
-                    if (row_base + i < seg.N) crow[row_base + i] = c_old[i][m] + (half_t)red[i][m];
+                    if (row_base + i < seg.N) crow[row_base + i] = crow[row_base + i] + (half_t)red[i][m];
             } else {
 #pragma unroll
                 for (int i = 0; i < ROWS; ++i)
