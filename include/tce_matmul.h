@@ -283,6 +283,13 @@ TCE_API int tce_plan_create(const tce_w4a16_desc *descs, const int32_t *group_si
  * than the stream-ordered graph (1.40 vs 0.995 ms): opt-in, and bench.py picks whichever is faster. */
 #define TCE_PLAN_CHAINED 1
 #define TCE_PLAN_TAGGED 2
+/* TCE_PLAN_OVERLAPPED: the same tagged data flow, but every launch stays a kernel of its own; the launches are issued on two (tunable)
+ * alternating graph branches with NO edge between consecutive launches, so launch j+1's workgroups are dispatched, request their first
+ * weight steps and poll their activation words while launch j is still running (csrc/w4a16_gemv_ovl.hip).  A launch's grid is capped at
+ * 1 / branches of what the chip holds of that kernel, so waiting workgroups cannot keep their producers off the chip.  Same acceptance
+ * rules as TCE_PLAN_TAGGED (plus: no fused RMSNorm prologue yet); tce_plan_is_chained returns 3.  Outputs bit-identical to the
+ * stream-ordered plan. */
+#define TCE_PLAN_OVERLAPPED 4
 TCE_API int tce_plan_create_ex(const tce_w4a16_desc *descs, const int32_t *group_sizes, int n_launches, int flags, tce_plan **out);
 TCE_API int tce_plan_is_chained(const tce_plan *plan);
 TCE_API int tce_plan_geometry(const tce_plan *plan, int *rows, int *depth, int *waves, int *workgroups);

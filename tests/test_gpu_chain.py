@@ -131,17 +131,24 @@ def _mlp_chain(dev, oracle, dims, G, seed):
     return launches, bufs, keep, wts
 
 
-@pytest.mark.parametrize("tagged", [False, True])
+@pytest.mark.parametrize("tagged", [False, True, "overlapped", "overlapped-ring-depth-2"])
 def test_chained_plan_keeps_the_data_dependences(dev, oracle, tagged):
-    """Both spellings of the flag (TCE_PLAN_CHAINED is a synonym of TCE_PLAN_TAGGED since round 2)."""
+    """Both spellings of the flag (TCE_PLAN_CHAINED is a synonym of TCE_PLAN_TAGGED since round 2), and TCE_PLAN_OVERLAPPED (round 3:
+    one kernel per launch on alternating graph branches, ordered by the same tagged words)."""
     from tinychatengine_amd import capi
     dims = [4096, 11008, 4096, 1024, 4096, 256, 2048]
     launches, bufs, keep, wts = _mlp_chain(dev, oracle, dims, 128, seed=11)
     capi.set_gemv_config(2, 8, 0, 2)  # the stream-ordered plan on the persistent kernel too: outputs must be bit-identical
     plain = capi.Plan(launches)
     capi.set_gemv_config()
-    chained = capi.Plan(launches, chained=not tagged, tagged=tagged)
-    assert chained.tagged and not plain.chained
+    if isinstance(tagged, str):
+        capi.check(capi.lib().tce_w4a16_set_debug_mode(50002 if tagged.endswith("depth-2") else 50000))
+        chained = capi.Plan(launches, overlapped=True)
+        capi.check(capi.lib().tce_w4a16_set_debug_mode(50000))
+        assert chained.overlapped and not plain.chained
+    else:
+        chained = capi.Plan(launches, chained=not tagged, tagged=tagged)
+        assert chained.tagged and not plain.chained
     s = torch.cuda.current_stream().cuda_stream
     rng = np.random.default_rng(3)
     for it in range(40):
@@ -176,8 +183,9 @@ def test_chained_plan_keeps_the_data_dependences(dev, oracle, tagged):
     chained.close()
 
 
-def test_tagged_plan_decoder_block_dataflow(dev, oracle):
-    """A tagged plan over the launch shapes of two decoder blocks, wired the way the linears feed each other (the attention between
+@pytest.mark.parametrize("kind", ["tagged", "overlapped"])
+def test_tagged_plan_decoder_block_dataflow(dev, oracle, kind):
+    """A tagged (token kernel) / overlapped (one kernel per launch, alternating branches) plan over the launch shapes of two decoder blocks, wired the way the linears feed each other (the attention between
     qkv and o is not part of the path: o reads the q slice): grouped launches (q / k / v as three linears; gate + up), a consumer
     that reads a SLICE of a producer's output, the SiLU-mul pair epilogue, the residual-add epilogue, an input that comes from
     outside the plan, buffers reused from block to block (the latest writer is the producer), and 70 000 back-to-back replays
@@ -201,8 +209,8 @@ def test_tagged_plan_decoder_block_dataflow(dev, oracle):
     capi.set_gemv_config(2, 8, 0, 2)
     plain = capi.Plan(launches)
     capi.set_gemv_config()
-    tagged = capi.Plan(launches, tagged=True)
-    assert tagged.tagged and not plain.chained
+    tagged = capi.Plan(launches, tagged=kind == "tagged", overlapped=kind == "overlapped")
+    assert (tagged.tagged if kind == "tagged" else tagged.overlapped) and not plain.chained
     s = torch.cuda.current_stream().cuda_stream
     bufs = [qkv, o_out, act, x]
     for it in range(25):

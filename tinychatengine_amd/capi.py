@@ -22,6 +22,7 @@ TCE_W4_SILU_MUL_PAIRS = 8
 TCE_W4_ADD_TO_C = 16
 TCE_PLAN_CHAINED = 1
 TCE_PLAN_TAGGED = 2
+TCE_PLAN_OVERLAPPED = 4
 TCE_W4_ZERO_POINT_IS_8 = 4
 TCE_BIAS_NONE, TCE_BIAS_INT8, TCE_BIAS_FP32 = 0, 1, 2
 TCE_OUT_INT8, TCE_OUT_FP32 = 0, 1
@@ -208,18 +209,19 @@ def gemm_variants() -> list[tuple[int, int]]:
 class Plan:
     """tce_plan: a fixed sequence of W4A16 launches captured into one hipGraph (one decode token's linears)."""
 
-    def __init__(self, launches: list[list[W4A16Desc]], chained: bool = False, tagged: bool = False):
+    def __init__(self, launches: list[list[W4A16Desc]], chained: bool = False, tagged: bool = False, overlapped: bool = False):
         """tagged (chained: accepted synonym): TCE_PLAN_TAGGED -- one persistent kernel walks the list, the plan's data flow
         ordered by polling tagged output words (include/tce_matmul.h).  self.tagged tells whether that form was built."""
         flat = [d for g in launches for d in g]
         self._descs = (W4A16Desc * len(flat))(*flat)
         self._groups = (C.c_int32 * len(launches))(*[len(g) for g in launches])
         self._h = C.c_void_p()
-        check(lib().tce_plan_create_ex(self._descs, self._groups, len(launches), (TCE_PLAN_TAGGED if tagged else 0) | (TCE_PLAN_CHAINED if chained else 0), C.byref(self._h)))
+        check(lib().tce_plan_create_ex(self._descs, self._groups, len(launches), (TCE_PLAN_TAGGED if tagged else 0) | (TCE_PLAN_CHAINED if chained else 0) | (TCE_PLAN_OVERLAPPED if overlapped else 0), C.byref(self._h)))
         self.n_launches = len(launches)
-        self.kind = int(lib().tce_plan_is_chained(self._h))  # 0 stream-ordered, 2 token kernel
+        self.kind = int(lib().tce_plan_is_chained(self._h))  # 0 stream-ordered, 2 token kernel, 3 overlapped launches
         self.chained = self.kind != 0
         self.tagged = self.kind == 2
+        self.overlapped = self.kind == 3
 
     def launch(self, stream: int | None) -> None:
         check(lib().tce_plan_launch(self._h, C.c_void_p(stream or 0)))

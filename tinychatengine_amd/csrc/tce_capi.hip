@@ -121,6 +121,10 @@ int tce_w4a16_set_gemv_config(int rows, int wn, int wk, int depth) {
 }
 
 int tce_w4a16_set_debug_mode(int mode) {
+    if (mode >= 50000 && mode <= 50499) {  // overlapped plans: 50000 + 100 * graph branches (0 = 2) + ring slots per wave (0 = as many as fit, 2..4)
+        tce::set_gemv_ovl_config((mode - 50000) % 100, (mode - 50000) / 100);
+        return TCE_OK;
+    }
     if (mode >= 2900 && mode <= 2916) {  // fast attention step: waves per workgroup (2900: by the chunk length, the default; 2904 / 2908 / 2916)
         tce::set_attention_fast_waves(mode - 2900);
         return TCE_OK;
@@ -178,6 +182,7 @@ int tce_w4a16_set_debug_mode(int mode) {
     if (mode < 0 || mode > 4) return fail(TCE_ERR_BAD_ARG, "debug mode %d", mode);
     tce::set_gemv_debug_mode(mode);
     tce::set_gemv_stream_debug(mode, g_dbg_buf_capi);
+    tce::set_gemv_ovl_stamps(mode == 2 ? g_dbg_buf_capi : nullptr);
     g_debug_mode_capi = mode;
     return TCE_OK;
 }
@@ -186,6 +191,7 @@ int tce_w4a16_set_debug_buffer(void *buf) {
     tce::set_gemv_debug_buffer(buf);
     g_dbg_buf_capi = buf;
     tce::set_gemv_stream_debug(g_debug_mode_capi, buf);
+    tce::set_gemv_ovl_stamps(g_debug_mode_capi == 2 ? buf : nullptr);
     return TCE_OK;
 }
 
@@ -719,7 +725,7 @@ static void plan_free(tce_plan *p) {
 
 int tce_plan_create_ex(const tce_w4a16_desc *descs, const int32_t *group_sizes, int n_launches, int flags, tce_plan **out) {
     if (!descs || !group_sizes || n_launches < 1 || !out) return fail(TCE_ERR_BAD_ARG, "bad argument");
-    if (flags & ~(TCE_PLAN_CHAINED | TCE_PLAN_TAGGED)) return fail(TCE_ERR_BAD_ARG, "unknown plan flags 0x%x", flags);
+    if (flags & ~(TCE_PLAN_CHAINED | TCE_PLAN_TAGGED | TCE_PLAN_OVERLAPPED)) return fail(TCE_ERR_BAD_ARG, "unknown plan flags 0x%x", flags);
     tce_plan *p = new (std::nothrow) tce_plan();
     if (!p) return fail(TCE_ERR_BAD_ARG, "out of host memory");
     int total = 0;
@@ -735,7 +741,7 @@ int tce_plan_create_ex(const tce_w4a16_desc *descs, const int32_t *group_sizes, 
 
     // Chained form: only if every launch is a valid GEMV group the persistent kernel takes (same checks as the
     // unchained entry points), and there is something to overlap.
-    bool chained = (flags & (TCE_PLAN_CHAINED | TCE_PLAN_TAGGED)) && n_launches > 1 && g_gemv_kernel != 1;
+    bool chained = (flags & (TCE_PLAN_CHAINED | TCE_PLAN_TAGGED | TCE_PLAN_OVERLAPPED)) && n_launches > 1 && (g_gemv_kernel != 1 || (flags & TCE_PLAN_OVERLAPPED));
     for (int i = 0, off = 0; i < n_launches && chained; off += p->groups[i], ++i)
         for (int j = 0; j < p->groups[i] && chained; ++j) {
             const tce_w4a16_desc &a = p->descs[off], &b = p->descs[off + j];
@@ -746,7 +752,7 @@ int tce_plan_create_ex(const tce_w4a16_desc *descs, const int32_t *group_sizes, 
         }
     hipError_t he = hipSuccess;
     if (chained) {
-        const int rc = tce::token_plan_create(p->descs.data(), p->groups.data(), n_launches, &p->token, &he);
+        const int rc = tce::token_plan_create(p->descs.data(), p->groups.data(), n_launches, &p->token, &he, (flags & TCE_PLAN_OVERLAPPED) ? 1 : 0);
         if (rc == TCE_ERR_HIP) {
             plan_free(p);
             return hip_fail(he, "token plan");
@@ -796,7 +802,7 @@ int tce_plan_create(const tce_w4a16_desc *descs, const int32_t *group_sizes, int
     return tce_plan_create_ex(descs, group_sizes, n_launches, 0, out);
 }
 
-int tce_plan_is_chained(const tce_plan *plan) { return plan && plan->token ? 2 : 0; }
+int tce_plan_is_chained(const tce_plan *plan) { return plan && plan->token ? (tce::token_plan_mode(plan->token) == 1 ? 3 : 2) : 0; }
 
 int tce_plan_geometry(const tce_plan *plan, int *rows, int *depth, int *waves, int *workgroups) {
     if (!plan || !plan->token || !rows || !depth || !waves || !workgroups) return fail(TCE_ERR_BAD_ARG, "not a chained plan");

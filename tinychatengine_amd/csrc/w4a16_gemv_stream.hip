@@ -718,6 +718,12 @@ struct TokenPlan {
     int n = 0, rows = 0, depth = 0, nw = 0, blocks = 0;
     bool z8 = false;
     size_t lds = 0;
+    // mode 1 (overlapped launches, w4a16_gemv_ovl.hip): one kernel per launch, issued on `chains` alternating branches
+    int mode = 0, chains = 0;
+    std::vector<StreamLaunch> host;
+    std::vector<OvlGeom> geom;
+    std::vector<hipStream_t> side;   // chains - 1 side streams
+    std::vector<hipEvent_t> events;  // [0] fork, [1 ..] joins
 };
 
 void token_plan_destroy(TokenPlan *tp) {
@@ -725,8 +731,12 @@ void token_plan_destroy(TokenPlan *tp) {
     if (tp->launches) (void)hipFree(tp->launches);
     if (tp->sync) (void)hipFree(tp->sync);
     if (tp->shadow) (void)hipFree(tp->shadow);
+    for (hipStream_t s : tp->side) (void)hipStreamDestroy(s);
+    for (hipEvent_t e : tp->events) (void)hipEventDestroy(e);
     delete tp;
 }
+
+int token_plan_mode(const TokenPlan *tp) { return tp ? tp->mode : 0; }
 
 
 namespace {
@@ -759,7 +769,7 @@ hipError_t token_launch(const TokenPlan &tp, hipStream_t stream) {
 }  // namespace
 
 // Builds the device-side launch list.  Returns TCE_ERR_UNSUPPORTED_SHAPE if a launch is not an M = 1 GEMV this kernel takes.
-int token_plan_create(const tce_w4a16_desc *descs, const int32_t *groups, int n_launches, TokenPlan **out, hipError_t *hip_err) {
+int token_plan_create(const tce_w4a16_desc *descs, const int32_t *groups, int n_launches, TokenPlan **out, hipError_t *hip_err, int mode) {
     const int cus = num_cus();
     if (cus == 0) return TCE_ERR_HIP;
     int maxK = 0;
@@ -771,6 +781,18 @@ int token_plan_create(const tce_w4a16_desc *descs, const int32_t *groups, int n_
     if (!tpp) return TCE_ERR_BAD_ARG;
     TokenPlan &tp = *tpp;
     tp.n = n_launches;
+    tp.mode = mode;
+    if (mode == 1) {  // per-launch geometry: waves per workgroup from K, the grid from the occupancy (ovl_geometry)
+        tp.chains = ovl_chains();
+        tp.geom.resize(n_launches);
+        for (int l = 0, off = 0; l < n_launches; off += groups[l], ++l) {
+            const int rc = ovl_geometry(descs + off, groups[l], cus, tp.chains, &tp.geom[l], hip_err);
+            if (rc != TCE_OK) {
+                token_plan_destroy(tpp);
+                return rc;
+            }
+        }
+    }
     tp.nw = g_stream_nw ? g_stream_nw : 16;
     int bpc = g_stream_bpc ? g_stream_bpc : 1;
     if (bpc * tp.nw > 16) bpc = 16 / tp.nw > 0 ? 16 / tp.nw : 1;
@@ -786,21 +808,38 @@ int token_plan_create(const tce_w4a16_desc *descs, const int32_t *groups, int n_
     if (tp.rows == 1) tp.depth = 3;
     tp.lds = lds_bytes(maxK);
     tp.z8 = true;
-    std::vector<StreamLaunch> host(n_launches);
-    for (int l = 0, off = 0; l < n_launches; off += groups[l], ++l)
-        if (!fill_launch(descs + off, groups[l], tp.rows, &host[l], &tp.z8)) {
+    std::vector<StreamLaunch> &host = tp.host;
+    host.resize(n_launches);
+    for (int l = 0, off = 0; l < n_launches; off += groups[l], ++l) {
+        bool z8 = true;
+        if (!fill_launch(descs + off, groups[l], mode == 1 ? tp.geom[l].rows_per_block : tp.rows, &host[l], mode == 1 ? &z8 : &tp.z8)) {
             token_plan_destroy(tpp);
             return TCE_ERR_UNSUPPORTED_SHAPE;
         }
-    // every workgroup must be resident at once: a launch spins until its producers have delivered
-    int per_cu = 0;
-    hipError_t e = TCE_TOKEN_DISPATCH(token_setup, tp, &per_cu);
-    if (e == hipSuccess && per_cu < 1) {
-        token_plan_destroy(tpp);
-        return TCE_ERR_UNSUPPORTED_SHAPE;
     }
-    if (per_cu < bpc) bpc = per_cu;
-    tp.blocks = cus * bpc;
+    hipError_t e = hipSuccess;
+    if (mode == 0) {
+        // every workgroup must be resident at once: a launch spins until its producers have delivered
+        int per_cu = 0;
+        e = TCE_TOKEN_DISPATCH(token_setup, tp, &per_cu);
+        if (e == hipSuccess && per_cu < 1) {
+            token_plan_destroy(tpp);
+            return TCE_ERR_UNSUPPORTED_SHAPE;
+        }
+        if (per_cu < bpc) bpc = per_cu;
+        tp.blocks = cus * bpc;
+    } else {
+        tp.blocks = 0;
+        for (const OvlGeom &g : tp.geom)
+            if (g.grid > tp.blocks) tp.blocks = g.grid;
+        if (tp.blocks > 4096) {  // (the diagnostics buffer is laid out for 4096 workgroups per launch)
+            token_plan_destroy(tpp);
+            return TCE_ERR_UNSUPPORTED_SHAPE;
+        }
+        tp.rows = 2;
+        tp.depth = 2;
+        tp.nw = tp.geom[0].wn;
+    }
     if (e == hipSuccess) {
         // Who produces what: launch l's activation vector is looked up among the outputs of the launches in front of it, latest
         // first (buffers are reused from layer to layer; the latest writer is the one stream order would have made visible).
@@ -876,6 +915,18 @@ int token_plan_create(const tce_w4a16_desc *descs, const int32_t *groups, int n_
     }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&tp.launches), sizeof(StreamLaunch) * n_launches);
     if (e == hipSuccess) e = hipMemcpy(tp.launches, host.data(), sizeof(StreamLaunch) * n_launches, hipMemcpyHostToDevice);
+    if (e == hipSuccess && mode == 1) {
+        for (int i = 1; i < tp.chains && e == hipSuccess; ++i) {
+            hipStream_t s = nullptr;
+            e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+            if (e == hipSuccess) tp.side.push_back(s);
+        }
+        for (int i = 0; i < tp.chains && e == hipSuccess; ++i) {
+            hipEvent_t ev = nullptr;
+            e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e == hipSuccess) tp.events.push_back(ev);
+        }
+    }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&tp.sync), sizeof(unsigned) * 2);
     if (e == hipSuccess) {
         const unsigned init[2] = {0u, 1u};  // status clear; the first token's tag
@@ -893,7 +944,27 @@ int token_plan_create(const tce_w4a16_desc *descs, const int32_t *groups, int n_
 // Enqueues the token: one kernel runs the whole list, a one-thread kernel behind it advances the tag.
 int token_plan_enqueue(TokenPlan *tpp, hipStream_t stream, hipError_t *hip_err) {
     const TokenPlan &tp = *tpp;
-    hipError_t e = TCE_TOKEN_DISPATCH(token_launch, tp, stream);
+    hipError_t e = hipSuccess;
+    if (tp.mode == 1) {
+        // fork: the side branches start where `stream` is now; launch l goes to branch l % chains; join; then the tag advances.
+        // (Inside a stream capture this records a graph of `chains` parallel kernel chains with no edge between consecutive launches.)
+        e = hipEventRecord(tp.events[0], stream);
+        for (size_t i = 0; i < tp.side.size() && e == hipSuccess; ++i) e = hipStreamWaitEvent(tp.side[i], tp.events[0], 0);
+        for (int l = 0; l < tp.n && e == hipSuccess; ++l) {
+            const int b = l % tp.chains;
+            e = ovl_enqueue(tp.launches + l, tp.geom[l], tp.sync + 1, tp.sync, l, b == 0 ? stream : tp.side[b - 1]);
+        }
+        for (size_t i = 0; i < tp.side.size() && e == hipSuccess; ++i) {
+            e = hipEventRecord(tp.events[1 + i], tp.side[i]);
+            if (e == hipSuccess) e = hipStreamWaitEvent(stream, tp.events[1 + i], 0);
+        }
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(token_epoch_kernel, dim3(1), dim3(1), 0, stream, tp.sync + 1);
+            e = hipGetLastError();
+        }
+    } else {
+        e = TCE_TOKEN_DISPATCH(token_launch, tp, stream);
+    }
     if (e != hipSuccess) {
         if (hip_err) *hip_err = e;
         return TCE_ERR_HIP;

@@ -72,7 +72,21 @@ int launch_w4a16_gemv_stream(const tce_w4a16_desc *descs, int count, hipStream_t
                              const float *gamma = nullptr, float eps = 0.f);
 // token plans: a list of launches walked by ONE persistent kernel, the data flow between them ordered by tagged output words
 struct TokenPlan;
-int token_plan_create(const tce_w4a16_desc *descs, const int32_t *groups, int n_launches, TokenPlan **out, hipError_t *hip_err);
+// mode 0: the token kernel (one persistent kernel walks the list); mode 1: one kernel per launch on alternating graph branches, ordered
+// by the same tagged words (w4a16_gemv_ovl.hip)
+int token_plan_create(const tce_w4a16_desc *descs, const int32_t *groups, int n_launches, TokenPlan **out, hipError_t *hip_err, int mode = 0);
+int token_plan_mode(const TokenPlan *tp);
+// w4a16_gemv_ovl.hip: the per-launch kernel of overlapped plans
+struct OvlGeom {
+    int wn, xb, depth, rows_per_block, grid, per_cu;
+    bool z8;
+    size_t lds;
+};
+int ovl_chains();
+int ovl_geometry(const tce_w4a16_desc *descs, int count, int cus, int chains, OvlGeom *g, hipError_t *hip_err);
+hipError_t ovl_enqueue(const StreamLaunch *L, const OvlGeom &g, const unsigned *epoch, unsigned *status, int launch_index, hipStream_t stream);
+void set_gemv_ovl_config(int depth, int chains);
+void set_gemv_ovl_stamps(void *buf);
 int token_plan_enqueue(TokenPlan *tp, hipStream_t stream, hipError_t *hip_err);
 int token_plan_status(TokenPlan *tp, unsigned *status, hipError_t *hip_err);
 void token_plan_geometry(const TokenPlan *tp, int *rows, int *depth, int *waves, int *blocks);
