@@ -277,16 +277,18 @@ def whole_token_leg(torch, dev, shape, dl):
     from tinychatengine_amd import capi
     from tinychatengine_amd.decoder_block import DecoderBlock
     heads, hd, ctx_max = shape.hidden // 128, 128, 2048
+    kv_heads = shape.qkv[1] // 128 if len(shape.qkv) == 3 else heads  # separate q / k / v widths: grouped-query attention (Llama-3-8B: 32 / 8, model.h:83)
     ang = np.random.default_rng(0).uniform(0, 2 * np.pi, (ctx_max, hd // 2))
     cos = torch.from_numpy(np.concatenate([np.cos(ang), np.cos(ang)], axis=1).astype(np.float16)).to(dev)
     sin = torch.from_numpy(np.concatenate([np.sin(ang), np.sin(ang)], axis=1).astype(np.float16)).to(dev)
-    blocks = [DecoderBlock(shape.hidden, heads, shape.ffn, ctx_max, dev, cos, sin, seed=100 + i) for i in range(shape.layers)]
+    blocks = [DecoderBlock(shape.hidden, heads, shape.ffn, ctx_max, dev, cos, sin, seed=100 + i, kv_heads=kv_heads) for i in range(shape.layers)]
     for b in blocks:
         b.attention.k_cache.normal_(0, 0.8)
         b.attention.v_cache.normal_(0, 0.8)
     hid = torch.randn(1, shape.hidden, device=dev).to(torch.float16)
     hid0 = hid.clone()
-    out = {"launches_per_token": shape.layers * DecoderBlock.LAUNCHES + 1, "layers": shape.layers}
+    out = {"launches_per_token": shape.layers * DecoderBlock.LAUNCHES + 1, "layers": shape.layers, "query_heads": heads, "kv_heads": kv_heads,
+           "note": "the attention step is captured at a fixed position (tce_attention_decode_step_*_f16 takes `pos` by value): a decode loop re-captures or updates the node per token"}
     for ctx in (512, 2048):
         pos = ctx - 1
         def token():
@@ -309,7 +311,7 @@ def whole_token_leg(torch, dev, shape, dl):
         b_.record()
         torch.cuda.synchronize()
         ms = a.elapsed_time(b_) / 50
-        kv = 2 * heads * ctx * hd * 2 * shape.layers
+        kv = 2 * kv_heads * ctx * hd * 2 * shape.layers
         wb = sum(b.linear_bytes() for b in blocks)
         out[f"context_{ctx}"] = {"tokens_per_s": round(1e3 / ms, 1), "ms_per_token": round(ms, 4), "kv_cache_bytes_read": kv,
                                  "frac_of_8TBs": round((wb + kv) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -716,7 +718,12 @@ def main():
                     "tokens_per_s": round(1e3 / ms3, 1), "ms_per_token": round(ms3, 4), "algorithmic_bytes_per_token": dl3.token_bytes(),
                     "frac_of_8TBs": round(dl3.token_bytes() / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "launch_shapes": launch_shape_table(dl3, torch, 96)}
-                del dl3, plan3
+                del plan3
+                try:  # the whole token for the model the metric names: grouped-query attention (32 query heads over 8 key / value heads)
+                    extras["decode_llama3_8b_true_shapes"]["decode_with_attention"] = whole_token_leg(torch, dev, SHAPES["llama3-8b"], dl3)
+                except Exception as e:  # noqa: BLE001
+                    extras["decode_llama3_8b_true_shapes"]["decode_with_attention"] = {"error": f"{type(e).__name__}: {e}"}
+                del dl3
             except Exception as e:  # noqa: BLE001
                 extras["decode_llama3_8b_true_shapes"] = {"error": f"{type(e).__name__}: {e}"}
 

@@ -47,7 +47,7 @@ extern "C" {
 
 #define TCE_API __attribute__((visibility("default")))
 
-#define TCE_VERSION 102 /* 0.1.2: tce_w4a16_desc.scratch (0.1.1: .prepacked, tce_w4a16_prepack*) */
+#define TCE_VERSION 103 /* 0.1.3: tce_attention_decode_step_gqa_f16, TCE_PLAN_OVERLAPPED (0.1.2: tce_w4a16_desc.scratch; 0.1.1: .prepacked, tce_w4a16_prepack*) */
 
 /* error codes (return values) */
 #define TCE_OK 0
@@ -161,6 +161,18 @@ TCE_API int tce_attention_decode_describe(int heads, int keys, char *buf, int bu
 TCE_API int tce_attention_decode_step_f16(const void *qkv, void *k_cache, void *v_cache, const void *cos_table, const void *sin_table, const void *mask,
                                           void *out, void *workspace, int heads, int head_dim, int max_keys, int pos, unsigned short alpha_half_bits,
                                           void *stream);
+/* The same step for grouped-query attention (Llama-3-8B: 32 query heads over 8 key / value heads, llm/include/model.h:83): query head i reads
+ * key / value head i / (heads / kv_heads), the reference's `repeat` (llm/src/nn_modules/non_cuda/Int4llamaAttention.cc:166-185) without the copy.
+ *   qkv  fp16 [heads + 2 * kv_heads][head_dim]: the query heads, then the key heads, then the value heads (the fused projection's row)
+ *   k_cache, v_cache  fp16 [kv_heads][max_keys][head_dim];  out fp16 [heads][head_dim]
+ *   workspace  tce_attention_decode_workspace_bytes(heads, max_keys, head_dim) bytes, zeroed once
+ * A workgroup owns (key / value head, chunk of keys) and streams its cache rows ONCE for all of its query heads.  heads / kv_heads in {1, 2, 4}
+ * (kv_heads == heads is tce_attention_decode_step_f16).  Rows of the caches at and beyond `pos` may hold anything on entry (uninitialised
+ * memory included): they are never weighted into the result. */
+TCE_API int tce_attention_decode_step_gqa_f16(const void *qkv, void *k_cache, void *v_cache, const void *cos_table, const void *sin_table, const void *mask,
+                                              void *out, void *workspace, int heads, int kv_heads, int head_dim, int max_keys, int pos,
+                                              unsigned short alpha_half_bits, void *stream);
+TCE_API int tce_attention_decode_describe_gqa(int heads, int kv_heads, int keys, char *buf, int buf_len);
 /* Reads [ptr, ptr + bytes) with at most `workgroups` workgroups (0 = as many as the range needs) and discards the data: the
  * range then sits in the memory-side cache (256 MiB) for the launch that needs it.  Meant for a side stream / graph branch
  * next to the launch BEFORE that one (no reference counterpart: cudaMallocManaged prefetching is the closest idea). */

@@ -299,6 +299,86 @@ def test_attention_decode_step_random_contexts(dev, oracle):
         assert np.all(np.abs(got - ref) <= tol), f"heads {heads} capacity {max_keys} position {pos} mask {mask is not None}: worst |err|/tol = {(np.abs(got - ref) / tol).max():.3f}"
 
 
+@pytest.mark.parametrize("heads,kv_heads,max_keys,start,steps", [(32, 8, 2048, 2040, 3), (32, 8, 700, 600, 2), (8, 2, 300, 0, 6), (16, 8, 1100, 1000, 2),
+                                                                 (32, 8, 257, 255, 2), (4, 1, 4200, 4190, 2)])
+def test_attention_decode_step_grouped_queries(dev, oracle, heads, kv_heads, max_keys, start, steps):
+    """Grouped-query attention (Llama-3-8B: 32 query heads over 8 key / value heads, model.h:83): query head i reads key / value head
+    i // (heads // kv_heads) -- the reference's `repeat` (non_cuda/Int4llamaAttention.cc:166-185).  Checked against float64 on the repeated
+    caches, against the multi-head kernel run on physically repeated caches (same arithmetic per query head: bit-identical where both
+    use one chunk, tolerance-level where their chunkings differ), and the appended rows against the reference's RoPE."""
+    from tinychatengine_amd.attention_ops import DecodeAttention
+    hd, rep = 128, heads // kv_heads
+    rng = np.random.default_rng(heads * 7 + max_keys)
+    cos, sin = _rope_tables(max_keys, hd, 5)
+    tc, ts = torch.from_numpy(cos).to(dev), torch.from_numpy(sin).to(dev)
+    gqa = DecodeAttention(heads, hd, max_keys, dev, tc, ts, kv_heads=kv_heads)
+    mha = DecodeAttention(heads, hd, max_keys, dev, tc, ts)
+    Kc = np.zeros((kv_heads, max_keys, hd), np.float16)
+    Vc = np.zeros((kv_heads, max_keys, hd), np.float16)
+    Kc[:, :start] = (rng.standard_normal((kv_heads, start, hd)) * 0.8).astype(np.float16)
+    Vc[:, :start] = (rng.standard_normal((kv_heads, start, hd)) * 0.8).astype(np.float16)
+    # behind the position: bit patterns of inf / nan (an uninitialised cache), which must never reach the result
+    Kc[:, start:] = np.array([0x7C00, 0x7E00, 0xFC00, 0x7FFF], np.uint16).view(np.float16)[rng.integers(0, 4, (kv_heads, max_keys - start, hd))]
+    Vc[:, start:] = np.array([0x7C00, 0x7E00, 0xFC00, 0x7FFF], np.uint16).view(np.float16)[rng.integers(0, 4, (kv_heads, max_keys - start, hd))]
+    gqa.k_cache.copy_(torch.from_numpy(Kc)); gqa.v_cache.copy_(torch.from_numpy(Vc))
+    mha.k_cache.copy_(torch.from_numpy(np.repeat(Kc, rep, axis=0))); mha.v_cache.copy_(torch.from_numpy(np.repeat(Vc, rep, axis=0)))
+    alpha = float(np.float16(1.0 / np.sqrt(hd)))
+    for t in range(steps):
+        pos = start + t
+        q = (rng.standard_normal((heads, hd)) * 0.9).astype(np.float16)
+        kv = (rng.standard_normal((2, kv_heads, hd)) * 0.9).astype(np.float16)
+        mask = None
+        if t % 2 == 1:
+            mask = np.zeros(pos + 1, np.float16)
+            mask[rng.integers(0, pos + 1, size=max(1, (pos + 1) // 7))] = np.float16(-65504.0)
+            mask[pos] = 0
+        tm = None if mask is None else torch.from_numpy(mask).to(dev)
+        row = np.concatenate([q.reshape(-1), kv[0].reshape(-1), kv[1].reshape(-1)])
+        out = gqa.step(torch.from_numpy(row).to(dev), pos, mask=tm)
+        row_mha = np.concatenate([q.reshape(-1), np.repeat(kv[0], rep, axis=0).reshape(-1), np.repeat(kv[1], rep, axis=0).reshape(-1)])
+        out_mha = mha.step(torch.from_numpy(row_mha).to(dev), pos, mask=tm)
+        torch.cuda.synchronize()
+        q_rot, _ = oracle.rope_half(q[:, None, :], q[:, None, :], cos, sin, pos)
+        _, k_rot = oracle.rope_half(kv[0][:, None, :], kv[0][:, None, :], cos, sin, pos)
+        Kc[:, pos] = k_rot[:, 0]
+        Vc[:, pos] = kv[1]
+        assert np.array_equal(gqa.k_cache[:, pos].cpu().numpy().view(np.uint16), Kc[:, pos].view(np.uint16)), "appended key differs from the reference's rotated key"
+        assert np.array_equal(gqa.v_cache[:, pos].cpu().numpy().view(np.uint16), Vc[:, pos].view(np.uint16))
+        if pos + 1 < max_keys:  # nothing behind the position was written
+            assert np.array_equal(gqa.k_cache[:, pos + 1:].cpu().numpy().view(np.uint16), Kc[:, pos + 1:].view(np.uint16))
+        ref = _attention_reference_f64(q_rot[:, 0], np.repeat(Kc[:, : pos + 1], rep, axis=0), np.repeat(Vc[:, : pos + 1], rep, axis=0), alpha, mask)
+        got = out.cpu().numpy().astype(np.float64)
+        assert np.isfinite(got).all(), f"step {t}: inf / nan bits behind the position leaked into the output"
+        tol = 2e-3 * np.abs(ref).max(axis=1, keepdims=True) + 2.0 ** -11 * np.abs(ref)
+        assert np.all(np.abs(got - ref) <= tol), f"step {t}: worst |err|/tol = {(np.abs(got - ref) / tol).max():.3f}"
+        g2 = out_mha.cpu().numpy().astype(np.float64)
+        assert np.all(np.abs(got - g2) <= 2 * tol), f"step {t}: grouped vs multi-head kernel on repeated caches: {(np.abs(got - g2) / tol).max():.3f}"
+
+
+def test_attention_decode_step_ignores_inf_nan_bits_behind_the_position(dev, oracle):
+    """The multi-head entry point on a cache whose rows at and behind `pos` hold inf / nan bit patterns (a zero weight times
+    an infinite value row is NaN; the kernel now zeroes such rows instead of weighting them)."""
+    from tinychatengine_amd.attention_ops import DecodeAttention
+    heads, hd, max_keys = 8, 128, 400
+    rng = np.random.default_rng(3)
+    for pos in (0, 5, 17, 100, 333):
+        att = DecodeAttention(heads, hd, max_keys, dev, None, None)
+        K = (rng.standard_normal((heads, max_keys, hd)) * 0.8).astype(np.float16)
+        V = (rng.standard_normal((heads, max_keys, hd)) * 0.8).astype(np.float16)
+        K[:, pos:] = np.array([0x7C00], np.uint16).view(np.float16)[0]
+        V[:, pos:] = np.array([0xFE00], np.uint16).view(np.float16)[0]
+        att.k_cache.copy_(torch.from_numpy(K)); att.v_cache.copy_(torch.from_numpy(V))
+        qkv = (rng.standard_normal((3, heads, hd)) * 0.9).astype(np.float16)
+        out = att.step(torch.from_numpy(qkv.reshape(-1)).to(dev), pos)
+        torch.cuda.synchronize()
+        K[:, pos] = qkv[1]; V[:, pos] = qkv[2]
+        ref = _attention_reference_f64(qkv[0], K[:, : pos + 1], V[:, : pos + 1], float(np.float16(1.0 / np.sqrt(hd))), None)
+        got = out.cpu().numpy().astype(np.float64)
+        assert np.isfinite(got).all(), f"pos {pos}"
+        tol = 2e-3 * np.abs(ref).max(axis=1, keepdims=True) + 2.0 ** -11 * np.abs(ref)
+        assert np.all(np.abs(got - ref) <= tol), f"pos {pos}"
+
+
 def test_attention_decode_step_argument_checks(dev):
     from tinychatengine_amd import capi
     L = capi.lib()
@@ -308,3 +388,5 @@ def test_attention_decode_step_argument_checks(dev):
     p = z.data_ptr()
     assert L.tce_attention_decode_step_f16(p, p, p, None, None, None, p, ws.data_ptr(), 2, 128, 64, 64, 0x3C00, None) == capi.TCE_ERR_BAD_ARG  # pos == max_keys
     assert L.tce_attention_decode_step_f16(p, p, p, p, None, None, p, ws.data_ptr(), 2, 128, 64, 0, 0x3C00, None) == capi.TCE_ERR_BAD_ARG  # cos without sin
+    assert L.tce_attention_decode_step_gqa_f16(p, p, p, None, None, None, p, ws.data_ptr(), 6, 4, 128, 64, 0, 0x3C00, None) == capi.TCE_ERR_BAD_ARG  # 6 query heads over 4
+    assert L.tce_attention_decode_step_gqa_f16(p, p, p, None, None, None, p, ws.data_ptr(), 16, 2, 128, 64, 0, 0x3C00, None) == capi.TCE_ERR_UNSUPPORTED_SHAPE  # 8 per head

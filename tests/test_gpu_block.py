@@ -21,8 +21,10 @@ def _rope(v, cos, sin):  # v [heads][128]; RotaryPosEmb_cuda_forward: v * cos + 
     return v * cos[None, :] + rot * sin[None, :]
 
 
-@pytest.mark.parametrize("hidden,heads,ffn,layers,tokens", [(256, 2, 512, 2, 6), (512, 4, 1408, 1, 3)])
-def test_decoder_blocks_against_float64(hidden, heads, ffn, layers, tokens):
+@pytest.mark.parametrize("hidden,heads,kv_heads,ffn,layers,tokens", [(256, 2, 2, 512, 2, 6), (512, 4, 4, 1408, 1, 3), (512, 4, 1, 1408, 2, 5), (1024, 8, 4, 512, 1, 3)])
+def test_decoder_blocks_against_float64(hidden, heads, kv_heads, ffn, layers, tokens):
+    """kv_heads < heads: grouped-query attention (Llama-3-8B's form, llm/include/model.h:83): the fused projection's row is q | k | v with
+    kv_heads key and value heads, query head i attends over key / value head i // (heads // kv_heads)."""
     from tinychatengine_amd import capi
     from tinychatengine_amd.decoder_block import DecoderBlock, dequantize
     assert torch.cuda.is_available()
@@ -33,11 +35,12 @@ def test_decoder_blocks_against_float64(hidden, heads, ffn, layers, tokens):
     ang = rng.uniform(0, 2 * np.pi, (max_keys, hd // 2))
     cos = np.concatenate([np.cos(ang), np.cos(ang)], axis=1).astype(np.float16)  # the reference's tables repeat the half (RotaryPosEmb.cc)
     sin = np.concatenate([np.sin(ang), np.sin(ang)], axis=1).astype(np.float16)
-    blocks = [DecoderBlock(hidden, heads, ffn, max_keys, dev, torch.from_numpy(cos).to(dev), torch.from_numpy(sin).to(dev), seed=10 + i) for i in range(layers)]
+    blocks = [DecoderBlock(hidden, heads, ffn, max_keys, dev, torch.from_numpy(cos).to(dev), torch.from_numpy(sin).to(dev), seed=10 + i, kv_heads=kv_heads) for i in range(layers)]
+    rep = heads // kv_heads
     W = [{k: dequantize(getattr(b, k)) for k in ("qkv", "o", "gate", "up", "down")} for b in blocks]
     G = [(b.gamma1.cpu().numpy().astype(np.float64), b.gamma2.cpu().numpy().astype(np.float64)) for b in blocks]
-    Kc = [np.zeros((heads, 0, hd)) for _ in blocks]
-    Vc = [np.zeros((heads, 0, hd)) for _ in blocks]
+    Kc = [np.zeros((kv_heads, 0, hd)) for _ in blocks]
+    Vc = [np.zeros((kv_heads, 0, hd)) for _ in blocks]
     alpha = float(np.float16(1.0 / np.sqrt(hd)))
     for pos in range(tokens):
         x0 = rng.standard_normal(hidden).astype(np.float16)
@@ -49,14 +52,17 @@ def test_decoder_blocks_against_float64(hidden, heads, ffn, layers, tokens):
         c, s = cos[pos].astype(np.float64), sin[pos].astype(np.float64)
         for li in range(layers):
             qkv = W[li]["qkv"] @ _rmsnorm(h, G[li][0], 1e-6)
-            q, k, v = (qkv[i * hidden:(i + 1) * hidden].reshape(heads, hd) for i in range(3))
+            kvw = kv_heads * hd
+            q = qkv[:hidden].reshape(heads, hd)
+            k = qkv[hidden:hidden + kvw].reshape(kv_heads, hd)
+            v = qkv[hidden + kvw:].reshape(kv_heads, hd)
             q, k = _rope(q, c, s), _rope(k, c, s)
             Kc[li] = np.concatenate([Kc[li], k[:, None, :]], axis=1)
             Vc[li] = np.concatenate([Vc[li], v[:, None, :]], axis=1)
-            sc = alpha * np.einsum("hd,hkd->hk", q, Kc[li])
+            sc = alpha * np.einsum("hd,hkd->hk", q, np.repeat(Kc[li], rep, axis=0))  # the reference's `repeat` (Int4llamaAttention.cc:166-185)
             p = np.exp(sc - sc.max(axis=1, keepdims=True))
             p /= p.sum(axis=1, keepdims=True)
-            attn = np.einsum("hk,hkd->hd", p, Vc[li]).reshape(-1)
+            attn = np.einsum("hk,hkd->hd", p, np.repeat(Vc[li], rep, axis=0)).reshape(-1)
             h = h + W[li]["o"] @ attn
             hn = _rmsnorm(h, G[li][1], 1e-6)
             gate, up = W[li]["gate"] @ hn, W[li]["up"] @ hn

@@ -68,10 +68,15 @@ class DecodeAttention:
     (tce_attention_decode_step_f16; Int4llamaAttention.cu:130-217 without its copies and transposes): fixed-capacity caches
     [heads][max_keys][hd], RoPE on q and the new key with the reference's binary16 arithmetic, fp32 online softmax over key chunks."""
 
-    def __init__(self, heads: int, head_dim: int, max_keys: int, device, cos: torch.Tensor | None = None, sin: torch.Tensor | None = None):
+    def __init__(self, heads: int, head_dim: int, max_keys: int, device, cos: torch.Tensor | None = None, sin: torch.Tensor | None = None,
+                 kv_heads: int | None = None):
+        """kv_heads < heads: grouped-query attention (tce_attention_decode_step_gqa_f16; query head i reads key / value head
+        i // (heads // kv_heads), Int4llamaAttention.cc:166-185); the caches are [kv_heads][max_keys][hd] and the projection's row is
+        [heads + 2 * kv_heads][hd]."""
         self.heads, self.hd, self.max_keys = heads, head_dim, max_keys
-        self.k_cache = torch.zeros((heads, max_keys, head_dim), dtype=torch.float16, device=device)
-        self.v_cache = torch.zeros((heads, max_keys, head_dim), dtype=torch.float16, device=device)
+        self.kv_heads = heads if kv_heads is None else kv_heads
+        self.k_cache = torch.zeros((self.kv_heads, max_keys, head_dim), dtype=torch.float16, device=device)
+        self.v_cache = torch.zeros((self.kv_heads, max_keys, head_dim), dtype=torch.float16, device=device)
         need = int(capi.lib().tce_attention_decode_workspace_bytes(heads, max_keys, head_dim))
         if need == 0:
             raise ValueError("unsupported attention shape (head_dim must be 128)")
@@ -80,10 +85,10 @@ class DecodeAttention:
         self.alpha_bits = int(np.array([1.0 / np.sqrt(head_dim)], np.float16).view(np.uint16)[0])
 
     def step(self, qkv: torch.Tensor, pos: int, out: torch.Tensor | None = None, mask: torch.Tensor | None = None) -> torch.Tensor:
-        assert qkv.dtype == torch.float16 and qkv.is_contiguous() and qkv.numel() == 3 * self.heads * self.hd and qkv.is_cuda
+        assert qkv.dtype == torch.float16 and qkv.is_contiguous() and qkv.numel() == (self.heads + 2 * self.kv_heads) * self.hd and qkv.is_cuda
         if out is None:
             out = torch.empty((self.heads, self.hd), dtype=torch.float16, device=qkv.device)
         p = lambda t: C.c_void_p(t.data_ptr() if t is not None else 0)
-        capi.check(capi.lib().tce_attention_decode_step_f16(p(qkv), p(self.k_cache), p(self.v_cache), p(self.cos), p(self.sin), p(mask), p(out), p(self.workspace),
-                                                            self.heads, self.hd, self.max_keys, int(pos), self.alpha_bits, C.c_void_p(_stream())))
+        capi.check(capi.lib().tce_attention_decode_step_gqa_f16(p(qkv), p(self.k_cache), p(self.v_cache), p(self.cos), p(self.sin), p(mask), p(out), p(self.workspace),
+                                                                self.heads, self.kv_heads, self.hd, self.max_keys, int(pos), self.alpha_bits, C.c_void_p(_stream())))
         return out

@@ -32,14 +32,14 @@ namespace tce {
 namespace {
 
 struct FastAttnArgs {
-    const half_t *qkv;    // [3][heads][hd]
-    half_t *kc, *vc;      // [heads][max_keys][hd]
+    const half_t *qkv;    // [q_heads + 2 * kv_heads][hd]: q heads, then k heads, then v heads (the fused projection's row)
+    half_t *kc, *vc;      // [kv_heads][max_keys][hd]
     const half_t *cosv, *sinv;  // [positions][hd] or null (no RoPE: q / k used as they are)
     const half_t *mask;   // [keys] additive or null
-    half_t *out;          // [heads][hd]
-    float *part;          // [heads][chunks][2 + hd]
-    unsigned *cnt;        // [heads], zero between launches
-    int heads, hd, max_keys, pos, keys, chunk, chunks;
+    half_t *out;          // [q_heads][hd]
+    float *part;          // [q_heads][chunks][2 + hd]
+    unsigned *cnt;        // [kv_heads], zero between launches
+    int heads, kv_heads, hd, max_keys, pos, keys, chunk, chunks;  // heads = query heads
     float alpha;
 };
 
@@ -73,13 +73,16 @@ constexpr float kNegBig = -1.0e30f;
 
 // MASK: the caller gave a mask row (a compile-time form: a branch inside the fetch block makes hipcc drain the load queue at the loop head)
 // NW: waves per workgroup (4; 8 and 16 exist for the sweep that ruled them out, see pick_chunk).
-template <bool MASK, int NW>
+// R: query heads per key / value head (grouped-query attention, llm/src/nn_modules/non_cuda/Int4llamaAttention.cc:166-185: query head i reads
+//    key / value head i / R; Llama-3-8B: 32 / 8, llm/include/model.h:83).  A workgroup is (key / value head, chunk of keys): it streams the
+//    chunk's cache rows ONCE and keeps R online-softmax states per lane, so the R query heads cost one pass over the cache, not R.
+template <bool MASK, int NW, int R>
 __global__ __launch_bounds__(64 * NW) void attn_decode_fast_kernel(const FastAttnArgs a) {
     constexpr int NT = 64 * NW, NS = 4 * NW;
-    __shared__ __attribute__((aligned(16))) float st[NS][2 + kHD];  // the (wave, slot) states: m, l, o[hd]
+    __shared__ __attribute__((aligned(16))) float st[NS][R][2 + kHD];  // the (wave, slot) states per query head: m, l, o[hd]
     __shared__ __attribute__((aligned(16))) half_t newrow[2][kHD];  // the token's own (rotated) key and value
     __shared__ unsigned last_flag;
-    const int head = blockIdx.x / a.chunks, c = blockIdx.x - head * a.chunks;
+    const int head = blockIdx.x / a.chunks, c = blockIdx.x - head * a.chunks;  // head: the key / value head
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int slot = lane >> 4, piece = lane & 15;
     const int key0 = c * a.chunk, key1 = key0 + a.chunk < a.keys ? key0 + a.chunk : a.keys;
@@ -114,14 +117,22 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fast_kernel(const FastAtt
     // ---- every piece the prologue needs, requested together behind them: q, k (with their partner halves), v, cos, sin.  All four
     //      waves fetch the k / v pieces (L2 hits, 3 instructions) so that nobody waits for a second batch; wave 0 uses them ----
     const bool rope = cosr != nullptr;
-    const half_t *xq = a.qkv + hoff, *xk = a.qkv + (size_t)a.heads * kHD + hoff, *xv = a.qkv + (size_t)2 * a.heads * kHD + hoff;
+    const half_t *xq = a.qkv + hoff * R, *xk = a.qkv + (size_t)a.heads * kHD + hoff, *xv = a.qkv + (size_t)(a.heads + a.kv_heads) * kHD + hoff;
     const half_t *cp = rope ? cosr : xq, *sp = rope ? sinr : xq;  // no rotation: harmless repeats of the q piece, not used
     auto ld8 = [](const half_t *ptr) { return *reinterpret_cast<const half8_t *>(ptr); };
-    const half8_t q_v = ld8(xq + piece * 8), q_p = ld8(xq + (piece ^ 8) * 8), cc = ld8(cp + piece * 8), ss = ld8(sp + piece * 8);
+    half8_t q_v[R], q_p[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        q_v[r] = ld8(xq + r * kHD + piece * 8);
+        q_p[r] = ld8(xq + r * kHD + (piece ^ 8) * 8);
+    }
+    const half8_t cc = ld8(cp + piece * 8), ss = ld8(sp + piece * 8);
     const half8_t k_v = ld8(xk + piece * 8), k_p = ld8(xk + (piece ^ 8) * 8), v_v = ld8(xv + piece * 8);
     __builtin_amdgcn_sched_barrier(0);
-    // ---- q (rotated), this lane's 8 dimensions ----
-    const half8_t qh = rope ? rope_apply(q_v, q_p, cc, ss, piece) : q_v;
+    // ---- the R query heads (rotated), this lane's 8 dimensions of each ----
+    half8_t qh[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) qh[r] = rope ? rope_apply(q_v[r], q_p[r], cc, ss, piece) : q_v[r];
     // ---- the new key / value of this head: into LDS for this workgroup's use, into the cache by the workgroup that owns index pos ----
     if (wave == 0) {
         const half8_t kh = rope ? rope_apply(k_v, k_p, cc, ss, piece) : k_v;
@@ -136,9 +147,14 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fast_kernel(const FastAtt
         }
     }
     __syncthreads();
-    float m = kNegBig, l = 0.f, acc[8];
+    float m[R], l[R], acc[R][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int r = 0; r < R; ++r) {
+        m[r] = kNegBig;
+        l[r] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[r][e] = 0.f;
+    }
     auto consume = [&](const half8_t (&kd)[BLK], const half8_t (&vd)[BLK], const half_t (&md)[BLK], int it0) {
 #pragma unroll
         for (int u = 0; u < BLK; ++u) {
@@ -149,20 +165,29 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fast_kernel(const FastAtt
                 kv = *reinterpret_cast<const half8_t *>(&newrow[0][piece * 8]);
                 vv = *reinterpret_cast<const half8_t *>(&newrow[1][piece * 8]);
             }
-            float d = 0.f;
+            // a slot past the range was loaded from a row that may hold anything (the row at `pos` before this launch wrote it, an
+            // uninitialised cache): its weight is 0, and 0 * inf would still be NaN -- the value row is zeroed, not just weighted
+            if (!valid) vv = half8_t{(half_t)0, (half_t)0, (half_t)0, (half_t)0, (half_t)0, (half_t)0, (half_t)0, (half_t)0};
+            float vf[8];
 #pragma unroll
-            for (int e = 0; e < 8; e += 2) d = __builtin_amdgcn_fdot2(half2_t{qh[e], qh[e + 1]}, half2_t{kv[e], kv[e + 1]}, d, false);
-            d = row16_sum(d);
-            float s = a.alpha * d;
-            if constexpr (MASK) s += (float)md[u];
-            if (!(__builtin_fabsf(s) <= 65504.0f)) s = -65504.0f;  // check_inf_half (Int4llamaAttention.cu:105-115): inf / nan / beyond binary16 -> -65504
-            if (!valid) s = kNegBig;
-            const float mn = __builtin_fmaxf(m, s);
-            const float sc = __expf(m - mn), p = valid ? __expf(s - mn) : 0.f;
-            m = mn;
-            l = l * sc + p;
+            for (int e = 0; e < 8; ++e) vf[e] = (float)vv[e];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] = acc[e] * sc + p * (float)vv[e];
+            for (int r = 0; r < R; ++r) {
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) d = __builtin_amdgcn_fdot2(half2_t{qh[r][e], qh[r][e + 1]}, half2_t{kv[e], kv[e + 1]}, d, false);
+                d = row16_sum(d);
+                float s = a.alpha * d;
+                if constexpr (MASK) s += (float)md[u];
+                if (!(__builtin_fabsf(s) <= 65504.0f)) s = -65504.0f;  // check_inf_half (Int4llamaAttention.cu:105-115): inf / nan / beyond binary16 -> -65504
+                if (!valid) s = kNegBig;
+                const float mn = __builtin_fmaxf(m[r], s);
+                const float sc = __expf(m[r] - mn), p = valid ? __expf(s - mn) : 0.f;
+                m[r] = mn;
+                l[r] = l[r] * sc + p;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[r][e] = acc[r][e] * sc + p * vf[e];
+            }
         }
     };
     // per_wave is a multiple of 4 (steps); blocks of 4 steps, the last one possibly past the range (clamped loads, zero weights)
@@ -173,39 +198,55 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fast_kernel(const FastAtt
         fetch(kbuf[0], vbuf[0], mbuf[0], it + 2 * BLK * 4);
         consume(kbuf[1], vbuf[1], mbuf[1], it + BLK * 4);
     }
-    // ---- merge the workgroup's 16 states ----
-    {
-        float *s_ = st[wave * 4 + slot];
+    // ---- merge the workgroup's 4 * NW states, per query head ----
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float *s_ = st[wave * 4 + slot][r];
         if (piece == 0) {
-            s_[0] = m;
-            s_[1] = l;
+            s_[0] = m[r];
+            s_[1] = l[r];
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s_[2 + piece * 8 + e] = acc[e];
+        for (int e = 0; e < 8; ++e) s_[2 + piece * 8 + e] = acc[r][e];
     }
     __syncthreads();
-    float M = kNegBig, L = 0.f, O = 0.f;  // thread d < 128 owns output dimension d
+    float M[R], Lq[R], O[R];  // thread d < 128 owns output dimension d of every query head
     if (tid < kHD) {
 #pragma unroll
-        for (int i = 0; i < NS; ++i) M = __builtin_fmaxf(M, st[i][0]);
+        for (int r = 0; r < R; ++r) {
+            float Mx = kNegBig;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) Mx = __builtin_fmaxf(Mx, st[i][r][0]);
+            float Lx = 0.f, Ox = 0.f;
 #pragma unroll 16
-        for (int i = 0; i < NS; ++i) {
-            const float w = __expf(st[i][0] - M);
-            L += st[i][1] * w;
-            O += st[i][2 + tid] * w;
+            for (int i = 0; i < NS; ++i) {
+                const float w = __expf(st[i][r][0] - Mx);
+                Lx += st[i][r][1] * w;
+                Ox += st[i][r][2 + tid] * w;
+            }
+            M[r] = Mx;
+            Lq[r] = Lx;
+            O[r] = Ox;
         }
     }
+    const size_t qoff = (size_t)head * R * kHD;  // the first of this workgroup's query heads in `out`
     if (a.chunks == 1) {
-        if (tid < kHD) a.out[hoff + tid] = (half_t)(O / L);
+        if (tid < kHD) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) a.out[qoff + r * kHD + tid] = (half_t)(O[r] / Lq[r]);
+        }
         return;
     }
     // ---- several chunks per head: partial (M, L, O) to the workspace, the last workgroup to arrive combines ----
-    float *mine = a.part + ((size_t)head * a.chunks + c) * (2 + kHD);
     if (tid < kHD) {
-        __hip_atomic_store(mine + 2 + tid, O, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through (sc1) stores
-        if (tid == 0) {
-            __hip_atomic_store(mine, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(mine + 1, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float *mine = a.part + ((size_t)(head * R + r) * a.chunks + c) * (2 + kHD);
+            __hip_atomic_store(mine + 2 + tid, O[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through (sc1) stores
+            if (tid == 0) {
+                __hip_atomic_store(mine, M[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(mine + 1, Lq[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores are acknowledged before the workgroup arrives
@@ -220,38 +261,45 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fast_kernel(const FastAtt
     // The partials were stored write-through; they are read back with device-coherent (sc0 sc1) buffer loads -- plain loads as
     // far as the compiler is concerned, so all of a thread's loads are in flight together (a loop of relaxed atomic loads is a
     // chain of round trips: 1 us per chunk, measured).  Thread i < chunks fetches (M_i, L_i), every thread d < hd its O_i[d].
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.part + (size_t)head * a.chunks * (2 + kHD), 0, (int)((size_t)a.chunks * (2 + kHD) * 4), 0x00020000);
-    float *ml = &st[0][0];  // [chunks][2], reuses the state area
-    for (int i = tid; i < a.chunks; i += NT) {
-        ml[2 * i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, i * (2 + kHD) * 4, 0, /*sc0|sc1*/ 17));
-        ml[2 * i + 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, i * (2 + kHD) * 4 + 4, 0, 17));
-    }
     constexpr int kMaxChunksUnrolled = 16;
-    float oi[kMaxChunksUnrolled];
+    float *ml = &st[0][0][0];  // [R][chunks][2], reuses the state area
+    const int stride = (2 + kHD) * 4;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.part + (size_t)head * R * a.chunks * (2 + kHD), 0, (int)((size_t)R * a.chunks * stride), 0x00020000);
+    for (int i = tid; i < R * a.chunks; i += NT) {
+        ml[2 * i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, i * stride, 0, /*sc0|sc1*/ 17));
+        ml[2 * i + 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, i * stride + 4, 0, 17));
+    }
+    float oi[R][kMaxChunksUnrolled];
     if (tid < kHD) {
 #pragma unroll
-        for (int i = 0; i < kMaxChunksUnrolled; ++i)
-            oi[i] = i < a.chunks ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (i * (2 + kHD) + 2 + tid) * 4, 0, 17)) : 0.f;
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int i = 0; i < kMaxChunksUnrolled; ++i)
+                oi[r][i] = i < a.chunks ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (r * a.chunks + i) * stride + (2 + tid) * 4, 0, 17)) : 0.f;
     }
     __syncthreads();
     if (tid < kHD) {
-        float Mx = kNegBig;
-        for (int i = 0; i < a.chunks; ++i) Mx = __builtin_fmaxf(Mx, ml[2 * i]);
-        float Lx = 0.f, Ox = 0.f;
 #pragma unroll
-        for (int i = 0; i < kMaxChunksUnrolled; ++i) {
-            if (i < a.chunks) {
-                const float w = __expf(ml[2 * i] - Mx);
-                Lx += ml[2 * i + 1] * w;
-                Ox += oi[i] * w;
+        for (int r = 0; r < R; ++r) {
+            const float *mlr = ml + 2 * r * a.chunks;
+            float Mx = kNegBig;
+            for (int i = 0; i < a.chunks; ++i) Mx = __builtin_fmaxf(Mx, mlr[2 * i]);
+            float Lx = 0.f, Ox = 0.f;
+#pragma unroll
+            for (int i = 0; i < kMaxChunksUnrolled; ++i) {
+                if (i < a.chunks) {
+                    const float w = __expf(mlr[2 * i] - Mx);
+                    Lx += mlr[2 * i + 1] * w;
+                    Ox += oi[r][i] * w;
+                }
             }
+            for (int i = kMaxChunksUnrolled; i < a.chunks; ++i) {  // many chunks: the rest one by one
+                const float w = __expf(mlr[2 * i] - Mx);
+                Lx += mlr[2 * i + 1] * w;
+                Ox += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (r * a.chunks + i) * stride + (2 + tid) * 4, 0, 17)) * w;
+            }
+            a.out[qoff + r * kHD + tid] = (half_t)(Ox / Lx);
         }
-        for (int i = kMaxChunksUnrolled; i < a.chunks; ++i) {  // very long contexts: the rest one by one
-            const float w = __expf(ml[2 * i] - Mx);
-            Lx += ml[2 * i + 1] * w;
-            Ox += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (i * (2 + kHD) + 2 + tid) * 4, 0, 17)) * w;
-        }
-        a.out[hoff + tid] = (half_t)(Ox / Lx);
     }
 }
 
@@ -278,9 +326,20 @@ void set_attention_fast_target(int wgs) { g_attn_target_wgs = wgs >= 32 && wgs <
 static int g_attn_waves = 0;  // 0: by the chunk's length; tuning: tce_w4a16_set_debug_mode(2900 + 4 / 8 / 16)
 void set_attention_fast_waves(int nw) { g_attn_waves = (nw == 4 || nw == 8 || nw == 16) ? nw : 0; }
 
-static void pick_chunk(int heads, int keys, int *chunk_out, int *waves_out) {
+static void pick_chunk(int heads, int keys, int *chunk_out, int *waves_out, int kv_heads = 0) {
     int chunk;
+    if (kv_heads > 0 && kv_heads < heads && g_attn_target_wgs == 0) {
+        // grouped queries: kv_heads x chunks workgroups, each streaming its chunk once for all of its query heads.  One chunk per head and
+        // no combine while the chunk is short; then chunks of >= 128 keys, sixteen at most (what the combine reads in one batch)
+        chunk = keys <= 256 ? keys : (keys + 15) / 16;
+        if (chunk < 128 && keys > 256) chunk = 128;
+        chunk = (chunk + 15) / 16 * 16;
+        *chunk_out = chunk;
+        *waves_out = 4;
+        return;
+    }
     if (g_attn_target_wgs > 0) {
+        if (kv_heads > 0) heads = kv_heads;
         const int target_chunks = heads >= g_attn_target_wgs ? 1 : g_attn_target_wgs / heads;
         chunk = (keys + target_chunks - 1) / target_chunks;
         if (chunk < 64) chunk = 64;
@@ -305,8 +364,8 @@ static void pick_chunk(int heads, int keys, int *chunk_out, int *waves_out) {
 }
 
 // the cut launch_attention_decode_fast would use for `keys` keys (no HIP call)
-void describe_attention_decode_fast(int heads, int keys, int *chunk, int *chunks, int *waves) {
-    pick_chunk(heads, keys, chunk, waves);
+void describe_attention_decode_fast(int heads, int keys, int *chunk, int *chunks, int *waves, int kv_heads) {
+    pick_chunk(heads, keys, chunk, waves, kv_heads);
     *chunks = (keys + *chunk - 1) / *chunk;
 }
 
@@ -319,8 +378,10 @@ size_t attention_decode_workspace_bytes(int heads, int max_keys, int hd) {
 }
 
 int launch_attention_decode_fast(const void *qkv, void *kc, void *vc, const void *cosv, const void *sinv, const void *mask, void *out, void *workspace,
-                                 int heads, int hd, int max_keys, int pos, unsigned short alpha_bits, hipStream_t stream, hipError_t *hip_err) {
-    if (hd != kHD) return TCE_ERR_UNSUPPORTED_SHAPE;
+                                 int heads, int kv_heads, int hd, int max_keys, int pos, unsigned short alpha_bits, hipStream_t stream, hipError_t *hip_err) {
+    if (hd != kHD || kv_heads <= 0 || heads % kv_heads != 0) return TCE_ERR_UNSUPPORTED_SHAPE;
+    const int rep = heads / kv_heads;
+    if (rep != 1 && rep != 2 && rep != 4) return TCE_ERR_UNSUPPORTED_SHAPE;
     FastAttnArgs a{};
     a.qkv = static_cast<const half_t *>(qkv);
     a.kc = static_cast<half_t *>(kc);
@@ -333,23 +394,26 @@ int launch_attention_decode_fast(const void *qkv, void *kc, void *vc, const void
     a.cnt = static_cast<unsigned *>(workspace);
     a.part = reinterpret_cast<float *>(static_cast<unsigned char *>(workspace) + cnt_bytes);
     a.heads = heads;
+    a.kv_heads = kv_heads;
     a.hd = hd;
     a.max_keys = max_keys;
     a.pos = pos;
     a.keys = pos + 1;
     int nw = 4;
-    pick_chunk(heads, a.keys, &a.chunk, &nw);
+    pick_chunk(heads, a.keys, &a.chunk, &nw, kv_heads);
     a.chunks = (a.keys + a.chunk - 1) / a.chunk;
     if (a.chunks > 1024) return TCE_ERR_UNSUPPORTED_SHAPE;  // (the combine's LDS image; unreachable with the fitted rule below 500k keys)
     half_t ah;
     __builtin_memcpy(&ah, &alpha_bits, 2);
     a.alpha = (float)ah;
-    const dim3 grid(heads * a.chunks);
+    const dim3 grid(kv_heads * a.chunks);
     auto go = [&](auto has_mask) {
         constexpr bool MK = decltype(has_mask)::value;
-        if (nw == 16) hipLaunchKernelGGL((attn_decode_fast_kernel<MK, 16>), grid, dim3(1024), 0, stream, a);
-        else if (nw == 8) hipLaunchKernelGGL((attn_decode_fast_kernel<MK, 8>), grid, dim3(512), 0, stream, a);
-        else hipLaunchKernelGGL((attn_decode_fast_kernel<MK, 4>), grid, dim3(256), 0, stream, a);
+        if (rep == 4) hipLaunchKernelGGL((attn_decode_fast_kernel<MK, 4, 4>), grid, dim3(256), 0, stream, a);
+        else if (rep == 2) hipLaunchKernelGGL((attn_decode_fast_kernel<MK, 4, 2>), grid, dim3(256), 0, stream, a);
+        else if (nw == 16) hipLaunchKernelGGL((attn_decode_fast_kernel<MK, 16, 1>), grid, dim3(1024), 0, stream, a);
+        else if (nw == 8) hipLaunchKernelGGL((attn_decode_fast_kernel<MK, 8, 1>), grid, dim3(512), 0, stream, a);
+        else hipLaunchKernelGGL((attn_decode_fast_kernel<MK, 4, 1>), grid, dim3(256), 0, stream, a);
     };
     if (a.mask) go(std::true_type{});
     else go(std::false_type{});

@@ -658,24 +658,34 @@ void tce_comm_destroy(tce_comm *comm) { tce::comm_destroy(reinterpret_cast<tce::
 
 size_t tce_attention_decode_workspace_bytes(int heads, int max_keys, int hd) { return tce::attention_decode_workspace_bytes(heads, max_keys, hd); }
 
-int tce_attention_decode_describe(int heads, int keys, char *buf, int buf_len) {
-    if (!buf || buf_len <= 0 || heads <= 0 || keys <= 0) return fail(TCE_ERR_BAD_ARG, "tce_attention_decode_describe: bad argument");
+int tce_attention_decode_describe(int heads, int keys, char *buf, int buf_len) { return tce_attention_decode_describe_gqa(heads, heads, keys, buf, buf_len); }
+
+int tce_attention_decode_describe_gqa(int heads, int kv_heads, int keys, char *buf, int buf_len) {
+    if (!buf || buf_len <= 0 || heads <= 0 || kv_heads <= 0 || heads % kv_heads != 0 || keys <= 0) return fail(TCE_ERR_BAD_ARG, "tce_attention_decode_describe: bad argument");
     int chunk = 0, chunks = 0, waves = 0;
-    tce::describe_attention_decode_fast(heads, keys, &chunk, &chunks, &waves);
-    std::snprintf(buf, (size_t)buf_len, "chunks=%d keys-per-chunk=%d waves=%d workgroups=%d combine=%s", chunks, chunk, waves, heads * chunks, chunks > 1 ? "yes" : "no");
+    tce::describe_attention_decode_fast(heads, keys, &chunk, &chunks, &waves, kv_heads);
+    std::snprintf(buf, (size_t)buf_len, "chunks=%d keys-per-chunk=%d waves=%d workgroups=%d combine=%s", chunks, chunk, waves, kv_heads * chunks, chunks > 1 ? "yes" : "no");
     return TCE_OK;
 }
 
 int tce_attention_decode_step_f16(const void *qkv, void *kc, void *vc, const void *cosv, const void *sinv, const void *mask, void *out, void *workspace, int heads,
                                   int hd, int max_keys, int pos, unsigned short alpha_bits, void *stream) {
+    return tce_attention_decode_step_gqa_f16(qkv, kc, vc, cosv, sinv, mask, out, workspace, heads, heads, hd, max_keys, pos, alpha_bits, stream);
+}
+
+int tce_attention_decode_step_gqa_f16(const void *qkv, void *kc, void *vc, const void *cosv, const void *sinv, const void *mask, void *out, void *workspace, int heads,
+                                      int kv_heads, int hd, int max_keys, int pos, unsigned short alpha_bits, void *stream) {
     if (!qkv || !kc || !vc || !out || !workspace) return fail(TCE_ERR_BAD_ARG, "tce_attention_decode_step_f16: null pointer");
     if ((cosv == nullptr) != (sinv == nullptr)) return fail(TCE_ERR_BAD_ARG, "tce_attention_decode_step_f16: cos and sin tables come together");
     if (heads <= 0 || max_keys <= 0 || pos < 0 || pos >= max_keys) return fail(TCE_ERR_BAD_ARG, "tce_attention_decode_step_f16: need heads > 0 and 0 <= pos < max_keys");
+    if (kv_heads <= 0 || heads % kv_heads != 0) return fail(TCE_ERR_BAD_ARG, "tce_attention_decode_step_gqa_f16: %d query heads do not divide over %d key / value heads", heads, kv_heads);
+    if (heads / kv_heads != 1 && heads / kv_heads != 2 && heads / kv_heads != 4)
+        return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_attention_decode_step_gqa_f16: %d query heads per key / value head (1, 2 or 4)", heads / kv_heads);
     if (hd != 128) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_attention_decode_step_f16: head_dim %d (128 only: Llama's)", hd);
     for (const void *p : {qkv, (const void *)kc, (const void *)vc, cosv, sinv})
         if (reinterpret_cast<uintptr_t>(p) & 15) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_attention_decode_step_f16: 16-byte aligned pointers");
     hipError_t he = hipSuccess;
-    const int rc = tce::launch_attention_decode_fast(qkv, kc, vc, cosv, sinv, mask, out, workspace, heads, hd, max_keys, pos, alpha_bits, static_cast<hipStream_t>(stream), &he);
+    const int rc = tce::launch_attention_decode_fast(qkv, kc, vc, cosv, sinv, mask, out, workspace, heads, kv_heads, hd, max_keys, pos, alpha_bits, static_cast<hipStream_t>(stream), &he);
     return rc == TCE_ERR_HIP ? hip_fail(he, "attention decode step launch") : rc;
 }
 

@@ -161,10 +161,10 @@ int launch_allgather_f16(Comm *c, int slot, const void *src_slice, void *dst_ful
 // attention_fast.hip
 void set_attention_fast_target(int wgs);
 void set_attention_fast_waves(int nw);
-void describe_attention_decode_fast(int heads, int keys, int *chunk, int *chunks, int *waves);
+void describe_attention_decode_fast(int heads, int keys, int *chunk, int *chunks, int *waves, int kv_heads = 0);
 size_t attention_decode_workspace_bytes(int heads, int max_keys, int hd);
 int launch_attention_decode_fast(const void *qkv, void *kc, void *vc, const void *cosv, const void *sinv, const void *mask, void *out, void *workspace,
-                                 int heads, int hd, int max_keys, int pos, unsigned short alpha_bits, hipStream_t stream, hipError_t *hip_err);
+                                 int heads, int kv_heads, int hd, int max_keys, int pos, unsigned short alpha_bits, hipStream_t stream, hipError_t *hip_err);
 int launch_rope_half(void *q, void *k, const void *cosv, const void *sinv, int heads, int len, int hd, int start_idx, hipStream_t stream, hipError_t *hip_err);
 int launch_softmax_half(const void *x, void *out, long long rows, int n, hipStream_t stream, hipError_t *hip_err);
 int launch_prefetch(const void *ptr, long long bytes, int workgroups, hipStream_t stream, hipError_t *hip_err);

@@ -27,12 +27,15 @@ from .linear import Linear_half_int4, _stream
 
 class DecoderBlock:
     def __init__(self, hidden: int, heads: int, ffn: int, max_keys: int, device, cos: torch.Tensor, sin: torch.Tensor, seed: int = 0,
-                 group_size: int = 128, eps: float = 1e-6):
+                 group_size: int = 128, eps: float = 1e-6, kv_heads: int | None = None):
+        """kv_heads < heads: grouped-query attention (Llama-3-8B: 32 / 8, llm/include/model.h:83) -- the fused projection is
+        (heads + 2 * kv_heads) * 128 rows wide and the caches hold kv_heads heads."""
         assert hidden % heads == 0 and hidden // heads == 128, "the attention step is built for head_dim 128 (Llama)"
         self.hidden, self.heads, self.ffn, self.eps = hidden, heads, ffn, eps
+        self.kv_heads = heads if kv_heads is None else kv_heads
         g = torch.Generator(device=device).manual_seed(seed)
         rnd = lambda n, k: torch.empty(n, k, device=device).normal_(0.0, k ** -0.5, generator=g)
-        self.qkv = Linear_half_int4.from_float(rnd(3 * hidden, hidden), group_size)   # rows: q | k | v, head-major (llama_qkv_merger.py:27-48)
+        self.qkv = Linear_half_int4.from_float(rnd((heads + 2 * self.kv_heads) * 128, hidden), group_size)   # rows: q | k | v, head-major (llama_qkv_merger.py:27-48)
         self.o = Linear_half_int4.from_float(rnd(hidden, hidden), group_size)
         self.gate = Linear_half_int4.from_float(rnd(ffn, hidden), group_size)
         self.up = Linear_half_int4.from_float(rnd(ffn, hidden), group_size)
@@ -40,9 +43,9 @@ class DecoderBlock:
         self.down = Linear_half_int4.from_float(rnd(hidden, ffn), group_size)
         self.gamma1 = (1.0 + 0.1 * torch.empty(hidden, device=device).normal_(0, 1, generator=g)).float()
         self.gamma2 = (1.0 + 0.1 * torch.empty(hidden, device=device).normal_(0, 1, generator=g)).float()
-        self.attention = DecodeAttention(heads, 128, max_keys, device, cos, sin)
+        self.attention = DecodeAttention(heads, 128, max_keys, device, cos, sin, kv_heads=self.kv_heads)
         e = lambda n: torch.empty((1, n), dtype=torch.float16, device=device)
-        self.qkv_out, self.attn_out, self.act = e(3 * hidden), e(hidden), e(ffn)
+        self.qkv_out, self.attn_out, self.act = e((heads + 2 * self.kv_heads) * 128), e(hidden), e(ffn)
 
     def step(self, hidden_state: torch.Tensor, pos: int) -> None:
         """hidden_state fp16 [1][hidden], updated in place (it is the residual stream)."""
