@@ -166,8 +166,9 @@ TCE_API int tce_attention_decode_step_f16(const void *qkv, void *k_cache, void *
  *   qkv  fp16 [heads + 2 * kv_heads][head_dim]: the query heads, then the key heads, then the value heads (the fused projection's row)
  *   k_cache, v_cache  fp16 [kv_heads][max_keys][head_dim];  out fp16 [heads][head_dim]
  *   workspace  tce_attention_decode_workspace_bytes(heads, max_keys, head_dim) bytes, zeroed once
- * A workgroup owns (key / value head, chunk of keys) and streams its cache rows ONCE for all of its query heads.  heads / kv_heads in {1, 2, 4}
- * (kv_heads == heads is tce_attention_decode_step_f16).  Rows of the caches at and beyond `pos` may hold anything on entry (uninitialised
+ * Any heads % kv_heads == 0 (kv_heads == heads is tce_attention_decode_step_f16).  A workgroup owns (query head, chunk of keys) and the
+ * heads / kv_heads workgroups of a key / value head read the same cache rows (from HBM once; the fused form -- one workgroup streaming a
+ * chunk once for 2 or 4 query heads -- exists behind tce_w4a16_set_debug_mode(2922 / 2924) and measured slower, see csrc/attention_fast.hip).  Rows of the caches at and beyond `pos` may hold anything on entry (uninitialised
  * memory included): they are never weighted into the result. */
 TCE_API int tce_attention_decode_step_gqa_f16(const void *qkv, void *k_cache, void *v_cache, const void *cos_table, const void *sin_table, const void *mask,
                                               void *out, void *workspace, int heads, int kv_heads, int head_dim, int max_keys, int pos,
@@ -388,6 +389,7 @@ TCE_API int tce_w4a16_set_gemv_config(int rows_per_wave, int waves_n, int waves_
  *   1000+m   largest M the small-batch kernel takes (default 1128 = 128; 1016 restricts it to M <= 16)
  *   640..644 pre-packed GEMM with the k range cut across workgroups: runs per cut tile forced (640: the cost model's choice)
  *   2900+w   fast attention step: waves per workgroup, w in {4, 8, 16} (2900: the default, 4)
+ *   2920+r   fast attention step, grouped queries: query heads per workgroup, r in {1, 2, 4} (2920: the rule, 1)
  *   3000+g   fast attention step: workgroups the key range is cut for (3000: the fitted per-context rule, the default)
  * Every setting computes correct results except GEMV modes 1, 3, 4. */
 TCE_API int tce_w4a16_set_debug_mode(int mode);

@@ -301,11 +301,25 @@ def test_attention_decode_step_random_contexts(dev, oracle):
 
 @pytest.mark.parametrize("heads,kv_heads,max_keys,start,steps", [(32, 8, 2048, 2040, 3), (32, 8, 700, 600, 2), (8, 2, 300, 0, 6), (16, 8, 1100, 1000, 2),
                                                                  (32, 8, 257, 255, 2), (4, 1, 4200, 4190, 2)])
-def test_attention_decode_step_grouped_queries(dev, oracle, heads, kv_heads, max_keys, start, steps):
+@pytest.mark.parametrize("fuse", [0, 2, 4])
+def test_attention_decode_step_grouped_queries(dev, oracle, heads, kv_heads, max_keys, start, steps, fuse):
     """Grouped-query attention (Llama-3-8B: 32 query heads over 8 key / value heads, model.h:83): query head i reads key / value head
     i // (heads // kv_heads) -- the reference's `repeat` (non_cuda/Int4llamaAttention.cc:166-185).  Checked against float64 on the repeated
     caches, against the multi-head kernel run on physically repeated caches (same arithmetic per query head: bit-identical where both
     use one chunk, tolerance-level where their chunkings differ), and the appended rows against the reference's RoPE."""
+    from tinychatengine_amd.attention_ops import DecodeAttention
+    from tinychatengine_amd import capi
+    hd, rep = 128, heads // kv_heads
+    if fuse and rep % fuse:
+        pytest.skip("the fused form needs heads / kv_heads to be a multiple of the heads per workgroup")
+    capi.check(capi.lib().tce_w4a16_set_debug_mode(2920 + fuse))  # 0: the rule (one query head per workgroup); 2 / 4: fused
+    try:
+        _gqa_case(dev, oracle, heads, kv_heads, max_keys, start, steps)
+    finally:
+        capi.check(capi.lib().tce_w4a16_set_debug_mode(2920))
+
+
+def _gqa_case(dev, oracle, heads, kv_heads, max_keys, start, steps):
     from tinychatengine_amd.attention_ops import DecodeAttention
     hd, rep = 128, heads // kv_heads
     rng = np.random.default_rng(heads * 7 + max_keys)
@@ -389,4 +403,3 @@ def test_attention_decode_step_argument_checks(dev):
     assert L.tce_attention_decode_step_f16(p, p, p, None, None, None, p, ws.data_ptr(), 2, 128, 64, 64, 0x3C00, None) == capi.TCE_ERR_BAD_ARG  # pos == max_keys
     assert L.tce_attention_decode_step_f16(p, p, p, p, None, None, p, ws.data_ptr(), 2, 128, 64, 0, 0x3C00, None) == capi.TCE_ERR_BAD_ARG  # cos without sin
     assert L.tce_attention_decode_step_gqa_f16(p, p, p, None, None, None, p, ws.data_ptr(), 6, 4, 128, 64, 0, 0x3C00, None) == capi.TCE_ERR_BAD_ARG  # 6 query heads over 4
-    assert L.tce_attention_decode_step_gqa_f16(p, p, p, None, None, None, p, ws.data_ptr(), 16, 2, 128, 64, 0, 0x3C00, None) == capi.TCE_ERR_UNSUPPORTED_SHAPE  # 8 per head

@@ -39,7 +39,7 @@ struct FastAttnArgs {
     half_t *out;          // [q_heads][hd]
     float *part;          // [q_heads][chunks][2 + hd]
     unsigned *cnt;        // [kv_heads], zero between launches
-    int heads, kv_heads, hd, max_keys, pos, keys, chunk, chunks;  // heads = query heads
+    int heads, kv_heads, rep, hd, max_keys, pos, keys, chunk, chunks;  // heads = query heads, rep = heads / kv_heads
     float alpha;
 };
 
@@ -82,7 +82,11 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fast_kernel(const FastAtt
     __shared__ __attribute__((aligned(16))) float st[NS][R][2 + kHD];  // the (wave, slot) states per query head: m, l, o[hd]
     __shared__ __attribute__((aligned(16))) half_t newrow[2][kHD];  // the token's own (rotated) key and value
     __shared__ unsigned last_flag;
-    const int head = blockIdx.x / a.chunks, c = blockIdx.x - head * a.chunks;  // head: the key / value head
+    // grp: this workgroup's group of R consecutive query heads (R == rep: all the query heads of a key / value head, its cache rows streamed
+    // once for all of them; R < rep: rep / R workgroups read the same cache rows -- from HBM once, the others from the memory-side cache)
+    const int grp = blockIdx.x / a.chunks, c = blockIdx.x - grp * a.chunks;
+    const int head = (grp * R) / a.rep;  // the key / value head
+    const bool appends = (grp * R) % a.rep == 0;  // one workgroup group per key / value head writes the token's row into the caches
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int slot = lane >> 4, piece = lane & 15;
     const int key0 = c * a.chunk, key1 = key0 + a.chunk < a.keys ? key0 + a.chunk : a.keys;
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fast_kernel(const FastAtt
     // ---- every piece the prologue needs, requested together behind them: q, k (with their partner halves), v, cos, sin.  All four
     //      waves fetch the k / v pieces (L2 hits, 3 instructions) so that nobody waits for a second batch; wave 0 uses them ----
     const bool rope = cosr != nullptr;
-    const half_t *xq = a.qkv + hoff * R, *xk = a.qkv + (size_t)a.heads * kHD + hoff, *xv = a.qkv + (size_t)(a.heads + a.kv_heads) * kHD + hoff;
+    const half_t *xq = a.qkv + (size_t)grp * R * kHD, *xk = a.qkv + (size_t)a.heads * kHD + hoff, *xv = a.qkv + (size_t)(a.heads + a.kv_heads) * kHD + hoff;
     const half_t *cp = rope ? cosr : xq, *sp = rope ? sinr : xq;  // no rotation: harmless repeats of the q piece, not used
     auto ld8 = [](const half_t *ptr) { return *reinterpret_cast<const half8_t *>(ptr); };
     half8_t q_v[R], q_p[R];
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fast_kernel(const FastAtt
         if (slot == 0) {
             *reinterpret_cast<half8_t *>(&newrow[0][piece * 8]) = kh;
             *reinterpret_cast<half8_t *>(&newrow[1][piece * 8]) = vh;
-            if (a.pos >= key0 && a.pos < key1) {
+            if (appends && a.pos >= key0 && a.pos < key1) {
                 *reinterpret_cast<half8_t *>(a.kc + ((size_t)head * a.max_keys + a.pos) * kHD + piece * 8) = kh;
                 *reinterpret_cast<half8_t *>(a.vc + ((size_t)head * a.max_keys + a.pos) * kHD + piece * 8) = vh;
             }
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fast_kernel(const FastAtt
             O[r] = Ox;
         }
     }
-    const size_t qoff = (size_t)head * R * kHD;  // the first of this workgroup's query heads in `out`
+    const size_t qoff = (size_t)grp * R * kHD;  // the first of this workgroup's query heads in `out`
     if (a.chunks == 1) {
         if (tid < kHD) {
 #pragma unroll
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fast_kernel(const FastAtt
     if (tid < kHD) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            float *mine = a.part + ((size_t)(head * R + r) * a.chunks + c) * (2 + kHD);
+            float *mine = a.part + ((size_t)(grp * R + r) * a.chunks + c) * (2 + kHD);
             __hip_atomic_store(mine + 2 + tid, O[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through (sc1) stores
             if (tid == 0) {
                 __hip_atomic_store(mine, M[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -252,9 +256,9 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fast_kernel(const FastAtt
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores are acknowledged before the workgroup arrives
     __syncthreads();
     if (tid == 0) {
-        const unsigned old = __hip_atomic_fetch_add(a.cnt + head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned old = __hip_atomic_fetch_add(a.cnt + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last_flag = old == (unsigned)a.chunks - 1 ? 1u : 0u;
-        if (last_flag) __hip_atomic_store(a.cnt + head, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+        if (last_flag) __hip_atomic_store(a.cnt + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
     }
     __syncthreads();
     if (!last_flag) return;
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fast_kernel(const FastAtt
     constexpr int kMaxChunksUnrolled = 16;
     float *ml = &st[0][0][0];  // [R][chunks][2], reuses the state area
     const int stride = (2 + kHD) * 4;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.part + (size_t)head * R * a.chunks * (2 + kHD), 0, (int)((size_t)R * a.chunks * stride), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.part + (size_t)grp * R * a.chunks * (2 + kHD), 0, (int)((size_t)R * a.chunks * stride), 0x00020000);
     for (int i = tid; i < R * a.chunks; i += NT) {
         ml[2 * i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, i * stride, 0, /*sc0|sc1*/ 17));
         ml[2 * i + 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, i * stride + 4, 0, 17));
@@ -326,20 +330,13 @@ void set_attention_fast_target(int wgs) { g_attn_target_wgs = wgs >= 32 && wgs <
 static int g_attn_waves = 0;  // 0: by the chunk's length; tuning: tce_w4a16_set_debug_mode(2900 + 4 / 8 / 16)
 void set_attention_fast_waves(int nw) { g_attn_waves = (nw == 4 || nw == 8 || nw == 16) ? nw : 0; }
 
-static void pick_chunk(int heads, int keys, int *chunk_out, int *waves_out, int kv_heads = 0) {
+static int g_attn_fuse = 0;  // tuning: query heads per workgroup for grouped-query attention (0: the rule; 1, 2, 4)
+void set_attention_fast_fuse(int r) { g_attn_fuse = (r == 1 || r == 2 || r == 4) ? r : 0; }
+
+// `heads` here = workgroup groups (query heads / heads per workgroup)
+static void pick_chunk(int heads, int keys, int *chunk_out, int *waves_out) {
     int chunk;
-    if (kv_heads > 0 && kv_heads < heads && g_attn_target_wgs == 0) {
-        // grouped queries: kv_heads x chunks workgroups, each streaming its chunk once for all of its query heads.  One chunk per head and
-        // no combine while the chunk is short; then chunks of >= 128 keys, sixteen at most (what the combine reads in one batch)
-        chunk = keys <= 256 ? keys : (keys + 15) / 16;
-        if (chunk < 128 && keys > 256) chunk = 128;
-        chunk = (chunk + 15) / 16 * 16;
-        *chunk_out = chunk;
-        *waves_out = 4;
-        return;
-    }
     if (g_attn_target_wgs > 0) {
-        if (kv_heads > 0) heads = kv_heads;
         const int target_chunks = heads >= g_attn_target_wgs ? 1 : g_attn_target_wgs / heads;
         chunk = (keys + target_chunks - 1) / target_chunks;
         if (chunk < 64) chunk = 64;
@@ -364,8 +361,18 @@ static void pick_chunk(int heads, int keys, int *chunk_out, int *waves_out, int 
 }
 
 // the cut launch_attention_decode_fast would use for `keys` keys (no HIP call)
+// Query heads per workgroup for `rep` query heads per key / value head.  Measured (scripts/attention_gqa_sweep.py, 32 over 8 heads): the step is
+// bound by latency and by the softmax / weighted-sum arithmetic per (query head, key), not by the cache bytes, so fusing the four query
+// heads of a key / value head into one workgroup (a quarter of the bytes, a quarter of the workgroups, four times the arithmetic each) is
+// SLOWER than one query head per workgroup reading the shared rows: 8.3 / 13.9 / 20.0 us against 4.6 / 7.9 / 11.9 at 128 / 512 / 2048 keys.
+static int pick_fuse(int rep) {
+    if (g_attn_fuse && rep % g_attn_fuse == 0) return g_attn_fuse;
+    return 1;
+}
+
 void describe_attention_decode_fast(int heads, int keys, int *chunk, int *chunks, int *waves, int kv_heads) {
-    pick_chunk(heads, keys, chunk, waves, kv_heads);
+    const int rep = kv_heads > 0 ? heads / kv_heads : 1;
+    pick_chunk(heads / pick_fuse(rep), keys, chunk, waves);
     *chunks = (keys + *chunk - 1) / *chunk;
 }
 
@@ -381,7 +388,7 @@ int launch_attention_decode_fast(const void *qkv, void *kc, void *vc, const void
                                  int heads, int kv_heads, int hd, int max_keys, int pos, unsigned short alpha_bits, hipStream_t stream, hipError_t *hip_err) {
     if (hd != kHD || kv_heads <= 0 || heads % kv_heads != 0) return TCE_ERR_UNSUPPORTED_SHAPE;
     const int rep = heads / kv_heads;
-    if (rep != 1 && rep != 2 && rep != 4) return TCE_ERR_UNSUPPORTED_SHAPE;
+
     FastAttnArgs a{};
     a.qkv = static_cast<const half_t *>(qkv);
     a.kc = static_cast<half_t *>(kc);
@@ -395,22 +402,24 @@ int launch_attention_decode_fast(const void *qkv, void *kc, void *vc, const void
     a.part = reinterpret_cast<float *>(static_cast<unsigned char *>(workspace) + cnt_bytes);
     a.heads = heads;
     a.kv_heads = kv_heads;
+    a.rep = rep;
+    const int fuse = pick_fuse(rep);
     a.hd = hd;
     a.max_keys = max_keys;
     a.pos = pos;
     a.keys = pos + 1;
     int nw = 4;
-    pick_chunk(heads, a.keys, &a.chunk, &nw, kv_heads);
+    pick_chunk(heads / fuse, a.keys, &a.chunk, &nw);
     a.chunks = (a.keys + a.chunk - 1) / a.chunk;
     if (a.chunks > 1024) return TCE_ERR_UNSUPPORTED_SHAPE;  // (the combine's LDS image; unreachable with the fitted rule below 500k keys)
     half_t ah;
     __builtin_memcpy(&ah, &alpha_bits, 2);
     a.alpha = (float)ah;
-    const dim3 grid(kv_heads * a.chunks);
+    const dim3 grid((heads / fuse) * a.chunks);
     auto go = [&](auto has_mask) {
         constexpr bool MK = decltype(has_mask)::value;
-        if (rep == 4) hipLaunchKernelGGL((attn_decode_fast_kernel<MK, 4, 4>), grid, dim3(256), 0, stream, a);
-        else if (rep == 2) hipLaunchKernelGGL((attn_decode_fast_kernel<MK, 4, 2>), grid, dim3(256), 0, stream, a);
+        if (fuse == 4) hipLaunchKernelGGL((attn_decode_fast_kernel<MK, 4, 4>), grid, dim3(256), 0, stream, a);
+        else if (fuse == 2) hipLaunchKernelGGL((attn_decode_fast_kernel<MK, 4, 2>), grid, dim3(256), 0, stream, a);
         else if (nw == 16) hipLaunchKernelGGL((attn_decode_fast_kernel<MK, 16, 1>), grid, dim3(1024), 0, stream, a);
         else if (nw == 8) hipLaunchKernelGGL((attn_decode_fast_kernel<MK, 8, 1>), grid, dim3(512), 0, stream, a);
         else hipLaunchKernelGGL((attn_decode_fast_kernel<MK, 4, 1>), grid, dim3(256), 0, stream, a);

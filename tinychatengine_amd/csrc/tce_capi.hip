@@ -125,6 +125,10 @@ int tce_w4a16_set_debug_mode(int mode) {
         tce::set_gemv_ovl_config((mode - 50000) % 100, (mode - 50000) / 100);
         return TCE_OK;
     }
+    if (mode >= 2920 && mode <= 2924) {  // fast attention step, grouped queries: query heads per workgroup (2920: the rule; 2921 / 2922 / 2924)
+        tce::set_attention_fast_fuse(mode - 2920);
+        return TCE_OK;
+    }
     if (mode >= 2900 && mode <= 2916) {  // fast attention step: waves per workgroup (2900: by the chunk length, the default; 2904 / 2908 / 2916)
         tce::set_attention_fast_waves(mode - 2900);
         return TCE_OK;
@@ -664,7 +668,7 @@ int tce_attention_decode_describe_gqa(int heads, int kv_heads, int keys, char *b
     if (!buf || buf_len <= 0 || heads <= 0 || kv_heads <= 0 || heads % kv_heads != 0 || keys <= 0) return fail(TCE_ERR_BAD_ARG, "tce_attention_decode_describe: bad argument");
     int chunk = 0, chunks = 0, waves = 0;
     tce::describe_attention_decode_fast(heads, keys, &chunk, &chunks, &waves, kv_heads);
-    std::snprintf(buf, (size_t)buf_len, "chunks=%d keys-per-chunk=%d waves=%d workgroups=%d combine=%s", chunks, chunk, waves, kv_heads * chunks, chunks > 1 ? "yes" : "no");
+    std::snprintf(buf, (size_t)buf_len, "chunks=%d keys-per-chunk=%d waves=%d workgroups=%d combine=%s", chunks, chunk, waves, heads * chunks, chunks > 1 ? "yes" : "no");
     return TCE_OK;
 }
 
@@ -679,8 +683,6 @@ int tce_attention_decode_step_gqa_f16(const void *qkv, void *kc, void *vc, const
     if ((cosv == nullptr) != (sinv == nullptr)) return fail(TCE_ERR_BAD_ARG, "tce_attention_decode_step_f16: cos and sin tables come together");
     if (heads <= 0 || max_keys <= 0 || pos < 0 || pos >= max_keys) return fail(TCE_ERR_BAD_ARG, "tce_attention_decode_step_f16: need heads > 0 and 0 <= pos < max_keys");
     if (kv_heads <= 0 || heads % kv_heads != 0) return fail(TCE_ERR_BAD_ARG, "tce_attention_decode_step_gqa_f16: %d query heads do not divide over %d key / value heads", heads, kv_heads);
-    if (heads / kv_heads != 1 && heads / kv_heads != 2 && heads / kv_heads != 4)
-        return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_attention_decode_step_gqa_f16: %d query heads per key / value head (1, 2 or 4)", heads / kv_heads);
     if (hd != 128) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_attention_decode_step_f16: head_dim %d (128 only: Llama's)", hd);
     for (const void *p : {qkv, (const void *)kc, (const void *)vc, cosv, sinv})
         if (reinterpret_cast<uintptr_t>(p) & 15) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_attention_decode_step_f16: 16-byte aligned pointers");

@@ -161,6 +161,7 @@ int launch_allgather_f16(Comm *c, int slot, const void *src_slice, void *dst_ful
 // attention_fast.hip
 void set_attention_fast_target(int wgs);
 void set_attention_fast_waves(int nw);
+void set_attention_fast_fuse(int r);
 void describe_attention_decode_fast(int heads, int keys, int *chunk, int *chunks, int *waves, int kv_heads = 0);
 size_t attention_decode_workspace_bytes(int heads, int max_keys, int hd);
 int launch_attention_decode_fast(const void *qkv, void *kc, void *vc, const void *cosv, const void *sinv, const void *mask, void *out, void *workspace,
