@@ -47,6 +47,8 @@ def parse_args():
     ap.add_argument("--roofline-only", action="store_true", help="run only the dominant-kernel loop (for rocprofv3)")
     ap.add_argument("--roofline-launches", type=int, default=256)
     ap.add_argument("--roofline-eager", action="store_true", help="roofline leg without graph capture (for rocprofv3 PMC passes)")
+    ap.add_argument("--shapes-only", action="store_true", help="run only the per-launch-shape legs (every launch shape of the token + the attention step) and print them: the "
+                    "command scripts/profile_r3.sh traces with rocprofv3 (graph-replayed; with --roofline-eager issued eagerly for the PMC passes)")
     ap.add_argument("--no-extras", action="store_true", help="skip the short prefill-GEMM / W8A8 legs (BASELINE configs 3 and 4) reported under \"other_configs\"")
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (RCCL init, gathers, graph capture) even with one rank")
     ap.add_argument("--no-graph", action="store_true", help="N > 1: issue the token eagerly instead of capturing GEMVs + gathers into one graph")
@@ -266,6 +268,83 @@ def launch_shape_table(dl, torch, launches: int = 128):
     rows.append({"launch": f"{d.N} x {d.K} (lm_head)", "us": round(us, 2), "GBs": round(b / us / 1e3, 1), "frac_of_8TBs": round(b / us / 1e3 / HBM_PEAK_GBS, 3),
                  "bytes": b, "timing": "interleaved with 3 gate+up launches (cache flush), their time subtracted"})
     return rows
+
+
+def shapes_only_leg(dl, torch, dev, shape, eager: bool):
+    """Every launch shape of the token and the attention step on their own, for rocprofv3 (scripts/profile_r3.sh): graph-replayed exactly
+    like `other_configs.decode_launch_shapes` of the bench line, or (eager) as plain launches for the PMC passes, which serialise kernels."""
+    import ctypes as C
+    import numpy as np
+    from tinychatengine_amd import capi
+    from tinychatengine_amd.attention_ops import DecodeAttention
+    L = capi.lib()
+    out = {"mode": "eager launches" if eager else "hipGraph replays (the bench line's method)"}
+    if eager:
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rows = []
+        for w in range(4):
+            groups = [dl.block_launches(li)[w] for li in range(dl.n_layers)]
+            arrs = [(capi.W4A16Desc * len(g))(*g) for g in groups]
+            for i in range(96):
+                capi.check(L.tce_w4a16_forward_group(arrs[i % len(arrs)], len(groups[0]), st))
+            torch.cuda.synchronize()
+            rows.append({"launch": "+".join(str(d.N) for d in groups[0]) + f" x {groups[0][0].K}", "eager_launches": 96})
+        lm = (capi.W4A16Desc * 1)(dl.lm_head.desc(dl.x, dl.logits))
+        gu = [dl.block_launches(li)[2] for li in range(dl.n_layers)]
+        ga = [(capi.W4A16Desc * len(g))(*g) for g in gu]
+        for i in range(12):
+            capi.check(L.tce_w4a16_forward_group(lm, 1, st))
+            for j in range(3):  # > 256 MB of other weights between two lm_head launches
+                capi.check(L.tce_w4a16_forward_group(ga[(3 * i + j) % len(ga)], len(gu[0]), st))
+        torch.cuda.synchronize()
+        rows.append({"launch": f"{dl.lm_head.out_features} x {dl.lm_head.in_features} (lm_head)", "eager_launches": 12})
+        out["linears"] = rows
+    else:
+        out["linears"] = launch_shape_table(dl, torch)
+    # the attention step: multi-head (the baseline-named model) and 32 query heads over 8 key / value heads (Llama-3-8B), caches rotating through > 256 MB
+    heads = shape.hidden // 128
+    att_rows = []
+    for (h, kvh) in ((heads, heads), (heads, max(1, heads // 4))):
+        for ctx in (512, 2048):
+            bytes_ = 2 * kvh * ctx * 128 * 2
+            nsets = min(96, max(4, int(3.2e8 // bytes_) + 1))
+            cos = torch.randn(ctx + 1, 128, device=dev).half()
+            sin = torch.randn(ctx + 1, 128, device=dev).half()
+            atts = [DecodeAttention(h, 128, ctx, dev, cos, sin, kv_heads=kvh) for _ in range(nsets)]
+            for a_ in atts:
+                a_.k_cache.normal_(0, 0.8)
+                a_.v_cache.normal_(0, 0.8)
+            qkv = torch.randn((h + 2 * kvh) * 128, device=dev).half()
+            oo = torch.empty(h, 128, dtype=torch.float16, device=dev)
+            n = max(32, nsets)
+
+            def step(i):
+                atts[i % nsets].step(qkv, ctx - 1, out=oo)
+            if eager:
+                for i in range(n):
+                    step(i)
+                torch.cuda.synchronize()
+                us = None
+            else:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for i in range(n):
+                        step(i)
+                g.replay()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    g.replay()
+                e1.record()
+                torch.cuda.synchronize()
+                us = round(e0.elapsed_time(e1) * 1e3 / (3 * n), 2)
+                del g
+            att_rows.append({"launch": f"attention step {h} query / {kvh} kv heads, {ctx} keys", "us": us, "kv_cache_bytes": bytes_, "launches": n,
+                             "GBs": None if us is None else round(bytes_ / us / 1e3, 1), "cut": capi.describe_attention_step(h, ctx, kvh)})
+            del atts
+    out["attention_step"] = att_rows
+    return out
 
 
 def whole_token_leg(torch, dev, shape, dl):
@@ -516,6 +595,11 @@ def main():
         r = roofline_leg(dl, torch, args.roofline_launches, eager=args.roofline_eager)
         if rank == 0:
             print(json.dumps({"roofline": r}))
+        return
+    if args.shapes_only:
+        r = shapes_only_leg(dl, torch, dev, shape, eager=args.roofline_eager)
+        if rank == 0:
+            print(json.dumps({"decode_launch_shapes": r}))
         return
 
     # ---- the step ----
