@@ -37,9 +37,11 @@ def parse_args():
     ap.add_argument("--workload", default="baseline-named", choices=["baseline-named", "llama3-8b", "llama2-13b", "tiny"])
     ap.add_argument("--layers", type=int, default=None, help="override the number of transformer blocks (debug only)")
     ap.add_argument("--ungrouped", action="store_true", help="one launch per linear, as the reference issues them")
-    ap.add_argument("--gathers-per-block", type=int, default=1, choices=[1, 4])
-    ap.add_argument("--gather", default="peer", choices=["peer", "rccl"],
-                    help="N > 1: how the ranks' output slices are joined -- peer: tce_allgather_f16 (one peer-write kernel per exchange over xGMI, csrc/comm.hip); rccl: torch.distributed all_gather_into_tensor")
+    ap.add_argument("--gathers-per-block", type=int, default=0, choices=[0, 1, 4], help="N > 1: 0 (default) = time both the north-star definition (1) and the dependency-faithful form (4)")
+    ap.add_argument("--gather", default="all", choices=["all", "peer", "rccl"],
+                    help="N > 1: how the ranks' output slices are joined -- peer: tce_allgather_f16 (one peer-write kernel per exchange over xGMI, csrc/comm.hip); rccl: torch.distributed "
+                         "all_gather_into_tensor; all (default): both are timed in the same run (config.gather_variants), the headline is the faster one-gather-per-block variant")
+    ap.add_argument("--no-projection", action="store_true", help="N = 1: skip other_configs.projected_scaling (this GPU timing one rank's N/P-row shards for P = 2, 4, 8)")
     ap.add_argument("--issue", default="auto", choices=["auto", "graph", "token"],
                     help="N = 1: graph = one hipGraph of 129 launches per token (stream order); token = ONE persistent kernel per token, the linears' data "
                          "flow ordered by tagged output words (TCE_PLAN_TAGGED); auto = both are verified against each other and timed, the faster one is the step")
@@ -347,6 +349,53 @@ def shapes_only_leg(dl, torch, dev, shape, eager: bool):
     return out
 
 
+def projected_scaling_leg(torch, dev, G):
+    """"if only one GPU is visible, report P > 1 as not measurable here plus the measured per-shard kernel times at N/P shapes".
+    This GPU plays rank 0 of P = 2, 4, 8: all of one token's linears at N/P rows (tce_w4a16_shard's row ranges; weights 1/P of the model, still
+    more than the memory-side cache for the 7B-class sets at P <= 8) as one stream-ordered hipGraph -- the compute side of a sharded token,
+    MEASURED.  The exchange side is NOT measurable on one GPU: the projection adds gathers x an ASSUMED cost per gather (stated) and is
+    labelled as a projection; nothing here is a scaling measurement."""
+    from tinychatengine_amd.decode import SHAPES, DecodeLinears
+    st = torch.cuda.current_stream().cuda_stream
+    assumed = {"peer_write_gather_us": 3.0, "rccl_gather_us": 12.0}
+    out = {"label": "PROJECTION from one GPU: per-rank shard compute is measured, the gather cost is assumed",
+           "assumed_gather_cost_us": dict(assumed, source="MI355X_MICROARCH.md price list, allgather row (8-32 KB all-to-all inside one device: 2.4-4.2 us; an xGMI hop is not in it); "
+                                                          "RCCL: order of 10 us per small collective"),
+           "models": {}}
+    for key in ("baseline-named", "llama3-8b", "llama2-13b"):
+        shape = SHAPES[key]
+        rows = {}
+        for P in (1, 2, 4, 8):
+            try:
+                dlp = DecodeLinears(shape, device=dev, group_size=G, rank=0, world=P, m=1)
+                plan = dlp.make_plan()
+                for _ in range(5):
+                    plan.launch(st)
+                torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(30):
+                    plan.launch(st)
+                b.record()
+                torch.cuda.synchronize()
+                ms = a.elapsed_time(b) / 30
+                n1, n4 = shape.layers + 1, shape.layers * (3 + len(shape.qkv)) + 1  # exchanges per token: 1 per block + logits; qkv slices, o, gate, up, down per block + logits
+                row = {"shard_compute_ms_per_token": round(ms, 4), "shard_weight_bytes": dlp.token_bytes(), "launches": plan.n_launches}
+                if P > 1:
+                    for gname, gus in assumed.items():
+                        row[f"projected_tokens_per_s_1_gather_per_block_{gname[:-10]}"] = round(1e3 / (ms + n1 * gus * 1e-3), 1)
+                        row[f"projected_tokens_per_s_4_gathers_per_block_{gname[:-10]}"] = round(1e3 / (ms + n4 * gus * 1e-3), 1)
+                else:
+                    row["tokens_per_s"] = round(1e3 / ms, 1)
+                rows[f"P={P}"] = row
+                del plan, dlp
+                torch.cuda.empty_cache()
+            except Exception as e:  # noqa: BLE001
+                rows[f"P={P}"] = {"error": f"{type(e).__name__}: {e}"}
+        out["models"][shape.name] = rows
+    return out
+
+
 def whole_token_leg(torch, dev, shape, dl):
     """One decode token through 32 complete decoder layers on this library's calls (tinychatengine_amd/decoder_block.py): per layer
     [RMSNorm + q/k/v] [RoPE + KV append + attention, one launch] [o_proj + residual] [RMSNorm + gate/up + SiLU*mul] [down_proj + residual],
@@ -545,7 +594,8 @@ def main():
         os.environ["TCE_FORCE_GATHER_BUFFERS"] = "1"
     dl = DecodeLinears(shape, device=dev, group_size=G, rank=rank, world=world, m=1, layers=args.layers,
                        dataflow=(world == 1 and not args.ungrouped and shape.qkv[0] >= shape.hidden))
-    if dist is not None and args.gather == "peer":
+    want_peer = args.gather in ("all", "peer")
+    if dist is not None and want_peer:
         # The peer-write gather needs every rank's window mapped into every other rank (hipIpc) and one exchange to come back right.
         # Every step is agreed on by ALL ranks (a rank that failed alone would leave the others waiting); otherwise: RCCL.
         def agree(ok: bool) -> bool:
@@ -587,7 +637,8 @@ def main():
                 print(f"[bench] rank {rank}: peer-write gather not available ({why}); using RCCL all-gathers", file=sys.stderr)
             elif rank == 0:
                 print("[bench] peer-write gather not available on another rank; using RCCL all-gathers", file=sys.stderr)
-            args.gather = "rccl"
+            if args.gather == "peer":
+                args.gather = "rccl"
     torch.cuda.synchronize()
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -676,24 +727,24 @@ def main():
     else:
         n_launches = dl.n_layers * 4 + 1
 
-        def build_dist_step():
-            """The distributed token as a callable + how it is issued (called again if the peer-write gather has to be given up)."""
+        def build_dist_step(gpb, gather):
+            """The distributed token (gpb gathers per block, joined by `gather`) as a callable + how it is issued."""
             graph = None
             try:  # capture GEMVs + RCCL all-gathers of one token into one graph; fall back to eager issue if capture fails
-                if args.no_graph or (args.backend != "nccl" and args.gather != "peer"):
+                if args.no_graph or (args.backend != "nccl" and gather != "peer"):
                     raise RuntimeError("graph capture not requested / not available with this backend")
-                # the ranks meet before anything that exchanges data runs: a peer-write gather waits ~0.4 s for the other ranks' slices and then
-                # flags the communicator, and building the shards / capturing the graph takes the ranks seconds, not all the same number
+                # the ranks meet before anything that exchanges data runs: a peer-write gather waits a bounded time (2 s) for the other ranks' slices and
+                # then flags the communicator, and building the shards / capturing the graph takes the ranks seconds, not all the same number
                 dist.barrier()
                 torch.cuda.synchronize()
                 for _ in range(3):
-                    dl.run_token_distributed(args.gathers_per_block, gather=args.gather)
+                    dl.run_token_distributed(gpb, gather=gather)
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):  # the RCCL watchdog thread may call HIP APIs meanwhile
-                    dl.run_token_distributed(args.gathers_per_block, gather=args.gather)
+                    dl.run_token_distributed(gpb, gather=gather)
                 step = graph.replay
-                mode = f"one graph replay per token (GEMVs + {'peer-write' if args.gather == 'peer' else 'RCCL'} all-gathers captured)"
+                mode = f"one graph replay per token (GEMVs + {'peer-write' if gather == 'peer' else 'RCCL'} all-gathers captured)"
             except Exception as e:  # noqa: BLE001
                 if rank == 0:
                     print(f"[bench] graph capture of the distributed token failed ({type(e).__name__}: {e}); issuing eagerly", file=sys.stderr)
@@ -704,11 +755,9 @@ def main():
                 torch.cuda.set_stream(torch.cuda.default_stream())
                 capi.lib().tce_reset_last_error()
                 torch.cuda.synchronize()
-                step = lambda: dl.run_token_distributed(args.gathers_per_block, gather=args.gather)
+                step = lambda: dl.run_token_distributed(gpb, gather=gather)
                 mode = "eager issue per token"
             return step, mode
-
-        step, mode = build_dist_step()
 
     def fence():
         if dist is not None:
@@ -736,18 +785,52 @@ def main():
             wall = float(tw.item())
         return wall, e0.elapsed_time(e1)
 
-    wall, ev_ms_total = timed_run(step)
-    if dist is not None and getattr(dl, "comm", None) is not None:
-        # a peer-write gather that timed out (a rank trailing by more than ~0.4 s, a window that stopped being reachable) voids the
-        # timing; all ranks agree on that and the run is repeated over RCCL all-gathers instead of ending without a line
-        bad = torch.tensor([1 if dl.comm.status() != 0 else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
-        if int(bad.item()):
-            if rank == 0:
-                print("[bench] tce_comm_status != 0 on some rank (a peer-write gather timed out): repeating the run with RCCL all-gathers", file=sys.stderr)
-            args.gather = "rccl"
-            step, mode = build_dist_step()
-            wall, ev_ms_total = timed_run(step)
+    gather_variants = None
+    if dist is None:
+        wall, ev_ms_total = timed_run(step)
+    else:
+        # Every way the ranks' slices can be joined, in ONE run (the first session on an 8-GPU node should not have to be repeated four
+        # times): {peer-write kernel, RCCL} x {1 gather per block -- the north-star definition --, 4 -- the dependency-faithful form}.
+        # The headline is the faster one-gather-per-block variant; all of them are under config.gather_variants.
+        gathers = [g for g in (("peer", "rccl") if args.gather == "all" else (args.gather,)) if g != "peer" or getattr(dl, "comm", None) is not None]
+        gpbs = (1, 4) if args.gathers_per_block == 0 else (args.gathers_per_block,)
+        gather_variants, runs = {}, []
+        for gpb in gpbs:
+            for gth in gathers:
+                name = f"{'peer-write kernel (tce_allgather_f16)' if gth == 'peer' else 'RCCL all_gather_into_tensor'}, {gpb} gather{'s' if gpb > 1 else ''} per block"
+                try:
+                    step_v, mode_v = build_dist_step(gpb, gth)
+                    wall_v, ev_v = timed_run(step_v)
+                    ok = True
+                    if gth == "peer":
+                        # a peer-write gather that timed out (a rank trailing by more than the bound, a window that stopped being reachable) voids the
+                        # timing; all ranks agree on that, the communicator is re-armed for the next variant
+                        bad = torch.tensor([1 if dl.comm.status() != 0 else 0], dtype=torch.int32, device=dev)
+                        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+                        if int(bad.item()):
+                            ok = False
+                            dist.barrier()
+                            torch.cuda.synchronize()
+                            dl.comm.reset()
+                            dist.barrier()
+                    gather_variants[name] = ({"ms_per_token": round(wall_v * 1e3 / args.steps, 4), "tokens_per_s": round(args.steps / wall_v, 1), "issue": mode_v} if ok
+                                             else {"rejected": "tce_comm_status != 0 on some rank: a peer-write gather timed out"})
+                    if ok:
+                        runs.append((gpb, gth, wall_v, ev_v, mode_v, name))
+                except Exception as e:  # noqa: BLE001 -- one variant never takes the others down with it
+                    gather_variants[name] = {"rejected": f"{type(e).__name__}: {e}"}
+                    try:
+                        torch.cuda.set_stream(torch.cuda.default_stream())
+                        capi.lib().tce_reset_last_error()
+                        torch.cuda.synchronize()
+                    except Exception:  # noqa: BLE001
+                        pass
+        if not runs:
+            raise SystemExit("no gather variant completed: " + json.dumps(gather_variants))
+        one = [r for r in runs if r[0] == min(g for g, *_ in runs)]
+        gpb_h, gth_h, wall, ev_ms_total, mode, name_h = min(one, key=lambda r: r[2])
+        args.gathers_per_block, args.gather = gpb_h, gth_h
+        gather_variants["headline"] = name_h
     ms_per_step = wall * 1e3 / args.steps
     ev_ms_per_step = ev_ms_total / args.steps
     tok_s = args.steps / wall
@@ -780,6 +863,11 @@ def main():
             extras["decode_launch_shapes"] = launch_shape_table(dl, torch)
         except Exception as e:  # noqa: BLE001
             extras["decode_launch_shapes"] = {"error": f"{type(e).__name__}: {e}"}
+        if args.workload == "baseline-named" and not args.no_projection:
+            try:  # SURVEY 8e on one GPU: per-rank shard compute at N/P rows, measured; the exchange side assumed and labelled
+                extras["projected_scaling"] = projected_scaling_leg(torch, dev, G)
+            except Exception as e:  # noqa: BLE001
+                extras["projected_scaling"] = {"error": f"{type(e).__name__}: {e}"}
         if args.workload == "baseline-named":
             try:  # the callers either side of the path: a WHOLE decode token -- norms, RoPE, KV append, attention, residuals -- in 5 launches per layer
                 extras["decode_with_attention"] = whole_token_leg(torch, dev, shape, dl)
@@ -828,7 +916,8 @@ def main():
                        "parallelism": (f"tp{world} column-sharded, {args.gathers_per_block} "
                                        + ("peer-write all-gather(s) (tce_allgather_f16)" if args.gather == "peer" else f"{'RCCL' if args.backend == 'nccl' else args.backend} all-gather(s)")
                                        + " per block") if world > 1 else "single GPU",
-                       "issue": mode, **({"issue_variants": variants} if variants else {}), "grouped_launches": not args.ungrouped,
+                       "issue": mode, **({"issue_variants": variants} if variants else {}), **({"gather_variants": gather_variants} if gather_variants else {}),
+                       "grouped_launches": not args.ungrouped,
                        "activations": ("the linears feed each other as in the decoder (x -> qkv; o reads the q slice; o -> gate/up; gate -> down; down -> next block; "
                                        "last down -> lm_head); W ~ N(0, 1/K)") if dl.dataflow else "every linear reads its own fixed N(0,1) vector; W ~ N(0, 0.02^2)",
                        "algorithmic_bytes_per_token": token_bytes_full},

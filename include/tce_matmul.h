@@ -323,8 +323,16 @@ TCE_API void tce_plan_destroy(tce_plan *plan);
  *   tce_comm_create   rank's window for vectors of up to max_vector_elems halves, `slots` independent exchange slots
  *   tce_comm_export / tce_comm_connect   the host all-gathers the 64-byte handles (MPI, torch.distributed, a file ...) and hands every
  *                     rank the table [world][64]; tce_comm_connect_local instead when all ranks live in one process (tests)
- *   tce_comm_status   synchronous: 1 if a wait ever timed out (~0.4 s: a rank never arrived), 0 if not, negative on error; a flagged
- *                     communicator's later exchanges do not wait any more (their outputs are void): one lost exchange costs 0.4 s, not 0.4 s each
+ *                     (ONE host thread driving several devices, the reference's host shape -- Int4llamaForCausalLM.cu:40-44: create each rank's
+ *                     communicator with that rank's device current; tce_comm_connect_local enables peer access between the devices, and
+ *                     tce_allgather_f16 / tce_comm_status / tce_comm_reset make the communicator's device current for their own calls and restore
+ *                     the caller's; the stream passed to tce_allgather_f16 must be a stream of the communicator's device)
+ *   tce_comm_status   synchronous: 1 if a wait ever timed out (a rank never arrived within the bound: 2 s, tce_comm_set_timeout_ms), 0 if not,
+ *                     negative on error; a flagged communicator's later exchanges do not wait any more (their outputs are void): one lost exchange
+ *                     costs one bound, not one bound each.  A host that uses the outputs checks the status (per token, or per batch of tokens).
+ *   tce_comm_reset    re-arms a flagged communicator.  Every rank calls it after the host made sure no exchange is in flight anywhere
+ *                     (barrier + device synchronisation); the per-slot epochs are kept -- every rank's gather kernels ran to their end.
+ *   tce_comm_export refuses a window that is not fine-grained memory (the flags are polled across the link; TCE_ERR_UNSUPPORTED_SHAPE).
  * Prefill (M >= 17) moves megabytes per exchange: use RCCL there (ncclAllGather; this repository's host code does, through
  * torch.distributed) -- the peer-write kernel is a single workgroup. */
 typedef struct tce_comm tce_comm;
@@ -337,6 +345,9 @@ TCE_API int tce_comm_connect(tce_comm *comm, const void *handles /* [world][64],
 TCE_API int tce_comm_connect_local(tce_comm *comm, tce_comm *const *all_ranks /* [world] */);
 TCE_API int tce_allgather_f16(tce_comm *comm, int slot, const void *src_slice, void *dst_full, int n_total, void *stream);
 TCE_API int tce_comm_status(tce_comm *comm);
+TCE_API int tce_comm_set_timeout_ms(tce_comm *comm, int milliseconds); /* 1 .. 600000; takes effect for exchanges enqueued (or captured) afterwards */
+TCE_API int tce_comm_reset(tce_comm *comm);
+TCE_API int tce_comm_device(const tce_comm *comm);
 TCE_API void tce_comm_destroy(tce_comm *comm);
 
 /* ---- memory / sync helpers: what the L2 wrappers need from the runtime ----

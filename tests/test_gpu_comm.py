@@ -34,7 +34,62 @@ def test_shard_descriptor_arithmetic_needs_no_gpu():
     assert capi.lib().tce_w4a16_shard(C.byref(full), 8, 8, C.byref(sh)) == capi.TCE_ERR_BAD_ARG
 
 
+def test_comm_argument_checks_need_no_gpu():
+    """What the multi-GPU entry points refuse before they touch the device (CPU: no HIP call is reached)."""
+    from tinychatengine_amd import capi
+    L = capi.lib()
+    h = C.c_void_p()
+    assert L.tce_comm_create(2, 2, 4096, 4, C.byref(h)) == capi.TCE_ERR_BAD_ARG      # rank >= world
+    assert L.tce_comm_create(0, 9, 4096, 4, C.byref(h)) == capi.TCE_ERR_BAD_ARG      # more than TCE_COMM_MAX_RANKS
+    assert L.tce_comm_create(0, 2, 0, 4, C.byref(h)) == capi.TCE_ERR_BAD_ARG         # empty vectors
+    assert L.tce_comm_create(0, 2, 4096, 0, C.byref(h)) == capi.TCE_ERR_BAD_ARG      # no slots
+    assert L.tce_comm_create(0, 2, 4096, 4, None) == capi.TCE_ERR_BAD_ARG
+    for fn in (L.tce_comm_status, L.tce_comm_reset, L.tce_comm_device):
+        assert fn(None) == capi.TCE_ERR_BAD_ARG
+    assert L.tce_comm_set_timeout_ms(None, 100) == capi.TCE_ERR_BAD_ARG
+    assert L.tce_comm_export(None, None) == capi.TCE_ERR_BAD_ARG
+    assert L.tce_comm_connect(None, None) == capi.TCE_ERR_BAD_ARG
+    assert L.tce_comm_connect_local(None, None) == capi.TCE_ERR_BAD_ARG
+    assert L.tce_allgather_f16(None, 0, None, None, 16, None) == capi.TCE_ERR_BAD_ARG
+
+
 gpu = pytest.mark.gpu
+
+
+@gpu
+def test_comm_timeout_reset_and_device():
+    """A lone rank of a 2-rank group: its exchange gives up after the (shortened) bound and flags the communicator; tce_comm_reset re-arms it."""
+    from tinychatengine_amd import capi
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda:0")
+    a, b = capi.Comm(0, 2, 1024, slots=2), capi.Comm(1, 2, 1024, slots=2)
+    capi.Comm.connect_local([a, b])
+    assert a.device == 0 and b.device == 0
+    a.set_timeout_ms(50)
+    with pytest.raises(capi.TceError):
+        a.set_timeout_ms(0)
+    src = torch.ones(512, dtype=torch.float16, device=dev)
+    dst = torch.zeros(1024, dtype=torch.float16, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    assert a.status() == 0
+    a.allgather(0, src.data_ptr(), dst.data_ptr(), 1024, st)   # rank 1 never sends
+    torch.cuda.synchronize()
+    assert a.status() == 1
+    a.reset()
+    assert a.status() == 0
+    # both ranks now: rank 1 catches up on slot 0 (its first exchange there), then a complete exchange works again
+    s1 = torch.cuda.Stream()
+    src1 = torch.full((512,), 2.0, dtype=torch.float16, device=dev)
+    dst1 = torch.zeros(1024, dtype=torch.float16, device=dev)
+    b.allgather(0, src1.data_ptr(), dst1.data_ptr(), 1024, s1.cuda_stream)   # epoch 1 of slot 0 on rank 1: rank 0's flag of epoch 1 is already there
+    torch.cuda.synchronize()
+    a.allgather(0, src.data_ptr(), dst.data_ptr(), 1024, st)
+    b.allgather(0, src1.data_ptr(), dst1.data_ptr(), 1024, s1.cuda_stream)
+    torch.cuda.synchronize()
+    assert a.status() == 0 and b.status() == 0
+    want = torch.cat([torch.ones(512), torch.full((512,), 2.0)]).to(torch.float16).to(dev)
+    assert torch.equal(dst, want) and torch.equal(dst1, want)
+    a.close(); b.close()
 
 
 def _sharded_forward(lin, x, rank, world, stream):

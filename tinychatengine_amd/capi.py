@@ -30,7 +30,7 @@ TCE_OUT_INT8, TCE_OUT_FP32 = 0, 1
 # every symbol include/tce_matmul.h declares (tests/test_boundary.py checks the .so exports exactly these)
 EXPORTS = [
     "tce_w4a16_forward", "tce_w4a16_prepack_bytes", "tce_w4a16_prepack", "tce_w4a16_gemm_scratch_bytes", "tce_w4a16_describe_dispatch", "tce_reset_last_error", "tce_bmm_f16t", "tce_rope_half", "tce_softmax_half", "tce_attention_decode_f16", "tce_attention_decode_workspace_bytes", "tce_attention_decode_describe", "tce_attention_decode_step_f16", "tce_attention_decode_step_gqa_f16", "tce_attention_decode_describe_gqa", "tce_prefetch", "tce_add_half", "tce_silu_mul_half", "tce_rmsnorm_half", "tce_w4a16_forward_group_rmsnorm", "tce_w4a16_forward_group", "tce_w4a16_check_zero_point_8", "tce_w4a16_awq_fp16acc", "tce_w4a16_awq_workspace_bytes",
-    "tce_w4a16_gemm_awq", "tce_w4a16_shard", "tce_comm_create", "tce_comm_export", "tce_comm_connect", "tce_comm_connect_local", "tce_allgather_f16", "tce_comm_status", "tce_comm_destroy", "tce_w8a8_matmul", "tce_layernorm_q", "tce_layernorm_q_w8a8_group", "tce_plan_create", "tce_plan_create_ex", "tce_plan_is_chained", "tce_plan_geometry", "tce_plan_status", "tce_plan_launch", "tce_plan_n_launches",
+    "tce_w4a16_gemm_awq", "tce_w4a16_shard", "tce_comm_create", "tce_comm_export", "tce_comm_connect", "tce_comm_connect_local", "tce_allgather_f16", "tce_comm_status", "tce_comm_set_timeout_ms", "tce_comm_reset", "tce_comm_device", "tce_comm_destroy", "tce_w8a8_matmul", "tce_layernorm_q", "tce_layernorm_q_w8a8_group", "tce_plan_create", "tce_plan_create_ex", "tce_plan_is_chained", "tce_plan_geometry", "tce_plan_status", "tce_plan_launch", "tce_plan_n_launches",
     "tce_plan_destroy", "tce_version", "tce_last_error", "tce_build_info", "tce_w4a16_set_gemv_config",
     "tce_w4a16_set_gemm_config", "tce_w4a16_algorithmic_bytes", "tce_w4a16_gemv_variant", "tce_w4a16_gemm_variant",
     "tce_w4a16_set_debug_mode", "tce_w4a16_set_debug_buffer", "tce_malloc", "tce_free", "tce_memcpy", "tce_synchronize", "tce_device_count",
@@ -117,6 +117,9 @@ def lib() -> C.CDLL:
         L.tce_comm_connect_local.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.tce_allgather_f16.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.tce_comm_status.argtypes = [C.c_void_p]
+        L.tce_comm_set_timeout_ms.argtypes = [C.c_void_p, C.c_int]
+        L.tce_comm_reset.argtypes = [C.c_void_p]
+        L.tce_comm_device.argtypes = [C.c_void_p]
         L.tce_comm_destroy.argtypes = [C.c_void_p]
         L.tce_comm_destroy.restype = None
         L.tce_layernorm_q.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
@@ -279,6 +282,17 @@ class Comm:
 
     def status(self) -> int:
         return int(lib().tce_comm_status(self.handle))
+
+    def set_timeout_ms(self, ms: int) -> None:
+        check(lib().tce_comm_set_timeout_ms(self.handle, int(ms)))
+
+    def reset(self) -> None:
+        """Re-arm after a timed-out wait (every rank, with no exchange in flight anywhere)."""
+        check(lib().tce_comm_reset(self.handle))
+
+    @property
+    def device(self) -> int:
+        return int(lib().tce_comm_device(self.handle))
 
     def close(self) -> None:
         if self.handle:

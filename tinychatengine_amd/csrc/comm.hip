@@ -10,7 +10,7 @@
 //   exchange  the kernel of rank r (a) writes its slice into EVERY rank's window -- buffer (slot, parity of the slot's epoch) at
 //             the slice's offset -- with 16-byte stores straight into peer memory, (b) after a system-scope release writes the
 //             epoch into flag (slot, parity, r) of every window, (c) waits until its own window shows all ranks' flags at this
-//             epoch (bounded: a rank that never arrives sets the status word after ~0.4 s instead of hanging the queue),
+//             epoch (bounded: a rank that never arrives sets the status word after 2 s -- tce_comm_set_timeout_ms -- instead of hanging the queue),
 //             (d) copies the complete vector from the window to an ordinary device buffer -- the next linear's activation.
 //             Epochs are counted on the device (one word per slot), so the same captured kernel node is correct on every
 //             replay; two buffers per slot are enough: a rank can start exchange e+1 (and write into peers' buffers of parity
@@ -20,6 +20,7 @@
 // repository's host code, tinychatengine_amd/decode.py); nothing here replaces it.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -33,6 +34,8 @@ constexpr int kFlagStride = 16;  // words between flags (their own 64-byte lines
 
 struct Comm {
     int rank = 0, world = 1, slots = 0;
+    int device = 0;                      // the HIP device the window lives on: launches and peer-access calls run with it current
+    unsigned long long timeout_ticks = 200000000ull;  // bound of a wait, 100 MHz ticks (2 s; tce_comm_set_timeout_ms)
     size_t vec_bytes = 0, window_bytes = 0;
     unsigned char *window = nullptr;     // this rank's window
     unsigned char *peer[kMaxRanks] = {};  // every rank's window as mapped here (peer[rank] == window)
@@ -54,6 +57,7 @@ struct GatherArgs {
     int rank, world, slot, slots;
     unsigned slice16;      // 16-byte pieces per rank's slice
     size_t vec_bytes, flags_off;
+    unsigned long long timeout_ticks;
 };
 
 __global__ __launch_bounds__(1024) void allgather_peer_kernel(const GatherArgs a) {
@@ -77,11 +81,12 @@ __global__ __launch_bounds__(1024) void allgather_peer_kernel(const GatherArgs a
     if (tid < a.world) {
         const unsigned *flag = reinterpret_cast<const unsigned *>(a.peer[a.rank] + a.flags_off) + (((size_t)a.slot * 2 + par) * kMaxRanks + tid) * kFlagStride;
         const unsigned long long t0 = wall_clock64();  // 100 MHz
-        // a communicator that is already flagged does not wait again: one lost exchange costs ~0.4 s, not 0.4 s per exchange after it
+        // a communicator that is already flagged does not wait again: one lost exchange costs one bound, not one bound per exchange after it (tce_comm_reset re-arms)
         const bool dead = __hip_atomic_load(a.epochs + a.slots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
         while (!dead && (int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
             __builtin_amdgcn_s_sleep(8);
-            if (wall_clock64() - t0 > 40000000ull) {  // ~0.4 s (100 MHz clock; a first launch may trail its peers by a code-object load): give up, flag the communicator (tce_comm_status)
+            if (wall_clock64() - t0 > a.timeout_ticks) {  // 2 s unless tce_comm_set_timeout_ms says otherwise (ranks are processes of their own: a host-side stall -- a
+                // collector pause, a code-object load -- must not void an exchange): give up, flag the communicator (tce_comm_status), tce_comm_reset re-arms it
                 __hip_atomic_store(a.epochs + a.slots, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
@@ -114,6 +119,7 @@ int comm_create(int rank, int world, int max_vector_elems, int slots, Comm **out
     c->rank = rank;
     c->world = world;
     c->slots = slots;
+    if (hipGetDevice(&c->device) != hipSuccess) c->device = 0;
     c->vec_bytes = (((size_t)max_vector_elems * 2) + 255) & ~(size_t)255;
     c->window_bytes = data_bytes(*c) + flags_bytes(*c);
     void *p = nullptr;
@@ -140,8 +146,24 @@ int comm_create(int rank, int world, int max_vector_elems, int slots, Comm **out
     return TCE_OK;
 }
 
+// RAII: make the communicator's device current for the calls below, restore the caller's afterwards
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
 int comm_export(Comm *c, void *handle64, hipError_t *he) {
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "the C ABI promises 64-byte handles");
+    // a coarse-grained window mapped by another GPU is not coherent for the flag protocol: such a window is never exported
+    // (TCE_COMM_ALLOW_COARSE=1 lifts this for ranks that share ONE device, where device-scope coherence is all that is needed)
+    if (!c->finegrained && !getenv("TCE_COMM_ALLOW_COARSE")) return TCE_ERR_UNSUPPORTED_SHAPE;
+    DeviceGuard guard(c->device);
     hipIpcMemHandle_t h;
     const hipError_t e = hipIpcGetMemHandle(&h, c->window);
     if (e != hipSuccess) {
@@ -153,6 +175,7 @@ int comm_export(Comm *c, void *handle64, hipError_t *he) {
 }
 
 int comm_connect_ipc(Comm *c, const void *handles, hipError_t *he) {
+    DeviceGuard guard(c->device);
     for (int p = 0; p < c->world; ++p) {
         if (p == c->rank || c->peer[p]) continue;
         hipIpcMemHandle_t h;
@@ -177,19 +200,65 @@ int comm_connect_ipc(Comm *c, const void *handles, hipError_t *he) {
     return TCE_OK;
 }
 
-int comm_connect_local(Comm *c, Comm *const *all) {
+// All ranks in ONE process (the reference's host is one process, one thread: Int4llamaForCausalLM.cu:40-44), one rank per device or several
+// per device: the windows are handed over as pointers.  A peer on ANOTHER device needs peer access from this rank's device
+// (hipDeviceEnablePeerAccess; "already enabled" is fine) and a fine-grained window (its flags are polled across the link).
+int comm_connect_local(Comm *c, Comm *const *all, hipError_t *he) {
+    for (int p = 0; p < c->world; ++p)
+        if (!all[p] || all[p]->world != c->world || all[p]->rank != p || all[p]->window_bytes != c->window_bytes || all[p]->slots != c->slots) return TCE_ERR_BAD_ARG;
+    DeviceGuard guard(c->device);
     for (int p = 0; p < c->world; ++p) {
-        if (!all[p] || all[p]->world != c->world || all[p]->rank != p || all[p]->window_bytes != c->window_bytes) return TCE_ERR_BAD_ARG;
+        if (all[p]->device != c->device) {
+            if (!all[p]->finegrained || !c->finegrained) return TCE_ERR_UNSUPPORTED_SHAPE;
+            int can = 0;
+            hipError_t e = hipDeviceCanAccessPeer(&can, c->device, all[p]->device);
+            if (e == hipSuccess && !can) e = hipErrorPeerAccessUnsupported;
+            if (e == hipSuccess) {
+                e = hipDeviceEnablePeerAccess(all[p]->device, 0);
+                if (e == hipErrorPeerAccessAlreadyEnabled) {
+                    (void)hipGetLastError();
+                    e = hipSuccess;
+                }
+            }
+            if (e != hipSuccess) {
+                if (he) *he = e;
+                return TCE_ERR_HIP;
+            }
+        }
         c->peer[p] = all[p]->window;
     }
     return TCE_OK;
 }
+
+int comm_set_timeout_ms(Comm *c, int ms) {
+    if (ms < 1 || ms > 600000) return TCE_ERR_BAD_ARG;
+    c->timeout_ticks = (unsigned long long)ms * 100000ull;
+    return TCE_OK;
+}
+
+// Re-arms a communicator whose status word was set by a timed-out wait.  COLLECTIVE in the host's sense: every rank calls it after the
+// host has made sure that no exchange is in flight on any rank (a barrier + device synchronisation); the epochs stay as they are -- every
+// rank's gather kernels ran to their end, timed out or not, so the per-slot counts still agree.
+int comm_reset(Comm *c, hipError_t *he) {
+    DeviceGuard guard(c->device);
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemset(c->epochs + c->slots, 0, 4);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        if (he) *he = e;
+        return TCE_ERR_HIP;
+    }
+    return TCE_OK;
+}
+
+int comm_device(const Comm *c) { return c->device; }
 
 void *comm_window(Comm *c) { return c->window; }
 int comm_rank(const Comm *c) { return c->rank; }
 int comm_world(const Comm *c) { return c->world; }
 
 int comm_status(Comm *c, hipError_t *he) {
+    DeviceGuard guard(c->device);
     unsigned st = 0;
     const hipError_t e = hipMemcpy(&st, c->epochs + c->slots, 4, hipMemcpyDeviceToHost);
     if (e != hipSuccess) {
@@ -201,6 +270,7 @@ int comm_status(Comm *c, hipError_t *he) {
 
 void comm_destroy(Comm *c) {
     if (!c) return;
+    DeviceGuard guard(c->device);
     for (int p = 0; p < c->world; ++p)
         if (c->ipc_opened[p] && c->peer[p]) (void)hipIpcCloseMemHandle(c->peer[p]);
     if (c->window) (void)hipFree(c->window);
@@ -228,6 +298,8 @@ int launch_allgather_f16(Comm *c, int slot, const void *src_slice, void *dst_ful
     a.slice16 = (unsigned)(slice_bytes / 16);
     a.vec_bytes = c->vec_bytes;
     a.flags_off = data_bytes(*c);
+    a.timeout_ticks = c->timeout_ticks;
+    DeviceGuard guard(c->device);  // one host thread driving several devices: the launch goes to the communicator's device (the stream must be one of that device's)
     hipLaunchKernelGGL(allgather_peer_kernel, dim3(1), dim3(1024), 0, stream, a);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

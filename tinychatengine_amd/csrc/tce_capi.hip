@@ -631,6 +631,7 @@ int tce_comm_export(tce_comm *comm, void *handle_out) {
     if (!comm || !handle_out) return fail(TCE_ERR_BAD_ARG, "tce_comm_export: null argument");
     hipError_t he = hipSuccess;
     const int rc = tce::comm_export(reinterpret_cast<tce::Comm *>(comm), handle_out, &he);
+    if (rc == TCE_ERR_UNSUPPORTED_SHAPE) return fail(rc, "tce_comm_export: the window is not fine-grained memory (hipExtMallocWithFlags failed at tce_comm_create): mapped by another GPU it would not be coherent for the flag protocol");
     return rc == TCE_ERR_HIP ? hip_fail(he, "hipIpcGetMemHandle") : rc;
 }
 int tce_comm_connect(tce_comm *comm, const void *handles) {
@@ -641,9 +642,24 @@ int tce_comm_connect(tce_comm *comm, const void *handles) {
 }
 int tce_comm_connect_local(tce_comm *comm, tce_comm *const *all) {
     if (!comm || !all) return fail(TCE_ERR_BAD_ARG, "tce_comm_connect_local: null argument");
-    const int rc = tce::comm_connect_local(reinterpret_cast<tce::Comm *>(comm), reinterpret_cast<tce::Comm *const *>(all));
+    hipError_t he = hipSuccess;
+    const int rc = tce::comm_connect_local(reinterpret_cast<tce::Comm *>(comm), reinterpret_cast<tce::Comm *const *>(all), &he);
+    if (rc == TCE_ERR_HIP) return hip_fail(he, "tce_comm_connect_local: peer access between the ranks' devices");
+    if (rc == TCE_ERR_UNSUPPORTED_SHAPE) return fail(rc, "tce_comm_connect_local: ranks on different devices need fine-grained windows (hipExtMallocWithFlags failed at tce_comm_create)");
     return rc == TCE_OK ? TCE_OK : fail(rc, "tce_comm_connect_local: the communicators do not form one group");
 }
+int tce_comm_set_timeout_ms(tce_comm *comm, int ms) {
+    if (!comm) return fail(TCE_ERR_BAD_ARG, "tce_comm_set_timeout_ms: null");
+    const int rc = tce::comm_set_timeout_ms(reinterpret_cast<tce::Comm *>(comm), ms);
+    return rc == TCE_OK ? TCE_OK : fail(rc, "tce_comm_set_timeout_ms: 1 .. 600000 ms");
+}
+int tce_comm_reset(tce_comm *comm) {
+    if (!comm) return fail(TCE_ERR_BAD_ARG, "tce_comm_reset: null");
+    hipError_t he = hipSuccess;
+    const int rc = tce::comm_reset(reinterpret_cast<tce::Comm *>(comm), &he);
+    return rc == TCE_ERR_HIP ? hip_fail(he, "tce_comm_reset") : rc;
+}
+int tce_comm_device(const tce_comm *comm) { return comm ? tce::comm_device(reinterpret_cast<const tce::Comm *>(comm)) : fail(TCE_ERR_BAD_ARG, "tce_comm_device: null"); }
 int tce_allgather_f16(tce_comm *comm, int slot, const void *src_slice, void *dst_full, int n_total, void *stream) {
     if (!comm || !src_slice || !dst_full) return fail(TCE_ERR_BAD_ARG, "tce_allgather_f16: null argument");
     hipError_t he = hipSuccess;

@@ -154,7 +154,10 @@ struct Comm;
 int comm_create(int rank, int world, int max_vector_elems, int slots, Comm **out, hipError_t *he);
 int comm_export(Comm *c, void *handle64, hipError_t *he);
 int comm_connect_ipc(Comm *c, const void *handles, hipError_t *he);
-int comm_connect_local(Comm *c, Comm *const *all);
+int comm_connect_local(Comm *c, Comm *const *all, hipError_t *he);
+int comm_set_timeout_ms(Comm *c, int ms);
+int comm_reset(Comm *c, hipError_t *he);
+int comm_device(const Comm *c);
 int comm_status(Comm *c, hipError_t *he);
 void comm_destroy(Comm *c);
 int launch_allgather_f16(Comm *c, int slot, const void *src_slice, void *dst_full, int n_total, hipStream_t stream, hipError_t *he);

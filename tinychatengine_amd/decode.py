@@ -171,7 +171,13 @@ class DecodeLinears:
         self.comm = capi.Comm(self.rank, self.world, n_max, slots=8)
         self.comm.connect(exchange(self.comm.export()))
 
-    def run_token_distributed(self, gathers_per_block: int = 1, launch=None, gather: str = "rccl") -> None:
+    def check_comm(self) -> None:
+        """Synchronises and raises if a peer-write gather of this rank ever gave up waiting (tce_comm_status): its outputs since then are
+        void.  A host that uses the outputs calls this per token or per batch of tokens; after a host-side barrier tce_comm_reset re-arms."""
+        if getattr(self, "comm", None) is not None and self.comm.status() != 0:
+            raise RuntimeError(f"rank {self.rank}: a peer-write all-gather timed out (tce_comm_status != 0); the token's outputs are void")
+
+    def run_token_distributed(self, gathers_per_block: int = 1, launch=None, gather: str = "rccl", check: bool = False) -> None:
         """world > 1: per block, the rank-local GEMVs on N/P shards, then the all-gather(s) of the fp16 output slices --
         gather="rccl": torch.distributed (backend 'nccl' == RCCL over xGMI on the GPU box; 'gloo' in the CPU tests, where
         `launch` is a CPU stand-in for the kernel launch); gather="peer": tce_allgather_f16, one peer-write kernel per
@@ -204,3 +210,5 @@ class DecodeLinears:
                 launch(lch[3]); ag(self.g_down.view(-1), self.out_down.view(-1))
         launch([self.lm_head.desc(self.x, self.logits, allow_host=self._host_ok)])
         ag(self.g_logits.view(-1), self.logits.view(-1))
+        if check and gather == "peer":  # (synchronises: not for a timed loop or a graph capture)
+            self.check_comm()
