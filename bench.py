@@ -90,7 +90,7 @@ def other_configs_leg(torch, dev):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e3 / (reps * launches)
 
-    out = {"w4a16_prefill_gemm_M512": [], "w4a16_prefill_gemm_M2048": [], "w8a8_opt125m": []}
+    out = {"w4a16_prefill_gemm_M512": [], "w4a16_prefill_gemm_M2048": [], "w4a16_prefill_gemm_M4096": [], "w8a8_opt125m": []}
     scratch = torch.zeros(int(L.tce_w4a16_gemm_scratch_bytes()), dtype=torch.uint8, device=dev)  # lets the pre-packed GEMM split K across workgroups
     gen = torch.Generator(device=dev).manual_seed(1)
     for (N, K) in ((4096, 4096), (11008, 4096), (4096, 11008)):
@@ -111,7 +111,7 @@ def other_configs_leg(torch, dev):
             capi.check(L.tce_w4a16_prepack(C.byref(d), pk.data_ptr(), None))
             packs.append(pk)
         torch.cuda.synchronize()
-        for M in (512, 2048):
+        for M in (512, 2048, 4096):
             x = torch.randn(M, K, device=dev, generator=gen).to(torch.float16)
             y = torch.empty(M, N, dtype=torch.float16, device=dev)
             row = {"M": M, "N": N, "K": K}
@@ -127,7 +127,7 @@ def other_configs_leg(torch, dev):
             row["TFLOPs"] = row["prepacked"]["TFLOPs"]  # what a caller that prepacked at load time gets
             row["frac_of_2500_TFLOPs"] = round(row["TFLOPs"] / 2500.0, 3)
             row["best_of_both_TFLOPs"] = best
-            out["w4a16_prefill_gemm_M512" if M == 512 else "w4a16_prefill_gemm_M2048"].append(row)
+            out[f"w4a16_prefill_gemm_M{M}"].append(row)
         del packs
         del sets
     for (M, N, K) in ((512, 768, 768), (512, 3072, 768), (512, 768, 3072), (1, 768, 768)):

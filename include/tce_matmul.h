@@ -253,10 +253,29 @@ typedef struct tce_w8a8_desc {
     int32_t q_min, q_max; /* C.qparams.q_min/q_max: -128..127, or 0..127 for the fused-ReLU linear (W8A8B8O8LinearReLU.cc:32) */
     int32_t bias_kind, out_kind;
     int32_t b_per_row;
-    int32_t reserved;
+    int32_t accumulate;   /* TCE_OUT_FP32 only: C[m][n] = C[m][n] + result, one more rounding -- the residual add the reference issues behind out_proj / fc2
+                             (`add`, llm/src/nn_modules/Int8OPTDecoderLayer.cc:14-22, 39, 54) in the same launch; bit-exact against the two-step form */
+    int32_t lda, ldb, ldc; /* row strides in elements, 0 = dense (K, K, N): a head's 64-column slice of a [rows][heads * 64] projection output is an
+                             operand as it lies (strideA = 64, lda = heads * 64), a cache with room for max_keys keys likewise; b_per_row with
+                             batch == 1 and strideB != 0: the per-row B_m are strideB elements apart */
+    int32_t reserved2;
 } tce_w8a8_desc;
 
 TCE_API int tce_w8a8_matmul(const tce_w8a8_desc *d, void *stream);
+
+/* The element-wise steps between the two int8 BMMs of the reference's OPT attention (llm/src/nn_modules/Int8OPTAttention.cc:254-268), as ONE launch:
+ *   batch_Add (llm/src/ops/batch_add.cc:3-24): s[h][j][k] + mask[j][k];  softmax over k (llm/src/ops/softmax.cc:5-40: the running maximum starts
+ *   from `m_data[0]` -- element [0][0][0] of the tensor the reference normalises IN PLACE, i.e. the masked score for row (0, 0) and that row's first
+ *   probability for every later row --, exponentials summed in k order in fp32, the quotient formed in double: exp / (sum + 1e-10));
+ *   attn_probs_int8 = (int8) std::round(p * 127)  (:266).
+ * scores fp32 [heads][sq][tgz] (the qk BMM's output), mask fp32 [sq][tgz], probs int8 [heads][sq][ld_probs] (ld_probs 0 = tgz; a multiple of 16
+ * lets the pv BMM take its vector path).  Same operations in the same order; the device's expf may differ from the host's in the last bit. */
+TCE_API int tce_opt_softmax_q(const float *scores, const float *mask, void *probs, int heads, int sq, int tgz, int ld_probs, void *stream);
+/* The KV append of Int8OPTAttention::forward (:205-236; the reference copies the whole past into the other cache buffer per token): the new
+ * key / value rows k, v int8 [sq][heads * hd] (k_proj / v_proj outputs as they lie) go to rows [pos, pos + sq) of k_cache [heads][max_keys][hd]
+ * and, TRANSPOSED (the pv BMM's operand, :271-273 without the per-token transpose of the whole cache), to columns [pos, pos + sq) of
+ * vt_cache [heads][hd][max_keys]. */
+TCE_API int tce_opt_kv_append(const void *k, const void *v, void *k_cache, void *vt_cache, int heads, int hd, int sq, int pos, int max_keys, void *stream);
 
 /* LayerNormQ::forward (llm/src/ops/LayerNormQ.cc:12-52), the op in front of the W8A8 linears: x fp32 [m][n],
  * weight / bias fp32 [n], out int8 [m][n] = (int8) round((x - mean) / sqrt(var + 1e-5) * weight + bias), sums sequential

@@ -15,6 +15,8 @@
 //                                                                 own source, block (32, 4) as concurrent threads, __shfl_down_sync warp reduction)
 //   glue_harness lnq   m n x_f32.bin w_f32.bin b_f32.bin out_i8.bin   (LayerNormQ::forward, llm/src/ops/LayerNormQ.cc:12-52 -- host code in the
 //                                                                 reference, compiled as it is: pins orc_layernorm_q)
+//   glue_harness optsm heads sq tgz scores_f32.bin mask_f32.bin out_i8.bin   (batch_Add -> softmax -> the int8 conversion of Int8OPTAttention.cc:254-268:
+//                                                                 llm/src/ops/batch_add.cc and softmax.cc compiled as they are: pins orc_opt_softmax_q)
 //   glue_harness rmsnorm m n eps x.bin gamma_f32.bin out.bin     (LlamaRMSNorm_cuda::forward -> generalT5LayerNorm: warp shuffles and
 //                                                                 __syncthreads, so its block runs as concurrent OS threads)
 // Nothing of this is part of the product.
@@ -156,6 +158,28 @@ int main(int argc, char **argv) {
         Matrix3D<float> X(x.data(), 1, m, n);
         Matrix3D<int8_t> O(out.data(), 1, m, n);
         ln.forward(X, O);
+        FILE *f = fopen(argv[7], "wb");
+        if (!f || fwrite(out.data(), 1, out.size(), f) != out.size()) return 2;
+        fclose(f);
+        return 0;
+    }
+    if (op == "optsm" && argc == 8) {  // batch_Add (batch_add.cc) -> softmax (softmax.cc), the reference's own sources, then Int8OPTAttention.cc:264-267's loop
+        const int heads = I(2), sq = I(3), tgz = I(4);
+        auto rdf = [&](const char *path, size_t cnt) {
+            std::vector<float> v(cnt);
+            FILE *f = fopen(path, "rb");
+            if (!f || fread(v.data(), 4, cnt, f) != cnt) exit(2);
+            fclose(f);
+            return v;
+        };
+        auto sc = rdf(argv[5], (size_t)heads * sq * tgz), mk = rdf(argv[6], (size_t)sq * tgz);
+        Matrix3D<float> attn_weights(sc.data(), heads, sq, tgz), mask(mk.data(), 1, sq, tgz);
+        batch_Add(attn_weights, mask, attn_weights);
+        Matrix3D<float> attn_probs(sc.data(), heads, sq, tgz);
+        softmax(attn_weights, attn_probs, 2);
+        std::vector<int8_t> out(sc.size());
+        const int len = attn_probs.length();
+        for (int i = 0; i < len; i++) out[i] = static_cast<int8_t>(std::round(attn_probs.m_data[i] * 127));  // Int8OPTAttention.cc:266
         FILE *f = fopen(argv[7], "wb");
         if (!f || fwrite(out.data(), 1, out.size(), f) != out.size()) return 2;
         fclose(f);

@@ -237,6 +237,15 @@ class Oracle(_Lib):
         self.lib.orc_layernorm_q(_p(x), _p(w), _p(b), _p(out), C.c_int(m), C.c_int(n))
         return out
 
+    def opt_softmax_q(self, scores_f32, mask_f32):
+        """batch_Add + softmax + int8 probabilities of the OPT attention: scores [heads][sq][tgz], mask [sq][tgz] -> int8 [heads][sq][tgz]."""
+        s = np.ascontiguousarray(scores_f32, np.float32); m = np.ascontiguousarray(mask_f32, np.float32)
+        heads, sq, tgz = s.shape
+        assert m.shape == (sq, tgz)
+        out = np.empty(s.shape, np.int8)
+        self.lib.orc_opt_softmax_q(_p(s), _p(m), _p(out), C.c_int(heads), C.c_int(sq), C.c_int(tgz))
+        return out
+
     def rmsnorm_half(self, x_f16, gamma_f32, eps):
         x = np.ascontiguousarray(x_f16, np.float16); g = np.ascontiguousarray(gamma_f32, np.float32)
         m, n = x.reshape(-1, x.shape[-1]).shape

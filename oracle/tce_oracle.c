@@ -632,6 +632,40 @@ ORC_API void orc_layernorm_q(const float *x, const float *w, const float *b, int
     }
 }
 
+/* The element-wise steps between the two int8 BMMs of the reference's OPT attention, restated operation by operation:
+ *   batch_Add   (llm/src/ops/batch_add.cc:13-19):   v = s[i][j][k] + mask[0][j][k]
+ *   softmax     (llm/src/ops/softmax.cc:11-36):     max_value starts from input.m_data[0] -- element [0][0][0] of the WHOLE tensor, not of the
+ *               row (:13) -- and the caller runs it IN PLACE (attn_probs wraps attn_weights' array, Int8OPTAttention.cc:258-260), so from the
+ *               second row on that element already holds row (0, 0)'s first PROBABILITY, not its score; sum += std::exp(v - max) for k ascending (fp32); the quotient std::exp(v - max) / (sum + 1e-10) is a
+ *               DOUBLE division (the literal 1e-10 promotes the divisor, :31) rounded to float on assignment
+ *   int8 probs  (llm/src/nn_modules/Int8OPTAttention.cc:264-267): static_cast<int8_t>(std::round(p * 127)), the product in fp32
+ * Pinned against the reference's own batch_add.cc and softmax.cc compiled into oracle/_ref/glue_harness (tests/test_oracle_glue.py). */
+ORC_API void orc_opt_softmax_q(const float *scores, const float *mask, int8_t *probs, int heads, int sq, int tgz) {
+    float first = scores[0] + mask[0];  /* m_data[0] as row (0, 0) sees it; overwritten by that row's first output (in place) */
+    for (int i = 0; i < heads; i++)
+        for (int j = 0; j < sq; j++) {
+            const float *s = scores + ((int64_t)i * sq + j) * tgz;
+            const float *m = mask + (int64_t)j * tgz;
+            float max_value = first;
+            float sum = 0;
+            for (int k = 0; k < tgz; k++) {
+                const float value = s[k] + m[k];
+                if (value > max_value) max_value = value;
+            }
+            for (int k = 0; k < tgz; k++) {
+                const float value = s[k] + m[k];
+                sum += expf(value - max_value);
+            }
+            for (int k = 0; k < tgz; k++) {
+                const float value = s[k] + m[k];
+                const float final_v = (float)((double)expf(value - max_value) / ((double)sum + 1e-10));
+                const float scaled = final_v * 127;
+                probs[((int64_t)i * sq + j) * tgz + k] = (int8_t)roundf(scaled);
+                if (i == 0 && j == 0 && k == 0) first = final_v;
+            }
+        }
+}
+
 /* ------------------------------------------------------------------------------------------------------------------ */
 /* Attention ops either side of the int4 linears.  The reference implements these only as CUDA      */
 /* kernels (llm/src/ops/cuda/BMM_F16T.cu, softmax.cu, RotaryPosEmb.cu), which cannot run on a device here; what       */

@@ -441,6 +441,19 @@ def test_full_size_prefill_gemm(dev, oracle, N, K):
                                       lin.zero_point.cpu().numpy().view(np.uint32), len(rows), N, K, G)
     _check(y[rows].cpu().numpy(), ref32, f"prefill {N}x{K}")
     _floor_gate(y[rows].cpu().numpy(), ref32, f"prefill M=512 {N}x{K} (128 rows)")
+    if N == 4096 and K == 4096:
+        # and ALL 512 rows of the 4096 x 4096 shape against the threaded oracle (8.6e9 scalar MACs: tens of seconds on the box's host
+        # cores) -- on 512 DISTINCT rows, both weight forms (q4_6 as loaded: the 64-row LDS-DMA tiles; pre-packed: the 128-row tiles)
+        xa = torch.empty(M, K, device=dev).normal_(0, 1, generator=g).to(torch.float16)
+        ref_all = oracle.w4a16_gemv_q4_6_mt(xa.cpu().numpy(), lin.weight.cpu().numpy().view(np.uint32), lin.scale.cpu().numpy(),
+                                            lin.zero_point.cpu().numpy().view(np.uint32), M, N, K, G)
+        _check(lin.forward(xa).cpu().numpy(), ref_all, "prefill 4096 x 4096, all 512 rows, q4_6 as loaded")
+        lin.prepack()
+        ya = lin.forward(xa)
+        torch.cuda.synchronize()
+        assert "gemm-pk" in capi.describe_dispatch(lin.desc(xa, ya))
+        _check(ya.cpu().numpy(), ref_all, "prefill 4096 x 4096, all 512 rows, pre-packed")
+        lin.packed = None
     yv = torch.empty(4, N, dtype=torch.float16, device=dev)
     d = lin.desc(x[3:7].contiguous(), yv)
     d.flags = capi.TCE_W4_FORCE_GEMV

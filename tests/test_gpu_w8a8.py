@@ -268,3 +268,83 @@ def test_layernorm_q_fused_argument_checks(dev):
     arr[0].M = 2
     assert L.tce_layernorm_q_w8a8_group(x.data_ptr(), w.data_ptr(), w.data_ptr(), 1, 64, arr, 1, None, None) == capi.TCE_ERR_BAD_ARG  # M mismatch
     assert L.tce_layernorm_q_w8a8_group(x.data_ptr(), w.data_ptr(), w.data_ptr(), 1, 40, arr, 1, None, None) == capi.TCE_ERR_UNSUPPORTED_SHAPE  # k % 16
+
+
+@pytest.mark.parametrize("embed,heads,ffn,steps", [(256, 4, 512, [(0, 5), (5, 1), (6, 1), (7, 3)]),      # a prompt of 5, two decode tokens, a batch of 3
+                                                   (768, 12, 3072, [(0, 40), (40, 1)]),                   # OPT-125M's sizes (model.h:70): prefill 40, one decode token
+                                                   (256, 4, 512, [(0, 1), (1, 1), (2, 20)])])
+def test_opt_decoder_layer_against_the_oracle_composition(dev, oracle, embed, heads, ffn, steps):
+    """A whole SmoothQuant OPT decoder layer on this library's launches (tinychatengine_amd/opt_layer.py: 8 per decode step, 12 per prefill) against
+    the ORACLE'S composition of Int8OPTDecoderLayer::forward (Int8OPTDecoderLayer.cc:24-59, Int8OPTAttention.cc:183-284): LayerNormQ, the three
+    projections, the KV append, the per-head qk BMM, batch_Add + softmax + int8 conversion, the per-head pv BMM, out_proj + add, LayerNormQ,
+    fc1 (ReLU), fc2 + add -- token after token with a growing cache.  Every stage is compared BIT FOR BIT (q / k / v, the scores, the attention
+    rows, fc1's output, the residual stream); the int8 probabilities may differ where the device's expf and the host's disagree in the last bit
+    (counted: < 2e-4 of them, by one step), and the stages behind them are then checked against the oracle fed with the device's probabilities."""
+    from tinychatengine_amd.opt_layer import Int8OPTDecoderLayer
+    hd, max_keys, max_rows = embed // heads, 64, 40
+    layer = Int8OPTDecoderLayer(embed, heads, ffn, max_keys, max_rows, dev, seed=embed + ffn)
+    P = {k: getattr(layer, k).cpu().numpy() for k in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "Wq", "Wk", "Wv", "bq", "bk", "bv", "Wo", "bo", "W1", "b1", "W2", "b2")}
+    rng = np.random.default_rng(embed + len(steps))
+    Kc = np.zeros((heads, 0, hd), np.int8)
+    Vc = np.zeros((heads, 0, hd), np.int8)
+    for (pos, m) in steps:
+        tgz = pos + m
+        hidden0 = (rng.standard_normal((m, embed)) * 2).astype(np.float32)
+        mask = np.zeros((m, tgz), np.float32)
+        for j in range(m):  # causal: row j sees keys 0 .. pos + j
+            mask[j, pos + j + 1:] = np.finfo(np.float32).min
+        h_gpu = torch.from_numpy(hidden0.copy()).to(dev)
+        layer.step(h_gpu, pos, torch.from_numpy(mask).to(dev))
+        torch.cuda.synchronize()
+        # ---- the oracle's composition ----
+        ln = oracle.layernorm_q(hidden0, P["ln1_w"], P["ln1_b"]).reshape(m, embed)
+        q, k, v = (oracle.int8_matmul_bias_i8(ln, P["W" + n], P["b" + n], layer.a_qkv, layer.b_qkv, -128, 127, m, embed, embed) for n in "qkv")
+        for name, want in (("q", q), ("k", k), ("v", v)):
+            assert np.array_equal(getattr(layer, name)[:m].cpu().numpy(), want), f"step {(pos, m)}: {name} projection"
+        Kc = np.concatenate([Kc, k.reshape(m, heads, hd).transpose(1, 0, 2)], axis=1)
+        Vc = np.concatenate([Vc, v.reshape(m, heads, hd).transpose(1, 0, 2)], axis=1)
+        assert np.array_equal(layer.k_cache[:, :tgz].cpu().numpy(), Kc) and np.array_equal(layer.vt_cache[:, :, :tgz].cpu().numpy(), Vc.transpose(0, 2, 1)), "KV append"
+        qh = q.reshape(m, heads, hd).transpose(1, 0, 2)
+        scores = np.stack([oracle.int8_matmul_nobias_f32(qh[h], Kc[h], layer.a_qk, m, tgz, hd) for h in range(heads)])
+        got_scores = layer.scores.view(-1)[: heads * m * tgz].view(heads, m, tgz).cpu().numpy()
+        assert np.array_equal(got_scores.view(np.uint32), scores.view(np.uint32)), f"step {(pos, m)}: qk BMM"
+        probs = oracle.opt_softmax_q(scores, mask)
+        ldp = (tgz + 15) // 16 * 16
+        got_probs = layer.probs.view(-1)[: heads * m * ldp].view(heads, m, ldp)[:, :, :tgz].cpu().numpy()
+        diff = np.abs(got_probs.astype(np.int32) - probs.astype(np.int32))
+        assert diff.max() <= 1 and (diff > 0).mean() < 2e-4, f"step {(pos, m)}: int8 probabilities: max step {diff.max()}, {float((diff > 0).mean()):.2e} differ"
+        attn = np.concatenate([oracle.int8_matmul_nobias_i8(got_probs[h], np.ascontiguousarray(Vc[h].T), layer.a_pv, -128, 127, m, hd, tgz) for h in range(heads)], axis=1)
+        assert np.array_equal(layer.attn[:m].cpu().numpy(), attn), f"step {(pos, m)}: pv BMM / unshape"
+        h1 = hidden0 + oracle.int8_matmul_bias_f32(attn, P["Wo"], P["bo"], layer.a_o, m, embed, embed)  # fp32 add: one rounding (Int8OPTDecoderLayer.cc:14-22)
+        ln2 = oracle.layernorm_q(h1, P["ln2_w"], P["ln2_b"]).reshape(m, embed)
+        f1 = oracle.int8_matmul_bias_i8(ln2, P["W1"], P["b1"], layer.a_1, layer.b_1, 0, 127, m, ffn, embed)
+        assert np.array_equal(layer.fc1[:m].cpu().numpy(), f1), f"step {(pos, m)}: final_layer_norm + fc1"
+        want = h1 + oracle.int8_matmul_bias_f32(f1, P["W2"], P["b2"], layer.a_2, m, embed, ffn)
+        assert np.array_equal(h_gpu.cpu().numpy().view(np.uint32), want.view(np.uint32)), f"step {(pos, m)}: the residual stream"
+
+
+def test_w8a8_leading_dimensions_and_accumulate(dev, oracle):
+    """tce_w8a8_desc.lda / ldb / ldc (a head's 64 columns of a wider matrix as an operand as it lies) and `accumulate` (the fp32 residual add in
+    the launch), MFMA and generic kernels, against the oracle on the gathered operands."""
+    from tinychatengine_amd import capi
+    import ctypes as C
+    rng = np.random.default_rng(8)
+    for (M, N, K, lda, ldb, ldc) in ((70, 96, 64, 320, 128, 200), (5, 40, 48, 64, 48, 40), (130, 64, 192, 192, 256, 64)):
+        A = rng.integers(-128, 128, (M, lda), dtype=np.int8)
+        B = rng.integers(-128, 128, (N, ldb), dtype=np.int8)
+        bias = rng.standard_normal(N).astype(np.float32)
+        C0 = rng.standard_normal((M, ldc)).astype(np.float32)
+        tA, tB, tb, tC = (torch.from_numpy(x).to(dev) for x in (A, B, bias, C0.copy()))
+        d = capi.W8A8Desc(M=M, N=N, K=K, batch=1, A=tA.data_ptr(), B=tB.data_ptr(), bias=tb.data_ptr(), C=tC.data_ptr(), alpha=0.001, q_min=-128, q_max=127,
+                          bias_kind=capi.TCE_BIAS_FP32, out_kind=capi.TCE_OUT_FP32, accumulate=1, lda=lda, ldb=ldb, ldc=ldc)
+        capi.check(capi.w8a8_matmul(d, torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        want = C0.copy()
+        want[:, :N] = C0[:, :N] + oracle.int8_matmul_bias_f32(np.ascontiguousarray(A[:, :K]), np.ascontiguousarray(B[:, :K]), bias, 0.001, M, N, K)
+        assert np.array_equal(tC.cpu().numpy().view(np.uint32), want.view(np.uint32)), (M, N, K)
+    bad = capi.W8A8Desc(M=4, N=4, K=16, batch=1, A=tA.data_ptr(), B=tB.data_ptr(), C=tC.data_ptr(), alpha=1.0, q_min=-128, q_max=127, bias_kind=capi.TCE_BIAS_NONE,
+                        out_kind=capi.TCE_OUT_INT8, accumulate=1)
+    assert capi.w8a8_matmul(bad, None) == capi.TCE_ERR_UNSUPPORTED_KIND
+    bad = capi.W8A8Desc(M=4, N=4, K=16, batch=1, A=tA.data_ptr(), B=tB.data_ptr(), C=tC.data_ptr(), alpha=1.0, q_min=-128, q_max=127, bias_kind=capi.TCE_BIAS_NONE,
+                        out_kind=capi.TCE_OUT_FP32, lda=8)
+    assert capi.w8a8_matmul(bad, None) == capi.TCE_ERR_BAD_ARG

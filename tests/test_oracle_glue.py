@@ -129,6 +129,26 @@ def test_layernorm_q_against_the_reference_source(tmp_path, oracle, m, n):
     assert np.array_equal(ref, oracle.layernorm_q(x, w, b).reshape(m, n))
 
 
+@needs_harness
+@pytest.mark.parametrize("heads,sq,tgz", [(12, 1, 513), (3, 5, 40), (12, 64, 64), (2, 7, 1)])
+def test_opt_softmax_q_against_the_reference_sources(tmp_path, oracle, heads, sq, tgz):
+    """batch_Add (llm/src/ops/batch_add.cc) and softmax (llm/src/ops/softmax.cc) are host C++ in the reference: compiled as they are, followed by
+    the int8 conversion loop of Int8OPTAttention.cc:264-267, and compared with orc_opt_softmax_q bit for bit -- including the running maximum that
+    starts from element [0][0][0] of the whole tensor and the double-precision quotient."""
+    rng = np.random.default_rng(heads * 100 + sq * 10 + tgz)
+    scores = (rng.standard_normal((heads, sq, tgz)) * 4).astype(np.float32)
+    scores[0, 0, 0] = 9.5  # above most rows' own maxima: the m_data[0] quirk matters
+    mask = np.zeros((sq, tgz), np.float32)
+    if tgz > 1:
+        mask[:, rng.integers(0, tgz, size=max(1, tgz // 5))] = np.finfo(np.float32).min
+    sp, mp, out = tmp_path / "s.bin", tmp_path / "m.bin", tmp_path / "o.bin"
+    scores.tofile(sp); mask.tofile(mp)
+    r = subprocess.run([HARNESS, "optsm", str(heads), str(sq), str(tgz), str(sp), str(mp), str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    ref = np.fromfile(out, np.int8).reshape(heads, sq, tgz)
+    assert np.array_equal(ref, oracle.opt_softmax_q(scores, mask))
+
+
 def _golden():
     import importlib.util
     spec = importlib.util.spec_from_file_location("make_cuda_gemv_golden", os.path.join(REPO, "tests", "golden", "make_cuda_gemv_golden.py"))

@@ -96,6 +96,97 @@ int launch_layernorm_q(const float *x, const float *w, const float *b, void *out
     return TCE_OK;
 }
 
+namespace {
+
+// batch_Add + softmax + the int8 conversion between the two BMMs of the OPT attention (llm/src/ops/batch_add.cc:3-24, softmax.cc:5-40,
+// llm/src/nn_modules/Int8OPTAttention.cc:254-268), one wavefront per (head, query row), the reference's operations in the reference's order:
+//   v_k   = s[h][j][k] + mask[j][k]                                    (fp32 add)
+//   max   = the running maximum over k, STARTING from `input.m_data[0]` (softmax.cc:13).  The reference runs its softmax IN PLACE
+//           (Int8OPTAttention.cc:258-260), so that element is the masked score [0][0][0] for row (0, 0) and row (0, 0)'s first
+//           PROBABILITY for every row behind it: a fifth wavefront of every workgroup evaluates row (0, 0) up to that value first
+//   sum   = 0; sum += expf(v_k - max) for k ascending                   (sequential fp32 additions: sequential_sum_lane0)
+//   p_k   = (float)((double)expf(v_k - max) / ((double)sum + 1e-10))    (softmax.cc:31: the literal 1e-10 makes the quotient a double one)
+//   q_k   = (int8) std::round(p_k * 127)                                (:266; half away from zero)
+// The device's expf is not the host's to the last bit: a probability within a few fp32 steps of a rounding boundary can land on the
+// other side (tests/test_gpu_w8a8.py counts them).
+__global__ __launch_bounds__(320) void opt_softmax_q_kernel(const float *scores, const float *mask, int8_t *probs, int rows, int sq, int tgz, int ldp) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // [5 waves][tgz] + [1]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float *first_p = sm + (size_t)5 * tgz;
+    const int row = wave == 4 ? 0 : blockIdx.x * 4 + wave;  // = h * sq + j; wave 4: row (0, 0), up to its first probability only
+    const bool live = row < rows;
+    float *e = sm + (size_t)wave * tgz;
+    const float *s = scores + (size_t)(live ? row : 0) * tgz;
+    const float *mk = mask + (size_t)((live ? row : 0) % sq) * tgz;
+    const float v000 = scores[0] + mask[0];
+    // one row up to (max, the exponentials in e[], their sequential sum): `init` = what m_data[0] holds when the reference reaches the row
+    auto row_stats = [&](float init, float &sum_out) {
+        float mx = init;
+        for (int k = lane; k < tgz; k += 64) {
+            const float v = s[k] + mk[k];
+            e[k] = v;
+            mx = v > mx ? v : mx;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float o = __shfl_xor(mx, off, 64);
+            mx = o > mx ? o : mx;
+        }
+        for (int k = lane; k < tgz; k += 64) e[k] = expf(e[k] - mx);
+        float sum = sequential_sum_lane0(e, tgz, lane, [](float v) { return v; });
+        sum_out = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sum)));
+    };
+    if (wave == 4) {
+        float sum;
+        row_stats(v000, sum);
+        if (lane == 0) *first_p = (float)((double)e[0] / ((double)sum + 1e-10));
+    }
+    __syncthreads();
+    if (wave == 4 || !live) return;
+    float sum;
+    row_stats(row == 0 ? v000 : *first_p, sum);
+    const double denom = (double)sum + 1e-10;
+    int8_t *out = probs + (size_t)row * ldp;
+    for (int k = lane; k < tgz; k += 64) {
+        const float p = (float)((double)e[k] / denom);
+        out[k] = (int8_t)(int)roundf(p * 127.0f);
+    }
+}
+
+__global__ __launch_bounds__(256) void opt_kv_append_kernel(const int8_t *k, const int8_t *v, int8_t *kc, int8_t *vt, int heads, int hd, int sq, int pos, int max_keys) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int width = heads * hd;
+    if (i >= (long long)sq * width) return;
+    const int j = (int)(i / width), c = (int)(i % width), h = c / hd, d = c % hd;
+    kc[((size_t)h * max_keys + pos + j) * hd + d] = k[i];
+    vt[((size_t)h * hd + d) * max_keys + pos + j] = v[i];
+}
+
+}  // namespace
+
+int launch_opt_softmax_q(const float *scores, const float *mask, void *probs, int heads, int sq, int tgz, int ldp, hipStream_t stream, hipError_t *hip_err) {
+    const int rows = heads * sq;
+    hipLaunchKernelGGL(opt_softmax_q_kernel, dim3((rows + 3) / 4), dim3(320), ((size_t)5 * tgz + 4) * sizeof(float), stream, scores, mask, static_cast<int8_t *>(probs), rows, sq, tgz, ldp);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (hip_err) *hip_err = e;
+        return TCE_ERR_HIP;
+    }
+    return TCE_OK;
+}
+
+int launch_opt_kv_append(const void *k, const void *v, void *kc, void *vt, int heads, int hd, int sq, int pos, int max_keys, hipStream_t stream, hipError_t *hip_err) {
+    const long long total = (long long)sq * heads * hd;
+    hipLaunchKernelGGL(opt_kv_append_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, static_cast<const int8_t *>(k), static_cast<const int8_t *>(v),
+                       static_cast<int8_t *>(kc), static_cast<int8_t *>(vt), heads, hd, sq, pos, max_keys);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (hip_err) *hip_err = e;
+        return TCE_ERR_HIP;
+    }
+    return TCE_OK;
+}
+
 int launch_rmsnorm_half(const void *x, const float *gamma, void *out, int m, int n, float eps, hipStream_t stream, hipError_t *hip_err) {
     hipLaunchKernelGGL(rmsnorm_half_kernel, dim3(m), dim3(512), 0, stream, static_cast<const half_t *>(x), gamma, static_cast<half_t *>(out), n, eps);
     const hipError_t e = hipGetLastError();

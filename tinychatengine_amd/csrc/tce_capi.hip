@@ -510,6 +510,24 @@ int tce_layernorm_q(const float *x, const float *weight, const float *bias, void
     return rc == TCE_ERR_HIP ? hip_fail(he, "layernorm_q launch") : rc;
 }
 
+int tce_opt_softmax_q(const float *scores, const float *mask, void *probs, int heads, int sq, int tgz, int ld_probs, void *stream) {
+    if (!scores || !mask || !probs || heads <= 0 || sq <= 0 || tgz <= 0) return fail(TCE_ERR_BAD_ARG, "tce_opt_softmax_q: bad argument");
+    if (ld_probs == 0) ld_probs = tgz;
+    if (ld_probs < tgz) return fail(TCE_ERR_BAD_ARG, "tce_opt_softmax_q: ld_probs < tgz");
+    if (tgz > 8000) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_opt_softmax_q: rows of at most 8192 keys (five rows in LDS per workgroup)");
+    hipError_t he = hipSuccess;
+    const int rc = tce::launch_opt_softmax_q(scores, mask, probs, heads, sq, tgz, ld_probs, static_cast<hipStream_t>(stream), &he);
+    return rc == TCE_ERR_HIP ? hip_fail(he, "opt softmax launch") : rc;
+}
+
+int tce_opt_kv_append(const void *k, const void *v, void *k_cache, void *vt_cache, int heads, int hd, int sq, int pos, int max_keys, void *stream) {
+    if (!k || !v || !k_cache || !vt_cache || heads <= 0 || hd <= 0 || sq <= 0 || pos < 0 || pos + sq > max_keys)
+        return fail(TCE_ERR_BAD_ARG, "tce_opt_kv_append: bad argument (need pos + sq <= max_keys)");
+    hipError_t he = hipSuccess;
+    const int rc = tce::launch_opt_kv_append(k, v, k_cache, vt_cache, heads, hd, sq, pos, max_keys, static_cast<hipStream_t>(stream), &he);
+    return rc == TCE_ERR_HIP ? hip_fail(he, "opt kv append launch") : rc;
+}
+
 int tce_rmsnorm_half(const void *x, const float *gamma, void *out, int m, int n, float eps, void *stream) {
     if (!x || !gamma || !out || m <= 0 || n <= 0) return fail(TCE_ERR_BAD_ARG, "tce_rmsnorm_half: bad argument");
     if (n % 8 != 0 || (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(gamma)) % 16 != 0)
@@ -594,8 +612,12 @@ int tce_w8a8_matmul(const tce_w8a8_desc *d, void *stream) {
     if (d->b_per_row && d->bias_kind != TCE_BIAS_NONE) return fail(TCE_ERR_UNSUPPORTED_KIND, "the *_batch variants have no bias");
     if (d->out_kind == TCE_OUT_INT8 && (d->q_min < -128 || d->q_max > 127 || d->q_min > d->q_max))
         return fail(TCE_ERR_BAD_ARG, "q_min/q_max out of int8 range");
+    if (d->accumulate && d->out_kind != TCE_OUT_FP32) return fail(TCE_ERR_UNSUPPORTED_KIND, "accumulate is the fp32 residual add (TCE_OUT_FP32 only)");
+    if (d->lda < 0 || d->ldb < 0 || d->ldc < 0 || (d->lda && d->lda < d->K) || (d->ldb && d->ldb < d->K) || (d->ldc && d->ldc < d->N))
+        return fail(TCE_ERR_BAD_ARG, "lda / ldb / ldc must be 0 (dense) or at least K / K / N");
     hipError_t he = hipSuccess;
     const int rc = tce::launch_w8a8(*d, static_cast<hipStream_t>(stream), &he);
+    if (rc == TCE_ERR_BAD_ARG) return fail(rc, "w8a8: bad leading dimensions");
     return rc == TCE_ERR_HIP ? hip_fail(he, "w8a8 launch") : rc;
 }
 

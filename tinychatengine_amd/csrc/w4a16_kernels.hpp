@@ -144,6 +144,8 @@ int launch_layernorm_q(const float *x, const float *w, const float *b, void *out
 // w8a8_lnq_fused.hip
 int launch_lnq_w8a8_group(const float *x, const float *ln_w, const float *ln_b, int m, int k, const tce_w8a8_desc *lin, int count, void *ln_out,
                           hipStream_t stream, hipError_t *hip_err);
+int launch_opt_softmax_q(const float *scores, const float *mask, void *probs, int heads, int sq, int tgz, int ldp, hipStream_t stream, hipError_t *hip_err);
+int launch_opt_kv_append(const void *k, const void *v, void *kc, void *vt, int heads, int hd, int sq, int pos, int max_keys, hipStream_t stream, hipError_t *hip_err);
 int launch_rmsnorm_half(const void *x, const float *gamma, void *out, int m, int n, float eps, hipStream_t stream, hipError_t *hip_err);
 // attention_ops.hip
 int launch_bmm_f16t(const void *A, const void *B, void *C, int batch, int M, int N, int K, unsigned short alpha_bits, hipStream_t stream, hipError_t *hip_err);

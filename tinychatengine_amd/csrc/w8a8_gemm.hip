@@ -27,9 +27,11 @@ struct W8A8Args {
     void *C;
     long long strideA, strideB, strideC;
     int M, N, K;
+    int lda, ldb, ldc;  // row strides in elements (>= K, K, N): a head's slice of a [rows][heads * 64] matrix is an operand as it lies
     float alpha, beta;
     int q_min, q_max;
     int bias_kind, out_kind, b_per_row, vec_ok;
+    int accumulate;     // fp32 output only: C = fadd_rn(C, result) -- the residual add behind out_proj / fc2 (Int8OPTDecoderLayer.cc:39, 54)
 };
 
 // The additive term of output column n: fmul_rn(bias[n], beta) for the int8 form, bias[n] for the fp32 form, none.
@@ -51,10 +53,12 @@ __device__ __forceinline__ void epilogue_store(const W8A8Args &a, void *Cb, int 
         // narrowing afterwards gives the same int8 for every |v| < 2^31 -- beyond that the reference's float -> int32 cast is UB
         r = fmaxf(r, (float)a.q_min);
         r = fminf(r, (float)a.q_max);
-        static_cast<int8_t *>(Cb)[(size_t)m * a.N + n] = (int8_t)(int)r;
+        static_cast<int8_t *>(Cb)[(size_t)m * a.ldc + n] = (int8_t)(int)r;
     } else {
         if (a.bias_kind == TCE_BIAS_FP32) v = __fadd_rn(v, u);
-        static_cast<float *>(Cb)[(size_t)m * a.N + n] = v;
+        float *dst = static_cast<float *>(Cb) + (size_t)m * a.ldc + n;
+        if (a.accumulate) v = __fadd_rn(*dst, v);  // add(a, b, c): c = a + b, one rounding (Int8OPTDecoderLayer.cc:14-22)
+        *dst = v;
     }
 }
 
@@ -98,10 +102,10 @@ __global__ __launch_bounds__(256 * KS) void w8a8_mfma_kernel(const W8A8Args a) {
     for (int i = 0; i < 2; ++i) {
         int m = m_base + i * 16 + lrow;
         m = m < a.M ? m : a.M - 1;
-        pa[i] = A + (size_t)m * a.K + lchunk * 16;
+        pa[i] = A + (size_t)m * a.lda + lchunk * 16;
         int n = n_base + i * 16 + lrow;
         n = n < a.N ? n : a.N - 1;
-        pb[i] = B + (size_t)n * a.K + lchunk * 16;
+        pb[i] = B + (size_t)n * a.ldb + lchunk * 16;
     }
     int4_t acc[2][2];
 #pragma unroll
@@ -230,8 +234,9 @@ __global__ __launch_bounds__(256) void w8a8_generic_kernel(const W8A8Args a) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)a.M * a.N) return;
     const int m = (int)(idx / a.N), n = (int)(idx % a.N);
-    const int8_t *pa = A + (size_t)m * a.K;
-    const int8_t *pb = a.b_per_row ? B + ((size_t)m * a.N + n) * a.K : B + (size_t)n * a.K;
+    const int8_t *pa = A + (size_t)m * a.lda;
+    // b_per_row: row m of A has its own B_m; the B_m are strideB elements apart (dense [M][N][K] when the caller gave none)
+    const int8_t *pb = a.b_per_row ? B + (size_t)m * a.strideB + (size_t)n * a.ldb : B + (size_t)n * a.ldb;
     int acc = 0;
     int k = 0;
     if (a.vec_ok) {
@@ -264,6 +269,15 @@ int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err)
     a.M = d.M;
     a.N = d.N;
     a.K = d.K;
+    a.lda = d.lda ? d.lda : d.K;
+    a.ldb = d.ldb ? d.ldb : d.K;
+    a.ldc = d.ldc ? d.ldc : d.N;
+    a.accumulate = d.accumulate;
+    if (a.lda < d.K || a.ldb < d.K || a.ldc < d.N) return TCE_ERR_BAD_ARG;
+    if (d.b_per_row) {  // the per-row B_m: strideB apart when given (batch must be 1 then), dense [M][N][K] otherwise
+        if (d.batch > 1) a.strideB = (long long)d.strideB;  // (batched *_batch problems are not a reference shape; kept for symmetry)
+        else a.strideB = d.strideB ? d.strideB : (long long)d.N * a.ldb;
+    }
     a.alpha = d.alpha;
     a.beta = d.beta;
     a.q_min = d.q_min;
@@ -272,7 +286,7 @@ int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err)
     a.out_kind = d.out_kind;
     a.b_per_row = d.b_per_row;
     const bool aligned = (d.K % 16 == 0) && (reinterpret_cast<uintptr_t>(d.A) % 16 == 0) &&
-                         (reinterpret_cast<uintptr_t>(d.B) % 16 == 0) &&
+                         (reinterpret_cast<uintptr_t>(d.B) % 16 == 0) && a.lda % 16 == 0 && a.ldb % 16 == 0 && a.strideB % 16 == 0 &&
                          (d.batch == 1 || (d.strideA % 16 == 0 && d.strideB % 16 == 0));
     a.vec_ok = aligned ? 1 : 0;
     if (!d.b_per_row && aligned && d.K >= 64) {
