@@ -349,6 +349,51 @@ def shapes_only_leg(dl, torch, dev, shape, eager: bool):
     return out
 
 
+def opt_layer_leg(torch, dev):
+    """BASELINE config 4 as a WORKLOAD, not four shapes: whole SmoothQuant OPT-125M decoder layers (embed 768, 12 heads, ffn 3072,
+    12 layers -- llm/include/model.h:70) on this library's launches (tinychatengine_amd/opt_layer.py; Int8OPTDecoderLayer.cc:24-59, Int8OPTAttention.cc:183-284):
+    one decode token over a 512-key cache (8 launches per layer) and a 512-row prefill (12 launches per layer), the 12 layers captured in one hipGraph."""
+    from tinychatengine_amd.opt_layer import Int8OPTDecoderLayer
+    E, H, F, NL = 768, 12, 3072, 12
+    out = {"model": "OPT-125M (embed 768, 12 heads, ffn 3072, 12 layers)", "weights": "synthetic int8"}
+    for name, m, pos in (("decode_512_keys", 1, 511), ("prefill_512_rows", 512, 0)):
+        tgz = pos + m
+        layers = [Int8OPTDecoderLayer(E, H, F, 512, m, dev, seed=7 + i) for i in range(NL)]
+        hid = torch.randn(m, E, device=dev)
+        hid0 = hid.clone()
+        mask = torch.zeros((m, tgz), device=dev)
+        if m > 1:
+            mask.masked_fill_(torch.triu(torch.ones(m, tgz, dtype=torch.bool, device=dev), diagonal=pos + 1), torch.finfo(torch.float32).min)
+
+        def token():
+            hid.copy_(hid0)
+            for l in layers:
+                l.step(hid, pos, mask)
+        token()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            token()
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        a.record()
+        for _ in range(reps):
+            g.replay()
+        b.record()
+        torch.cuda.synchronize()
+        us = a.elapsed_time(b) * 1e3 / reps
+        ops = layers[0].int8_ops(m, tgz)
+        out[name] = {"rows": m, "keys": tgz, "us_per_layer": round(us / NL, 2), "launches_per_layer": Int8OPTDecoderLayer.launches(m), "us_per_12_layers": round(us, 1),
+                     "int8_TOPs": round(ops * NL / us / 1e6, 2), "finite": bool(torch.isfinite(hid).all().item()),
+                     **({"tokens_per_s_12_layers": round(1e6 / us, 1)} if m == 1 else {"prefill_tokens_per_s_12_layers": round(m * 1e6 / us, 1)})}
+        del g, layers
+    torch.cuda.empty_cache()
+    return out
+
+
 def projected_scaling_leg(torch, dev, G):
     """"if only one GPU is visible, report P > 1 as not measurable here plus the measured per-shard kernel times at N/P shapes".
     This GPU plays rank 0 of P = 2, 4, 8: all of one token's linears at N/P rows (tce_w4a16_shard's row ranges; weights 1/P of the model, still
@@ -859,6 +904,10 @@ def main():
             extras = other_configs_leg(torch, dev)
         except Exception as e:  # noqa: BLE001 -- never takes the headline number down with it
             extras = {"error": f"{type(e).__name__}: {e}"}
+        try:  # BASELINE config 4 as whole OPT-125M decoder layers (graph plans): us and launches per layer
+            extras["w8a8_opt125m_layer"] = opt_layer_leg(torch, dev)
+        except Exception as e:  # noqa: BLE001
+            extras["w8a8_opt125m_layer"] = {"error": f"{type(e).__name__}: {e}"}
         try:  # every launch shape of the token on its own: us, GB/s, fraction of 8 TB/s (same timing method as the roofline leg)
             extras["decode_launch_shapes"] = launch_shape_table(dl, torch)
         except Exception as e:  # noqa: BLE001
