@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(23
     const int T = (nloc + KS - 1) / KS;  // iterations (own k-blocks, the last one may be past the run for quartet 1)
 
     // ---- DMA sources of a half-stage: instruction ii of this wave fills 8 rows; the lane fetches the piece that belongs at its position ----
-    // (uniform 64-bit base + 32-bit lane offset: the address arithmetic of a refill is scalar; the host checked M * lda * 2 < 4 GiB)
+    // (uniform 64-bit base + 32-bit lane offset: the address arithmetic of a refill is scalar; launch_w4a16_gemm_pk refuses M * lda * 2 >= 4 GiB)
     unsigned a_voff[DPW];
 #pragma unroll
     for (int ii = 0; ii < DPW; ++ii) {
@@ -715,6 +715,8 @@ int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_
     if (d.K % 128 != 0 || !packed) return TCE_ERR_UNSUPPORTED_SHAPE;
     const int lda = d.lda ? d.lda : d.K;
     if ((lda * 2) % 16 != 0 || (reinterpret_cast<uintptr_t>(d.A) & 15)) return TCE_ERR_UNSUPPORTED_SHAPE;  // 16-byte DMA pieces
+    // the activation DMAs address rows as a 32-bit byte offset from a uniform base: a batch beyond 4 GiB of activations goes to the other GEMM kernel
+    if ((unsigned long long)d.M * (unsigned long long)lda * 2ull >= (1ull << 32)) return TCE_ERR_UNSUPPORTED_SHAPE;
     PkGemmArgs g{};
     const unsigned char *base = static_cast<const unsigned char *>(packed);
     g.A = static_cast<const half_t *>(d.A);

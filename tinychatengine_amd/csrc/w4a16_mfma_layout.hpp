@@ -32,7 +32,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define TCE_HD __host__ __device__ inline
 #else
 #define TCE_HD inline
