@@ -461,13 +461,15 @@ def whole_token_leg(torch, dev, shape, dl):
     hid = torch.randn(1, shape.hidden, device=dev).to(torch.float16)
     hid0 = hid.clone()
     out = {"launches_per_token": shape.layers * DecoderBlock.LAUNCHES + 1, "layers": shape.layers, "query_heads": heads, "kv_heads": kv_heads,
-           "note": "the attention step is captured at a fixed position (tce_attention_decode_step_*_f16 takes `pos` by value): a decode loop re-captures or updates the node per token"}
+           "note": "the position lives in a device word (tce_attention_decode_step_pos_f16): the captured token is replayable for growing contexts; timed at a fixed context"}
+    pos_t = torch.zeros(1, dtype=torch.int32, device=dev)
     for ctx in (512, 2048):
         pos = ctx - 1
+        pos_t.fill_(pos)
         def token():
             hid.copy_(hid0)
             for b in blocks:
-                b.step(hid, pos)
+                b.step(hid, pos, pos_device=pos_t)
             capi.check(capi.w4a16_forward(dl.lm_head.desc(hid, dl.logits), torch.cuda.current_stream().cuda_stream))
         token()
         torch.cuda.synchronize()

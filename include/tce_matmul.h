@@ -174,6 +174,14 @@ TCE_API int tce_attention_decode_step_gqa_f16(const void *qkv, void *k_cache, vo
                                               void *out, void *workspace, int heads, int kv_heads, int head_dim, int max_keys, int pos,
                                               unsigned short alpha_half_bits, void *stream);
 TCE_API int tce_attention_decode_describe_gqa(int heads, int kv_heads, int keys, char *buf, int buf_len);
+/* The same step with the position read ON THE DEVICE: `pos_device` (int32, device memory) holds the token's position when the kernel runs, `pos_bound` >= every
+ * value it will hold while this launch is replayed (the grid and the chunk length are cut for pos_bound; workgroups of chunks past the actual context leave at
+ * once).  A launch captured into a hipGraph is then replayable token after token -- the host (or a one-thread kernel in the same graph) advances the word -- where
+ * the by-value entry points bake the position into the graph node.  pos_device == NULL: pos_bound is the position (the by-value form).  `mask`, if given, must
+ * cover pos_bound + 1 keys. */
+TCE_API int tce_attention_decode_step_pos_f16(const void *qkv, void *k_cache, void *v_cache, const void *cos_table, const void *sin_table, const void *mask,
+                                              void *out, void *workspace, int heads, int kv_heads, int head_dim, int max_keys, const int32_t *pos_device,
+                                              int pos_bound, unsigned short alpha_half_bits, void *stream);
 /* Reads [ptr, ptr + bytes) with at most `workgroups` workgroups (0 = as many as the range needs) and discards the data: the
  * range then sits in the memory-side cache (256 MiB) for the launch that needs it.  Meant for a side stream / graph branch
  * next to the launch BEFORE that one (no reference counterpart: cudaMallocManaged prefetching is the closest idea). */

@@ -393,6 +393,45 @@ def test_attention_decode_step_ignores_inf_nan_bits_behind_the_position(dev, ora
         assert np.all(np.abs(got - ref) <= tol), f"pos {pos}"
 
 
+@pytest.mark.parametrize("heads,kv_heads,bound", [(32, 8, 700), (8, 8, 300), (4, 1, 2100)])
+def test_attention_decode_step_with_the_position_on_the_device(dev, oracle, heads, kv_heads, bound):
+    """tce_attention_decode_step_pos_f16: ONE captured launch (cut for the bound) replayed for growing contexts -- a one-element device tensor holds
+    the position -- must equal the by-value entry point at every position: the appended rows bit for bit, the outputs within the merge's
+    reassociation (the two forms may cut a short context into different chunks)."""
+    from tinychatengine_amd.attention_ops import DecodeAttention
+    hd = 128
+    rng = np.random.default_rng(bound)
+    cos, sin = _rope_tables(bound + 1, hd, 5)
+    tc, ts = torch.from_numpy(cos).to(dev), torch.from_numpy(sin).to(dev)
+    a_dev = DecodeAttention(heads, hd, bound + 1, dev, tc, ts, kv_heads=kv_heads)
+    a_val = DecodeAttention(heads, hd, bound + 1, dev, tc, ts, kv_heads=kv_heads)
+    K = (rng.standard_normal((kv_heads, bound + 1, hd)) * 0.8).astype(np.float16)
+    V = (rng.standard_normal((kv_heads, bound + 1, hd)) * 0.8).astype(np.float16)
+    for a_ in (a_dev, a_val):
+        a_.k_cache.copy_(torch.from_numpy(K)); a_.v_cache.copy_(torch.from_numpy(V))
+    qkv = torch.from_numpy((rng.standard_normal((heads + 2 * kv_heads) * hd) * 0.9).astype(np.float16)).to(dev)
+    pos_t = torch.zeros(1, dtype=torch.int32, device=dev)
+    out_dev = torch.empty((heads, hd), dtype=torch.float16, device=dev)
+    a_dev.step(qkv, bound, out=out_dev, pos_device=pos_t)  # warm-up outside the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        a_dev.step(qkv, bound, out=out_dev, pos_device=pos_t)
+    for pos in (0, 1, 15, 16, 63, 64, 255, 256, 257, bound // 2, bound - 1, bound):
+        if pos > bound:
+            continue
+        for a_ in (a_dev, a_val):  # both start from the same past (a step appends its row at `pos`)
+            a_.k_cache.copy_(torch.from_numpy(K)); a_.v_cache.copy_(torch.from_numpy(V))
+        pos_t.fill_(pos)
+        g.replay()
+        want = a_val.step(qkv, pos)
+        torch.cuda.synchronize()
+        assert torch.equal(a_dev.k_cache, a_val.k_cache) and torch.equal(a_dev.v_cache, a_val.v_cache), f"pos {pos}: caches differ"
+        got, ref = out_dev.float().cpu().numpy(), want.float().cpu().numpy()
+        tol = 2e-3 * np.abs(ref).max(axis=1, keepdims=True) + 2.0 ** -10 * np.abs(ref)
+        assert np.isfinite(got).all() and np.all(np.abs(got - ref) <= tol), f"pos {pos}: worst |err|/tol = {(np.abs(got - ref) / tol).max():.3f}"
+
+
 def test_attention_decode_step_argument_checks(dev):
     from tinychatengine_amd import capi
     L = capi.lib()

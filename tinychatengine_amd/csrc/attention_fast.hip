@@ -39,7 +39,9 @@ struct FastAttnArgs {
     half_t *out;          // [q_heads][hd]
     float *part;          // [q_heads][chunks][2 + hd]
     unsigned *cnt;        // [kv_heads], zero between launches
-    int heads, kv_heads, rep, hd, max_keys, pos, keys, chunk, chunks;  // heads = query heads, rep = heads / kv_heads
+    int heads, kv_heads, rep, hd, max_keys, pos, keys, chunk, chunks;  // heads = query heads, rep = heads / kv_heads; chunks = chunk slots of the grid
+    const int *pos_dev;   // non-null: the position is read from this device word (a captured launch replayed token after token); pos / keys above
+                          // then only bound it (the grid and the chunk length were cut for them)
     float alpha;
 };
 
@@ -85,12 +87,18 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fast_kernel(const FastAtt
     // grp: this workgroup's group of R consecutive query heads (R == rep: all the query heads of a key / value head, its cache rows streamed
     // once for all of them; R < rep: rep / R workgroups read the same cache rows -- from HBM once, the others from the memory-side cache)
     const int grp = blockIdx.x / a.chunks, c = blockIdx.x - grp * a.chunks;
+    // the position: by value, or from a device word (wave-uniform scalar load) -- then chunks past the context have nothing to do and the
+    // head's combine expects only the chunks that exist
+    const int pos = a.pos_dev ? __builtin_amdgcn_readfirstlane(*a.pos_dev) : a.pos;
+    const int keys = pos + 1;
+    const int chunks = a.pos_dev ? (keys + a.chunk - 1) / a.chunk : a.chunks;  // active chunks (<= the grid's chunk slots)
+    if (c >= chunks) return;
     const int head = (grp * R) / a.rep;  // the key / value head
     const bool appends = (grp * R) % a.rep == 0;  // one workgroup group per key / value head writes the token's row into the caches
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int slot = lane >> 4, piece = lane & 15;
-    const int key0 = c * a.chunk, key1 = key0 + a.chunk < a.keys ? key0 + a.chunk : a.keys;
-    const half_t *cosr = a.cosv ? a.cosv + (size_t)a.pos * kHD : nullptr, *sinr = a.sinv ? a.sinv + (size_t)a.pos * kHD : nullptr;
+    const int key0 = c * a.chunk, key1 = key0 + a.chunk < keys ? key0 + a.chunk : keys;
+    const half_t *cosr = a.cosv ? a.cosv + (size_t)pos * kHD : nullptr, *sinr = a.sinv ? a.sinv + (size_t)pos * kHD : nullptr;
     const size_t hoff = (size_t)head * kHD;
     // ---- this wave's keys: chunk / 4 consecutive ones, 4 per step.  Their addresses depend on nothing but the arguments, so the
     //      first block of cache rows is requested BEFORE q / cos / sin: one memory round trip per launch instead of two (the
@@ -109,7 +117,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fast_kernel(const FastAtt
 #pragma unroll
         for (int u = 0; u < BLK; ++u) {
             const int key = kw0 + it0 + u * 4 + slot;
-            const int kk = key < kw1 ? key : (a.keys - 1);  // clamped: rows past the range are read (harmlessly) and weigh nothing
+            const int kk = key < kw1 ? key : (keys - 1);  // clamped: rows past the range are read (harmlessly) and weigh nothing
             kd[u] = *reinterpret_cast<const half8_t *>(kbase + (size_t)kk * kHD + piece * 8);
             vd[u] = *reinterpret_cast<const half8_t *>(vbase + (size_t)kk * kHD + piece * 8);
             if constexpr (MASK) md[u] = a.mask[kk];
@@ -144,9 +152,9 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fast_kernel(const FastAtt
         if (slot == 0) {
             *reinterpret_cast<half8_t *>(&newrow[0][piece * 8]) = kh;
             *reinterpret_cast<half8_t *>(&newrow[1][piece * 8]) = vh;
-            if (appends && a.pos >= key0 && a.pos < key1) {
-                *reinterpret_cast<half8_t *>(a.kc + ((size_t)head * a.max_keys + a.pos) * kHD + piece * 8) = kh;
-                *reinterpret_cast<half8_t *>(a.vc + ((size_t)head * a.max_keys + a.pos) * kHD + piece * 8) = vh;
+            if (appends && pos >= key0 && pos < key1) {
+                *reinterpret_cast<half8_t *>(a.kc + ((size_t)head * a.max_keys + pos) * kHD + piece * 8) = kh;
+                *reinterpret_cast<half8_t *>(a.vc + ((size_t)head * a.max_keys + pos) * kHD + piece * 8) = vh;
             }
         }
     }
@@ -165,7 +173,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fast_kernel(const FastAtt
             const int key = kw0 + it0 + u * 4 + slot;
             const bool valid = key < kw1;
             half8_t kv = kd[u], vv = vd[u];
-            if (key == a.pos) {  // the token's own row: not necessarily visible in the cache yet
+            if (key == pos) {  // the token's own row: not necessarily visible in the cache yet
                 kv = *reinterpret_cast<const half8_t *>(&newrow[0][piece * 8]);
                 vv = *reinterpret_cast<const half8_t *>(&newrow[1][piece * 8]);
             }
@@ -234,7 +242,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fast_kernel(const FastAtt
         }
     }
     const size_t qoff = (size_t)grp * R * kHD;  // the first of this workgroup's query heads in `out`
-    if (a.chunks == 1) {
+    if (chunks == 1) {
         if (tid < kHD) {
 #pragma unroll
             for (int r = 0; r < R; ++r) a.out[qoff + r * kHD + tid] = (half_t)(O[r] / Lq[r]);
@@ -245,7 +253,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fast_kernel(const FastAtt
     if (tid < kHD) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            float *mine = a.part + ((size_t)(grp * R + r) * a.chunks + c) * (2 + kHD);
+            float *mine = a.part + ((size_t)(grp * R + r) * chunks + c) * (2 + kHD);
             __hip_atomic_store(mine + 2 + tid, O[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through (sc1) stores
             if (tid == 0) {
                 __hip_atomic_store(mine, M[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -257,7 +265,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fast_kernel(const FastAtt
     __syncthreads();
     if (tid == 0) {
         const unsigned old = __hip_atomic_fetch_add(a.cnt + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last_flag = old == (unsigned)a.chunks - 1 ? 1u : 0u;
+        last_flag = old == (unsigned)chunks - 1 ? 1u : 0u;
         if (last_flag) __hip_atomic_store(a.cnt + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
     }
     __syncthreads();
@@ -268,8 +276,8 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fast_kernel(const FastAtt
     constexpr int kMaxChunksUnrolled = 16;
     float *ml = &st[0][0][0];  // [R][chunks][2], reuses the state area
     const int stride = (2 + kHD) * 4;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.part + (size_t)grp * R * a.chunks * (2 + kHD), 0, (int)((size_t)R * a.chunks * stride), 0x00020000);
-    for (int i = tid; i < R * a.chunks; i += NT) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.part + (size_t)grp * R * chunks * (2 + kHD), 0, (int)((size_t)R * chunks * stride), 0x00020000);
+    for (int i = tid; i < R * chunks; i += NT) {
         ml[2 * i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, i * stride, 0, /*sc0|sc1*/ 17));
         ml[2 * i + 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, i * stride + 4, 0, 17));
     }
@@ -279,28 +287,28 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fast_kernel(const FastAtt
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int i = 0; i < kMaxChunksUnrolled; ++i)
-                oi[r][i] = i < a.chunks ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (r * a.chunks + i) * stride + (2 + tid) * 4, 0, 17)) : 0.f;
+                oi[r][i] = i < chunks ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (r * chunks + i) * stride + (2 + tid) * 4, 0, 17)) : 0.f;
     }
     __syncthreads();
     if (tid < kHD) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const float *mlr = ml + 2 * r * a.chunks;
+            const float *mlr = ml + 2 * r * chunks;
             float Mx = kNegBig;
-            for (int i = 0; i < a.chunks; ++i) Mx = __builtin_fmaxf(Mx, mlr[2 * i]);
+            for (int i = 0; i < chunks; ++i) Mx = __builtin_fmaxf(Mx, mlr[2 * i]);
             float Lx = 0.f, Ox = 0.f;
 #pragma unroll
             for (int i = 0; i < kMaxChunksUnrolled; ++i) {
-                if (i < a.chunks) {
+                if (i < chunks) {
                     const float w = __expf(mlr[2 * i] - Mx);
                     Lx += mlr[2 * i + 1] * w;
                     Ox += oi[r][i] * w;
                 }
             }
-            for (int i = kMaxChunksUnrolled; i < a.chunks; ++i) {  // many chunks: the rest one by one
+            for (int i = kMaxChunksUnrolled; i < chunks; ++i) {  // many chunks: the rest one by one
                 const float w = __expf(mlr[2 * i] - Mx);
                 Lx += mlr[2 * i + 1] * w;
-                Ox += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (r * a.chunks + i) * stride + (2 + tid) * 4, 0, 17)) * w;
+                Ox += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (r * chunks + i) * stride + (2 + tid) * 4, 0, 17)) * w;
             }
             a.out[qoff + r * kHD + tid] = (half_t)(Ox / Lx);
         }
@@ -385,7 +393,8 @@ size_t attention_decode_workspace_bytes(int heads, int max_keys, int hd) {
 }
 
 int launch_attention_decode_fast(const void *qkv, void *kc, void *vc, const void *cosv, const void *sinv, const void *mask, void *out, void *workspace,
-                                 int heads, int kv_heads, int hd, int max_keys, int pos, unsigned short alpha_bits, hipStream_t stream, hipError_t *hip_err) {
+                                 int heads, int kv_heads, int hd, int max_keys, int pos, unsigned short alpha_bits, hipStream_t stream, hipError_t *hip_err,
+                                 const int *pos_dev) {
     if (hd != kHD || kv_heads <= 0 || heads % kv_heads != 0) return TCE_ERR_UNSUPPORTED_SHAPE;
     const int rep = heads / kv_heads;
 
@@ -408,6 +417,7 @@ int launch_attention_decode_fast(const void *qkv, void *kc, void *vc, const void
     a.max_keys = max_keys;
     a.pos = pos;
     a.keys = pos + 1;
+    a.pos_dev = pos_dev;
     int nw = 4;
     pick_chunk(heads / fuse, a.keys, &a.chunk, &nw);
     a.chunks = (a.keys + a.chunk - 1) / a.chunk;

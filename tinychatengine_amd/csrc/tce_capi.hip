@@ -717,6 +717,11 @@ int tce_attention_decode_step_f16(const void *qkv, void *kc, void *vc, const voi
 
 int tce_attention_decode_step_gqa_f16(const void *qkv, void *kc, void *vc, const void *cosv, const void *sinv, const void *mask, void *out, void *workspace, int heads,
                                       int kv_heads, int hd, int max_keys, int pos, unsigned short alpha_bits, void *stream) {
+    return tce_attention_decode_step_pos_f16(qkv, kc, vc, cosv, sinv, mask, out, workspace, heads, kv_heads, hd, max_keys, nullptr, pos, alpha_bits, stream);
+}
+
+int tce_attention_decode_step_pos_f16(const void *qkv, void *kc, void *vc, const void *cosv, const void *sinv, const void *mask, void *out, void *workspace, int heads,
+                                      int kv_heads, int hd, int max_keys, const int32_t *pos_device, int pos, unsigned short alpha_bits, void *stream) {
     if (!qkv || !kc || !vc || !out || !workspace) return fail(TCE_ERR_BAD_ARG, "tce_attention_decode_step_f16: null pointer");
     if ((cosv == nullptr) != (sinv == nullptr)) return fail(TCE_ERR_BAD_ARG, "tce_attention_decode_step_f16: cos and sin tables come together");
     if (heads <= 0 || max_keys <= 0 || pos < 0 || pos >= max_keys) return fail(TCE_ERR_BAD_ARG, "tce_attention_decode_step_f16: need heads > 0 and 0 <= pos < max_keys");
@@ -725,7 +730,7 @@ int tce_attention_decode_step_gqa_f16(const void *qkv, void *kc, void *vc, const
     for (const void *p : {qkv, (const void *)kc, (const void *)vc, cosv, sinv})
         if (reinterpret_cast<uintptr_t>(p) & 15) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_attention_decode_step_f16: 16-byte aligned pointers");
     hipError_t he = hipSuccess;
-    const int rc = tce::launch_attention_decode_fast(qkv, kc, vc, cosv, sinv, mask, out, workspace, heads, kv_heads, hd, max_keys, pos, alpha_bits, static_cast<hipStream_t>(stream), &he);
+    const int rc = tce::launch_attention_decode_fast(qkv, kc, vc, cosv, sinv, mask, out, workspace, heads, kv_heads, hd, max_keys, pos, alpha_bits, static_cast<hipStream_t>(stream), &he, pos_device);
     return rc == TCE_ERR_HIP ? hip_fail(he, "attention decode step launch") : rc;
 }
 

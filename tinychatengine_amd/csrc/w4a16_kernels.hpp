@@ -170,7 +170,8 @@ void set_attention_fast_fuse(int r);
 void describe_attention_decode_fast(int heads, int keys, int *chunk, int *chunks, int *waves, int kv_heads = 0);
 size_t attention_decode_workspace_bytes(int heads, int max_keys, int hd);
 int launch_attention_decode_fast(const void *qkv, void *kc, void *vc, const void *cosv, const void *sinv, const void *mask, void *out, void *workspace,
-                                 int heads, int kv_heads, int hd, int max_keys, int pos, unsigned short alpha_bits, hipStream_t stream, hipError_t *hip_err);
+                                 int heads, int kv_heads, int hd, int max_keys, int pos, unsigned short alpha_bits, hipStream_t stream, hipError_t *hip_err,
+                                 const int *pos_dev = nullptr);
 int launch_rope_half(void *q, void *k, const void *cosv, const void *sinv, int heads, int len, int hd, int start_idx, hipStream_t stream, hipError_t *hip_err);
 int launch_softmax_half(const void *x, void *out, long long rows, int n, hipStream_t stream, hipError_t *hip_err);
 int launch_prefetch(const void *ptr, long long bytes, int workgroups, hipStream_t stream, hipError_t *hip_err);

@@ -47,11 +47,12 @@ class DecoderBlock:
         e = lambda n: torch.empty((1, n), dtype=torch.float16, device=device)
         self.qkv_out, self.attn_out, self.act = e((heads + 2 * self.kv_heads) * 128), e(hidden), e(ffn)
 
-    def step(self, hidden_state: torch.Tensor, pos: int) -> None:
-        """hidden_state fp16 [1][hidden], updated in place (it is the residual stream)."""
+    def step(self, hidden_state: torch.Tensor, pos: int, pos_device: torch.Tensor | None = None) -> None:
+        """hidden_state fp16 [1][hidden], updated in place (it is the residual stream).  pos_device: the position on the device (`pos` then
+        bounds it): the five launches can be captured once and replayed token after token."""
         st = _stream()
         capi.check(capi.w4a16_forward(self.qkv.desc(hidden_state, self.qkv_out, gamma=self.gamma1, eps=self.eps), st))
-        self.attention.step(self.qkv_out.view(-1), pos, out=self.attn_out.view(self.heads, 128))
+        self.attention.step(self.qkv_out.view(-1), pos, out=self.attn_out.view(self.heads, 128), pos_device=pos_device)
         capi.check(capi.w4a16_forward(self.o.desc(self.attn_out, hidden_state, flags=capi.TCE_W4_ADD_TO_C), st))
         capi.check(capi.w4a16_forward(self.gate_up.desc(hidden_state, self.act, flags=capi.TCE_W4_SILU_MUL_PAIRS, gamma=self.gamma2, eps=self.eps), st))
         capi.check(capi.w4a16_forward(self.down.desc(self.act, hidden_state, flags=capi.TCE_W4_ADD_TO_C), st))
