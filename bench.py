@@ -757,6 +757,38 @@ def main():
                         n_launches = 2
                         mode = ("one persistent kernel per token: the 129 launches walked by the same workgroups, the linears' data flow ordered by tagged "
                                 "output words (TCE_PLAN_TAGGED) + a one-thread kernel that advances the tag")
+                    try:  # round 3: the same data flow as ONE KERNEL PER LAUNCH on two alternating graph branches (TCE_PLAN_OVERLAPPED, csrc/w4a16_gemv_ovl.hip)
+                        oplan = dl.make_plan(overlapped=True)
+                        if not oplan.overlapped:
+                            variants["overlapped launches (TCE_PLAN_OVERLAPPED)"] = {"rejected": f"built as kind {oplan.kind}"}
+                        else:
+                            bad = None
+                            for rep in range(3):
+                                for o in outs:
+                                    o.fill_(float("nan"))
+                                oplan.launch(stream)
+                                oplan.status()
+                                if not all(torch.equal(a.view(torch.int16), b.view(torch.int16)) for a, b in zip(want, outs)):
+                                    bad = f"outputs differ from the stream-ordered plan (replay {rep})"
+                                    break
+                            if bad:
+                                variants["overlapped launches (TCE_PLAN_OVERLAPPED)"] = {"rejected": bad}
+                            else:
+                                ms_o = rate(lambda: oplan.launch(stream), max(50, args.steps // 2))
+                                oplan.status()
+                                variants["overlapped launches (TCE_PLAN_OVERLAPPED)"] = {"ms_per_token": round(ms_o, 4), "tokens_per_s": round(1e3 / ms_o, 1),
+                                                                                          "verified": "all outputs of the token bit-identical to the stream-ordered plan, 3 replays"}
+                                if ms_o < min(ms_g, ms_t) and args.issue == "auto":
+                                    step = lambda: oplan.launch(stream)
+                                    n_launches = plan.n_launches + 1
+                                    mode = "one kernel per launch on two alternating graph branches, the data flow ordered by tagged output words (TCE_PLAN_OVERLAPPED)"
+                    except Exception as e:  # noqa: BLE001
+                        variants["overlapped launches (TCE_PLAN_OVERLAPPED)"] = {"rejected": f"{type(e).__name__}: {e}"}
+                        try:
+                            capi.lib().tce_reset_last_error()
+                            torch.cuda.synchronize()
+                        except Exception:  # noqa: BLE001
+                            pass
             except SystemExit:
                 raise
             except Exception as e:  # noqa: BLE001
