@@ -2,6 +2,8 @@
 kernels/ref/matmul_ref_int8.cc (the reference's own tests demand check_two_exact_equal for int8 outputs,
 llm/tests/non_cuda/test_ops.cc:204,238,340,373).  Shapes and scalar constants are the reference's test shapes
 (test_ops.cc:177-209, 245-276, 311-345, 380-410, 444-473) plus the edge cases it exercises implicitly."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -177,7 +179,7 @@ def test_unsupported_kind_is_rejected(dev):
     assert capi.w8a8_matmul(d, 0) == capi.TCE_ERR_UNSUPPORTED_KIND
 
 
-@pytest.mark.parametrize("m,n", [(108, 768), (1, 768), (512, 768), (65, 1024), (3, 2048), (7, 20)])
+@pytest.mark.parametrize("m,n", [(108, 768), (1, 768), (512, 768), (65, 1024), (3, 2048), (7, 20), (5, 772), (2, 36), (3, 60), (1, 8192), (4, 4)])
 def test_layernorm_q_bit_exact(dev, oracle, m, n):
     """tce_layernorm_q against the oracle's restatement of LayerNormQ::forward (LayerNormQ.cc:12-52): bit for bit."""
     import ctypes as C
@@ -348,3 +350,102 @@ def test_w8a8_leading_dimensions_and_accumulate(dev, oracle):
     bad = capi.W8A8Desc(M=4, N=4, K=16, batch=1, A=tA.data_ptr(), B=tB.data_ptr(), C=tC.data_ptr(), alpha=1.0, q_min=-128, q_max=127, bias_kind=capi.TCE_BIAS_NONE,
                         out_kind=capi.TCE_OUT_FP32, lda=8)
     assert capi.w8a8_matmul(bad, None) == capi.TCE_ERR_BAD_ARG
+
+
+@pytest.mark.parametrize("M,N,K,lda,ldc,batch", [(1, 768, 3072, 0, 0, 1), (1, 768, 768, 0, 0, 1), (8, 100, 8192, 0, 0, 1), (2, 19, 64, 128, 40, 1), (3, 130, 272, 288, 0, 3),
+                                                 (8, 64, 8208, 0, 0, 1), (5, 3, 80, 96, 8, 2)])
+def test_decode_sized_wave_per_column_kernel_bit_exact(dev, oracle, M, N, K, lda, ldc, batch):
+    """M <= 8 rows: one wave per output column (w8a8_rowdot_kernel<0>), against the oracle and against the MFMA / generic kernels it replaces (debug mode
+    73), every epilogue: int8 with bias and ReLU floor, fp32 with bias and `accumulate`; leading dimensions, a batch, an N that is not a multiple of the
+    workgroup's four columns, M * K on both sides of the 64 KiB LDS bound (8 x 8208 stays on the MFMA kernel)."""
+    from tinychatengine_amd import capi
+    rng = np.random.default_rng(M * 1000 + N + K)
+    la, lc = lda or K, ldc or N
+    A = rng.integers(-128, 128, (batch, M, la), dtype=np.int8)
+    B = rng.integers(-128, 128, (batch, N, K), dtype=np.int8)
+    b8 = rng.integers(-128, 128, N, dtype=np.int8)
+    bf = rng.standard_normal(N).astype(np.float32)
+    C0 = rng.standard_normal((batch, M, lc)).astype(np.float32)
+    tA, tB, tb8, tbf = _t(dev, A), _t(dev, B), _t(dev, b8), _t(dev, bf)
+    st = torch.cuda.current_stream().cuda_stream
+    alpha = 0.0007 if K > 1000 else 0.004
+    for mode in (70, 73):
+        capi.check(capi.lib().tce_w4a16_set_debug_mode(mode))
+        try:
+            o8 = torch.zeros((batch, M, lc), dtype=torch.int8, device=dev)
+            d = capi.W8A8Desc(M=M, N=N, K=K, batch=batch, A=tA.data_ptr(), B=tB.data_ptr(), bias=tb8.data_ptr(), C=o8.data_ptr(), strideA=M * la, strideB=N * K, strideC=M * lc,
+                              alpha=alpha, beta=0.02, q_min=0, q_max=127, bias_kind=capi.TCE_BIAS_INT8, out_kind=capi.TCE_OUT_INT8, lda=lda, ldc=ldc)
+            capi.check(capi.w8a8_matmul(d, st))
+            of = _t(dev, C0.copy())
+            d = capi.W8A8Desc(M=M, N=N, K=K, batch=batch, A=tA.data_ptr(), B=tB.data_ptr(), bias=tbf.data_ptr(), C=of.data_ptr(), strideA=M * la, strideB=N * K, strideC=M * lc,
+                              alpha=alpha, q_min=-128, q_max=127, bias_kind=capi.TCE_BIAS_FP32, out_kind=capi.TCE_OUT_FP32, lda=lda, ldc=ldc, accumulate=1)
+            capi.check(capi.w8a8_matmul(d, st))
+            torch.cuda.synchronize()
+        finally:
+            capi.lib().tce_w4a16_set_debug_mode(70)
+        for h in range(batch):
+            Ah = np.ascontiguousarray(A[h, :, :K])
+            want8 = oracle.int8_matmul_bias_i8(Ah, B[h], b8, alpha, 0.02, 0, 127, M, N, K)
+            assert np.array_equal(o8[h, :, :N].cpu().numpy(), want8), (mode, h, "int8")
+            wantf = C0[h, :, :N] + oracle.int8_matmul_bias_f32(Ah, B[h], bf, alpha, M, N, K)
+            assert np.array_equal(of[h, :, :N].cpu().numpy().view(np.uint32), wantf.view(np.uint32)), (mode, h, "fp32 accumulate")
+            if lc > N:  # nothing outside the N columns was touched
+                assert np.array_equal(of[h, :, N:].cpu().numpy(), C0[h, :, N:]) and not o8[h, :, N:].any()
+
+
+@pytest.mark.parametrize("M,N,K,lda,ldb", [(12, 64, 512, 512, 512), (12, 64, 400, 400, 2048), (3, 5, 272, 288, 320), (32, 128, 4096, 0, 0)])
+def test_per_row_operand_with_long_rows_bit_exact(dev, oracle, M, N, K, lda, ldb):
+    """The *_batch form (row m of A meets its own B_m; BMM_S8T_S8N_S8T.cc:45-52) with K >= 256: one wave per output element (w8a8_rowdot_kernel<1>) --
+    the probabilities x V^T product of a decode step, V^T rows `max_keys` apart -- against the oracle and the one-thread-per-output kernel (mode 73)."""
+    from tinychatengine_amd import capi
+    rng = np.random.default_rng(M + N + K)
+    la, lb = lda or K, ldb or K
+    A = rng.integers(-128, 128, (M, la), dtype=np.int8)
+    B = rng.integers(-128, 128, (M, N, lb), dtype=np.int8)
+    tA, tB = _t(dev, A), _t(dev, B)
+    st = torch.cuda.current_stream().cuda_stream
+    Bc = np.ascontiguousarray(B[:, :, :K])
+    want8 = oracle.int8_matmul_nobias_i8(np.ascontiguousarray(A[:, :K]), Bc, 0.0009, -128, 127, M, N, K, batch=True)
+    wantf = oracle.int8_matmul_nobias_f32(np.ascontiguousarray(A[:, :K]), Bc, 0.0009, M, N, K, batch=True)
+    for mode in (70, 73):
+        capi.check(capi.lib().tce_w4a16_set_debug_mode(mode))
+        try:
+            o8 = torch.zeros((M, N), dtype=torch.int8, device=dev)
+            d = capi.W8A8Desc(M=M, N=N, K=K, batch=1, A=tA.data_ptr(), B=tB.data_ptr(), C=o8.data_ptr(), alpha=0.0009, q_min=-128, q_max=127, bias_kind=capi.TCE_BIAS_NONE,
+                              out_kind=capi.TCE_OUT_INT8, b_per_row=1, strideB=N * lb, lda=lda, ldb=ldb)
+            capi.check(capi.w8a8_matmul(d, st))
+            of = torch.zeros((M, N), dtype=torch.float32, device=dev)
+            d.C, d.out_kind = of.data_ptr(), capi.TCE_OUT_FP32
+            capi.check(capi.w8a8_matmul(d, st))
+            torch.cuda.synchronize()
+        finally:
+            capi.lib().tce_w4a16_set_debug_mode(70)
+        assert np.array_equal(o8.cpu().numpy(), want8), mode
+        assert np.array_equal(of.cpu().numpy().view(np.uint32), wantf.view(np.uint32)), mode
+
+
+@pytest.mark.parametrize("heads,sq,tgz,scale", [(12, 1, 512, 3.0), (12, 1, 512, 0.05), (4, 7, 33, 2.0), (2, 3, 1, 1.0), (3, 2, 5, 0.2), (2, 5, 100, 0.3), (1, 4, 511, 4.0), (2, 2, 513, 0.1),
+                                                (1, 1, 4000, 1.0)])
+def test_opt_softmax_q_against_the_oracle(dev, oracle, heads, sq, tgz, scale):
+    """tce_opt_softmax_q on its own against orc_opt_softmax_q (pinned to the reference's softmax.cc run in place: tests/test_oracle_glue.py): rows whose own
+    maximum is >= 1 (they do not wait for row (0, 0)'s first probability) and rows below it (small `scale`: they start their maximum from that probability),
+    lengths that are not multiples of 4 / 16 / 32, a causal mask, padded output rows.  The device's expf may differ from libm's in the last bit: at most one
+    int8 step on a few elements."""
+    from tinychatengine_amd import capi
+    rng = np.random.default_rng(heads * 100 + tgz)
+    scores = (rng.standard_normal((heads, sq, tgz)) * scale).astype(np.float32)
+    mask = np.zeros((sq, tgz), np.float32)
+    for j in range(sq):
+        if tgz - sq + j + 1 < tgz:
+            mask[j, max(1, tgz - sq + j + 1):] = np.finfo(np.float32).min
+    ldp = (tgz + 15) // 16 * 16
+    probs = torch.full((heads, sq, ldp), 77, dtype=torch.int8, device=dev)
+    ts, tm = _t(dev, scores), _t(dev, mask)
+    capi.check(capi.lib().tce_opt_softmax_q(C.c_void_p(ts.data_ptr()), C.c_void_p(tm.data_ptr()), C.c_void_p(probs.data_ptr()), heads, sq, tgz, ldp,
+                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    want = oracle.opt_softmax_q(scores, mask)
+    got = probs.cpu().numpy()
+    diff = np.abs(got[:, :, :tgz].astype(np.int32) - want.astype(np.int32))
+    assert diff.max() <= 1 and (diff > 0).mean() <= max(2e-4, 1.5 / diff.size), f"max step {diff.max()}, {int((diff > 0).sum())} of {diff.size} differ"
+    assert (got[:, :, tgz:] == 77).all()

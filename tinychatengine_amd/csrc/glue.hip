@@ -55,39 +55,64 @@ __global__ __launch_bounds__(512) void rmsnorm_half_kernel(const half_t *x, cons
 
 // LayerNormQ::forward (llm/src/ops/LayerNormQ.cc:12-52): fp32 in, int8 out, in front of the W8A8 linears.  Bit-exact
 // with the reference's CPU loop, which fixes the design: both row sums are SEQUENTIAL fp32 additions.  One wavefront per
-// row: the row is loaded coalesced into LDS, lane 0 walks it for the two sums (16-byte LDS reads, the additions are the
-// critical path: ~2 x n dependent adds), then all lanes produce outputs in parallel (the division, multiply and add are
+// row: the row is loaded coalesced into LDS, the wave walks it for the two sums (broadcast 16-byte LDS reads, the additions are the
+// critical path: ~2 x n dependent adds of 6 cycles), then all lanes produce outputs in parallel (the division, multiply and add are
 // separate roundings: -ffp-contract=off).  n <= 8192.
+template <bool BCAST>
 __global__ __launch_bounds__(64) void layernorm_q_kernel(const float *x, const float *w, const float *b, int8_t *out, int m, int n) {
-    extern __shared__ __attribute__((aligned(16))) float row[];
+    extern __shared__ __attribute__((aligned(16))) float row[];  // [n] the row, [n] its squared deviations
     const int lane = threadIdx.x;
     const float *xr = x + (size_t)blockIdx.x * n;
     int8_t *orow = out + (size_t)blockIdx.x * n;
     const int n4 = n >> 2;  // n % 4 == 0
     for (int p = lane; p < n4; p += 64) reinterpret_cast<float4_t *>(row)[p] = reinterpret_cast<const float4_t *>(xr)[p];
+    // the affine parameters of the lane's outputs, requested now (they are needed behind the two chains; n <= 1024: 16 per lane)
+    constexpr int PF = 16;
+    float pw[PF], pb[PF];
+    const bool prefetched = n <= 64 * PF;
+    if (prefetched) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int k = lane + 64 * i;
+            pw[i] = k < n ? w[k] : 0.f;
+            pb[i] = k < n ? b[k] : 0.f;
+        }
+    }
     __syncthreads();
-    // the two sums in the reference's order (sequential_sum_lane0: one dependent add per element, tce_common.hpp)
-    float mean = sequential_sum_lane0(row, n, lane, [](float v) { return v; });
+    // the two sums in the reference's order (sequential_sum: one dependent add per element, tce_common.hpp); the squared deviations are
+    // computed by all lanes into the second half of the LDS area first
+    float *dev = row + n;
+    float mean = sequential_sum<BCAST>(row, n, lane);
     mean /= (float)n;
-    mean = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, mean)));
-    float sq = sequential_sum_lane0(row, n, lane, [&](float v) {
-        const float d = v - mean;
-        return __fmul_rn(d, d);
-    });
-    float std_dev = sqrtf(sq / (float)n + 0.00001f);
-    mean = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, mean)));
-    std_dev = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, std_dev)));
     for (int k = lane; k < n; k += 64) {
-        const float t = __fdiv_rn(row[k] - mean, std_dev);
-        const float f = __fadd_rn(__fmul_rn(t, w[k]), b[k]);
-        orow[k] = (int8_t)(int)roundf(f);
+        const float d = row[k] - mean;
+        dev[k] = __fmul_rn(d, d);
+    }
+    const float sq = sequential_sum<BCAST>(dev, n, lane);
+    const float std_dev = sqrtf(sq / (float)n + 0.00001f);
+    if (prefetched) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int k = lane + 64 * i;
+            if (k < n) {
+                const float t = __fdiv_rn(row[k] - mean, std_dev);
+                orow[k] = (int8_t)(int)roundf(__fadd_rn(__fmul_rn(t, pw[i]), pb[i]));
+            }
+        }
+    } else {
+        for (int k = lane; k < n; k += 64) {
+            const float t = __fdiv_rn(row[k] - mean, std_dev);
+            const float f = __fadd_rn(__fmul_rn(t, w[k]), b[k]);
+            orow[k] = (int8_t)(int)roundf(f);
+        }
     }
 }
 
 }  // namespace
 
 int launch_layernorm_q(const float *x, const float *w, const float *b, void *out, int m, int n, hipStream_t stream, hipError_t *hip_err) {
-    hipLaunchKernelGGL(layernorm_q_kernel, dim3(m), dim3(64), (size_t)n * sizeof(float), stream, x, w, b, static_cast<int8_t *>(out), m, n);
+    if (m <= kSeqSumBcastMaxWaves) hipLaunchKernelGGL(layernorm_q_kernel<true>, dim3(m), dim3(64), (size_t)2 * n * sizeof(float), stream, x, w, b, static_cast<int8_t *>(out), m, n);
+    else hipLaunchKernelGGL(layernorm_q_kernel<false>, dim3(m), dim3(64), (size_t)2 * n * sizeof(float), stream, x, w, b, static_cast<int8_t *>(out), m, n);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         if (hip_err) *hip_err = e;
@@ -104,53 +129,68 @@ namespace {
 //   max   = the running maximum over k, STARTING from `input.m_data[0]` (softmax.cc:13).  The reference runs its softmax IN PLACE
 //           (Int8OPTAttention.cc:258-260), so that element is the masked score [0][0][0] for row (0, 0) and row (0, 0)'s first
 //           PROBABILITY for every row behind it: a fifth wavefront of every workgroup evaluates row (0, 0) up to that value first
-//   sum   = 0; sum += expf(v_k - max) for k ascending                   (sequential fp32 additions: sequential_sum_lane0)
+//   sum   = 0; sum += expf(v_k - max) for k ascending                   (sequential fp32 additions: sequential_sum_bcast)
 //   p_k   = (float)((double)expf(v_k - max) / ((double)sum + 1e-10))    (softmax.cc:31: the literal 1e-10 makes the quotient a double one)
 //   q_k   = (int8) std::round(p_k * 127)                                (:266; half away from zero)
 // The device's expf is not the host's to the last bit: a probability within a few fp32 steps of a rounding boundary can land on the
 // other side (tests/test_gpu_w8a8.py counts them).
+// Who has to wait for row (0, 0): m_data[0] only enters a row as the START of its running maximum, and a probability is <= 1 (the sum starts with
+// its own first term and only grows), so a row whose own maximum is >= 1 has the same maximum whatever row (0, 0) produced -- such rows run beside
+// the fifth wavefront instead of behind it (finite scores assumed: a NaN in row (0, 0) would poison every maximum in the reference).
+template <bool BCAST>
 __global__ __launch_bounds__(320) void opt_softmax_q_kernel(const float *scores, const float *mask, int8_t *probs, int rows, int sq, int tgz, int ldp) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];  // [5 waves][tgz] + [1]
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // [5 waves][tgz rounded up to 4] + [1] + [4]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float *first_p = sm + (size_t)5 * tgz;
+    const int tgzp = (tgz + 3) & ~3;
+    float *first_p = sm + (size_t)5 * tgzp;
+    int *waits = reinterpret_cast<int *>(first_p + 1);  // [4]: does wave w's row wait for row (0, 0)?
     const int row = wave == 4 ? 0 : blockIdx.x * 4 + wave;  // = h * sq + j; wave 4: row (0, 0), up to its first probability only
     const bool live = row < rows;
-    float *e = sm + (size_t)wave * tgz;
+    float *e = sm + (size_t)wave * tgzp;
     const float *s = scores + (size_t)(live ? row : 0) * tgz;
     const float *mk = mask + (size_t)((live ? row : 0) % sq) * tgz;
     const float v000 = scores[0] + mask[0];
-    // one row up to (max, the exponentials in e[], their sequential sum): `init` = what m_data[0] holds when the reference reaches the row
-    auto row_stats = [&](float init, float &sum_out) {
-        float mx = init;
-        for (int k = lane; k < tgz; k += 64) {
-            const float v = s[k] + mk[k];
-            e[k] = v;
-            mx = v > mx ? v : mx;
-        }
+    // the masked scores into e[] and their maximum
+    float rmax = -__builtin_inff();
+    for (int k = lane; k < tgz; k += 64) {
+        const float v = s[k] + mk[k];
+        e[k] = v;
+        rmax = v > rmax ? v : rmax;
+    }
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const float o = __shfl_xor(mx, off, 64);
-            mx = o > mx ? o : mx;
-        }
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float o = __shfl_xor(rmax, off, 64);
+        rmax = o > rmax ? o : rmax;
+    }
+    // the exponentials in e[] and their sequential sum; `init` = what m_data[0] holds when the reference reaches the row (softmax.cc:13):
+    // max over {init, v_0, v_1, ...} by `v > max` comparisons equals max(init, rmax) for finite values
+    auto finish_stats = [&](float init) -> float {
+        const float mx = rmax > init ? rmax : init;
         for (int k = lane; k < tgz; k += 64) e[k] = expf(e[k] - mx);
-        float sum = sequential_sum_lane0(e, tgz, lane, [](float v) { return v; });
-        sum_out = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sum)));
+        return sequential_sum<BCAST>(e, tgz, lane);
     };
+    auto write_row = [&](float sum) {
+        const double denom = (double)sum + 1e-10;
+        int8_t *out = probs + (size_t)row * ldp;
+        for (int k = lane; k < tgz; k += 64) {
+            const float p = (float)((double)e[k] / denom);
+            out[k] = (int8_t)(int)roundf(p * 127.0f);
+        }
+    };
+    const bool independent = row == 0 || rmax >= 1.0f;  // wave-uniform
+    if (wave < 4 && lane == 0) waits[wave] = live && !independent;
+    __syncthreads();
     if (wave == 4) {
-        float sum;
-        row_stats(v000, sum);
-        if (lane == 0) *first_p = (float)((double)e[0] / ((double)sum + 1e-10));
+        if (waits[0] | waits[1] | waits[2] | waits[3]) {  // somebody needs row (0, 0)'s first probability
+            const float sum = finish_stats(v000);
+            if (lane == 0) *first_p = (float)((double)e[0] / ((double)sum + 1e-10));
+        }
+    } else if (live && independent) {
+        write_row(finish_stats(row == 0 ? v000 : rmax));
     }
     __syncthreads();
-    if (wave == 4 || !live) return;
-    float sum;
-    row_stats(row == 0 ? v000 : *first_p, sum);
-    const double denom = (double)sum + 1e-10;
-    int8_t *out = probs + (size_t)row * ldp;
-    for (int k = lane; k < tgz; k += 64) {
-        const float p = (float)((double)e[k] / denom);
-        out[k] = (int8_t)(int)roundf(p * 127.0f);
-    }
+    if (wave == 4 || !live || independent) return;
+    write_row(finish_stats(*first_p));
 }
 
 __global__ __launch_bounds__(256) void opt_kv_append_kernel(const int8_t *k, const int8_t *v, int8_t *kc, int8_t *vt, int heads, int hd, int sq, int pos, int max_keys) {
@@ -166,7 +206,17 @@ __global__ __launch_bounds__(256) void opt_kv_append_kernel(const int8_t *k, con
 
 int launch_opt_softmax_q(const float *scores, const float *mask, void *probs, int heads, int sq, int tgz, int ldp, hipStream_t stream, hipError_t *hip_err) {
     const int rows = heads * sq;
-    hipLaunchKernelGGL(opt_softmax_q_kernel, dim3((rows + 3) / 4), dim3(320), ((size_t)5 * tgz + 4) * sizeof(float), stream, scores, mask, static_cast<int8_t *>(probs), rows, sq, tgz, ldp);
+    const size_t lds = ((size_t)5 * ((tgz + 3) & ~3) + 8) * sizeof(float);
+    const bool bcast = (long long)((rows + 3) / 4) * 5 <= kSeqSumBcastMaxWaves;
+    auto kfn = bcast ? opt_softmax_q_kernel<true> : opt_softmax_q_kernel<false>;
+    if (lds > 64 * 1024) {
+        const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ea != hipSuccess) {
+            if (hip_err) *hip_err = ea;
+            return TCE_ERR_HIP;
+        }
+    }
+    hipLaunchKernelGGL(kfn, dim3((rows + 3) / 4), dim3(320), lds, stream, scores, mask, static_cast<int8_t *>(probs), rows, sq, tgz, ldp);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         if (hip_err) *hip_err = e;

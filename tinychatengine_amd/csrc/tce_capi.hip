@@ -141,7 +141,7 @@ int tce_w4a16_set_debug_mode(int mode) {
         tce::set_skinny_max_m(mode - 1000);
         return TCE_OK;
     }
-    if (mode >= 70 && mode <= 74) {  // W8A8: wave quartets per tile (70 automatic)
+    if (mode >= 70 && mode <= 74) {  // W8A8: wave quartets per tile (70 automatic; 73: automatic, without the decode-sized wave-per-column kernels)
         tce::set_w8a8_ksplit(mode - 70);
         return TCE_OK;
     }

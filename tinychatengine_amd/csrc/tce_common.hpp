@@ -225,6 +225,75 @@ __device__ __forceinline__ float sequential_sum_lane0(const float *lds_x, int n,
     return acc;
 }
 
+// The same sequential sum with the values handed to EVERY lane by LDS broadcast reads (all lanes read the same 16-byte pieces:
+// conflict-free, one LDS cycle per instruction) instead of to lane 0 by DPP shifts: the chain's step is then a plain
+// `v_add_f32 acc, v[i], acc` -- 6.0 shader cycles per dependent addition against 11.3 for the DPP form
+// (scripts/probes/dep_add_probe.hip: 2.86 against 4.68 ns per element with the reads included).  Two 16-value buffers in FIXED registers
+// v96..v127, one being refilled while the other is added; the loop is ONE asm statement, so the compiler never sees a register whose data
+// has not landed (and a kernel that calls this reports >= 128 VGPRs).  `vals` is 16-byte aligned; the loop reads up to 128 bytes past the
+// last 32-value pair (LDS reads past the allocation return zero; nothing read there is added).  The total is valid in EVERY lane.  A
+// mapped sum (the squared deviations of LayerNormQ.cc:33-36) is taken over values the wave computed into LDS beforehand, in parallel.
+__device__ __forceinline__ float sequential_sum_bcast(const float *vals, int n) {
+    float acc = 0.f;
+    int pairs = n >> 5;
+    if (pairs > 0) {
+        unsigned p = (unsigned)(size_t)vals;  // LDS byte address
+        asm volatile(
+            "ds_read_b128 v[96:99], %1\n\tds_read_b128 v[100:103], %1 offset:16\n\tds_read_b128 v[104:107], %1 offset:32\n\tds_read_b128 v[108:111], %1 offset:48\n\t"
+            "ds_read_b128 v[112:115], %1 offset:64\n\tds_read_b128 v[116:119], %1 offset:80\n\tds_read_b128 v[120:123], %1 offset:96\n\tds_read_b128 v[124:127], %1 offset:112\n"
+            "1:\n\t"
+            "s_waitcnt lgkmcnt(4)\n\t"
+            "v_add_f32 %0, v96, %0\n\tv_add_f32 %0, v97, %0\n\tv_add_f32 %0, v98, %0\n\tv_add_f32 %0, v99, %0\n\t"
+            "v_add_f32 %0, v100, %0\n\tv_add_f32 %0, v101, %0\n\tv_add_f32 %0, v102, %0\n\tv_add_f32 %0, v103, %0\n\t"
+            "v_add_f32 %0, v104, %0\n\tv_add_f32 %0, v105, %0\n\tv_add_f32 %0, v106, %0\n\tv_add_f32 %0, v107, %0\n\t"
+            "v_add_f32 %0, v108, %0\n\tv_add_f32 %0, v109, %0\n\tv_add_f32 %0, v110, %0\n\tv_add_f32 %0, v111, %0\n\t"
+            "ds_read_b128 v[96:99], %1 offset:128\n\tds_read_b128 v[100:103], %1 offset:144\n\tds_read_b128 v[104:107], %1 offset:160\n\tds_read_b128 v[108:111], %1 offset:176\n\t"
+            "s_waitcnt lgkmcnt(4)\n\t"
+            "v_add_f32 %0, v112, %0\n\tv_add_f32 %0, v113, %0\n\tv_add_f32 %0, v114, %0\n\tv_add_f32 %0, v115, %0\n\t"
+            "v_add_f32 %0, v116, %0\n\tv_add_f32 %0, v117, %0\n\tv_add_f32 %0, v118, %0\n\tv_add_f32 %0, v119, %0\n\t"
+            "v_add_f32 %0, v120, %0\n\tv_add_f32 %0, v121, %0\n\tv_add_f32 %0, v122, %0\n\tv_add_f32 %0, v123, %0\n\t"
+            "v_add_f32 %0, v124, %0\n\tv_add_f32 %0, v125, %0\n\tv_add_f32 %0, v126, %0\n\tv_add_f32 %0, v127, %0\n\t"
+            "ds_read_b128 v[112:115], %1 offset:192\n\tds_read_b128 v[116:119], %1 offset:208\n\tds_read_b128 v[120:123], %1 offset:224\n\tds_read_b128 v[124:127], %1 offset:240\n\t"
+            "v_add_u32 %1, 0x80, %1\n\t"
+            "s_sub_u32 %2, %2, 1\n\t"
+            "s_cmp_lg_u32 %2, 0\n\t"
+            "s_cbranch_scc1 1b\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "+v"(acc), "+v"(p), "+s"(pairs)
+            :
+            : "memory", "scc", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113",
+              "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
+    }
+    // the last n % 32 values: two 16-value groups read at once (past the end: unused), added under wave-uniform conditions
+    const int done = n & ~31, rest = n - done;
+    if (rest > 0) {
+        float t[32];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4_t v = *reinterpret_cast<const float4_t *>(vals + done + 4 * j);
+            t[4 * j] = v.x; t[4 * j + 1] = v.y; t[4 * j + 2] = v.z; t[4 * j + 3] = v.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 31; ++j)
+            if (j < rest) acc = acc + t[j];
+    }
+    return acc;
+}
+
+// Which form: the broadcast form is the shorter CHAIN (a launch of a few rows: decode), but its four ds_read_b128 per 16 values occupy the CU's LDS
+// for 16 cycles per wave and 16 values -- with four or more waves per SIMD walking rows the LDS, not the adder, is then the limit, and the DPP form
+// (one ds_read_b32 per 16 values) is the faster one (OPT-125M prefill softmax, 6144 rows: 26.4 us against 31.6).  BCAST is chosen per launch.
+template <bool BCAST>
+__device__ __forceinline__ float sequential_sum(const float *vals, int n, int lane) {
+    if constexpr (BCAST) {
+        return sequential_sum_bcast(vals, n);
+    } else {
+        const float s = sequential_sum_lane0(vals, n, lane, [](float v) { return v; });
+        return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s)));
+    }
+}
+constexpr int kSeqSumBcastMaxWaves = 256 * 8;  // up to ~two row-walking waves per SIMD: the chain is the limit; beyond: the LDS
+
 // non-temporal 16-byte load: streamed weights are read exactly once by exactly one CU
 __device__ __forceinline__ uint4_t load_nt(const uint4_t *p) { return __builtin_nontemporal_load(p); }
 

@@ -251,11 +251,111 @@ __global__ __launch_bounds__(256) void w8a8_generic_kernel(const W8A8Args a) {
     epilogue_store(a, Cb, m, n, acc, bias_term(a, n));
 }
 
-int g_w8a8_ks = 0;  // forced K split (tuning), 0 = automatic
+// Decode-sized problems.  PER_ROW = 0: M <= 8 activation rows against a shared B (the linears of a decode step: 1 x 768 x 3072 is
+// 12 tiles of 64 x 64 for the MFMA kernel -- twelve workgroups walking 48 serial k-steps, 11 us -- and 2.4 MB that 192 workgroups stream
+// in one round trip): ONE WAVE per output column, the lanes across K in 16-byte pieces (a row of B is read once, coalesced, and meets
+// all M rows), the activation rows staged in LDS once per workgroup.  PER_ROW = 1: the *_batch members (row m of A has its own B_m)
+// with long rows -- the probabilities x V^T product of a decode step, K = the context: one wave per output element, both operands
+// coalesced (the one-thread-per-output kernel reads 512-byte rows strided across its lanes).  int32 sums, exact in any order; the
+// epilogue is the shared one.
+constexpr int kRowdotMaxM = 8;
+template <int PER_ROW>
+__global__ __launch_bounds__(256) void w8a8_rowdot_kernel(const W8A8Args a) {
+    extern __shared__ __attribute__((aligned(16))) int4_t lds_dyn[];  // PER_ROW = 0: [M][K] int8
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int batch = blockIdx.z;
+    const int8_t *A = a.A + (size_t)batch * a.strideA;
+    const int8_t *B = a.B + (size_t)(PER_ROW ? 0 : batch) * a.strideB;
+    const size_t c_off = (size_t)batch * a.strideC;
+    void *Cb = a.out_kind == TCE_OUT_INT8 ? static_cast<void *>(static_cast<int8_t *>(a.C) + c_off)
+                                          : static_cast<void *>(static_cast<float *>(a.C) + c_off);
+    const int pieces = a.K >> 4;
+    if constexpr (PER_ROW == 0) {
+        for (int e = tid; e < a.M * pieces; e += 256) {
+            const int r = e / pieces, p = e - r * pieces;
+            lds_dyn[e] = *reinterpret_cast<const int4_t *>(A + (size_t)r * a.lda + p * 16);
+        }
+        __syncthreads();
+        const int n = blockIdx.x * 4 + wave;  // wave-uniform
+        if (n >= a.N) return;
+        const int4_t *brow = reinterpret_cast<const int4_t *>(B + (size_t)n * a.ldb);
+        const float u = bias_term(a, n);  // requested now, used after the contraction
+        int acc[kRowdotMaxM];
+#pragma unroll
+        for (int mm = 0; mm < kRowdotMaxM; ++mm) acc[mm] = 0;
+        // a lane's pieces of the row, eight at a time: all of their loads are in flight before the first dot product (K = 3072 is three
+        // pieces per lane; one load per loop iteration made them three dependent memory round trips)
+        for (int base = lane; base < pieces; base += 64 * 8) {
+            int4_t w[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int p = base + 64 * i;
+                w[i] = p < pieces ? brow[p] : int4_t{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int p = base + 64 * i;
+                if (p < pieces) {
+#pragma unroll
+                    for (int mm = 0; mm < kRowdotMaxM; ++mm) {
+                        if (mm < a.M) {
+                            const int4_t x = lds_dyn[mm * pieces + p];
+                            acc[mm] = __builtin_amdgcn_sdot4(w[i].x, x.x, acc[mm], false);
+                            acc[mm] = __builtin_amdgcn_sdot4(w[i].y, x.y, acc[mm], false);
+                            acc[mm] = __builtin_amdgcn_sdot4(w[i].z, x.z, acc[mm], false);
+                            acc[mm] = __builtin_amdgcn_sdot4(w[i].w, x.w, acc[mm], false);
+                        }
+                    }
+                }
+            }
+        }
+        int mine = 0;  // after the butterflies every lane holds every total; lane mm keeps row mm's and stores it
+#pragma unroll
+        for (int mm = 0; mm < kRowdotMaxM; ++mm) {
+            if (mm < a.M) {
+                int v = acc[mm];
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+                if (lane == mm) mine = v;
+            }
+        }
+        if (lane < a.M) epilogue_store(a, Cb, lane, n, mine, u);
+    } else {
+        const long long idx = (long long)blockIdx.x * 4 + wave;
+        if (idx >= (long long)a.M * a.N) return;
+        const int m = (int)(idx / a.N), n = (int)(idx % a.N);
+        const int4_t *arow = reinterpret_cast<const int4_t *>(A + (size_t)m * a.lda);
+        const int4_t *brow = reinterpret_cast<const int4_t *>(B + (size_t)m * a.strideB + (size_t)n * a.ldb);
+        const float u = bias_term(a, n);
+        int acc = 0;
+        for (int base = lane; base < pieces; base += 64 * 4) {
+            int4_t w[4], x[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int p = base + 64 * i;
+                w[i] = p < pieces ? brow[p] : int4_t{0, 0, 0, 0};
+                x[i] = p < pieces ? arow[p] : int4_t{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc = __builtin_amdgcn_sdot4(w[i].x, x[i].x, acc, false);
+                acc = __builtin_amdgcn_sdot4(w[i].y, x[i].y, acc, false);
+                acc = __builtin_amdgcn_sdot4(w[i].z, x[i].z, acc, false);
+                acc = __builtin_amdgcn_sdot4(w[i].w, x[i].w, acc, false);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane == 0) epilogue_store(a, Cb, m, n, acc, u);
+    }
+}
+
+int g_w8a8_ks = 0;  // forced K split (tuning), 0 = automatic; 3: the decode-sized kernels above are not used (A/B)
 
 }  // namespace
 
-void set_w8a8_ksplit(int ks) { g_w8a8_ks = (ks == 1 || ks == 2 || ks == 4) ? ks : 0; }
+void set_w8a8_ksplit(int ks) { g_w8a8_ks = (ks >= 1 && ks <= 4) ? ks : 0; }
 
 int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err) {
     W8A8Args a{};
@@ -289,11 +389,17 @@ int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err)
                          (reinterpret_cast<uintptr_t>(d.B) % 16 == 0) && a.lda % 16 == 0 && a.ldb % 16 == 0 && a.strideB % 16 == 0 &&
                          (d.batch == 1 || (d.strideA % 16 == 0 && d.strideB % 16 == 0));
     a.vec_ok = aligned ? 1 : 0;
-    if (!d.b_per_row && aligned && d.K >= 64) {
+    const bool rowdot_ok = aligned && g_w8a8_ks != 3;
+    if (rowdot_ok && !d.b_per_row && d.M <= kRowdotMaxM && d.K >= 64 && (size_t)d.M * d.K <= 64 * 1024) {
+        hipLaunchKernelGGL(w8a8_rowdot_kernel<0>, dim3((d.N + 3) / 4, 1, d.batch), dim3(256), (size_t)d.M * d.K, stream, a);
+    } else if (rowdot_ok && d.b_per_row && d.batch == 1 && d.K >= 256) {
+        const long long outs = (long long)d.M * d.N;
+        hipLaunchKernelGGL(w8a8_rowdot_kernel<1>, dim3((unsigned)((outs + 3) / 4), 1, d.batch), dim3(256), 0, stream, a);
+    } else if (!d.b_per_row && aligned && d.K >= 64) {
         dim3 grid((d.N + 63) / 64, (d.M + 63) / 64, d.batch);
         // wave quartets per tile: while the tiles do not fill the chip and every quartet keeps >= 2 k-steps
         const long tiles = (long)grid.x * grid.y * grid.z;
-        int ks = g_w8a8_ks;
+        int ks = g_w8a8_ks == 3 ? 0 : g_w8a8_ks;
         if (ks == 0) {
             ks = 1;
             if (tiles < 512 && d.K / 64 >= 4) ks = 2;  // four quartets measured no better than two (profiles/r1/w8a8_ksplit_sweep.jsonl)

@@ -10,8 +10,8 @@
 // output rows of up to TCE_MAX_GROUP linears: one launch.
 //
 // BIT-EXACT against LayerNormQ::forward followed by int8_ref_matmul (kernels/ref/matmul_ref_int8.cc:11-35):
-//   * the reference's two row sums are sequential fp32 additions, so ONE LANE adds them in order (values handed to it by DPP
-//     row shifts, one dependent add per element; a wave per row for m > 1); the division, multiply and add of the output are separate roundings (-ffp-contract=off), std::round = half away
+//   * the reference's two row sums are sequential fp32 additions, so they are added in order (every lane holds the same accumulator and
+//     gets the values by LDS broadcast reads, one dependent add per element; a wave per row for m > 1); the division, multiply and add of the output are separate roundings (-ffp-contract=off), std::round = half away
 //     from zero -- the same code as tce_layernorm_q (glue.hip);
 //   * the dot products are int32 (v_dot4_i32_i8), exact in any order;
 //   * the epilogue is the int8 path's: (float)acc, * alpha, + (float)bias * beta, each rounded separately, roundf, clamp.
@@ -43,6 +43,9 @@ constexpr int kRowsPerWave = 2;
 constexpr int kWaves = 4;
 constexpr int kMaxM = 8;
 
+// LDS: [m][K] fp32 rows | [m][K] int8 | (pad) [m][2] stats | (pad) [min(m, kWaves)][K] fp32 squared deviations
+__host__ __device__ constexpr size_t lnq_dev_offset(int m, int K) { return (((size_t)m * K * 5 + 16 + (size_t)m * 8 + 16) + 15) & ~(size_t)15; }
+
 __global__ __launch_bounds__(64 * kWaves) void lnq_w8a8_kernel(const LnqArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -51,21 +54,58 @@ __global__ __launch_bounds__(64 * kWaves) void lnq_w8a8_kernel(const LnqArgs a) 
     float *rows = reinterpret_cast<float *>(smem);                     // [m][K] fp32
     int8_t *q8 = reinterpret_cast<int8_t *>(smem + (size_t)m * K * 4);  // [m][K] int8
     float *stats = reinterpret_cast<float *>(smem + (size_t)m * K * 5 + 16 - ((size_t)m * K * 5) % 16);  // [m][2]: mean, std
+    const int row0 = (blockIdx.x * kWaves + wave) * kRowsPerWave;
+    const int pieces = K >> 4;
+    // the first weight pieces of BOTH rows of the wave are requested before anything else: they do not depend on the normalisation and land while
+    // the row sums are walked (K = 768: one piece per lane and row is the whole row)
+    int4_t wfirst[kRowsPerWave][2];
+    float ufirst[kRowsPerWave];
+#pragma unroll
+    for (int rr = 0; rr < kRowsPerWave; ++rr) {
+        const int row = row0 + rr < a.total_rows ? row0 + rr : a.total_rows - 1;
+        int li = 0;
+#pragma unroll
+        for (int s = 1; s < TCE_MAX_GROUP; ++s)
+            if (s < a.count && row >= a.lin[s].row_begin) li = s;
+        const int4_t *brow = reinterpret_cast<const int4_t *>(a.lin[li].B + (size_t)(row - a.lin[li].row_begin) * K);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wfirst[rr][i] = lane + 64 * i < pieces ? brow[lane + 64 * i] : int4_t{0, 0, 0, 0};
+        // the additive term of this output column, once (kernels/ref/matmul_ref_int8.cc:29-31)
+        const LnqLinear &L = a.lin[li];
+        const int n = row - L.row_begin;
+        ufirst[rr] = 0.f;
+        if (L.bias_kind == TCE_BIAS_INT8) ufirst[rr] = __fmul_rn((float)static_cast<const int8_t *>(L.bias)[n], L.beta);
+        else if (L.bias_kind == TCE_BIAS_FP32) ufirst[rr] = static_cast<const float *>(L.bias)[n];
+    }
+    // ... and the affine parameters of the elements this thread will quantize in step 3 (m * K <= 1024: decode at OPT sizes)
+    constexpr int PF = 4;
+    const bool affine_prefetched = m * K <= 64 * kWaves * PF;
+    float pw[PF], pb[PF];
+    if (affine_prefetched) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int e = tid + 64 * kWaves * i;
+            const int k = e < m * K ? e % K : 0;
+            pw[i] = a.ln_w[k];
+            pb[i] = a.ln_b[k];
+        }
+    }
     // ---- 1. the rows into LDS (coalesced) ----
     const int n4 = (m * K) >> 2;
     for (int p = tid; p < n4; p += 64 * kWaves) reinterpret_cast<float4_t *>(rows)[p] = reinterpret_cast<const float4_t *>(a.x)[p];
     __syncthreads();
     // ---- 2. the two sequential sums of every row (LayerNormQ.cc:27-37), in the reference's order: wave w takes rows w, w + 4
-    //         (sequential_sum_lane0, tce_common.hpp: one dependent add per element) ----
+    //         (sequential_sum_bcast, tce_common.hpp: one dependent add per element) ----
+    float *dev = reinterpret_cast<float *>(smem + lnq_dev_offset(m, K)) + (size_t)wave * K;  // this wave's squared deviations
     for (int r = wave; r < m; r += kWaves) {
         const float *xr = rows + (size_t)r * K;
-        float mean = sequential_sum_lane0(xr, K, lane, [](float v) { return v; });
+        float mean = sequential_sum_bcast(xr, K);
         mean /= (float)K;
-        mean = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, mean)));
-        const float sq = sequential_sum_lane0(xr, K, lane, [&](float v) {
-            const float d = v - mean;
-            return __fmul_rn(d, d);
-        });
+        for (int k = lane; k < K; k += 64) {
+            const float d = xr[k] - mean;
+            dev[k] = __fmul_rn(d, d);
+        }
+        const float sq = sequential_sum_bcast(dev, K);
         if (lane == 0) {
             stats[2 * r] = mean;
             stats[2 * r + 1] = sqrtf(sq / (float)K + 0.00001f);
@@ -73,17 +113,25 @@ __global__ __launch_bounds__(64 * kWaves) void lnq_w8a8_kernel(const LnqArgs a) 
     }
     __syncthreads();
     // ---- 3. the int8 rows (LayerNormQ.cc:42-48), into LDS and -- by workgroup 0 -- to memory if asked for ----
-    for (int e = tid; e < m * K; e += 64 * kWaves) {
-        const int r = e / K, k = e - r * K;
+    auto quantize = [&](int e, float lw, float lb) {
+        const int r = e / K;
         const float t = __fdiv_rn(rows[e] - stats[2 * r], stats[2 * r + 1]);
-        const float f = __fadd_rn(__fmul_rn(t, a.ln_w[k]), a.ln_b[k]);
+        const float f = __fadd_rn(__fmul_rn(t, lw), lb);
         const int8_t q = (int8_t)(int)roundf(f);
         q8[e] = q;
         if (a.ln_out && blockIdx.x == 0) a.ln_out[e] = q;
+    };
+    if (affine_prefetched) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int e = tid + 64 * kWaves * i;
+            if (e < m * K) quantize(e, pw[i], pb[i]);
+        }
+    } else {
+        for (int e = tid; e < m * K; e += 64 * kWaves) quantize(e, a.ln_w[e % K], a.ln_b[e % K]);
     }
     __syncthreads();
     // ---- 4. this workgroup's output rows: a wave per row, lanes across K in 16-byte pieces ----
-    const int row0 = (blockIdx.x * kWaves + wave) * kRowsPerWave;
 #pragma unroll
     for (int rr = 0; rr < kRowsPerWave; ++rr) {
         const int row = row0 + rr;  // wave-uniform
@@ -98,8 +146,8 @@ __global__ __launch_bounds__(64 * kWaves) void lnq_w8a8_kernel(const LnqArgs a) 
         int acc[kMaxM];
 #pragma unroll
         for (int mm = 0; mm < kMaxM; ++mm) acc[mm] = 0;
-        for (int p = lane; p < (K >> 4); p += 64) {
-            const int4_t w = brow[p];
+        for (int p = lane, it = 0; p < pieces; p += 64, ++it) {
+            const int4_t w = it == 0 ? wfirst[rr][0] : (it == 1 ? wfirst[rr][1] : brow[p]);
 #pragma unroll
             for (int mm = 0; mm < kMaxM; ++mm) {
                 if (mm < m) {
@@ -111,10 +159,7 @@ __global__ __launch_bounds__(64 * kWaves) void lnq_w8a8_kernel(const LnqArgs a) 
                 }
             }
         }
-        // the additive term of this output column, once (kernels/ref/matmul_ref_int8.cc:29-31)
-        float u = 0.f;
-        if (L.bias_kind == TCE_BIAS_INT8) u = __fmul_rn((float)static_cast<const int8_t *>(L.bias)[n], L.beta);
-        else if (L.bias_kind == TCE_BIAS_FP32) u = static_cast<const float *>(L.bias)[n];
+        const float u = ufirst[rr];
 #pragma unroll
         for (int mm = 0; mm < kMaxM; ++mm) {
             if (mm < m) {
@@ -169,7 +214,7 @@ int launch_lnq_w8a8_group(const float *x, const float *ln_w, const float *ln_b, 
     }
     for (int i = count; i < TCE_MAX_GROUP; ++i) a.lin[i] = a.lin[0];
     a.total_rows = rows;
-    const size_t lds = (size_t)m * k * 5 + 16 + (size_t)m * 8 + 16;
+    const size_t lds = lnq_dev_offset(m, k) + (size_t)(m < kWaves ? m : kWaves) * k * 4;  // a scratch row per wave that walks a row
     if (lds > 160 * 1024) return TCE_ERR_UNSUPPORTED_SHAPE;
     auto kfn = lnq_w8a8_kernel;
     if (lds > 64 * 1024) {
