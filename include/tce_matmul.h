@@ -47,7 +47,7 @@ extern "C" {
 
 #define TCE_API __attribute__((visibility("default")))
 
-#define TCE_VERSION 103 /* 0.1.3: tce_attention_decode_step_gqa_f16, TCE_PLAN_OVERLAPPED (0.1.2: tce_w4a16_desc.scratch; 0.1.1: .prepacked, tce_w4a16_prepack*) */
+#define TCE_VERSION 104 /* 0.1.4: tce_attention_prefill_f16 (0.1.3: tce_attention_decode_step_gqa_f16, TCE_PLAN_OVERLAPPED; 0.1.2: tce_w4a16_desc.scratch; 0.1.1: .prepacked, tce_w4a16_prepack*) */
 
 /* error codes (return values) */
 #define TCE_OK 0
@@ -182,6 +182,23 @@ TCE_API int tce_attention_decode_describe_gqa(int heads, int kv_heads, int keys,
 TCE_API int tce_attention_decode_step_pos_f16(const void *qkv, void *k_cache, void *v_cache, const void *cos_table, const void *sin_table, const void *mask,
                                               void *out, void *workspace, int heads, int kv_heads, int head_dim, int max_keys, const int32_t *pos_device,
                                               int pos_bound, unsigned short alpha_half_bits, void *stream);
+/* The same block for m > 1 NEW rows -- a prompt, or a chunk of one on top of pos cached keys (Int4llamaAttention.cu:116-229 with sqlen > 1) -- as two
+ * launches (csrc/attention_prefill.hip): rotation of q and the new keys with the reference's binary16 arithmetic + the KV append (rows pos .. pos + m - 1;
+ * bit-identical to what m decode steps append), then one pass over the keys per (query head, 64 query rows): scores and the weighted sum of V on the
+ * matrix pipe with fp32 accumulation, online softmax in fp32.
+ *   qkv        fp16 [m][ld_qkv]: per row the query heads, the key heads, the value heads (what the fused projection writes for M = m);
+ *              ld_qkv = 0: (heads + 2 kv_heads) * head_dim
+ *   k_cache, v_cache  fp16 [kv_heads][max_keys][head_dim] as for the decode step (pos + m <= max_keys); cos / sin tables [positions][head_dim] or both NULL
+ *   mask       fp16 [m][ld_mask] additive (the reference's attention_mask: 0 / the lowest half), or NULL;  ld_mask = 0: pos + m
+ *   causal     non-zero: row r sees keys 0 .. pos + r (in addition to the mask, if any) -- key tiles behind a block's diagonal are skipped
+ *   out        fp16 [m][ld_out]: row r, columns head * head_dim .. (= o_proj's input rows; ld_out = 0: heads * head_dim)
+ *   workspace  tce_attention_prefill_workspace_bytes(heads, m, head_dim) bytes (the rotated queries; no zeroing needed)
+ * Not the reference's binary16 accumulation chains (tce_bmm_f16t + tce_softmax_half are those, bit for bit): agrees with a float64 evaluation within
+ * 2e-3 * max|out| per head and row.  head_dim == 128.  Cache rows at and beyond pos + m may hold anything. */
+TCE_API size_t tce_attention_prefill_workspace_bytes(int heads, int m, int head_dim);
+TCE_API int tce_attention_prefill_f16(const void *qkv, int ld_qkv, void *k_cache, void *v_cache, const void *cos_table, const void *sin_table, const void *mask,
+                                      int ld_mask, int causal, void *out, int ld_out, void *workspace, int heads, int kv_heads, int head_dim, int max_keys,
+                                      int pos, int m, unsigned short alpha_half_bits, void *stream);
 /* Reads [ptr, ptr + bytes) with at most `workgroups` workgroups (0 = as many as the range needs) and discards the data: the
  * range then sits in the memory-side cache (256 MiB) for the launch that needs it.  Meant for a side stream / graph branch
  * next to the launch BEFORE that one (no reference counterpart: cudaMallocManaged prefetching is the closest idea). */

@@ -442,3 +442,103 @@ def test_attention_decode_step_argument_checks(dev):
     assert L.tce_attention_decode_step_f16(p, p, p, None, None, None, p, ws.data_ptr(), 2, 128, 64, 64, 0x3C00, None) == capi.TCE_ERR_BAD_ARG  # pos == max_keys
     assert L.tce_attention_decode_step_f16(p, p, p, p, None, None, p, ws.data_ptr(), 2, 128, 64, 0, 0x3C00, None) == capi.TCE_ERR_BAD_ARG  # cos without sin
     assert L.tce_attention_decode_step_gqa_f16(p, p, p, None, None, None, p, ws.data_ptr(), 6, 4, 128, 64, 0, 0x3C00, None) == capi.TCE_ERR_BAD_ARG  # 6 query heads over 4
+
+
+@pytest.mark.parametrize("heads,kv_heads,max_keys,pos,m,causal,masked", [(8, 8, 256, 0, 100, True, False), (32, 8, 700, 37, 130, True, False), (4, 1, 200, 0, 64, False, True),
+                                                                         (4, 4, 300, 50, 7, True, True), (2, 2, 1100, 0, 1024, True, False), (8, 2, 400, 128, 65, False, False),
+                                                                         (2, 1, 130, 1, 129, True, False)])
+def test_attention_prefill_against_float64_and_the_decode_step(dev, oracle, heads, kv_heads, max_keys, pos, m, causal, masked):
+    """tce_attention_prefill_f16 (m new rows on top of `pos` cached keys): the appended keys / values bit for bit against the oracle's RotaryPosEmb
+    (RotaryPosEmb.cu:4-34) -- and therefore against what m decode steps append --, the outputs against a float64 evaluation of
+    softmax(alpha q K^T + mask) V per row and head (2e-3 * max|out| + one binary16 ulp: the decode step's tolerance), and the LAST row against the decode
+    step run on the same caches.  Grouped queries, a context in front of the chunk, m that is not a multiple of the 64-row block or the 64-key tile, an
+    explicit additive mask (the reference's attention_mask) with and without the causal cut, inf / nan bit patterns behind pos + m."""
+    from tinychatengine_amd.attention_ops import DecodeAttention
+    hd, rep = 128, heads // kv_heads
+    rng = np.random.default_rng(heads * 7 + m + pos)
+    cos, sin = _rope_tables(max_keys, hd, 9)
+    tc, ts = torch.from_numpy(cos).to(dev), torch.from_numpy(sin).to(dev)
+    att = DecodeAttention(heads, hd, max_keys, dev, tc, ts, kv_heads=kv_heads)
+    Kc = np.full((kv_heads, max_keys, hd), np.array([0x7C00], np.uint16).view(np.float16)[0])  # +inf bits where nothing was appended yet
+    Vc = np.full((kv_heads, max_keys, hd), np.array([0xFE00], np.uint16).view(np.float16)[0])  # nan bits
+    Kc[:, :pos] = (rng.standard_normal((kv_heads, pos, hd)) * 0.8).astype(np.float16)
+    Vc[:, :pos] = (rng.standard_normal((kv_heads, pos, hd)) * 0.8).astype(np.float16)
+    att.k_cache.copy_(torch.from_numpy(Kc)); att.v_cache.copy_(torch.from_numpy(Vc))
+    width = (heads + 2 * kv_heads) * hd
+    qkv = (rng.standard_normal((m, width)) * 0.9).astype(np.float16)
+    tgz = pos + m
+    mask = None
+    if masked:  # the reference's attention_mask: causal as the lowest half, plus a few keys switched off for every row (padding)
+        mask = np.zeros((m, tgz), np.float16)
+        for r in range(m):
+            mask[r, pos + r + 1:] = np.float16(-65504.0)
+        off = rng.integers(0, max(1, pos), size=3) if pos else []
+        for c in off:
+            mask[:, c] = np.float16(-65504.0)
+    t_qkv = torch.from_numpy(qkv).to(dev)
+    out = att.prefill(t_qkv, pos, mask=None if mask is None else torch.from_numpy(mask).to(dev), causal=causal)
+    torch.cuda.synchronize()
+    q = qkv[:, : heads * hd].reshape(m, heads, hd).transpose(1, 0, 2)
+    k = qkv[:, heads * hd: (heads + kv_heads) * hd].reshape(m, kv_heads, hd).transpose(1, 0, 2)
+    v = qkv[:, (heads + kv_heads) * hd:].reshape(m, kv_heads, hd).transpose(1, 0, 2)
+    q_rot, _ = oracle.rope_half(np.ascontiguousarray(q), np.ascontiguousarray(q), cos, sin, pos)
+    _, k_rot = oracle.rope_half(np.ascontiguousarray(k), np.ascontiguousarray(k), cos, sin, pos)
+    Kc[:, pos:tgz] = k_rot
+    Vc[:, pos:tgz] = v
+    assert np.array_equal(att.k_cache.cpu().numpy().view(np.uint16), Kc.view(np.uint16)), "appended keys differ from the reference's rotated keys (or rows outside pos .. pos + m were touched)"
+    assert np.array_equal(att.v_cache.cpu().numpy().view(np.uint16), Vc.view(np.uint16))
+    alpha = float(np.float16(1.0 / np.sqrt(hd)))
+    got = out.cpu().numpy().astype(np.float64).reshape(m, heads, hd)
+    assert np.isfinite(got).all()
+    Kr, Vr = np.repeat(Kc[:, :tgz], rep, axis=0).astype(np.float64), np.repeat(Vc[:, :tgz], rep, axis=0).astype(np.float64)
+    worst = 0.0
+    for r in range(m):
+        s = alpha * np.einsum("hd,hkd->hk", q_rot[:, r].astype(np.float64), Kr)
+        if mask is not None:
+            s = s + mask[r].astype(np.float64)[None, :]
+        if causal:
+            s[:, pos + r + 1:] = -np.inf
+        s = s - s.max(axis=1, keepdims=True)
+        p = np.exp(s)
+        p /= p.sum(axis=1, keepdims=True)
+        ref = np.einsum("hk,hkd->hd", p, Vr)
+        tol = 2e-3 * np.abs(ref).max(axis=1, keepdims=True) + 2.0 ** -11 * np.abs(ref)
+        err = np.abs(got[r] - ref) / tol
+        worst = max(worst, err.max())
+        assert err.max() <= 1.0, f"row {r}: worst |err|/tol = {err.max():.3f}"
+    if causal and not masked:  # the decode step for the last row, on caches that hold everything in front of it
+        dec = DecodeAttention(heads, hd, max_keys, dev, tc, ts, kv_heads=kv_heads)
+        dec.k_cache.copy_(att.k_cache); dec.v_cache.copy_(att.v_cache)
+        one = dec.step(t_qkv[m - 1].contiguous(), tgz - 1)
+        torch.cuda.synchronize()
+        assert torch.equal(dec.k_cache.view(torch.int16), att.k_cache.view(torch.int16)) and torch.equal(dec.v_cache.view(torch.int16), att.v_cache.view(torch.int16)), \
+            "a decode step appends other bits than the prefill did"
+        a, b = one.float().cpu().numpy().reshape(heads, hd), got[m - 1]
+        tol = 4e-3 * np.abs(b).max(axis=1, keepdims=True) + 2.0 ** -10 * np.abs(b)
+        assert np.all(np.abs(a - b) <= tol), f"decode step vs prefill, last row: {(np.abs(a - b) / tol).max():.3f}"
+
+
+@pytest.mark.parametrize("waves", [4, 8])
+def test_attention_prefill_both_block_sizes(dev, oracle, waves):
+    """Blocks of 64 and of 128 query rows (4 / 8 waves per workgroup; the launch picks by the number of blocks) compute the same thing."""
+    from tinychatengine_amd import capi
+    capi.check(capi.lib().tce_w4a16_set_debug_mode(2950 + waves))
+    try:
+        test_attention_prefill_against_float64_and_the_decode_step(dev, oracle, 8, 2, 400, 37, 200, True, False)
+        test_attention_prefill_against_float64_and_the_decode_step(dev, oracle, 4, 4, 300, 50, 130, True, True)
+    finally:
+        capi.check(capi.lib().tce_w4a16_set_debug_mode(2950))
+
+
+def test_attention_prefill_argument_checks(dev):
+    from tinychatengine_amd import capi
+    L = capi.lib()
+    assert int(L.tce_attention_prefill_workspace_bytes(32, 100, 64)) == 0 and int(L.tce_attention_prefill_workspace_bytes(32, 100, 128)) == 32 * 100 * 128 * 2
+    z = torch.zeros(1 << 16, dtype=torch.float16, device=dev)
+    p = z.data_ptr()
+    args = lambda **kw: [kw.get("qkv", p), 0, p, p, None, None, None, 0, 1, p, 0, kw.get("ws", p), kw.get("heads", 4), kw.get("kv", 2), kw.get("hd", 128), 64, kw.get("pos", 0), kw.get("m", 8), 0x2DA8, None]
+    assert L.tce_attention_prefill_f16(*args(kv=3)) == capi.TCE_ERR_BAD_ARG
+    assert L.tce_attention_prefill_f16(*args(hd=64)) == capi.TCE_ERR_UNSUPPORTED_SHAPE
+    assert L.tce_attention_prefill_f16(*args(pos=60, m=8)) == capi.TCE_ERR_BAD_ARG          # pos + m > max_keys
+    assert L.tce_attention_prefill_f16(*args(ws=None)) == capi.TCE_ERR_BAD_ARG
+    assert L.tce_attention_prefill_f16(*args(qkv=p + 2)) == capi.TCE_ERR_UNSUPPORTED_SHAPE

@@ -96,3 +96,22 @@ class DecodeAttention:
         capi.check(capi.lib().tce_attention_decode_step_pos_f16(p(qkv), p(self.k_cache), p(self.v_cache), p(self.cos), p(self.sin), p(mask), p(out), p(self.workspace),
                                                                 self.heads, self.kv_heads, self.hd, self.max_keys, p(pos_device), int(pos), self.alpha_bits, C.c_void_p(_stream())))
         return out
+
+    def prefill(self, qkv: torch.Tensor, pos: int, out: torch.Tensor | None = None, mask: torch.Tensor | None = None, causal: bool = True) -> torch.Tensor:
+        """m > 1 new rows on top of `pos` cached keys (tce_attention_prefill_f16; Int4llamaAttention.cu:116-229 with sqlen > 1): qkv [m][(heads + 2 kv_heads) * hd]
+        as the fused projection writes it, mask fp16 [m][pos + m] additive or None, causal: row r sees keys 0 .. pos + r.  Appends rows pos .. pos + m - 1 to the
+        caches and returns out [m][heads * hd] (o_proj's input rows)."""
+        assert qkv.dtype == torch.float16 and qkv.is_contiguous() and qkv.dim() == 2 and qkv.shape[1] == (self.heads + 2 * self.kv_heads) * self.hd and qkv.is_cuda
+        m = qkv.shape[0]
+        if out is None:
+            out = torch.empty((m, self.heads * self.hd), dtype=torch.float16, device=qkv.device)
+        need = int(capi.lib().tce_attention_prefill_workspace_bytes(self.heads, m, self.hd))
+        ws = getattr(self, "_prefill_ws", None)
+        if ws is None or ws.numel() < need:
+            ws = self._prefill_ws = torch.empty(need, dtype=torch.uint8, device=qkv.device)
+        if mask is not None:
+            assert mask.dtype == torch.float16 and mask.is_contiguous() and tuple(mask.shape) == (m, pos + m)
+        p = lambda t: C.c_void_p(t.data_ptr() if t is not None else 0)
+        capi.check(capi.lib().tce_attention_prefill_f16(p(qkv), 0, p(self.k_cache), p(self.v_cache), p(self.cos), p(self.sin), p(mask), 0, 1 if causal else 0, p(out), 0, p(ws),
+                                                        self.heads, self.kv_heads, self.hd, self.max_keys, int(pos), m, self.alpha_bits, C.c_void_p(_stream())))
+        return out

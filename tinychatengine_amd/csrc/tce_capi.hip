@@ -141,6 +141,10 @@ int tce_w4a16_set_debug_mode(int mode) {
         tce::set_skinny_max_m(mode - 1000);
         return TCE_OK;
     }
+    if (mode == 2950 || mode == 2954 || mode == 2958) {  // prefill attention: waves per workgroup (2950 automatic)
+        tce::set_attention_prefill_waves(mode - 2950);
+        return TCE_OK;
+    }
     if (mode >= 70 && mode <= 74) {  // W8A8: wave quartets per tile (70 automatic; 73: automatic, without the decode-sized wave-per-column kernels)
         tce::set_w8a8_ksplit(mode - 70);
         return TCE_OK;
@@ -732,6 +736,32 @@ int tce_attention_decode_step_pos_f16(const void *qkv, void *kc, void *vc, const
     hipError_t he = hipSuccess;
     const int rc = tce::launch_attention_decode_fast(qkv, kc, vc, cosv, sinv, mask, out, workspace, heads, kv_heads, hd, max_keys, pos, alpha_bits, static_cast<hipStream_t>(stream), &he, pos_device);
     return rc == TCE_ERR_HIP ? hip_fail(he, "attention decode step launch") : rc;
+}
+
+size_t tce_attention_prefill_workspace_bytes(int heads, int m, int hd) { return tce::attention_prefill_workspace_bytes(heads, m, hd); }
+
+int tce_attention_prefill_f16(const void *qkv, int ld_qkv, void *kc, void *vc, const void *cosv, const void *sinv, const void *mask, int ld_mask, int causal, void *out,
+                              int ld_out, void *workspace, int heads, int kv_heads, int hd, int max_keys, int pos, int m, unsigned short alpha_bits, void *stream) {
+    if (!qkv || !kc || !vc || !out || !workspace) return fail(TCE_ERR_BAD_ARG, "tce_attention_prefill_f16: null pointer");
+    if ((cosv == nullptr) != (sinv == nullptr)) return fail(TCE_ERR_BAD_ARG, "tce_attention_prefill_f16: cos and sin tables come together");
+    if (heads <= 0 || max_keys <= 0 || m <= 0 || pos < 0 || pos + m > max_keys) return fail(TCE_ERR_BAD_ARG, "tce_attention_prefill_f16: need heads, m > 0 and 0 <= pos, pos + m <= max_keys");
+    if (kv_heads <= 0 || heads % kv_heads != 0) return fail(TCE_ERR_BAD_ARG, "tce_attention_prefill_f16: %d query heads do not divide over %d key / value heads", heads, kv_heads);
+    if (hd != 128) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_attention_prefill_f16: head_dim %d (128 only: Llama's)", hd);
+    const int width = (heads + 2 * kv_heads) * hd;
+    if (ld_qkv == 0) ld_qkv = width;
+    if (ld_out == 0) ld_out = heads * hd;
+    if (mask && ld_mask == 0) ld_mask = pos + m;
+    if (ld_qkv < width || ld_out < heads * hd || (mask && ld_mask < pos + m)) return fail(TCE_ERR_BAD_ARG, "tce_attention_prefill_f16: a leading dimension is shorter than its row");
+    if (ld_qkv % 8 != 0) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_attention_prefill_f16: ld_qkv must be a multiple of 8 (16-byte pieces)");
+    for (const void *p : {qkv, (const void *)kc, (const void *)vc, cosv, sinv, (const void *)workspace})
+        if (reinterpret_cast<uintptr_t>(p) & 15) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_attention_prefill_f16: 16-byte aligned pointers");
+    tce::half_t ah;
+    __builtin_memcpy(&ah, &alpha_bits, 2);
+    const float alpha = (float)ah;
+    hipError_t he = hipSuccess;
+    const int rc = tce::launch_attention_prefill(qkv, ld_qkv, kc, vc, cosv, sinv, mask, ld_mask, causal ? 1 : 0, out, ld_out, workspace, heads, kv_heads, max_keys, pos, m, alpha,
+                                                 static_cast<hipStream_t>(stream), &he);
+    return rc == TCE_ERR_HIP ? hip_fail(he, "attention prefill launch") : rc;
 }
 
 int tce_layernorm_q_w8a8_group(const float *x, const float *ln_weight, const float *ln_bias, int m, int k, const tce_w8a8_desc *lin, int count,

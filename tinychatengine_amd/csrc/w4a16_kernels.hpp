@@ -169,6 +169,12 @@ void set_attention_fast_waves(int nw);
 void set_attention_fast_fuse(int r);
 void describe_attention_decode_fast(int heads, int keys, int *chunk, int *chunks, int *waves, int kv_heads = 0);
 size_t attention_decode_workspace_bytes(int heads, int max_keys, int hd);
+// attention_prefill.hip: m > 1 new rows (rotation + append + causal / masked attention over pos + m keys), two launches
+size_t attention_prefill_workspace_bytes(int heads, int m, int hd);
+void set_attention_prefill_waves(int w);  // 0 automatic, 4 / 8 forced
+int launch_attention_prefill(const void *qkv, int ld_qkv, void *kc, void *vc, const void *cosv, const void *sinv, const void *mask, int ld_mask, int causal,
+                             void *out, int ld_out, void *workspace, int heads, int kv_heads, int max_keys, int pos, int m, float alpha, hipStream_t stream,
+                             hipError_t *hip_err);
 int launch_attention_decode_fast(const void *qkv, void *kc, void *vc, const void *cosv, const void *sinv, const void *mask, void *out, void *workspace,
                                  int heads, int kv_heads, int hd, int max_keys, int pos, unsigned short alpha_bits, hipStream_t stream, hipError_t *hip_err,
                                  const int *pos_dev = nullptr);
