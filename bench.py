@@ -492,6 +492,39 @@ def whole_token_leg(torch, dev, shape, dl):
                                  "frac_of_8TBs": round((wb + kv) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                  "finite": bool(torch.isfinite(hid.float()).all().item())}
         del g
+    # the same layers for a PROMPT: m rows at once through DecoderBlock.prefill (RMSNorm, the MFMA GEMMs on pre-packed weights, the prefill attention:
+    # 10 launches per layer), positions 0 .. m - 1; eager launches (a 512-row layer is ~0.3 ms of kernels)
+    try:
+        for b in blocks:
+            b.prepare_prefill()
+        pre = {"launches_per_layer": DecoderBlock.PREFILL_LAUNCHES}
+        for m in (512, 2048):
+            rows0 = torch.randn(m, shape.hidden, device=dev).to(torch.float16)
+            rows = rows0.clone()
+
+            def prompt():
+                rows.copy_(rows0)
+                for b in blocks:
+                    b.prefill(rows, 0)
+            prompt()
+            torch.cuda.synchronize()
+            a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 3
+            a.record()
+            for _ in range(reps):
+                prompt()
+            b_.record()
+            torch.cuda.synchronize()
+            ms = a.elapsed_time(b_) / reps
+            lin_flops = 2.0 * m * sum(l.out_features * l.in_features for b in blocks[:1] for l in (b.qkv, b.o, b.gate, b.up, b.down)) * shape.layers
+            att_flops = 4.0 * heads * hd * (m * (m + 1) / 2) * shape.layers
+            pre[f"prompt_{m}_rows"] = {"ms": round(ms, 3), "prompt_tokens_per_s": round(m * 1e3 / ms, 0), "ms_per_layer": round(ms / shape.layers, 4),
+                                       "TFLOPs_linears_plus_causal_attention": round((lin_flops + att_flops) / (ms * 1e-3) / 1e12, 1),
+                                       "finite": bool(torch.isfinite(rows.float()).all().item())}
+            del rows, rows0
+        out["prefill"] = pre
+    except Exception as e:  # noqa: BLE001
+        out["prefill"] = {"error": f"{type(e).__name__}: {e}"}
     del blocks
     torch.cuda.empty_cache()
     return out

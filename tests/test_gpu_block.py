@@ -70,3 +70,50 @@ def test_decoder_blocks_against_float64(hidden, heads, kv_heads, ffn, layers, to
         got = h_gpu.cpu().numpy().astype(np.float64).reshape(-1)
         tol = 2e-2 * np.abs(h).max()
         assert np.abs(got - h).max() <= tol, f"token {pos}: max |err| {np.abs(got - h).max():.4f} vs tol {tol:.4f}"
+
+
+@pytest.mark.parametrize("hidden,heads,kv_heads,ffn,layers,prompt,chunk,prepacked", [(512, 4, 1, 1408, 2, 37, 0, False), (1024, 8, 4, 512, 1, 200, 0, True), (512, 4, 4, 1408, 2, 70, 33, True)])
+def test_prefill_blocks_against_token_by_token_decode(hidden, heads, kv_heads, ffn, layers, prompt, chunk, prepacked):
+    """DecoderBlock.prefill (m rows at once: RMSNorm, GEMMs, the prefill attention, 10 launches per layer) against the SAME blocks stepped token by token
+    through the decode path (5 launches per layer, held to float64 above): the residual streams of all rows within binary16-intermediate tolerance, the caches
+    within the linears' tolerance -- the two paths differ in accumulation order (GEMM / GEMV, fp32 attention both), not in mathematics.  `chunk`: the prompt
+    enters in two pieces (the second on top of the first's cache); `prepacked`: the 128-row GEMM on the q4_mfma copies."""
+    from tinychatengine_amd import capi
+    from tinychatengine_amd.decoder_block import DecoderBlock
+    capi.lib()
+    dev = torch.device("cuda:0")
+    max_keys, hd = 256, 128
+    rng = np.random.default_rng(hidden + prompt)
+    ang = rng.uniform(0, 2 * np.pi, (max_keys, hd // 2))
+    cos = torch.from_numpy(np.concatenate([np.cos(ang), np.cos(ang)], axis=1).astype(np.float16)).to(dev)
+    sin = torch.from_numpy(np.concatenate([np.sin(ang), np.sin(ang)], axis=1).astype(np.float16)).to(dev)
+    mk = lambda: [DecoderBlock(hidden, heads, ffn, max_keys, dev, cos, sin, seed=40 + i, kv_heads=kv_heads) for i in range(layers)]
+    a_blocks, b_blocks = mk(), mk()
+    if prepacked:
+        for b in a_blocks:
+            b.prepare_prefill()
+    x = torch.from_numpy(rng.standard_normal((prompt, hidden)).astype(np.float16)).to(dev)
+    # token by token
+    want = torch.empty_like(x)
+    for t in range(prompt):
+        h = x[t:t + 1].clone()
+        for b in b_blocks:
+            b.step(h, t)
+        want[t] = h[0]
+    # all rows at once (or in two pieces)
+    got = x.clone()
+    pieces = [(0, prompt)] if not chunk else [(0, chunk), (chunk, prompt)]
+    for lo, hi in pieces:
+        rows = got[lo:hi].contiguous()
+        for b in a_blocks:
+            b.prefill(rows, lo)
+        got[lo:hi] = rows
+    torch.cuda.synchronize()
+    w, g = want.float().cpu().numpy(), got.float().cpu().numpy()
+    assert np.isfinite(g).all()
+    tol = 2e-2 * np.abs(w).max()
+    assert np.abs(g - w).max() <= tol, f"residual stream: max |err| {np.abs(g - w).max():.4f} vs tol {tol:.4f}"
+    for a, b in zip(a_blocks, b_blocks):
+        for ca, cb in ((a.attention.k_cache, b.attention.k_cache), (a.attention.v_cache, b.attention.v_cache)):
+            ka, kb = ca[:, :prompt].float().cpu().numpy(), cb[:, :prompt].float().cpu().numpy()
+            assert np.abs(ka - kb).max() <= 2e-2 * np.abs(kb).max(), "caches of the two paths"
