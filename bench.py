@@ -130,7 +130,8 @@ def other_configs_leg(torch, dev):
             out[f"w4a16_prefill_gemm_M{M}"].append(row)
         del packs
         del sets
-    for (M, N, K) in ((512, 768, 768), (512, 3072, 768), (512, 768, 3072), (1, 768, 768)):
+    # BASELINE config 4: the OPT-125M linears at M = 512 / 108 / 1 (the reference's test shapes: test_ops.cc:177-345) ...
+    for (M, N, K) in ((512, 768, 768), (512, 3072, 768), (512, 768, 3072), (108, 768, 768), (108, 3072, 768), (108, 768, 3072), (1, 768, 768), (1, 3072, 768), (1, 768, 3072)):
         a = torch.randint(-128, 128, (M, K), dtype=torch.int8, device=dev)
         b = torch.randint(-128, 128, (N, K), dtype=torch.int8, device=dev)
         bias = torch.randint(-128, 128, (N,), dtype=torch.int8, device=dev)
@@ -139,6 +140,15 @@ def other_configs_leg(torch, dev):
                           q_min=-128, q_max=127, bias_kind=capi.TCE_BIAS_INT8, out_kind=capi.TCE_OUT_INT8)
         us = time_graph(lambda i, sp: capi.check(L.tce_w8a8_matmul(C.byref(d), sp)), 64)
         out["w8a8_opt125m"].append({"M": M, "N": N, "K": K, "us": round(us, 2), "TOPs": round(2.0 * M * N * K / us / 1e6, 1)})
+    # ... and its two attention BMMs as one batched launch each: b = 12, (512, 512, 64) fp32 out and (512, 64, 512) int8 out (test_ops.cc:380-410, 444-473)
+    for (b_, M, N, K, fp32) in ((12, 512, 512, 64, True), (12, 512, 64, 512, False)):
+        a = torch.randint(-128, 128, (b_, M, K), dtype=torch.int8, device=dev)
+        w = torch.randint(-128, 128, (b_, N, K), dtype=torch.int8, device=dev)
+        o = torch.empty((b_, M, N), dtype=torch.float32 if fp32 else torch.int8, device=dev)
+        d = capi.W8A8Desc(M=M, N=N, K=K, batch=b_, A=a.data_ptr(), B=w.data_ptr(), C=o.data_ptr(), strideA=M * K, strideB=N * K, strideC=M * N, alpha=0.0013,
+                          q_min=-128, q_max=127, bias_kind=capi.TCE_BIAS_NONE, out_kind=capi.TCE_OUT_FP32 if fp32 else capi.TCE_OUT_INT8)
+        us = time_graph(lambda i, sp: capi.check(L.tce_w8a8_matmul(C.byref(d), sp)), 64)
+        out["w8a8_opt125m"].append({"batch": b_, "M": M, "N": N, "K": K, "out": "fp32" if fp32 else "int8", "us": round(us, 2), "TOPs": round(2.0 * b_ * M * N * K / us / 1e6, 1)})
     torch.cuda.empty_cache()
     return out
 
