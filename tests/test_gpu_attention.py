@@ -518,9 +518,10 @@ def test_attention_prefill_against_float64_and_the_decode_step(dev, oracle, head
         assert np.all(np.abs(a - b) <= tol), f"decode step vs prefill, last row: {(np.abs(a - b) / tol).max():.3f}"
 
 
-@pytest.mark.parametrize("waves", [4, 8])
+@pytest.mark.parametrize("waves", [4, 8, 14, 18])
 def test_attention_prefill_both_block_sizes(dev, oracle, waves):
-    """Blocks of 64 and of 128 query rows (4 / 8 waves per workgroup; the launch picks by the number of blocks) compute the same thing."""
+    """Blocks of 64, 128 and 256 query rows (4 / 8 waves per workgroup with one 16-row tile per wave; 14 / 18: with two; the launch picks by the number of
+    blocks) compute the same thing."""
     from tinychatengine_amd import capi
     capi.check(capi.lib().tce_w4a16_set_debug_mode(2950 + waves))
     try:

@@ -20,12 +20,14 @@
 // Attention kernel: workgroup = (block of 64 or 128 query rows, query head), 4 or 8 waves x 16 query rows.  Per tile of 64 keys:
 //   * the K tile [64 keys][128] is staged in LDS as it lies (row stride 272 bytes: the MFMA B fragments -- key = lane % 16, 8 consecutive head
 //     dimensions -- are conflict-free 16-byte reads); S = Q K^T: 4 key tiles x 4 k-steps of 32 head dimensions, the Q fragments stay in registers;
-//   * scale, additive mask, causal cut, online softmax on the accumulator layout (a lane holds 4 rows x 4 key columns; row maxima and sums over the
-//     16 lanes of a DPP row);
-//   * P goes through a per-wave LDS slab into A-fragment order (fp16); the V tile is TRANSPOSED while it is staged (V^T [128][64 keys], row stride
-//     144 bytes), because the P V product contracts over keys and an MFMA operand wants its contraction index contiguous: a lane loads 16 bytes
-//     of one key's row and scatters them as eight 2-byte LDS writes (lane = key: neighbouring lanes write neighbouring halves);
-//   * O += P V: 8 column tiles x 2 k-steps of 32 keys.
+//   * scale, additive mask, causal cut, online softmax in fp32 in registers (log2 units: one v_exp_f32 per probability; the validity tests only on tiles
+//     that hold keys past the context or on the causal diagonal);
+//   * everything is computed transposed (see the kernel): S^T = K Q^T leaves ONE query row per lane, so P never touches LDS -- the S^T accumulator
+//     layout is the B-operand layout of v_mfma_f32_16x16x16_f16 -- and O^T += V^T P^T;
+//   * the V tile is staged as it lies too (row stride 288 bytes); the P V product contracts over keys and an MFMA operand wants its contraction index
+//     contiguous per lane, which a row-major V does not give: gfx950's LDS transpose read (ds_read_b64_tr_b16) hands each lane 4 keys of one head dimension
+//     out of a [4 keys][16 dims] block.  (The first version transposed V while staging it -- eight 2-byte LDS writes per 16 bytes, the global loads one
+//     row per lane -- and ran 158 us at 2048 rows; this one 130.)
 // Grouped-query attention: query head i reads key / value head i / (heads / kv_heads); the workgroups of a group stage the same tiles (L2).
 // Rows of the caches at and beyond pos + m may hold anything (uninitialised memory): staged as zeros, and their scores are cut.
 #include "tce_common.hpp"
@@ -38,8 +40,7 @@ namespace {
 constexpr int kHD = 128;
 constexpr int kBK = 64;
 constexpr int kKStride = 272;  // bytes per key row of the K tile in LDS
-constexpr int kVStride = 144;  // bytes per head-dimension row of the V^T tile
-constexpr int kPStride = 144;  // bytes per query row of a wave's P slab
+constexpr int kVStride = 288;  // bytes per key row of the V tile (72 dwords = 8 mod 64: the 8 key rows a 32-lane half reads with the transpose read hit 64 different banks)
 constexpr float kNegBig = -1.0e30f;
 
 struct PrepareArgs {
@@ -109,165 +110,202 @@ __device__ __forceinline__ float row16_max(float v) {
     return v;
 }
 
-// NW: waves per workgroup = 16 query rows each (4: blocks of 64 rows; 8: blocks of 128 rows -- a staged tile serves twice the rows; taken when the
-// launch still has two workgroups per CU's worth of blocks)
-template <bool MASK, int NW>
+// NW: waves per workgroup; RT: 16-row MFMA tiles per wave (2: a K / V fragment feeds two MFMAs; kept for the sweep that ruled it out: > 200 registers,
+// half the occupancy).  A block is 16 * RT * NW query rows: a staged K / V tile serves all of them.
+//
+// Everything is computed TRANSPOSED so that nothing but the operands' tiles touches LDS:
+//   S^T = K Q^T    A = a K fragment (row = key, 8 head dimensions), B = the Q fragment (column = query row): the accumulator lane (n16, quad) holds
+//                  query row n16, keys 16 j + 4 quad + r -- ONE query row per lane, so the online-softmax state is one (m, l) per lane and row tile,
+//                  the row maximum is a register maximum over (j, r) plus two cross-quad exchanges, and the row sum stays a per-lane partial until the end
+//                  (the rescale factor is the same in the four quads);
+//   O^T += V^T P^T  on v_mfma_f32_16x16x16_f16 (contraction = 16 keys, 4 per lane): the B operand -- column = query row n16, keys 4 quad .. 4 quad + 3 -- IS
+//                  the S^T accumulator layout of key tile j: the probabilities go from fp32 to packed fp16 in registers and never see LDS; A = a V^T
+//                  fragment (row = head dimension, 4 keys: an 8-byte LDS read); the accumulator holds head dimensions 16 c + 4 quad + r of query row n16.
+// The validity tests (keys past the context, the causal diagonal) run only on tiles that contain such keys.
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) fp16x4_t lds_fp16x4_t;
+
+__device__ __forceinline__ float quad_max(float v) {  // over the four lanes n16, n16 + 16, n16 + 32, n16 + 48
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+template <bool MASK, int NW, int RT>
 __global__ __launch_bounds__(64 * NW) void attn_prefill_kernel(const PrefillArgs a) {
-    constexpr int kBQ = 16 * NW, NT = 64 * NW, KI = 1024 / NT, VI = 16 / NW;
-    __shared__ __attribute__((aligned(16))) unsigned char ks[kBK * kKStride];      // K tile
-    __shared__ __attribute__((aligned(16))) unsigned char vt[kHD * kVStride];      // V^T tile
-    __shared__ __attribute__((aligned(16))) unsigned char ps[NW][16 * kPStride];   // a P slab per wave
+    constexpr int kBQ = 16 * RT * NW, NT = 64 * NW, KI = 1024 / NT;
+    constexpr float kLog2e = 1.4426950408889634f;
+    __shared__ __attribute__((aligned(16))) unsigned char ks[kBK * kKStride];  // K tile
+    __shared__ __attribute__((aligned(16))) unsigned char vs[kBK * kVStride];  // V tile
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n16 = lane & 15, quad = lane >> 4;
     // (causal: the blocks with the most key tiles are dispatched first)
     const int qb = (int)gridDim.x - 1 - (int)blockIdx.x, head = blockIdx.y, kvh = head / a.rep;
     const int tgz = a.pos + a.m;
-    const int r0 = qb * kBQ + wave * 16;
+    const int r0 = qb * kBQ + wave * 16 * RT;
     // keys this block needs: all of them, or (causal) up to the block's last row's own position
     const int last_row = (qb * kBQ + kBQ < a.m ? qb * kBQ + kBQ : a.m) - 1;
     const int kend = a.causal ? a.pos + last_row + 1 : tgz;
     const int ntiles = (kend + kBK - 1) / kBK;
+    const float scale2 = a.alpha * kLog2e;  // scores in units of log2: exp(x) = exp2(x * log2 e), one v_exp_f32 per probability
 
-    // Q fragments: row r0 + n16 (clamped), head dimensions 32 s + 8 quad ..
-    half8_t qf[4];
-    {
-        int row = r0 + n16;
-        row = row < a.m ? row : a.m - 1;
-        const half_t *qrow = a.qrot + ((size_t)head * a.m + row) * kHD;
+    // Q fragments of row tile t: row r0 + 16 t + n16 (clamped), head dimensions 32 s + 8 quad ..; that row is also the lane's softmax row
+    half8_t qf[RT][4];
+    int rowc[RT];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const half8_t *>(qrow + 32 * s + 8 * quad);
+    for (int t = 0; t < RT; ++t) {
+        const int row = r0 + 16 * t + n16;
+        rowc[t] = row < a.m ? row : a.m - 1;
+        const half_t *qrow = a.qrot + ((size_t)head * a.m + rowc[t]) * kHD;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[t][s] = *reinterpret_cast<const half8_t *>(qrow + 32 * s + 8 * quad);
     }
-    float4_t o[8];
+    float4_t o[RT][8];     // O^T: head dimensions 16 c + 4 quad + r of query row n16
+    float m_i[RT], l_i[RT];  // the row's running maximum (log2 units; the same in the four quads) and this lane's share of its sum
 #pragma unroll
-    for (int c = 0; c < 8; ++c) o[c] = float4_t{0.f, 0.f, 0.f, 0.f};
-    float m_i[4], l_i[4];
+    for (int t = 0; t < RT; ++t) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        m_i[r] = kNegBig;
-        l_i[r] = 0.f;
+        for (int c = 0; c < 8; ++c) o[t][c] = float4_t{0.f, 0.f, 0.f, 0.f};
+        m_i[t] = kNegBig;
+        l_i[t] = 0.f;
     }
     const half_t *kbase = a.kc + (size_t)kvh * a.max_keys * kHD, *vbase = a.vc + (size_t)kvh * a.max_keys * kHD;
-    unsigned char *pw = ps[wave];
 
-    // a tile's global loads: K piece idx = tid + 256 i -> key idx / 16, piece idx % 16 (coalesced rows); V: lane = key, piece = wave + 4 i.  The loads of
-    // tile kt + 1 are requested before tile kt is multiplied (registers), and written to LDS once every wave is done with tile kt.
-    half8_t kreg[KI], vreg[VI];
+    // a tile's global loads, K and V alike: piece idx = tid + NT i -> key idx / 16, piece idx % 16 (coalesced rows).  The loads of tile kt + 1 are requested
+    // before tile kt is multiplied (registers) and written to LDS once every wave is done with tile kt.  (A ring of 3-4 register sets, tiles requested that
+    // far ahead, measured SLOWER -- 151 -> 202 us at 2048 rows: the registers cost occupancy and the rows were not what the waves waited for.)
+    half8_t kreg[KI], vreg[KI];
     auto fetch_tile = [&](int kt) {
         const int key0 = kt * kBK;
 #pragma unroll
         for (int i = 0; i < KI; ++i) {
             const int idx = tid + NT * i, gk = key0 + (idx >> 4);
             kreg[i] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
-            if (gk < kend) kreg[i] = *reinterpret_cast<const half8_t *>(kbase + (size_t)gk * kHD + (idx & 15) * 8);
-        }
-#pragma unroll
-        for (int i = 0; i < VI; ++i) {
-            const int gk = key0 + lane;
             vreg[i] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
-            if (gk < kend) vreg[i] = *reinterpret_cast<const half8_t *>(vbase + (size_t)gk * kHD + (wave + NW * i) * 8);
+            if (gk < kend) {
+                kreg[i] = *reinterpret_cast<const half8_t *>(kbase + (size_t)gk * kHD + (idx & 15) * 8);
+                vreg[i] = *reinterpret_cast<const half8_t *>(vbase + (size_t)gk * kHD + (idx & 15) * 8);
+            }
         }
     };
     fetch_tile(0);
+    // this lane's piece of a [4 keys][16 head dimensions] block for the transpose read: key 4 quad + n16 / 4, head dimensions 4 (n16 % 4) ..
+    const unsigned char *vfrag = vs + (4 * quad + (n16 >> 2)) * kVStride + (n16 & 3) * 8;
     for (int kt = 0; kt < ntiles; ++kt) {
         const int key0 = kt * kBK;
         __syncthreads();  // everybody has read the previous tiles
-        // ---- K as it lies; V transposed: eight 2-byte writes per piece (neighbouring lanes: neighbouring halves of a row of V^T) ----
+        // ---- both tiles as they lie ----
 #pragma unroll
         for (int i = 0; i < KI; ++i) {
             const int idx = tid + NT * i;
             *reinterpret_cast<half8_t *>(ks + (idx >> 4) * kKStride + (idx & 15) * 16) = kreg[i];
-        }
-#pragma unroll
-        for (int i = 0; i < VI; ++i) {
-            const int piece = wave + NW * i;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) *reinterpret_cast<half_t *>(vt + (piece * 8 + e) * kVStride + lane * 2) = vreg[i][e];
+            *reinterpret_cast<half8_t *>(vs + (idx >> 4) * kVStride + (idx & 15) * 16) = vreg[i];
         }
         __syncthreads();
         if (kt + 1 < ntiles) fetch_tile(kt + 1);
-        // ---- S = Q K^T (this wave's 16 rows x 64 keys) ----
-        float4_t sacc[4];
+        // ---- S^T = K Q^T (64 keys x this wave's 16 RT rows): a K fragment feeds the RT row tiles ----
+        float4_t sacc[RT][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            sacc[j] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < RT; ++t) sacc[t][j] = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const half8_t kf = *reinterpret_cast<const half8_t *>(ks + (16 * j + n16) * kKStride + (32 * s + 8 * quad) * 2);
-                sacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[s], kf, sacc[j], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < RT; ++t) sacc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[t][s], sacc[t][j], 0, 0, 0);
             }
         }
-        // ---- scale, mask, cut; online softmax.  The lane holds rows 4 quad + r, key columns 16 j + n16 ----
-        float mx[4];
+        // does this tile hold keys some row of the wave must not see?  (wave-uniform; the last tile, and the tiles on the wave's causal diagonal)
+        const bool edge = key0 + kBK > tgz || (a.causal && key0 + kBK - 1 > a.pos + r0);
+        // ---- scale, mask, cut; online softmax: the lane's row is rowc[t], its keys key0 + 16 j + 4 quad + r ----
+        half4_t pb[RT][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = r0 + 4 * quad + r;
-            const int rowc = row < a.m ? row : a.m - 1;
+        for (int t = 0; t < RT; ++t) {
             float best = kNegBig;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int key = key0 + 16 * j + n16;
-                float s = sacc[j][r] * a.alpha;
-                const bool valid = key < tgz && !(a.causal && key > a.pos + rowc);
+                float4_t mk4 = float4_t{0.f, 0.f, 0.f, 0.f};
                 if constexpr (MASK) {
-                    if (valid) s += (float)a.mask[(size_t)rowc * a.ld_mask + key];
-                }
-                s = valid ? s : kNegBig;
-                s = s > kNegBig ? s : kNegBig;  // a mask of -inf / -65504 sums stays a finite "nothing"
-                sacc[j][r] = s;
-                best = fmaxf(best, s);
-            }
-            mx[r] = row16_max(best);
-        }
+                    const int kb = key0 + 16 * j + 4 * quad;
+                    const half_t *mrow = a.mask + (size_t)rowc[t] * a.ld_mask;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float m_new = fmaxf(m_i[r], mx[r]);
-            const float corr = __expf(m_i[r] - m_new);
+                    for (int r = 0; r < 4; ++r) mk4[r] = kb + r < tgz ? (float)mrow[kb + r] * kLog2e : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float s = sacc[t][j][r] * scale2;
+                    if constexpr (MASK) s += mk4[r];
+                    if (MASK || edge) {
+                        const int key = key0 + 16 * j + 4 * quad + r;
+                        const bool valid = !edge || (key < tgz && !(a.causal && key > a.pos + rowc[t]));
+                        s = valid && s > kNegBig ? s : kNegBig;  // a mask of -inf / -65504 stays a finite "nothing"
+                    }
+                    sacc[t][j][r] = s;
+                    best = fmaxf(best, s);
+                }
+            }
+            const float m_new = fmaxf(m_i[t], quad_max(best));
+            const float corr = __builtin_amdgcn_exp2f(m_i[t] - m_new);
             float rs = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                // a key that is cut weighs nothing even when the whole row so far is cut (m_new == kNegBig: exp(0) would be 1)
-                const float p = sacc[j][r] > kNegBig ? __expf(sacc[j][r] - m_new) : 0.f;
-                rs += p;
-                *reinterpret_cast<half_t *>(pw + (4 * quad + r) * kPStride + (16 * j + n16) * 2) = (half_t)p;
+                float4_t p;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // a key that is cut weighs nothing even when the whole row so far is cut (m_new == kNegBig: exp2(0) would be 1)
+                    p[r] = __builtin_amdgcn_exp2f(sacc[t][j][r] - m_new);
+                    if (MASK || edge) p[r] = sacc[t][j][r] > kNegBig ? p[r] : 0.f;
+                    rs += p[r];
+                }
+                pb[t][j] = half4_t{(half_t)p[0], (half_t)p[1], (half_t)p[2], (half_t)p[3]};
             }
-            l_i[r] = l_i[r] * corr + row16_sum(rs);
-            m_i[r] = m_new;
+            l_i[t] = l_i[t] * corr + rs;
+            m_i[t] = m_new;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) o[c][r] *= corr;
+            for (int c = 0; c < 8; ++c) o[t][c] *= corr;
         }
-        // ---- O += P V: P back in A-fragment order (the slab is this wave's own: LDS operations of a wave complete in order; the empty asm
-        //      statements keep the compiler from moving the 16-byte reads across the 2-byte writes of another type) ----
-        asm volatile("" ::: "memory");
-        half8_t pf[2];
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) pf[s2] = *reinterpret_cast<const half8_t *>(pw + n16 * kPStride + (32 * s2 + 8 * quad) * 2);
+        // ---- O^T += V^T P^T: 8 head-dimension tiles x 4 sub-tiles of 16 keys; a V^T fragment (4 keys: 8 bytes) feeds the RT row tiles ----
 #pragma unroll
         for (int c = 0; c < 8; ++c)
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const half8_t vf = *reinterpret_cast<const half8_t *>(vt + (16 * c + n16) * kVStride + (32 * s2 + 8 * quad) * 2);
-                o[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf[s2], vf, o[c], 0, 0, 0);
-            }
-        asm volatile("" ::: "memory");
-    }
-    // ---- out[row][head * hd + 16 c + n16] ----
+            for (int j = 0; j < 4; ++j) {
+                // V[key 16 j + 4 quad + r][head dimension 16 c + n16], r = 0 .. 3: the 16 lanes of a quad read a [4 keys][16 dims] block of the row-major
+                // tile, 8 bytes each, and ds_read_b64_tr_b16 hands lane n16 the block's column n16 (gfx950's LDS transpose read)
+                const half4_t vf = __builtin_bit_cast(half4_t, __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                    (lds_fp16x4_t *)(vfrag + (16 * j) * kVStride + (16 * c) * 2)));
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = r0 + 4 * quad + r;
+                for (int t = 0; t < RT; ++t) o[t][c] = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pb[t][j], o[t][c], 0, 0, 0);
+            }
+    }
+    // ---- out[row n16][head * hd + 16 c + 4 quad + r]: four consecutive halves per lane and column tile ----
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const float l = quad_sum(l_i[t]);
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        const int row = r0 + 16 * t + n16;
         if (row >= a.m) continue;
-        const float inv = l_i[r] > 0.f ? 1.0f / l_i[r] : 0.f;
         half_t *orow = a.out + (size_t)row * a.ld_out + (size_t)head * kHD;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) orow[16 * c + n16] = (half_t)(o[c][r] * inv);
+        for (int c = 0; c < 8; ++c) {
+            const half4_t v = half4_t{(half_t)(o[t][c][0] * inv), (half_t)(o[t][c][1] * inv), (half_t)(o[t][c][2] * inv), (half_t)(o[t][c][3] * inv)};
+            *reinterpret_cast<half4_t *>(orow + 16 * c + 4 * quad) = v;
+        }
     }
 }
 
-int g_prefill_waves = 0;  // 0: by the rule in launch_attention_prefill; 4 / 8 forced (tests, sweeps)
+int g_prefill_waves = 0;  // 0: by the rule in launch_attention_prefill; forced (tests, sweeps): 4 / 8 waves with one row tile per wave, 14 / 18: with two
 
 }  // namespace
 
-void set_attention_prefill_waves(int w) { g_prefill_waves = (w == 4 || w == 8) ? w : 0; }
+void set_attention_prefill_waves(int w) { g_prefill_waves = (w == 4 || w == 8 || w == 14 || w == 18) ? w : 0; }
 
 size_t attention_prefill_workspace_bytes(int heads, int m, int hd) {
     if (hd != kHD || heads <= 0 || m <= 0) return 0;
@@ -307,16 +345,24 @@ int launch_attention_prefill(const void *qkv, int ld_qkv, void *kc, void *vc, co
     a.m = m;
     a.causal = causal;
     a.alpha = alpha;
-    const bool wide = g_prefill_waves == 8 || (g_prefill_waves == 0 && (long long)((m + 127) / 128) * heads >= 512);
-    if (wide) {
-        const dim3 grid((m + 127) / 128, heads);
-        if (mask) hipLaunchKernelGGL((attn_prefill_kernel<true, 8>), grid, dim3(512), 0, stream, a);
-        else hipLaunchKernelGGL((attn_prefill_kernel<false, 8>), grid, dim3(512), 0, stream, a);
-    } else {
-        const dim3 grid((m + 63) / 64, heads);
-        if (mask) hipLaunchKernelGGL((attn_prefill_kernel<true, 4>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((attn_prefill_kernel<false, 4>), grid, dim3(256), 0, stream, a);
-    }
+    // the block: 128 rows (8 waves) while that leaves two workgroups per CU, else 64 rows (forced: g_prefill_waves)
+    auto blocks = [&](int rows) { return (long long)((m + rows - 1) / rows) * heads; };
+    int form = g_prefill_waves;
+    if (form == 0) form = blocks(128) >= 512 ? 8 : 4;  // (two row tiles per wave -- forms 14 / 18 -- cost more in occupancy than the shared fragments give: 147 vs 130 us at 2048 rows)
+    auto go = [&](auto nw_c, auto rt_c) {
+        constexpr int NW = decltype(nw_c)::value, RT = decltype(rt_c)::value;
+        const dim3 grid((m + 16 * RT * NW - 1) / (16 * RT * NW), heads);
+        if (mask) hipLaunchKernelGGL((attn_prefill_kernel<true, NW, RT>), grid, dim3(64 * NW), 0, stream, a);
+        else hipLaunchKernelGGL((attn_prefill_kernel<false, NW, RT>), grid, dim3(64 * NW), 0, stream, a);
+    };
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I4 = std::integral_constant<int, 4>;
+    using I8 = std::integral_constant<int, 8>;
+    if (form == 18) go(I8{}, I2{});
+    else if (form == 14) go(I4{}, I2{});
+    else if (form == 8) go(I8{}, I1{});
+    else go(I4{}, I1{});
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         if (hip_err) *hip_err = e;
