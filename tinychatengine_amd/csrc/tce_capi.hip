@@ -753,6 +753,7 @@ int tce_attention_prefill_f16(const void *qkv, int ld_qkv, void *kc, void *vc, c
     if (mask && ld_mask == 0) ld_mask = pos + m;
     if (ld_qkv < width || ld_out < heads * hd || (mask && ld_mask < pos + m)) return fail(TCE_ERR_BAD_ARG, "tce_attention_prefill_f16: a leading dimension is shorter than its row");
     if (ld_qkv % 8 != 0) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_attention_prefill_f16: ld_qkv must be a multiple of 8 (16-byte pieces)");
+    if (ld_out % 4 != 0 || (reinterpret_cast<uintptr_t>(out) & 7)) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_attention_prefill_f16: ld_out must be a multiple of 4 and out 8-byte aligned (8-byte stores)");
     for (const void *p : {qkv, (const void *)kc, (const void *)vc, cosv, sinv, (const void *)workspace})
         if (reinterpret_cast<uintptr_t>(p) & 15) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_attention_prefill_f16: 16-byte aligned pointers");
     tce::half_t ah;
