@@ -272,9 +272,20 @@ __global__ __launch_bounds__(256) void w8a8_rowdot_kernel(const W8A8Args a) {
                                           : static_cast<void *>(static_cast<float *>(a.C) + c_off);
     const int pieces = a.K >> 4;
     if constexpr (PER_ROW == 0) {
-        for (int e = tid; e < a.M * pieces; e += 256) {
-            const int r = e / pieces, p = e - r * pieces;
-            lds_dyn[e] = *reinterpret_cast<const int4_t *>(A + (size_t)r * a.lda + p * 16);
+        // the activation rows into LDS, four pieces per thread in flight (left as one load -> one store per iteration, M = 8 x K = 3072 is six dependent
+        // memory round trips in front of everything)
+        const int total = a.M * pieces;
+        for (int e0 = tid; e0 < total; e0 += 256 * 4) {
+            int4_t v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = e0 + 256 * i, ec = e < total ? e : 0;
+                const int r = ec / pieces, p = ec - r * pieces;
+                v[i] = *reinterpret_cast<const int4_t *>(A + (size_t)r * a.lda + p * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (e0 + 256 * i < total) lds_dyn[e0 + 256 * i] = v[i];
         }
         __syncthreads();
         const int n = blockIdx.x * 4 + wave;  // wave-uniform
@@ -390,7 +401,9 @@ int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err)
                          (d.batch == 1 || (d.strideA % 16 == 0 && d.strideB % 16 == 0));
     a.vec_ok = aligned ? 1 : 0;
     const bool rowdot_ok = aligned && g_w8a8_ks != 3;
-    if (rowdot_ok && !d.b_per_row && d.M <= kRowdotMaxM && d.K >= 64 && (size_t)d.M * d.K <= 64 * 1024) {
+    // wave-per-column for M <= 4, and for 5 .. 8 rows when K is long (8 x 768 x 768: 5.2 us against the MFMA kernel's 4.6; 8 x 768 x 3072: 6.5 against 9.8;
+    // 1 x 768 x 3072: 3.4 against 9.4 -- scratch measurements of round 3)
+    if (rowdot_ok && !d.b_per_row && d.M <= kRowdotMaxM && (d.M <= 4 || d.K >= 2048) && d.K >= 64 && (size_t)d.M * d.K <= 64 * 1024) {
         hipLaunchKernelGGL(w8a8_rowdot_kernel<0>, dim3((d.N + 3) / 4, 1, d.batch), dim3(256), (size_t)d.M * d.K, stream, a);
     } else if (rowdot_ok && d.b_per_row && d.batch == 1 && d.K >= 256) {
         const long long outs = (long long)d.M * d.N;
