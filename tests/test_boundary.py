@@ -90,6 +90,30 @@ def test_argument_validation_needs_no_gpu(built):
     assert (4, 4, 1, 2) in capi.gemv_variants() and (4, 2) in capi.gemm_variants()
 
 
+def test_attention_and_glue_argument_validation_needs_no_gpu(built):
+    """The attention / OPT glue entry points refuse bad arguments before any HIP call (host pointers are never dereferenced on these paths)."""
+    capi = built
+    L = capi.lib()
+    buf = (C.c_char * 8192)()
+    p = (C.addressof(buf) + 15) & ~15
+    vp = C.c_void_p
+    assert int(L.tce_attention_prefill_workspace_bytes(32, 100, 128)) == 32 * 100 * 128 * 2 and int(L.tce_attention_prefill_workspace_bytes(32, 100, 64)) == 0
+    pre = lambda **kw: L.tce_attention_prefill_f16(vp(kw.get("qkv", p)), kw.get("ld_qkv", 0), vp(p), vp(p), None, None, None, 0, 1, vp(kw.get("out", p)), kw.get("ld_out", 0), vp(kw.get("ws", p)),
+                                                   kw.get("heads", 4), kw.get("kv", 2), kw.get("hd", 128), 64, kw.get("pos", 0), kw.get("m", 8), 0x2DA8, None)
+    assert pre(kv=3) == capi.TCE_ERR_BAD_ARG and "do not divide" in capi.last_error()
+    assert pre(hd=64) == capi.TCE_ERR_UNSUPPORTED_SHAPE
+    assert pre(pos=60) == capi.TCE_ERR_BAD_ARG                 # pos + m > max_keys
+    assert pre(ws=None) == capi.TCE_ERR_BAD_ARG
+    assert pre(qkv=p + 2) == capi.TCE_ERR_UNSUPPORTED_SHAPE    # 16-byte pieces
+    assert pre(ld_qkv=100) == capi.TCE_ERR_BAD_ARG             # shorter than a row
+    assert pre(out=p + 4) == capi.TCE_ERR_UNSUPPORTED_SHAPE    # 8-byte stores
+    assert pre(ld_out=4 * 128 + 2) == capi.TCE_ERR_UNSUPPORTED_SHAPE
+    assert L.tce_attention_decode_step_gqa_f16(vp(p), vp(p), vp(p), None, None, None, vp(p), vp(p), 6, 4, 128, 64, 0, 0x2DA8, None) == capi.TCE_ERR_BAD_ARG
+    assert L.tce_opt_softmax_q(vp(p), vp(p), vp(p), 2, 2, 8, 4, None) == capi.TCE_ERR_BAD_ARG            # ld_probs < tgz
+    assert L.tce_opt_softmax_q(vp(p), vp(p), vp(p), 2, 2, 9000, 0, None) == capi.TCE_ERR_UNSUPPORTED_SHAPE
+    assert L.tce_opt_kv_append(vp(p), vp(p), vp(p), vp(p), 2, 64, 4, 62, 64, None) == capi.TCE_ERR_BAD_ARG  # pos + sq > max_keys
+
+
 def test_adapter_exports_the_reference_member_functions(built):
     from tinychatengine_amd import build as B
     out = subprocess.check_output(["nm", "-D", "--defined-only", "-C", B.ADAPTER_LIB_PATH], text=True)
