@@ -111,7 +111,9 @@ typedef struct tce_w4a16_desc {
  *       linear holds the two projections' rows INTERLEAVED (row 2n = gate row n, row 2n+1 = up row n; a load-time row
  *       permutation, like the reference's offline qkv merge), N is even, and
  *           C[m][n] = hmul( hmul(g, hdiv(1, hadd(1, hexp(hneg(g))))), u ),  g = fp16(y[m][2n]), u = fp16(y[m][2n+1])
- *       with every operation rounded to fp16 as in the reference kernel.  C is [M][N/2] (ldc 0 = N/2).  M <= 8 path.
+ *       with every operation rounded to fp16 as in the reference kernel.  C is [M][N/2] (ldc 0 = N/2).  Decode batches (M <= 8) run it in the GEMV
+ *       kernels' epilogue; a batch of M >= 192 rows with a `prepacked` copy in the 128-row GEMM's (the prompt path); anything else on the GEMV kernel,
+ *       four rows per pass.
  *   TCE_W4_ADD_TO_C        replaces o_proj / down_proj + add_half (Int4llamaDecoderLayer.cu:12-18, 86-88, 107-108):
  *           C[m][n] = hadd(C[m][n], fp16(y[m][n]))   (C holds the residual on entry, like residual_add there). */
 #define TCE_W4_SILU_MUL_PAIRS 8

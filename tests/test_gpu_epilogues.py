@@ -257,3 +257,44 @@ def test_decoder_layer_linears_fused_in_plans(dev, oracle):
         plan.status()
         check(f"token kernel, replay {it}")
     plan.close()
+
+
+@pytest.mark.parametrize("M,H,K", [(512, 2752, 1024), (200, 136, 512), (300, 1032, 2048), (130, 264, 512)])
+def test_gate_up_silu_mul_on_the_prefill_gemm(dev, oracle, M, H, K):
+    """TCE_W4_SILU_MUL_PAIRS on a batch with pre-packed weights: the pair epilogue of the 128-row GEMM (w4a16_gemm_pk.hip) against the
+    gate GEMM and the up GEMM on the same kernel followed by tce_silu_mul_half (the prefill form of Int4llamaDecoderLayer.cu:96-102); column tails (H = 136:
+    272 interleaved columns, not a multiple of 128 or 16) and the k range cut across workgroups (few tiles) included.  Below the GEMM's row threshold (M = 130)
+    the flag runs on the GEMV kernel as before: there the tolerance is the linears' (another accumulation order), one binary16 step on the products."""
+    from tinychatengine_amd import capi
+    from tinychatengine_amd.linear import Linear_half_int4
+    g = torch.Generator(device=dev).manual_seed(M + H + K)
+    rnd = lambda n, k: torch.empty(n, k, device=dev).normal_(0.0, k ** -0.5, generator=g)
+    gate, up = Linear_half_int4.from_float(rnd(H, K)), Linear_half_int4.from_float(rnd(H, K))
+    both = Linear_half_int4.interleave(gate, up)
+    for l in (gate, up, both):
+        l.prepack()
+    x = torch.randn(M, K, device=dev, generator=g).to(torch.float16)
+    st = torch.cuda.current_stream().cuda_stream
+    a, b = torch.empty((M, H), dtype=torch.float16, device=dev), torch.empty((M, H), dtype=torch.float16, device=dev)
+    capi.check(capi.w4a16_forward(gate.desc(x, a), st))
+    capi.check(capi.w4a16_forward(up.desc(x, b), st))
+    capi.check(capi.lib().tce_silu_mul_half(a.data_ptr(), b.data_ptr(), a.numel(), st))
+    fused = torch.full((M, H), 7.0, dtype=torch.float16, device=dev)
+    d = both.desc(x, fused, flags=capi.TCE_W4_SILU_MUL_PAIRS)
+    capi.check(capi.w4a16_forward(d, st))
+    torch.cuda.synchronize()
+    import ctypes as C
+    buf = C.create_string_buffer(256)
+    capi.lib().tce_w4a16_describe_dispatch(C.byref(d), buf, 256)
+    want, got = a.cpu().numpy(), fused.cpu().numpy()
+    assert np.isfinite(got).all()
+    if M >= 192:
+        assert buf.value.decode().startswith("gemm-pk"), buf.value
+        # the fused launch (N = 2 H columns) and the separate ones (N = H) may run different forms of the kernel (tile width, k range cut across workgroups): the
+        # same products summed in another fp32 order, so a gate or up value can round to the neighbouring half -- few elements, one step on the factors
+        differ = got != want
+        assert differ.mean() < 5e-3, f"{differ.sum()} elements differ"
+        g64, w64 = got.astype(np.float64), want.astype(np.float64)
+        assert np.all(np.abs(g64 - w64) <= 2.0 ** -8 * np.abs(w64) + 2.0 ** -14), "more than rounding-order differences"
+    else:
+        assert np.abs(got.astype(np.float64) - want.astype(np.float64)).max() <= 2e-2 * np.abs(want.astype(np.float64)).max()

@@ -76,9 +76,10 @@ constexpr int kPkMinM = 192;  // below: the 64-row tiles / the small-batch kerne
 
 // the pre-packed 128-row GEMM takes the launch when a packed copy came with the descriptor and the batch is large enough
 static bool use_pk(const tce_w4a16_desc *d, bool want_gemm) {
-    if (!d->prepacked || g_pk_mode == 9 || !want_gemm || d->K % 128 != 0 || (d->flags & TCE_W4_SILU_MUL_PAIRS) || d->rmsnorm_gamma) return false;
+    if (!d->prepacked || g_pk_mode == 9 || !want_gemm || d->K % 128 != 0 || d->rmsnorm_gamma) return false;
     if (g_pk_mode >= 1 && g_pk_mode <= 4) return true;
     if (d->M < kPkMinM || g_gemm_mt != 0) return false;
+    if (d->flags & TCE_W4_SILU_MUL_PAIRS) return true;  // the other GEMM kernels have no pair epilogue: the alternative is the GEMV kernel, M / 4 passes
     // both dispatchers' cost models, fitted to the same kind of sweep (the 64-row tiles win while the 128-row tiles are too few
     // to fill the chip: M = 512 at N = 4096); groups of 64 / 32: the pre-packed kernel needs no LDS re-deal, it takes them
     if (d->group_size != 128) return true;
@@ -364,11 +365,12 @@ int tce_w4a16_forward_group(const tce_w4a16_desc *descs, int count, void *stream
 int tce_w4a16_forward(const tce_w4a16_desc *d, void *stream) {
     const int rc0 = check_w4a16(d);
     if (rc0 != TCE_OK) return rc0;
-    // (the pair epilogue lives in the GEMV kernels: for M > 8 it runs there too, 4 activation rows per pass)
+    // (the pair epilogue lives in the GEMV kernels and in the pre-packed GEMM: without a packed copy a batch of M > 8 runs on the GEMV kernel, 4 activation rows per pass)
     const bool want_gemm = (d->flags & TCE_W4_FORCE_GEMM) ||
                            (d->M > TCE_W4A16_GEMV_MAX_M && !(d->flags & (TCE_W4_FORCE_GEMV | TCE_W4_SILU_MUL_PAIRS)));
+    const bool pairs_on_pk = (d->flags & TCE_W4_SILU_MUL_PAIRS) && d->prepacked && d->M >= kPkMinM && !(d->flags & TCE_W4_FORCE_GEMV);
     hipError_t he = hipSuccess;
-    if (use_pk(d, want_gemm)) {  // large batches on a pre-packed copy: 128 rows per wave (w4a16_gemm_pk.hip)
+    if (use_pk(d, want_gemm || pairs_on_pk)) {  // large batches on a pre-packed copy: 128 rows per wave (w4a16_gemm_pk.hip)
         const int rc = tce::launch_w4a16_gemm_pk(*d, d->prepacked, static_cast<hipStream_t>(stream), &he);
         if (rc == TCE_OK) return TCE_OK;
         if (rc == TCE_ERR_HIP) return hip_fail(he, "w4a16 gemm (pre-packed) launch");
@@ -411,7 +413,8 @@ int tce_w4a16_describe_dispatch(const tce_w4a16_desc *d, char *buf, int buf_len)
     if (rc0 != TCE_OK) return rc0;
     const bool want_gemm = (d->flags & TCE_W4_FORCE_GEMM) ||
                            (d->M > TCE_W4A16_GEMV_MAX_M && !(d->flags & (TCE_W4_FORCE_GEMV | TCE_W4_SILU_MUL_PAIRS)));
-    if (use_pk(d, want_gemm)) {
+    const bool pairs_on_pk = (d->flags & TCE_W4_SILU_MUL_PAIRS) && d->prepacked && d->M >= kPkMinM && !(d->flags & TCE_W4_FORCE_GEMV);
+    if (use_pk(d, want_gemm || pairs_on_pk)) {
         int form = 1, split = 1;
         tce::gemm_pk_estimate_us(d->M, d->N, d->K, &form, d->scratch != nullptr && (reinterpret_cast<uintptr_t>(d->scratch) & 255) == 0, &split);
         if (form == 4) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=128x128 quartets=1 ksplit=%d group=%d", split, d->group_size);

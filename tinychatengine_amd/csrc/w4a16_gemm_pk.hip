@@ -114,6 +114,7 @@ struct PkGemmArgs {
     int M, N, K, lda, ldc;
     int n_blocks, m_blocks;  // 128 x 128 tiles
     int add_to_c;
+    int pairs;  // TCE_W4_SILU_MUL_PAIRS: output column n / 2 = SiLuMul_half(column n, column n + 1) for even n; C is [M][N / 2]
     int xm, m_per, n_per;
     int split_s;          // > 1: the k-blocks of the tiles in slots >= full_slots are cut into split_s runs, one workgroup each (one quartet,
     int full_slots;       //      128 x 128 tiles only); slot = workgroup index / 8 of the tile's first run.  0: every tile is cut
@@ -559,6 +560,13 @@ __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(23
         const int m = m_base + row, n = nb0 + pc * 8;
         if (m >= g.M || n >= g.N) continue;
         const half8_t v = *reinterpret_cast<const half8_t *>(lds_c + row * BN + pc * 8);
+        if (g.pairs) {  // interleaved gate / up columns: the fp16 values the two linears would have stored, then SiLuMul_half (Int4llamaDecoderLayer.cu:20-30, 96-102)
+            half_t *c2 = g.C + (size_t)m * g.ldc + (n >> 1);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (n + 2 * u + 1 < g.N) c2[u] = silu_mul_half(v[2 * u], v[2 * u + 1]);
+            continue;
+        }
         half_t *c = g.C + (size_t)m * g.ldc + n;
         if (vec_ok && n + 8 <= g.N) {
             half8_t o = v;
@@ -727,7 +735,8 @@ int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_
     g.N = d.N;
     g.K = d.K;
     g.lda = lda;
-    g.ldc = d.ldc ? d.ldc : d.N;
+    g.pairs = (d.flags & TCE_W4_SILU_MUL_PAIRS) ? 1 : 0;
+    g.ldc = d.ldc ? d.ldc : (g.pairs ? d.N / 2 : d.N);
     g.add_to_c = (d.flags & TCE_W4_ADD_TO_C) ? 1 : 0;
     int form = 1, split = 1;
     const bool has_scratch = d.scratch != nullptr && (reinterpret_cast<uintptr_t>(d.scratch) & 255) == 0;

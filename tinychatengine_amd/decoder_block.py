@@ -62,14 +62,14 @@ class DecoderBlock:
     # ---- m > 1 rows: a prompt, or a chunk of one (the same reference code path with sqlen > 1) ----
     def prepare_prefill(self) -> "DecoderBlock":
         """Load-time work for the prefill path: the q4_mfma copies the 128-row GEMM reads (tce_w4a16_prepack)."""
-        for l in (self.qkv, self.o, self.gate, self.up, self.down):
+        for l in (self.qkv, self.o, self.gate_up, self.down):
             l.prepack()
         return self
 
     def prefill(self, hidden_rows: torch.Tensor, pos: int) -> None:
-        """hidden_rows fp16 [m][hidden], updated in place; the m rows take positions pos .. pos + m - 1.  TEN launches where the reference issues its ~20 + the
-        per-head copies: RMSNorm, q/k/v GEMM, [rotation + KV append], attention, o_proj GEMM + residual, RMSNorm, gate GEMM, up GEMM, SiLU*mul, down_proj GEMM +
-        residual (the GEMMs have no fused norm prologue / pair epilogue: those are decode forms)."""
+        """hidden_rows fp16 [m][hidden], updated in place; the m rows take positions pos .. pos + m - 1.  EIGHT launches where the reference issues its ~20 + the
+        per-head copies: RMSNorm, q/k/v GEMM, [rotation + KV append], attention, o_proj GEMM + residual, RMSNorm, gate/up GEMM with the SiLU*mul pair epilogue,
+        down_proj GEMM + residual (the GEMMs have no fused norm prologue: that is a decode form)."""
         from .linear import rmsnorm_half
         m = hidden_rows.shape[0]
         assert hidden_rows.dtype == torch.float16 and hidden_rows.is_contiguous() and hidden_rows.shape[1] == self.hidden
@@ -84,12 +84,15 @@ class DecoderBlock:
         self.attention.prefill(qkv, pos, out=attn, causal=True)
         capi.check(capi.w4a16_forward(self.o.desc(attn, hidden_rows, flags=capi.TCE_W4_ADD_TO_C), st))
         rmsnorm_half(hidden_rows, self.gamma2, self.eps, out=xn)
-        capi.check(capi.w4a16_forward(self.gate.desc(xn, g), st))
-        capi.check(capi.w4a16_forward(self.up.desc(xn, u), st))
-        capi.check(capi.lib().tce_silu_mul_half(g.data_ptr(), u.data_ptr(), g.numel(), st))
+        if m >= 192 and self.gate_up.packed is not None:  # gate + up + SiLU*mul as ONE GEMM launch on the interleaved rows (pair epilogue of the 128-row GEMM)
+            capi.check(capi.w4a16_forward(self.gate_up.desc(xn, g, flags=capi.TCE_W4_SILU_MUL_PAIRS), st))
+        else:
+            capi.check(capi.w4a16_forward(self.gate.desc(xn, g), st))
+            capi.check(capi.w4a16_forward(self.up.desc(xn, u), st))
+            capi.check(capi.lib().tce_silu_mul_half(g.data_ptr(), u.data_ptr(), g.numel(), st))
         capi.check(capi.w4a16_forward(self.down.desc(g, hidden_rows, flags=capi.TCE_W4_ADD_TO_C), st))
 
-    PREFILL_LAUNCHES = 10
+    PREFILL_LAUNCHES = 8  # with pre-packed weights and m >= 192 (otherwise 10: gate, up and SiLU*mul as three launches)
 
     def linear_bytes(self) -> int:
         return sum(capi.algorithmic_bytes(1, l.out_features, l.in_features, l.group_size) for l in (self.qkv, self.o, self.gate_up, self.down))
