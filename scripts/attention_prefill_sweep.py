@@ -32,12 +32,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="gpurun_out/attention_prefill_sweep.jsonl")
     ap.add_argument("--chain", action="store_true", help="also time the reference-arithmetic operators (slow)")
-    ap.add_argument("--waves", type=int, default=0, help="force 4 / 8 waves per workgroup (0: the launch's rule)")
+    ap.add_argument("--waves", type=int, default=0, help="force 4 / 8 waves per workgroup (0: the launch's rule; 14 / 18: two row tiles per wave)")
+    ap.add_argument("--pair", type=int, default=0, help="heavy / light block pairing: 0 the launch's rule, 1 forced on, 2 forced off (with --waves 0 / 4 / 8)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     hd = 128
     from tinychatengine_amd import capi
-    capi.check(capi.lib().tce_w4a16_set_debug_mode(2950 + args.waves))
+    capi.check(capi.lib().tce_w4a16_set_debug_mode((2950 if args.pair == 0 else (2700 if args.pair == 1 else 2800)) + args.waves))
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
     with open(args.out, "w") as f:
         for heads, kv_heads, pos, m in [(32, 32, 0, 128), (32, 32, 0, 512), (32, 8, 0, 512), (32, 32, 0, 2048), (32, 8, 0, 2048), (32, 32, 1536, 512), (32, 8, 3584, 512), (32, 8, 0, 4096)]:
@@ -52,7 +53,7 @@ def main():
             reps = 20 if m <= 2048 else 5
             us = timed(lambda: att.prefill(qkv, pos, out=out, causal=True), reps)
             flops = 4.0 * heads * hd * (m * pos + m * (m + 1) / 2)
-            rec = {"waves_forced": args.waves, "query_heads": heads, "kv_heads": kv_heads, "cached_keys": pos, "new_rows": m, "us": round(us, 1), "TFLOPs_causal": round(flops / us / 1e6, 1),
+            rec = {"waves_forced": args.waves, "pairing": ["rule", "on", "off"][args.pair], "query_heads": heads, "kv_heads": kv_heads, "cached_keys": pos, "new_rows": m, "us": round(us, 1), "TFLOPs_causal": round(flops / us / 1e6, 1),
                    "finite": bool(torch.isfinite(out).all().item())}
             # yardstick: torch SDPA on [1][heads][m][hd] x [1][heads][pos + m][hd], causal on the last m rows
             q = qkv[:, : heads * hd].reshape(m, heads, hd).transpose(0, 1).contiguous()[None]

@@ -88,6 +88,7 @@ struct PrefillArgs {
     half_t *out;             // [m][ld_out]: row r, columns head * hd ..
     int ld_mask, ld_out;
     int heads, rep, max_keys, pos, m, causal;
+    int pair;  // a workgroup takes two query blocks (see attn_prefill_kernel)
     float alpha;
 };
 
@@ -138,16 +139,13 @@ __device__ __forceinline__ float quad_sum(float v) {
 }
 
 template <bool MASK, int NW, int RT>
-__global__ __launch_bounds__(64 * NW) void attn_prefill_kernel(const PrefillArgs a) {
+__device__ __forceinline__ void attn_prefill_block(const PrefillArgs &a, const int qb, const int head, unsigned char *ks, unsigned char *vs) {
     constexpr int kBQ = 16 * RT * NW, NT = 64 * NW, KI = 1024 / NT;
     constexpr float kLog2e = 1.4426950408889634f;
-    __shared__ __attribute__((aligned(16))) unsigned char ks[kBK * kKStride];  // K tile
-    __shared__ __attribute__((aligned(16))) unsigned char vs[kBK * kVStride];  // V tile
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n16 = lane & 15, quad = lane >> 4;
-    // (causal: the blocks with the most key tiles are dispatched first)
-    const int qb = (int)gridDim.x - 1 - (int)blockIdx.x, head = blockIdx.y, kvh = head / a.rep;
+    const int kvh = head / a.rep;
     const int tgz = a.pos + a.m;
     const int r0 = qb * kBQ + wave * 16 * RT;
     // keys this block needs: all of them, or (causal) up to the block's last row's own position
@@ -301,11 +299,36 @@ __global__ __launch_bounds__(64 * NW) void attn_prefill_kernel(const PrefillArgs
     }
 }
 
+// The launch: a workgroup takes query block nb - 1 - blockIdx.x (causal launches dispatch the blocks with the most key tiles first) and, when `pair` is set,
+// block blockIdx.x after it: block b of a causal prompt walks b + 1 (x 2 for 128-row blocks) key tiles, so the pair (nb - 1 - i, i) is the same work for every
+// i -- unpaired, all workgroups are resident at once and the launch lasts as long as its heaviest block while the CUs of the light ones idle.
+template <bool MASK, int NW, int RT, bool PAIR>
+__global__ __launch_bounds__(64 * NW) void attn_prefill_kernel(const PrefillArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char ks[kBK * kKStride];  // K tile
+    __shared__ __attribute__((aligned(16))) unsigned char vs[kBK * kVStride];  // V tile
+    constexpr int kBQ = 16 * RT * NW;
+    const int nb = (a.m + kBQ - 1) / kBQ;
+    const int first = nb - 1 - (int)blockIdx.x;
+    if constexpr (PAIR) {
+        // (two inlined copies, not a loop around one: 35 registers more -- the paired launch is one 8-wave workgroup per CU anyway -- and 107 against 118 us
+        //  at 2048 rows; the unpaired kernel is its own instantiation because those registers would cost it its second workgroup per CU)
+        attn_prefill_block<MASK, NW, RT>(a, first, blockIdx.y, ks, vs);
+        if ((int)blockIdx.x < first) attn_prefill_block<MASK, NW, RT>(a, blockIdx.x, blockIdx.y, ks, vs);
+    } else {
+        attn_prefill_block<MASK, NW, RT>(a, first, blockIdx.y, ks, vs);
+    }
+}
+
+int g_prefill_pair = 0;   // 0: by the rule; 1 / 2: pairing forced on / off
 int g_prefill_waves = 0;  // 0: by the rule in launch_attention_prefill; forced (tests, sweeps): 4 / 8 waves with one row tile per wave, 14 / 18: with two
 
 }  // namespace
 
-void set_attention_prefill_waves(int w) { g_prefill_waves = (w == 4 || w == 8 || w == 14 || w == 18) ? w : 0; }
+void set_attention_prefill_waves(int w) {
+    g_prefill_pair = w / 100;  // + 100: pairs forced on, + 200: off
+    w %= 100;
+    g_prefill_waves = (w == 4 || w == 8 || w == 14 || w == 18) ? w : 0;
+}
 
 size_t attention_prefill_workspace_bytes(int heads, int m, int hd) {
     if (hd != kHD || heads <= 0 || m <= 0) return 0;
@@ -348,12 +371,20 @@ int launch_attention_prefill(const void *qkv, int ld_qkv, void *kc, void *vc, co
     // the block: 128 rows (8 waves) while that leaves two workgroups per CU, else 64 rows (forced: g_prefill_waves)
     auto blocks = [&](int rows) { return (long long)((m + rows - 1) / rows) * heads; };
     int form = g_prefill_waves;
-    if (form == 0) form = blocks(128) >= 512 ? 8 : 4;  // (two row tiles per wave -- forms 14 / 18 -- cost more in occupancy than the shared fragments give: 147 vs 130 us at 2048 rows)
+    if (form == 0) form = blocks(128) >= 512 ? 8 : 4;
+    // causal prompts: pair a heavy block with a light one while the pairs still fill the chip
+    a.pair = g_prefill_pair == 1 || (g_prefill_pair == 0 && causal && blocks(form == 8 || form == 18 ? (form == 18 ? 256 : 128) : (form == 14 ? 128 : 64)) >= 512) ? 1 : 0;  // (two row tiles per wave -- forms 14 / 18 -- cost more in occupancy than the shared fragments give: 147 vs 130 us at 2048 rows)
     auto go = [&](auto nw_c, auto rt_c) {
         constexpr int NW = decltype(nw_c)::value, RT = decltype(rt_c)::value;
-        const dim3 grid((m + 16 * RT * NW - 1) / (16 * RT * NW), heads);
-        if (mask) hipLaunchKernelGGL((attn_prefill_kernel<true, NW, RT>), grid, dim3(64 * NW), 0, stream, a);
-        else hipLaunchKernelGGL((attn_prefill_kernel<false, NW, RT>), grid, dim3(64 * NW), 0, stream, a);
+        const int nb = (m + 16 * RT * NW - 1) / (16 * RT * NW);
+        const dim3 grid(a.pair ? (nb + 1) / 2 : nb, heads);
+        if (a.pair) {
+            if (mask) hipLaunchKernelGGL((attn_prefill_kernel<true, NW, RT, true>), grid, dim3(64 * NW), 0, stream, a);
+            else hipLaunchKernelGGL((attn_prefill_kernel<false, NW, RT, true>), grid, dim3(64 * NW), 0, stream, a);
+        } else {
+            if (mask) hipLaunchKernelGGL((attn_prefill_kernel<true, NW, RT, false>), grid, dim3(64 * NW), 0, stream, a);
+            else hipLaunchKernelGGL((attn_prefill_kernel<false, NW, RT, false>), grid, dim3(64 * NW), 0, stream, a);
+        }
     };
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;

@@ -142,6 +142,10 @@ int tce_w4a16_set_debug_mode(int mode) {
         tce::set_skinny_max_m(mode - 1000);
         return TCE_OK;
     }
+    if (mode >= 2700 && mode <= 2899 && ((mode - 2700) % 100 == 0 || (mode - 2700) % 100 == 4 || (mode - 2700) % 100 == 8)) {  // prefill attention, block pairing forced: 27xx on, 28xx off; xx = 00 / 04 / 08 as 2950 / 2954 / 2958
+        tce::set_attention_prefill_waves((mode >= 2800 ? 200 : 100) + (mode % 100));
+        return TCE_OK;
+    }
     if (mode == 2950 || mode == 2954 || mode == 2958 || mode == 2964 || mode == 2968) {  // prefill attention: 2950 automatic; 4 / 8 waves x 1 row tile; 2964 / 2968: x 2 row tiles
         tce::set_attention_prefill_waves(mode - 2950);
         return TCE_OK;
