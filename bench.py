@@ -396,7 +396,7 @@ def opt_layer_leg(torch, dev):
         torch.cuda.synchronize()
         us = a.elapsed_time(b) * 1e3 / reps
         ops = layers[0].int8_ops(m, tgz)
-        out[name] = {"rows": m, "keys": tgz, "us_per_layer": round(us / NL, 2), "launches_per_layer": Int8OPTDecoderLayer.launches(m), "us_per_12_layers": round(us, 1),
+        out[name] = {"rows": m, "keys": tgz, "us_per_layer": round(us / NL, 2), "launches_per_layer": layers[0].launches(m), "us_per_12_layers": round(us, 1),
                      "int8_TOPs": round(ops * NL / us / 1e6, 2), "finite": bool(torch.isfinite(hid).all().item()),
                      **({"tokens_per_s_12_layers": round(1e6 / us, 1)} if m == 1 else {"prefill_tokens_per_s_12_layers": round(m * 1e6 / us, 1)})}
         del g, layers

@@ -47,7 +47,7 @@ extern "C" {
 
 #define TCE_API __attribute__((visibility("default")))
 
-#define TCE_VERSION 104 /* 0.1.4: tce_attention_prefill_f16 (0.1.3: tce_attention_decode_step_gqa_f16, TCE_PLAN_OVERLAPPED; 0.1.2: tce_w4a16_desc.scratch; 0.1.1: .prepacked, tce_w4a16_prepack*) */
+#define TCE_VERSION 105 /* 0.1.5: tce_opt_attention_decode; 0.1.4: tce_attention_prefill_f16 (0.1.3: tce_attention_decode_step_gqa_f16, TCE_PLAN_OVERLAPPED; 0.1.2: tce_w4a16_desc.scratch; 0.1.1: .prepacked, tce_w4a16_prepack*) */
 
 /* error codes (return values) */
 #define TCE_OK 0
@@ -303,6 +303,15 @@ TCE_API int tce_opt_softmax_q(const float *scores, const float *mask, void *prob
  * and, TRANSPOSED (the pv BMM's operand, :271-273 without the per-token transpose of the whole cache), to columns [pos, pos + sq) of
  * vt_cache [heads][hd][max_keys]. */
 TCE_API int tce_opt_kv_append(const void *k, const void *v, void *k_cache, void *vt_cache, int heads, int hd, int sq, int pos, int max_keys, void *stream);
+/* The whole OPT attention of a DECODE step (m <= 8 new rows) between the q/k/v projections and out_proj as ONE launch (csrc/opt_attention.hip): the KV append
+ * of tce_opt_kv_append, the qk BMM (BMM_S8T_S8N_F32T.cc:12-62), tce_opt_softmax_q and the pv BMM (BMM_S8T_S8N_S8T.cc:12-63, clamp -128 .. 127) -- int32 dot
+ * products and the same floating-point operations in the same order, so `out` and both caches are bit-identical to the four separate launches.
+ *   q, k_new, v_new  int8 [m][ld]: the projections' output rows (head h: columns h * 64 ..; ld 0 = heads * 64)
+ *   k_cache int8 [heads][max_keys][64], vt_cache int8 [heads][64][max_keys]: rows / columns pos .. pos + m - 1 are written
+ *   mask fp32 [m][pos + m] additive;  out int8 [m][ld]: head h writes its 64 columns (out_proj's input rows)
+ * head_dim == 64, m <= 8, ld and max_keys multiples of 16. */
+TCE_API int tce_opt_attention_decode(const void *q, const void *k_new, const void *v_new, void *k_cache, void *vt_cache, const float *mask, void *out, int heads,
+                                     int head_dim, int m, int pos, int max_keys, int ld, float alpha_qk, float alpha_pv, void *stream);
 
 /* LayerNormQ::forward (llm/src/ops/LayerNormQ.cc:12-52), the op in front of the W8A8 linears: x fp32 [m][n],
  * weight / bias fp32 [n], out int8 [m][n] = (int8) round((x - mean) / sqrt(var + 1e-5) * weight + bias), sums sequential

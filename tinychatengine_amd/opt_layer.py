@@ -7,6 +7,7 @@ the whole past into the other cache buffer, the qk BMM (a host loop over heads),
 the whole value cache, the pv BMM (host loop over heads), `unshape`, out_proj, add, LayerNormQ, fc1, fc2, add.  Here a layer is
 
     decode (m <= 8 new rows)                                   prefill (m > 8)
+    (decode, the default: steps 2-5 are ONE launch, tce_opt_attention_decode -- 5 launches per layer; `fused_attention = False` issues them separately)
     1  LayerNormQ + q, k, v        tce_layernorm_q_w8a8_group   tce_layernorm_q + 3 x tce_w8a8_matmul
     2  KV append (k as rows, v as columns)  tce_opt_kv_append   same
     3  qk BMM, all heads           tce_w8a8_matmul (the head's 64 columns of q as they lie: lda = embed; keys from the cache)
@@ -16,7 +17,7 @@ the whole value cache, the pv BMM (host loop over heads), `unshape`, out_proj, a
     7  LayerNormQ + fc1 (ReLU)     tce_layernorm_q_w8a8_group   tce_layernorm_q + tce_w8a8_matmul
     8  fc2 + residual add          tce_w8a8_matmul (fp32 out, accumulate)
 
-8 launches (decode) / 12 (prefill); every buffer is allocated once, so a step is a fixed launch sequence (capturable in a hipGraph for a
+5 launches (decode; 8 with the attention's steps issued separately) / 12 (prefill); every buffer is allocated once, so a step is a fixed launch sequence (capturable in a hipGraph for a
 fixed position).  Synthetic parameters; nothing here loads a checkpoint.  The arithmetic of every launch is the reference's
 (tests/test_gpu_w8a8.py holds the layer to the oracle's composition of the same steps).
 """
@@ -53,6 +54,7 @@ class Int8OPTDecoderLayer:
         self.W1, self.b1, self.a_1, self.b_1 = i8(ffn, embed), i8(ffn), 2.0e-4, 0.05
         self.W2, self.b2, self.a_2 = i8(embed, ffn), f32(embed) * 0.1, 5.0e-5
         self.a_qk, self.a_pv = 2.0e-3, 1.0 / 127.0
+        self.fused_attention = True  # decode steps: KV append + both BMMs + softmax as one launch (False: the four separate launches)
         # state and scratch, allocated once
         z8 = lambda *s: torch.zeros(s, dtype=torch.int8, device=device)
         self.k_cache = z8(heads, max_keys, self.hd)
@@ -86,6 +88,11 @@ class Int8OPTDecoderLayer:
             capi.check(L.tce_layernorm_q(_p(hidden), _p(self.ln1_w), _p(self.ln1_b), _p(self.ln_out), m, E, st))
             for d in qkv:
                 capi.check(L.tce_w8a8_matmul(C.byref(d), st))
+        if fused and self.fused_attention:
+            # 2-5 as ONE launch for a decode step (tce_opt_attention_decode: the append, qk, + mask / softmax / int8, pv -- bit-identical to the four launches below)
+            capi.check(L.tce_opt_attention_decode(_p(self.q), _p(self.k), _p(self.v), _p(self.k_cache), _p(self.vt_cache), _p(mask), _p(self.attn), H, hd, m, pos, self.max_keys, E,
+                                                  self.a_qk, self.a_pv, st))
+            return self._rest(hidden, m, fused, L, st)
         # 2. KV append
         capi.check(L.tce_opt_kv_append(_p(self.k), _p(self.v), _p(self.k_cache), _p(self.vt_cache), H, hd, m, pos, self.max_keys, st))
         # 3. qk BMM: head h contracts its 64 columns of q with its keys; scores [heads][m][tgz] fp32 (BMM_S8T_S8N_F32T.cc:12-62)
@@ -107,6 +114,10 @@ class Int8OPTDecoderLayer:
             pv = capi.W8A8Desc(M=m, N=hd, K=tgz, batch=H, A=_p(self.probs), B=_p(self.vt_cache), C=_p(self.attn), strideA=m * ldp, strideB=hd * self.max_keys, strideC=hd,
                                lda=ldp, ldb=self.max_keys, ldc=E, alpha=self.a_pv, q_min=-128, q_max=127, bias_kind=capi.TCE_BIAS_NONE, out_kind=capi.TCE_OUT_INT8)
         capi.check(L.tce_w8a8_matmul(C.byref(pv), st))
+        self._rest(hidden, m, fused, L, st)
+
+    def _rest(self, hidden, m, fused, L, st):
+        E = self.embed
         # 6. out_proj + residual add (W8A8BFP32OFP32Linear, then `add`: Int8OPTDecoderLayer.cc:39)
         d = self._lin(m, self.attn, self.Wo, self.bo, hidden, self.a_o, fp32=True, accumulate=True)
         capi.check(L.tce_w8a8_matmul(C.byref(d), st))
@@ -121,9 +132,8 @@ class Int8OPTDecoderLayer:
         d = self._lin(m, self.fc1, self.W2, self.b2, hidden, self.a_2, fp32=True, accumulate=True)
         capi.check(L.tce_w8a8_matmul(C.byref(d), st))
 
-    @staticmethod
-    def launches(m: int) -> int:
-        return 8 if m <= 8 else 12
+    def launches(self, m: int) -> int:
+        return (5 if self.fused_attention else 8) if m <= 8 else 12
 
     def int8_ops(self, m: int, tgz: int) -> int:
         """Multiply-accumulates x 2 of one step (the linears and both BMMs)."""
