@@ -183,6 +183,10 @@ int tce_w4a16_set_debug_mode(int mode) {
         tce::set_gemm_dma_xcd_rows(mode - 40);
         return TCE_OK;
     }
+    if (mode == 40 || mode == 41) {  // GEMV: the per-chunk activation sums once per workgroup (41) or by every wave (40, the default)
+        tce::set_gemv_shared_xsum(mode - 40);
+        return TCE_OK;
+    }
     if (mode >= 20 && mode <= 30) {  // small-batch kernel tuning: 20 automatic, 21/22/24/28 = waves per tile, 30 = shared-x form, 29 = off
         g_skinny_enabled = mode != 29;
         tce::set_skinny_config(mode == 29 ? 0 : (mode == 30 ? 9 : mode - 20));

@@ -251,6 +251,27 @@ __global__ __launch_bounds__(64 * WN * WK, (MB * ROWS * DEPTH >= 8 ? 2 : (MB * R
         for (int d = 0; d < DEPTH; ++d) issue(st[d], d);
     }
     if constexpr (MODE == 2) ts1 = wall_clock64();
+    // The sum of a chunk's 32 activations (the zero-point term's factor) does not depend on the row: all WN waves along N used to form it for every
+    // step with 8 MFMAs (A = ones) -- a third of the launch's MFMAs at two rows per wave.  With `shared_xsum` wave wn forms it for the steps
+    // t = wn, wn + WN, ... only (the same 8 MFMAs in the same order: the same bits), the table goes through LDS behind the trash slots.
+    float *sxt = reinterpret_cast<float *>(smem + (size_t)total_pieces * 16 + (size_t)NTHREADS * 16);  // [MB][T][WK][64]
+    if (args.shared_xsum) {
+        const half4_t ones_t = half4_t{(half_t)1.0f, (half_t)1.0f, (half_t)1.0f, (half_t)1.0f};
+        for (int t = wn; t < T; t += WN) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                float4_t xs4 = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint4_t xp = xs[(((m * T + t) * WK + wk) * 4 + j) * 64 + lane];
+                    xs4 = __builtin_amdgcn_mfma_f32_4x4x4f16(ones_t, __builtin_bit_cast(half4_t, uint2_t{xp.x, xp.y}), xs4, 0, 0, 0);
+                    xs4 = __builtin_amdgcn_mfma_f32_4x4x4f16(ones_t, __builtin_bit_cast(half4_t, uint2_t{xp.z, xp.w}), xs4, 0, 0, 0);
+                }
+                sxt[((m * T + t) * WK + wk) * 64 + lane] = xs4[0];
+            }
+        }
+        __syncthreads();
+    }
 
     float acc[ROWS][MB][4];  // the 4 accumulator registers of the 4x4x4 MFMA; the lane's own dot product is [lane & 3]
     float corr[ROWS][MB];    // sum over chunks of s * (1024 + 16 z) * sum_k x_k
@@ -279,16 +300,23 @@ __global__ __launch_bounds__(64 * WN * WK, (MB * ROWS * DEPTH >= 8 ? 2 : (MB * R
         float xsum[MB];
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
-            float4_t xs4 = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint4_t xp = xs[(((m * T + t) * WK + wk) * 4 + j) * 64 + lane];
                 xb[m][2 * j] = __builtin_bit_cast(half4_t, uint2_t{xp.x, xp.y});      // (x0,x4,x1,x5) of word j
                 xb[m][2 * j + 1] = __builtin_bit_cast(half4_t, uint2_t{xp.z, xp.w});  // (x2,x6,x3,x7)
-                xs4 = __builtin_amdgcn_mfma_f32_4x4x4f16(ones, xb[m][2 * j], xs4, 0, 0, 0);
-                xs4 = __builtin_amdgcn_mfma_f32_4x4x4f16(ones, xb[m][2 * j + 1], xs4, 0, 0, 0);
             }
-            xsum[m] = xs4[0];  // D[i][j] = sum_k B_j[k] for every i: all four registers hold this lane's sum
+            if (args.shared_xsum) {  // wave-uniform
+                xsum[m] = sxt[((m * T + t) * WK + wk) * 64 + lane];
+            } else {
+                float4_t xs4 = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    xs4 = __builtin_amdgcn_mfma_f32_4x4x4f16(ones, xb[m][2 * j], xs4, 0, 0, 0);
+                    xs4 = __builtin_amdgcn_mfma_f32_4x4x4f16(ones, xb[m][2 * j + 1], xs4, 0, 0, 0);
+                }
+                xsum[m] = xs4[0];  // D[i][j] = sum_k B_j[k] for every i: all four registers hold this lane's sum
+            }
         }
         const int zsh = (st.g & 7) * 4;
 #pragma unroll
@@ -443,7 +471,7 @@ hipError_t launch_one(const GemvArgs &a, int total_blocks, int m_blocks, hipStre
     const int nchunks = a.K >> 5;
     const int LS = 64 * WK;
     const int T = (nchunks + LS - 1) / LS;
-    size_t lds = (size_t)MB * T * LS * 64 + (size_t)64 * WN * WK * 16;  // x image + trash slots
+    size_t lds = (size_t)MB * T * LS * 64 + (size_t)64 * WN * WK * 16 + (size_t)MB * T * LS * sizeof(float);  // x image + trash slots + the shared activation-sum table
     const size_t red = (size_t)WN * WK * ROWS * MB * sizeof(float);
     if (lds < red) lds = red;
     auto kfn = w4a16_gemv_kernel<MB, ROWS, WN, WK, DEPTH, XB, MODE, Z8, NORM>;
@@ -526,6 +554,8 @@ hipError_t launch_mb(const Variant &v, const GemvArgs &a, int total_blocks, int 
 
 void set_gemv_debug_mode(int mode) { g_debug_mode = mode; }
 void set_gemv_order(int force) { g_order_force = force >= 0 && force <= 2 ? force : 0; }
+int g_shared_xsum = 0;
+void set_gemv_shared_xsum(int on) { g_shared_xsum = on == 1 ? 1 : 0; }
 void set_gemv_debug_buffer(void *p) { g_debug_buf = static_cast<unsigned long long *>(p); }
 
 bool gemv_variant_exists(int rows, int wn, int wk, int depth) {
@@ -558,6 +588,7 @@ int launch_w4a16_gemv(const tce_w4a16_desc *descs, int count, int forced_rows, i
     a.zeros_are_8 = 1;
     for (int i = 0; i < count; ++i)
         if (!(descs[i].flags & TCE_W4_ZERO_POINT_IS_8)) a.zeros_are_8 = 0;
+    a.shared_xsum = g_shared_xsum;
 
     int total_n = 0;
     for (int i = 0; i < count; ++i) total_n += descs[i].N;

@@ -24,6 +24,7 @@ struct GemvArgs {
     int zeros_are_8;          // every linear of the launch carries TCE_W4_ZERO_POINT_IS_8
     const float *gamma;       // non-null: stage RMSNorm(A) * gamma instead of A (fused prologue, M = 1)
     float eps;
+    int shared_xsum;          // the per-chunk activation sums are computed once per workgroup (table in LDS) instead of by every wave in every step
     GemvSeg seg[TCE_MAX_GROUP];
 };
 
@@ -47,6 +48,7 @@ struct GemvArgs {
 bool gemv_variant_exists(int rows, int wn, int wk, int depth);
 void set_gemv_debug_mode(int mode);
 void set_gemv_order(int force);
+void set_gemv_shared_xsum(int on);  // 0 automatic (off), 1 on, 2 off
 void set_gemv_debug_buffer(void *p);
 
 // persistent form, w4a16_gemv_stream.hip
