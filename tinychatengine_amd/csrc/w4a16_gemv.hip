@@ -605,8 +605,12 @@ int launch_w4a16_gemv(const tce_w4a16_desc *descs, int count, int forced_rows, i
         // A/B in one process (scripts/gemv_ab.py, profiles/r2/gemv_geometry_ab.jsonl; best / median of 7 rounds): gate+up 22016 rows:
         // (2 rows, 4 waves, depth 2) 11.35 / 11.40 us, (2, 4, 1) 11.48 / 12.68 (bimodal), (4, 4, 1) 11.94 / 12.10; qkv 12288 rows: (4, 4, 1)
         // 7.02 / 7.09, (2, 4, 1) 7.16 / 7.17; Llama-3 gate+up 28672 rows: (4, 4, 1) 13.18, (2, 4, 2) 13.64.
-        if (total_n >= 24000) v = {4, 4, 1, 1};
-        else if (total_n >= 16384) v = {2, 4, 1, 2};
+        // Round 3 (scratch A/B of the same kind, three rows per wave added: profiles/r3/gemv_rows3_ab.jsonl): a workgroup of 12 rows puts the grouped
+        // gate+up launches closer to whole generations of workgroups -- 2 x 11008 rows: (3, 4, 2) 11.18 / 11.23 us against (2, 4, 2) 11.47 / 11.71;
+        // 2 x 14336 rows: 13.44 / 13.61 against (4, 4, 1) 13.78 / 13.93 -- while single linears of that size (lm_head) and K = 5120 keep four rows.
+        const bool m1 = d0.M == 1;
+        if (total_n >= 24000) v = (m1 && count >= 2 && nchunks <= 128) ? Variant{3, 4, 1, 2} : Variant{4, 4, 1, 1};
+        else if (total_n >= 16384) v = m1 ? Variant{3, 4, 1, 2} : Variant{2, 4, 1, 2};
         else if (total_n >= 8192) v = {4, 4, 1, 1};
         else if (total_n >= 3072) v = nchunks >= 256 && d0.M == 1 ? Variant{2, 8, 1, 2} : Variant{2, 4, 1, 2};  // long K (down_proj): 7.5 vs 7.8 us, 8.2 vs 8.5
         else if (total_n >= 1536) v = {1, 4, 1, 2};

@@ -38,6 +38,8 @@ struct GemvArgs {
     X(2, 4, 1, 2)            \
     X(4, 4, 1, 2)            \
     X(2, 4, 1, 3)            \
+    X(3, 4, 1, 1)            \
+    X(3, 4, 1, 2)            \
     X(2, 8, 1, 2)            \
     X(4, 8, 1, 1)            \
     X(1, 2, 2, 1)            \
