@@ -495,6 +495,9 @@ hipError_t launch_variant(const GemvArgs &a, int total_blocks, int m_blocks, hip
     } else {
         if constexpr (MB == 1) {
             if (a.gamma) {
+                if constexpr ((64 * WN * WK) < 256 || 1024 % (64 * WN * WK) != 0) {
+                    return hipErrorInvalidConfiguration;  // (the fused prologue's slot scheme needs 256 / 512 / 1024 threads; the dispatcher never asks for it here)
+                } else {
                 // like the plain launches below: "x first" when the whole grid is one generation of workgroups -- round 2 found the fused
                 // prologue 2.6 us slower than the plain launch for exactly this reason (its x loads queued behind every wave's weights)
                 const int wps = (ROWS == 4 && DEPTH == 1) ? 5 : (ROWS * DEPTH <= 2 ? 8 : 4);
@@ -503,6 +506,7 @@ hipError_t launch_variant(const GemvArgs &a, int total_blocks, int m_blocks, hip
                                          : launch_one<1, ROWS, WN, WK, DEPTH, 2, 3, false, true>(a, total_blocks, m_blocks, stream);
                 return a.zeros_are_8 ? launch_one<1, ROWS, WN, WK, DEPTH, 2, 0, true, true>(a, total_blocks, m_blocks, stream)
                                      : launch_one<1, ROWS, WN, WK, DEPTH, 2, 0, false, true>(a, total_blocks, m_blocks, stream);
+                }
             }
             if (g_debug_mode == 1) return launch_one<1, ROWS, WN, WK, DEPTH, 8, 1>(a, total_blocks, m_blocks, stream);
             if (g_debug_mode == 2) return launch_one<1, ROWS, WN, WK, DEPTH, 2, 2>(a, total_blocks, m_blocks, stream);
@@ -605,12 +609,10 @@ int launch_w4a16_gemv(const tce_w4a16_desc *descs, int count, int forced_rows, i
         // A/B in one process (scripts/gemv_ab.py, profiles/r2/gemv_geometry_ab.jsonl; best / median of 7 rounds): gate+up 22016 rows:
         // (2 rows, 4 waves, depth 2) 11.35 / 11.40 us, (2, 4, 1) 11.48 / 12.68 (bimodal), (4, 4, 1) 11.94 / 12.10; qkv 12288 rows: (4, 4, 1)
         // 7.02 / 7.09, (2, 4, 1) 7.16 / 7.17; Llama-3 gate+up 28672 rows: (4, 4, 1) 13.18, (2, 4, 2) 13.64.
-        // Round 3 (scratch A/B of the same kind, three rows per wave added: profiles/r3/gemv_rows3_ab.jsonl): a workgroup of 12 rows puts the grouped
-        // gate+up launches closer to whole generations of workgroups -- 2 x 11008 rows: (3, 4, 2) 11.18 / 11.23 us against (2, 4, 2) 11.47 / 11.71;
-        // 2 x 14336 rows: 13.44 / 13.61 against (4, 4, 1) 13.78 / 13.93 -- while single linears of that size (lm_head) and K = 5120 keep four rows.
-        const bool m1 = d0.M == 1;
-        if (total_n >= 24000) v = (m1 && count >= 2 && nchunks <= 128) ? Variant{3, 4, 1, 2} : Variant{4, 4, 1, 1};
-        else if (total_n >= 16384) v = m1 ? Variant{3, 4, 1, 2} : Variant{2, 4, 1, 2};
+        // Round 3: three rows per wave (compiled: X(3, 4, 1, 1 / 2), forceable) were A/B'd on the grouped gate+up launches and NOT taken: on one box
+        // (3, 4, 2) ran 11.18 / 11.23 us against (2, 4, 2) 11.47 / 11.71, on the next 10.73 / 10.80 against 10.34 / 10.50 (profiles/r3/gemv_rows3_ab.jsonl).
+        if (total_n >= 24000) v = {4, 4, 1, 1};
+        else if (total_n >= 16384) v = {2, 4, 1, 2};
         else if (total_n >= 8192) v = {4, 4, 1, 1};
         else if (total_n >= 3072) v = nchunks >= 256 && d0.M == 1 ? Variant{2, 8, 1, 2} : Variant{2, 4, 1, 2};  // long K (down_proj): 7.5 vs 7.8 us, 8.2 vs 8.5
         else if (total_n >= 1536) v = {1, 4, 1, 2};
