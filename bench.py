@@ -832,6 +832,35 @@ def main():
                             torch.cuda.synchronize()
                         except Exception:  # noqa: BLE001
                             pass
+                    try:  # the stream-ordered graph with every launch's geometry timed on THIS device at plan creation (TCE_PLAN_TUNED): neighbouring
+                        # geometries rank differently from box to box (profiles/r3/gemv_rows3_ab.jsonl)
+                        uplan = dl.make_plan(tuned=True)
+                        for o in outs:
+                            o.fill_(float("nan"))
+                        uplan.launch(stream)
+                        torch.cuda.synchronize()
+                        worst = max(float((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-6)) for a, b in zip(outs, want))
+                        if not all(bool(torch.isfinite(o.float()).all()) for o in outs) or worst > 4e-3:
+                            variants["hipGraph, geometries timed on this device (TCE_PLAN_TUNED)"] = {"rejected": f"outputs differ from the untuned plan: worst |diff| / max = {worst:.2e}"}
+                        else:
+                            ustep = lambda: uplan.launch(stream)
+                            n_ab = max(50, args.steps // 2)
+                            ab = [(rate(step_g0, n_ab), rate(ustep, n_ab)) for step_g0 in (lambda: plan.launch(stream),) * 3]  # alternating: clocks drift within a process
+                            ms_g2, ms_u = min(x for x, _ in ab), min(y for _, y in ab)
+                            variants["hipGraph, geometries timed on this device (TCE_PLAN_TUNED)"] = {
+                                "ms_per_token": round(ms_u, 4), "tokens_per_s": round(1e3 / ms_u, 1), "untuned_graph_in_the_same_alternation_ms": round(ms_g2, 4),
+                                "verified": f"all outputs within {worst:.1e} of the untuned plan's (relative to the largest output; identical unless a K-split geometry was chosen)",
+                                "chosen (rows, waves_n, waves_k, depth) for the first block's launches and lm_head; zeros: the dispatcher's rule kept": [list(g) for g in (uplan.launch_geometries()[:4] + uplan.launch_geometries()[-1:])]}
+                            if ms_u < 0.995 * ms_g2 and ms_u < ms_t and args.issue == "auto" and n_launches == plan.n_launches:
+                                step = ustep
+                                mode = "one hipGraph replay per token (129 launches in stream order, launch geometries timed on this device at plan creation: TCE_PLAN_TUNED)"
+                    except Exception as e:  # noqa: BLE001
+                        variants["hipGraph, geometries timed on this device (TCE_PLAN_TUNED)"] = {"rejected": f"{type(e).__name__}: {e}"}
+                        try:
+                            capi.lib().tce_reset_last_error()
+                            torch.cuda.synchronize()
+                        except Exception:  # noqa: BLE001
+                            pass
             except SystemExit:
                 raise
             except Exception as e:  # noqa: BLE001

@@ -47,7 +47,7 @@ extern "C" {
 
 #define TCE_API __attribute__((visibility("default")))
 
-#define TCE_VERSION 105 /* 0.1.5: tce_opt_attention_decode; 0.1.4: tce_attention_prefill_f16 (0.1.3: tce_attention_decode_step_gqa_f16, TCE_PLAN_OVERLAPPED; 0.1.2: tce_w4a16_desc.scratch; 0.1.1: .prepacked, tce_w4a16_prepack*) */
+#define TCE_VERSION 106 /* 0.1.6: TCE_PLAN_TUNED; 0.1.5: tce_opt_attention_decode; 0.1.4: tce_attention_prefill_f16 (0.1.3: tce_attention_decode_step_gqa_f16, TCE_PLAN_OVERLAPPED; 0.1.2: tce_w4a16_desc.scratch; 0.1.1: .prepacked, tce_w4a16_prepack*) */
 
 /* error codes (return values) */
 #define TCE_OK 0
@@ -358,9 +358,17 @@ TCE_API int tce_plan_create(const tce_w4a16_desc *descs, const int32_t *group_si
  * rules as TCE_PLAN_TAGGED (plus: no fused RMSNorm prologue yet); tce_plan_is_chained returns 3.  Outputs bit-identical to the
  * stream-ordered plan. */
 #define TCE_PLAN_OVERLAPPED 4
+/* TCE_PLAN_TUNED (stream-ordered plans): the geometry of every decode (M = 1) launch is chosen at plan creation by timing the compiled candidates on this
+ * device -- the WHOLE launch list is captured and replayed with one group of same-shaped launches at a time on each compiled candidate, a candidate stays
+ * only if the whole plan gets 0.7 % faster; outputs are redirected to a scratch buffer (the caller's buffers are not written).  Costs a second or two, once; results agree with the untuned plan within
+ * the kernels' own rounding (a geometry that splits K between waves adds in another order; the others are bit-identical). */
+#define TCE_PLAN_TUNED 8
 TCE_API int tce_plan_create_ex(const tce_w4a16_desc *descs, const int32_t *group_sizes, int n_launches, int flags, tce_plan **out);
 TCE_API int tce_plan_is_chained(const tce_plan *plan);
 TCE_API int tce_plan_geometry(const tce_plan *plan, int *rows, int *depth, int *waves, int *workgroups);
+/* TCE_PLAN_TUNED plans: the geometry that won the timing for launch `launch` -- (rows per wave, waves along N, waves splitting K, pipeline depth) of the
+ * row-block GEMV -- or all zero where the dispatcher's own choice stayed (also for untuned plans). */
+TCE_API int tce_plan_launch_geometry(const tce_plan *plan, int launch, int *rows, int *waves_n, int *waves_k, int *depth);
 TCE_API int tce_plan_status(tce_plan *plan);
 TCE_API int tce_plan_launch(tce_plan *plan, void *stream);
 TCE_API int tce_plan_n_launches(const tce_plan *plan);

@@ -311,3 +311,33 @@ def test_chained_plan_falls_back_when_a_launch_is_not_a_decode_gemv(dev, oracle)
     ok, worst = w4a16_close(outs[0].cpu().numpy(), refs[0])
     assert ok
     plan.close()
+
+
+def test_tuned_plan_matches_the_untuned_plan(dev_chain=None):
+    """TCE_PLAN_TUNED: a stream-ordered plan whose launch geometries were timed at creation computes what the untuned plan computes (bit-identical unless a geometry
+    that splits K between waves won; then within the linears' rounding), leaves the caller's output buffers untouched during the timing, and replays."""
+    import torch
+    from tinychatengine_amd import capi
+    from tinychatengine_amd.decode import SHAPES, DecodeLinears
+    capi.lib()
+    dev = torch.device("cuda:0")
+    dl = DecodeLinears(SHAPES["tiny"], device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    plan = dl.make_plan()
+    plan.launch(st)
+    torch.cuda.synchronize()
+    outs = [*dl.out_qkv, dl.out_o, dl.out_gate, dl.out_up, dl.out_down, dl.logits]
+    want = [o.clone() for o in outs]
+    for o in outs:
+        o.fill_(3.0)
+    tuned = dl.make_plan(tuned=True)
+    torch.cuda.synchronize()
+    assert all(bool((o == 3.0).all()) for o in outs), "plan creation wrote into the caller's buffers"
+    for _ in range(2):
+        for o in outs:
+            o.fill_(float("nan"))
+        tuned.launch(st)
+        torch.cuda.synchronize()
+        for a, b in zip(outs, want):
+            assert torch.isfinite(a.float()).all()
+            assert float((a.float() - b.float()).abs().max()) <= 4e-3 * float(b.float().abs().max())

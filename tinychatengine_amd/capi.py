@@ -23,6 +23,7 @@ TCE_W4_ADD_TO_C = 16
 TCE_PLAN_CHAINED = 1
 TCE_PLAN_TAGGED = 2
 TCE_PLAN_OVERLAPPED = 4
+TCE_PLAN_TUNED = 8
 TCE_W4_ZERO_POINT_IS_8 = 4
 TCE_BIAS_NONE, TCE_BIAS_INT8, TCE_BIAS_FP32 = 0, 1, 2
 TCE_OUT_INT8, TCE_OUT_FP32 = 0, 1
@@ -30,7 +31,7 @@ TCE_OUT_INT8, TCE_OUT_FP32 = 0, 1
 # every symbol include/tce_matmul.h declares (tests/test_boundary.py checks the .so exports exactly these)
 EXPORTS = [
     "tce_w4a16_forward", "tce_w4a16_prepack_bytes", "tce_w4a16_prepack", "tce_w4a16_gemm_scratch_bytes", "tce_w4a16_describe_dispatch", "tce_reset_last_error", "tce_bmm_f16t", "tce_rope_half", "tce_softmax_half", "tce_attention_decode_f16", "tce_attention_decode_workspace_bytes", "tce_attention_decode_describe", "tce_attention_decode_step_f16", "tce_attention_decode_step_gqa_f16", "tce_attention_decode_describe_gqa", "tce_attention_decode_step_pos_f16", "tce_attention_prefill_f16", "tce_attention_prefill_workspace_bytes", "tce_opt_attention_decode", "tce_prefetch", "tce_add_half", "tce_silu_mul_half", "tce_rmsnorm_half", "tce_w4a16_forward_group_rmsnorm", "tce_w4a16_forward_group", "tce_w4a16_check_zero_point_8", "tce_w4a16_awq_fp16acc", "tce_w4a16_awq_workspace_bytes",
-    "tce_w4a16_gemm_awq", "tce_w4a16_shard", "tce_comm_create", "tce_comm_export", "tce_comm_connect", "tce_comm_connect_local", "tce_allgather_f16", "tce_comm_status", "tce_comm_set_timeout_ms", "tce_comm_reset", "tce_comm_device", "tce_comm_destroy", "tce_w8a8_matmul", "tce_opt_softmax_q", "tce_opt_kv_append", "tce_layernorm_q", "tce_layernorm_q_w8a8_group", "tce_plan_create", "tce_plan_create_ex", "tce_plan_is_chained", "tce_plan_geometry", "tce_plan_status", "tce_plan_launch", "tce_plan_n_launches",
+    "tce_w4a16_gemm_awq", "tce_w4a16_shard", "tce_comm_create", "tce_comm_export", "tce_comm_connect", "tce_comm_connect_local", "tce_allgather_f16", "tce_comm_status", "tce_comm_set_timeout_ms", "tce_comm_reset", "tce_comm_device", "tce_comm_destroy", "tce_w8a8_matmul", "tce_opt_softmax_q", "tce_opt_kv_append", "tce_layernorm_q", "tce_layernorm_q_w8a8_group", "tce_plan_create", "tce_plan_create_ex", "tce_plan_is_chained", "tce_plan_geometry", "tce_plan_status", "tce_plan_launch_geometry", "tce_plan_launch", "tce_plan_n_launches",
     "tce_plan_destroy", "tce_version", "tce_last_error", "tce_build_info", "tce_w4a16_set_gemv_config",
     "tce_w4a16_set_gemm_config", "tce_w4a16_algorithmic_bytes", "tce_w4a16_gemv_variant", "tce_w4a16_gemm_variant",
     "tce_w4a16_set_debug_mode", "tce_w4a16_set_debug_buffer", "tce_malloc", "tce_free", "tce_memcpy", "tce_synchronize", "tce_device_count",
@@ -223,14 +224,15 @@ def gemm_variants() -> list[tuple[int, int]]:
 class Plan:
     """tce_plan: a fixed sequence of W4A16 launches captured into one hipGraph (one decode token's linears)."""
 
-    def __init__(self, launches: list[list[W4A16Desc]], chained: bool = False, tagged: bool = False, overlapped: bool = False):
+    def __init__(self, launches: list[list[W4A16Desc]], chained: bool = False, tagged: bool = False, overlapped: bool = False, tuned: bool = False):
         """tagged (chained: accepted synonym): TCE_PLAN_TAGGED -- one persistent kernel walks the list, the plan's data flow
-        ordered by polling tagged output words (include/tce_matmul.h).  self.tagged tells whether that form was built."""
+        ordered by polling tagged output words (include/tce_matmul.h).  self.tagged tells whether that form was built.
+        tuned: TCE_PLAN_TUNED -- the decode launches' geometries are timed on this device at creation (stream-ordered plans)."""
         flat = [d for g in launches for d in g]
         self._descs = (W4A16Desc * len(flat))(*flat)
         self._groups = (C.c_int32 * len(launches))(*[len(g) for g in launches])
         self._h = C.c_void_p()
-        check(lib().tce_plan_create_ex(self._descs, self._groups, len(launches), (TCE_PLAN_TAGGED if tagged else 0) | (TCE_PLAN_CHAINED if chained else 0) | (TCE_PLAN_OVERLAPPED if overlapped else 0), C.byref(self._h)))
+        check(lib().tce_plan_create_ex(self._descs, self._groups, len(launches), (TCE_PLAN_TAGGED if tagged else 0) | (TCE_PLAN_CHAINED if chained else 0) | (TCE_PLAN_OVERLAPPED if overlapped else 0) | (TCE_PLAN_TUNED if tuned else 0), C.byref(self._h)))
         self.n_launches = len(launches)
         self.kind = int(lib().tce_plan_is_chained(self._h))  # 0 stream-ordered, 2 token kernel, 3 overlapped launches
         self.chained = self.kind != 0
@@ -245,6 +247,15 @@ class Plan:
         v = [C.c_int() for _ in range(4)]
         check(lib().tce_plan_geometry(self._h, *[C.byref(x) for x in v]))
         return dict(zip(("rows", "depth", "waves", "workgroups"), (x.value for x in v)))
+
+    def launch_geometries(self) -> list[tuple[int, int, int, int]]:
+        """Per launch: the (rows, waves_n, waves_k, depth) a TCE_PLAN_TUNED plan chose, (0, 0, 0, 0) where the dispatcher's rule stayed."""
+        out = []
+        for i in range(self.n_launches):
+            v = [C.c_int() for _ in range(4)]
+            check(lib().tce_plan_launch_geometry(self._h, i, *[C.byref(x) for x in v]))
+            out.append(tuple(x.value for x in v))
+        return out
 
     def status(self) -> None:
         """Synchronise and raise if a chained launch ever gave up waiting for its predecessor."""

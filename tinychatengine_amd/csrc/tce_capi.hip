@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <algorithm>
+#include <string>
 #include <vector>
 
 #include "tce_common.hpp"
@@ -821,12 +823,17 @@ int tce_layernorm_q_w8a8_group(const float *x, const float *ln_weight, const flo
 // ---------------------------------------------------------------------------------------------
 // Plans: a fixed sequence of W4A16 launches (one decode token's linears) captured into a hipGraph.
 // ---------------------------------------------------------------------------------------------
+struct TunedGeometry {
+    int rows = 0, wn = 0, wk = 0, depth = 0;  // all zero: the dispatcher's choice
+};
+
 struct tce_plan {
     std::vector<tce_w4a16_desc> descs;
     std::vector<int32_t> groups;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     tce::TokenPlan *token = nullptr;  // chained plans: the device-side launch list of the token kernel
+    std::vector<TunedGeometry> tuned;   // TCE_PLAN_TUNED: per launch, the geometry that won the timing (rows == 0: the dispatcher's choice)
 };
 
 static void plan_free(tce_plan *p) {
@@ -837,9 +844,134 @@ static void plan_free(tce_plan *p) {
     delete p;
 }
 
+// TCE_PLAN_TUNED: the geometry of every decode (M = 1) launch of a stream-ordered plan is chosen by timing on THIS device.  Neighbouring geometries of
+// the row-block GEMV rank differently from box to box (profiles/r3/gemv_rows3_ab.jsonl: three rows per wave won 2.5-4 % on one MI355X and lost 3-4 % on
+// the next), so a rule fitted on one box is not the best on another -- and a launch timed on its own does not rank them the way the token does (a first
+// version that timed each launch shape alone picked plans 1.5-3 % SLOWER on one box).  So the WHOLE launch list is timed: launches grouped by signature
+// (shapes, group size, epilogue flags), one group at a time tries every compiled candidate with the others at their current best, the list captured
+// as a graph and replayed 3 x 10 times; a candidate stays only if the whole plan gets 0.7 % faster.  Outputs are redirected to a scratch buffer, so plan
+// creation leaves the caller's buffers alone.  ~50 captures of the list: a second or two, once.
+
+static std::string launch_signature(const tce_w4a16_desc *d, int count) {
+    char buf[64];
+    std::string s;
+    std::snprintf(buf, sizeof buf, "M%d K%d G%d n%d", d[0].M, d[0].K, d[0].group_size, count);
+    s = buf;
+    for (int j = 0; j < count; ++j) {
+        std::snprintf(buf, sizeof buf, " N%d f%x", d[j].N, (unsigned)d[j].flags);
+        s += buf;
+    }
+    s += d[0].rmsnorm_gamma ? " norm" : "";
+    return s;
+}
+
+static int tune_plan_launches(const std::vector<tce_w4a16_desc> &descs, const std::vector<int32_t> &groups, std::vector<TunedGeometry> &out) {
+    const int n_launches = (int)groups.size();
+    out.assign(n_launches, TunedGeometry{});
+    // the decode launches by signature; every launch's outputs redirected to ONE scratch area (the values are irrelevant to the timing: later launches read
+    // whatever the caller's buffers hold)
+    std::vector<std::string> sig(n_launches);
+    std::vector<int> offs(n_launches);
+    std::vector<tce_w4a16_desc> copy(descs);
+    size_t scratch_halves = 0;
+    for (int i = 0, off = 0; i < n_launches; off += groups[i], ++i) {
+        offs[i] = off;
+        const tce_w4a16_desc *d = &descs[off];
+        if (d->M == 1 && !(d->flags & TCE_W4_FORCE_GEMM)) sig[i] = launch_signature(d, groups[i]);
+        size_t need = 0;
+        for (int j = 0; j < groups[i]; ++j) need += (((size_t)(d[j].ldc ? d[j].ldc : d[j].N) * d[j].M + 127) & ~(size_t)127) + 128;
+        scratch_halves = need > scratch_halves ? need : scratch_halves;
+    }
+    void *scratch = nullptr;
+    hipStream_t st = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipMalloc(&scratch, scratch_halves * 2 + 256) != hipSuccess) return TCE_OK;  // no memory for the timing: keep the dispatcher's choices
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        (void)hipFree(scratch);
+        if (st) (void)hipStreamDestroy(st);
+        if (e0) (void)hipEventDestroy(e0);
+        return TCE_OK;
+    }
+    (void)hipMemsetAsync(scratch, 0, scratch_halves * 2 + 256, st);
+    for (int i = 0; i < n_launches; ++i) {
+        size_t at = 0;
+        for (int j = 0; j < groups[i]; ++j) {
+            tce_w4a16_desc &d = copy[offs[i] + j];
+            d.C = static_cast<char *>(scratch) + at * 2;
+            at += (((size_t)(d.ldc ? d.ldc : d.N) * d.M + 127) & ~(size_t)127) + 128;
+        }
+    }
+    // the whole launch list as a graph with the given geometries; its time per replay
+    auto time_plan = [&](const std::vector<TunedGeometry> &g) -> float {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) return -1.f;
+        int rc = TCE_OK;
+        for (int i = 0; i < n_launches && rc == TCE_OK; ++i) {
+            const bool forced = g[i].rows != 0;
+            if (forced && tce_w4a16_set_gemv_config(g[i].rows, g[i].wn, g[i].wk, g[i].depth) != TCE_OK) rc = TCE_ERR_BAD_ARG;
+            if (rc == TCE_OK) rc = groups[i] == 1 ? tce_w4a16_forward(&copy[offs[i]], st) : tce_w4a16_forward_group(&copy[offs[i]], groups[i], st);
+            if (forced) (void)tce_w4a16_set_gemv_config(0, 0, 0, 0);
+        }
+        const hipError_t ee = hipStreamEndCapture(st, &graph);
+        float us = -1.f;
+        if (rc == TCE_OK && ee == hipSuccess && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+            bool ok = true;
+            for (int w = 0; w < 3 && ok; ++w) ok = hipGraphLaunch(exec, st) == hipSuccess;
+            ok = ok && hipStreamSynchronize(st) == hipSuccess;
+            for (int round = 0; ok && round < 3; ++round) {
+                (void)hipEventRecord(e0, st);
+                for (int r = 0; r < 10 && ok; ++r) ok = hipGraphLaunch(exec, st) == hipSuccess;
+                (void)hipEventRecord(e1, st);
+                ok = ok && hipEventSynchronize(e1) == hipSuccess;
+                float ms = 0.f;
+                if (ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) us = us < 0.f ? ms * 100.f : std::min(us, ms * 100.f);
+            }
+            if (!ok) us = -1.f;
+        }
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        return us;
+    };
+    static const int cands[][4] = {{2, 4, 1, 2}, {3, 4, 1, 2}, {4, 4, 1, 1}, {2, 8, 1, 2}, {2, 4, 1, 1}, {1, 4, 1, 2}};
+    const int ncand = (int)(sizeof cands / sizeof cands[0]);
+    std::vector<TunedGeometry> best(n_launches);
+    float best_us = time_plan(best);
+    std::vector<char> done(n_launches, 0);
+    for (int i = 0; i < n_launches && best_us > 0.f; ++i) {
+        if (sig[i].empty() || done[i]) continue;
+        std::vector<int> members;
+        for (int k = i; k < n_launches; ++k)
+            if (sig[k] == sig[i]) {
+                members.push_back(k);
+                done[k] = 1;
+            }
+        for (int c = 0; c < ncand; ++c) {
+            if (!tce::gemv_variant_exists(cands[c][0], cands[c][1], cands[c][2], cands[c][3])) continue;
+            std::vector<TunedGeometry> trial(best);
+            for (int k : members) trial[k] = TunedGeometry{cands[c][0], cands[c][1], cands[c][2], cands[c][3]};
+            const float us = time_plan(trial);
+            if (us > 0.f && us < 0.993f * best_us) {  // the WHOLE plan must get faster by more than the timing's noise
+                best_us = us;
+                best = trial;
+            }
+        }
+    }
+    out = best;
+    (void)tce_w4a16_set_gemv_config(0, 0, 0, 0);
+    (void)hipStreamSynchronize(st);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipStreamDestroy(st);
+    (void)hipFree(scratch);
+    tce_reset_last_error();
+    return TCE_OK;
+}
+
 int tce_plan_create_ex(const tce_w4a16_desc *descs, const int32_t *group_sizes, int n_launches, int flags, tce_plan **out) {
     if (!descs || !group_sizes || n_launches < 1 || !out) return fail(TCE_ERR_BAD_ARG, "bad argument");
-    if (flags & ~(TCE_PLAN_CHAINED | TCE_PLAN_TAGGED | TCE_PLAN_OVERLAPPED)) return fail(TCE_ERR_BAD_ARG, "unknown plan flags 0x%x", flags);
+    if (flags & ~(TCE_PLAN_CHAINED | TCE_PLAN_TAGGED | TCE_PLAN_OVERLAPPED | TCE_PLAN_TUNED)) return fail(TCE_ERR_BAD_ARG, "unknown plan flags 0x%x", flags);
     tce_plan *p = new (std::nothrow) tce_plan();
     if (!p) return fail(TCE_ERR_BAD_ARG, "out of host memory");
     int total = 0;
@@ -874,6 +1006,7 @@ int tce_plan_create_ex(const tce_w4a16_desc *descs, const int32_t *group_sizes, 
         if (rc != TCE_OK) p->token = nullptr;  // a launch the token kernel does not take: stream-ordered plan
     }
 
+    if ((flags & TCE_PLAN_TUNED) && !p->token && g_gemv_kernel == 0) (void)tune_plan_launches(p->descs, p->groups, p->tuned);
     hipStream_t cap = nullptr;
     hipError_t e = hipStreamCreateWithFlags(&cap, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -890,8 +1023,12 @@ int tce_plan_create_ex(const tce_w4a16_desc *descs, const int32_t *group_sizes, 
     if (p->token) {
         rc = tce::token_plan_enqueue(p->token, cap, &he);
     } else {
-        for (int i = 0, off = 0; i < n_launches && rc == TCE_OK; off += p->groups[i], ++i)
+        for (int i = 0, off = 0; i < n_launches && rc == TCE_OK; off += p->groups[i], ++i) {
+            const bool forced = i < (int)p->tuned.size() && p->tuned[i].rows != 0;
+            if (forced) (void)tce_w4a16_set_gemv_config(p->tuned[i].rows, p->tuned[i].wn, p->tuned[i].wk, p->tuned[i].depth);
             rc = p->groups[i] == 1 ? tce_w4a16_forward(&p->descs[off], cap) : tce_w4a16_forward_group(&p->descs[off], p->groups[i], cap);
+            if (forced) (void)tce_w4a16_set_gemv_config(0, 0, 0, 0);
+        }
     }
     e = hipStreamEndCapture(cap, &p->graph);
     (void)hipStreamDestroy(cap);
@@ -921,6 +1058,16 @@ int tce_plan_is_chained(const tce_plan *plan) { return plan && plan->token ? (tc
 int tce_plan_geometry(const tce_plan *plan, int *rows, int *depth, int *waves, int *workgroups) {
     if (!plan || !plan->token || !rows || !depth || !waves || !workgroups) return fail(TCE_ERR_BAD_ARG, "not a chained plan");
     tce::token_plan_geometry(plan->token, rows, depth, waves, workgroups);
+    return TCE_OK;
+}
+
+int tce_plan_launch_geometry(const tce_plan *plan, int launch, int *rows, int *waves_n, int *waves_k, int *depth) {
+    if (!plan || launch < 0 || launch >= (int)plan->groups.size() || !rows || !waves_n || !waves_k || !depth) return fail(TCE_ERR_BAD_ARG, "tce_plan_launch_geometry: bad argument");
+    const TunedGeometry g = launch < (int)plan->tuned.size() ? plan->tuned[launch] : TunedGeometry{};
+    *rows = g.rows;
+    *waves_n = g.wn;
+    *waves_k = g.wk;
+    *depth = g.depth;
     return TCE_OK;
 }
 

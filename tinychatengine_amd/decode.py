@@ -146,8 +146,8 @@ class DecodeLinears:
         """Algorithmic HBM bytes of one token on THIS rank (SURVEY §8d formula, summed over its linears)."""
         return sum(capi.algorithmic_bytes(self.m, l.out_features, l.in_features, self.group_size) for l in self.all_linears())
 
-    def make_plan(self, grouped: bool = True, tagged: bool = False, overlapped: bool = False) -> capi.Plan:
-        return capi.Plan(self.token_launches(grouped), tagged=tagged, overlapped=overlapped)
+    def make_plan(self, grouped: bool = True, tagged: bool = False, overlapped: bool = False, tuned: bool = False) -> capi.Plan:
+        return capi.Plan(self.token_launches(grouped), tagged=tagged, overlapped=overlapped, tuned=tuned)
 
     # ---- eager issue (used inside torch graph capture for world > 1, and by tests) ----
     @staticmethod
