@@ -154,7 +154,7 @@ def other_configs_leg(torch, dev):
 
 
 # ----------------------------------------------------------------------------------------------------------------
-def roofline_leg(dl, torch, launches: int, eager: bool = False, which: int = 2, quick: bool = False):
+def roofline_leg(dl, torch, launches: int, eager: bool = False, which: int = 2, quick: bool = False, knobs=None):
     """The dominant kernel in isolation: the grouped gate+up GEMV launch (2*ffn rows x hidden), `launches` back-to-back
     launches on one stream, rotating over the layers' distinct weights (ring >> Infinity Cache), HIP events on that
     stream around the whole sequence.  achieved = algorithmic bytes per launch / average launch duration."""
@@ -171,6 +171,22 @@ def roofline_leg(dl, torch, launches: int, eager: bool = False, which: int = 2, 
     L = capi.lib()
     import ctypes as C
     stp = C.c_void_p(st)
+    if knobs and any(knobs):  # the headline step is a TCE_PLAN_TUNED plan: the launch is measured the way that plan issues it (tce_plan_launch_geometry's encoding)
+        rows, wn, wk, dcode = knobs
+        if rows:
+            capi.set_gemv_config(rows, wn, wk, dcode % 100)
+        capi.check(L.tce_w4a16_set_debug_mode(41 if (dcode // 100) % 10 else 40))
+        capi.check(L.tce_w4a16_set_debug_mode(10 + dcode // 1000))
+    try:
+        return _roofline_leg_body(dl, torch, launches, eager, quick, capi, L, C, st, stp, groups, d0, arrs, formula_bytes, bytes_per_launch, zeros_bytes, knobs)
+    finally:
+        if knobs and any(knobs):
+            capi.set_gemv_config()
+            L.tce_w4a16_set_debug_mode(40)
+            L.tce_w4a16_set_debug_mode(10)
+
+
+def _roofline_leg_body(dl, torch, launches, eager, quick, capi, L, C, st, stp, groups, d0, arrs, formula_bytes, bytes_per_launch, zeros_bytes, knobs):
     for i in range(min(32, launches)):
         capi.check(L.tce_w4a16_forward_group(arrs[i % len(arrs)], len(d0), stp))
     torch.cuda.synchronize()
@@ -241,6 +257,7 @@ def roofline_leg(dl, torch, launches: int, eager: bool = False, which: int = 2, 
         "launch_us_p10_p50_p90": [round(per[1], 3), round(per[len(per) // 2], 3), round(per[-2], 3)],
         "measured_streaming_read_GBs": ceiling, "frac_of_measured_streaming_read": (round(gbs / ceiling, 4) if ceiling else None),
         "timing": "HIP events on the launch stream around graph-replayed back-to-back launches rotating over all layers' weights (includes inter-kernel gaps)",
+        **({"issued_as": f"the headline plan's choice for this launch (TCE_PLAN_TUNED): rows, waves_n, waves_k, depth code = {list(knobs)}"} if knobs and any(knobs) else {}),
     }
 
 
@@ -745,6 +762,7 @@ def main():
 
     # ---- the step ----
     variants = None
+    tuned_knobs = None
     if dist is None:
         plan = dl.make_plan(grouped=not args.ungrouped)
         step = lambda: plan.launch(stream)
@@ -852,6 +870,7 @@ def main():
                                 "verified": f"all outputs within {worst:.1e} of the untuned plan's (relative to the largest output; identical unless a K-split geometry was chosen)",
                                 "chosen (rows, waves_n, waves_k, depth) for the first block's launches and lm_head; zeros: the dispatcher's rule kept": [list(g) for g in (uplan.launch_geometries()[:4] + uplan.launch_geometries()[-1:])]}
                             if ms_u < 0.995 * ms_g2 and ms_u < ms_t and args.issue == "auto" and n_launches == plan.n_launches:
+                                tuned_knobs = uplan.launch_geometries()[2] if plan.n_launches > 2 else None  # the grouped gate+up launch of block 0
                                 step = ustep
                                 mode = "one hipGraph replay per token (129 launches in stream order, launch geometries timed on this device at plan creation: TCE_PLAN_TUNED)"
                     except Exception as e:  # noqa: BLE001
@@ -994,7 +1013,7 @@ def main():
     # the dominant kernel in isolation (at N > 1: this rank's row shard of it; purely local, every rank runs it so the ranks
     # stay in step for the teardown)
     try:
-        roof = roofline_leg(dl, torch, args.roofline_launches)
+        roof = roofline_leg(dl, torch, args.roofline_launches, knobs=tuned_knobs)
         if world > 1:
             roof["kernel"] += f", rows sharded {world}-way (this rank's shard)"
     except Exception as e:  # noqa: BLE001 -- never takes the headline number down with it

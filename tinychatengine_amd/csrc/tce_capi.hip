@@ -826,6 +826,7 @@ int tce_layernorm_q_w8a8_group(const float *x, const float *ln_weight, const flo
 struct TunedGeometry {
     int rows = 0, wn = 0, wk = 0, depth = 0;  // all zero: the dispatcher's choice
     int shared_xsum = 0;                      // the per-chunk activation sums once per workgroup (w4a16_gemv.hip)
+    int order = 0;                            // 0: the rule; 1: x staged before the first weight load; 2: weights first
 };
 
 struct tce_plan {
@@ -912,7 +913,9 @@ static int tune_plan_launches(const std::vector<tce_w4a16_desc> &descs, const st
             const bool forced = g[i].rows != 0;
             if (forced && tce_w4a16_set_gemv_config(g[i].rows, g[i].wn, g[i].wk, g[i].depth) != TCE_OK) rc = TCE_ERR_BAD_ARG;
             tce::set_gemv_shared_xsum(g[i].shared_xsum);
+            tce::set_gemv_order(g[i].order);
             if (rc == TCE_OK) rc = groups[i] == 1 ? tce_w4a16_forward(&copy[offs[i]], st) : tce_w4a16_forward_group(&copy[offs[i]], groups[i], st);
+            tce::set_gemv_order(0);
             tce::set_gemv_shared_xsum(0);
             if (forced) (void)tce_w4a16_set_gemv_config(0, 0, 0, 0);
         }
@@ -937,7 +940,8 @@ static int tune_plan_launches(const std::vector<tce_w4a16_desc> &descs, const st
         (void)hipGetLastError();
         return us;
     };
-    static const int cands[][4] = {{2, 4, 1, 2}, {3, 4, 1, 2}, {4, 4, 1, 1}, {2, 8, 1, 2}, {2, 4, 1, 1}, {1, 4, 1, 2}};
+    static const int cands[][4] = {{2, 4, 1, 2}, {3, 4, 1, 2}, {4, 4, 1, 1}, {2, 8, 1, 2}, {2, 4, 1, 1}, {1, 4, 1, 2}, {1, 4, 1, 1}, {4, 8, 1, 1},
+                                   {2, 2, 2, 2}, {2, 2, 2, 1}, {1, 2, 2, 1}, {1, 2, 4, 1}};  // (the last four split K between waves: another summation order)
     const int ncand = (int)(sizeof cands / sizeof cands[0]);
     std::vector<TunedGeometry> best(n_launches);
     float best_us = time_plan(best);
@@ -961,20 +965,23 @@ static int tune_plan_launches(const std::vector<tce_w4a16_desc> &descs, const st
             }
         }
     }
-    // second knob, same acceptance rule: the activation sums once per workgroup (bit-identical results)
-    std::fill(done.begin(), done.end(), 0);
-    for (int i = 0; i < n_launches && best_us > 0.f; ++i) {
-        if (sig[i].empty() || done[i]) continue;
-        std::vector<TunedGeometry> trial(best);
-        for (int k = i; k < n_launches; ++k)
-            if (sig[k] == sig[i]) {
-                trial[k].shared_xsum = 1;
-                done[k] = 1;
+    // further knobs, same acceptance rule (results bit-identical): the activation sums once per workgroup; the issue order (x staged first / weights first)
+    for (int knob = 0; knob < 3; ++knob) {
+        std::fill(done.begin(), done.end(), 0);
+        for (int i = 0; i < n_launches && best_us > 0.f; ++i) {
+            if (sig[i].empty() || done[i]) continue;
+            std::vector<TunedGeometry> trial(best);
+            for (int k = i; k < n_launches; ++k)
+                if (sig[k] == sig[i]) {
+                    if (knob == 0) trial[k].shared_xsum = 1;
+                    else trial[k].order = knob;
+                    done[k] = 1;
+                }
+            const float us = time_plan(trial);
+            if (us > 0.f && us < 0.993f * best_us) {
+                best_us = us;
+                best = trial;
             }
-        const float us = time_plan(trial);
-        if (us > 0.f && us < 0.993f * best_us) {
-            best_us = us;
-            best = trial;
         }
     }
     out = best;
@@ -1045,8 +1052,12 @@ int tce_plan_create_ex(const tce_w4a16_desc *descs, const int32_t *group_sizes, 
         for (int i = 0, off = 0; i < n_launches && rc == TCE_OK; off += p->groups[i], ++i) {
             const bool forced = i < (int)p->tuned.size() && p->tuned[i].rows != 0;
             if (forced) (void)tce_w4a16_set_gemv_config(p->tuned[i].rows, p->tuned[i].wn, p->tuned[i].wk, p->tuned[i].depth);
-            if (i < (int)p->tuned.size()) tce::set_gemv_shared_xsum(p->tuned[i].shared_xsum);
+            if (i < (int)p->tuned.size()) {
+                tce::set_gemv_shared_xsum(p->tuned[i].shared_xsum);
+                tce::set_gemv_order(p->tuned[i].order);
+            }
             rc = p->groups[i] == 1 ? tce_w4a16_forward(&p->descs[off], cap) : tce_w4a16_forward_group(&p->descs[off], p->groups[i], cap);
+            tce::set_gemv_order(0);
             tce::set_gemv_shared_xsum(0);
             if (forced) (void)tce_w4a16_set_gemv_config(0, 0, 0, 0);
         }
@@ -1088,7 +1099,7 @@ int tce_plan_launch_geometry(const tce_plan *plan, int launch, int *rows, int *w
     *rows = g.rows;
     *waves_n = g.wn;
     *waves_k = g.wk;
-    *depth = g.depth + 100 * g.shared_xsum;  // (+ 100: the activation sums once per workgroup were taken for this launch)
+    *depth = g.depth + 100 * g.shared_xsum + 1000 * g.order;  // (+ 100: the activation sums once per workgroup; + 1000 / 2000: x first / weights first forced)
     return TCE_OK;
 }
 
