@@ -858,7 +858,7 @@ def main():
                         uplan.launch(stream)
                         torch.cuda.synchronize()
                         worst = max(float((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-6)) for a, b in zip(outs, want))
-                        if not all(bool(torch.isfinite(o.float()).all()) for o in outs) or worst > 4e-3:
+                        if not all(bool(torch.isfinite(o.float()).all()) for o in outs) or worst != 0.0:
                             variants["hipGraph, geometries timed on this device (TCE_PLAN_TUNED)"] = {"rejected": f"outputs differ from the untuned plan: worst |diff| / max = {worst:.2e}"}
                         else:
                             ustep = lambda: uplan.launch(stream)
@@ -867,7 +867,7 @@ def main():
                             ms_g2, ms_u = min(x for x, _ in ab), min(y for _, y in ab)
                             variants["hipGraph, geometries timed on this device (TCE_PLAN_TUNED)"] = {
                                 "ms_per_token": round(ms_u, 4), "tokens_per_s": round(1e3 / ms_u, 1), "untuned_graph_in_the_same_alternation_ms": round(ms_g2, 4),
-                                "verified": f"all outputs within {worst:.1e} of the untuned plan's (relative to the largest output; identical unless a K-split geometry was chosen)",
+                                "verified": "all outputs of the token bit-identical to the untuned plan",
                                 "chosen (rows, waves_n, waves_k, depth) for the first block's launches and lm_head; zeros: the dispatcher's rule kept": [list(g) for g in (uplan.launch_geometries()[:4] + uplan.launch_geometries()[-1:])]}
                             if ms_u < 0.995 * ms_g2 and ms_u < ms_t and args.issue == "auto" and n_launches == plan.n_launches:
                                 tuned_knobs = uplan.launch_geometries()[2] if plan.n_launches > 2 else None  # the grouped gate+up launch of block 0

@@ -360,8 +360,8 @@ TCE_API int tce_plan_create(const tce_w4a16_desc *descs, const int32_t *group_si
 #define TCE_PLAN_OVERLAPPED 4
 /* TCE_PLAN_TUNED (stream-ordered plans): the geometry of every decode (M = 1) launch is chosen at plan creation by timing the compiled candidates on this
  * device -- the WHOLE launch list is captured and replayed with one group of same-shaped launches at a time on each compiled candidate, a candidate stays
- * only if the whole plan gets 0.7 % faster; outputs are redirected to a scratch buffer (the caller's buffers are not written).  Costs a second or two, once; results agree with the untuned plan within
- * the kernels' own rounding (a geometry that splits K between waves adds in another order; the others are bit-identical). */
+ * only if the whole plan gets 0.7 % faster; outputs are redirected to a scratch buffer (the caller's buffers are not written).  Costs a second or two, once; results are bit-identical to the
+ * untuned plan's (only geometries that keep every row's summation order are candidates). */
 #define TCE_PLAN_TUNED 8
 TCE_API int tce_plan_create_ex(const tce_w4a16_desc *descs, const int32_t *group_sizes, int n_launches, int flags, tce_plan **out);
 TCE_API int tce_plan_is_chained(const tce_plan *plan);

@@ -314,8 +314,7 @@ def test_chained_plan_falls_back_when_a_launch_is_not_a_decode_gemv(dev, oracle)
 
 
 def test_tuned_plan_matches_the_untuned_plan(dev_chain=None):
-    """TCE_PLAN_TUNED: a stream-ordered plan whose launch geometries were timed at creation computes what the untuned plan computes (bit-identical unless a geometry
-    that splits K between waves won; then within the linears' rounding), leaves the caller's output buffers untouched during the timing, and replays."""
+    """TCE_PLAN_TUNED: a stream-ordered plan whose launch geometries were timed at creation computes the untuned plan's bits (only geometries that keep every row's summation order are candidates), leaves the caller's output buffers untouched during the timing, and replays."""
     import torch
     from tinychatengine_amd import capi
     from tinychatengine_amd.decode import SHAPES, DecodeLinears
@@ -340,4 +339,4 @@ def test_tuned_plan_matches_the_untuned_plan(dev_chain=None):
         torch.cuda.synchronize()
         for a, b in zip(outs, want):
             assert torch.isfinite(a.float()).all()
-            assert float((a.float() - b.float()).abs().max()) <= 4e-3 * float(b.float().abs().max())
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16))
