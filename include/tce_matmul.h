@@ -306,10 +306,10 @@ TCE_API int tce_opt_kv_append(const void *k, const void *v, void *k_cache, void 
 /* The whole OPT attention of a DECODE step (m <= 8 new rows) between the q/k/v projections and out_proj as ONE launch (csrc/opt_attention.hip): the KV append
  * of tce_opt_kv_append, the qk BMM (BMM_S8T_S8N_F32T.cc:12-62), tce_opt_softmax_q and the pv BMM (BMM_S8T_S8N_S8T.cc:12-63, clamp -128 .. 127) -- int32 dot
  * products and the same floating-point operations in the same order, so `out` and both caches are bit-identical to the four separate launches.
- *   q, k_new, v_new  int8 [m][ld]: the projections' output rows (head h: columns h * 64 ..; ld 0 = heads * 64)
- *   k_cache int8 [heads][max_keys][64], vt_cache int8 [heads][64][max_keys]: rows / columns pos .. pos + m - 1 are written
- *   mask fp32 [m][pos + m] additive;  out int8 [m][ld]: head h writes its 64 columns (out_proj's input rows)
- * head_dim == 64, m <= 8, ld and max_keys multiples of 16. */
+ *   q, k_new, v_new  int8 [m][ld]: the projections' output rows (head h: columns h * hd ..; ld 0 = heads * hd)
+ *   k_cache int8 [heads][max_keys][hd], vt_cache int8 [heads][hd][max_keys]: rows / columns pos .. pos + m - 1 are written
+ *   mask fp32 [m][pos + m] additive;  out int8 [m][ld]: head h writes its hd columns (out_proj's input rows)
+ * hd == 64 (OPT-125M / 1.3B) or 128 (OPT-6.7B), m <= 8, ld and max_keys multiples of 16. */
 TCE_API int tce_opt_attention_decode(const void *q, const void *k_new, const void *v_new, void *k_cache, void *vt_cache, const float *mask, void *out, int heads,
                                      int head_dim, int m, int pos, int max_keys, int ld, float alpha_qk, float alpha_pv, void *stream);
 

@@ -274,7 +274,8 @@ def test_layernorm_q_fused_argument_checks(dev):
 
 @pytest.mark.parametrize("embed,heads,ffn,steps", [(256, 4, 512, [(0, 5), (5, 1), (6, 1), (7, 3)]),      # a prompt of 5, two decode tokens, a batch of 3
                                                    (768, 12, 3072, [(0, 40), (40, 1)]),                   # OPT-125M's sizes (model.h:70): prefill 40, one decode token
-                                                   (256, 4, 512, [(0, 1), (1, 1), (2, 20)])])
+                                                   (256, 4, 512, [(0, 1), (1, 1), (2, 20)]),
+                                                   (512, 4, 1024, [(0, 7), (7, 1), (8, 2), (10, 1)])])                    # heads of 128 (OPT-6.7B's head dimension)
 def test_opt_decoder_layer_against_the_oracle_composition(dev, oracle, embed, heads, ffn, steps):
     """A whole SmoothQuant OPT decoder layer on this library's launches (tinychatengine_amd/opt_layer.py: 8 per decode step, 12 per prefill) against
     the ORACLE'S composition of Int8OPTDecoderLayer::forward (Int8OPTDecoderLayer.cc:24-59, Int8OPTAttention.cc:183-284): LayerNormQ, the three
@@ -461,17 +462,19 @@ def test_opt_softmax_q_against_the_oracle(dev, oracle, heads, sq, tgz, scale):
     assert (got[:, :, tgz:] == 77).all()
 
 
-@pytest.mark.parametrize("heads,max_keys,pos,m,a_qk", [(12, 512, 511, 1, 2.0e-3), (12, 512, 500, 1, 2.0e-6), (4, 1040, 1000, 8, 1.0e-3), (3, 64, 0, 5, 5.0e-4), (2, 4096, 4000, 3, 1.0e-5),
-                                                       (12, 2048, 17, 2, 1.0e-3)])
-def test_opt_attention_decode_equals_the_four_launches(dev, oracle, heads, max_keys, pos, m, a_qk):
+@pytest.mark.parametrize("heads,hd,max_keys,pos,m,a_qk", [(12, 64, 512, 511, 1, 2.0e-3), (12, 64, 512, 500, 1, 2.0e-6), (4, 64, 1040, 1000, 8, 1.0e-3), (3, 64, 64, 0, 5, 5.0e-4),
+                                                          (2, 64, 4096, 4000, 3, 1.0e-5), (12, 64, 2048, 17, 2, 1.0e-3),
+                                                          # head dimension 128 (OPT-6.7B: 32 heads of 128, model.h): the same cases' corners
+                                                          (32, 128, 512, 511, 1, 1.0e-3), (4, 128, 1040, 1000, 8, 1.0e-6), (3, 128, 64, 0, 5, 3.0e-4), (2, 128, 2048, 1937, 3, 1.0e-3)])
+def test_opt_attention_decode_equals_the_four_launches(dev, oracle, heads, hd, max_keys, pos, m, a_qk):
     """tce_opt_attention_decode (KV append + qk BMM + mask / softmax / int8 + pv BMM, one launch) against tce_opt_kv_append -> tce_w8a8_matmul -> tce_opt_softmax_q ->
     tce_w8a8_matmul on the same inputs: the attention rows and both caches bit for bit -- long contexts, several new rows, a position that is not a multiple of 16
     (the cached value rows are read in 16-byte pieces), score scales that put the rows' maxima above 1 (rows independent of row (0, 0)) and far below it (every row
     starts its maximum from row (0, 0)'s first probability), garbage in the caches behind the position."""
     from tinychatengine_amd import capi
     L = capi.lib()
-    hd, E, tgz = 64, heads * 64, pos + m
-    rng = np.random.default_rng(heads + pos + m)
+    E, tgz = heads * hd, pos + m
+    rng = np.random.default_rng(heads + pos + m + hd)
     kc0 = rng.integers(-128, 128, (heads, max_keys, hd), dtype=np.int8)
     vt0 = rng.integers(-128, 128, (heads, hd, max_keys), dtype=np.int8)
     q, k, v = (rng.integers(-128, 128, (m, E), dtype=np.int8) for _ in range(3))
@@ -505,6 +508,7 @@ def test_opt_attention_decode_equals_the_four_launches(dev, oracle, heads, max_k
     assert torch.equal(out_a, out_b), f"{int((out_a != out_b).sum())} attention outputs differ"
     assert a_qk < 1e-3 or int(probs.abs().sum()) > 0
     rmax = (scores.cpu().numpy() + mask[None]).max(axis=-1)
-    if a_qk <= 2e-6:
+    if a_qk <= 2e-6 and hd == 64:
         assert (rmax < 1).all()   # every row (but (0, 0)) took the dependent path
     assert L.tce_opt_attention_decode(vp(tq), vp(tk), vp(tv), vp(kc_b), vp(vt_b), vp(tm), vp(out_b), heads, hd, 9, 0, max_keys, 0, a_qk, a_pv, None) == capi.TCE_ERR_UNSUPPORTED_SHAPE
+    assert L.tce_opt_attention_decode(vp(tq), vp(tk), vp(tv), vp(kc_b), vp(vt_b), vp(tm), vp(out_b), heads, 96, 1, 0, max_keys, 0, a_qk, a_pv, None) == capi.TCE_ERR_UNSUPPORTED_SHAPE  # head_dim

@@ -755,14 +755,14 @@ int tce_opt_attention_decode(const void *q, const void *k_new, const void *v_new
                              int pos, int max_keys, int ld, float alpha_qk, float alpha_pv, void *stream) {
     if (!q || !k_new || !v_new || !k_cache || !vt_cache || !mask || !out) return fail(TCE_ERR_BAD_ARG, "tce_opt_attention_decode: null pointer");
     if (heads <= 0 || m <= 0 || pos < 0 || pos + m > max_keys) return fail(TCE_ERR_BAD_ARG, "tce_opt_attention_decode: need heads, m > 0 and pos + m <= max_keys");
-    if (hd != 64) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_opt_attention_decode: head_dim %d (64 only: OPT's)", hd);
+    if (hd != 64 && hd != 128) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_opt_attention_decode: head_dim %d (64 or 128: OPT-125M / 1.3B and OPT-6.7B)", hd);
     if (m > 8) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_opt_attention_decode is a decode path: m <= 8 new rows, got %d (use the BMM + tce_opt_softmax_q launches)", m);
     if (ld == 0) ld = heads * hd;
-    if (ld < heads * hd || ld % 16 != 0 || max_keys % 16 != 0) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_opt_attention_decode: ld >= heads * 64, ld and max_keys multiples of 16");
+    if (ld < heads * hd || ld % 16 != 0 || max_keys % 16 != 0) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_opt_attention_decode: ld >= heads * hd, ld and max_keys multiples of 16");
     for (const void *p : {q, k_new, v_new, (const void *)k_cache, (const void *)vt_cache})
         if (reinterpret_cast<uintptr_t>(p) & 15) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_opt_attention_decode: 16-byte aligned pointers");
     hipError_t he = hipSuccess;
-    const int rc = tce::launch_opt_attention_decode(q, k_new, v_new, k_cache, vt_cache, mask, out, heads, m, pos, max_keys, ld, alpha_qk, alpha_pv, static_cast<hipStream_t>(stream), &he);
+    const int rc = tce::launch_opt_attention_decode(q, k_new, v_new, k_cache, vt_cache, mask, out, heads, hd, m, pos, max_keys, ld, alpha_qk, alpha_pv, static_cast<hipStream_t>(stream), &he);
     if (rc == TCE_ERR_HIP) return hip_fail(he, "opt attention decode launch");
     if (rc != TCE_OK) return fail(rc, "tce_opt_attention_decode: the context does not fit the CU's LDS");
     return TCE_OK;

@@ -175,7 +175,7 @@ void describe_attention_decode_fast(int heads, int keys, int *chunk, int *chunks
 size_t attention_decode_workspace_bytes(int heads, int max_keys, int hd);
 // attention_prefill.hip: m > 1 new rows (rotation + append + causal / masked attention over pos + m keys), two launches
 // opt_attention.hip: KV append + qk + mask / softmax / int8 + pv of the SmoothQuant OPT attention for m <= 8 new rows, one launch
-int launch_opt_attention_decode(const void *q, const void *kn, const void *vn, void *kc, void *vtc, const float *mask, void *out, int heads, int m, int pos,
+int launch_opt_attention_decode(const void *q, const void *kn, const void *vn, void *kc, void *vtc, const float *mask, void *out, int heads, int hd, int m, int pos,
                                 int max_keys, int ld, float a_qk, float a_pv, hipStream_t stream, hipError_t *hip_err);
 size_t attention_prefill_workspace_bytes(int heads, int m, int hd);
 void set_attention_prefill_waves(int w);  // 0 automatic, 4 / 8 forced
