@@ -367,8 +367,8 @@ TCE_API int tce_plan_create_ex(const tce_w4a16_desc *descs, const int32_t *group
 TCE_API int tce_plan_is_chained(const tce_plan *plan);
 TCE_API int tce_plan_geometry(const tce_plan *plan, int *rows, int *depth, int *waves, int *workgroups);
 /* TCE_PLAN_TUNED plans: the geometry that won the timing for launch `launch` -- (rows per wave, waves along N, waves splitting K, pipeline depth) of the
- * row-block GEMV -- or all zero where the dispatcher's own choice stayed (also for untuned plans); depth + 100: the launch also forms its activation sums
- * once per workgroup; + 1000 / + 2000: its issue order was forced to activations-first / weights-first (the other knobs the timing tries). */
+ * row-block GEMV -- or all zero where the dispatcher's own choice stayed (also for untuned plans); depth + 200: the launch forms its activation sums
+ * by every wave instead of once per workgroup (the default for M = 1); + 1000 / + 2000: its issue order was forced to activations-first / weights-first (the other knobs the timing tries). */
 TCE_API int tce_plan_launch_geometry(const tce_plan *plan, int launch, int *rows, int *waves_n, int *waves_k, int *depth);
 TCE_API int tce_plan_status(tce_plan *plan);
 TCE_API int tce_plan_launch(tce_plan *plan, void *stream);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """In-process A/B of the row-block GEMV's issue order on the token's launches: the rule (x first when the grid is one generation of
-workgroups, ...) -- HERE: the per-chunk activation sums by every wave (40) against once per workgroup through an LDS table (41) (tce_w4a16_set_debug_mode 40 / 41).
+workgroups, ...) -- HERE: the per-chunk activation sums by every wave (45) against once per workgroup through an LDS table (47; 46 = the rule) (tce_w4a16_set_debug_mode; an earlier version of this script used 40 / 41, which the GEMM's XCD-rows modes shadowed: that run compared a kernel with itself).
    gpurun -- 'python scripts/gemv_xsum_ab.py > gpurun_out/gemv_xsum_ab.jsonl'"""
 import ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,7 +19,7 @@ def graph_for(which, mode):
         with torch.cuda.graph(g, stream=s):
             for i in range(128):
                 capi.check(L.tce_w4a16_forward_group(arrs[i % len(arrs)], len(groups[0]), sp))
-    capi.check(L.tce_w4a16_set_debug_mode(40))
+    capi.check(L.tce_w4a16_set_debug_mode(46))
     return g, arrs
 def t(g):
     g.replay(); torch.cuda.synchronize()
@@ -29,7 +29,7 @@ def t(g):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) * 1e3 / (5 * 128)
 for which, name in ((0, "qkv"), (1, "o"), (2, "gate+up"), (3, "down")):
-    gs = {k: graph_for(which, m) for k, m in (("every_wave", 40), ("shared_table", 41))}
+    gs = {k: graph_for(which, m) for k, m in (("every_wave", 45), ("shared_table", 47))}
     res = {k: [] for k in gs}
     for rnd in range(7):
         for k in gs:

@@ -218,7 +218,8 @@ def test_wave_quartets_per_tile_are_bit_exact(dev, oracle, M, N, K):
         L.tce_w4a16_set_debug_mode(70)
 
 
-@pytest.mark.parametrize("m,k,ns", [(1, 768, (768, 768, 768)), (1, 768, (3072,)), (3, 2048, (2048, 512)), (8, 96, (40, 24, 16, 8)), (1, 8192, (64,))])
+@pytest.mark.parametrize("m,k,ns", [(1, 768, (768, 768, 768)), (1, 768, (3072,)), (3, 2048, (2048, 512)), (8, 96, (40, 24, 16, 8)), (1, 8192, (64,)),
+                                     (1, 4096, (16384,)), (2, 1024, (1000, 24, 3000)), (1, 4096, (4096, 4096, 4096))])  # k >= 1024: the weights-resident form (OPT-6.7B: fc1, q / k / v)
 def test_layernorm_q_fused_with_its_linears_is_bit_exact(dev, oracle, m, k, ns):
     """tce_layernorm_q_w8a8_group (SURVEY 8f-3): LayerNormQ::forward (LayerNormQ.cc:12-52) + q/k/v (Int8OPTAttention.cc:186-201) or
     fc1 as ONE launch, against the oracle's LayerNormQ followed by int8_ref_matmul, and against the library's separate launches."""
@@ -255,6 +256,45 @@ def test_layernorm_q_fused_with_its_linears_is_bit_exact(dev, oracle, m, k, ns):
     capi.check(capi.lib().tce_layernorm_q(xt.data_ptr(), lwt.data_ptr(), lbt.data_ptr(), q_sep.data_ptr(), m, k, torch.cuda.current_stream().cuda_stream))
     for lin, o in zip(lins, outs):
         assert torch.equal(lin(q_sep), o)
+
+
+@pytest.mark.parametrize("m,k", [(1, 4096), (1, 2048), (2, 1040), (1, 2064), (3, 1024), (1, 8192)])
+def test_layernorm_q_long_rows_when_the_speculated_sums_miss(dev, oracle, m, k):
+    """The wide form of tce_layernorm_q_w8a8_group (k >= 1024) walks a row's two sequential fp32 sums with 16 waves at once, each starting its segment from 64
+    candidate running values around the exactly rounded prefix (sequential_sum_speculated, tce_common.hpp); where no candidate is the true running value the
+    segment is re-added.  Rows built to miss: running sums that return to (almost) zero at the segment boundaries, cancellation of huge values (the running value
+    loses its low bits, then regains them), zero-mean noise, a constant row (all deviations zero), tiny values after large ones -- against the oracle, bit for bit."""
+    from tinychatengine_amd.linear import W8A8B8O8Linear, layernorm_q_linears
+    rng = np.random.default_rng(m * 13 + k)
+    seg = ((k + 16 * 32 - 1) // (16 * 32)) * 32
+    rows = []
+    base = rng.standard_normal(k).astype(np.float32)
+    r0 = base.copy()                                      # zero-mean noise
+    r1 = base.copy()                                      # every segment sums to (almost) nothing: the running value sits near zero at each boundary
+    for b in range(0, k, seg):
+        e = min(b + seg, k)
+        r1[e - 1] = np.float32(-np.sum(r1[b:e - 1], dtype=np.float64))
+    r2 = base.copy() * np.float32(1e-3)                   # cancellation: +1e7 early, -1e7 late, small values between and after
+    r2[3], r2[k // 2 + 5] = 1.0e7, -1.0e7
+    r3 = np.full(k, 0.7, np.float32)                      # a constant row: every squared deviation is the same tiny number (or zero)
+    r4 = np.concatenate([base[: k // 2] * np.float32(3e4), base[k // 2:] * np.float32(1e-4)]).astype(np.float32)  # large, then tiny
+    r5 = np.abs(base) + np.float32(0.25)                  # all positive (a steadily growing sum)
+    pool = [r0, r1, r2, r3, r4, r5]
+    lw = (rng.standard_normal(k) * 20.0).astype(np.float32)
+    lb = (rng.standard_normal(k) * 5.0).astype(np.float32)
+    W = rng.integers(-128, 128, (48, k), dtype=np.int8)
+    b8 = rng.integers(-128, 128, 48, dtype=np.int8)
+    lin = W8A8B8O8Linear(_t(dev, W), _t(dev, b8), ALPHA, BETA)
+    lwt, lbt = _t(dev, lw), _t(dev, lb)
+    for start in range(0, len(pool), m):
+        x = np.stack([pool[(start + i) % len(pool)] for i in range(m)]).astype(np.float32)
+        q_ref = oracle.layernorm_q(x, lw, lb)
+        xt = _t(dev, x)
+        ln_out = torch.zeros((m, k), dtype=torch.int8, device=dev)
+        (out,) = layernorm_q_linears(xt, lwt, lbt, [lin], ln_out=ln_out)
+        torch.cuda.synchronize()
+        assert np.array_equal(ln_out.cpu().numpy(), q_ref), f"rows {start}..: {int((ln_out.cpu().numpy() != q_ref).sum())} normalised values differ"
+        assert np.array_equal(out.cpu().numpy(), oracle.int8_matmul_bias_i8(q_ref, W, b8, ALPHA, BETA, -128, 127, m, 48, k))
 
 
 def test_layernorm_q_fused_argument_checks(dev):

@@ -185,8 +185,12 @@ int tce_w4a16_set_debug_mode(int mode) {
         tce::set_gemm_dma_xcd_rows(mode - 40);
         return TCE_OK;
     }
-    if (mode == 40 || mode == 41) {  // GEMV: the per-chunk activation sums once per workgroup (41) or by every wave (40, the default)
-        tce::set_gemv_shared_xsum(mode - 40);
+    if (mode >= 45 && mode <= 47) {  // GEMV, the per-chunk activation sums: 46 the rule (once per workgroup for M = 1), 47 once per workgroup, 45 by every wave
+        tce::set_gemv_shared_xsum(mode == 45 ? 2 : mode - 46);
+        return TCE_OK;
+    }
+    if (mode == 80 || mode == 81) {  // LayerNormQ + W8A8 group: 81 = the workgroup-per-8-rows form at every k (A/B of the weights-resident form)
+        tce::set_lnq_form(mode - 80);
         return TCE_OK;
     }
     if (mode >= 20 && mode <= 30) {  // small-batch kernel tuning: 20 automatic, 21/22/24/28 = waves per tile, 30 = shared-x form, 29 = off
@@ -825,7 +829,7 @@ int tce_layernorm_q_w8a8_group(const float *x, const float *ln_weight, const flo
 // ---------------------------------------------------------------------------------------------
 struct TunedGeometry {
     int rows = 0, wn = 0, wk = 0, depth = 0;  // all zero: the dispatcher's choice
-    int shared_xsum = 0;                      // the per-chunk activation sums once per workgroup (w4a16_gemv.hip)
+    int shared_xsum = 0;                      // the per-chunk activation sums (w4a16_gemv.hip): 0 the rule (once per workgroup), 2 by every wave
     int order = 0;                            // 0: the rule; 1: x staged before the first weight load; 2: weights first
 };
 
@@ -975,7 +979,7 @@ static int tune_plan_launches(const std::vector<tce_w4a16_desc> &descs, const st
             std::vector<TunedGeometry> trial(best);
             for (int k = i; k < n_launches; ++k)
                 if (sig[k] == sig[i]) {
-                    if (knob == 0) trial[k].shared_xsum = 1;
+                    if (knob == 0) trial[k].shared_xsum = 2;
                     else trial[k].order = knob;
                     done[k] = 1;
                 }
@@ -1101,7 +1105,7 @@ int tce_plan_launch_geometry(const tce_plan *plan, int launch, int *rows, int *w
     *rows = g.rows;
     *waves_n = g.wn;
     *waves_k = g.wk;
-    *depth = g.depth + 100 * g.shared_xsum + 1000 * g.order;  // (+ 100: the activation sums once per workgroup; + 1000 / 2000: x first / weights first forced)
+    *depth = g.depth + 100 * g.shared_xsum + 1000 * g.order;  // (+ 200: the activation sums by every wave instead of once per workgroup; + 1000 / 2000: x first / weights first forced)
     return TCE_OK;
 }
 

@@ -233,8 +233,8 @@ __device__ __forceinline__ float sequential_sum_lane0(const float *lds_x, int n,
 // has not landed (and a kernel that calls this reports >= 128 VGPRs).  `vals` is 16-byte aligned; the loop reads up to 128 bytes past the
 // last 32-value pair (LDS reads past the allocation return zero; nothing read there is added).  The total is valid in EVERY lane.  A
 // mapped sum (the squared deviations of LayerNormQ.cc:33-36) is taken over values the wave computed into LDS beforehand, in parallel.
-__device__ __forceinline__ float sequential_sum_bcast(const float *vals, int n) {
-    float acc = 0.f;
+__device__ __forceinline__ float sequential_sum_bcast(const float *vals, int n, float init = 0.f) {  // init: the running value the additions start from (may differ per lane)
+    float acc = init;
     int pairs = n >> 5;
     if (pairs > 0) {
         unsigned p = (unsigned)(size_t)vals;  // LDS byte address
@@ -292,6 +292,62 @@ __device__ __forceinline__ float sequential_sum(const float *vals, int n, int la
         return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s)));
     }
 }
+// The same sum by ALL NW waves of a workgroup, for ONE long row (LayerNormQ at OPT-1.3B / 6.7B widths: 2 x 4096 dependent additions = 22 us for a single wave).
+// An fp32 sum rounded after every addition cannot be re-associated -- but it can be SPECULATED: the row is cut into NW segments; wave w takes segment w and starts
+// it from 64 different running values at once, one per lane: the fp32 neighbours (-32 .. +31 units in the last place) of the exactly rounded sum of everything
+// before the segment, which is known at once from a double-precision reduction.  (A wave's 64 lanes are idle during a dependent chain anyway: every lane adds the
+// same broadcast value to ITS running value.)  Then wave 0 walks the segments in order: the true running value at the start of segment w is the end value of
+// segment w - 1; if one of the 64 candidates of segment w is that very number (bit pattern), the lane's end value IS the sequential sum over the segment, else
+// (the running value came closer to zero than the rounding errors accumulated so far, signed zeros, inf / NaN) the segment is re-added from the true value.
+// Every addition that contributes to the result is the reference's, in the reference's order, on the reference's operands: bit-identical by construction, the
+// speculation only decides how much of it was done ahead.  Cost: n / NW dependent additions per wave (with 16 waves the CU's four SIMDs are the limit: n cycles)
+// + one segment per miss.  All threads of the workgroup must call it (three barriers); `sp` is 16 + 2 * NW * 64 floats of LDS scratch.
+template <int NW>
+__device__ __forceinline__ float sequential_sum_speculated(const float *vals, int n, float *sp, int wave, int lane) {
+    double *segsum = reinterpret_cast<double *>(sp);  // [NW] (NW <= 16: 32 floats)
+    float *cand = sp + 32, *fin = sp + 32 + NW * 64, *res = sp + 32 + 2 * NW * 64;
+    const int L = ((n + NW * 32 - 1) / (NW * 32)) * 32;  // segment length: a multiple of 32 (sequential_sum_bcast's unit, and 128-byte alignment)
+    const int b = wave * L;
+    const int len = n - b < 0 ? 0 : (n - b < L ? n - b : L);
+    double ds = 0.0;
+    for (int k = b + lane; k < b + len; k += 64) ds += (double)vals[k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ds += __shfl_xor(ds, off, 64);
+    if (lane == 0) segsum[wave] = ds;
+    __syncthreads();
+    double before = 0.0;
+    for (int u = 0; u < wave; ++u) before += segsum[u];
+    float c = 0.f;  // wave 0 starts from the sum's own start
+    if (wave > 0) {
+        // the fp32 neighbours of the estimate: bit patterns in monotone order (an involution: negative values run backwards)
+        int i = __builtin_bit_cast(int, (float)before);
+        i ^= (i >> 31) & 0x7fffffff;
+        i += lane - 32;
+        i ^= (i >> 31) & 0x7fffffff;
+        c = __builtin_bit_cast(float, i);
+    }
+    const float f = len > 0 ? sequential_sum_bcast(vals + b, len, c) : c;
+    cand[wave * 64 + lane] = c;
+    fin[wave * 64 + lane] = f;
+    __syncthreads();
+    if (wave == 0) {
+        float s = f;  // (segment 0: every lane started from 0)
+        for (int w = 1; w < NW; ++w) {
+            const int bw = w * L;
+            if (bw >= n) break;
+            const int lw = n - bw < L ? n - bw : L;
+            const float cw = cand[w * 64 + lane], fw = fin[w * 64 + lane];
+            const unsigned long long hit = __ballot(__builtin_bit_cast(int, cw) == __builtin_bit_cast(int, s));
+            if (hit) s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fw), __builtin_ctzll(hit)));
+            else s = sequential_sum_bcast(vals + bw, lw, s);
+        }
+        if (lane == 0) res[0] = s;
+    }
+    __syncthreads();
+    return res[0];
+}
+constexpr int kSpecScratchFloats(int nw) { return 32 + 2 * nw * 64 + 16; }
+
 constexpr int kSeqSumBcastMaxWaves = 256 * 8;  // up to ~two row-walking waves per SIMD: the chain is the limit; beyond: the LDS
 
 // non-temporal 16-byte load: streamed weights are read exactly once by exactly one CU

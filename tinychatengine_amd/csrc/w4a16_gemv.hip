@@ -558,8 +558,11 @@ hipError_t launch_mb(const Variant &v, const GemvArgs &a, int total_blocks, int 
 
 void set_gemv_debug_mode(int mode) { g_debug_mode = mode; }
 void set_gemv_order(int force) { g_order_force = force >= 0 && force <= 2 ? force : 0; }
+// 0: the rule -- ON for a decode launch (M = 1): 2-3 % on each of the token's four launch shapes (7.31 -> 7.09, 4.22 -> 4.09, 10.79 -> 10.47, 7.73 -> 7.60 us,
+// profiles/r3/gemv_shared_xsum_ab.jsonl; the round's first A/B of this switch compared a kernel with itself -- its debug mode was shadowed -- and is withdrawn);
+// 1 on, 2 off
 int g_shared_xsum = 0;
-void set_gemv_shared_xsum(int on) { g_shared_xsum = on == 1 ? 1 : 0; }
+void set_gemv_shared_xsum(int on) { g_shared_xsum = on == 1 || on == 2 ? on : 0; }
 void set_gemv_debug_buffer(void *p) { g_debug_buf = static_cast<unsigned long long *>(p); }
 
 bool gemv_variant_exists(int rows, int wn, int wk, int depth) {
@@ -592,7 +595,7 @@ int launch_w4a16_gemv(const tce_w4a16_desc *descs, int count, int forced_rows, i
     a.zeros_are_8 = 1;
     for (int i = 0; i < count; ++i)
         if (!(descs[i].flags & TCE_W4_ZERO_POINT_IS_8)) a.zeros_are_8 = 0;
-    a.shared_xsum = g_shared_xsum;
+    a.shared_xsum = g_shared_xsum == 1 || (g_shared_xsum == 0 && d0.M == 1);
 
     int total_n = 0;
     for (int i = 0; i < count; ++i) total_n += descs[i].N;
@@ -666,7 +669,7 @@ int launch_w4a16_gemv(const tce_w4a16_desc *descs, int count, int forced_rows, i
         // the x image of mb rows must fit the CU's 160 KiB of LDS (launch_one's formula): fewer rows per pass for a long K,
         // and a clear refusal -- not a generic HIP launch error -- when even one row does not fit (K > ~80k)
         const int LS = 64 * v.wk, T = (nchunks + LS - 1) / LS;
-        auto need = [&](int m) { return (size_t)m * T * LS * 64 + (size_t)64 * v.wn * v.wk * 16; };
+        auto need = [&](int m) { return (size_t)m * T * LS * 64 + (size_t)64 * v.wn * v.wk * 16 + (size_t)m * T * LS * 4; };  // (launch_one's formula: x image, trash slots, sum table)
         while (mb > 1 && need(mb) > 160 * 1024) mb >>= 1;
         if (need(mb) > 160 * 1024) return TCE_ERR_UNSUPPORTED_SHAPE;
     }

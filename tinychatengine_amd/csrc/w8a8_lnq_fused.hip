@@ -9,6 +9,15 @@
 // latency each.  Here every workgroup recomputes the (tiny) normalisation for its own use and then produces its slice of the
 // output rows of up to TCE_MAX_GROUP linears: one launch.
 //
+// Two kernels.  lnq_w8a8_kernel<2, 2, 4>: the OPT-125M form above -- a workgroup of 4 waves per 8 output rows, the first two 16-byte pieces per lane of a wave's
+// two rows requested before the sums.  lnq_w8a8_wide_kernel (k >= 1024: OPT-1.3B / 6.7B, where a row's two sequential sums are 2 x 4096 dependent additions -- 22 us
+// for one wave -- and a launch's int8 weights are 50-67 MB): ONE workgroup of 16 waves per CU, each normalises once and owns a contiguous run of output rows per
+// wave; the two sums are walked by all 16 waves at once (sequential_sum_speculated, tce_common.hpp: every wave adds its sixteenth of the row from 64 candidate
+// running values, wave 0 then picks the lanes that started from the true ones -- the additions that count are the reference's, in its order); a wave requests its
+// first two rows completely right after the activation row, so weights stream from memory WHILE the sums are walked, and streams the rest of its run afterwards
+// with eight 16-byte pieces per lane in flight.  Measured per launch at OPT-6.7B (q/k/v 3 x 4096 x 4096, fc1 16384 x 4096): 87 / 94 us for the 8-rows-per-workgroup
+// form (1536-2048 workgroups: the sums are walked in several rounds), 49 / 53 us with one round of 4-wave workgroups (three per CU: their three chains share a SIMD).
+//
 // BIT-EXACT against LayerNormQ::forward followed by int8_ref_matmul (kernels/ref/matmul_ref_int8.cc:11-35):
 //   * the reference's two row sums are sequential fp32 additions, so they are added in order (every lane holds the same accumulator and
 //     gets the values by LDS broadcast reads, one dependent add per element; a wave per row for m > 1); the division, multiply and add of the output are separate roundings (-ffp-contract=off), std::round = half away
@@ -19,6 +28,9 @@
 #include "w4a16_kernels.hpp"
 
 namespace tce {
+
+static int g_lnq_form = 0;  // debug: 1 = the workgroup-per-8-rows form at every k (A/B of the weights-resident form)
+void set_lnq_form(int f) { g_lnq_form = f; }
 
 namespace {
 
@@ -36,16 +48,18 @@ struct LnqArgs {
     const float *x, *ln_w, *ln_b;
     int8_t *ln_out;  // optional: the normalised int8 rows [m][K]
     int m, K, count, total_rows;
+    int rpw;  // output rows per wave (a contiguous run)
     LnqLinear lin[TCE_MAX_GROUP];
 };
 
-constexpr int kRowsPerWave = 2;
 constexpr int kWaves = 4;
 constexpr int kMaxM = 8;
 
 // LDS: [m][K] fp32 rows | [m][K] int8 | (pad) [m][2] stats | (pad) [min(m, kWaves)][K] fp32 squared deviations
 __host__ __device__ constexpr size_t lnq_dev_offset(int m, int K) { return (((size_t)m * K * 5 + 16 + (size_t)m * 8 + 16) + 15) & ~(size_t)15; }
 
+// RW rows of a wave's run are requested ahead, PL 16-byte pieces per lane of each; PF affine parameter pairs per thread are requested ahead (else read in step 3)
+template <int RW, int PL, int PF>
 __global__ __launch_bounds__(64 * kWaves) void lnq_w8a8_kernel(const LnqArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -54,22 +68,29 @@ __global__ __launch_bounds__(64 * kWaves) void lnq_w8a8_kernel(const LnqArgs a) 
     float *rows = reinterpret_cast<float *>(smem);                     // [m][K] fp32
     int8_t *q8 = reinterpret_cast<int8_t *>(smem + (size_t)m * K * 4);  // [m][K] int8
     float *stats = reinterpret_cast<float *>(smem + (size_t)m * K * 5 + 16 - ((size_t)m * K * 5) % 16);  // [m][2]: mean, std
-    const int row0 = (blockIdx.x * kWaves + wave) * kRowsPerWave;
+    const int row0 = (blockIdx.x * kWaves + wave) * a.rpw;
     const int pieces = K >> 4;
-    // the first weight pieces of BOTH rows of the wave are requested before anything else: they do not depend on the normalisation and land while
-    // the row sums are walked (K = 768: one piece per lane and row is the whole row)
-    int4_t wfirst[kRowsPerWave][2];
-    float ufirst[kRowsPerWave];
+    // the activation rows are requested FIRST (loads return in order: the sums must not wait behind the weights) ...
+    constexpr int XB = 4;
+    const int n4 = (m * K) >> 2;
+    float4_t xfirst[XB];
 #pragma unroll
-    for (int rr = 0; rr < kRowsPerWave; ++rr) {
-        const int row = row0 + rr < a.total_rows ? row0 + rr : a.total_rows - 1;
+    for (int i = 0; i < XB; ++i) xfirst[i] = tid + 64 * kWaves * i < n4 ? reinterpret_cast<const float4_t *>(a.x)[tid + 64 * kWaves * i] : float4_t{0.f, 0.f, 0.f, 0.f};
+    // ... then the first weight pieces of the wave's first RW rows: they do not depend on the normalisation and land while the row sums are walked
+    // (K = 768: one piece per lane and row is the whole row; <4, 4>: 4 rows of up to 4096 bytes completely)
+    int4_t wfirst[RW][PL];
+    float ufirst[RW];
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) {
+        const int rw = rr < a.rpw ? row0 + rr : row0;
+        const int row = rw < a.total_rows ? rw : a.total_rows - 1;
         int li = 0;
 #pragma unroll
         for (int s = 1; s < TCE_MAX_GROUP; ++s)
             if (s < a.count && row >= a.lin[s].row_begin) li = s;
         const int4_t *brow = reinterpret_cast<const int4_t *>(a.lin[li].B + (size_t)(row - a.lin[li].row_begin) * K);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) wfirst[rr][i] = lane + 64 * i < pieces ? brow[lane + 64 * i] : int4_t{0, 0, 0, 0};
+        for (int i = 0; i < PL; ++i) wfirst[rr][i] = lane + 64 * i < pieces ? brow[lane + 64 * i] : int4_t{0, 0, 0, 0};
         // the additive term of this output column, once (kernels/ref/matmul_ref_int8.cc:29-31)
         const LnqLinear &L = a.lin[li];
         const int n = row - L.row_begin;
@@ -77,8 +98,7 @@ __global__ __launch_bounds__(64 * kWaves) void lnq_w8a8_kernel(const LnqArgs a) 
         if (L.bias_kind == TCE_BIAS_INT8) ufirst[rr] = __fmul_rn((float)static_cast<const int8_t *>(L.bias)[n], L.beta);
         else if (L.bias_kind == TCE_BIAS_FP32) ufirst[rr] = static_cast<const float *>(L.bias)[n];
     }
-    // ... and the affine parameters of the elements this thread will quantize in step 3 (m * K <= 1024: decode at OPT sizes)
-    constexpr int PF = 4;
+    // ... and the affine parameters of the elements this thread will quantize in step 3 (m * K <= 256 PF)
     const bool affine_prefetched = m * K <= 64 * kWaves * PF;
     float pw[PF], pb[PF];
     if (affine_prefetched) {
@@ -91,8 +111,10 @@ __global__ __launch_bounds__(64 * kWaves) void lnq_w8a8_kernel(const LnqArgs a) 
         }
     }
     // ---- 1. the rows into LDS (coalesced) ----
-    const int n4 = (m * K) >> 2;
-    for (int p = tid; p < n4; p += 64 * kWaves) reinterpret_cast<float4_t *>(rows)[p] = reinterpret_cast<const float4_t *>(a.x)[p];
+#pragma unroll
+    for (int i = 0; i < XB; ++i)
+        if (tid + 64 * kWaves * i < n4) reinterpret_cast<float4_t *>(rows)[tid + 64 * kWaves * i] = xfirst[i];
+    for (int p = tid + 64 * kWaves * XB; p < n4; p += 64 * kWaves) reinterpret_cast<float4_t *>(rows)[p] = reinterpret_cast<const float4_t *>(a.x)[p];
     __syncthreads();
     // ---- 2. the two sequential sums of every row (LayerNormQ.cc:27-37), in the reference's order: wave w takes rows w, w + 4
     //         (sequential_sum_bcast, tce_common.hpp: one dependent add per element) ----
@@ -131,35 +153,8 @@ __global__ __launch_bounds__(64 * kWaves) void lnq_w8a8_kernel(const LnqArgs a) 
         for (int e = tid; e < m * K; e += 64 * kWaves) quantize(e, a.ln_w[e % K], a.ln_b[e % K]);
     }
     __syncthreads();
-    // ---- 4. this workgroup's output rows: a wave per row, lanes across K in 16-byte pieces ----
-#pragma unroll
-    for (int rr = 0; rr < kRowsPerWave; ++rr) {
-        const int row = row0 + rr;  // wave-uniform
-        if (row >= a.total_rows) break;
-        int li = 0;
-#pragma unroll
-        for (int s = 1; s < TCE_MAX_GROUP; ++s)
-            if (s < a.count && row >= a.lin[s].row_begin) li = s;
-        const LnqLinear &L = a.lin[li];
-        const int n = row - L.row_begin;
-        const int4_t *brow = reinterpret_cast<const int4_t *>(L.B + (size_t)n * K);
-        int acc[kMaxM];
-#pragma unroll
-        for (int mm = 0; mm < kMaxM; ++mm) acc[mm] = 0;
-        for (int p = lane, it = 0; p < pieces; p += 64, ++it) {
-            const int4_t w = it == 0 ? wfirst[rr][0] : (it == 1 ? wfirst[rr][1] : brow[p]);
-#pragma unroll
-            for (int mm = 0; mm < kMaxM; ++mm) {
-                if (mm < m) {
-                    const int4_t xq = *reinterpret_cast<const int4_t *>(q8 + (size_t)mm * K + p * 16);
-                    acc[mm] = __builtin_amdgcn_sdot4(w.x, xq.x, acc[mm], false);
-                    acc[mm] = __builtin_amdgcn_sdot4(w.y, xq.y, acc[mm], false);
-                    acc[mm] = __builtin_amdgcn_sdot4(w.z, xq.z, acc[mm], false);
-                    acc[mm] = __builtin_amdgcn_sdot4(w.w, xq.w, acc[mm], false);
-                }
-            }
-        }
-        const float u = ufirst[rr];
+    // ---- 4. this wave's output rows, lanes across K in 16-byte pieces: the first RW rows start from the registers requested at the top ----
+    auto finish_row = [&](const LnqLinear &L, int n, const int (&acc)[kMaxM], float u) {
 #pragma unroll
         for (int mm = 0; mm < kMaxM; ++mm) {
             if (mm < m) {
@@ -181,7 +176,301 @@ __global__ __launch_bounds__(64 * kWaves) void lnq_w8a8_kernel(const LnqArgs a) 
                 }
             }
         }
+    };
+    auto linear_of = [&](int row) {
+        int li = 0;
+#pragma unroll
+        for (int s = 1; s < TCE_MAX_GROUP; ++s)
+            if (s < a.count && row >= a.lin[s].row_begin) li = s;
+        return li;
+    };
+    auto dot_piece = [&](const int4_t &w, int p, int (&acc)[kMaxM]) {
+#pragma unroll
+        for (int mm = 0; mm < kMaxM; ++mm) {
+            if (mm < m) {
+                const int4_t xq = *reinterpret_cast<const int4_t *>(q8 + (size_t)mm * K + p * 16);
+                acc[mm] = __builtin_amdgcn_sdot4(w.x, xq.x, acc[mm], false);
+                acc[mm] = __builtin_amdgcn_sdot4(w.y, xq.y, acc[mm], false);
+                acc[mm] = __builtin_amdgcn_sdot4(w.z, xq.z, acc[mm], false);
+                acc[mm] = __builtin_amdgcn_sdot4(w.w, xq.w, acc[mm], false);
+            }
+        }
+    };
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) {
+        const int row = row0 + rr;  // wave-uniform
+        if (rr >= a.rpw || row >= a.total_rows) break;
+        const LnqLinear &L = a.lin[linear_of(row)];
+        const int n = row - L.row_begin;
+        const int4_t *brow = reinterpret_cast<const int4_t *>(L.B + (size_t)n * K);
+        int acc[kMaxM];
+#pragma unroll
+        for (int mm = 0; mm < kMaxM; ++mm) acc[mm] = 0;
+#pragma unroll
+        for (int i = 0; i < PL; ++i)
+            if (lane + 64 * i < pieces) dot_piece(wfirst[rr][i], lane + 64 * i, acc);
+        for (int p = lane + 64 * PL; p < pieces; p += 64) dot_piece(brow[p], p, acc);
+        finish_row(L, n, acc, ufirst[rr]);
     }
+    // rows of the run beyond the RW requested ahead (a launch held to the chip's capacity): streamed now, four pieces per lane in flight
+    for (int rr = RW; rr < a.rpw; ++rr) {
+        const int row = row0 + rr;
+        if (row >= a.total_rows) break;
+        const LnqLinear &L = a.lin[linear_of(row)];
+        const int n = row - L.row_begin;
+        const int4_t *brow = reinterpret_cast<const int4_t *>(L.B + (size_t)n * K);
+        float u = 0.f;
+        if (L.bias_kind == TCE_BIAS_INT8) u = __fmul_rn((float)static_cast<const int8_t *>(L.bias)[n], L.beta);
+        else if (L.bias_kind == TCE_BIAS_FP32) u = static_cast<const float *>(L.bias)[n];
+        int acc[kMaxM];
+#pragma unroll
+        for (int mm = 0; mm < kMaxM; ++mm) acc[mm] = 0;
+        for (int p0 = lane; p0 < pieces; p0 += 256) {
+            int4_t w[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[i] = p0 + 64 * i < pieces ? brow[p0 + 64 * i] : int4_t{0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (p0 + 64 * i < pieces) dot_piece(w[i], p0 + 64 * i, acc);
+        }
+        finish_row(L, n, acc, u);
+    }
+}
+
+
+// ---- the wide form: see the header comment ----
+constexpr int kWideWaves = 16;
+constexpr int kWideRW = 2;  // rows of a wave's run requested ahead ...
+constexpr int kWidePL = 4;  // ... completely up to k = 4096 (four 16-byte pieces per lane)
+
+// LDS: [m][K] fp32 rows | [m][K] int8 | (pad) [m][2] stats | (pad) [K] fp32 squared deviations | the speculated sum's scratch
+__host__ __device__ constexpr size_t lnq_wide_lds(int m, int K) { return lnq_dev_offset(m, K) + (size_t)K * 4 + (size_t)kSpecScratchFloats(kWideWaves) * 4; }
+
+__global__ __launch_bounds__(64 * kWideWaves) void lnq_w8a8_wide_kernel(const LnqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NT = 64 * kWideWaves, RW = kWideRW, PL = kWidePL, PF = 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K = a.K, m = a.m;
+    float *rows = reinterpret_cast<float *>(smem);
+    int8_t *q8 = reinterpret_cast<int8_t *>(smem + (size_t)m * K * 4);
+    float *stats = reinterpret_cast<float *>(smem + (size_t)m * K * 5 + 16 - ((size_t)m * K * 5) % 16);
+    float *dev = reinterpret_cast<float *>(smem + lnq_dev_offset(m, K));
+    float *sp = dev + K;
+    const int row0 = (blockIdx.x * kWideWaves + wave) * a.rpw;
+    const int pieces = K >> 4;
+    // requested in this order (loads return in order): the activation rows, the affine parameters, the first rows of the wave's run
+    const int n4 = (m * K) >> 2;
+    const float4_t xfirst = tid < n4 ? reinterpret_cast<const float4_t *>(a.x)[tid] : float4_t{0.f, 0.f, 0.f, 0.f};
+    const bool affine_prefetched = m * K <= NT * PF;
+    float pw[PF], pb[PF];
+    if (affine_prefetched) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int e = tid + NT * i;
+            const int k = e < m * K ? e % K : 0;
+            pw[i] = a.ln_w[k];
+            pb[i] = a.ln_b[k];
+        }
+    }
+    auto linear_of = [&](int row) {
+        int li = 0;
+#pragma unroll
+        for (int s = 1; s < TCE_MAX_GROUP; ++s)
+            if (s < a.count && row >= a.lin[s].row_begin) li = s;
+        return li;
+    };
+    auto additive = [&](const LnqLinear &L, int n) {  // the additive term of an output column (kernels/ref/matmul_ref_int8.cc:29-31)
+        float u = 0.f;
+        if (L.bias_kind == TCE_BIAS_INT8) u = __fmul_rn((float)static_cast<const int8_t *>(L.bias)[n], L.beta);
+        else if (L.bias_kind == TCE_BIAS_FP32) u = static_cast<const float *>(L.bias)[n];
+        return u;
+    };
+    int4_t wfirst[RW][PL];
+    float ufirst[RW];
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) {
+        const int rw = rr < a.rpw ? row0 + rr : row0;
+        const int row = rw < a.total_rows ? rw : a.total_rows - 1;
+        const LnqLinear &L = a.lin[linear_of(row)];
+        const int4_t *brow = reinterpret_cast<const int4_t *>(L.B + (size_t)(row - L.row_begin) * K);
+#pragma unroll
+        for (int i = 0; i < PL; ++i) wfirst[rr][i] = lane + 64 * i < pieces ? brow[lane + 64 * i] : int4_t{0, 0, 0, 0};
+        ufirst[rr] = additive(L, row - L.row_begin);
+    }
+    // ---- 1. the rows into LDS ----
+    if (tid < n4) reinterpret_cast<float4_t *>(rows)[tid] = xfirst;
+    for (int p = tid + NT; p < n4; p += NT) reinterpret_cast<float4_t *>(rows)[p] = reinterpret_cast<const float4_t *>(a.x)[p];
+    __syncthreads();
+    // ---- 2. the two sequential sums of every row (LayerNormQ.cc:27-37), all waves on one row at a time ----
+    for (int r = 0; r < m; ++r) {
+        const float *xr = rows + (size_t)r * K;
+        float mean = sequential_sum_speculated<kWideWaves>(xr, K, sp, wave, lane);
+        mean /= (float)K;
+        for (int k = tid; k < K; k += NT) {
+            const float d = xr[k] - mean;
+            dev[k] = __fmul_rn(d, d);
+        }
+        __syncthreads();
+        const float sq = sequential_sum_speculated<kWideWaves>(dev, K, sp, wave, lane);
+        if (tid == 0) {
+            stats[2 * r] = mean;
+            stats[2 * r + 1] = sqrtf(sq / (float)K + 0.00001f);
+        }
+    }
+    __syncthreads();
+    // ---- 3. the int8 rows (LayerNormQ.cc:42-48), into LDS and -- by workgroup 0 -- to memory if asked for ----
+    auto quantize = [&](int e, float lw, float lb) {
+        const int r = e / K;
+        const float t = __fdiv_rn(rows[e] - stats[2 * r], stats[2 * r + 1]);
+        const float f = __fadd_rn(__fmul_rn(t, lw), lb);
+        const int8_t q = (int8_t)(int)roundf(f);
+        q8[e] = q;
+        if (a.ln_out && blockIdx.x == 0) a.ln_out[e] = q;
+    };
+    if (affine_prefetched) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int e = tid + NT * i;
+            if (e < m * K) quantize(e, pw[i], pb[i]);
+        }
+    } else {
+        for (int e = tid; e < m * K; e += NT) quantize(e, a.ln_w[e % K], a.ln_b[e % K]);
+    }
+    __syncthreads();
+    // ---- 4. this wave's run of output rows, lanes across K in 16-byte pieces ----
+    auto finish_row = [&](const LnqLinear &L, int n, const int (&acc)[kMaxM], float u) {
+#pragma unroll
+        for (int mm = 0; mm < kMaxM; ++mm) {
+            if (mm < m) {
+                int v = acc[mm];
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);  // int32: exact in any order
+                if (lane == 0) {
+                    float f = __fmul_rn((float)v, L.alpha);
+                    if (L.out_kind == TCE_OUT_INT8) {
+                        if (L.bias_kind == TCE_BIAS_INT8) f = __fadd_rn(f, u);
+                        float r = roundf(f);
+                        r = fmaxf(r, (float)L.q_min);
+                        r = fminf(r, (float)L.q_max);
+                        static_cast<int8_t *>(L.C)[(size_t)mm * L.N + n] = (int8_t)(int)r;
+                    } else {
+                        if (L.bias_kind == TCE_BIAS_FP32) f = __fadd_rn(f, u);
+                        static_cast<float *>(L.C)[(size_t)mm * L.N + n] = f;
+                    }
+                }
+            }
+        }
+    };
+    auto dot_piece = [&](const int4_t &w, int p, int (&acc)[kMaxM]) {
+#pragma unroll
+        for (int mm = 0; mm < kMaxM; ++mm) {
+            if (mm < m) {
+                const int4_t xq = *reinterpret_cast<const int4_t *>(q8 + (size_t)mm * K + p * 16);
+                acc[mm] = __builtin_amdgcn_sdot4(w.x, xq.x, acc[mm], false);
+                acc[mm] = __builtin_amdgcn_sdot4(w.y, xq.y, acc[mm], false);
+                acc[mm] = __builtin_amdgcn_sdot4(w.z, xq.z, acc[mm], false);
+                acc[mm] = __builtin_amdgcn_sdot4(w.w, xq.w, acc[mm], false);
+            }
+        }
+    };
+    // the rows beyond the two requested ahead are requested NOW, two rows x four pieces per lane at a time, before the resident rows' arithmetic
+    const int last = row0 + a.rpw < a.total_rows ? row0 + a.rpw : a.total_rows;  // one past the wave's last row
+    auto request = [&](int row, int p0, int4_t (&w)[PL]) {
+        const int rc = row < last ? row : last - 1;
+        const LnqLinear &L = a.lin[linear_of(rc)];
+        const int4_t *brow = reinterpret_cast<const int4_t *>(L.B + (size_t)(rc - L.row_begin) * K);
+#pragma unroll
+        for (int i = 0; i < PL; ++i) w[i] = (row < last && p0 + 64 * i < pieces) ? brow[p0 + 64 * i] : int4_t{0, 0, 0, 0};
+    };
+    int4_t wa[PL], wb[PL];
+    if (row0 + RW < last) {
+        request(row0 + RW, lane, wa);
+        request(row0 + RW + 1, lane, wb);
+    }
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) {
+        const int row = row0 + rr;  // wave-uniform
+        if (row >= last) break;
+        const LnqLinear &L = a.lin[linear_of(row)];
+        const int n = row - L.row_begin;
+        const int4_t *brow = reinterpret_cast<const int4_t *>(L.B + (size_t)n * K);
+        int acc[kMaxM];
+#pragma unroll
+        for (int mm = 0; mm < kMaxM; ++mm) acc[mm] = 0;
+#pragma unroll
+        for (int i = 0; i < PL; ++i)
+            if (lane + 64 * i < pieces) dot_piece(wfirst[rr][i], lane + 64 * i, acc);
+        for (int p = lane + 64 * PL; p < pieces; p += 64) dot_piece(brow[p], p, acc);
+        finish_row(L, n, acc, ufirst[rr]);
+    }
+    for (int row = row0 + RW; row < last; row += 2) {
+        int acca[kMaxM], accb[kMaxM];
+#pragma unroll
+        for (int mm = 0; mm < kMaxM; ++mm) acca[mm] = accb[mm] = 0;
+        for (int p0 = lane; p0 < pieces; p0 += 64 * PL) {
+            int4_t ca[PL], cb[PL];
+#pragma unroll
+            for (int i = 0; i < PL; ++i) {
+                ca[i] = wa[i];
+                cb[i] = wb[i];
+            }
+            // the next batch: the rest of these two rows, else the first pieces of the next two
+            if (p0 + 64 * PL < pieces) {
+                request(row, p0 + 64 * PL, wa);
+                request(row + 1, p0 + 64 * PL, wb);
+            } else if (row + 2 < last) {
+                request(row + 2, lane, wa);
+                request(row + 3, lane, wb);
+            }
+#pragma unroll
+            for (int i = 0; i < PL; ++i) {
+                if (p0 + 64 * i < pieces) {
+                    dot_piece(ca[i], p0 + 64 * i, acca);
+                    if (row + 1 < last) dot_piece(cb[i], p0 + 64 * i, accb);
+                }
+            }
+        }
+        {
+            const LnqLinear &L = a.lin[linear_of(row)];
+            finish_row(L, row - L.row_begin, acca, additive(L, row - L.row_begin));
+        }
+        if (row + 1 < last) {
+            const LnqLinear &L = a.lin[linear_of(row + 1)];
+            finish_row(L, row + 1 - L.row_begin, accb, additive(L, row + 1 - L.row_begin));
+        }
+    }
+}
+
+int launch_wide(LnqArgs &a, int rows, hipStream_t stream, hipError_t *hip_err) {
+    const size_t lds = lnq_wide_lds(a.m, a.K);
+    if (lds > 160 * 1024) return TCE_ERR_UNSUPPORTED_SHAPE;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    // one workgroup per CU (a second one would only share the CU's adders and LDS with the first); fewer when there are fewer than 2 rows per wave
+    int grid = (rows + 2 * kWideWaves - 1) / (2 * kWideWaves);
+    if (grid > cus) grid = cus;
+    a.rpw = (rows + grid * kWideWaves - 1) / (grid * kWideWaves);
+    grid = (rows + a.rpw * kWideWaves - 1) / (a.rpw * kWideWaves);
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lnq_w8a8_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            if (hip_err) *hip_err = e;
+            return TCE_ERR_HIP;
+        }
+    }
+    hipLaunchKernelGGL(lnq_w8a8_wide_kernel, dim3(grid), dim3(64 * kWideWaves), lds, stream, a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (hip_err) *hip_err = e;
+        return TCE_ERR_HIP;
+    }
+    return TCE_OK;
 }
 
 }  // namespace
@@ -214,9 +503,13 @@ int launch_lnq_w8a8_group(const float *x, const float *ln_w, const float *ln_b, 
     }
     for (int i = count; i < TCE_MAX_GROUP; ++i) a.lin[i] = a.lin[0];
     a.total_rows = rows;
+    const bool wide = k >= 1024 && g_lnq_form != 1;
+    if (wide) return launch_wide(a, rows, stream, hip_err);
     const size_t lds = lnq_dev_offset(m, k) + (size_t)(m < kWaves ? m : kWaves) * k * 4;  // a scratch row per wave that walks a row
     if (lds > 160 * 1024) return TCE_ERR_UNSUPPORTED_SHAPE;
-    auto kfn = lnq_w8a8_kernel;
+    auto kfn = lnq_w8a8_kernel<2, 2, 4>;
+    const int grid = (rows + 2 * kWaves - 1) / (2 * kWaves);
+    a.rpw = 2;
     if (lds > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
@@ -224,8 +517,7 @@ int launch_lnq_w8a8_group(const float *x, const float *ln_w, const float *ln_b, 
             return TCE_ERR_HIP;
         }
     }
-    const int per_wg = kWaves * kRowsPerWave;
-    hipLaunchKernelGGL(kfn, dim3((rows + per_wg - 1) / per_wg), dim3(64 * kWaves), lds, stream, a);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * kWaves), lds, stream, a);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         if (hip_err) *hip_err = e;
