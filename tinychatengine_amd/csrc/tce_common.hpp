@@ -292,6 +292,74 @@ __device__ __forceinline__ float sequential_sum(const float *vals, int n, int la
         return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s)));
     }
 }
+// A workgroup barrier that publishes LDS writes and leaves global loads IN FLIGHT: __syncthreads() carries a fence the compiler implements as vmcnt(0) -- every
+// barrier of a kernel that requested its weights ahead would wait for the last of them.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// The form for MANY waves of a CU walking sums at once (sequential_sum_speculated): the four ds_read_b128 per 16 values of the form above occupy the LDS for
+// ~32 cycles per wave -- with 16 waves the LDS, not the adders, sets the pace.  Here a lane of every 16-lane row reads ONE value (a single ds_read_b32 brings 16
+// values, the same 16 in each row) and each addition takes its operand through the DPP row broadcast (row_newbcast:j = lane j of the row to all of its lanes): one
+// VALU instruction per addition and one LDS instruction per 16, so 4 waves per SIMD advance at one addition per 16 cycles each: n cycles per sum and CU.
+// Same contract as sequential_sum_bcast (the tail of n % 32 values is added from plain broadcast reads); reads up to 256 bytes past the last 32 values.
+__device__ __forceinline__ float sequential_sum_rowbcast(const float *vals, int n, float init, int lane) {
+    float acc = init;
+    int groups = n >> 5;
+    if (groups > 0) {
+        unsigned p = (unsigned)(size_t)vals + ((unsigned)(lane & 15) << 2);
+        float va, vb;
+        asm volatile(
+            "ds_read_b32 %3, %1\n\tds_read_b32 %4, %1 offset:64\n"
+            "1:\n\t"
+            "s_waitcnt lgkmcnt(1)\n\t"
+            "v_add_f32_dpp %0, %3, %0 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %3, %0 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %3, %0 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %3, %0 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %3, %0 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %3, %0 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %3, %0 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %3, %0 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %3, %0 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %3, %0 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %3, %0 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %3, %0 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %3, %0 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %3, %0 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %3, %0 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %3, %0 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+            "ds_read_b32 %3, %1 offset:128\n\t"
+            "s_waitcnt lgkmcnt(1)\n\t"
+            "v_add_f32_dpp %0, %4, %0 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %4, %0 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %4, %0 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %4, %0 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %4, %0 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %4, %0 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %4, %0 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %4, %0 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %4, %0 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %4, %0 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %4, %0 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %4, %0 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %4, %0 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %4, %0 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %4, %0 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %4, %0 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+            "ds_read_b32 %4, %1 offset:192\n\t"
+            "v_add_u32 %1, 0x80, %1\n\t"
+            "s_sub_u32 %2, %2, 1\n\t"
+            "s_cmp_lg_u32 %2, 0\n\t"
+            "s_cbranch_scc1 1b\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "+v"(acc), "+v"(p), "+s"(groups), "=&v"(va), "=&v"(vb)
+            :
+            : "memory", "scc");
+    }
+    const int done = n & ~31;
+    for (int j = done; j < n; ++j) acc = acc + vals[j];  // (every lane reads the same address; the additions stay in order)
+    return acc;
+}
+
 // The same sum by ALL NW waves of a workgroup, for ONE long row (LayerNormQ at OPT-1.3B / 6.7B widths: 2 x 4096 dependent additions = 22 us for a single wave).
 // An fp32 sum rounded after every addition cannot be re-associated -- but it can be SPECULATED: the row is cut into NW segments; wave w takes segment w and starts
 // it from 64 different running values at once, one per lane: the fp32 neighbours (-32 .. +31 units in the last place) of the exactly rounded sum of everything
@@ -301,22 +369,38 @@ __device__ __forceinline__ float sequential_sum(const float *vals, int n, int la
 // (the running value came closer to zero than the rounding errors accumulated so far, signed zeros, inf / NaN) the segment is re-added from the true value.
 // Every addition that contributes to the result is the reference's, in the reference's order, on the reference's operands: bit-identical by construction, the
 // speculation only decides how much of it was done ahead.  Cost: n / NW dependent additions per wave (with 16 waves the CU's four SIMDs are the limit: n cycles)
-// + one segment per miss.  All threads of the workgroup must call it (three barriers); `sp` is 16 + 2 * NW * 64 floats of LDS scratch.
+// + one segment per miss (zero-mean noise, 4096 values: ~11 % of the boundaries of the plain sum, ~0.4 % of the sum of squares).  All threads of the workgroup
+// must call it (three barriers, which leave global loads in flight); `sp` is kSpecScratchFloats(NW) floats of LDS scratch.
+// the segment of wave `wave`: [b, b + len), a multiple of 32 long (the chain loops' unit, and 128-byte alignment) except the last one
 template <int NW>
-__device__ __forceinline__ float sequential_sum_speculated(const float *vals, int n, float *sp, int wave, int lane) {
-    double *segsum = reinterpret_cast<double *>(sp);  // [NW] (NW <= 16: 32 floats)
+__device__ __forceinline__ void speculated_segment(int n, int wave, int &b, int &len) {
+    const int L = ((n + NW * 32 - 1) / (NW * 32)) * 32;
+    b = wave * L;
+    len = n - b < 0 ? 0 : (n - b < L ? n - b : L);
+}
+
+// `ds_mine`: the double-precision sum of the wave's own segment, valid in every lane (the caller forms it -- while it computes the values, if they are computed);
+// the chain of a wave reads only its own segment (and up to 256 bytes behind it, unused), so values a wave wrote itself need no barrier before the call.
+struct SpecNoOp {
+    __device__ __forceinline__ void operator()() const {}
+};
+// `mid` is called by every wave between its chain and the barrier behind it (a place to issue memory requests that should not all be in flight at once)
+template <int NW, bool ROWB = true, class Mid = SpecNoOp>
+__device__ __forceinline__ float sequential_sum_speculated(const float *vals, int n, float *sp, int wave, int lane, double ds_mine, unsigned long long *stamps = nullptr,
+                                                            Mid mid = Mid()) {
+    static_assert(NW <= 16, "segment sums are exchanged through 16 doubles");
+    double *segsum = reinterpret_cast<double *>(sp);  // [16]
     float *cand = sp + 32, *fin = sp + 32 + NW * 64, *res = sp + 32 + 2 * NW * 64;
-    const int L = ((n + NW * 32 - 1) / (NW * 32)) * 32;  // segment length: a multiple of 32 (sequential_sum_bcast's unit, and 128-byte alignment)
-    const int b = wave * L;
-    const int len = n - b < 0 ? 0 : (n - b < L ? n - b : L);
-    double ds = 0.0;
-    for (int k = b + lane; k < b + len; k += 64) ds += (double)vals[k];
+    int b, len;
+    speculated_segment<NW>(n, wave, b, len);
+    const int L = ((n + NW * 32 - 1) / (NW * 32)) * 32;
+    if (lane == 0) segsum[wave] = ds_mine;
+    lds_barrier();
+    // the exactly rounded sum of everything before the segment (the order of THIS sum is free: it only centres the candidates)
+    double before = lane < wave ? segsum[lane & 15] : 0.0;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) ds += __shfl_xor(ds, off, 64);
-    if (lane == 0) segsum[wave] = ds;
-    __syncthreads();
-    double before = 0.0;
-    for (int u = 0; u < wave; ++u) before += segsum[u];
+    for (int off = 8; off >= 1; off >>= 1) before += __shfl_xor(before, off, 64);
+    before = __shfl(before, 0, 64);
     float c = 0.f;  // wave 0 starts from the sum's own start
     if (wave > 0) {
         // the fp32 neighbours of the estimate: bit patterns in monotone order (an involution: negative values run backwards)
@@ -326,25 +410,61 @@ __device__ __forceinline__ float sequential_sum_speculated(const float *vals, in
         i ^= (i >> 31) & 0x7fffffff;
         c = __builtin_bit_cast(float, i);
     }
-    const float f = len > 0 ? sequential_sum_bcast(vals + b, len, c) : c;
+    const float f = len <= 0 ? c : (ROWB ? sequential_sum_rowbcast(vals + b, len, c, lane) : sequential_sum_bcast(vals + b, len, c));
+    mid();
     cand[wave * 64 + lane] = c;
     fin[wave * 64 + lane] = f;
-    __syncthreads();
+    if (stamps && wave == 0 && lane == 0) stamps[0] = wall_clock64();  // (timing experiments: wave 0's chain done; all chains done; the walk done)
+    lds_barrier();
+    if (stamps && wave == 0 && lane == 0) stamps[1] = wall_clock64();
     if (wave == 0) {
+        // four segments' candidates and end values into registers at once (one LDS round trip), then a short dependent walk: compare, first hit, read that lane
         float s = f;  // (segment 0: every lane started from 0)
-        for (int w = 1; w < NW; ++w) {
-            const int bw = w * L;
-            if (bw >= n) break;
-            const int lw = n - bw < L ? n - bw : L;
-            const float cw = cand[w * 64 + lane], fw = fin[w * 64 + lane];
-            const unsigned long long hit = __ballot(__builtin_bit_cast(int, cw) == __builtin_bit_cast(int, s));
-            if (hit) s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fw), __builtin_ctzll(hit)));
-            else s = sequential_sum_bcast(vals + bw, lw, s);
+#pragma unroll 1
+        for (int base = 1; base < NW; base += 4) {
+            float cw[4], fw[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int w = base + j < NW ? base + j : NW - 1;
+                cw[j] = cand[w * 64 + lane];
+                fw[j] = fin[w * 64 + lane];
+            }
+            int start = base;
+            for (;;) {  // (one pass unless a segment misses: then that segment is re-added from the true value and the walk resumes behind it)
+                int miss = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {  // branch-free: compare -> ballot -> first set bit -> read that lane -> scalar selects (a dependent chain of ~6 instructions per segment)
+                    const int w = base + j;
+                    const unsigned long long hit = __ballot(__builtin_bit_cast(int, cw[j]) == __builtin_bit_cast(int, s));
+                    const int src = __builtin_ctzll(hit | (1ull << 63));
+                    const float fs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fw[j]), src));
+                    const bool active = (w < NW) & (w >= start) & (miss == 0) & (w * L < n);
+                    s = (active & (hit != 0)) ? fs : s;
+                    miss = (active & (hit == 0)) ? w : miss;
+                }
+                if (miss == 0) break;
+                const int bw = miss * L, lw = n - bw < L ? n - bw : L;
+                s = ROWB ? sequential_sum_rowbcast(vals + bw, lw, s, lane) : sequential_sum_bcast(vals + bw, lw, s);
+                start = miss + 1;
+            }
         }
         if (lane == 0) res[0] = s;
+        if (stamps && lane == 0) stamps[2] = wall_clock64();
     }
-    __syncthreads();
+    lds_barrier();
     return res[0];
+}
+
+// ... with the segment sums formed here (values that already lie in LDS, visible to all waves)
+template <int NW, bool ROWB = true, class Mid = SpecNoOp>
+__device__ __forceinline__ float sequential_sum_speculated(const float *vals, int n, float *sp, int wave, int lane, unsigned long long *stamps = nullptr, Mid mid = Mid()) {
+    int b, len;
+    speculated_segment<NW>(n, wave, b, len);
+    double ds = 0.0;
+    for (int k = b + lane; k < b + len; k += 64) ds += (double)vals[k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ds += __shfl_xor(ds, off, 64);
+    return sequential_sum_speculated<NW, ROWB, Mid>(vals, n, sp, wave, lane, ds, stamps, mid);
 }
 constexpr int kSpecScratchFloats(int nw) { return 32 + 2 * nw * 64 + 16; }
 

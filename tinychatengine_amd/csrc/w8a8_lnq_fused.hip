@@ -14,8 +14,8 @@
 // for one wave -- and a launch's int8 weights are 50-67 MB): ONE workgroup of 16 waves per CU, each normalises once and owns a contiguous run of output rows per
 // wave; the two sums are walked by all 16 waves at once (sequential_sum_speculated, tce_common.hpp: every wave adds its sixteenth of the row from 64 candidate
 // running values, wave 0 then picks the lanes that started from the true ones -- the additions that count are the reference's, in its order); a wave requests its
-// first two rows completely right after the activation row, so weights stream from memory WHILE the sums are walked, and streams the rest of its run afterwards
-// with eight 16-byte pieces per lane in flight.  Measured per launch at OPT-6.7B (q/k/v 3 x 4096 x 4096, fc1 16384 x 4096): 87 / 94 us for the 8-rows-per-workgroup
+// first FOUR rows completely right after the activation row (16 x 16 bytes per lane: 67 MB across the chip -- all of OPT-6.7B's fc1), so the weights stream from
+// memory WHILE the sums are walked, and streams what is left of its run afterwards with eight 16-byte pieces per lane in flight.  Measured per launch at OPT-6.7B (q/k/v 3 x 4096 x 4096, fc1 16384 x 4096): 87 / 94 us for the 8-rows-per-workgroup
 // form (1536-2048 workgroups: the sums are walked in several rounds), 49 / 53 us with one round of 4-wave workgroups (three per CU: their three chains share a SIMD).
 //
 // BIT-EXACT against LayerNormQ::forward followed by int8_ref_matmul (kernels/ref/matmul_ref_int8.cc:11-35):
@@ -31,6 +31,8 @@ namespace tce {
 
 static int g_lnq_form = 0;  // debug: 1 = the workgroup-per-8-rows form at every k (A/B of the weights-resident form)
 void set_lnq_form(int f) { g_lnq_form = f; }
+static unsigned long long *g_lnq_stamps = nullptr;
+void set_lnq_stamps(void *p) { g_lnq_stamps = static_cast<unsigned long long *>(p); }
 
 namespace {
 
@@ -49,6 +51,8 @@ struct LnqArgs {
     int8_t *ln_out;  // optional: the normalised int8 rows [m][K]
     int m, K, count, total_rows;
     int rpw;  // output rows per wave (a contiguous run)
+    int dbg;  // timing experiments (debug modes 83, 84): 2 no sums (mean 0, std 1: WRONG results), 3 no output rows
+    unsigned long long *stamps;  // debug mode 85: workgroup 0's phase times (100 MHz clock) into the debug buffer
     LnqLinear lin[TCE_MAX_GROUP];
 };
 
@@ -57,6 +61,24 @@ constexpr int kMaxM = 8;
 
 // LDS: [m][K] fp32 rows | [m][K] int8 | (pad) [m][2] stats | (pad) [min(m, kWaves)][K] fp32 squared deviations
 __host__ __device__ constexpr size_t lnq_dev_offset(int m, int K) { return (((size_t)m * K * 5 + 16 + (size_t)m * 8 + 16) + 15) & ~(size_t)15; }
+
+// The bias of output column n is requested early and converted late (kernels/ref/matmul_ref_int8.cc:29-31 forms the additive term from it): ONE unconditional
+// load of the aligned 32-bit word that holds it (an int8 value -> the word around it; no bias -> a word of the weights, ignored).  With a branch per bias kind the
+// compiler put a wait for ALL loads issued so far between two rows' weight requests (measured: the four rows of a wave arrived one after the other, 10 us).
+__device__ __forceinline__ int bias_raw(const LnqLinear &L, int n) {
+    const char *base = L.bias_kind == TCE_BIAS_NONE ? reinterpret_cast<const char *>(L.B) : static_cast<const char *>(L.bias);
+    const size_t off = L.bias_kind == TCE_BIAS_FP32 ? (size_t)n * 4 : (L.bias_kind == TCE_BIAS_INT8 ? (size_t)n : 0);
+    const char *p = base + off;
+    p -= reinterpret_cast<uintptr_t>(p) & 3;  // (pointer arithmetic, not an integer round trip: the load stays a global one)
+    return *reinterpret_cast<const int *>(p);
+}
+__device__ __forceinline__ float bias_term(const LnqLinear &L, int n, int raw) {
+    if (L.bias_kind == TCE_BIAS_INT8) {
+        const int sh = (int)((reinterpret_cast<uintptr_t>(static_cast<const char *>(L.bias) + n) & 3) * 8);
+        return __fmul_rn((float)(int)(int8_t)(raw >> sh), L.beta);
+    }
+    return L.bias_kind == TCE_BIAS_FP32 ? __builtin_bit_cast(float, raw) : 0.f;
+}
 
 // RW rows of a wave's run are requested ahead, PL 16-byte pieces per lane of each; PF affine parameter pairs per thread are requested ahead (else read in step 3)
 template <int RW, int PL, int PF>
@@ -79,7 +101,7 @@ __global__ __launch_bounds__(64 * kWaves) void lnq_w8a8_kernel(const LnqArgs a) 
     // ... then the first weight pieces of the wave's first RW rows: they do not depend on the normalisation and land while the row sums are walked
     // (K = 768: one piece per lane and row is the whole row; <4, 4>: 4 rows of up to 4096 bytes completely)
     int4_t wfirst[RW][PL];
-    float ufirst[RW];
+    int ufirst[RW];
 #pragma unroll
     for (int rr = 0; rr < RW; ++rr) {
         const int rw = rr < a.rpw ? row0 + rr : row0;
@@ -91,12 +113,9 @@ __global__ __launch_bounds__(64 * kWaves) void lnq_w8a8_kernel(const LnqArgs a) 
         const int4_t *brow = reinterpret_cast<const int4_t *>(a.lin[li].B + (size_t)(row - a.lin[li].row_begin) * K);
 #pragma unroll
         for (int i = 0; i < PL; ++i) wfirst[rr][i] = lane + 64 * i < pieces ? brow[lane + 64 * i] : int4_t{0, 0, 0, 0};
-        // the additive term of this output column, once (kernels/ref/matmul_ref_int8.cc:29-31)
+        // the bias of this output column is requested too -- RAW: converting it here would put a wait for ALL loads issued so far between two rows' requests
         const LnqLinear &L = a.lin[li];
-        const int n = row - L.row_begin;
-        ufirst[rr] = 0.f;
-        if (L.bias_kind == TCE_BIAS_INT8) ufirst[rr] = __fmul_rn((float)static_cast<const int8_t *>(L.bias)[n], L.beta);
-        else if (L.bias_kind == TCE_BIAS_FP32) ufirst[rr] = static_cast<const float *>(L.bias)[n];
+        ufirst[rr] = bias_raw(L, row - L.row_begin);
     }
     // ... and the affine parameters of the elements this thread will quantize in step 3 (m * K <= 256 PF)
     const bool affine_prefetched = m * K <= 64 * kWaves * PF;
@@ -115,7 +134,7 @@ __global__ __launch_bounds__(64 * kWaves) void lnq_w8a8_kernel(const LnqArgs a) 
     for (int i = 0; i < XB; ++i)
         if (tid + 64 * kWaves * i < n4) reinterpret_cast<float4_t *>(rows)[tid + 64 * kWaves * i] = xfirst[i];
     for (int p = tid + 64 * kWaves * XB; p < n4; p += 64 * kWaves) reinterpret_cast<float4_t *>(rows)[p] = reinterpret_cast<const float4_t *>(a.x)[p];
-    __syncthreads();
+    lds_barrier();
     // ---- 2. the two sequential sums of every row (LayerNormQ.cc:27-37), in the reference's order: wave w takes rows w, w + 4
     //         (sequential_sum_bcast, tce_common.hpp: one dependent add per element) ----
     float *dev = reinterpret_cast<float *>(smem + lnq_dev_offset(m, K)) + (size_t)wave * K;  // this wave's squared deviations
@@ -133,7 +152,7 @@ __global__ __launch_bounds__(64 * kWaves) void lnq_w8a8_kernel(const LnqArgs a) 
             stats[2 * r + 1] = sqrtf(sq / (float)K + 0.00001f);
         }
     }
-    __syncthreads();
+    lds_barrier();
     // ---- 3. the int8 rows (LayerNormQ.cc:42-48), into LDS and -- by workgroup 0 -- to memory if asked for ----
     auto quantize = [&](int e, float lw, float lb) {
         const int r = e / K;
@@ -152,7 +171,7 @@ __global__ __launch_bounds__(64 * kWaves) void lnq_w8a8_kernel(const LnqArgs a) 
     } else {
         for (int e = tid; e < m * K; e += 64 * kWaves) quantize(e, a.ln_w[e % K], a.ln_b[e % K]);
     }
-    __syncthreads();
+    lds_barrier();
     // ---- 4. this wave's output rows, lanes across K in 16-byte pieces: the first RW rows start from the registers requested at the top ----
     auto finish_row = [&](const LnqLinear &L, int n, const int (&acc)[kMaxM], float u) {
 #pragma unroll
@@ -210,7 +229,7 @@ __global__ __launch_bounds__(64 * kWaves) void lnq_w8a8_kernel(const LnqArgs a) 
         for (int i = 0; i < PL; ++i)
             if (lane + 64 * i < pieces) dot_piece(wfirst[rr][i], lane + 64 * i, acc);
         for (int p = lane + 64 * PL; p < pieces; p += 64) dot_piece(brow[p], p, acc);
-        finish_row(L, n, acc, ufirst[rr]);
+        finish_row(L, n, acc, bias_term(L, n, ufirst[rr]));
     }
     // rows of the run beyond the RW requested ahead (a launch held to the chip's capacity): streamed now, four pieces per lane in flight
     for (int rr = RW; rr < a.rpw; ++rr) {
@@ -219,9 +238,7 @@ __global__ __launch_bounds__(64 * kWaves) void lnq_w8a8_kernel(const LnqArgs a) 
         const LnqLinear &L = a.lin[linear_of(row)];
         const int n = row - L.row_begin;
         const int4_t *brow = reinterpret_cast<const int4_t *>(L.B + (size_t)n * K);
-        float u = 0.f;
-        if (L.bias_kind == TCE_BIAS_INT8) u = __fmul_rn((float)static_cast<const int8_t *>(L.bias)[n], L.beta);
-        else if (L.bias_kind == TCE_BIAS_FP32) u = static_cast<const float *>(L.bias)[n];
+        const int uraw = bias_raw(L, n);
         int acc[kMaxM];
 #pragma unroll
         for (int mm = 0; mm < kMaxM; ++mm) acc[mm] = 0;
@@ -233,14 +250,14 @@ __global__ __launch_bounds__(64 * kWaves) void lnq_w8a8_kernel(const LnqArgs a) 
             for (int i = 0; i < 4; ++i)
                 if (p0 + 64 * i < pieces) dot_piece(w[i], p0 + 64 * i, acc);
         }
-        finish_row(L, n, acc, u);
+        finish_row(L, n, acc, bias_term(L, n, uraw));
     }
 }
 
 
 // ---- the wide form: see the header comment ----
 constexpr int kWideWaves = 16;
-constexpr int kWideRW = 2;  // rows of a wave's run requested ahead ...
+constexpr int kWideRW = 4;  // rows of a wave's run requested ahead ...
 constexpr int kWidePL = 4;  // ... completely up to k = 4096 (four 16-byte pieces per lane)
 
 // LDS: [m][K] fp32 rows | [m][K] int8 | (pad) [m][2] stats | (pad) [K] fp32 squared deviations | the speculated sum's scratch
@@ -259,9 +276,15 @@ __global__ __launch_bounds__(64 * kWideWaves) void lnq_w8a8_wide_kernel(const Ln
     float *sp = dev + K;
     const int row0 = (blockIdx.x * kWideWaves + wave) * a.rpw;
     const int pieces = K >> 4;
-    // requested in this order (loads return in order): the activation rows, the affine parameters, the first rows of the wave's run
+    unsigned long long *stamps = (a.stamps && blockIdx.x == 0) ? a.stamps : nullptr;
+    if (stamps && tid == 0) stamps[0] = wall_clock64();
+    // ---- 1. the activation rows into LDS, BEFORE anything else is requested: loads return in order, and with the weight requests in front of them (or merely
+    //         behind them, but with a wait the compiler cannot count across their conditions) the sums would start when the last weight has arrived -- measured:
+    //         10 us into the launch.  This way the weights' whole flight lies under the sums ----
     const int n4 = (m * K) >> 2;
-    const float4_t xfirst = tid < n4 ? reinterpret_cast<const float4_t *>(a.x)[tid] : float4_t{0.f, 0.f, 0.f, 0.f};
+    for (int p = tid; p < n4; p += NT) reinterpret_cast<float4_t *>(rows)[p] = reinterpret_cast<const float4_t *>(a.x)[p];
+    asm volatile("" ::: "memory");
+    // then the affine parameters and the first rows of the wave's run
     const bool affine_prefetched = m * K <= NT * PF;
     float pw[PF], pb[PF];
     if (affine_prefetched) {
@@ -280,45 +303,61 @@ __global__ __launch_bounds__(64 * kWideWaves) void lnq_w8a8_wide_kernel(const Ln
             if (s < a.count && row >= a.lin[s].row_begin) li = s;
         return li;
     };
-    auto additive = [&](const LnqLinear &L, int n) {  // the additive term of an output column (kernels/ref/matmul_ref_int8.cc:29-31)
-        float u = 0.f;
-        if (L.bias_kind == TCE_BIAS_INT8) u = __fmul_rn((float)static_cast<const int8_t *>(L.bias)[n], L.beta);
-        else if (L.bias_kind == TCE_BIAS_FP32) u = static_cast<const float *>(L.bias)[n];
-        return u;
-    };
+    // The wave's first four rows are requested in FOUR batches at four points of the sums, not all at once: a CU accepts only so many requests (~64 KB in
+    // flight), a wave whose request is not accepted yet stands still, and with 256 KB per CU requested up front the first sum started when most of it had
+    // arrived (measured: 8-10 us into the launch).  A batch is 64 KB per CU, 17 MB across the chip: about what streams in during one phase of the sums.
     int4_t wfirst[RW][PL];
-    float ufirst[RW];
-#pragma unroll
-    for (int rr = 0; rr < RW; ++rr) {
+    int ufirst[RW];  // (the bias RAW: see bias_raw)
+    auto request_row = [&](int rr) {  // rr: compile-time after unrolling
         const int rw = rr < a.rpw ? row0 + rr : row0;
         const int row = rw < a.total_rows ? rw : a.total_rows - 1;
         const LnqLinear &L = a.lin[linear_of(row)];
         const int4_t *brow = reinterpret_cast<const int4_t *>(L.B + (size_t)(row - L.row_begin) * K);
 #pragma unroll
-        for (int i = 0; i < PL; ++i) wfirst[rr][i] = lane + 64 * i < pieces ? brow[lane + 64 * i] : int4_t{0, 0, 0, 0};
-        ufirst[rr] = additive(L, row - L.row_begin);
+        for (int i = 0; i < PL; ++i) wfirst[rr][i] = brow[lane + 64 * i < pieces ? lane + 64 * i : pieces - 1];  // (unconditional: pieces past the row are not used)
+        ufirst[rr] = bias_raw(L, row - L.row_begin);
+    };
+    request_row(0);
+    if (a.dbg == 2) {
+        request_row(1);
+        request_row(2);
+        request_row(3);
     }
-    // ---- 1. the rows into LDS ----
-    if (tid < n4) reinterpret_cast<float4_t *>(rows)[tid] = xfirst;
-    for (int p = tid + NT; p < n4; p += NT) reinterpret_cast<float4_t *>(rows)[p] = reinterpret_cast<const float4_t *>(a.x)[p];
-    __syncthreads();
-    // ---- 2. the two sequential sums of every row (LayerNormQ.cc:27-37), all waves on one row at a time ----
+    lds_barrier();
+    if (stamps && tid == 0) stamps[1] = wall_clock64();
+    // ---- 2. the two sequential sums of every row (LayerNormQ.cc:27-37), all waves on one row at a time; a wave forms the squared deviations of ITS segment (and
+    //         their double-precision sum) itself, so nothing but the speculated sum's own barriers stands between the two sums ----
     for (int r = 0; r < m; ++r) {
         const float *xr = rows + (size_t)r * K;
-        float mean = sequential_sum_speculated<kWideWaves>(xr, K, sp, wave, lane);
-        mean /= (float)K;
-        for (int k = tid; k < K; k += NT) {
-            const float d = xr[k] - mean;
-            dev[k] = __fmul_rn(d, d);
+        float mean, sq;
+        if (a.dbg == 2) {
+            mean = 0.f;
+            sq = (float)K;
+        } else {
+            mean = sequential_sum_speculated<kWideWaves>(xr, K, sp, wave, lane, stamps ? stamps + 8 : nullptr, [&]() { if (r == 0) request_row(1); });
+            if (stamps && tid == 0) stamps[2] = wall_clock64();
+            mean /= (float)K;
+            int b, len;
+            speculated_segment<kWideWaves>(K, wave, b, len);
+            double ds = 0.0;
+            for (int k = b + lane; k < b + len; k += 64) {
+                const float d = xr[k] - mean;
+                const float d2 = __fmul_rn(d, d);
+                dev[k] = d2;
+                ds += (double)d2;
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) ds += __shfl_xor(ds, off, 64);
+            if (r == 0) request_row(2);
+            sq = sequential_sum_speculated<kWideWaves>(dev, K, sp, wave, lane, ds, stamps ? stamps + 12 : nullptr, [&]() { if (r == 0) request_row(3); });
+            if (stamps && tid == 0) stamps[3] = wall_clock64();
         }
-        __syncthreads();
-        const float sq = sequential_sum_speculated<kWideWaves>(dev, K, sp, wave, lane);
         if (tid == 0) {
             stats[2 * r] = mean;
             stats[2 * r + 1] = sqrtf(sq / (float)K + 0.00001f);
         }
     }
-    __syncthreads();
+    lds_barrier();
     // ---- 3. the int8 rows (LayerNormQ.cc:42-48), into LDS and -- by workgroup 0 -- to memory if asked for ----
     auto quantize = [&](int e, float lw, float lb) {
         const int r = e / K;
@@ -337,7 +376,8 @@ __global__ __launch_bounds__(64 * kWideWaves) void lnq_w8a8_wide_kernel(const Ln
     } else {
         for (int e = tid; e < m * K; e += NT) quantize(e, a.ln_w[e % K], a.ln_b[e % K]);
     }
-    __syncthreads();
+    lds_barrier();
+    if (stamps && tid == 0) stamps[4] = wall_clock64();
     // ---- 4. this wave's run of output rows, lanes across K in 16-byte pieces ----
     auto finish_row = [&](const LnqLinear &L, int n, const int (&acc)[kMaxM], float u) {
 #pragma unroll
@@ -374,7 +414,7 @@ __global__ __launch_bounds__(64 * kWideWaves) void lnq_w8a8_wide_kernel(const Ln
             }
         }
     };
-    // the rows beyond the two requested ahead are requested NOW, two rows x four pieces per lane at a time, before the resident rows' arithmetic
+    if (a.dbg == 3) return;
     const int last = row0 + a.rpw < a.total_rows ? row0 + a.rpw : a.total_rows;  // one past the wave's last row
     auto request = [&](int row, int p0, int4_t (&w)[PL]) {
         const int rc = row < last ? row : last - 1;
@@ -383,11 +423,6 @@ __global__ __launch_bounds__(64 * kWideWaves) void lnq_w8a8_wide_kernel(const Ln
 #pragma unroll
         for (int i = 0; i < PL; ++i) w[i] = (row < last && p0 + 64 * i < pieces) ? brow[p0 + 64 * i] : int4_t{0, 0, 0, 0};
     };
-    int4_t wa[PL], wb[PL];
-    if (row0 + RW < last) {
-        request(row0 + RW, lane, wa);
-        request(row0 + RW + 1, lane, wb);
-    }
 #pragma unroll
     for (int rr = 0; rr < RW; ++rr) {
         const int row = row0 + rr;  // wave-uniform
@@ -402,7 +437,14 @@ __global__ __launch_bounds__(64 * kWideWaves) void lnq_w8a8_wide_kernel(const Ln
         for (int i = 0; i < PL; ++i)
             if (lane + 64 * i < pieces) dot_piece(wfirst[rr][i], lane + 64 * i, acc);
         for (int p = lane + 64 * PL; p < pieces; p += 64) dot_piece(brow[p], p, acc);
-        finish_row(L, n, acc, ufirst[rr]);
+        finish_row(L, n, acc, bias_term(L, n, ufirst[rr]));
+    }
+    if (stamps && tid == 0) stamps[5] = wall_clock64();
+    // what is left of the run (a launch with more than 4 rows per wave: over 16384 rows) is streamed now, two rows x four pieces per lane in flight
+    int4_t wa[PL], wb[PL];
+    if (row0 + RW < last) {
+        request(row0 + RW, lane, wa);
+        request(row0 + RW + 1, lane, wb);
     }
     for (int row = row0 + RW; row < last; row += 2) {
         int acca[kMaxM], accb[kMaxM];
@@ -433,11 +475,11 @@ __global__ __launch_bounds__(64 * kWideWaves) void lnq_w8a8_wide_kernel(const Ln
         }
         {
             const LnqLinear &L = a.lin[linear_of(row)];
-            finish_row(L, row - L.row_begin, acca, additive(L, row - L.row_begin));
+            finish_row(L, row - L.row_begin, acca, bias_term(L, row - L.row_begin, bias_raw(L, row - L.row_begin)));
         }
         if (row + 1 < last) {
             const LnqLinear &L = a.lin[linear_of(row + 1)];
-            finish_row(L, row + 1 - L.row_begin, accb, additive(L, row + 1 - L.row_begin));
+            finish_row(L, row + 1 - L.row_begin, accb, bias_term(L, row + 1 - L.row_begin, bias_raw(L, row + 1 - L.row_begin)));
         }
     }
 }
@@ -504,6 +546,8 @@ int launch_lnq_w8a8_group(const float *x, const float *ln_w, const float *ln_b, 
     for (int i = count; i < TCE_MAX_GROUP; ++i) a.lin[i] = a.lin[0];
     a.total_rows = rows;
     const bool wide = k >= 1024 && g_lnq_form != 1;
+    a.dbg = g_lnq_form >= 2 && g_lnq_form <= 4 ? g_lnq_form - 1 : 0;
+    a.stamps = g_lnq_form == 5 ? g_lnq_stamps : nullptr;
     if (wide) return launch_wide(a, rows, stream, hip_err);
     const size_t lds = lnq_dev_offset(m, k) + (size_t)(m < kWaves ? m : kWaves) * k * 4;  // a scratch row per wave that walks a row
     if (lds > 160 * 1024) return TCE_ERR_UNSUPPORTED_SHAPE;
