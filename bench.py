@@ -376,14 +376,16 @@ def shapes_only_leg(dl, torch, dev, shape, eager: bool):
     return out
 
 
-def opt_layer_leg(torch, dev):
-    """BASELINE config 4 as a WORKLOAD, not four shapes: whole SmoothQuant OPT-125M decoder layers (embed 768, 12 heads, ffn 3072,
-    12 layers -- llm/include/model.h:70) on this library's launches (tinychatengine_amd/opt_layer.py; Int8OPTDecoderLayer.cc:24-59, Int8OPTAttention.cc:183-284):
-    one decode token over a 512-key cache (8 launches per layer) and a 512-row prefill (12 launches per layer), the 12 layers captured in one hipGraph."""
+def opt_layer_leg(torch, dev, size="125M"):
+    """BASELINE config 4 as a WORKLOAD, not four shapes: whole SmoothQuant OPT decoder stacks (llm/include/model.h: OPT-125M -- embed 768,
+    12 heads, ffn 3072, 12 layers; OPT-1.3B -- 2048, 32, 8192, 24; OPT-6.7B -- 4096, 32, 16384, 32) on this library's launches (tinychatengine_amd/opt_layer.py;
+    Int8OPTDecoderLayer.cc:24-59, Int8OPTAttention.cc:183-284): one decode token over a 512-key cache (5 launches per layer) and -- at 125M -- a 512-row
+    prefill (12 launches per layer), every layer with its own weights, the stack captured in one hipGraph.  At 1.3B / 6.7B a layer's int8 weights are 50 / 201 MB
+    (the stack far beyond the memory-side cache): `weight_stream_GBps` is the figure a roofline prices."""
     from tinychatengine_amd.opt_layer import Int8OPTDecoderLayer
-    E, H, F, NL = 768, 12, 3072, 12
-    out = {"model": "OPT-125M (embed 768, 12 heads, ffn 3072, 12 layers)", "weights": "synthetic int8"}
-    for name, m, pos in (("decode_512_keys", 1, 511), ("prefill_512_rows", 512, 0)):
+    E, H, F, NL = {"125M": (768, 12, 3072, 12), "1.3B": (2048, 32, 8192, 24), "6.7B": (4096, 32, 16384, 32)}[size]
+    out = {"model": f"OPT-{size} (embed {E}, {H} heads, ffn {F}, {NL} layers)", "weights": "synthetic int8"}
+    for name, m, pos in (("decode_512_keys", 1, 511), ("prefill_512_rows", 512, 0)) if size == "125M" else (("decode_512_keys", 1, 511),):
         tgz = pos + m
         layers = [Int8OPTDecoderLayer(E, H, F, 512, m, dev, seed=7 + i) for i in range(NL)]
         hid = torch.randn(m, E, device=dev)
@@ -413,9 +415,11 @@ def opt_layer_leg(torch, dev):
         torch.cuda.synchronize()
         us = a.elapsed_time(b) * 1e3 / reps
         ops = layers[0].int8_ops(m, tgz)
-        out[name] = {"rows": m, "keys": tgz, "us_per_layer": round(us / NL, 2), "launches_per_layer": layers[0].launches(m), "us_per_12_layers": round(us, 1),
+        wbytes = 4 * E * E + 2 * E * F + 2 * H * tgz * (E // H)  # a layer's int8 weights + the cache rows a decode token reads
+        out[name] = {"rows": m, "keys": tgz, "us_per_layer": round(us / NL, 2), "launches_per_layer": layers[0].launches(m), f"us_per_{NL}_layers": round(us, 1),
                      "int8_TOPs": round(ops * NL / us / 1e6, 2), "finite": bool(torch.isfinite(hid).all().item()),
-                     **({"tokens_per_s_12_layers": round(1e6 / us, 1)} if m == 1 else {"prefill_tokens_per_s_12_layers": round(m * 1e6 / us, 1)})}
+                     **({f"tokens_per_s_{NL}_layers": round(1e6 / us, 1), "weight_MB_per_layer": round(wbytes / 1e6, 2), "weight_stream_GBps": round(wbytes * NL / us / 1e3, 1),
+                         "frac_of_8TBps": round(wbytes * NL / us / 1e3 / 8000, 3)} if m == 1 else {f"prefill_tokens_per_s_{NL}_layers": round(m * 1e6 / us, 1)})}
         del g, layers
     torch.cuda.empty_cache()
     return out
@@ -1029,10 +1033,11 @@ def main():
             extras = other_configs_leg(torch, dev)
         except Exception as e:  # noqa: BLE001 -- never takes the headline number down with it
             extras = {"error": f"{type(e).__name__}: {e}"}
-        try:  # BASELINE config 4 as whole OPT-125M decoder layers (graph plans): us and launches per layer
-            extras["w8a8_opt125m_layer"] = opt_layer_leg(torch, dev)
-        except Exception as e:  # noqa: BLE001
-            extras["w8a8_opt125m_layer"] = {"error": f"{type(e).__name__}: {e}"}
+        for size, key in (("125M", "w8a8_opt125m_layer"), ("1.3B", "w8a8_opt1p3b_layer"), ("6.7B", "w8a8_opt6p7b_layer")):
+            try:  # BASELINE config 4 as whole OPT decoder stacks (graph plans): us and launches per layer, the rate the int8 weights stream at
+                extras[key] = opt_layer_leg(torch, dev, size)
+            except Exception as e:  # noqa: BLE001
+                extras[key] = {"error": f"{type(e).__name__}: {e}"}
         try:  # every launch shape of the token on its own: us, GB/s, fraction of 8 TB/s (same timing method as the roofline leg)
             extras["decode_launch_shapes"] = launch_shape_table(dl, torch)
         except Exception as e:  # noqa: BLE001

@@ -17,6 +17,10 @@ from tinychatengine_amd.opt_layer import Int8OPTDecoderLayer  # noqa: E402
 dev = torch.device("cuda:0")
 eager = "--eager" in sys.argv
 only = [a for a in sys.argv[1:] if not a.startswith("--")]
+for a in sys.argv[1:]:
+    if a.startswith("--mode="):  # a debug mode of the library (timing experiments), e.g. --mode=86
+        from tinychatengine_amd import capi
+        capi.check(capi.lib().tce_w4a16_set_debug_mode(int(a.split("=")[1])))
 SIZES = {"OPT-125M": (768, 12, 3072, 12), "OPT-1.3B": (2048, 32, 8192, 24), "OPT-6.7B": (4096, 32, 16384, 32)}
 for name, (E, H, F, NL) in SIZES.items():
     if only and name not in only:

@@ -11,7 +11,8 @@
 // so the attention rows and both caches are BIT-IDENTICAL to tce_opt_kv_append -> tce_w8a8_matmul -> tce_opt_softmax_q -> tce_w8a8_matmul (tests/test_gpu_w8a8.py).
 //
 // Workgroup = (head, new row j), 5 waves: waves 0-3 take the row's keys (a thread per key: a cache row of hd = 64 or 128 bytes -- OPT-125M / 1.3B and 6.7B -- against the query held in registers, 256 bytes of keys'
-// loads in flight), wave 4 appends; row (0, 0) is evaluated -- by all five waves, its sum by wave 4 -- only if this row's maximum is below 1.
+// loads in flight), wave 4 appends; row (0, 0) is evaluated -- by all five waves -- only if this row's maximum is below 1.  The softmax sums are sequential
+// fp32 additions in key order; waves 0-3 walk them together (sequential_sum_speculated, tce_common.hpp: bit-identical, a quarter of the dependent chain).
 // New keys / values (t >= pos) are read from the projections' output rows, not from the caches, so the m rows' workgroups do not depend on each other.
 #include "tce_common.hpp"
 #include "w4a16_kernels.hpp"
@@ -98,7 +99,7 @@ __device__ __forceinline__ float wave_max(float v) {
 template <int HD>
 __global__ __launch_bounds__(320) void opt_attn_decode_kernel(const OptAttnArgs a) {
     constexpr int QW = HD / 16, DW = HD / 4;  // 16-byte pieces per row; head dimensions per wave in the last step (in passes of 16)
-    extern __shared__ __attribute__((aligned(16))) float sm[];  // e[tgzp] | e0[tgzp] | probs int8 [tgz16] | red[16]
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // e[tgzp] | e0[tgzp] | probs int8 [tgz16] | red[16] | spec[kSpecScratchFloats(4)]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = blockIdx.x, j = blockIdx.y;
     const int tgz = a.tgz, pos = a.pos;
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(320) void opt_attn_decode_kernel(const OptAttnArgs 
     float *e = sm, *e0 = sm + tgzp;
     int8_t *pq = reinterpret_cast<int8_t *>(sm + 2 * tgzp);
     float *red = reinterpret_cast<float *>(pq + tgz16);
+    float *spec = red + 16;  // the speculated sums' scratch
     const bool row00 = h == 0 && j == 0;
     // ---- wave 4: the append (this row's key as a cache row, its value as a cache column) and the masked score [0][0][0]; waves 0-3: the row's scores ----
     if (wave == 4) {
@@ -124,11 +126,14 @@ __global__ __launch_bounds__(320) void opt_attn_decode_kernel(const OptAttnArgs 
     // the cached value rows this lane will contract in the last step (16 head dimensions x its 16 keys) are requested NOW: they depend on nothing, and twelve
     // workgroups on twelve CUs have nothing else to hide a memory round trip behind
     const int pieces = (pos + 15) >> 4;
-    const int8_t *vbase = a.vtc + ((size_t)h * HD + DW * (wave & 3)) * a.max_keys;  // (the first 16 of the wave's DW dimensions: the first pass)
-    int4_t vfirst[16];
+    const int8_t *vbase = a.vtc + ((size_t)h * HD + DW * (wave & 3)) * a.max_keys;  // (the wave's DW dimensions, consumed in passes of 16)
+    int4_t vfirst[DW / 16][16];
     if (wave < 4) {
 #pragma unroll
-        for (int dd = 0; dd < 16; ++dd) vfirst[dd] = lane < pieces ? *reinterpret_cast<const int4_t *>(vbase + (size_t)dd * a.max_keys + 16 * lane) : int4_t{0, 0, 0, 0};
+        for (int ps = 0; ps < DW / 16; ++ps)
+#pragma unroll
+            for (int dd = 0; dd < 16; ++dd)
+                vfirst[ps][dd] = lane < pieces ? *reinterpret_cast<const int4_t *>(vbase + (size_t)(16 * ps + dd) * a.max_keys + 16 * lane) : int4_t{0, 0, 0, 0};
         const float r = wave_max(score_row<HD>(a, h, j, tid, 256, e));
         if (lane == 0) red[wave] = r;
     }
@@ -136,18 +141,20 @@ __global__ __launch_bounds__(320) void opt_attn_decode_kernel(const OptAttnArgs 
     const float r03 = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));  // this row's maximum
     const float v000 = red[8];
     const bool independent = row00 || r03 >= 1.0f;  // (tce_opt_softmax_q: a probability is <= 1, so such a row's maximum does not depend on row (0, 0))
-    // ---- row (0, 0) up to its first probability, only if this row needs it: all five waves score it, wave 4 walks its sum ----
+    // ---- row (0, 0) up to its first probability, only if this row needs it: all five waves score it, waves 0-3 walk its sum ----
     if (!independent) {
         const float r = wave_max(score_row<HD>(a, 0, 0, tid, 320, e0));
         if (lane == 0) red[9 + wave] = r;
         __syncthreads();
-        if (wave == 4) {
+        {
             float mx0 = v000;
 #pragma unroll
             for (int w = 0; w < 5; ++w) mx0 = red[9 + w] > mx0 ? red[9 + w] : mx0;
-            for (int t = lane; t < tgz; t += 64) e0[t] = expf(e0[t] - mx0);
-            const float sum0 = sequential_sum<true>(e0, tgz, lane);
-            if (lane == 0) red[5] = (float)((double)e0[0] / ((double)sum0 + 1e-10));
+            for (int t = tid; t < tgz; t += 320) e0[t] = expf(e0[t] - mx0);
+            __syncthreads();
+            // its sum: sequential fp32 additions in key order (softmax.cc:21-26) -- walked by waves 0-3 at once (sequential_sum_speculated, tce_common.hpp)
+            const float sum0 = sequential_sum_speculated<4, false>(e0, tgz, spec, wave, lane);
+            if (tid == 0) red[5] = (float)((double)e0[0] / ((double)sum0 + 1e-10));
         }
         __syncthreads();
     }
@@ -156,12 +163,9 @@ __global__ __launch_bounds__(320) void opt_attn_decode_kernel(const OptAttnArgs 
     const float mx = r03 > init ? r03 : init;
     for (int t = tid; t < tgz; t += 256) e[t] = expf(e[t] - mx);
     __syncthreads();  // waves 0-3 only from here on (wave 4 has left: a barrier counts the waves still running)
-    if (wave == 0) {
-        const float sum = sequential_sum<true>(e, tgz, lane);
-        if (lane == 0) red[6] = sum;
-    }
-    __syncthreads();
-    const double denom = (double)red[6] + 1e-10;
+    // the row's sum: sequential fp32 additions in key order, speculated across the four waves (bit-identical; 512 keys: 128 dependent additions per wave, not 512)
+    const float sum = sequential_sum_speculated<4, false>(e, tgz, spec, wave, lane);
+    const double denom = (double)sum + 1e-10;
     for (int t = tid; t < tgz16; t += 256) {
         int8_t qb = 0;
         if (t < tgz) {
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(320) void opt_attn_decode_kernel(const OptAttnArgs 
     //      together), lane 0 the new rows.  The piece that straddles pos: what lies behind pos in the cache is not part of the context -- its probabilities
     //      are masked out of the lane's copy (the bytes exist: max_keys is a multiple of 16) ----
 #pragma unroll
-    for (int pass = 0; pass < DW / 16; ++pass) {  // (head dimension 128: two passes of 16 dimensions per wave; only the first one's rows were requested ahead)
+    for (int pass = 0; pass < DW / 16; ++pass) {  // (head dimension 128: two passes of 16 dimensions per wave, both requested ahead)
         const int8_t *vpass = vbase + (size_t)16 * pass * a.max_keys;
         int acc[16];
 #pragma unroll
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(320) void opt_attn_decode_kernel(const OptAttnArgs 
             }
             int4_t vv[16];
 #pragma unroll
-            for (int dd = 0; dd < 16; ++dd) vv[dd] = (it == 0 && pass == 0) ? vfirst[dd] : *reinterpret_cast<const int4_t *>(vpass + (size_t)dd * a.max_keys + 16 * p);
+            for (int dd = 0; dd < 16; ++dd) vv[dd] = it == 0 ? vfirst[pass][dd] : *reinterpret_cast<const int4_t *>(vpass + (size_t)dd * a.max_keys + 16 * p);
 #pragma unroll
             for (int dd = 0; dd < 16; ++dd) {
                 acc[dd] = __builtin_amdgcn_sdot4(pv.x, vv[dd].x, acc[dd], false);
@@ -248,7 +252,7 @@ int launch_opt_attention_decode(const void *q, const void *kn, const void *vn, v
     a.a_qk = a_qk;
     a.a_pv = a_pv;
     const int tgzp = (a.tgz + 3) & ~3, tgz16 = (a.tgz + 15) & ~15;
-    const size_t lds = (size_t)2 * tgzp * sizeof(float) + tgz16 + 16 * sizeof(float);
+    const size_t lds = (size_t)2 * tgzp * sizeof(float) + tgz16 + 16 * sizeof(float) + (size_t)kSpecScratchFloats(4) * sizeof(float);
     if (lds > 160 * 1024) return TCE_ERR_UNSUPPORTED_SHAPE;
     if (hd != 64 && hd != 128) return TCE_ERR_UNSUPPORTED_SHAPE;
     const auto kernel = hd == 64 ? opt_attn_decode_kernel<64> : opt_attn_decode_kernel<128>;

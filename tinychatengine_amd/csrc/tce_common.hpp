@@ -394,6 +394,12 @@ __device__ __forceinline__ float sequential_sum_speculated(const float *vals, in
     int b, len;
     speculated_segment<NW>(n, wave, b, len);
     const int L = ((n + NW * 32 - 1) / (NW * 32)) * 32;
+    if (wave >= NW) {  // a workgroup with more waves than segments: the others only keep the barriers' count
+        lds_barrier();
+        lds_barrier();
+        lds_barrier();
+        return res[0];
+    }
     if (lane == 0) segsum[wave] = ds_mine;
     lds_barrier();
     // the exactly rounded sum of everything before the segment (the order of THIS sum is free: it only centres the candidates)

@@ -545,7 +545,7 @@ int launch_lnq_w8a8_group(const float *x, const float *ln_w, const float *ln_b, 
     }
     for (int i = count; i < TCE_MAX_GROUP; ++i) a.lin[i] = a.lin[0];
     a.total_rows = rows;
-    const bool wide = k >= 1024 && g_lnq_form != 1;
+    const bool wide = (k >= 1024 || (g_lnq_form == 6 && k >= 256)) && g_lnq_form != 1;  // (debug mode 86: the wide form from k = 256 on)
     a.dbg = g_lnq_form >= 2 && g_lnq_form <= 4 ? g_lnq_form - 1 : 0;
     a.stamps = g_lnq_form == 5 ? g_lnq_stamps : nullptr;
     if (wide) return launch_wide(a, rows, stream, hip_err);
