@@ -27,6 +27,20 @@ HIPCC_FLAGS = [
 ]
 # per-file additions (experiments land here first)
 EXTRA_FLAGS: dict[str, list[str]] = {}  # (-fno-slp-vectorize on the GEMM: no packed fp32 fma beside the MFMAs -- measured neutral)
+# Kernels that must not spill a vector register: lnq_w8a8_wide_kernel keeps 16 requested weight pieces per lane in flight through its sums; ONE spilled register
+# makes the compiler wait for all of them at the spill (measured: the OPT-6.7B layer 94 -> 103 us, found only by accident).  The build fails instead.
+NO_VGPR_SPILL: dict[str, list[str]] = {"w8a8_lnq_fused.hip": ["lnq_w8a8_wide_kernel"]}
+
+
+def _check_spills(src: str, stderr_text: str) -> None:
+    name = None
+    for line in stderr_text.splitlines():
+        if "Function Name:" in line:
+            name = line.split("Function Name:")[1].split()[0]
+        elif "VGPRs Spill:" in line and name:
+            n = int(line.split("VGPRs Spill:")[1].split()[0])
+            if n > 0 and any(k in name for k in NO_VGPR_SPILL.get(src, [])):
+                raise RuntimeError(f"{src}: kernel {name} spills {n} vector registers (see NO_VGPR_SPILL in build.py)")
 
 
 def _hipcc() -> str:
@@ -52,7 +66,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         sp = os.path.join(CSRC, src)
         op = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
         if force or _stale(op, [sp] + headers):
-            jobs.append([hipcc, *HIPCC_FLAGS, *EXTRA_FLAGS.get(src, []), "-I", os.path.join(REPO_DIR, "include"), "-I", CSRC, "-c", sp, "-o", op])
+            check = ["-Rpass-analysis=kernel-resource-usage"] if src in NO_VGPR_SPILL else []
+            jobs.append([hipcc, *HIPCC_FLAGS, *EXTRA_FLAGS.get(src, []), *check, "-I", os.path.join(REPO_DIR, "include"), "-I", CSRC, "-c", sp, "-o", op])
         objs.append(op)
     if jobs:  # the translation units are independent: compile them side by side
         from concurrent.futures import ThreadPoolExecutor
@@ -60,7 +75,29 @@ def build(force: bool = False, verbose: bool = False) -> str:
         def run(cmd):
             if verbose:
                 print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            src = os.path.basename(cmd[-3])
+            if src not in NO_VGPR_SPILL:
+                subprocess.check_call(cmd)
+                return
+            r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+            rest, in_remark = [], False  # the compiler's other diagnostics pass through; the remarks and their source excerpts do not
+            for ln in r.stderr.splitlines():
+                if "kernel-resource-usage" in ln:
+                    in_remark = True
+                elif in_remark and ln.lstrip()[:1].isdigit() is False and ln.strip().startswith("|") or in_remark and "|" in ln[:8]:
+                    pass
+                else:
+                    in_remark = False
+                    rest.append(ln)
+            if rest:
+                print("\n".join(rest), file=sys.stderr, flush=True)
+            if r.returncode != 0:
+                raise subprocess.CalledProcessError(r.returncode, cmd)
+            try:
+                _check_spills(src, r.stderr)
+            except RuntimeError:
+                os.remove(cmd[-1])  # (the object must not count as built)
+                raise
 
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
             list(pool.map(run, jobs))

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(320) void opt_attn_decode_kernel(const OptAttnArgs 
             for (int t = tid; t < tgz; t += 320) e0[t] = expf(e0[t] - mx0);
             __syncthreads();
             // its sum: sequential fp32 additions in key order (softmax.cc:21-26) -- walked by waves 0-3 at once (sequential_sum_speculated, tce_common.hpp)
-            const float sum0 = sequential_sum_speculated<4, false>(e0, tgz, spec, wave, lane);
+            const float sum0 = sequential_sum_speculated<4, false, SpecNoOp, true>(e0, tgz, spec, wave, lane);  // (wave 4 only keeps the barriers' count)
             if (tid == 0) red[5] = (float)((double)e0[0] / ((double)sum0 + 1e-10));
         }
         __syncthreads();

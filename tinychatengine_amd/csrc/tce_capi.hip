@@ -189,7 +189,7 @@ int tce_w4a16_set_debug_mode(int mode) {
         tce::set_gemv_shared_xsum(mode == 45 ? 2 : mode - 46);
         return TCE_OK;
     }
-    if (mode >= 80 && mode <= 86) {  // LayerNormQ + W8A8 group: 81 = the workgroup-per-8-rows form at every k; wide form: 83 no sums (wrong results), 84 no output rows, 85 phase times of workgroup 0 into the debug buffer, 86 the wide form from k = 256 on
+    if (mode >= 80 && mode <= 87) {  // LayerNormQ + W8A8 group: 81 = the workgroup-per-8-rows form at every k; wide form: 83 no sums (wrong results), 84 no output rows, 85 phase times of workgroup 0 into the debug buffer, 86 the wide form from k = 256 on, 87 the 4-wave form's single row walked by one wave
         tce::set_lnq_form(mode - 80);
         return TCE_OK;
     }

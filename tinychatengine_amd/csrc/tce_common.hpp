@@ -385,7 +385,8 @@ struct SpecNoOp {
     __device__ __forceinline__ void operator()() const {}
 };
 // `mid` is called by every wave between its chain and the barrier behind it (a place to issue memory requests that should not all be in flight at once)
-template <int NW, bool ROWB = true, class Mid = SpecNoOp>
+// MORE_WAVES: the workgroup has waves beyond the NW that walk the sum; they only keep the barriers' count
+template <int NW, bool ROWB = true, class Mid = SpecNoOp, bool MORE_WAVES = false>
 __device__ __forceinline__ float sequential_sum_speculated(const float *vals, int n, float *sp, int wave, int lane, double ds_mine, unsigned long long *stamps = nullptr,
                                                             Mid mid = Mid()) {
     static_assert(NW <= 16, "segment sums are exchanged through 16 doubles");
@@ -394,7 +395,7 @@ __device__ __forceinline__ float sequential_sum_speculated(const float *vals, in
     int b, len;
     speculated_segment<NW>(n, wave, b, len);
     const int L = ((n + NW * 32 - 1) / (NW * 32)) * 32;
-    if (wave >= NW) {  // a workgroup with more waves than segments: the others only keep the barriers' count
+    if (MORE_WAVES && wave >= NW) {
         lds_barrier();
         lds_barrier();
         lds_barrier();
@@ -462,7 +463,7 @@ __device__ __forceinline__ float sequential_sum_speculated(const float *vals, in
 }
 
 // ... with the segment sums formed here (values that already lie in LDS, visible to all waves)
-template <int NW, bool ROWB = true, class Mid = SpecNoOp>
+template <int NW, bool ROWB = true, class Mid = SpecNoOp, bool MORE_WAVES = false>
 __device__ __forceinline__ float sequential_sum_speculated(const float *vals, int n, float *sp, int wave, int lane, unsigned long long *stamps = nullptr, Mid mid = Mid()) {
     int b, len;
     speculated_segment<NW>(n, wave, b, len);
@@ -470,7 +471,7 @@ __device__ __forceinline__ float sequential_sum_speculated(const float *vals, in
     for (int k = b + lane; k < b + len; k += 64) ds += (double)vals[k];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) ds += __shfl_xor(ds, off, 64);
-    return sequential_sum_speculated<NW, ROWB, Mid>(vals, n, sp, wave, lane, ds, stamps, mid);
+    return sequential_sum_speculated<NW, ROWB, Mid, MORE_WAVES>(vals, n, sp, wave, lane, ds, stamps, mid);
 }
 constexpr int kSpecScratchFloats(int nw) { return 32 + 2 * nw * 64 + 16; }
 

@@ -138,6 +138,30 @@ __global__ __launch_bounds__(64 * kWaves) void lnq_w8a8_kernel(const LnqArgs a) 
     // ---- 2. the two sequential sums of every row (LayerNormQ.cc:27-37), in the reference's order: wave w takes rows w, w + 4
     //         (sequential_sum_bcast, tce_common.hpp: one dependent add per element) ----
     float *dev = reinterpret_cast<float *>(smem + lnq_dev_offset(m, K)) + (size_t)wave * K;  // this wave's squared deviations
+    if (m == 1 && a.dbg != 4) {
+        // ONE row (the decode token): its two sums are walked by the four waves together (sequential_sum_speculated, tce_common.hpp: a quarter of the row per
+        // wave from 64 candidate running values, bit-identical); a wave forms the squared deviations of its own quarter
+        float *dev0 = reinterpret_cast<float *>(smem + lnq_dev_offset(m, K));
+        float *sp = dev0 + K;
+        float mean = sequential_sum_speculated<kWaves, false>(rows, K, sp, wave, lane);
+        mean /= (float)K;
+        int b, len;
+        speculated_segment<kWaves>(K, wave, b, len);
+        double ds = 0.0;
+        for (int k = b + lane; k < b + len; k += 64) {
+            const float d = rows[k] - mean;
+            const float d2 = __fmul_rn(d, d);
+            dev0[k] = d2;
+            ds += (double)d2;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) ds += __shfl_xor(ds, off, 64);
+        const float sq = sequential_sum_speculated<kWaves, false>(dev0, K, sp, wave, lane, ds);
+        if (tid == 0) {
+            stats[0] = mean;
+            stats[1] = sqrtf(sq / (float)K + 0.00001f);
+        }
+    } else
     for (int r = wave; r < m; r += kWaves) {
         const float *xr = rows + (size_t)r * K;
         float mean = sequential_sum_bcast(xr, K);
@@ -546,10 +570,10 @@ int launch_lnq_w8a8_group(const float *x, const float *ln_w, const float *ln_b, 
     for (int i = count; i < TCE_MAX_GROUP; ++i) a.lin[i] = a.lin[0];
     a.total_rows = rows;
     const bool wide = (k >= 1024 || (g_lnq_form == 6 && k >= 256)) && g_lnq_form != 1;  // (debug mode 86: the wide form from k = 256 on)
-    a.dbg = g_lnq_form >= 2 && g_lnq_form <= 4 ? g_lnq_form - 1 : 0;
+    a.dbg = g_lnq_form >= 2 && g_lnq_form <= 4 ? g_lnq_form - 1 : (g_lnq_form == 7 ? 4 : 0);  // (debug mode 87: the 4-wave form walks one row's sums with one wave, as before)
     a.stamps = g_lnq_form == 5 ? g_lnq_stamps : nullptr;
     if (wide) return launch_wide(a, rows, stream, hip_err);
-    const size_t lds = lnq_dev_offset(m, k) + (size_t)(m < kWaves ? m : kWaves) * k * 4;  // a scratch row per wave that walks a row
+    const size_t lds = lnq_dev_offset(m, k) + (size_t)(m < kWaves ? m : kWaves) * k * 4 + (m == 1 ? (size_t)kSpecScratchFloats(kWaves) * 4 : 0);  // a scratch row per wave that walks a row (+ one row's speculated sums)
     if (lds > 160 * 1024) return TCE_ERR_UNSUPPORTED_SHAPE;
     auto kfn = lnq_w8a8_kernel<2, 2, 4>;
     const int grid = (rows + 2 * kWaves - 1) / (2 * kWaves);
