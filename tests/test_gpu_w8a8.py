@@ -179,13 +179,27 @@ def test_unsupported_kind_is_rejected(dev):
     assert capi.w8a8_matmul(d, 0) == capi.TCE_ERR_UNSUPPORTED_KIND
 
 
-@pytest.mark.parametrize("m,n", [(108, 768), (1, 768), (512, 768), (65, 1024), (3, 2048), (7, 20), (5, 772), (2, 36), (3, 60), (1, 8192), (4, 4)])
+@pytest.mark.parametrize("m,n", [(108, 768), (1, 768), (512, 768), (65, 1024), (3, 2048), (7, 20), (5, 772), (2, 36), (3, 60), (1, 8192), (4, 4),
+                                 (1, 4096), (256, 1024), (257, 1024), (6, 4096), (2, 260), (1, 2080), (300, 256)])
 def test_layernorm_q_bit_exact(dev, oracle, m, n):
-    """tce_layernorm_q against the oracle's restatement of LayerNormQ::forward (LayerNormQ.cc:12-52): bit for bit."""
+    """tce_layernorm_q against the oracle's restatement of LayerNormQ::forward (LayerNormQ.cc:12-52): bit for bit -- the wave-per-row form (many rows, short
+    rows) and the forms that walk a row's sums with 4 or 16 waves at once (up to 256 rows of 256 / 1024 columns or more; sequential_sum_speculated), with rows
+    whose running sums return to zero or cancel (the speculation's misses) among them."""
     import ctypes as C
     from tinychatengine_amd import capi
     rng = np.random.default_rng(m * 1000 + n)
     x = (rng.standard_normal((m, n)) * 3 + rng.standard_normal((m, 1))).astype(np.float32)
+    if n >= 256:
+        x[0] = rng.standard_normal(n).astype(np.float32)              # zero-mean noise
+        r = x[m - 1]
+        for nw in (4, 16):                                            # every segment of either form sums to (almost) nothing
+            seg = ((n + nw * 32 - 1) // (nw * 32)) * 32
+            for s0 in range(0, n, seg):
+                e = min(s0 + seg, n)
+                r[e - 1] = np.float32(-np.sum(r[s0:e - 1], dtype=np.float64))
+        if m > 2:
+            x[1] *= np.float32(1e-3)
+            x[1, 3], x[1, n // 2 + 5] = 1.0e7, -1.0e7                 # cancellation of huge values
     w = (8 + 4 * rng.standard_normal(n)).astype(np.float32)
     b = (rng.standard_normal(n) * 2).astype(np.float32)
     out = torch.zeros((m, n), dtype=torch.int8, device=dev)

@@ -108,10 +108,61 @@ __global__ __launch_bounds__(64) void layernorm_q_kernel(const float *x, const f
     }
 }
 
+// A FEW long rows (decode: the token's row at OPT-1.3B / 6.7B widths is 2 x 4096 dependent additions for the kernel above, 22 us): a workgroup of NW waves per row,
+// the two sums walked by all of them at once (sequential_sum_speculated, tce_common.hpp: every wave adds its share of the row from 64 candidate running values;
+// the additions that reach the result are the reference's, in its order -- bit-identical); a wave forms the squared deviations of its own segment.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void layernorm_q_rows_kernel(const float *x, const float *w, const float *b, int8_t *out, int m, int n) {
+    extern __shared__ __attribute__((aligned(16))) float row[];  // [n] the row | [n] its squared deviations | the speculated sums' scratch
+    constexpr bool ROWB = NW > 4;  // (many waves: the DPP row broadcast, else the LDS would set the pace; few: the LDS broadcast reads' shorter chain)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float *xr = x + (size_t)blockIdx.x * n;
+    int8_t *orow = out + (size_t)blockIdx.x * n;
+    float *dev = row + n, *sp = row + 2 * n;
+    const int n4 = n >> 2;  // n % 4 == 0
+    for (int p = tid; p < n4; p += 64 * NW) reinterpret_cast<float4_t *>(row)[p] = reinterpret_cast<const float4_t *>(xr)[p];
+    lds_barrier();
+    float mean = sequential_sum_speculated<NW, ROWB>(row, n, sp, wave, lane);
+    mean /= (float)n;
+    int sb, len;
+    speculated_segment<NW>(n, wave, sb, len);
+    double ds = 0.0;
+    for (int k = sb + lane; k < sb + len; k += 64) {
+        const float d = row[k] - mean;
+        const float d2 = __fmul_rn(d, d);
+        dev[k] = d2;
+        ds += (double)d2;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ds += __shfl_xor(ds, off, 64);
+    const float sq = sequential_sum_speculated<NW, ROWB>(dev, n, sp, wave, lane, ds);
+    const float std_dev = sqrtf(sq / (float)n + 0.00001f);
+    for (int k = tid; k < n; k += 64 * NW) {
+        const float t = __fdiv_rn(row[k] - mean, std_dev);
+        const float f = __fadd_rn(__fmul_rn(t, w[k]), b[k]);
+        orow[k] = (int8_t)(int)roundf(f);
+    }
+}
+
 }  // namespace
 
 int launch_layernorm_q(const float *x, const float *w, const float *b, void *out, int m, int n, hipStream_t stream, hipError_t *hip_err) {
-    if (m <= kSeqSumBcastMaxWaves) hipLaunchKernelGGL(layernorm_q_kernel<true>, dim3(m), dim3(64), (size_t)2 * n * sizeof(float), stream, x, w, b, static_cast<int8_t *>(out), m, n);
+    // up to a row per CU: 16 waves per row from 1024 columns, 4 waves from 256 (the chain per wave must stay longer than the three barriers it costs)
+    const int nw = (m <= 256 && n >= 1024) ? 16 : ((m <= 256 && n >= 256) ? 4 : 0);
+    if (nw) {
+        const size_t lds = ((size_t)2 * n + (nw == 16 ? kSpecScratchFloats(16) : kSpecScratchFloats(4))) * sizeof(float);
+        const void *kfn = nw == 16 ? reinterpret_cast<const void *>(layernorm_q_rows_kernel<16>) : reinterpret_cast<const void *>(layernorm_q_rows_kernel<4>);
+        if (lds > 64 * 1024) {
+            const hipError_t ea = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (ea != hipSuccess) {
+                if (hip_err) *hip_err = ea;
+                return TCE_ERR_HIP;
+            }
+        }
+        if (nw == 16) hipLaunchKernelGGL(layernorm_q_rows_kernel<16>, dim3(m), dim3(1024), lds, stream, x, w, b, static_cast<int8_t *>(out), m, n);
+        else hipLaunchKernelGGL(layernorm_q_rows_kernel<4>, dim3(m), dim3(256), lds, stream, x, w, b, static_cast<int8_t *>(out), m, n);
+    }
+    else if (m <= kSeqSumBcastMaxWaves) hipLaunchKernelGGL(layernorm_q_kernel<true>, dim3(m), dim3(64), (size_t)2 * n * sizeof(float), stream, x, w, b, static_cast<int8_t *>(out), m, n);
     else hipLaunchKernelGGL(layernorm_q_kernel<false>, dim3(m), dim3(64), (size_t)2 * n * sizeof(float), stream, x, w, b, static_cast<int8_t *>(out), m, n);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
