@@ -390,6 +390,54 @@ def test_opt_decoder_layer_against_the_oracle_composition(dev, oracle, embed, he
         assert np.array_equal(h_gpu.cpu().numpy().view(np.uint32), want.view(np.uint32)), f"step {(pos, m)}: the residual stream"
 
 
+@pytest.mark.parametrize("M,N,K,mode,lda,ldb,ldc,batch", [(512, 4096, 1024, 75, 0, 0, 0, 1),      # the rule: 128 x 128 tiles (4 x 32 x ... >= 224 is not met: 128 x 64)
+                                                          (1024, 4096, 512, 75, 0, 0, 0, 1),      # the rule: 128 x 128 tiles
+                                                          (300, 2100, 1024, 76, 0, 0, 0, 1),      # ragged in M and N, 128 columns forced
+                                                          (300, 2100, 1024, 77, 0, 0, 0, 1),      # the same with 64 columns
+                                                          (129, 65, 256, 76, 0, 0, 0, 1), (129, 65, 256, 77, 0, 0, 0, 1),
+                                                          (128, 128, 4096, 77, 0, 0, 0, 1),       # one tile, 64 k-steps
+                                                          (200, 260, 320, 76, 384, 448, 300, 2),  # leading dimensions, a batch of two
+                                                          (200, 260, 320, 77, 384, 448, 300, 2)])
+def test_w8a8_large_tiles_bit_exact(dev, oracle, M, N, K, mode, lda, ldb, ldc, batch):
+    """The prefill-sized int8 kernel (w8a8_mfma_big_kernel: 128 x 128 / 128 x 64 tiles, operand panels through a three-stage LDS ring) against the oracle: the
+    int8-out form with an int8 bias (clamp at 0: the ReLU linear) and the fp32-out form with an fp32 bias accumulating into C -- every element, ragged edges,
+    leading dimensions and batches, the -128 corner rows."""
+    from tinychatengine_amd import capi
+    L = capi.lib()
+    rng = np.random.default_rng(M + N + K + mode)
+    lda_, ldb_, ldc_ = lda or K, ldb or K, ldc or N
+    A = rng.integers(-128, 128, (batch, M, lda_), dtype=np.int8)
+    B = rng.integers(-128, 128, (batch, N, ldb_), dtype=np.int8)
+    A[:, 0, :] = -128
+    B[:, 0, :] = -128
+    b8 = rng.integers(-128, 128, N, dtype=np.int8)
+    bf = rng.standard_normal(N).astype(np.float32)
+    C0 = rng.standard_normal((batch, M, ldc_)).astype(np.float32)
+    tA, tB, tb8, tbf = _t(dev, A), _t(dev, B), _t(dev, b8), _t(dev, bf)
+    st = torch.cuda.current_stream().cuda_stream
+    capi.check(L.tce_w4a16_set_debug_mode(mode))
+    try:
+        out8 = torch.full((batch, M, ldc_), 77, dtype=torch.int8, device=dev)
+        d = capi.W8A8Desc(M=M, N=N, K=K, batch=batch, A=tA.data_ptr(), B=tB.data_ptr(), bias=tb8.data_ptr(), C=out8.data_ptr(), alpha=ALPHA, beta=BETA, q_min=0, q_max=127,
+                          bias_kind=capi.TCE_BIAS_INT8, out_kind=capi.TCE_OUT_INT8, lda=lda, ldb=ldb, ldc=ldc, strideA=M * lda_, strideB=N * ldb_, strideC=M * ldc_)
+        capi.check(capi.w8a8_matmul(d, st))
+        tC = _t(dev, C0.copy())
+        d = capi.W8A8Desc(M=M, N=N, K=K, batch=batch, A=tA.data_ptr(), B=tB.data_ptr(), bias=tbf.data_ptr(), C=tC.data_ptr(), alpha=0.0071, q_min=-128, q_max=127,
+                          bias_kind=capi.TCE_BIAS_FP32, out_kind=capi.TCE_OUT_FP32, accumulate=1, lda=lda, ldb=ldb, ldc=ldc, strideA=M * lda_, strideB=N * ldb_, strideC=M * ldc_)
+        capi.check(capi.w8a8_matmul(d, st))
+        torch.cuda.synchronize()
+    finally:
+        capi.check(L.tce_w4a16_set_debug_mode(75))
+    got8, gotf = out8.cpu().numpy(), tC.cpu().numpy()
+    for bi in range(batch):
+        Ab, Bb = np.ascontiguousarray(A[bi, :, :K]), np.ascontiguousarray(B[bi, :, :K])
+        assert np.array_equal(got8[bi, :, :N], oracle.int8_matmul_bias_i8(Ab, Bb, b8, ALPHA, BETA, 0, 127, M, N, K)), f"int8 out, batch {bi}"
+        assert (got8[bi, :, N:] == 77).all(), "columns behind N were written"
+        want = C0[bi, :, :N] + oracle.int8_matmul_bias_f32(Ab, Bb, bf, 0.0071, M, N, K)
+        assert np.array_equal(gotf[bi, :, :N].view(np.uint32), want.view(np.uint32)), f"fp32 out + accumulate, batch {bi}"
+        assert np.array_equal(gotf[bi, :, N:], C0[bi, :, N:])
+
+
 def test_w8a8_leading_dimensions_and_accumulate(dev, oracle):
     """tce_w8a8_desc.lda / ldb / ldc (a head's 64 columns of a wider matrix as an operand as it lies) and `accumulate` (the fp32 residual add in
     the launch), MFMA and generic kernels, against the oracle on the gathered operands."""

@@ -152,6 +152,10 @@ int tce_w4a16_set_debug_mode(int mode) {
         tce::set_attention_prefill_waves(mode - 2950);
         return TCE_OK;
     }
+    if (mode >= 75 && mode <= 78) {  // W8A8, the 128-row tiles: 75 the rule, 76 / 77 forced with 128 / 64 columns, 78 off
+        tce::set_w8a8_big(mode == 78 ? 9 : mode - 75);
+        return TCE_OK;
+    }
     if (mode >= 70 && mode <= 74) {  // W8A8: wave quartets per tile (70 automatic; 73: automatic, without the decode-sized wave-per-column kernels)
         tce::set_w8a8_ksplit(mode - 70);
         return TCE_OK;

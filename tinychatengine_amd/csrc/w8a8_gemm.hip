@@ -221,6 +221,113 @@ __global__ __launch_bounds__(256 * KS) void w8a8_mfma_kernel(const W8A8Args a) {
         }
 }
 
+// Prefill-sized problems (OPT-1.3B / 6.7B linears at 512+ rows: 512 x 4096 x 4096 ran at 0.45 POP/s on the 64 x 64 kernel above, whose waves each fetch their
+// own operand rows from memory).  128 x TN tile per workgroup (TN = 128 or 64), 4 waves as 2 x 2, wave tile 64 x TN/2 = 4 x (TN/32) MFMA tiles of 16 x 16 x 64;
+// both operand panels of a k-step (64 k: 128 + TN rows of 64 bytes) go through LDS ONCE per workgroup -- coalesced 16-byte loads (four lanes per 64-byte row
+// piece), lane-linear ds_write_b128 into the XOR-swizzled slot order of the kernel above, fragment-shaped ds_read_b128 back -- in a ring of three stages:
+// iteration t writes the registers loaded for step t + 1, requests step t + 2, passes ONE barrier (lds_barrier: the requests stay in flight) and contracts
+// step t.  int32 accumulation and the shared epilogue: bit-exact like every other path (the order of an int32 sum is free).  K % 64 == 0.
+template <int TN>
+__global__ __launch_bounds__(256) void w8a8_mfma_big_kernel(const W8A8Args a) {
+    constexpr int TM = 128, MI = 4, NJ = TN / 32, STAGES = 3;
+    constexpr int A_SLOTS = TM * 4, B_SLOTS = TN * 4, STAGE_SLOTS = A_SLOTS + B_SLOTS;  // 16-byte slots
+    constexpr int BL = TN / 64;  // B pieces per thread and k-step (A: 2)
+    extern __shared__ __attribute__((aligned(16))) int4_t lds_big[];  // [STAGES][A: 128 rows x 4 | B: TN rows x 4]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int batch = blockIdx.z;
+    const int8_t *A = a.A + (size_t)batch * a.strideA;
+    const int8_t *B = a.B + (size_t)batch * a.strideB;
+    const size_t c_off = (size_t)batch * a.strideC;
+    void *Cb = a.out_kind == TCE_OUT_INT8 ? static_cast<void *>(static_cast<int8_t *>(a.C) + c_off) : static_cast<void *>(static_cast<float *>(a.C) + c_off);
+    const int m_tile = blockIdx.y * TM, n_tile = blockIdx.x * TN;
+    // load view: thread -> (row = tid / 4 (+ 64 per piece), chunk = tid % 4); the slot it writes
+    const int lrow = tid >> 2, lchunk = tid & 3;
+    const int8_t *pa[2], *pb[BL];
+    int wsa[2], wsb[BL];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = lrow + 64 * i;
+        int m = m_tile + row;
+        m = m < a.M ? m : a.M - 1;
+        pa[i] = A + (size_t)m * a.lda + lchunk * 16;
+        wsa[i] = row * 4 + (lchunk ^ ((row >> 2) & 3));
+    }
+#pragma unroll
+    for (int i = 0; i < BL; ++i) {
+        const int row = lrow + 64 * i;
+        int n = n_tile + row;
+        n = n < a.N ? n : a.N - 1;
+        pb[i] = B + (size_t)n * a.ldb + lchunk * 16;
+        wsb[i] = A_SLOTS + row * 4 + (lchunk ^ ((row >> 2) & 3));
+    }
+    // MFMA view: the fragment of 16-row block R0 is slot (R0 + r16) * 4 + (kq ^ (r16 / 4 % 4))  (R0 a multiple of 16)
+    const int rslot = r16 * 4 + (kq ^ ((r16 >> 2) & 3));
+    const int fa0 = (wm * 64) * 4 + rslot, fb0 = A_SLOTS + (wn * (TN / 2)) * 4 + rslot;
+    int4_t acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = int4_t{0, 0, 0, 0};
+    const int T = a.K >> 6;
+    // (Two register sets -- the loads of step t + 3 requested in iteration t and written in iteration t + 2 -- were measured: the unrolled loop took 142 + 128
+    //  registers instead of 83 + 64, one workgroup per CU instead of three, and 2048 x 16384 x 4096 ran 367 us instead of 199.)
+    int4_t ra[2], rb[BL];
+    auto request = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ra[i] = *reinterpret_cast<const int4_t *>(pa[i] + (size_t)t * 64);
+#pragma unroll
+        for (int i = 0; i < BL; ++i) rb[i] = *reinterpret_cast<const int4_t *>(pb[i] + (size_t)t * 64);
+    };
+    auto stage_write = [&](int st) {
+        int4_t *base = lds_big + st * STAGE_SLOTS;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) base[wsa[i]] = ra[i];
+#pragma unroll
+        for (int i = 0; i < BL; ++i) base[wsb[i]] = rb[i];
+    };
+    request(0);
+    stage_write(0);
+    if (T > 1) request(1);
+    for (int t = 0; t < T; ++t) {
+        const int st = t % STAGES;
+        if (t + 1 < T) stage_write((t + 1) % STAGES);  // (the registers requested one iteration ago)
+        if (t + 2 < T) request(t + 2);
+        lds_barrier();
+        const int4_t *base = lds_big + st * STAGE_SLOTS;
+        int4_t fa[MI], fb[NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) fa[i] = base[fa0 + i * 64];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) fb[j] = base[fb0 + j * 64];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    // D[row = 4 * (lane >> 4) + r][col = lane & 15]; the additive terms of the lane's NJ columns once
+    const int m_base = m_tile + wm * 64, n_base = n_tile + wn * (TN / 2);
+    float bterm[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int n = n_base + j * 16 + r16;
+        bterm[j] = bias_term(a, n < a.N ? n : a.N - 1);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n_base + j * 16 + r16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m_base + i * 16 + kq * 4 + r;
+                if (m < a.M && n < a.N) epilogue_store(a, Cb, m, n, acc[i][j][r], bterm[j]);
+            }
+        }
+}
+
 // Generic path: any K, and the *_batch variants where row i of A has its own B_i ([M][N][K], ref :79,:153).
 // One wavefront per output element pair would be overkill at these sizes (decode-time BMMs: heads x tgt_len x 64):
 // one thread per output, 16-byte loads when K % 16 == 0, exact int32 accumulate.
@@ -367,6 +474,8 @@ int g_w8a8_ks = 0;  // forced K split (tuning), 0 = automatic; 3: the decode-siz
 }  // namespace
 
 void set_w8a8_ksplit(int ks) { g_w8a8_ks = (ks >= 1 && ks <= 4) ? ks : 0; }
+int g_w8a8_big = 0;  // the 128-row tiles: 0 the rule, 1 / 2 forced with 128 / 64 columns, 9 off (A/B)
+void set_w8a8_big(int b) { g_w8a8_big = b; }
 
 int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err) {
     W8A8Args a{};
@@ -408,6 +517,24 @@ int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err)
     } else if (rowdot_ok && d.b_per_row && d.batch == 1 && d.K >= 256) {
         const long long outs = (long long)d.M * d.N;
         hipLaunchKernelGGL(w8a8_rowdot_kernel<1>, dim3((unsigned)((outs + 3) / 4), 1, d.batch), dim3(256), 0, stream, a);
+    } else if (!d.b_per_row && aligned && d.K % 64 == 0 && d.K >= 256 && g_w8a8_big != 9 &&
+               (g_w8a8_big == 1 || g_w8a8_big == 2 || (long)((d.M + 127) / 128) * ((d.N + 63) / 64) * d.batch >= 256)) {
+        // prefill-sized: 128 x 128 tiles from two per CU on, 128 x 64 from one per CU on, else the 64 x 64 kernel (scripts/w8a8_gemm_sizes.py,
+        // profiles/r3/w8a8_gemm_sizes.jsonl: 512 x 16384 x 4096 149 -> 57 us, 2048 x 4096 x 4096 131 -> 56; 512 x 2048 x 2048 stays at 10.7)
+        const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch;
+        const bool wide = g_w8a8_big == 1 || (g_w8a8_big != 2 && t128 >= 512);
+        if (wide) {
+            const size_t lds = (size_t)3 * (128 + 128) * 4 * 16;
+            static bool attr = false;
+            if (!attr) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(w8a8_mfma_big_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr = true;
+            }
+            hipLaunchKernelGGL(w8a8_mfma_big_kernel<128>, dim3((d.N + 127) / 128, (d.M + 127) / 128, d.batch), dim3(256), lds, stream, a);
+        } else {
+            const size_t lds = (size_t)3 * (128 + 64) * 4 * 16;
+            hipLaunchKernelGGL(w8a8_mfma_big_kernel<64>, dim3((d.N + 63) / 64, (d.M + 127) / 128, d.batch), dim3(256), lds, stream, a);
+        }
     } else if (!d.b_per_row && aligned && d.K >= 64) {
         dim3 grid((d.N + 63) / 64, (d.M + 63) / 64, d.batch);
         // wave quartets per tile: while the tiles do not fill the chip and every quartet keeps >= 2 k-steps
