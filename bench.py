@@ -149,6 +149,19 @@ def other_configs_leg(torch, dev):
                           q_min=-128, q_max=127, bias_kind=capi.TCE_BIAS_NONE, out_kind=capi.TCE_OUT_FP32 if fp32 else capi.TCE_OUT_INT8)
         us = time_graph(lambda i, sp: capi.check(L.tce_w8a8_matmul(C.byref(d), sp)), 64)
         out["w8a8_opt125m"].append({"batch": b_, "M": M, "N": N, "K": K, "out": "fp32" if fp32 else "int8", "us": round(us, 2), "TOPs": round(2.0 * b_ * M * N * K / us / 1e6, 1)})
+    # ... and the same operator at the larger OPT widths' prefill shapes (OPT-6.7B q / fc1 / fc2 at 512 and 2048 rows: the 128-row int8 tiles), two weight
+    # copies alternating (134 MB: more than an XCD's L2)
+    out["w8a8_opt6p7b_prefill"] = []
+    for (M, N, K) in ((512, 4096, 4096), (512, 16384, 4096), (512, 4096, 16384), (2048, 4096, 4096), (2048, 16384, 4096), (2048, 4096, 16384)):
+        a = torch.randint(-128, 128, (M, K), dtype=torch.int8, device=dev)
+        bs = [torch.randint(-128, 128, (N, K), dtype=torch.int8, device=dev) for _ in range(2)]
+        bias = torch.randint(-128, 128, (N,), dtype=torch.int8, device=dev)
+        o = torch.empty((M, N), dtype=torch.int8, device=dev)
+        ds = [capi.W8A8Desc(M=M, N=N, K=K, batch=1, A=a.data_ptr(), B=b.data_ptr(), bias=bias.data_ptr(), C=o.data_ptr(), alpha=0.0005, beta=0.02,
+                            q_min=-128, q_max=127, bias_kind=capi.TCE_BIAS_INT8, out_kind=capi.TCE_OUT_INT8) for b in bs]
+        us = time_graph(lambda i, sp: capi.check(L.tce_w8a8_matmul(C.byref(ds[i % 2]), sp)), 16)
+        out["w8a8_opt6p7b_prefill"].append({"M": M, "N": N, "K": K, "us": round(us, 2), "TOPs": round(2.0 * M * N * K / us / 1e6, 1), "frac_of_5000_TOPs": round(2.0 * M * N * K / us / 1e6 / 5000.0, 3)})
+        del bs, ds
     torch.cuda.empty_cache()
     return out
 
