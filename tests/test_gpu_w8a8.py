@@ -397,11 +397,14 @@ def test_opt_decoder_layer_against_the_oracle_composition(dev, oracle, embed, he
                                                           (129, 65, 256, 76, 0, 0, 0, 1), (129, 65, 256, 77, 0, 0, 0, 1),
                                                           (128, 128, 4096, 77, 0, 0, 0, 1),       # one tile, 64 k-steps
                                                           (200, 260, 320, 76, 384, 448, 300, 2),  # leading dimensions, a batch of two
-                                                          (200, 260, 320, 77, 384, 448, 300, 2)])
+                                                          (200, 260, 320, 77, 384, 448, 300, 2),
+                                                          # two wave quartets per tile, each on half of K (176 / 177: 128 / 64 columns), odd numbers of k-steps
+                                                          (129, 65, 256, 176, 0, 0, 0, 1), (300, 2100, 1024, 177, 0, 0, 0, 1), (200, 260, 320, 176, 384, 448, 300, 2),
+                                                          (512, 4096, 4096, 75, 0, 0, 0, 1), (130, 200, 576, 177, 0, 0, 0, 1)])
 def test_w8a8_large_tiles_bit_exact(dev, oracle, M, N, K, mode, lda, ldb, ldc, batch):
     """The prefill-sized int8 kernel (w8a8_mfma_big_kernel: 128 x 128 / 128 x 64 tiles, operand panels through a three-stage LDS ring) against the oracle: the
     int8-out form with an int8 bias (clamp at 0: the ReLU linear) and the fp32-out form with an fp32 bias accumulating into C -- every element, ragged edges,
-    leading dimensions and batches, the -128 corner rows."""
+    leading dimensions and batches, the -128 corner rows; and the form with two wave quartets per tile (each on half of K, int32 tiles added through LDS)."""
     from tinychatengine_amd import capi
     L = capi.lib()
     rng = np.random.default_rng(M + N + K + mode)

@@ -152,8 +152,8 @@ int tce_w4a16_set_debug_mode(int mode) {
         tce::set_attention_prefill_waves(mode - 2950);
         return TCE_OK;
     }
-    if (mode >= 75 && mode <= 78) {  // W8A8, the 128-row tiles: 75 the rule, 76 / 77 forced with 128 / 64 columns, 78 off
-        tce::set_w8a8_big(mode == 78 ? 9 : mode - 75);
+    if ((mode >= 75 && mode <= 78) || mode == 176 || mode == 177) {  // W8A8, the 128-row tiles: 75 the rule, 76 / 77 forced with 128 / 64 columns, 176 / 177 the same with two quartets per tile, 78 off
+        tce::set_w8a8_big(mode == 78 ? 9 : (mode >= 176 ? mode - 173 : mode - 75));
         return TCE_OK;
     }
     if (mode >= 70 && mode <= 74) {  // W8A8: wave quartets per tile (70 automatic; 73: automatic, without the decode-sized wave-per-column kernels)

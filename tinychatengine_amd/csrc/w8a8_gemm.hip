@@ -227,14 +227,19 @@ __global__ __launch_bounds__(256 * KS) void w8a8_mfma_kernel(const W8A8Args a) {
 // piece), lane-linear ds_write_b128 into the XOR-swizzled slot order of the kernel above, fragment-shaped ds_read_b128 back -- in a ring of three stages:
 // iteration t writes the registers loaded for step t + 1, requests step t + 2, passes ONE barrier (lds_barrier: the requests stay in flight) and contracts
 // step t.  int32 accumulation and the shared epilogue: bit-exact like every other path (the order of an int32 sum is free).  K % 64 == 0.
-template <int TN>
-__global__ __launch_bounds__(256) void w8a8_mfma_big_kernel(const W8A8Args a) {
+// KS = 2: two wave quartets per tile, each with its own ring, take the two halves of K and add their int32 tiles through LDS at the end (exact in any order) --
+// for launches whose tiles number fewer than the CUs' capacity: a quartet alone on its CU is latency-bound (0.75 us per k-step at 512 x 4096 x 4096).
+template <int TN, int KS>
+__global__ __launch_bounds__(256 * KS) void w8a8_mfma_big_kernel(const W8A8Args a) {
     constexpr int TM = 128, MI = 4, NJ = TN / 32, STAGES = 3;
     constexpr int A_SLOTS = TM * 4, B_SLOTS = TN * 4, STAGE_SLOTS = A_SLOTS + B_SLOTS;  // 16-byte slots
     constexpr int BL = TN / 64;  // B pieces per thread and k-step (A: 2)
-    extern __shared__ __attribute__((aligned(16))) int4_t lds_big[];  // [STAGES][A: 128 rows x 4 | B: TN rows x 4]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    extern __shared__ __attribute__((aligned(16))) int4_t lds_all[];  // [KS quartets][STAGES][A: 128 rows x 4 | B: TN rows x 4]
+    const int lane = threadIdx.x & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = wave8 & 3, grp = wave8 >> 2;
+    const int tid = threadIdx.x & 255;  // within the quartet
+    int4_t *lds_big = lds_all + grp * (STAGES * STAGE_SLOTS);
     const int wm = wave >> 1, wn = wave & 1;
     const int r16 = lane & 15, kq = lane >> 4;
     const int batch = blockIdx.z;
@@ -271,15 +276,18 @@ __global__ __launch_bounds__(256) void w8a8_mfma_big_kernel(const W8A8Args a) {
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = int4_t{0, 0, 0, 0};
-    const int T = a.K >> 6;
+    const int Tall = a.K >> 6;
+    const int Tmax = (Tall + KS - 1) / KS;                              // every wave passes Tmax barriers
+    const int t_begin = KS > 1 ? grp * Tmax : 0;
+    const int T = KS > 1 ? ((t_begin + Tmax < Tall ? t_begin + Tmax : Tall) - t_begin) : Tall;  // this quartet's k-steps (the last quartet's may be fewer, or none)
     // (Two register sets -- the loads of step t + 3 requested in iteration t and written in iteration t + 2 -- were measured: the unrolled loop took 142 + 128
     //  registers instead of 83 + 64, one workgroup per CU instead of three, and 2048 x 16384 x 4096 ran 367 us instead of 199.)
     int4_t ra[2], rb[BL];
     auto request = [&](int t) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) ra[i] = *reinterpret_cast<const int4_t *>(pa[i] + (size_t)t * 64);
+        for (int i = 0; i < 2; ++i) ra[i] = *reinterpret_cast<const int4_t *>(pa[i] + (size_t)(t_begin + t) * 64);
 #pragma unroll
-        for (int i = 0; i < BL; ++i) rb[i] = *reinterpret_cast<const int4_t *>(pb[i] + (size_t)t * 64);
+        for (int i = 0; i < BL; ++i) rb[i] = *reinterpret_cast<const int4_t *>(pb[i] + (size_t)(t_begin + t) * 64);
     };
     auto stage_write = [&](int st) {
         int4_t *base = lds_big + st * STAGE_SLOTS;
@@ -288,14 +296,19 @@ __global__ __launch_bounds__(256) void w8a8_mfma_big_kernel(const W8A8Args a) {
 #pragma unroll
         for (int i = 0; i < BL; ++i) base[wsb[i]] = rb[i];
     };
-    request(0);
-    stage_write(0);
+    if (KS == 1 || T > 0) {
+        request(0);
+        stage_write(0);
+    }
     if (T > 1) request(1);
-    for (int t = 0; t < T; ++t) {
+    for (int t = 0; t < (KS > 1 ? Tmax : T); ++t) {
         const int st = t % STAGES;
         if (t + 1 < T) stage_write((t + 1) % STAGES);  // (the registers requested one iteration ago)
         if (t + 2 < T) request(t + 2);
         lds_barrier();
+        if constexpr (KS > 1) {
+            if (t >= T) continue;
+        }
         const int4_t *base = lds_big + st * STAGE_SLOTS;
         int4_t fa[MI], fb[NJ];
 #pragma unroll
@@ -306,6 +319,27 @@ __global__ __launch_bounds__(256) void w8a8_mfma_big_kernel(const W8A8Args a) {
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if constexpr (KS > 1) {  // the other quartets hand their int32 tiles to quartet 0 through LDS (the rings are done with)
+        lds_barrier();
+        int4_t *red = lds_all;  // [quartet - 1][MI * NJ][256 threads]
+        if (grp > 0) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) red[((grp - 1) * MI * NJ + i * NJ + j) * 256 + tid] = acc[i][j];
+        }
+        lds_barrier();
+        if (grp > 0) return;
+        for (int g2 = 0; g2 < KS - 1; ++g2)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int4_t o = red[(g2 * MI * NJ + i * NJ + j) * 256 + tid];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] += o[r];
+                }
     }
     // D[row = 4 * (lane >> 4) + r][col = lane & 15]; the additive terms of the lane's NJ columns once
     const int m_base = m_tile + wm * 64, n_base = n_tile + wn * (TN / 2);
@@ -474,7 +508,7 @@ int g_w8a8_ks = 0;  // forced K split (tuning), 0 = automatic; 3: the decode-siz
 }  // namespace
 
 void set_w8a8_ksplit(int ks) { g_w8a8_ks = (ks >= 1 && ks <= 4) ? ks : 0; }
-int g_w8a8_big = 0;  // the 128-row tiles: 0 the rule, 1 / 2 forced with 128 / 64 columns, 9 off (A/B)
+int g_w8a8_big = 0;  // the 128-row tiles: 0 the rule, 1 / 2 forced with 128 / 64 columns (one quartet), 3 / 4 the same with two quartets, 9 off (A/B)
 void set_w8a8_big(int b) { g_w8a8_big = b; }
 
 int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err) {
@@ -518,23 +552,27 @@ int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err)
         const long long outs = (long long)d.M * d.N;
         hipLaunchKernelGGL(w8a8_rowdot_kernel<1>, dim3((unsigned)((outs + 3) / 4), 1, d.batch), dim3(256), 0, stream, a);
     } else if (!d.b_per_row && aligned && d.K % 64 == 0 && d.K >= 256 && g_w8a8_big != 9 &&
-               (g_w8a8_big == 1 || g_w8a8_big == 2 || (long)((d.M + 127) / 128) * ((d.N + 63) / 64) * d.batch >= 256)) {
-        // prefill-sized: 128 x 128 tiles from two per CU on, 128 x 64 from one per CU on, else the 64 x 64 kernel (scripts/w8a8_gemm_sizes.py,
-        // profiles/r3/w8a8_gemm_sizes.jsonl: 512 x 16384 x 4096 149 -> 57 us, 2048 x 4096 x 4096 131 -> 56; 512 x 2048 x 2048 stays at 10.7)
+               ((g_w8a8_big >= 1 && g_w8a8_big <= 4) || (long)((d.M + 127) / 128) * ((d.N + 63) / 64) * d.batch >= 512 ||
+                ((long)((d.M + 127) / 128) * ((d.N + 63) / 64) * d.batch >= 256 && d.K >= 2048))) {
+        // prefill-sized (scripts/w8a8_gemm_sizes.py, profiles/r3/w8a8_gemm_sizes.jsonl; never slower than the 64 x 64 kernel on the 18 shapes measured):
+        // 128 x 128 tiles from two per CU on (512 x 16384 x 4096: 149 -> 57 us; 2048 x 4096 x 4096: 131 -> 56), 128 x 64 tiles from two per CU on
+        // (512 x 8192 x 2048: 32 -> 24), from one per CU on with TWO quartets per tile when K is long (512 x 4096 x 4096: 38 -> 29; 512 x 4096 x 16384: 124 -> 85),
+        // else the 64 x 64 kernel (512 x 2048 x 2048 stays at 10.7 us, 512 x 2048 x 8192 at 36).
         const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch;
-        const bool wide = g_w8a8_big == 1 || (g_w8a8_big != 2 && t128 >= 512);
-        if (wide) {
-            const size_t lds = (size_t)3 * (128 + 128) * 4 * 16;
-            static bool attr = false;
-            if (!attr) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(w8a8_mfma_big_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                attr = true;
-            }
-            hipLaunchKernelGGL(w8a8_mfma_big_kernel<128>, dim3((d.N + 127) / 128, (d.M + 127) / 128, d.batch), dim3(256), lds, stream, a);
-        } else {
-            const size_t lds = (size_t)3 * (128 + 64) * 4 * 16;
-            hipLaunchKernelGGL(w8a8_mfma_big_kernel<64>, dim3((d.N + 63) / 64, (d.M + 127) / 128, d.batch), dim3(256), lds, stream, a);
-        }
+        const long t64 = (long)((d.M + 127) / 128) * ((d.N + 63) / 64) * d.batch;
+        const bool wide = g_w8a8_big == 1 || g_w8a8_big == 3 || (g_w8a8_big == 0 && t128 >= 512);
+        const bool split = g_w8a8_big == 3 || g_w8a8_big == 4 || (g_w8a8_big == 0 && !wide && t64 < 512);
+        const size_t ring = (size_t)3 * (128 + (wide ? 128 : 64)) * 4 * 16;
+        const size_t lds = split ? ((2 * ring > (size_t)(wide ? 16 : 8) * 256 * 16) ? 2 * ring : (size_t)(wide ? 16 : 8) * 256 * 16) : ring;
+        const dim3 grid((d.N + (wide ? 127 : 63)) / (wide ? 128 : 64), (d.M + 127) / 128, d.batch);
+        auto launch = [&](auto kfn, int threads) {
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kfn, grid, dim3(threads), lds, stream, a);
+        };
+        if (wide && split) launch(w8a8_mfma_big_kernel<128, 2>, 512);
+        else if (wide) launch(w8a8_mfma_big_kernel<128, 1>, 256);
+        else if (split) launch(w8a8_mfma_big_kernel<64, 2>, 512);
+        else launch(w8a8_mfma_big_kernel<64, 1>, 256);
     } else if (!d.b_per_row && aligned && d.K >= 64) {
         dim3 grid((d.N + 63) / 64, (d.M + 63) / 64, d.batch);
         // wave quartets per tile: while the tiles do not fill the chip and every quartet keeps >= 2 k-steps
