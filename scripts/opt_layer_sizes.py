@@ -25,12 +25,16 @@ SIZES = {"OPT-125M": (768, 12, 3072, 12), "OPT-1.3B": (2048, 32, 8192, 24), "OPT
 for name, (E, H, F, NL) in SIZES.items():
     if only and name not in only:
         continue
-    m, pos = 1, 511
+    m, pos = (512, 0) if "--prefill" in sys.argv else (1, 511)  # --prefill: a 512-row prompt instead of a decode token
+    if m > 1:
+        NL = min(NL, 8)
     tgz = pos + m
     layers = [Int8OPTDecoderLayer(E, H, F, 512, m, dev, seed=7 + i) for i in range(NL)]
     hid0 = torch.randn(m, E, device=dev)
     hid = hid0.clone()
     mask = torch.zeros((m, tgz), device=dev)
+    if m > 1:
+        mask.masked_fill_(torch.triu(torch.ones(m, tgz, dtype=torch.bool, device=dev), diagonal=pos + 1), torch.finfo(torch.float32).min)
 
     def token():
         hid.copy_(hid0)

@@ -147,8 +147,9 @@ __global__ __launch_bounds__(64 * NW) void layernorm_q_rows_kernel(const float *
 }  // namespace
 
 int launch_layernorm_q(const float *x, const float *w, const float *b, void *out, int m, int n, hipStream_t stream, hipError_t *hip_err) {
-    // up to a row per CU: 16 waves per row from 1024 columns, 4 waves from 256 (the chain per wave must stay longer than the three barriers it costs)
-    const int nw = (m <= 256 && n >= 1024) ? 16 : ((m <= 256 && n >= 256) ? 4 : 0);
+    // up to a row per CU: 16 waves per row from 1024 columns; up to 1024 rows (four row-walking waves per SIMD): 4 waves per row from 256 columns (the chain
+    // per wave must stay longer than the three barriers it costs; 512 x 4096 -- an OPT-6.7B prompt -- took 57 us with a wave per row)
+    const int nw = (m <= 256 && n >= 1024) ? 16 : (((m <= 1024 && n >= 256) || (m <= 8192 && n >= 2048)) ? 4 : 0);  // (long rows: in rounds of 1024 workgroups, still ahead: 2048 x 4096 89 -> 50 us)
     if (nw) {
         const size_t lds = ((size_t)2 * n + (nw == 16 ? kSpecScratchFloats(16) : kSpecScratchFloats(4))) * sizeof(float);
         const void *kfn = nw == 16 ? reinterpret_cast<const void *>(layernorm_q_rows_kernel<16>) : reinterpret_cast<const void *>(layernorm_q_rows_kernel<4>);
