@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak test (not part of pytest): seeded random W8A8 problems through tce_w8a8_matmul -- every kernel behind it (MFMA tiles with 1 / 2 wave quartets, the
+"""Soak test (not part of pytest): seeded random W8A8 problems through tce_w8a8_matmul -- every kernel behind it (MFMA tiles with 1 / 2 wave quartets, the 128-row tiles in their four forced forms, the
 wave-per-column kernel for small M, the wave-per-output kernel for per-row operands with long rows, the generic kernel), every epilogue kind, batches, leading
 dimensions, `accumulate` -- against the CPU oracle, BIT FOR BIT.  usage: fuzz_w8a8.py [cases] [seed]"""
 import os, sys, time
@@ -24,7 +24,7 @@ def main():
     for case in range(cases):
         M = int(rng.choice([1, 2, 3, 4, 5, 8, 9, 16, 33, 64, 65, 108, 130, 300]))
         N = int(rng.choice([rng.integers(1, 40), rng.integers(40, 300), rng.integers(300, 1200)]))
-        K = int(rng.choice([16 * rng.integers(1, 12), 16 * rng.integers(12, 80), 16 * rng.integers(80, 300), rng.integers(1, 500)]))
+        K = int(rng.choice([16 * rng.integers(1, 12), 16 * rng.integers(12, 80), 16 * rng.integers(80, 300), rng.integers(1, 500), 64 * rng.integers(4, 40)]))
         if M * N * K > 4e8:
             M = 5
         per_row = bool(rng.integers(0, 5) == 0) and M * N * K < 3e7
@@ -49,9 +49,13 @@ def main():
                           ldb=ldb if ldb != K else 0, ldc=ldc if ldc != N else 0)
         mode = int(rng.choice([70, 70, 71, 72, 73]))
         capi.check(L.tce_w4a16_set_debug_mode(mode))
+        # the 128-row tiles (K % 64 == 0, K >= 256, a shared B): forced in one of their four forms on a part of the eligible cases
+        big = int(rng.choice([75, 75, 76, 77, 176, 177, 78]))
+        capi.check(L.tce_w4a16_set_debug_mode(big))
         capi.check(capi.w8a8_matmul(d, None))
         torch.cuda.synchronize()
         L.tce_w4a16_set_debug_mode(70)
+        L.tce_w4a16_set_debug_mode(75)
         got = out.cpu().numpy()
         ok = True
         for h in range(batch):
