@@ -80,6 +80,12 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} is missing: build it with `python -m tinychatengine_amd.build` "
                 "(hipcc, gfx950).  tinychatengine_amd has no CPU or PyTorch fallback."
             )
+        try:
+            # FIRST: the PyTorch wheel ships its own HIP runtime.  Loaded before it, this library would bring the system's copy into the process and the two
+            # runtimes do not share a device (hipStreamCreate: "no ROCm-capable device" -- seen with build() and smoke() called in one process).
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.tce_version.restype = C.c_int
         L.tce_last_error.restype = C.c_char_p
