@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libtce_hip.so")
+LIB_PATH = os.environ.get("TCE_LIB_PATH") or os.path.join(_PKG, "lib", "libtce_hip.so")  # (TCE_LIB_PATH: another build of the same library, for A/B runs)
 
 TCE_OK = 0
 TCE_ERR_BAD_ARG = -1

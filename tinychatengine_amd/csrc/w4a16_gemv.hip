@@ -245,7 +245,7 @@ __global__ __launch_bounds__(64 * WN * WK, (MB * ROWS * DEPTH >= 8 ? 2 : (MB * R
             x_write(base);
         }
     }
-    __syncthreads();
+    lds_barrier();  // (publishes the x image; the weight loads issued above stay in flight -- a __syncthreads would wait for all of them)
     if constexpr (XFIRST) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) issue(st[d], d);
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(64 * WN * WK, (MB * ROWS * DEPTH >= 8 ? 2 : (MB * R
                 sxt[((m * T + t) * WK + wk) * 64 + lane] = xs4[0];
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
 
     float acc[ROWS][MB][4];  // the 4 accumulator registers of the 4x4x4 MFMA; the lane's own dot product is [lane & 3]
