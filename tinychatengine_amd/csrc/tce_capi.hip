@@ -949,7 +949,7 @@ static int tune_plan_launches(const std::vector<tce_w4a16_desc> &descs, const st
         (void)hipGetLastError();
         return us;
     };
-    static const int cands[][4] = {{2, 4, 1, 2}, {3, 4, 1, 2}, {4, 4, 1, 1}, {2, 8, 1, 2}, {2, 4, 1, 1}, {1, 4, 1, 2}, {1, 4, 1, 1}, {4, 8, 1, 1},
+    static const int cands[][4] = {{2, 4, 1, 2}, {3, 4, 1, 2}, {4, 4, 1, 1}, {2, 8, 1, 2}, {2, 4, 1, 1}, {2, 4, 1, 3}, {4, 4, 1, 2}, {1, 4, 1, 2}, {1, 4, 1, 1}, {4, 8, 1, 1},
                                    // (geometries that split K between waves add in another order: a token's outputs then drift by several binary16 steps through 32
                                    //  layers -- 3e-3 of the largest logit in the bench -- so they are not candidates: a tuned plan computes the untuned plan's bits)
                                    {2, 16, 0, 0}, {22, 8, 0, 3}, {4, 16, 0, 0}};  // (waves_k = 0: the persistent kernel of w4a16_gemv_stream.hip -- rows, waves per workgroup, depth)
