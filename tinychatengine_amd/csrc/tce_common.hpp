@@ -150,6 +150,10 @@ __device__ __forceinline__ half_t rmsnorm_out(half_t x, float rs, float gamma) {
 // from there -- rmsnorm_slots_finish() below is the part from `slot[]` on; rmsnorm_rs_block() is the whole thing for callers that
 // read the row through `load_piece(p)` (the row's p-th piece as 8 halves): wave w fills slots 64 c + lane for c = w, w + nwaves, ...
 // `part` = 4 KiB of LDS holding slot[]; both contain two barriers (the second one frees `part` for reuse).
+// A workgroup barrier that publishes LDS writes and leaves global loads IN FLIGHT: __syncthreads() carries a fence the compiler implements as vmcnt(0) -- every
+// barrier of a kernel that requested its weights ahead would wait for the last of them.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ float rmsnorm_piece_sum(half8_t v) {
     float s = 0.f;
 #pragma unroll
@@ -157,13 +161,13 @@ __device__ __forceinline__ float rmsnorm_piece_sum(half8_t v) {
     return s;
 }
 __device__ __forceinline__ float rmsnorm_slots_finish(const float *part, int n, float eps, int lane) {
-    __syncthreads();
+    lds_barrier();  // (LDS only: the fused GEMV has its weight loads in flight here)
     float tot = 0.f;
 #pragma unroll
     for (int c = 0; c < 16; ++c) tot += part[c * 64 + lane];
     tot = wave_sum_dpp_lane63(tot);
     tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), 63));
-    __syncthreads();
+    lds_barrier();
     return 1.0f / sqrtf(tot / (float)n + eps);
 }
 template <typename LoadPiece>
@@ -292,9 +296,6 @@ __device__ __forceinline__ float sequential_sum(const float *vals, int n, int la
         return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s)));
     }
 }
-// A workgroup barrier that publishes LDS writes and leaves global loads IN FLIGHT: __syncthreads() carries a fence the compiler implements as vmcnt(0) -- every
-// barrier of a kernel that requested its weights ahead would wait for the last of them.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // The form for MANY waves of a CU walking sums at once (sequential_sum_speculated): the four ds_read_b128 per 16 values of the form above occupy the LDS for
 // ~32 cycles per wave -- with 16 waves the LDS, not the adders, sets the pace.  Here a lane of every 16-lane row reads ONE value (a single ds_read_b32 brings 16
