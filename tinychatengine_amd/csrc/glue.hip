@@ -65,7 +65,14 @@ __global__ __launch_bounds__(64) void layernorm_q_kernel(const float *x, const f
     const float *xr = x + (size_t)blockIdx.x * n;
     int8_t *orow = out + (size_t)blockIdx.x * n;
     const int n4 = n >> 2;  // n % 4 == 0
-    for (int p = lane; p < n4; p += 64) reinterpret_cast<float4_t *>(row)[p] = reinterpret_cast<const float4_t *>(xr)[p];
+    for (int p0 = lane; p0 < n4; p0 += 64 * 4) {  // four pieces per lane requested at once
+        float4_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const float4_t *>(xr)[p0 + 64 * u < n4 ? p0 + 64 * u : n4 - 1];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (p0 + 64 * u < n4) reinterpret_cast<float4_t *>(row)[p0 + 64 * u] = v[u];
+    }
     // the affine parameters of the lane's outputs, requested now (they are needed behind the two chains; n <= 1024: 16 per lane)
     constexpr int PF = 16;
     float pw[PF], pb[PF];
@@ -120,7 +127,14 @@ __global__ __launch_bounds__(64 * NW) void layernorm_q_rows_kernel(const float *
     int8_t *orow = out + (size_t)blockIdx.x * n;
     float *dev = row + n, *sp = row + 2 * n;
     const int n4 = n >> 2;  // n % 4 == 0
-    for (int p = tid; p < n4; p += 64 * NW) reinterpret_cast<float4_t *>(row)[p] = reinterpret_cast<const float4_t *>(xr)[p];
+    for (int p0 = tid; p0 < n4; p0 += 64 * NW * 4) {  // four pieces per thread requested at once (one per loop iteration: a memory round trip each)
+        float4_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const float4_t *>(xr)[p0 + 64 * NW * u < n4 ? p0 + 64 * NW * u : n4 - 1];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (p0 + 64 * NW * u < n4) reinterpret_cast<float4_t *>(row)[p0 + 64 * NW * u] = v[u];
+    }
     lds_barrier();
     float mean = sequential_sum_speculated<NW, ROWB>(row, n, sp, wave, lane);
     mean /= (float)n;
@@ -204,10 +218,24 @@ __global__ __launch_bounds__(320) void opt_softmax_q_kernel(const float *scores,
     const float v000 = scores[0] + mask[0];
     // the masked scores into e[] and their maximum
     float rmax = -__builtin_inff();
-    for (int k = lane; k < tgz; k += 64) {
-        const float v = s[k] + mk[k];
-        e[k] = v;
-        rmax = v > rmax ? v : rmax;
+    // eight keys' scores and mask values per lane requested at once (a loop of one dependent pair of loads per 64 keys walked a 512-key row in eight memory
+    // round trips: most of this launch's time at prompt sizes)
+    for (int k0 = lane; k0 < tgz; k0 += 64 * 8) {
+        float sv[8], mv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + 64 * u < tgz ? k0 + 64 * u : tgz - 1;
+            sv[u] = s[k];
+            mv[u] = mk[k];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (k0 + 64 * u < tgz) {
+                const float v = sv[u] + mv[u];
+                e[k0 + 64 * u] = v;
+                rmax = v > rmax ? v : rmax;
+            }
+        }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
