@@ -260,6 +260,33 @@ __global__ __launch_bounds__(320) void opt_softmax_q_kernel(const float *scores,
     const bool independent = row == 0 || rmax >= 1.0f;  // wave-uniform
     if (wave < 4 && lane == 0) waits[wave] = live && !independent;
     __syncthreads();
+    if constexpr (!BCAST) {
+        // MANY rows (a prompt): the launch is bound by the instructions its waves issue, and a row's sum is one wave instruction per key with ONE lane at work.
+        // The DPP row shifts act inside every 16-lane row of a wave on its own, so wave 0 walks the FOUR rows' sums of the workgroup at once -- lanes 0 / 16 /
+        // 32 / 48 each add their row's exponentials in key order (the same additions in the same order: the same bits), a quarter of the sum instructions.
+        float *sums4 = reinterpret_cast<float *>(waits + 4);
+        const bool need = (waits[0] | waits[1] | waits[2] | waits[3]) != 0;  // workgroup-uniform: somebody needs row (0, 0)'s first probability
+        if (need) {
+            if (wave == 4) {
+                const float sum = finish_stats(v000);
+                if (lane == 0) *first_p = (float)((double)e[0] / ((double)sum + 1e-10));
+            }
+            __syncthreads();
+        }
+        if (wave < 4 && live) {
+            const float init = independent ? (row == 0 ? v000 : rmax) : *first_p;
+            const float mx = rmax > init ? rmax : init;
+            for (int k = lane; k < tgz; k += 64) e[k] = expf(e[k] - mx);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const float acc = sequential_sum_lane0(sm + (size_t)(lane >> 4) * tgzp, tgz, lane, [](float v) { return v; });  // (a per-lane base: row lane / 16)
+            if ((lane & 15) == 0) sums4[lane >> 4] = acc;
+        }
+        __syncthreads();
+        if (wave < 4 && live) write_row(sums4[wave]);
+        return;
+    }
     if (wave == 4) {
         if (waits[0] | waits[1] | waits[2] | waits[3]) {  // somebody needs row (0, 0)'s first probability
             const float sum = finish_stats(v000);
@@ -286,7 +313,7 @@ __global__ __launch_bounds__(256) void opt_kv_append_kernel(const int8_t *k, con
 
 int launch_opt_softmax_q(const float *scores, const float *mask, void *probs, int heads, int sq, int tgz, int ldp, hipStream_t stream, hipError_t *hip_err) {
     const int rows = heads * sq;
-    const size_t lds = ((size_t)5 * ((tgz + 3) & ~3) + 8) * sizeof(float);
+    const size_t lds = ((size_t)5 * ((tgz + 3) & ~3) + 12) * sizeof(float);  // five rows | row (0, 0)'s first probability | four flags | four sums
     const bool bcast = (long long)((rows + 3) / 4) * 5 <= kSeqSumBcastMaxWaves;
     auto kfn = bcast ? opt_softmax_q_kernel<true> : opt_softmax_q_kernel<false>;
     if (lds > 64 * 1024) {
