@@ -9,18 +9,24 @@
 // latency each.  Here every workgroup recomputes the (tiny) normalisation for its own use and then produces its slice of the
 // output rows of up to TCE_MAX_GROUP linears: one launch.
 //
-// Two kernels.  lnq_w8a8_kernel<2, 2, 4>: the OPT-125M form above -- a workgroup of 4 waves per 8 output rows, the first two 16-byte pieces per lane of a wave's
-// two rows requested before the sums.  lnq_w8a8_wide_kernel (k >= 1024: OPT-1.3B / 6.7B, where a row's two sequential sums are 2 x 4096 dependent additions -- 22 us
-// for one wave -- and a launch's int8 weights are 50-67 MB): ONE workgroup of 16 waves per CU, each normalises once and owns a contiguous run of output rows per
-// wave; the two sums are walked by all 16 waves at once (sequential_sum_speculated, tce_common.hpp: every wave adds its sixteenth of the row from 64 candidate
-// running values, wave 0 then picks the lanes that started from the true ones -- the additions that count are the reference's, in its order); a wave requests its
-// first FOUR rows completely right after the activation row (16 x 16 bytes per lane: 67 MB across the chip -- all of OPT-6.7B's fc1), so the weights stream from
-// memory WHILE the sums are walked, and streams what is left of its run afterwards with eight 16-byte pieces per lane in flight.  Measured per launch at OPT-6.7B (q/k/v 3 x 4096 x 4096, fc1 16384 x 4096): 87 / 94 us for the 8-rows-per-workgroup
-// form (1536-2048 workgroups: the sums are walked in several rounds), 49 / 53 us with one round of 4-wave workgroups (three per CU: their three chains share a SIMD).
+// Two kernels.
+// lnq_w8a8_kernel<2, 2, 4>: the OPT-125M form above -- a workgroup of 4 waves per 8 output rows, the first two 16-byte pieces per lane of a wave's two rows requested
+// before the sums; ONE normalised row (the decode token) has its two sums walked by the four waves together (sequential_sum_speculated, below).
+// lnq_w8a8_wide_kernel (k >= 1024: OPT-1.3B / 6.7B, where a row's two sequential sums are 2 x 4096 dependent additions -- 22 us for one wave -- and a launch's
+// int8 weights are 50-67 MB): ONE workgroup of 16 waves per CU, each normalises once and owns a contiguous run of output rows per wave.
+//   * the two sums are walked by all 16 waves at once (sequential_sum_speculated, tce_common.hpp: every wave adds its sixteenth of the row from 64 candidate
+//     running values, wave 0 then picks the lanes that started from the true ones -- the additions that count are the reference's, in its order);
+//   * a wave's first four rows are held in registers (16 x 16 bytes per lane: 67 MB across the chip -- all of OPT-6.7B's fc1), requested in FOUR batches at four
+//     points of the sums (a CU accepts ~64 KB of requests; with everything requested up front the waves that walk the sums stood in the queue), so the weights
+//     stream from memory WHILE the sums are walked; what is left of a longer run is streamed afterwards, eight 16-byte pieces per lane in flight;
+//   * its barriers leave global loads in flight (lds_barrier), its bias words are requested by one unconditional load and converted late, and the build fails if
+//     it spills a vector register (build.py): each of the three had put the first sum behind the last weight (debug mode 85 + scripts/lnq_wide_phases.py).
+// Per launch at OPT-6.7B (q/k/v 3 x 4096 x 4096, fc1 16384 x 4096): 87 / 94 us for the 8-rows-per-workgroup form (1536-2048 workgroups: the sums are walked in
+// several rounds), 49 / 53 us with one round of 4-wave workgroups (three per CU: their three chains share a SIMD), 23-24 / 24-25 us as it stands.
 //
 // BIT-EXACT against LayerNormQ::forward followed by int8_ref_matmul (kernels/ref/matmul_ref_int8.cc:11-35):
-//   * the reference's two row sums are sequential fp32 additions, so they are added in order (every lane holds the same accumulator and
-//     gets the values by LDS broadcast reads, one dependent add per element; a wave per row for m > 1); the division, multiply and add of the output are separate roundings (-ffp-contract=off), std::round = half away
+//   * the reference's two row sums are sequential fp32 additions, so they are added in order (a wave per row for m > 1 in the 4-wave form: every lane holds
+//     the same accumulator and gets the values by LDS broadcast reads; else speculated across the waves, which changes when an addition is done, not which); the division, multiply and add of the output are separate roundings (-ffp-contract=off), std::round = half away
 //     from zero -- the same code as tce_layernorm_q (glue.hip);
 //   * the dot products are int32 (v_dot4_i32_i8), exact in any order;
 //   * the epilogue is the int8 path's: (float)acc, * alpha, + (float)bias * beta, each rounded separately, roundf, clamp.
