@@ -112,6 +112,19 @@ def test_attention_and_glue_argument_validation_needs_no_gpu(built):
     assert L.tce_opt_softmax_q(vp(p), vp(p), vp(p), 2, 2, 8, 4, None) == capi.TCE_ERR_BAD_ARG            # ld_probs < tgz
     assert L.tce_opt_softmax_q(vp(p), vp(p), vp(p), 2, 2, 9000, 0, None) == capi.TCE_ERR_UNSUPPORTED_SHAPE
     assert L.tce_opt_kv_append(vp(p), vp(p), vp(p), vp(p), 2, 64, 4, 62, 64, None) == capi.TCE_ERR_BAD_ARG  # pos + sq > max_keys
+    # the one-launch OPT attention: heads of 64 or 128 (OPT-125M / 1.3B, OPT-6.7B), a decode path (m <= 8), 16-byte pieces
+    oa = lambda hd=64, m=1, pos=0, mk=64, ld=0, q=p: L.tce_opt_attention_decode(vp(q), vp(p), vp(p), vp(p), vp(p), vp(p), vp(p), 2, hd, m, pos, mk, ld, 1.0e-3, 7.8e-3, None)
+    assert oa(hd=96) == capi.TCE_ERR_UNSUPPORTED_SHAPE and "64 or 128" in capi.last_error()
+    assert oa(m=9) == capi.TCE_ERR_UNSUPPORTED_SHAPE
+    assert oa(pos=60, m=8) == capi.TCE_ERR_BAD_ARG               # pos + m > max_keys
+    assert oa(mk=72, pos=1) == capi.TCE_ERR_UNSUPPORTED_SHAPE    # max_keys % 16
+    assert oa(hd=128, ld=200) == capi.TCE_ERR_UNSUPPORTED_SHAPE  # ld < heads * 128
+    assert oa(q=p + 8) == capi.TCE_ERR_UNSUPPORTED_SHAPE         # 16-byte aligned pointers
+    assert L.tce_opt_attention_decode(None, vp(p), vp(p), vp(p), vp(p), vp(p), vp(p), 2, 64, 1, 0, 64, 0, 1.0e-3, 7.8e-3, None) == capi.TCE_ERR_BAD_ARG
+    # tce_layernorm_q: n % 4, n <= 8192; the LayerNormQ + linears group: a decode path, k % 16
+    assert L.tce_layernorm_q(vp(p), vp(p), vp(p), vp(p), 2, 6, None) == capi.TCE_ERR_UNSUPPORTED_SHAPE
+    assert L.tce_layernorm_q(vp(p), vp(p), vp(p), vp(p), 2, 8196, None) == capi.TCE_ERR_UNSUPPORTED_SHAPE
+    assert L.tce_layernorm_q(vp(p), vp(p), vp(p), vp(p), 0, 64, None) == capi.TCE_ERR_BAD_ARG
 
 
 def test_adapter_exports_the_reference_member_functions(built):
