@@ -47,7 +47,7 @@ extern "C" {
 
 #define TCE_API __attribute__((visibility("default")))
 
-#define TCE_VERSION 106 /* 0.1.6: TCE_PLAN_TUNED; 0.1.5: tce_opt_attention_decode; 0.1.4: tce_attention_prefill_f16 (0.1.3: tce_attention_decode_step_gqa_f16, TCE_PLAN_OVERLAPPED; 0.1.2: tce_w4a16_desc.scratch; 0.1.1: .prepacked, tce_w4a16_prepack*) */
+#define TCE_VERSION 107 /* 0.1.7: decode on the pre-packed copy (int8 contraction), tce_w4a16_set_gemv_i8; 0.1.6: TCE_PLAN_TUNED; 0.1.5: tce_opt_attention_decode; 0.1.4: tce_attention_prefill_f16 (0.1.3: tce_attention_decode_step_gqa_f16, TCE_PLAN_OVERLAPPED; 0.1.2: tce_w4a16_desc.scratch; 0.1.1: .prepacked, tce_w4a16_prepack*) */
 
 /* error codes (return values) */
 #define TCE_OK 0
@@ -89,8 +89,9 @@ typedef struct tce_w4a16_desc {
     float rmsnorm_eps;
     int32_t reserved2;
     const void *prepacked;                /* NULL = none.  The q4_mfma copy of this linear's weights built by tce_w4a16_prepack
-                                             (same N, K, group size): the prefill GEMM for large M reads it instead of
-                                             qweight / scales / zeros (which must still be valid: every other M uses them) */
+                                             (same N, K, group size): the prefill GEMM for large M AND the decode kernel for M <= 4
+                                             (round 4: csrc/w4a16_gemv_i8.hip) read it instead of qweight / scales / zeros (which must
+                                             still be valid: every other M, and the fused RMSNorm prologue, use them) */
     void *scratch;                        /* NULL = none.  tce_w4a16_gemm_scratch_bytes() bytes of device memory, 256-byte aligned, its first 4096
                                              bytes ZEROED once by the caller (every call leaves them zero): lets the pre-packed GEMM cut the k range of
                                              a launch with few tiles (M = 512 at N = 4096 is 128 tiles for 256 CUs) across workgroups
@@ -437,7 +438,7 @@ TCE_API const char *tce_build_info(void);
  * "last error", and the next launch's check here would return it as TCE_ERR_HIP.  Returns the HIP error code it dropped. */
 TCE_API int tce_reset_last_error(void);
 /* Which kernel family (and, for the GEMM, which tile and form) tce_w4a16_forward would run for this descriptor, as text:
- * "gemv passes=P kernel=row-block|persistent" | "small-batch slices=S" | "gemm-pk tile=128xC quartets=Q group=G" |
+ * "gemv passes=P kernel=row-block|persistent" | "gemv-i8 rows-per-pass=R group=G" | "small-batch slices=S" | "gemm-pk tile=128xC quartets=Q group=G" |
  * "gemm-dma tile=RxC quartets=Q group=G" | "gemm tile=RxC".  Launches nothing and
  * makes no HIP call (works without a GPU); a shape the chosen GEMM form cannot hold in LDS still falls back at launch time. */
 TCE_API int tce_w4a16_describe_dispatch(const tce_w4a16_desc *d, char *buf, int buf_len);
@@ -448,6 +449,12 @@ TCE_API int tce_w4a16_describe_dispatch(const tce_w4a16_desc *d, char *buf, int 
  *                 workgroup (one workgroup per CU), depth in {0 = auto, 2, 3} units in flight.
  * TCE_ERR_BAD_ARG if that variant was not compiled. */
 TCE_API int tce_w4a16_set_gemv_config(int rows_per_wave, int waves_n, int waves_k, int depth);
+/* The decode kernel on pre-packed copies (csrc/w4a16_gemv_i8.hip: M <= 4 rows as an exact int8 contraction on the matrix pipe; taken by tce_w4a16_forward /
+ * _forward_group / plans whenever every descriptor of the launch carries `prepacked`, K % 128 == 0 and no fused RMSNorm prologue is asked for; group sizes 64 / 32:
+ * M <= 2 / M = 1).  mode 0 = that rule, 1 = off (the fp16 GEMV kernels on the q4_6 arrays take those launches: A/B runs); rows = 16-row tiles per wave for the
+ * M = 1, K <= 8192 launches: 0 = the rule (two from 1024 tiles up), 1, 2.  A row's arithmetic depends on K, the group size and the rows per pass only -- never on N or on
+ * `rows`: column shards and grouped launches are bit-identical to the plain launch.  Process-wide; results do not depend on it beyond the kernel family. */
+TCE_API int tce_w4a16_set_gemv_i8(int mode, int tiles_per_wave);
 /* Tuning / diagnostics switch for the sweeps under scripts/ (process-wide, not thread-safe, never needed by a host):
  *   0..4     GEMV kernels, M = 1: 0 normal; 1 stream the weights only (no unpack, no dot products: the memory-side ceiling
  *            of the access pattern, outputs meaningless); 2 normal math plus per-wave timestamps into the debug buffer;

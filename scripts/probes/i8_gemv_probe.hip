@@ -1,0 +1,652 @@
+// i8_gemv_probe.hip -- round-4 prototype of the decode GEMV as an int8-MFMA contraction (Next #1: "cheaper math per byte").
+//
+// Idea measured here before it goes into the library:
+//   * weights: 16-row tiles; lane (i = l % 16, kq = l / 16) holds the 16-byte chunk 4u + kq of row i of the tile (u = 128-wide k unit): its
+//     32 nibbles become the A operands of two v_mfma_i32_16x16x64_i8 (even nibbles, odd nibbles) as signed 16 * (q - 8) bytes:
+//     xor 0x88888888, and 0xF0F0F0F0, shift, and  -- 4 VALU per 8 weights, no unpack to halves, no zero-point term;
+//   * activations: each wave converts the 128 * UW activations IT consumes to a 30-bit fixed-point integer under one block exponent and splits it
+//     into four balanced base-256 digit planes; the planes are the COLUMNS of the B operand, so one MFMA contracts all four planes at once and the
+//     products are exact int32;
+//   * per quantization group one v_cvt_f32_i32 + one fma per output register applies the fp16 group scale in fp32.
+// LAYOUT 0 reads a tile-major re-layout of q4_6 (a wave's load instruction is 1 KiB of consecutive bytes); LAYOUT 1 reads q4_6 as loaded (16 rows x 64 bytes per
+// load instruction): does the scattered form stream as fast?
+//
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o scripts/probes/i8_gemv_probe scripts/probes/i8_gemv_probe.hip   (run through gpurun)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+typedef _Float16 half_t;
+typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
+typedef int int4v_t __attribute__((ext_vector_type(4)));
+typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
+
+#define CK(x)                                                                                   \
+    do {                                                                                        \
+        hipError_t e_ = (x);                                                                    \
+        if (e_ != hipSuccess) {                                                                 \
+            fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(1);                                                                            \
+        }                                                                                       \
+    } while (0)
+
+struct Args {
+    const void *w;        // LAYOUT 0: [N/16][U][64][16 B]; LAYOUT 1: q4_6 [N][K/2]
+    const half_t *sc;     // LAYOUT 0: [N/16][U][16]; LAYOUT 1: [N][U]
+    const half_t *x;      // [K]
+    half_t *y;            // [N]
+    int N, K, U;          // U = K / 128
+    int bytes_w, bytes_s;
+    unsigned long long *dbg;  // MODE 2: 5 timestamps per wave
+};
+
+__device__ inline unsigned long long wall_clock64_() { return __builtin_readcyclecounter(); }
+template <int DPP_CTRL>
+__device__ inline float dpp_add(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), DPP_CTRL, 0xF, 0xF, false);
+    return v + __builtin_bit_cast(float, t);
+}
+
+template <int ROWS, int UW, int LAYOUT, int MODE, int MAXT>
+__global__ __launch_bounds__(MAXT) void i8_gemv(const Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wk = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int WK = blockDim.x >> 6;
+    const int u0 = wk * UW;
+    const int i = lane & 15, kq = lane >> 4;
+    const int tile0 = blockIdx.x * ROWS;
+    const int U = a.U;
+
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.w), 0, a.bytes_w, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(a.sc), 0, a.bytes_s, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(a.x), 0, a.K * 2, 0x00020000);
+
+    // ---- 1. every weight byte this wave will use is requested now ----
+    uint4_t w[ROWS][UW];
+    uint2_t sc[ROWS][UW];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int tile = tile0 + r;
+#pragma unroll
+        for (int t = 0; t < UW; ++t) {
+            const int u = u0 + t;
+            if constexpr (LAYOUT == 0) {
+                const int so = (tile * U + u0) * 1024;                    // scalar
+                w[r][t] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16 + t * 1024, so, /*nt*/ 2);
+            } else {
+                const int so = tile * 16 * (a.K >> 1) + u0 * 64;          // scalar: tile's first row, this wave's first chunk
+                w[r][t] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, i * (a.K >> 1) + kq * 16 + t * 64, so, /*nt*/ 2);
+            }
+            (void)u;
+        }
+    }
+    if constexpr (MODE != 1) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int tile = tile0 + r;
+#pragma unroll
+            for (int t = 0; t < UW; ++t) {
+                if constexpr (LAYOUT == 0) {
+                    const int so = (tile * U + u0) * 32;
+                    sc[r][t] = __builtin_bit_cast(uint2_t, __builtin_amdgcn_raw_buffer_load_b64(rs_s, kq * 8 + t * 32, so, 0));
+                } else {
+                    unsigned short h[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) h[q] = __builtin_amdgcn_raw_buffer_load_b16(rs_s, ((kq * 4 + q) * U + t) * 2, (tile * 16 * U + u0) * 2, 0);
+                    sc[r][t] = uint2_t{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    float acc[ROWS][4];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[r][q] = 0.f;
+    int sh = 0;
+
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+            for (int t = 0; t < UW; ++t) acc[r][0] += (float)((w[r][t][0] ^ w[r][t][1] ^ w[r][t][2] ^ w[r][t][3]) & 0xFFu);
+    } else {
+        // ---- 2. this wave's activations -> four digit planes in its own LDS region (no workgroup barrier) ----
+        constexpr int XC = (UW * 16 + 63) / 64;  // 8-element chunks per lane
+        unsigned *planes = reinterpret_cast<unsigned *>(smem) + wk * (UW * 128);  // [UW][2][4][4 planes][4 dwords]
+        uint4_t xv[XC];
+#pragma unroll
+        for (int c = 0; c < XC; ++c) xv[c] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (lane + 64 * c) * 16, u0 * 256, 0);
+        unsigned mx = 0;
+#pragma unroll
+        for (int c = 0; c < XC; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned v = xv[c][q] & 0x7FFF7FFFu;
+                const unsigned m2 = v > (v << 16 | v >> 16) ? v : (v << 16 | v >> 16);  // high half = max of the two halves
+                mx = mx > (m2 >> 16) ? mx : (m2 >> 16);
+            }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const unsigned other = (unsigned)__shfl_xor((int)mx, o);
+            mx = mx > other ? mx : other;
+        }
+        const int E = (int)(mx >> 10);  // exponent field of the largest magnitude; value < 2^(E - 14)
+        sh = 44 - E;                    // |x * 2^sh| < 2^30
+        const float scale = __builtin_bit_cast(float, (unsigned)(127 + sh) << 23);
+#pragma unroll
+        for (int c = 0; c < XC; ++c) {
+            unsigned d[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const half_t lo = __builtin_bit_cast(half_t, (unsigned short)(xv[c][q] & 0xFFFFu));
+                const half_t hi = __builtin_bit_cast(half_t, (unsigned short)(xv[c][q] >> 16));
+                d[2 * q] = ((unsigned)(int)((float)lo * scale) + 0x00808080u) ^ 0x00808080u;
+                d[2 * q + 1] = ((unsigned)(int)((float)hi * scale) + 0x00808080u) ^ 0x00808080u;
+            }
+            const int cc = lane + 64 * c;
+            const int tu = cc >> 4, kq_x = (cc >> 2) & 3, s = cc & 3;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const unsigned t0 = __builtin_amdgcn_perm(d[h + 2], d[h], 0x05010400u);      // (e0.b0, e2.b0, e0.b1, e2.b1)
+                const unsigned t1 = __builtin_amdgcn_perm(d[h + 2], d[h], 0x07030602u);      // (e0.b2, e2.b2, e0.b3, e2.b3)
+                const unsigned t2 = __builtin_amdgcn_perm(d[h + 6], d[h + 4], 0x05010400u);
+                const unsigned t3 = __builtin_amdgcn_perm(d[h + 6], d[h + 4], 0x07030602u);
+                const unsigned p0 = __builtin_amdgcn_perm(t2, t0, 0x05040100u);
+                const unsigned p1 = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+                const unsigned p2 = __builtin_amdgcn_perm(t3, t1, 0x05040100u);
+                const unsigned p3 = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+                const int base = (((tu * 2 + h) * 4 + kq_x) * 4) * 4 + s;
+                if (XC * 64 == UW * 16 || cc < UW * 16) {
+                    planes[base + 0] = p0;
+                    planes[base + 4] = p1;
+                    planes[base + 8] = p2;
+                    planes[base + 12] = p3;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- 3. contraction ----
+        const uint4_t *bimg = reinterpret_cast<const uint4_t *>(planes);
+        const int jb = lane & 3;  // columns 4..15 re-read columns 0..3 (broadcast reads; their outputs are discarded)
+#pragma unroll
+        for (int t = 0; t < UW; ++t) {
+            const int4v_t b0 = __builtin_bit_cast(int4v_t, bimg[((t * 2 + 0) * 4 + kq) * 4 + jb]);
+            const int4v_t b1 = __builtin_bit_cast(int4v_t, bimg[((t * 2 + 1) * 4 + kq) * 4 + jb]);
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                int4v_t alo, ahi;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned x8 = w[r][t][q] ^ 0x88888888u;
+                    ahi[q] = (int)(x8 & 0xF0F0F0F0u);
+                    alo[q] = (int)((x8 << 4) & 0xF0F0F0F0u);
+                }
+                int4v_t dd = int4v_t{0, 0, 0, 0};
+                dd = __builtin_amdgcn_mfma_i32_16x16x64_i8(alo, b0, dd, 0, 0, 0);
+                dd = __builtin_amdgcn_mfma_i32_16x16x64_i8(ahi, b1, dd, 0, 0, 0);
+                const half_t s0 = __builtin_bit_cast(half_t, (unsigned short)(sc[r][t][0] & 0xFFFFu));
+                const half_t s1 = __builtin_bit_cast(half_t, (unsigned short)(sc[r][t][0] >> 16));
+                const half_t s2 = __builtin_bit_cast(half_t, (unsigned short)(sc[r][t][1] & 0xFFFFu));
+                const half_t s3 = __builtin_bit_cast(half_t, (unsigned short)(sc[r][t][1] >> 16));
+                acc[r][0] = __builtin_fmaf((float)dd[0], (float)s0, acc[r][0]);
+                acc[r][1] = __builtin_fmaf((float)dd[1], (float)s1, acc[r][1]);
+                acc[r][2] = __builtin_fmaf((float)dd[2], (float)s2, acc[r][2]);
+                acc[r][3] = __builtin_fmaf((float)dd[3], (float)s3, acc[r][3]);
+            }
+        }
+    }
+
+    // ---- 4. planes -> value, K blocks -> row, store ----
+    const int j = lane & 15;
+    // 2^(8 j) * 2^(-sh) / 16 for the four plane columns, 0 for the discarded columns
+    const float cj = j < 4 ? __builtin_bit_cast(float, (unsigned)(127 + 8 * j - sh - 4) << 23) : 0.f;
+    float *red = reinterpret_cast<float *>(smem + (size_t)WK * UW * 512);  // [WK][ROWS][16]
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v = acc[r][q] * cj;
+            if constexpr (MODE == 1) v = acc[r][q];
+            v = dpp_add<0xB1>(v);  // quad_perm [1,0,3,2]
+            v = dpp_add<0x4E>(v);  // quad_perm [2,3,0,1]
+            if (j == 0) red[(wk * ROWS + r) * 16 + kq * 4 + q] = v;
+        }
+    __syncthreads();
+    if (tid < ROWS * 16) {
+        float v = 0.f;
+        for (int k2 = 0; k2 < WK; ++k2) v += red[k2 * ROWS * 16 + tid];
+        const int row = tile0 * 16 + tid;
+        if (row < a.N) a.y[row] = (half_t)v;
+    }
+}
+
+
+// ---- version 2: x and scales requested BEFORE the weights (loads retire in order: a wait for x must not be a wait for every weight byte); one epilogue per FOUR units:
+// unit c of a pass feeds columns 4c..4c+3 only (the other lanes' B registers stay zero under the exec mask), so all 16 output columns are live and the
+// cvt + scale runs once per pass; UW = 4 * NP units per wave.
+template <int DPP_CTRL, int ROW_MASK = 0xF>
+__device__ inline unsigned dpp_max_u32(unsigned v) {
+    const unsigned t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, DPP_CTRL, ROW_MASK, 0xF, false);
+    return v > t ? v : t;
+}
+
+// ---- version 3: v2 + max by DPP, fused convert-multiply, B operands read before the weights arrive, two accumulator chains, unrolled final sum ----
+template <int ROWS, int NP, int MODE, int MAXT>
+__global__ __launch_bounds__(MAXT) void i8_gemv2(const Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int UW = 4 * NP;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wk = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int WK = blockDim.x >> 6;
+    const int u0 = wk * UW;
+    const int kq = lane >> 4, j = lane & 15;
+    const int tile0 = blockIdx.x * ROWS;
+    const int U = a.U;
+    unsigned long long ts[5] = {0, 0, 0, 0, 0};
+    if constexpr (MODE == 2) ts[0] = wall_clock64();
+
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.w), 0, a.bytes_w, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(a.sc), 0, a.bytes_s, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(a.x), 0, a.K * 2, 0x00020000);
+
+    uint4_t xv[NP];
+    uint2_t sc[ROWS][NP];
+    uint4_t w[ROWS][UW];
+    if constexpr (MODE != 1) {
+#pragma unroll
+        for (int c = 0; c < NP; ++c) xv[c] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (lane + 64 * c) * 16, u0 * 256, 0);
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+            for (int ps = 0; ps < NP; ++ps)
+                sc[r][ps] = __builtin_bit_cast(uint2_t, __builtin_amdgcn_raw_buffer_load_b64(rs_s, ((4 * ps + (j >> 2)) * 16 + 4 * kq) * 2, ((tile0 + r) * U + u0) * 32, 0));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int t = 0; t < UW; ++t) w[r][t] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16 + t * 1024, ((tile0 + r) * U + u0) * 1024, /*nt*/ 2);
+    __builtin_amdgcn_sched_barrier(0);
+
+    float acc[ROWS][4];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[r][q] = 0.f;
+    int sh = 0;
+
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+            for (int t = 0; t < UW; ++t) acc[r][0] += (float)((w[r][t][0] ^ w[r][t][1] ^ w[r][t][2] ^ w[r][t][3]) & 0xFFu);
+    } else {
+        unsigned *planes = reinterpret_cast<unsigned *>(smem) + wk * (UW * 128);  // [UW][2][4][4 planes][4 dwords]
+        if constexpr (MODE != 3) {
+        unsigned mx = 0;
+#pragma unroll
+        for (int c = 0; c < NP; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned v = xv[c][q] & 0x7FFF7FFFu;
+                const unsigned m2 = v > (v << 16) ? v : (v << 16);  // the high half holds max(hi, lo) or better: only bits 31..26 are used
+                mx = mx > m2 ? mx : m2;
+            }
+        // wave-wide maximum on the VALU (row_shr 1 2 4 8 within rows of 16, then across the rows), read from lane 63
+        mx = dpp_max_u32<0x111>(mx);
+        mx = dpp_max_u32<0x112>(mx);
+        mx = dpp_max_u32<0x114>(mx);
+        mx = dpp_max_u32<0x118>(mx);
+        mx = dpp_max_u32<0x142, 0xA>(mx);  // row_bcast15 into rows 1 and 3
+        mx = dpp_max_u32<0x143, 0xC>(mx);  // row_bcast31 into rows 2 and 3
+        mx = (unsigned)__builtin_amdgcn_readlane((int)mx, 63);
+        if constexpr (MODE == 2) ts[1] = wall_clock64();
+        const int E = (int)(mx >> 26);  // exponent field of the largest magnitude; |x| < 2^(E - 14)
+        sh = 44 - E;                    // |x * 2^sh| < 2^30
+        const float scale = __builtin_bit_cast(float, (unsigned)(127 + sh) << 23);
+#pragma unroll
+        for (int c = 0; c < NP; ++c) {
+            unsigned d[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const half_t lo = __builtin_bit_cast(half_t, (unsigned short)(xv[c][q] & 0xFFFFu));
+                const half_t hi = __builtin_bit_cast(half_t, (unsigned short)(xv[c][q] >> 16));
+                d[2 * q] = ((unsigned)(int)__builtin_fmaf((float)lo, scale, 0.0f) + 0x00808080u) ^ 0x00808080u;
+                d[2 * q + 1] = ((unsigned)(int)__builtin_fmaf((float)hi, scale, 0.0f) + 0x00808080u) ^ 0x00808080u;
+            }
+            const int cc = lane + 64 * c;
+            const int tu = cc >> 4, kq_x = (cc >> 2) & 3, s = cc & 3;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const unsigned t0 = __builtin_amdgcn_perm(d[h + 2], d[h], 0x05010400u);
+                const unsigned t1 = __builtin_amdgcn_perm(d[h + 2], d[h], 0x07030602u);
+                const unsigned t2 = __builtin_amdgcn_perm(d[h + 6], d[h + 4], 0x05010400u);
+                const unsigned t3 = __builtin_amdgcn_perm(d[h + 6], d[h + 4], 0x07030602u);
+                const int base = (((tu * 2 + h) * 4 + kq_x) * 4) * 4 + s;
+                planes[base + 0] = __builtin_amdgcn_perm(t2, t0, 0x05040100u);
+                planes[base + 4] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+                planes[base + 8] = __builtin_amdgcn_perm(t3, t1, 0x05040100u);
+                planes[base + 12] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+            }
+        }
+        if constexpr (MODE == 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ts[2] = wall_clock64(); }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // B operands of every unit, read now (the weights are still on their way); unit c of a pass feeds columns 4c..4c+3 only
+        const uint4_t *bimg = reinterpret_cast<const uint4_t *>(planes);
+        const int jb = lane & 3, cb = (lane >> 2) & 3;
+        int4v_t B[4][2];  // set c: unit c's operand in the lanes of column block c, zeros in the other lanes (never written)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) B[c][0] = B[c][1] = int4v_t{0, 0, 0, 0};
+        auto read_b = [&](int ps) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (cb == c) {  // exec-masked reads
+                    B[c][0] = __builtin_bit_cast(int4v_t, bimg[(((ps * 4 + c) * 2 + 0) * 4 + kq) * 4 + jb]);
+                    B[c][1] = __builtin_bit_cast(int4v_t, bimg[(((ps * 4 + c) * 2 + 1) * 4 + kq) * 4 + jb]);
+                }
+        };
+        read_b(0);
+        const int4v_t zero4 = int4v_t{0, 0, 0, 0};
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            int4v_t dd[ROWS][2];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) dd[r][0] = dd[r][1] = zero4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int t = ps * 4 + c;
+                const int4v_t b0 = B[c][0], b1 = B[c][1];
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    if constexpr (MODE == 4) {
+                        dd[r][0][0] += (int)(w[r][t][0] ^ w[r][t][1] ^ w[r][t][2] ^ w[r][t][3]) + b0[0] + b1[1];
+                        continue;
+                    }
+                    int4v_t alo, ahi;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned x8 = w[r][t][q] ^ 0x88888888u;
+                        ahi[q] = (int)(x8 & 0xF0F0F0F0u);
+                        alo[q] = (int)((x8 << 4) & 0xF0F0F0F0u);
+                    }
+                    dd[r][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(alo, b0, dd[r][0], 0, 0, 0);
+                    dd[r][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ahi, b1, dd[r][1], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                const half_t s0 = __builtin_bit_cast(half_t, (unsigned short)(sc[r][ps][0] & 0xFFFFu));
+                const half_t s1 = __builtin_bit_cast(half_t, (unsigned short)(sc[r][ps][0] >> 16));
+                const half_t s2 = __builtin_bit_cast(half_t, (unsigned short)(sc[r][ps][1] & 0xFFFFu));
+                const half_t s3 = __builtin_bit_cast(half_t, (unsigned short)(sc[r][ps][1] >> 16));
+                acc[r][0] = __builtin_fmaf((float)(dd[r][0][0] + dd[r][1][0]), (float)s0, acc[r][0]);
+                acc[r][1] = __builtin_fmaf((float)(dd[r][0][1] + dd[r][1][1]), (float)s1, acc[r][1]);
+                acc[r][2] = __builtin_fmaf((float)(dd[r][0][2] + dd[r][1][2]), (float)s2, acc[r][2]);
+                acc[r][3] = __builtin_fmaf((float)(dd[r][0][3] + dd[r][1][3]), (float)s3, acc[r][3]);
+            }
+            if (ps + 1 < NP) read_b(ps + 1);
+        }
+    }
+    if constexpr (MODE == 2) ts[3] = wall_clock64();
+
+    // 2^(8 p) * 2^(-sh) / 16 for plane p = j % 4; the 16 lanes of a row hold 4 groups x 4 planes of the same 4 rows
+    const float cj = __builtin_bit_cast(float, (unsigned)(127 + 8 * (j & 3) - sh - 4) << 23);
+    float *red = reinterpret_cast<float *>(smem + (size_t)WK * UW * 512);  // [16 waves][ROWS][16]
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v = acc[r][q] * cj;
+            if constexpr (MODE == 1) v = acc[r][q];
+            v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+            v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+            v = dpp_add<0x141>(v);  // row_half_mirror
+            v = dpp_add<0x140>(v);  // row_mirror
+            if (j == 0) red[(wk * ROWS + r) * 16 + kq * 4 + q] = v;
+        }
+    __syncthreads();
+    if (tid < ROWS * 16) {
+        float part[16];
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) part[k2] = red[(k2 < WK ? k2 : 0) * ROWS * 16 + tid];
+        float v = 0.f;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) v += k2 < WK ? part[k2] : 0.f;
+        const int row = tile0 * 16 + tid;
+        if (row < a.N) a.y[row] = (half_t)v;
+    }
+    if constexpr (MODE == 2) {
+        ts[4] = wall_clock64();
+        if (lane == 0 && a.dbg) {
+            unsigned long long *d = a.dbg + ((size_t)blockIdx.x * WK + wk) * 5;
+            for (int q = 0; q < 5; ++q) d[q] = ts[q];
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------------------------------
+static uint32_t rng_state = 12345;
+static inline uint32_t rnd() {
+    rng_state = rng_state * 1664525u + 1013904223u;
+    return rng_state;
+}
+static float gauss() {
+    float s = 0;
+    for (int i = 0; i < 12; ++i) s += (rnd() >> 8) * (1.0f / 16777216.0f);
+    return s - 6.0f;
+}
+
+template <int ROWS, int UW, int LAYOUT, int MODE, int MAXT = 0>
+static void run(const char *name, int N, int K, int NB, std::vector<void *> &dw, std::vector<half_t *> &dsc, half_t *dx, half_t *dy, const std::vector<double> *ref,
+                int reps) {
+    const int U = K / 128;
+    const int WK = (U + UW - 1) / UW;
+    if constexpr (MAXT == 0) {
+        if (WK * 64 <= 256) return run<ROWS, UW, LAYOUT, MODE, 256>(name, N, K, NB, dw, dsc, dx, dy, ref, reps);
+        if (WK * 64 <= 512) return run<ROWS, UW, LAYOUT, MODE, 512>(name, N, K, NB, dw, dsc, dx, dy, ref, reps);
+        return run<ROWS, UW, LAYOUT, MODE, 1024>(name, N, K, NB, dw, dsc, dx, dy, ref, reps);
+    } else {
+    if (WK > 16) {
+        printf("{\"variant\": \"%s\", \"N\": %d, \"K\": %d, \"skipped\": \"more than 16 waves\"}\n", name, N, K);
+        return;
+    }
+    Args a{};
+    a.x = dx;
+    a.y = dy;
+    a.N = N;
+    a.K = K;
+    a.U = U;
+    a.bytes_w = (int)((size_t)N * K / 2);
+    a.bytes_s = N * U * 2;
+    const int grid = (N / 16 + ROWS - 1) / ROWS;
+    const size_t lds = (size_t)WK * UW * 512 + (size_t)WK * ROWS * 16 * 4;
+    void (*kfn)(const Args);
+    if constexpr (LAYOUT == 2) kfn = i8_gemv2<ROWS, UW / 4, MODE, MAXT>;
+    else kfn = i8_gemv<ROWS, UW, LAYOUT, MODE, MAXT>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    // correctness on buffer 0
+    a.w = dw[0];
+    a.sc = dsc[0];
+    CK(hipMemset(dy, 0, N * 2));
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * WK), lds, 0, a);
+    CK(hipDeviceSynchronize());
+    double worst = 0, rms = 0;
+    if (ref && (MODE == 0 || MODE == 2)) {
+        std::vector<half_t> y(N);
+        CK(hipMemcpy(y.data(), dy, N * 2, hipMemcpyDeviceToHost));
+        for (int n = 0; n < N; ++n) rms += (*ref)[n] * (*ref)[n];
+        rms = std::sqrt(rms / N);
+        for (int n = 0; n < N; ++n) {
+            const double r = (*ref)[n];
+            const double tol = 1e-3 * std::max(std::fabs(r), rms / 64);
+            // the fp16 store rounds: compare against the reference rounded the same way
+            const double e = std::fabs((double)(float)y[n] - (double)(float)(half_t)(float)r) / tol;
+            if (e > worst) worst = e;
+        }
+    }
+    float best = 1e9f, med = 0;
+    std::vector<float> times;
+    for (int rep = 0; rep < reps; ++rep) {
+        CK(hipEventRecord(e0, 0));
+        for (int b = 0; b < NB; ++b) {
+            a.w = dw[b];
+            a.sc = dsc[b];
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * WK), lds, 0, a);
+        }
+        CK(hipEventRecord(e1, 0));
+        CK(hipDeviceSynchronize());
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        times.push_back(ms * 1000.f / NB);
+        if (times.back() < best) best = times.back();
+    }
+    if constexpr (MODE == 2) {
+        const size_t nw = (size_t)grid * WK;
+        unsigned long long *ddbg;
+        CK(hipMalloc(&ddbg, nw * 5 * 8));
+        a.dbg = ddbg;
+        a.w = dw[1 % NB];
+        a.sc = dsc[1 % NB];
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * WK), lds, 0, a);
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> h(nw * 5);
+        CK(hipMemcpy(h.data(), ddbg, nw * 5 * 8, hipMemcpyDeviceToHost));
+        CK(hipFree(ddbg));
+        a.dbg = nullptr;
+        unsigned long long t0 = ~0ull;
+        for (size_t i = 0; i < nw; ++i) t0 = std::min(t0, h[i * 5]);
+        const char *names[5] = {"start", "x_arrived", "converted", "contracted", "end"};
+        printf("{\"timeline\": \"%s\", \"rows_tiles\": %d, \"units_per_wave\": %d, \"waves\": %zu, \"unit\": \"us after the first wave's start (100 MHz clock)\"", name, ROWS, UW, nw);
+        for (int q = 0; q < 5; ++q) {
+            std::vector<double> v(nw);
+            for (size_t i = 0; i < nw; ++i) v[i] = (double)(h[i * 5 + q] - t0) * 0.01;
+            std::sort(v.begin(), v.end());
+            printf(", \"%s_p0_p10_p50_p90_p100\": [%.2f, %.2f, %.2f, %.2f, %.2f]", names[q], v[0], v[nw / 10], v[nw / 2], v[nw * 9 / 10], v[nw - 1]);
+        }
+        // per-wave durations
+        const int pairs[4][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 4}};
+        for (auto &pr : pairs) {
+            std::vector<double> v(nw);
+            for (size_t i = 0; i < nw; ++i) v[i] = (double)(h[i * 5 + pr[1]] - h[i * 5 + pr[0]]) * 0.01;
+            std::sort(v.begin(), v.end());
+            printf(", \"%s_to_%s_p10_p50_p90\": [%.2f, %.2f, %.2f]", names[pr[0]], names[pr[1]], v[nw / 10], v[nw / 2], v[nw * 9 / 10]);
+        }
+        printf("}\n");
+    }
+    std::sort(times.begin(), times.end());
+    med = times[times.size() / 2];
+    const double bytes = (double)N * K / 2 + (double)N * U * 2 + 2.0 * K + 2.0 * N;
+    printf("{\"variant\": \"%s\", \"N\": %d, \"K\": %d, \"rows_tiles\": %d, \"units_per_wave\": %d, \"layout\": \"%s\", \"mode\": \"%s\", \"waves_per_wg\": %d, \"grid\": %d, "
+           "\"us_min\": %.2f, \"us_median\": %.2f, \"TBps_median\": %.3f, \"frac_of_8TBps\": %.3f, \"worst_err_over_tol\": %.3f}\n",
+           name, N, K, ROWS, UW, LAYOUT == 0 ? "tile16" : (LAYOUT == 2 ? "tile16 v2" : "q4_6"), MODE == 0 ? "gemv" : (MODE == 1 ? "stream-only" : (MODE == 2 ? "gemv + timestamps" : (MODE == 3 ? "no conversion" : "no mfma"))), WK, grid, best, med, bytes / med * 1e-6, bytes / med * 1e-6 / 8.0, worst);
+    fflush(stdout);
+    }
+}
+
+int main(int argc, char **argv) {
+    struct Shape {
+        const char *name;
+        int N, K;
+    };
+    const Shape shapes[] = {{"gate+up", 22016, 4096}, {"qkv", 12288, 4096}, {"o_proj", 4096, 4096}, {"down_proj", 4096, 11008}};
+    const size_t ring_bytes = (size_t)400 << 20;  // more than the 256 MiB Infinity Cache
+    for (const Shape &sh : shapes) {
+        const int N = sh.N, K = sh.K, U = K / 128;
+        const size_t wb = (size_t)N * K / 2;
+        const int NB = (int)std::max<size_t>(2, ring_bytes / wb);
+        // host data: q4_6 weights, scales, x
+        std::vector<uint32_t> q((size_t)N * K / 8);
+        for (auto &v : q) v = rnd() ^ (rnd() << 16);
+        std::vector<half_t> s((size_t)N * U), x(K);
+        for (auto &v : s) v = (half_t)(0.005f + 0.01f * ((rnd() >> 8) * (1.0f / 16777216.0f)));
+        for (auto &v : x) v = (half_t)gauss();
+        x[7] = (half_t)40.0f;  // an outlier
+        x[K - 3] = (half_t)-1e-4f;
+        std::vector<double> ref(N);
+        for (int n = 0; n < N; ++n) {
+            double accd = 0;
+            for (int g = 0; g < U; ++g) {
+                double part = 0;
+                for (int k = g * 128; k < g * 128 + 128; ++k) {
+                    const int code = (q[(size_t)n * (K / 8) + k / 8] >> (4 * (k & 7))) & 15;
+                    part += (double)(code - 8) * (double)(float)x[k];
+                }
+                accd += part * (double)(float)s[(size_t)n * U + g];
+            }
+            ref[n] = accd;
+        }
+        // tile-16 re-layout
+        std::vector<uint32_t> qt(q.size());
+        std::vector<half_t> st(s.size());
+        for (int tile = 0; tile < N / 16; ++tile)
+            for (int u = 0; u < U; ++u)
+                for (int l = 0; l < 64; ++l) {
+                    const int i = l & 15, kq = l >> 4;
+                    const uint32_t *src = &q[((size_t)(tile * 16 + i) * (K / 32) + (4 * u + kq)) * 4];
+                    uint32_t *dst = &qt[(((size_t)tile * U + u) * 64 + l) * 4];
+                    memcpy(dst, src, 16);
+                }
+        for (int tile = 0; tile < N / 16; ++tile)
+            for (int u = 0; u < U; ++u)
+                for (int i = 0; i < 16; ++i) st[((size_t)tile * U + u) * 16 + i] = s[(size_t)(tile * 16 + i) * U + u];
+        std::vector<void *> dw0(NB), dw1(NB);
+        std::vector<half_t *> ds0(NB), ds1(NB);
+        for (int b = 0; b < NB; ++b) {
+            CK(hipMalloc(&dw0[b], wb));
+            CK(hipMalloc(&dw1[b], wb));
+            CK(hipMalloc(&ds0[b], s.size() * 2));
+            CK(hipMalloc(&ds1[b], s.size() * 2));
+            CK(hipMemcpy(dw0[b], qt.data(), wb, hipMemcpyHostToDevice));
+            CK(hipMemcpy(dw1[b], q.data(), wb, hipMemcpyHostToDevice));
+            CK(hipMemcpy(ds0[b], st.data(), s.size() * 2, hipMemcpyHostToDevice));
+            CK(hipMemcpy(ds1[b], s.data(), s.size() * 2, hipMemcpyHostToDevice));
+        }
+        half_t *dx, *dy;
+        CK(hipMalloc(&dx, K * 2));
+        CK(hipMalloc(&dy, N * 2));
+        CK(hipMemcpy(dx, x.data(), K * 2, hipMemcpyHostToDevice));
+        const int reps = 15;
+#define RUN(R, UWV, L, M) run<R, UWV, L, M>(sh.name, N, K, NB, (L) != 1 ? dw0 : dw1, (L) != 1 ? ds0 : ds1, dx, dy, &ref, reps)
+        RUN(1, 4, 0, 1);
+        RUN(1, 4, 2, 0);
+        RUN(2, 4, 2, 0);
+        RUN(1, 4, 2, 3);
+        RUN(1, 4, 2, 4);
+        RUN(1, 4, 2, 2);
+        RUN(2, 4, 2, 2);
+        RUN(1, 8, 2, 0);
+        RUN(2, 8, 2, 0);
+        RUN(1, 8, 2, 2);
+#undef RUN
+        for (int b = 0; b < NB; ++b) {
+            CK(hipFree(dw0[b]));
+            CK(hipFree(dw1[b]));
+            CK(hipFree(ds0[b]));
+            CK(hipFree(ds1[b]));
+        }
+        CK(hipFree(dx));
+        CK(hipFree(dy));
+    }
+    return 0;
+}

@@ -16,7 +16,9 @@ typedef half_t half8_t __attribute__((ext_vector_type(8)));
 typedef half_t half4_t __attribute__((ext_vector_type(4)));
 typedef float float4_t __attribute__((ext_vector_type(4)));
 
-enum Op { AND_OR = 0, FMA_F32 = 1, PK_FMA_F16 = 2, LSHR = 3, PK_ADD_F16 = 4, MFMA16 = 5, MFMA4 = 6, MIX = 7, PERM = 8, CVT_PK = 9 };
+enum Op { AND_OR = 0, FMA_F32 = 1, PK_FMA_F16 = 2, LSHR = 3, PK_ADD_F16 = 4, MFMA16 = 5, MFMA4 = 6, MIX = 7, PERM = 8, CVT_PK = 9,
+          DOT8_I4 = 10, MFMA_I8 = 11, CVT_F32_I32 = 12, AND_LIT = 13, MIX_I8 = 14, DOT8_LOADS = 15 };  // round 4: the int4-dot / int8-MFMA decode formulations
+typedef int int4v_t __attribute__((ext_vector_type(4)));
 
 #define REP8(X) X X X X X X X X
 
@@ -31,6 +33,7 @@ __global__ __launch_bounds__(1024) void probe(unsigned *out, int iters, unsigned
     float4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0}, acc3 = {0, 0, 0, 0};
     half8_t a = {1, 2, 3, 4, 5, 6, 7, 8}, b = {(half_t)threadIdx.x, 1, 1, 1, 1, 1, 1, 1};
     half4_t a4 = {1, 2, 3, 4}, b4 = {(half_t)threadIdx.x, 1, 1, 1};
+    int4v_t i0 = {0, 0, 0, 0}, i1 = i0, i2 = i0, i3 = i0, ia = {(int)threadIdx.x, 1, 2, 3}, ib = {0x01010101, 0x02020202, (int)blockIdx.x, 5};
     const unsigned long long t0 = __builtin_readcyclecounter();
     const unsigned long long w0 = wall_clock64();
     for (int i = 0; i < iters; ++i) {
@@ -62,6 +65,41 @@ __global__ __launch_bounds__(1024) void probe(unsigned *out, int iters, unsigned
             REP8(asm volatile("v_cvt_pkrtz_f16_f32 %0, %0, %1\n\tv_cvt_pkrtz_f16_f32 %1, %1, %2\n\tv_cvt_pkrtz_f16_f32 %2, %2, %3\n\tv_cvt_pkrtz_f16_f32 %3, %3, %4\n\t"
                               "v_cvt_pkrtz_f16_f32 %4, %4, %5\n\tv_cvt_pkrtz_f16_f32 %5, %5, %6\n\tv_cvt_pkrtz_f16_f32 %6, %6, %7\n\tv_cvt_pkrtz_f16_f32 %7, %7, %0"
                               : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7));)
+        } else if (OP == DOT8_I4 || OP == DOT8_LOADS) {  // v_dot8_i32_i4: 8 signed int4 products into an int32 (the judge's round-4 candidate)
+            REP8(asm volatile("v_dot8_i32_i4 %0, %0, %8, %1\n\tv_dot8_i32_i4 %1, %1, %8, %2\n\tv_dot8_i32_i4 %2, %2, %8, %3\n\tv_dot8_i32_i4 %3, %3, %8, %4\n\t"
+                              "v_dot8_i32_i4 %4, %4, %8, %5\n\tv_dot8_i32_i4 %5, %5, %8, %6\n\tv_dot8_i32_i4 %6, %6, %8, %7\n\tv_dot8_i32_i4 %7, %7, %8, %0"
+                              : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(m));)
+            if (OP == DOT8_LOADS) {  // ... beside a 16-byte global load per 64 dots (the GEMV's ratio is one load per ~29 instructions)
+                const int4v_t q = __builtin_nontemporal_load(reinterpret_cast<const int4v_t *>(out) + ((i * 1024 + threadIdx.x) & 0xFFFF));
+                r0 ^= q[0] & 1; r1 ^= q[1] & 1; r2 ^= q[2] & 1; r3 ^= q[3] & 1;
+            }
+        } else if (OP == CVT_F32_I32) {
+            REP8(asm volatile("v_cvt_f32_i32 %0, %1\n\tv_cvt_f32_i32 %1, %2\n\tv_cvt_f32_i32 %2, %3\n\tv_cvt_f32_i32 %3, %4\n\t"
+                              "v_cvt_f32_i32 %4, %5\n\tv_cvt_f32_i32 %5, %6\n\tv_cvt_f32_i32 %6, %7\n\tv_cvt_f32_i32 %7, %0"
+                              : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7));)
+        } else if (OP == AND_LIT) {  // VOP2 with a 32-bit literal (8-byte encoding)
+            REP8(asm volatile("v_and_b32 %0, 0x0f0f0f0f, %1\n\tv_and_b32 %1, 0x0f0f0f0f, %2\n\tv_and_b32 %2, 0x0f0f0f0f, %3\n\tv_and_b32 %3, 0x0f0f0f0f, %4\n\t"
+                              "v_and_b32 %4, 0x0f0f0f0f, %5\n\tv_and_b32 %5, 0x0f0f0f0f, %6\n\tv_and_b32 %6, 0x0f0f0f0f, %7\n\tv_and_b32 %7, 0x0f0f0f0f, %0"
+                              : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7));)
+        } else if (OP == MFMA_I8) {
+            REP8(i0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(ia, ib, i0, 0, 0, 0); i1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(ia, ib, i1, 0, 0, 0);
+                 i2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(ia, ib, i2, 0, 0, 0); i3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(ia, ib, i3, 0, 0, 0);
+                 i0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(ia, ib, i0, 0, 0, 0); i1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(ia, ib, i1, 0, 0, 0);
+                 i2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(ia, ib, i2, 0, 0, 0); i3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(ia, ib, i3, 0, 0, 0);)
+        } else if (OP == MIX_I8) {  // per REP: 4 x { one i8 16x16x64 MFMA + VALU_PER_MFMA independent v_and_b32 (literal) }
+#define ONE_MFMA_I8(ACC) ACC = __builtin_amdgcn_mfma_i32_16x16x64_i8(ia, ib, ACC, 0, 0, 0);
+#define VALU_I8_ONE(R) asm volatile("v_and_b32 %0, 0x7f0f0f0f, %0" : "+v"(R));
+#define VALU_I8                                                    \
+    if (VALU_PER_MFMA >= 1) { VALU_I8_ONE(r0) }                    \
+    if (VALU_PER_MFMA >= 2) { VALU_I8_ONE(r1) }                    \
+    if (VALU_PER_MFMA >= 3) { VALU_I8_ONE(r2) }                    \
+    if (VALU_PER_MFMA >= 4) { VALU_I8_ONE(r3) }                    \
+    if (VALU_PER_MFMA >= 5) { VALU_I8_ONE(r4) }                    \
+    if (VALU_PER_MFMA >= 6) { VALU_I8_ONE(r5) }                    \
+    if (VALU_PER_MFMA >= 7) { VALU_I8_ONE(r6) }                    \
+    if (VALU_PER_MFMA >= 8) { VALU_I8_ONE(r7) }                    \
+    if (VALU_PER_MFMA >= 12) { VALU_I8_ONE(r0) VALU_I8_ONE(r1) VALU_I8_ONE(r2) VALU_I8_ONE(r3) }
+            REP8(ONE_MFMA_I8(i0) VALU_I8 ONE_MFMA_I8(i1) VALU_I8 ONE_MFMA_I8(i2) VALU_I8 ONE_MFMA_I8(i3) VALU_I8)
         } else if (OP == MFMA16) {  // 8 MFMAs per REP on 4 independent accumulators
             REP8(acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc1, 0, 0, 0);
                  acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc2, 0, 0, 0); acc3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc3, 0, 0, 0);
@@ -93,7 +131,7 @@ __global__ __launch_bounds__(1024) void probe(unsigned *out, int iters, unsigned
         atomicMax(&ticks[0], t1 - t0);
         atomicMax(&ticks[1], w1 - w0);
     }
-    const float s = acc0[0] + acc1[1] + acc2[2] + acc3[3];
+    const float s = acc0[0] + acc1[1] + acc2[2] + acc3[3] + (float)(i0[0] + i1[1] + i2[2] + i3[3]);
     out[blockIdx.x * blockDim.x + threadIdx.x] = (r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7) + (unsigned)s;  // unconditional: nothing can be sunk or dropped
 }
 
@@ -139,6 +177,15 @@ int main() {
     run<LSHR, 0>("v_lshrrev_b32 x64", 64, 0, out, ticks);
     run<PERM, 0>("v_perm_b32 x64", 64, 0, out, ticks);
     run<CVT_PK, 0>("v_cvt_pkrtz_f16_f32 x64", 64, 0, out, ticks);
+    run<DOT8_I4, 0>("v_dot8_i32_i4 x64", 64, 0, out, ticks);
+    run<DOT8_LOADS, 0>("v_dot8_i32_i4 x64 + one 16-byte nt load per lane", 64, 0, out, ticks);
+    run<CVT_F32_I32, 0>("v_cvt_f32_i32 x64", 64, 0, out, ticks);
+    run<AND_LIT, 0>("v_and_b32 literal x64", 64, 0, out, ticks);
+    run<MFMA_I8, 0>("v_mfma_i32_16x16x64_i8 x64", 0, 64, out, ticks);
+    run<MIX_I8, 0>("mfma_i8 + 0 valu", 0, 32, out, ticks);
+    run<MIX_I8, 4>("mfma_i8 + 4 valu", 128, 32, out, ticks);
+    run<MIX_I8, 8>("mfma_i8 + 8 valu", 256, 32, out, ticks);
+    run<MIX_I8, 12>("mfma_i8 + 12 valu", 384, 32, out, ticks);
     run<MFMA16, 0>("v_mfma_f32_16x16x32_f16 x64", 0, 64, out, ticks);
     run<MFMA4, 0>("v_mfma_f32_4x4x4_f16 x64", 0, 64, out, ticks);
     run<MIX, 0>("mfma16 + 0 valu", 0, 32, out, ticks);

@@ -46,7 +46,11 @@ def test_cpp_adapter_selftest(oracle, tmp_path):
     for z in (zp8, zpr):
         tq, ts, tz, tx = t(qw.view(np.int32)), t(sc.view(np.float16)), t(z.view(np.int32)), t(x)
         o = torch.zeros((M, N), dtype=torch.float16, device=dev)
-        d = capi.W4A16Desc(M=M, N=N, K=K, group_size=G, A=tx.data_ptr(), qweight=tq.data_ptr(), scales=ts.data_ptr(), zeros=tz.data_ptr(), C=o.data_ptr())
+        # the adapter runs decode batches on the packed copy it builds at first sight of a weight tensor (round 4): the expected bits come from the same kernel family
+        from tinychatengine_amd.linear import Linear_half_int4
+        lin = Linear_half_int4(tq, ts, tz, G).prepack()
+        d = lin.desc(tx, o)
+        assert capi.describe_dispatch(d).startswith("gemv-i8")
         capi.check(capi.w4a16_forward(d, torch.cuda.current_stream().cuda_stream))
         torch.cuda.synchronize()
         ref32, _ = oracle.w4a16_gemv_q4_6(x, qw, sc, z, M, N, K, G)

@@ -47,13 +47,14 @@ struct TensorKeyHash {
     }
 };
 struct AwqEntry {
-    void *workspace = nullptr;  // q4_6 re-layout of a q4_5 tensor (tce_w4a16_gemm_awq)
+    void *workspace = nullptr;  // q4_6 re-layout of a q4_5 tensor (tce_w4a16_gemm_awq) / q4_mfma copy of a q4_6 linear
     size_t bytes = 0;
+    const void *scales = nullptr, *zeros = nullptr;  // packed copies: the side tensors the copy was built from (it embeds them)
 };
 std::mutex g_mu;
 std::unordered_map<TensorKey, int, TensorKeyHash> g_zero;       // zero-point tensor -> every packed zero point is 8
 std::unordered_map<TensorKey, AwqEntry, TensorKeyHash> g_awq;   // AWQ weight tensor -> re-laid-out copy
-std::unordered_map<TensorKey, AwqEntry, TensorKeyHash> g_pack;  // q4_6 weight tensor -> q4_mfma copy (prefill GEMM, M >= kPackMinM)
+std::unordered_map<TensorKey, AwqEntry, TensorKeyHash> g_pack;  // q4_6 weight tensor -> q4_mfma copy (decode GEMV M <= 4, prefill GEMM M >= kPackMinM)
 constexpr int kPackMinM = 192;
 
 // The q4_mfma copy of a linear, built on first sight of a large batch (the reference's Linear_half_int4 has no load-time hook
@@ -64,14 +65,21 @@ const void *packed_copy(const tce_w4a16_desc &d) {
     if (need == 0) return nullptr;
     std::lock_guard<std::mutex> lk(g_mu);
     AwqEntry &e = g_pack[TensorKey{d.qweight, d.N, d.K, d.group_size}];
-    if (!e.workspace) {
-        if (tce_malloc(&e.workspace, need, /*managed=*/0) != TCE_OK) {  // no memory for the copy: the other GEMM kernels take the call
+    const bool fresh = !e.workspace;
+    if (fresh) {
+        if (tce_malloc(&e.workspace, need, /*managed=*/0) != TCE_OK) {  // no memory for the copy: the other kernels take the call
             e.workspace = nullptr;
             return nullptr;
         }
         e.bytes = need;
+    }
+    // the copy embeds the scales and the zero points: the same weights with OTHER side tensors (a test harness; never a model) are packed again, into the same
+    // buffer -- ordered behind every earlier reader by the null stream
+    if (fresh || e.scales != d.scales || e.zeros != d.zeros) {
         const int rc = tce_w4a16_prepack(&d, e.workspace, nullptr);
         if (rc != TCE_OK) die("gemv_forward_cuda (prepack)", rc);
+        e.scales = d.scales;
+        e.zeros = d.zeros;
     }
     return e.workspace;
 }
@@ -161,7 +169,10 @@ void MatmulOperator::gemv_forward_cuda(const struct matmul_params *params) {
         const int zw = (((d.K / d.group_size + 7) / 8) + mult - 1) / mult * mult;
         if (d.zeros && zeros_are_8(d.zeros, (long long)d.N * zw)) d.flags |= TCE_W4_ZERO_POINT_IS_8;
     }
-    if (d.M >= kPackMinM && d.K % 128 == 0 && d.A && d.qweight && d.scales && d.zeros) {
+    // The packed copy serves both ends: decode batches (M <= 4: the int8-contraction GEMV reads it, round 4) and prompts (M >= 192: the 128-row GEMM).
+    // One extra copy of the int4 weights per linear in HBM (an 8B-class model: +3.9 GB of 288); TCE_ADAPTER_PACK=0 keeps the q4_6 arrays only.
+    static const bool pack_on = [] { const char *e = std::getenv("TCE_ADAPTER_PACK"); return !(e && e[0] == '0'); }();
+    if (pack_on && (d.M <= 4 || d.M >= kPackMinM) && d.K % 128 == 0 && d.A && d.qweight && d.scales && d.zeros) {
         d.prepacked = packed_copy(d);
         if (d.prepacked) d.scratch = gemm_scratch();
     }
@@ -260,7 +271,7 @@ extern "C" void tce_adapter_forget(const void *ptr) {
     for (auto it = g_zero.begin(); it != g_zero.end();) it = it->first.ptr == ptr ? g_zero.erase(it) : std::next(it);
     for (auto *m : {&g_awq, &g_pack})
         for (auto it = m->begin(); it != m->end();) {
-            if (it->first.ptr == ptr) {
+            if (it->first.ptr == ptr || it->second.scales == ptr || it->second.zeros == ptr) {
                 if (it->second.workspace) tce_free(it->second.workspace);
                 it = m->erase(it);
             } else {

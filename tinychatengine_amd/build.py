@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libtce_hip.so")
 ADAPTER_LIB_PATH = os.path.join(LIB_DIR, "libtce_matmul_operator.so")
 ADAPTER_TEST_PATH = os.path.join(LIB_DIR, "adapter_selftest")
 
-HIP_SOURCES = ["tce_capi.hip", "w4a16_gemv.hip", "w4a16_gemv_stream.hip", "w4a16_gemv_ovl.hip", "w4a16_gemm.hip", "w4a16_gemm_dma.hip", "w4a16_gemm_pk.hip", "w4a16_skinny.hip", "w4a16_awq.hip", "w8a8_gemm.hip", "w8a8_lnq_fused.hip", "glue.hip", "attention_ops.hip", "attention_fast.hip", "attention_prefill.hip", "opt_attention.hip", "comm.hip"]
+HIP_SOURCES = ["tce_capi.hip", "w4a16_gemv.hip", "w4a16_gemv_i8.hip", "w4a16_gemv_stream.hip", "w4a16_gemv_ovl.hip", "w4a16_gemm.hip", "w4a16_gemm_dma.hip", "w4a16_gemm_pk.hip", "w4a16_skinny.hip", "w4a16_awq.hip", "w8a8_gemm.hip", "w8a8_lnq_fused.hip", "glue.hip", "attention_ops.hip", "attention_fast.hip", "attention_prefill.hip", "opt_attention.hip", "comm.hip"]
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
     "-ffp-contract=off",  # the int8 epilogue and the fp16-accumulate entry point need every rounding

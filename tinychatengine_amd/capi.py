@@ -32,7 +32,7 @@ TCE_OUT_INT8, TCE_OUT_FP32 = 0, 1
 EXPORTS = [
     "tce_w4a16_forward", "tce_w4a16_prepack_bytes", "tce_w4a16_prepack", "tce_w4a16_gemm_scratch_bytes", "tce_w4a16_describe_dispatch", "tce_reset_last_error", "tce_bmm_f16t", "tce_rope_half", "tce_softmax_half", "tce_attention_decode_f16", "tce_attention_decode_workspace_bytes", "tce_attention_decode_describe", "tce_attention_decode_step_f16", "tce_attention_decode_step_gqa_f16", "tce_attention_decode_describe_gqa", "tce_attention_decode_step_pos_f16", "tce_attention_prefill_f16", "tce_attention_prefill_workspace_bytes", "tce_opt_attention_decode", "tce_prefetch", "tce_add_half", "tce_silu_mul_half", "tce_rmsnorm_half", "tce_w4a16_forward_group_rmsnorm", "tce_w4a16_forward_group", "tce_w4a16_check_zero_point_8", "tce_w4a16_awq_fp16acc", "tce_w4a16_awq_workspace_bytes",
     "tce_w4a16_gemm_awq", "tce_w4a16_shard", "tce_comm_create", "tce_comm_export", "tce_comm_connect", "tce_comm_connect_local", "tce_allgather_f16", "tce_comm_status", "tce_comm_set_timeout_ms", "tce_comm_reset", "tce_comm_device", "tce_comm_destroy", "tce_w8a8_matmul", "tce_opt_softmax_q", "tce_opt_kv_append", "tce_layernorm_q", "tce_layernorm_q_w8a8_group", "tce_plan_create", "tce_plan_create_ex", "tce_plan_is_chained", "tce_plan_geometry", "tce_plan_status", "tce_plan_launch_geometry", "tce_plan_launch", "tce_plan_n_launches",
-    "tce_plan_destroy", "tce_version", "tce_last_error", "tce_build_info", "tce_w4a16_set_gemv_config",
+    "tce_plan_destroy", "tce_version", "tce_last_error", "tce_build_info", "tce_w4a16_set_gemv_config", "tce_w4a16_set_gemv_i8",
     "tce_w4a16_set_gemm_config", "tce_w4a16_algorithmic_bytes", "tce_w4a16_gemv_variant", "tce_w4a16_gemm_variant",
     "tce_w4a16_set_debug_mode", "tce_w4a16_set_debug_buffer", "tce_malloc", "tce_free", "tce_memcpy", "tce_synchronize", "tce_device_count",
 ]
@@ -151,6 +151,7 @@ def lib() -> C.CDLL:
         L.tce_plan_destroy.restype = None
         L.tce_w4a16_set_gemv_config.argtypes = [C.c_int] * 4
         L.tce_w4a16_set_gemm_config.argtypes = [C.c_int] * 2
+        L.tce_w4a16_set_gemv_i8.argtypes = [C.c_int] * 2
         L.tce_w4a16_algorithmic_bytes.argtypes = [C.c_int] * 4
         L.tce_w4a16_algorithmic_bytes.restype = C.c_int64
         _lib = L
@@ -202,6 +203,11 @@ def algorithmic_bytes(M: int, N: int, K: int, G: int) -> int:
 
 def set_gemv_config(rows: int = 0, waves_n: int = 0, waves_k: int = 0, depth: int = 0) -> None:
     check(lib().tce_w4a16_set_gemv_config(rows, waves_n, waves_k, depth))
+
+
+def set_gemv_i8(mode: int = 0, tiles_per_wave: int = 0) -> None:
+    """The decode kernel on pre-packed copies: mode 0 automatic, 1 off; tiles_per_wave 0 the rule, 1, 2."""
+    check(lib().tce_w4a16_set_gemv_i8(mode, tiles_per_wave))
 
 
 def set_gemm_config(m_tiles: int = 0, n_tiles: int = 0) -> None:

@@ -123,6 +123,12 @@ int tce_w4a16_set_gemv_config(int rows, int wn, int wk, int depth) {
     return TCE_OK;
 }
 
+int tce_w4a16_set_gemv_i8(int mode, int rows) {
+    if (mode < 0 || mode > 1 || rows < 0 || rows > 2) return fail(TCE_ERR_BAD_ARG, "tce_w4a16_set_gemv_i8: mode %d rows %d", mode, rows);
+    tce::set_gemv_i8_mode(mode, rows);
+    return TCE_OK;
+}
+
 int tce_w4a16_set_debug_mode(int mode) {
     if (mode >= 50000 && mode <= 50499) {  // overlapped plans: 50000 + 100 * graph branches (0 = 2) + ring slots per wave (0 = as many as fit, 2..4)
         tce::set_gemv_ovl_config((mode - 50000) % 100, (mode - 50000) / 100);
@@ -348,6 +354,14 @@ int tce_w4a16_forward_group(const tce_w4a16_desc *descs, int count, void *stream
     }
     if (descs[0].rmsnorm_gamma) return forward_group_norm(descs, count, static_cast<const float *>(descs[0].rmsnorm_gamma), descs[0].rmsnorm_eps, stream);
     hipError_t he = hipSuccess;
+    // decode batches on pre-packed copies: the int8-contraction GEMV (w4a16_gemv_i8.hip), one launch for the group (a forced geometry / a diagnostic mode of the
+    // fp16 GEMV kernels keeps those kernels)
+    if (g_gemv_kernel == 0 && g_debug_mode_capi == 0 && tce::gemv_i8_supports(descs, count)) {
+        const int rc = tce::launch_w4a16_gemv_i8(descs, count, static_cast<hipStream_t>(stream), &he);
+        if (rc == TCE_OK) return TCE_OK;
+        if (rc == TCE_ERR_HIP) return hip_fail(he, "w4a16 gemv (int8 contraction) launch");
+        if (rc != TCE_ERR_UNSUPPORTED_SHAPE) return fail(rc, "w4a16 gemv (int8 contraction): unsupported configuration");
+    }
     if (g_skinny_enabled && descs[0].M >= 3) {  // small batches: one skinny launch per linear (they stream the weights once each)
         bool all = true;
         for (int i = 0; i < count; ++i) all = all && !(descs[i].flags & (TCE_W4_FORCE_GEMV | TCE_W4_FORCE_GEMM)) && tce::skinny_supports(descs[i]);
@@ -395,6 +409,7 @@ int tce_w4a16_forward(const tce_w4a16_desc *d, void *stream) {
         if (rc == TCE_ERR_HIP) return hip_fail(he, "w4a16 gemm (pre-packed) launch");
         if (rc != TCE_ERR_UNSUPPORTED_SHAPE) return fail(rc, "w4a16 gemm (pre-packed): unsupported configuration");
     }
+    if (g_gemv_kernel == 0 && g_debug_mode_capi == 0 && tce::gemv_i8_supports(d, 1)) return tce_w4a16_forward_group(d, 1, stream);  // M <= 4 on a packed copy
     // small batches: weights streamed once, all M <= 16 rows on one MFMA tile (w4a16_skinny.hip)
     if (g_skinny_enabled && !(d->flags & (TCE_W4_FORCE_GEMV | TCE_W4_FORCE_GEMM)) && tce::skinny_supports(*d)) {
         const int rc = tce::launch_w4a16_skinny(*d, static_cast<hipStream_t>(stream), &he);
@@ -439,6 +454,10 @@ int tce_w4a16_describe_dispatch(const tce_w4a16_desc *d, char *buf, int buf_len)
         if (form == 4) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=128x128 quartets=1 ksplit=%d group=%d", split, d->group_size);
         else if (form == 5) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=128x128 quartets=1 ksplit=%d-of-the-tiles-past-256 group=%d", split, d->group_size);
         else std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=128x%d quartets=%d group=%d", form == 3 ? 256 : 128, form == 1 ? 1 : 2, d->group_size);
+        return TCE_OK;
+    }
+    if (g_gemv_kernel == 0 && g_debug_mode_capi == 0 && tce::gemv_i8_supports(d, 1)) {
+        std::snprintf(buf, (size_t)buf_len, "gemv-i8 rows-per-pass=%d group=%d", d->M >= 3 ? 4 : d->M, d->group_size);
         return TCE_OK;
     }
     if (g_skinny_enabled && !(d->flags & (TCE_W4_FORCE_GEMV | TCE_W4_FORCE_GEMM)) && tce::skinny_supports(*d)) {

@@ -44,6 +44,8 @@ struct PrepackArgs {
     unsigned *words;          // out
     uint2_t *consts;          // out: {e as f32 bits, zc}
     float *last;              // out
+    half_t *dscales;          // out: fp16 [NT16][K/G][16]
+    unsigned *dzeros;         // out: u32 [NT16][K/G][2]
     int N, K, log2g, scales_stride, zeros_stride;
 };
 
@@ -100,6 +102,31 @@ __global__ __launch_bounds__(64) void prepack_consts_kernel(const PrepackArgs a)
         a.consts[pk::const_index(n, g, a.K, G)] = uint2_t{__builtin_bit_cast(unsigned, e), pk::zc_word(z)};
     }
     a.last[n] = e;
+}
+
+// one thread per (row tile, group): the decode kernel's side arrays (w4a16_gemv_i8.hip) -- the fp16 scales and the zero points of the tile's 16 rows, side by side
+__global__ __launch_bounds__(64) void prepack_decode_kernel(const PrepackArgs a) {
+    const int ng = a.K >> a.log2g;
+    const long long idx = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (idx >= (long long)pk::nt16(a.N) * ng) return;
+    const int jt = (int)(idx / ng), g = (int)(idx % ng);
+    unsigned zw[2] = {0u, 0u};
+    unsigned short sb[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int n = jt * 16 + i;
+        unsigned z = 8u;
+        sb[i] = 0;
+        if (n < a.N) {
+            z = (a.zeros[(size_t)n * a.zeros_stride + (g >> 3)] >> ((g & 7) * 4)) & 0xFu;
+            sb[i] = __builtin_bit_cast(unsigned short, a.scales[(size_t)n * a.scales_stride + g]);
+        }
+        zw[i >> 3] |= z << (4 * (i & 7));
+    }
+    uint4_t *ds = reinterpret_cast<uint4_t *>(a.dscales) + (size_t)idx * 2;
+    ds[0] = uint4_t{sb[0] | ((unsigned)sb[1] << 16), sb[2] | ((unsigned)sb[3] << 16), sb[4] | ((unsigned)sb[5] << 16), sb[6] | ((unsigned)sb[7] << 16)};
+    ds[1] = uint4_t{sb[8] | ((unsigned)sb[9] << 16), sb[10] | ((unsigned)sb[11] << 16), sb[12] | ((unsigned)sb[13] << 16), sb[14] | ((unsigned)sb[15] << 16)};
+    reinterpret_cast<uint2_t *>(a.dzeros)[idx] = uint2_t{zw[0], zw[1]};
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -626,6 +653,8 @@ int launch_w4a16_prepack(const tce_w4a16_desc &d, void *out, hipStream_t stream,
     a.words = reinterpret_cast<unsigned *>(base);
     a.consts = reinterpret_cast<uint2_t *>(base + pk::consts_offset(d.N, d.K));
     a.last = reinterpret_cast<float *>(base + pk::last_offset(d.N, d.K, d.group_size));
+    a.dscales = reinterpret_cast<half_t *>(base + pk::dscales_offset(d.N, d.K, d.group_size));
+    a.dzeros = reinterpret_cast<unsigned *>(base + pk::dzeros_offset(d.N, d.K, d.group_size));
     a.N = d.N;
     a.K = d.K;
     a.log2g = d.group_size == 128 ? 7 : (d.group_size == 64 ? 6 : 5);
@@ -634,6 +663,7 @@ int launch_w4a16_prepack(const tce_w4a16_desc &d, void *out, hipStream_t stream,
     const int nt = pk::nt16(d.N);
     hipLaunchKernelGGL(prepack_words_kernel, dim3(nt, d.K >> 7), dim3(64), 0, stream, a);
     hipLaunchKernelGGL(prepack_consts_kernel, dim3((nt * 16 + 63) / 64), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL(prepack_decode_kernel, dim3((unsigned)(((long long)nt * (d.K / d.group_size) + 63) / 64)), dim3(64), 0, stream, a);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         if (hip_err) *hip_err = e;

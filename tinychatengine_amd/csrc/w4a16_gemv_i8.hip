@@ -1,0 +1,432 @@
+// w4a16_gemv_i8.hip -- the decode GEMV (M <= 4) as an EXACT int8 contraction on the matrix pipe, on the pre-packed copy of a linear (q4_mfma words + the
+// tile-major fp16 scales / zero points tce_w4a16_prepack writes beside them, w4a16_mfma_layout.hpp).  Round 4; replaces the unpack-to-halves GEMV
+// (w4a16_gemv.hip) wherever a packed copy comes with the descriptor.  Same math as gemv_kernel_g128 / g64 (reference kernels/cuda/gemv_cuda.cu:140-194, 68-123):
+//     C[m][n] = fp16( sum_g fp32(s[n][g]) * sum_{k in g} (q[n][k] - z[n][g]) * A[m][k] )
+// Why another kernel: the fp16 form spends 7 vector instructions per 8 weights on the unpack alone and is issue-bound; measured issue rates
+// (profiles/r4/valu_probe.jsonl): v_and_or / v_perm / v_cvt / v_dot8_i32_i4 4.2 cycles per wave instruction, plain VOP2 logic 2.4, an i8 16x16x64 MFMA 16, and
+// MFMA time ADDS to VALU time on a SIMD.  Here:
+//   * WEIGHTS  a lane's 16 bytes of the packed copy (row n16 of a 16-row tile, 32 codes of one 128-wide k unit) become the A operands of two
+//              v_mfma_i32_16x16x64_i8 as signed bytes 16 * (q - 8): one v_bitop3 for the high nibbles, shift + v_bitop3 for the low ones -- 3 instructions per
+//              8 weights, no zero-point term for the reference's zero point 8 (other zero points: (8 - z) * sum_k X_k from one more MFMA pair with A = 16).
+//   * X        every wave converts the 128 * UW activations IT consumes: x * 2^sh truncated to a 31-bit integer under ONE block exponent per wave and row
+//              (sh from the block's largest exponent: every element within 2^19 of the block maximum is represented exactly), split into four balanced
+//              base-256 digit planes ((I + 0x808080) ^ 0x808080: 2 instructions), byte-transposed into the B operand image in the wave's OWN LDS region: no
+//              workgroup barrier in front of the contraction.  The planes are COLUMNS of B: one MFMA contracts all four at once, products and sums exact.
+//   * COLUMNS  M = 1 uses 4 of the 16 output columns per 128-k unit, so four units (four quantization groups) share one accumulator: unit c of a pass presents
+//              its planes in columns 4c..4c+3 and zeros elsewhere (the B registers of the other lanes are never written).  One v_cvt_f32_i32 + one v_fma_mix
+//              (fp16 scale) per output register then serve FOUR groups; M = 2 / 4 rows of A take the columns instead (2 / 1 units per pass).
+//   * STREAM   a wave owns ROWS tiles x UW units: every weight byte it will use is requested at once (after the few x / scale bytes: loads retire in order,
+//              a wait for x must not be a wait for the weights), 1 KiB of consecutive memory per load instruction, non-temporal.
+//   * K        the waves of a workgroup split K (UW depends on K only: a row's bits do not depend on N, so column shards are bit-identical to the whole);
+//              partial rows meet in LDS and are added in wave order.
+// Numerics: integer part exact; the roundings are one fp32 fma per (row, group), the plane / group / wave additions in a fixed order, the fp16 store.
+// Activations holding inf / NaN: every output of that row is NaN (the reference yields NaN or +-inf there).
+#include "tce_common.hpp"
+#include "w4a16_kernels.hpp"
+#include "w4a16_mfma_layout.hpp"
+
+namespace tce {
+
+namespace {
+
+struct I8Seg {
+    const void *words;       // u32 [NT16][U][64][4]
+    const half_t *dscales;   // fp16 [NT16][NG][16]
+    const unsigned *dzeros;  // u32 [NT16][NG][2]
+    half_t *C;               // fp16 [M][ldc]
+    int N, ldc, epilogue;
+    int bytes_w, bytes_s, bytes_z;
+    int block_begin;  // first blockIdx.x of this linear
+};
+
+struct I8Args {
+    const half_t *A;  // fp16 [M][lda]
+    int lda, M, K, U, NG;  // U = K / 128 units, NG = K / G groups
+    int nseg;
+    I8Seg seg[TCE_MAX_GROUP];
+};
+
+template <int DPP_CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ unsigned dpp_max_u32(unsigned v) {
+    const unsigned t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, DPP_CTRL, ROW_MASK, 0xF, false);
+    return v > t ? v : t;
+}
+template <int DPP_CTRL>
+__device__ __forceinline__ float dpp_add_f32(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), DPP_CTRL, 0xF, 0xF, false);
+    return v + __builtin_bit_cast(float, t);
+}
+
+// MB rows of A per pass over the weights (1 / 2 / 4), GPU groups per 128-k unit (1 / 2 / 4 for G = 128 / 64 / 32), ROWS tiles per wave, UW units per wave.
+// Output column j of the MFMA = ((uu * GPU + gi) * MB + m) * 4 + p: unit-in-pass uu, group-in-unit gi, activation row m, digit plane p.
+template <int MB, int GPU, int ROWS, int UW, bool Z8, int MAXT>
+__global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const I8Args args) {
+    static_assert(MB * GPU <= 4, "sixteen output columns: rows x groups-per-unit x 4 planes");
+    constexpr int UPP = 4 / (MB * GPU);  // units per pass
+    static_assert(UW % UPP == 0 && UW % 4 == 0, "whole passes; whole 16-byte x loads per lane");
+    constexpr int NP = UW / UPP;         // passes
+    constexpr int XC = UW / 4;           // 8-element activation chunks per lane and row (64 lanes x 8 = 4 units)
+    constexpr int SPG = 4 / GPU;         // dwords of a lane's B operand that belong to one group
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wk = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int WK = blockDim.x >> 6;
+    const int u0 = wk * UW;
+    const int kq = lane >> 4, j = lane & 15;
+    const int U = args.U, NG = args.NG;
+    const int m0 = blockIdx.y * MB;
+
+    int si = 0;
+#pragma unroll
+    for (int s = 1; s < TCE_MAX_GROUP; ++s)
+        if (s < args.nseg && (int)blockIdx.x >= args.seg[s].block_begin) si = s;
+    const I8Seg seg = args.seg[si];
+    const int tile0 = ((int)blockIdx.x - seg.block_begin) * ROWS;
+    const int ntiles = (seg.N + 15) >> 4;
+    auto tile_of = [&](int r) { return tile0 + r < ntiles ? tile0 + r : ntiles - 1; };  // a surplus tile of the last workgroup re-reads the last one; its stores are masked
+
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(seg.words), 0, seg.bytes_w, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(seg.dscales), 0, seg.bytes_s, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(seg.dzeros), 0, seg.bytes_z, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_none = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(seg.words), 0, 0, 0x00020000);
+
+    // column of this lane
+    const int p_l = j & 3;
+    const int m_l = (j >> 2) % MB;
+    const int gi_l = ((j >> 2) / MB) % GPU;
+    const int uu_l = (j >> 2) / (MB * GPU);
+
+    // ---- 1. requests, in the order they are needed: activations, scales (zero points), then every weight byte of the wave ----
+    uint4_t xv[MB][XC];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        int mrow = m0 + m;
+        mrow = mrow < args.M ? mrow : args.M - 1;
+        // a descriptor per row, K halves long: chunks past K (a ragged last wave) read as zeros
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(args.A + (size_t)mrow * args.lda), 0, args.K * 2, 0x00020000);
+#pragma unroll
+        for (int c = 0; c < XC; ++c) xv[m][c] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, u0 * 256 + (lane + 64 * c) * 16, 0, 0);  // (the scalar offset of a buffer load is NOT range-checked: everything that may run past K sits in the vector offset)
+    }
+    uint2_t sc[ROWS][NP];
+    unsigned short zq[ROWS][NP];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            const int g = (ps * UPP + uu_l) * GPU + gi_l;  // group of this lane's column, relative to the wave's first group
+            const int ga = (tile_of(r) * NG + u0 * GPU) + g;  // groups past K (a ragged last wave) read the next tile's values or, behind the last tile, zeros: their products are zero
+            sc[r][ps] = __builtin_bit_cast(uint2_t, __builtin_amdgcn_raw_buffer_load_b64(rs_s, (ga * 16 + 4 * kq) * 2, 0, 0));
+            if constexpr (!Z8) zq[r][ps] = __builtin_amdgcn_raw_buffer_load_b16(rs_z, ga * 8 + 2 * kq, 0, 0);
+        }
+    __builtin_amdgcn_sched_barrier(0);
+    uint4_t w[ROWS][UW];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int t = 0; t < UW; ++t) {
+            // units past K (a ragged last wave): an empty descriptor -- answered with zeros by the buffer unit, no memory traffic
+            w[r][t] = __builtin_amdgcn_raw_buffer_load_b128(u0 + t < U ? rs_w : rs_none, lane * 16, (tile_of(r) * U + u0 + t) * 1024, /*nt*/ 2);
+        }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- 2. the wave's activations -> digit planes, image [unit][lo/hi][m][plane][kq][word s] in its own LDS region ----
+    unsigned *planes = reinterpret_cast<unsigned *>(smem) + wk * (UW * MB * 128);
+    int sh[MB];
+    bool bad[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        unsigned mx = 0;
+#pragma unroll
+        for (int c = 0; c < XC; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned v = xv[m][c][q] & 0x7FFF7FFFu;
+                const unsigned v2 = v << 16;
+                const unsigned m2 = v > v2 ? v : v2;  // bits 30..26: the larger exponent field of the two halves
+                mx = mx > m2 ? mx : m2;
+            }
+        // wave-wide maximum on the VALU: row_shr 1 2 4 8 inside rows of 16, then row_bcast15 / row_bcast31; the total sits in lane 63
+        mx = dpp_max_u32<0x111>(mx);
+        mx = dpp_max_u32<0x112>(mx);
+        mx = dpp_max_u32<0x114>(mx);
+        mx = dpp_max_u32<0x118>(mx);
+        mx = dpp_max_u32<0x142, 0xA>(mx);
+        mx = dpp_max_u32<0x143, 0xC>(mx);
+        const int E = (int)((unsigned)__builtin_amdgcn_readlane((int)mx, 63) >> 26);  // exponent field of the block's largest magnitude: |x| < 2^(E - 14)
+        bad[m] = E == 31;
+        sh[m] = 44 - E;  // |x * 2^sh| < 2^30
+        const float scale = __builtin_bit_cast(float, (unsigned)(127 + sh[m]) << 23);
+#pragma unroll
+        for (int c = 0; c < XC; ++c) {
+            unsigned d[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const half_t lo = __builtin_bit_cast(half_t, (unsigned short)(xv[m][c][q] & 0xFFFFu));
+                const half_t hi = __builtin_bit_cast(half_t, (unsigned short)(xv[m][c][q] >> 16));
+                // exact product (11 significant bits), truncated to an integer; balanced digits: the bytes of (I + 0x808080) ^ 0x808080
+                d[2 * q] = ((unsigned)(int)__builtin_fmaf((float)lo, scale, 0.0f) + 0x00808080u) ^ 0x00808080u;
+                d[2 * q + 1] = ((unsigned)(int)__builtin_fmaf((float)hi, scale, 0.0f) + 0x00808080u) ^ 0x00808080u;
+            }
+            // chunk cc of the wave's block = the 8 activations of (unit tu, word s, k-quarter q): k = 128 tu + 32 s + 8 q + e
+            const int cc = lane + 64 * c;
+            const int tu = cc >> 4, s = (cc >> 2) & 3, q4 = cc & 3;
+            // a packed word's low nibbles are the codes e = (0, 4, 1, 5), its high nibbles e = (2, 6, 3, 7) (pk::nibble_index)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const unsigned a0 = d[2 * h], a1 = d[2 * h + 4], a2 = d[2 * h + 1], a3 = d[2 * h + 5];
+                const unsigned t0 = __builtin_amdgcn_perm(a1, a0, 0x05010400u);  // (a0.b0, a1.b0, a0.b1, a1.b1)
+                const unsigned t1 = __builtin_amdgcn_perm(a1, a0, 0x07030602u);  // (a0.b2, a1.b2, a0.b3, a1.b3)
+                const unsigned t2 = __builtin_amdgcn_perm(a3, a2, 0x05010400u);
+                const unsigned t3 = __builtin_amdgcn_perm(a3, a2, 0x07030602u);
+                const int base = ((((tu * 2 + h) * MB + m) * 4) * 4 + q4) * 4 + s;  // + plane * 16
+                planes[base + 0] = __builtin_amdgcn_perm(t2, t0, 0x05040100u);
+                planes[base + 16] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+                planes[base + 32] = __builtin_amdgcn_perm(t3, t1, 0x05040100u);
+                planes[base + 48] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- 3. contraction.  B set uu: the operand of unit uu of the pass in the lanes of ITS columns, zeros in the others (never written) ----
+    int4_t B[UPP][2];
+#pragma unroll
+    for (int uu = 0; uu < UPP; ++uu) B[uu][0] = B[uu][1] = int4_t{0, 0, 0, 0};
+    auto read_b = [&](int ps) {
+#pragma unroll
+        for (int uu = 0; uu < UPP; ++uu)
+#pragma unroll
+            for (int gi = 0; gi < GPU; ++gi)
+                if (uu_l == uu && gi_l == gi) {  // exec-masked reads
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const unsigned *src = planes + ((((((ps * UPP + uu) * 2 + h) * MB + m_l) * 4 + p_l) * 4 + kq) * 4 + gi * SPG);
+                        if constexpr (GPU == 1) {
+                            B[uu][h] = __builtin_bit_cast(int4_t, *reinterpret_cast<const uint4_t *>(src));
+                        } else if constexpr (GPU == 2) {
+                            const uint2_t v = *reinterpret_cast<const uint2_t *>(src);
+                            B[uu][h][gi * 2] = (int)v[0];
+                            B[uu][h][gi * 2 + 1] = (int)v[1];
+                        } else {
+                            B[uu][h][gi] = (int)*src;
+                        }
+                    }
+                }
+    };
+    read_b(0);
+
+    float acc[ROWS][4];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[r][q] = 0.f;
+    const int4_t zero4 = int4_t{0, 0, 0, 0};
+    const int4_t sixteens = int4_t{0x10101010, 0x10101010, 0x10101010, 0x10101010};
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+        int4_t dd[ROWS][2];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) dd[r][0] = dd[r][1] = zero4;
+        int4_t dz = zero4;  // 16 * sum of the digits of the column's group (zero points other than 8)
+#pragma unroll
+        for (int uu = 0; uu < UPP; ++uu) {
+            const int t = ps * UPP + uu;
+            if constexpr (!Z8) {
+                dz = __builtin_amdgcn_mfma_i32_16x16x64_i8(sixteens, B[uu][0], dz, 0, 0, 0);
+                dz = __builtin_amdgcn_mfma_i32_16x16x64_i8(sixteens, B[uu][1], dz, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                int4_t alo, ahi;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned x8 = w[r][t][q] ^ 0x88888888u;
+                    ahi[q] = (int)(x8 & 0xF0F0F0F0u);
+                    alo[q] = (int)((x8 << 4) & 0xF0F0F0F0u);
+                }
+                dd[r][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(alo, B[uu][0], dd[r][0], 0, 0, 0);
+                dd[r][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ahi, B[uu][1], dd[r][1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const half_t s0 = __builtin_bit_cast(half_t, (unsigned short)(sc[r][ps][0] & 0xFFFFu));
+            const half_t s1 = __builtin_bit_cast(half_t, (unsigned short)(sc[r][ps][0] >> 16));
+            const half_t s2 = __builtin_bit_cast(half_t, (unsigned short)(sc[r][ps][1] & 0xFFFFu));
+            const half_t s3 = __builtin_bit_cast(half_t, (unsigned short)(sc[r][ps][1] >> 16));
+            int4_t tot = dd[r][0] + dd[r][1];
+            if constexpr (!Z8) {
+                // sum (q - z) X = sum (q - 8) X + (8 - z) sum X, in the same units of 16
+#pragma unroll
+                for (int q = 0; q < 4; ++q) tot[q] += __mul24(8 - (int)((zq[r][ps] >> (4 * q)) & 0xFu), dz[q]);
+            }
+            acc[r][0] = __builtin_fmaf((float)tot[0], (float)s0, acc[r][0]);
+            acc[r][1] = __builtin_fmaf((float)tot[1], (float)s1, acc[r][1]);
+            acc[r][2] = __builtin_fmaf((float)tot[2], (float)s2, acc[r][2]);
+            acc[r][3] = __builtin_fmaf((float)tot[3], (float)s3, acc[r][3]);
+        }
+        if (ps + 1 < NP) read_b(ps + 1);
+    }
+
+    // ---- 4. planes and groups -> the wave's partial rows (fixed lane order), waves -> rows (wave order), store ----
+    int sh_l = sh[0];
+    bool bad_l = bad[0];
+#pragma unroll
+    for (int m = 1; m < MB; ++m) {
+        sh_l = m_l == m ? sh[m] : sh_l;
+        bad_l = m_l == m ? bad[m] : bad_l;
+    }
+    // 2^(8 p) * 2^(-sh) / 16 (the A operand carries 16 (q - 8))
+    const float cj = bad_l ? __builtin_nanf("") : __builtin_bit_cast(float, (unsigned)(127 + 8 * p_l - sh_l - 4) << 23);
+    float *red = reinterpret_cast<float *>(smem + (size_t)WK * UW * MB * 512);  // [WK][ROWS][MB][16]
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v = acc[r][q] * cj;
+            v = dpp_add_f32<0xB1>(v);  // quad_perm [1,0,3,2]: planes
+            v = dpp_add_f32<0x4E>(v);  // quad_perm [2,3,0,1]
+            if constexpr (MB <= 2) v = dpp_add_f32<0x128>(v);  // row_ror 8
+            if constexpr (MB == 1) v = dpp_add_f32<0x124>(v);  // row_ror 4
+            if (p_l == 0 && (j >> 2) < MB) red[((wk * ROWS + r) * MB + m_l) * 16 + kq * 4 + q] = v;
+        }
+    __syncthreads();
+    if (tid < ROWS * MB * 16) {
+        float part[16];
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) part[k2] = red[(k2 < WK ? k2 : 0) * (ROWS * MB * 16) + tid];
+        float v = 0.f;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) v += k2 < WK ? part[k2] : 0.f;
+        const int i16 = tid & 15, m = (tid >> 4) % MB, r = tid / (16 * MB);
+        const int row = (tile0 + r) * 16 + i16;  // (unclamped: a surplus tile's rows are >= N)
+        const half_t y = (half_t)v;
+        // the (gate, up) neighbour of the pair epilogue: rows 2n, 2n + 1 are adjacent lanes
+        const half_t y_other = __builtin_bit_cast(half_t, (unsigned short)__builtin_amdgcn_update_dpp(0, (int)__builtin_bit_cast(unsigned short, y), 0xB1, 0xF, 0xF, false));
+        if (m0 + m < args.M && row < seg.N) {
+            half_t *crow = seg.C + (size_t)(m0 + m) * seg.ldc;
+            if (seg.epilogue & TCE_W4_SILU_MUL_PAIRS) {
+                if ((i16 & 1) == 0) crow[row >> 1] = silu_mul_half(y, y_other);
+            } else if (seg.epilogue & TCE_W4_ADD_TO_C) {
+                crow[row] = crow[row] + y;
+            } else {
+                crow[row] = y;
+            }
+        }
+    }
+}
+
+int g_i8_mode = 0;  // 0 automatic, 1 off, 2 forced wherever the shape allows
+int g_i8_rows = 0;  // 0 the rule, 1 / 2 forced tiles per wave
+
+template <int MB, int GPU, int ROWS, int UW, bool Z8, int MAXT>
+hipError_t launch_i8(const I8Args &a, int blocks, int m_blocks, int wk, hipStream_t stream) {
+    const size_t lds = (size_t)wk * UW * MB * 512 + (size_t)wk * ROWS * MB * 16 * sizeof(float);
+    auto kfn = w4a16_gemv_i8_kernel<MB, GPU, ROWS, UW, Z8, MAXT>;
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kfn, dim3(blocks, m_blocks, 1), dim3(64 * wk, 1, 1), lds, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+void set_gemv_i8_mode(int mode, int rows) {
+    g_i8_mode = mode >= 0 && mode <= 2 ? mode : 0;
+    g_i8_rows = rows == 1 || rows == 2 ? rows : 0;
+}
+
+// units per wave: a function of K (and of the rows / groups per pass) ONLY, so that a row's arithmetic does not depend on N
+static int i8_units_per_wave(int U) { return U <= 128 ? 8 : (U <= 256 ? 16 : 0); }
+
+bool gemv_i8_supports(const tce_w4a16_desc *descs, int count) {
+    if (g_i8_mode == 1) return false;
+    const tce_w4a16_desc &d0 = descs[0];
+    if (d0.M < 1 || d0.M > 4 || d0.K % 128 != 0 || d0.rmsnorm_gamma) return false;
+    if (d0.group_size != 128 && d0.M > (d0.group_size == 64 ? 2 : 1)) return false;
+    const int uw = i8_units_per_wave(d0.K / 128);
+    if (uw == 0 || (uw == 16 && (d0.M > 1 || d0.group_size != 128))) return false;  // (very long K: single rows only -- the registers hold 16 KiB of weights per wave)
+    for (int i = 0; i < count; ++i) {
+        const tce_w4a16_desc &d = descs[i];
+        if (!d.prepacked || (reinterpret_cast<uintptr_t>(d.prepacked) & 255)) return false;
+        if ((long long)pk::nt16(d.N) * (d.K / 2) * 16 >= (1LL << 31)) return false;  // buffer descriptors address 32-bit byte offsets
+        if (d.flags & TCE_W4_FORCE_GEMM) return false;
+    }
+    return true;
+}
+
+int launch_w4a16_gemv_i8(const tce_w4a16_desc *descs, int count, hipStream_t stream, hipError_t *hip_err) {
+    const tce_w4a16_desc &d0 = descs[0];
+    I8Args a{};
+    a.A = static_cast<const half_t *>(d0.A);
+    a.lda = d0.lda ? d0.lda : d0.K;
+    a.M = d0.M;
+    a.K = d0.K;
+    a.U = d0.K / 128;
+    a.NG = d0.K / d0.group_size;
+    a.nseg = count;
+    const int gpu = 128 / d0.group_size;
+    const int uw = i8_units_per_wave(a.U);
+    const int wk = (a.U + uw - 1) / uw;
+    bool z8 = true;
+    long long total_tiles = 0;
+    for (int i = 0; i < count; ++i) {
+        z8 = z8 && (descs[i].flags & TCE_W4_ZERO_POINT_IS_8);
+        total_tiles += pk::nt16(descs[i].N);
+    }
+    // rows of A per pass: 1 / 2 / 4, bounded by the sixteen columns and by the planes fitting LDS twice per CU
+    int mb = d0.M >= 3 ? 4 : d0.M;
+    while (mb > 1 && (mb * gpu > 4 || (size_t)wk * uw * mb * 512 > 72 * 1024)) mb >>= 1;
+    const int m_blocks = (d0.M + mb - 1) / mb;
+    // tiles per wave: one.  Two (the conversion of x amortised over twice the bytes, one generation of workgroups for the gate+up launch) measured slower on every
+    // launch of the token (profiles/r4/gemv_i8_ab.jsonl: qkv 6.6 -> 7.4 us, o 3.9 -> 4.5, gate+up 9.9 -> 10.2, down a tie); compiled, forceable (tce_w4a16_set_gemv_i8)
+    int rows = 1;
+    (void)total_tiles;
+    if (g_i8_rows && mb == 1 && gpu == 1 && uw == 8 && wk <= 8) rows = g_i8_rows;
+    int blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        const tce_w4a16_desc &d = descs[i];
+        I8Seg &s = a.seg[i];
+        const unsigned char *base = static_cast<const unsigned char *>(d.prepacked);
+        s.words = base;
+        s.dscales = reinterpret_cast<const half_t *>(base + pk::dscales_offset(d.N, d.K, d.group_size));
+        s.dzeros = reinterpret_cast<const unsigned *>(base + pk::dzeros_offset(d.N, d.K, d.group_size));
+        s.C = static_cast<half_t *>(d.C);
+        s.N = d.N;
+        s.epilogue = d.flags & (TCE_W4_SILU_MUL_PAIRS | TCE_W4_ADD_TO_C);
+        s.ldc = d.ldc ? d.ldc : ((s.epilogue & TCE_W4_SILU_MUL_PAIRS) ? d.N / 2 : d.N);
+        s.bytes_w = (int)pk::words_bytes(d.N, d.K);
+        s.bytes_s = (int)pk::dscales_bytes(d.N, d.K, d.group_size);
+        s.bytes_z = (int)pk::dzeros_bytes(d.N, d.K, d.group_size);
+        s.block_begin = blocks;
+        blocks += (pk::nt16(d.N) + rows - 1) / rows;
+    }
+    for (int i = count; i < TCE_MAX_GROUP; ++i) a.seg[i] = a.seg[0];
+    hipError_t e = hipErrorInvalidConfiguration;
+#define TCE_I8(MB_, GPU_, ROWS_, UW_, MAXT_)                                                                                        \
+    if (mb == MB_ && gpu == GPU_ && rows == ROWS_ && uw == UW_) {                                                                   \
+        e = z8 ? launch_i8<MB_, GPU_, ROWS_, UW_, true, MAXT_>(a, blocks, m_blocks, wk, stream)                                     \
+               : launch_i8<MB_, GPU_, ROWS_, UW_, false, MAXT_>(a, blocks, m_blocks, wk, stream);                                   \
+    } else
+    TCE_I8(1, 1, 1, 8, 1024)
+    TCE_I8(1, 1, 2, 8, 512)
+    TCE_I8(1, 1, 1, 16, 1024)
+    TCE_I8(2, 1, 1, 8, 1024)
+    TCE_I8(4, 1, 1, 8, 1024)
+    TCE_I8(1, 2, 1, 8, 1024)
+    TCE_I8(2, 2, 1, 8, 1024)
+    TCE_I8(1, 4, 1, 8, 1024)
+    return TCE_ERR_UNSUPPORTED_SHAPE;
+#undef TCE_I8
+    if (e != hipSuccess) {
+        if (hip_err) *hip_err = e;
+        return TCE_ERR_HIP;
+    }
+    return TCE_OK;
+}
+
+}  // namespace tce

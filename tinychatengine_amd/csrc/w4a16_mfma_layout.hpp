@@ -27,7 +27,10 @@
 //                                            group once at the end:  sum_g s_g * blk_g  ==  e_last * (((blk_0 r_1 + blk_1) r_2 + ...)
 //   last    f32 [NT16][16]                   e of the row's last group (written by the prepack for tools and tests; the kernel carries
 //                                            the value it needs in a register: a k-split wave quartet ends on ITS last group)
-//   rows past N (N % 16 != 0) are zero-filled tile rows: codes = 8, zc for z = 8, e = 1, last = 0.
+//   dscales fp16 [NT16][K/G][16]             (round 4) the fp16 group scales as loaded, tile-major: the 16 rows of a tile side by side per group -- what the
+//                                            decode kernel on this copy (w4a16_gemv_i8.hip) reads: 8 bytes per lane = the four rows of its MFMA output registers
+//   dzeros  u32 [NT16][K/G][2]               (round 4) the 4-bit zero points of the same 16 rows: nibble n16 % 8 of word n16 / 8 (read only without TCE_W4_ZERO_POINT_IS_8)
+//   rows past N (N % 16 != 0) are zero-filled tile rows: codes = 8, zc for z = 8, e = 1, last = 0, dscale = 0, dzero = 8.
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
@@ -49,11 +52,15 @@ TCE_HD int nt16(int N) { return (N + 15) / 16; }
 TCE_HD size_t words_bytes(int N, int K) { return (size_t)nt16(N) * (K / 128) * 64 * 4 * 4; }
 TCE_HD size_t consts_bytes(int N, int K, int G) { return (size_t)nt16(N) * (K / G) * 16 * 8; }
 TCE_HD size_t last_bytes(int N) { return (size_t)nt16(N) * 16 * 4; }
-// one allocation: [words | consts | last], each part 256-byte aligned
+// one allocation: [words | consts | last | dscales | dzeros], each part 256-byte aligned
 TCE_HD size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 TCE_HD size_t consts_offset(int N, int K) { return align256(words_bytes(N, K)); }
 TCE_HD size_t last_offset(int N, int K, int G) { return consts_offset(N, K) + align256(consts_bytes(N, K, G)); }
-TCE_HD size_t total_bytes(int N, int K, int G) { return last_offset(N, K, G) + align256(last_bytes(N)); }
+TCE_HD size_t dscales_bytes(int N, int K, int G) { return (size_t)nt16(N) * (K / G) * 16 * 2; }
+TCE_HD size_t dzeros_bytes(int N, int K, int G) { return (size_t)nt16(N) * (K / G) * 8; }
+TCE_HD size_t dscales_offset(int N, int K, int G) { return last_offset(N, K, G) + align256(last_bytes(N)); }
+TCE_HD size_t dzeros_offset(int N, int K, int G) { return dscales_offset(N, K, G) + align256(dscales_bytes(N, K, G)); }
+TCE_HD size_t total_bytes(int N, int K, int G) { return dzeros_offset(N, K, G) + align256(dzeros_bytes(N, K, G)); }
 
 // ---- packed words ----
 // position of code (n, k): index of the u32 word in `words`, and the nibble (0..7) inside it

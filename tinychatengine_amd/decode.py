@@ -70,7 +70,7 @@ class DecodeLinears:
     """All W4A16 linears of one decode token for rank `rank` of `world`, plus the launch list / plan to run them."""
 
     def __init__(self, shape: ModelShape, device="cuda", group_size: int = 128, rank: int = 0, world: int = 1,
-                 m: int = 1, seed: int = 1234, layers: int | None = None, dataflow: bool = False):
+                 m: int = 1, seed: int = 1234, layers: int | None = None, dataflow: bool = False, prepack: bool = False):
         """dataflow = False: every linear reads its own fixed synthetic activation vector (the launches are ordered by the
         stream only).  dataflow = True (world 1, M = 1): the linears FEED each other the way they do in the decoder --
         x -> qkv; o reads the q slice of qkv's output (the attention between them is not part of this path and same-sized);
@@ -97,6 +97,10 @@ class DecodeLinears:
                 qkv=[mk(n, h, s + i) for i, n in enumerate(shape.qkv)],
                 o=mk(h, h, s + 4), gate=mk(f, h, s + 5), up=mk(f, h, s + 6), down=mk(h, f, s + 7)))
         self.lm_head = mk(shape.vocab, h, 999_983)
+        self.prepacked = bool(prepack)
+        if prepack:  # load-time re-layout (tce_w4a16_prepack): the descriptors then carry the packed copy and the decode launches run on it (csrc/w4a16_gemv_i8.hip)
+            for l in self.all_linears():
+                l.prepack()
         # activations (fp16).  x ~ N(0,1); every buffer a linear READS is full width (replicated input).
         gx = torch.Generator(device=self.device).manual_seed(4321)
         rnd = lambda *sz: torch.empty(sz, dtype=torch.float32, device=self.device).normal_(0, 1, generator=gx).to(torch.float16)
