@@ -34,7 +34,12 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="baseline-named", choices=["baseline-named", "llama3-8b", "llama2-13b", "tiny"])
+    ap.add_argument("--workload", default="llama3-8b", choices=["baseline-named", "llama3-8b", "llama2-13b", "tiny"],
+                    help="the model whose decode token is the headline `value`.  Default: the model the metric names (Llama-3-8B's true shapes, llm/include/model.h:83); "
+                         "the shape set BASELINE.json's configs[1] spells (4096x4096, 4096x11008: Llama-2-7B widths) is timed beside it and reported under `baseline_named_shapes` "
+                         "and, launch by launch, under `roofline.shapes`")
+    ap.add_argument("--no-prepack", action="store_true", help="decode on the q4_6 arrays with the fp16-unpack GEMV kernels (rounds 1-3) instead of the int8-contraction "
+                                                               "kernel on the packed copies (round 4): A/B runs")
     ap.add_argument("--layers", type=int, default=None, help="override the number of transformer blocks (debug only)")
     ap.add_argument("--ungrouped", action="store_true", help="one launch per linear, as the reference issues them")
     ap.add_argument("--gathers-per-block", type=int, default=0, choices=[0, 1, 4], help="N > 1: 0 (default) = time both the north-star definition (1) and the dependency-faithful form (4)")
@@ -42,7 +47,7 @@ def parse_args():
                     help="N > 1: how the ranks' output slices are joined -- peer: tce_allgather_f16 (one peer-write kernel per exchange over xGMI, csrc/comm.hip); rccl: torch.distributed "
                          "all_gather_into_tensor; all (default): both are timed in the same run (config.gather_variants), the headline is the faster one-gather-per-block variant")
     ap.add_argument("--no-projection", action="store_true", help="N = 1: skip other_configs.projected_scaling (this GPU timing one rank's N/P-row shards for P = 2, 4, 8)")
-    ap.add_argument("--issue", default="auto", choices=["auto", "graph", "token"],
+    ap.add_argument("--issue", default="graph", choices=["auto", "graph", "token"],
                     help="N = 1: graph = one hipGraph of 129 launches per token (stream order); token = ONE persistent kernel per token, the linears' data "
                          "flow ordered by tagged output words (TCE_PLAN_TAGGED); auto = both are verified against each other and timed, the faster one is the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -167,13 +172,14 @@ def other_configs_leg(torch, dev):
 
 
 # ----------------------------------------------------------------------------------------------------------------
-def roofline_leg(dl, torch, launches: int, eager: bool = False, which: int = 2, quick: bool = False, knobs=None):
+def roofline_leg(dl, torch, launches: int, eager: bool = False, which: int = 2, quick: bool = False, knobs=None, groups=None):
     """The dominant kernel in isolation: the grouped gate+up GEMV launch (2*ffn rows x hidden), `launches` back-to-back
     launches on one stream, rotating over the layers' distinct weights (ring >> Infinity Cache), HIP events on that
     stream around the whole sequence.  achieved = algorithmic bytes per launch / average launch duration."""
     from tinychatengine_amd import capi
     st = torch.cuda.current_stream().cuda_stream
-    groups = [dl.block_launches(li)[which] for li in range(dl.n_layers)]
+    if groups is None:
+        groups = [dl.block_launches(li)[which] for li in range(dl.n_layers)]
     d0 = groups[0]
     formula_bytes = sum(capi.algorithmic_bytes(dl.m, d.N, d.K, d.group_size) for d in d0)
     # SURVEY 8d's formula counts the packed zero points (N*K/(2G) bytes); with TCE_W4_ZERO_POINT_IS_8 (what the reference quantizer
@@ -236,7 +242,7 @@ def _roofline_leg_body(dl, torch, launches, eager, quick, capi, L, C, st, stp, g
     gbs = bytes_per_launch / us / 1e3
     if quick:  # the per-shape table: rate only
         return {"launch": "+".join(str(d.N) for d in d0) + f" x {d0[0].K}", "us": round(us, 2), "GBs": round(gbs, 1), "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 3),
-                "bytes": bytes_per_launch}
+                "bytes": bytes_per_launch, "kernel": capi.describe_dispatch(d0[0])}
     # spread: the same graph replayed 15 more times, each replay timed on its own (median and p10 / p90)
     per = []
     for _ in range(15):
@@ -263,7 +269,9 @@ def _roofline_leg_body(dl, torch, launches, eager, quick, capi, L, C, st, stp, g
     return {
         "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
         **_pmc_traffic(bytes_per_launch),
-        "kernel": f"w4a16_gemv_kernel (grouped gate+up launch, N={'+'.join(str(d.N) for d in d0)}, K={d0[0].K}, M={dl.m})",
+        "kernel": f"{'w4a16_gemv_i8_kernel (int8 contraction on the packed copy)' if capi.describe_dispatch(d0[0]).startswith('gemv-i8') else 'w4a16_gemv_kernel (fp16 unpack on q4_6)'}"
+                  f", grouped gate+up launch, N={'+'.join(str(d.N) for d in d0)}, K={d0[0].K}, M={dl.m}",
+        "dispatch": capi.describe_dispatch(d0[0]),
         "algorithmic_bytes_per_launch": bytes_per_launch, "survey_8d_formula_bytes_per_launch": formula_bytes,
         "bytes_note": "formula of SURVEY 8d minus the packed zero points the zero-point-8 kernel never reads" if zeros_bytes else "formula of SURVEY 8d",
         "avg_launch_us": round(us, 3), "launches_timed": reps * launches,
@@ -282,6 +290,10 @@ def launch_shape_table(dl, torch, launches: int = 128):
     from tinychatengine_amd import capi
     import ctypes as C
     rows = [roofline_leg(dl, torch, launches, which=w, quick=True) for w in range(4)]
+    for r, nm in zip(rows, ("qkv (one launch)", "o_proj", "gate+up (one launch)", "down_proj")):
+        r["name"] = nm
+    # the ffn x hidden projection ALONE (the shape BASELINE.json spells as 4096x11008 read row-major: one of gate / up without its sibling)
+    rows.append(dict(roofline_leg(dl, torch, launches, quick=True, groups=[dl.block_launches(li)[2][:1] for li in range(dl.n_layers)]), name="gate_proj alone"))
     L = capi.lib()
     gu = [dl.block_launches(li)[2] for li in range(dl.n_layers)]
     arrs = [(capi.W4A16Desc * len(g))(*g) for g in gu]
@@ -307,7 +319,7 @@ def launch_shape_table(dl, torch, launches: int = 128):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / (5 * n) - 3 * rows[2]["us"]
     b = capi.algorithmic_bytes(dl.m, d.N, d.K, d.group_size) - (d.N * d.K // (2 * d.group_size) if d.flags & capi.TCE_W4_ZERO_POINT_IS_8 else 0)
-    rows.append({"launch": f"{d.N} x {d.K} (lm_head)", "us": round(us, 2), "GBs": round(b / us / 1e3, 1), "frac_of_8TBs": round(b / us / 1e3 / HBM_PEAK_GBS, 3),
+    rows.append({"name": "lm_head", "launch": f"{d.N} x {d.K} (lm_head)", "kernel": capi.describe_dispatch(d), "us": round(us, 2), "GBs": round(b / us / 1e3, 1), "frac_of_8TBs": round(b / us / 1e3 / HBM_PEAK_GBS, 3),
                  "bytes": b, "timing": "interleaved with 3 gate+up launches (cache flush), their time subtracted"})
     return rows
 
@@ -438,7 +450,7 @@ def opt_layer_leg(torch, dev, size="125M"):
     return out
 
 
-def projected_scaling_leg(torch, dev, G):
+def projected_scaling_leg(torch, dev, G, prepack=True):
     """"if only one GPU is visible, report P > 1 as not measurable here plus the measured per-shard kernel times at N/P shapes".
     This GPU plays rank 0 of P = 2, 4, 8: all of one token's linears at N/P rows (tce_w4a16_shard's row ranges; weights 1/P of the model, still
     more than the memory-side cache for the 7B-class sets at P <= 8) as one stream-ordered hipGraph -- the compute side of a sharded token,
@@ -456,7 +468,7 @@ def projected_scaling_leg(torch, dev, G):
         rows = {}
         for P in (1, 2, 4, 8):
             try:
-                dlp = DecodeLinears(shape, device=dev, group_size=G, rank=0, world=P, m=1)
+                dlp = DecodeLinears(shape, device=dev, group_size=G, rank=0, world=P, m=1, prepack=prepack)
                 plan = dlp.make_plan()
                 for _ in range(5):
                     plan.launch(st)
@@ -690,11 +702,22 @@ def main():
     from tinychatengine_amd import capi
     from tinychatengine_amd.decode import SHAPES, DecodeLinears
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1) and become that job --
+        # rank 0's JSON line is this command's last line of stdout, exactly as under `python -m torch.distributed.run ... bench.py --gpus N`
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__), *sys.argv[1:]]
+        print(f"[bench] --gpus {args.gpus} without WORLD_SIZE: starting the ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+        os.execv(sys.executable, cmd)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     capi.lib()
@@ -716,8 +739,9 @@ def main():
     G = 128
     if args.force_dist:
         os.environ["TCE_FORCE_GATHER_BUFFERS"] = "1"
+    prepack = not args.no_prepack  # load-time re-layout of every linear (tce_w4a16_prepack): the decode launches then run on the packed copies (csrc/w4a16_gemv_i8.hip)
     dl = DecodeLinears(shape, device=dev, group_size=G, rank=rank, world=world, m=1, layers=args.layers,
-                       dataflow=(world == 1 and not args.ungrouped and shape.qkv[0] >= shape.hidden))
+                       dataflow=(world == 1 and not args.ungrouped and shape.qkv[0] >= shape.hidden), prepack=prepack)
     want_peer = args.gather in ("all", "peer")
     if dist is not None and want_peer:
         # The peer-write gather needs every rank's window mapped into every other rank (hipIpc) and one exchange to come back right.
@@ -1041,6 +1065,7 @@ def main():
              "event_ms_per_token": round(ev_ms_per_step, 4)}
 
     extras = None
+    secondary = None
     if rank == 0 and world == 1 and not args.no_extras:
         try:
             extras = other_configs_leg(torch, dev)
@@ -1055,41 +1080,46 @@ def main():
             extras["decode_launch_shapes"] = launch_shape_table(dl, torch)
         except Exception as e:  # noqa: BLE001
             extras["decode_launch_shapes"] = {"error": f"{type(e).__name__}: {e}"}
-        if args.workload == "baseline-named" and not args.no_projection:
+        if args.workload in ("baseline-named", "llama3-8b") and not args.no_projection:
             try:  # SURVEY 8e on one GPU: per-rank shard compute at N/P rows, measured; the exchange side assumed and labelled
-                extras["projected_scaling"] = projected_scaling_leg(torch, dev, G)
+                extras["projected_scaling"] = projected_scaling_leg(torch, dev, G, prepack)
             except Exception as e:  # noqa: BLE001
                 extras["projected_scaling"] = {"error": f"{type(e).__name__}: {e}"}
-        if args.workload == "baseline-named":
+        if args.workload in ("baseline-named", "llama3-8b"):
             try:  # the callers either side of the path: a WHOLE decode token -- norms, RoPE, KV append, attention, residuals -- in 5 launches per layer
                 extras["decode_with_attention"] = whole_token_leg(torch, dev, shape, dl)
             except Exception as e:  # noqa: BLE001
                 extras["decode_with_attention"] = {"error": f"{type(e).__name__}: {e}"}
-            try:  # BASELINE.json says "Llama-3-8B" but spells Llama-2-7B widths: the true Llama-3-8B shape set beside it
-                dl3 = DecodeLinears(SHAPES["llama3-8b"], device=dev, group_size=G, m=1)
-                plan3 = dl3.make_plan()
+            # The other of the two shape sets this metric is read on: BASELINE.json names "Llama-3-8B" and spells Llama-2-7B widths (4096x4096, 4096x11008).
+            # The headline `value` is the model the metric names; the spelled shapes are timed here, the same way, and reported at the top level.
+            other_key = "baseline-named" if args.workload == "llama3-8b" else "llama3-8b"
+            try:
+                dl2 = DecodeLinears(SHAPES[other_key], device=dev, group_size=G, m=1, prepack=prepack,
+                                    dataflow=(not args.ungrouped and SHAPES[other_key].qkv[0] >= SHAPES[other_key].hidden))
+                plan2 = dl2.make_plan()
                 for _ in range(5):
-                    plan3.launch(stream)
+                    plan2.launch(stream)
                 torch.cuda.synchronize()
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
-                for _ in range(30):
-                    plan3.launch(stream)
+                for _ in range(50):
+                    plan2.launch(stream)
                 b.record()
                 torch.cuda.synchronize()
-                ms3 = a.elapsed_time(b) / 30
-                extras["decode_llama3_8b_true_shapes"] = {
-                    "tokens_per_s": round(1e3 / ms3, 1), "ms_per_token": round(ms3, 4), "algorithmic_bytes_per_token": dl3.token_bytes(),
-                    "frac_of_8TBs": round(dl3.token_bytes() / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                    "launch_shapes": launch_shape_table(dl3, torch, 96)}
-                del plan3
-                try:  # the whole token for the model the metric names: grouped-query attention (32 query heads over 8 key / value heads)
-                    extras["decode_llama3_8b_true_shapes"]["decode_with_attention"] = whole_token_leg(torch, dev, SHAPES["llama3-8b"], dl3)
+                ms2 = a.elapsed_time(b) / 50
+                secondary = {
+                    "workload": SHAPES[other_key].name, "tokens_per_s": round(1e3 / ms2, 1), "ms_per_token": round(ms2, 4), "algorithmic_bytes_per_token": dl2.token_bytes(),
+                    "frac_of_8TBs": round(dl2.token_bytes() / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "launches_per_token": plan2.n_launches,
+                    "launch_shapes": launch_shape_table(dl2, torch, 96)}
+                del plan2
+                try:
+                    secondary["decode_with_attention"] = whole_token_leg(torch, dev, SHAPES[other_key], dl2)
                 except Exception as e:  # noqa: BLE001
-                    extras["decode_llama3_8b_true_shapes"]["decode_with_attention"] = {"error": f"{type(e).__name__}: {e}"}
-                del dl3
+                    secondary["decode_with_attention"] = {"error": f"{type(e).__name__}: {e}"}
+                del dl2
+                torch.cuda.empty_cache()
             except Exception as e:  # noqa: BLE001
-                extras["decode_llama3_8b_true_shapes"] = {"error": f"{type(e).__name__}: {e}"}
+                secondary = {"error": f"{type(e).__name__}: {e}"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -1110,13 +1140,27 @@ def main():
                                        + " per block") if world > 1 else "single GPU",
                        "issue": mode, **({"issue_variants": variants} if variants else {}), **({"gather_variants": gather_variants} if gather_variants else {}),
                        "grouped_launches": not args.ungrouped,
+                       "decode_kernel": ("int8 contraction on the packed copy of every linear (tce_w4a16_prepack at load time; csrc/w4a16_gemv_i8.hip)" if prepack
+                                         else "fp16 unpack on the q4_6 arrays (csrc/w4a16_gemv.hip)"),
                        "activations": ("the linears feed each other as in the decoder (x -> qkv; o reads the q slice; o -> gate/up; gate -> down; down -> next block; "
                                        "last down -> lm_head); W ~ N(0, 1/K)") if dl.dataflow else "every linear reads its own fixed N(0,1) vector; W ~ N(0, 0.02^2)",
                        "algorithmic_bytes_per_token": token_bytes_full},
             "whole_token": whole,
         }
         if roof is not None:
+            # every launch shape of the token inside the block the driver keeps: this workload's and -- the shapes BASELINE.json spells, on which the 0.70 bar is
+            # quoted -- the baseline-named set's (4096 x 4096 = o_proj, 4096 x 11008 = down_proj / the gate projection alone)
+            if extras is not None and isinstance(extras.get("decode_launch_shapes"), list) and isinstance(roof, dict) and "error" not in roof:
+                keep = ("name", "launch", "kernel", "us", "GBs", "frac_of_8TBs", "bytes")
+                shp = [dict({k: r[k] for k in keep if k in r}, workload=args.workload) for r in extras["decode_launch_shapes"]]
+                if isinstance(secondary, dict) and isinstance(secondary.get("launch_shapes"), list):
+                    other_key = "baseline-named" if args.workload == "llama3-8b" else "llama3-8b"
+                    shp += [dict({k: r[k] for k in keep if k in r}, workload=other_key) for r in secondary["launch_shapes"]]
+                roof["shapes"] = shp
+                roof["shapes_timing"] = "as the dominant launch: hipGraph of back-to-back launches rotating over the 32 layers' weights, HIP events on the launch stream (rocprofv3 rows: profiles/r4/)"
             out["roofline"] = roof
+        if secondary is not None:
+            out["baseline_named_shapes" if args.workload == "llama3-8b" else "llama3_8b_true_shapes"] = secondary
         if extras is not None:
             out["other_configs"] = extras
         if cpu is not None:

@@ -29,3 +29,22 @@ def test_bench_line_contract(path):
     if "cpu_baseline" in line:
         c = line["cpu_baseline"]
         assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == line["unit"] and c["sample"]
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus N` the way the driver invokes it (no launcher, WORLD_SIZE unset) must start the N ranks itself (it used to abort with
+    "--gpus N needs torch.distributed.run").  Without a GPU every rank stops at bench.py's own "needs an MI355X" -- which proves the re-exec under
+    torch.distributed.run happened, with the right world size, and that the ranks got past the argument / rendezvous-variable path."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-side check of the launcher path (the GPU box runs the real thing)")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    err = r.stderr
+    assert "starting the ranks" in err and "--nproc-per-node=2" in err, err[-2000:]
+    assert "needs torch.distributed.run" not in err
+    assert err.count("bench.py needs an MI355X") >= 1, err[-2000:]  # the ranks ran bench.py's main() (both print it; the launcher may cut the second short)
+    assert r.returncode != 0  # and the job fails loudly: no CPU fallback
