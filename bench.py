@@ -588,23 +588,29 @@ def whole_token_leg(torch, dev, shape, dl):
 
 def _pmc_traffic(bytes_per_launch):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 --pmc FETCH_SIZE pass of this same roofline command
-    (scripts/profile.sh; corrected as the MI355X guide prescribes: KiB x 1024 x 2 on gfx950).  The counters cannot be
-    collected from inside the timed process, so the figure comes from the newest committed profiles/*/traffic.json and
-    is only reported if that pass ran on the same launch (same algorithmic bytes); otherwise null."""
+    (scripts/profile_r4.sh; corrected as the MI355X guide prescribes: KiB x 1024 x 2 on gfx950).  The counters cannot be
+    collected from inside the timed process, so the figure comes from a committed profiles/*/traffic.json -- and is reported ONLY if
+    that pass ran on this launch (same algorithmic bytes) of THIS kernel: the file carries the sha256 of the kernel's sources, and a
+    source that has changed since (a change that could add traffic) makes the figure null until the profile script is re-run."""
     import glob
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
     best = None
-    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*", "traffic.json"))):
+    for f in sorted(glob.glob(os.path.join(here, "profiles", "*", "traffic.json"))):
         try:
             t = json.load(open(f))
+            if t.get("algorithmic_bytes_per_launch") != bytes_per_launch or not t.get("kernel_sources"):
+                continue
+            sha = hashlib.sha256(b"".join(open(os.path.join(here, "tinychatengine_amd", "csrc", s), "rb").read() for s in t["kernel_sources"])).hexdigest()
+            if sha == t.get("kernel_sources_sha256"):
+                best = (t, f)
         except Exception:  # noqa: BLE001
             continue
-        if t.get("algorithmic_bytes_per_launch") in (bytes_per_launch, bytes_per_launch + 352256):  # (older files carry the formula incl. zeros)
-            best = (t, f)
     if not best:
-        return {"traffic": None}
+        return {"traffic": None, "traffic_source": "no committed rocprofv3 FETCH_SIZE pass matches this launch AND the current kernel sources (scripts/profile_r4.sh writes one)"}
     t, f = best
     return {"traffic": t["hbm_read_bytes_per_launch"],
-            "traffic_source": f"rocprofv3 --pmc FETCH_SIZE (x1024x2), median of {t['dispatches']} dispatches, {os.path.relpath(f, os.path.dirname(os.path.abspath(__file__)))}"}
+            "traffic_source": f"rocprofv3 --pmc FETCH_SIZE (x1024x2), median of {t['dispatches']} dispatches of {t['kernel'][:60]}, {os.path.relpath(f, here)} (kernel sources unchanged since: sha256 match)"}
 
 
 def cpu_baseline_worker(args):

@@ -259,7 +259,7 @@ TCE_API int tce_w4a16_gemm_awq(int M, int N, int K, int group_size, const void *
  *   out_kind TCE_OUT_INT8: C int8 [M][N] = clamp( (int32) round( (float)acc*alpha [+ (float)bias_i8[n]*beta] ), q_min, q_max )
  *            (round = half away from zero; multiply, multiply, add each rounded separately -- :29-32)
  *   out_kind TCE_OUT_FP32: C fp32 [M][N] = (float)acc*alpha [+ bias_f32[n]]          (:108, :132)
- *   b_per_row != 0: row i of A multiplies its own B_i, B laid out [M][N][K] (the *_batch variants, :79, :153)
+ *   b_per_row != 0: row i of A multiplies its own B_i, B laid out [M][N][K] (the *_batch variants, :79, :153); batch must be 1 (TCE_ERR_UNSUPPORTED_KIND otherwise)
  *   batch > 1: `batch` independent problems at element strides strideA/strideB/strideC (the per-head loop of
  *            llm/src/ops/BMM_S8T_S8N_F32T.cc:45-59 / BMM_S8T_S8N_S8T.cc:47-60 as one launch).
  */

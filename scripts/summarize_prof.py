@@ -83,7 +83,12 @@ for k, m in med.items():
         n = 0
         for d in glob.glob(os.path.join(root, "pmc_fetch", "**", "*counter_collection.csv"), recursive=True):
             n += sum(1 for r in csv.DictReader(open(d)) if MINE in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE")
-        json.dump({"kernel": k, "hbm_read_bytes_per_launch": int(m["FETCH_SIZE"] * 2048), "fetch_size_kib_median": m["FETCH_SIZE"],
+        import hashlib
+        csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tinychatengine_amd", "csrc")
+        srcs = ["w4a16_gemv_i8.hip", "w4a16_mfma_layout.hpp"] if "gemv_i8" in k else ["w4a16_gemv.hip"]
+        sha = hashlib.sha256(b"".join(open(os.path.join(csrc, f), "rb").read() for f in srcs)).hexdigest()
+        json.dump({"kernel": k, "kernel_sources": srcs, "kernel_sources_sha256": sha,
+                   "hbm_read_bytes_per_launch": int(m["FETCH_SIZE"] * 2048), "fetch_size_kib_median": m["FETCH_SIZE"],
                    "dispatches": n, "algorithmic_bytes_per_launch": int(os.environ.get("TCE_ALGO_BYTES", "46910464")),
                    "correction": "FETCH_SIZE [KiB] x 1024 x 2 (gfx950 reports half of a wide coalesced streaming read)"},
                   open(os.path.join(root, "traffic.json"), "w"), indent=1)

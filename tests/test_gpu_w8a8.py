@@ -177,6 +177,13 @@ def test_unsupported_kind_is_rejected(dev):
     d = capi.W8A8Desc(M=4, N=4, K=64, batch=1, A=a.data_ptr(), B=a.data_ptr(), bias=a.data_ptr(), C=a.data_ptr(), alpha=1.0, beta=1.0,
                       q_min=-128, q_max=127, bias_kind=capi.TCE_BIAS_FP32, out_kind=capi.TCE_OUT_INT8)
     assert capi.w8a8_matmul(d, 0) == capi.TCE_ERR_UNSUPPORTED_KIND
+    # the *_batch form (a B per row of A) is a single problem in the reference: with batch > 1 one stride word would have to be both the batch and the row
+    # stride of B -- refused, not mis-addressed
+    b = torch.zeros(2 * 4 * 4 * 64, dtype=torch.int8, device=dev)
+    c = torch.zeros(2 * 4 * 4, dtype=torch.int8, device=dev)
+    d = capi.W8A8Desc(M=4, N=4, K=64, batch=2, A=a.data_ptr(), B=b.data_ptr(), C=c.data_ptr(), strideA=0, strideB=4 * 4 * 64, strideC=16, alpha=1.0, beta=0.0,
+                      q_min=-128, q_max=127, bias_kind=capi.TCE_BIAS_NONE, out_kind=capi.TCE_OUT_INT8, b_per_row=1)
+    assert capi.w8a8_matmul(d, 0) == capi.TCE_ERR_UNSUPPORTED_KIND
 
 
 @pytest.mark.parametrize("m,n", [(108, 768), (1, 768), (512, 768), (65, 1024), (3, 2048), (7, 20), (5, 772), (2, 36), (3, 60), (1, 8192), (4, 4),

@@ -241,11 +241,15 @@ __device__ __forceinline__ void attn_prefill_block(const PrefillArgs &a, const i
                 for (int r = 0; r < 4; ++r) {
                     float s = sacc[t][j][r] * scale2;
                     if constexpr (MASK) s += mk4[r];
+                    // check_inf_half (Int4llamaAttention.cu:105-115, applied by the decode step as well, attention_fast.hip): inf / NaN / a score beyond
+                    // binary16 weighs nothing -- in EVERY tile, interior and unmasked ones included (a NaN from an overflowed q.k used to poison
+                    // the row here and not in the decode step).  !(|s| <= bound) is true for NaN.
+                    bool valid = __builtin_fabsf(s) <= 65504.0f * kLog2e;
                     if (MASK || edge) {
                         const int key = key0 + 16 * j + 4 * quad + r;
-                        const bool valid = !edge || (key < tgz && !(a.causal && key > a.pos + rowc[t]));
-                        s = valid && s > kNegBig ? s : kNegBig;  // a mask of -inf / -65504 stays a finite "nothing"
+                        valid = valid && (!edge || (key < tgz && !(a.causal && key > a.pos + rowc[t])));
                     }
+                    s = valid ? s : kNegBig;  // (a mask of -inf / -65504 stays a finite "nothing")
                     sacc[t][j][r] = s;
                     best = fmaxf(best, s);
                 }

@@ -655,6 +655,9 @@ int tce_w8a8_matmul(const tce_w8a8_desc *d, void *stream) {
     if (!ok) return fail(TCE_ERR_UNSUPPORTED_KIND, "bias_kind %d with out_kind %d has no reference counterpart", d->bias_kind, d->out_kind);
     if (d->bias_kind != TCE_BIAS_NONE && !d->bias) return fail(TCE_ERR_BAD_ARG, "bias_kind set but bias is null");
     if (d->b_per_row && d->bias_kind != TCE_BIAS_NONE) return fail(TCE_ERR_UNSUPPORTED_KIND, "the *_batch variants have no bias");
+    // one stride word cannot be both the batch stride and the per-row stride of B: the reference's *_batch members are single problems
+    // (kernels/ref/matmul_ref_int8.cc:79, 153), and so is this entry point (the combination used to address B wrongly)
+    if (d->b_per_row && d->batch > 1) return fail(TCE_ERR_UNSUPPORTED_KIND, "b_per_row with batch > 1 has no reference counterpart: issue one call per batch entry");
     if (d->out_kind == TCE_OUT_INT8 && (d->q_min < -128 || d->q_max > 127 || d->q_min > d->q_max))
         return fail(TCE_ERR_BAD_ARG, "q_min/q_max out of int8 range");
     if (d->accumulate && d->out_kind != TCE_OUT_FP32) return fail(TCE_ERR_UNSUPPORTED_KIND, "accumulate is the fp32 residual add (TCE_OUT_FP32 only)");

@@ -242,9 +242,11 @@ __global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const I8Args args) 
                 int4_t alo, ahi;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const unsigned x8 = w[r][t][q] ^ 0x88888888u;
-                    ahi[q] = (int)(x8 & 0xF0F0F0F0u);
-                    alo[q] = (int)((x8 << 4) & 0xF0F0F0F0u);
+                    // signed bytes 16 (q - 8): (nibble in the high half of the byte) ^ 0x80.  Written as two independent and-xor forms so that each is ONE
+                    // v_bitop3 (a shared w ^ 0x88888888 costs a fourth instruction per word)
+                    const unsigned wq = w[r][t][q];
+                    ahi[q] = (int)((wq & 0xF0F0F0F0u) ^ 0x80808080u);
+                    alo[q] = (int)(((wq << 4) & 0xF0F0F0F0u) ^ 0x80808080u);
                 }
                 dd[r][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(alo, B[uu][0], dd[r][0], 0, 0, 0);
                 dd[r][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ahi, B[uu][1], dd[r][1], 0, 0, 0);

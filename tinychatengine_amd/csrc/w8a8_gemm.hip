@@ -528,9 +528,9 @@ int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err)
     a.ldc = d.ldc ? d.ldc : d.N;
     a.accumulate = d.accumulate;
     if (a.lda < d.K || a.ldb < d.K || a.ldc < d.N) return TCE_ERR_BAD_ARG;
-    if (d.b_per_row) {  // the per-row B_m: strideB apart when given (batch must be 1 then), dense [M][N][K] otherwise
-        if (d.batch > 1) a.strideB = (long long)d.strideB;  // (batched *_batch problems are not a reference shape; kept for symmetry)
-        else a.strideB = d.strideB ? d.strideB : (long long)d.N * a.ldb;
+    if (d.b_per_row) {  // the per-row B_m: strideB apart when given, dense [M][N][K] otherwise (batch is 1: tce_w8a8_matmul rejects anything else)
+        if (d.batch > 1) return TCE_ERR_UNSUPPORTED_KIND;
+        a.strideB = d.strideB ? d.strideB : (long long)d.N * a.ldb;
     }
     a.alpha = d.alpha;
     a.beta = d.beta;

@@ -517,13 +517,16 @@ __global__ __launch_bounds__(64 * kWideWaves) void lnq_w8a8_wide_kernel(const Ln
 int launch_wide(LnqArgs &a, int rows, hipStream_t stream, hipError_t *hip_err) {
     const size_t lds = lnq_wide_lds(a.m, a.K);
     if (lds > 160 * 1024) return TCE_ERR_UNSUPPORTED_SHAPE;
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
+    // CU count of the CURRENT device, cached per device id (one host thread may drive several devices: comm.hip's DeviceGuard mode)
+    static int cus_of[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (cus_of[dev] == 0) {
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus_of[dev] = prop.multiProcessorCount;
+        if (cus_of[dev] <= 0) cus_of[dev] = 256;
     }
+    const int cus = cus_of[dev];
     // one workgroup per CU (a second one would only share the CU's adders and LDS with the first); fewer when there are fewer than 2 rows per wave
     int grid = (rows + 2 * kWideWaves - 1) / (2 * kWideWaves);
     if (grid > cus) grid = cus;
