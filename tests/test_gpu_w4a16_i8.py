@@ -230,6 +230,35 @@ def test_i8_projection_plus_residual_fused(dev, oracle, M, N, K):
     assert torch.equal(got, res + y)  # hadd of two halves: torch's fp16 add rounds the same way
 
 
+@pytest.mark.parametrize("Ns,K,pairs", [([4096, 1024, 1024], 4096, False), ([520, 264], 11008, False), ([72], 1408, False), ([2752], 4096, True), ([1024], 14336, False)])
+def test_i8_rmsnorm_prologue_fused(dev, oracle, Ns, K, pairs):
+    """The fused RMSNorm prologue in this kernel (input_layernorm + q/k/v, post_attention_layernorm + gate/up, Int4llamaDecoderLayer.cu:78, 92-99): the same rs bits
+    as tce_rmsnorm_half (the shape-independent order of tce_common.hpp), the same normalised halves, hence outputs bit-identical to the two-launch form -- on
+    grouped launches, on K > 8192 (two pieces per slot of the order) and together with the pair epilogue; and the normalisation itself against the oracle."""
+    from tinychatengine_amd import capi
+    from tinychatengine_amd.linear import forward_group_rmsnorm, rmsnorm_half
+    lins = [_lin(oracle, dev, n, K, 128, seed=n + K)[0] for n in Ns]
+    x = (torch.randn((1, K), device=dev) * 3.0).to(torch.float16)
+    gamma = (1.0 + 0.1 * torch.randn(K, device=dev)).float()
+    eps = 1e-6
+    xn = rmsnorm_half(x, gamma, eps)
+    # (tce_rmsnorm_half against the oracle: tests/test_gpu_epilogues.py::test_rmsnorm_kernel_matches_oracle)
+    flags = capi.TCE_W4_SILU_MUL_PAIRS if pairs else 0
+    outs = []
+    for l in lins:
+        o = torch.full((1, l.out_features // 2 if pairs else l.out_features), float("nan"), dtype=torch.float16, device=dev)
+        d = l.desc(x, o, flags=flags, gamma=gamma, eps=eps)
+        assert capi.describe_dispatch(d).startswith("gemv-i8"), capi.describe_dispatch(d)
+        outs.append(o)
+    if len(lins) > 1:
+        forward_group_rmsnorm(lins, x, outs, gamma, eps)
+    else:
+        capi.check(capi.w4a16_forward(lins[0].desc(x, outs[0], flags=flags, gamma=gamma, eps=eps), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    for l, o in zip(lins, outs):
+        assert torch.equal(o, _fwd(l, xn, flags=flags)), "fused prologue != rmsnorm launch + plain launch"
+
+
 FULL = [(4096, 4096), (11008, 4096), (4096, 11008), (14336, 4096), (4096, 14336), (1024, 4096), (12288, 4096), (32000, 4096), (128256, 4096),
         (15360, 5120), (5120, 5120), (13824, 5120), (5120, 13824)]
 

@@ -220,7 +220,7 @@ int main(int argc, char **argv) {
         // the host rewrites tensor 3 (model reload): forget, then real zero points must be read
         int *z3 = zps + (size_t)3 * N * zw;
         tce_adapter_forget(z3);
-        ok &= tce_adapter_cache_entries() == n_tensors - 1;  // (the packed copy was built from z3: forgotten with it)
+        ok &= tce_adapter_cache_entries() == n_tensors - 1 + packs;  // (the packed copy was last built from tensor 699's zero points, not from z3: it stays, and is rebuilt below when z3 comes with the weights)
         std::memcpy(z3, zpr, (size_t)N * zw * 4);
         params.int32_zero_point = z3;
         op.gemv_forward_cuda(&params);

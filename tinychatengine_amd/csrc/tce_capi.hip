@@ -325,6 +325,12 @@ static int forward_group_norm(const tce_w4a16_desc *descs, int count, const floa
     // launches).  So the persistent kernel takes the fused form from ~16k rows up; the row-block kernel below that
     // (in-process A/B, scripts/fused_launch_ab.py, profiles/r2/fused_launch_ab.jsonl: norm + q/k/v 12288 rows 9.6 us row-block (4 rows,
     // 4 waves) vs 10.9 persistent; norm + gate/up 22016 rows 13.4 us persistent vs 15.8 row-block).
+    if (g_gemv_kernel == 0 && g_debug_mode_capi == 0 && tce::gemv_i8_supports(descs, count, /*with_norm=*/true)) {  // packed copies: the int8-contraction GEMV carries the prologue
+        const int rc = tce::launch_w4a16_gemv_i8(descs, count, static_cast<hipStream_t>(stream), &he, gamma, eps);
+        if (rc == TCE_OK) return TCE_OK;
+        if (rc == TCE_ERR_HIP) return hip_fail(he, "w4a16 gemv (int8 contraction, rmsnorm prologue) launch");
+        if (rc != TCE_ERR_UNSUPPORTED_SHAPE) return fail(rc, "w4a16 gemv (int8 contraction, rmsnorm prologue): unsupported configuration");
+    }
     long long rows = 0;
     for (int i = 0; i < count; ++i) rows += descs[i].N;
     if (g_gemv_kernel == 2 || (g_gemv_kernel == 0 && rows >= kFusedNormPersistentRows)) {

@@ -43,6 +43,8 @@ struct I8Args {
     const half_t *A;  // fp16 [M][lda]
     int lda, M, K, U, NG;  // U = K / 128 units, NG = K / G groups
     int nseg;
+    const float *gamma;  // non-null: the activation is the UN-normalised hidden state; the conversion stages RMSNorm(A) * gamma (generalT5LayerNorm arithmetic; M = 1)
+    float eps;
     I8Seg seg[TCE_MAX_GROUP];
 };
 
@@ -59,9 +61,13 @@ __device__ __forceinline__ float dpp_add_f32(float v) {
 
 // MB rows of A per pass over the weights (1 / 2 / 4), GPU groups per 128-k unit (1 / 2 / 4 for G = 128 / 64 / 32), ROWS tiles per wave, UW units per wave.
 // Output column j of the MFMA = ((uu * GPU + gi) * MB + m) * 4 + p: unit-in-pass uu, group-in-unit gi, activation row m, digit plane p.
-template <int MB, int GPU, int ROWS, int UW, bool Z8, int MAXT>
+// NORM: the fused RMSNorm prologue (LlamaRMSNorm.cu:68-93 in front of q/k/v and gate/up, Int4llamaDecoderLayer.cu:78, 92-99): the waves' piece sums of x^2 meet in LDS
+// (tce_common.hpp's shape-independent order: the same rs, bit for bit, as tce_rmsnorm_half and the fp16 GEMV's prologue), one barrier, then every wave normalises the
+// activations it converts.
+template <int MB, int GPU, int ROWS, int UW, bool Z8, int MAXT, bool NORM = false>
 __global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const I8Args args) {
     static_assert(MB * GPU <= 4, "sixteen output columns: rows x groups-per-unit x 4 planes");
+    static_assert(!NORM || MB == 1, "the fused RMSNorm prologue is a decode (M = 1) feature");
     constexpr int UPP = 4 / (MB * GPU);  // units per pass
     static_assert(UW % UPP == 0 && UW % 4 == 0, "whole passes; whole 16-byte x loads per lane");
     constexpr int NP = UW / UPP;         // passes
@@ -108,6 +114,15 @@ __global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const I8Args args) 
 #pragma unroll
         for (int c = 0; c < XC; ++c) xv[m][c] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, u0 * 256 + (lane + 64 * c) * 16, 0, 0);  // (the scalar offset of a buffer load is NOT range-checked: everything that may run past K sits in the vector offset)
     }
+    float4_t gm[NORM ? XC : 1][2];  // gamma of the lane's 8 columns per chunk
+    if constexpr (NORM) {
+        const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(args.gamma), 0, args.K * 4, 0x00020000);
+#pragma unroll
+        for (int c = 0; c < XC; ++c) {
+            gm[c][0] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_g, u0 * 512 + (lane + 64 * c) * 32, 0, 0));
+            gm[c][1] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_g, u0 * 512 + (lane + 64 * c) * 32 + 16, 0, 0));
+        }
+    }
     uint2_t sc[ROWS][NP];
     unsigned short zq[ROWS][NP];
 #pragma unroll
@@ -132,6 +147,41 @@ __global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const I8Args args) 
 
     // ---- 2. the wave's activations -> digit planes, image [unit][lo/hi][m][plane][kq][word s] in its own LDS region ----
     unsigned *planes = reinterpret_cast<unsigned *>(smem) + wk * (UW * MB * 128);
+    if constexpr (NORM) {
+        // slot[p] = the sum of squares of the row's p-th 16-byte piece (fmaf chain over its 8 values); K <= 16384: at most two pieces per slot of the
+        // 1024-slot order, and a two-term sum does not depend on which wave wrote which
+        float *slots = reinterpret_cast<float *>(smem + (size_t)WK * UW * MB * 512 + (size_t)WK * ROWS * MB * 16 * sizeof(float));  // [2048]
+        const int pieces = args.K >> 3;
+#pragma unroll
+        for (int c = 0; c < XC; ++c) {
+            const int p = u0 * 16 + lane + 64 * c;
+            if (p < 2048) slots[p] = rmsnorm_piece_sum(__builtin_bit_cast(half8_t, xv[0][c]));  // (pieces past K: zeros were loaded)
+        }
+        lds_barrier();  // (LDS only: every weight byte of the wave stays in flight)
+        float tot = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int q = c * 64 + lane;
+            float slot = 0.f;
+            slot += q < pieces ? slots[q] : 0.f;
+            if (q + 1024 < pieces) slot += slots[q + 1024];
+            tot += slot;
+        }
+        tot = wave_sum_dpp_lane63(tot);
+        tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), 63));
+        const float rs = 1.0f / sqrtf(tot / (float)args.K + args.eps);
+#pragma unroll
+        for (int c = 0; c < XC; ++c) {
+            const half8_t v = __builtin_bit_cast(half8_t, xv[0][c]);
+            half8_t y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[e] = rmsnorm_out(v[e], rs, gm[c][0][e]);
+                y[4 + e] = rmsnorm_out(v[4 + e], rs, gm[c][1][e]);
+            }
+            xv[0][c] = __builtin_bit_cast(uint4_t, y);
+        }
+    }
     int sh[MB];
     bool bad[MB];
 #pragma unroll
@@ -323,10 +373,10 @@ __global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const I8Args args) 
 int g_i8_mode = 0;  // 0 automatic, 1 off, 2 forced wherever the shape allows
 int g_i8_rows = 0;  // 0 the rule, 1 / 2 forced tiles per wave
 
-template <int MB, int GPU, int ROWS, int UW, bool Z8, int MAXT>
+template <int MB, int GPU, int ROWS, int UW, bool Z8, int MAXT, bool NORM = false>
 hipError_t launch_i8(const I8Args &a, int blocks, int m_blocks, int wk, hipStream_t stream) {
-    const size_t lds = (size_t)wk * UW * MB * 512 + (size_t)wk * ROWS * MB * 16 * sizeof(float);
-    auto kfn = w4a16_gemv_i8_kernel<MB, GPU, ROWS, UW, Z8, MAXT>;
+    const size_t lds = (size_t)wk * UW * MB * 512 + (size_t)wk * ROWS * MB * 16 * sizeof(float) + (NORM ? 2048 * sizeof(float) : 0);
+    auto kfn = w4a16_gemv_i8_kernel<MB, GPU, ROWS, UW, Z8, MAXT, NORM>;
     if (lds > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -345,10 +395,11 @@ void set_gemv_i8_mode(int mode, int rows) {
 // units per wave: a function of K (and of the rows / groups per pass) ONLY, so that a row's arithmetic does not depend on N
 static int i8_units_per_wave(int U) { return U <= 128 ? 8 : (U <= 256 ? 16 : 0); }
 
-bool gemv_i8_supports(const tce_w4a16_desc *descs, int count) {
+bool gemv_i8_supports(const tce_w4a16_desc *descs, int count, bool with_norm) {
     if (g_i8_mode == 1) return false;
     const tce_w4a16_desc &d0 = descs[0];
-    if (d0.M < 1 || d0.M > 4 || d0.K % 128 != 0 || d0.rmsnorm_gamma) return false;
+    if (d0.M < 1 || d0.M > 4 || d0.K % 128 != 0) return false;
+    if ((d0.rmsnorm_gamma || with_norm) && (d0.M != 1 || d0.group_size != 128 || d0.K > 16384)) return false;  // the fused RMSNorm prologue: decode rows, groups of 128
     if (d0.group_size != 128 && d0.M > (d0.group_size == 64 ? 2 : 1)) return false;
     const int uw = i8_units_per_wave(d0.K / 128);
     if (uw == 0 || (uw == 16 && (d0.M > 1 || d0.group_size != 128))) return false;  // (very long K: single rows only -- the registers hold 16 KiB of weights per wave)
@@ -361,9 +412,15 @@ bool gemv_i8_supports(const tce_w4a16_desc *descs, int count) {
     return true;
 }
 
-int launch_w4a16_gemv_i8(const tce_w4a16_desc *descs, int count, hipStream_t stream, hipError_t *hip_err) {
+int launch_w4a16_gemv_i8(const tce_w4a16_desc *descs, int count, hipStream_t stream, hipError_t *hip_err, const float *gamma, float eps) {
     const tce_w4a16_desc &d0 = descs[0];
+    if (!gamma && d0.rmsnorm_gamma) {
+        gamma = static_cast<const float *>(d0.rmsnorm_gamma);
+        eps = d0.rmsnorm_eps;
+    }
     I8Args a{};
+    a.gamma = gamma;
+    a.eps = eps;
     a.A = static_cast<const half_t *>(d0.A);
     a.lda = d0.lda ? d0.lda : d0.K;
     a.M = d0.M;
@@ -409,6 +466,15 @@ int launch_w4a16_gemv_i8(const tce_w4a16_desc *descs, int count, hipStream_t str
     }
     for (int i = count; i < TCE_MAX_GROUP; ++i) a.seg[i] = a.seg[0];
     hipError_t e = hipErrorInvalidConfiguration;
+    if (gamma) {
+        if (mb != 1 || gpu != 1 || uw != 8) return TCE_ERR_UNSUPPORTED_SHAPE;
+        e = z8 ? launch_i8<1, 1, 1, 8, true, 1024, true>(a, blocks, m_blocks, wk, stream) : launch_i8<1, 1, 1, 8, false, 1024, true>(a, blocks, m_blocks, wk, stream);
+        if (e != hipSuccess) {
+            if (hip_err) *hip_err = e;
+            return TCE_ERR_HIP;
+        }
+        return TCE_OK;
+    }
 #define TCE_I8(MB_, GPU_, ROWS_, UW_, MAXT_)                                                                                        \
     if (mb == MB_ && gpu == GPU_ && rows == ROWS_ && uw == UW_) {                                                                   \
         e = z8 ? launch_i8<MB_, GPU_, ROWS_, UW_, true, MAXT_>(a, blocks, m_blocks, wk, stream)                                     \

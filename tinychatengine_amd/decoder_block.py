@@ -27,7 +27,7 @@ from .linear import Linear_half_int4, _stream
 
 class DecoderBlock:
     def __init__(self, hidden: int, heads: int, ffn: int, max_keys: int, device, cos: torch.Tensor, sin: torch.Tensor, seed: int = 0,
-                 group_size: int = 128, eps: float = 1e-6, kv_heads: int | None = None):
+                 group_size: int = 128, eps: float = 1e-6, kv_heads: int | None = None, prepack: bool = True):
         """kv_heads < heads: grouped-query attention (Llama-3-8B: 32 / 8, llm/include/model.h:83) -- the fused projection is
         (heads + 2 * kv_heads) * 128 rows wide and the caches hold kv_heads heads."""
         assert hidden % heads == 0 and hidden // heads == 128, "the attention step is built for head_dim 128 (Llama)"
@@ -43,6 +43,8 @@ class DecoderBlock:
         self.down = Linear_half_int4.from_float(rnd(hidden, ffn), group_size)
         self.gamma1 = (1.0 + 0.1 * torch.empty(hidden, device=device).normal_(0, 1, generator=g)).float()
         self.gamma2 = (1.0 + 0.1 * torch.empty(hidden, device=device).normal_(0, 1, generator=g)).float()
+        if prepack:  # load-time re-layout: the four launches of a decode step then run on the packed copies (csrc/w4a16_gemv_i8.hip, fused prologue / epilogues included)
+            self.prepare_prefill()
         self.attention = DecodeAttention(heads, 128, max_keys, device, cos, sin, kv_heads=self.kv_heads)
         e = lambda n: torch.empty((1, n), dtype=torch.float16, device=device)
         self.qkv_out, self.attn_out, self.act = e((heads + 2 * self.kv_heads) * 128), e(hidden), e(ffn)
