@@ -409,6 +409,19 @@ TCE_API int tce_comm_export(tce_comm *comm, void *handle_out /* 64 bytes */);
 TCE_API int tce_comm_connect(tce_comm *comm, const void *handles /* [world][64], rank order */);
 TCE_API int tce_comm_connect_local(tce_comm *comm, tce_comm *const *all_ranks /* [world] */);
 TCE_API int tce_allgather_f16(tce_comm *comm, int slot, const void *src_slice, void *dst_full, int n_total, void *stream);
+/* Round 4: RCCL behind the same communicator, for exchanges beyond the latency regime (north star: "a single RCCL all-gather over xGMI per transformer block";
+ * SURVEY 8e sizes a prompt's exchange at 0.65-1.97 MB per rank).  librccl is opened on first use (dlopen); the communicator is built from an opaque
+ * TCE_RCCL_ID_BYTES blob that rank 0 obtains (tce_comm_rccl_unique_id) and the host hands to every rank exactly like the IPC handles (tce_comm_rccl_init is
+ * collective: every rank calls it; one rank per device -- RCCL refuses two ranks on one GPU).  tce_allgather_f16 then dispatches by size: slices of at most
+ * 64 KiB that fit the window -> the peer-write kernel (one launch, graph-capturable); larger -> ncclAllGather on `stream`.
+ *   tce_allgather_rows_f16: the column-sharded outputs of M > 1 rows (a sharded prompt): src fp16 [M][n_total / world] (this rank's columns), dst fp16 [M][ldd]
+ *   (ldd = 0: n_total) on every rank.  M = 1 is tce_allgather_f16.  M > 1: the ranks' whole blocks are gathered rank-major into `workspace`
+ *   (tce_allgather_rows_workspace_bytes(M, n_total) bytes, 16-byte aligned; peer-write kernel or RCCL by size) and one kernel lays the rows side by side. */
+#define TCE_RCCL_ID_BYTES 128
+TCE_API int tce_comm_rccl_unique_id(void *id_out /* TCE_RCCL_ID_BYTES */);
+TCE_API int tce_comm_rccl_init(tce_comm *comm, const void *id /* TCE_RCCL_ID_BYTES */);
+TCE_API size_t tce_allgather_rows_workspace_bytes(int M, int n_total);
+TCE_API int tce_allgather_rows_f16(tce_comm *comm, int slot, const void *src, void *dst, int M, int n_total, int ldd, void *workspace, void *stream);
 TCE_API int tce_comm_status(tce_comm *comm);
 TCE_API int tce_comm_set_timeout_ms(tce_comm *comm, int milliseconds); /* 1 .. 600000; takes effect for exchanges enqueued (or captured) afterwards */
 TCE_API int tce_comm_reset(tce_comm *comm);

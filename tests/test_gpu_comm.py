@@ -224,3 +224,65 @@ def test_processes_exchange_through_ipc_windows(world, use_graph):
             p.join(timeout=60)
             if p.is_alive():
                 p.kill()
+
+
+@gpu
+def test_rccl_side_of_the_communicator_and_the_size_dispatch():
+    """Round 4: RCCL behind the C ABI.  One GPU = one RCCL rank (RCCL refuses two ranks on a device), so this exercises the plumbing -- librccl opened on first use,
+    the opaque id blob, tce_comm_rccl_init, the dispatch of tce_allgather_f16 by size -- with world = 1, where an all-gather is a copy: a vector far larger than
+    the window and its 64 KiB-per-rank regime must take the RCCL path and arrive intact; a small one stays on the peer-write kernel."""
+    from tinychatengine_amd import capi
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda:0")
+    comm = capi.Comm(0, 1, 1024, slots=2)
+    capi.Comm.connect_local([comm])
+    st = torch.cuda.current_stream().cuda_stream
+    big = torch.randn(1 << 20, device=dev).to(torch.float16)
+    out = torch.zeros_like(big)
+    with pytest.raises(capi.TceError):  # no RCCL side yet: beyond the window -> refused, not truncated
+        comm.allgather(0, big.data_ptr(), out.data_ptr(), big.numel(), st)
+    comm.rccl_init(capi.Comm.rccl_unique_id())
+    comm.allgather(0, big.data_ptr(), out.data_ptr(), big.numel(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(out, big)
+    small = torch.randn(512, device=dev).to(torch.float16)
+    o2 = torch.zeros_like(small)
+    comm.allgather(1, small.data_ptr(), o2.data_ptr(), 512, st)
+    torch.cuda.synchronize()
+    assert torch.equal(o2, small) and comm.status() == 0
+    # rows: M = 300 x 4096 halves = 2.4 MB -> RCCL regime + the interleave kernel (world 1: rows unchanged), into a wider destination
+    src = torch.randn(300, 4096, device=dev).to(torch.float16)
+    dst = torch.zeros(300, 4096 + 64, dtype=torch.float16, device=dev)
+    ws = torch.empty(int(capi.lib().tce_allgather_rows_workspace_bytes(300, 4096)), dtype=torch.uint8, device=dev)
+    comm.allgather_rows(0, src.data_ptr(), dst.data_ptr(), 300, 4096, ws.data_ptr(), st, ldd=4096 + 64)
+    torch.cuda.synchronize()
+    assert torch.equal(dst[:, :4096], src) and torch.count_nonzero(dst[:, 4096:]).item() == 0
+    comm.close()
+
+
+@gpu
+def test_allgather_rows_two_ranks_peer_regime():
+    """The column-sharded outputs of M > 1 rows (a sharded prompt chunk): two ranks in one process, each with its [M][N/2] block; every rank ends with [M][N],
+    rank 0's columns left of rank 1's, over several exchanges on one slot."""
+    from tinychatengine_amd import capi
+    dev = torch.device("cuda:0")
+    world, M, N = 2, 6, 1024
+    comms = [capi.Comm(r, world, M * N, slots=2) for r in range(world)]
+    capi.Comm.connect_local(comms)
+    streams = [torch.cuda.Stream() for _ in range(world)]
+    ws = [torch.empty(M * N, dtype=torch.float16, device=dev) for _ in range(world)]
+    try:
+        for it in range(4):
+            parts = [torch.randn(M, N // world, device=dev).to(torch.float16) for _ in range(world)]
+            fulls = [torch.zeros(M, N, dtype=torch.float16, device=dev) for _ in range(world)]
+            torch.cuda.synchronize()
+            for r in range(world):
+                comms[r].allgather_rows(1, parts[r].data_ptr(), fulls[r].data_ptr(), M, N, ws[r].data_ptr(), streams[r].cuda_stream)
+            torch.cuda.synchronize()
+            want = torch.cat(parts, dim=1)
+            for r in range(world):
+                assert comms[r].status() == 0
+                assert torch.equal(fulls[r], want), (it, r)
+    finally:
+        for c in comms:
+            c.close()

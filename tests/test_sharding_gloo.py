@@ -46,7 +46,7 @@ def _oracle_launch(orc):
     return launch
 
 
-def _worker(rank, world, port, gathers, q):
+def _worker(rank, world, port, gathers, q, m=1):
     sys.path.insert(0, REPO)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -54,7 +54,7 @@ def _worker(rank, world, port, gathers, q):
         from oracle.oracle import Oracle
         from tinychatengine_amd.decode import SHAPES, DecodeLinears
         orc = Oracle()
-        dl = DecodeLinears(SHAPES["tiny"], device="cpu", rank=rank, world=world)
+        dl = DecodeLinears(SHAPES["tiny"], device="cpu", rank=rank, world=world, m=m)
         dl.run_token_distributed(gathers_per_block=gathers, launch=_oracle_launch(orc))
         out = {"logits": dl.g_logits.clone(), "down": dl.g_down.clone()}
         if gathers == 4:
@@ -67,14 +67,16 @@ def _worker(rank, world, port, gathers, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("gathers", [1, 4])
-def test_column_sharded_token_equals_unsharded(gathers):
+@pytest.mark.parametrize("gathers,m", [(1, 1), (4, 1), (4, 64)])
+def test_column_sharded_token_equals_unsharded(gathers, m):
+    """m = 64: a sharded PROMPT chunk -- the ranks' [M][N/P] blocks are gathered rank-major and the rows laid side by side (the sharded path used to
+    assert M == 1)."""
     from oracle.oracle import Oracle
     from tinychatengine_amd.decode import SHAPES, DecodeLinears
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, gathers, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, gathers, q, m)) for r in range(2)]
     for p in procs:
         p.start()
     gathered = q.get(timeout=180)
@@ -85,7 +87,7 @@ def test_column_sharded_token_equals_unsharded(gathers):
     assert gathered[0] == gathered[1]
     # ... and they equal the single-rank computation
     orc = Oracle()
-    ref = DecodeLinears(SHAPES["tiny"], device="cpu", rank=0, world=1)
+    ref = DecodeLinears(SHAPES["tiny"], device="cpu", rank=0, world=1, m=m)
     launch = _oracle_launch(orc)
     for li in range(ref.n_layers):
         ref.run_block(li, launch=launch)

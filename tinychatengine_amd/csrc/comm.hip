@@ -27,6 +27,10 @@
 #include "tce_common.hpp"
 #include "w4a16_kernels.hpp"
 
+#include <dlfcn.h>
+
+#include <cstring>
+
 namespace tce {
 
 constexpr int kMaxRanks = 8;
@@ -42,6 +46,7 @@ struct Comm {
     bool ipc_opened[kMaxRanks] = {};
     unsigned *epochs = nullptr;          // [slots] exchanges completed per slot, + [1] status
     bool finegrained = false;
+    void *nccl = nullptr;                // ncclComm_t once tce_comm_rccl_init ran: exchanges too large for the peer-write kernel go through RCCL
 };
 
 namespace {
@@ -256,6 +261,7 @@ int comm_device(const Comm *c) { return c->device; }
 void *comm_window(Comm *c) { return c->window; }
 int comm_rank(const Comm *c) { return c->rank; }
 int comm_world(const Comm *c) { return c->world; }
+int comm_world_of(const Comm *c) { return c->world; }
 
 int comm_status(Comm *c, hipError_t *he) {
     DeviceGuard guard(c->device);
@@ -268,7 +274,9 @@ int comm_status(Comm *c, hipError_t *he) {
     return st ? 1 : 0;
 }
 
+void comm_rccl_destroy(Comm *c);
 void comm_destroy(Comm *c) {
+    if (c) comm_rccl_destroy(c);
     if (!c) return;
     DeviceGuard guard(c->device);
     for (int p = 0; p < c->world; ++p)
@@ -301,6 +309,120 @@ int launch_allgather_f16(Comm *c, int slot, const void *src_slice, void *dst_ful
     a.timeout_ticks = c->timeout_ticks;
     DeviceGuard guard(c->device);  // one host thread driving several devices: the launch goes to the communicator's device (the stream must be one of that device's)
     hipLaunchKernelGGL(allgather_peer_kernel, dim3(1), dim3(1024), 0, stream, a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (he) *he = e;
+        return TCE_ERR_HIP;
+    }
+    return TCE_OK;
+}
+
+
+// ---- RCCL behind the same communicator (round 4): exchanges beyond the latency regime ----
+// A decode exchange is 1-4 KB per rank: one peer-write kernel.  A prompt's exchange (0.65-1.97 MB per rank at M = 512) is a bandwidth problem, and
+// a ring all-gather over the xGMI links is RCCL's job.  librccl is opened on first use (dlopen: the library itself does not link against it; a host that never
+// asks for the large regime never loads it); the communicator comes from an opaque 128-byte ncclUniqueId blob the host exchanges exactly like the IPC handles.
+struct Id128 {  // ncclUniqueId: 128 opaque bytes, passed BY VALUE to ncclCommInitRank
+    char bytes[128];
+};
+namespace {
+struct RcclApi {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, Id128, int) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+RcclApi &rccl() {
+    static RcclApi api = [] {
+        RcclApi a;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (a.lib) break;
+        }
+        if (!a.lib) return a;
+        a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(a.lib, "ncclGetUniqueId"));
+        a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(a.lib, "ncclCommInitRank"));
+        a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(a.lib, "ncclAllGather"));
+        a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(a.lib, "ncclCommDestroy"));
+        a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(a.lib, "ncclGetErrorString"));
+        a.ok = a.GetUniqueId && a.CommInitRank && a.AllGather && a.CommDestroy;
+        return a;
+    }();
+    return api;
+}
+constexpr int kNcclHalf = 6;  // ncclFloat16 / ncclHalf (rccl.h: ncclDataType_t)
+
+// [P][M][n_loc] (what an all-gather of whole [M][n_loc] blocks produces) -> [M][P * n_loc]: the column-sharded rows side by side
+__global__ __launch_bounds__(256) void interleave_rows_kernel(const uint4_t *__restrict__ ws, uint4_t *__restrict__ dst, int P, int M, int loc16, long long ld16) {
+    const long long total = (long long)P * M * loc16;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int j = (int)(i % loc16);
+        const long long r = i / loc16;
+        const int m = (int)(r % M), p = (int)(r / M);
+        dst[(long long)m * ld16 + (long long)p * loc16 + j] = ws[i];
+    }
+}
+}  // namespace
+
+int comm_rccl_unique_id(void *id128) {
+    RcclApi &a = rccl();
+    if (!a.ok) return TCE_ERR_UNSUPPORTED_KIND;
+    return a.GetUniqueId(id128) == 0 ? TCE_OK : TCE_ERR_HIP;
+}
+int comm_rccl_init(Comm *c, const void *id128) {
+    RcclApi &a = rccl();
+    if (!a.ok) return TCE_ERR_UNSUPPORTED_KIND;
+    if (c->nccl) return TCE_OK;
+    DeviceGuard guard(c->device);
+    Id128 id;
+    std::memcpy(id.bytes, id128, 128);
+    void *comm = nullptr;
+    if (a.CommInitRank(&comm, c->world, id, c->rank) != 0 || !comm) return TCE_ERR_HIP;
+    c->nccl = comm;
+    return TCE_OK;
+}
+bool comm_has_rccl(const Comm *c) { return c->nccl != nullptr; }
+void comm_rccl_destroy(Comm *c) {
+    if (c->nccl && rccl().ok) (void)rccl().CommDestroy(c->nccl);
+    c->nccl = nullptr;
+}
+// the peer-write kernel's regime: slices of at most 64 KiB (beyond: one workgroup copying is slower than the links) that fit the window
+bool comm_peer_regime(const Comm *c, int n_total) {
+    const size_t slice_bytes = (size_t)(n_total / c->world) * 2;
+    return slice_bytes <= 64 * 1024 && (size_t)n_total * 2 <= c->vec_bytes;
+}
+int launch_allgather_rccl(Comm *c, const void *src_slice, void *dst_full, size_t n_per_rank, hipStream_t stream) {
+    RcclApi &a = rccl();
+    if (!a.ok || !c->nccl) return TCE_ERR_UNSUPPORTED_KIND;
+    DeviceGuard guard(c->device);
+    return a.AllGather(src_slice, dst_full, n_per_rank, kNcclHalf, c->nccl, stream) == 0 ? TCE_OK : TCE_ERR_HIP;
+}
+size_t allgather_rows_workspace_bytes(int M, int n_total) { return (size_t)M * (size_t)n_total * 2; }
+// src [M][n_total / world] (this rank's columns of M rows) -> dst [M][ldd] on every rank.  M = 1 is tce_allgather_f16.
+int launch_allgather_rows_f16(Comm *c, int slot, const void *src, void *dst, int M, int n_total, int ldd, void *workspace, hipStream_t stream, hipError_t *he) {
+    if (M < 1 || n_total <= 0 || n_total % c->world || ldd < n_total) return TCE_ERR_BAD_ARG;
+    const int n_loc = n_total / c->world;
+    if (n_loc % 8 || ldd % 8 || ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15)) return TCE_ERR_UNSUPPORTED_SHAPE;
+    if (M == 1) {
+        if (comm_peer_regime(c, n_total)) return launch_allgather_f16(c, slot, src, dst, n_total, stream, he);
+        return launch_allgather_rccl(c, src, dst, (size_t)n_loc, stream);
+    }
+    if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15)) return TCE_ERR_BAD_ARG;
+    // stage 1: every rank's whole [M][n_loc] block, rank-major, into the workspace
+    const long long flat = (long long)M * n_total;
+    int rc;
+    if (flat <= 0x7FFFFFFF && comm_peer_regime(c, (int)flat)) rc = launch_allgather_f16(c, slot, src, workspace, (int)flat, stream, he);
+    else rc = launch_allgather_rccl(c, src, workspace, (size_t)M * n_loc, stream);
+    if (rc != TCE_OK) return rc;
+    // stage 2: rows side by side
+    DeviceGuard guard(c->device);
+    const long long total16 = flat / 8;
+    const int grid = (int)((total16 + 255) / 256 < 2048 ? (total16 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(interleave_rows_kernel, dim3(grid), dim3(256), 0, stream, static_cast<const uint4_t *>(workspace), static_cast<uint4_t *>(dst), c->world, M, n_loc / 8,
+                       (long long)ldd / 8);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         if (he) *he = e;

@@ -738,10 +738,40 @@ int tce_comm_reset(tce_comm *comm) {
 int tce_comm_device(const tce_comm *comm) { return comm ? tce::comm_device(reinterpret_cast<const tce::Comm *>(comm)) : fail(TCE_ERR_BAD_ARG, "tce_comm_device: null"); }
 int tce_allgather_f16(tce_comm *comm, int slot, const void *src_slice, void *dst_full, int n_total, void *stream) {
     if (!comm || !src_slice || !dst_full) return fail(TCE_ERR_BAD_ARG, "tce_allgather_f16: null argument");
+    tce::Comm *c = reinterpret_cast<tce::Comm *>(comm);
     hipError_t he = hipSuccess;
-    const int rc = tce::launch_allgather_f16(reinterpret_cast<tce::Comm *>(comm), slot, src_slice, dst_full, n_total, static_cast<hipStream_t>(stream), &he);
+    // by size: slices up to 64 KiB that fit the window -> ONE peer-write kernel (the decode regime); anything else -> RCCL's all-gather on the same communicator
+    // (tce_comm_rccl_init), when the host set it up
+    if (n_total > 0 && !tce::comm_peer_regime(c, n_total) && tce::comm_has_rccl(c)) {
+        if (n_total % tce::comm_world_of(c)) return fail(TCE_ERR_BAD_ARG, "tce_allgather_f16: n_total %% world != 0");
+        const int rc = tce::launch_allgather_rccl(c, src_slice, dst_full, (size_t)(n_total / tce::comm_world_of(c)), static_cast<hipStream_t>(stream));
+        return rc == TCE_OK ? TCE_OK : fail(rc, "tce_allgather_f16: ncclAllGather failed");
+    }
+    const int rc = tce::launch_allgather_f16(c, slot, src_slice, dst_full, n_total, static_cast<hipStream_t>(stream), &he);
     if (rc == TCE_ERR_HIP) return hip_fail(he, "allgather launch");
-    if (rc != TCE_OK) return fail(rc, "tce_allgather_f16: slot out of range, group not connected, n_total %% world != 0, slices not multiples of 16 bytes, or vector larger than the window");
+    if (rc != TCE_OK) return fail(rc, "tce_allgather_f16: slot out of range, group not connected, n_total %% world != 0, slices not multiples of 16 bytes, or vector larger than the window (and no RCCL communicator: tce_comm_rccl_init)");
+    return TCE_OK;
+}
+int tce_comm_rccl_unique_id(void *id_out) {
+    if (!id_out) return fail(TCE_ERR_BAD_ARG, "tce_comm_rccl_unique_id: null");
+    const int rc = tce::comm_rccl_unique_id(id_out);
+    if (rc == TCE_ERR_UNSUPPORTED_KIND) return fail(rc, "librccl could not be loaded (dlopen librccl.so.1)");
+    return rc == TCE_OK ? TCE_OK : fail(rc, "ncclGetUniqueId failed");
+}
+int tce_comm_rccl_init(tce_comm *comm, const void *id) {
+    if (!comm || !id) return fail(TCE_ERR_BAD_ARG, "tce_comm_rccl_init: null argument");
+    const int rc = tce::comm_rccl_init(reinterpret_cast<tce::Comm *>(comm), id);
+    if (rc == TCE_ERR_UNSUPPORTED_KIND) return fail(rc, "librccl could not be loaded (dlopen librccl.so.1)");
+    return rc == TCE_OK ? TCE_OK : fail(rc, "ncclCommInitRank failed (every rank of the group must call with the same id; one rank per device)");
+}
+size_t tce_allgather_rows_workspace_bytes(int M, int n_total) { return M > 1 && n_total > 0 ? tce::allgather_rows_workspace_bytes(M, n_total) : 0; }
+int tce_allgather_rows_f16(tce_comm *comm, int slot, const void *src, void *dst, int M, int n_total, int ldd, void *workspace, void *stream) {
+    if (!comm || !src || !dst) return fail(TCE_ERR_BAD_ARG, "tce_allgather_rows_f16: null argument");
+    hipError_t he = hipSuccess;
+    const int rc = tce::launch_allgather_rows_f16(reinterpret_cast<tce::Comm *>(comm), slot, src, dst, M, n_total, ldd ? ldd : n_total, workspace, static_cast<hipStream_t>(stream), &he);
+    if (rc == TCE_ERR_HIP) return hip_fail(he, "allgather (rows) launch");
+    if (rc == TCE_ERR_UNSUPPORTED_KIND) return fail(rc, "tce_allgather_rows_f16: the exchange is beyond the peer-write kernel's regime and the communicator has no RCCL side (tce_comm_rccl_init)");
+    if (rc != TCE_OK) return fail(rc, "tce_allgather_rows_f16: bad slot / sizes (n_total %% world, 16-byte slices, ldd >= n_total), no workspace for M > 1, or group not connected");
     return TCE_OK;
 }
 int tce_comm_status(tce_comm *comm) {

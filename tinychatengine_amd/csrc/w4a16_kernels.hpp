@@ -175,6 +175,14 @@ int comm_device(const Comm *c);
 int comm_status(Comm *c, hipError_t *he);
 void comm_destroy(Comm *c);
 int launch_allgather_f16(Comm *c, int slot, const void *src_slice, void *dst_full, int n_total, hipStream_t stream, hipError_t *he);
+int comm_world_of(const Comm *c);
+int comm_rccl_unique_id(void *id128);
+int comm_rccl_init(Comm *c, const void *id128);
+bool comm_has_rccl(const Comm *c);
+bool comm_peer_regime(const Comm *c, int n_total);
+int launch_allgather_rccl(Comm *c, const void *src_slice, void *dst_full, size_t n_per_rank, hipStream_t stream);
+size_t allgather_rows_workspace_bytes(int M, int n_total);
+int launch_allgather_rows_f16(Comm *c, int slot, const void *src, void *dst, int M, int n_total, int ldd, void *workspace, hipStream_t stream, hipError_t *he);
 // attention_fast.hip
 void set_attention_fast_target(int wgs);
 void set_attention_fast_waves(int nw);

@@ -175,6 +175,13 @@ class DecodeLinears:
         self.comm = capi.Comm(self.rank, self.world, n_max, slots=8)
         self.comm.connect(exchange(self.comm.export()))
 
+    def _rows_workspace(self, full: torch.Tensor) -> torch.Tensor:
+        """tce_allgather_rows_f16's workspace (M > 1): one buffer per rank, sized for the widest gathered tensor."""
+        if getattr(self, "_rows_ws", None) is None or self._rows_ws.numel() < full.numel():
+            n_max = max(*self.shape.qkv, self.shape.hidden, self.shape.ffn, self.shape.vocab)
+            self._rows_ws = torch.empty(self.m * n_max, dtype=torch.float16, device=self.device)
+        return self._rows_ws[:full.numel()]
+
     def check_comm(self) -> None:
         """Synchronises and raises if a peer-write gather of this rank ever gave up waiting (tce_comm_status): its outputs since then are
         void.  A host that uses the outputs calls this per token or per batch of tokens; after a host-side barrier tce_comm_reset re-arms."""
@@ -188,31 +195,42 @@ class DecodeLinears:
         exchange (attach_peer_comm first).  gathers_per_block = 1 is the north-star definition (all five linears of a block
         from replicated inputs, one gather of the block output); 4 is the dependency-faithful variant."""
         launch = launch or self._hip_launch
+        m = self.m
         if gather == "peer":
             st = _stream()
             slot_of = {}
 
             def ag(full, part):  # one slot per gather site: a site's epochs advance once per token on every rank
                 slot = slot_of.setdefault(full.data_ptr(), len(slot_of))
-                self.comm.allgather(slot, part.data_ptr(), full.data_ptr(), full.numel(), st)
+                if m == 1:
+                    self.comm.allgather(slot, part.data_ptr(), full.data_ptr(), full.numel(), st)
+                else:  # M > 1 rows (a sharded prompt): the ranks' [M][N/P] blocks, rows laid side by side (peer-write kernel or RCCL by size, csrc/comm.hip)
+                    ws = self._rows_workspace(full)
+                    self.comm.allgather_rows(slot, part.data_ptr(), full.data_ptr(), m, full.shape[1], ws.data_ptr(), st)
         else:
             import torch.distributed as dist
-            ag = dist.all_gather_into_tensor
-        assert self.m == 1, "column-sharded outputs are gathered as flat [N] vectors (M = 1 decode)"
+
+            def ag(full, part):
+                if m == 1:
+                    dist.all_gather_into_tensor(full.view(-1), part.view(-1))
+                else:  # all_gather of whole blocks is rank-major [P][M][N/P]; the rows go side by side afterwards
+                    ws = self._rows_workspace(full).view(self.world, m, part.shape[1])
+                    dist.all_gather_into_tensor(ws.view(-1), part.contiguous().view(-1))
+                    full.copy_(ws.permute(1, 0, 2).reshape(m, full.shape[1]))
         for li in range(self.n_layers):
             lch = self.block_launches(li)
             if gathers_per_block == 1:
                 for g in lch:
                     launch(g)
-                ag(self.g_down.view(-1), self.out_down.view(-1))
+                ag(self.g_down, self.out_down)
             else:
                 launch(lch[0])
                 for gfull, part in zip(self.g_qkv, self.out_qkv):
-                    ag(gfull.view(-1), part.view(-1))
-                launch(lch[1]); ag(self.g_o.view(-1), self.out_o.view(-1))
-                launch(lch[2]); ag(self.g_gate.view(-1), self.out_gate.view(-1)); ag(self.g_up.view(-1), self.out_up.view(-1))
-                launch(lch[3]); ag(self.g_down.view(-1), self.out_down.view(-1))
+                    ag(gfull, part)
+                launch(lch[1]); ag(self.g_o, self.out_o)
+                launch(lch[2]); ag(self.g_gate, self.out_gate); ag(self.g_up, self.out_up)
+                launch(lch[3]); ag(self.g_down, self.out_down)
         launch([self.lm_head.desc(self.x, self.logits, allow_host=self._host_ok)])
-        ag(self.g_logits.view(-1), self.logits.view(-1))
+        ag(self.g_logits, self.logits)
         if check and gather == "peer":  # (synchronises: not for a timed loop or a graph capture)
             self.check_comm()
