@@ -519,14 +519,33 @@ def whole_token_leg(torch, dev, shape, dl):
     out = {"launches_per_token": shape.layers * DecoderBlock.LAUNCHES + 1, "layers": shape.layers, "query_heads": heads, "kv_heads": kv_heads,
            "note": "the position lives in a device word (tce_attention_decode_step_pos_f16): the captured token is replayable for growing contexts; timed at a fixed context"}
     pos_t = torch.zeros(1, dtype=torch.int32, device=dev)
+    # round 4: the norms on the PRODUCER side (tce_w4a16_forward_residual_rmsnorm): q/k/v and gate/up are plain launches on rows the previous launch's residual
+    # epilogue normalised; one tce_rmsnorm_half in front of the first layer, the final norm (gamma = 1) in front of lm_head from the last down_proj
+    from tinychatengine_amd.linear import rmsnorm_half
+    # (measured SLOWER, profiles/r4: 1.65 against 1.41 ms per token -- every producer launch pays the write-through acknowledgements and the last workgroup's serial pass,
+    # +3.8 us each; kept behind TCE_BENCH_WHOLE_TOKEN_CHAINED=1 for the record.  The default token carries the norms as fused prologues of q/k/v and gate/up.)
+    chained = all(b.qkv.packed is not None for b in blocks) and os.environ.get("TCE_BENCH_WHOLE_TOKEN_CHAINED", "") == "1"
+    ws = torch.zeros(int(capi.lib().tce_w4a16_residual_rmsnorm_workspace_bytes()), dtype=torch.uint8, device=dev)
+    xn = [torch.empty_like(hid), torch.empty_like(hid)]
+    final_gamma = torch.ones(shape.hidden, device=dev)
+    out["norms"] = ("on the producer side: o_proj / down_proj + residual + the next RMSNorm as one launch (tce_w4a16_forward_residual_rmsnorm), q/k/v and gate/up plain; "
+                    "+ 1 tce_rmsnorm_half per token") if chained else "fused prologues in the q/k/v and gate/up launches"
+    if chained:
+        out["launches_per_token"] += 1
     for ctx in (512, 2048):
         pos = ctx - 1
         pos_t.fill_(pos)
         def token():
             hid.copy_(hid0)
-            for b in blocks:
-                b.step(hid, pos, pos_device=pos_t)
-            capi.check(capi.w4a16_forward(dl.lm_head.desc(hid, dl.logits), torch.cuda.current_stream().cuda_stream))
+            if not chained:
+                for b in blocks:
+                    b.step(hid, pos, pos_device=pos_t)
+                capi.check(capi.w4a16_forward(dl.lm_head.desc(hid, dl.logits), torch.cuda.current_stream().cuda_stream))
+                return
+            rmsnorm_half(hid, blocks[0].gamma1, blocks[0].eps, out=xn[0])
+            for i, b in enumerate(blocks):
+                b.step_chained(hid, xn[i % 2], pos, blocks[i + 1].gamma1 if i + 1 < len(blocks) else final_gamma, xn[(i + 1) % 2], ws, pos_device=pos_t)
+            capi.check(capi.w4a16_forward(dl.lm_head.desc(xn[len(blocks) % 2], dl.logits), torch.cuda.current_stream().cuda_stream))
         token()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()

@@ -122,6 +122,19 @@ typedef struct tce_w4a16_desc {
 
 TCE_API int tce_w4a16_forward(const tce_w4a16_desc *d, void *stream);
 
+/* Round 4: o_proj / down_proj + residual add + the RMSNorm that FOLLOWS, one launch (decode, M = 1) -- replaces `linear; add_half; LlamaRMSNorm` of
+ * Int4llamaDecoderLayer.cu:86-99 (post_attention_layernorm) and :107-108 + :78 of the next layer (input_layernorm):
+ *   C[n]  = hadd(C[n], fp16(y[n]))                                           as TCE_W4_ADD_TO_C (which `d` must carry; C is the whole residual row: ldc 0 or N)
+ *   xn[n] = half( clamp( (float(C[n]) * rs) * gamma[n] ) ),  rs = 1 / sqrt(mean_n C[n]^2 + eps)   generalT5LayerNorm on the UPDATED row: the bits of tce_rmsnorm_half
+ * so that the next linears (q/k/v, gate/up) are plain launches on xn instead of carrying the prologue -- which every one of their workgroups repeats.  Every workgroup
+ * writes its 16 values and their sums of squares through to memory and counts itself in; the one that arrives last normalises the row.  Needs `d->prepacked` (the
+ * int8-contraction kernel), group 128, N % 8 == 0, N <= 16384.  `workspace`: tce_w4a16_residual_rmsnorm_workspace_bytes() bytes, 16-byte aligned, ZEROED once by the
+ * caller (every launch leaves its counter zero); one per stream that runs such launches concurrently.
+ * Measured (round 4): bit-exact and SLOWER than what it replaces on this part -- +3.8 us per launch (write-through acknowledgements, the last workgroup's
+ * serial pass) against the +1.7 / +5.5 us the fused prologues cost q/k/v and gate/up: a whole token 1.65 against 1.41 ms.  Offered for hosts that must count launches. */
+TCE_API size_t tce_w4a16_residual_rmsnorm_workspace_bytes(void);
+TCE_API int tce_w4a16_forward_residual_rmsnorm(const tce_w4a16_desc *d, const float *gamma, float eps, void *xn_out, void *workspace, void *stream);
+
 /* The same two element-wise operations as stand-alone kernels (for hosts that keep the reference's launch structure):
  *   tce_add_half:       c[i] = hadd(a[i], b[i])                                   (add_half, Int4llamaDecoderLayer.cu:12-18)
  *   tce_silu_mul_half:  a[i] = hmul(hmul(a[i], hdiv(1, hadd(1, hexp(-a[i])))), b[i])  (SiLuMul_half, :20-30)

@@ -259,6 +259,79 @@ def test_i8_rmsnorm_prologue_fused(dev, oracle, Ns, K, pairs):
         assert torch.equal(o, _fwd(l, xn, flags=flags)), "fused prologue != rmsnorm launch + plain launch"
 
 
+@pytest.mark.parametrize("N,K,zeros", [(4096, 4096, False), (4096, 11008, False), (264, 1408, False), (5120, 13824, False), (11008, 4096, False), (4096, 4096, True), (1024, 28672, False)])
+def test_i8_residual_plus_next_rmsnorm_fused(dev, oracle, N, K, zeros):
+    """tce_w4a16_forward_residual_rmsnorm (o_proj / down_proj + residual add + the RMSNorm that follows, Int4llamaDecoderLayer.cu:86-99, 107-108): the residual row as
+    TCE_W4_ADD_TO_C writes it and the normalised row as tce_rmsnorm_half forms it from that row -- bit for bit, launch after launch on one workspace (the counter
+    returns to zero), with a ragged last tile (N % 16 = 8), more than 1024 pieces (two per slot of the order), 16 units per wave, real zero points, and replayed from a graph."""
+    from tinychatengine_amd import capi
+    from tinychatengine_amd.linear import rmsnorm_half
+    lin, _ = _lin(oracle, dev, N, K, 128, seed=N + K, random_zeros=zeros)
+    gamma = (1.0 + 0.1 * torch.randn(N, device=dev)).float()
+    eps = 1e-6
+    ws = torch.zeros(int(capi.lib().tce_w4a16_residual_rmsnorm_workspace_bytes()), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for it in range(3):
+        x = torch.randn((1, K), device=dev).to(torch.float16)
+        res = torch.randn((1, N), device=dev).to(torch.float16)
+        want_c = _fwd(lin, x, flags=capi.TCE_W4_ADD_TO_C, out=res.clone())
+        want_xn = rmsnorm_half(want_c, gamma, eps)
+        c = res.clone()
+        xn = torch.full((1, N), float("nan"), dtype=torch.float16, device=dev)
+        capi.check(capi.w4a16_forward_residual_rmsnorm(lin.desc(x, c, flags=capi.TCE_W4_ADD_TO_C), gamma.data_ptr(), eps, xn.data_ptr(), ws.data_ptr(), st))
+        torch.cuda.synchronize()
+        assert torch.equal(c, want_c), f"residual row, launch {it}"
+        assert torch.equal(xn, want_xn), f"normalised row, launch {it}: {(xn != want_xn).sum().item()} of {N} differ"
+        assert int(ws.view(torch.int32)[2048].item()) == 0
+    # graph replay: the same launch three times per replay (the residual keeps accumulating: compare against the eager sequence)
+    c_g, c_e = res.clone(), res.clone()
+    xn_g, xn_e = torch.zeros_like(xn), torch.zeros_like(xn)
+    for _ in range(3):
+        capi.check(capi.w4a16_forward_residual_rmsnorm(lin.desc(x, c_e, flags=capi.TCE_W4_ADD_TO_C), gamma.data_ptr(), eps, xn_e.data_ptr(), ws.data_ptr(), st))
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s2 = torch.cuda.Stream()
+    with torch.cuda.stream(s2):
+        with torch.cuda.graph(g, stream=s2):
+            for _ in range(3):
+                capi.check(capi.w4a16_forward_residual_rmsnorm(lin.desc(x, c_g, flags=capi.TCE_W4_ADD_TO_C), gamma.data_ptr(), eps, xn_g.data_ptr(), ws.data_ptr(), s2.cuda_stream))
+    c_g.copy_(res)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(c_g, c_e) and torch.equal(xn_g, xn_e)
+    # argument checks: no packed copy / no residual flag -> refused
+    assert capi.w4a16_forward_residual_rmsnorm(lin.desc(x, c), gamma.data_ptr(), eps, xn.data_ptr(), ws.data_ptr(), st) == capi.TCE_ERR_BAD_ARG
+
+
+def test_decoder_block_with_the_norms_on_the_producer_side(dev):
+    """DecoderBlock.step_chained (q/k/v and gate/up as plain launches on rows normalised by the PREVIOUS launch's residual epilogue) against DecoderBlock.step (the fused
+    prologues): the same residual stream, bit for bit, over three layers and two tokens."""
+    from tinychatengine_amd import capi
+    from tinychatengine_amd.decoder_block import DecoderBlock
+    from tinychatengine_amd.linear import rmsnorm_half
+    hidden, heads, ffn, ctx = 1024, 8, 2816, 64
+    ang = np.random.default_rng(0).uniform(0, 2 * np.pi, (ctx, 64))
+    cos = torch.from_numpy(np.concatenate([np.cos(ang), np.cos(ang)], axis=1).astype(np.float16)).to(dev)
+    sin = torch.from_numpy(np.concatenate([np.sin(ang), np.sin(ang)], axis=1).astype(np.float16)).to(dev)
+    mk = lambda: [DecoderBlock(hidden, heads, ffn, ctx, dev, cos, sin, seed=50 + i, kv_heads=4) for i in range(3)]
+    a, b = mk(), mk()
+    final_gamma = torch.ones(hidden, device=dev)
+    ws = torch.zeros(int(capi.lib().tce_w4a16_residual_rmsnorm_workspace_bytes()), dtype=torch.uint8, device=dev)
+    h0 = torch.randn(1, hidden, device=dev).to(torch.float16)
+    for pos in range(2):
+        ha, hb = h0.clone() * (pos + 1), h0.clone() * (pos + 1)
+        for blk in a:
+            blk.step(ha, pos)
+        xn = [rmsnorm_half(hb, b[0].gamma1, b[0].eps), torch.empty_like(hb)]
+        for i, blk in enumerate(b):
+            nxt = b[i + 1].gamma1 if i + 1 < len(b) else final_gamma
+            blk.step_chained(hb, xn[i % 2], pos, nxt, xn[(i + 1) % 2], ws)
+        torch.cuda.synchronize()
+        assert torch.isfinite(ha.float()).all()
+        assert torch.equal(ha, hb), f"token {pos}: {(ha != hb).sum().item()} of {hidden} residual values differ"
+        assert torch.equal(xn[len(b) % 2], rmsnorm_half(hb, final_gamma, b[0].eps))
+
+
 FULL = [(4096, 4096), (11008, 4096), (4096, 11008), (14336, 4096), (4096, 14336), (1024, 4096), (12288, 4096), (32000, 4096), (128256, 4096),
         (15360, 5120), (5120, 5120), (13824, 5120), (5120, 13824)]
 

@@ -30,7 +30,7 @@ TCE_OUT_INT8, TCE_OUT_FP32 = 0, 1
 
 # every symbol include/tce_matmul.h declares (tests/test_boundary.py checks the .so exports exactly these)
 EXPORTS = [
-    "tce_w4a16_forward", "tce_w4a16_prepack_bytes", "tce_w4a16_prepack", "tce_w4a16_gemm_scratch_bytes", "tce_w4a16_describe_dispatch", "tce_reset_last_error", "tce_bmm_f16t", "tce_rope_half", "tce_softmax_half", "tce_attention_decode_f16", "tce_attention_decode_workspace_bytes", "tce_attention_decode_describe", "tce_attention_decode_step_f16", "tce_attention_decode_step_gqa_f16", "tce_attention_decode_describe_gqa", "tce_attention_decode_step_pos_f16", "tce_attention_prefill_f16", "tce_attention_prefill_workspace_bytes", "tce_opt_attention_decode", "tce_prefetch", "tce_add_half", "tce_silu_mul_half", "tce_rmsnorm_half", "tce_w4a16_forward_group_rmsnorm", "tce_w4a16_forward_group", "tce_w4a16_check_zero_point_8", "tce_w4a16_awq_fp16acc", "tce_w4a16_awq_workspace_bytes",
+    "tce_w4a16_forward", "tce_w4a16_residual_rmsnorm_workspace_bytes", "tce_w4a16_forward_residual_rmsnorm", "tce_w4a16_prepack_bytes", "tce_w4a16_prepack", "tce_w4a16_gemm_scratch_bytes", "tce_w4a16_describe_dispatch", "tce_reset_last_error", "tce_bmm_f16t", "tce_rope_half", "tce_softmax_half", "tce_attention_decode_f16", "tce_attention_decode_workspace_bytes", "tce_attention_decode_describe", "tce_attention_decode_step_f16", "tce_attention_decode_step_gqa_f16", "tce_attention_decode_describe_gqa", "tce_attention_decode_step_pos_f16", "tce_attention_prefill_f16", "tce_attention_prefill_workspace_bytes", "tce_opt_attention_decode", "tce_prefetch", "tce_add_half", "tce_silu_mul_half", "tce_rmsnorm_half", "tce_w4a16_forward_group_rmsnorm", "tce_w4a16_forward_group", "tce_w4a16_check_zero_point_8", "tce_w4a16_awq_fp16acc", "tce_w4a16_awq_workspace_bytes",
     "tce_w4a16_gemm_awq", "tce_w4a16_shard", "tce_comm_create", "tce_comm_export", "tce_comm_connect", "tce_comm_connect_local", "tce_allgather_f16", "tce_comm_rccl_unique_id", "tce_comm_rccl_init", "tce_allgather_rows_workspace_bytes", "tce_allgather_rows_f16", "tce_comm_status", "tce_comm_set_timeout_ms", "tce_comm_reset", "tce_comm_device", "tce_comm_destroy", "tce_w8a8_matmul", "tce_opt_softmax_q", "tce_opt_kv_append", "tce_layernorm_q", "tce_layernorm_q_w8a8_group", "tce_plan_create", "tce_plan_create_ex", "tce_plan_is_chained", "tce_plan_geometry", "tce_plan_status", "tce_plan_launch_geometry", "tce_plan_launch", "tce_plan_n_launches",
     "tce_plan_destroy", "tce_version", "tce_last_error", "tce_build_info", "tce_w4a16_set_gemv_config", "tce_w4a16_set_gemv_i8",
     "tce_w4a16_set_gemm_config", "tce_w4a16_algorithmic_bytes", "tce_w4a16_gemv_variant", "tce_w4a16_gemm_variant",
@@ -152,6 +152,8 @@ def lib() -> C.CDLL:
         L.tce_w4a16_set_gemv_config.argtypes = [C.c_int] * 4
         L.tce_w4a16_set_gemm_config.argtypes = [C.c_int] * 2
         L.tce_w4a16_set_gemv_i8.argtypes = [C.c_int] * 2
+        L.tce_w4a16_residual_rmsnorm_workspace_bytes.restype = C.c_size_t
+        L.tce_w4a16_forward_residual_rmsnorm.argtypes = [C.POINTER(W4A16Desc), C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.tce_comm_rccl_unique_id.argtypes = [C.c_void_p]
         L.tce_comm_rccl_init.argtypes = [C.c_void_p, C.c_void_p]
         L.tce_allgather_rows_workspace_bytes.argtypes = [C.c_int, C.c_int]
@@ -191,6 +193,11 @@ def describe_dispatch(desc: W4A16Desc) -> str:
 
 def w4a16_forward(desc: W4A16Desc, stream: int | None) -> int:
     return lib().tce_w4a16_forward(C.byref(desc), C.c_void_p(stream or 0))
+
+
+def w4a16_forward_residual_rmsnorm(desc: W4A16Desc, gamma_ptr: int, eps: float, xn_ptr: int, workspace_ptr: int, stream: int | None) -> int:
+    """o_proj / down_proj + residual add + the RMSNorm that follows, one launch (tce_w4a16_forward_residual_rmsnorm)."""
+    return lib().tce_w4a16_forward_residual_rmsnorm(C.byref(desc), C.c_void_p(gamma_ptr), float(eps), C.c_void_p(xn_ptr), C.c_void_p(workspace_ptr), C.c_void_p(stream or 0))
 
 
 def w4a16_forward_group(descs: list[W4A16Desc], stream: int | None) -> int:

@@ -401,6 +401,25 @@ int tce_w4a16_forward_group(const tce_w4a16_desc *descs, int count, void *stream
     return TCE_OK;
 }
 
+size_t tce_w4a16_residual_rmsnorm_workspace_bytes(void) { return 2048 * sizeof(float) + 256; }
+
+int tce_w4a16_forward_residual_rmsnorm(const tce_w4a16_desc *d, const float *gamma, float eps, void *xn_out, void *workspace, void *stream) {
+    const int rc0 = check_w4a16(d);
+    if (rc0 != TCE_OK) return rc0;
+    if (!gamma || !xn_out || !workspace || (reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(xn_out) | reinterpret_cast<uintptr_t>(workspace)) % 16 != 0)
+        return fail(TCE_ERR_BAD_ARG, "tce_w4a16_forward_residual_rmsnorm: gamma / xn_out / workspace must be non-null and 16-byte aligned");
+    if (!(d->flags & TCE_W4_ADD_TO_C) || d->M != 1 || d->rmsnorm_gamma)
+        return fail(TCE_ERR_BAD_ARG, "tce_w4a16_forward_residual_rmsnorm: a decode row (M = 1) with TCE_W4_ADD_TO_C and no prologue of its own");
+    if ((d->ldc && d->ldc != d->N)) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_w4a16_forward_residual_rmsnorm: the linear must produce the whole residual row (ldc = N)");
+    if (!tce::gemv_i8_supports(d, 1)) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_w4a16_forward_residual_rmsnorm needs the packed copy (desc.prepacked, K %% 128 == 0, group 128): it lives in the int8-contraction kernel");
+    hipError_t he = hipSuccess;
+    const tce::I8ResidualNorm rn{gamma, eps, xn_out, workspace};
+    const int rc = tce::launch_w4a16_gemv_i8(d, 1, static_cast<hipStream_t>(stream), &he, nullptr, 0.f, &rn);
+    if (rc == TCE_ERR_HIP) return hip_fail(he, "w4a16 gemv (residual + next rmsnorm) launch");
+    if (rc != TCE_OK) return fail(rc, "tce_w4a16_forward_residual_rmsnorm: unsupported shape (group 128, N %% 8 == 0, N <= 16384)");
+    return TCE_OK;
+}
+
 int tce_w4a16_forward(const tce_w4a16_desc *d, void *stream) {
     const int rc0 = check_w4a16(d);
     if (rc0 != TCE_OK) return rc0;

@@ -45,6 +45,12 @@ struct I8Args {
     int nseg;
     const float *gamma;  // non-null: the activation is the UN-normalised hidden state; the conversion stages RMSNorm(A) * gamma (generalT5LayerNorm arithmetic; M = 1)
     float eps;
+    // RNORM (tce_w4a16_forward_residual_rmsnorm): the residual epilogue also produces the NEXT RMSNorm of the updated row -- out_gamma fp32 [N], xn_out fp16 [N],
+    // ws = float slots[2048] (the row's piece sums) + unsigned counter at word 2048 (zero between launches)
+    const float *out_gamma;
+    float out_eps;
+    half_t *xn_out;
+    float *ws;
     I8Seg seg[TCE_MAX_GROUP];
 };
 
@@ -66,9 +72,17 @@ __device__ __forceinline__ float dpp_add_f32(float v) {
 // activations it converts.  (A form that factors rs out of the row -- x * gamma kept in fp32, rs applied to the finished rows behind the barrier the K reduction needs
 // anyway: no barrier and no second pass in front of the contraction -- ran the whole token 2.6 % faster and FAILED parity: the reference rounds the normalised
 // activation to binary16 before the linear, and that rounding is 2.8e-4 of the output's rms, 18 x the tolerance floor of outputs near zero.  Round 4, not kept.)
-template <int MB, int GPU, int ROWS, int UW, bool Z8, int MAXT, bool NORM = false>
+// RNORM: o_proj / down_proj + residual add + the RMSNorm that FOLLOWS (post_attention_layernorm / the next layer's input_layernorm, Int4llamaDecoderLayer.cu:86-99,
+// 107-108 + :78 of the next layer) as one launch: every workgroup stores its 16 updated residual values and their two piece sums of squares write-through (system
+// scope: the per-XCD L2s are not coherent), counts itself in; the workgroup that arrives LAST forms rs in tce_common.hpp's order from all piece sums and writes the
+// normalised row once -- instead of every workgroup of the NEXT launch normalising all of x behind a barrier (its fused prologue: +1.7 / +5.5 us on the q/k/v and
+// gate/up launches; the next launch is then the plain kernel).  Bits: C as TCE_W4_ADD_TO_C, xn as tce_rmsnorm_half on the updated row.
+// MEASURED (round 4): correct and SLOWER than the prologue it replaces -- the write-through stores must be acknowledged before a workgroup may count itself in and the last
+// workgroup's pass is serial: +3.8 us per producer launch, a whole token 1.65 against 1.41 ms.  Kept as an entry point (tests pin its bits); DecoderBlock.step does not use it.
+template <int MB, int GPU, int ROWS, int UW, bool Z8, int MAXT, bool NORM = false, bool RNORM = false>
 __global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const I8Args args) {
     static_assert(MB * GPU <= 4, "sixteen output columns: rows x groups-per-unit x 4 planes");
+    static_assert(!RNORM || (MB == 1 && ROWS == 1 && !NORM), "the residual + next-norm epilogue: one decode row, one tile per workgroup");
     static_assert(!NORM || MB == 1, "the fused RMSNorm prologue is a decode (M = 1) feature");
     constexpr int UPP = 4 / (MB * GPU);  // units per pass
     static_assert(UW % UPP == 0 && UW % 4 == 0, "whole passes; whole 16-byte x loads per lane");
@@ -177,9 +191,11 @@ __global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const I8Args args) 
             const half8_t v = __builtin_bit_cast(half8_t, xv[0][c]);
             half8_t y;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                y[e] = rmsnorm_out(v[e], rs, gm[c][0][e]);
-                y[4 + e] = rmsnorm_out(v[4 + e], rs, gm[c][1][e]);
+            for (int e = 0; e < 8; ++e) {
+                // rmsnorm_out's arithmetic -- half(clamp((x * rs) * gamma)) -- with the clamp as ONE v_med3_f32 (the same value for every finite product; a NaN / inf
+                // activation poisons the row anyway): 3 vector instructions fewer per element, 48 per wave, in a kernel that is bound by issue
+                const float f = ((float)v[e] * rs) * (e < 4 ? gm[c][0][e] : gm[c][1][e - 4]);
+                y[e] = (half_t)__builtin_amdgcn_fmed3f(f, -(65504.f - 1000.f), 65504.f - 1000.f);
             }
             xv[0][c] = __builtin_bit_cast(uint4_t, y);
         }
@@ -359,15 +375,74 @@ __global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const I8Args args) 
         const half_t y = (half_t)v;
         // the (gate, up) neighbour of the pair epilogue: rows 2n, 2n + 1 are adjacent lanes
         const half_t y_other = __builtin_bit_cast(half_t, (unsigned short)__builtin_amdgcn_update_dpp(0, (int)__builtin_bit_cast(unsigned short, y), 0xB1, 0xF, 0xF, false));
+        half_t hnew = (half_t)0.0f;
+        (void)hnew;
         if (m0 + m < args.M && row < seg.N) {
             half_t *crow = seg.C + (size_t)(m0 + m) * seg.ldc;
             if (seg.epilogue & TCE_W4_SILU_MUL_PAIRS) {
                 if ((i16 & 1) == 0) crow[row >> 1] = silu_mul_half(y, y_other);
             } else if (seg.epilogue & TCE_W4_ADD_TO_C) {
-                crow[row] = crow[row] + y;
+                if constexpr (RNORM) hnew = crow[row] + y;  // (stored below, write-through)
+                else crow[row] = crow[row] + y;
             } else {
                 crow[row] = y;
             }
+        }
+        if constexpr (RNORM) {
+            // the tile's 16 updated values -> memory, past every cache (the last workgroup reads them from another XCD); their two piece sums likewise
+            if (row < seg.N) __hip_atomic_store(reinterpret_cast<unsigned short *>(seg.C) + row, __builtin_bit_cast(unsigned short, hnew), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const float hf = row < seg.N ? (float)hnew : 0.f;
+            float s0 = 0.f, s1 = 0.f;  // fmaf chains over the two pieces' 8 values, in order (rmsnorm_piece_sum), formed by every lane from broadcasts
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hf), e));
+                const float v1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hf), 8 + e));
+                s0 = __builtin_fmaf(v0, v0, s0);
+                s1 = __builtin_fmaf(v1, v1, s1);
+            }
+            if (tid < 2) __hip_atomic_store(args.ws + 2 * tile0 + tid, tid == 0 ? s0 : s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if constexpr (RNORM) {
+        unsigned *flag = reinterpret_cast<unsigned *>(smem);  // (the planes are dead)
+        if (tid < 64) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores above have left this wave before it counts itself in
+            if (tid == 0) {
+                const unsigned old = __hip_atomic_fetch_add(reinterpret_cast<unsigned *>(args.ws) + 2048, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                flag[0] = old == gridDim.x - 1 ? 1u : 0u;
+            }
+        }
+        __syncthreads();
+        if (flag[0] == 0u) return;
+        // ---- the last workgroup: rs, then the normalised row ----
+        if (tid == 0) reinterpret_cast<unsigned *>(args.ws)[2048] = 0u;  // for the next launch on this workspace (ordered by the kernel boundary)
+        const int n = seg.N, pieces = n >> 3;
+        auto sys_load_f32 = [](const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+        float tot = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int q = c * 64 + lane;
+            float slot = 0.f;
+            slot += q < pieces ? sys_load_f32(args.ws + q) : 0.f;
+            if (q + 1024 < pieces) slot += sys_load_f32(args.ws + q + 1024);
+            tot += slot;
+        }
+        tot = wave_sum_dpp_lane63(tot);
+        tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), 63));
+        const float rs = 1.0f / sqrtf(tot / (float)n + args.out_eps);
+        const half_t *hrow = seg.C;
+        for (int p = tid; p < pieces; p += (int)blockDim.x) {
+            uint4_t raw;
+            asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(raw) : "v"(hrow + p * 8) : "memory");
+            const half8_t hv = __builtin_bit_cast(half8_t, raw);
+            const float4_t g0 = *reinterpret_cast<const float4_t *>(args.out_gamma + p * 8), g1 = *reinterpret_cast<const float4_t *>(args.out_gamma + p * 8 + 4);
+            half8_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = rmsnorm_out(hv[e], rs, g0[e]);
+                o[4 + e] = rmsnorm_out(hv[4 + e], rs, g1[e]);
+            }
+            *reinterpret_cast<half8_t *>(args.xn_out + p * 8) = o;
         }
     }
 }
@@ -375,10 +450,10 @@ __global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const I8Args args) 
 int g_i8_mode = 0;  // 0 automatic, 1 off, 2 forced wherever the shape allows
 int g_i8_rows = 0;  // 0 the rule, 1 / 2 forced tiles per wave
 
-template <int MB, int GPU, int ROWS, int UW, bool Z8, int MAXT, bool NORM = false>
+template <int MB, int GPU, int ROWS, int UW, bool Z8, int MAXT, bool NORM = false, bool RNORM = false>
 hipError_t launch_i8(const I8Args &a, int blocks, int m_blocks, int wk, hipStream_t stream) {
     const size_t lds = (size_t)wk * UW * MB * 512 + (size_t)wk * ROWS * MB * 16 * sizeof(float) + (NORM ? (size_t)(a.K >> 3) * sizeof(float) + 1024 : 0);  // the row's piece sums (+ the ragged last wave's zero pieces)
-    auto kfn = w4a16_gemv_i8_kernel<MB, GPU, ROWS, UW, Z8, MAXT, NORM>;
+    auto kfn = w4a16_gemv_i8_kernel<MB, GPU, ROWS, UW, Z8, MAXT, NORM, RNORM>;
     if (lds > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -414,7 +489,7 @@ bool gemv_i8_supports(const tce_w4a16_desc *descs, int count, bool with_norm) {
     return true;
 }
 
-int launch_w4a16_gemv_i8(const tce_w4a16_desc *descs, int count, hipStream_t stream, hipError_t *hip_err, const float *gamma, float eps) {
+int launch_w4a16_gemv_i8(const tce_w4a16_desc *descs, int count, hipStream_t stream, hipError_t *hip_err, const float *gamma, float eps, const I8ResidualNorm *rn) {
     const tce_w4a16_desc &d0 = descs[0];
     if (!gamma && d0.rmsnorm_gamma) {
         gamma = static_cast<const float *>(d0.rmsnorm_gamma);
@@ -468,6 +543,20 @@ int launch_w4a16_gemv_i8(const tce_w4a16_desc *descs, int count, hipStream_t str
     }
     for (int i = count; i < TCE_MAX_GROUP; ++i) a.seg[i] = a.seg[0];
     hipError_t e = hipErrorInvalidConfiguration;
+    if (rn) {  // residual add + the next RMSNorm: one decode row, one linear, groups of 128, N <= 16384 (the 2048 slots of the order)
+        if (count != 1 || gamma || mb != 1 || gpu != 1 || d0.M != 1 || !(d0.flags & TCE_W4_ADD_TO_C) || d0.N > 16384 || d0.N % 8 != 0) return TCE_ERR_UNSUPPORTED_SHAPE;
+        a.out_gamma = rn->gamma;
+        a.out_eps = rn->eps;
+        a.xn_out = static_cast<half_t *>(rn->xn_out);
+        a.ws = static_cast<float *>(rn->workspace);
+        if (uw == 8) e = z8 ? launch_i8<1, 1, 1, 8, true, 1024, false, true>(a, blocks, m_blocks, wk, stream) : launch_i8<1, 1, 1, 8, false, 1024, false, true>(a, blocks, m_blocks, wk, stream);
+        else e = z8 ? launch_i8<1, 1, 1, 16, true, 1024, false, true>(a, blocks, m_blocks, wk, stream) : launch_i8<1, 1, 1, 16, false, 1024, false, true>(a, blocks, m_blocks, wk, stream);
+        if (e != hipSuccess) {
+            if (hip_err) *hip_err = e;
+            return TCE_ERR_HIP;
+        }
+        return TCE_OK;
+    }
     if (gamma) {
         if (mb != 1 || gpu != 1 || uw != 8) return TCE_ERR_UNSUPPORTED_SHAPE;
         e = z8 ? launch_i8<1, 1, 1, 8, true, 1024, true>(a, blocks, m_blocks, wk, stream) : launch_i8<1, 1, 1, 8, false, 1024, true>(a, blocks, m_blocks, wk, stream);

@@ -104,7 +104,13 @@ int launch_w4a16_gemv(const tce_w4a16_desc *descs, int count, int forced_rows, i
 // w4a16_gemv_i8.hip: the decode GEMV (M <= 4) as an int8 contraction on the pre-packed copy
 bool gemv_i8_supports(const tce_w4a16_desc *descs, int count, bool with_norm = false);
 void set_gemv_i8_mode(int mode, int rows);  // mode 0 automatic (taken wherever a packed copy comes with the descriptors), 1 off; rows 0 the rule, 1 / 2 tiles per wave
-int launch_w4a16_gemv_i8(const tce_w4a16_desc *descs, int count, hipStream_t stream, hipError_t *hip_err, const float *gamma = nullptr, float eps = 0.f);
+struct I8ResidualNorm {  // tce_w4a16_forward_residual_rmsnorm: the RMSNorm that follows the residual add, produced by the same launch
+    const float *gamma;
+    float eps;
+    void *xn_out;
+    void *workspace;  // float [2048] + unsigned counter (zero between launches)
+};
+int launch_w4a16_gemv_i8(const tce_w4a16_desc *descs, int count, hipStream_t stream, hipError_t *hip_err, const float *gamma = nullptr, float eps = 0.f, const I8ResidualNorm *rn = nullptr);
 
 // MFMA GEMM on the q4_6 layout (prefill).  m_tiles x n_tiles 16x16 MFMA tiles per wave, 4 waves along N.
 #define TCE_GEMM_VARIANTS(X) \

@@ -48,6 +48,7 @@ class DecoderBlock:
         self.attention = DecodeAttention(heads, 128, max_keys, device, cos, sin, kv_heads=self.kv_heads)
         e = lambda n: torch.empty((1, n), dtype=torch.float16, device=device)
         self.qkv_out, self.attn_out, self.act = e((heads + 2 * self.kv_heads) * 128), e(hidden), e(ffn)
+        self.xn2 = e(hidden)  # post_attention_layernorm of the residual row (step_chained)
 
     def step(self, hidden_state: torch.Tensor, pos: int, pos_device: torch.Tensor | None = None) -> None:
         """hidden_state fp16 [1][hidden], updated in place (it is the residual stream).  pos_device: the position on the device (`pos` then
@@ -58,6 +59,21 @@ class DecoderBlock:
         capi.check(capi.w4a16_forward(self.o.desc(self.attn_out, hidden_state, flags=capi.TCE_W4_ADD_TO_C), st))
         capi.check(capi.w4a16_forward(self.gate_up.desc(hidden_state, self.act, flags=capi.TCE_W4_SILU_MUL_PAIRS, gamma=self.gamma2, eps=self.eps), st))
         capi.check(capi.w4a16_forward(self.down.desc(self.act, hidden_state, flags=capi.TCE_W4_ADD_TO_C), st))
+
+    def step_chained(self, hidden_state: torch.Tensor, xn_in: torch.Tensor, pos: int, next_gamma: torch.Tensor, xn_out: torch.Tensor, workspace: torch.Tensor,
+                     pos_device: torch.Tensor | None = None) -> None:
+        """The same five launches with the norms on the PRODUCER side (round 4, tce_w4a16_forward_residual_rmsnorm): `xn_in` is input_layernorm(hidden_state), already
+        formed by the launch that produced hidden_state (the previous layer's down_proj; tce_rmsnorm_half for the first layer); o_proj's residual epilogue forms
+        post_attention_layernorm, down_proj's forms the NEXT layer's input_layernorm (`next_gamma`) into `xn_out`.  q/k/v and gate/up are plain launches.
+        Same bits as step(): every piece has the arithmetic of the separate kernels."""
+        st = _stream()
+        capi.check(capi.w4a16_forward(self.qkv.desc(xn_in, self.qkv_out), st))
+        self.attention.step(self.qkv_out.view(-1), pos, out=self.attn_out.view(self.heads, 128), pos_device=pos_device)
+        capi.check(capi.w4a16_forward_residual_rmsnorm(self.o.desc(self.attn_out, hidden_state, flags=capi.TCE_W4_ADD_TO_C), self.gamma2.data_ptr(), self.eps,
+                                                        self.xn2.data_ptr(), workspace.data_ptr(), st))
+        capi.check(capi.w4a16_forward(self.gate_up.desc(self.xn2, self.act, flags=capi.TCE_W4_SILU_MUL_PAIRS), st))
+        capi.check(capi.w4a16_forward_residual_rmsnorm(self.down.desc(self.act, hidden_state, flags=capi.TCE_W4_ADD_TO_C), next_gamma.data_ptr(), self.eps,
+                                                        xn_out.data_ptr(), workspace.data_ptr(), st))
 
     LAUNCHES = 5
 
