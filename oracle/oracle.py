@@ -24,6 +24,8 @@ ORACLE_SO = os.path.join(_HERE, "libtce_oracle.so")
 REF_SO = os.path.join(_HERE, "_ref", "libtce_ref.so")
 REF_AVX_SO = os.path.join(_HERE, "_ref", "libtce_ref_avx.so")
 REF_X86NAIVE_SO = os.path.join(_HERE, "_ref", "libtce_ref_x86naive.so")
+REF_ARMNAIVE_SO = os.path.join(_HERE, "_ref", "libtce_ref_armnaive.so")
+REF_METALNAIVE_SO = os.path.join(_HERE, "_ref", "libtce_ref_metalnaive.so")
 
 
 def build(with_ref: bool | None = None) -> None:
@@ -318,6 +320,14 @@ def naive_mat_mul_int4_x86(lib, prefix, A, B_q4_3, scales, M, N, K, G=32):
     A = np.ascontiguousarray(A, np.float32); B = np.ascontiguousarray(B_q4_3, np.uint8); sc = np.ascontiguousarray(scales, np.float32)
     out = np.empty((M, N), np.float32)
     getattr(lib, prefix + "naive_mat_mul_int4_x86")(C.c_int(M), C.c_int(N), C.c_int(K), C.c_int(G), _p(A), _p(B), _p(sc), _p(out))
+    return out
+
+
+def naive_mat_mul_int4_isa(lib, prefix, isa, A, B_bytes, scales, M, N, K, G):
+    """The QM_ARM / QM_METAL branch of naive_mat_mul_int4 (isa = 'arm' | 'metal') through either library (prefix 'orc_' or 'ref_'): pure byte arithmetic, any bytes."""
+    A = np.ascontiguousarray(A, np.float32); B = np.ascontiguousarray(B_bytes, np.uint8); sc = np.ascontiguousarray(scales, np.float32)
+    out = np.empty((M, N), np.float32)
+    getattr(lib, f"{prefix}naive_mat_mul_int4_{isa}")(C.c_int(M), C.c_int(N), C.c_int(K), C.c_int(G), _p(A), _p(B), _p(sc), _p(out))
     return out
 
 

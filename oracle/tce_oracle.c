@@ -274,6 +274,68 @@ ORC_API int orc_naive_mat_mul_int4_x86(int M, int N, int K, int G, const float *
     return 0;
 }
 
+/*
+ * MatmulOperator::naive_mat_mul_int4, QM_ARM branch -- kernels/matmul_int4.cc:50-76.  Per group of G weights (G / 2 bytes), per run of 16 bytes: byte e holds a
+ * code in its low nibble that meets x[e] and one in its high nibble that meets x[16 + e]; the activation pointer advances by 16 per run (NOT by the 32 weights the run
+ * holds -- for G = 32, the ARM models' group size, a group is one run and the pointer restarts at the next group: consistent; for larger groups the runs overlap,
+ * restated as written).  Zero point hard-coded 8.
+ */
+ORC_API int orc_naive_mat_mul_int4_arm(int M, int N, int K, int G, const float *A, const uint8_t *B, const float *scales, float *C) {
+    if (G % 32 != 0 || K % G != 0) return -1;
+    for (int i = 0; i < M; i++)
+        for (int j = 0; j < N; j++) {
+            float acc = 0.0f;
+            for (int k = 0; k < K; k += G) {
+                float s = scales[((int64_t)j * K + k) / G];
+                const uint8_t *b = B + (int64_t)j * (K / 2) + k / 2;
+                const float *x = A + (int64_t)i * K + k;
+                for (int qi = 0; qi < G / 2; qi += 16)
+                    for (int qj = 0; qj < 16; qj++) {
+                        uint8_t p = b[qi + qj];
+                        float d0 = (float)((double)(p & 0x0F) - 8.0) * s;
+                        float d1 = (float)((double)(p >> 4) - 8.0) * s;
+                        float t0 = *x * d0;
+                        acc = acc + t0;
+                        float t1 = x[16] * d1;
+                        acc = acc + t1;
+                        x++;
+                    }
+            }
+            C[(int64_t)i * N + j] = acc;
+        }
+    return 0;
+}
+
+/*
+ * MatmulOperator::naive_mat_mul_int4, QM_METAL branch -- kernels/matmul_int4.cc:16-49.  Per 4 bytes: the four low nibbles are weights 0..3, the four high nibbles
+ * weights 4..7 of eight consecutive k; all eight dequantised first, then accumulated in k order.  Zero point hard-coded 8.
+ */
+ORC_API int orc_naive_mat_mul_int4_metal(int M, int N, int K, int G, const float *A, const uint8_t *B, const float *scales, float *C) {
+    if (G % 8 != 0 || K % G != 0) return -1;
+    for (int i = 0; i < M; i++)
+        for (int j = 0; j < N; j++) {
+            float acc = 0.0f;
+            for (int k = 0; k < K; k += G) {
+                float s = scales[((int64_t)j * K + k) / G];
+                const uint8_t *b = B + (int64_t)j * (K / 2) + k / 2;
+                const float *x = A + (int64_t)i * K + k;
+                for (int qi = 0; qi < G / 2; qi += 4) {
+                    float d[8];
+                    for (int e = 0; e < 4; e++) {
+                        d[e] = (float)((double)(b[qi + e] & 0x0F) - 8.0) * s;
+                        d[4 + e] = (float)((double)(b[qi + e] >> 4) - 8.0) * s;
+                    }
+                    for (int e = 0; e < 8; e++) {
+                        float t = *x++ * d[e];
+                        acc = acc + t;
+                    }
+                }
+            }
+            C[(int64_t)i * N + j] = acc;
+        }
+    return 0;
+}
+
 /* naive_mat_mul_int4_with_offset -- kernels/matmul_int4.cc:133-165 (deq = (q-z)*s + o). */
 ORC_API void orc_naive_mat_mul_int4_with_offset(int M, int N, int K, int G, const float *A, const uint8_t *B,
                                                 const float *scales, const float *offset, float zero_point, float *C) {

@@ -160,6 +160,40 @@ def test_x86_interleave_branch_and_avx_baseline_sanity(oracle):
         assert float(np.mean((avx - mine[:1]) ** 2)) <= 7e-4
 
 
+@pytest.mark.parametrize("isa,G", [("arm", 32), ("arm", 128), ("metal", 32), ("metal", 128)])
+def test_arm_and_metal_nibble_orders_restated_and_pinned(oracle, isa, G):
+    """SURVEY 8a row a7 (round 4): the QM_ARM (kernels/matmul_int4.cc:50-76) and QM_METAL (:16-49) flavours of naive_mat_mul_int4 -- two more nibble orders of the
+    same weights, CPU-ISA storage layouts with no caller on the GPU path -- restated in oracle/tce_oracle.c and held to the reference's own function built under that
+    flavour (oracle/_ref/libtce_ref_{arm,metal}naive.so), bit for bit, on random bytes (the branches are pure byte arithmetic; G = 128 exercises the ARM branch's
+    overlapping runs as written).  Against the generic branch on the bytes re-ordered accordingly: the same products, another summation order."""
+    import ctypes as C
+    import os
+    from oracle import oracle as O
+    path = O.REF_ARMNAIVE_SO if isa == "arm" else O.REF_METALNAIVE_SO
+    if not os.path.exists(path):
+        pytest.skip(f"{os.path.basename(path)} not built")
+    ref = C.CDLL(path)
+    rng = np.random.default_rng(17 + G)
+    M, N, K = 3, 40, 512
+    B = rng.integers(0, 256, (N, K // 2), dtype=np.uint8)
+    d = (rng.random((N, K // G)).astype(np.float32) * 0.02 + 0.001)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    mine = O.naive_mat_mul_int4_isa(oracle.lib, "orc_", isa, A, B, d, M, N, K, G)
+    theirs = O.naive_mat_mul_int4_isa(ref, "ref_", isa, A, B, d, M, N, K, G)
+    assert np.array_equal(mine, theirs)
+    if isa == "metal" or G == 32:  # the layouts as orders of codes along k (ARM with G > 32 overlaps its runs: not a permutation)
+        lo, hi = (B & 0x0F).astype(np.int64), (B >> 4).astype(np.int64)
+        codes = np.empty((N, K), np.int64)
+        if isa == "metal":
+            codes.reshape(N, K // 8, 8)[:, :, :4] = lo.reshape(N, K // 8, 4)
+            codes.reshape(N, K // 8, 8)[:, :, 4:] = hi.reshape(N, K // 8, 4)
+        else:
+            codes.reshape(N, K // 32, 32)[:, :, :16] = lo.reshape(N, K // 32, 16)
+            codes.reshape(N, K // 32, 32)[:, :, 16:] = hi.reshape(N, K // 32, 16)
+        want = ((codes - 8) * np.repeat(d.astype(np.float64), G, axis=1)) @ A.astype(np.float64).T
+        assert np.abs(mine - want.T).max() < 1e-4
+
+
 def test_glue_ops_are_binary16_arithmetic(oracle):
     """orc_add_half / orc_silu_mul_half (Int4llamaDecoderLayer.cu:12-30) against numpy's float16 arithmetic, which rounds
     every operation to binary16 like __hadd / __hmul / __hdiv; exp is the float exponential rounded to half."""

@@ -174,9 +174,10 @@ __global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const I8Args args) 
             if (p < pieces + 128) slots[p] = rmsnorm_piece_sum(__builtin_bit_cast(half8_t, xv[0][c]));  // (pieces past K: zeros were loaded)
         }
         lds_barrier();  // (LDS only: every weight byte of the wave stays in flight)
+        // (the order's sixteen terms per lane; the terms past the row's pieces are zeros: only the first ceil(pieces / 64) are read -- 8 for K = 4096)
         float tot = 0.f;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
+        const int nc = pieces >= 1024 ? 16 : (pieces + 63) >> 6;
+        for (int c = 0; c < nc; ++c) {
             const int q = c * 64 + lane;
             float slot = 0.f;
             slot += q < pieces ? slots[q] : 0.f;
