@@ -27,6 +27,16 @@ namespace {
     std::exit(1);
 }
 
+// The descriptors are plain structs without a size field: an adapter compiled against one header revision and a libtce_hip.so built from another
+// would hand structs of the wrong layout across the boundary.  Checked once, when the adapter library is loaded; the failure is loud.
+const int g_abi_checked = [] {
+    if (tce_version() != TCE_VERSION) {
+        std::printf("libtce_matmul_operator: libtce_hip.so reports ABI version %d, this adapter was compiled against %d (include/tce_matmul.h): rebuild both\n", tce_version(), TCE_VERSION);
+        std::exit(1);
+    }
+    return 1;
+}();
+
 // Per-tensor state the stateless reference operator does not have ("the HIP shim may keep an internal cache keyed
 // by weight pointer").  Both caches are hash maps keyed by the tensor's identity AS THE CALL DESCRIBES IT -- pointer AND shape
 // (a different N / K / group at a recycled address is a different key, never a stale hit) -- guarded by one mutex, with no

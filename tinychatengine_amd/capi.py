@@ -22,6 +22,7 @@ TCE_W4_SILU_MUL_PAIRS = 8
 TCE_W4_ADD_TO_C = 16
 TCE_PLAN_CHAINED = 1
 TCE_PLAN_TAGGED = 2
+TCE_ABI_VERSION = 107  # include/tce_matmul.h TCE_VERSION: the struct layouts mirrored below
 TCE_PLAN_OVERLAPPED = 4
 TCE_PLAN_TUNED = 8
 TCE_W4_ZERO_POINT_IS_8 = 4
@@ -88,6 +89,10 @@ def lib() -> C.CDLL:
             pass
         L = C.CDLL(LIB_PATH)
         L.tce_version.restype = C.c_int
+        # the descriptors are plain structs without a size field: a library built from another header revision would read the mirrored
+        # structs below at the wrong offsets -- refuse it here, loudly, instead
+        if int(L.tce_version()) != TCE_ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} reports ABI version {int(L.tce_version())}, this wrapper mirrors {TCE_ABI_VERSION} (include/tce_matmul.h: TCE_VERSION): rebuild with `python -m tinychatengine_amd.build`")
         L.tce_last_error.restype = C.c_char_p
         L.tce_build_info.restype = C.c_char_p
         L.tce_w4a16_forward.argtypes = [C.POINTER(W4A16Desc), C.c_void_p]
