@@ -965,7 +965,8 @@ static int tune_plan_launches(const std::vector<tce_w4a16_desc> &descs, const st
     for (int i = 0, off = 0; i < n_launches; off += groups[i], ++i) {
         offs[i] = off;
         const tce_w4a16_desc *d = &descs[off];
-        if (d->M == 1 && !(d->flags & TCE_W4_FORCE_GEMM)) sig[i] = launch_signature(d, groups[i]);
+        // (launches the int8-contraction kernel takes -- packed copies -- have no geometry to choose: a row's arithmetic, the K split included, is fixed by K alone)
+        if (d->M == 1 && !(d->flags & TCE_W4_FORCE_GEMM) && !tce::gemv_i8_supports(d, groups[i], d->rmsnorm_gamma != nullptr)) sig[i] = launch_signature(d, groups[i]);
         size_t need = 0;
         for (int j = 0; j < groups[i]; ++j) need += (((size_t)(d[j].ldc ? d[j].ldc : d[j].N) * d[j].M + 127) & ~(size_t)127) + 128;
         scratch_halves = need > scratch_halves ? need : scratch_halves;
