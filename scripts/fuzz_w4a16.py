@@ -41,7 +41,7 @@ def main():
         while K % 32 or K % G:
             K += G
         N = int(rng.choice([rng.integers(1, 64), rng.integers(64, 1100), rng.integers(1100, 5000)]))
-        M = int(rng.choice([1, 2, 3, 7, 16, 17, 31, 64, 100, 128, 129, 200, 300, 520, 1030]))
+        M = int(rng.choice([1, 1, 2, 3, 4, 7, 16, 17, 31, 64, 100, 128, 129, 200, 300, 520, 1030]))
         if M * N * K > 3e9:
             M = 64
         rz = bool(rng.integers(0, 2))
@@ -79,6 +79,34 @@ def main():
                 bad += 1
                 print(f"FAIL case {case}: M={M} N={N} K={K} G={G} rz={rz} cfg={cfg} mode={mode} add={add} ldc={ldc} worst={worst:.3f} tail_ok={tail_ok}", flush=True)
         capi.set_gemm_config(); capi.check(L.tce_w4a16_set_debug_mode(50))
+        # round 4: the same problem on the packed copy -- M <= 4 runs the int8-contraction GEMV (groups 128 / 64 / 32 by their row limits), M >= 192 the 128-row GEMM
+        need = int(L.tce_w4a16_prepack_bytes(N, K, G)) if K % 128 == 0 else 0
+        if need and (M <= 4 or M >= 192):
+            buf = torch.empty(need + 256, dtype=torch.uint8, device=dev)
+            packed = buf[(-buf.data_ptr()) % 256:][:need]
+            capi.check(L.tce_w4a16_prepack(capi.W4A16Desc(M=1, N=N, K=K, group_size=G, qweight=tq.data_ptr(), scales=ts.data_ptr(), zeros=tz.data_ptr()), packed.data_ptr(), None))
+            add = bool(rng.integers(0, 3) == 0)
+            ldc = N + int(rng.choice([0, 0, 8, 16]))
+            c0 = (torch.randn(M, ldc, device=dev) * 0.25).to(torch.float16)
+            out = c0.clone()
+            flags = (capi.TCE_W4_ADD_TO_C if add else 0) | (0 if rz else capi.TCE_W4_ZERO_POINT_IS_8 * int(rng.integers(0, 2)))
+            d = capi.W4A16Desc(M=M, N=N, K=K, group_size=G, A=ta.data_ptr(), qweight=tq.data_ptr(), scales=ts.data_ptr(), zeros=tz.data_ptr(), C=out.data_ptr(), ldc=ldc,
+                               flags=flags, prepacked=packed.data_ptr())
+            path = capi.describe_dispatch(d)
+            capi.check(capi.w4a16_forward(d, torch.cuda.current_stream().cuda_stream))
+            torch.cuda.synchronize()
+            got = out[:, :N].float().cpu().numpy()
+            want = (c0[:, :N].cpu().numpy().astype(np.float16) + ref32.astype(np.float16)).astype(np.float32) if add else ref32
+            ok, worst = w4a16_close(got.astype(np.float16), want)
+            if not ok and add:
+                err = np.abs(got - want)
+                tol = 1e-3 * np.maximum(np.abs(ref32), np.sqrt(np.mean(ref32.astype(np.float64) ** 2)) / 64) + np.abs(want) * 2.0 ** -10
+                ok = bool((err <= tol).all())
+            tail_ok = ldc == N or torch.equal(out[:, N:], c0[:, N:])
+            packed_runs = packed_runs + 1 if "packed_runs" in dir() else 1
+            if not (ok and tail_ok) or np.isnan(got).any():
+                bad += 1
+                print(f"FAIL case {case} (packed copy, {path}): M={M} N={N} K={K} G={G} rz={rz} add={add} ldc={ldc} flags={flags} worst={worst:.3f} tail_ok={tail_ok}", flush=True)
     print(f"fuzz: {cases} cases, {bad} failures, {time.time() - t0:.0f} s (seed {seed})", flush=True)
     sys.exit(1 if bad else 0)
 
