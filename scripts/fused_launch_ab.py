@@ -23,6 +23,8 @@ def descs(kind):
     return out
 cfgs = {"auto": None, "rowblock_2_4_d2": (2, 4, 1, 2), "rowblock_2_4_d1": (2, 4, 1, 1), "rowblock_4_4_d1": (4, 4, 1, 1), "persistent_2x16_d2": (2, 16, 0, 2), "persistent_4x16_d2": (4, 16, 0, 2),
         "rowblock_4_8_d1": (4, 8, 1, 1), "rowblock_2_8_d2": (2, 8, 1, 2)}
+if os.environ.get("FUSED_AB_I8_TILES"): capi.set_gemv_i8(0, int(os.environ["FUSED_AB_I8_TILES"]))  # (tiles per wave of the int8-MFMA kernel, forced)
+if os.environ.get("FUSED_AB_AUTO_ONLY"): cfgs = {"auto": None}  # (pre-packed weights: the dispatch takes the int8-MFMA kernel, the knobs above do not apply)
 def graph(ds, cfg):
     capi.set_gemv_config(*(cfg or (0, 0, 0, 0)))
     g = torch.cuda.CUDAGraph(); s = torch.cuda.Stream()

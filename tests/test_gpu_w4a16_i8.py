@@ -230,7 +230,8 @@ def test_i8_projection_plus_residual_fused(dev, oracle, M, N, K):
     assert torch.equal(got, res + y)  # hadd of two halves: torch's fp16 add rounds the same way
 
 
-@pytest.mark.parametrize("Ns,K,pairs", [([4096, 1024, 1024], 4096, False), ([520, 264], 11008, False), ([72], 1408, False), ([2752], 4096, True), ([1024], 14336, False)])
+@pytest.mark.parametrize("Ns,K,pairs", [([4096, 1024, 1024], 4096, False), ([520, 264], 11008, False), ([72], 1408, False), ([2752], 4096, True), ([1024], 14336, False),
+                                          ([11008, 11008], 4096, False), ([22016], 4096, True), ([16400], 4096, False)])  # (>= 1024 tiles: two tiles per wave, an odd tile count)
 def test_i8_rmsnorm_prologue_fused(dev, oracle, Ns, K, pairs):
     """The fused RMSNorm prologue in this kernel (input_layernorm + q/k/v, post_attention_layernorm + gate/up, Int4llamaDecoderLayer.cu:78, 92-99): the same rs bits
     as tce_rmsnorm_half (the shape-independent order of tce_common.hpp), the same normalised halves, hence outputs bit-identical to the two-launch form -- on

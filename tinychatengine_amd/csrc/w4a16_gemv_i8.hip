@@ -177,12 +177,19 @@ __global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const I8Args args) 
         // (the order's sixteen terms per lane; the terms past the row's pieces are zeros: only the first ceil(pieces / 64) are read -- 8 for K = 4096)
         float tot = 0.f;
         const int nc = pieces >= 1024 ? 16 : (pieces + 63) >> 6;
-        for (int c = 0; c < nc; ++c) {
-            const int q = c * 64 + lane;
-            float slot = 0.f;
-            slot += q < pieces ? slots[q] : 0.f;
-            if (q + 1024 < pieces) slot += slots[q + 1024];
-            tot += slot;
+        if (pieces <= 1024 && (pieces & 63) == 0) {
+            // whole 64-piece terms, no second piece per slot (K = 4096: 8 reads at fixed offsets and 8 adds; the same sum, without the bounds arithmetic of the
+            // general form below -- measured 0.25 / 0.65 us per launch on norm + q/k/v and norm + gate/up of a 4096-wide layer)
+            const float *sl = slots + lane;
+            for (int c = 0; c < nc; ++c) tot += sl[c * 64];
+        } else {
+            for (int c = 0; c < nc; ++c) {
+                const int q = c * 64 + lane;
+                float slot = 0.f;
+                slot += q < pieces ? slots[q] : 0.f;
+                if (q + 1024 < pieces) slot += slots[q + 1024];
+                tot += slot;
+            }
         }
         tot = wave_sum_dpp_lane63(tot);
         tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), 63));
@@ -521,9 +528,13 @@ int launch_w4a16_gemv_i8(const tce_w4a16_desc *descs, int count, hipStream_t str
     const int m_blocks = (d0.M + mb - 1) / mb;
     // tiles per wave: one.  Two (the conversion of x amortised over twice the bytes, one generation of workgroups for the gate+up launch) measured slower on every
     // launch of the token (profiles/r4/gemv_i8_ab.jsonl: qkv 6.6 -> 7.4 us, o 3.9 -> 4.5, gate+up 9.9 -> 10.2, down a tie); compiled, forceable (tce_w4a16_set_gemv_i8)
+    // With the RMSNorm prologue -- x, gamma, the piece sums and the normalisation on top of the conversion, all per wave -- two tiles per wave win on the wide launch:
+    // norm + gate/up of a 4096 x 11008 layer 11.84 -> 11.31 us; norm + q/k/v (768 tiles) 7.7 -> 8.3, so only from 1024 tiles on.  (The tile count per wave does not
+    // enter the arithmetic: same bits.)
     int rows = 1;
-    (void)total_tiles;
-    if (g_i8_rows && mb == 1 && gpu == 1 && uw == 8 && wk <= 8) rows = g_i8_rows;
+    const bool two_ok = mb == 1 && gpu == 1 && uw == 8 && wk <= 8;
+    if (gamma && two_ok && total_tiles >= 1024) rows = 2;
+    if (g_i8_rows && two_ok) rows = g_i8_rows;
     int blocks = 0;
     for (int i = 0; i < count; ++i) {
         const tce_w4a16_desc &d = descs[i];
@@ -560,7 +571,8 @@ int launch_w4a16_gemv_i8(const tce_w4a16_desc *descs, int count, hipStream_t str
     }
     if (gamma) {
         if (mb != 1 || gpu != 1 || uw != 8) return TCE_ERR_UNSUPPORTED_SHAPE;
-        e = z8 ? launch_i8<1, 1, 1, 8, true, 1024, true>(a, blocks, m_blocks, wk, stream) : launch_i8<1, 1, 1, 8, false, 1024, true>(a, blocks, m_blocks, wk, stream);
+        if (rows == 2) e = z8 ? launch_i8<1, 1, 2, 8, true, 512, true>(a, blocks, m_blocks, wk, stream) : launch_i8<1, 1, 2, 8, false, 512, true>(a, blocks, m_blocks, wk, stream);
+        else e = z8 ? launch_i8<1, 1, 1, 8, true, 1024, true>(a, blocks, m_blocks, wk, stream) : launch_i8<1, 1, 1, 8, false, 1024, true>(a, blocks, m_blocks, wk, stream);
         if (e != hipSuccess) {
             if (hip_err) *hip_err = e;
             return TCE_ERR_HIP;
