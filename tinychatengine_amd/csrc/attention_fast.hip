@@ -125,6 +125,9 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fast_kernel(const FastAtt
         }
     };
     fetch(kbuf[0], vbuf[0], mbuf[0], 0);  // (the row at index pos may not be in the cache yet: consume() takes it from LDS)
+    // (Round 4, tried: the SECOND block requested here too, so that a wave's first 32 keys cost one memory round trip instead of two.  Slower at every context --
+    // 7.5 -> 8.0 us at 512 keys, 9.3 -> 9.9 at 1024, same-session A/B with scripts/probes/attn_quick.py: loads return in order, so q / cos / sin below, which every
+    // wave needs before its first score, then wait behind twice the cache rows.)
     __builtin_amdgcn_sched_barrier(0);
     // ---- every piece the prologue needs, requested together behind them: q, k (with their partner halves), v, cos, sin.  All four
     //      waves fetch the k / v pieces (L2 hits, 3 instructions) so that nobody waits for a second batch; wave 0 uses them ----
