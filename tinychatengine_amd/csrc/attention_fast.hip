@@ -101,8 +101,9 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fast_kernel(const FastAtt
     const half_t *cosr = a.cosv ? a.cosv + (size_t)pos * kHD : nullptr, *sinr = a.sinv ? a.sinv + (size_t)pos * kHD : nullptr;
     const size_t hoff = (size_t)head * kHD;
     // ---- this wave's keys: chunk / 4 consecutive ones, 4 per step.  Their addresses depend on nothing but the arguments, so the
-    //      first block of cache rows is requested BEFORE q / cos / sin: one memory round trip per launch instead of two (the
-    //      same rule as the GEMV's "weights right behind x") ----
+    //      first block of cache rows is requested in the same batch as q / cos / sin: one memory round trip per launch instead of
+    //      two -- and BEHIND them (round 4): loads return in order, the prologue's pieces are L2 hits, and with the cache rows in
+    //      front of them the rotation waited for HBM (4.95 -> 4.5 us at 128 keys, 7.8 -> 7.5 at 512, 10.2 -> 9.8 at 2048) ----
     const int per_wave = a.chunk / NW;  // (the host made the chunk a multiple of 4 * NW)
     const int kw0 = key0 + wave * per_wave;
     const int kw1 = kw0 + per_wave < key1 ? kw0 + per_wave : key1;  // a block is 16 keys, a wave's run any multiple of 4: the rest weighs nothing
@@ -124,12 +125,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fast_kernel(const FastAtt
             else md[u] = (half_t)0;
         }
     };
-    fetch(kbuf[0], vbuf[0], mbuf[0], 0);  // (the row at index pos may not be in the cache yet: consume() takes it from LDS)
-    // (Round 4, tried: the SECOND block requested here too, so that a wave's first 32 keys cost one memory round trip instead of two.  Slower at every context --
-    // 7.5 -> 8.0 us at 512 keys, 9.3 -> 9.9 at 1024, same-session A/B with scripts/probes/attn_quick.py: loads return in order, so q / cos / sin below, which every
-    // wave needs before its first score, then wait behind twice the cache rows.)
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- every piece the prologue needs, requested together behind them: q, k (with their partner halves), v, cos, sin.  All four
+    // ---- every piece the prologue needs, requested together: q, k (with their partner halves), v, cos, sin.  All four
     //      waves fetch the k / v pieces (L2 hits, 3 instructions) so that nobody waits for a second batch; wave 0 uses them ----
     const bool rope = cosr != nullptr;
     const half_t *xq = a.qkv + (size_t)grp * R * kHD, *xk = a.qkv + (size_t)a.heads * kHD + hoff, *xv = a.qkv + (size_t)(a.heads + a.kv_heads) * kHD + hoff;
@@ -143,6 +139,10 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fast_kernel(const FastAtt
     }
     const half8_t cc = ld8(cp + piece * 8), ss = ld8(sp + piece * 8);
     const half8_t k_v = ld8(xk + piece * 8), k_p = ld8(xk + (piece ^ 8) * 8), v_v = ld8(xv + piece * 8);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(kbuf[0], vbuf[0], mbuf[0], 0);  // (the row at index pos may not be in the cache yet: consume() takes it from LDS)
+    // (Round 4, tried: the SECOND block requested here too, so that a wave's first 32 keys cost one memory round trip instead of two.  Slower at every context, in
+    // front of the prologue's loads or behind them -- 7.2 -> 7.7 us at 512 keys, 9.05 -> 9.6 at 1024; same-session A/B with scripts/probes/attn_quick.py.)
     __builtin_amdgcn_sched_barrier(0);
     // ---- the R query heads (rotated), this lane's 8 dimensions of each ----
     half8_t qh[R];
