@@ -56,6 +56,18 @@ __device__ __forceinline__ float row16_sum(float v) {  // sum over the 16 lanes 
     return v;
 }
 
+// acc + p * (the low / high binary16 half of `pair`, widened exactly): one v_fma_mix_f32, no separate conversion
+__device__ __forceinline__ float fma_mix_lo(float p, unsigned pair, float acc) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(d) : "v"(p), "v"(pair), "v"(acc));
+    return d;
+}
+__device__ __forceinline__ float fma_mix_hi(float p, unsigned pair, float acc) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(d) : "v"(p), "v"(pair), "v"(acc));
+    return d;
+}
+
 // RotaryPosEmb_cuda_forward on the 8 elements of `piece` (hd = 128: the partner half is piece ^ 8):
 //   out[j] = hfma(x[j], cos[j], hmul(rot[j], sin[j])),  rot[j] = j < hd/2 ? -x[j + hd/2] : x[j - hd/2]
 // v = the piece, p = the partner piece, c / s = the cos / sin pieces (all loaded by the caller, in one batch)
@@ -142,7 +154,9 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fast_kernel(const FastAtt
     __builtin_amdgcn_sched_barrier(0);
     fetch(kbuf[0], vbuf[0], mbuf[0], 0);  // (the row at index pos may not be in the cache yet: consume() takes it from LDS)
     // (Round 4, tried: the SECOND block requested here too, so that a wave's first 32 keys cost one memory round trip instead of two.  Slower at every context, in
-    // front of the prologue's loads or behind them -- 7.2 -> 7.7 us at 512 keys, 9.05 -> 9.6 at 1024; same-session A/B with scripts/probes/attn_quick.py.)
+    // front of the prologue's loads or behind them -- 7.2 -> 7.7 us at 512 keys, 9.05 -> 9.6 at 1024; and again after consume() was made cheaper, as a ring of three
+    // buffers with two blocks in flight: 4.35 -> 4.67 us at 128 keys, 7.2 -> 7.55 at 512, a tie on 256-key-per-wave runs.  Same-session A/Bs with
+    // scripts/probes/attn_quick.py, profiles/r4/attention_block_softmax_ab.jsonl.)
     __builtin_amdgcn_sched_barrier(0);
     // ---- the R query heads (rotated), this lane's 8 dimensions of each ----
     half8_t qh[R];
@@ -170,38 +184,72 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fast_kernel(const FastAtt
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[r][e] = 0.f;
     }
+    // One block = 4 steps = 16 keys of the wave.  The online-softmax state moves ONCE per block (round 4): the block's scores first, one new maximum, one rescale
+    // of the accumulators, then the four weighted value rows as fused multiply-adds that take the binary16 value straight from its register (v_fma_mix_f32).  The
+    // step-by-step form this replaces -- a rescale, two exponentials and 8 conversions per step -- was bound by exactly that arithmetic: 58 vector instructions per
+    // step, one wave per SIMD, 0.62 us per block against a memory round trip of about the same length (profiles/r4/attention_block_softmax_ab.jsonl).
     auto consume = [&](const half8_t (&kd)[BLK], const half8_t (&vd)[BLK], const half_t (&md)[BLK], int it0) {
+        half8_t kk[BLK], vv[BLK];
+        float sco[R][BLK];
+        bool valid[BLK];
 #pragma unroll
         for (int u = 0; u < BLK; ++u) {
-            const int key = kw0 + it0 + u * 4 + slot;
-            const bool valid = key < kw1;
-            half8_t kv = kd[u], vv = vd[u];
-            if (key == pos) {  // the token's own row: not necessarily visible in the cache yet
-                kv = *reinterpret_cast<const half8_t *>(&newrow[0][piece * 8]);
-                vv = *reinterpret_cast<const half8_t *>(&newrow[1][piece * 8]);
-            }
-            // a slot past the range was loaded from a row that may hold anything (the row at `pos` before this launch wrote it, an
-            // uninitialised cache): its weight is 0, and 0 * inf would still be NaN -- the value row is zeroed, not just weighted
-            if (!valid) vv = half8_t{(half_t)0, (half_t)0, (half_t)0, (half_t)0, (half_t)0, (half_t)0, (half_t)0, (half_t)0};
-            float vf[8];
+            kk[u] = kd[u];
+            vv[u] = vd[u];
+            valid[u] = true;
+        }
+        // the rare blocks -- the one that runs past the wave's range, the one that holds the token's own row -- are told apart by a wave-uniform test, so the
+        // others carry no per-slot validity arithmetic at all
+        const int b0 = kw0 + it0;
+        if (b0 + BLK * 4 > kw1 || (pos >= b0 && pos < b0 + BLK * 4)) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) vf[e] = (float)vv[e];
+            for (int u = 0; u < BLK; ++u) {
+                const int key = b0 + u * 4 + slot;
+                valid[u] = key < kw1;
+                if (key == pos) {  // the token's own row: not necessarily visible in the cache yet
+                    kk[u] = *reinterpret_cast<const half8_t *>(&newrow[0][piece * 8]);
+                    vv[u] = *reinterpret_cast<const half8_t *>(&newrow[1][piece * 8]);
+                }
+                // a slot past the range was loaded from a row that may hold anything (the row at `pos` before this launch wrote it, an
+                // uninitialised cache): its weight is 0, and 0 * inf would still be NaN -- the value row is zeroed, not just weighted
+                if (!valid[u]) vv[u] = half8_t{(half_t)0, (half_t)0, (half_t)0, (half_t)0, (half_t)0, (half_t)0, (half_t)0, (half_t)0};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < BLK; ++u) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 float d = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; e += 2) d = __builtin_amdgcn_fdot2(half2_t{qh[r][e], qh[r][e + 1]}, half2_t{kv[e], kv[e + 1]}, d, false);
+                for (int e = 0; e < 8; e += 2) d = __builtin_amdgcn_fdot2(half2_t{qh[r][e], qh[r][e + 1]}, half2_t{kk[u][e], kk[u][e + 1]}, d, false);
                 d = row16_sum(d);
-                float s = a.alpha * d;
-                if constexpr (MASK) s += (float)md[u];
-                if (!(__builtin_fabsf(s) <= 65504.0f)) s = -65504.0f;  // check_inf_half (Int4llamaAttention.cu:105-115): inf / nan / beyond binary16 -> -65504
-                if (!valid) s = kNegBig;
-                const float mn = __builtin_fmaxf(m[r], s);
-                const float sc = __expf(m[r] - mn), p = valid ? __expf(s - mn) : 0.f;
-                m[r] = mn;
-                l[r] = l[r] * sc + p;
+                float sv = a.alpha * d;
+                if constexpr (MASK) sv += (float)md[u];
+                if (!(__builtin_fabsf(sv) <= 65504.0f)) sv = -65504.0f;  // check_inf_half (Int4llamaAttention.cu:105-115): inf / nan / beyond binary16 -> -65504
+                if (!valid[u]) sv = kNegBig;
+                sco[r][u] = sv;
+            }
+        }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[r][e] = acc[r][e] * sc + p * vf[e];
+        for (int r = 0; r < R; ++r) {
+            const float bm = __builtin_fmaxf(__builtin_fmaxf(sco[r][0], sco[r][1]), __builtin_fmaxf(sco[r][2], sco[r][3]));
+            const float mn = __builtin_fmaxf(m[r], bm);
+            const float sc = __expf(m[r] - mn);
+            float p[BLK];
+#pragma unroll
+            for (int u = 0; u < BLK; ++u) p[u] = valid[u] ? __expf(sco[r][u] - mn) : 0.f;  // (a block of nothing but invalid slots on a fresh state: mn == kNegBig, the difference is 0)
+            m[r] = mn;
+            l[r] = l[r] * sc + ((p[0] + p[1]) + (p[2] + p[3]));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[r][e] *= sc;
+#pragma unroll
+            for (int u = 0; u < BLK; ++u) {
+                const uint4_t vw = __builtin_bit_cast(uint4_t, vv[u]);
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    acc[r][e] = fma_mix_lo(p[u], vw[e >> 1], acc[r][e]);
+                    acc[r][e + 1] = fma_mix_hi(p[u], vw[e >> 1], acc[r][e + 1]);
+                }
             }
         }
     };
