@@ -149,7 +149,7 @@ def _attention_reference_f64(q_rot, K, V, alpha, mask):
 @pytest.mark.parametrize("heads,max_keys,steps,start,cut", [(32, 64, 40, 0, 0), (8, 2048, 3, 2045, 0), (8, 2048, 3, 2045, 1024), (32, 2048, 2, 1000, 0),
                                                              (4, 300, 5, 250, 0), (32, 700, 3, 600, 0), (4, 300, 3, 100, 64)])
 def test_attention_decode_step_against_float64_and_the_binary16_chain_kernel(dev, oracle, heads, max_keys, steps, start, cut):
-    """cut = 0: the fitted rule picks the chunks (one per head up to 320 keys, four up to 1024, eight beyond); otherwise the key range is cut
+    """cut = 0: the fitted rule picks the chunks (one per head up to 320 keys, four up to 640, eight beyond); otherwise the key range is cut
     for that many workgroups (8 heads, 1024 workgroups: 32 chunks, the combine's one-by-one tail past 16 chunks)."""
     from tinychatengine_amd.attention_ops import DecodeAttention, attention_decode
     from tinychatengine_amd import capi

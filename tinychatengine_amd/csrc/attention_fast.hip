@@ -378,7 +378,7 @@ void set_attention_fast_target(int wgs) { g_attn_target_wgs = wgs >= 32 && wgs <
 //   128 keys: one chunk 4.5 us, two 6.0          256: one chunk 6.5, two or four 7.0        512: 8.9 / 8.6 / 7.6 / 8.5 for 1 / 2 / 4 / 8 chunks
 //   1024: 9.0 with 4 chunks, 9.3 with 8, 12.5 with 16      2048: 12.0 / 11.8 / 13.7 with 4 / 8 / 16      4096: 18.6 / 16.7 / 18.3
 //   8192: 30.0 / 28.9 / 33.4 with 8 / 16 / 32
-// Rule: up to 320 keys one chunk per head and no combine; up to 1024 four chunks; beyond, eight chunks of at most 512 keys.
+// Rule: up to 320 keys one chunk per head and no combine; up to 640 four chunks (1024 until round 4); beyond, eight chunks of at most 512 keys.
 // A combine without the acknowledged-store -> counter -> coherent-read chain (the head's last workgroup polling (value, tag) pairs)
 // was tried and was SLOWER (13.2 us at 2048 keys): a poll is a full memory round trip, and the chain it replaces is three of them
 // only on the LAST workgroup.  So was the hybrid -- (value, tag) pairs stored without waiting for acknowledgements, the counter only
@@ -401,7 +401,7 @@ static void pick_chunk(int heads, int keys, int *chunk_out, int *waves_out) {
         if (chunk < 64) chunk = 64;
     } else if (keys <= 320) {
         chunk = keys;
-    } else if (keys <= 1024) {
+    } else if (keys <= 640) {  // (round 4, after the block softmax: 1024 keys 8.7 us with four chunks, 8.2 with eight; 512 keys 7.25 / 7.45)
         chunk = (keys + 3) >> 2;
     } else {
         chunk = (keys + 7) >> 3;
