@@ -8,8 +8,10 @@ from tinychatengine_amd import capi
 from tinychatengine_amd.decoder_block import DecoderBlock
 dev = torch.device("cuda:0"); L = capi.lib()
 hidden, heads, ffn = 4096, 32, 11008
+kvh = None
+if os.environ.get("FUSED_AB_SHAPES") == "llama3-8b": ffn, kvh = 14336, 8  # (default: the 7B-shaped layer BASELINE.json spells)
 cos = torch.zeros(64, 128, dtype=torch.float16, device=dev); sin = torch.zeros_like(cos)
-blocks = [DecoderBlock(hidden, heads, ffn, 64, dev, cos, sin, seed=i) for i in range(32)]
+blocks = [DecoderBlock(hidden, heads, ffn, 64, dev, cos, sin, seed=i, kv_heads=kvh) for i in range(32)]
 hid = torch.randn(1, hidden, device=dev).to(torch.float16)
 def descs(kind):
     out = []
