@@ -259,6 +259,16 @@ __global__ __launch_bounds__(MAXT) void i8_gemv2(const Args a) {
     const int U = a.U;
     unsigned long long ts[5] = {0, 0, 0, 0, 0};
     if constexpr (MODE == 2) ts[0] = wall_clock64();
+    if constexpr (MODE == 5) {  // the launch alone: the same grid, workgroup shape and LDS allocation, no work
+        if (a.U < 0) a.y[tid] = (half_t)0;
+        return;
+    }
+    if constexpr (MODE == 6) {  // the launch + one L2 round trip per wave (x) + one 2-byte store per tile
+        const __amdgpu_buffer_rsrc_t rs_x0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(a.x), 0, a.K * 2, 0x00020000);
+        const uint4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs_x0, lane * 16, u0 * 256, 0);
+        if (tid == 0) a.y[tile0 * 16] = __builtin_bit_cast(half_t, (unsigned short)(v[0] & 0xFFFFu));
+        return;
+    }
 
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.w), 0, a.bytes_w, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(a.sc), 0, a.bytes_s, 0x00020000);
@@ -559,7 +569,7 @@ static void run(const char *name, int N, int K, int NB, std::vector<void *> &dw,
     const double bytes = (double)N * K / 2 + (double)N * U * 2 + 2.0 * K + 2.0 * N;
     printf("{\"variant\": \"%s\", \"N\": %d, \"K\": %d, \"rows_tiles\": %d, \"units_per_wave\": %d, \"layout\": \"%s\", \"mode\": \"%s\", \"waves_per_wg\": %d, \"grid\": %d, "
            "\"us_min\": %.2f, \"us_median\": %.2f, \"TBps_median\": %.3f, \"frac_of_8TBps\": %.3f, \"worst_err_over_tol\": %.3f}\n",
-           name, N, K, ROWS, UW, LAYOUT == 0 ? "tile16" : (LAYOUT == 2 ? "tile16 v2" : "q4_6"), MODE == 0 ? "gemv" : (MODE == 1 ? "stream-only" : (MODE == 2 ? "gemv + timestamps" : (MODE == 3 ? "no conversion" : "no mfma"))), WK, grid, best, med, bytes / med * 1e-6, bytes / med * 1e-6 / 8.0, worst);
+           name, N, K, ROWS, UW, LAYOUT == 0 ? "tile16" : (LAYOUT == 2 ? "tile16 v2" : "q4_6"), MODE == 0 ? "gemv" : (MODE == 1 ? "stream-only" : (MODE == 2 ? "gemv + timestamps" : (MODE == 3 ? "no conversion" : (MODE == 4 ? "no mfma" : (MODE == 5 ? "launch only" : "launch + x round trip"))))), WK, grid, best, med, bytes / med * 1e-6, bytes / med * 1e-6 / 8.0, worst);
     fflush(stdout);
     }
 }
@@ -628,6 +638,11 @@ int main(int argc, char **argv) {
         CK(hipMemcpy(dx, x.data(), K * 2, hipMemcpyHostToDevice));
         const int reps = 15;
 #define RUN(R, UWV, L, M) run<R, UWV, L, M>(sh.name, N, K, NB, (L) != 1 ? dw0 : dw1, (L) != 1 ? ds0 : ds1, dx, dy, &ref, reps)
+        RUN(1, 8, 2, 5);
+        RUN(1, 8, 2, 6);
+        RUN(1, 8, 2, 1);
+        RUN(1, 8, 2, 0);
+        if (getenv("PROBE_LAUNCH_ONLY")) continue;
         RUN(1, 4, 0, 1);
         RUN(1, 4, 2, 0);
         RUN(2, 4, 2, 0);
