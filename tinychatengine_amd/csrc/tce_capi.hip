@@ -162,6 +162,10 @@ int tce_w4a16_set_debug_mode(int mode) {
         tce::set_w8a8_big(mode == 78 ? 9 : (mode >= 176 ? mode - 173 : mode - 75));
         return TCE_OK;
     }
+    if (mode == 170 || mode == 171 || mode == 172 || mode == 174 || mode == 179) {  // W8A8, the 64 x 64 tile with 8 k-steps in flight: 170 the rule, 171 / 172 / 174 forced with 1 / 2 / 4 quartets, 179 off
+        tce::set_w8a8_deep(mode - 170);
+        return TCE_OK;
+    }
     if (mode >= 70 && mode <= 74) {  // W8A8: wave quartets per tile (70 automatic; 73: automatic, without the decode-sized wave-per-column kernels)
         tce::set_w8a8_ksplit(mode - 70);
         return TCE_OK;

@@ -50,6 +50,7 @@ struct GemvArgs {
 bool gemv_variant_exists(int rows, int wn, int wk, int depth);
 void set_gemv_debug_mode(int mode);
 void set_gemv_order(int force);
+void set_w8a8_deep(int d);          // W8A8 64 x 64 tile with 8 k-steps in flight: 0 the rule, 1 / 2 / 4 quartets forced, 9 off
 void set_w8a8_big(int b);           // W8A8 128-row tiles: 0 the rule, 1 / 2 forced (128 / 64 columns), 9 off
 void set_lnq_stamps(void *p);
 void set_lnq_form(int f);           // 1: the workgroup-per-8-rows form of the LayerNormQ + W8A8 launch at every k

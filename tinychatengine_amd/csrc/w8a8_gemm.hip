@@ -160,9 +160,11 @@ __global__ __launch_bounds__(256 * KS) void w8a8_mfma_kernel(const W8A8Args a) {
         load_raw(ra0, rb0, k_begin);
         for (int k0 = k_begin; k0 < k_end; k0 += 128) {
             load_raw(ra1, rb1, k0 + 64 <= k_last ? k0 + 64 : k_last);
+            __builtin_amdgcn_sched_barrier(0);  // (without it the scheduler sinks these loads to their use and both "sets" share registers: no load is in flight during a contraction)
             contract(ra0, rb0);
             if (k0 + 64 < k_end) {
                 load_raw(ra0, rb0, k0 + 128 <= k_last ? k0 + 128 : k_last);
+                __builtin_amdgcn_sched_barrier(0);
                 contract(ra1, rb1);
             }
         }
@@ -217,6 +219,126 @@ __global__ __launch_bounds__(256 * KS) void w8a8_mfma_kernel(const W8A8Args a) {
             for (int r = 0; r < 4; ++r) {
                 const int m = m_base + i * 16 + kq * 4 + r;
                 if (m < a.M && n < a.N) epilogue_store(a, Cb, m, n, acc[i][j][r], bterm[j]);
+            }
+        }
+}
+
+// The same 64 x 64 tile for launches whose k chain is long and whose tiles are few (OPT-125M's 512 x 768 x 3072 is 96 tiles of 48 k-steps): the kernel above keeps ONE
+// k-step of loads in flight per wave, and a step is 4 MFMAs -- 64 cycles of work against a memory round trip of ~1500 -- so the chain runs at memory LATENCY
+// (0.3 us per step).  Here a quartet stages its panels cooperatively (a k-step is 64 + 64 rows of 64 bytes = ONE 16-byte piece of A and one of B per thread, half
+// of what four waves fetching their own fragments move) and keeps P steps in flight in registers (P x 8 registers), written to a double-buffered LDS stage in
+// the slot order of the kernel above one step ahead of the contraction; one LDS-only barrier per step (the requests stay in flight).  Requests past the end
+// are clamped re-reads, so every wave issues the same loads and the wait counts are exact.  int32 sums: bit-exact in any order, like every other path.
+template <int KS, int P>
+__global__ __launch_bounds__(256 * KS) void w8a8_mfma_deep_kernel(const W8A8Args a) {
+    constexpr int STAGE_SLOTS = 512;  // A: 64 rows x 4 | B: 64 rows x 4 (16-byte slots)
+    extern __shared__ __attribute__((aligned(16))) int4_t lds_deep[];  // [KS quartets][2 stages][512 slots]
+    const int lane = threadIdx.x & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = wave8 & 3, grp = wave8 >> 2;
+    const int tid = threadIdx.x & 255;  // within the quartet
+    int4_t *ring = lds_deep + grp * (2 * STAGE_SLOTS);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int batch = blockIdx.z;
+    const int8_t *A = a.A + (size_t)batch * a.strideA;
+    const int8_t *B = a.B + (size_t)batch * a.strideB;
+    const size_t c_off = (size_t)batch * a.strideC;
+    void *Cb = a.out_kind == TCE_OUT_INT8 ? static_cast<void *>(static_cast<int8_t *>(a.C) + c_off) : static_cast<void *>(static_cast<float *>(a.C) + c_off);
+    const int m_tile = blockIdx.y * 64, n_tile = blockIdx.x * 64;
+    const int lrow = tid >> 2, lchunk = tid & 3;
+    int m = m_tile + lrow, n = n_tile + lrow;
+    m = m < a.M ? m : a.M - 1;
+    n = n < a.N ? n : a.N - 1;
+    const int8_t *pa = A + (size_t)m * a.lda + lchunk * 16, *pb = B + (size_t)n * a.ldb + lchunk * 16;
+    const int wslot = lrow * 4 + (lchunk ^ ((lrow >> 2) & 3));
+    const int rslot = r16 * 4 + (kq ^ ((r16 >> 2) & 3));
+    const int fa0 = (wm * 32) * 4 + rslot, fb0 = 256 + (wn * 32) * 4 + rslot;
+    int4_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = int4_t{0, 0, 0, 0};
+    const int Tall = a.K >> 6;                  // K % 64 == 0 (the host's condition)
+    const int Tmax = (Tall + KS - 1) / KS;      // every wave passes Tmax barriers
+    const int t_begin = grp * Tmax < Tall ? grp * Tmax : Tall;
+    const int T = (t_begin + Tmax < Tall ? t_begin + Tmax : Tall) - t_begin;  // this quartet's k-steps (the last quartet's may be fewer, or none)
+    const int t_last = T > 0 ? t_begin + T - 1 : 0;
+    int4_t ra[P], rb[P];
+    auto request = [&](int u, int t) {  // step t of this quartet (clamped: a re-read of its last step)
+        const int tt = t_begin + t <= t_last ? t_begin + t : t_last;
+        ra[u] = *reinterpret_cast<const int4_t *>(pa + (size_t)tt * 64);
+        rb[u] = *reinterpret_cast<const int4_t *>(pb + (size_t)tt * 64);
+    };
+#pragma unroll
+    for (int u = 0; u < P; ++u) request(u, u);
+    __builtin_amdgcn_sched_barrier(0);
+    // (the body covers three rounds of the register ring: hipcc's wait-count pass answers the loop HEADER with vmcnt(0) -- a drained pipeline once per body)
+    constexpr int BODY = 3 * P;
+    for (int t0 = 0; t0 < Tmax; t0 += BODY) {
+#pragma unroll
+        for (int v = 0; v < BODY; ++v) {
+            const int u = v % P;
+            const int t = t0 + v;
+            if (t >= Tmax) break;
+            int4_t *stage = ring + (t & 1) * STAGE_SLOTS;
+            stage[wslot] = ra[u];
+            stage[256 + wslot] = rb[u];
+            __builtin_amdgcn_sched_barrier(0);
+            request(u, t + P);
+            __builtin_amdgcn_sched_barrier(0);
+            lds_barrier();
+            if (t < T) {
+                int4_t fa[2], fb[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    fa[i] = stage[fa0 + i * 64];
+                    fb[i] = stage[fb0 + i * 64];
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    if constexpr (KS > 1) {  // quartets 1.. hand their int32 tiles to quartet 0: [quartet - 1][register][thread of the quartet]
+        lds_barrier();       // every wave is done with the stages
+        int4_t *red = lds_deep;
+        if (grp > 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) red[((grp - 1) * 4 + i * 2 + j) * 256 + tid] = acc[i][j];
+        }
+        lds_barrier();
+        if (grp > 0) return;
+        for (int g2 = 0; g2 < KS - 1; ++g2)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int4_t o = red[(g2 * 4 + i * 2 + j) * 256 + tid];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] += o[r];
+                }
+    }
+    const int m_base = m_tile + wm * 32, n_base = n_tile + wn * 32;
+    float bterm[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int nn = n_base + j * 16 + r16;
+        bterm[j] = bias_term(a, nn < a.N ? nn : a.N - 1);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int nn = n_base + j * 16 + r16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mm = m_base + i * 16 + kq * 4 + r;
+                if (mm < a.M && nn < a.N) epilogue_store(a, Cb, mm, nn, acc[i][j][r], bterm[j]);
             }
         }
 }
@@ -508,8 +630,10 @@ int g_w8a8_ks = 0;  // forced K split (tuning), 0 = automatic; 3: the decode-siz
 }  // namespace
 
 void set_w8a8_ksplit(int ks) { g_w8a8_ks = (ks >= 1 && ks <= 4) ? ks : 0; }
+int g_w8a8_deep = 0;  // the 64 x 64 tile with 8 k-steps in flight: 0 the rule, 1 / 2 / 4 forced with that many quartets, 9 off (A/B)
 int g_w8a8_big = 0;  // the 128-row tiles: 0 the rule, 1 / 2 forced with 128 / 64 columns (one quartet), 3 / 4 the same with two quartets, 9 off (A/B)
 void set_w8a8_big(int b) { g_w8a8_big = b; }
+void set_w8a8_deep(int d) { g_w8a8_deep = d; }
 
 int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err) {
     W8A8Args a{};
@@ -583,6 +707,19 @@ int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err)
             if (tiles < 512 && d.K / 64 >= 4) ks = 2;  // four quartets measured no better than two (profiles/r1/w8a8_ksplit_sweep.jsonl)
         }
         const size_t lds = (size_t)ks * 4 * 4 * 64 * 16;  // transpose slots; the reduction ((ks - 1) * 16 KiB) reuses them
+        // long k chains on few tiles: the cooperative panels with 8 k-steps in flight (w8a8_mfma_deep_kernel)
+        // Measured (scripts/probes/w8a8_small_ab.py, same-session A/B, weights rotating through HBM): it wins where the chain is 128 steps long -- 512 / 108 / 16 x 2048 x 8192:
+        // 35.9 -> 32.5 / 31.3 -> 24.7 / 30.3 -> 21.9 us -- and LOSES at 48 and 32 steps (512 x 768 x 3072: 13.6 -> 14.8; 512 x 2048 x 2048: 10.5 -> 12.9): those launches do
+        // not depend on the quartet count in either kernel (one / two / four: 15.1 / 13.2 / 12.8 us), i.e. not on the chain -- 96 workgroups pull 0.4-0.8 MB each through
+        // their own CU's L1, and spreading that over more CUs needs a reduction across workgroups, which costs a launch boundary.
+        const bool deep = g_w8a8_deep != 9 && d.K % 64 == 0 && (g_w8a8_deep > 0 || (tiles < 512 && d.K / 64 >= 64));
+        if (deep) {
+            const int dks = g_w8a8_deep == 1 || g_w8a8_deep == 2 || g_w8a8_deep == 4 ? g_w8a8_deep : (d.K / 64 >= 32 && tiles <= 256 ? 4 : 2);
+            const size_t dl = (size_t)dks * 2 * 512 * 16;  // (>= the reduction's (dks - 1) * 16 KiB)
+            if (dks == 4) hipLaunchKernelGGL((w8a8_mfma_deep_kernel<4, 8>), grid, dim3(1024), dl, stream, a);
+            else if (dks == 2) hipLaunchKernelGGL((w8a8_mfma_deep_kernel<2, 8>), grid, dim3(512), dl, stream, a);
+            else hipLaunchKernelGGL((w8a8_mfma_deep_kernel<1, 8>), grid, dim3(256), dl, stream, a);
+        } else
         if (ks == 4) hipLaunchKernelGGL(w8a8_mfma_kernel<4>, grid, dim3(1024), lds, stream, a);
         else if (ks == 2) hipLaunchKernelGGL(w8a8_mfma_kernel<2>, grid, dim3(512), lds, stream, a);
         else hipLaunchKernelGGL(w8a8_mfma_kernel<1>, grid, dim3(256), lds, stream, a);
