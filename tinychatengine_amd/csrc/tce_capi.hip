@@ -129,6 +129,7 @@ int tce_w4a16_set_gemv_i8(int mode, int rows) {
     return TCE_OK;
 }
 
+static int g_plan_eager = 0;  // experiment (tce_w4a16_set_debug_mode(15001 / 15000)): stream-ordered plans issue their launches one by one instead of replaying the graph
 int tce_w4a16_set_debug_mode(int mode) {
     if (mode >= 50000 && mode <= 50499) {  // overlapped plans: 50000 + 100 * graph branches (0 = 2) + ring slots per wave (0 = as many as fit, 2..4)
         tce::set_gemv_ovl_config((mode - 50000) % 100, (mode - 50000) / 100);
@@ -164,6 +165,10 @@ int tce_w4a16_set_debug_mode(int mode) {
     }
     if (mode == 170 || mode == 171 || mode == 172 || mode == 174 || mode == 179) {  // W8A8, the 64 x 64 tile with 8 k-steps in flight: 170 the rule, 171 / 172 / 174 forced with 1 / 2 / 4 quartets, 179 off
         tce::set_w8a8_deep(mode - 170);
+        return TCE_OK;
+    }
+    if (mode == 15000 || mode == 15001) {  // experiment: tce_plan_launch issues a stream-ordered plan's launches eagerly (15001) / replays its graph (15000)
+        g_plan_eager = mode - 15000;
         return TCE_OK;
     }
     if (mode >= 70 && mode <= 74) {  // W8A8: wave quartets per tile (70 automatic; 73: automatic, without the decode-sized wave-per-column kernels)
@@ -1208,6 +1213,13 @@ int tce_plan_status(tce_plan *plan) {
 
 int tce_plan_launch(tce_plan *plan, void *stream) {
     if (!plan || !plan->exec) return fail(TCE_ERR_BAD_ARG, "null plan");
+    if (g_plan_eager && !plan->token) {
+        int rc = TCE_OK;
+        const int n_launches = (int)plan->groups.size();
+        for (int i = 0, off = 0; i < n_launches && rc == TCE_OK; off += plan->groups[i], ++i)
+            rc = plan->groups[i] == 1 ? tce_w4a16_forward(&plan->descs[off], stream) : tce_w4a16_forward_group(&plan->descs[off], plan->groups[i], stream);
+        return rc;
+    }
     const hipError_t e = hipGraphLaunch(plan->exec, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? TCE_OK : hip_fail(e, "hipGraphLaunch");
 }
