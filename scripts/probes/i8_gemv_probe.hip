@@ -42,6 +42,7 @@ struct Args {
     const half_t *sc;     // LAYOUT 0: [N/16][U][16]; LAYOUT 1: [N][U]
     const half_t *x;      // [K]
     half_t *y;            // [N]
+    int WN;               // tiles per workgroup side by side (each with its own waves and LDS): PROBE_WN
     int N, K, U;          // U = K / 128
     int bytes_w, bytes_s;
     unsigned long long *dbg;  // MODE 2: 5 timestamps per wave
@@ -247,15 +248,19 @@ __device__ inline unsigned dpp_max_u32(unsigned v) {
 // ---- version 3: v2 + max by DPP, fused convert-multiply, B operands read before the weights arrive, two accumulator chains, unrolled final sum ----
 template <int ROWS, int NP, int MODE, int MAXT>
 __global__ __launch_bounds__(MAXT) void i8_gemv2(const Args a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    unsigned char *smem = smem_all;
     constexpr int UW = 4 * NP;
-    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int WK = (blockDim.x >> 6) / a.WN;
+    const int tn = wv / WK;
+    const int wk = wv - tn * WK;
+    const int tid = threadIdx.x - tn * WK * 64;
     const int lane = tid & 63;
-    const int wk = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int WK = blockDim.x >> 6;
+    smem += (size_t)tn * ((size_t)WK * UW * 512 + (size_t)WK * ROWS * 16 * 4);
     const int u0 = wk * UW;
     const int kq = lane >> 4, j = lane & 15;
-    const int tile0 = blockIdx.x * ROWS;
+    const int tile0 = (blockIdx.x * a.WN + tn) * ROWS;
     const int U = a.U;
     unsigned long long ts[5] = {0, 0, 0, 0, 0};
     if constexpr (MODE == 2) ts[0] = wall_clock64();
@@ -470,6 +475,7 @@ static void run(const char *name, int N, int K, int NB, std::vector<void *> &dw,
     const int U = K / 128;
     const int WK = (U + UW - 1) / UW;
     if constexpr (MAXT == 0) {
+        if (getenv("PROBE_WN") && atoi(getenv("PROBE_WN")) > 1) return run<ROWS, UW, LAYOUT, MODE, 1024>(name, N, K, NB, dw, dsc, dx, dy, ref, reps);
         if (WK * 64 <= 256) return run<ROWS, UW, LAYOUT, MODE, 256>(name, N, K, NB, dw, dsc, dx, dy, ref, reps);
         if (WK * 64 <= 512) return run<ROWS, UW, LAYOUT, MODE, 512>(name, N, K, NB, dw, dsc, dx, dy, ref, reps);
         return run<ROWS, UW, LAYOUT, MODE, 1024>(name, N, K, NB, dw, dsc, dx, dy, ref, reps);
@@ -486,8 +492,11 @@ static void run(const char *name, int N, int K, int NB, std::vector<void *> &dw,
     a.U = U;
     a.bytes_w = (int)((size_t)N * K / 2);
     a.bytes_s = N * U * 2;
-    const int grid = (N / 16 + ROWS - 1) / ROWS;
-    const size_t lds = (size_t)WK * UW * 512 + (size_t)WK * ROWS * 16 * 4;
+    const int WN = (LAYOUT == 2 && getenv("PROBE_WN")) ? atoi(getenv("PROBE_WN")) : 1;
+    a.WN = WN;
+    if (WK * WN > 16 || ((N / 16 + ROWS - 1) / ROWS) % WN) { printf("{\"variant\": \"%s\", \"skipped\": \"tiles per workgroup\"}\n", name); return; }
+    const int grid = (N / 16 + ROWS - 1) / ROWS / WN;
+    const size_t lds = ((size_t)WK * UW * 512 + (size_t)WK * ROWS * 16 * 4) * WN;
     void (*kfn)(const Args);
     if constexpr (LAYOUT == 2) kfn = i8_gemv2<ROWS, UW / 4, MODE, MAXT>;
     else kfn = i8_gemv<ROWS, UW, LAYOUT, MODE, MAXT>;
@@ -499,7 +508,7 @@ static void run(const char *name, int N, int K, int NB, std::vector<void *> &dw,
     a.w = dw[0];
     a.sc = dsc[0];
     CK(hipMemset(dy, 0, N * 2));
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * WK), lds, 0, a);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * WK * WN), lds, 0, a);
     CK(hipDeviceSynchronize());
     double worst = 0, rms = 0;
     if (ref && (MODE == 0 || MODE == 2)) {
@@ -527,7 +536,7 @@ static void run(const char *name, int N, int K, int NB, std::vector<void *> &dw,
         for (int b = 0; b < NB; ++b) {
             a.w = dw[b];
             a.sc = dsc[b];
-            hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * WK), lds, cs, a);
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * WK * WN), lds, cs, a);
         }
         CK(hipStreamEndCapture(cs, &g));
         CK(hipGraphInstantiate(&gexec, g, nullptr, nullptr, 0));
@@ -550,7 +559,7 @@ static void run(const char *name, int N, int K, int NB, std::vector<void *> &dw,
         for (int b = 0; b < NB; ++b) {
             a.w = dw[b];
             a.sc = dsc[b];
-            hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * WK), lds, 0, a);
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * WK * WN), lds, 0, a);
         }
         CK(hipEventRecord(e1, 0));
         CK(hipDeviceSynchronize());
@@ -566,7 +575,7 @@ static void run(const char *name, int N, int K, int NB, std::vector<void *> &dw,
         a.dbg = ddbg;
         a.w = dw[1 % NB];
         a.sc = dsc[1 % NB];
-        hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * WK), lds, 0, a);
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * WK * WN), lds, 0, a);
         CK(hipDeviceSynchronize());
         std::vector<unsigned long long> h(nw * 5);
         CK(hipMemcpy(h.data(), ddbg, nw * 5 * 8, hipMemcpyDeviceToHost));
@@ -595,9 +604,9 @@ static void run(const char *name, int N, int K, int NB, std::vector<void *> &dw,
     std::sort(times.begin(), times.end());
     med = times[times.size() / 2];
     const double bytes = (double)N * K / 2 + (double)N * U * 2 + 2.0 * K + 2.0 * N;
-    printf("{\"variant\": \"%s\", \"N\": %d, \"K\": %d, \"rows_tiles\": %d, \"units_per_wave\": %d, \"layout\": \"%s\", \"mode\": \"%s\", \"waves_per_wg\": %d, \"grid\": %d, "
+    printf("{\"tiles_per_wg\": %d, \"variant\": \"%s\", \"N\": %d, \"K\": %d, \"rows_tiles\": %d, \"units_per_wave\": %d, \"layout\": \"%s\", \"mode\": \"%s\", \"waves_per_wg\": %d, \"grid\": %d, "
            "\"us_min\": %.2f, \"us_median\": %.2f, \"TBps_median\": %.3f, \"frac_of_8TBps\": %.3f, \"worst_err_over_tol\": %.3f}\n",
-           name, N, K, ROWS, UW, LAYOUT == 0 ? "tile16" : (LAYOUT == 2 ? "tile16 v2" : "q4_6"), MODE == 0 ? "gemv" : (MODE == 1 ? "stream-only" : (MODE == 2 ? "gemv + timestamps" : (MODE == 3 ? "no conversion" : (MODE == 4 ? "no mfma" : (MODE == 5 ? "launch only" : "launch + x round trip"))))), WK, grid, best, med, bytes / med * 1e-6, bytes / med * 1e-6 / 8.0, worst);
+           WN, name, N, K, ROWS, UW, LAYOUT == 0 ? "tile16" : (LAYOUT == 2 ? "tile16 v2" : "q4_6"), MODE == 0 ? "gemv" : (MODE == 1 ? "stream-only" : (MODE == 2 ? "gemv + timestamps" : (MODE == 3 ? "no conversion" : (MODE == 4 ? "no mfma" : (MODE == 5 ? "launch only" : "launch + x round trip"))))), WK, grid, best, med, bytes / med * 1e-6, bytes / med * 1e-6 / 8.0, worst);
     fflush(stdout);
     }
 }
@@ -670,6 +679,11 @@ int main(int argc, char **argv) {
         RUN(1, 8, 2, 6);
         RUN(1, 8, 2, 1);
         RUN(1, 8, 2, 0);
+        RUN(1, 16, 2, 5);
+        RUN(1, 16, 2, 1);
+        RUN(1, 16, 2, 0);
+        RUN(1, 4, 2, 5);
+        RUN(1, 4, 2, 0);
         if (getenv("PROBE_LAUNCH_ONLY")) continue;
         RUN(1, 4, 0, 1);
         RUN(1, 4, 2, 0);
