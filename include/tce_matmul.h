@@ -47,7 +47,7 @@ extern "C" {
 
 #define TCE_API __attribute__((visibility("default")))
 
-#define TCE_VERSION 107 /* 0.1.7: decode on the pre-packed copy (int8 contraction), tce_w4a16_set_gemv_i8; 0.1.6: TCE_PLAN_TUNED; 0.1.5: tce_opt_attention_decode; 0.1.4: tce_attention_prefill_f16 (0.1.3: tce_attention_decode_step_gqa_f16, TCE_PLAN_OVERLAPPED; 0.1.2: tce_w4a16_desc.scratch; 0.1.1: .prepacked, tce_w4a16_prepack*) */
+#define TCE_VERSION 108 /* 0.1.8: per-family tuning setters (tce_attention_set_tuning, tce_w8a8_set_tuning); 0.1.7: decode on the pre-packed copy (int8 contraction), tce_w4a16_set_gemv_i8; 0.1.6: TCE_PLAN_TUNED; 0.1.5: tce_opt_attention_decode; 0.1.4: tce_attention_prefill_f16 (0.1.3: tce_attention_decode_step_gqa_f16, TCE_PLAN_OVERLAPPED; 0.1.2: tce_w4a16_desc.scratch; 0.1.1: .prepacked, tce_w4a16_prepack*) */
 
 /* error codes (return values) */
 #define TCE_OK 0
@@ -501,6 +501,14 @@ TCE_API int tce_w4a16_set_gemv_i8(int mode, int tiles_per_wave);
  *   3000+g   fast attention step: workgroups the key range is cut for (3000: the fitted per-context rule, the default)
  * Every setting computes correct results except GEMV modes 1, 3, 4. */
 TCE_API int tce_w4a16_set_debug_mode(int mode);
+/* The same knobs per kernel family, by name (round 4: one numbered mode space for every family had already produced an A/B that compared a setting with itself, and
+ * a mode of one family landing in another's range).  Process-wide, for tuning sweeps and tests; 0 everywhere = the fitted rules.  Every setting computes the same results.
+ *   tce_attention_set_tuning: the fast decode attention step -- waves per workgroup (0 | 4 | 8 | 16), workgroups the key range is cut for (0 | 32..8192),
+ *                             query heads per workgroup for grouped queries (0 | 1 | 2 | 4)
+ *   tce_w8a8_set_tuning:      wave quartets per 64 x 64 tile (0 | 1 | 2 | 4); the 128-row tiles (0 the rule | 1 / 2: forced with 128 / 64 columns | 3 / 4: the same with two
+ *                             quartets | 9 off); the 64 x 64 tile with eight k-steps in flight (0 the rule | 1 / 2 / 4: forced with that many quartets | 9 off) */
+TCE_API int tce_attention_set_tuning(int waves_per_workgroup, int workgroups, int heads_per_workgroup);
+TCE_API int tce_w8a8_set_tuning(int quartets_per_tile, int big_tiles, int deep_pipeline);
 /* mode 2: every wave writes {start, x staged, math done, end} (100 MHz wall clock, 4 x u64 per wave) to this device buffer */
 TCE_API int tce_w4a16_set_debug_buffer(void *device_buffer);
 /* Force an MFMA GEMM tile (m_tiles x n_tiles of 16x16 per wave); 0,0 = automatic. */

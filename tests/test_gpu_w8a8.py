@@ -242,7 +242,7 @@ def test_wave_quartets_per_tile_are_bit_exact(dev, oracle, M, N, K):
 @pytest.mark.parametrize("M,N,K", [(64, 64, 64), (65, 100, 1024), (512, 768, 3072), (108, 2048, 8192), (16, 136, 1600), (9, 64, 192), (130, 70, 4160)])
 def test_deep_pipeline_tile_is_bit_exact(dev, oracle, M, N, K):
     """The 64x64 tile with eight k-steps in flight (w8a8_mfma_deep_kernel; the rule takes it for chains of 64+ steps on few tiles) forced with 1 / 2 / 4 wave quartets
-    (debug modes 171 / 172 / 174): cooperative panels through a double-buffered LDS stage, requests past the chain clamped -- fewer steps than the ring (1, 3), step
+    (tce_w8a8_set_tuning(0, 0, 1 / 2 / 4)): cooperative panels through a double-buffered LDS stage, requests past the chain clamped -- fewer steps than the ring (1, 3), step
     counts that are no multiple of the ring or of the quartets (25, 65), ragged M and N; the oracle's bytes every time."""
     from tinychatengine_amd import capi
     from tinychatengine_amd.matmul import MatmulOperator
@@ -251,14 +251,14 @@ def test_deep_pipeline_tile_is_bit_exact(dev, oracle, M, N, K):
     A, B, b8, _ = _data(M, N, K, seed=3 * K + M)
     exp = oracle.int8_matmul_bias_i8(A, B, b8, ALPHA, BETA, -128, 127, M, N, K)
     try:
-        for mode in (171, 172, 174, 170):
-            capi.check(L.tce_w4a16_set_debug_mode(mode))
+        for quartets in (1, 2, 4, 0):
+            capi.w8a8_set_tuning(deep_pipeline=quartets)
             p, out = _params(dev, A, B, torch.int8, b8)
             op.mat_mul_accelerator_int8_fast_2x2_32unroll(p)
             torch.cuda.synchronize()
-            assert np.array_equal(out.cpu().numpy(), exp), f"mode {mode}: {(out.cpu().numpy() != exp).sum()} mismatches"
+            assert np.array_equal(out.cpu().numpy(), exp), f"{quartets} quartets: {(out.cpu().numpy() != exp).sum()} mismatches"
     finally:
-        L.tce_w4a16_set_debug_mode(170)
+        capi.w8a8_set_tuning()
 
 
 @pytest.mark.parametrize("m,k,ns", [(1, 768, (768, 768, 768)), (1, 768, (3072,)), (3, 2048, (2048, 512)), (8, 96, (40, 24, 16, 8)), (1, 8192, (64,)),

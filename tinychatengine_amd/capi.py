@@ -22,7 +22,7 @@ TCE_W4_SILU_MUL_PAIRS = 8
 TCE_W4_ADD_TO_C = 16
 TCE_PLAN_CHAINED = 1
 TCE_PLAN_TAGGED = 2
-TCE_ABI_VERSION = 107  # include/tce_matmul.h TCE_VERSION: the struct layouts mirrored below
+TCE_ABI_VERSION = 108  # include/tce_matmul.h TCE_VERSION: the struct layouts mirrored below
 TCE_PLAN_OVERLAPPED = 4
 TCE_PLAN_TUNED = 8
 TCE_W4_ZERO_POINT_IS_8 = 4
@@ -35,7 +35,7 @@ EXPORTS = [
     "tce_w4a16_gemm_awq", "tce_w4a16_shard", "tce_comm_create", "tce_comm_export", "tce_comm_connect", "tce_comm_connect_local", "tce_allgather_f16", "tce_comm_rccl_unique_id", "tce_comm_rccl_init", "tce_allgather_rows_workspace_bytes", "tce_allgather_rows_f16", "tce_comm_status", "tce_comm_set_timeout_ms", "tce_comm_reset", "tce_comm_device", "tce_comm_destroy", "tce_w8a8_matmul", "tce_opt_softmax_q", "tce_opt_kv_append", "tce_layernorm_q", "tce_layernorm_q_w8a8_group", "tce_plan_create", "tce_plan_create_ex", "tce_plan_is_chained", "tce_plan_geometry", "tce_plan_status", "tce_plan_launch_geometry", "tce_plan_launch", "tce_plan_n_launches",
     "tce_plan_destroy", "tce_version", "tce_last_error", "tce_build_info", "tce_w4a16_set_gemv_config", "tce_w4a16_set_gemv_i8",
     "tce_w4a16_set_gemm_config", "tce_w4a16_algorithmic_bytes", "tce_w4a16_gemv_variant", "tce_w4a16_gemm_variant",
-    "tce_w4a16_set_debug_mode", "tce_w4a16_set_debug_buffer", "tce_malloc", "tce_free", "tce_memcpy", "tce_synchronize", "tce_device_count",
+    "tce_w4a16_set_debug_mode", "tce_attention_set_tuning", "tce_w8a8_set_tuning", "tce_w4a16_set_debug_buffer", "tce_malloc", "tce_free", "tce_memcpy", "tce_synchronize", "tce_device_count",
 ]
 
 
@@ -225,6 +225,16 @@ def set_gemv_config(rows: int = 0, waves_n: int = 0, waves_k: int = 0, depth: in
 def set_gemv_i8(mode: int = 0, tiles_per_wave: int = 0) -> None:
     """The decode kernel on pre-packed copies: mode 0 automatic, 1 off; tiles_per_wave 0 the rule, 1, 2."""
     check(lib().tce_w4a16_set_gemv_i8(mode, tiles_per_wave))
+
+
+def attention_set_tuning(waves_per_workgroup: int = 0, workgroups: int = 0, heads_per_workgroup: int = 0) -> None:
+    """The fast decode attention step's cut, by name (0 = the fitted rule): waves per workgroup 4 / 8 / 16, workgroups 32..8192, query heads per workgroup 1 / 2 / 4."""
+    check(lib().tce_attention_set_tuning(waves_per_workgroup, workgroups, heads_per_workgroup))
+
+
+def w8a8_set_tuning(quartets_per_tile: int = 0, big_tiles: int = 0, deep_pipeline: int = 0) -> None:
+    """tce_w8a8_matmul's kernel choice, by name (0 = the rules): quartets per 64x64 tile 1 / 2 / 4; the 128-row tiles 1..4 forced, 9 off; the deep-pipeline 64x64 tile 1 / 2 / 4 forced, 9 off."""
+    check(lib().tce_w8a8_set_tuning(quartets_per_tile, big_tiles, deep_pipeline))
 
 
 def set_gemm_config(m_tiles: int = 0, n_tiles: int = 0) -> None:

@@ -129,6 +129,28 @@ int tce_w4a16_set_gemv_i8(int mode, int rows) {
     return TCE_OK;
 }
 
+int tce_attention_set_tuning(int waves_per_workgroup, int workgroups, int heads_per_workgroup) {
+    const bool ok = (waves_per_workgroup == 0 || waves_per_workgroup == 4 || waves_per_workgroup == 8 || waves_per_workgroup == 16) &&
+                    (workgroups == 0 || (workgroups >= 32 && workgroups <= 8192)) &&
+                    (heads_per_workgroup == 0 || heads_per_workgroup == 1 || heads_per_workgroup == 2 || heads_per_workgroup == 4);
+    if (!ok) return fail(TCE_ERR_BAD_ARG, "tce_attention_set_tuning(%d, %d, %d)", waves_per_workgroup, workgroups, heads_per_workgroup);
+    tce::set_attention_fast_waves(waves_per_workgroup);
+    tce::set_attention_fast_target(workgroups);
+    tce::set_attention_fast_fuse(heads_per_workgroup);
+    return TCE_OK;
+}
+
+int tce_w8a8_set_tuning(int quartets_per_tile, int big_tiles, int deep_pipeline) {
+    const bool ok = (quartets_per_tile == 0 || quartets_per_tile == 1 || quartets_per_tile == 2 || quartets_per_tile == 4) &&
+                    ((big_tiles >= 0 && big_tiles <= 4) || big_tiles == 9) &&
+                    (deep_pipeline == 0 || deep_pipeline == 1 || deep_pipeline == 2 || deep_pipeline == 4 || deep_pipeline == 9);
+    if (!ok) return fail(TCE_ERR_BAD_ARG, "tce_w8a8_set_tuning(%d, %d, %d)", quartets_per_tile, big_tiles, deep_pipeline);
+    tce::set_w8a8_ksplit(quartets_per_tile);
+    tce::set_w8a8_big(big_tiles);
+    tce::set_w8a8_deep(deep_pipeline);
+    return TCE_OK;
+}
+
 static int g_plan_eager = 0;  // experiment (tce_w4a16_set_debug_mode(15001 / 15000)): stream-ordered plans issue their launches one by one instead of replaying the graph
 int tce_w4a16_set_debug_mode(int mode) {
     if (mode >= 50000 && mode <= 50499) {  // overlapped plans: 50000 + 100 * graph branches (0 = 2) + ring slots per wave (0 = as many as fit, 2..4)
