@@ -532,8 +532,11 @@ __global__ __launch_bounds__(1024) void w4a16_gemv_stream_kernel(const StreamArg
 }
 
 // A whole list of launches (a decode token's linears) in one kernel; see the header.
+// Workgroup size: 16 waves where the body fits 128 registers; the forms that did not (every general-zero-point form and four rows per wave: 3-34 registers
+// spilled to scratch under __launch_bounds__(1024), round-3 verdict) run 8-wave workgroups, two per CU, with the 256 registers that leaves them.
+constexpr int token_max_waves(int rows, int depth, bool z8) { return (!z8 || rows == 4) ? 8 : 16; }
 template <int ROWS, int DEPTH, bool Z8, int CHAIN>
-__global__ __launch_bounds__(1024) void w4a16_gemv_token_kernel(const TokenArgs args) {
+__global__ __launch_bounds__(64 * token_max_waves(ROWS, DEPTH, Z8)) void w4a16_gemv_token_kernel(const TokenArgs args) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n = args.n_launches;
     unsigned tag = 0;
@@ -819,6 +822,10 @@ int token_plan_create(const tce_w4a16_desc *descs, const int32_t *groups, int n_
     }
     hipError_t e = hipSuccess;
     if (mode == 0) {
+        if (tp.nw > token_max_waves(tp.rows, tp.depth, tp.z8)) {  // (the kernel form is known only now: the zero points were just examined)
+            tp.nw = token_max_waves(tp.rows, tp.depth, tp.z8);
+            if (!g_stream_bpc) bpc = 16 / tp.nw;
+        }
         // every workgroup must be resident at once: a launch spins until its producers have delivered
         int per_cu = 0;
         e = TCE_TOKEN_DISPATCH(token_setup, tp, &per_cu);
