@@ -30,8 +30,7 @@ EXTRA_FLAGS: dict[str, list[str]] = {}  # (-fno-slp-vectorize on the GEMM: no pa
 # Kernels that must not spill a vector register: lnq_w8a8_wide_kernel keeps 16 requested weight pieces per lane in flight through its sums; ONE spilled register
 # makes the compiler wait for all of them at the spill (measured: the OPT-6.7B layer 94 -> 103 us, found only by accident).  The build fails instead.
 NO_VGPR_SPILL: dict[str, list[str]] = {"w8a8_lnq_fused.hip": ["lnq_w8a8_wide_kernel"],
-                                        "w4a16_gemv_stream.hip": ["w4a16_gemv_token_kernel"],  # (round 3: four forms spilled 3-34 registers under __launch_bounds__(1024))
-                                        "w4a16_gemv_i8.hip": ["w4a16_gemv_i8_kernel"]}
+                                        "w4a16_gemv_stream.hip": ["w4a16_gemv_token_kernel"]}  # (round 3: four forms spilled 3-34 registers under __launch_bounds__(1024))
 
 
 def _check_spills(src: str, stderr_text: str) -> None:
