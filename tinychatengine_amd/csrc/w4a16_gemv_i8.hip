@@ -130,6 +130,16 @@ __global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const I8Args args) 
 #pragma unroll
         for (int c = 0; c < XC; ++c) xv[m][c] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, u0 * 256 + (lane + 64 * c) * 16, 0, 0);  // (the scalar offset of a buffer load is NOT range-checked: everything that may run past K sits in the vector offset)
     }
+    // the residual epilogue's old values (TCE_W4_ADD_TO_C): requested HERE, by the lanes that will add to them -- behind the barrier of the K reduction the load was a
+    // memory round trip at the very end of every o_proj / down_proj launch (the row was written by another launch, possibly on another XCD: no cache holds it)
+    half_t c_old = (half_t)0.0f;
+    if constexpr (!RNORM) {
+        if (wk == 0 && (seg.epilogue & TCE_W4_ADD_TO_C) && tid < ROWS * MB * 16) {
+            const int i16 = tid & 15, m = (tid >> 4) % MB, r = tid / (16 * MB);
+            const int row = (tile0 + r) * 16 + i16;
+            if (m0 + m < args.M && row < seg.N) c_old = seg.C[(size_t)(m0 + m) * seg.ldc + row];
+        }
+    }
     float4_t gm[NORM ? XC : 1][2];  // gamma of the lane's 8 columns per chunk
     if constexpr (NORM) {
         const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(args.gamma), 0, args.K * 4, 0x00020000);
@@ -391,7 +401,7 @@ __global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const I8Args args) 
                 if ((i16 & 1) == 0) crow[row >> 1] = silu_mul_half(y, y_other);
             } else if (seg.epilogue & TCE_W4_ADD_TO_C) {
                 if constexpr (RNORM) hnew = crow[row] + y;  // (stored below, write-through)
-                else crow[row] = crow[row] + y;
+                else crow[row] = c_old + y;
             } else {
                 crow[row] = y;
             }
