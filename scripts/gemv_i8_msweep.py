@@ -11,8 +11,9 @@ model = sys.argv[1] if len(sys.argv) > 1 else "baseline-named"
 for m in (1, 2, 3, 4):
     dl = DecodeLinears(SHAPES[model], device=dev, group_size=128, m=m, prepack=True)
     row = {"model": model, "M": m}
-    for name, mode in (("i8", 0), ("i8_off", 1)):
-        capi.set_gemv_i8(mode)
+    for name, mode, tiles in (("i8", 0, 0), ("i8_two_tiles_per_wave", 0, 2), ("i8_off", 1, 0)):
+        if tiles and not os.environ.get("MSWEEP_TWO_TILES"): continue
+        capi.set_gemv_i8(mode, tiles)
         plan = dl.make_plan()
         capi.set_gemv_i8()
         s = torch.cuda.current_stream().cuda_stream
