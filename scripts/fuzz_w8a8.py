@@ -1,86 +1,77 @@
 #!/usr/bin/env python3
-"""Soak test (not part of pytest): seeded random W8A8 problems through tce_w8a8_matmul -- every kernel behind it (MFMA tiles with 1 / 2 wave quartets, the 128-row tiles in their four forced forms, the
-wave-per-column kernel for small M, the wave-per-output kernel for per-row operands with long rows, the generic kernel), every epilogue kind, batches, leading
-dimensions, `accumulate` -- against the CPU oracle, BIT FOR BIT.  usage: fuzz_w8a8.py [cases] [seed]"""
+"""Soak test (not part of pytest): seeded random W8A8 problems through the MatmulOperator mirror -> tce_w8a8_matmul, every kernel family the dispatcher picks
+(wave-per-column, 64x64 tiles with 1 / 2 / 4 quartets, the deep-pipeline tile, the 128-row tiles, the generic kernel for odd K) and, every fourth case, a forced
+family -- against the CPU oracle, BIT-EXACT (kernels/ref/matmul_ref_int8.cc:11-159).  usage: fuzz_w8a8.py [cases] [seed]"""
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-import numpy as np
-import torch
-from tinychatengine_amd import capi
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
 from oracle.oracle import Oracle
-
-oracle = Oracle()
-dev = torch.device("cuda", 0)
-L = capi.lib()
-t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+from tinychatengine_amd import capi
+from tinychatengine_amd.matmul import MatmulOperator, matmul_params, matrix
 
 
 def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
-    t0, bad = time.time(), 0
-    kinds = {}
+    dev = torch.device("cuda:0")
+    orc = Oracle()
+    op = MatmulOperator()
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    bad, t0 = 0, time.time()
+    forced = [dict(quartets_per_tile=1), dict(quartets_per_tile=2), dict(quartets_per_tile=4), dict(deep_pipeline=1), dict(deep_pipeline=2), dict(deep_pipeline=4),
+              dict(big_tiles=1), dict(big_tiles=2), dict(big_tiles=3), dict(big_tiles=4), dict(big_tiles=9, deep_pipeline=9)]
     for case in range(cases):
-        M = int(rng.choice([1, 2, 3, 4, 5, 8, 9, 16, 33, 64, 65, 108, 130, 300]))
-        N = int(rng.choice([rng.integers(1, 40), rng.integers(40, 300), rng.integers(300, 1200)]))
-        K = int(rng.choice([16 * rng.integers(1, 12), 16 * rng.integers(12, 80), 16 * rng.integers(80, 300), rng.integers(1, 500), 64 * rng.integers(4, 40)]))
-        if M * N * K > 4e8:
-            M = 5
-        per_row = bool(rng.integers(0, 5) == 0) and M * N * K < 3e7
-        batch = 1 if per_row else int(rng.choice([1, 1, 1, 2, 5]))
-        pad = lambda n: n + (int(rng.choice([0, 0, 16, 48])) if K % 16 == 0 else 0)
-        lda, ldb = pad(K), pad(K)
-        out_fp32 = bool(rng.integers(0, 2))
-        bias_kind = int(rng.choice([capi.TCE_BIAS_NONE, capi.TCE_BIAS_FP32 if out_fp32 else capi.TCE_BIAS_INT8])) if not per_row else capi.TCE_BIAS_NONE
-        accumulate = out_fp32 and bool(rng.integers(0, 3) == 0)
-        ldc = N + int(rng.choice([0, 0, 5, 16]))
-        qmin = int(rng.choice([-128, 0]))
-        alpha, beta = float(rng.choice([0.0005035400390625, 0.003, 1.0e-4])), 0.02130126953125
-        A = rng.integers(-128, 128, (batch, M, lda), dtype=np.int8)
-        B = rng.integers(-128, 128, (M if per_row else batch, N, ldb), dtype=np.int8)
-        b8, bf = rng.integers(-128, 128, N, dtype=np.int8), rng.standard_normal(N).astype(np.float32)
-        C0 = rng.standard_normal((batch, M, ldc)).astype(np.float32)
-        tA, tB, tb8, tbf = t(A), t(B), t(b8), t(bf)
-        out = t(C0.copy()) if out_fp32 else torch.full((batch, M, ldc), 55, dtype=torch.int8, device=dev)
-        d = capi.W8A8Desc(M=M, N=N, K=K, batch=batch, A=tA.data_ptr(), B=tB.data_ptr(), bias=(tbf if out_fp32 else tb8).data_ptr() if bias_kind != capi.TCE_BIAS_NONE else None,
-                          C=out.data_ptr(), strideA=M * lda, strideB=N * ldb, strideC=M * ldc, alpha=alpha, beta=beta, q_min=qmin, q_max=127, bias_kind=bias_kind,
-                          out_kind=capi.TCE_OUT_FP32 if out_fp32 else capi.TCE_OUT_INT8, b_per_row=1 if per_row else 0, accumulate=1 if accumulate else 0, lda=lda if lda != K else 0,
-                          ldb=ldb if ldb != K else 0, ldc=ldc if ldc != N else 0)
-        mode = int(rng.choice([70, 70, 71, 72, 73]))
-        capi.check(L.tce_w4a16_set_debug_mode(mode))
-        # the 128-row tiles (K % 64 == 0, K >= 256, a shared B): forced in one of their four forms on a part of the eligible cases
-        big = int(rng.choice([75, 75, 76, 77, 176, 177, 78]))
-        capi.check(L.tce_w4a16_set_debug_mode(big))
-        capi.check(capi.w8a8_matmul(d, None))
-        torch.cuda.synchronize()
-        L.tce_w4a16_set_debug_mode(70)
-        L.tce_w4a16_set_debug_mode(75)
-        got = out.cpu().numpy()
-        ok = True
-        for h in range(batch):
-            Ah = np.ascontiguousarray(A[h, :, :K])
-            Bh = np.ascontiguousarray(B[:, :, :K]) if per_row else np.ascontiguousarray(B[h, :, :K])
-            if out_fp32:
-                if bias_kind == capi.TCE_BIAS_FP32:
-                    want = oracle.int8_matmul_bias_f32(Ah, Bh, bf, alpha, M, N, K)
-                else:
-                    want = oracle.int8_matmul_nobias_f32(Ah, Bh, alpha, M, N, K, batch=per_row)
-                if accumulate:
-                    want = C0[h, :, :N] + want
-                ok &= np.array_equal(got[h, :, :N].view(np.uint32), want.view(np.uint32)) and np.array_equal(got[h, :, N:], C0[h, :, N:])
+        M = int(rng.choice([1, 2, 5, 8, 9, 16, 33, 64, 65, 108, 130, 200, 512, int(rng.integers(1, 600))]))
+        N = int(rng.choice([1, 3, 16, 64, 65, 100, 136, 768, 1000, int(rng.integers(1, 1500))]))
+        K = int(rng.choice([16, 48, 64, 80, 192, 768, 1024, 1600, 2048, 3072, 4160, 8192, 16 * int(rng.integers(1, 300)), int(rng.integers(1, 2000))]))
+        if M * N * K > 6e8: K = max(16, K // 8)
+        A = rng.integers(-128, 128, (M, K), dtype=np.int8)
+        B = rng.integers(-128, 128, (N, K), dtype=np.int8)
+        alpha, beta = float(np.float32(rng.uniform(1e-4, 2e-3))), float(np.float32(rng.uniform(0.005, 0.05)))
+        kind = int(rng.integers(0, 4))  # bias int8 -> int8 | no bias -> int8 | bias fp32 -> fp32 | no bias -> fp32
+        tune = forced[int(rng.integers(0, len(forced)))] if case % 4 == 3 else {}
+        capi.w8a8_set_tuning(**tune)
+        try:
+            if kind == 0:
+                b8 = rng.integers(-128, 128, N, dtype=np.int8)
+                exp = orc.int8_matmul_bias_i8(A, B, b8, alpha, beta, -128, 127, M, N, K)
+                out = torch.zeros((M, N), dtype=torch.int8, device=dev)
+                p = matmul_params(A=matrix(M, K, t(A)), B=matrix(K, N, t(B)), C=matrix(M, N, out), alpha=alpha, beta=beta)
+                p.bias = matrix(1, N, t(b8))
+                p.C.qparams.q_min, p.C.qparams.q_max = -128, 127
+                op.mat_mul_accelerator_int8_fast_2x2_32unroll(p)
+            elif kind == 1:
+                qmin = 0 if rng.integers(0, 2) else -128  # (the ReLU clamp of fc1)
+                exp = orc.int8_matmul_nobias_i8(A, B, alpha, qmin, 127, M, N, K)
+                out = torch.zeros((M, N), dtype=torch.int8, device=dev)
+                p = matmul_params(A=matrix(M, K, t(A)), B=matrix(K, N, t(B)), C=matrix(M, N, out), alpha=alpha, beta=beta)
+                p.C.qparams.q_min, p.C.qparams.q_max = qmin, 127
+                op.mat_mul_accelerator_int8_fast_2x2_32unroll_nobias(p)
+            elif kind == 2:
+                bf = rng.standard_normal(N).astype(np.float32)
+                exp = orc.int8_matmul_bias_f32(A, B, bf, alpha, M, N, K)
+                out = torch.zeros((M, N), dtype=torch.float32, device=dev)
+                p = matmul_params(A=matrix(M, K, t(A)), B=matrix(K, N, t(B)), C=matrix(M, N, out), alpha=alpha, beta=beta)
+                p.bias = matrix(1, N, t(bf))
+                op.mat_mul_accelerator_int8_fast_2x2_32unroll_bfp32_ofp32(p)
             else:
-                if bias_kind == capi.TCE_BIAS_INT8:
-                    want = oracle.int8_matmul_bias_i8(Ah, Bh, b8, alpha, beta, qmin, 127, M, N, K)
-                else:
-                    want = oracle.int8_matmul_nobias_i8(Ah, Bh, alpha, qmin, 127, M, N, K, batch=per_row)
-                ok &= np.array_equal(got[h, :, :N], want) and bool((got[h, :, N:] == 55).all())
-        key = ("per-row" if per_row else "shared") + (" fp32" if out_fp32 else " int8")
-        kinds[key] = kinds.get(key, 0) + 1
+                exp = orc.int8_matmul_nobias_f32(A, B, alpha, M, N, K)
+                out = torch.zeros((M, N), dtype=torch.float32, device=dev)
+                p = matmul_params(A=matrix(M, K, t(A)), B=matrix(K, N, t(B)), C=matrix(M, N, out), alpha=alpha, beta=beta)
+                op.mat_mul_accelerator_int8_fast_2x2_32unroll_nobias_ofp32(p)
+            torch.cuda.synchronize()
+            got = out.cpu().numpy()
+            ok = np.array_equal(got.view(np.uint32) if got.dtype == np.float32 else got, np.asarray(exp).view(np.uint32) if got.dtype == np.float32 else np.asarray(exp))
+        except Exception as e:  # noqa: BLE001
+            ok = False
+            print(f"case {case}: {type(e).__name__}: {e}", flush=True)
+            capi.lib().tce_reset_last_error()
         if not ok:
             bad += 1
-            print(f"MISMATCH case {case}: M={M} N={N} K={K} batch={batch} per_row={per_row} lda={lda} ldb={ldb} ldc={ldc} fp32={out_fp32} bias={bias_kind} acc={accumulate} mode={mode}")
-    print(f"fuzz w8a8: {cases} cases {kinds}, {bad} failures, {time.time() - t0:.0f} s (seed {seed})")
+            print(f"MISMATCH case {case}: M={M} N={N} K={K} kind={kind} tuning={tune}", flush=True)
+    capi.w8a8_set_tuning()
+    print(f"fuzz_w8a8: {cases} cases, {bad} failures, {time.time() - t0:.0f} s (seed {seed})", flush=True)
     return 1 if bad else 0
 
 
