@@ -1,4 +1,4 @@
-"""512 x 11008 x 4096 (344 tiles) and neighbours with the tail tiles' k range cut into 2 / 3 / 4 runs (tce_w4a16_set_debug_mode(640 + s))."""
+"""Prefill GEMM shapes MxNxK (arguments; default 512x11008x4096) with the k range of the tiles past the CUs (or of all tiles where they are fewer) cut into 2 / 3 / 4 runs (tce_w4a16_set_debug_mode(640 + s)); "auto" = the cost model."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -15,7 +15,7 @@ def timed(fn, reps=30, warm=8):
         e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) * 1000.0 / reps)
     return min(ts)
 g = torch.Generator(device=dev).manual_seed(1)
-for (M, N, K) in ((512, 11008, 4096), (384, 11008, 4096), (448, 11008, 4096), (512, 9216, 4096), (512, 10240, 4096), (384, 14336, 4096)):
+for (M, N, K) in [tuple(int(v) for v in a.split("x")) for a in (sys.argv[1:] or ["512x11008x4096"])]:
     lins = [Linear_half_int4.from_float(torch.empty(N, K, device=dev).normal_(0, 0.02, generator=g), 128).prepack() for _ in range(3)]
     x = torch.empty(M, K, device=dev).normal_(0, 1, generator=g).to(torch.float16)
     out = torch.empty(M, N, dtype=torch.float16, device=dev)
@@ -23,7 +23,7 @@ for (M, N, K) in ((512, 11008, 4096), (384, 11008, 4096), (448, 11008, 4096), (5
     def run():
         capi.check(capi.w4a16_forward(descs[it[0] % 3], st)); it[0] += 1
     row = {"M": M, "N": N, "K": K, "tiles": ((M + 127) // 128) * ((N + 127) // 128)}
-    for name, mode in (("whole", 61), ("cut2", 642), ("cut3", 643), ("cut4", 644)):
+    for name, mode in (("auto", 640), ("whole", 61), ("cut2", 642), ("cut3", 643), ("cut4", 644)):
         L.tce_w4a16_set_debug_mode(mode)
         row[name + "_us"] = round(timed(run), 2)
         row[name + "_what"] = capi.describe_dispatch(descs[0]).split()[3]

@@ -256,7 +256,7 @@ def test_pk_dispatch_rules(dev, oracle):
     d.M, d.N, d.K, d.lda, d.ldc = 512, 4096, 4096, 4096, 4096
     assert d.scratch and "ksplit=2" in capi.describe_dispatch(d), capi.describe_dispatch(d)
     d.K = d.lda = 11008
-    assert "ksplit=2" in capi.describe_dispatch(d)
+    assert "ksplit=4" in capi.describe_dispatch(d), capi.describe_dispatch(d)  # (round 4: the scratch area holds 512 units; four runs per tile win on the long k range)
     d.scratch = None
     assert capi.describe_dispatch(d).startswith("gemm-dma")
     assert capi.describe_dispatch(lin.desc(x[:1], out[:1])).startswith("gemv")
@@ -276,8 +276,8 @@ def test_full_size_prefill_on_the_packed_kernel(dev, oracle, N, K):
     x = torch.cat([xh, xh], dim=0).contiguous()
     y = torch.full((M, N), float("nan"), dtype=torch.float16, device=dev)
     what = capi.describe_dispatch(lin.desc(x, y))
-    # N = 4096: 128 tiles, every tile's k range cut in two; N = 11008: 344 tiles, the 88 past the first 256 cut in two (one run per CU at most)
-    assert what.startswith("gemm-pk") and ("ksplit=2 " in what if N == 4096 else "ksplit=2-of-the-tiles-past-256" in what), what
+    # N = 4096: 128 tiles, every tile's k range cut in two (K = 4096) or four (K = 11008: round 4); N = 11008: 344 tiles, the 88 past the first 256 cut in two (one run per CU at most)
+    assert what.startswith("gemm-pk") and ((("ksplit=2 " if K == 4096 else "ksplit=4 ") in what) if N == 4096 else "ksplit=2-of-the-tiles-past-256" in what), what
     for rep in range(3):  # (the scratch counters must be back to zero after every call)
         y.fill_(float("nan"))
         lin.forward(x, y)

@@ -677,8 +677,8 @@ int launch_w4a16_prepack(const tce_w4a16_desc &d, void *out, hipStream_t stream,
 // A workgroup's time per k-block c grows with the load on its CU and on the chip (f = resident waves / 2048); fitted to
 // profiles/r2/gemm_pk_sweep.jsonl: form 1 alone on its CU 1.06 us, sharing it 1.25 + 0.73 f; form 2 per PAIR of k-blocks
 // 1.7 + 0.4 f; form 3 (every active CU carries eight waves) 1.5 + 0.4 f; + 3 us of launch, prologue and epilogue.
-// Scratch for the K split across workgroups (form 4): [4 KiB of tile counters][kPkSplitMaxUnits partial tiles of 64 KiB].
-constexpr int kPkSplitMaxUnits = 288;
+// Scratch for the K split across workgroups (form 4): [4 KiB of tile counters][kPkSplitMaxUnits partial tiles of 64 KiB] (32 MiB + 4 KiB; 288 units until round 4).
+constexpr int kPkSplitMaxUnits = 512;
 size_t gemm_pk_scratch_bytes() { return 4096 + (size_t)kPkSplitMaxUnits * 65536; }
 
 // form 4 = form 1 with every tile's k-blocks cut into s runs on s workgroups (partial tiles added through the scratch area in a fixed
@@ -690,12 +690,14 @@ static int pk_split_factor(long tiles1, int nkb, bool has_scratch, float *cost_o
     float best = 1e30f;
     if (has_scratch && tiles1 <= 1024)
         for (int s = 2; s <= 4; ++s) {
-            if (tiles1 * s > kPkSplitMaxUnits || nkb / s < 4) continue;
+            if (tiles1 * s > kPkSplitMaxUnits || nkb / s < 4 || (g_pk_split_force && s != g_pk_split_force)) continue;
             // fitted to profiles/r2/gemm_pk_ksplit_sweep.jsonl: a run of k-blocks at the lone-quartet rate (units that have to share a CU:
             // two runs back to back) + 3 us of launch / prologue / epilogue + 5 + 1.3 s us for the exchange (64 KiB per unit written
             // through to memory -- 16 MB per launch --, the counter, the other partials read back)
             const float run = (float)((nkb + s - 1) / s);
-            const float c = (tiles1 * s <= 256 ? run * 1.06f : 2.0f * run) + 8.0f + 1.3f * (float)s;
+            // (round 4, profiles/r4/gemm_pk_split_probe.jsonl: with room for 512 units in the scratch area, four runs per tile beat two on the long k ranges --
+            //  512 x 4096 x 11008: 55.6 -> 52.0 us, x 14336: 70.7 -> 64.0 -- and lose on 4096 (26.9 -> 28.9); two units sharing a CU walk a k-block in ~1.8 us, + 1.5 us once)
+            const float c = (tiles1 * s <= 256 ? run * 1.06f : 1.8f * run + 1.5f) + 8.0f + 1.3f * (float)s;
             if (c < best) best = c, best_s = s;
         }
     if (cost_out) *cost_out = best;
