@@ -677,15 +677,17 @@ int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err)
         hipLaunchKernelGGL(w8a8_rowdot_kernel<1>, dim3((unsigned)((outs + 3) / 4), 1, d.batch), dim3(256), 0, stream, a);
     } else if (!d.b_per_row && aligned && d.K % 64 == 0 && d.K >= 256 && g_w8a8_big != 9 &&
                ((g_w8a8_big >= 1 && g_w8a8_big <= 4) || (long)((d.M + 127) / 128) * ((d.N + 63) / 64) * d.batch >= 512 ||
-                ((long)((d.M + 127) / 128) * ((d.N + 63) / 64) * d.batch >= 256 && d.K >= 2048))) {
+                ((long)((d.M + 127) / 128) * ((d.N + 63) / 64) * d.batch >= 256 && d.K >= 2048 && d.K < 4096))) {  // (round 4: from 64 k-steps on the 64 x 64 deep-pipeline kernel is level or ahead at one tile per CU -- 512 x 4096 x 16384: 83 -> 78 us -- and far ahead where M leaves most of a 128-row tile empty: 16 x 16384 x 4096 23.2 -> 16.6)
         // prefill-sized (scripts/w8a8_gemm_sizes.py, profiles/r3/w8a8_gemm_sizes.jsonl; never slower than the 64 x 64 kernel on the 18 shapes measured):
         // 128 x 128 tiles from two per CU on (512 x 16384 x 4096: 149 -> 57 us; 2048 x 4096 x 4096: 131 -> 56), 128 x 64 tiles from two per CU on
         // (512 x 8192 x 2048: 32 -> 24), from one per CU on with TWO quartets per tile when K is long (512 x 4096 x 4096: 38 -> 29; 512 x 4096 x 16384: 124 -> 85),
         // else the 64 x 64 kernel (512 x 2048 x 2048 stays at 10.7 us, 512 x 2048 x 8192 at 36).
         const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch;
         const long t64 = (long)((d.M + 127) / 128) * ((d.N + 63) / 64) * d.batch;
-        const bool wide = g_w8a8_big == 1 || g_w8a8_big == 3 || (g_w8a8_big == 0 && t128 >= 512);
-        const bool split = g_w8a8_big == 3 || g_w8a8_big == 4 || (g_w8a8_big == 0 && !wide && t64 < 512);
+        // (round 4: one 128 x 128 tile per CU with two quartets on half of K each beats the 128 x 64 tiles when K is long -- 2048 x 2048 x 8192: 71.8 -> 64.4 us)
+        const bool long_k_one_per_cu = g_w8a8_big == 0 && t128 >= 256 && t128 < 512 && d.K >= 8192;
+        const bool wide = g_w8a8_big == 1 || g_w8a8_big == 3 || (g_w8a8_big == 0 && t128 >= 512) || long_k_one_per_cu;
+        const bool split = g_w8a8_big == 3 || g_w8a8_big == 4 || (g_w8a8_big == 0 && !wide && t64 < 512) || long_k_one_per_cu;
         const size_t ring = (size_t)3 * (128 + (wide ? 128 : 64)) * 4 * 16;
         const size_t lds = split ? ((2 * ring > (size_t)(wide ? 16 : 8) * 256 * 16) ? 2 * ring : (size_t)(wide ? 16 : 8) * 256 * 16) : ring;
         const dim3 grid((d.N + (wide ? 127 : 63)) / (wide ? 128 : 64), (d.M + 127) / 128, d.batch);
@@ -704,17 +706,16 @@ int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err)
         int ks = g_w8a8_ks == 3 ? 0 : g_w8a8_ks;
         if (ks == 0) {
             ks = 1;
-            if (tiles < 512 && d.K / 64 >= 4) ks = 2;  // four quartets measured no better than two (profiles/r1/w8a8_ksplit_sweep.jsonl)
+            if (tiles <= 256 && d.K / 64 >= 4) ks = 2;  // four quartets measured no better than two (profiles/r1/w8a8_ksplit_sweep.jsonl); from 384 tiles on ONE is ahead (512 x 3072 x 768: 8.45 -> 8.0 us, profiles/r4/w8a8_form_sweep_before_refit.jsonl)
         }
         const size_t lds = (size_t)ks * 4 * 4 * 64 * 16;  // transpose slots; the reduction ((ks - 1) * 16 KiB) reuses them
         // long k chains on few tiles: the cooperative panels with 8 k-steps in flight (w8a8_mfma_deep_kernel)
-        // Measured (scripts/probes/w8a8_small_ab.py, same-session A/B, weights rotating through HBM): it wins where the chain is 128 steps long -- 512 / 108 / 16 x 2048 x 8192:
-        // 35.9 -> 32.5 / 31.3 -> 24.7 / 30.3 -> 21.9 us -- and LOSES at 48 and 32 steps (512 x 768 x 3072: 13.6 -> 14.8; 512 x 2048 x 2048: 10.5 -> 12.9): those launches do
-        // not depend on the quartet count in either kernel (one / two / four: 15.1 / 13.2 / 12.8 us), i.e. not on the chain -- 96 workgroups pull 0.4-0.8 MB each through
-        // their own CU's L1, and spreading that over more CUs needs a reduction across workgroups, which costs a launch boundary.
-        const bool deep = g_w8a8_deep != 9 && d.K % 64 == 0 && (g_w8a8_deep > 0 || (tiles < 512 && d.K / 64 >= 64));
+        // Rule (round 4, scripts/w8a8_form_sweep.py over 36 launches, profiles/r4/w8a8_form_sweep_*.jsonl): from 48 k-steps on it is level with or ahead of the kernel above at every
+        // tile count this branch sees -- 2048 x 768 x 3072: 25.6 -> 19.9 us, 108 x 768 x 3072: 15.3 -> 13.6, 512 x 2048 x 8192: 38.5 -> 30.3, 16 x 4096 x 16384: 58 -> 39 -- and behind it
+        // at 32 and 12 steps (512 x 2048 x 2048: 10.2 -> 11.1; 512 x 768 x 768: 6.3 -> 8.0).  Two quartets up to 256 tiles (up to 512 from 128 steps on: 512 x 4096 x 8192 47.4 -> 44.8), one beyond; four were never ahead.
+        const bool deep = g_w8a8_deep != 9 && d.K % 64 == 0 && (g_w8a8_deep > 0 || d.K / 64 >= 48);
         if (deep) {
-            const int dks = g_w8a8_deep == 1 || g_w8a8_deep == 2 || g_w8a8_deep == 4 ? g_w8a8_deep : (d.K / 64 >= 32 && tiles <= 256 ? 4 : 2);
+            const int dks = g_w8a8_deep == 1 || g_w8a8_deep == 2 || g_w8a8_deep == 4 ? g_w8a8_deep : (tiles <= 256 || (tiles <= 512 && d.K / 64 >= 128) ? 2 : 1);
             const size_t dl = (size_t)dks * 2 * 512 * 16;  // (>= the reduction's (dks - 1) * 16 KiB)
             if (dks == 4) hipLaunchKernelGGL((w8a8_mfma_deep_kernel<4, 8>), grid, dim3(1024), dl, stream, a);
             else if (dks == 2) hipLaunchKernelGGL((w8a8_mfma_deep_kernel<2, 8>), grid, dim3(512), dl, stream, a);
