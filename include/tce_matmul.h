@@ -113,7 +113,7 @@ typedef struct tce_w4a16_desc {
  *       permutation, like the reference's offline qkv merge), N is even, and
  *           C[m][n] = hmul( hmul(g, hdiv(1, hadd(1, hexp(hneg(g))))), u ),  g = fp16(y[m][2n]), u = fp16(y[m][2n+1])
  *       with every operation rounded to fp16 as in the reference kernel.  C is [M][N/2] (ldc 0 = N/2).  Decode batches (M <= 8) run it in the GEMV
- *       kernels' epilogue; a batch of M >= 192 rows with a `prepacked` copy in the 128-row GEMM's (the prompt path); anything else on the GEMV kernel,
+ *       kernels' epilogue; a batch of M > 128 rows with a `prepacked` copy in the 128-row GEMM's (the prompt path); anything else on the GEMV kernel,
  *       four rows per pass.
  *   TCE_W4_ADD_TO_C        replaces o_proj / down_proj + add_half (Int4llamaDecoderLayer.cu:12-18, 86-88, 107-108):
  *           C[m][n] = hadd(C[m][n], fp16(y[m][n]))   (C holds the residual on entry, like residual_add there). */
@@ -243,7 +243,7 @@ TCE_API int tce_w4a16_check_zero_point_8(const void *zeros, long long n_words);
  * exact unpack, per-group effective scales and zero-point constants) into `packed`, which must hold
  * tce_w4a16_prepack_bytes(N, K, group_size) bytes of device memory (0 = shape not supported: K % 128 != 0).  Asynchronous on
  * `stream`; once per weight tensor.  A descriptor whose `prepacked` points at that copy lets tce_w4a16_forward run the 128-row
- * MFMA kernel (csrc/w4a16_gemm_pk.hip) for M >= 192; results stay within the W4A16 tolerance of every other path. */
+ * MFMA kernel (csrc/w4a16_gemm_pk.hip) for M > 128 (where its cost model beats the 64-row kernel's); results stay within the W4A16 tolerance of every other path. */
 TCE_API size_t tce_w4a16_prepack_bytes(int N, int K, int group_size);
 TCE_API size_t tce_w4a16_gemm_scratch_bytes(void); /* size of tce_w4a16_desc.scratch (about 18 MiB) */
 TCE_API int tce_w4a16_prepack(const tce_w4a16_desc *d, void *packed, void *stream);

@@ -228,7 +228,7 @@ def test_pk_gemm_k_split_exchange_under_repetition(dev, oracle):
 
 
 def test_pk_dispatch_rules(dev, oracle):
-    """No packed copy -> the other kernels; M < 192 -> the other kernels; in between the two GEMMs' cost models decide (the 64-row
+    """No packed copy -> the other kernels; M <= 128 -> the other kernels; in between the two GEMMs' cost models decide (the 64-row
     tiles keep M = 512 at N = 4096, where 128-row tiles are too few to fill 256 CUs); K % 128 != 0 -> no packed form at all."""
     from tinychatengine_amd import capi
     qw, sc, zp = _quant(oracle, 256, 512, 128, seed=1, random_zeros=False)

@@ -65,7 +65,7 @@ std::mutex g_mu;
 std::unordered_map<TensorKey, int, TensorKeyHash> g_zero;       // zero-point tensor -> every packed zero point is 8
 std::unordered_map<TensorKey, AwqEntry, TensorKeyHash> g_awq;   // AWQ weight tensor -> re-laid-out copy
 std::unordered_map<TensorKey, AwqEntry, TensorKeyHash> g_pack;  // q4_6 weight tensor -> q4_mfma copy (decode GEMV M <= 4, prefill GEMM M >= kPackMinM)
-constexpr int kPackMinM = 192;
+constexpr int kPackMinM = 129;
 
 // The q4_mfma copy of a linear, built on first sight of a large batch (the reference's Linear_half_int4 has no load-time hook
 // the adapter could use: its constructor only reads files, llm/include/ops/linear.h:215-240).  Enqueued on the null stream in
@@ -179,7 +179,7 @@ void MatmulOperator::gemv_forward_cuda(const struct matmul_params *params) {
         const int zw = (((d.K / d.group_size + 7) / 8) + mult - 1) / mult * mult;
         if (d.zeros && zeros_are_8(d.zeros, (long long)d.N * zw)) d.flags |= TCE_W4_ZERO_POINT_IS_8;
     }
-    // The packed copy serves both ends: decode batches (M <= 4: the int8-contraction GEMV reads it, round 4) and prompts (M >= 192: the 128-row GEMM).
+    // The packed copy serves both ends: decode batches (M <= 4: the int8-contraction GEMV reads it, round 4) and prompts (M > 128: the 128-row GEMM).
     // One extra copy of the int4 weights per linear in HBM (an 8B-class model: +3.9 GB of 288); TCE_ADAPTER_PACK=0 keeps the q4_6 arrays only.
     static const bool pack_on = [] { const char *e = std::getenv("TCE_ADAPTER_PACK"); return !(e && e[0] == '0'); }();
     if (pack_on && (d.M <= 4 || d.M >= kPackMinM) && d.K % 128 == 0 && d.A && d.qweight && d.scales && d.zeros) {

@@ -74,7 +74,7 @@ int64_t tce_w4a16_algorithmic_bytes(int M, int N, int K, int G) {
 }
 
 int g_pk_mode = 0;  // 0 automatic, 1 / 2 / 3 forced form (taken whenever a packed copy is given), 9 off
-constexpr int kPkMinM = 192;  // below: the 64-row tiles / the small-batch kernel waste fewer rows
+constexpr int kPkMinM = 129;  // below: the 64-row tiles / the small-batch kernel waste fewer rows (192 until round 4: from 129 rows on two 128-row tiles already beat the 64-row tiles on the wide linears -- 160 x 11008 x 4096: 42.4 -> 32.6 us -- and the cost models keep N = 4096 with the 64-row kernel)
 
 // the pre-packed 128-row GEMM takes the launch when a packed copy came with the descriptor and the batch is large enough
 static bool use_pk(const tce_w4a16_desc *d, bool want_gemm) {

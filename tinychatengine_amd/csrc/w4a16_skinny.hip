@@ -375,7 +375,11 @@ bool skinny_supports(const tce_w4a16_desc &d) {
     // when N is small (4096 x 4096, M = 32: 64 workgroups, 24 us; here 8.8 us) and win once there are enough of them
     // (22016 x 4096 from M = 24).  Both estimates in us, fitted to profiles/r1/m_sweep_17_384.jsonl and gemm_dma_*.jsonl.
     const float scale = (float)d.N / 4096.f * (float)d.K / 4096.f;
-    const float here = (4.0f + 2.3f * (float)((d.M + 15) / 16)) * scale;
+    // (round 4, scripts/mid_m_sweep.py: 5.5 / 7.8 / 10.4 / 12.5 / 19.8 us at 1 / 2 / 3 / 4 / 6 slices on 4096 x 4096 -- the sixth slice costs more than the first five suggest,
+    //  and at M = 96 the GEMM was ahead on both N = 4096 shapes: 16.1 against 19.8 us, 37.9 against 46.7 at K = 11008; never more than four slices)
+    const int slices = (d.M + 15) / 16;
+    if (slices > 4) return false;
+    const float here = (3.0f + 2.5f * (float)slices) * scale;
     const float gemm = gemm_dma_estimate_us(d.M, d.N, d.K);  // (fitted to the same sweeps; 16.6 us measured at M = 128, 4096 x 4096 against 19.2)
     return here < gemm;
 }

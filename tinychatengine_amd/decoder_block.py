@@ -102,7 +102,7 @@ class DecoderBlock:
         self.attention.prefill(qkv, pos, out=attn, causal=True)
         capi.check(capi.w4a16_forward(self.o.desc(attn, hidden_rows, flags=capi.TCE_W4_ADD_TO_C), st))
         rmsnorm_half(hidden_rows, self.gamma2, self.eps, out=xn)
-        if m >= 192 and self.gate_up.packed is not None:  # gate + up + SiLU*mul as ONE GEMM launch on the interleaved rows (pair epilogue of the 128-row GEMM)
+        if m > 128 and self.gate_up.packed is not None:  # gate + up + SiLU*mul as ONE GEMM launch on the interleaved rows (pair epilogue of the 128-row GEMM)
             capi.check(capi.w4a16_forward(self.gate_up.desc(xn, g, flags=capi.TCE_W4_SILU_MUL_PAIRS), st))
         else:
             capi.check(capi.w4a16_forward(self.gate.desc(xn, g), st))
@@ -110,7 +110,7 @@ class DecoderBlock:
             capi.check(capi.lib().tce_silu_mul_half(g.data_ptr(), u.data_ptr(), g.numel(), st))
         capi.check(capi.w4a16_forward(self.down.desc(g, hidden_rows, flags=capi.TCE_W4_ADD_TO_C), st))
 
-    PREFILL_LAUNCHES = 8  # with pre-packed weights and m >= 192 (otherwise 10: gate, up and SiLU*mul as three launches)
+    PREFILL_LAUNCHES = 8  # with pre-packed weights and m > 128 (otherwise 10: gate, up and SiLU*mul as three launches)
 
     def linear_bytes(self) -> int:
         return sum(capi.algorithmic_bytes(1, l.out_features, l.in_features, l.group_size) for l in (self.qkv, self.o, self.gate_up, self.down))

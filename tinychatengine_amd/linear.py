@@ -91,7 +91,7 @@ class Linear_half_int4:
                               C=out.data_ptr(), ldc=ldc, flags=flags | (capi.TCE_W4_ZERO_POINT_IS_8 if self.zeros_are_8 else 0),
                               rmsnorm_gamma=gamma.data_ptr() if gamma is not None else None, rmsnorm_eps=float(eps),
                               prepacked=self.packed.data_ptr() if self.packed is not None else None,
-                              scratch=gemm_scratch(self.weight.device).data_ptr() if self.packed is not None and m >= 192 else None)
+                              scratch=gemm_scratch(self.weight.device).data_ptr() if self.packed is not None and m > 128 else None)
 
     @classmethod
     def interleave(cls, gate: "Linear_half_int4", up: "Linear_half_int4") -> "Linear_half_int4":
