@@ -478,7 +478,7 @@ TCE_API int tce_w4a16_set_gemv_config(int rows_per_wave, int waves_n, int waves_
 /* The decode kernel on pre-packed copies (csrc/w4a16_gemv_i8.hip: M <= 4 rows as an exact int8 contraction on the matrix pipe; taken by tce_w4a16_forward /
  * _forward_group / plans whenever every descriptor of the launch carries `prepacked`, K % 128 == 0 and no fused RMSNorm prologue is asked for; group sizes 64 / 32:
  * M <= 2 / M = 1).  mode 0 = that rule, 1 = off (the fp16 GEMV kernels on the q4_6 arrays take those launches: A/B runs); rows = 16-row tiles per wave for the
- * M = 1, K <= 8192 launches: 0 = the rule (two from 1024 tiles up), 1, 2.  A row's arithmetic depends on K, the group size and the rows per pass only -- never on N or on
+ * M = 1, K <= 8192 launches: 0 = the rule (one; two with the RMSNorm prologue where one leaves a short second generation of workgroups), 1, 2.  A row's arithmetic depends on K, the group size and the rows per pass only -- never on N or on
  * `rows`: column shards and grouped launches are bit-identical to the plain launch.  Process-wide; results do not depend on it beyond the kernel family. */
 TCE_API int tce_w4a16_set_gemv_i8(int mode, int tiles_per_wave);
 /* Tuning / diagnostics switch for the sweeps under scripts/ (process-wide, not thread-safe, never needed by a host):

@@ -538,12 +538,15 @@ int launch_w4a16_gemv_i8(const tce_w4a16_desc *descs, int count, hipStream_t str
     const int m_blocks = (d0.M + mb - 1) / mb;
     // tiles per wave: one.  Two (the conversion of x amortised over twice the bytes, one generation of workgroups for the gate+up launch) measured slower on every
     // launch of the token (profiles/r4/gemv_i8_ab.jsonl: qkv 6.6 -> 7.4 us, o 3.9 -> 4.5, gate+up 9.9 -> 10.2, down a tie); compiled, forceable (tce_w4a16_set_gemv_i8)
-    // With the RMSNorm prologue -- x, gamma, the piece sums and the normalisation on top of the conversion, all per wave -- two tiles per wave win on the wide launch:
-    // norm + gate/up of a 4096 x 11008 layer 11.84 -> 11.31 us; norm + q/k/v (768 tiles) 7.7 -> 8.3, so only from 1024 tiles on.  (The tile count per wave does not
-    // enter the arithmetic: same bits.)
+    // With the RMSNorm prologue -- x, gamma, the piece sums and the normalisation on top of the conversion, all per wave -- two tiles per wave win where one tile per
+    // workgroup leaves a short second generation of workgroups behind the resident ones (256 CUs x 20 waves at five per SIMD: 1280 four-wave workgroups): norm + gate/up of
+    // a 4096 x 11008 layer, 1376 tiles, 11.84 -> 11.31 us.  Elsewhere one tile per wave is level or ahead (scripts/probes/norm_tiles_ab.py: 768 tiles 7.1 / 8.3 us,
+    // 1024: 8.65 / 9.04, 1280: 10.4 / 11.1, 1536: 11.6 / 11.75, 1792: 12.9 / 13.5, 2000: 14.2 / 14.0, 8016: 43.3 / 43.8).  (The tile count per wave does not enter
+    // the arithmetic: same bits.)
     int rows = 1;
     const bool two_ok = mb == 1 && gpu == 1 && uw == 8 && wk <= 8;
-    if (gamma && two_ok && total_tiles >= 1024) rows = 2;
+    const long long resident = 256LL * (20 / wk);
+    if (gamma && two_ok && total_tiles > resident && total_tiles * 5 <= resident * 6) rows = 2;
     if (g_i8_rows && two_ok) rows = g_i8_rows;
     int blocks = 0;
     for (int i = 0; i < count; ++i) {
