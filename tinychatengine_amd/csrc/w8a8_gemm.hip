@@ -713,7 +713,8 @@ int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err)
         // Rule (round 4, scripts/w8a8_form_sweep.py over 36 launches, profiles/r4/w8a8_form_sweep_*.jsonl): from 48 k-steps on it is level with or ahead of the kernel above at every
         // tile count this branch sees -- 2048 x 768 x 3072: 25.6 -> 19.9 us, 108 x 768 x 3072: 15.3 -> 13.6, 512 x 2048 x 8192: 38.5 -> 30.3, 16 x 4096 x 16384: 58 -> 39 -- and behind it
         // at 32 and 12 steps (512 x 2048 x 2048: 10.2 -> 11.1; 512 x 768 x 768: 6.3 -> 8.0).  Two quartets up to 256 tiles (up to 512 from 128 steps on: 512 x 4096 x 8192 47.4 -> 44.8), one beyond; four were never ahead.
-        const bool deep = g_w8a8_deep != 9 && d.K % 64 == 0 && (g_w8a8_deep > 0 || d.K / 64 >= 48);
+        // (48 .. 63 steps on 64 .. 256 tiles stay with the kernel above: a tie on weights from HBM -- 512 x 768 x 3072 13.1 / 13.2 us --, 6 % behind on weights that sit in L2: 11.5 / 10.85)
+        const bool deep = g_w8a8_deep != 9 && d.K % 64 == 0 && (g_w8a8_deep > 0 || d.K / 64 >= 64 || (d.K / 64 >= 48 && (tiles < 64 || tiles > 256)));
         if (deep) {
             const int dks = g_w8a8_deep == 1 || g_w8a8_deep == 2 || g_w8a8_deep == 4 ? g_w8a8_deep : (tiles <= 256 || (tiles <= 512 && d.K / 64 >= 128) ? 2 : 1);
             const size_t dl = (size_t)dks * 2 * 512 * 16;  // (>= the reduction's (dks - 1) * 16 KiB)
