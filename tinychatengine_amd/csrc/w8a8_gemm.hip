@@ -669,8 +669,9 @@ int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err)
     a.vec_ok = aligned ? 1 : 0;
     const bool rowdot_ok = aligned && g_w8a8_ks != 3;
     // wave-per-column for M <= 4, and for 5 .. 8 rows when K is long (8 x 768 x 768: 5.2 us against the MFMA kernel's 4.6; 8 x 768 x 3072: 6.5 against 9.8;
-    // 1 x 768 x 3072: 3.4 against 9.4 -- scratch measurements of round 3)
-    if (rowdot_ok && !d.b_per_row && d.M <= kRowdotMaxM && (d.M <= 4 || d.K >= 2048) && d.K >= 64 && (size_t)d.M * d.K <= 64 * 1024) {
+    // 1 x 768 x 3072: 3.4 against 9.4 -- scratch measurements of round 3); from 3 rows on only up to 4096 columns (round 4, scripts/probes/w8a8_rowdot_ab.py: a wave per
+    // column walks all M rows -- 8 x 16384 x 4096: 30.5 us against the MFMA tiles' 15.6; 5 x 8192 x 2048: 10.4 against 9.2)
+    if (rowdot_ok && !d.b_per_row && d.M <= kRowdotMaxM && (d.M <= 2 || (d.N <= 4096 && (d.M <= 4 || d.K >= 2048))) && d.K >= 64 && (size_t)d.M * d.K <= 64 * 1024) {
         hipLaunchKernelGGL(w8a8_rowdot_kernel<0>, dim3((d.N + 3) / 4, 1, d.batch), dim3(256), (size_t)d.M * d.K, stream, a);
     } else if (rowdot_ok && d.b_per_row && d.batch == 1 && d.K >= 256) {
         const long long outs = (long long)d.M * d.N;
