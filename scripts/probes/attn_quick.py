@@ -7,7 +7,7 @@ from tune import dev, time_graph, capi
 from tinychatengine_amd.attention_ops import DecodeAttention
 L = capi.lib()
 al = int(np.array([0.0884], np.float16).view(np.uint16)[0])
-H, KV = 32, 8
+H, KV = 32, int(os.environ.get("ATTN_KV_HEADS", "8"))
 qkv = torch.randn((H + 2 * KV) * 128, device=dev).half()
 oo = torch.empty(H, 128, dtype=torch.float16, device=dev)
 for mode in os.environ.get("ATTN_MODES", "0").split(","):  # e.g. "0,2916+3032": debug modes applied together (2900 + waves, 3000 + workgroups)

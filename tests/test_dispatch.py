@@ -59,7 +59,7 @@ def test_cost_model_prefers_fewer_rounds():
 
 
 def test_attention_step_cut_rule():
-    """The fitted rule of the fast attention step: one chunk per head and no combine up to 320 keys, four chunks up to 640 (1024 until round 4),
+    """The fitted rule of the fast attention step: one chunk per head and no combine up to 320 keys, four chunks up to 1024 (up to 640 with four query heads per key / value head: round 4),
     eight chunks of at most 512 keys beyond; every chunk a multiple of 16 keys (four waves x four keys per step), all keys covered,
     never more chunks than the workspace was sized for (64-key chunks)."""
     from tinychatengine_amd import capi
@@ -73,9 +73,11 @@ def test_attention_step_cut_rule():
             assert d["workgroups"] == heads * chunks and d["combine"] == ("yes" if chunks > 1 else "no")
             if keys <= 320:
                 assert chunks == 1
-            elif keys <= 640:
+            elif keys <= 640 or (keys <= 1024):  # (multi-head launches -- describe_attention_step(heads, keys) -- keep four chunks up to 1024 keys; grouped queries: below)
                 assert chunks in (3, 4), (keys, d)  # (ceil(keys / 4) rounded up to 16 keys can leave the fourth chunk empty: 321..336 keys)
             elif keys <= 4096:
                 assert chunks in (6, 7, 8), (keys, d)  # (641..672 keys: ceil(keys / 8) rounded up to 16 keys leaves fewer chunks)
             else:
                 assert chunk == 512
+    for keys, want in ((512, (4,)), (640, (4,)), (641, (6, 7, 8)), (1024, (8,)), (2048, (8,))):  # grouped queries, 32 over 8
+        assert capi.describe_attention_step(32, keys, 8)["chunks"] in want, keys

@@ -378,7 +378,7 @@ void set_attention_fast_target(int wgs) { g_attn_target_wgs = wgs >= 32 && wgs <
 //   128 keys: one chunk 4.5 us, two 6.0          256: one chunk 6.5, two or four 7.0        512: 8.9 / 8.6 / 7.6 / 8.5 for 1 / 2 / 4 / 8 chunks
 //   1024: 9.0 with 4 chunks, 9.3 with 8, 12.5 with 16      2048: 12.0 / 11.8 / 13.7 with 4 / 8 / 16      4096: 18.6 / 16.7 / 18.3
 //   8192: 30.0 / 28.9 / 33.4 with 8 / 16 / 32
-// Rule: up to 320 keys one chunk per head and no combine; up to 640 four chunks (1024 until round 4); beyond, eight chunks of at most 512 keys.
+// Rule: up to 320 keys one chunk per head and no combine; four chunks up to 1024 keys (up to 640 with 4+ query heads per key / value head: round 4); beyond, eight chunks of at most 512 keys.
 // A combine without the acknowledged-store -> counter -> coherent-read chain (the head's last workgroup polling (value, tag) pairs)
 // was tried and was SLOWER (13.2 us at 2048 keys): a poll is a full memory round trip, and the chain it replaces is three of them
 // only on the LAST workgroup.  So was the hybrid -- (value, tag) pairs stored without waiting for acknowledgements, the counter only
@@ -393,7 +393,7 @@ static int g_attn_fuse = 0;  // tuning: query heads per workgroup for grouped-qu
 void set_attention_fast_fuse(int r) { g_attn_fuse = (r == 1 || r == 2 || r == 4) ? r : 0; }
 
 // `heads` here = workgroup groups (query heads / heads per workgroup)
-static void pick_chunk(int heads, int keys, int *chunk_out, int *waves_out) {
+static void pick_chunk(int heads, int keys, int rep, int *chunk_out, int *waves_out) {
     int chunk;
     if (g_attn_target_wgs > 0) {
         const int target_chunks = heads >= g_attn_target_wgs ? 1 : g_attn_target_wgs / heads;
@@ -401,7 +401,8 @@ static void pick_chunk(int heads, int keys, int *chunk_out, int *waves_out) {
         if (chunk < 64) chunk = 64;
     } else if (keys <= 320) {
         chunk = keys;
-    } else if (keys <= 640) {  // (round 4, after the block softmax: 1024 keys 8.7 us with four chunks, 8.2 with eight; 512 keys 7.25 / 7.45)
+    } else if (keys <= (rep >= 4 ? 640 : 1024)) {  // (round 4, after the block softmax, 4 query heads per key / value head: 1024 keys 8.7 us with four chunks, 8.2 with eight; 512 keys 7.25 / 7.45.
+                                                   //  One query head per key / value head -- four times the cache bytes per query head --: 768 / 1024 keys 8.4 / 8.75 with four, 8.9 / 9.2 with eight)
         chunk = (keys + 3) >> 2;
     } else {
         chunk = (keys + 7) >> 3;
@@ -431,7 +432,7 @@ static int pick_fuse(int rep) {
 
 void describe_attention_decode_fast(int heads, int keys, int *chunk, int *chunks, int *waves, int kv_heads) {
     const int rep = kv_heads > 0 ? heads / kv_heads : 1;
-    pick_chunk(heads / pick_fuse(rep), keys, chunk, waves);
+    pick_chunk(heads / pick_fuse(rep), keys, rep, chunk, waves);
     *chunks = (keys + *chunk - 1) / *chunk;
 }
 
@@ -470,7 +471,7 @@ int launch_attention_decode_fast(const void *qkv, void *kc, void *vc, const void
     a.keys = pos + 1;
     a.pos_dev = pos_dev;
     int nw = 4;
-    pick_chunk(heads / fuse, a.keys, &a.chunk, &nw);
+    pick_chunk(heads / fuse, a.keys, rep, &a.chunk, &nw);
     a.chunks = (a.keys + a.chunk - 1) / a.chunk;
     if (a.chunks > 1024) return TCE_ERR_UNSUPPORTED_SHAPE;  // (the combine's LDS image; unreachable with the fitted rule below 500k keys)
     half_t ah;
