@@ -121,7 +121,16 @@ def compact_line(full: dict, details_file: str | None = None, budget: int = LINE
         opt(1, "cpu_baseline_ref_naive", {"value": rn.get("value"), "unit": rn.get("unit"), "cores": rn.get("cores"), "kind": rn.get("kind"), "sample": str(rn.get("sample", ""))[:90]})
     ap_ = full.get("adapter_path")
     if isinstance(ap_, dict):
-        opt(0, "adapter_path", ap_)
+        a = ap_.get("adapter") if isinstance(ap_.get("adapter"), dict) else {}
+        c_ = {"model": ap_.get("model"), "keys": ap_.get("keys"), **{k: a.get(k) for k in ("tokens_per_s", "ms_per_token_wall", "ms_per_token_events", "host_us_per_call", "launches_per_token")}}
+        for leg in ("capi_eager", "capi_graph"):
+            if isinstance(ap_.get(leg), dict):
+                c_[leg + "_tokens_per_s"] = ap_[leg].get("tokens_per_s")
+                c_[leg + "_host_us_per_call"] = ap_[leg].get("host_us_per_call")
+        for k in ("adapter_over_graph", "adapter_first_token_ms", "error"):
+            if k in ap_:
+                c_[k] = ap_[k] if k != "error" else str(ap_[k])[:160]
+        opt(0, "adapter_path", c_)
     for key in ("baseline_named_shapes", "llama3_8b_true_shapes"):
         sec = full.get(key)
         if isinstance(sec, dict):
@@ -448,6 +457,31 @@ def launch_shape_table(dl, torch, launches: int = 128):
     return rows
 
 
+def random_zero_points_leg(dl, torch, layers: int = 8, launches: int = 128):
+    """The dominant launch with REAL (random) zero points: the same gate+up weights, the zero-point words replaced and re-packed, so the kernel reads them and runs
+    its general-zero-point form (one more MFMA pair per unit for (8 - z) * sum x, csrc/w4a16_gemv_i8.hip; reference: gemv_cuda.cu:159-166 reads them too).
+    Timed exactly like roofline.shapes' rows (a graph of back-to-back launches rotating over `layers` weight sets: 8 x 61 MB > the 256 MB cache)."""
+    from tinychatengine_amd.linear import Linear_half_int4
+    groups, keep = [], []
+    g = torch.Generator(device=dl.device).manual_seed(77)
+    for li in range(min(layers, dl.n_layers)):
+        b = dl.blocks[li]
+        pair = []
+        for lin, out in ((b["gate"], dl.out_gate), (b["up"], dl.out_up)):
+            z = torch.randint(-(1 << 31), (1 << 31) - 1, lin.zero_point.shape, dtype=torch.int64, device=dl.device, generator=g).to(torch.int32)
+            l2 = Linear_half_int4(lin.weight, lin.scale, z, lin.group_size).prepack()
+            assert not l2.zeros_are_8
+            keep.append(l2)
+            pair.append(l2.desc(dl.h2, out))
+        groups.append(pair)
+    torch.cuda.synchronize()
+    r = roofline_leg(dl, torch, launches, quick=True, groups=groups)
+    same = roofline_leg(dl, torch, launches, quick=True, groups=[dl.block_launches(li)[2] for li in range(len(groups))])
+    zb = sum(d.N * d.K // (2 * d.group_size) for d in groups[0])
+    return {"launch": r["launch"], "us": r["us"], "bytes_with_zero_points": r["bytes"], "GBs": r["GBs"], "frac_of_8TBs": r["frac_of_8TBs"], "kernel": r["kernel"],
+            "us_zero_point_8": same["us"], "frac_zero_point_8": same["frac_of_8TBs"], "zero_point_bytes": zb, "weight_sets": len(groups)}
+
+
 def shapes_only_leg(dl, torch, dev, shape, eager: bool):
     """Every launch shape of the token and the attention step on their own, for rocprofv3 (scripts/profile_r3.sh): graph-replayed exactly
     like `other_configs.decode_launch_shapes` of the bench line, or (eager) as plain launches for the PMC passes, which serialise kernels."""
@@ -727,6 +761,26 @@ def whole_token_leg(torch, dev, shape, dl):
     del blocks
     torch.cuda.empty_cache()
     return out
+
+
+def adapter_path_leg(workload: str, keys: int = 512):
+    """The DROP-IN path on the clock: tinychatengine_amd/lib/adapter_bench (adapter/adapter_bench.cc, plain C++) issues whole decode tokens the way
+    the reference's host does -- matmul::MatmulOperator::gemv_forward_cuda per linear through libtce_matmul_operator.so, null stream, eager, the reference's glue order
+    (Int4llamaDecoderLayer.cu:73-115) -- 200 tokens after 20, wall-clock + HIP events + host time per call; beside it the same launch list through the C ABI directly
+    (eager, and captured into one hipGraph).  Runs as its own process while this one is idle."""
+    import subprocess
+    exe = os.path.join(REPO, "tinychatengine_amd", "lib", "adapter_bench")
+    model = {"llama3-8b": "llama3-8b", "baseline-named": "llama2-7b", "tiny": "tiny"}.get(workload)
+    if model is None or not os.path.exists(exe):
+        return {"error": f"no adapter_bench for workload {workload}" if model is None else f"{exe} not built (python -m tinychatengine_amd.build)"}
+    r = subprocess.run([exe, "--model", model, "--tokens", "200", "--warmup", "20", "--keys", str(keys)], capture_output=True, text=True, timeout=600)
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": f"adapter_bench rc {r.returncode}: {(r.stdout + r.stderr)[-300:]}"}
+    d = json.loads(lines[-1])
+    d["how"] = ("adapter/adapter_bench.cc: MatmulOperator::gemv_forward_cuda per linear (fused qkv, o, gate, up, down, lm_head), null stream, eager; glue = tce_rmsnorm_half / tce_add_half / "
+                "tce_silu_mul_half + one attention-step launch; 11 launches per block; capi_* = the same launch list through the C ABI without the adapter")
+    return d
 
 
 def _pmc_traffic(bytes_per_launch):
@@ -1231,6 +1285,10 @@ def main():
             extras["decode_launch_shapes"] = launch_shape_table(dl, torch)
         except Exception as e:  # noqa: BLE001
             extras["decode_launch_shapes"] = {"error": f"{type(e).__name__}: {e}"}
+        try:  # the cost of real AWQ zero points on the dominant launch
+            extras["gate_up_random_zero_points"] = random_zero_points_leg(dl, torch)
+        except Exception as e:  # noqa: BLE001
+            extras["gate_up_random_zero_points"] = {"error": f"{type(e).__name__}: {e}"}
         if args.workload in ("baseline-named", "llama3-8b") and not args.no_projection:
             try:  # SURVEY 8e on one GPU: per-rank shard compute at N/P rows, measured; the exchange side assumed and labelled
                 extras["projected_scaling"] = projected_scaling_leg(torch, dev, G, prepack)
@@ -1271,6 +1329,14 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:  # noqa: BLE001
                 secondary = {"error": f"{type(e).__name__}: {e}"}
+
+    adapter = None
+    if rank == 0 and world == 1 and not args.no_extras and args.workload in ("baseline-named", "llama3-8b", "tiny"):
+        torch.cuda.synchronize()
+        try:
+            adapter = adapter_path_leg(args.workload)
+        except Exception as e:  # noqa: BLE001
+            adapter = {"error": f"{type(e).__name__}: {e}"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -1325,6 +1391,8 @@ def main():
                 out["w8a8_opt125m_shapes"] = {"note": "tce_w8a8_matmul, bit-exact with kernels/ref/matmul_ref_int8.cc; graphs of 64 back-to-back launches on ONE weight set (L2-resident; the whole model is 94 MB: other_configs.w8a8_opt125m_layer walks per-layer weights), HIP events; boundary = 1.55 us per dependent launch",
                                               "launches": cfg4}
             out["other_configs"] = extras
+        if adapter is not None:
+            out["adapter_path"] = adapter
         if cpu is not None:
             main_cpu = cpu.get("avx") or cpu.get("ref")
             if main_cpu:

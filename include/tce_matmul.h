@@ -47,7 +47,7 @@ extern "C" {
 
 #define TCE_API __attribute__((visibility("default")))
 
-#define TCE_VERSION 108 /* 0.1.8: per-family tuning setters (tce_attention_set_tuning, tce_w8a8_set_tuning); 0.1.7: decode on the pre-packed copy (int8 contraction), tce_w4a16_set_gemv_i8; 0.1.6: TCE_PLAN_TUNED; 0.1.5: tce_opt_attention_decode; 0.1.4: tce_attention_prefill_f16 (0.1.3: tce_attention_decode_step_gqa_f16, TCE_PLAN_OVERLAPPED; 0.1.2: tce_w4a16_desc.scratch; 0.1.1: .prepacked, tce_w4a16_prepack*) */
+#define TCE_VERSION 109 /* 0.1.9: tce_w4a16_check_zero_point_8_async, tce_host_alloc / tce_host_free (the adapter no longer synchronises); 0.1.8: per-family tuning setters (tce_attention_set_tuning, tce_w8a8_set_tuning); 0.1.7: decode on the pre-packed copy (int8 contraction), tce_w4a16_set_gemv_i8; 0.1.6: TCE_PLAN_TUNED; 0.1.5: tce_opt_attention_decode; 0.1.4: tce_attention_prefill_f16 (0.1.3: tce_attention_decode_step_gqa_f16, TCE_PLAN_OVERLAPPED; 0.1.2: tce_w4a16_desc.scratch; 0.1.1: .prepacked, tce_w4a16_prepack*) */
 
 /* error codes (return values) */
 #define TCE_OK 0
@@ -235,6 +235,11 @@ TCE_API int tce_silu_mul_half(void *a, const void *b, long long n, void *stream)
 /* Load-time helper for TCE_W4_ZERO_POINT_IS_8: returns 1 if all `n_words` packed zero-point words are 0x88888888, 0 if
  * not, negative on error.  Synchronous; call it once per weight tensor (weights are immutable after loading). */
 TCE_API int tce_w4a16_check_zero_point_8(const void *zeros, long long n_words);
+/* The same check WITHOUT a synchronisation (round 5; what the C++ adapter uses inside gemv_forward_cuda, whose contract is "asynchronous, never syncs" --
+ * kernels/cuda/gemv_cuda.cu:237-251): enqueues one kernel on `stream` that writes 1 (every word is 0x88888888) or 2 (not) to *verdict when it has run.
+ * `verdict` must be a word the device can write and the host can read without a copy -- tce_host_alloc memory -- and should be 0 on entry; the caller polls it
+ * with plain loads.  Returns after the launch. */
+TCE_API int tce_w4a16_check_zero_point_8_async(const void *zeros, long long n_words, int *verdict, void *stream);
 
 /* Load-time re-layout for the prefill GEMM ("offline pre-swizzle to an MFMA-friendly tile layout"; no reference
  * counterpart -- the reference re-runs its GEMV M times).  tce_w4a16_prepack reads qweight / scales / zeros (+ strides) of `d`
@@ -245,7 +250,7 @@ TCE_API int tce_w4a16_check_zero_point_8(const void *zeros, long long n_words);
  * `stream`; once per weight tensor.  A descriptor whose `prepacked` points at that copy lets tce_w4a16_forward run the 128-row
  * MFMA kernel (csrc/w4a16_gemm_pk.hip) for M > 128 (where its cost model beats the 64-row kernel's); results stay within the W4A16 tolerance of every other path. */
 TCE_API size_t tce_w4a16_prepack_bytes(int N, int K, int group_size);
-TCE_API size_t tce_w4a16_gemm_scratch_bytes(void); /* size of tce_w4a16_desc.scratch (about 18 MiB) */
+TCE_API size_t tce_w4a16_gemm_scratch_bytes(void); /* size of tce_w4a16_desc.scratch (32 MiB + 4 KiB) */
 TCE_API int tce_w4a16_prepack(const tce_w4a16_desc *d, void *packed, void *stream);
 
 /* count (<= TCE_MAX_GROUP) linears with identical M, K, group_size and A/lda, one launch (GEMV path only). */
@@ -451,6 +456,9 @@ TCE_API void tce_comm_destroy(tce_comm *comm);
 #define TCE_MEMCPY_D2D 2
 TCE_API int tce_malloc(void **ptr, size_t bytes, int managed);
 TCE_API int tce_free(void *ptr);
+/* Pinned, device-mapped, coherent host memory (hipHostMalloc): small words the device writes and the host polls (see tce_w4a16_check_zero_point_8_async). */
+TCE_API int tce_host_alloc(void **ptr, size_t bytes);
+TCE_API int tce_host_free(void *ptr);
 TCE_API int tce_memcpy(void *dst, const void *src, size_t bytes, int kind, void *stream);
 TCE_API int tce_synchronize(void *stream);
 TCE_API int tce_device_count(void);

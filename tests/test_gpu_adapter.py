@@ -65,3 +65,46 @@ def test_cpp_adapter_selftest(oracle, tmp_path):
     print(r.stdout, r.stderr)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("Passed!") == 4 and "Fail!" not in r.stdout
+
+
+def test_adapter_bench_tiny_runs_every_leg():
+    """adapter/adapter_bench.cc (the drop-in path on the clock: MatmulOperator::gemv_forward_cuda per linear, null stream, eager, the reference's glue order) on the
+    tiny model: all three legs run, every launch is counted (11 per block + final norm + lm_head), the logits are finite, the adapter holds one packed copy per linear."""
+    import json
+    from tinychatengine_amd import build as B
+    B.build_adapter()
+    r = subprocess.run([B.ADAPTER_BENCH_PATH, "--model", "tiny", "--tokens", "20", "--warmup", "3", "--keys", "96"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["non_finite_logits"] == 0
+    for leg in ("adapter", "capi_eager", "capi_graph"):
+        assert d[leg]["launches_per_token"] == 11 * 2 + 2 and d[leg]["tokens_per_s"] > 0 and d[leg]["ms_per_token_events"] > 0
+    assert d["adapter_device_bytes"] > 0
+
+
+def test_adapter_never_synchronises_in_steady_state(tmp_path):
+    """SURVEY 8b: the operator is asynchronous and never syncs.  Round 4's adapter read the zero-point verdict back with a blocking copy on first sight of a tensor;
+    round 5 polls a pinned word.  rocprofv3's HIP-API trace of adapter_bench (adapter leg only, 3 + 10 tokens): between the first hipEventRecord and the second --
+    the timed tokens -- there is no hipDeviceSynchronize / hipStreamSynchronize / hipMemcpy* at all."""
+    import csv
+    import glob
+    import shutil
+    from tinychatengine_amd import build as B
+    B.build_adapter()
+    if not shutil.which("rocprofv3"):
+        pytest.skip("rocprofv3 not on PATH")
+    out = tmp_path / "trace"
+    env = dict(os.environ, TMPDIR=str(tmp_path))
+    r = subprocess.run(["rocprofv3", "--hip-runtime-trace", "--output-format", "csv", "-d", str(out), "--", B.ADAPTER_BENCH_PATH, "--model", "tiny", "--tokens", "10", "--warmup", "3",
+                        "--keys", "96", "--legs", "adapter"], capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    files = glob.glob(str(out / "**" / "*hip_api_trace.csv"), recursive=True)
+    assert files, os.listdir(out)
+    rows = sorted(csv.DictReader(open(files[0])), key=lambda x: int(x["Start_Timestamp"]))
+    names = [x["Function"] for x in rows]
+    rec = [i for i, n in enumerate(names) if n == "hipEventRecord"]
+    assert len(rec) >= 2
+    timed = names[rec[0] + 1:rec[1]]
+    assert sum(n in ("hipLaunchKernel", "hipModuleLaunchKernel", "hipExtModuleLaunchKernel", "hipExtLaunchKernel") for n in timed) >= 10 * 24
+    blocking = [n for n in timed if "Synchronize" in n or n.startswith("hipMemcpy") or n.startswith("hipMemset") or "Malloc" in n or "Free" in n]
+    assert not blocking, sorted(set(blocking))

@@ -10,13 +10,16 @@
 //     (gemv_cuda.cu:254-256); its asserts become the same exit path.
 #include "tce_matmul_operator.h"
 
+#include <atomic>
 #include <cstddef>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 
 #include "tce_matmul.h"
 
@@ -62,10 +65,10 @@ struct AwqEntry {
     const void *scales = nullptr, *zeros = nullptr;  // packed copies: the side tensors the copy was built from (it embeds them)
 };
 std::mutex g_mu;
-std::unordered_map<TensorKey, int, TensorKeyHash> g_zero;       // zero-point tensor -> every packed zero point is 8
 std::unordered_map<TensorKey, AwqEntry, TensorKeyHash> g_awq;   // AWQ weight tensor -> re-laid-out copy
 std::unordered_map<TensorKey, AwqEntry, TensorKeyHash> g_pack;  // q4_6 weight tensor -> q4_mfma copy (decode GEMV M <= 4, prefill GEMM M >= kPackMinM)
 constexpr int kPackMinM = 129;
+std::atomic<uint64_t> g_generation{1};  // bumped by tce_adapter_forget* and by a re-pack: un-publishes every entry of the lock-free front cache below
 
 // The q4_mfma copy of a linear, built on first sight of a large batch (the reference's Linear_half_int4 has no load-time hook
 // the adapter could use: its constructor only reads files, llm/include/ops/linear.h:215-240).  Enqueued on the null stream in
@@ -86,6 +89,7 @@ const void *packed_copy(const tce_w4a16_desc &d) {
     // the copy embeds the scales and the zero points: the same weights with OTHER side tensors (a test harness; never a model) are packed again, into the same
     // buffer -- ordered behind every earlier reader by the null stream
     if (fresh || e.scales != d.scales || e.zeros != d.zeros) {
+        if (!fresh) g_generation.fetch_add(1, std::memory_order_acq_rel);  // the buffer changes under front-cache entries that point at it: un-publish them all
         const int rc = tce_w4a16_prepack(&d, e.workspace, nullptr);
         if (rc != TCE_OK) die("gemv_forward_cuda (prepack)", rc);
         e.scales = d.scales;
@@ -106,26 +110,105 @@ void *gemm_scratch() {
         void *p = nullptr;
         if (need && tce_malloc(&p, need, /*managed=*/0) == TCE_OK) {
             static const unsigned char zeros[4096] = {};
-            if (tce_memcpy(p, zeros, sizeof(zeros), TCE_MEMCPY_H2D, nullptr) == TCE_OK && tce_synchronize(nullptr) == TCE_OK) area = p;
+            if (tce_memcpy(p, zeros, sizeof(zeros), TCE_MEMCPY_H2D, nullptr) == TCE_OK) area = p;  // (null stream: ordered in front of every GEMM; the source is static -- no synchronisation)
             else tce_free(p);
         }
     }
     return area;
 }
 
-// TCE_W4_ZERO_POINT_IS_8 fast path: checked once per zero-point tensor
-int zeros_are_8(const void *zeros, long long words) {
-    const TensorKey key{zeros, words, 0, 0};
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        auto it = g_zero.find(key);
-        if (it != g_zero.end()) return it->second;
+// TCE_W4_ZERO_POINT_IS_8 fast path, decided once per zero-point tensor WITHOUT a host synchronisation (round 5; the operator's contract is "asynchronous, never
+// syncs"): first sight enqueues a check kernel on the null stream that writes its verdict into a word of pinned, device-mapped host memory; until that
+// word is non-zero the calls simply do not make the promise (the kernels then READ the zero points -- same bits when they are all 8); a later call -- in practice
+// the next token -- finds the verdict.  No hipMemcpy D2H, no hipDeviceSynchronize, on any call.
+struct ZeroState {
+    volatile int *verdict = nullptr;  // 0 pending, 1 every zero point is 8, 2 not
+    int known = 0;                    // cached verdict once it arrived
+};
+std::unordered_map<TensorKey, ZeroState, TensorKeyHash> g_zero_state;
+volatile int *g_verdict_pool = nullptr;  // pinned words, handed out one per zero-point tensor; chunks are never freed (a forgotten tensor's kernel may still be queued)
+size_t g_verdict_used = 0, g_verdict_cap = 0;
+
+volatile int *new_verdict_word() {  // g_mu held
+    if (g_verdict_used == g_verdict_cap) {
+        void *p = nullptr;
+        constexpr size_t kChunk = 4096;
+        if (tce_host_alloc(&p, kChunk * sizeof(int)) != TCE_OK) return nullptr;
+        g_verdict_pool = static_cast<volatile int *>(p);
+        g_verdict_used = 0;
+        g_verdict_cap = kChunk;
     }
-    const int r = tce_w4a16_check_zero_point_8(zeros, words);  // synchronous, once per tensor
-    if (r < 0) return 0;
+    volatile int *w = g_verdict_pool + g_verdict_used++;
+    *w = 0;
+    return w;
+}
+
+// 1: every zero point is 8 (verdict in); 0: not, or not known yet.  *final: the answer will not change.
+int zeros_are_8(const void *zeros, long long words, bool *final) {
+    const TensorKey key{zeros, words, 0, 0};
     std::lock_guard<std::mutex> lk(g_mu);
-    g_zero[key] = r;
-    return r;
+    ZeroState &z = g_zero_state[key];
+    if (!z.known) {
+        if (!z.verdict) {
+            z.verdict = new_verdict_word();
+            if (!z.verdict || tce_w4a16_check_zero_point_8_async(zeros, words, const_cast<int *>(z.verdict), nullptr) != TCE_OK) {
+                z.known = 2;  // no pinned memory / launch refused: never make the promise for this tensor
+            }
+        }
+        if (!z.known) z.known = *z.verdict;  // (a plain read of coherent host memory)
+    }
+    *final = z.known != 0;
+    return z.known == 1;
+}
+
+// ---- the hot path: a lock-free front cache of fully resolved decode calls --------------------------------------------------------------------------------
+// A steady-state token calls gemv_forward_cuda 161-225 times with tensors the adapter has seen; everything it needs per call -- the packed copy, the zero-point
+// verdict, the scratch area -- is then a pure function of (qweight, scales, zeros, N, K, G).  Round 4 took g_mu two or three times per call for it; now one
+// acquire load of a direct-mapped table entry.  Entries are immutable once published; tce_adapter_forget* bump the generation, which un-publishes all of them
+// (they are rebuilt from the maps below on the next call).  Retired entries are kept until process exit: a few dozen bytes per weight tensor.
+struct FrontEntry {
+    const void *qweight, *scales, *zeros;
+    int N, K, G;
+    const void *prepacked;
+    void *scratch;
+    int flags;
+    uint64_t generation;
+};
+constexpr size_t kFrontSize = 8192;  // direct-mapped, 2 probes; a 70B-class model has ~560 linears
+std::atomic<FrontEntry *> g_front[kFrontSize];
+std::vector<FrontEntry *> g_retired;  // g_mu
+
+inline size_t front_slot(const void *p) {
+    uint64_t x = reinterpret_cast<uintptr_t>(p) >> 6;
+    x ^= x >> 17;
+    x *= 0x9E3779B97F4A7C15ull;
+    return (size_t)(x >> 40) & (kFrontSize - 1);
+}
+inline const FrontEntry *front_find(const tce_w4a16_desc &d) {
+    const uint64_t gen = g_generation.load(std::memory_order_acquire);
+    const size_t s0 = front_slot(d.qweight);
+    for (size_t i = 0; i < 2; ++i) {
+        const FrontEntry *e = g_front[(s0 + i) & (kFrontSize - 1)].load(std::memory_order_acquire);
+        if (e && e->qweight == d.qweight && e->generation == gen && e->scales == d.scales && e->zeros == d.zeros && e->N == d.N && e->K == d.K && e->G == d.group_size) return e;
+    }
+    return nullptr;
+}
+void front_publish(const tce_w4a16_desc &d, uint64_t gen) {
+    auto *e = new FrontEntry{d.qweight, d.scales, d.zeros, d.N, d.K, d.group_size, d.prepacked, d.scratch, d.flags, gen};
+    const size_t s0 = front_slot(d.qweight);
+    size_t slot = s0;
+    for (size_t i = 0; i < 2; ++i) {  // an empty or stale probe, else the first (newest wins)
+        const FrontEntry *cur = g_front[(s0 + i) & (kFrontSize - 1)].load(std::memory_order_acquire);
+        if (!cur || cur->generation != gen) {
+            slot = (s0 + i) & (kFrontSize - 1);
+            break;
+        }
+    }
+    FrontEntry *old = g_front[slot].exchange(e, std::memory_order_acq_rel);
+    if (old) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_retired.push_back(old);
+    }
 }
 
 void int8_call(const char *who, const struct matmul_params *p, int bias_kind, int out_kind, int b_per_row) {
@@ -173,18 +256,33 @@ void MatmulOperator::gemv_forward_cuda(const struct matmul_params *params) {
     d.scales = params->half_scales;
     d.zeros = params->int32_zero_point;
     d.C = params->C.half_data_ptr;
-    if (d.group_size == 128 || d.group_size == 64 || d.group_size == 32) {
-        // rows of packed zero points: calculate_zeros_width (llm/src/nn_modules/cuda/utils.cu:162-178)
-        const int mult = d.group_size >= 128 ? 1 : (d.group_size == 64 ? 2 : 4);
-        const int zw = (((d.K / d.group_size + 7) / 8) + mult - 1) / mult * mult;
-        if (d.zeros && zeros_are_8(d.zeros, (long long)d.N * zw)) d.flags |= TCE_W4_ZERO_POINT_IS_8;
-    }
-    // The packed copy serves both ends: decode batches (M <= 4: the int8-contraction GEMV reads it, round 4) and prompts (M > 128: the 128-row GEMM).
-    // One extra copy of the int4 weights per linear in HBM (an 8B-class model: +3.9 GB of 288); TCE_ADAPTER_PACK=0 keeps the q4_6 arrays only.
     static const bool pack_on = [] { const char *e = std::getenv("TCE_ADAPTER_PACK"); return !(e && e[0] == '0'); }();
-    if (pack_on && (d.M <= 4 || d.M >= kPackMinM) && d.K % 128 == 0 && d.A && d.qweight && d.scales && d.zeros) {
-        d.prepacked = packed_copy(d);
-        if (d.prepacked) d.scratch = gemm_scratch();
+    // The packed copy serves both ends: decode batches (M <= 4: the int8-contraction GEMV reads it, round 4) and prompts (M > 128: the 128-row GEMM).
+    // One extra copy of the int4 weights per linear in HBM (an 8B-class model: +3.9 GB of 288); TCE_ADAPTER_PACK=0 keeps the q4_6 arrays only;
+    // tce_adapter_prepare() builds it at load time instead of inside the first call.
+    const bool wants_pack = pack_on && (d.M <= 4 || d.M >= kPackMinM) && d.K % 128 == 0 && d.A && d.qweight && d.scales && d.zeros;
+    if (const FrontEntry *fe = front_find(d)) {  // steady state: one table probe, no lock
+        d.flags |= fe->flags;
+        if (wants_pack) {
+            d.prepacked = fe->prepacked;
+            d.scratch = fe->scratch;
+        }
+    } else {
+        const uint64_t gen = g_generation.load(std::memory_order_acquire);
+        bool final = true;
+        if (d.group_size == 128 || d.group_size == 64 || d.group_size == 32) {
+            // rows of packed zero points: calculate_zeros_width (llm/src/nn_modules/cuda/utils.cu:162-178)
+            const int mult = d.group_size >= 128 ? 1 : (d.group_size == 64 ? 2 : 4);
+            const int zw = (((d.K / d.group_size + 7) / 8) + mult - 1) / mult * mult;
+            if (d.zeros && zeros_are_8(d.zeros, (long long)d.N * zw, &final)) d.flags |= TCE_W4_ZERO_POINT_IS_8;
+        }
+        if (wants_pack) {
+            d.prepacked = packed_copy(d);
+            if (d.prepacked) d.scratch = gemm_scratch();
+        }
+        // published once nothing about the call can change any more (the zero-point verdict is in) and only from a call that resolved the packed copy
+        const bool packable = pack_on && d.K % 128 == 0 && d.qweight && d.scales && d.zeros;
+        if (final && (!packable || d.prepacked)) front_publish(d, gen);
     }
     const int rc = tce_w4a16_forward(&d, nullptr);
     if (rc == TCE_ERR_UNSUPPORTED_GROUP) {
@@ -278,7 +376,8 @@ void MatmulOperator::mat_mul_accelerator_int4_fast_no_offset(const struct matmul
 // rewriting model memory.  tce_adapter_forget_all() drops everything (e.g. on model reload).
 extern "C" void tce_adapter_forget(const void *ptr) {
     std::lock_guard<std::mutex> lk(g_mu);
-    for (auto it = g_zero.begin(); it != g_zero.end();) it = it->first.ptr == ptr ? g_zero.erase(it) : std::next(it);
+    g_generation.fetch_add(1, std::memory_order_acq_rel);  // every front-cache entry is stale from here on
+    for (auto it = g_zero_state.begin(); it != g_zero_state.end();) it = it->first.ptr == ptr ? g_zero_state.erase(it) : std::next(it);
     for (auto *m : {&g_awq, &g_pack})
         for (auto it = m->begin(); it != m->end();) {
             if (it->first.ptr == ptr || it->second.scales == ptr || it->second.zeros == ptr) {
@@ -291,7 +390,8 @@ extern "C" void tce_adapter_forget(const void *ptr) {
 }
 extern "C" void tce_adapter_forget_all(void) {
     std::lock_guard<std::mutex> lk(g_mu);
-    g_zero.clear();
+    g_generation.fetch_add(1, std::memory_order_acq_rel);
+    g_zero_state.clear();
     for (auto *m : {&g_awq, &g_pack}) {
         for (auto &kv : *m)
             if (kv.second.workspace) tce_free(kv.second.workspace);
@@ -300,7 +400,40 @@ extern "C" void tce_adapter_forget_all(void) {
 }
 extern "C" long tce_adapter_cache_entries(void) {
     std::lock_guard<std::mutex> lk(g_mu);
-    return (long)(g_zero.size() + g_awq.size() + g_pack.size());
+    return (long)(g_zero_state.size() + g_awq.size() + g_pack.size());
+}
+
+// Load-time hook (optional): what the first gemv_forward_cuda on this linear would do lazily -- build the packed copy, start the zero-point
+// check -- done when the host calls it, e.g. from Linear_half_int4's constructor behind the three file reads (llm/include/ops/linear.h:215-240), so that the first
+// token pays neither the re-layout (3 prepack launches per linear) nor the allocation.  Asynchronous on the null stream like everything else.  Returns the bytes of
+// device memory the adapter now holds for this linear (0: no packed form for this shape / TCE_ADAPTER_PACK=0).
+extern "C" long long tce_adapter_prepare(const void *qweight, const void *scales, const void *zeros, int N, int K, int group_size) {
+    static const bool pack_on = [] { const char *e = std::getenv("TCE_ADAPTER_PACK"); return !(e && e[0] == '0'); }();
+    if (!qweight || !scales || !zeros || N <= 0 || K <= 0 || (group_size != 128 && group_size != 64 && group_size != 32)) return 0;
+    tce_w4a16_desc d;
+    std::memset(&d, 0, sizeof(d));
+    d.M = 1;
+    d.N = N;
+    d.K = K;
+    d.group_size = group_size;
+    d.qweight = qweight;
+    d.scales = scales;
+    d.zeros = zeros;
+    const int mult = group_size >= 128 ? 1 : (group_size == 64 ? 2 : 4);
+    const int zw = (((K / group_size + 7) / 8) + mult - 1) / mult * mult;
+    bool final = false;
+    (void)zeros_are_8(zeros, (long long)N * zw, &final);
+    if (!pack_on || K % 128 != 0) return 0;
+    return packed_copy(d) ? (long long)tce_w4a16_prepack_bytes(N, K, group_size) : 0;
+}
+
+// Bytes of device memory the adapter holds beyond the model's own tensors (packed copies + AWQ re-layouts).
+extern "C" long long tce_adapter_device_bytes(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    long long n = 0;
+    for (auto *m : {&g_awq, &g_pack})
+        for (auto &kv : *m) n += (long long)kv.second.bytes;
+    return n;
 }
 
 extern "C" long tce_adapter_layout(int idx) {

@@ -99,6 +99,11 @@ class MatmulOperator {
 extern "C" void tce_adapter_forget(const void *ptr);
 extern "C" void tce_adapter_forget_all(void);
 extern "C" long tce_adapter_cache_entries(void);
+// Optional load-time hook (round 5): build the packed copy of one q4_6 linear and start its zero-point check NOW (asynchronously, null stream) instead of inside the
+// first gemv_forward_cuda that sees it; returns the device bytes held for it (0: shape has no packed form, or TCE_ADAPTER_PACK=0).  tce_adapter_device_bytes(): total
+// device memory the adapter holds beyond the model's own tensors.
+extern "C" long long tce_adapter_prepare(const void *qweight, const void *scales, const void *zeros, int N, int K, int group_size);
+extern "C" long long tce_adapter_device_bytes(void);
 
 // Layout probe used by the tests: index -> value (0 sizeof(matmul_params), 1 sizeof(matrix), 2.. offsets).
 extern "C" long tce_adapter_layout(int idx);

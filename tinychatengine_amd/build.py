@@ -18,6 +18,7 @@ LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libtce_hip.so")
 ADAPTER_LIB_PATH = os.path.join(LIB_DIR, "libtce_matmul_operator.so")
 ADAPTER_TEST_PATH = os.path.join(LIB_DIR, "adapter_selftest")
+ADAPTER_BENCH_PATH = os.path.join(LIB_DIR, "adapter_bench")
 
 HIP_SOURCES = ["tce_capi.hip", "w4a16_gemv.hip", "w4a16_gemv_i8.hip", "w4a16_gemv_stream.hip", "w4a16_gemv_ovl.hip", "w4a16_gemm.hip", "w4a16_gemm_dma.hip", "w4a16_gemm_pk.hip", "w4a16_skinny.hip", "w4a16_awq.hip", "w8a8_gemm.hip", "w8a8_lnq_fused.hip", "glue.hip", "attention_ops.hip", "attention_fast.hip", "attention_prefill.hip", "opt_attention.hip", "comm.hip"]
 HIPCC_FLAGS = [
@@ -30,7 +31,10 @@ EXTRA_FLAGS: dict[str, list[str]] = {}  # (-fno-slp-vectorize on the GEMM: no pa
 # Kernels that must not spill a vector register: lnq_w8a8_wide_kernel keeps 16 requested weight pieces per lane in flight through its sums; ONE spilled register
 # makes the compiler wait for all of them at the spill (measured: the OPT-6.7B layer 94 -> 103 us, found only by accident).  The build fails instead.
 NO_VGPR_SPILL: dict[str, list[str]] = {"w8a8_lnq_fused.hip": ["lnq_w8a8_wide_kernel"],
-                                        "w4a16_gemv_stream.hip": ["w4a16_gemv_token_kernel"]}  # (round 3: four forms spilled 3-34 registers under __launch_bounds__(1024))
+                                        "w4a16_gemv_stream.hip": ["w4a16_gemv_token_kernel"],
+                                        # round 5: EVERY instantiation of the decode kernel, the general-zero-point forms included (round 4 let four of them spill 3-19 registers: each
+                                        # spilled scale / zero-point load became load -> wait -> scratch store, i.e. the wave's requests went out one at a time)
+                                        "w4a16_gemv_i8.hip": ["w4a16_gemv_i8_kernel"]}  # (round 3: four forms spilled 3-34 registers under __launch_bounds__(1024))
 
 
 def _check_spills(src: str, stderr_text: str) -> None:
@@ -128,6 +132,15 @@ def build_adapter(force: bool = False, verbose: bool = False) -> str:
     if force or _stale(ADAPTER_TEST_PATH, [test_src, ADAPTER_LIB_PATH] + hdrs):
         cmd = ["g++", "-std=c++17", "-O2", "-Wall", *inc, test_src, "-o", ADAPTER_TEST_PATH, "-L", LIB_DIR,
                "-ltce_matmul_operator", "-ltce_hip", rpath]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    # the drop-in path on the clock (adapter_bench.cc): a measurement tool -- links the HIP runtime directly for events and graph capture
+    bench_src = os.path.join(adir, "adapter_bench.cc")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    if force or _stale(ADAPTER_BENCH_PATH, [bench_src, ADAPTER_LIB_PATH] + hdrs):
+        cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Wno-unused-result", *inc, "-I", os.path.join(rocm, "include"), bench_src, "-o", ADAPTER_BENCH_PATH, "-L", LIB_DIR,
+               "-ltce_matmul_operator", "-ltce_hip", "-L", os.path.join(rocm, "lib"), "-lamdhip64", rpath, "-Wl,-rpath," + os.path.join(rocm, "lib")]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -22,7 +22,7 @@ TCE_W4_SILU_MUL_PAIRS = 8
 TCE_W4_ADD_TO_C = 16
 TCE_PLAN_CHAINED = 1
 TCE_PLAN_TAGGED = 2
-TCE_ABI_VERSION = 108  # include/tce_matmul.h TCE_VERSION: the struct layouts mirrored below
+TCE_ABI_VERSION = 109  # include/tce_matmul.h TCE_VERSION: the struct layouts mirrored below
 TCE_PLAN_OVERLAPPED = 4
 TCE_PLAN_TUNED = 8
 TCE_W4_ZERO_POINT_IS_8 = 4
@@ -35,7 +35,7 @@ EXPORTS = [
     "tce_w4a16_gemm_awq", "tce_w4a16_shard", "tce_comm_create", "tce_comm_export", "tce_comm_connect", "tce_comm_connect_local", "tce_allgather_f16", "tce_comm_rccl_unique_id", "tce_comm_rccl_init", "tce_allgather_rows_workspace_bytes", "tce_allgather_rows_f16", "tce_comm_status", "tce_comm_set_timeout_ms", "tce_comm_reset", "tce_comm_device", "tce_comm_destroy", "tce_w8a8_matmul", "tce_opt_softmax_q", "tce_opt_kv_append", "tce_layernorm_q", "tce_layernorm_q_w8a8_group", "tce_plan_create", "tce_plan_create_ex", "tce_plan_is_chained", "tce_plan_geometry", "tce_plan_status", "tce_plan_launch_geometry", "tce_plan_launch", "tce_plan_n_launches",
     "tce_plan_destroy", "tce_version", "tce_last_error", "tce_build_info", "tce_w4a16_set_gemv_config", "tce_w4a16_set_gemv_i8",
     "tce_w4a16_set_gemm_config", "tce_w4a16_algorithmic_bytes", "tce_w4a16_gemv_variant", "tce_w4a16_gemm_variant",
-    "tce_w4a16_set_debug_mode", "tce_attention_set_tuning", "tce_w8a8_set_tuning", "tce_w4a16_set_debug_buffer", "tce_malloc", "tce_free", "tce_memcpy", "tce_synchronize", "tce_device_count",
+    "tce_w4a16_set_debug_mode", "tce_attention_set_tuning", "tce_w8a8_set_tuning", "tce_w4a16_set_debug_buffer", "tce_w4a16_check_zero_point_8_async", "tce_host_alloc", "tce_host_free", "tce_malloc", "tce_free", "tce_memcpy", "tce_synchronize", "tce_device_count",
 ]
 
 

@@ -283,6 +283,18 @@ int tce_free(void *ptr) {
     return e == hipSuccess ? TCE_OK : hip_fail(e, "hipFree");
 }
 
+int tce_host_alloc(void **ptr, size_t bytes) {
+    if (!ptr || bytes == 0) return fail(TCE_ERR_BAD_ARG, "tce_host_alloc: bad argument");
+    const hipError_t e = hipHostMalloc(ptr, bytes, hipHostMallocMapped | hipHostMallocCoherent);
+    return e == hipSuccess ? TCE_OK : hip_fail(e, "hipHostMalloc");
+}
+
+int tce_host_free(void *ptr) {
+    if (!ptr) return TCE_OK;
+    const hipError_t e = hipHostFree(ptr);
+    return e == hipSuccess ? TCE_OK : hip_fail(e, "hipHostFree");
+}
+
 int tce_memcpy(void *dst, const void *src, size_t bytes, int kind, void *stream) {
     if (!dst || !src) return fail(TCE_ERR_BAD_ARG, "tce_memcpy: null pointer");
     const hipMemcpyKind k = kind == TCE_MEMCPY_H2D ? hipMemcpyHostToDevice : (kind == TCE_MEMCPY_D2H ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice);
@@ -447,7 +459,7 @@ int tce_w4a16_forward_residual_rmsnorm(const tce_w4a16_desc *d, const float *gam
     const tce::I8ResidualNorm rn{gamma, eps, xn_out, workspace};
     const int rc = tce::launch_w4a16_gemv_i8(d, 1, static_cast<hipStream_t>(stream), &he, nullptr, 0.f, &rn);
     if (rc == TCE_ERR_HIP) return hip_fail(he, "w4a16 gemv (residual + next rmsnorm) launch");
-    if (rc != TCE_OK) return fail(rc, "tce_w4a16_forward_residual_rmsnorm: unsupported shape (group 128, N %% 8 == 0, N <= 16384)");
+    if (rc != TCE_OK) return fail(rc, "tce_w4a16_forward_residual_rmsnorm: unsupported shape (group 128, N %% 8 == 0, N <= 16384; K > 16384 only with TCE_W4_ZERO_POINT_IS_8)");
     return TCE_OK;
 }
 
@@ -559,6 +571,13 @@ int tce_w4a16_check_zero_point_8(const void *zeros, long long n_words) {
     hipError_t he = hipSuccess;
     const int rc = tce::check_zero_point_8(zeros, n_words, &he);
     return rc == TCE_ERR_HIP ? hip_fail(he, "zero-point check") : rc;
+}
+
+int tce_w4a16_check_zero_point_8_async(const void *zeros, long long n_words, int *verdict, void *stream) {
+    if (!zeros || n_words <= 0 || !verdict) return fail(TCE_ERR_BAD_ARG, "tce_w4a16_check_zero_point_8_async: bad argument");
+    hipError_t he = hipSuccess;
+    const int rc = tce::check_zero_point_8_async(zeros, n_words, verdict, static_cast<hipStream_t>(stream), &he);
+    return rc == TCE_ERR_HIP ? hip_fail(he, "zero-point check (async)") : rc;
 }
 
 int tce_w4a16_awq_fp16acc(int M, int N, int K, int G, const void *A, const void *qweight, const void *scales, void *C,

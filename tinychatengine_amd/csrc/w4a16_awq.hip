@@ -76,6 +76,24 @@ __global__ __launch_bounds__(256) void zeros_check_kernel(const unsigned *__rest
     if (i < n_words && z[i] != 0x88888888u) g_zero_mismatch = 1;
 }
 
+// One workgroup walks the whole tensor (at most a few MB, once per tensor) and publishes the verdict itself: no second launch, no counter to zero.
+__global__ __launch_bounds__(1024) void zeros_check_async_kernel(const unsigned *__restrict__ z, long long n_words, int *verdict) {
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    int mine = 0;
+    const long long n4 = (reinterpret_cast<uintptr_t>(z) & 15) == 0 ? n_words >> 2 : 0;
+    const uint4_t *z4 = reinterpret_cast<const uint4_t *>(z);
+    for (long long i = threadIdx.x; i < n4; i += 1024) {
+        const uint4_t v = z4[i];
+        mine |= (v[0] != 0x88888888u) | (v[1] != 0x88888888u) | (v[2] != 0x88888888u) | (v[3] != 0x88888888u);
+    }
+    for (long long i = n4 * 4 + threadIdx.x; i < n_words; i += 1024) mine |= z[i] != 0x88888888u;
+    if (mine) bad = 1;  // (benign race: every writer stores 1)
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(verdict, bad ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace
 
 // 1 if every packed zero-point word is 0x88888888, 0 if not, negative on a HIP error.  Synchronous (used once per
@@ -94,6 +112,16 @@ int check_zero_point_8(const void *zeros, long long n_words, hipError_t *hip_err
         return TCE_ERR_HIP;
     }
     return out ? 0 : 1;
+}
+
+int check_zero_point_8_async(const void *zeros, long long n_words, int *verdict, hipStream_t stream, hipError_t *hip_err) {
+    hipLaunchKernelGGL(zeros_check_async_kernel, dim3(1), dim3(1024), 0, stream, static_cast<const unsigned *>(zeros), n_words, verdict);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (hip_err) *hip_err = e;
+        return TCE_ERR_HIP;
+    }
+    return TCE_OK;
 }
 
 int launch_awq_fp16acc(int M, int N, int K, int G, const void *A, const void *qweight, const void *scales, void *C,

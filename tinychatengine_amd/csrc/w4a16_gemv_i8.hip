@@ -150,7 +150,7 @@ __global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const I8Args args) 
         }
     }
     uint2_t sc[ROWS][NP];
-    unsigned short zq[ROWS][NP];
+    unsigned zq[ROWS][(NP + 1) / 2];  // zero points other than 8: the lane's four rows' nibbles of pass ps in half (ps & 1) of word ps / 2 (two passes per register: the general-zero-point forms are the ones short of registers)
 #pragma unroll
     for (int r = 0; r < ROWS; ++r)
 #pragma unroll
@@ -158,7 +158,10 @@ __global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const I8Args args) 
             const int g = (ps * UPP + uu_l) * GPU + gi_l;  // group of this lane's column, relative to the wave's first group
             const int ga = (tile_of(r) * NG + u0 * GPU) + g;  // groups past K (a ragged last wave) read the next tile's values or, behind the last tile, zeros: their products are zero
             sc[r][ps] = __builtin_bit_cast(uint2_t, __builtin_amdgcn_raw_buffer_load_b64(rs_s, (ga * 16 + 4 * kq) * 2, 0, 0));
-            if constexpr (!Z8) zq[r][ps] = __builtin_amdgcn_raw_buffer_load_b16(rs_z, ga * 8 + 2 * kq, 0, 0);
+            if constexpr (!Z8) {
+                const unsigned z16 = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs_z, ga * 8 + 2 * kq, 0, 0);
+                zq[r][ps >> 1] = (ps & 1) ? (zq[r][ps >> 1] | (z16 << 16)) : z16;
+            }
         }
     __builtin_amdgcn_sched_barrier(0);
     uint4_t w[ROWS][UW];
@@ -312,6 +315,9 @@ __global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const I8Args args) 
     const int4_t sixteens = int4_t{0x10101010, 0x10101010, 0x10101010, 0x10101010};
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) {
+        // general zero points: the scheduler would otherwise unpack every pass's (8 - z) nibbles ahead of the first MFMA (NP x 4 registers: 19 spilled in the
+        // M = 2 / G = 64 form under the 128-register bound of a 16-wave workgroup).  A pass's work stays inside the pass.
+        if constexpr (!Z8) __builtin_amdgcn_sched_barrier(0);
         int4_t dd[ROWS][2];
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) dd[r][0] = dd[r][1] = zero4;
@@ -335,7 +341,8 @@ __global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const I8Args args) 
                     alo[q] = (int)(((wq << 4) & 0xF0F0F0F0u) ^ 0x80808080u);
                 }
                 dd[r][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(alo, B[uu][0], dd[r][0], 0, 0, 0);
-                dd[r][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ahi, B[uu][1], dd[r][1], 0, 0, 0);
+                if constexpr (Z8) dd[r][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ahi, B[uu][1], dd[r][1], 0, 0, 0);
+                else dd[r][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ahi, B[uu][1], dd[r][0], 0, 0, 0);  // (one accumulator chain: integer sums, the same value; four registers fewer beside dz and the sixteens)
             }
         }
 #pragma unroll
@@ -348,7 +355,7 @@ __global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const I8Args args) 
             if constexpr (!Z8) {
                 // sum (q - z) X = sum (q - 8) X + (8 - z) sum X, in the same units of 16
 #pragma unroll
-                for (int q = 0; q < 4; ++q) tot[q] += __mul24(8 - (int)((zq[r][ps] >> (4 * q)) & 0xFu), dz[q]);
+                for (int q = 0; q < 4; ++q) tot[q] += __mul24(8 - (int)((zq[r][ps >> 1] >> (16 * (ps & 1) + 4 * q)) & 0xFu), dz[q]);
             }
             acc[r][0] = __builtin_fmaf((float)tot[0], (float)s0, acc[r][0]);
             acc[r][1] = __builtin_fmaf((float)tot[1], (float)s1, acc[r][1]);
@@ -575,7 +582,8 @@ int launch_w4a16_gemv_i8(const tce_w4a16_desc *descs, int count, hipStream_t str
         a.xn_out = static_cast<half_t *>(rn->xn_out);
         a.ws = static_cast<float *>(rn->workspace);
         if (uw == 8) e = z8 ? launch_i8<1, 1, 1, 8, true, 1024, false, true>(a, blocks, m_blocks, wk, stream) : launch_i8<1, 1, 1, 8, false, 1024, false, true>(a, blocks, m_blocks, wk, stream);
-        else e = z8 ? launch_i8<1, 1, 1, 16, true, 1024, false, true>(a, blocks, m_blocks, wk, stream) : launch_i8<1, 1, 1, 16, false, 1024, false, true>(a, blocks, m_blocks, wk, stream);
+        else if (z8) e = launch_i8<1, 1, 1, 16, true, 1024, false, true>(a, blocks, m_blocks, wk, stream);
+        else return TCE_ERR_UNSUPPORTED_SHAPE;  // K > 16384 with general zero points: the epilogue's registers on top of 16 KiB of weights per wave and the zero-point chain do not fit 128 (the form spilled; no instantiation spills: build.py NO_VGPR_SPILL)
         if (e != hipSuccess) {
             if (hip_err) *hip_err = e;
             return TCE_ERR_HIP;

@@ -145,6 +145,7 @@ void set_gemm_pk_mode(int ks, int xm);
 void set_gemm_pk_ablation(int abl);  // timing experiments (results meaningless): see w4a16_gemm_pk_kernel  // tuning: forced wave quartets per tile / XCD rows (0 = automatic)
 
 int check_zero_point_8(const void *zeros, long long n_words, hipError_t *hip_err);
+int check_zero_point_8_async(const void *zeros, long long n_words, int *verdict, hipStream_t stream, hipError_t *hip_err);  // one launch, no synchronisation: *verdict (host-mapped) = 1 / 2
 
 // AWQ (q4_5) helpers
 int launch_awq_fp16acc(int M, int N, int K, int G, const void *A, const void *qweight, const void *scales, void *C,
