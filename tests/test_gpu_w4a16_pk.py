@@ -106,7 +106,7 @@ def test_pk_gemm_matches_oracle(dev, oracle, M, N, K, G):
         lin = _lin(dev, qw, sc, zp, G).prepack()
         x = torch.from_numpy(a).to(dev)
         try:
-            for mode in (61, 62, 63, 64, 60):  # 64: the k range cut across workgroups (needs the scratch area desc() attaches)
+            for mode in (61, 62, 63, 64, 66, 67, 672, 68, 2669, 60):  # 64: the k range cut across workgroups (needs the scratch area desc() attaches); 66 / 67 / 672 / 68 / 2669: the 256-row wave tiles (round 5; groups of 128 -- other group sizes run form 1 under these modes): whole tiles / k range cut / two quartets alternating a tile's k-blocks (even counts; odd: one quartet) / two quartets side by side on 256 x 256
                 capi.check(L.tce_w4a16_set_debug_mode(mode))
                 out = torch.full((M, N), float("nan"), dtype=torch.float16, device=dev)
                 d = lin.desc(x, out)

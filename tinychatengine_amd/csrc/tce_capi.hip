@@ -79,14 +79,14 @@ constexpr int kPkMinM = 129;  // below: the 64-row tiles / the small-batch kerne
 // the pre-packed 128-row GEMM takes the launch when a packed copy came with the descriptor and the batch is large enough
 static bool use_pk(const tce_w4a16_desc *d, bool want_gemm) {
     if (!d->prepacked || g_pk_mode == 9 || !want_gemm || d->K % 128 != 0 || d->rmsnorm_gamma) return false;
-    if (g_pk_mode >= 1 && g_pk_mode <= 4) return true;
+    if (g_pk_mode >= 1 && g_pk_mode <= 8) return true;
     if (d->M < kPkMinM || g_gemm_mt != 0) return false;
     if (d->flags & TCE_W4_SILU_MUL_PAIRS) return true;  // the other GEMM kernels have no pair epilogue: the alternative is the GEMV kernel, M / 4 passes
     // both dispatchers' cost models, fitted to the same kind of sweep (the 64-row tiles win while the 128-row tiles are too few
     // to fill the chip: M = 512 at N = 4096); groups of 64 / 32: the pre-packed kernel needs no LDS re-deal, it takes them
     if (d->group_size != 128) return true;
     const bool has_scratch = d->scratch != nullptr && (reinterpret_cast<uintptr_t>(d->scratch) & 255) == 0;
-    return tce::gemm_pk_estimate_us(d->M, d->N, d->K, nullptr, has_scratch) < tce::gemm_dma_estimate_us(d->M, d->N, d->K) + 1.5f;
+    return tce::gemm_pk_estimate_us(d->M, d->N, d->K, nullptr, has_scratch, nullptr, d->group_size) < tce::gemm_dma_estimate_us(d->M, d->N, d->K) + 1.5f;
 }
 
 // Plain (no fused prologue) launches: the persistent kernel is no longer chosen automatically -- with four rows per wave and four waves
@@ -204,17 +204,41 @@ int tce_w4a16_set_debug_mode(int mode) {
         tce::set_gemm_pk_split(mode - 640);
         return TCE_OK;
     }
+    if (mode >= 2600 && mode <= 2664) {  // the same switches on the 256-row form (round 5)
+        g_pk_mode = mode == 2600 ? 0 : 6;
+        tce::set_gemm_pk_mode(mode == 2600 ? 0 : 6, 0);
+        tce::set_gemm_pk_ablation(mode - 2600);
+        return TCE_OK;
+    }
     if (mode >= 600 && mode <= 664) {  // pre-packed GEMM with parts of its loop switched off (timing experiments, one quartet)
         g_pk_mode = mode == 600 ? 0 : 1;
         tce::set_gemm_pk_mode(mode == 600 ? 0 : 1, 0);
         tce::set_gemm_pk_ablation(mode - 600);
         return TCE_OK;
     }
-    if (mode >= 60 && mode <= 69) {  // pre-packed 128-row GEMM: 60 automatic, 61 / 62 forced quartets, 69 off
+    if (mode == 2669) {  // pre-packed GEMM: 256 x 256 tiles, two quartets side by side (form 9)
+        g_pk_mode = 8;
+        tce::set_gemm_pk_ablation(0);
+        tce::set_gemm_pk_split(0);
+        tce::set_gemm_pk_mode(9, 0);
+        return TCE_OK;
+    }
+    if (mode >= 672 && mode <= 674) {  // pre-packed GEMM, 256-row wave tiles with every tile's k range cut into 2 / 3 / 4 runs
+        g_pk_mode = 7;
+        tce::set_gemm_pk_ablation(0);
+        tce::set_gemm_pk_mode(7, 0);
+        tce::set_gemm_pk_split(mode - 670);
+        return TCE_OK;
+    }
+    if (mode == 690 || mode == 691) {  // pre-packed GEMM: 691 = the dispatcher may pick the 256-row forms (the default), 690 = never (A/B against the 128-row forms)
+        tce::set_gemm_pk256_auto(mode - 690);
+        return TCE_OK;
+    }
+    if (mode >= 60 && mode <= 69) {  // pre-packed GEMM: 60 automatic, 61 / 62 / 63 / 64 forced 128-row forms, 66 / 67 the 256-row wave tiles (whole tiles / k range cut), 68 the 256-row tile shared by two quartets, 69 off
         g_pk_mode = mode - 60;
         tce::set_gemm_pk_split(0);
         tce::set_gemm_pk_ablation(0);
-        tce::set_gemm_pk_mode(g_pk_mode >= 1 && g_pk_mode <= 4 ? g_pk_mode : 0, 0);
+        tce::set_gemm_pk_mode(g_pk_mode >= 1 && g_pk_mode <= 8 && g_pk_mode != 5 ? g_pk_mode : 0, 0);
         return TCE_OK;
     }
     if (mode >= 50 && mode <= 52) {  // LDS-DMA GEMM: wave quartets per tile (50 automatic)
@@ -518,9 +542,13 @@ int tce_w4a16_describe_dispatch(const tce_w4a16_desc *d, char *buf, int buf_len)
     const bool pairs_on_pk = (d->flags & TCE_W4_SILU_MUL_PAIRS) && d->prepacked && d->M >= kPkMinM && !(d->flags & TCE_W4_FORCE_GEMV);
     if (use_pk(d, want_gemm || pairs_on_pk)) {
         int form = 1, split = 1;
-        tce::gemm_pk_estimate_us(d->M, d->N, d->K, &form, d->scratch != nullptr && (reinterpret_cast<uintptr_t>(d->scratch) & 255) == 0, &split);
+        tce::gemm_pk_estimate_us(d->M, d->N, d->K, &form, d->scratch != nullptr && (reinterpret_cast<uintptr_t>(d->scratch) & 255) == 0, &split, d->group_size);
         if (form == 4) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=128x128 quartets=1 ksplit=%d group=%d", split, d->group_size);
         else if (form == 5) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=128x128 quartets=1 ksplit=%d-of-the-tiles-past-256 group=%d", split, d->group_size);
+        else if (form == 6) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=256x128 quartets=1 group=%d", d->group_size);
+        else if (form == 7) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=256x128 quartets=1 ksplit=%d group=%d", split, d->group_size);
+        else if (form == 8) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=256x128 quartets=2 group=%d", d->group_size);
+        else if (form == 9) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=256x256 quartets=2 group=%d", d->group_size);
         else std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=128x%d quartets=%d group=%d", form == 3 ? 256 : 128, form == 1 ? 1 : 2, d->group_size);
         return TCE_OK;
     }

@@ -172,27 +172,37 @@ __device__ __forceinline__ void sched_group() {
     __builtin_amdgcn_sched_group_barrier(MASK, COUNT, 0);
 }
 
-constexpr int kMT = 8;  // 16-row MFMA tiles per wave (128 rows)
+// 16-row MFMA tiles per wave: template parameter MT of the kernel body -- 8 (128 rows: rounds 2-4) or 16 (256 rows, round 5: every unpacked weight word and every
+// landed asm load feeds twice the MFMAs; one wave per SIMD, the 128 accumulator registers beside double-buffered A fragments the compiler may keep in AGPRs)
 constexpr int kNT = 2;  // 16-column MFMA tiles per wave (32 columns); 4 waves side by side = 128 columns
 
 // The compiler allocates v0 .. v231 only; v232 .. v255 belong to the inline asm below (a block's words and constants in flight).
-constexpr int kAsmVgprBase = 232;
+constexpr int kAsmVgprBase = 232;  // 128-row forms (and every group size); the 256-row form does not reserve registers at all (round 5: amdgpu_num_vgpr turned out to be a HINT in this toolchain -- a kernel under pressure is given v232 .. v255 as well; the 128-row forms stay below 232 by themselves, checked in the ISA)
 // ABL: timing experiments only (tce_w4a16_set_debug_mode(600 + ABL); results are then meaningless): bit 0 no rescale, 1 no unpack,
 // 2 no fragment reads, 3 no MFMAs, 4 no activation DMAs, 5 no barriers.
 // NS = 2: two wave quartets side by side on a 128 x 256 tile, sharing ONE activation ring (KS = 1 then): the activation bytes a CU
 // pulls through L2 -> LDS per MFMA halve.  That path, not the matrix pipe, bounds the 128 x 128 forms: the activation DMAs of
 // M = 2048, 4096 x 4096 alone take 32 us of the 68 (profiles/r2/gemm_pk_ablation.jsonl; ~64 GB/s per CU), the MFMAs alone 38.
-template <int KS, int LG, int ABL = 0, int NS = 1>
-__global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(232))) void w4a16_gemm_pk_kernel(const PkGemmArgs g) {
+template <int KS, int LG, int ABL, int NS, int kMT>
+__device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
     static_assert(KS == 1 || NS == 1, "two quartets either split K or sit side by side");
+    static_assert(kMT == 8 || (kMT == 16 && (NS == 1 || KS == 1)), "256-row wave tiles: one quartet per tile, two quartets splitting the k-blocks of one tile, or two quartets side by side on one activation ring");
+    constexpr int ROWS = 16 * kMT;                   // rows of the activation tile
+    constexpr int HALF_BYTES = ROWS * pk::kHalfK * 2;  // one half-stage of activations: 16 / 32 KiB
+    static_assert(kMT == 8 || LG == 7, "256-row wave tiles: groups of 128 only (12 landing registers for the asm loads)");
+    constexpr int ASMB = kAsmVgprBase;  // first register of the 128-row forms' landing area (the 256-row form lands its asm loads in ordinary variables: see `inflight`)
     constexpr int NTHREADS = 256 * KS * NS;
     constexpr int AB = ABL & 63;         // loop parts switched off; bit 6 (64): the rescale as four scalar multiplies per tile (this round's first form, for the A/B)
     constexpr int NWR = 4 * NS;          // waves feeding (and reading) one ring
-    constexpr int DPW = 16 / NWR;        // DMA instructions per wave and half-stage
+    constexpr int DPW = (ROWS / 8) / NWR;  // DMA instructions per wave and half-stage (8 rows each)
     constexpr int BN = 128 * NS;
     constexpr int GPB = 128 >> LG;  // groups per k-block
     constexpr int SPG = 4 / GPB;    // MFMA steps per group
-    constexpr int QUARTET_BYTES = 4 * pk::kHalfBytes;  // ring of four half-stages
+    // ring depth in half-stages per quartet: four (a half-stage is refilled two k-blocks ahead) -- or TWO for the 256-row tile shared by two quartets (round 5:
+    // 2 x 2 x 32 KiB = the 128 KiB one workgroup gets): a slot is refilled with the NEXT block's half as soon as its quartet has read it, half a k-block ahead of its
+    // first use -- which, with two waves sharing every SIMD, is a whole lone-quartet k-block of wall-clock time
+    constexpr int RD = (kMT == 16 && KS == 2) ? 2 : 4;
+    constexpr int QUARTET_BYTES = RD * HALF_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     // K split across workgroups: part p of a tile is workgroup p * (grid / split_s) + (the tile's index): bid % 8 -- the XCD the
@@ -220,7 +230,7 @@ __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(23
     const int grp = KS == 2 ? wave8 >> 2 : 0;
     unsigned char *const ring = smem + grp * QUARTET_BYTES;
     const int n16 = lane & 15, q = lane >> 4;
-    const int m_base = m_blk * 128, nb0 = n_blk * BN;
+    const int m_base = m_blk * ROWS, nb0 = n_blk * BN;
     const int nkb = g.K >> 7;
     const int split = (KS == 1 && NS == 1 && g.split_s > 1 && slot >= g.full_slots) ? g.split_s : 1;
     const int kb_lo = part * nkb / split, nloc = (part + 1) * nkb / split - kb_lo;  // this workgroup's run of k-blocks
@@ -228,24 +238,37 @@ __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(23
 
     // ---- DMA sources of a half-stage: instruction ii of this wave fills 8 rows; the lane fetches the piece that belongs at its position ----
     // (uniform 64-bit base + 32-bit lane offset: the address arithmetic of a refill is scalar; launch_w4a16_gemm_pk refuses M * lda * 2 >= 4 GiB)
-    unsigned a_voff[DPW];
+    unsigned a_voff[kMT == 16 ? 1 : DPW];
 #pragma unroll
-    for (int ii = 0; ii < DPW; ++ii) {
+    for (int ii = 0; ii < (kMT == 16 ? 0 : DPW); ++ii) {
         const int row = pk::dma_row(wave, ii, lane, NWR);
         int m = m_base + row;
         m = m < g.M ? m : g.M - 1;  // rows past M repeat the last row; their outputs are not stored
         a_voff[ii] = (unsigned)m * (unsigned)(g.lda * 2) + (unsigned)(pk::dma_src_piece(row, lane) << 4);
     }
     const char *const a_bytes = reinterpret_cast<const char *>(g.A);
+    // 256-row form: the same pieces through a buffer descriptor over A -- ONE lane offset (row-in-eight x pitch + swizzled piece; the swizzle term (row >> 1) & 7 does
+    // not depend on the instruction: rows advance by 32 per instruction), everything else in the scalar offset; rows past M are out of range and read as zeros
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(g.A), 0, (int)((unsigned)g.M * (unsigned)(g.lda * 2)), 0x00020000);
+    const unsigned a_lane_off = (unsigned)(lane >> 3) * (unsigned)(g.lda * 2) + (unsigned)(((lane & 7) ^ (((wave & 1) * 4 + (lane >> 4)) & 7)) << 4);
+    (void)rs_a;
+    (void)a_lane_off;
     // own half-block h (0 .. 2T-1): k-block grp + (h >> 1) * KS, half h & 1; clamped, never predicated (the counted waits rely on it)
     auto issue_half = [&](int h) {
         if constexpr (AB & 16) return;
         int kb = grp + (h >> 1) * KS;
         kb = kb_lo + (kb < nloc ? kb : nloc - 1);
         const char *src = a_bytes + ((size_t)kb * 256 + (h & 1) * 128);  // wave-uniform
-        unsigned char *st = ring + (h & 3) * pk::kHalfBytes;
+        unsigned char *st = ring + (h & (RD - 1)) * HALF_BYTES;
+        if constexpr (kMT == 16) {
+            const unsigned s0 = (unsigned)(m_base + wave * 8) * (unsigned)(g.lda * 2) + (unsigned)(kb * 256 + (h & 1) * 128);
 #pragma unroll
-        for (int ii = 0; ii < DPW; ++ii) pk_dma16(src + a_voff[ii], st + pk::dma_lds_base(wave, ii, NWR));
+            for (int ii = 0; ii < DPW; ++ii)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void_t *)(st + pk::dma_lds_base(wave, ii, NWR)), 16, a_lane_off, s0 + (unsigned)ii * (unsigned)(NWR * 8 * g.lda * 2), 0, 0);
+        } else {
+#pragma unroll
+            for (int ii = 0; ii < DPW; ++ii) pk_dma16(src + a_voff[ii], st + pk::dma_lds_base(wave, ii, NWR));
+        }
     };
     // ---- the lane's weights and constants ----
     const int jt0 = n_blk * (BN / 16) + wave * kNT;  // first 16-column tile of this wave
@@ -300,11 +323,16 @@ __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(23
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     issue_half(0);
     issue_half(1);
-    issue_half(2);
-    issue_half(3);
+    if constexpr (RD == 4) {
+        issue_half(2);
+        issue_half(3);
+    }
 
     // ---- pieces of a k-block ----
-    half8_t af[2][kMT], bf[2][kNT];  // fragments of the step being multiplied and of the next one
+    // fragments of the step being multiplied and of the next one.  kMT == 16: ONE set of A fragments (64 registers beside the 128 accumulators), refilled tile by
+    // tile -- m-tile i's fragment of the next step is read as soon as its two MFMAs of this step have issued
+    constexpr bool ROLL = kMT == 16;
+    half8_t af[ROLL ? 1 : 2][kMT], bf[ROLL ? 1 : 2][kNT];  // (256-row form: ONE set of B fragments too -- the next step's are unpacked behind this step's last MFMA)
     half2_t c1[kNT], c2[kNT];        // (-(1024+z)) x2 and (-(64+z)) x2 of the group being unpacked
     auto read_a = [&](half8_t (&dst)[kMT], const unsigned char *half_stage, int sl) {
         const unsigned char *st = half_stage + a_off[sl];
@@ -370,8 +398,58 @@ __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(23
         constexpr int s = decltype(s_c)::value;
         constexpr int sn = (s + 1) & 3;  // the step whose fragments are fetched here
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ROLL) {
+            // 256-row form: four chunks of four m-tiles, each fenced -- [the chunk's share of the rescale] [its 8 MFMAs] [its tiles' fragments of the NEXT step into
+            // the registers those MFMAs just read] [a share of the next step's unpack].  (MFMA and VALU issue serialise on a SIMD, scripts/probes/valu_probe.hip: what
+            // matters is that nothing waits, not the fine interleave; the fences keep the scheduler from hoisting the fragment reads over the MFMAs that still need
+            // the old values -- 64 live fragment registers, not 128 -- which sched_group_barrier sequences did not hold it to.)
+            float r[kNT];
+            if constexpr (s % SPG == 0 && !(AB & 1)) {
+#pragma unroll
+                for (int j = 0; j < kNT; ++j) {
+                    const float en = e_grp[s / SPG][j];
+                    r[j] = e_prev[j] == 0.f ? 1.0f : e_prev[j] * __builtin_amdgcn_rcpf(en);
+                    e_prev[j] = en;
+                }
+            }
+            const unsigned char *st_next = half_stage_next + a_off[sn & 1];
+            static_for<0, 4>([&](auto c_c) {
+                constexpr int c = decltype(c_c)::value;
+                if constexpr (s % SPG == 0 && !(AB & 1)) {
+#pragma unroll
+                    for (int i = 4 * c; i < 4 * c + 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < kNT; ++j) {
+                            const float2_t r2{r[j], r[j]};
+                            const float2_t lo = float2_t{acc[i][j][0], acc[i][j][1]} * r2, hi = float2_t{acc[i][j][2], acc[i][j][3]} * r2;
+                            acc[i][j] = float4_t{lo.x, lo.y, hi.x, hi.y};
+                        }
+                }
+                if constexpr (!(AB & 8)) {
+#pragma unroll
+                    for (int i = 4 * c; i < 4 * c + 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < kNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int i = 4 * c; i < 4 * c + 4; ++i) asm volatile("" ::"v"(af[0][i]));
+#pragma unroll
+                    for (int j = 0; j < kNT; ++j) asm volatile("" ::"v"(bf[0][j]));
+                }
+                if constexpr (!(AB & 4)) {
+#pragma unroll
+                    for (int i = 4 * c; i < 4 * c + 4; ++i) af[0][i] = *reinterpret_cast<const half8_t *>(st_next + i * 2048);
+                }
+                if constexpr (c == 3 && !(AB & 2)) {
+                    if constexpr (sn % SPG == 0) set_group(br_next, sn / SPG);
+                    unpack(bf[0], br_next, sn);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            return;
+        }
         if constexpr (s % SPG == 0 && !(AB & 1)) rescale(e_grp[s / SPG]);
-        if constexpr (!(AB & 4)) read_a(af[(s + 1) & 1], half_stage_next, sn & 1);
+        if constexpr (!(AB & 4) && !ROLL) read_a(af[(s + 1) & 1], half_stage_next, sn & 1);
         if constexpr (!(AB & 2)) {
             if constexpr (sn % SPG == 0) set_group(br_next, sn / SPG);
             unpack(bf[(s + 1) & 1], br_next, sn);
@@ -387,11 +465,11 @@ __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(23
 #pragma unroll
             for (int j = 0; j < kNT; ++j) asm volatile("" ::"v"(bf[(s + 1) & 1][j]));
         }
-        if constexpr (AB == 0) static_for<0, 16>([&](auto u_c) {
+        if constexpr (AB == 0) static_for<0, kMT * kNT>([&](auto u_c) {
             constexpr int u = decltype(u_c)::value;
             if constexpr (s % SPG == 0) sched_group<0x002, (ABL & 64) ? 4 : 2>();   // the tile's two packed multiplies, then its MFMA
             sched_group<0x008, 1>();                               // MFMA
-            if constexpr (u < 8) sched_group<0x100, 1>();          // DS read
+            if constexpr (u < kMT) sched_group<0x100, 1>();        // DS read
             sched_group<0x002, (u < 4 ? 2 : 1)>();                 // VALU: unpack of the next step (18 + constants)
         });
         __builtin_amdgcn_sched_barrier(0);
@@ -405,27 +483,29 @@ __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(23
     // registers 128 / 128 and move the MFMA accumulators behind v_accvgpr copies.)  After the counted wait at the end of a block
     // the landed words are copied out (12 v_mov per k-block for groups of 128) into ordinary variables, and the same registers
     // take the next request.
-#define TCE_PK_AGPR_CLOBBERS "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
+#define TCE_PK_CLOB232 "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
     static_assert(kNT == 2, "the request / collect macros below spell out two column tiles");
-#define TCE_PK_REQ_W(J)                                                                                                              \
-    asm volatile("s_nop 4\n\tglobal_load_dwordx4 v[%c2:%c3], %0, %1" ::"v"(w_voff), "s"(w_tile[J] + (size_t)kbn * 64), "i"(kAsmVgprBase + 4 * J), "i"(kAsmVgprBase + 4 * J + 3) \
-                 : "memory", TCE_PK_AGPR_CLOBBERS);
-#define TCE_PK_REQ_C(J, GI)                                                                                                          \
+#define TCE_PK_REQ_W(J, CLOB)                                                                                                        \
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 v[%c2:%c3], %0, %1" ::"v"(w_voff), "s"(w_tile[J] + (size_t)kbn * 64), "i"(ASMB + 4 * J), "i"(ASMB + 4 * J + 3) \
+                 : "memory", CLOB);
+#define TCE_PK_REQ_C(J, GI, CLOB)                                                                                                    \
     if constexpr (GI < GPB)                                                                                                          \
         asm volatile("s_nop 4\n\tglobal_load_dwordx2 v[%c2:%c3], %0, %1" ::"v"(c_voff), "s"(c_tile[J] + (size_t)(kbn * GPB + GI) * 16),   \
-                     "i"(kAsmVgprBase + 4 * kNT + 2 * (J * GPB + GI)), "i"(kAsmVgprBase + 4 * kNT + 2 * (J * GPB + GI) + 1)                                        \
-                     : "memory", TCE_PK_AGPR_CLOBBERS);
+                     "i"(ASMB + 4 * kNT + 2 * (J * GPB + GI)), "i"(ASMB + 4 * kNT + 2 * (J * GPB + GI) + 1)                                        \
+                     : "memory", CLOB);
     auto request_block = [&](int t_of_block) {
         const int kbn = block_of(t_of_block);
         // (s_nop 4: the scalar base was just computed by SALU instructions, and nothing pads an SGPR hazard inside an asm statement)
-        TCE_PK_REQ_W(0) TCE_PK_REQ_W(1)
-        TCE_PK_REQ_C(0, 0) TCE_PK_REQ_C(0, 1) TCE_PK_REQ_C(0, 2) TCE_PK_REQ_C(0, 3)
-        TCE_PK_REQ_C(1, 0) TCE_PK_REQ_C(1, 1) TCE_PK_REQ_C(1, 2) TCE_PK_REQ_C(1, 3)
+        {
+            TCE_PK_REQ_W(0, TCE_PK_CLOB232) TCE_PK_REQ_W(1, TCE_PK_CLOB232)
+            TCE_PK_REQ_C(0, 0, TCE_PK_CLOB232) TCE_PK_REQ_C(0, 1, TCE_PK_CLOB232) TCE_PK_REQ_C(0, 2, TCE_PK_CLOB232) TCE_PK_REQ_C(0, 3, TCE_PK_CLOB232)
+            TCE_PK_REQ_C(1, 0, TCE_PK_CLOB232) TCE_PK_REQ_C(1, 1, TCE_PK_CLOB232) TCE_PK_REQ_C(1, 2, TCE_PK_CLOB232) TCE_PK_REQ_C(1, 3, TCE_PK_CLOB232)
+        }
     };
 #define TCE_PK_GET(DST, R)                                                     \
     {                                                                          \
         unsigned v_;                                                           \
-        asm volatile("v_mov_b32 %0, v%c1" : "=v"(v_) : "i"(kAsmVgprBase + (R)));      \
+        asm volatile("v_mov_b32 %0, v%c1" : "=v"(v_) : "i"(ASMB + (R)));      \
         DST = v_;                                                              \
     }
 #define TCE_PK_GET_C(J, GI)                                                    \
@@ -440,8 +520,27 @@ __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(23
         TCE_PK_GET_C(1, 0) TCE_PK_GET_C(1, 1) TCE_PK_GET_C(1, 2) TCE_PK_GET_C(1, 3)
     };
     constexpr int NWL = kNT * (1 + GPB);  // VMEM instructions of request_block
-    request_block(1);
-    pk_wait_vmcnt<2 * DPW + NWL>();  // the first block's two half-stages have landed (this wave's part); the barrier makes that the workgroup's
+    // 256-row form: no reserved registers (the attribute that reserved them is only a hint, see kAsmVgprBase).  A block's words and constants are requested by asm
+    // loads into ORDINARY variables at the START of the iteration that ends with their first use, and become usable through the asm statement that carries the counted
+    // wait (it names them as in/out operands): between the two the compiler sees live values it has no reason to touch -- no loop back edge is crossed, so no phi copy --
+    // and every real use depends on the wait.  (A spill of one of them in between would store stale data: the build fails on ANY spill in this kernel, build.py.)
+    BlockRegs inflight;
+    auto request_inflight = [&](int t_of_block) {
+        const int kbn = block_of(t_of_block);
+#pragma unroll
+        for (int j = 0; j < kNT; ++j) {
+            asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(inflight.w[j]) : "v"(w_voff), "s"(w_tile[j] + (size_t)kbn * 64) : "memory");
+            asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "=v"(inflight.c[j][0]) : "v"(c_voff), "s"(c_tile[j] + (size_t)kbn * 16) : "memory");
+        }
+    };
+    if constexpr (RD == 2) {
+        pk_wait_vmcnt<DPW>();  // the first block's even half has landed (its odd half may still be in flight: awaited in front of the loop's first barrier)
+    } else if constexpr (ROLL) {
+        pk_wait_vmcnt<2 * DPW>();
+    } else {
+        request_block(1);
+        pk_wait_vmcnt<2 * DPW + NWL>();  // the first block's two half-stages have landed (this wave's part); the barrier makes that the workgroup's
+    }
     if constexpr (!(AB & 32)) __builtin_amdgcn_s_barrier();
     // fragments of step 0 of the first block
     set_group(cur, 0);
@@ -449,10 +548,43 @@ __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(23
     unpack(bf[0], cur, 0);
     load_e(cur);
 
+    if constexpr (RD == 2) {
+        // ---- two half-stage slots per quartet (256-row tile, two quartets alternating k-blocks) ----
+        // slot 0 = the even half of the quartet's current block (steps 0, 1), slot 1 = its odd half (steps 2, 3).  Per iteration, in VMEM issue order:
+        //   [odd(t): issued behind barrier B2 of the previous iteration]  [words(t+1)]  B1  [even(t+1) -> slot 0]  B2  [odd(t+1) -> slot 1]
+        // B1 sits behind region 0 (the last reads of even(t)); the wait in front of it, vmcnt(NWL), retires odd(t) -- read from region 1 on, i.e. one barrier later.
+        // B2 sits behind region 2 (the last reads of odd(t)); the wait in front of it, vmcnt(0), retires words(t+1) and even(t+1) -- read by region 3, behind B2.
+        // Every read of a staged half is thus separated from the wait that retires it by a barrier every wave of the workgroup has passed, and every refill from the
+        // last read of the slot by a barrier behind that wave's lgkmcnt(0).
+        static_assert(RD != 2 || (kNT == 2 && GPB == 1), "the wait statement below names two column tiles, one group per k-block");
+        const unsigned char *st_even = ring, *st_odd = ring + HALF_BYTES;
+        for (int t = 0; t < T; ++t) {
+            constexpr bool live = true;  // (this form is offered for an even number of k-blocks only: both quartets run every iteration -- a conditional region costs
+                                         //  the loop 48 spilled registers, and a spill inside the window of the in-flight asm loads would store stale data)
+            request_inflight(t + 1);
+            if (live) region(std::integral_constant<int, 0>{}, cur, st_even);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            pk_wait_vmcnt<NWL>();
+            if constexpr (!(AB & 32)) __builtin_amdgcn_s_barrier();
+            issue_half(2 * t + 2);
+            if (live) {
+                region(std::integral_constant<int, 1>{}, cur, st_odd);
+                region(std::integral_constant<int, 2>{}, cur, st_odd);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(inflight.w[0]), "+v"(inflight.w[1]), "+v"(inflight.c[0][0]), "+v"(inflight.c[1][0]) : : "memory");
+            cur = inflight;
+            if constexpr (!(AB & 32)) __builtin_amdgcn_s_barrier();
+            issue_half(2 * t + 3);
+            if (live) region(std::integral_constant<int, 3>{}, cur, st_even);
+            load_e(cur);
+        }
+    } else
     for (int t = 0; t < T; ++t) {
         const bool live = grp + t * KS < nloc;  // wave-uniform; only quartet 1's last iteration can be past the run
-        const unsigned char *st_even = ring + ((2 * t) & 3) * pk::kHalfBytes, *st_odd = ring + ((2 * t + 1) & 3) * pk::kHalfBytes;
-        const unsigned char *st_even_next = ring + ((2 * t + 2) & 3) * pk::kHalfBytes;
+        const unsigned char *st_even = ring + ((2 * t) & 3) * HALF_BYTES, *st_odd = ring + ((2 * t + 1) & 3) * HALF_BYTES;
+        const unsigned char *st_even_next = ring + ((2 * t + 2) & 3) * HALF_BYTES;
+        if constexpr (ROLL) request_inflight(t + 1);
         if (live) {
             region(std::integral_constant<int, 0>{}, cur, st_even);  // MFMAs of step 0 | fragments of step 1 (even half-stage)
             region(std::integral_constant<int, 1>{}, cur, st_odd);   // step 1 | step 2 (odd half-stage)
@@ -466,16 +598,22 @@ __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(23
         // [its words / constants] [half 2t+4].  vmcnt(DPW) leaves only the DMAs of half 2t+4 in flight: both half-stages of
         // block t+1 and its words have landed (in-order counter); the barrier extends that to the workgroup and orders this
         // block's reads of the odd half-stage before its refill.
-        pk_wait_vmcnt<DPW>();
-        collect_block(cur);  // `cur` (block t) is used up: step 3's fragments are unpacked
+        if constexpr (ROLL) {
+            static_assert(!ROLL || (kNT == 2 && GPB == 1), "the wait statement below names two column tiles, one group per k-block");
+            asm volatile("s_waitcnt vmcnt(%c4)" : "+v"(inflight.w[0]), "+v"(inflight.w[1]), "+v"(inflight.c[0][0]), "+v"(inflight.c[1][0]) : "n"(DPW) : "memory");
+            cur = inflight;  // `cur` (block t) is used up: step 3's fragments are unpacked
+        } else {
+            pk_wait_vmcnt<DPW>();
+            collect_block(cur);  // `cur` (block t) is used up: step 3's fragments are unpacked
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr (!(AB & 32)) __builtin_amdgcn_s_barrier();
         issue_half(2 * t + 5);
-        request_block(t + 2);
+        if constexpr (!ROLL) request_block(t + 2);
         if (live) region(std::integral_constant<int, 3>{}, cur, st_even_next);  // step 3 | step 0 of the next block (`cur` is the next block now)
         load_e(cur);
     }
-#undef TCE_PK_AGPR_CLOBBERS
+#undef TCE_PK_CLOB232
 #undef TCE_PK_REQ_W
 #undef TCE_PK_REQ_C
 #undef TCE_PK_GET
@@ -541,8 +679,26 @@ __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(23
         __syncthreads();
         if (*flag == 0u) return;
         __syncthreads();  // (the flag word is part of the output tile's LDS image below)
-        // the sum in run order 0, 1, ..., split_s - 1 whoever computes it: the other runs' partials from memory, its own from its registers
-        // (the same values it stored)
+        // the sum in run order 0, 1, ..., split_s - 1 whoever computes it
+        if constexpr (ROLL) {
+            // 256-row tiles: 128 accumulator registers leave no room for a second copy -- every run's partial (this one's included: the same values it stored) is
+            // read back, eight registers at a time
+#pragma unroll
+            for (int i = 0; i < kMT; ++i)
+#pragma unroll
+                for (int j = 0; j < kNT; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+            for (int p = 0; p < split; ++p) {
+#pragma unroll
+                for (int c0 = 0; c0 < kMT * kNT; c0 += 8) {
+                    uint4_t t4[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) t4[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_p, ((p * kMT * kNT + c0 + r) * 256 + tid) * 16, 0, /*sc0|sc1*/ 17);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) acc[(c0 + r) / kNT][(c0 + r) % kNT] += __builtin_bit_cast(float4_t, t4[r]);
+                }
+            }
+        } else {
+        // (128-row tiles) the other runs' partials from memory, its own from its registers (the same values it stored)
         float4_t own[kMT][kNT];
 #pragma unroll
         for (int i = 0; i < kMT; ++i)
@@ -567,10 +723,11 @@ __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(23
 #pragma unroll
                 for (int j = 0; j < kNT; ++j) acc[i][j] += __builtin_bit_cast(float4_t, t4[i * kNT + j]);
         }
+        }
     }
 
     // ---- epilogue: the tile leaves through LDS as 16-byte row pieces (accumulator layout: lane = column n16, registers = 4 consecutive rows) ----
-    half_t *lds_c = reinterpret_cast<half_t *>(smem);  // [128][BN]
+    half_t *lds_c = reinterpret_cast<half_t *>(smem);  // [ROWS][BN]
     if (grp == 0) {
 #pragma unroll
         for (int i = 0; i < kMT; ++i)
@@ -582,7 +739,7 @@ __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(23
     __syncthreads();
     const bool vec_ok = (g.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0;
     constexpr int PPR = BN / 8;  // 16-byte pieces per row
-    for (int e = tid; e < 128 * PPR; e += NTHREADS) {
+    for (int e = tid; e < ROWS * PPR; e += NTHREADS) {
         const int row = e / PPR, pc = e % PPR;
         const int m = m_base + row, n = nb0 + pc * 8;
         if (m >= g.M || n >= g.N) continue;
@@ -609,10 +766,25 @@ __global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(23
     }
 }
 
+template <int KS, int LG, int ABL = 0, int NS = 1>
+__global__ __launch_bounds__(256 * KS * NS, 2) __attribute__((amdgpu_num_vgpr(232))) void w4a16_gemm_pk_kernel(const PkGemmArgs g) {
+    w4a16_gemm_pk_body<KS, LG, ABL, NS, 8>(g);
+}
+// 256-row wave tiles (round 5): ONE wave per SIMD (the 128 KiB ring admits one workgroup per CU anyway), so the wave may use the whole register file -- v0..v231 for
+// the compiler (v232..v255 stay the asm loads'), AGPRs for what does not fit (the second set of A fragments)
+template <int LG, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void w4a16_gemm_pk256_kernel(const PkGemmArgs g) {
+    w4a16_gemm_pk_body<1, LG, ABL, 1, 16>(g);
+}
+
 int g_pk_ks = 0;  // 0: choose per launch, 1 / 2: forced (tuning)
 int g_pk_xm = 0;
 int g_pk_abl = 0;  // timing experiments: parts of the loop switched off (one quartet, groups of 128 only)
 int g_pk_split_force = 0;  // tuning: the number of runs a cut tile's k range is divided into (0: the cost model's choice)
+int g_pk256_auto = 1;      // 0: the dispatcher never picks the 256-row forms by itself (A/B runs: tce_w4a16_set_debug_mode(650 / 651))
+constexpr float kPk256wUsPerKBlock = 4.3f;  // eight waves of a 256 x 256 tile walking one k-block
+constexpr float kPk256x2UsPerPair = 3.45f;   // two quartets sharing a CU walking one 256-row k-block each
+constexpr float kPk256UsPerKBlock = 2.25f;  // one workgroup per CU walking a 256-row k-block (128 MFMAs per wave); fitted in round 5 (profiles/r5/gemm_pk256_sweep.jsonl)
 
 template <int KS, int LG, int ABL = 0, int NS = 1>
 hipError_t launch_pk(PkGemmArgs &g, hipStream_t stream) {
@@ -627,13 +799,56 @@ hipError_t launch_pk(PkGemmArgs &g, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// 256-row tile shared by TWO quartets that alternate its k-blocks (512 threads, two waves per SIMD, 2 x 64 KiB rings, partial tiles joined through LDS)
+template <int LG, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void w4a16_gemm_pk256x2_kernel(const PkGemmArgs g) {
+    w4a16_gemm_pk_body<2, LG, ABL, 1, 16>(g);
+}
+
+// 256 x 256 tile: two quartets side by side (256 rows x 32 columns per wave) on ONE activation ring of four half-stages -- half the DMA instructions and LDS writes per MFMA
+template <int LG, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void w4a16_gemm_pk256w_kernel(const PkGemmArgs g) {
+    w4a16_gemm_pk_body<1, LG, ABL, 2, 16>(g);
+}
+template <int LG, int ABL = 0>
+hipError_t launch_pk256w(PkGemmArgs &g, hipStream_t stream) {
+    const size_t lds = (size_t)4 * 256 * pk::kHalfK * 2;  // 128 KiB: the ring; the 256 x 256 output tile (128 KiB) reuses it
+    auto kfn = w4a16_gemm_pk256w_kernel<LG, ABL>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kfn, dim3(8 * g.m_per * g.n_per), dim3(512), lds, stream, g);
+    return hipGetLastError();
+}
+
+template <int LG, int ABL = 0>
+hipError_t launch_pk256x2(PkGemmArgs &g, hipStream_t stream) {
+    const size_t lds = (size_t)2 * 2 * 256 * pk::kHalfK * 2;  // two rings of two half-stages of 256 rows x 64 k: 128 KiB (the quartet exchange, 128 KiB, and the output tile reuse them)
+    auto kfn = w4a16_gemm_pk256x2_kernel<LG, ABL>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kfn, dim3(8 * g.m_per * g.n_per), dim3(512), lds, stream, g);
+    return hipGetLastError();
+}
+
+template <int LG, int ABL = 0>
+hipError_t launch_pk256(PkGemmArgs &g, hipStream_t stream) {
+    const size_t lds = (size_t)4 * 256 * pk::kHalfK * 2;  // ring of four half-stages of 256 rows x 64 k: 128 KiB (the output tile, 64 KiB, reuses it)
+    auto kfn = w4a16_gemm_pk256_kernel<LG, ABL>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const int per = 8 * g.m_per * g.n_per;
+    hipLaunchKernelGGL(kfn, dim3(g.split_s > 1 ? per + (per - 8 * g.full_slots) * (g.split_s - 1) : per), dim3(256), lds, stream, g);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 void set_gemm_pk_ablation(int abl) { g_pk_abl = abl; }
+void set_gemm_pk256_auto(int on) { g_pk256_auto = on ? 1 : 0; }
 void set_gemm_pk_split(int s) { g_pk_split_force = s >= 2 && s <= 4 ? s : 0; }
 
 void set_gemm_pk_mode(int form, int xm) {
-    g_pk_ks = (form >= 1 && form <= 4) ? form : 0;
+    g_pk_ks = (form >= 1 && form <= 9) ? form : 0;  // 9: 256 x 256 tiles, two quartets side by side (debug mode 2669)  // 6: 256-row wave tiles, whole tiles; 7: the same with every tile's k range cut across workgroups
     g_pk_xm = (xm == 1 || xm == 2 || xm == 4 || xm == 8) ? xm : 0;
 }
 
@@ -704,7 +919,7 @@ static int pk_split_factor(long tiles1, int nkb, bool has_scratch, float *cost_o
     return best_s;
 }
 
-float gemm_pk_estimate_us(int M, int N, int K, int *form_out, bool has_scratch, int *split_out) {
+float gemm_pk_estimate_us(int M, int N, int K, int *form_out, bool has_scratch, int *split_out, int group_size) {
     const long mt = (M + 127) / 128;
     const long tiles1 = mt * ((N + 127) / 128), tiles3 = mt * ((N + 255) / 256);
     const float nkb = (float)(K / 128);
@@ -741,13 +956,43 @@ float gemm_pk_estimate_us(int M, int N, int K, int *form_out, bool has_scratch, 
     if (cost3 < best) best = cost3, form = 3;
     if (cost4 < best) best = cost4, form = 4;
     if (cost5 < best) best = cost5, form = 5;
+    // forms 6 / 7 (round 5): 256-row wave tiles (one workgroup of four waves per CU on a 256 x 128 tile), whole tiles / every tile's k range cut into s runs.
+    // A 256-row k-block carries twice the MFMAs of a 128-row one beside the same unpack: c6 us per k-block (fitted below)
+    const long mt6 = (M + 255) / 256;
+    const long tiles6 = mt6 * ((N + 127) / 128);
+    float cost6 = 1e30f, cost7 = 1e30f;
+    int split7 = 1;
+    if (M > 128 && group_size == 128) {
+        cost6 = rounds(tiles6, 256) * nkb * kPk256UsPerKBlock + 4.0f;
+        if (has_scratch)
+            for (int s7 = 2; s7 <= 4; ++s7) {
+                if (tiles6 * s7 * 2 > kPkSplitMaxUnits || (int)nkb / s7 < 4 || (g_pk_split_force && s7 != g_pk_split_force)) continue;
+                const float run = (float)(((int)nkb + s7 - 1) / s7);
+                const float c = rounds(tiles6 * s7, 256) * run * kPk256UsPerKBlock + 9.0f + 2.0f * (float)s7;  // the exchange moves 128 KiB per unit
+                if (c < cost7) cost7 = c, split7 = s7;
+            }
+    }
+    // form 9 (round 5): 256 x 256 tiles, two quartets side by side on one ring
+    float cost9 = 1e30f;
+    const long tiles9 = mt6 * ((N + 255) / 256);
+    if (M > 128 && group_size == 128) cost9 = rounds(tiles9, 256) * nkb * kPk256wUsPerKBlock + 5.0f;
+    // form 8 (round 5): the 256 x 128 tile shared by two quartets that alternate its k-blocks (two waves per SIMD): kPk256x2UsPerPair per pair of k-blocks
+    float cost8 = 1e30f;
+    if (M > 128 && group_size == 128 && nkb >= 2.f && ((int)nkb & 1) == 0) cost8 = rounds(tiles6, 256) * (float)(((int)nkb + 1) / 2) * kPk256x2UsPerPair + 5.0f;
+    // Only form 8 is offered to the dispatcher: forms 6 / 7 (one wave per SIMD: DMA issue, fragment reads and barriers serialise with the MFMA stream -- 73 against 64 us at
+    // 2048 x 4096 x 4096) and form 9 (half the chip at that size, level at 4096 rows) lost every same-process comparison (profiles/r5/gemm_pk256_*.jsonl); they stay
+    // reachable through tce_w4a16_set_debug_mode (66 / 67 / 672-674 / 2669) and in the parity tests.
+    if (g_pk256_auto && cost8 < best) best = cost8, form = 8;
     if (g_pk_ks) {
         form = g_pk_ks;
         if (form == 4 && split == 1) form = split5 > 1 ? 5 : 1;  // "cut the k range": whichever of the two cut forms applies
-        best = form == 1 ? cost1 : (form == 2 ? cost2 : (form == 3 ? cost3 : (form == 4 ? cost4 : cost5)));
+        if (form == 7 && split7 == 1) form = 6;
+        if ((form >= 6 && form <= 9) && (M <= 128 || group_size != 128)) form = 1;
+        if (form == 8 && (nkb < 2.f || ((int)nkb & 1))) form = 6;
+        best = form == 1 ? cost1 : (form == 2 ? cost2 : (form == 3 ? cost3 : (form == 4 ? cost4 : (form == 5 ? cost5 : (form == 6 ? cost6 : (form == 7 ? cost7 : (form == 8 ? cost8 : cost9)))))));
     }
     if (form_out) *form_out = form;
-    if (split_out) *split_out = form == 4 ? split : (form == 5 ? split5 : 1);
+    if (split_out) *split_out = form == 4 ? split : (form == 5 ? split5 : (form == 7 ? split7 : 1));
     return best;
 }
 
@@ -772,9 +1017,11 @@ int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_
     g.add_to_c = (d.flags & TCE_W4_ADD_TO_C) ? 1 : 0;
     int form = 1, split = 1;
     const bool has_scratch = d.scratch != nullptr && (reinterpret_cast<uintptr_t>(d.scratch) & 255) == 0;
-    gemm_pk_estimate_us(d.M, d.N, d.K, &form, has_scratch, &split);
+    gemm_pk_estimate_us(d.M, d.N, d.K, &form, has_scratch, &split, d.group_size);
     const bool cut_tail_only = form == 5;
-    if (form == 4 || form == 5) {
+    const bool rows256 = form >= 6 && form <= 9;
+    const bool rows256x2 = form == 8, rows256w = form == 9;
+    if (form == 4 || form == 5 || form == 7) {
         form = 1;
         g.split_s = split;
         g.counters = static_cast<unsigned *>(d.scratch);
@@ -782,9 +1029,9 @@ int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_
     } else {
         g.split_s = 1;
     }
-    const int bn = form == 3 ? 256 : 128;
+    const int bn = (form == 3 || form == 9) ? 256 : 128;
     g.n_blocks = (d.N + bn - 1) / bn;
-    g.m_blocks = (d.M + 127) / 128;
+    g.m_blocks = rows256 ? (d.M + 255) / 256 : (d.M + 127) / 128;
     int best_xm = 1;
     long best_grid = -1;
     for (int xm = 8; xm >= 1; xm >>= 1) {  // the XCD grid that wastes the fewest workgroup slots, larger xm on ties (w4a16_gemm_dma.hip)
@@ -800,12 +1047,12 @@ int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_
     if (g.split_s > 1) {
         g.full_slots = cut_tail_only ? 32 : 0;  // 32 slots x 8 XCDs = the first 256 workgroups
         const int cut_wgs = 8 * (g.m_per * g.n_per - g.full_slots);
-        if (cut_wgs <= 0 || (long)cut_wgs * g.split_s > kPkSplitMaxUnits || cut_wgs > 1024) g.split_s = 1;  // does not fit the scratch area: whole tiles
+        if (cut_wgs <= 0 || (long)cut_wgs * g.split_s * (rows256 ? 2 : 1) > kPkSplitMaxUnits || cut_wgs > 1024) g.split_s = 1;  // does not fit the scratch area: whole tiles
     }
     const int ks = form;
     hipError_t e;
     const int lg = d.group_size == 128 ? 7 : (d.group_size == 64 ? 6 : 5);
-    if (g_pk_abl && lg == 7) {
+    if (g_pk_abl && lg == 7 && !rows256) {
         switch (g_pk_abl) {
 #define TCE_ABL(X) case X: e = launch_pk<1, 7, X>(g, stream); break;
             TCE_ABL(1) TCE_ABL(2) TCE_ABL(4) TCE_ABL(8) TCE_ABL(16) TCE_ABL(32) TCE_ABL(6) TCE_ABL(7) TCE_ABL(23) TCE_ABL(55) TCE_ABL(47) TCE_ABL(48) TCE_ABL(64)
@@ -818,7 +1065,17 @@ int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_
         }
         return TCE_OK;
     }
-    if (ks == 3) e = lg == 7 ? launch_pk<1, 7, 0, 2>(g, stream) : (lg == 6 ? launch_pk<1, 6, 0, 2>(g, stream) : launch_pk<1, 5, 0, 2>(g, stream));
+    if (rows256w) e = launch_pk256w<7>(g, stream);
+    else if (rows256x2) e = launch_pk256x2<7>(g, stream);
+    else if (rows256 && g_pk_abl) {  // timing experiments on the 256-row form (results meaningless): tce_w4a16_set_debug_mode(66), then 600 + bits as for the 128-row form
+        switch (g_pk_abl) {
+#define TCE_ABL(X) case X: e = launch_pk256<7, X>(g, stream); break;
+            TCE_ABL(1) TCE_ABL(2) TCE_ABL(4) TCE_ABL(8) TCE_ABL(16) TCE_ABL(32) TCE_ABL(7) TCE_ABL(55)
+#undef TCE_ABL
+            default: return TCE_ERR_BAD_ARG;
+        }
+    } else if (rows256) e = launch_pk256<7>(g, stream);  // (groups of 128 only: gemm_pk_estimate_us offers forms 6 / 7 for no other group size)
+    else if (ks == 3) e = lg == 7 ? launch_pk<1, 7, 0, 2>(g, stream) : (lg == 6 ? launch_pk<1, 6, 0, 2>(g, stream) : launch_pk<1, 5, 0, 2>(g, stream));
     else if (ks == 2) e = lg == 7 ? launch_pk<2, 7>(g, stream) : (lg == 6 ? launch_pk<2, 6>(g, stream) : launch_pk<2, 5>(g, stream));
     else e = lg == 7 ? launch_pk<1, 7>(g, stream) : (lg == 6 ? launch_pk<1, 6>(g, stream) : launch_pk<1, 5>(g, stream));
     if (e != hipSuccess) {
