@@ -8,7 +8,7 @@
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"
 TAG=${1:-r4}
 cd /tmp && export TMPDIR=/tmp
-for WL in llama3-8b baseline-named; do
+for WL in ${PROFILE_WORKLOADS-llama3-8b baseline-named}; do  # (PROFILE_WORKLOADS="" : the dominant launch only)
   OUT=$REPO/gpurun_out/prof_${TAG}_${WL}
   mkdir -p $OUT
   CMD="python $REPO/bench.py --shapes-only --workload $WL ${BENCH_EXTRA}"

@@ -14,33 +14,49 @@ from collections import defaultdict
 
 root = sys.argv[1]
 MINE = "tce::"
+import re
+FILTER = re.compile(os.environ.get("TCE_PROF_FILTER", ""))  # only kernels whose name matches (one summary file per kernel family: profile_r5.sh)
 
 
-def short(name):
+def mine(name):
+    return "tce::" in name and bool(FILTER.search(name))
+
+
+KEY_GRID = os.environ.get("TCE_PROF_KEY_GRID", "0") == "1"  # one row per (kernel, grid size): a driver that runs several shapes through one kernel (profile_r5.sh)
+
+
+def short(name, row=None):
     i = name.find(MINE)
-    return name[i:i + 110] if i >= 0 else name[:110]
+    s = name[i:i + 110] if i >= 0 else name[:110]
+    if KEY_GRID and row is not None:
+        gs = row.get("Grid_Size_X") or row.get("Grid_Size")
+        if gs:
+            s += f" [grid {gs}]"
+    return s
 
 
 avg_ns = {}
 for f in sorted(glob.glob(os.path.join(root, "kt", "**", "*kernel_stats.csv"), recursive=True)):
     print("== kernel stats (rocprofv3 --kernel-trace --stats):", os.path.relpath(f, root))
     for row in csv.DictReader(open(f)):
-        if MINE in row.get("Name", ""):
+        if mine(row.get("Name", "")):
             avg_ns[short(row["Name"])] = float(row["AverageNs"])
             print("  ", short(row["Name"]), "| calls", row.get("Calls"), "| avg ns", row.get("AverageNs"), "| min", row.get("MinNs"), "| max", row.get("MaxNs"),
                   "| stddev", row.get("StdDev"))
 for f in sorted(glob.glob(os.path.join(root, "kt", "**", "*kernel_trace.csv"), recursive=True)):
-    rows = [r for r in csv.DictReader(open(f)) if MINE in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if mine(r["Kernel_Name"])]
     by = defaultdict(list)
     for r in rows:
-        by[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r))
+        by[short(r["Kernel_Name"], r) if KEY_GRID else r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r))
     print("== kernel trace:", os.path.relpath(f, root), len(rows), "dispatches of this library")
     for k, v in sorted(by.items(), key=lambda kv: -sum(e - s for s, e, _ in kv[1])):
         d = sorted(e - s for s, e, _ in v)
         v.sort(key=lambda t: t[0])
         gaps = sorted(v[i + 1][0] - v[i][1] for i in range(len(v) - 1))
         r0 = v[0][2]
-        print(f"   {short(k)}\n      n={len(d)} dur ns min/med/mean/max = {d[0]}/{d[len(d)//2]}/{sum(d)//len(d)}/{d[-1]}  gap ns med = {gaps[len(gaps)//2] if gaps else None}"
+        if KEY_GRID:
+            avg_ns[k] = sum(d) / len(d)
+        print(f"   {k if KEY_GRID else short(k)}\n      n={len(d)} dur ns min/med/mean/max = {d[0]}/{d[len(d)//2]}/{sum(d)//len(d)}/{d[-1]}  gap ns med = {gaps[len(gaps)//2] if gaps else None}"
               f"  grid={r0.get('Grid_Size_X', r0.get('Grid_Size'))} wg={r0.get('Workgroup_Size_X', r0.get('Workgroup_Size'))} vgpr={r0.get('VGPR_Count')} sgpr={r0.get('SGPR_Count')} lds={r0.get('LDS_Block_Size')}")
 med = defaultdict(dict)
 for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
@@ -48,8 +64,8 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
         acc = defaultdict(lambda: defaultdict(list))
         n = 0
         for r in csv.DictReader(open(f)):
-            if MINE in r["Kernel_Name"]:
-                acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if mine(r["Kernel_Name"]):
+                acc[short(r["Kernel_Name"], r)][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 n += 1
         print("== pmc:", os.path.relpath(f, root), n, "rows of this library")
         for k, cs in acc.items():
@@ -67,6 +83,15 @@ for k, m in med.items():
         out.append(f"HBM write traffic = {m['WRITE_SIZE'] * 2048 / 1e6:.3f} MB")
     if "SQ_INSTS_VALU" in m and "SQ_WAVES" in m:
         out.append(f"VALU instructions per wave = {m['SQ_INSTS_VALU'] / m['SQ_WAVES']:.0f}")
+    if "SQ_INSTS_VALU" in m and m.get("SQ_INSTS_MFMA"):
+        out.append(f"SQ_INSTS_VALU / SQ_INSTS_MFMA = {m['SQ_INSTS_VALU'] / m['SQ_INSTS_MFMA']:.2f} (the counter includes the MFMAs: {m['SQ_INSTS_VALU'] / m['SQ_INSTS_MFMA'] - 1:.2f} other vector instructions per MFMA)")
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in m and m.get("GRBM_GUI_ACTIVE"):
+        # SQ_VALU_MFMA_BUSY_CYCLES sums over the chip's 1024 SIMDs in units of 4 cycles? -- printed raw beside the launch's cycles; the ratio quoted in DESIGN is busy / (GRBM_GUI_ACTIVE x SIMDs)
+        out.append(f"SQ_VALU_MFMA_BUSY_CYCLES = {m['SQ_VALU_MFMA_BUSY_CYCLES']:.4g}, GRBM_GUI_ACTIVE = {m['GRBM_GUI_ACTIVE']:.4g}: matrix pipe busy = {m['SQ_VALU_MFMA_BUSY_CYCLES'] / (m['GRBM_GUI_ACTIVE'] * 1024):.2f} of the launch's SIMD-cycles (1024 SIMDs)")
+    if "SQ_BUSY_CYCLES" in m and "SQ_VALU_MFMA_BUSY_CYCLES" in m and "GRBM_GUI_ACTIVE" not in m:
+        out.append(f"SQ_VALU_MFMA_BUSY_CYCLES = {m['SQ_VALU_MFMA_BUSY_CYCLES']:.4g}")
+    if "SQ_INSTS_LDS" in m and m.get("SQ_INSTS_MFMA"):
+        out.append(f"LDS instructions per MFMA = {m['SQ_INSTS_LDS'] / m['SQ_INSTS_MFMA']:.2f}; bank-conflict cycles / LDS active cycles = {m.get('SQ_LDS_BANK_CONFLICT', 0) / max(1.0, m.get('SQ_ACTIVE_INST_LDS', 1)):.3f}")
     if "SQ_WAIT_ANY" in m and "SQ_WAVE_CYCLES" in m:
         out.append(f"wave-cycles parked on s_waitcnt/barrier = {m['SQ_WAIT_ANY'] / m['SQ_WAVE_CYCLES']:.2f}, stalled at issue = {m.get('SQ_WAIT_INST_ANY', 0) / m['SQ_WAVE_CYCLES']:.2f}, "
                    f"issuing = {m.get('SQ_ACTIVE_INST_ANY', 0) / m['SQ_WAVE_CYCLES']:.2f}")
@@ -82,7 +107,7 @@ for k, m in med.items():
     if "w4a16_gemv" in k and "FETCH_SIZE" in m:
         n = 0
         for d in glob.glob(os.path.join(root, "pmc_fetch", "**", "*counter_collection.csv"), recursive=True):
-            n += sum(1 for r in csv.DictReader(open(d)) if MINE in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE")
+            n += sum(1 for r in csv.DictReader(open(d)) if mine(r["Kernel_Name"]) and r["Counter_Name"] == "FETCH_SIZE")
         import hashlib
         csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tinychatengine_amd", "csrc")
         srcs = ["w4a16_gemv_i8.hip", "w4a16_mfma_layout.hpp"] if "gemv_i8" in k else ["w4a16_gemv.hip"]
