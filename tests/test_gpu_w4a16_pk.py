@@ -99,19 +99,21 @@ def test_pk_gemm_matches_oracle(dev, oracle, M, N, K, G):
     from tinychatengine_amd import capi
     L = capi.lib()
     rng = np.random.default_rng(M + N + K)
-    for rz, zs in ((False, 0), (True, 4)):
+    for rz, zs in ((False, 0), (True, 4), (False, 3)):  # (the wide forms -- modes 2670 .. 2672 -- run on the linears whose zero points are all 8; the others keep the narrow forms under these modes)
         qw, sc, zp = _quant(oracle, N, K, G, seed=M * 3 + N + K, random_zeros=rz, zero_scale_groups=zs)
         a = rng.standard_normal((M, K)).astype(np.float16)
         ref32 = oracle.w4a16_gemv_q4_6_mt(a, qw, sc, zp, M, N, K, G)
         lin = _lin(dev, qw, sc, zp, G).prepack()
         x = torch.from_numpy(a).to(dev)
         try:
-            for mode in (61, 62, 63, 64, 66, 67, 672, 68, 2669, 60):  # 64: the k range cut across workgroups (needs the scratch area desc() attaches); 66 / 67 / 672 / 68 / 2669: the 256-row wave tiles (round 5; groups of 128 -- other group sizes run form 1 under these modes): whole tiles / k range cut / two quartets alternating a tile's k-blocks (even counts; odd: one quartet) / two quartets side by side on 256 x 256
+            for mode in (61, 62, 63, 64, 66, 67, 672, 68, 2669, 2670, 2671, 2672, 2683, 60):  # 64: the k range cut across workgroups (needs the scratch area desc() attaches); 66 / 67 / 672 / 68 / 2669: the 256-row wave tiles (round 5; groups of 128 -- other group sizes run form 1 under these modes): whole tiles / k range cut / two quartets alternating a tile's k-blocks (even counts; odd: one quartet) / two quartets side by side on 256 x 256
                 capi.check(L.tce_w4a16_set_debug_mode(mode))
                 out = torch.full((M, N), float("nan"), dtype=torch.float16, device=dev)
                 d = lin.desc(x, out)
                 if mode != 60:  # (60 = automatic: the cost models of the two GEMMs decide, test_pk_dispatch_rules)
                     assert capi.describe_dispatch(d).startswith("gemm-pk"), capi.describe_dispatch(d)
+                if mode in (2670, 2671, 2672, 2683) and not rz and G == 128 and M > 128:  # round 5: 128 rows x 64 columns per wave
+                    assert "wave=128x64" in capi.describe_dispatch(d), capi.describe_dispatch(d)
                 capi.check(capi.w4a16_forward(d, torch.cuda.current_stream().cuda_stream))
                 torch.cuda.synchronize()
                 got = out.cpu().numpy()
@@ -297,3 +299,43 @@ def test_full_size_prefill_on_the_packed_kernel(dev, oracle, N, K):
     rep = w4a16_report(got, ref32)
     record_parity(f"prefill M=512 {N}x{K} pre-packed kernel (128 rows)", rep)
     assert rep["frac_over_plain"] < 0.01 and rep["worst_plain"] <= 1.0, rep
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 4096, 4096), (512, 11008, 4096), (1024, 4096, 11008)])
+def test_wide_form_against_the_narrow_form_at_full_size(dev, oracle, M, N, K):
+    """Round 5, the wide form (128 rows x 64 columns per wave; modes 2670 / 2671 / 2672): one quartet per 128 x 256 tile walks the k-blocks in the order the 128 x 128
+    form does, with the same rescale sequence -- every output BIT-identical to form 1's (which the full-size tests above hold to the oracle); two quartets alternating
+    the k-blocks and the k range cut across workgroups add partial sums in a fixed order: close to it, identical from call to call; 64 rows against the oracle."""
+    from tinychatengine_amd import capi
+    from tinychatengine_amd.linear import Linear_half_int4, gemm_scratch
+    L = capi.lib()
+    g = torch.Generator(device=dev).manual_seed(91 + N + M)
+    lin = Linear_half_int4.from_float(torch.empty(N, K, device=dev).normal_(0, 0.02, generator=g), 128).prepack()
+    assert lin.zeros_are_8
+    x = torch.empty(M, K, device=dev).normal_(0, 1, generator=g).to(torch.float16)
+    outs = {}
+    try:
+        for mode in (61, 2670, 2671, 2672):
+            capi.check(L.tce_w4a16_set_debug_mode(mode))
+            ys = []
+            for rep in range(2):
+                y = torch.full((M, N), float("nan"), dtype=torch.float16, device=dev)
+                d = lin.desc(x, y)
+                if mode != 61:
+                    assert "wave=128x64" in capi.describe_dispatch(d), capi.describe_dispatch(d)
+                capi.check(capi.w4a16_forward(d, torch.cuda.current_stream().cuda_stream))
+                torch.cuda.synchronize()
+                ys.append(y)
+            assert torch.equal(ys[0], ys[1]), f"mode {mode}: two calls differ"
+            assert not torch.isnan(ys[0].float()).any(), f"mode {mode}: unwritten outputs"
+            outs[mode] = ys[0]
+    finally:
+        L.tce_w4a16_set_debug_mode(60)
+    assert int(gemm_scratch(dev)[:4096].to(torch.int32).sum().item()) == 0
+    assert torch.equal(outs[2670], outs[61]), "one quartet per wide tile: the same sums in the same order as the 128 x 128 form"
+    rows = list(range(0, M, M // 64))
+    ref32 = oracle.w4a16_gemv_q4_6_mt(x[rows].cpu().numpy(), lin.weight.cpu().numpy().view(np.uint32), lin.scale.cpu().numpy(),
+                                      lin.zero_point.cpu().numpy().view(np.uint32), len(rows), N, K, 128)
+    for mode in (2670, 2671, 2672):
+        ok, worst = w4a16_close(outs[mode][rows].cpu().numpy(), ref32)
+        assert ok, f"mode {mode}: worst |err|/tol = {worst:.3f}"

@@ -86,7 +86,7 @@ static bool use_pk(const tce_w4a16_desc *d, bool want_gemm) {
     // to fill the chip: M = 512 at N = 4096); groups of 64 / 32: the pre-packed kernel needs no LDS re-deal, it takes them
     if (d->group_size != 128) return true;
     const bool has_scratch = d->scratch != nullptr && (reinterpret_cast<uintptr_t>(d->scratch) & 255) == 0;
-    return tce::gemm_pk_estimate_us(d->M, d->N, d->K, nullptr, has_scratch, nullptr, d->group_size) < tce::gemm_dma_estimate_us(d->M, d->N, d->K) + 1.5f;
+    return tce::gemm_pk_estimate_us(d->M, d->N, d->K, nullptr, has_scratch, nullptr, d->group_size, (d->flags & TCE_W4_ZERO_POINT_IS_8) != 0) < tce::gemm_dma_estimate_us(d->M, d->N, d->K) + 1.5f;
 }
 
 // Plain (no fused prologue) launches: the persistent kernel is no longer chosen automatically -- with four rows per wave and four waves
@@ -214,6 +214,30 @@ int tce_w4a16_set_debug_mode(int mode) {
         g_pk_mode = mode == 600 ? 0 : 1;
         tce::set_gemm_pk_mode(mode == 600 ? 0 : 1, 0);
         tce::set_gemm_pk_ablation(mode - 600);
+        return TCE_OK;
+    }
+    if (mode >= 2670 && mode <= 2672) {  // pre-packed GEMM, the wide form (128 rows x 64 columns per wave): 2670 one quartet per 128 x 256 tile, 2671 two quartets alternating its k-blocks, 2672 every tile's k range cut across workgroups
+        g_pk_mode = 8;
+        tce::set_gemm_pk_ablation(0);
+        tce::set_gemm_pk_split(0);
+        tce::set_gemm_pk_mode(10 + mode - 2670, 0);
+        return TCE_OK;
+    }
+    if (mode >= 2682 && mode <= 2684) {  // the wide form with every tile's k range cut into 2 / 3 / 4 runs
+        g_pk_mode = 8;
+        tce::set_gemm_pk_ablation(0);
+        tce::set_gemm_pk_mode(12, 0);
+        tce::set_gemm_pk_split(mode - 2680);
+        return TCE_OK;
+    }
+    if (mode == 692 || mode == 693) {  // pre-packed GEMM: 693 = the dispatcher may pick the wide forms, 692 = never
+        tce::set_gemm_pk_wide_auto(mode - 692);
+        return TCE_OK;
+    }
+    if (mode >= 26000 && mode <= 26064) {  // the wide form (one quartet) with parts of its loop switched off (timing experiments)
+        g_pk_mode = mode == 26000 ? 0 : 8;
+        tce::set_gemm_pk_mode(mode == 26000 ? 0 : 10, 0);
+        tce::set_gemm_pk_ablation(mode - 26000);
         return TCE_OK;
     }
     if (mode == 2669) {  // pre-packed GEMM: 256 x 256 tiles, two quartets side by side (form 9)
@@ -542,8 +566,11 @@ int tce_w4a16_describe_dispatch(const tce_w4a16_desc *d, char *buf, int buf_len)
     const bool pairs_on_pk = (d->flags & TCE_W4_SILU_MUL_PAIRS) && d->prepacked && d->M >= kPkMinM && !(d->flags & TCE_W4_FORCE_GEMV);
     if (use_pk(d, want_gemm || pairs_on_pk)) {
         int form = 1, split = 1;
-        tce::gemm_pk_estimate_us(d->M, d->N, d->K, &form, d->scratch != nullptr && (reinterpret_cast<uintptr_t>(d->scratch) & 255) == 0, &split, d->group_size);
-        if (form == 4) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=128x128 quartets=1 ksplit=%d group=%d", split, d->group_size);
+        tce::gemm_pk_estimate_us(d->M, d->N, d->K, &form, d->scratch != nullptr && (reinterpret_cast<uintptr_t>(d->scratch) & 255) == 0, &split, d->group_size, (d->flags & TCE_W4_ZERO_POINT_IS_8) != 0);
+        if (form == 10) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=128x256 wave=128x64 quartets=1 group=%d", d->group_size);
+        else if (form == 11) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=128x256 wave=128x64 quartets=2 group=%d", d->group_size);
+        else if (form == 12) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=128x256 wave=128x64 quartets=1 ksplit=%d group=%d", split, d->group_size);
+        else if (form == 4) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=128x128 quartets=1 ksplit=%d group=%d", split, d->group_size);
         else if (form == 5) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=128x128 quartets=1 ksplit=%d-of-the-tiles-past-256 group=%d", split, d->group_size);
         else if (form == 6) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=256x128 quartets=1 group=%d", d->group_size);
         else if (form == 7) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=256x128 quartets=1 ksplit=%d group=%d", split, d->group_size);

@@ -174,7 +174,9 @@ __device__ __forceinline__ void sched_group() {
 
 // 16-row MFMA tiles per wave: template parameter MT of the kernel body -- 8 (128 rows: rounds 2-4) or 16 (256 rows, round 5: every unpacked weight word and every
 // landed asm load feeds twice the MFMAs; one wave per SIMD, the 128 accumulator registers beside double-buffered A fragments the compiler may keep in AGPRs)
-constexpr int kNT = 2;  // 16-column MFMA tiles per wave (32 columns); 4 waves side by side = 128 columns
+// 16-column MFMA tiles per wave: template parameter NT of the kernel body -- 2 (32 columns; 4 waves side by side = 128 columns: rounds 2-5) or 4 (round 5, the "wide" form:
+// 128 rows x 64 columns per wave, 128 x 256 per quartet -- every A fragment read from LDS feeds FOUR MFMAs and every activation DMA twice the MFMAs of the other forms; what
+// bounds those is not the vector ALU but the fragment reads, the DMA issue and the barriers, which serialise with the MFMA stream of an in-order wave: section 3.2 of DESIGN.md)
 
 // The compiler allocates v0 .. v231 only; v232 .. v255 belong to the inline asm below (a block's words and constants in flight).
 constexpr int kAsmVgprBase = 232;  // 128-row forms (and every group size); the 256-row form does not reserve registers at all (round 5: amdgpu_num_vgpr turned out to be a HINT in this toolchain -- a kernel under pressure is given v232 .. v255 as well; the 128-row forms stay below 232 by themselves, checked in the ISA)
@@ -183,9 +185,11 @@ constexpr int kAsmVgprBase = 232;  // 128-row forms (and every group size); the 
 // NS = 2: two wave quartets side by side on a 128 x 256 tile, sharing ONE activation ring (KS = 1 then): the activation bytes a CU
 // pulls through L2 -> LDS per MFMA halve.  That path, not the matrix pipe, bounds the 128 x 128 forms: the activation DMAs of
 // M = 2048, 4096 x 4096 alone take 32 us of the 68 (profiles/r2/gemm_pk_ablation.jsonl; ~64 GB/s per CU), the MFMAs alone 38.
-template <int KS, int LG, int ABL, int NS, int kMT>
+template <int KS, int LG, int ABL, int NS, int kMT, int kNT = 2>
 __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
     static_assert(KS == 1 || NS == 1, "two quartets either split K or sit side by side");
+    static_assert(kNT == 2 || (kNT == 4 && kMT == 8 && NS == 1 && LG == 7), "wide form: 128 rows x 64 columns per wave, one quartet per 128 x 256 tile (or two alternating its k-blocks), groups of 128");
+    constexpr bool WIDE = kNT == 4;
     static_assert(kMT == 8 || (kMT == 16 && (NS == 1 || KS == 1)), "256-row wave tiles: one quartet per tile, two quartets splitting the k-blocks of one tile, or two quartets side by side on one activation ring");
     constexpr int ROWS = 16 * kMT;                   // rows of the activation tile
     constexpr int HALF_BYTES = ROWS * pk::kHalfK * 2;  // one half-stage of activations: 16 / 32 KiB
@@ -195,7 +199,7 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
     constexpr int AB = ABL & 63;         // loop parts switched off; bit 6 (64): the rescale as four scalar multiplies per tile (this round's first form, for the A/B)
     constexpr int NWR = 4 * NS;          // waves feeding (and reading) one ring
     constexpr int DPW = (ROWS / 8) / NWR;  // DMA instructions per wave and half-stage (8 rows each)
-    constexpr int BN = 128 * NS;
+    constexpr int BN = 64 * kNT * NS;
     constexpr int GPB = 128 >> LG;  // groups per k-block
     constexpr int SPG = 4 / GPB;    // MFMA steps per group
     // ring depth in half-stages per quartet: four (a half-stage is refilled two k-blocks ahead) -- or TWO for the 256-row tile shared by two quartets (round 5:
@@ -238,9 +242,10 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
 
     // ---- DMA sources of a half-stage: instruction ii of this wave fills 8 rows; the lane fetches the piece that belongs at its position ----
     // (uniform 64-bit base + 32-bit lane offset: the address arithmetic of a refill is scalar; launch_w4a16_gemm_pk refuses M * lda * 2 >= 4 GiB)
-    unsigned a_voff[kMT == 16 ? 1 : DPW];
+    constexpr bool BUFDMA = kMT == 16 || WIDE;  // the activation DMAs through a buffer descriptor (one lane offset, everything else scalar)
+    unsigned a_voff[BUFDMA ? 1 : DPW];
 #pragma unroll
-    for (int ii = 0; ii < (kMT == 16 ? 0 : DPW); ++ii) {
+    for (int ii = 0; ii < (BUFDMA ? 0 : DPW); ++ii) {
         const int row = pk::dma_row(wave, ii, lane, NWR);
         int m = m_base + row;
         m = m < g.M ? m : g.M - 1;  // rows past M repeat the last row; their outputs are not stored
@@ -260,7 +265,7 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
         kb = kb_lo + (kb < nloc ? kb : nloc - 1);
         const char *src = a_bytes + ((size_t)kb * 256 + (h & 1) * 128);  // wave-uniform
         unsigned char *st = ring + (h & (RD - 1)) * HALF_BYTES;
-        if constexpr (kMT == 16) {
+        if constexpr (BUFDMA) {
             const unsigned s0 = (unsigned)(m_base + wave * 8) * (unsigned)(g.lda * 2) + (unsigned)(kb * 256 + (h & 1) * 128);
 #pragma unroll
             for (int ii = 0; ii < DPW; ++ii)
@@ -287,8 +292,12 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl) a_off[sl] = pk::frag_offset(0, n16, q, sl);  // + i * 2048 per m-tile
 
-    unsigned mask_lo;
-    asm volatile("v_mov_b32 %0, 0x000F000F" : "=v"(mask_lo));
+    // (a VALU instruction of this chip reads ONE scalar / literal operand: of the two constants of `(w & mask) | 0x6400_6400` one lives in a vector register.  The narrow
+    // forms keep the two masks there; the wide form, which has no register to spare, keeps the 0x6400 pair and takes both masks from scalar registers)
+    unsigned mask_lo = 0x000F000Fu, k64 = 0x64006400u;
+    unsigned k2v = 0xD480D480u;  // -(64 + 8) twice: the third operand of the packed fma beside a scalar 1/16 -- in a vector register like k64
+    if constexpr (WIDE) asm volatile("v_mov_b32 %0, 0x64006400\n\tv_mov_b32 %1, 0xD480D480" : "=v"(k64), "=v"(k2v));
+    else asm volatile("v_mov_b32 %0, 0x000F000F" : "=v"(mask_lo));
     const unsigned mask_hi = mask_lo << 4;
     const half2_t sixteenth = as_half2(0x2C002C00u);
 
@@ -301,9 +310,15 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
 #pragma unroll
     for (int j = 0; j < kNT; ++j) e_prev[j] = 0.f;  // "no group yet": the first ratio is forced to 1
 
+    // (wide form: offered for linears whose zero points are all 8 -- TCE_W4_ZERO_POINT_IS_8, what the reference's quantizer writes -- so a block's constants are the
+    //  effective scales alone: 4 landing registers + 4 current ones less than with the packed zero-point words; other linears keep the narrow forms)
+    struct CW {
+        unsigned x;
+    };
+    using const_t = std::conditional_t<WIDE, CW, uint2_t>;
     struct BlockRegs {
         uint4_t w[kNT];
-        uint2_t c[kNT][GPB];
+        const_t c[kNT][GPB];
     };
     BlockRegs cur;
     auto block_of = [&](int t) {
@@ -317,7 +332,11 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
         for (int j = 0; j < kNT; ++j) {
             cur.w[j] = w_tile[j][(size_t)kb * 64 + lane];
 #pragma unroll
-            for (int gi = 0; gi < GPB; ++gi) cur.c[j][gi] = c_tile[j][(size_t)(kb * GPB + gi) * 16 + n16];
+            for (int gi = 0; gi < GPB; ++gi) {
+                const uint2_t c2_ = c_tile[j][(size_t)(kb * GPB + gi) * 16 + n16];
+                if constexpr (WIDE) cur.c[j][gi].x = c2_.x;
+                else cur.c[j][gi] = c2_;
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -332,7 +351,8 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
     // fragments of the step being multiplied and of the next one.  kMT == 16: ONE set of A fragments (64 registers beside the 128 accumulators), refilled tile by
     // tile -- m-tile i's fragment of the next step is read as soon as its two MFMAs of this step have issued
     constexpr bool ROLL = kMT == 16;
-    half8_t af[ROLL ? 1 : 2][kMT], bf[ROLL ? 1 : 2][kNT];  // (256-row form: ONE set of B fragments too -- the next step's are unpacked behind this step's last MFMA)
+    constexpr bool INFL = ROLL || WIDE;  // the next block's words land in ordinary variables behind a counted wait (see `inflight`); one set of A / B fragments
+    half8_t af[INFL ? 1 : 2][kMT], bf[INFL ? 1 : 2][kNT];  // (256-row form: ONE set of B fragments too -- the next step's are unpacked behind this step's last MFMA)
     half2_t c1[kNT], c2[kNT];        // (-(1024+z)) x2 and (-(64+z)) x2 of the group being unpacked
     auto read_a = [&](half8_t (&dst)[kMT], const unsigned char *half_stage, int sl) {
         const unsigned char *st = half_stage + a_off[sl];
@@ -342,7 +362,8 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
     auto set_group = [&](const BlockRegs &br, int gi) {
 #pragma unroll
         for (int j = 0; j < kNT; ++j) {
-            const unsigned zc = br.c[j][gi].y;
+            unsigned zc = 0;
+            if constexpr (!WIDE) zc = br.c[j][gi].y;
             c1[j] = as_half2(__builtin_amdgcn_perm(zc, zc, 0x01000100u));  // low half twice
             c2[j] = as_half2(__builtin_amdgcn_perm(zc, zc, 0x03020302u));  // high half twice
         }
@@ -358,6 +379,18 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
             const half2_t d3 = __builtin_elementwise_fma(as_half2((sh & mask_hi) | 0x64006400u), sixteenth, c2[j]);
             dst[j] = half8_t{d0.x, d0.y, d1.x, d1.y, d2.x, d2.y, d3.x, d3.y};
         }
+    };
+    // wide form: one column tile's fragment of step s; the zero-point constants come straight from the block's zc word -- the two splats fold into op_sel of the packed
+    // add / fma (no v_perm, no c1 / c2 registers)
+    auto unpack_col = [&](half8_t &dst, const BlockRegs &br, int s, int j) {
+        const half2_t k1 = as_half2(0xE408E408u), k2 = as_half2(k2v);  // -(1024 + 8), -(64 + 8)
+        const unsigned w = br.w[j][s];
+        const unsigned sh = w >> 8;
+        const half2_t d0 = as_half2((w & 0x000F000Fu) | k64) + k1;
+        const half2_t d1 = __builtin_elementwise_fma(as_half2((w & 0x00F000F0u) | k64), sixteenth, k2);
+        const half2_t d2 = as_half2((sh & 0x000F000Fu) | k64) + k1;
+        const half2_t d3 = __builtin_elementwise_fma(as_half2((sh & 0x00F000F0u) | k64), sixteenth, k2);
+        dst = half8_t{d0.x, d0.y, d1.x, d1.y, d2.x, d2.y, d3.x, d3.y};
     };
     auto rescale = [&](const float (&e_new)[kNT]) {  // acc <- acc * e_prev / e_g: the accumulator moves into the units of group g
 #pragma unroll
@@ -398,6 +431,52 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
         constexpr int s = decltype(s_c)::value;
         constexpr int sn = (s + 1) & 3;  // the step whose fragments are fetched here
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (WIDE) {
+            // wide form (128 rows x 64 columns per wave): two phases of four m-tiles, each walked column tile by column tile -- eight fenced groups of four MFMAs:
+            //   [the group's share of the rescale] [its 4 MFMAs] [behind a phase's LAST group: its four m-tiles' fragments of the NEXT step, into the registers those
+            //   MFMAs just read -- sixteen MFMAs ahead of their use] [second phase: the next step's fragment of THIS column tile, which no MFMA of this step reads again].
+            // One set of A fragments (32 registers) and one of B fragments (16) beside the 128 accumulators; 36 unpack instructions per 32 MFMAs.
+            float r[kNT];
+            if constexpr (s % SPG == 0 && !(AB & 1)) {
+#pragma unroll
+                for (int j = 0; j < kNT; ++j) {
+                    const float en = e_grp[s / SPG][j];
+                    r[j] = e_prev[j] == 0.f ? 1.0f : e_prev[j] * __builtin_amdgcn_rcpf(en);
+                    e_prev[j] = en;
+                }
+            }
+            // (the second local step's fragment offset is the first one's with bit 6 flipped -- piece index + 4 under the swizzle; made here, by an instruction the
+            //  compiler may not hoist, instead of living in a register across the loop)
+            int a_off_sn = a_off[0];
+            if constexpr (sn & 1) asm volatile("v_xor_b32 %0, 64, %1" : "=v"(a_off_sn) : "v"(a_off[0]));
+            const unsigned char *st_next = half_stage_next + a_off_sn;
+            static_for<0, 2 * kNT>([&](auto u_c) {
+                constexpr int ph = decltype(u_c)::value / kNT, j = decltype(u_c)::value % kNT;
+                if constexpr (s % SPG == 0 && !(AB & 1)) {
+                    const float2_t r2{r[j], r[j]};
+#pragma unroll
+                    for (int i = 4 * ph; i < 4 * ph + 4; ++i) {
+                        const float2_t lo = float2_t{acc[i][j][0], acc[i][j][1]} * r2, hi = float2_t{acc[i][j][2], acc[i][j][3]} * r2;
+                        acc[i][j] = float4_t{lo.x, lo.y, hi.x, hi.y};
+                    }
+                }
+                if constexpr (!(AB & 8)) {
+#pragma unroll
+                    for (int i = 4 * ph; i < 4 * ph + 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int i = 4 * ph; i < 4 * ph + 4; ++i) asm volatile("" ::"v"(af[0][i]));
+                    asm volatile("" ::"v"(bf[0][j]));
+                }
+                if constexpr (j == kNT - 1 && !(AB & 4)) {
+#pragma unroll
+                    for (int i = 4 * ph; i < 4 * ph + 4; ++i) af[0][i] = *reinterpret_cast<const half8_t *>(st_next + i * 2048);
+                }
+                if constexpr (ph == 1 && !(AB & 2)) unpack_col(bf[0][j], br_next, sn, j);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            return;
+        }
         if constexpr (ROLL) {
             // 256-row form: four chunks of four m-tiles, each fenced -- [the chunk's share of the rescale] [its 8 MFMAs] [its tiles' fragments of the NEXT step into
             // the registers those MFMAs just read] [a share of the next step's unpack].  (MFMA and VALU issue serialise on a SIMD, scripts/probes/valu_probe.hip: what
@@ -484,7 +563,7 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
     // the landed words are copied out (12 v_mov per k-block for groups of 128) into ordinary variables, and the same registers
     // take the next request.
 #define TCE_PK_CLOB232 "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
-    static_assert(kNT == 2, "the request / collect macros below spell out two column tiles");
+    static_assert(kNT == 2 || INFL, "the request / collect macros below spell out two column tiles");
 #define TCE_PK_REQ_W(J, CLOB)                                                                                                        \
     asm volatile("s_nop 4\n\tglobal_load_dwordx4 v[%c2:%c3], %0, %1" ::"v"(w_voff), "s"(w_tile[J] + (size_t)kbn * 64), "i"(ASMB + 4 * J), "i"(ASMB + 4 * J + 3) \
                  : "memory", CLOB);
@@ -514,10 +593,12 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
         TCE_PK_GET(dst.c[J][GI].y, 4 * kNT + 2 * (J * GPB + GI) + 1)           \
     }
     auto collect_block = [&](BlockRegs &dst) {  // only behind the counted wait that retires the request
+        if constexpr (!INFL) {
         TCE_PK_GET(dst.w[0].x, 0) TCE_PK_GET(dst.w[0].y, 1) TCE_PK_GET(dst.w[0].z, 2) TCE_PK_GET(dst.w[0].w, 3)
         TCE_PK_GET(dst.w[1].x, 4) TCE_PK_GET(dst.w[1].y, 5) TCE_PK_GET(dst.w[1].z, 6) TCE_PK_GET(dst.w[1].w, 7)
         TCE_PK_GET_C(0, 0) TCE_PK_GET_C(0, 1) TCE_PK_GET_C(0, 2) TCE_PK_GET_C(0, 3)
         TCE_PK_GET_C(1, 0) TCE_PK_GET_C(1, 1) TCE_PK_GET_C(1, 2) TCE_PK_GET_C(1, 3)
+        }
     };
     constexpr int NWL = kNT * (1 + GPB);  // VMEM instructions of request_block
     // 256-row form: no reserved registers (the attribute that reserved them is only a hint, see kAsmVgprBase).  A block's words and constants are requested by asm
@@ -530,12 +611,25 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
 #pragma unroll
         for (int j = 0; j < kNT; ++j) {
             asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(inflight.w[j]) : "v"(w_voff), "s"(w_tile[j] + (size_t)kbn * 64) : "memory");
-            asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "=v"(inflight.c[j][0]) : "v"(c_voff), "s"(c_tile[j] + (size_t)kbn * 16) : "memory");
+            if constexpr (WIDE) asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(inflight.c[j][0].x) : "v"(c_voff), "s"(c_tile[j] + (size_t)kbn * 16) : "memory");
+            else asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "=v"(inflight.c[j][0]) : "v"(c_voff), "s"(c_tile[j] + (size_t)kbn * 16) : "memory");
         }
     };
+    // the counted wait behind which `inflight` becomes valid (N = the newer VMEM instructions that may stay in flight); it names every landing register as in / out
+    static_assert(!INFL || GPB == 1, "the wait statement names one group per k-block");
+#define TCE_PK_WAIT_INFLIGHT(N)                                                                                                                                          \
+    if constexpr (kNT == 4) {                                                                                                                                            \
+        asm volatile("s_waitcnt vmcnt(%c8)"                                                                                                                              \
+                     : "+v"(inflight.w[0]), "+v"(inflight.w[1]), "+v"(inflight.w[2 % kNT]), "+v"(inflight.w[3 % kNT]), "+v"(inflight.c[0][0].x), "+v"(inflight.c[1][0].x), \
+                       "+v"(inflight.c[2 % kNT][0].x), "+v"(inflight.c[3 % kNT][0].x)                                                                                      \
+                     : "n"(N)                                                                                                                                            \
+                     : "memory");                                                                                                                                        \
+    } else {                                                                                                                                                             \
+        asm volatile("s_waitcnt vmcnt(%c4)" : "+v"(inflight.w[0]), "+v"(inflight.w[1]), "+v"(inflight.c[0][0]), "+v"(inflight.c[1][0]) : "n"(N) : "memory");             \
+    }
     if constexpr (RD == 2) {
         pk_wait_vmcnt<DPW>();  // the first block's even half has landed (its odd half may still be in flight: awaited in front of the loop's first barrier)
-    } else if constexpr (ROLL) {
+    } else if constexpr (INFL) {
         pk_wait_vmcnt<2 * DPW>();
     } else {
         request_block(1);
@@ -543,9 +637,14 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
     }
     if constexpr (!(AB & 32)) __builtin_amdgcn_s_barrier();
     // fragments of step 0 of the first block
-    set_group(cur, 0);
     read_a(af[0], ring, 0);
-    unpack(bf[0], cur, 0);
+    if constexpr (WIDE) {
+#pragma unroll
+        for (int j = 0; j < kNT; ++j) unpack_col(bf[0][j], cur, 0, j);
+    } else {
+        set_group(cur, 0);
+        unpack(bf[0], cur, 0);
+    }
     load_e(cur);
 
     if constexpr (RD == 2) {
@@ -572,7 +671,7 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
                 region(std::integral_constant<int, 2>{}, cur, st_odd);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(inflight.w[0]), "+v"(inflight.w[1]), "+v"(inflight.c[0][0]), "+v"(inflight.c[1][0]) : : "memory");
+            TCE_PK_WAIT_INFLIGHT(0)
             cur = inflight;
             if constexpr (!(AB & 32)) __builtin_amdgcn_s_barrier();
             issue_half(2 * t + 3);
@@ -581,12 +680,17 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
         }
     } else
     for (int t = 0; t < T; ++t) {
-        const bool live = grp + t * KS < nloc;  // wave-uniform; only quartet 1's last iteration can be past the run
+        // wave-uniform; only quartet 1's last iteration can be past the run (the wide form with two quartets is offered for an even number of k-blocks only: a conditional
+        // region inside the window of the in-flight asm loads invites spills -- see the two-slot loop above)
+        const bool live = (WIDE && KS == 2) ? true : grp + t * KS < nloc;
         const unsigned char *st_even = ring + ((2 * t) & 3) * HALF_BYTES, *st_odd = ring + ((2 * t + 1) & 3) * HALF_BYTES;
         const unsigned char *st_even_next = ring + ((2 * t + 2) & 3) * HALF_BYTES;
         if constexpr (ROLL) request_inflight(t + 1);
         if (live) {
             region(std::integral_constant<int, 0>{}, cur, st_even);  // MFMAs of step 0 | fragments of step 1 (even half-stage)
+            // (wide form: the request goes out behind region 0 -- with the rescale ratios of region 0 dead and a quarter of the block's words unpacked the landing
+            //  registers fit; two regions of MFMAs remain to cover the loads)
+            if constexpr (WIDE) request_inflight(t + 1);
             region(std::integral_constant<int, 1>{}, cur, st_odd);   // step 1 | step 2 (odd half-stage)
         }
         // all waves have taken their last fragment of the even half-stage: it may be refilled (own half-block 2t+4)
@@ -598,9 +702,8 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
         // [its words / constants] [half 2t+4].  vmcnt(DPW) leaves only the DMAs of half 2t+4 in flight: both half-stages of
         // block t+1 and its words have landed (in-order counter); the barrier extends that to the workgroup and orders this
         // block's reads of the odd half-stage before its refill.
-        if constexpr (ROLL) {
-            static_assert(!ROLL || (kNT == 2 && GPB == 1), "the wait statement below names two column tiles, one group per k-block");
-            asm volatile("s_waitcnt vmcnt(%c4)" : "+v"(inflight.w[0]), "+v"(inflight.w[1]), "+v"(inflight.c[0][0]), "+v"(inflight.c[1][0]) : "n"(DPW) : "memory");
+        if constexpr (INFL) {
+            TCE_PK_WAIT_INFLIGHT(DPW)
             cur = inflight;  // `cur` (block t) is used up: step 3's fragments are unpacked
         } else {
             pk_wait_vmcnt<DPW>();
@@ -609,11 +712,12 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr (!(AB & 32)) __builtin_amdgcn_s_barrier();
         issue_half(2 * t + 5);
-        if constexpr (!ROLL) request_block(t + 2);
+        if constexpr (!INFL) request_block(t + 2);
         if (live) region(std::integral_constant<int, 3>{}, cur, st_even_next);  // step 3 | step 0 of the next block (`cur` is the next block now)
         load_e(cur);
     }
 #undef TCE_PK_CLOB232
+#undef TCE_PK_WAIT_INFLIGHT
 #undef TCE_PK_REQ_W
 #undef TCE_PK_REQ_C
 #undef TCE_PK_GET
@@ -680,8 +784,8 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
         if (*flag == 0u) return;
         __syncthreads();  // (the flag word is part of the output tile's LDS image below)
         // the sum in run order 0, 1, ..., split_s - 1 whoever computes it
-        if constexpr (ROLL) {
-            // 256-row tiles: 128 accumulator registers leave no room for a second copy -- every run's partial (this one's included: the same values it stored) is
+        if constexpr (kMT * kNT > 16) {
+            // 256-row and wide tiles: 128 accumulator registers leave no room for a second copy -- every run's partial (this one's included: the same values it stored) is
             // read back, eight registers at a time
 #pragma unroll
             for (int i = 0; i < kMT; ++i)
@@ -777,6 +881,17 @@ __global__ __launch_bounds__(256, 2) void w4a16_gemm_pk256_kernel(const PkGemmAr
     w4a16_gemm_pk_body<1, LG, ABL, 1, 16>(g);
 }
 
+// wide form (round 5): 128 rows x 64 columns per wave.  One quartet per 128 x 256 tile, two workgroups per CU (64 KiB ring each) ...
+template <int LG, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void w4a16_gemm_pkw_kernel(const PkGemmArgs g) {
+    w4a16_gemm_pk_body<1, LG, ABL, 1, 8, 4>(g);
+}
+// ... or two quartets alternating the k-blocks of ONE 128 x 256 tile (launches with at most one tile per CU: both SIMD slots of a CU still carry a wave)
+template <int LG, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void w4a16_gemm_pkwx2_kernel(const PkGemmArgs g) {
+    w4a16_gemm_pk_body<2, LG, ABL, 1, 8, 4>(g);
+}
+
 int g_pk_ks = 0;  // 0: choose per launch, 1 / 2: forced (tuning)
 int g_pk_xm = 0;
 int g_pk_abl = 0;  // timing experiments: parts of the loop switched off (one quartet, groups of 128 only)
@@ -784,6 +899,9 @@ int g_pk_split_force = 0;  // tuning: the number of runs a cut tile's k range is
 int g_pk256_auto = 1;      // 0: the dispatcher never picks the 256-row forms by itself (A/B runs: tce_w4a16_set_debug_mode(650 / 651))
 constexpr float kPk256wUsPerKBlock = 4.3f;  // eight waves of a 256 x 256 tile walking one k-block
 constexpr float kPk256x2UsPerPair = 3.45f;   // two quartets sharing a CU walking one 256-row k-block each
+int g_pk_wide_auto = 0;                    // 1: the dispatcher may pick the wide forms 10 / 11 / 12 by itself
+constexpr float kPkWideAloneUs = 2.1f;     // wide form: one quartet alone on its CU walking a k-block (128 MFMAs per wave)  [first guess; fitted in profiles/r5/gemm_pkw_sweep.jsonl]
+constexpr float kPkWidePairUs = 3.4f;      // wide form: two quartets sharing a CU, one k-block each
 constexpr float kPk256UsPerKBlock = 2.25f;  // one workgroup per CU walking a 256-row k-block (128 MFMAs per wave); fitted in round 5 (profiles/r5/gemm_pk256_sweep.jsonl)
 
 template <int KS, int LG, int ABL = 0, int NS = 1>
@@ -831,6 +949,26 @@ hipError_t launch_pk256x2(PkGemmArgs &g, hipStream_t stream) {
 }
 
 template <int LG, int ABL = 0>
+hipError_t launch_pkw(PkGemmArgs &g, hipStream_t stream) {
+    const size_t lds = (size_t)4 * pk::kHalfBytes;  // ring of four half-stages of 128 rows x 64 k: 64 KiB (the 128 x 256 output tile, 64 KiB, reuses it)
+    auto kfn = w4a16_gemm_pkw_kernel<LG, ABL>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const int per = 8 * g.m_per * g.n_per;
+    hipLaunchKernelGGL(kfn, dim3(g.split_s > 1 ? per + (per - 8 * g.full_slots) * (g.split_s - 1) : per), dim3(256), lds, stream, g);
+    return hipGetLastError();
+}
+template <int LG, int ABL = 0>
+hipError_t launch_pkwx2(PkGemmArgs &g, hipStream_t stream) {
+    const size_t lds = (size_t)2 * 4 * pk::kHalfBytes;  // two rings: 128 KiB (the quartet exchange, 128 KiB, and the output tile reuse them)
+    auto kfn = w4a16_gemm_pkwx2_kernel<LG, ABL>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kfn, dim3(8 * g.m_per * g.n_per), dim3(512), lds, stream, g);
+    return hipGetLastError();
+}
+
+template <int LG, int ABL = 0>
 hipError_t launch_pk256(PkGemmArgs &g, hipStream_t stream) {
     const size_t lds = (size_t)4 * 256 * pk::kHalfK * 2;  // ring of four half-stages of 256 rows x 64 k: 128 KiB (the output tile, 64 KiB, reuses it)
     auto kfn = w4a16_gemm_pk256_kernel<LG, ABL>;
@@ -845,10 +983,11 @@ hipError_t launch_pk256(PkGemmArgs &g, hipStream_t stream) {
 
 void set_gemm_pk_ablation(int abl) { g_pk_abl = abl; }
 void set_gemm_pk256_auto(int on) { g_pk256_auto = on ? 1 : 0; }
+void set_gemm_pk_wide_auto(int on) { g_pk_wide_auto = on ? 1 : 0; }
 void set_gemm_pk_split(int s) { g_pk_split_force = s >= 2 && s <= 4 ? s : 0; }
 
 void set_gemm_pk_mode(int form, int xm) {
-    g_pk_ks = (form >= 1 && form <= 9) ? form : 0;  // 9: 256 x 256 tiles, two quartets side by side (debug mode 2669)  // 6: 256-row wave tiles, whole tiles; 7: the same with every tile's k range cut across workgroups
+    g_pk_ks = (form >= 1 && form <= 12) ? form : 0;  // 10 / 11 / 12: the wide form (one quartet per 128 x 256 tile; two quartets alternating its k-blocks; every tile's k range cut across workgroups)  // 9: 256 x 256 tiles, two quartets side by side (debug mode 2669)  // 6: 256-row wave tiles, whole tiles; 7: the same with every tile's k range cut across workgroups
     g_pk_xm = (xm == 1 || xm == 2 || xm == 4 || xm == 8) ? xm : 0;
 }
 
@@ -919,7 +1058,7 @@ static int pk_split_factor(long tiles1, int nkb, bool has_scratch, float *cost_o
     return best_s;
 }
 
-float gemm_pk_estimate_us(int M, int N, int K, int *form_out, bool has_scratch, int *split_out, int group_size) {
+float gemm_pk_estimate_us(int M, int N, int K, int *form_out, bool has_scratch, int *split_out, int group_size, bool zero_point_8) {
     const long mt = (M + 127) / 128;
     const long tiles1 = mt * ((N + 127) / 128), tiles3 = mt * ((N + 255) / 256);
     const float nkb = (float)(K / 128);
@@ -983,16 +1122,42 @@ float gemm_pk_estimate_us(int M, int N, int K, int *form_out, bool has_scratch, 
     // 2048 x 4096 x 4096) and form 9 (half the chip at that size, level at 4096 rows) lost every same-process comparison (profiles/r5/gemm_pk256_*.jsonl); they stay
     // reachable through tce_w4a16_set_debug_mode (66 / 67 / 672-674 / 2669) and in the parity tests.
     if (g_pk256_auto && cost8 < best) best = cost8, form = 8;
+    // forms 10 / 11 / 12 (round 5): the wide form -- 128 x 256 tiles, 128 rows x 64 columns per wave.  10: one quartet per tile, two workgroups per CU; 11: two quartets
+    // alternating the k-blocks of one tile (one workgroup per CU); 12: form 10 with every tile's k range cut into s runs on s workgroups
+    const long tilesw = mt * ((N + 255) / 256);
+    float cost10 = 1e30f, cost11 = 1e30f, cost12 = 1e30f;
+    int split12 = 1;
+    if (M > 128 && group_size == 128 && zero_point_8) {  // (the wide form reads no zero points: linears whose zero points are all 8 -- the flag the caller sets after tce_w4a16_check_zero_point_8)
+        cost10 = (tilesw <= 256 ? nkb * kPkWideAloneUs : 0.5f * rounds(tilesw, 256) * nkb * kPkWidePairUs) + 3.5f;
+        if (((int)nkb & 1) == 0 && nkb >= 2.f) cost11 = rounds(tilesw, 256) * (nkb * 0.5f) * kPkWidePairUs + 4.5f;
+        if (has_scratch)
+            for (int s = 2; s <= 4; ++s) {
+                if (tilesw * s * 2 > kPkSplitMaxUnits || (int)nkb / s < 4 || (g_pk_split_force && s != g_pk_split_force)) continue;
+                const float run = (float)(((int)nkb + s - 1) / s);
+                const float c = (tilesw * s <= 256 ? run * kPkWideAloneUs : 0.5f * rounds(tilesw * s, 256) * run * kPkWidePairUs) + 9.0f + 2.0f * (float)s;  // the exchange moves 128 KiB per unit
+                if (c < cost12) cost12 = c, split12 = s;
+            }
+    }
+    if (g_pk_wide_auto) {
+        if (cost10 < best) best = cost10, form = 10;
+        if (cost11 < best) best = cost11, form = 11;
+        if (cost12 < best) best = cost12, form = 12;
+    }
     if (g_pk_ks) {
         form = g_pk_ks;
         if (form == 4 && split == 1) form = split5 > 1 ? 5 : 1;  // "cut the k range": whichever of the two cut forms applies
         if (form == 7 && split7 == 1) form = 6;
         if ((form >= 6 && form <= 9) && (M <= 128 || group_size != 128)) form = 1;
         if (form == 8 && (nkb < 2.f || ((int)nkb & 1))) form = 6;
+        if (form >= 10 && (M <= 128 || group_size != 128 || !zero_point_8)) form = 1;
+        if (form == 11 && (nkb < 2.f || ((int)nkb & 1))) form = 10;
+        if (form == 12 && split12 == 1) form = 10;
+        if (form >= 10) best = form == 10 ? cost10 : (form == 11 ? cost11 : cost12);
+        else
         best = form == 1 ? cost1 : (form == 2 ? cost2 : (form == 3 ? cost3 : (form == 4 ? cost4 : (form == 5 ? cost5 : (form == 6 ? cost6 : (form == 7 ? cost7 : (form == 8 ? cost8 : cost9)))))));
     }
     if (form_out) *form_out = form;
-    if (split_out) *split_out = form == 4 ? split : (form == 5 ? split5 : (form == 7 ? split7 : 1));
+    if (split_out) *split_out = form == 4 ? split : (form == 5 ? split5 : (form == 7 ? split7 : (form == 12 ? split12 : 1)));
     return best;
 }
 
@@ -1017,11 +1182,12 @@ int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_
     g.add_to_c = (d.flags & TCE_W4_ADD_TO_C) ? 1 : 0;
     int form = 1, split = 1;
     const bool has_scratch = d.scratch != nullptr && (reinterpret_cast<uintptr_t>(d.scratch) & 255) == 0;
-    gemm_pk_estimate_us(d.M, d.N, d.K, &form, has_scratch, &split, d.group_size);
+    gemm_pk_estimate_us(d.M, d.N, d.K, &form, has_scratch, &split, d.group_size, (d.flags & TCE_W4_ZERO_POINT_IS_8) != 0);
     const bool cut_tail_only = form == 5;
     const bool rows256 = form >= 6 && form <= 9;
     const bool rows256x2 = form == 8, rows256w = form == 9;
-    if (form == 4 || form == 5 || form == 7) {
+    const bool wide = form >= 10 && form <= 12, widex2 = form == 11;
+    if (form == 4 || form == 5 || form == 7 || form == 12) {
         form = 1;
         g.split_s = split;
         g.counters = static_cast<unsigned *>(d.scratch);
@@ -1029,7 +1195,7 @@ int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_
     } else {
         g.split_s = 1;
     }
-    const int bn = (form == 3 || form == 9) ? 256 : 128;
+    const int bn = (form == 3 || form == 9 || wide) ? 256 : 128;
     g.n_blocks = (d.N + bn - 1) / bn;
     g.m_blocks = rows256 ? (d.M + 255) / 256 : (d.M + 127) / 128;
     int best_xm = 1;
@@ -1047,12 +1213,25 @@ int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_
     if (g.split_s > 1) {
         g.full_slots = cut_tail_only ? 32 : 0;  // 32 slots x 8 XCDs = the first 256 workgroups
         const int cut_wgs = 8 * (g.m_per * g.n_per - g.full_slots);
-        if (cut_wgs <= 0 || (long)cut_wgs * g.split_s * (rows256 ? 2 : 1) > kPkSplitMaxUnits || cut_wgs > 1024) g.split_s = 1;  // does not fit the scratch area: whole tiles
+        if (cut_wgs <= 0 || (long)cut_wgs * g.split_s * ((rows256 || wide) ? 2 : 1) > kPkSplitMaxUnits || cut_wgs > 1024) g.split_s = 1;  // does not fit the scratch area: whole tiles
     }
     const int ks = form;
     hipError_t e;
     const int lg = d.group_size == 128 ? 7 : (d.group_size == 64 ? 6 : 5);
-    if (g_pk_abl && lg == 7 && !rows256) {
+    if (wide && lg == 7 && g_pk_abl && !widex2) {  // timing experiments on the wide form (results meaningless)
+        switch (g_pk_abl) {
+#define TCE_ABL(X) case X: e = launch_pkw<7, X>(g, stream); break;
+            TCE_ABL(1) TCE_ABL(2) TCE_ABL(4) TCE_ABL(8) TCE_ABL(16) TCE_ABL(32) TCE_ABL(7) TCE_ABL(55)
+#undef TCE_ABL
+            default: return TCE_ERR_BAD_ARG;
+        }
+        if (e != hipSuccess) {
+            if (hip_err) *hip_err = e;
+            return TCE_ERR_HIP;
+        }
+        return TCE_OK;
+    }
+    if (g_pk_abl && lg == 7 && !rows256 && !wide) {
         switch (g_pk_abl) {
 #define TCE_ABL(X) case X: e = launch_pk<1, 7, X>(g, stream); break;
             TCE_ABL(1) TCE_ABL(2) TCE_ABL(4) TCE_ABL(8) TCE_ABL(16) TCE_ABL(32) TCE_ABL(6) TCE_ABL(7) TCE_ABL(23) TCE_ABL(55) TCE_ABL(47) TCE_ABL(48) TCE_ABL(64)
@@ -1065,7 +1244,8 @@ int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_
         }
         return TCE_OK;
     }
-    if (rows256w) e = launch_pk256w<7>(g, stream);
+    if (wide) e = widex2 ? launch_pkwx2<7>(g, stream) : launch_pkw<7>(g, stream);
+    else if (rows256w) e = launch_pk256w<7>(g, stream);
     else if (rows256x2) e = launch_pk256x2<7>(g, stream);
     else if (rows256 && g_pk_abl) {  // timing experiments on the 256-row form (results meaningless): tce_w4a16_set_debug_mode(66), then 600 + bits as for the 128-row form
         switch (g_pk_abl) {
