@@ -188,8 +188,8 @@ constexpr int kAsmVgprBase = 232;  // 128-row forms (and every group size); the 
 template <int KS, int LG, int ABL, int NS, int kMT, int kNT = 2>
 __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
     static_assert(KS == 1 || NS == 1, "two quartets either split K or sit side by side");
-    static_assert(kNT == 2 || (kNT == 4 && kMT == 8 && NS == 1 && LG == 7), "wide form: 128 rows x 64 columns per wave, one quartet per 128 x 256 tile (or two alternating its k-blocks), groups of 128");
-    constexpr bool WIDE = kNT == 4;
+    static_assert(kNT == 2 || ((kNT == 4 || kNT == 3) && kMT == 8 && NS == 1 && LG == 7), "wide form: 128 rows x 64 (48) columns per wave, one quartet per 128 x 256 (192) tile (or two alternating its k-blocks), groups of 128");
+    constexpr bool WIDE = kNT >= 3;  // (kNT == 3: 128 x 192 tiles -- 58 column blocks on N = 11008 where 256-wide tiles make 43: 232 tiles instead of 172 for the 256 CUs at M = 512)
     static_assert(kMT == 8 || (kMT == 16 && (NS == 1 || KS == 1)), "256-row wave tiles: one quartet per tile, two quartets splitting the k-blocks of one tile, or two quartets side by side on one activation ring");
     constexpr int ROWS = 16 * kMT;                   // rows of the activation tile
     constexpr int HALF_BYTES = ROWS * pk::kHalfK * 2;  // one half-stage of activations: 16 / 32 KiB
@@ -643,7 +643,12 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
     // the counted wait behind which `inflight` becomes valid (N = the newer VMEM instructions that may stay in flight); it names every landing register as in / out
     static_assert(!INFL || GPB == 1, "the wait statement names one group per k-block");
 #define TCE_PK_WAIT_INFLIGHT(N)                                                                                                                                          \
-    if constexpr (kNT == 4) {                                                                                                                                            \
+    if constexpr (kNT == 3) {                                                                                                                                            \
+        asm volatile("s_waitcnt vmcnt(%c6)"                                                                                                                              \
+                     : "+v"(inflight.w[0]), "+v"(inflight.w[1]), "+v"(inflight.w[2 % kNT]), "+v"(inflight.c[0][0].x), "+v"(inflight.c[1][0].x), "+v"(inflight.c[2 % kNT][0].x) \
+                     : "n"(N)                                                                                                                                            \
+                     : "memory");                                                                                                                                        \
+    } else if constexpr (kNT == 4) {                                                                                                                                     \
         asm volatile("s_waitcnt vmcnt(%c8)"                                                                                                                              \
                      : "+v"(inflight.w[0]), "+v"(inflight.w[1]), "+v"(inflight.w[2 % kNT]), "+v"(inflight.w[3 % kNT]), "+v"(inflight.c[0][0].x), "+v"(inflight.c[1][0].x), \
                        "+v"(inflight.c[2 % kNT][0].x), "+v"(inflight.c[3 % kNT][0].x)                                                                                      \
@@ -917,6 +922,16 @@ __global__ __launch_bounds__(512, 2) void w4a16_gemm_pkwx2_kernel(const PkGemmAr
     w4a16_gemm_pk_body<2, LG, ABL, 1, 8, 4>(g);
 }
 
+// the same with 48 columns per wave (128 x 192 tiles)
+template <int LG, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void w4a16_gemm_pkw3_kernel(const PkGemmArgs g) {
+    w4a16_gemm_pk_body<1, LG, ABL, 1, 8, 3>(g);
+}
+template <int LG, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void w4a16_gemm_pkw3x2_kernel(const PkGemmArgs g) {
+    w4a16_gemm_pk_body<2, LG, ABL, 1, 8, 3>(g);
+}
+
 int g_pk_ks = 0;  // 0: choose per launch, 1 / 2: forced (tuning)
 int g_pk_xm = 0;
 int g_pk_abl = 0;  // timing experiments: parts of the loop switched off (one quartet, groups of 128 only)
@@ -995,6 +1010,24 @@ hipError_t launch_pkwx2(PkGemmArgs &g, hipStream_t stream) {
     return hipGetLastError();
 }
 
+template <int KS>
+hipError_t launch_pkw3(PkGemmArgs &g, hipStream_t stream) {
+    const size_t lds = (size_t)KS * 4 * pk::kHalfBytes;
+    hipError_t e;
+    if constexpr (KS == 2) {
+        auto kfn = w4a16_gemm_pkw3x2_kernel<7, 0>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kfn, dim3(8 * g.m_per * g.n_per), dim3(512), lds, stream, g);
+    } else {
+        auto kfn = w4a16_gemm_pkw3_kernel<7, 0>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kfn, dim3(8 * g.m_per * g.n_per), dim3(256), lds, stream, g);
+    }
+    return hipGetLastError();
+}
+
 template <int LG, int ABL = 0>
 hipError_t launch_pk256(PkGemmArgs &g, hipStream_t stream) {
     const size_t lds = (size_t)4 * 256 * pk::kHalfK * 2;  // ring of four half-stages of 256 rows x 64 k: 128 KiB (the output tile, 64 KiB, reuses it)
@@ -1014,7 +1047,7 @@ void set_gemm_pk_wide_auto(int on) { g_pk_wide_auto = on ? 1 : 0; }
 void set_gemm_pk_split(int s) { g_pk_split_force = s >= 2 && s <= 4 ? s : 0; }
 
 void set_gemm_pk_mode(int form, int xm) {
-    g_pk_ks = (form >= 1 && form <= 12) ? form : 0;  // 10 / 11 / 12: the wide form (one quartet per 128 x 256 tile; two quartets alternating its k-blocks; every tile's k range cut across workgroups)  // 9: 256 x 256 tiles, two quartets side by side (debug mode 2669)  // 6: 256-row wave tiles, whole tiles; 7: the same with every tile's k range cut across workgroups
+    g_pk_ks = (form >= 1 && form <= 14) ? form : 0;  // 13 / 14: the wide form on 128 x 192 tiles, one quartet per tile / two alternating its k-blocks  // 10 / 11 / 12: the wide form (one quartet per 128 x 256 tile; two quartets alternating its k-blocks; every tile's k range cut across workgroups)  // 9: 256 x 256 tiles, two quartets side by side (debug mode 2669)  // 6: 256-row wave tiles, whole tiles; 7: the same with every tile's k range cut across workgroups
     g_pk_xm = (xm == 1 || xm == 2 || xm == 4 || xm == 8) ? xm : 0;
 }
 
@@ -1165,7 +1198,16 @@ float gemm_pk_estimate_us(int M, int N, int K, int *form_out, bool has_scratch, 
                 if (c < cost12) cost12 = c, split12 = s;
             }
     }
+    // forms 13 / 14: 128 x 192 tiles (48 columns per wave): three quarters of a 256-wide tile's work per k-block
+    const long tilesw3 = mt * ((N + 191) / 192);
+    float cost13 = 1e30f, cost14 = 1e30f;
+    if (M > 128 && group_size == 128 && zero_point_8) {
+        cost13 = (tilesw3 <= 256 ? nkb * kPkWideAloneUs : 0.5f * rounds(tilesw3, 256) * nkb * kPkWidePairUs) * 0.78f + 3.5f;
+        if (((int)nkb & 1) == 0 && nkb >= 2.f) cost14 = rounds(tilesw3, 256) * (nkb * 0.5f) * kPkWideX2PairUs * 0.78f + 4.5f;
+    }
     if (g_pk_wide_auto) {
+        if (cost13 < best) best = cost13, form = 13;
+        if (cost14 < best) best = cost14, form = 14;
         if (cost10 < best) best = cost10, form = 10;
         if (cost11 < best) best = cost11, form = 11;
         if (cost12 < best) best = cost12, form = 12;
@@ -1179,7 +1221,8 @@ float gemm_pk_estimate_us(int M, int N, int K, int *form_out, bool has_scratch, 
         if (form >= 10 && (M <= 128 || group_size != 128 || !zero_point_8)) form = 1;
         if (form == 11 && (nkb < 2.f || ((int)nkb & 1))) form = 10;
         if (form == 12 && split12 == 1) form = 10;
-        if (form >= 10) best = form == 10 ? cost10 : (form == 11 ? cost11 : cost12);
+        if (form == 14 && (nkb < 2.f || ((int)nkb & 1))) form = 13;
+        if (form >= 10) best = form == 10 ? cost10 : (form == 11 ? cost11 : (form == 12 ? cost12 : (form == 13 ? cost13 : cost14)));
         else
         best = form == 1 ? cost1 : (form == 2 ? cost2 : (form == 3 ? cost3 : (form == 4 ? cost4 : (form == 5 ? cost5 : (form == 6 ? cost6 : (form == 7 ? cost7 : (form == 8 ? cost8 : cost9)))))));
     }
@@ -1213,7 +1256,7 @@ int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_
     const bool cut_tail_only = form == 5;
     const bool rows256 = form >= 6 && form <= 9;
     const bool rows256x2 = form == 8, rows256w = form == 9;
-    const bool wide = form >= 10 && form <= 12, widex2 = form == 11;
+    const bool wide = form >= 10 && form <= 14, widex2 = form == 11, wide3 = form == 13 || form == 14;
     if (form == 4 || form == 5 || form == 7 || form == 12) {
         form = 1;
         g.split_s = split;
@@ -1222,7 +1265,7 @@ int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_
     } else {
         g.split_s = 1;
     }
-    const int bn = (form == 3 || form == 9 || wide) ? 256 : 128;
+    const int bn = wide3 ? 192 : ((form == 3 || form == 9 || wide) ? 256 : 128);
     g.n_blocks = (d.N + bn - 1) / bn;
     g.m_blocks = rows256 ? (d.M + 255) / 256 : (d.M + 127) / 128;
     int best_xm = 1;
@@ -1245,7 +1288,7 @@ int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_
     const int ks = form;
     hipError_t e;
     const int lg = d.group_size == 128 ? 7 : (d.group_size == 64 ? 6 : 5);
-    if (wide && lg == 7 && g_pk_abl && !widex2) {  // timing experiments on the wide form (results meaningless)
+    if (wide && lg == 7 && g_pk_abl && !widex2 && !wide3) {  // timing experiments on the wide form (results meaningless)
         switch (g_pk_abl) {
 #define TCE_ABL(X) case X: e = launch_pkw<7, X>(g, stream); break;
             TCE_ABL(1) TCE_ABL(2) TCE_ABL(4) TCE_ABL(8) TCE_ABL(16) TCE_ABL(32) TCE_ABL(7) TCE_ABL(55)
@@ -1271,7 +1314,8 @@ int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_
         }
         return TCE_OK;
     }
-    if (wide) e = widex2 ? launch_pkwx2<7>(g, stream) : launch_pkw<7>(g, stream);
+    if (wide3) e = form == 14 ? launch_pkw3<2>(g, stream) : launch_pkw3<1>(g, stream);
+    else if (wide) e = widex2 ? launch_pkwx2<7>(g, stream) : launch_pkw<7>(g, stream);
     else if (rows256w) e = launch_pk256w<7>(g, stream);
     else if (rows256x2) e = launch_pk256x2<7>(g, stream);
     else if (rows256 && g_pk_abl) {  // timing experiments on the 256-row form (results meaningless): tce_w4a16_set_debug_mode(66), then 600 + bits as for the 128-row form
