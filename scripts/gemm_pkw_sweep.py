@@ -39,7 +39,7 @@ for (M, N, K) in shapes:
     fl = 2.0 * M * N * K
     forms = [("narrow_auto", 60), ("form1", 61), ("form8", 68), ("wide1", 2670), ("wide2", 2671), ("wide_cut2", 2682), ("wide_cut3", 2683), ("wide_cut4", 2684), ("wide3_1", 2673), ("wide3_2", 2674), ("narrow_auto_again", 60)]
     if ABL:  # parts of the wide loop switched off (results meaningless): 1 no rescale, 2 no unpack, 4 no fragment reads, 8 no MFMAs, 16 no activation DMAs, 32 no barriers
-        forms = [("wide1", 2670)] + [(f"wide1_abl{b}", 26000 + b) for b in (1, 2, 4, 8, 16, 32, 7, 55)] + [("wide1_again", 2670)]
+        forms = [("wide1", 2670)] + [(f"wide1_abl{b}", 26000 + b) for b in (1, 2, 4, 8, 16, 32, 7, 55)] + [("wide1_again", 2670), ("wide1_dma_in_phase1", 26128), ("wide1_dma_in_front", 26256), ("wide1_third", 2670), ("wide1_dma_in_phase1_again", 26128)]
     for name, mode in forms:
         L.tce_w4a16_set_debug_mode(692 if mode == 60 else 693)
         L.tce_w4a16_set_debug_mode(mode)

@@ -281,7 +281,8 @@ def test_full_size_prefill_on_the_packed_kernel(dev, oracle, N, K):
     y = torch.full((M, N), float("nan"), dtype=torch.float16, device=dev)
     what = capi.describe_dispatch(lin.desc(x, y))
     # N = 4096: 128 tiles, every tile's k range cut in two (K = 4096) or four (K = 11008: round 4); N = 11008: 344 tiles, the 88 past the first 256 cut in two (one run per CU at most)
-    assert what.startswith("gemm-pk") and ((("ksplit=2 " if K == 4096 else "ksplit=4 ") in what) if N == 4096 else "ksplit=2-of-the-tiles-past-256" in what), what
+    # N = 11008 (round 5): 128 x 192 tiles -- 232 of them for the 256 CUs --, two quartets alternating a tile's k-blocks (until then: 344 tiles of 128 x 128, the 88 past the first 256 cut in two)
+    assert what.startswith("gemm-pk") and ((("ksplit=2 " if K == 4096 else "ksplit=4 ") in what) if N == 4096 else "tile=128x192 wave=128x48 quartets=2" in what), what
     for rep in range(3):  # (the scratch counters must be back to zero after every call)
         y.fill_(float("nan"))
         lin.forward(x, y)

@@ -17,6 +17,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libtce_hip.so")
 ADAPTER_LIB_PATH = os.path.join(LIB_DIR, "libtce_matmul_operator.so")
+TESTKIT_LIB_PATH = os.path.join(LIB_DIR, "libtce_testkit.so")
 ADAPTER_TEST_PATH = os.path.join(LIB_DIR, "adapter_selftest")
 ADAPTER_BENCH_PATH = os.path.join(LIB_DIR, "adapter_bench")
 
@@ -111,6 +112,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
             list(pool.map(run, jobs))
     if force or _stale(LIB_PATH, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    # test infrastructure (tests/, scripts/probes/ only): a launch that fills every CU's registers and LDS with NaNs (csrc/testkit_poison.hip)
+    tk_src = os.path.join(CSRC, "testkit_poison.hip")
+    if force or _stale(TESTKIT_LIB_PATH, [tk_src]):
+        cmd = [hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", tk_src, "-o", TESTKIT_LIB_PATH]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

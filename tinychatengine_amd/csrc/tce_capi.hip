@@ -241,7 +241,7 @@ int tce_w4a16_set_debug_mode(int mode) {
         tce::set_gemm_pk_wide_auto(mode - 692);
         return TCE_OK;
     }
-    if (mode >= 26000 && mode <= 26064) {  // the wide form (one quartet) with parts of its loop switched off (timing experiments)
+    if (mode >= 26000 && mode <= 26256) {  // the wide form (one quartet) with parts of its loop switched off (timing experiments)
         g_pk_mode = mode == 26000 ? 0 : 8;
         tce::set_gemm_pk_mode(mode == 26000 ? 0 : 10, 0);
         tce::set_gemm_pk_ablation(mode - 26000);
