@@ -47,7 +47,7 @@ extern "C" {
 
 #define TCE_API __attribute__((visibility("default")))
 
-#define TCE_VERSION 109 /* 0.1.9: tce_w4a16_check_zero_point_8_async, tce_host_alloc / tce_host_free (the adapter no longer synchronises); 0.1.8: per-family tuning setters (tce_attention_set_tuning, tce_w8a8_set_tuning); 0.1.7: decode on the pre-packed copy (int8 contraction), tce_w4a16_set_gemv_i8; 0.1.6: TCE_PLAN_TUNED; 0.1.5: tce_opt_attention_decode; 0.1.4: tce_attention_prefill_f16 (0.1.3: tce_attention_decode_step_gqa_f16, TCE_PLAN_OVERLAPPED; 0.1.2: tce_w4a16_desc.scratch; 0.1.1: .prepacked, tce_w4a16_prepack*) */
+#define TCE_VERSION 110 /* 0.1.10: size-prefixed descriptors (tce_w4a16_desc_v2 / tce_w8a8_desc_v2 + the *_v2 entry points; the plain ones stay), TCE_ERR_RCCL, the tuning setters act on the CALLING THREAD only; 0.1.9: tce_w4a16_check_zero_point_8_async, tce_host_alloc / tce_host_free (the adapter no longer synchronises); 0.1.8: per-family tuning setters (tce_attention_set_tuning, tce_w8a8_set_tuning); 0.1.7: decode on the pre-packed copy (int8 contraction), tce_w4a16_set_gemv_i8; 0.1.6: TCE_PLAN_TUNED; 0.1.5: tce_opt_attention_decode; 0.1.4: tce_attention_prefill_f16 (0.1.3: tce_attention_decode_step_gqa_f16, TCE_PLAN_OVERLAPPED; 0.1.2: tce_w4a16_desc.scratch; 0.1.1: .prepacked, tce_w4a16_prepack*) */
 
 /* error codes (return values) */
 #define TCE_OK 0
@@ -56,6 +56,7 @@ extern "C" {
 #define TCE_ERR_UNSUPPORTED_SHAPE (-3) /* K % 32 != 0, N % 8 != 0 for the AWQ layout, ... */
 #define TCE_ERR_HIP (-4)               /* a HIP runtime call failed; see tce_last_error() */
 #define TCE_ERR_UNSUPPORTED_KIND (-5)  /* bias/out kind combination that has no reference counterpart */
+#define TCE_ERR_RCCL (-6)              /* an RCCL call failed (ncclAllGather ...): tce_last_error() carries ncclGetErrorString's text -- NOT a HIP error */
 
 /* M at or below which tce_w4a16_forward never uses the prefill GEMM (GEMV or small-batch kernels) */
 #define TCE_W4A16_GEMV_MAX_M 8
@@ -121,6 +122,18 @@ typedef struct tce_w4a16_desc {
 #define TCE_W4_ADD_TO_C 16
 
 TCE_API int tce_w4a16_forward(const tce_w4a16_desc *d, void *stream);
+
+/* Size-prefixed form (0.1.10): a host compiled against THIS header keeps working when a later library appends fields to the descriptor, and a later host talks to
+ * this library as long as it leaves the fields this library does not know at zero.  `struct_size` = sizeof(tce_w4a16_desc_v2) as the CALLER compiled it; the library
+ * copies min(struct_size, its own size) bytes into a zeroed descriptor of its own and refuses a size below the 0.1.10 layout (TCE_ERR_BAD_ARG) or non-zero bytes
+ * beyond what it knows.  Same semantics as tce_w4a16_forward(&v2->desc, stream). */
+typedef struct tce_w4a16_desc_v2 {
+    uint32_t struct_size;
+    uint32_t reserved0;
+    tce_w4a16_desc desc;
+    /* fields of later versions are appended here */
+} tce_w4a16_desc_v2;
+TCE_API int tce_w4a16_forward_v2(const tce_w4a16_desc_v2 *d, void *stream);
 
 /* Round 4: o_proj / down_proj + residual add + the RMSNorm that FOLLOWS, one launch (decode, M = 1) -- replaces `linear; add_half; LlamaRMSNorm` of
  * Int4llamaDecoderLayer.cu:86-99 (post_attention_layernorm) and :107-108 + :78 of the next layer (input_layernorm):
@@ -308,6 +321,13 @@ typedef struct tce_w8a8_desc {
 } tce_w8a8_desc;
 
 TCE_API int tce_w8a8_matmul(const tce_w8a8_desc *d, void *stream);
+/* size-prefixed form (0.1.10), as tce_w4a16_desc_v2 */
+typedef struct tce_w8a8_desc_v2 {
+    uint32_t struct_size;
+    uint32_t reserved0;
+    tce_w8a8_desc desc;
+} tce_w8a8_desc_v2;
+TCE_API int tce_w8a8_matmul_v2(const tce_w8a8_desc_v2 *d, void *stream);
 
 /* The element-wise steps between the two int8 BMMs of the reference's OPT attention (llm/src/nn_modules/Int8OPTAttention.cc:254-268), as ONE launch:
  *   batch_Add (llm/src/ops/batch_add.cc:3-24): s[h][j][k] + mask[j][k];  softmax over k (llm/src/ops/softmax.cc:5-40: the running maximum starts
@@ -487,9 +507,10 @@ TCE_API int tce_w4a16_set_gemv_config(int rows_per_wave, int waves_n, int waves_
  * _forward_group / plans whenever every descriptor of the launch carries `prepacked`, K % 128 == 0 and no fused RMSNorm prologue is asked for; group sizes 64 / 32:
  * M <= 2 / M = 1).  mode 0 = that rule, 1 = off (the fp16 GEMV kernels on the q4_6 arrays take those launches: A/B runs); rows = 16-row tiles per wave for the
  * M = 1, K <= 8192 launches: 0 = the rule (one; two with the RMSNorm prologue where one leaves a short second generation of workgroups), 1, 2.  A row's arithmetic depends on K, the group size and the rows per pass only -- never on N or on
- * `rows`: column shards and grouped launches are bit-identical to the plain launch.  Process-wide; results do not depend on it beyond the kernel family. */
+ * `rows`: column shards and grouped launches are bit-identical to the plain launch.  Per host thread (0.1.10: every tuning setter of this header acts on the calling thread's launches only -- two host threads driving
+ * two devices or streams may force different kernels without a lock); results do not depend on it beyond the kernel family. */
 TCE_API int tce_w4a16_set_gemv_i8(int mode, int tiles_per_wave);
-/* Tuning / diagnostics switch for the sweeps under scripts/ (process-wide, not thread-safe, never needed by a host):
+/* Tuning / diagnostics switch for the sweeps under scripts/ (per host thread since 0.1.10, never needed by a host):
  *   0..4     GEMV kernels, M = 1: 0 normal; 1 stream the weights only (no unpack, no dot products: the memory-side ceiling
  *            of the access pattern, outputs meaningless); 2 normal math plus per-wave timestamps into the debug buffer;
  *            3 / 4 further timing variants of the persistent kernel (w4a16_gemv_stream.hip)
@@ -510,7 +531,7 @@ TCE_API int tce_w4a16_set_gemv_i8(int mode, int tiles_per_wave);
  * Every setting computes correct results except GEMV modes 1, 3, 4. */
 TCE_API int tce_w4a16_set_debug_mode(int mode);
 /* The same knobs per kernel family, by name (round 4: one numbered mode space for every family had already produced an A/B that compared a setting with itself, and
- * a mode of one family landing in another's range).  Process-wide, for tuning sweeps and tests; 0 everywhere = the fitted rules.  Every setting computes the same results.
+ * a mode of one family landing in another's range).  Per host thread (0.1.10), for tuning sweeps and tests; 0 everywhere = the fitted rules.  Every setting computes the same results.
  *   tce_attention_set_tuning: the fast decode attention step -- waves per workgroup (0 | 4 | 8 | 16), workgroups the key range is cut for (0 | 32..8192),
  *                             query heads per workgroup for grouped queries (0 | 1 | 2 | 4)
  *   tce_w8a8_set_tuning:      wave quartets per 64 x 64 tile (0 | 1 | 2 | 4); the 128-row tiles (0 the rule | 1 / 2: forced with 128 / 64 columns | 3 / 4: the same with two

@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(built):
     lib = built.lib()
     for s in declared:
         assert hasattr(lib, s)
-    assert lib.tce_version() == 109
+    assert lib.tce_version() == 110
     assert b"gfx950" in lib.tce_build_info()
 
 
@@ -53,6 +53,25 @@ def test_library_contains_gfx950_code_objects_only(built):
 
 def test_descriptor_sizes(built):
     assert C.sizeof(built.W4A16Desc) == 112 and C.sizeof(built.W8A8Desc) == 120
+    assert C.sizeof(built.W4A16DescV2) == 120 and C.sizeof(built.W8A8DescV2) == 128
+
+
+def test_size_prefixed_descriptors_validate_their_size(built):
+    """ABI 110: a descriptor smaller than the first size-prefixed layout, or one whose extra bytes are not zero, is refused before anything touches a device."""
+    capi = built
+    L = capi.lib()
+    v2 = capi.W4A16DescV2()
+    v2.struct_size = C.sizeof(capi.W4A16DescV2) - 8
+    assert L.tce_w4a16_forward_v2(C.byref(v2), None) == -1 and b"struct_size" in L.tce_last_error()
+    buf = (C.c_ubyte * (C.sizeof(capi.W4A16DescV2) + 16))()
+    big = capi.W4A16DescV2.from_buffer(buf)
+    big.struct_size = C.sizeof(capi.W4A16DescV2) + 16
+    buf[C.sizeof(capi.W4A16DescV2) + 3] = 1  # a later host set a field this library does not know
+    assert L.tce_w4a16_forward_v2(C.byref(big), None) == -1 and b"does not know" in L.tce_last_error()
+    w = capi.W8A8DescV2()
+    w.struct_size = 12
+    assert L.tce_w8a8_matmul_v2(C.byref(w), None) == -1
+    assert L.tce_w4a16_forward_v2(None, None) == -1
 
 
 def test_argument_validation_needs_no_gpu(built):

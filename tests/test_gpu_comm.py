@@ -286,3 +286,84 @@ def test_allgather_rows_two_ranks_peer_regime():
     finally:
         for c in comms:
             c.close()
+
+
+@gpu
+def test_allgather_rows_beyond_64k_slices_without_rccl_uses_the_window():
+    """M = 64 rows of a 4096-wide tensor are 262144 halves -- 256 KiB slices for two ranks, beyond the peer-write kernel's preferred regime.  With no RCCL
+    communicator the exchange used to be refused (TCE_ERR_UNSUPPORTED_KIND); it fits the window, so the peer-write kernel carries it (slower than the links, correct)."""
+    from tinychatengine_amd import capi
+    dev = torch.device("cuda:0")
+    world, M, N = 2, 64, 4096
+    comms = [capi.Comm(r, world, M * N, slots=2) for r in range(world)]
+    capi.Comm.connect_local(comms)
+    streams = [torch.cuda.Stream() for _ in range(world)]
+    ws = [torch.empty(M * N, dtype=torch.float16, device=dev) for _ in range(world)]
+    try:
+        for it in range(3):
+            parts = [torch.randn(M, N // world, device=dev).to(torch.float16) for _ in range(world)]
+            fulls = [torch.zeros(M, N, dtype=torch.float16, device=dev) for _ in range(world)]
+            torch.cuda.synchronize()
+            for r in range(world):
+                comms[r].allgather_rows(0, parts[r].data_ptr(), fulls[r].data_ptr(), M, N, ws[r].data_ptr(), streams[r].cuda_stream)
+            torch.cuda.synchronize()
+            want = torch.cat(parts, dim=1)
+            for r in range(world):
+                assert comms[r].status() == 0
+                assert torch.equal(fulls[r], want), (it, r)
+        # and a window that is too small still refuses, by name
+        small = [capi.Comm(r, world, 4096, slots=1) for r in range(world)]
+        capi.Comm.connect_local(small)
+        with pytest.raises(capi.TceError):
+            small[0].allgather_rows(0, parts[0].data_ptr(), fulls[0].data_ptr(), M, N, ws[0].data_ptr(), streams[0].cuda_stream)
+        capi.lib().tce_reset_last_error()
+        for c in small:
+            c.close()
+    finally:
+        for c in comms:
+            c.close()
+
+
+@gpu
+def test_one_process_two_devices_through_connect_local():
+    """the first multi-GPU lease must not be the first test of the cross-device path.  One process, one communicator per DEVICE
+    (tce_comm_connect_local maps the peers' windows without IPC handles), a column-sharded linear per device, the gather across the link.  Skips on a one-GPU box --
+    every gpurun box so far."""
+    from tinychatengine_amd import capi
+    from tinychatengine_amd.linear import Linear_half_int4
+    if int(capi.lib().tce_device_count()) < 2 or torch.cuda.device_count() < 2:
+        pytest.skip("needs two devices in one process (tce_device_count() < 2)")
+    world = 2
+    devs = [torch.device(f"cuda:{r}") for r in range(world)]
+    g = torch.Generator(device=devs[0]).manual_seed(15)
+    w = torch.empty(4096, 4096, device=devs[0]).normal_(0, 0.02, generator=g)
+    x0 = torch.empty(1, 4096, device=devs[0]).normal_(0, 1, generator=g).to(torch.float16)
+    lin0 = Linear_half_int4.from_float(w, 128)
+    want = lin0.forward(x0)
+    torch.cuda.synchronize()
+    comms = []
+    for r in range(world):
+        with torch.cuda.device(devs[r]):
+            comms.append(capi.Comm(r, world, 16384, slots=2))
+    capi.Comm.connect_local(comms)
+    try:
+        fulls, keep = [], []
+        for r in range(world):
+            with torch.cuda.device(devs[r]):
+                assert comms[r].device() == r
+                lin = Linear_half_int4(lin0.weight.to(devs[r]), lin0.scale.to(devs[r]), lin0.zero_point.to(devs[r]), 128)
+                x = x0.to(devs[r])
+                st = torch.cuda.current_stream(devs[r])
+                part = _sharded_forward(lin, x, r, world, st)
+                full = torch.full((1, 4096), float("nan"), dtype=torch.float16, device=devs[r])
+                comms[r].allgather(0, part.data_ptr(), full.data_ptr(), 4096, st.cuda_stream)
+                fulls.append(full)
+                keep.append((lin, x, part))
+        for r in range(world):
+            torch.cuda.synchronize(devs[r])
+        for r in range(world):
+            assert comms[r].status() == 0
+            assert torch.equal(fulls[r].cpu(), want.cpu()), r
+    finally:
+        for c in comms:
+            c.close()

@@ -369,7 +369,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fast_kernel(const FastAtt
 }  // namespace
 
 // chunk of keys per workgroup: heads x chunks should cover the chip a couple of times; a multiple of 16 (4 waves x 4 keys per step)
-static int g_attn_target_wgs = 0;  // 0: the fitted rule below; tuning: tce_w4a16_set_debug_mode(3000 + workgroups)
+static thread_local int g_attn_target_wgs = 0;  // 0: the fitted rule below; tuning: tce_w4a16_set_debug_mode(3000 + workgroups)
 void set_attention_fast_target(int wgs) { g_attn_target_wgs = wgs >= 32 && wgs <= 8192 ? wgs : 0; }
 
 // Measured (scripts/attention_step_sweep.py, profiles/r2/attention_step_sweep.jsonl; 32 heads, caches rotating through > 256 MB so the
@@ -386,10 +386,10 @@ void set_attention_fast_target(int wgs) { g_attn_target_wgs = wgs >= 32 && wgs <
 // 128 / 512 / 2048 keys against 6.0 / 8.6 / 11.8 (profiles/r2/attention_merge_variants.jsonl): a write-through store takes longer to
 // become visible to another XCD than the counter's round trip, so the first read pass misses and every further pass is a round
 // trip of its own.
-static int g_attn_waves = 0;  // 0: by the chunk's length; tuning: tce_w4a16_set_debug_mode(2900 + 4 / 8 / 16)
+static thread_local int g_attn_waves = 0;  // 0: by the chunk's length; tuning: tce_w4a16_set_debug_mode(2900 + 4 / 8 / 16)
 void set_attention_fast_waves(int nw) { g_attn_waves = (nw == 4 || nw == 8 || nw == 16) ? nw : 0; }
 
-static int g_attn_fuse = 0;  // tuning: query heads per workgroup for grouped-query attention (0: the rule; 1, 2, 4)
+static thread_local int g_attn_fuse = 0;  // tuning: query heads per workgroup for grouped-query attention (0: the rule; 1, 2, 4)
 void set_attention_fast_fuse(int r) { g_attn_fuse = (r == 1 || r == 2 || r == 4) ? r : 0; }
 
 // `heads` here = workgroup groups (query heads / heads per workgroup)

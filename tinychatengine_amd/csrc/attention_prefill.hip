@@ -323,8 +323,8 @@ __global__ __launch_bounds__(64 * NW) void attn_prefill_kernel(const PrefillArgs
     }
 }
 
-int g_prefill_pair = 0;   // 0: by the rule; 1 / 2: pairing forced on / off
-int g_prefill_waves = 0;  // 0: by the rule in launch_attention_prefill; forced (tests, sweeps): 4 / 8 waves with one row tile per wave, 14 / 18: with two
+thread_local int g_prefill_pair = 0;   // 0: by the rule; 1 / 2: pairing forced on / off
+thread_local int g_prefill_waves = 0;  // 0: by the rule in launch_attention_prefill; forced (tests, sweeps): 4 / 8 waves with one row tile per wave, 14 / 18: with two
 
 }  // namespace
 

@@ -394,12 +394,21 @@ bool comm_peer_regime(const Comm *c, int n_total) {
     const size_t slice_bytes = (size_t)(n_total / c->world) * 2;
     return slice_bytes <= 64 * 1024 && (size_t)n_total * 2 <= c->vec_bytes;
 }
+// the last RCCL failure of this thread as text (ncclGetErrorString), for tce_last_error(): a failed ncclAllGather is not a HIP error
+thread_local char g_rccl_error[160] = "";
+const char *comm_rccl_last_error() { return g_rccl_error; }
 int launch_allgather_rccl(Comm *c, const void *src_slice, void *dst_full, size_t n_per_rank, hipStream_t stream) {
     RcclApi &a = rccl();
     if (!a.ok || !c->nccl) return TCE_ERR_UNSUPPORTED_KIND;
     DeviceGuard guard(c->device);
-    return a.AllGather(src_slice, dst_full, n_per_rank, kNcclHalf, c->nccl, stream) == 0 ? TCE_OK : TCE_ERR_HIP;
+    const int rc = a.AllGather(src_slice, dst_full, n_per_rank, kNcclHalf, c->nccl, stream);
+    if (rc == 0) return TCE_OK;
+    std::snprintf(g_rccl_error, sizeof g_rccl_error, "ncclAllGather failed: %s (ncclResult_t %d)", a.GetErrorString ? a.GetErrorString(rc) : "?", rc);
+    return TCE_ERR_RCCL;
 }
+// fits the window at all (whatever the slice size): the peer-write kernel can carry it when there is no RCCL communicator -- slower than the links beyond 64 KiB
+// slices, but correct (what tce_allgather_f16 has always done)
+static bool comm_fits_window(const Comm *c, long long n_total) { return n_total > 0 && (size_t)n_total * 2 <= c->vec_bytes; }
 size_t allgather_rows_workspace_bytes(int M, int n_total) { return (size_t)M * (size_t)n_total * 2; }
 // src [M][n_total / world] (this rank's columns of M rows) -> dst [M][ldd] on every rank.  M = 1 is tce_allgather_f16.
 int launch_allgather_rows_f16(Comm *c, int slot, const void *src, void *dst, int M, int n_total, int ldd, void *workspace, hipStream_t stream, hipError_t *he) {
@@ -407,14 +416,14 @@ int launch_allgather_rows_f16(Comm *c, int slot, const void *src, void *dst, int
     const int n_loc = n_total / c->world;
     if (n_loc % 8 || ldd % 8 || ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15)) return TCE_ERR_UNSUPPORTED_SHAPE;
     if (M == 1) {
-        if (comm_peer_regime(c, n_total)) return launch_allgather_f16(c, slot, src, dst, n_total, stream, he);
+        if (comm_peer_regime(c, n_total) || (!c->nccl && comm_fits_window(c, n_total))) return launch_allgather_f16(c, slot, src, dst, n_total, stream, he);
         return launch_allgather_rccl(c, src, dst, (size_t)n_loc, stream);
     }
     if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15)) return TCE_ERR_BAD_ARG;
     // stage 1: every rank's whole [M][n_loc] block, rank-major, into the workspace
     const long long flat = (long long)M * n_total;
     int rc;
-    if (flat <= 0x7FFFFFFF && comm_peer_regime(c, (int)flat)) rc = launch_allgather_f16(c, slot, src, workspace, (int)flat, stream, he);
+    if (flat <= 0x7FFFFFFF && (comm_peer_regime(c, (int)flat) || (!c->nccl && comm_fits_window(c, flat)))) rc = launch_allgather_f16(c, slot, src, workspace, (int)flat, stream, he);
     else rc = launch_allgather_rccl(c, src, workspace, (size_t)M * n_loc, stream);
     if (rc != TCE_OK) return rc;
     // stage 2: rows side by side

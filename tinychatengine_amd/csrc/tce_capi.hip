@@ -21,9 +21,9 @@ int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err)
 namespace {
 
 thread_local char g_err[512] = "";
-int g_gemv_rows = 0, g_gemv_wn = 0, g_gemv_wk = 0, g_gemv_depth = 0;
-int g_gemm_mt = 0, g_gemm_nt = 0;
-int g_debug_mode_capi = 0;
+thread_local int g_gemv_rows = 0, g_gemv_wn = 0, g_gemv_wk = 0, g_gemv_depth = 0;
+thread_local int g_gemm_mt = 0, g_gemm_nt = 0;
+thread_local int g_debug_mode_capi = 0;
 void *g_dbg_buf_capi = nullptr;
 
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
@@ -73,7 +73,7 @@ int64_t tce_w4a16_algorithmic_bytes(int M, int N, int K, int G) {
     return nk / 2 + 2 * nk / G + nk / (2 * (int64_t)G) + 2 * (int64_t)M * K + 2 * (int64_t)M * N;
 }
 
-int g_pk_mode = 0;  // 0 automatic, 1 / 2 / 3 forced form (taken whenever a packed copy is given), 9 off
+thread_local int g_pk_mode = 0;  // 0 automatic, 1 / 2 / 3 forced form (taken whenever a packed copy is given), 9 off
 constexpr int kPkMinM = 129;  // below: the 64-row tiles / the small-batch kernel waste fewer rows (192 until round 4: from 129 rows on two 128-row tiles already beat the 64-row tiles on the wide linears -- 160 x 11008 x 4096: 42.4 -> 32.6 us -- and the cost models keep N = 4096 with the 64-row kernel)
 
 // the pre-packed 128-row GEMM takes the launch when a packed copy came with the descriptor and the batch is large enough
@@ -95,8 +95,8 @@ static bool use_pk(const tce_w4a16_desc *d, bool want_gemm) {
 // RMSNorm prologue from 8k rows up, and is the body of the token kernel.
 constexpr long long kPersistentMinWeights = 1LL << 62;
 constexpr long long kFusedNormPersistentRows = 16384;  // fused RMSNorm prologue: rows from which the persistent kernel carries it
-int g_gemv_kernel = 0;  // 0 automatic, 1 workgroup-per-row-block kernel forced, 2 persistent stream kernel forced
-int g_skinny_enabled = 1;  // tuning: tce_w4a16_set_debug_mode(29) routes 3 <= M <= 16 to the GEMV / GEMM kernels again
+thread_local int g_gemv_kernel = 0;  // 0 automatic, 1 workgroup-per-row-block kernel forced, 2 persistent stream kernel forced
+thread_local int g_skinny_enabled = 1;  // tuning: tce_w4a16_set_debug_mode(29) routes 3 <= M <= 16 to the GEMV / GEMM kernels again
 
 int tce_w4a16_set_gemv_config(int rows, int wn, int wk, int depth) {
     if (rows == 0 && wn == 0 && wk == 0) {
@@ -151,7 +151,7 @@ int tce_w8a8_set_tuning(int quartets_per_tile, int big_tiles, int deep_pipeline)
     return TCE_OK;
 }
 
-static int g_plan_eager = 0;  // experiment (tce_w4a16_set_debug_mode(15001 / 15000)): stream-ordered plans issue their launches one by one instead of replaying the graph
+static thread_local int g_plan_eager = 0;  // experiment (tce_w4a16_set_debug_mode(15001 / 15000)): stream-ordered plans issue their launches one by one instead of replaying the graph
 int tce_w4a16_set_debug_mode(int mode) {
     if (mode >= 50000 && mode <= 50499) {  // overlapped plans: 50000 + 100 * graph branches (0 = 2) + ring slots per wave (0 = as many as fit, 2..4)
         tce::set_gemv_ovl_config((mode - 50000) % 100, (mode - 50000) / 100);
@@ -588,7 +588,7 @@ int tce_w4a16_describe_dispatch(const tce_w4a16_desc *d, char *buf, int buf_len)
         return TCE_OK;
     }
     if (g_gemv_kernel == 0 && g_debug_mode_capi == 0 && tce::gemv_i8_supports(d, 1)) {
-        std::snprintf(buf, (size_t)buf_len, "gemv-i8 rows-per-pass=%d group=%d", d->M >= 3 ? 4 : d->M, d->group_size);
+        std::snprintf(buf, (size_t)buf_len, "gemv-i8 rows-per-pass=%d group=%d", tce::gemv_i8_rows_per_pass(d->M, d->K, d->group_size), d->group_size);
         return TCE_OK;
     }
     if (g_skinny_enabled && !(d->flags & (TCE_W4_FORCE_GEMV | TCE_W4_FORCE_GEMM)) && tce::skinny_supports(*d)) {
@@ -806,6 +806,30 @@ int tce_w8a8_matmul(const tce_w8a8_desc *d, void *stream) {
     if (rc == TCE_ERR_BAD_ARG) return fail(rc, "w8a8: bad leading dimensions");
     return rc == TCE_ERR_HIP ? hip_fail(he, "w8a8 launch") : rc;
 }
+// size-prefixed descriptors (0.1.10): copy what the caller's layout and this library's have in common into a zeroed descriptor; unknown trailing bytes must be zero
+extern "C++" {
+template <typename V2>
+static int unwrap_v2(const V2 *d, V2 &local, const char *what) {
+    if (!d) return fail(TCE_ERR_BAD_ARG, "%s: null descriptor", what);
+    const size_t have = d->struct_size, mine = sizeof(V2);
+    if (have < mine) return fail(TCE_ERR_BAD_ARG, "%s: struct_size %zu is below this library's first size-prefixed layout (%zu)", what, have, mine);
+    std::memcpy(&local, d, mine);
+    const unsigned char *tail = reinterpret_cast<const unsigned char *>(d) + mine;
+    for (size_t i = 0; i < have - mine; ++i)
+        if (tail[i]) return fail(TCE_ERR_BAD_ARG, "%s: the caller set a field this library (ABI %d) does not know (byte %zu of %zu)", what, TCE_VERSION, mine + i, have);
+    return TCE_OK;
+}
+}  // extern "C++"
+int tce_w4a16_forward_v2(const tce_w4a16_desc_v2 *d, void *stream) {
+    tce_w4a16_desc_v2 local{};
+    const int rc = unwrap_v2(d, local, "tce_w4a16_forward_v2");
+    return rc != TCE_OK ? rc : tce_w4a16_forward(&local.desc, stream);
+}
+int tce_w8a8_matmul_v2(const tce_w8a8_desc_v2 *d, void *stream) {
+    tce_w8a8_desc_v2 local{};
+    const int rc = unwrap_v2(d, local, "tce_w8a8_matmul_v2");
+    return rc != TCE_OK ? rc : tce_w8a8_matmul(&local.desc, stream);
+}
 
 // ---- multi-GPU (csrc/comm.hip): tce_comm is tce::Comm ----
 int tce_w4a16_shard(const tce_w4a16_desc *full, int rank, int world, tce_w4a16_desc *shard) {
@@ -877,7 +901,7 @@ int tce_allgather_f16(tce_comm *comm, int slot, const void *src_slice, void *dst
     if (n_total > 0 && !tce::comm_peer_regime(c, n_total) && tce::comm_has_rccl(c)) {
         if (n_total % tce::comm_world_of(c)) return fail(TCE_ERR_BAD_ARG, "tce_allgather_f16: n_total %% world != 0");
         const int rc = tce::launch_allgather_rccl(c, src_slice, dst_full, (size_t)(n_total / tce::comm_world_of(c)), static_cast<hipStream_t>(stream));
-        return rc == TCE_OK ? TCE_OK : fail(rc, "tce_allgather_f16: ncclAllGather failed");
+        return rc == TCE_OK ? TCE_OK : fail(rc, "tce_allgather_f16: %s", rc == TCE_ERR_RCCL ? tce::comm_rccl_last_error() : "no RCCL communicator");
     }
     const int rc = tce::launch_allgather_f16(c, slot, src_slice, dst_full, n_total, static_cast<hipStream_t>(stream), &he);
     if (rc == TCE_ERR_HIP) return hip_fail(he, "allgather launch");
@@ -902,6 +926,7 @@ int tce_allgather_rows_f16(tce_comm *comm, int slot, const void *src, void *dst,
     hipError_t he = hipSuccess;
     const int rc = tce::launch_allgather_rows_f16(reinterpret_cast<tce::Comm *>(comm), slot, src, dst, M, n_total, ldd ? ldd : n_total, workspace, static_cast<hipStream_t>(stream), &he);
     if (rc == TCE_ERR_HIP) return hip_fail(he, "allgather (rows) launch");
+    if (rc == TCE_ERR_RCCL) return fail(rc, "tce_allgather_rows_f16: %s", tce::comm_rccl_last_error());
     if (rc == TCE_ERR_UNSUPPORTED_KIND) return fail(rc, "tce_allgather_rows_f16: the exchange is beyond the peer-write kernel's regime and the communicator has no RCCL side (tce_comm_rccl_init)");
     if (rc != TCE_OK) return fail(rc, "tce_allgather_rows_f16: bad slot / sizes (n_total %% world, 16-byte slices, ldd >= n_total), no workspace for M > 1, or group not connected");
     return TCE_OK;

@@ -39,7 +39,7 @@ struct GemmArgs {
     int xm, m_per, n_per;  // XCD grid: xm x (8 / xm) XCDs over (row blocks x column blocks), contiguous slices of m_per x n_per blocks
 };
 
-int g_gemm_xm = 1;
+thread_local int g_gemm_xm = 1;
 
 template <int MT, int NT>
 __global__ __launch_bounds__(256, (MT * NT >= 16 ? 1 : 2)) void w4a16_gemm_kernel(const GemmArgs g) {

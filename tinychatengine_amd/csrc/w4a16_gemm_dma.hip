@@ -419,9 +419,9 @@ __global__ __launch_bounds__(256 * KS, (KS == 2 || MT * NT >= 16 ? 1 : 2)) void 
     }
 }
 
-int g_dma_xm = 0;  // 0: choose per launch
+thread_local int g_dma_xm = 0;  // 0: choose per launch
 
-int g_dma_ks = 0;  // 0: choose, 1 / 2: forced
+thread_local int g_dma_ks = 0;  // 0: choose, 1 / 2: forced
 
 template <int MT, int NT, int KS, int LG>
 hipError_t launch_lg(DmaGemmArgs &g, hipStream_t stream) {

@@ -988,14 +988,14 @@ __global__ __launch_bounds__(512, 2) void w4a16_gemm_pkw3x2_kernel(const PkGemmA
     w4a16_gemm_pk_body<2, LG, ABL, 1, 8, 3>(g);
 }
 
-int g_pk_ks = 0;  // 0: choose per launch, 1 / 2: forced (tuning)
-int g_pk_xm = 0;
-int g_pk_abl = 0;  // timing experiments: parts of the loop switched off (one quartet, groups of 128 only)
-int g_pk_split_force = 0;  // tuning: the number of runs a cut tile's k range is divided into (0: the cost model's choice)
-int g_pk256_auto = 1;      // 0: the dispatcher never picks the 256-row forms by itself (A/B runs: tce_w4a16_set_debug_mode(650 / 651))
+thread_local int g_pk_ks = 0;  // 0: choose per launch, 1 / 2: forced (tuning)
+thread_local int g_pk_xm = 0;
+thread_local int g_pk_abl = 0;  // timing experiments: parts of the loop switched off (one quartet, groups of 128 only)
+thread_local int g_pk_split_force = 0;  // tuning: the number of runs a cut tile's k range is divided into (0: the cost model's choice)
+thread_local int g_pk256_auto = 1;      // 0: the dispatcher never picks the 256-row forms by itself (A/B runs: tce_w4a16_set_debug_mode(650 / 651))
 constexpr float kPk256wUsPerKBlock = 4.3f;  // eight waves of a 256 x 256 tile walking one k-block
 constexpr float kPk256x2UsPerPair = 3.45f;   // two quartets sharing a CU walking one 256-row k-block each
-int g_pk_wide_auto = 1;                    // 1: the dispatcher may pick the wide forms 10 / 11 / 12 by itself (tce_w4a16_set_debug_mode(692): never)
+thread_local int g_pk_wide_auto = 1;                    // 1: the dispatcher may pick the wide forms 10 / 11 / 12 by itself (tce_w4a16_set_debug_mode(692): never)
 // fitted to profiles/r5/gemm_pkw_sweep.jsonl: 2048 x 4096 x 4096 (256 tiles, one per CU) 68.1 us; 4096 x 4096 x 4096 (512 tiles, two per CU) 112.8 us; two quartets on one tile 62.7 / 147.0 us at K = 4096 / 11008
 constexpr float kPkWideAloneUs = 2.02f;    // wide form: one quartet alone on its CU walking a k-block (128 MFMAs per wave)
 constexpr float kPkWidePairUs = 3.42f;     // wide form: two workgroups sharing a CU, one k-block each

@@ -462,8 +462,8 @@ struct Variant {
     int rows, wn, wk, depth;
 };
 
-int g_debug_mode = 0;
-int g_order_force = 0;  // tuning (tce_w4a16_set_debug_mode 10 / 11 / 12): 0 the rule in launch_variant, 1 x first always, 2 weights first always
+thread_local int g_debug_mode = 0;
+thread_local int g_order_force = 0;  // tuning (tce_w4a16_set_debug_mode 10 / 11 / 12): 0 the rule in launch_variant, 1 x first always, 2 weights first always
 unsigned long long *g_debug_buf = nullptr;
 
 template <int MB, int ROWS, int WN, int WK, int DEPTH, int XB, int MODE = 0, bool Z8 = false, bool NORM = false>
@@ -561,7 +561,7 @@ void set_gemv_order(int force) { g_order_force = force >= 0 && force <= 2 ? forc
 // 0: the rule -- ON for a decode launch (M = 1): 2-3 % on each of the token's four launch shapes (7.31 -> 7.09, 4.22 -> 4.09, 10.79 -> 10.47, 7.73 -> 7.60 us,
 // profiles/r3/gemv_shared_xsum_ab.jsonl; the round's first A/B of this switch compared a kernel with itself -- its debug mode was shadowed -- and is withdrawn);
 // 1 on, 2 off
-int g_shared_xsum = 0;
+thread_local int g_shared_xsum = 0;
 void set_gemv_shared_xsum(int on) { g_shared_xsum = on == 1 || on == 2 ? on : 0; }
 void set_gemv_debug_buffer(void *p) { g_debug_buf = static_cast<unsigned long long *>(p); }
 

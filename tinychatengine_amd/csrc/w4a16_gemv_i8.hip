@@ -472,8 +472,9 @@ __global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const I8Args args) 
     }
 }
 
-int g_i8_mode = 0;  // 0 automatic, 1 off, 2 forced wherever the shape allows
-int g_i8_rows = 0;  // 0 the rule, 1 / 2 forced tiles per wave
+static int i8_units_per_wave(int U) { return U <= 128 ? 8 : (U <= 256 ? 16 : 0); }
+thread_local int g_i8_mode = 0;  // 0 automatic (wherever the shape allows and a packed copy is given), 1 off
+thread_local int g_i8_rows = 0;  // 0 the rule, 1 / 2 forced tiles per wave
 
 template <int MB, int GPU, int ROWS, int UW, bool Z8, int MAXT, bool NORM = false, bool RNORM = false>
 hipError_t launch_i8(const I8Args &a, int blocks, int m_blocks, int wk, hipStream_t stream) {
@@ -489,13 +490,23 @@ hipError_t launch_i8(const I8Args &a, int blocks, int m_blocks, int wk, hipStrea
 
 }  // namespace
 
+// rows of A per pass of the weights: 1 / 2 / 4, bounded by the sixteen columns of the MFMA and by the digit planes fitting LDS twice per CU (M = 4 at K = 11008 / 14336:
+// one row per pass).  ONE rule for the launcher and for tce_w4a16_describe_dispatch.
+int gemv_i8_rows_per_pass(int M, int K, int group_size) {
+    const int U = K / 128, gpu = 128 / group_size;
+    const int uw = i8_units_per_wave(U);
+    const int wk = (U + uw - 1) / uw;
+    int mb = M >= 3 ? 4 : M;
+    while (mb > 1 && (mb * gpu > 4 || (size_t)wk * uw * mb * 512 > 72 * 1024)) mb >>= 1;
+    return mb;
+}
+
 void set_gemv_i8_mode(int mode, int rows) {
-    g_i8_mode = mode >= 0 && mode <= 2 ? mode : 0;
+    g_i8_mode = mode == 1 ? 1 : 0;
     g_i8_rows = rows == 1 || rows == 2 ? rows : 0;
 }
 
 // units per wave: a function of K (and of the rows / groups per pass) ONLY, so that a row's arithmetic does not depend on N
-static int i8_units_per_wave(int U) { return U <= 128 ? 8 : (U <= 256 ? 16 : 0); }
 
 bool gemv_i8_supports(const tce_w4a16_desc *descs, int count, bool with_norm) {
     if (g_i8_mode == 1) return false;
@@ -539,9 +550,7 @@ int launch_w4a16_gemv_i8(const tce_w4a16_desc *descs, int count, hipStream_t str
         z8 = z8 && (descs[i].flags & TCE_W4_ZERO_POINT_IS_8);
         total_tiles += pk::nt16(descs[i].N);
     }
-    // rows of A per pass: 1 / 2 / 4, bounded by the sixteen columns and by the planes fitting LDS twice per CU
-    int mb = d0.M >= 3 ? 4 : d0.M;
-    while (mb > 1 && (mb * gpu > 4 || (size_t)wk * uw * mb * 512 > 72 * 1024)) mb >>= 1;
+    const int mb = gemv_i8_rows_per_pass(d0.M, d0.K, d0.group_size);
     const int m_blocks = (d0.M + mb - 1) / mb;
     // tiles per wave: one.  Two (the conversion of x amortised over twice the bytes, one generation of workgroups for the gate+up launch) measured slower on every
     // launch of the token (profiles/r4/gemv_i8_ab.jsonl: qkv 6.6 -> 7.4 us, o 3.9 -> 4.5, gate+up 9.9 -> 10.2, down a tie); compiled, forceable (tce_w4a16_set_gemv_i8)

@@ -417,11 +417,11 @@ __global__ __launch_bounds__(64 * NW, 8 / (NW / 4)) void w4a16_gemv_ovl_kernel(c
     stamp(3);
 }
 
-int g_ovl_chains = 0;  // tuning: graph branches the launches alternate over (0 = 2)
-int g_ovl_depth = 0;   // tuning: ring slots per wave (0 = as many as fit, up to 4)
+thread_local int g_ovl_chains = 0;  // tuning: graph branches the launches alternate over (0 = 2)
+thread_local int g_ovl_depth = 0;   // tuning: ring slots per wave (0 = as many as fit, up to 4)
 unsigned long long *g_ovl_stamps = nullptr;
 
-int g_ovl_x4 = 1;
+thread_local int g_ovl_x4 = 1;
 template <int NW, int D, int XB>
 hipError_t ovl_setup(size_t lds, int *per_cu) {
     const void *kfn = g_ovl_x4 == 4 ? reinterpret_cast<const void *>(w4a16_gemv_ovl_kernel<NW, D, XB, 4>) : reinterpret_cast<const void *>(w4a16_gemv_ovl_kernel<NW, D, XB, 1>);

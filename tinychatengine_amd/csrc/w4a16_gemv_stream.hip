@@ -554,8 +554,8 @@ __global__ __launch_bounds__(64 * token_max_waves(ROWS, DEPTH, Z8)) void w4a16_g
 __global__ void token_epoch_kernel(unsigned *epoch) { *epoch = *epoch % 65535u + 1u; }
 
 int g_num_cus = 0;
-int g_stream_rows = 0, g_stream_nw = 0, g_stream_depth = 0, g_stream_bpc = 0;  // forced geometry (0 = automatic)
-int g_stream_mode = 0;
+thread_local int g_stream_rows = 0, g_stream_nw = 0, g_stream_depth = 0, g_stream_bpc = 0;  // forced geometry (0 = automatic)
+thread_local int g_stream_mode = 0;
 unsigned long long *g_stream_dbg = nullptr;
 
 int num_cus() {

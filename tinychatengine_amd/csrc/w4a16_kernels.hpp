@@ -104,6 +104,7 @@ int launch_w4a16_gemv(const tce_w4a16_desc *descs, int count, int forced_rows, i
 
 // w4a16_gemv_i8.hip: the decode GEMV (M <= 4) as an int8 contraction on the pre-packed copy
 bool gemv_i8_supports(const tce_w4a16_desc *descs, int count, bool with_norm = false);
+int gemv_i8_rows_per_pass(int M, int K, int group_size);
 void set_gemv_i8_mode(int mode, int rows);  // mode 0 automatic (taken wherever a packed copy comes with the descriptors), 1 off; rows 0 the rule, 1 / 2 tiles per wave
 struct I8ResidualNorm {  // tce_w4a16_forward_residual_rmsnorm: the RMSNorm that follows the residual add, produced by the same launch
     const float *gamma;
@@ -189,6 +190,7 @@ int comm_world_of(const Comm *c);
 int comm_rccl_unique_id(void *id128);
 int comm_rccl_init(Comm *c, const void *id128);
 bool comm_has_rccl(const Comm *c);
+const char *comm_rccl_last_error();  // text of this thread's last failed RCCL call
 bool comm_peer_regime(const Comm *c, int n_total);
 int launch_allgather_rccl(Comm *c, const void *src_slice, void *dst_full, size_t n_per_rank, hipStream_t stream);
 size_t allgather_rows_workspace_bytes(int M, int n_total);

@@ -357,8 +357,8 @@ __global__ __launch_bounds__(512) void w4a16_skinny_shared_kernel(const SkinnyAr
     }
 }
 
-int g_skinny_ks = 0;  // forced K split (tuning), 0 = automatic
-int g_skinny_max_m = 128;
+thread_local int g_skinny_ks = 0;  // forced K split (tuning), 0 = automatic
+thread_local int g_skinny_max_m = 128;
 
 }  // namespace
 

@@ -625,13 +625,13 @@ __global__ __launch_bounds__(256) void w8a8_rowdot_kernel(const W8A8Args a) {
     }
 }
 
-int g_w8a8_ks = 0;  // forced K split (tuning), 0 = automatic; 3: the decode-sized kernels above are not used (A/B)
+thread_local int g_w8a8_ks = 0;  // forced K split (tuning), 0 = automatic; 3: the decode-sized kernels above are not used (A/B)
 
 }  // namespace
 
 void set_w8a8_ksplit(int ks) { g_w8a8_ks = (ks >= 1 && ks <= 4) ? ks : 0; }
-int g_w8a8_deep = 0;  // the 64 x 64 tile with 8 k-steps in flight: 0 the rule, 1 / 2 / 4 forced with that many quartets, 9 off (A/B)
-int g_w8a8_big = 0;  // the 128-row tiles: 0 the rule, 1 / 2 forced with 128 / 64 columns (one quartet), 3 / 4 the same with two quartets, 9 off (A/B)
+thread_local int g_w8a8_deep = 0;  // the 64 x 64 tile with 8 k-steps in flight: 0 the rule, 1 / 2 / 4 forced with that many quartets, 9 off (A/B)
+thread_local int g_w8a8_big = 0;  // the 128-row tiles: 0 the rule, 1 / 2 forced with 128 / 64 columns (one quartet), 3 / 4 the same with two quartets, 9 off (A/B)
 void set_w8a8_big(int b) { g_w8a8_big = b; }
 void set_w8a8_deep(int d) { g_w8a8_deep = d; }
 

@@ -35,7 +35,7 @@
 
 namespace tce {
 
-static int g_lnq_form = 0;  // debug: 1 = the workgroup-per-8-rows form at every k (A/B of the weights-resident form)
+static thread_local int g_lnq_form = 0;  // debug: 1 = the workgroup-per-8-rows form at every k (A/B of the weights-resident form)
 void set_lnq_form(int f) { g_lnq_form = f; }
 static unsigned long long *g_lnq_stamps = nullptr;
 void set_lnq_stamps(void *p) { g_lnq_stamps = static_cast<unsigned long long *>(p); }

@@ -172,7 +172,10 @@ class DecodeLinears:
         exchanges the 64-byte IPC handles through `exchange(bytes) -> list[bytes]` (e.g. torch.distributed.all_gather_object)
         and maps the peers.  run_token_distributed(gather="peer") then uses it instead of torch.distributed."""
         n_max = max(*self.shape.qkv, self.shape.hidden, self.shape.ffn, self.shape.vocab)
-        self.comm = capi.Comm(self.rank, self.world, n_max, slots=8)
+        # the window holds the widest gathered tensor of ALL M rows: tce_allgather_rows_f16 stages the ranks' whole [M][N/P] blocks through it (M = 64, hidden 4096 is
+        # 262144 halves -- a one-row window would send every M > 1 exchange to RCCL, which this path does not set up; ADVICE r4).  Beyond 64 KiB slices the peer-write
+        # kernel is slower than the links (csrc/comm.hip: RCCL takes those exchanges when the host called tce_comm_rccl_init), but it is correct at every size that fits.
+        self.comm = capi.Comm(self.rank, self.world, n_max * self.m, slots=8)
         self.comm.connect(exchange(self.comm.export()))
 
     def _rows_workspace(self, full: torch.Tensor) -> torch.Tensor:
