@@ -948,6 +948,18 @@ def main():
     dl = DecodeLinears(shape, device=dev, group_size=G, rank=rank, world=world, m=1, layers=args.layers,
                        dataflow=(world == 1 and not args.ungrouped and shape.qkv[0] >= shape.hidden), prepack=prepack)
     want_peer = args.gather in ("all", "peer")
+    peer_state = "not requested (--gather rccl)" if not want_peer else "single GPU"
+    ranks_info = None
+    if dist is not None:
+        # who runs where: one row per rank -- device index, PCI address, name -- so that a scaling record shows N distinct devices
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            mine = {"rank": rank, "device": dev.index, "pci_bus_id": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0)),
+                    "name": pr.name}
+        except Exception as e:  # noqa: BLE001
+            mine = {"rank": rank, "device": getattr(dev, "index", None), "error": f"{type(e).__name__}: {e}"}
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, mine)
     if dist is not None and want_peer:
         # The peer-write gather needs every rank's window mapped into every other rank (hipIpc) and one exchange to come back right.
         # Every step is agreed on by ALL ranks (a rank that failed alone would leave the others waiting); otherwise: RCCL.
@@ -983,6 +995,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 ok, why = False, f"test exchange: {type(e).__name__}: {e}"
             ok = agree(ok)
+        peer_state = "peer-write windows mapped on every rank, test exchange ok" if ok else ("not available: " + (why or "another rank failed to map a window or to exchange"))
         if ok:
             dl.comm = comm
         else:
@@ -1143,7 +1156,7 @@ def main():
     else:
         n_launches = dl.n_layers * 4 + 1
 
-        def build_dist_step(gpb, gather):
+        def build_dist_step(gpb, gather, dl=dl):
             """The distributed token (gpb gathers per block, joined by `gather`) as a callable + how it is issued."""
             graph = None
             try:  # capture GEMVs + RCCL all-gathers of one token into one graph; fall back to eager issue if capture fails
@@ -1201,13 +1214,8 @@ def main():
             wall = float(tw.item())
         return wall, e0.elapsed_time(e1)
 
-    gather_variants = None
-    if dist is None:
-        wall, ev_ms_total = timed_run(step)
-    else:
-        # Every way the ranks' slices can be joined, in ONE run (the first session on an 8-GPU node should not have to be repeated four
-        # times): {peer-write kernel, RCCL} x {1 gather per block -- the north-star definition --, 4 -- the dependency-faithful form}.
-        # The headline is the faster one-gather-per-block variant; all of them are under config.gather_variants.
+    def time_gather_variants(dl):
+        """(gather_variants, runs) for one set of sharded linears: every way the ranks' slices can be joined, timed one after the other."""
         gathers = [g for g in (("peer", "rccl") if args.gather == "all" else (args.gather,)) if g != "peer" or getattr(dl, "comm", None) is not None]
         gpbs = (1, 4) if args.gathers_per_block == 0 else (args.gathers_per_block,)
         gather_variants, runs = {}, []
@@ -1215,7 +1223,7 @@ def main():
             for gth in gathers:
                 name = f"{'peer-write kernel (tce_allgather_f16)' if gth == 'peer' else 'RCCL all_gather_into_tensor'}, {gpb} gather{'s' if gpb > 1 else ''} per block"
                 try:
-                    step_v, mode_v = build_dist_step(gpb, gth)
+                    step_v, mode_v = build_dist_step(gpb, gth, dl)
                     wall_v, ev_v = timed_run(step_v)
                     ok = True
                     if gth == "peer":
@@ -1241,12 +1249,47 @@ def main():
                         torch.cuda.synchronize()
                     except Exception:  # noqa: BLE001
                         pass
+        return gather_variants, runs
+
+    gather_variants = None
+    llama13 = None
+    if dist is None:
+        wall, ev_ms_total = timed_run(step)
+    else:
+        # Every way the ranks' slices can be joined, in ONE run (the first session on an 8-GPU node should not have to be repeated four
+        # times): {peer-write kernel, RCCL} x {1 gather per block -- the north-star definition --, 4 -- the dependency-faithful form}.
+        # The headline is the faster one-gather-per-block variant; all of them are under config.gather_variants.
+        gather_variants, runs = time_gather_variants(dl)
         if not runs:
             raise SystemExit("no gather variant completed: " + json.dumps(gather_variants))
         one = [r for r in runs if r[0] == min(g for g, *_ in runs)]
         gpb_h, gth_h, wall, ev_ms_total, mode, name_h = min(one, key=lambda r: r[2])
         args.gathers_per_block, args.gather = gpb_h, gth_h
         gather_variants["headline"] = name_h
+        # BASELINE config 5 (Llama-2-13B column-sharded 8 ways) beside the headline workload when the run has its eight ranks (VERDICT r4 item 7 ii): same
+        # variants, same timing; never takes the headline down with it
+        if world == 8 and args.workload != "llama2-13b" and not args.no_extras:
+            try:
+                dl13 = DecodeLinears(SHAPES["llama2-13b"], device=dev, group_size=G, rank=rank, world=world, m=1, prepack=prepack)
+                if getattr(dl, "comm", None) is not None:
+                    def exchange13(h):
+                        got13 = [None] * world
+                        dist.all_gather_object(got13, h)
+                        return got13
+                    dl13.attach_peer_comm(exchange13)
+                gv13, runs13 = time_gather_variants(dl13)
+                sh13 = SHAPES["llama2-13b"]
+                bytes13 = sum(capi.algorithmic_bytes(1, n, k, G) for (n, k) in
+                              ([(n, sh13.hidden) for n in sh13.qkv] + [(sh13.hidden, sh13.hidden), (sh13.ffn, sh13.hidden), (sh13.ffn, sh13.hidden), (sh13.hidden, sh13.ffn)]) * dl13.n_layers
+                              + [(sh13.vocab, sh13.hidden)])
+                one13 = [r for r in runs13 if r[0] == 1] or runs13
+                best13 = min(one13, key=lambda r: r[2]) if one13 else None
+                llama13 = {"workload": sh13.name, "gather_variants": gv13, "algorithmic_bytes_per_token": bytes13,
+                           **({"tokens_per_s": round(args.steps / best13[2], 1), "ms_per_token": round(best13[2] * 1e3 / args.steps, 4), "headline": best13[5],
+                               "gather": best13[5], "frac_of_8TBs": round(bytes13 * args.steps / best13[2] / (world * 8.0e12), 4)} if best13 else {})}
+                del dl13
+            except Exception as e:  # noqa: BLE001
+                llama13 = {"error": f"{type(e).__name__}: {e}"}
     ms_per_step = wall * 1e3 / args.steps
     ev_ms_per_step = ev_ms_total / args.steps
     tok_s = args.steps / wall
@@ -1356,6 +1399,9 @@ def main():
                                        + ("peer-write all-gather(s) (tce_allgather_f16)" if args.gather == "peer" else f"{'RCCL' if args.backend == 'nccl' else args.backend} all-gather(s)")
                                        + " per block") if world > 1 else "single GPU",
                        "issue": mode, **({"issue_variants": variants} if variants else {}), **({"gather_variants": gather_variants} if gather_variants else {}),
+                       **({"ranks": ranks_info, "rccl_ranks": (dist.get_world_size() if args.backend == "nccl" else 0),
+                           "gather_path": {"peer": peer_state, "rccl": f"torch.distributed backend {args.backend} ({'RCCL' if args.backend == 'nccl' else 'CPU stand-in'})",
+                                           "headline": args.gather}} if dist is not None else {}),
                        "grouped_launches": not args.ungrouped,
                        "decode_kernel": ("int8 contraction on the packed copy of every linear (tce_w4a16_prepack at load time; csrc/w4a16_gemv_i8.hip)" if prepack
                                          else "fp16 unpack on the q4_6 arrays (csrc/w4a16_gemv.hip)"),
@@ -1391,6 +1437,8 @@ def main():
                 out["w8a8_opt125m_shapes"] = {"note": "tce_w8a8_matmul, bit-exact with kernels/ref/matmul_ref_int8.cc; graphs of 64 back-to-back launches on ONE weight set (L2-resident; the whole model is 94 MB: other_configs.w8a8_opt125m_layer walks per-layer weights), HIP events; boundary = 1.55 us per dependent launch",
                                               "launches": cfg4}
             out["other_configs"] = extras
+        if llama13 is not None:
+            out["llama2_13b"] = llama13  # BASELINE config 5, column-sharded over the run's eight ranks
         if adapter is not None:
             out["adapter_path"] = adapter
         if cpu is not None:
