@@ -29,10 +29,27 @@ def short(name, row=None):
     i = name.find(MINE)
     s = name[i:i + 110] if i >= 0 else name[:110]
     if KEY_GRID and row is not None:
-        gs = row.get("Grid_Size_X") or row.get("Grid_Size")
+        if row.get("Grid_Size_X"):  # kernel trace: per dimension; counter collection: the product
+            gs = int(row["Grid_Size_X"]) * int(row.get("Grid_Size_Y") or 1) * int(row.get("Grid_Size_Z") or 1)
+        else:
+            gs = row.get("Grid_Size")
         if gs:
             s += f" [grid {gs}]"
     return s
+
+
+def segmented(rows, name_col):
+    """KEY_GRID: the driver runs its cases one after the other, a few launches each -- two cases may share (kernel, grid) (512 x 768 x 768 and 512 x 768 x 3072): a key's
+    dispatches are cut into runs of consecutive dispatches (in dispatch order, among this library's kernels) and the run's index joins the key: "... #0", "... #1"."""
+    rows = sorted(rows, key=lambda r: int(r["Dispatch_Id"]))
+    seen, last, out = defaultdict(int), None, []
+    for r in rows:
+        k = short(r[name_col], r)
+        if k != last:
+            seen[k] += 1
+            last = k
+        out.append((k + f" #{seen[k] - 1}", r))
+    return out
 
 
 avg_ns = {}
@@ -46,8 +63,8 @@ for f in sorted(glob.glob(os.path.join(root, "kt", "**", "*kernel_stats.csv"), r
 for f in sorted(glob.glob(os.path.join(root, "kt", "**", "*kernel_trace.csv"), recursive=True)):
     rows = [r for r in csv.DictReader(open(f)) if mine(r["Kernel_Name"])]
     by = defaultdict(list)
-    for r in rows:
-        by[short(r["Kernel_Name"], r) if KEY_GRID else r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r))
+    for k_, r in (segmented(rows, "Kernel_Name") if KEY_GRID else [(r["Kernel_Name"], r) for r in rows]):
+        by[k_].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r))
     print("== kernel trace:", os.path.relpath(f, root), len(rows), "dispatches of this library")
     for k, v in sorted(by.items(), key=lambda kv: -sum(e - s for s, e, _ in kv[1])):
         d = sorted(e - s for s, e, _ in v)
@@ -63,10 +80,15 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
     for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
         acc = defaultdict(lambda: defaultdict(list))
         n = 0
-        for r in csv.DictReader(open(f)):
-            if mine(r["Kernel_Name"]):
-                acc[short(r["Kernel_Name"], r)][r["Counter_Name"]].append(float(r["Counter_Value"]))
-                n += 1
+        prow = [r for r in csv.DictReader(open(f)) if mine(r["Kernel_Name"])]
+        if KEY_GRID:  # one row per (dispatch, counter): segment on the dispatches, then spread the keys over their counter rows
+            firsts = {}
+            for r in prow:
+                firsts.setdefault(r["Dispatch_Id"], r)
+            keyof = {r["Dispatch_Id"]: k_ for k_, r in segmented(list(firsts.values()), "Kernel_Name")}
+        for r in prow:
+            acc[keyof[r["Dispatch_Id"]] if KEY_GRID else short(r["Kernel_Name"], r)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            n += 1
         print("== pmc:", os.path.relpath(f, root), n, "rows of this library")
         for k, cs in acc.items():
             print("   ", k)
@@ -87,7 +109,7 @@ for k, m in med.items():
         out.append(f"SQ_INSTS_VALU / SQ_INSTS_MFMA = {m['SQ_INSTS_VALU'] / m['SQ_INSTS_MFMA']:.2f} (the counter includes the MFMAs: {m['SQ_INSTS_VALU'] / m['SQ_INSTS_MFMA'] - 1:.2f} other vector instructions per MFMA)")
     if "SQ_VALU_MFMA_BUSY_CYCLES" in m and m.get("GRBM_GUI_ACTIVE"):
         # SQ_VALU_MFMA_BUSY_CYCLES sums over the chip's 1024 SIMDs in units of 4 cycles? -- printed raw beside the launch's cycles; the ratio quoted in DESIGN is busy / (GRBM_GUI_ACTIVE x SIMDs)
-        out.append(f"SQ_VALU_MFMA_BUSY_CYCLES = {m['SQ_VALU_MFMA_BUSY_CYCLES']:.4g}, GRBM_GUI_ACTIVE = {m['GRBM_GUI_ACTIVE']:.4g}: matrix pipe busy = {m['SQ_VALU_MFMA_BUSY_CYCLES'] / (m['GRBM_GUI_ACTIVE'] * 1024):.2f} of the launch's SIMD-cycles (1024 SIMDs)")
+        out.append(f"SQ_VALU_MFMA_BUSY_CYCLES = {m['SQ_VALU_MFMA_BUSY_CYCLES']:.4g}, GRBM_GUI_ACTIVE = {m['GRBM_GUI_ACTIVE']:.4g} (summed over the 8 XCDs): matrix pipe busy = {m['SQ_VALU_MFMA_BUSY_CYCLES'] / (m['GRBM_GUI_ACTIVE'] / 8.0 * 1024):.2f} of the launch's SIMD-cycles (1024 SIMDs x the launch's cycles)")
     if "SQ_BUSY_CYCLES" in m and "SQ_VALU_MFMA_BUSY_CYCLES" in m and "GRBM_GUI_ACTIVE" not in m:
         out.append(f"SQ_VALU_MFMA_BUSY_CYCLES = {m['SQ_VALU_MFMA_BUSY_CYCLES']:.4g}")
     if "SQ_INSTS_LDS" in m and m.get("SQ_INSTS_MFMA"):
