@@ -253,8 +253,12 @@ def other_configs_leg(torch, dev):
             y = torch.empty(M, N, dtype=torch.float16, device=dev)
             row = {"M": M, "N": N, "K": K}
             for name, with_pack in (("q4_6_only", False), ("prepacked", True)):
+                # flags: what a host sets once per linear at load time -- the reference's quantizer writes zero point 8 everywhere (quantize_methods.py:436-440) and
+                # tce_w4a16_check_zero_point_8 confirms it on the tensor (the C++ adapter does exactly this: adapter/matmul_operator_hip.cc); the wide GEMM forms
+                # and the decode kernel's fast path read no zero points on such a linear
                 ds = [capi.W4A16Desc(M=M, N=N, K=K, group_size=128, A=x.data_ptr(), qweight=q.data_ptr(), scales=s_.data_ptr(), zeros=z.data_ptr(), C=y.data_ptr(),
-                                     prepacked=pk.data_ptr() if with_pack else None, scratch=scratch.data_ptr() if with_pack else None)
+                                     prepacked=pk.data_ptr() if with_pack else None, scratch=scratch.data_ptr() if with_pack else None,
+                                     flags=capi.TCE_W4_ZERO_POINT_IS_8 if int(L.tce_w4a16_check_zero_point_8(z.data_ptr(), z.numel())) == 1 else 0)
                       for (q, s_, z), pk in zip(sets, packs)]
                 us = time_graph(lambda i, sp: capi.check(L.tce_w4a16_forward(C.byref(ds[i % len(ds)]), sp)), 16)
                 buf = C.create_string_buffer(256)
