@@ -37,7 +37,7 @@ for (M, N, K) in shapes:
         capi.check(capi.w4a16_forward(descs[it[0] % 3], st)); it[0] += 1
     row = {"M": M, "N": N, "K": K}
     fl = 2.0 * M * N * K
-    forms = [("narrow_auto", 60), ("form1", 61), ("form8", 68), ("wide1", 2670), ("wide2", 2671), ("wide_cut2", 2682), ("wide_cut3", 2683), ("wide_cut4", 2684), ("wide3_1", 2673), ("wide3_2", 2674), ("narrow_auto_again", 60)]
+    forms = [("narrow_auto", 60), ("form1", 61), ("form8", 68), ("wide1", 2670), ("wide2", 2671), ("wide_cut2", 2682), ("wide_cut3", 2683), ("wide_cut4", 2684), ("wide3_1", 2673), ("wide3_2", 2674), ("wide512", 2675), ("narrow_auto_again", 60)]
     if ABL:  # parts of the wide loop switched off (results meaningless): 1 no rescale, 2 no unpack, 4 no fragment reads, 8 no MFMAs, 16 no activation DMAs, 32 no barriers
         forms = [("wide1", 2670)] + [(f"wide1_abl{b}", 26000 + b) for b in (1, 2, 4, 8, 16, 32, 7, 55)] + [("wide1_again", 2670), ("wide1_dma_in_phase1", 26128), ("wide1_dma_in_front", 26256), ("wide1_third", 2670), ("wide1_dma_in_phase1_again", 26128)]
     for name, mode in forms:

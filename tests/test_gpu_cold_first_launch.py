@@ -12,7 +12,7 @@ import sys
 import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-MODES_128 = [61, 62, 63, 64, 66, 67, 68, 2669, 2670, 2671, 2672, 2673, 2674, 60]
+MODES_128 = [61, 62, 63, 64, 66, 67, 68, 2669, 2670, 2671, 2672, 2673, 2674, 2675, 60]
 MODES_OTHER = [61, 62, 63, 64, 60]
 
 

@@ -106,13 +106,13 @@ def test_pk_gemm_matches_oracle(dev, oracle, M, N, K, G):
         lin = _lin(dev, qw, sc, zp, G).prepack()
         x = torch.from_numpy(a).to(dev)
         try:
-            for mode in (61, 62, 63, 64, 66, 67, 672, 68, 2669, 2670, 2671, 2672, 2683, 2673, 2674, 60):  # 64: the k range cut across workgroups (needs the scratch area desc() attaches); 66 / 67 / 672 / 68 / 2669: the 256-row wave tiles (round 5; groups of 128 -- other group sizes run form 1 under these modes): whole tiles / k range cut / two quartets alternating a tile's k-blocks (even counts; odd: one quartet) / two quartets side by side on 256 x 256
+            for mode in (61, 62, 63, 64, 66, 67, 672, 68, 2669, 2670, 2671, 2672, 2683, 2673, 2674, 2675, 60):  # 64: the k range cut across workgroups (needs the scratch area desc() attaches); 66 / 67 / 672 / 68 / 2669: the 256-row wave tiles (round 5; groups of 128 -- other group sizes run form 1 under these modes): whole tiles / k range cut / two quartets alternating a tile's k-blocks (even counts; odd: one quartet) / two quartets side by side on 256 x 256
                 capi.check(L.tce_w4a16_set_debug_mode(mode))
                 out = torch.full((M, N), float("nan"), dtype=torch.float16, device=dev)
                 d = lin.desc(x, out)
                 if mode != 60:  # (60 = automatic: the cost models of the two GEMMs decide, test_pk_dispatch_rules)
                     assert capi.describe_dispatch(d).startswith("gemm-pk"), capi.describe_dispatch(d)
-                if mode in (2670, 2671, 2672, 2683) and not rz and G == 128 and M > 128:  # round 5: 128 rows x 64 columns per wave
+                if mode in (2670, 2671, 2672, 2683, 2675) and not rz and G == 128 and M > 128:  # round 5: 128 rows x 64 columns per wave
                     assert "wave=128x64" in capi.describe_dispatch(d), capi.describe_dispatch(d)
                 if mode in (2673, 2674) and not rz and G == 128 and M > 128:  # the same on 128 x 192 tiles
                     assert "wave=128x48" in capi.describe_dispatch(d), capi.describe_dispatch(d)
@@ -318,14 +318,14 @@ def test_wide_form_against_the_narrow_form_at_full_size(dev, oracle, M, N, K):
     x = torch.empty(M, K, device=dev).normal_(0, 1, generator=g).to(torch.float16)
     outs = {}
     try:
-        for mode in (61, 2670, 2671, 2672, 2673, 2674):
+        for mode in (61, 2670, 2671, 2672, 2673, 2674, 2675):
             capi.check(L.tce_w4a16_set_debug_mode(mode))
             ys = []
             for rep in range(2):
                 y = torch.full((M, N), float("nan"), dtype=torch.float16, device=dev)
                 d = lin.desc(x, y)
                 if mode != 61:
-                    assert ("wave=128x48" if mode >= 2673 else "wave=128x64") in capi.describe_dispatch(d), capi.describe_dispatch(d)
+                    assert ("wave=128x48" if mode in (2673, 2674) else "wave=128x64") in capi.describe_dispatch(d), capi.describe_dispatch(d)
                 capi.check(capi.w4a16_forward(d, torch.cuda.current_stream().cuda_stream))
                 torch.cuda.synchronize()
                 ys.append(y)
@@ -337,9 +337,10 @@ def test_wide_form_against_the_narrow_form_at_full_size(dev, oracle, M, N, K):
     assert int(gemm_scratch(dev)[:4096].to(torch.int32).sum().item()) == 0
     assert torch.equal(outs[2670], outs[61]), "one quartet per wide tile: the same sums in the same order as the 128 x 128 form"
     assert torch.equal(outs[2673], outs[61]), "one quartet per 128 x 192 tile: likewise"
+    assert torch.equal(outs[2675], outs[61]), "128 x 512 tiles, two quartets side by side: likewise"
     rows = list(range(0, M, M // 64))
     ref32 = oracle.w4a16_gemv_q4_6_mt(x[rows].cpu().numpy(), lin.weight.cpu().numpy().view(np.uint32), lin.scale.cpu().numpy(),
                                       lin.zero_point.cpu().numpy().view(np.uint32), len(rows), N, K, 128)
-    for mode in (2670, 2671, 2672, 2673, 2674):
+    for mode in (2670, 2671, 2672, 2673, 2674, 2675):
         ok, worst = w4a16_close(outs[mode][rows].cpu().numpy(), ref32)
         assert ok, f"mode {mode}: worst |err|/tol = {worst:.3f}"

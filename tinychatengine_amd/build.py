@@ -38,7 +38,7 @@ NO_VGPR_SPILL: dict[str, list[str]] = {"w8a8_lnq_fused.hip": ["lnq_w8a8_wide_ker
                                         "w4a16_gemv_i8.hip": ["w4a16_gemv_i8_kernel"],
                                         # the 256-row prefill GEMM lands asm loads in ordinary variables that become valid at a counted wait: a spill of one of them in
                                         # between would store stale data (the product instantiation only; its timing-experiment variants may spill)
-                                        "w4a16_gemm_pk.hip": ["w4a16_gemm_pk256_kernelILi7ELi0E", "w4a16_gemm_pk256x2_kernelILi7ELi0E", "w4a16_gemm_pkw_kernelILi7ELi0E", "w4a16_gemm_pkwx2_kernelILi7ELi0E", "w4a16_gemm_pkw3_kernelILi7ELi0E", "w4a16_gemm_pkw3x2_kernelILi7ELi0E"]}  # (round 3: four forms spilled 3-34 registers under __launch_bounds__(1024))
+                                        "w4a16_gemm_pk.hip": ["w4a16_gemm_pk256_kernelILi7ELi0E", "w4a16_gemm_pk256x2_kernelILi7ELi0E", "w4a16_gemm_pkw_kernelILi7ELi0E", "w4a16_gemm_pkwx2_kernelILi7ELi0E", "w4a16_gemm_pkw3_kernelILi7ELi0E", "w4a16_gemm_pkw3x2_kernelILi7ELi0E", "w4a16_gemm_pkw512_kernelILi7ELi0E"]}  # (round 3: four forms spilled 3-34 registers under __launch_bounds__(1024))
 
 
 def _check_spills(src: str, stderr_text: str) -> None:

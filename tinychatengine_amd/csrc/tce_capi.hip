@@ -216,6 +216,13 @@ int tce_w4a16_set_debug_mode(int mode) {
         tce::set_gemm_pk_ablation(mode - 600);
         return TCE_OK;
     }
+    if (mode == 2675) {  // the wide form on 128 x 512 tiles (two quartets side by side on one activation ring)
+        g_pk_mode = 8;
+        tce::set_gemm_pk_ablation(0);
+        tce::set_gemm_pk_split(0);
+        tce::set_gemm_pk_mode(15, 0);
+        return TCE_OK;
+    }
     if (mode == 2673 || mode == 2674) {  // the wide form on 128 x 192 tiles (48 columns per wave): 2673 one quartet per tile, 2674 two quartets alternating its k-blocks
         g_pk_mode = 8;
         tce::set_gemm_pk_ablation(0);
@@ -574,7 +581,8 @@ int tce_w4a16_describe_dispatch(const tce_w4a16_desc *d, char *buf, int buf_len)
     if (use_pk(d, want_gemm || pairs_on_pk)) {
         int form = 1, split = 1;
         tce::gemm_pk_estimate_us(d->M, d->N, d->K, &form, d->scratch != nullptr && (reinterpret_cast<uintptr_t>(d->scratch) & 255) == 0, &split, d->group_size, (d->flags & TCE_W4_ZERO_POINT_IS_8) != 0);
-        if (form == 13 || form == 14) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=128x192 wave=128x48 quartets=%d group=%d", form - 12, d->group_size);
+        if (form == 15) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=128x512 wave=128x64 quartets=2-side-by-side group=%d", d->group_size);
+        else if (form == 13 || form == 14) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=128x192 wave=128x48 quartets=%d group=%d", form - 12, d->group_size);
         else if (form == 10) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=128x256 wave=128x64 quartets=1 group=%d", d->group_size);
         else if (form == 11) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=128x256 wave=128x64 quartets=2 group=%d", d->group_size);
         else if (form == 12) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=128x256 wave=128x64 quartets=1 ksplit=%d group=%d", split, d->group_size);

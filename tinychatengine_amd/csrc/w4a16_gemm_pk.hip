@@ -192,7 +192,7 @@ constexpr int kAsmVgprBase = 232;  // 128-row forms (and every group size); the 
 template <int KS, int LG, int ABL, int NS, int kMT, int kNT = 2>
 __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
     static_assert(KS == 1 || NS == 1, "two quartets either split K or sit side by side");
-    static_assert(kNT == 2 || ((kNT == 4 || kNT == 3) && kMT == 8 && NS == 1 && LG == 7), "wide form: 128 rows x 64 (48) columns per wave, one quartet per 128 x 256 (192) tile (or two alternating its k-blocks), groups of 128");
+    static_assert(kNT == 2 || ((kNT == 4 || kNT == 3) && kMT == 8 && (NS == 1 || kNT == 4) && LG == 7), "wide form: 128 rows x 64 (48) columns per wave, one quartet per 128 x 256 (192) tile (or two alternating its k-blocks), groups of 128");
     constexpr bool WIDE = kNT >= 3;  // (kNT == 3: 128 x 192 tiles -- 58 column blocks on N = 11008 where 256-wide tiles make 43: 232 tiles instead of 172 for the 256 CUs at M = 512)
     static_assert(kMT == 8 || (kMT == 16 && (NS == 1 || KS == 1)), "256-row wave tiles: one quartet per tile, two quartets splitting the k-blocks of one tile, or two quartets side by side on one activation ring");
     constexpr int ROWS = 16 * kMT;                   // rows of the activation tile
@@ -818,6 +818,15 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
         for (int i = 0; i < kMT; ++i)
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) acc[i][j][rr] *= e_prev[j];
+    // (the products stand in binary32 registers before anything converts them: in the 128 x 512 form hipcc folded this multiply into the epilogue's conversion --
+    //  v_fma_mixlo_f16, ONE rounding from the exact product to binary16 instead of two -- and 0.007 % of the outputs differed from the other forms' by an ulp;
+    //  every form of this kernel rounds the same way; tests/test_gpu_w4a16_pk.py holds every wide form to the 128 x 128 form's bits)
+    if constexpr (WIDE && NS == 2) {
+#pragma unroll
+        for (int i = 0; i < kMT; ++i)
+#pragma unroll
+            for (int j = 0; j < kNT; ++j) asm volatile("" : "+v"(acc[i][j]));
+    }
 
     if constexpr (KS == 2) {  // quartet 1 hands its partial sums over: [register][thread of the quartet] floats (64 KiB)
         float *red = reinterpret_cast<float *>(smem);
@@ -978,6 +987,11 @@ __global__ __launch_bounds__(512, 2) void w4a16_gemm_pkwx2_kernel(const PkGemmAr
     w4a16_gemm_pk_body<2, LG, ABL, 1, 8, 4>(g);
 }
 
+// 128 x 512 tiles: two quartets side by side on ONE activation ring (half the activation DMA instructions per MFMA again); one workgroup per CU
+template <int LG, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void w4a16_gemm_pkw512_kernel(const PkGemmArgs g) {
+    w4a16_gemm_pk_body<1, LG, ABL, 2, 8, 4>(g);
+}
 // the same with 48 columns per wave (128 x 192 tiles)
 template <int LG, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void w4a16_gemm_pkw3_kernel(const PkGemmArgs g) {
@@ -999,6 +1013,7 @@ thread_local int g_pk_wide_auto = 1;                    // 1: the dispatcher may
 // fitted to profiles/r5/gemm_pkw_sweep.jsonl: 2048 x 4096 x 4096 (256 tiles, one per CU) 68.1 us; 4096 x 4096 x 4096 (512 tiles, two per CU) 112.8 us; two quartets on one tile 62.7 / 147.0 us at K = 4096 / 11008
 constexpr float kPkWideAloneUs = 2.02f;    // wide form: one quartet alone on its CU walking a k-block (128 MFMAs per wave)
 constexpr float kPkWidePairUs = 3.42f;     // wide form: two workgroups sharing a CU, one k-block each
+constexpr float kPkWide512Us = 3.2f;       // 128 x 512 tile (eight waves, one ring) walking one k-block: 4096 x 4096 x 4096 (256 tiles) 109.0 us, 4096 x 4096 x 11008 270.4, 8192 x 4096 x 4096 210.9
 constexpr float kPkWideX2PairUs = 3.45f;   // wide form: two quartets of ONE workgroup alternating a tile's k-blocks, per pair of k-blocks
 constexpr float kPk256UsPerKBlock = 2.25f;  // one workgroup per CU walking a 256-row k-block (128 MFMAs per wave); fitted in round 5 (profiles/r5/gemm_pk256_sweep.jsonl)
 
@@ -1066,6 +1081,15 @@ hipError_t launch_pkwx2(PkGemmArgs &g, hipStream_t stream) {
     return hipGetLastError();
 }
 
+hipError_t launch_pkw512(PkGemmArgs &g, hipStream_t stream) {
+    const size_t lds = (size_t)128 * 512 * 2;  // the 128 x 512 output tile (128 KiB); the ring (64 KiB) sits inside it
+    auto kfn = w4a16_gemm_pkw512_kernel<7, 0>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kfn, dim3(8 * g.m_per * g.n_per), dim3(512), lds, stream, g);
+    return hipGetLastError();
+}
+
 template <int KS>
 hipError_t launch_pkw3(PkGemmArgs &g, hipStream_t stream) {
     const size_t lds = (size_t)KS * 4 * pk::kHalfBytes;
@@ -1103,7 +1127,7 @@ void set_gemm_pk_wide_auto(int on) { g_pk_wide_auto = on ? 1 : 0; }
 void set_gemm_pk_split(int s) { g_pk_split_force = s >= 2 && s <= 4 ? s : 0; }
 
 void set_gemm_pk_mode(int form, int xm) {
-    g_pk_ks = (form >= 1 && form <= 14) ? form : 0;  // 13 / 14: the wide form on 128 x 192 tiles, one quartet per tile / two alternating its k-blocks  // 10 / 11 / 12: the wide form (one quartet per 128 x 256 tile; two quartets alternating its k-blocks; every tile's k range cut across workgroups)  // 9: 256 x 256 tiles, two quartets side by side (debug mode 2669)  // 6: 256-row wave tiles, whole tiles; 7: the same with every tile's k range cut across workgroups
+    g_pk_ks = (form >= 1 && form <= 15) ? form : 0;  // 15: the wide form on 128 x 512 tiles (two quartets side by side on one activation ring)  // 13 / 14: the wide form on 128 x 192 tiles, one quartet per tile / two alternating its k-blocks  // 10 / 11 / 12: the wide form (one quartet per 128 x 256 tile; two quartets alternating its k-blocks; every tile's k range cut across workgroups)  // 9: 256 x 256 tiles, two quartets side by side (debug mode 2669)  // 6: 256-row wave tiles, whole tiles; 7: the same with every tile's k range cut across workgroups
     g_pk_xm = (xm == 1 || xm == 2 || xm == 4 || xm == 8) ? xm : 0;
 }
 
@@ -1261,7 +1285,12 @@ float gemm_pk_estimate_us(int M, int N, int K, int *form_out, bool has_scratch, 
         cost13 = (tilesw3 <= 256 ? nkb * kPkWideAloneUs : 0.5f * rounds(tilesw3, 256) * nkb * kPkWidePairUs) * 0.78f + 3.5f;
         if (((int)nkb & 1) == 0 && nkb >= 2.f) cost14 = rounds(tilesw3, 256) * (nkb * 0.5f) * kPkWideX2PairUs * 0.78f + 4.5f;
     }
+    // form 15: 128 x 512 tiles, eight waves on one ring, one workgroup per CU
+    const long tilesw512 = mt * ((N + 511) / 512);
+    float cost15 = 1e30f;
+    if (M > 128 && group_size == 128 && zero_point_8) cost15 = rounds(tilesw512, 256) * nkb * kPkWide512Us + 5.0f;
     if (g_pk_wide_auto) {
+        if (cost15 < best) best = cost15, form = 15;
         if (cost13 < best) best = cost13, form = 13;
         if (cost14 < best) best = cost14, form = 14;
         if (cost10 < best) best = cost10, form = 10;
@@ -1278,7 +1307,7 @@ float gemm_pk_estimate_us(int M, int N, int K, int *form_out, bool has_scratch, 
         if (form == 11 && (nkb < 2.f || ((int)nkb & 1))) form = 10;
         if (form == 12 && split12 == 1) form = 10;
         if (form == 14 && (nkb < 2.f || ((int)nkb & 1))) form = 13;
-        if (form >= 10) best = form == 10 ? cost10 : (form == 11 ? cost11 : (form == 12 ? cost12 : (form == 13 ? cost13 : cost14)));
+        if (form >= 10) best = form == 10 ? cost10 : (form == 11 ? cost11 : (form == 12 ? cost12 : (form == 13 ? cost13 : (form == 14 ? cost14 : cost15))));
         else
         best = form == 1 ? cost1 : (form == 2 ? cost2 : (form == 3 ? cost3 : (form == 4 ? cost4 : (form == 5 ? cost5 : (form == 6 ? cost6 : (form == 7 ? cost7 : (form == 8 ? cost8 : cost9)))))));
     }
@@ -1312,7 +1341,7 @@ int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_
     const bool cut_tail_only = form == 5;
     const bool rows256 = form >= 6 && form <= 9;
     const bool rows256x2 = form == 8, rows256w = form == 9;
-    const bool wide = form >= 10 && form <= 14, widex2 = form == 11, wide3 = form == 13 || form == 14;
+    const bool wide = form >= 10 && form <= 15, widex2 = form == 11, wide3 = form == 13 || form == 14, wide512 = form == 15;
     if (form == 4 || form == 5 || form == 7 || form == 12) {
         form = 1;
         g.split_s = split;
@@ -1321,7 +1350,7 @@ int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_
     } else {
         g.split_s = 1;
     }
-    const int bn = wide3 ? 192 : ((form == 3 || form == 9 || wide) ? 256 : 128);
+    const int bn = wide512 ? 512 : (wide3 ? 192 : ((form == 3 || form == 9 || wide) ? 256 : 128));
     g.n_blocks = (d.N + bn - 1) / bn;
     g.m_blocks = rows256 ? (d.M + 255) / 256 : (d.M + 127) / 128;
     int best_xm = 1;
@@ -1344,7 +1373,7 @@ int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_
     const int ks = form;
     hipError_t e;
     const int lg = d.group_size == 128 ? 7 : (d.group_size == 64 ? 6 : 5);
-    if (wide && lg == 7 && g_pk_abl && !widex2 && !wide3) {  // timing experiments on the wide form (results meaningless)
+    if (wide && lg == 7 && g_pk_abl && !widex2 && !wide3 && !wide512) {  // timing experiments on the wide form (results meaningless)
         switch (g_pk_abl) {
 #define TCE_ABL(X) case X: e = launch_pkw<7, X>(g, stream); break;
             TCE_ABL(1) TCE_ABL(2) TCE_ABL(4) TCE_ABL(8) TCE_ABL(16) TCE_ABL(32) TCE_ABL(7) TCE_ABL(55) TCE_ABL(128) TCE_ABL(256)
@@ -1370,7 +1399,8 @@ int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_
         }
         return TCE_OK;
     }
-    if (wide3) e = form == 14 ? launch_pkw3<2>(g, stream) : launch_pkw3<1>(g, stream);
+    if (wide512) e = launch_pkw512(g, stream);
+    else if (wide3) e = form == 14 ? launch_pkw3<2>(g, stream) : launch_pkw3<1>(g, stream);
     else if (wide) e = widex2 ? launch_pkwx2<7>(g, stream) : launch_pkw<7>(g, stream);
     else if (rows256w) e = launch_pk256w<7>(g, stream);
     else if (rows256x2) e = launch_pk256x2<7>(g, stream);
