@@ -43,6 +43,7 @@ struct FastAttnArgs {
     const int *pos_dev;   // non-null: the position is read from this device word (a captured launch replayed token after token); pos / keys above
                           // then only bound it (the grid and the chunk length were cut for them)
     float alpha;
+    int probe_no_combine;  // timing experiment (tce_w4a16_set_debug_mode(2931)): the partial states are stored plainly and the launch ends -- `out` is NOT written
 };
 
 __device__ __forceinline__ float row16_sum(float v) {  // sum over the 16 lanes of a DPP row, result in every lane of the row
@@ -300,6 +301,20 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fast_kernel(const FastAtt
         }
         return;
     }
+    if (a.probe_no_combine) {  // (round 5 probe: what the launch costs without its combine -- the upper bound of moving the combine into the next launch's prologue)
+        if (tid < kHD) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float *mine = a.part + ((size_t)(grp * R + r) * chunks + c) * (2 + kHD);
+                mine[2 + tid] = O[r];
+                if (tid == 0) {
+                    mine[0] = M[r];
+                    mine[1] = Lq[r];
+                }
+            }
+        }
+        return;
+    }
     // ---- several chunks per head: partial (M, L, O) to the workspace, the last workgroup to arrive combines ----
     if (tid < kHD) {
 #pragma unroll
@@ -389,6 +404,8 @@ void set_attention_fast_target(int wgs) { g_attn_target_wgs = wgs >= 32 && wgs <
 static thread_local int g_attn_waves = 0;  // 0: by the chunk's length; tuning: tce_w4a16_set_debug_mode(2900 + 4 / 8 / 16)
 void set_attention_fast_waves(int nw) { g_attn_waves = (nw == 4 || nw == 8 || nw == 16) ? nw : 0; }
 
+static thread_local int g_attn_probe_no_combine = 0;
+void set_attention_fast_probe_no_combine(int on) { g_attn_probe_no_combine = on ? 1 : 0; }
 static thread_local int g_attn_fuse = 0;  // tuning: query heads per workgroup for grouped-query attention (0: the rule; 1, 2, 4)
 void set_attention_fast_fuse(int r) { g_attn_fuse = (r == 1 || r == 2 || r == 4) ? r : 0; }
 
@@ -477,6 +494,7 @@ int launch_attention_decode_fast(const void *qkv, void *kc, void *vc, const void
     half_t ah;
     __builtin_memcpy(&ah, &alpha_bits, 2);
     a.alpha = (float)ah;
+    a.probe_no_combine = g_attn_probe_no_combine;
     const dim3 grid((heads / fuse) * a.chunks);
     auto go = [&](auto has_mask) {
         constexpr bool MK = decltype(has_mask)::value;

@@ -157,6 +157,10 @@ int tce_w4a16_set_debug_mode(int mode) {
         tce::set_gemv_ovl_config((mode - 50000) % 100, (mode - 50000) / 100);
         return TCE_OK;
     }
+    if (mode == 2930 || mode == 2931) {  // fast attention step, timing experiment: 2931 = partial states stored plainly, no combine, the output NOT written (2930: off)
+        tce::set_attention_fast_probe_no_combine(mode - 2930);
+        return TCE_OK;
+    }
     if (mode >= 2920 && mode <= 2924) {  // fast attention step, grouped queries: query heads per workgroup (2920: the rule; 2921 / 2922 / 2924)
         tce::set_attention_fast_fuse(mode - 2920);
         return TCE_OK;

@@ -199,6 +199,7 @@ int launch_allgather_rows_f16(Comm *c, int slot, const void *src, void *dst, int
 void set_attention_fast_target(int wgs);
 void set_attention_fast_waves(int nw);
 void set_attention_fast_fuse(int r);
+void set_attention_fast_probe_no_combine(int on);  // timing experiment: partial states stored, no combine, `out` not written
 void describe_attention_decode_fast(int heads, int keys, int *chunk, int *chunks, int *waves, int kv_heads = 0);
 size_t attention_decode_workspace_bytes(int heads, int max_keys, int hd);
 // attention_prefill.hip: m > 1 new rows (rotation + append + causal / masked attention over pos + m keys), two launches
