@@ -47,7 +47,7 @@ extern "C" {
 
 #define TCE_API __attribute__((visibility("default")))
 
-#define TCE_VERSION 110 /* 0.1.10: size-prefixed descriptors (tce_w4a16_desc_v2 / tce_w8a8_desc_v2 + the *_v2 entry points; the plain ones stay), TCE_ERR_RCCL, the tuning setters act on the CALLING THREAD only; 0.1.9: tce_w4a16_check_zero_point_8_async, tce_host_alloc / tce_host_free (the adapter no longer synchronises); 0.1.8: per-family tuning setters (tce_attention_set_tuning, tce_w8a8_set_tuning); 0.1.7: decode on the pre-packed copy (int8 contraction), tce_w4a16_set_gemv_i8; 0.1.6: TCE_PLAN_TUNED; 0.1.5: tce_opt_attention_decode; 0.1.4: tce_attention_prefill_f16 (0.1.3: tce_attention_decode_step_gqa_f16, TCE_PLAN_OVERLAPPED; 0.1.2: tce_w4a16_desc.scratch; 0.1.1: .prepacked, tce_w4a16_prepack*) */
+#define TCE_VERSION 110 /* 0.1.10: tce_attention_decode_step_deferred_f16 + tce_w4a16_forward_deferred_attention (the attention combine in o_proj's prologue); size-prefixed descriptors (tce_w4a16_desc_v2 / tce_w8a8_desc_v2 + the *_v2 entry points; the plain ones stay), TCE_ERR_RCCL, the tuning setters act on the CALLING THREAD only; 0.1.9: tce_w4a16_check_zero_point_8_async, tce_host_alloc / tce_host_free (the adapter no longer synchronises); 0.1.8: per-family tuning setters (tce_attention_set_tuning, tce_w8a8_set_tuning); 0.1.7: decode on the pre-packed copy (int8 contraction), tce_w4a16_set_gemv_i8; 0.1.6: TCE_PLAN_TUNED; 0.1.5: tce_opt_attention_decode; 0.1.4: tce_attention_prefill_f16 (0.1.3: tce_attention_decode_step_gqa_f16, TCE_PLAN_OVERLAPPED; 0.1.2: tce_w4a16_desc.scratch; 0.1.1: .prepacked, tce_w4a16_prepack*) */
 
 /* error codes (return values) */
 #define TCE_OK 0
@@ -211,6 +211,28 @@ TCE_API int tce_attention_decode_describe_gqa(int heads, int kv_heads, int keys,
 TCE_API int tce_attention_decode_step_pos_f16(const void *qkv, void *k_cache, void *v_cache, const void *cos_table, const void *sin_table, const void *mask,
                                               void *out, void *workspace, int heads, int kv_heads, int head_dim, int max_keys, const int32_t *pos_device,
                                               int pos_bound, unsigned short alpha_half_bits, void *stream);
+
+/* Round 5: the attention step WITHOUT its cross-workgroup combine, and the linear that consumes it (o_proj) doing the combine in its prologue.
+ * A decode step over more than ~320 keys cuts every head's keys into 4 or 8 chunks; each chunk's workgroup ends with a partial online-softmax state (M, L, O[128]) and
+ * the LAST one to arrive combines them -- acknowledged write-through stores, a counter, coherent re-reads: 2.3 - 3.2 us of a 7 - 10 us launch.
+ * tce_attention_decode_step_deferred_f16 is tce_attention_decode_step_pos_f16 that stops at plain stores of the partial states and describes them in *info;
+ * tce_w4a16_forward_deferred_attention is tce_w4a16_forward for the linear that reads the step's output row (d->A = the step's `out`; M = 1, d->prepacked, groups of
+ * 128, K = heads * 128 a multiple of 1024, no RMSNorm prologue; TCE_W4_ADD_TO_C allowed): every workgroup forms the row from the partial states with the operations, and in
+ * the order, of the step's own combine and rounds it to binary16 -- the SAME row, bit for bit -- while its weights are in flight.  The kernel boundary between the two launches
+ * is the only ordering needed.  info->slots == 1 (a short context, or a cut beyond 8 slots): nothing was deferred, `out` is final, and the second call is the plain
+ * tce_w4a16_forward.  With the position on the device the number of LIVE slots is recomputed by the consumer from the same word (when one is live the step wrote `out`
+ * itself).  Both calls must see the same pos_device / pos_bound.  `workspace` as for the other entry points (tce_attention_decode_workspace_bytes). */
+typedef struct tce_attention_deferred {
+    int32_t slots;   /* chunk slots per query head: 1 = nothing deferred */
+    int32_t chunk;   /* keys per chunk */
+    int32_t heads;   /* query heads */
+    int32_t stride;  /* floats per partial state: M, L, two unused, O[128] */
+    const float *part; /* [heads][slots][stride], inside `workspace` */
+} tce_attention_deferred;
+TCE_API int tce_attention_decode_step_deferred_f16(const void *qkv, void *k_cache, void *v_cache, const void *cos_table, const void *sin_table, const void *mask,
+                                                   void *out, void *workspace, int heads, int kv_heads, int head_dim, int max_keys, const int32_t *pos_device, int pos_bound,
+                                                   unsigned short alpha_half_bits, tce_attention_deferred *info, void *stream);
+TCE_API int tce_w4a16_forward_deferred_attention(const tce_w4a16_desc *d, const tce_attention_deferred *info, const int32_t *pos_device, int pos_bound, void *stream);
 /* The same block for m > 1 NEW rows -- a prompt, or a chunk of one on top of pos cached keys (Int4llamaAttention.cu:116-229 with sqlen > 1) -- as two
  * launches (csrc/attention_prefill.hip): rotation of q and the new keys with the reference's binary16 arithmetic + the KV append (rows pos .. pos + m - 1;
  * bit-identical to what m decode steps append), then one pass over the keys per (query head, 64 query rows): scores and the weighted sum of V on the

@@ -84,15 +84,25 @@ class DecodeAttention:
         self.cos, self.sin = cos, sin
         self.alpha_bits = int(np.array([1.0 / np.sqrt(head_dim)], np.float16).view(np.uint16)[0])
 
-    def step(self, qkv: torch.Tensor, pos: int, out: torch.Tensor | None = None, mask: torch.Tensor | None = None, pos_device: torch.Tensor | None = None) -> torch.Tensor:
+    def step(self, qkv: torch.Tensor, pos: int, out: torch.Tensor | None = None, mask: torch.Tensor | None = None, pos_device: torch.Tensor | None = None,
+             defer: bool = False) -> torch.Tensor:
         """pos_device (int32 device tensor of one element): the position is read on the device and `pos` only bounds it
-        (tce_attention_decode_step_pos_f16): the launch can be captured once and replayed for growing contexts."""
+        (tce_attention_decode_step_pos_f16): the launch can be captured once and replayed for growing contexts.
+        defer = True (tce_attention_decode_step_deferred_f16): with several chunks per head the launch stops at its partial states -- `out` is then NOT the
+        attention output until a linear issued through tce_w4a16_forward_deferred_attention with `self.deferred` has consumed it (DecoderBlock.step does)."""
         assert qkv.dtype == torch.float16 and qkv.is_contiguous() and qkv.numel() == (self.heads + 2 * self.kv_heads) * self.hd and qkv.is_cuda
         if out is None:
             out = torch.empty((self.heads, self.hd), dtype=torch.float16, device=qkv.device)
         p = lambda t: C.c_void_p(t.data_ptr() if t is not None else 0)
         if pos_device is not None:
             assert pos_device.dtype == torch.int32 and pos_device.is_cuda and pos_device.numel() == 1
+        if defer:  # round 5: the launch ends at its partial states; the linear that reads `out` combines them in its prologue (step_deferred's docstring)
+            info = capi.AttnDeferred()
+            capi.check(capi.lib().tce_attention_decode_step_deferred_f16(p(qkv), p(self.k_cache), p(self.v_cache), p(self.cos), p(self.sin), p(mask), p(out), p(self.workspace),
+                                                                         self.heads, self.kv_heads, self.hd, self.max_keys, p(pos_device), int(pos), self.alpha_bits, C.byref(info),
+                                                                         C.c_void_p(_stream())))
+            self.deferred = info
+            return out
         capi.check(capi.lib().tce_attention_decode_step_pos_f16(p(qkv), p(self.k_cache), p(self.v_cache), p(self.cos), p(self.sin), p(mask), p(out), p(self.workspace),
                                                                 self.heads, self.kv_heads, self.hd, self.max_keys, p(pos_device), int(pos), self.alpha_bits, C.c_void_p(_stream())))
         return out

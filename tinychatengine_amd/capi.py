@@ -33,7 +33,7 @@ TCE_OUT_INT8, TCE_OUT_FP32 = 0, 1
 EXPORTS = [
     "tce_w4a16_forward", "tce_w4a16_residual_rmsnorm_workspace_bytes", "tce_w4a16_forward_residual_rmsnorm", "tce_w4a16_prepack_bytes", "tce_w4a16_prepack", "tce_w4a16_gemm_scratch_bytes", "tce_w4a16_describe_dispatch", "tce_reset_last_error", "tce_bmm_f16t", "tce_rope_half", "tce_softmax_half", "tce_attention_decode_f16", "tce_attention_decode_workspace_bytes", "tce_attention_decode_describe", "tce_attention_decode_step_f16", "tce_attention_decode_step_gqa_f16", "tce_attention_decode_describe_gqa", "tce_attention_decode_step_pos_f16", "tce_attention_prefill_f16", "tce_attention_prefill_workspace_bytes", "tce_opt_attention_decode", "tce_prefetch", "tce_add_half", "tce_silu_mul_half", "tce_rmsnorm_half", "tce_w4a16_forward_group_rmsnorm", "tce_w4a16_forward_group", "tce_w4a16_check_zero_point_8", "tce_w4a16_awq_fp16acc", "tce_w4a16_awq_workspace_bytes",
     "tce_w4a16_gemm_awq", "tce_w4a16_shard", "tce_comm_create", "tce_comm_export", "tce_comm_connect", "tce_comm_connect_local", "tce_allgather_f16", "tce_comm_rccl_unique_id", "tce_comm_rccl_init", "tce_allgather_rows_workspace_bytes", "tce_allgather_rows_f16", "tce_comm_status", "tce_comm_set_timeout_ms", "tce_comm_reset", "tce_comm_device", "tce_comm_destroy", "tce_w8a8_matmul", "tce_opt_softmax_q", "tce_opt_kv_append", "tce_layernorm_q", "tce_layernorm_q_w8a8_group", "tce_plan_create", "tce_plan_create_ex", "tce_plan_is_chained", "tce_plan_geometry", "tce_plan_status", "tce_plan_launch_geometry", "tce_plan_launch", "tce_plan_n_launches",
-    "tce_w4a16_forward_v2", "tce_w8a8_matmul_v2", "tce_plan_destroy", "tce_version", "tce_last_error", "tce_build_info", "tce_w4a16_set_gemv_config", "tce_w4a16_set_gemv_i8",
+    "tce_w4a16_forward_v2", "tce_w8a8_matmul_v2", "tce_attention_decode_step_deferred_f16", "tce_w4a16_forward_deferred_attention", "tce_plan_destroy", "tce_version", "tce_last_error", "tce_build_info", "tce_w4a16_set_gemv_config", "tce_w4a16_set_gemv_i8",
     "tce_w4a16_set_gemm_config", "tce_w4a16_algorithmic_bytes", "tce_w4a16_gemv_variant", "tce_w4a16_gemm_variant",
     "tce_w4a16_set_debug_mode", "tce_attention_set_tuning", "tce_w8a8_set_tuning", "tce_w4a16_set_debug_buffer", "tce_w4a16_check_zero_point_8_async", "tce_host_alloc", "tce_host_free", "tce_malloc", "tce_free", "tce_memcpy", "tce_synchronize", "tce_device_count",
 ]
@@ -61,6 +61,11 @@ class W8A8Desc(C.Structure):
         ("bias_kind", C.c_int32), ("out_kind", C.c_int32), ("b_per_row", C.c_int32), ("accumulate", C.c_int32),
         ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32), ("reserved2", C.c_int32),
     ]
+
+
+class AttnDeferred(C.Structure):
+    """struct tce_attention_deferred: what a deferred attention step leaves for the linear that consumes it"""
+    _fields_ = [("slots", C.c_int32), ("chunk", C.c_int32), ("heads", C.c_int32), ("stride", C.c_int32), ("part", C.c_void_p)]
 
 
 class W4A16DescV2(C.Structure):
@@ -137,6 +142,8 @@ def lib() -> C.CDLL:
         L.tce_attention_decode_step_f16.argtypes = [C.c_void_p] * 8 + [C.c_int] * 4 + [C.c_ushort, C.c_void_p]
         L.tce_attention_decode_step_gqa_f16.argtypes = [C.c_void_p] * 8 + [C.c_int] * 5 + [C.c_ushort, C.c_void_p]
         L.tce_attention_decode_step_pos_f16.argtypes = [C.c_void_p] * 8 + [C.c_int] * 4 + [C.c_void_p, C.c_int, C.c_ushort, C.c_void_p]
+        L.tce_attention_decode_step_deferred_f16.argtypes = [C.c_void_p] * 8 + [C.c_int] * 4 + [C.c_void_p, C.c_int, C.c_ushort, C.POINTER(AttnDeferred), C.c_void_p]
+        L.tce_w4a16_forward_deferred_attention.argtypes = [C.POINTER(W4A16Desc), C.POINTER(AttnDeferred), C.c_void_p, C.c_int, C.c_void_p]
         L.tce_opt_attention_decode.argtypes = [C.c_void_p] * 7 + [C.c_int] * 6 + [C.c_float, C.c_float, C.c_void_p]
         L.tce_attention_prefill_workspace_bytes.restype = C.c_size_t
         L.tce_attention_prefill_workspace_bytes.argtypes = [C.c_int] * 3

@@ -43,6 +43,9 @@ struct FastAttnArgs {
     const int *pos_dev;   // non-null: the position is read from this device word (a captured launch replayed token after token); pos / keys above
                           // then only bound it (the grid and the chunk length were cut for them)
     float alpha;
+    int defer;             // round 5: with several chunk slots the launch ENDS at its partial states -- plain stores of (M, L, -, -, O[hd]) per (query head, chunk slot),
+                           // stride kDeferStride floats -- and the consumer (the o_proj launch: w4a16_gemv_i8.hip's COMB prologue) combines them while it stages its
+                           // activations.  No acknowledged stores, no counter, no last workgroup: the kernel boundary orders the two launches
     int probe_no_combine;  // timing experiment (tce_w4a16_set_debug_mode(2931)): the partial states are stored plainly and the launch ends -- `out` is NOT written
 };
 
@@ -85,6 +88,7 @@ __device__ __forceinline__ half8_t rope_apply(const half8_t v, const half8_t p, 
 
 constexpr int kHD = 128;
 constexpr float kNegBig = -1.0e30f;
+constexpr int kDeferStride = 4 + kHD;  // floats per deferred partial state: M, L, two unused, O[128] (16-byte aligned rows of O)
 
 // MASK: the caller gave a mask row (a compile-time form: a branch inside the fetch block makes hipcc drain the load queue at the loop head)
 // NW: waves per workgroup (4; 8 and 16 exist for the sweep that ruled them out, see pick_chunk).
@@ -301,6 +305,20 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fast_kernel(const FastAtt
         }
         return;
     }
+    if (a.defer) {  // the combine happens in the next launch's prologue (same arithmetic, same order: tce_w4a16_forward_deferred_attention)
+        if (tid < kHD) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float *mine = a.part + ((size_t)(grp * R + r) * a.chunks + c) * kDeferStride;
+                mine[4 + tid] = O[r];
+                if (tid == 0) {
+                    mine[0] = M[r];
+                    mine[1] = Lq[r];
+                }
+            }
+        }
+        return;
+    }
     if (a.probe_no_combine) {  // (round 5 probe: what the launch costs without its combine -- the upper bound of moving the combine into the next launch's prologue)
         if (tid < kHD) {
 #pragma unroll
@@ -458,12 +476,12 @@ size_t attention_decode_workspace_bytes(int heads, int max_keys, int hd) {
     const int chunk = 64;  // the smallest chunk bounds the number of partials
     const size_t chunks = (size_t)(max_keys + chunk - 1) / chunk;
     const size_t cnt_bytes = ((size_t)heads * 4 + 255) & ~(size_t)255;
-    return cnt_bytes + (size_t)heads * chunks * (2 + kHD) * 4;
+    return cnt_bytes + (size_t)heads * chunks * kDeferStride * 4;  // (the deferred layout's stride; the combined form's 2 + hd fits inside)
 }
 
 int launch_attention_decode_fast(const void *qkv, void *kc, void *vc, const void *cosv, const void *sinv, const void *mask, void *out, void *workspace,
                                  int heads, int kv_heads, int hd, int max_keys, int pos, unsigned short alpha_bits, hipStream_t stream, hipError_t *hip_err,
-                                 const int *pos_dev) {
+                                 const int *pos_dev, AttnDeferred *deferred) {
     if (hd != kHD || kv_heads <= 0 || heads % kv_heads != 0) return TCE_ERR_UNSUPPORTED_SHAPE;
     const int rep = heads / kv_heads;
 
@@ -495,6 +513,15 @@ int launch_attention_decode_fast(const void *qkv, void *kc, void *vc, const void
     __builtin_memcpy(&ah, &alpha_bits, 2);
     a.alpha = (float)ah;
     a.probe_no_combine = g_attn_probe_no_combine;
+    if (deferred) {
+        // deferred combine: 2 .. kDeferMaxSlots chunk slots (one slot: the launch writes `out` itself, as it does whenever only one chunk of the bound is live)
+        a.defer = a.chunks >= 2 && a.chunks <= kAttnDeferMaxSlots ? 1 : 0;
+        deferred->slots = a.defer ? a.chunks : 1;
+        deferred->chunk = a.chunk;
+        deferred->heads = heads;
+        deferred->stride = kDeferStride;
+        deferred->part = a.part;
+    }
     const dim3 grid((heads / fuse) * a.chunks);
     auto go = [&](auto has_mask) {
         constexpr bool MK = decltype(has_mask)::value;

@@ -987,6 +987,44 @@ int tce_attention_decode_step_pos_f16(const void *qkv, void *kc, void *vc, const
     return rc == TCE_ERR_HIP ? hip_fail(he, "attention decode step launch") : rc;
 }
 
+int tce_attention_decode_step_deferred_f16(const void *qkv, void *kc, void *vc, const void *cosv, const void *sinv, const void *mask, void *out, void *workspace, int heads,
+                                           int kv_heads, int hd, int max_keys, const int32_t *pos_device, int pos, unsigned short alpha_bits, tce_attention_deferred *info, void *stream) {
+    if (!qkv || !kc || !vc || !out || !workspace || !info) return fail(TCE_ERR_BAD_ARG, "tce_attention_decode_step_deferred_f16: null pointer");
+    if ((cosv == nullptr) != (sinv == nullptr)) return fail(TCE_ERR_BAD_ARG, "tce_attention_decode_step_deferred_f16: cos and sin tables come together");
+    if (heads <= 0 || max_keys <= 0 || pos < 0 || pos >= max_keys) return fail(TCE_ERR_BAD_ARG, "tce_attention_decode_step_deferred_f16: need heads > 0 and 0 <= pos < max_keys");
+    if (kv_heads <= 0 || heads % kv_heads != 0) return fail(TCE_ERR_BAD_ARG, "tce_attention_decode_step_deferred_f16: %d query heads do not divide over %d key / value heads", heads, kv_heads);
+    if (hd != 128) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_attention_decode_step_deferred_f16: head_dim %d (128 only: Llama's)", hd);
+    for (const void *p : {qkv, (const void *)kc, (const void *)vc, cosv, sinv})
+        if (reinterpret_cast<uintptr_t>(p) & 15) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_attention_decode_step_deferred_f16: 16-byte aligned pointers");
+    static_assert(sizeof(tce_attention_deferred) == sizeof(tce::AttnDeferred), "the C struct and the kernels' view of it are one layout");
+    hipError_t he = hipSuccess;
+    tce::AttnDeferred ad{};
+    const int rc = tce::launch_attention_decode_fast(qkv, kc, vc, cosv, sinv, mask, out, workspace, heads, kv_heads, hd, max_keys, pos, alpha_bits, static_cast<hipStream_t>(stream), &he, pos_device, &ad);
+    if (rc == TCE_ERR_HIP) return hip_fail(he, "attention decode step (deferred combine) launch");
+    if (rc != TCE_OK) return rc;
+    info->slots = ad.slots;
+    info->chunk = ad.chunk;
+    info->heads = ad.heads;
+    info->stride = ad.stride;
+    info->part = ad.part;
+    return TCE_OK;
+}
+
+int tce_w4a16_forward_deferred_attention(const tce_w4a16_desc *d, const tce_attention_deferred *info, const int32_t *pos_device, int pos, void *stream) {
+    if (!info) return fail(TCE_ERR_BAD_ARG, "tce_w4a16_forward_deferred_attention: null info");
+    if (info->slots <= 1) return tce_w4a16_forward(d, stream);  // nothing was deferred: the attention step's output row is final
+    const int rc0 = check_w4a16(d);
+    if (rc0 != TCE_OK) return rc0;
+    if (d->M != 1 || !d->prepacked || d->group_size != 128 || d->rmsnorm_gamma || (d->flags & (TCE_W4_SILU_MUL_PAIRS | TCE_W4_FORCE_GEMM)) || d->K != info->heads * 128 || d->K % 1024 != 0 || d->K > 4096 ||
+        info->slots > tce::kAttnDeferMaxSlots || info->stride != 132 || !info->part || pos < 0 || !tce::gemv_i8_supports(d, 1))
+        return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_w4a16_forward_deferred_attention: one decode row on a packed copy, groups of 128, K = heads * 128 a multiple of 1024 and at most 4096, 2..%d slots of %d floats", tce::kAttnDeferMaxSlots, 132);
+    hipError_t he = hipSuccess;
+    tce::AttnDeferred ad{info->slots, info->chunk, info->heads, info->stride, info->part};
+    const int rc = tce::launch_w4a16_gemv_i8(d, 1, static_cast<hipStream_t>(stream), &he, nullptr, 0.f, nullptr, &ad, pos_device, pos);
+    if (rc == TCE_ERR_HIP) return hip_fail(he, "deferred-attention linear launch");
+    return rc == TCE_OK ? TCE_OK : fail(rc, "tce_w4a16_forward_deferred_attention: unsupported shape");
+}
+
 int tce_opt_attention_decode(const void *q, const void *k_new, const void *v_new, void *k_cache, void *vt_cache, const float *mask, void *out, int heads, int hd, int m,
                              int pos, int max_keys, int ld, float alpha_qk, float alpha_pv, void *stream) {
     if (!q || !k_new || !v_new || !k_cache || !vt_cache || !mask || !out) return fail(TCE_ERR_BAD_ARG, "tce_opt_attention_decode: null pointer");

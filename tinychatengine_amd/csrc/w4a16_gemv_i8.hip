@@ -51,6 +51,12 @@ struct I8Args {
     float out_eps;
     half_t *xn_out;
     float *ws;
+    // COMB (tce_w4a16_forward_deferred_attention, round 5): the activation row is the output of a deferred attention step -- per query head `comb_slots` partial
+    // states (M, L, -, -, O[128]; `comb_stride` floats each) of which the first ceil((position + 1) / comb_chunk) are live; the prologue combines them exactly as the
+    // attention kernel's own last workgroup would (attention_fast.hip) and rounds to binary16 -- the same row, bit for bit -- while the weights are in flight
+    const float *comb_part;
+    const int *comb_pos_dev;
+    int comb_pos, comb_slots, comb_chunk, comb_stride, comb_heads;
     I8Seg seg[TCE_MAX_GROUP];
 };
 
@@ -79,8 +85,9 @@ __device__ __forceinline__ float dpp_add_f32(float v) {
 // gate/up launches; the next launch is then the plain kernel).  Bits: C as TCE_W4_ADD_TO_C, xn as tce_rmsnorm_half on the updated row.
 // MEASURED (round 4): correct and SLOWER than the prologue it replaces -- the write-through stores must be acknowledged before a workgroup may count itself in and the last
 // workgroup's pass is serial: +3.8 us per producer launch, a whole token 1.65 against 1.41 ms.  Kept as an entry point (tests pin its bits); DecoderBlock.step does not use it.
-template <int MB, int GPU, int ROWS, int UW, bool Z8, int MAXT, bool NORM = false, bool RNORM = false>
+template <int MB, int GPU, int ROWS, int UW, bool Z8, int MAXT, bool NORM = false, bool RNORM = false, int COMB = 0>
 __global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const I8Args args) {
+    static_assert(!COMB || (MB == 1 && ROWS == 1 && GPU == 1 && UW == 8 && !NORM && !RNORM), "the deferred-attention prologue: one decode row, groups of 128, K a multiple of 1024");
     static_assert(MB * GPU <= 4, "sixteen output columns: rows x groups-per-unit x 4 planes");
     static_assert(!RNORM || (MB == 1 && ROWS == 1 && !NORM), "the residual + next-norm epilogue: one decode row, one tile per workgroup");
     static_assert(!NORM || MB == 1, "the fused RMSNorm prologue is a decode (M = 1) feature");
@@ -121,8 +128,39 @@ __global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const I8Args args) 
 
     // ---- 1. requests, in the order they are needed: activations, scales (zero points), then every weight byte of the wave ----
     uint4_t xv[MB][XC];
+    // COMB: how many chunk slots of the deferred attention step are live (wave-uniform; one: that launch wrote the row itself and it is read like any other)
+    int nact = 1;
+    if constexpr (COMB) {
+        const int pos = args.comb_pos_dev ? __builtin_amdgcn_readfirstlane(*args.comb_pos_dev) : args.comb_pos;
+        nact = (pos + args.comb_chunk) / args.comb_chunk;  // ceil((pos + 1) / chunk)
+        nact = nact < args.comb_slots ? nact : args.comb_slots;
+    }
+    constexpr int kSlots = COMB ? COMB : 1;              // COMB = the slots the prologue is compiled for: 4 or 8 (kAttnDeferMaxSlots); the launch's slots <= COMB
+    uint2_t cml[COMB ? XC : 1][kSlots];                  // (M, L) of the lane's head per slot
+    uint4_t co[COMB ? XC : 1][kSlots][2];                // O[d0 .. d0 + 7] per slot
+    if constexpr (COMB) {
+        if (nact > 1) {
+            const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(args.comb_part), 0, args.comb_heads * args.comb_slots * args.comb_stride * 4, 0x00020000);
+#pragma unroll
+            for (int c = 0; c < XC; ++c) {
+                const int kpos = u0 * 128 + (lane + 64 * c) * 8;       // the lane's 8 columns: head kpos / 128, dimensions kpos % 128 ..
+                const int hbase = ((kpos >> 7) * args.comb_slots) * args.comb_stride * 4 + (kpos & 127) * 4;
+#pragma unroll
+                for (int i = 0; i < kSlots; ++i) {
+                    // dead slots re-read the first one (their weights are never formed): plain loads -- every lane's addresses are valid, nothing needs a range check
+                    const int ii = i < nact ? i : 0;
+                    const unsigned char *src = reinterpret_cast<const unsigned char *>(args.comb_part) + hbase + ii * args.comb_stride * 4;
+                    cml[c][i] = *reinterpret_cast<const uint2_t *>(src - (kpos & 127) * 4);
+                    co[c][i][0] = *reinterpret_cast<const uint4_t *>(src + 16);
+                    co[c][i][1] = *reinterpret_cast<const uint4_t *>(src + 32);
+                }
+                (void)rs_p;
+            }
+        }
+    }
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
+        if (COMB && nact > 1) break;
         int mrow = m0 + m;
         mrow = mrow < args.M ? mrow : args.M - 1;
         // a descriptor per row, K halves long: chunks past K (a ragged last wave) read as zeros
@@ -174,6 +212,38 @@ __global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const I8Args args) 
         }
     __builtin_amdgcn_sched_barrier(0);
 
+    if constexpr (COMB) {
+        if (nact > 1) {
+            // attention_fast.hip's combine, operation for operation: Mx = max M_i; w_i = exp(M_i - Mx); L = sum L_i w_i, O = sum O_i w_i in slot order (products and sums
+            // rounded separately: this file is compiled without contraction); x = half(O / L)
+#pragma unroll
+            for (int c = 0; c < XC; ++c) {
+                // (an element of a vector goes through a scalar before its bits are reinterpreted: __builtin_bit_cast applied to `v[k]` directly read v[0] for every k --
+                //  found by tests/test_gpu_deferred_attention.py: M for L, O[0] for O[1..3])
+                auto f32 = [](unsigned u) { return __builtin_bit_cast(float, u); };
+                float Mx = -1.0e30f;
+#pragma unroll
+                for (int i = 0; i < kSlots; ++i)
+                    if (i < nact) Mx = __builtin_fmaxf(Mx, f32(cml[c][i][0]));
+                float Lx = 0.f, Ox[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) Ox[e] = 0.f;
+#pragma unroll
+                for (int i = 0; i < kSlots; ++i) {
+                    if (i < nact) {  // (wave-uniform)
+                        const float w = __expf(f32(cml[c][i][0]) - Mx);
+                        Lx += f32(cml[c][i][1]) * w;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) Ox[e] += f32(co[c][i][e >> 2][e & 3]) * w;
+                    }
+                }
+                half8_t y;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = (half_t)(Ox[e] / Lx);
+                xv[0][c] = __builtin_bit_cast(uint4_t, y);
+            }
+        }
+    }
     // ---- 2. the wave's activations -> digit planes, image [unit][lo/hi][m][plane][kq][word s] in its own LDS region ----
     unsigned *planes = reinterpret_cast<unsigned *>(smem) + wk * (UW * MB * 128);
     if constexpr (NORM) {
@@ -476,10 +546,10 @@ static int i8_units_per_wave(int U) { return U <= 128 ? 8 : (U <= 256 ? 16 : 0);
 thread_local int g_i8_mode = 0;  // 0 automatic (wherever the shape allows and a packed copy is given), 1 off
 thread_local int g_i8_rows = 0;  // 0 the rule, 1 / 2 forced tiles per wave
 
-template <int MB, int GPU, int ROWS, int UW, bool Z8, int MAXT, bool NORM = false, bool RNORM = false>
+template <int MB, int GPU, int ROWS, int UW, bool Z8, int MAXT, bool NORM = false, bool RNORM = false, int COMB = 0>
 hipError_t launch_i8(const I8Args &a, int blocks, int m_blocks, int wk, hipStream_t stream) {
     const size_t lds = (size_t)wk * UW * MB * 512 + (size_t)wk * ROWS * MB * 16 * sizeof(float) + (NORM ? (size_t)(a.K >> 3) * sizeof(float) + 1024 : 0);  // the row's piece sums (+ the ragged last wave's zero pieces)
-    auto kfn = w4a16_gemv_i8_kernel<MB, GPU, ROWS, UW, Z8, MAXT, NORM, RNORM>;
+    auto kfn = w4a16_gemv_i8_kernel<MB, GPU, ROWS, UW, Z8, MAXT, NORM, RNORM, COMB>;
     if (lds > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -525,7 +595,8 @@ bool gemv_i8_supports(const tce_w4a16_desc *descs, int count, bool with_norm) {
     return true;
 }
 
-int launch_w4a16_gemv_i8(const tce_w4a16_desc *descs, int count, hipStream_t stream, hipError_t *hip_err, const float *gamma, float eps, const I8ResidualNorm *rn) {
+int launch_w4a16_gemv_i8(const tce_w4a16_desc *descs, int count, hipStream_t stream, hipError_t *hip_err, const float *gamma, float eps, const I8ResidualNorm *rn,
+                         const AttnDeferred *comb, const int *comb_pos_dev, int comb_pos) {
     const tce_w4a16_desc &d0 = descs[0];
     if (!gamma && d0.rmsnorm_gamma) {
         gamma = static_cast<const float *>(d0.rmsnorm_gamma);
@@ -593,6 +664,27 @@ int launch_w4a16_gemv_i8(const tce_w4a16_desc *descs, int count, hipStream_t str
         if (uw == 8) e = z8 ? launch_i8<1, 1, 1, 8, true, 1024, false, true>(a, blocks, m_blocks, wk, stream) : launch_i8<1, 1, 1, 8, false, 1024, false, true>(a, blocks, m_blocks, wk, stream);
         else if (z8) e = launch_i8<1, 1, 1, 16, true, 1024, false, true>(a, blocks, m_blocks, wk, stream);
         else return TCE_ERR_UNSUPPORTED_SHAPE;  // K > 16384 with general zero points: the epilogue's registers on top of 16 KiB of weights per wave and the zero-point chain do not fit 128 (the form spilled; no instantiation spills: build.py NO_VGPR_SPILL)
+        if (e != hipSuccess) {
+            if (hip_err) *hip_err = e;
+            return TCE_ERR_HIP;
+        }
+        return TCE_OK;
+    }
+    if (comb && comb->slots > 1) {  // the activation row = a deferred attention step's partial states (one decode row, one linear, groups of 128, K = heads x 128 in whole 1024-k waves)
+        if (count != 1 || gamma || mb != 1 || gpu != 1 || uw != 8 || d0.M != 1 || d0.K != comb->heads * 128 || d0.K % 1024 != 0 || comb->slots > kAttnDeferMaxSlots || comb->stride != 132)
+            return TCE_ERR_UNSUPPORTED_SHAPE;
+        a.comb_part = comb->part;
+        a.comb_pos_dev = comb_pos_dev;
+        a.comb_pos = comb_pos;
+        a.comb_slots = comb->slots;
+        a.comb_chunk = comb->chunk;
+        a.comb_stride = comb->stride;
+        a.comb_heads = comb->heads;
+        // (compiled for at most four waves -- K <= 4096, the 7B / 8B widths --: eight slots of partial states in flight beside the wave's weights need more registers than
+        //  sixteen waves per CU leave)
+        if (wk > 4) return TCE_ERR_UNSUPPORTED_SHAPE;
+        if (comb->slots <= 4) e = z8 ? launch_i8<1, 1, 1, 8, true, 256, false, false, 4>(a, blocks, m_blocks, wk, stream) : launch_i8<1, 1, 1, 8, false, 256, false, false, 4>(a, blocks, m_blocks, wk, stream);
+        else e = z8 ? launch_i8<1, 1, 1, 8, true, 256, false, false, 8>(a, blocks, m_blocks, wk, stream) : launch_i8<1, 1, 1, 8, false, 256, false, false, 8>(a, blocks, m_blocks, wk, stream);
         if (e != hipSuccess) {
             if (hip_err) *hip_err = e;
             return TCE_ERR_HIP;

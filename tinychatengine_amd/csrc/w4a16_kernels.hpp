@@ -112,7 +112,9 @@ struct I8ResidualNorm {  // tce_w4a16_forward_residual_rmsnorm: the RMSNorm that
     void *xn_out;
     void *workspace;  // float [2048] + unsigned counter (zero between launches)
 };
-int launch_w4a16_gemv_i8(const tce_w4a16_desc *descs, int count, hipStream_t stream, hipError_t *hip_err, const float *gamma = nullptr, float eps = 0.f, const I8ResidualNorm *rn = nullptr);
+struct AttnDeferred;
+int launch_w4a16_gemv_i8(const tce_w4a16_desc *descs, int count, hipStream_t stream, hipError_t *hip_err, const float *gamma = nullptr, float eps = 0.f, const I8ResidualNorm *rn = nullptr,
+                         const AttnDeferred *comb = nullptr, const int *comb_pos_dev = nullptr, int comb_pos = 0);
 
 // MFMA GEMM on the q4_6 layout (prefill).  m_tiles x n_tiles 16x16 MFMA tiles per wave, 4 waves along N.
 #define TCE_GEMM_VARIANTS(X) \
@@ -211,9 +213,18 @@ void set_attention_prefill_waves(int w);  // 0 automatic, 4 / 8 forced
 int launch_attention_prefill(const void *qkv, int ld_qkv, void *kc, void *vc, const void *cosv, const void *sinv, const void *mask, int ld_mask, int causal,
                              void *out, int ld_out, void *workspace, int heads, int kv_heads, int max_keys, int pos, int m, float alpha, hipStream_t stream,
                              hipError_t *hip_err);
+// what a deferred attention step leaves for its consumer (tce_attention_deferred of the C ABI, field for field)
+struct AttnDeferred {
+    int slots;   // chunk slots of the launch's grid: 1 = nothing deferred (`out` is final); 2 .. kAttnDeferMaxSlots = partial states per (query head, slot)
+    int chunk;   // keys per chunk: slot i of a head is live when i * chunk < position + 1
+    int heads;   // query heads
+    int stride;  // floats per partial state: M, L, -, -, O[128]
+    const float *part;
+};
+constexpr int kAttnDeferMaxSlots = 8;
 int launch_attention_decode_fast(const void *qkv, void *kc, void *vc, const void *cosv, const void *sinv, const void *mask, void *out, void *workspace,
                                  int heads, int kv_heads, int hd, int max_keys, int pos, unsigned short alpha_bits, hipStream_t stream, hipError_t *hip_err,
-                                 const int *pos_dev = nullptr);
+                                 const int *pos_dev = nullptr, AttnDeferred *deferred = nullptr);
 int launch_rope_half(void *q, void *k, const void *cosv, const void *sinv, int heads, int len, int hd, int start_idx, hipStream_t stream, hipError_t *hip_err);
 int launch_softmax_half(const void *x, void *out, long long rows, int n, hipStream_t stream, hipError_t *hip_err);
 int launch_prefetch(const void *ptr, long long bytes, int workgroups, hipStream_t stream, hipError_t *hip_err);

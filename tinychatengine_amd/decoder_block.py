@@ -18,6 +18,8 @@ Used by tests/test_gpu_block.py (against a float64 evaluation of the same layer 
 from __future__ import annotations
 
 import numpy as np
+import ctypes as C
+
 import torch
 
 from . import capi
@@ -27,12 +29,15 @@ from .linear import Linear_half_int4, _stream
 
 class DecoderBlock:
     def __init__(self, hidden: int, heads: int, ffn: int, max_keys: int, device, cos: torch.Tensor, sin: torch.Tensor, seed: int = 0,
-                 group_size: int = 128, eps: float = 1e-6, kv_heads: int | None = None, prepack: bool = True):
+                 group_size: int = 128, eps: float = 1e-6, kv_heads: int | None = None, prepack: bool = True, defer_combine: bool | None = None):
         """kv_heads < heads: grouped-query attention (Llama-3-8B: 32 / 8, llm/include/model.h:83) -- the fused projection is
         (heads + 2 * kv_heads) * 128 rows wide and the caches hold kv_heads heads."""
         assert hidden % heads == 0 and hidden // heads == 128, "the attention step is built for head_dim 128 (Llama)"
         self.hidden, self.heads, self.ffn, self.eps = hidden, heads, ffn, eps
         self.kv_heads = heads if kv_heads is None else kv_heads
+        # the attention combine in o_proj's prologue (tce_attention_decode_step_deferred_f16 + tce_w4a16_forward_deferred_attention): bit-identical, and MEASURED at
+        # +0.5 .. +0.8 % of the whole token (-0.4 % at 2048 keys; profiles/r5/deferred_attn_token_ab.jsonl) -- under the 1 % the round's stop rule asks for: opt-in
+        self.defer_combine = bool(defer_combine) and prepack and group_size == 128 and hidden % 1024 == 0 and hidden <= 4096
         g = torch.Generator(device=device).manual_seed(seed)
         rnd = lambda n, k: torch.empty(n, k, device=device).normal_(0.0, k ** -0.5, generator=g)
         self.qkv = Linear_half_int4.from_float(rnd((heads + 2 * self.kv_heads) * 128, hidden), group_size)   # rows: q | k | v, head-major (llama_qkv_merger.py:27-48)
@@ -55,8 +60,13 @@ class DecoderBlock:
         bounds it): the five launches can be captured once and replayed token after token."""
         st = _stream()
         capi.check(capi.w4a16_forward(self.qkv.desc(hidden_state, self.qkv_out, gamma=self.gamma1, eps=self.eps), st))
-        self.attention.step(self.qkv_out.view(-1), pos, out=self.attn_out.view(self.heads, 128), pos_device=pos_device)
-        capi.check(capi.w4a16_forward(self.o.desc(self.attn_out, hidden_state, flags=capi.TCE_W4_ADD_TO_C), st))
+        if self.defer_combine:  # round 5: the attention step ends at its per-chunk partial states, o_proj's prologue combines them (same row, bit for bit; one launch boundary instead of a cross-workgroup exchange)
+            self.attention.step(self.qkv_out.view(-1), pos, out=self.attn_out.view(self.heads, 128), pos_device=pos_device, defer=True)
+            capi.check(capi.lib().tce_w4a16_forward_deferred_attention(C.byref(self.o.desc(self.attn_out, hidden_state, flags=capi.TCE_W4_ADD_TO_C)), C.byref(self.attention.deferred),
+                                                                       C.c_void_p(pos_device.data_ptr() if pos_device is not None else 0), int(pos), C.c_void_p(st)))
+        else:
+            self.attention.step(self.qkv_out.view(-1), pos, out=self.attn_out.view(self.heads, 128), pos_device=pos_device)
+            capi.check(capi.w4a16_forward(self.o.desc(self.attn_out, hidden_state, flags=capi.TCE_W4_ADD_TO_C), st))
         capi.check(capi.w4a16_forward(self.gate_up.desc(hidden_state, self.act, flags=capi.TCE_W4_SILU_MUL_PAIRS, gamma=self.gamma2, eps=self.eps), st))
         capi.check(capi.w4a16_forward(self.down.desc(self.act, hidden_state, flags=capi.TCE_W4_ADD_TO_C), st))
 
