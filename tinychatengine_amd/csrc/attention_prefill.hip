@@ -244,12 +244,16 @@ __device__ __forceinline__ void attn_prefill_block(const PrefillArgs &a, const i
                     // check_inf_half (Int4llamaAttention.cu:105-115, applied by the decode step as well, attention_fast.hip): inf / NaN / a score beyond
                     // binary16 weighs nothing -- in EVERY tile, interior and unmasked ones included (a NaN from an overflowed q.k used to poison
                     // the row here and not in the decode step).  !(|s| <= bound) is true for NaN.
-                    bool valid = __builtin_fabsf(s) <= 65504.0f * kLog2e;
+                    // (round 5, ADVICE r4: such a score becomes -65504 and still takes part in the softmax -- what the reference and the decode step do; a row of
+                    //  nothing but such scores then weighs its keys equally in prefill as in decode -- while a key that is CUT, past the context or the causal
+                    //  bound, weighs nothing)
+                    const bool in_range = __builtin_fabsf(s) <= 65504.0f * kLog2e;
+                    bool cut = false;
                     if (MASK || edge) {
                         const int key = key0 + 16 * j + 4 * quad + r;
-                        valid = valid && (!edge || (key < tgz && !(a.causal && key > a.pos + rowc[t])));
+                        cut = edge && !(key < tgz && !(a.causal && key > a.pos + rowc[t]));
                     }
-                    s = valid ? s : kNegBig;  // (a mask of -inf / -65504 stays a finite "nothing")
+                    s = cut ? kNegBig : (in_range ? s : -65504.0f * kLog2e);
                     sacc[t][j][r] = s;
                     best = fmaxf(best, s);
                 }
