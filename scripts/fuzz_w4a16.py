@@ -14,6 +14,8 @@ from conftest import w4a16_close
 
 dev = torch.device("cuda", 0)
 L = capi.lib()
+SCRATCH = torch.zeros(int(L.tce_w4a16_gemm_scratch_bytes()), dtype=torch.uint8, device=dev)
+FORMS = {}
 
 
 def make(rng, M, N, K, G, random_zeros):
@@ -92,21 +94,33 @@ def main():
             flags = (capi.TCE_W4_ADD_TO_C if add else 0) | (0 if rz else capi.TCE_W4_ZERO_POINT_IS_8 * int(rng.integers(0, 2)))
             d = capi.W4A16Desc(M=M, N=N, K=K, group_size=G, A=ta.data_ptr(), qweight=tq.data_ptr(), scales=ts.data_ptr(), zeros=tz.data_ptr(), C=out.data_ptr(), ldc=ldc,
                                flags=flags, prepacked=packed.data_ptr())
-            path = capi.describe_dispatch(d)
-            capi.check(capi.w4a16_forward(d, torch.cuda.current_stream().cuda_stream))
-            torch.cuda.synchronize()
-            got = out[:, :N].float().cpu().numpy()
-            want = (c0[:, :N].cpu().numpy().astype(np.float16) + ref32.astype(np.float16)).astype(np.float32) if add else ref32
-            ok, worst = w4a16_close(got.astype(np.float16), want)
-            if not ok and add:
-                err = np.abs(got - want)
-                tol = 1e-3 * np.maximum(np.abs(ref32), np.sqrt(np.mean(ref32.astype(np.float64) ** 2)) / 64) + np.abs(want) * 2.0 ** -10
-                ok = bool((err <= tol).all())
-            tail_ok = ldc == N or torch.equal(out[:, N:], c0[:, N:])
-            packed_runs = packed_runs + 1 if "packed_runs" in dir() else 1
-            if not (ok and tail_ok) or np.isnan(got).any():
-                bad += 1
-                print(f"FAIL case {case} (packed copy, {path}): M={M} N={N} K={K} G={G} rz={rz} add={add} ldc={ldc} flags={flags} worst={worst:.3f} tail_ok={tail_ok}", flush=True)
+            # round 5: beside the dispatcher's choice, two forced forms of the GEMM per case -- the wide ones (128 rows x 64 / 48 columns per wave; they run where the
+            # zero-point-8 promise is given, groups of 128) with and without the scratch area that lets the k range be cut across workgroups
+            modes = [60]
+            if M >= 129:
+                modes += [int(v) for v in rng.choice([61, 62, 63, 64, 66, 68, 2669, 2670, 2671, 2672, 2683, 2673, 2674, 2675], size=2, replace=False)]
+            for pmode in modes:
+                capi.check(L.tce_w4a16_set_debug_mode(pmode))
+                out.copy_(c0)
+                d.scratch = SCRATCH.data_ptr() if (pmode != 60 or rng.integers(0, 2)) and M > 128 else None
+                path = capi.describe_dispatch(d)
+                capi.check(capi.w4a16_forward(d, torch.cuda.current_stream().cuda_stream))
+                torch.cuda.synchronize()
+                got = out[:, :N].float().cpu().numpy()
+                want = (c0[:, :N].cpu().numpy().astype(np.float16) + ref32.astype(np.float16)).astype(np.float32) if add else ref32
+                ok, worst = w4a16_close(got.astype(np.float16), want)
+                if not ok and add:
+                    err = np.abs(got - want)
+                    tol = 1e-3 * np.maximum(np.abs(ref32), np.sqrt(np.mean(ref32.astype(np.float64) ** 2)) / 64) + np.abs(want) * 2.0 ** -10
+                    ok = bool((err <= tol).all())
+                tail_ok = ldc == N or torch.equal(out[:, N:], c0[:, N:])
+                FORMS[" ".join(path.split()[:4])] = FORMS.get(" ".join(path.split()[:4]), 0) + 1
+                if not (ok and tail_ok) or np.isnan(got).any():
+                    bad += 1
+                    print(f"FAIL case {case} (packed copy, mode {pmode}, {path}): M={M} N={N} K={K} G={G} rz={rz} add={add} ldc={ldc} flags={flags} worst={worst:.3f} tail_ok={tail_ok}", flush=True)
+            capi.check(L.tce_w4a16_set_debug_mode(60))
+            assert int(SCRATCH[:4096].to(torch.int32).sum().item()) == 0, "the scratch area's counters must be back at zero"
+    print("packed-copy launches by form:", dict(sorted(FORMS.items(), key=lambda kv: -kv[1])), flush=True)
     print(f"fuzz: {cases} cases, {bad} failures, {time.time() - t0:.0f} s (seed {seed})", flush=True)
     sys.exit(1 if bad else 0)
 
