@@ -279,8 +279,11 @@ def other_configs_leg(torch, dev):
         o = torch.empty((M, N), dtype=torch.int8, device=dev)
         d = capi.W8A8Desc(M=M, N=N, K=K, batch=1, A=a.data_ptr(), B=b.data_ptr(), bias=bias.data_ptr(), C=o.data_ptr(), alpha=0.0005, beta=0.02,
                           q_min=-128, q_max=127, bias_kind=capi.TCE_BIAS_INT8, out_kind=capi.TCE_OUT_INT8)
-        us = time_graph(lambda i, sp: capi.check(L.tce_w8a8_matmul(C.byref(d), sp)), 64)
-        out["w8a8_opt125m"].append({"M": M, "N": N, "K": K, "us": round(us, 2), "TOPs": round(2.0 * M * N * K / us / 1e6, 1)})
+        # (round 5: through the size-prefixed descriptor with a scratch area -- few tiles with a long k chain, 512 / 108 x 768 x 3072, have their k-steps cut across workgroups)
+        v2 = capi.W8A8DescV2(struct_size=C.sizeof(capi.W8A8DescV2), reserved0=0, desc=d, scratch=capi.w8a8_scratch(dev).data_ptr())
+        us = time_graph(lambda i, sp: capi.check(L.tce_w8a8_matmul_v2(C.byref(v2), sp)), 64)
+        us_plain = time_graph(lambda i, sp: capi.check(L.tce_w8a8_matmul(C.byref(d), sp)), 64)
+        out["w8a8_opt125m"].append({"M": M, "N": N, "K": K, "us": round(us, 2), "TOPs": round(2.0 * M * N * K / us / 1e6, 1), "us_without_scratch": round(us_plain, 2)})
     # ... and its two attention BMMs as one batched launch each: b = 12, (512, 512, 64) fp32 out and (512, 64, 512) int8 out (test_ops.cc:380-410, 444-473)
     for (b_, M, N, K, fp32) in ((12, 512, 512, 64, True), (12, 512, 64, 512, False)):
         a = torch.randint(-128, 128, (b_, M, K), dtype=torch.int8, device=dev)

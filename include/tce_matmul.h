@@ -348,8 +348,13 @@ typedef struct tce_w8a8_desc_v2 {
     uint32_t struct_size;
     uint32_t reserved0;
     tce_w8a8_desc desc;
+    void *scratch;  /* NULL = none.  tce_w8a8_scratch_bytes() bytes of device memory, 256-byte aligned, its first 4096 bytes ZEROED once by the caller (every call leaves
+                       them zero): lets a launch with few 64 x 64 tiles and a long k chain (OPT's fc2 at prefill: 512 x 768 x 3072 is 96 tiles of 48 steps on 256 CUs) cut
+                       the chain into runs on several workgroups; the int32 partial tiles are added exactly, in any order -- the result stays bit-exact.  One area per
+                       stream that runs such calls concurrently */
 } tce_w8a8_desc_v2;
 TCE_API int tce_w8a8_matmul_v2(const tce_w8a8_desc_v2 *d, void *stream);
+TCE_API size_t tce_w8a8_scratch_bytes(void);
 
 /* The element-wise steps between the two int8 BMMs of the reference's OPT attention (llm/src/nn_modules/Int8OPTAttention.cc:254-268), as ONE launch:
  *   batch_Add (llm/src/ops/batch_add.cc:3-24): s[h][j][k] + mask[j][k];  softmax over k (llm/src/ops/softmax.cc:5-40: the running maximum starts

@@ -53,7 +53,7 @@ def test_library_contains_gfx950_code_objects_only(built):
 
 def test_descriptor_sizes(built):
     assert C.sizeof(built.W4A16Desc) == 112 and C.sizeof(built.W8A8Desc) == 120
-    assert C.sizeof(built.W4A16DescV2) == 120 and C.sizeof(built.W8A8DescV2) == 128
+    assert C.sizeof(built.W4A16DescV2) == 120 and C.sizeof(built.W8A8DescV2) == 136
 
 
 def test_size_prefixed_descriptors_validate_their_size(built):

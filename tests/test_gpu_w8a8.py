@@ -650,3 +650,47 @@ def test_opt_attention_decode_equals_the_four_launches(dev, oracle, heads, hd, m
         assert (rmax < 1).all()   # every row (but (0, 0)) took the dependent path
     assert L.tce_opt_attention_decode(vp(tq), vp(tk), vp(tv), vp(kc_b), vp(vt_b), vp(tm), vp(out_b), heads, hd, 9, 0, max_keys, 0, a_qk, a_pv, None) == capi.TCE_ERR_UNSUPPORTED_SHAPE
     assert L.tce_opt_attention_decode(vp(tq), vp(tk), vp(tv), vp(kc_b), vp(vt_b), vp(tm), vp(out_b), heads, 96, 1, 0, max_keys, 0, a_qk, a_pv, None) == capi.TCE_ERR_UNSUPPORTED_SHAPE  # head_dim
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 768, 3072), (108, 768, 3072), (300, 520, 2048 + 48), (64, 64, 1536), (1000, 200, 4096)])
+def test_k_steps_cut_across_workgroups_stay_bit_exact(M, N, K):
+    """Round 5 (tce_w8a8_desc_v2.scratch): few 64 x 64 tiles with a long k chain have their k-steps cut into runs on several workgroups; the int32 partial tiles are exact,
+    so every cut gives the bits of the uncut launch (itself held to the oracle above) -- int8 output with bias and fp32 output accumulating into C, the rule's cut and
+    every forced one, ragged M / N / K, repeated calls on one scratch area (its counters are back at zero after every call)."""
+    from tinychatengine_amd import capi
+    dev = torch.device("cuda:0")
+    L = capi.lib()
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    ri = lambda *s: torch.randint(-128, 128, s, device=dev, generator=g, dtype=torch.int32).to(torch.int8)
+    A, W, b8 = ri(M, K), ri(N, K), ri(N)
+    bf = torch.empty(N, device=dev).normal_(0, 1, generator=g)
+    c0 = torch.empty(M, N, device=dev).normal_(0, 1, generator=g)
+    scratch = capi.w8a8_scratch(dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(kind, scratch_ptr, v2):
+        if kind == "int8":
+            out = torch.zeros(M, N, dtype=torch.int8, device=dev)
+            d = capi.W8A8Desc(M=M, N=N, K=K, batch=1, A=A.data_ptr(), B=W.data_ptr(), bias=b8.data_ptr(), C=out.data_ptr(), alpha=0.0005035400390625, beta=0.02130126953125,
+                              q_min=-128, q_max=127, bias_kind=capi.TCE_BIAS_INT8, out_kind=capi.TCE_OUT_INT8)
+        else:
+            out = c0.clone()
+            d = capi.W8A8Desc(M=M, N=N, K=K, batch=1, A=A.data_ptr(), B=W.data_ptr(), bias=bf.data_ptr(), C=out.data_ptr(), alpha=0.0007, q_min=-128, q_max=127,
+                              bias_kind=capi.TCE_BIAS_FP32, out_kind=capi.TCE_OUT_FP32, accumulate=1)
+        capi.check(capi.w8a8_matmul_v2(d, st, scratch_ptr) if v2 else capi.w8a8_matmul(d, st))
+        torch.cuda.synchronize()
+        return out
+
+    try:
+        for kind in ("int8", "fp32"):
+            want = run(kind, None, False)
+            assert bool(want.float().abs().sum() > 0)
+            assert torch.equal(run(kind, None, True), want)  # the size-prefixed descriptor without a scratch area: the same launch
+            for mode in (180, 182, 183, 184, 186, 188, 180):
+                capi.check(L.tce_w4a16_set_debug_mode(mode))
+                for rep in range(2):
+                    got = run(kind, scratch.data_ptr(), True)
+                    assert torch.equal(got, want), f"{kind} {M}x{N}x{K} cut mode {mode} call {rep}"
+                assert int(scratch[:4096].to(torch.int32).sum().item()) == 0
+    finally:
+        L.tce_w4a16_set_debug_mode(180)

@@ -33,7 +33,7 @@ TCE_OUT_INT8, TCE_OUT_FP32 = 0, 1
 EXPORTS = [
     "tce_w4a16_forward", "tce_w4a16_residual_rmsnorm_workspace_bytes", "tce_w4a16_forward_residual_rmsnorm", "tce_w4a16_prepack_bytes", "tce_w4a16_prepack", "tce_w4a16_gemm_scratch_bytes", "tce_w4a16_describe_dispatch", "tce_reset_last_error", "tce_bmm_f16t", "tce_rope_half", "tce_softmax_half", "tce_attention_decode_f16", "tce_attention_decode_workspace_bytes", "tce_attention_decode_describe", "tce_attention_decode_step_f16", "tce_attention_decode_step_gqa_f16", "tce_attention_decode_describe_gqa", "tce_attention_decode_step_pos_f16", "tce_attention_prefill_f16", "tce_attention_prefill_workspace_bytes", "tce_opt_attention_decode", "tce_prefetch", "tce_add_half", "tce_silu_mul_half", "tce_rmsnorm_half", "tce_w4a16_forward_group_rmsnorm", "tce_w4a16_forward_group", "tce_w4a16_check_zero_point_8", "tce_w4a16_awq_fp16acc", "tce_w4a16_awq_workspace_bytes",
     "tce_w4a16_gemm_awq", "tce_w4a16_shard", "tce_comm_create", "tce_comm_export", "tce_comm_connect", "tce_comm_connect_local", "tce_allgather_f16", "tce_comm_rccl_unique_id", "tce_comm_rccl_init", "tce_allgather_rows_workspace_bytes", "tce_allgather_rows_f16", "tce_comm_status", "tce_comm_set_timeout_ms", "tce_comm_reset", "tce_comm_device", "tce_comm_destroy", "tce_w8a8_matmul", "tce_opt_softmax_q", "tce_opt_kv_append", "tce_layernorm_q", "tce_layernorm_q_w8a8_group", "tce_plan_create", "tce_plan_create_ex", "tce_plan_is_chained", "tce_plan_geometry", "tce_plan_status", "tce_plan_launch_geometry", "tce_plan_launch", "tce_plan_n_launches",
-    "tce_w4a16_forward_v2", "tce_w8a8_matmul_v2", "tce_attention_decode_step_deferred_f16", "tce_w4a16_forward_deferred_attention", "tce_plan_destroy", "tce_version", "tce_last_error", "tce_build_info", "tce_w4a16_set_gemv_config", "tce_w4a16_set_gemv_i8",
+    "tce_w4a16_forward_v2", "tce_w8a8_matmul_v2", "tce_w8a8_scratch_bytes", "tce_attention_decode_step_deferred_f16", "tce_w4a16_forward_deferred_attention", "tce_plan_destroy", "tce_version", "tce_last_error", "tce_build_info", "tce_w4a16_set_gemv_config", "tce_w4a16_set_gemv_i8",
     "tce_w4a16_set_gemm_config", "tce_w4a16_algorithmic_bytes", "tce_w4a16_gemv_variant", "tce_w4a16_gemm_variant",
     "tce_w4a16_set_debug_mode", "tce_attention_set_tuning", "tce_w8a8_set_tuning", "tce_w4a16_set_debug_buffer", "tce_w4a16_check_zero_point_8_async", "tce_host_alloc", "tce_host_free", "tce_malloc", "tce_free", "tce_memcpy", "tce_synchronize", "tce_device_count",
 ]
@@ -75,7 +75,7 @@ class W4A16DescV2(C.Structure):
 
 class W8A8DescV2(C.Structure):
     """struct tce_w8a8_desc_v2"""
-    _fields_ = [("struct_size", C.c_uint32), ("reserved0", C.c_uint32), ("desc", W8A8Desc)]
+    _fields_ = [("struct_size", C.c_uint32), ("reserved0", C.c_uint32), ("desc", W8A8Desc), ("scratch", C.c_void_p)]
 
 
 def w4a16_forward_v2(desc: W4A16Desc, stream: int | None, extra_zero_bytes: int = 0) -> int:
@@ -87,8 +87,22 @@ def w4a16_forward_v2(desc: W4A16Desc, stream: int | None, extra_zero_bytes: int 
     return lib().tce_w4a16_forward_v2(C.byref(v2), C.c_void_p(stream or 0))
 
 
-def w8a8_matmul_v2(desc: W8A8Desc, stream: int | None) -> int:
-    v2 = W8A8DescV2(struct_size=C.sizeof(W8A8DescV2), reserved0=0, desc=desc)
+_w8a8_scratch: dict = {}
+
+
+def w8a8_scratch(device) -> "torch.Tensor":
+    """tce_w8a8_desc_v2.scratch for `device`: one zeroed area shared by the harness's calls (ordered by its one stream)."""
+    import torch
+    key = str(device)
+    if key not in _w8a8_scratch:
+        L = lib()
+        L.tce_w8a8_scratch_bytes.restype = C.c_size_t
+        _w8a8_scratch[key] = torch.zeros(int(L.tce_w8a8_scratch_bytes()), dtype=torch.uint8, device=device)
+    return _w8a8_scratch[key]
+
+
+def w8a8_matmul_v2(desc: W8A8Desc, stream: int | None, scratch_ptr: int | None = None) -> int:
+    v2 = W8A8DescV2(struct_size=C.sizeof(W8A8DescV2), reserved0=0, desc=desc, scratch=scratch_ptr)
     return lib().tce_w8a8_matmul_v2(C.byref(v2), C.c_void_p(stream or 0))
 
 

@@ -15,7 +15,9 @@
 #include "w4a16_kernels.hpp"
 
 namespace tce {
-int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err);
+int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err, void *scratch = nullptr);
+size_t w8a8_scratch_bytes();
+void set_w8a8_xsplit(int xs);
 }
 
 namespace {
@@ -187,6 +189,10 @@ int tce_w4a16_set_debug_mode(int mode) {
     }
     if ((mode >= 75 && mode <= 78) || mode == 176 || mode == 177) {  // W8A8, the 128-row tiles: 75 the rule, 76 / 77 forced with 128 / 64 columns, 176 / 177 the same with two quartets per tile, 78 off
         tce::set_w8a8_big(mode == 78 ? 9 : (mode >= 176 ? mode - 173 : mode - 75));
+        return TCE_OK;
+    }
+    if (mode >= 180 && mode <= 188) {  // W8A8, a tile's k-steps cut across workgroups (needs tce_w8a8_desc_v2.scratch): 180 the rule, 181 off, 182 / 183 / 184 / 186 / 188 that many runs
+        tce::set_w8a8_xsplit(mode - 180);
         return TCE_OK;
     }
     if (mode == 170 || mode == 171 || mode == 172 || mode == 174 || mode == 179) {  // W8A8, the 64 x 64 tile with 8 k-steps in flight: 170 the rule, 171 / 172 / 174 forced with 1 / 2 / 4 quartets, 179 off
@@ -794,7 +800,9 @@ int tce_silu_mul_half(void *a, const void *b, long long n, void *stream) {
     return rc == TCE_ERR_HIP ? hip_fail(he, "silu_mul_half launch") : rc;
 }
 
-int tce_w8a8_matmul(const tce_w8a8_desc *d, void *stream) {
+static int w8a8_matmul_impl(const tce_w8a8_desc *d, void *scratch, void *stream);
+int tce_w8a8_matmul(const tce_w8a8_desc *d, void *stream) { return w8a8_matmul_impl(d, nullptr, stream); }
+static int w8a8_matmul_impl(const tce_w8a8_desc *d, void *scratch, void *stream) {
     if (!d) return fail(TCE_ERR_BAD_ARG, "null descriptor");
     if (!d->A || !d->B || !d->C) return fail(TCE_ERR_BAD_ARG, "null data pointer");
     if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch < 1) return fail(TCE_ERR_BAD_ARG, "non-positive M/N/K/batch");
@@ -814,7 +822,7 @@ int tce_w8a8_matmul(const tce_w8a8_desc *d, void *stream) {
     if (d->lda < 0 || d->ldb < 0 || d->ldc < 0 || (d->lda && d->lda < d->K) || (d->ldb && d->ldb < d->K) || (d->ldc && d->ldc < d->N))
         return fail(TCE_ERR_BAD_ARG, "lda / ldb / ldc must be 0 (dense) or at least K / K / N");
     hipError_t he = hipSuccess;
-    const int rc = tce::launch_w8a8(*d, static_cast<hipStream_t>(stream), &he);
+    const int rc = tce::launch_w8a8(*d, static_cast<hipStream_t>(stream), &he, scratch);
     if (rc == TCE_ERR_BAD_ARG) return fail(rc, "w8a8: bad leading dimensions");
     return rc == TCE_ERR_HIP ? hip_fail(he, "w8a8 launch") : rc;
 }
@@ -840,8 +848,9 @@ int tce_w4a16_forward_v2(const tce_w4a16_desc_v2 *d, void *stream) {
 int tce_w8a8_matmul_v2(const tce_w8a8_desc_v2 *d, void *stream) {
     tce_w8a8_desc_v2 local{};
     const int rc = unwrap_v2(d, local, "tce_w8a8_matmul_v2");
-    return rc != TCE_OK ? rc : tce_w8a8_matmul(&local.desc, stream);
+    return rc != TCE_OK ? rc : w8a8_matmul_impl(&local.desc, local.scratch, stream);
 }
+size_t tce_w8a8_scratch_bytes(void) { return tce::w8a8_scratch_bytes(); }
 
 // ---- multi-GPU (csrc/comm.hip): tce_comm is tce::Comm ----
 int tce_w4a16_shard(const tce_w4a16_desc *full, int rank, int world, tce_w4a16_desc *shard) {

@@ -32,6 +32,12 @@ struct W8A8Args {
     int q_min, q_max;
     int bias_kind, out_kind, b_per_row, vec_ok;
     int accumulate;     // fp32 output only: C = fadd_rn(C, result) -- the residual add behind out_proj / fc2 (Int8OPTDecoderLayer.cc:39, 54)
+    // round 5: a tile's k-steps cut into `xs` runs on as many WORKGROUPS (few tiles with a long chain: 512 x 768 x 3072 is 96 tiles of 48 steps, each bound by what ONE CU
+    // pulls through its L1).  int32 partial tiles are exact: written through to `xpart`, the workgroup that arrives last at the tile's counter adds the others' in any
+    // order and runs the epilogue -- the same integers as the unsplit kernel, bit-exact.  xcnt is zero between launches.
+    int xs;
+    int4_t *xpart;      // [tiles][xs][4 accumulator tiles][256 threads]
+    unsigned *xcnt;     // [tiles]
 };
 
 // The additive term of output column n: fmul_rn(bias[n], beta) for the int8 form, bias[n] for the fp32 form, none.
@@ -75,7 +81,7 @@ __device__ __forceinline__ void epilogue_store(const W8A8Args &a, void *Cb, int 
 // KS > 1: the K range is cut between KS wave quartets of the same 64x64 tile (the OPT shapes give 24-96 tiles, each a serial
 // chain of K/64 steps: 512x768x3072 15.4 us with 96 workgroups).  int32 partial sums are exact, so the quartets' tiles are
 // added through LDS in any order and the epilogue sees the same integers as the unsplit kernel: still bit-exact.
-template <int KS>
+template <int KS, bool XS = false>
 __global__ __launch_bounds__(256 * KS) void w8a8_mfma_kernel(const W8A8Args a) {
     extern __shared__ __attribute__((aligned(16))) int4_t lds_dyn[];  // [4 * KS waves][fragment: A0 A1 B0 B1][64 slots]
     const int tid = threadIdx.x;
@@ -88,7 +94,8 @@ __global__ __launch_bounds__(256 * KS) void w8a8_mfma_kernel(const W8A8Args a) {
     const int lrow = lane >> 2, lchunk = lane & 3;  // load view of the lane
     const int wslot = lrow * 4 + (lchunk ^ ((lrow >> 2) & 3));
     const int rslot = r16 * 4 + (kq ^ ((r16 >> 2) & 3));
-    const int batch = blockIdx.z;
+    const int batch = XS ? 0 : blockIdx.z;        // (the cut across workgroups: one problem per launch, blockIdx.z = the run)
+    const int part = XS ? (int)blockIdx.z : 0, xs = XS ? a.xs : 1;
     const int8_t *A = a.A + (size_t)batch * a.strideA;
     const int8_t *B = a.B + (size_t)batch * a.strideB;
     const size_t c_off = (size_t)batch * a.strideC;
@@ -140,9 +147,10 @@ __global__ __launch_bounds__(256 * KS) void w8a8_mfma_kernel(const W8A8Args a) {
 
     // this quartet's full k-steps: [k_begin, k_end)
     const int nfull = a.K >> 6;
-    const int spg = (nfull + KS - 1) / KS;
-    const int k_begin = (grp * spg < nfull ? grp * spg : nfull) * 64;
-    const int k_end = ((grp + 1) * spg < nfull ? (grp + 1) * spg : nfull) * 64;
+    const int s_lo = part * nfull / xs, nloc = (part + 1) * nfull / xs - s_lo;  // this workgroup's run of k-steps (all of them unless XS)
+    const int spg = (nloc + KS - 1) / KS;
+    const int k_begin = (s_lo + (grp * spg < nloc ? grp * spg : nloc)) * 64;
+    const int k_end = (s_lo + ((grp + 1) * spg < nloc ? (grp + 1) * spg : nloc)) * 64;
     // the next k-step's raw fragments are requested before the current one goes through LDS and the MFMAs (two static
     // register sets; requests past the end are clamped re-reads)
     auto load_raw = [&](int4_t (&ra)[2], int4_t (&rb)[2], int k0) {
@@ -170,7 +178,7 @@ __global__ __launch_bounds__(256 * KS) void w8a8_mfma_kernel(const W8A8Args a) {
         }
     }
     const int k_full = nfull * 64;
-    if (k_full < a.K && grp == KS - 1) {  // K % 64 in {16,32,48}: chunks past the end contribute zeros (K % 16 == 0 is guaranteed)
+    if (k_full < a.K && grp == KS - 1 && part == xs - 1) {  // K % 64 in {16,32,48}: chunks past the end contribute zeros (K % 16 == 0 is guaranteed)
         const bool live = k_full + lchunk * 16 < a.K;
         int4_t ra[2], rb[2];
 #pragma unroll
@@ -197,7 +205,8 @@ __global__ __launch_bounds__(256 * KS) void w8a8_mfma_kernel(const W8A8Args a) {
                 for (int j = 0; j < 2; ++j) red[((grp - 1) * 4 + i * 2 + j) * 256 + t4] = acc[i][j];
         }
         __syncthreads();
-        if (grp > 0) return;
+        if (!XS && grp > 0) return;  // (with the cut across workgroups every wave stays for the barriers below)
+        if (grp == 0)
         for (int g2 = 0; g2 < KS - 1; ++g2)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -207,6 +216,41 @@ __global__ __launch_bounds__(256 * KS) void w8a8_mfma_kernel(const W8A8Args a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[i][j][r] += o[r];
                 }
+    }
+    if constexpr (XS) {
+        // the run's partial tile, written through; the counter elects the last workgroup; it adds the other runs' tiles (any order: integers) -- visibility as in the
+        // W4A16 GEMM's k-range cut and the attention step's merge: acknowledged device-scope stores, then the counter, then coherent loads
+        const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+        const int t4x = tid & 255;
+        const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(a.xpart + (size_t)tile * xs * 4 * 256, 0, xs * 4 * 256 * 16, 0x00020000);
+        if (grp == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, acc[i][j]), rs_p, ((part * 4 + i * 2 + j) * 256 + t4x) * 16, 0, /*sc0|sc1*/ 17);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned *flag = reinterpret_cast<unsigned *>(lds_dyn);
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(a.xcnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned last = old == (unsigned)xs - 1 ? 1u : 0u;
+            if (last) __hip_atomic_store(a.xcnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+            *flag = last;
+        }
+        __syncthreads();
+        if (*flag == 0u || grp > 0) return;
+        for (int p = 0; p < xs; ++p) {
+            if (p == part) continue;  // (workgroup-uniform)
+            uint4_t o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) o[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_p, ((p * 4 + u) * 256 + t4x) * 16, 0, /*sc0|sc1*/ 17);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] += __builtin_bit_cast(int4_t, o[i * 2 + j]);
+        }
     }
 
     // D[row = 4*(lane>>4) + r][col = lane & 15]
@@ -630,12 +674,16 @@ thread_local int g_w8a8_ks = 0;  // forced K split (tuning), 0 = automatic; 3: t
 }  // namespace
 
 void set_w8a8_ksplit(int ks) { g_w8a8_ks = (ks >= 1 && ks <= 4) ? ks : 0; }
+thread_local int g_w8a8_xs = 0;  // the cut across workgroups: 0 the rule, 1 off, 2 / 3 / 4 / 6 / 8 forced where the rule's bounds allow it (A/B)
+void set_w8a8_xsplit(int xs) { g_w8a8_xs = (xs >= 1 && xs <= 8) ? xs : 0; }
 thread_local int g_w8a8_deep = 0;  // the 64 x 64 tile with 8 k-steps in flight: 0 the rule, 1 / 2 / 4 forced with that many quartets, 9 off (A/B)
 thread_local int g_w8a8_big = 0;  // the 128-row tiles: 0 the rule, 1 / 2 forced with 128 / 64 columns (one quartet), 3 / 4 the same with two quartets, 9 off (A/B)
 void set_w8a8_big(int b) { g_w8a8_big = b; }
 void set_w8a8_deep(int d) { g_w8a8_deep = d; }
 
-int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err) {
+size_t w8a8_scratch_bytes() { return 4096 + (size_t)1024 * 16384; }  // [1024 tile counters][1024 partial tiles of 64 x 64 int32]
+
+int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err, void *scratch) {
     W8A8Args a{};
     a.A = static_cast<const int8_t *>(d.A);
     a.B = static_cast<const int8_t *>(d.B);
@@ -716,6 +764,27 @@ int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err)
         // at 32 and 12 steps (512 x 2048 x 2048: 10.2 -> 11.1; 512 x 768 x 768: 6.3 -> 8.0).  Two quartets up to 256 tiles (up to 512 from 128 steps on: 512 x 4096 x 8192 47.4 -> 44.8), one beyond; four were never ahead.
         // (48 .. 63 steps on 64 .. 256 tiles stay with the kernel above: a tie on weights from HBM -- 512 x 768 x 3072 13.1 / 13.2 us --, 6 % behind on weights that sit in L2: 11.5 / 10.85)
         const bool deep = g_w8a8_deep != 9 && d.K % 64 == 0 && (g_w8a8_deep > 0 || d.K / 64 >= 64 || (d.K / 64 >= 48 && (tiles < 64 || tiles > 256)));
+        // round 5: few tiles with a long chain and a scratch area from the caller (tce_w8a8_desc_v2.scratch): the k-steps cut into runs on several workgroups, as many as
+        // keep >= 6 steps per run and <= 384 workgroups (512 x 768 x 3072: 96 tiles x 4 runs of 12 steps; 108 x 768 x 3072: 24 tiles x 8 runs of 6)
+        int xs = 1;
+        // MEASURED (profiles/r5/w8a8_xsplit_ab.jsonl): the exchange is three dependent memory round trips (acknowledged stores, the counter, the coherent re-reads: ~5 us) --
+        // 512 x 768 x 3072 (96 tiles, an ~8 us chain) 11.2 us uncut, 11.1 / 13.6 / 12.0 / 10.8 / 11.0 cut in 2 / 3 / 4 / 6 / 8: nothing gained; 108 x 768 x 3072 (24 tiles)
+        // 11.4 -> 9.5 cut in 3 or 4, 11.0 cut in 8.  The rule cuts launches of at most 32 tiles, in four; forced cuts (tce_w4a16_set_debug_mode(182 .. 188)) go up to 128 tiles.
+        if (scratch && (reinterpret_cast<uintptr_t>(scratch) & 255) == 0 && d.batch == 1 && g_w8a8_deep == 0 && g_w8a8_ks == 0 && g_w8a8_xs != 1 && tiles <= 128 && d.K / 64 >= 24) {
+            if (g_w8a8_xs == 0) {
+                if (tiles <= 32 && d.K / 64 / 4 >= 6) xs = 4;
+            } else if (tiles * g_w8a8_xs <= 1024 && d.K / 64 / g_w8a8_xs >= 3) {
+                xs = g_w8a8_xs;
+            }
+        }
+        if (xs > 1) {
+            a.xs = xs;
+            a.xcnt = static_cast<unsigned *>(scratch);
+            a.xpart = reinterpret_cast<int4_t *>(static_cast<unsigned char *>(scratch) + 4096);
+            const dim3 gx(grid.x, grid.y, xs);
+            if (d.K / 64 / xs >= 4) hipLaunchKernelGGL((w8a8_mfma_kernel<2, true>), gx, dim3(512), (size_t)2 * 4 * 4 * 64 * 16, stream, a);
+            else hipLaunchKernelGGL((w8a8_mfma_kernel<1, true>), gx, dim3(256), (size_t)4 * 4 * 64 * 16, stream, a);
+        } else
         if (deep) {
             const int dks = g_w8a8_deep == 1 || g_w8a8_deep == 2 || g_w8a8_deep == 4 ? g_w8a8_deep : (tiles <= 256 || (tiles <= 512 && d.K / 64 >= 128) ? 2 : 1);
             const size_t dl = (size_t)dks * 2 * 512 * 16;  // (>= the reduction's (dks - 1) * 16 KiB)
