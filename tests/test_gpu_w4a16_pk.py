@@ -260,7 +260,7 @@ def test_pk_dispatch_rules(dev, oracle):
     d.M, d.N, d.K, d.lda, d.ldc = 512, 4096, 4096, 4096, 4096
     assert d.scratch and "ksplit=2" in capi.describe_dispatch(d), capi.describe_dispatch(d)
     d.K = d.lda = 11008
-    assert "ksplit=4" in capi.describe_dispatch(d), capi.describe_dispatch(d)  # (round 4: the scratch area holds 512 units; four runs per tile win on the long k range)
+    assert "ksplit=2" in capi.describe_dispatch(d), capi.describe_dispatch(d)  # (round 5: two runs as a directed hand-off, 52.1 us, ahead of round 4's four runs through the last arriver, 53.4-53.6)
     d.scratch = None
     assert capi.describe_dispatch(d).startswith("gemm-dma")
     assert capi.describe_dispatch(lin.desc(x[:1], out[:1])).startswith("gemv")
@@ -282,7 +282,7 @@ def test_full_size_prefill_on_the_packed_kernel(dev, oracle, N, K):
     what = capi.describe_dispatch(lin.desc(x, y))
     # N = 4096: 128 tiles, every tile's k range cut in two (K = 4096) or four (K = 11008: round 4); N = 11008: 344 tiles, the 88 past the first 256 cut in two (one run per CU at most)
     # N = 11008 (round 5): 128 x 192 tiles -- 232 of them for the 256 CUs --, two quartets alternating a tile's k-blocks (until then: 344 tiles of 128 x 128, the 88 past the first 256 cut in two)
-    assert what.startswith("gemm-pk") and ((("ksplit=2 " if K == 4096 else "ksplit=4 ") in what) if N == 4096 else "tile=128x192 wave=128x48 quartets=2" in what), what
+    assert what.startswith("gemm-pk") and (("ksplit=2 " in what) if N == 4096 else "tile=128x192 wave=128x48 quartets=2" in what), what
     for rep in range(3):  # (the scratch counters must be back to zero after every call)
         y.fill_(float("nan"))
         lin.forward(x, y)
@@ -344,3 +344,39 @@ def test_wide_form_against_the_narrow_form_at_full_size(dev, oracle, M, N, K):
     for mode in (2670, 2671, 2672, 2673, 2674, 2675):
         ok, worst = w4a16_close(outs[mode][rows].cpu().numpy(), ref32)
         assert ok, f"mode {mode}: worst |err|/tol = {worst:.3f}"
+
+
+def test_two_run_k_cut_as_a_directed_hand_off(dev, oracle):
+    """Round 5: a k range cut in TWO runs is a hand-off -- run 0 (two k-blocks shorter) writes its tile through and raises the tile's counter, run 1 adds it to its own in run
+    order -- instead of both meeting at the counter.  Same arithmetic as the last-arriver form with the cut moved by a k-block: against the oracle, repeatable bit for
+    bit, the counters back at zero, and the A/B switch (mode 694) still gives the old form."""
+    from tinychatengine_amd import capi
+    from tinychatengine_amd.linear import Linear_half_int4, gemm_scratch
+    L = capi.lib()
+    for (M, N, K) in ((512, 4096, 4096), (300, 1000, 1408), (512, 2048, 1024)):
+        g = torch.Generator(device=dev).manual_seed(7 + N)
+        lin = Linear_half_int4.from_float(torch.empty(N, K, device=dev).normal_(0, 0.02, generator=g), 128).prepack()
+        x = torch.empty(M, K, device=dev).normal_(0, 1, generator=g).to(torch.float16)
+        rows = list(range(0, M, max(1, M // 48)))
+        ref32 = oracle.w4a16_gemv_q4_6_mt(x[rows].cpu().numpy(), lin.weight.cpu().numpy().view(np.uint32), lin.scale.cpu().numpy(), lin.zero_point.cpu().numpy().view(np.uint32), len(rows), N, K, 128)
+        try:
+            capi.check(L.tce_w4a16_set_debug_mode(642))  # every tile's k range cut in two
+            outs = {}
+            for sw in (695, 694):
+                capi.check(L.tce_w4a16_set_debug_mode(sw))
+                ys = []
+                for rep in range(3):
+                    y = torch.full((M, N), float("nan"), dtype=torch.float16, device=dev)
+                    d = lin.desc(x, y)
+                    assert "ksplit=2" in capi.describe_dispatch(d), capi.describe_dispatch(d)
+                    capi.check(capi.w4a16_forward(d, torch.cuda.current_stream().cuda_stream))
+                    torch.cuda.synchronize()
+                    ys.append(y)
+                assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2]), (sw, M, N, K)
+                assert int(gemm_scratch(dev)[:4096].to(torch.int32).sum().item()) == 0
+                ok, worst = w4a16_close(ys[0][rows].cpu().numpy(), ref32)
+                assert ok, f"switch {sw} {M}x{N}x{K}: worst |err|/tol = {worst:.3f}"
+                outs[sw] = ys[0]
+        finally:
+            L.tce_w4a16_set_debug_mode(695)
+            L.tce_w4a16_set_debug_mode(60)

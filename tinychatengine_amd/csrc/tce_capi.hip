@@ -254,6 +254,14 @@ int tce_w4a16_set_debug_mode(int mode) {
         tce::set_gemm_pk_split(mode - 2680);
         return TCE_OK;
     }
+    if (mode >= 6950 && mode <= 6958) {  // the hand-off's cut: run 0 shorter than run 1 by (mode - 6950) k-blocks (tuning)
+        tce::set_gemm_pk_handoff_delta(mode - 6950);
+        return TCE_OK;
+    }
+    if (mode == 694 || mode == 695) {  // pre-packed GEMM, k range cut in two: 695 = run 0 hands its tile to run 1 (the default), 694 = both runs meet at the counter (A/B)
+        tce::set_gemm_pk_handoff(mode - 694);
+        return TCE_OK;
+    }
     if (mode == 692 || mode == 693) {  // pre-packed GEMM: 693 = the dispatcher may pick the wide forms, 692 = never
         tce::set_gemm_pk_wide_auto(mode - 692);
         return TCE_OK;

@@ -145,6 +145,9 @@ struct PkGemmArgs {
     int xm, m_per, n_per;
     int split_s;          // > 1: the k-blocks of the tiles in slots >= full_slots are cut into split_s runs, one workgroup each (one quartet,
     int full_slots;       //      128 x 128 tiles only); slot = workgroup index / 8 of the tile's first run.  0: every tile is cut
+    int handoff;          // split_s == 2 only (round 5): run 0 takes a slightly SHORTER part of the k range, writes its partial tile through and raises the tile's counter; run 1 --
+                          // dispatched behind run 0 of the same tile: block indices grow with the run -- finishes its longer part, finds the counter raised (or waits a bounded
+                          // time), adds run 0's tile to its own in run order and stores.  Off the critical path: run 1's write-through, the counter's round trip
     unsigned *counters;   // [cut tiles], zero between launches (scratch)
     float4_t *partials;   // [cut tiles][split_s][16 accumulators][256 threads] fp32 x 4 (scratch)
 };
@@ -241,7 +244,11 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
     const int m_base = m_blk * ROWS, nb0 = n_blk * BN;
     const int nkb = g.K >> 7;
     const int split = (KS == 1 && NS == 1 && g.split_s > 1 && slot >= g.full_slots) ? g.split_s : 1;
-    const int kb_lo = part * nkb / split, nloc = (part + 1) * nkb / split - kb_lo;  // this workgroup's run of k-blocks
+    // this workgroup's run of k-blocks (the hand-off form: run 0 is two k-blocks shorter than run 1 -- about the time its write-through takes to become visible)
+    const bool handoff = KS == 1 && NS == 1 && kMT == 8 && kNT == 2 && split == 2 && g.handoff != 0;
+    const int n0_h = nkb >= 8 ? (nkb - (g.handoff - 1)) / 2 : nkb / 2;  // (g.handoff = 1 + the k-blocks run 0 is shorter by)
+    const int kb_lo = handoff ? (part == 0 ? 0 : n0_h) : part * nkb / split;
+    const int nloc = handoff ? (part == 0 ? n0_h : nkb - n0_h) : (part + 1) * nkb / split - kb_lo;
     const int T = (nloc + KS - 1) / KS;  // iterations (own k-blocks, the last one may be past the run for quartet 1)
 
     // ---- DMA sources of a half-stage: instruction ii of this wave fills 8 rows; the lane fetches the piece that belongs at its position ----
@@ -861,6 +868,38 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
         const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(g.partials + (size_t)tile_lin * split * (kMT * kNT * 256), 0,
                                                                                split * kMT * kNT * 256 * 16, 0x00020000);
         (void)mine;
+        if (handoff && part == 1) {
+            // run 1 of a hand-off: no partial of its own leaves the registers.  Wait for run 0's (bounded: ~0.3 s of polls -- the launch then ends with this run's part
+            // alone rather than hanging a queue; it has never been seen to happen), take the counter back to zero for the next launch
+            unsigned *flag = reinterpret_cast<unsigned *>(smem);
+            __syncthreads();
+            if (tid == 0) {
+                unsigned v = 0;
+                for (int n = 0; n < (1 << 20) && !v; ++n) {
+                    v = __hip_atomic_load(g.counters + tile_lin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!v) __builtin_amdgcn_s_sleep(2);
+                }
+                __hip_atomic_store(g.counters + tile_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *flag = v;
+            }
+            __syncthreads();
+            const bool have = *flag != 0u;
+            __syncthreads();  // (the flag word is part of the output tile's LDS image below)
+            if (have) {  // run order: run 0's partial first, then this run's (the same sum the last-arriver form computes)
+                uint4_t t4[kMT * kNT];
+#pragma unroll
+                for (int r = 0; r < kMT * kNT; ++r) t4[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_p, (r * 256 + tid) * 16, 0, /*sc0|sc1*/ 17);
+#pragma unroll
+                for (int i = 0; i < kMT; ++i)
+#pragma unroll
+                    for (int j = 0; j < kNT; ++j) {
+                        const float4_t own = acc[i][j];
+                        acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+                        acc[i][j] += __builtin_bit_cast(float4_t, t4[i * kNT + j]);
+                        acc[i][j] += own;
+                    }
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < kMT; ++i)
 #pragma unroll
@@ -869,6 +908,10 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         unsigned *flag = reinterpret_cast<unsigned *>(smem);
         __syncthreads();
+        if (handoff) {  // run 0 of a hand-off: its tile is acknowledged; raise the counter and leave
+            if (tid == 0) __hip_atomic_store(g.counters + tile_lin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
         if (tid == 0) {
             const unsigned old = __hip_atomic_fetch_add(g.counters + tile_lin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned last = old == (unsigned)split - 1 ? 1u : 0u;
@@ -923,6 +966,7 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
                 for (int j = 0; j < kNT; ++j) acc[i][j] += __builtin_bit_cast(float4_t, t4[i * kNT + j]);
         }
         }
+        }  // (not run 1 of a hand-off)
     }
 
     // ---- epilogue: the tile leaves through LDS as 16-byte row pieces (accumulator layout: lane = column n16, registers = 4 consecutive rows) ----
@@ -1009,6 +1053,9 @@ thread_local int g_pk_split_force = 0;  // tuning: the number of runs a cut tile
 thread_local int g_pk256_auto = 1;      // 0: the dispatcher never picks the 256-row forms by itself (A/B runs: tce_w4a16_set_debug_mode(650 / 651))
 constexpr float kPk256wUsPerKBlock = 4.3f;  // eight waves of a 256 x 256 tile walking one k-block
 constexpr float kPk256x2UsPerPair = 3.45f;   // two quartets sharing a CU walking one 256-row k-block each
+thread_local int g_pk_handoff_delta = 2;   // k-blocks run 0 of a hand-off is shorter than run 1 (tce_w4a16_set_debug_mode(6950 + d))
+thread_local int g_pk_handoff = 1;         // 1: a k range cut in two runs is a directed hand-off (tce_w4a16_set_debug_mode(694): the last-arriver exchange, for the A/B)
+constexpr float kPkHandoffUs = 3.5f;       // run 1's read of run 0's tile + what is left of run 0's write-through when run 1 arrives  [first guess]
 thread_local int g_pk_wide_auto = 1;                    // 1: the dispatcher may pick the wide forms 10 / 11 / 12 by itself (tce_w4a16_set_debug_mode(692): never)
 // fitted to profiles/r5/gemm_pkw_sweep.jsonl: 2048 x 4096 x 4096 (256 tiles, one per CU) 68.1 us; 4096 x 4096 x 4096 (512 tiles, two per CU) 112.8 us; two quartets on one tile 62.7 / 147.0 us at K = 4096 / 11008
 constexpr float kPkWideAloneUs = 2.02f;    // wide form: one quartet alone on its CU walking a k-block (128 MFMAs per wave)
@@ -1124,6 +1171,8 @@ hipError_t launch_pk256(PkGemmArgs &g, hipStream_t stream) {
 void set_gemm_pk_ablation(int abl) { g_pk_abl = abl; }
 void set_gemm_pk256_auto(int on) { g_pk256_auto = on ? 1 : 0; }
 void set_gemm_pk_wide_auto(int on) { g_pk_wide_auto = on ? 1 : 0; }
+void set_gemm_pk_handoff(int on) { g_pk_handoff = on ? 1 : 0; }
+void set_gemm_pk_handoff_delta(int d) { g_pk_handoff_delta = d >= 0 && d <= 8 ? d : 2; }
 void set_gemm_pk_split(int s) { g_pk_split_force = s >= 2 && s <= 4 ? s : 0; }
 
 void set_gemm_pk_mode(int form, int xm) {
@@ -1191,7 +1240,9 @@ static int pk_split_factor(long tiles1, int nkb, bool has_scratch, float *cost_o
             const float run = (float)((nkb + s - 1) / s);
             // (round 4, profiles/r4/gemm_pk_split_probe.jsonl: with room for 512 units in the scratch area, four runs per tile beat two on the long k ranges --
             //  512 x 4096 x 11008: 55.6 -> 52.0 us, x 14336: 70.7 -> 64.0 -- and lose on 4096 (26.9 -> 28.9); two units sharing a CU walk a k-block in ~1.8 us, + 1.5 us once)
-            const float c = (tiles1 * s <= 256 ? run * 1.06f : 1.8f * run + 1.5f) + 8.0f + 1.3f * (float)s;
+            float c = (tiles1 * s <= 256 ? run * 1.06f : 1.8f * run + 1.5f) + 8.0f + 1.3f * (float)s;
+            // (round 5) two runs as a directed hand-off: run 1 is a k-block longer than half, the exchange on its path is one read of run 0's tile
+            if (s == 2 && g_pk_handoff && nkb >= 6) c = (tiles1 * s <= 256 ? (run + 1.f) * 1.06f : 1.8f * (run + 1.f) + 1.5f) + 3.0f + kPkHandoffUs;
             if (c < best) best = c, best_s = s;
         }
     if (cost_out) *cost_out = best;
@@ -1342,9 +1393,11 @@ int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_
     const bool rows256 = form >= 6 && form <= 9;
     const bool rows256x2 = form == 8, rows256w = form == 9;
     const bool wide = form >= 10 && form <= 15, widex2 = form == 11, wide3 = form == 13 || form == 14, wide512 = form == 15;
+    const bool handoff_form = form == 4 && split == 2 && g_pk_handoff;
     if (form == 4 || form == 5 || form == 7 || form == 12) {
         form = 1;
         g.split_s = split;
+        g.handoff = handoff_form ? 1 + g_pk_handoff_delta : 0;
         g.counters = static_cast<unsigned *>(d.scratch);
         g.partials = reinterpret_cast<float4_t *>(static_cast<unsigned char *>(d.scratch) + 4096);
     } else {
