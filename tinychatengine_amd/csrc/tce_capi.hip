@@ -258,6 +258,14 @@ int tce_w4a16_set_debug_mode(int mode) {
         tce::set_gemm_pk_handoff_delta(mode - 6950);
         return TCE_OK;
     }
+    if (mode == 696 || mode == 697 || mode == 698 || (mode >= 6972 && mode <= 6974)) {  // pre-packed GEMM: the two waves of a SIMD at different priorities
+        tce::set_gemm_pk_prio(mode == 698 ? -1 : mode >= 6970 ? mode - 6970 : mode - 696);  // 696 off, 697 on, 698 the launcher's rule (default);  // 6972: priority 3, 6973: priority 1, 6974: by slot parity instead of dispatch round
+        return TCE_OK;
+    }
+    if (mode == 6262 || mode == 6263) {  // probes only: the two-quartet 128-row forms for groups of 64 / 32 too (6262; the dispatcher keeps them to groups of 128: DESIGN.md section 3.2) / off (6263)
+        tce::set_gemm_pk_x2_any_group(mode == 6262);
+        return TCE_OK;
+    }
     if (mode == 694 || mode == 695) {  // pre-packed GEMM, k range cut in two: 695 = run 0 hands its tile to run 1 (the default), 694 = both runs meet at the counter (A/B)
         tce::set_gemm_pk_handoff(mode - 694);
         return TCE_OK;

@@ -133,6 +133,7 @@ __global__ __launch_bounds__(64) void prepack_decode_kernel(const PrepackArgs a)
 // the GEMM
 // ------------------------------------------------------------------------------------------------------------------------
 typedef float float2_t __attribute__((ext_vector_type(2)));
+constexpr int kPkFaultWord = 1023;  // last word of the scratch area's counter page
 struct PkGemmArgs {
     const half_t *A;
     const uint4_t *words;   // [NT16][NKB][64]
@@ -148,7 +149,8 @@ struct PkGemmArgs {
     int handoff;          // split_s == 2 only (round 5): run 0 takes a slightly SHORTER part of the k range, writes its partial tile through and raises the tile's counter; run 1 --
                           // dispatched behind run 0 of the same tile: block indices grow with the run -- finishes its longer part, finds the counter raised (or waits a bounded
                           // time), adds run 0's tile to its own in run order and stores.  Off the critical path: run 1's write-through, the counter's round trip
-    unsigned *counters;   // [cut tiles], zero between launches (scratch)
+    int prio;             // != 0: the two waves sharing a SIMD run at different priorities for the whole kernel (launch_w4a16_gemm_pk sets it for the one-quartet wide form)
+    unsigned *counters;   // [cut tiles], zero between launches (scratch); word kPkFaultWord counts hand-offs whose wait ran out (never seen; the tests hold it at zero)
     float4_t *partials;   // [cut tiles][split_s][16 accumulators][256 threads] fp32 x 4 (scratch)
 };
 
@@ -231,6 +233,14 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
         }
     }
     const int xcd = bid & 7, slot = bid >> 3;
+    if (g.prio) {  // (the second quartet of a workgroup / the workgroups of the second dispatch round of a CU -- 32 CUs per XCD -- give way)
+        const bool low = (KS == 2 || NS == 2) ? (int)(threadIdx.x >> 8) == 1 : (((g.prio == 4 ? slot : slot >> 5)) & 1) == 1;
+        if (!low) {
+            if (g.prio == 2) __builtin_amdgcn_s_setprio(3);
+            else if (g.prio == 3) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(2);
+        }
+    }
     const int m_blk = (xcd % g.xm) * g.m_per + slot % g.m_per;
     const int n_blk = (xcd / g.xm) * g.n_per + slot / g.m_per;
     if (n_blk >= g.n_blocks || m_blk >= g.m_blocks) return;
@@ -428,15 +438,12 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
 #ifdef TCE_PK_VAR_PIN_AFTER_RCP
             asm volatile("" : "+v"(r));
 #endif
-            // Round 5, found by tests/test_gpu_cold_first_launch.py: THIS instantiation (two quartets per tile, groups of 32) returned a wrong sum -- the first quartet's
-            // part missing in one to four accumulator registers of the second column tile, lanes 48-63 -- on its FIRST execution in a process (6 of 6 fresh processes,
-            // behind a launch of another form; never on a repeat, never with groups of 64 / 128, never when it is the first GEMM of the process), with device code
-            // byte-identical to the build that had passed every run of rounds 4 and 5 until then.  Counted waits replaced by vmcnt(0), extra lgkmcnt(0) waits and a scalar
-            // rescale do not remove it (scripts/probes/pk_form2_g32_repeat.py, profiles/r5/pk_form2_g32_first_launch.txt); ANY change of the instruction schedule does
-            // (0 of 30 fresh processes over five variants, this empty statement among them).  Cause not established (an issue-order hazard would not depend on a cold
-            // start; a race between the quartets would not vanish with an empty statement); the statement pins the ratio in a register at this point, which yields a
-            // schedule that does not show it, and the cold-start test now runs every form as its first launch in a fresh process.
+            // (probe-only instantiation -- two quartets, groups of 32: the dispatcher no longer offers it, see gemm_pk_estimate_us.  WITH this empty statement hipcc's schedule
+            //  shows the lost-accumulator failure under scripts/probes/pk_stress.py (X2ANY=1: 10-100 of ~8000 launches on every box tried); WITHOUT it the schedule it picks does not
+            //  (0 of 10 000) -- which says nothing about the cause, only that the evidence stays reproducible this way.  Round 4's build failed on first executions without it.)
+#ifndef TCE_PK_VAR_NO_PIN
             if constexpr (KS == 2 && LG == 5 && ABL == 0) asm volatile("" : "+v"(r));
+#endif
             e_prev[j] = e_new[j];
             // as two-element vector products: v_pk_mul_f32, two per accumulator tile (left to itself hipcc emits four v_mul_f32 here --
             // 64 instead of 32 VALU instructions per group beside the MFMAs -- while it packs the same loop after the k-loop)
@@ -880,6 +887,7 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
                     if (!v) __builtin_amdgcn_s_sleep(2);
                 }
                 __hip_atomic_store(g.counters + tile_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!v) __hip_atomic_fetch_add(g.counters + kPkFaultWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 *flag = v;
             }
             __syncthreads();
@@ -1054,6 +1062,8 @@ thread_local int g_pk256_auto = 1;      // 0: the dispatcher never picks the 256
 constexpr float kPk256wUsPerKBlock = 4.3f;  // eight waves of a 256 x 256 tile walking one k-block
 constexpr float kPk256x2UsPerPair = 3.45f;   // two quartets sharing a CU walking one 256-row k-block each
 thread_local int g_pk_handoff_delta = 2;   // k-blocks run 0 of a hand-off is shorter than run 1 (tce_w4a16_set_debug_mode(6950 + d))
+thread_local int g_pk_x2_any_group = 0;  // probes only (debug mode 6262 / 6263): forms 2 / 3 for groups of 64 / 32 as well
+thread_local int g_pk_prio = -1;  // -1: the rule below (the wide form with one quartet per tile); 0 .. 4 forced (tce_w4a16_set_debug_mode(696 / 697 / 6972 .. 6974; 698: the rule))
 thread_local int g_pk_handoff = 1;         // 1: a k range cut in two runs is a directed hand-off (tce_w4a16_set_debug_mode(694): the last-arriver exchange, for the A/B)
 constexpr float kPkHandoffUs = 3.5f;       // run 1's read of run 0's tile + what is left of run 0's write-through when run 1 arrives  [first guess]
 thread_local int g_pk_wide_auto = 1;                    // 1: the dispatcher may pick the wide forms 10 / 11 / 12 by itself (tce_w4a16_set_debug_mode(692): never)
@@ -1172,6 +1182,8 @@ void set_gemm_pk_ablation(int abl) { g_pk_abl = abl; }
 void set_gemm_pk256_auto(int on) { g_pk256_auto = on ? 1 : 0; }
 void set_gemm_pk_wide_auto(int on) { g_pk_wide_auto = on ? 1 : 0; }
 void set_gemm_pk_handoff(int on) { g_pk_handoff = on ? 1 : 0; }
+void set_gemm_pk_x2_any_group(int on) { g_pk_x2_any_group = on ? 1 : 0; }
+void set_gemm_pk_prio(int on) { g_pk_prio = on >= 0 && on <= 4 ? on : -1; }
 void set_gemm_pk_handoff_delta(int d) { g_pk_handoff_delta = d >= 0 && d <= 8 ? d : 2; }
 void set_gemm_pk_split(int s) { g_pk_split_force = s >= 2 && s <= 4 ? s : 0; }
 
@@ -1222,6 +1234,7 @@ int launch_w4a16_prepack(const tce_w4a16_desc &d, void *out, hipStream_t stream,
 // 1.7 + 0.4 f; form 3 (every active CU carries eight waves) 1.5 + 0.4 f; + 3 us of launch, prologue and epilogue.
 // Scratch for the K split across workgroups (form 4): [4 KiB of tile counters][kPkSplitMaxUnits partial tiles of 64 KiB] (32 MiB + 4 KiB; 288 units until round 4).
 constexpr int kPkSplitMaxUnits = 512;
+
 size_t gemm_pk_scratch_bytes() { return 4096 + (size_t)kPkSplitMaxUnits * 65536; }
 
 // form 4 = form 1 with every tile's k-blocks cut into s runs on s workgroups (partial tiles added through the scratch area in a fixed
@@ -1282,8 +1295,15 @@ float gemm_pk_estimate_us(int M, int N, int K, int *form_out, bool has_scratch, 
     }
     int form = 1;
     float best = cost1;
-    if (cost2 < best) best = cost2, form = 2;
-    if (cost3 < best) best = cost3, form = 3;
+    // Two quartets per workgroup (forms 2 / 3): groups of 128 only.  Round 5: the groups-of-32 instantiation of form 2 returned, once in ~700 launches under load on another
+    // stream (and on some boxes on its first execution), ONE accumulator register's lanes 48-63 of a second-column tile without the first quartet's history -- device code the
+    // compiler's own hazard rules accept, not moved by full waits, gone with any change of schedule; no instantiation for groups of 128 / 64 and no one-quartet form has shown
+    // it in 10^4-10^5 launches under the same load (scripts/probes/pk_stress.py, tests/test_gpu_under_load.py).  The cause is not established, so the
+    // forms whose instruction mix it was seen in are not offered where nobody asked for them: the reference's GPU formats are groups of 128 (and 64 for the GEMV).
+    if (group_size == 128 || g_pk_x2_any_group) {
+        if (cost2 < best) best = cost2, form = 2;
+        if (cost3 < best) best = cost3, form = 3;
+    }
     if (cost4 < best) best = cost4, form = 4;
     if (cost5 < best) best = cost5, form = 5;
     // forms 6 / 7 (round 5): 256-row wave tiles (one workgroup of four waves per CU on a 256 x 128 tile), whole tiles / every tile's k range cut into s runs.
@@ -1352,6 +1372,7 @@ float gemm_pk_estimate_us(int M, int N, int K, int *form_out, bool has_scratch, 
         form = g_pk_ks;
         if (form == 4 && split == 1) form = split5 > 1 ? 5 : 1;  // "cut the k range": whichever of the two cut forms applies
         if (form == 7 && split7 == 1) form = 6;
+        if ((form == 2 || form == 3) && group_size != 128 && !g_pk_x2_any_group) form = 1;
         if ((form >= 6 && form <= 9) && (M <= 128 || group_size != 128)) form = 1;
         if (form == 8 && (nkb < 2.f || ((int)nkb & 1))) form = 6;
         if (form >= 10 && (M <= 128 || group_size != 128 || !zero_point_8)) form = 1;
@@ -1394,6 +1415,10 @@ int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_
     const bool rows256x2 = form == 8, rows256w = form == 9;
     const bool wide = form >= 10 && form <= 15, widex2 = form == 11, wide3 = form == 13 || form == 14, wide512 = form == 15;
     const bool handoff_form = form == 4 && split == 2 && g_pk_handoff;
+    // Two workgroups of the one-quartet wide form share a CU, a wave of each on every SIMD, with nothing tying their progress: half of them (a CU's first dispatch round) run at
+    // s_setprio 2 for the whole kernel -- 2048 x 11008 x 4096 162 -> 156 us, 3072 rows 260.4 -> 255.9, 4096 x 14336 x 4096 384-391 -> 379 (profiles/r5/gemm_pk_prio_ab.jsonl: whichever half,
+    // whichever level); nothing for the forms whose two quartets share barriers, nothing for the narrow forms.  Priorities do not touch the arithmetic.
+    g.prio = g_pk_prio >= 0 ? g_pk_prio : ((form == 10 || form == 12) ? 1 : 0);
     if (form == 4 || form == 5 || form == 7 || form == 12) {
         form = 1;
         g.split_s = split;
@@ -1465,6 +1490,7 @@ int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_
             default: return TCE_ERR_BAD_ARG;
         }
     } else if (rows256) e = launch_pk256<7>(g, stream);  // (groups of 128 only: gemm_pk_estimate_us offers forms 6 / 7 for no other group size)
+    // (forms 2 / 3: groups of 128 only, see gemm_pk_estimate_us; the other instantiations stay reachable for the probe that shows why -- tce_w4a16_set_debug_mode(6262))
     else if (ks == 3) e = lg == 7 ? launch_pk<1, 7, 0, 2>(g, stream) : (lg == 6 ? launch_pk<1, 6, 0, 2>(g, stream) : launch_pk<1, 5, 0, 2>(g, stream));
     else if (ks == 2) e = lg == 7 ? launch_pk<2, 7>(g, stream) : (lg == 6 ? launch_pk<2, 6>(g, stream) : launch_pk<2, 5>(g, stream));
     else e = lg == 7 ? launch_pk<1, 7>(g, stream) : (lg == 6 ? launch_pk<1, 6>(g, stream) : launch_pk<1, 5>(g, stream));
