@@ -7,6 +7,7 @@ without the first quartet's history (profiles/r5/pk_form2_g32_first_launch.txt).
 shown it, and it runs every other form and family the same way.  The first result of each case is also checked against the oracle (packed GEMM) -- the other families'
 parity lives in their own test files."""
 import ctypes as C
+import os
 import time
 
 import numpy as np
@@ -17,7 +18,7 @@ from conftest import w4a16_close
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
-SECONDS = 1.5  # per case
+SECONDS = float(os.environ.get("TCE_UNDER_LOAD_SECONDS", "1.5"))  # per case (a soak: TCE_UNDER_LOAD_SECONDS=10 python -m pytest tests/test_gpu_under_load.py -m gpu)
 
 
 @pytest.fixture(scope="module")
@@ -172,3 +173,56 @@ def test_w8a8_gemm_under_load(dev):
 
     rounds, bad, _ = repeat_under_load(dev, launch, lambda: [s_[4] for s_ in sets])
     assert rounds > 50 and bad == 0, f"{bad} of {rounds} rounds differ"
+
+
+def test_prompt_and_chunk_through_decoder_layers_under_load(dev):
+    """512 prompt rows (the full-size prefill GEMMs -- q/k/v, o_proj + residual, gate/up with the pair epilogue, down_proj at K = 14336 --, the prefill attention, the norms) and an
+    8-row chunk behind them (the small-batch kernels), through two Llama-3-8B-shaped layers."""
+    from tinychatengine_amd.decode import SHAPES
+    from tinychatengine_amd.decoder_block import DecoderBlock
+    shape = SHAPES["llama3-8b"]
+    heads, hd, ctx_max = shape.hidden // 128, 128, 1024
+    ang = np.random.default_rng(0).uniform(0, 2 * np.pi, (ctx_max, hd // 2))
+    cos = torch.from_numpy(np.concatenate([np.cos(ang), np.cos(ang)], axis=1).astype(np.float16)).to(dev)
+    sin = torch.from_numpy(np.concatenate([np.sin(ang), np.sin(ang)], axis=1).astype(np.float16)).to(dev)
+    kv_heads = shape.qkv[1] // 128 if len(shape.qkv) == 3 else heads
+    blocks = [DecoderBlock(shape.hidden, heads, shape.ffn, ctx_max, dev, cos, sin, seed=300 + i, kv_heads=kv_heads).prepare_prefill() for i in range(2)]
+    rows0 = (torch.randn(512, shape.hidden, device=dev) * 0.5).to(torch.float16)
+    chunk0 = (torch.randn(8, shape.hidden, device=dev) * 0.5).to(torch.float16)
+    rows, chunk = rows0.clone(), chunk0.clone()
+
+    def launch():
+        rows.copy_(rows0)
+        chunk.copy_(chunk0)
+        for b in blocks:
+            b.prefill(rows, 0)
+        for b in blocks:
+            b.prefill(chunk, 512)
+
+    rounds, bad, first = repeat_under_load(dev, launch, lambda: [rows, chunk], seconds=SECONDS + 1.0)
+    assert all(bool(torch.isfinite(f.float()).all().item()) for f in first)
+    assert rounds > 30 and bad == 0, f"{bad} of {rounds} rounds differ from the first"
+
+
+def test_opt_int8_layer_under_load(dev):
+    """An OPT-125M-shaped W8A8 decoder layer (LayerNormQ fused into the projections, the int8 attention, fc1 / fc2): a 108-row prompt and a decode step."""
+    from tinychatengine_amd.opt_layer import Int8OPTDecoderLayer
+    embed, heads, ffn, max_keys = 768, 12, 3072, 256
+    layer = Int8OPTDecoderLayer(embed, heads, ffn, max_keys, 108, dev, seed=11)
+    g = torch.Generator(device=dev).manual_seed(2)
+    h0 = torch.empty(108, embed, device=dev).normal_(0, 2, generator=g)
+    h1 = torch.empty(1, embed, device=dev).normal_(0, 2, generator=g)
+    mask0 = torch.zeros(108, 108, device=dev)
+    mask0.masked_fill_(torch.ones(108, 108, device=dev, dtype=torch.bool).triu(1), float(np.finfo(np.float32).min))
+    mask1 = torch.zeros(1, 109, device=dev)
+    a, b = h0.clone(), h1.clone()
+
+    def launch():
+        a.copy_(h0)
+        b.copy_(h1)
+        layer.step(a, 0, mask0)
+        layer.step(b, 108, mask1)
+
+    rounds, bad, first = repeat_under_load(dev, launch, lambda: [a, b])
+    assert all(bool(torch.isfinite(f).all().item()) for f in first)
+    assert rounds > 50 and bad == 0, f"{bad} of {rounds} rounds differ from the first"
