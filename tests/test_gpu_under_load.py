@@ -226,3 +226,18 @@ def test_opt_int8_layer_under_load(dev):
     rounds, bad, first = repeat_under_load(dev, launch, lambda: [a, b])
     assert all(bool(torch.isfinite(f).all().item()) for f in first)
     assert rounds > 50 and bad == 0, f"{bad} of {rounds} rounds differ from the first"
+
+
+def test_headline_plan_replay_under_load(dev):
+    """bench.py's timed path -- the decode token's W4A16 launches on the packed copies as ONE graph replay (tce_plan) -- on four Llama-3-8B-shaped layers + lm_head."""
+    from tinychatengine_amd.decode import SHAPES, DecodeLinears
+    dl = DecodeLinears(SHAPES["llama3-8b"], device=dev, layers=4, prepack=True)
+    plan = dl.make_plan()
+    outs = [*dl.out_qkv, dl.out_o, dl.out_gate, dl.out_up, dl.out_down, dl.logits]
+    try:
+        rounds, bad, first = repeat_under_load(dev, lambda: plan.launch(torch.cuda.current_stream().cuda_stream), lambda: outs)
+        plan.status()
+    finally:
+        plan.close()
+    assert all(bool(torch.isfinite(f.float()).all().item()) for f in first)
+    assert rounds > 50 and bad == 0, f"{bad} of {rounds} replays differ from the first"
