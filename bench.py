@@ -208,7 +208,7 @@ def other_configs_leg(torch, dev):
     from tinychatengine_amd.linear import Linear_half_int4
     L = capi.lib()
 
-    def time_graph(fn, launches, reps=3):
+    def time_graph(fn, launches, reps=int(os.environ.get("TCE_BENCH_GEMM_REPS", "8"))):
         g = torch.cuda.CUDAGraph()
         s = torch.cuda.Stream()
         with torch.cuda.stream(s):
@@ -219,13 +219,16 @@ def other_configs_leg(torch, dev):
         for _ in range(8):  # burn-in: the first replays after allocating fresh weights run ~10 % slow
             g.replay()
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            g.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) * 1e3 / (reps * launches)
+        samples = []
+        for _ in range(3):  # (round 5: three samples of `reps` replays, the median -- one sample of 3 x 16 launches moved by +-5 % from run to run)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            samples.append(e0.elapsed_time(e1) * 1e3 / (reps * launches))
+        return sorted(samples)[1]
 
     out = {"w4a16_prefill_gemm_M512": [], "w4a16_prefill_gemm_M2048": [], "w4a16_prefill_gemm_M4096": [], "w8a8_opt125m": []}
     scratch = torch.zeros(int(L.tce_w4a16_gemm_scratch_bytes()), dtype=torch.uint8, device=dev)  # lets the pre-packed GEMM split K across workgroups

@@ -1065,7 +1065,7 @@ thread_local int g_pk_handoff_delta = 2;   // k-blocks run 0 of a hand-off is sh
 thread_local int g_pk_x2_any_group = 0;  // probes only (debug mode 6262 / 6263): forms 2 / 3 for groups of 64 / 32 as well
 thread_local int g_pk_prio = -1;  // -1: the rule below (the wide form with one quartet per tile); 0 .. 4 forced (tce_w4a16_set_debug_mode(696 / 697 / 6972 .. 6974; 698: the rule))
 thread_local int g_pk_handoff = 1;         // 1: a k range cut in two runs is a directed hand-off (tce_w4a16_set_debug_mode(694): the last-arriver exchange, for the A/B)
-constexpr float kPkHandoffUs = 3.5f;       // run 1's read of run 0's tile + what is left of run 0's write-through when run 1 arrives  [first guess]
+constexpr float kPkHandoffUs = 5.0f;       // run 1's read of run 0's tile + what is left of run 0's write-through when run 1 arrives; fitted with the weights coming from HBM (scripts/probes/gemm_pk_handoff_cold_ab.py: 512 x 4096 x 4096 26.15 -> 24.85 us; at K = 11008 two handed-off runs take 54.55, four runs through the last arriver 53.5 -- the model keeps four there)
 thread_local int g_pk_wide_auto = 1;                    // 1: the dispatcher may pick the wide forms 10 / 11 / 12 by itself (tce_w4a16_set_debug_mode(692): never)
 // fitted to profiles/r5/gemm_pkw_sweep.jsonl: 2048 x 4096 x 4096 (256 tiles, one per CU) 68.1 us; 4096 x 4096 x 4096 (512 tiles, two per CU) 112.8 us; two quartets on one tile 62.7 / 147.0 us at K = 4096 / 11008
 constexpr float kPkWideAloneUs = 2.02f;    // wide form: one quartet alone on its CU walking a k-block (128 MFMAs per wave)
