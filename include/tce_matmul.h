@@ -555,7 +555,17 @@ TCE_API int tce_w4a16_set_gemv_i8(int mode, int tiles_per_wave);
  *   2900+w   fast attention step: waves per workgroup, w in {4, 8, 16} (2900: the default, 4)
  *   2920+r   fast attention step, grouped queries: query heads per workgroup, r in {1, 2, 4} (2920: the rule, 1)
  *   3000+g   fast attention step: workgroups the key range is cut for (3000: the fitted per-context rule, the default)
- * Every setting computes correct results except GEMV modes 1, 3, 4. */
+ * Round 5 (the full list is the dispatch in csrc/tce_capi.hip, one commented `if` per range):
+ *   66..69, 672..674, 2669, 690 / 691   pre-packed GEMM, 256-row wave tiles: whole tiles / k range cut / the tile shared by two quartets / 256 x 256 tiles; the dispatcher may pick them (691) or not (690)
+ *   2670..2675, 2682..2684, 692 / 693   pre-packed GEMM, the wide forms (128 rows x 64 / 48 columns per wave) on 128 x 256 / 192 / 512 tiles, their k range cut in 2 / 3 / 4; offered (693) or not (692)
+ *   694 / 695, 6950+d                   a k range cut in two runs: both meet at the counter (694) / run 0 hands its tile to run 1 (695, the default); run 0 shorter by d k-blocks (default 2)
+ *   696 / 697 / 698, 6972..6974         the two waves of a SIMD at different priorities: off / on / the launcher's rule (default); level 3 / 1 / chosen by slot parity
+ *   2600+a, 26000+a                     the 256-row / wide form with parts of the loop switched off (as 600+a; 128 / 256: where the refill is issued); outputs meaningless
+ *   6262 / 6263                         probes only: the two-quartet 128-row forms for groups of 64 / 32 as well (the dispatcher keeps them to groups of 128) / off
+ *   170..179, 180..188                  W8A8: the 64 x 64 tile with 8 k-steps in flight (quartets forced / off); a tile's k-steps cut across workgroups (180 the rule, 181 off, 182.. runs)
+ *   2700..2899, 2950..2968, 2930 / 2931 prefill attention: block pairing, waves x row tiles; fast attention step without its combine (2931: timing only, the output is NOT written)
+ *   15000 / 15001, 50000+..             plans: graph replay / eager issue of a stream-ordered plan; overlapped plans' branches and ring slots
+ * Every setting computes correct results except GEMV modes 1, 3, 4, the "switched off" ablations (600+a, 2600+a, 26000+a), 83 and 2931. */
 TCE_API int tce_w4a16_set_debug_mode(int mode);
 /* The same knobs per kernel family, by name (round 4: one numbered mode space for every family had already produced an A/B that compared a setting with itself, and
  * a mode of one family landing in another's range).  Per host thread (0.1.10), for tuning sweeps and tests; 0 everywhere = the fitted rules.  Every setting computes the same results.
