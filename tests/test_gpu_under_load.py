@@ -63,6 +63,7 @@ def repeat_under_load(dev, launch, results, seconds=SECONDS):
         if not all(torch.equal(r, f) for r, f in zip(results(), first)):
             bad += 1
     torch.cuda.synchronize()
+    print(f"[under load] {rounds} rounds x {len(first)} results, {bad} rounds differing from the first", flush=True)  # (pytest -s shows it; the soak's log is kept under profiles/)
     return rounds, bad, first
 
 
