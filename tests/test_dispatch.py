@@ -81,3 +81,32 @@ def test_attention_step_cut_rule():
                 assert chunk == 512
     for keys, want in ((512, (4,)), (640, (4,)), (641, (6, 7, 8)), (1024, (8,)), (2048, (8,))):  # grouped queries, 32 over 8
         assert capi.describe_attention_step(32, keys, 8)["chunks"] in want, keys
+
+
+def _pk(M, N, K, G=128, z8=True, scratch=True):
+    # a descriptor that carries a packed copy (and the scratch area): the query reads no memory
+    return capi.W4A16Desc(M=M, N=N, K=K, group_size=G, A=16, qweight=16, scales=16, zeros=16, C=16, prepacked=4096, scratch=8192 if scratch else None,
+                          flags=capi.TCE_W4_ZERO_POINT_IS_8 if z8 else 0)
+
+
+def test_packed_prefill_dispatch_rules_of_round_5():
+    """The cost model's choices the GPU tests also see (tests/test_gpu_w4a16_pk.py), held here without a GPU: which form of the packed prefill GEMM a shape is sent to."""
+    d = capi.describe_dispatch
+    # few tiles: the k range of every 128 x 128 tile cut across workgroups -- two runs (a directed hand-off) at K = 4096, four through the last arriver at K = 11008
+    assert "tile=128x128 quartets=1 ksplit=2 " in d(_pk(512, 4096, 4096)), d(_pk(512, 4096, 4096))
+    assert "tile=128x128 quartets=1 ksplit=4 " in d(_pk(512, 4096, 11008)), d(_pk(512, 4096, 11008))
+    assert "ksplit" not in d(_pk(512, 4096, 4096, scratch=False))  # no scratch area, no cut
+    # the wide forms (128 rows x 64 / 48 columns per wave): linears whose zero points are all 8, groups of 128
+    assert "tile=128x192 wave=128x48 quartets=2" in d(_pk(512, 11008, 4096))
+    assert "tile=128x256 wave=128x64 quartets=2" in d(_pk(2048, 4096, 4096))
+    assert "tile=128x256 wave=128x64 quartets=1" in d(_pk(2048, 11008, 4096))
+    assert "tile=128x512 wave=128x64" in d(_pk(4096, 4096, 4096))
+    for shape in ((512, 11008, 4096), (2048, 4096, 4096), (4096, 4096, 4096)):
+        assert "wave=" not in d(_pk(*shape, z8=False)), d(_pk(*shape, z8=False))  # real zero points: the narrow forms
+        assert d(_pk(*shape, z8=False)).startswith("gemm-pk")
+    # two quartets per workgroup on the narrow body: groups of 128 only (DESIGN.md section 3.2: the groups-of-32 instantiation's lost accumulator lanes)
+    for (M, N, K) in ((192, 200, 512), (700, 392, 3072), (1024, 4096, 4096), (256, 2048, 1024), (384, 1024, 4096)):
+        for G in (64, 32):
+            s = d(_pk(M, N, K, G=G))
+            assert s.startswith("gemm-pk") and "quartets=1" in s and f"group={G}" in s, s
+    assert "quartets=2" in d(_pk(1024, 4096, 4096, z8=False))  # ... and still offered there for groups of 128
