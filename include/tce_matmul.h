@@ -97,7 +97,10 @@ typedef struct tce_w4a16_desc {
                                              bytes ZEROED once by the caller (every call leaves them zero): lets the pre-packed GEMM cut the k range of
                                              a launch with few tiles (M = 512 at N = 4096 is 128 tiles for 256 CUs) across workgroups
                                              and add the partial tiles in a fixed order.  One scratch area per stream that runs such
-                                             calls concurrently; calls on one stream may share it. */
+                                             calls concurrently; calls on one stream may share it.  (0.1.10: a range cut in TWO runs is a
+                                             directed hand-off -- run 1 waits, for a bounded number of polls, for the tile of run 0, which is
+                                             dispatched before it on the same XCD's queue; the last word of the first 4096 bytes counts waits
+                                             that ran out.  It has never been seen other than zero, and a caller that wants to know reads it.) */
 } tce_w4a16_desc;
 
 /* flags */
