@@ -5,7 +5,7 @@ Why this file exists (round 5): one instantiation of the packed prefill GEMM (tw
 run on an idle chip and still returned, about once in 700 launches under such load -- and on some boxes on its first execution --, one accumulator register's lanes 48-63
 without the first quartet's history (profiles/r5/pk_form2_g32_first_launch.txt).  That instantiation is no longer offered by the dispatcher; this test is what would have
 shown it, and it runs every other form and family the same way.  The first result of each case is also checked against the oracle (packed GEMM) -- the other families'
-parity lives in their own test files."""
+parity lives in their own test files.  (The file name sorts last on purpose: under `pytest -x` everything else has reported before these timing-dependent cases run.)"""
 import ctypes as C
 import os
 import time
@@ -18,7 +18,7 @@ from conftest import w4a16_close
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
-SECONDS = float(os.environ.get("TCE_UNDER_LOAD_SECONDS", "1.5"))  # per case (a soak: TCE_UNDER_LOAD_SECONDS=10 python -m pytest tests/test_gpu_under_load.py -m gpu)
+SECONDS = float(os.environ.get("TCE_UNDER_LOAD_SECONDS", "1.5"))  # per case (a soak: TCE_UNDER_LOAD_SECONDS=10 python -m pytest tests/test_gpu_zz_under_load.py -m gpu)
 
 
 @pytest.fixture(scope="module")
