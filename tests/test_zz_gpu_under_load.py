@@ -18,7 +18,7 @@ from conftest import w4a16_close
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
-SECONDS = float(os.environ.get("TCE_UNDER_LOAD_SECONDS", "1.5"))  # per case (a soak: TCE_UNDER_LOAD_SECONDS=10 python -m pytest tests/test_gpu_zz_under_load.py -m gpu)
+SECONDS = float(os.environ.get("TCE_UNDER_LOAD_SECONDS", "1.5"))  # per case (a soak: TCE_UNDER_LOAD_SECONDS=10 python -m pytest tests/test_zz_gpu_under_load.py -m gpu)
 
 
 @pytest.fixture(scope="module")

@@ -1298,7 +1298,7 @@ float gemm_pk_estimate_us(int M, int N, int K, int *form_out, bool has_scratch, 
     // Two quartets per workgroup (forms 2 / 3): groups of 128 only.  Round 5: the groups-of-32 instantiation of form 2 returned, once in ~700 launches under load on another
     // stream (and on some boxes on its first execution), ONE accumulator register's lanes 48-63 of a second-column tile without the first quartet's history -- device code the
     // compiler's own hazard rules accept, not moved by full waits, gone with any change of schedule; no instantiation for groups of 128 / 64 and no one-quartet form has shown
-    // it in 10^4-10^5 launches under the same load (scripts/probes/pk_stress.py, tests/test_gpu_zz_under_load.py).  The cause is not established, so the
+    // it in 10^4-10^5 launches under the same load (scripts/probes/pk_stress.py, tests/test_zz_gpu_under_load.py).  The cause is not established, so the
     // forms whose instruction mix it was seen in are not offered where nobody asked for them: the reference's GPU formats are groups of 128 (and 64 for the GEMV).
     if (group_size == 128 || g_pk_x2_any_group) {
         if (cost2 < best) best = cost2, form = 2;
