@@ -871,10 +871,8 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
         //      depend on who was last -- and stores the tile.  (Same visibility
         //      rules as the fast attention step's chunk merge: acknowledged device-scope stores, then the counter, then coherent loads.)
         const int tile_lin = bid - 8 * g.full_slots;  // index among the cut tiles (holes of the grid included)
-        float4_t *mine = g.partials + ((size_t)tile_lin * split + part) * (kMT * kNT * 256);
         const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(g.partials + (size_t)tile_lin * split * (kMT * kNT * 256), 0,
                                                                                split * kMT * kNT * 256 * 16, 0x00020000);
-        (void)mine;
         if (handoff && part == 1) {
             // run 1 of a hand-off: no partial of its own leaves the registers.  Wait for run 0's (bounded: ~0.3 s of polls -- the launch then ends with this run's part
             // alone rather than hanging a queue; it has never been seen to happen), take the counter back to zero for the next launch
