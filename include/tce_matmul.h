@@ -129,7 +129,9 @@ TCE_API int tce_w4a16_forward(const tce_w4a16_desc *d, void *stream);
 /* Size-prefixed form (0.1.10): a host compiled against THIS header keeps working when a later library appends fields to the descriptor, and a later host talks to
  * this library as long as it leaves the fields this library does not know at zero.  `struct_size` = sizeof(tce_w4a16_desc_v2) as the CALLER compiled it; the library
  * copies min(struct_size, its own size) bytes into a zeroed descriptor of its own and refuses a size below the 0.1.10 layout (TCE_ERR_BAD_ARG) or non-zero bytes
- * beyond what it knows.  Same semantics as tce_w4a16_forward(&v2->desc, stream). */
+ * beyond what it knows.  `struct_size` above TCE_DESC_V2_MAX_BYTES (an uninitialised descriptor) and a non-zero `reserved0` are refused too (TCE_ERR_BAD_ARG).
+ * Same semantics as tce_w4a16_forward(&v2->desc, stream). */
+#define TCE_DESC_V2_MAX_BYTES 4096
 typedef struct tce_w4a16_desc_v2 {
     uint32_t struct_size;
     uint32_t reserved0;
@@ -564,7 +566,7 @@ TCE_API int tce_w4a16_set_gemv_i8(int mode, int tiles_per_wave);
  *   694 / 695, 6950+d                   a k range cut in two runs: both meet at the counter (694) / run 0 hands its tile to run 1 (695, the default); run 0 shorter by d k-blocks (default 2)
  *   696 / 697 / 698, 6972..6974         the two waves of a SIMD at different priorities: off / on / the launcher's rule (default); level 3 / 1 / chosen by slot parity
  *   2600+a, 26000+a                     the 256-row / wide form with parts of the loop switched off (as 600+a; 128 / 256: where the refill is issued); outputs meaningless
- *   6262 / 6263                         probes only: the two-quartet 128-row forms for groups of 64 / 32 as well (the dispatcher keeps them to groups of 128) / off
+ *   (6262 / 6263 of round 5 are gone: the two-quartet forms are offered for every group size again -- isa_lint.py RULE 1, profiles/r6/pk_lost_lanes_rule.md)
  *   170..179, 180..188                  W8A8: the 64 x 64 tile with 8 k-steps in flight (quartets forced / off); a tile's k-steps cut across workgroups (180 the rule, 181 off, 182.. runs)
  *   2700..2899, 2950..2968, 2930 / 2931 prefill attention: block pairing, waves x row tiles; fast attention step without its combine (2931: timing only, the output is NOT written)
  *   15000 / 15001, 50000+..             plans: graph replay / eager issue of a stream-ordered plan; overlapped plans' branches and ring slots

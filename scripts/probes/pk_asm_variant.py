@@ -19,6 +19,18 @@ WORK = "/tmp/asmx"
 KERNEL = "_ZN3tce12_GLOBAL__N_120w4a16_gemm_pk_kernelILi2ELi5ELi0ELi1EEEvNS0_10PkGemmArgsE"
 
 
+def pad(n):
+    """n wait states as an EVEN number of s_nop instructions (whole 8-byte units: the code behind the pad keeps its position modulo 8)"""
+    assert n >= 2 and n % 2 == 0, "an even number of wait states, at least two"
+    out, half = [], n // 2
+    for part in (half, half):
+        while part > 0:
+            out.append(f"\ts_nop {min(part, 16) - 1}")
+            part -= min(part, 16)
+    if len(out) % 2: out.append("\ts_nop 0")
+    return out
+
+
 def sh(cmd):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode:
@@ -78,8 +90,90 @@ def apply(lines, edits):
                 raise SystemExit(f"no site found for {ed}")
             for (pk, mf1, mf2) in reversed(sites):
                 at = {"A": mf1, "B": mf2, "C": mf1 + 1}[which]
-                out[at:at] = [f"\ts_nop {n - 1}"]
+                out[at:at] = pad(n)
             print(f"  {ed}: {len(sites)} site(s)", flush=True)
+        elif ed.startswith("post:"):  # N wait states behind the loop's exit (in front of the first instruction that reads an accumulator after the last MFMA)
+            n = int(ed.split(":")[1])
+            bb, ee = kernel_range(out)
+            last_mfma = max(i for i in range(bb, ee) if out[i].strip().startswith("v_mfma"))
+            at = next(i for i in range(last_mfma, ee) if out[i].strip().startswith("v_pk_mul_f32") or out[i].strip().startswith("v_mul_f32"))
+            pads = pad(n)
+            out[at:at] = pads
+            print(f"  {ed}: in front of line {at - bb} of the kernel: {out[at + len(pads)].strip()}", flush=True)
+        elif ed.startswith("postafter:"):  # N wait states behind the post-loop multiplies (in front of the wait + barrier that follow them)
+            n = int(ed.split(":")[1])
+            bb, ee = kernel_range(out)
+            last_mfma = max(i for i in range(bb, ee) if out[i].strip().startswith("v_mfma"))
+            at = next(i for i in range(last_mfma, ee) if out[i].strip().startswith("s_barrier"))
+            at = max(i for i in range(last_mfma, at) if out[i].strip().startswith("v_pk_mul_f32")) + 1
+            pads = pad(n)
+            out[at:at] = pads
+            print(f"  {ed}: behind line {at - bb - 1} of the kernel: {out[at - 1].strip()}", flush=True)
+        elif ed.startswith("postvalu:"):  # N independent vector moves (a busy vector ALU instead of an idle one) behind the loop's exit
+            n = int(ed.split(":")[1])
+            bb, ee = kernel_range(out)
+            last_mfma = max(i for i in range(bb, ee) if out[i].strip().startswith("v_mfma"))
+            at = next(i for i in range(last_mfma, ee) if out[i].strip().startswith("v_pk_mul_f32") or out[i].strip().startswith("v_mul_f32"))
+            out[at:at] = ["\tv_mov_b32_e32 v232, v233"] * n
+            print(f"  {ed}: {n} v_mov in front of {out[at + n].strip()}", flush=True)
+        elif ed in ("unpk", "unpk1", "spread"):  # the post-loop packed multiplies as two plain ones each (unpk: all of them; unpk1: those that take the scale pair's HIGH register for both products) / one wait state between them
+            bb, ee = kernel_range(out)
+            last_mfma = max(i for i in range(bb, ee) if out[i].strip().startswith("v_mfma"))
+            bar = next(i for i in range(last_mfma, ee) if out[i].strip().startswith("s_barrier"))
+            cnt = 0
+            for i in range(bar, last_mfma, -1):
+                t = out[i].split(";")[0].strip()
+                m = re.match(r"v_pk_mul_f32 v\[(\d+):(\d+)\], v\[(\d+):(\d+)\], v\[(\d+):(\d+)\] (op_sel_hi:\[1,0\]|op_sel:\[0,1\])$", t)
+                if not m: continue
+                d0, s0, e0 = int(m.group(1)), int(m.group(3)), int(m.group(5))
+                hi = m.group(7) == "op_sel:[0,1]"
+                if ed == "spread":
+                    out[i + 1:i + 1] = ["\ts_nop 0"]
+                    cnt += 1
+                    continue
+                if ed == "unpk1" and not hi: continue
+                e = e0 + 1 if hi else e0
+                assert d0 != s0 + 1, t
+                out[i:i + 1] = [f"\tv_mul_f32_e32 v{d0}, v{s0}, v{e}", f"\tv_mul_f32_e32 v{d0 + 1}, v{s0 + 1}, v{e}"]
+                cnt += 1
+            print(f"  {ed}: {cnt} instruction(s)", flush=True)
+        elif ed == "hipair":  # the post-loop multiplies that take the scale pair's HIGH register for both products read a pair {hi, hi} through the LOW-register form instead (no op_sel:[0,1])
+            bb, ee = kernel_range(out)
+            last_mfma = max(i for i in range(bb, ee) if out[i].strip().startswith("v_mfma"))
+            bar = next(i for i in range(last_mfma, ee) if out[i].strip().startswith("s_barrier"))
+            first = None
+            cnt = 0
+            for i in range(last_mfma, bar):
+                t = out[i].split(";")[0].strip()
+                m = re.match(r"(v_pk_mul_f32 v\[\d+:\d+\], v\[\d+:\d+\]), v\[(\d+):(\d+)\] op_sel:\[0,1\]$", t)
+                if not m: continue
+                if first is None: first, hi = i, int(m.group(3))
+                out[i] = f"\t{m.group(1)}, v[232:233] op_sel_hi:[1,0]"
+                cnt += 1
+            out[first:first] = [f"\tv_mov_b32_e32 v232, v{hi}", f"\tv_mov_b32_e32 v233, v{hi}"]
+            print(f"  {ed}: {cnt} instruction(s)", flush=True)
+        elif ed.startswith("allB:"):  # s_nop N-1 in front of EVERY MFMA of the loop whose accumulator input was written by a vector instruction fewer than `within` wait states earlier
+            n = int(ed.split(":")[1])
+            within = int(ed.split(":")[2]) if ed.count(":") > 1 else 8
+            bb, ee = kernel_range(out)
+            ins = [i for i in range(bb, ee) if out[i].startswith("\t") and not out[i].strip().startswith((".", ";"))]
+            hits = []
+            for k, i in enumerate(ins):
+                t = out[i].split(";")[0].strip()
+                if not t.startswith("v_mfma"): continue
+                m = re.findall(r"v\[(\d+):(\d+)\]", t)
+                lo, hi = int(m[-1][0]), int(m[-1][1])
+                d = 0
+                for kk in range(k - 1, max(0, k - 14), -1):
+                    tt = out[ins[kk]].split(";")[0].strip()
+                    mm = re.match(r"(v_pk_mul_f32|v_mul_f32_e64|v_mul_f32_e32) v\[?(\d+)", tt)
+                    if mm and lo <= int(mm.group(2)) <= hi:
+                        if d < within: hits.append(i)
+                        break
+                    d += int(tt.split()[1]) + 1 if tt.startswith("s_nop") else 1
+            for i in reversed(hits):
+                out[i:i] = pad(n)
+            print(f"  {ed}: {len(hits)} MFMA(s) padded", flush=True)
         else:
             raise SystemExit(f"unknown edit {ed}")
     return out

@@ -11,9 +11,8 @@ from conftest import w4a16_close
 from tinychatengine_amd import capi
 from oracle.oracle import Oracle  # (the checker: this probe is test infrastructure)
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 4.0
-# X2ANY=1: the two-quartet forms for groups of 64 / 32 too (debug mode 6262) -- the instantiation this probe was written for; the dispatcher keeps those forms to groups of 128
+# (round 6: the two-quartet forms are offered for every group size again -- mode 62 forces form 2 on groups of 32 directly)
 dev = torch.device("cuda:0"); L = capi.lib(); oracle = Oracle()
-if os.environ.get("X2ANY"): capi.check(L.tce_w4a16_set_debug_mode(6262))
 side = torch.cuda.Stream()
 big_a = torch.empty(256 << 20, dtype=torch.uint8, device=dev); big_b = torch.empty_like(big_a)
 small = [torch.randn(1 << 16, device=dev) for _ in range(8)]

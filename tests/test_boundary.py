@@ -72,6 +72,16 @@ def test_size_prefixed_descriptors_validate_their_size(built):
     w.struct_size = 12
     assert L.tce_w8a8_matmul_v2(C.byref(w), None) == -1
     assert L.tce_w4a16_forward_v2(None, None) == -1
+    #  an uninitialised size is refused instead of being walked (0xFFFFFFFF would read 4 GiB past the caller's struct); reserved0 must be zero
+    v2 = capi.W4A16DescV2()
+    v2.struct_size = 0xFFFFFFFF
+    assert L.tce_w4a16_forward_v2(C.byref(v2), None) == -1 and b"cap" in L.tce_last_error()
+    v2.struct_size = C.sizeof(capi.W4A16DescV2)
+    v2.reserved0 = 7
+    assert L.tce_w4a16_forward_v2(C.byref(v2), None) == -1 and b"reserved0" in L.tce_last_error()
+    w = capi.W8A8DescV2()
+    w.struct_size = 4097
+    assert L.tce_w8a8_matmul_v2(C.byref(w), None) == -1 and b"cap" in L.tce_last_error()
 
 
 def test_argument_validation_needs_no_gpu(built):

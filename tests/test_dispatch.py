@@ -104,9 +104,10 @@ def test_packed_prefill_dispatch_rules_of_round_5():
     for shape in ((512, 11008, 4096), (2048, 4096, 4096), (4096, 4096, 4096)):
         assert "wave=" not in d(_pk(*shape, z8=False)), d(_pk(*shape, z8=False))  # real zero points: the narrow forms
         assert d(_pk(*shape, z8=False)).startswith("gemm-pk")
-    # two quartets per workgroup on the narrow body: groups of 128 only (the groups-of-32 instantiation's lost accumulator lanes)
-    for (M, N, K) in ((192, 200, 512), (700, 392, 3072), (1024, 4096, 4096), (256, 2048, 1024), (384, 1024, 4096)):
+    # two quartets per workgroup on the narrow body: every group size again (round 5 kept them to groups of 128 for the groups-of-32 instantiation's lost accumulator
+    # lanes; round 6 found the instruction form behind them, removed it and made the build refuse it: isa_lint.py RULE 1, profiles/r6/pk_lost_lanes_rule.md)
+    for (M, N, K, q) in ((192, 200, 512, 2), (700, 392, 3072, 1), (1024, 4096, 4096, 2), (256, 2048, 1024, 2), (384, 1024, 4096, 1)):
         for G in (64, 32):
             s = d(_pk(M, N, K, G=G))
-            assert s.startswith("gemm-pk") and "quartets=1" in s and f"group={G}" in s, s
-    assert "quartets=2" in d(_pk(1024, 4096, 4096, z8=False))  # ... and still offered there for groups of 128
+            assert s.startswith("gemm-pk") and f"quartets={q}" in s and f"group={G}" in s, s
+    assert "quartets=2" in d(_pk(1024, 4096, 4096, z8=False))

@@ -260,11 +260,12 @@ def test_i8_rmsnorm_prologue_fused(dev, oracle, Ns, K, pairs):
         assert torch.equal(o, _fwd(l, xn, flags=flags)), "fused prologue != rmsnorm launch + plain launch"
 
 
-@pytest.mark.parametrize("N,K,zeros", [(4096, 4096, False), (4096, 11008, False), (264, 1408, False), (5120, 13824, False), (11008, 4096, False), (4096, 4096, True), (1024, 28672, False)])
+@pytest.mark.parametrize("N,K,zeros", [(4096, 4096, False), (4096, 11008, False), (264, 1408, False), (5120, 13824, False), (11008, 4096, False), (4096, 4096, True), (1024, 28672, False), (1024, 28672, True)])
 def test_i8_residual_plus_next_rmsnorm_fused(dev, oracle, N, K, zeros):
     """tce_w4a16_forward_residual_rmsnorm (o_proj / down_proj + residual add + the RMSNorm that follows, Int4llamaDecoderLayer.cu:86-99, 107-108): the residual row as
     TCE_W4_ADD_TO_C writes it and the normalised row as tce_rmsnorm_half forms it from that row -- bit for bit, launch after launch on one workspace (the counter
-    returns to zero), with a ragged last tile (N % 16 = 8), more than 1024 pieces (two per slot of the order), 16 units per wave, real zero points, and replayed from a graph."""
+    returns to zero), with a ragged last tile (N % 16 = 8), more than 1024 pieces (two per slot of the order), 16 units per wave, real zero points, and replayed from a graph.
+    (K > 16384 with general zero points has no one-launch form: the entry point serves it as the two launches it is defined by -- round 6)"""
     from tinychatengine_amd import capi
     from tinychatengine_amd.linear import rmsnorm_half
     lin, _ = _lin(oracle, dev, N, K, 128, seed=N + K, random_zeros=zeros)

@@ -239,6 +239,40 @@ def test_wave_quartets_per_tile_are_bit_exact(dev, oracle, M, N, K):
         L.tce_w4a16_set_debug_mode(70)
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 768, 3072), (108, 768, 3072), (65, 130, 208), (33, 65, 128), (70, 33, 1136), (40, 16, 64), (300, 768, 1552)])
+def test_32_row_tiles_are_bit_exact(dev, oracle, M, N, K):
+    """Round 6: the 32 x 64 tile (w8a8_mfma_kernel<KS, false, 1>: each wave 16 rows x 32 columns) that the rule takes where 64 x 64 tiles would leave most CUs without a
+    workgroup (512 x 768 x 3072: 96 -> 192 workgroups) -- forced on (debug mode 191) with 1 / 2 / 4 quartets per tile and under the rule, int8 and fp32 outputs, ragged last
+    row / column tiles, a K tail: the oracle's bytes every time."""
+    from tinychatengine_amd import capi
+    from tinychatengine_amd.matmul import MatmulOperator
+    op = MatmulOperator()
+    L = capi.lib()
+    A, B, b8, bf = _data(M, N, K, seed=K + M + 7)
+    exp = oracle.int8_matmul_bias_i8(A, B, b8, ALPHA, BETA, -128, 127, M, N, K)
+    exp32 = oracle.int8_matmul_bias_f32(A, B, bf, ALPHA, M, N, K)
+    try:
+        capi.check(L.tce_w4a16_set_debug_mode(191))
+        for mode in (71, 72, 74, 70):
+            capi.check(L.tce_w4a16_set_debug_mode(mode))
+            p, out = _params(dev, A, B, torch.int8, b8)
+            op.mat_mul_accelerator_int8_fast_2x2_32unroll(p)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), exp), f"mode {mode}: {(out.cpu().numpy() != exp).sum()} mismatches"
+            p, out = _params(dev, A, B, torch.float32, bf)
+            op.mat_mul_accelerator_int8_fast_2x2_32unroll_bfp32_ofp32(p)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy().view(np.uint32), exp32.view(np.uint32)), f"mode {mode}, fp32 output"
+        capi.check(L.tce_w4a16_set_debug_mode(190))  # the rule
+        p, out = _params(dev, A, B, torch.int8, b8)
+        op.mat_mul_accelerator_int8_fast_2x2_32unroll(p)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), exp)
+    finally:
+        L.tce_w4a16_set_debug_mode(70)
+        L.tce_w4a16_set_debug_mode(190)
+
+
 @pytest.mark.parametrize("M,N,K", [(64, 64, 64), (65, 100, 1024), (512, 768, 3072), (108, 2048, 8192), (16, 136, 1600), (9, 64, 192), (130, 70, 4160)])
 def test_deep_pipeline_tile_is_bit_exact(dev, oracle, M, N, K):
     """The 64x64 tile with eight k-steps in flight (w8a8_mfma_deep_kernel; the rule takes it for chains of 64+ steps on few tiles) forced with 1 / 2 / 4 wave quartets

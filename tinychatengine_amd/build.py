@@ -41,6 +41,18 @@ NO_VGPR_SPILL: dict[str, list[str]] = {"w8a8_lnq_fused.hip": ["lnq_w8a8_wide_ker
                                         "w4a16_gemm_pk.hip": ["w4a16_gemm_pk256_kernelILi7ELi0E", "w4a16_gemm_pk256x2_kernelILi7ELi0E", "w4a16_gemm_pkw_kernelILi7ELi0E", "w4a16_gemm_pkwx2_kernelILi7ELi0E", "w4a16_gemm_pkw3_kernelILi7ELi0E", "w4a16_gemm_pkw3x2_kernelILi7ELi0E", "w4a16_gemm_pkw512_kernelILi7ELi0E"]}  # (round 3: four forms spilled 3-34 registers under __launch_bounds__(1024))
 
 
+def _lint(src: str, obj: str) -> list[str]:
+    """ISA lint of one freshly compiled object (isa_lint.py: the rules measured on MI355X that the toolchain does not know).  A violating object is deleted and the build
+    fails: the rule is enforced on every kernel of every translation unit, not sampled by a soak test."""
+    from . import isa_lint
+    names, viol = isa_lint.lint_object(obj)
+    if viol:
+        msg = isa_lint.format_violations(obj, viol)
+        os.remove(obj)
+        raise RuntimeError(msg + f"\n(change {src} until hipcc stops emitting the form: see isa_lint.py)")
+    return names
+
+
 def _check_spills(src: str, stderr_text: str) -> None:
     name = None
     for line in stderr_text.splitlines():
@@ -87,6 +99,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             src = os.path.basename(cmd[-3])
             if src not in NO_VGPR_SPILL:
                 subprocess.check_call(cmd)
+                _lint(src, cmd[-1])
                 return
             r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
             rest, in_remark = [], False  # the compiler's other diagnostics pass through; the remarks and their source excerpts do not
@@ -107,6 +120,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             except RuntimeError:
                 os.remove(cmd[-1])  # (the object must not count as built)
                 raise
+            _lint(src, cmd[-1])
 
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
             list(pool.map(run, jobs))

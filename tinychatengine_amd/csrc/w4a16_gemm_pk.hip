@@ -162,11 +162,7 @@ __device__ __forceinline__ void pk_dma16(const void *src, void *lds_dst_wave_uni
 }
 template <int N>
 __device__ __forceinline__ void pk_wait_vmcnt() {
-#ifdef TCE_PK_VAR_VMCNT0
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-#endif
 }
 
 template <int I, int N, typename F>
@@ -256,7 +252,9 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
     const int split = (KS == 1 && NS == 1 && g.split_s > 1 && slot >= g.full_slots) ? g.split_s : 1;
     // this workgroup's run of k-blocks (the hand-off form: run 0 is two k-blocks shorter than run 1 -- about the time its write-through takes to become visible)
     const bool handoff = KS == 1 && NS == 1 && kMT == 8 && kNT == 2 && split == 2 && g.handoff != 0;
-    const int n0_h = nkb >= 8 ? (nkb - (g.handoff - 1)) / 2 : nkb / 2;  // (g.handoff = 1 + the k-blocks run 0 is shorter by)
+    // (g.handoff = 1 + the k-blocks run 0 is shorter by; never fewer than two k-blocks for run 0 -- ADVICE r5: an unclamped delta of 8 at K = 1024 left run 0 without a k-block)
+    const int n0_raw = nkb >= 8 ? (nkb - (g.handoff - 1)) / 2 : nkb / 2;
+    const int n0_h = n0_raw >= 2 ? n0_raw : (nkb >= 4 ? 2 : nkb / 2);
     const int kb_lo = handoff ? (part == 0 ? 0 : n0_h) : part * nkb / split;
     const int nloc = handoff ? (part == 0 ? n0_h : nkb - n0_h) : (part + 1) * nkb / split - kb_lo;
     const int T = (nloc + KS - 1) / KS;  // iterations (own k-blocks, the last one may be past the run for quartet 1)
@@ -429,29 +427,10 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
         for (int j = 0; j < kNT; ++j) {
             // e != 0 by construction of the table; 1-ulp reciprocal (an IEEE division is ~10 instructions per group and column tile)
             float r = e_prev[j] == 0.f ? 1.0f : e_prev[j] * __builtin_amdgcn_rcpf(e_new[j]);
-#ifdef TCE_PK_VAR_NOPS_AFTER_RCP
-            asm volatile("s_nop 7\n\tv_mov_b32 %0, %0\n\ts_nop 7" : "+v"(r));
-#endif
-#ifdef TCE_PK_VAR_MOV_AFTER_RCP
-            asm volatile("v_mov_b32 %0, %0" : "+v"(r));
-#endif
-#ifdef TCE_PK_VAR_PIN_AFTER_RCP
-            asm volatile("" : "+v"(r));
-#endif
-            // (probe-only instantiation -- two quartets, groups of 32: the dispatcher no longer offers it, see gemm_pk_estimate_us.  WITH this empty statement hipcc's schedule
-            //  shows the lost-accumulator failure under scripts/probes/pk_stress.py (X2ANY=1: 10-100 of ~8000 launches on every box tried); WITHOUT it the schedule it picks does not
-            //  (0 of 10 000) -- which says nothing about the cause, only that the evidence stays reproducible this way.  Round 4's build failed on first executions without it.)
-#ifndef TCE_PK_VAR_NO_PIN
-            if constexpr (KS == 2 && LG == 5 && ABL == 0) asm volatile("" : "+v"(r));
-#endif
             e_prev[j] = e_new[j];
             // as two-element vector products: v_pk_mul_f32, two per accumulator tile (left to itself hipcc emits four v_mul_f32 here --
             // 64 instead of 32 VALU instructions per group beside the MFMAs -- while it packs the same loop after the k-loop)
-#ifdef TCE_PK_VAR_SCALAR_RESCALE
-            if constexpr (true) {
-#else
             if constexpr (ABL & 64) {
-#endif
 #pragma unroll
                 for (int i = 0; i < kMT; ++i)
 #pragma unroll
@@ -616,14 +595,7 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
 #pragma unroll
             for (int j = 0; j < kNT; ++j) asm volatile("" ::"v"(bf[(s + 1) & 1][j]));
         }
-#ifdef TCE_PK_VAR_LGKM
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-#ifdef TCE_PK_VAR_NO_SCHED
-        if constexpr (false) static_for<0, kMT * kNT>([&](auto u_c) {
-#else
         if constexpr (AB == 0) static_for<0, kMT * kNT>([&](auto u_c) {
-#endif
             constexpr int u = decltype(u_c)::value;
             if constexpr (s % SPG == 0) sched_group<0x002, (ABL & 64) ? 4 : 2>();   // the tile's two packed multiplies, then its MFMA
             sched_group<0x008, 1>();                               // MFMA
@@ -807,31 +779,27 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
 #undef TCE_PK_GET
 #undef TCE_PK_GET_C
     pk_wait_vmcnt<0>();
-#ifdef TCE_PK_VAR_EPREV_NOPS
-    static_assert(kNT >= 2, "");
-    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(e_prev[0]), "+v"(e_prev[1]) : : "memory");
-#endif
-#ifdef TCE_PK_VAR_ACC_NOPS
-    // every accumulator named: the multiplies below cannot be hoisted above the wait states
-#pragma unroll
-    for (int i = 0; i < kMT; ++i)
-#pragma unroll
-        for (int j = 0; j < kNT; ++j) asm volatile("" : "+v"(acc[i][j]));
-    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < kMT; ++i)
-#pragma unroll
-        for (int j = 0; j < kNT; ++j) asm volatile("" : "+v"(acc[i][j]));
-#endif
     __syncthreads();  // every wave's last (clamped, redundant) DMAs have landed: the ring may be overwritten
 
     // ---- into true units: e of the quartet's last group ----
+    // Round 6, the lost-lanes defect (profiles/r6/pk_lost_lanes_rule.md): hipcc packs these multiplies two by two (v_pk_mul_f32) and, with e_prev[0..] living in 64-bit
+    // register pairs, broadcast the ODD register of a pair through `op_sel:[0,1]` -- the low product takes the second source's HIGH register.  On gfx950 that form's low
+    // product came back as 0.0 in lanes 48-63 once in ~10^2-10^3 launches (always behind a long enough idle stretch of the wave's vector ALU): the accumulator register of
+    // one column tile lost its whole history.  The scale of each column tile is therefore made an independent 32-bit value here (the empty statement): the packed multiply
+    // then reads it as the LOW register of its pair (op_sel_hi:[1,0], the form the loop's rescale has always had and that never failed), and build.py's ISA lint
+    // (isa_lint.py) refuses any object that still holds a packed-f32 instruction with a low-half op_sel.
+    float e_last[kNT];
+#pragma unroll
+    for (int j = 0; j < kNT; ++j) {
+        e_last[j] = e_prev[j];
+        asm volatile("" : "+v"(e_last[j]));
+    }
 #pragma unroll
     for (int j = 0; j < kNT; ++j)
 #pragma unroll
         for (int i = 0; i < kMT; ++i)
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) acc[i][j][rr] *= e_prev[j];
+            for (int rr = 0; rr < 4; ++rr) acc[i][j][rr] *= e_last[j];
     // (the products stand in binary32 registers before anything converts them: in the 128 x 512 form hipcc folded this multiply into the epilogue's conversion --
     //  v_fma_mixlo_f16, ONE rounding from the exact product to binary16 instead of two -- and 0.007 % of the outputs differed from the other forms' by an ulp;
     //  every form of this kernel rounds the same way; tests/test_gpu_w4a16_pk.py holds every wide form to the 128 x 128 form's bits)
@@ -1060,7 +1028,6 @@ thread_local int g_pk256_auto = 1;      // 0: the dispatcher never picks the 256
 constexpr float kPk256wUsPerKBlock = 4.3f;  // eight waves of a 256 x 256 tile walking one k-block
 constexpr float kPk256x2UsPerPair = 3.45f;   // two quartets sharing a CU walking one 256-row k-block each
 thread_local int g_pk_handoff_delta = 2;   // k-blocks run 0 of a hand-off is shorter than run 1 (tce_w4a16_set_debug_mode(6950 + d))
-thread_local int g_pk_x2_any_group = 0;  // probes only (debug mode 6262 / 6263): forms 2 / 3 for groups of 64 / 32 as well
 thread_local int g_pk_prio = -1;  // -1: the rule below (the wide form with one quartet per tile); 0 .. 4 forced (tce_w4a16_set_debug_mode(696 / 697 / 6972 .. 6974; 698: the rule))
 thread_local int g_pk_handoff = 1;         // 1: a k range cut in two runs is a directed hand-off (tce_w4a16_set_debug_mode(694): the last-arriver exchange, for the A/B)
 constexpr float kPkHandoffUs = 5.0f;       // run 1's read of run 0's tile + what is left of run 0's write-through when run 1 arrives; fitted with the weights coming from HBM (scripts/probes/gemm_pk_handoff_cold_ab.py: 512 x 4096 x 4096 26.15 -> 24.85 us; at K = 11008 two handed-off runs take 54.55, four runs through the last arriver 53.5 -- the model keeps four there)
@@ -1180,7 +1147,6 @@ void set_gemm_pk_ablation(int abl) { g_pk_abl = abl; }
 void set_gemm_pk256_auto(int on) { g_pk256_auto = on ? 1 : 0; }
 void set_gemm_pk_wide_auto(int on) { g_pk_wide_auto = on ? 1 : 0; }
 void set_gemm_pk_handoff(int on) { g_pk_handoff = on ? 1 : 0; }
-void set_gemm_pk_x2_any_group(int on) { g_pk_x2_any_group = on ? 1 : 0; }
 void set_gemm_pk_prio(int on) { g_pk_prio = on >= 0 && on <= 4 ? on : -1; }
 void set_gemm_pk_handoff_delta(int d) { g_pk_handoff_delta = d >= 0 && d <= 8 ? d : 2; }
 void set_gemm_pk_split(int s) { g_pk_split_force = s >= 2 && s <= 4 ? s : 0; }
@@ -1293,15 +1259,13 @@ float gemm_pk_estimate_us(int M, int N, int K, int *form_out, bool has_scratch, 
     }
     int form = 1;
     float best = cost1;
-    // Two quartets per workgroup (forms 2 / 3): groups of 128 only.  Round 5: the groups-of-32 instantiation of form 2 returned, once in ~700 launches under load on another
-    // stream (and on some boxes on its first execution), ONE accumulator register's lanes 48-63 of a second-column tile without the first quartet's history -- device code the
-    // compiler's own hazard rules accept, not moved by full waits, gone with any change of schedule; no instantiation for groups of 128 / 64 and no one-quartet form has shown
-    // it in 10^4-10^5 launches under the same load (scripts/probes/pk_stress.py, tests/test_zz_gpu_under_load.py).  The cause is not established, so the
-    // forms whose instruction mix it was seen in are not offered where nobody asked for them: the reference's GPU formats are groups of 128 (and 64 for the GEMV).
-    if (group_size == 128 || g_pk_x2_any_group) {
-        if (cost2 < best) best = cost2, form = 2;
-        if (cost3 < best) best = cost3, form = 3;
-    }
+    // Two quartets per workgroup (forms 2 / 3).  Round 5 took them away from groups of 64 / 32 after the groups-of-32 instantiation of form 2 returned, once in ~10^2-10^3
+    // launches under load, one accumulator register's lanes 48-63 without the first quartet's history.  Round 6 found the cause -- ONE instruction form hipcc emitted in the
+    // post-loop block (v_pk_mul_f32 with op_sel:[0,1]; isa_lint.py RULE 1, profiles/r6/pk_lost_lanes_rule.md, reproduced standalone) --, removed it from the sources and
+    // made the build refuse it; the forms are offered for every group size again (profiles/r6: 0 of 1.7e5 launches of the fixed kernel under the pads that drove the old
+    // one to 45-100 % failures).
+    if (cost2 < best) best = cost2, form = 2;
+    if (cost3 < best) best = cost3, form = 3;
     if (cost4 < best) best = cost4, form = 4;
     if (cost5 < best) best = cost5, form = 5;
     // forms 6 / 7 (round 5): 256-row wave tiles (one workgroup of four waves per CU on a 256 x 128 tile), whole tiles / every tile's k range cut into s runs.
@@ -1370,7 +1334,6 @@ float gemm_pk_estimate_us(int M, int N, int K, int *form_out, bool has_scratch, 
         form = g_pk_ks;
         if (form == 4 && split == 1) form = split5 > 1 ? 5 : 1;  // "cut the k range": whichever of the two cut forms applies
         if (form == 7 && split7 == 1) form = 6;
-        if ((form == 2 || form == 3) && group_size != 128 && !g_pk_x2_any_group) form = 1;
         if ((form >= 6 && form <= 9) && (M <= 128 || group_size != 128)) form = 1;
         if (form == 8 && (nkb < 2.f || ((int)nkb & 1))) form = 6;
         if (form >= 10 && (M <= 128 || group_size != 128 || !zero_point_8)) form = 1;
@@ -1488,7 +1451,6 @@ int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_
             default: return TCE_ERR_BAD_ARG;
         }
     } else if (rows256) e = launch_pk256<7>(g, stream);  // (groups of 128 only: gemm_pk_estimate_us offers forms 6 / 7 for no other group size)
-    // (forms 2 / 3: groups of 128 only, see gemm_pk_estimate_us; the other instantiations stay reachable for the probe that shows why -- tce_w4a16_set_debug_mode(6262))
     else if (ks == 3) e = lg == 7 ? launch_pk<1, 7, 0, 2>(g, stream) : (lg == 6 ? launch_pk<1, 6, 0, 2>(g, stream) : launch_pk<1, 5, 0, 2>(g, stream));
     else if (ks == 2) e = lg == 7 ? launch_pk<2, 7>(g, stream) : (lg == 6 ? launch_pk<2, 6>(g, stream) : launch_pk<2, 5>(g, stream));
     else e = lg == 7 ? launch_pk<1, 7>(g, stream) : (lg == 6 ? launch_pk<1, 6>(g, stream) : launch_pk<1, 5>(g, stream));

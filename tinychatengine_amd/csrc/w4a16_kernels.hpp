@@ -51,6 +51,7 @@ bool gemv_variant_exists(int rows, int wn, int wk, int depth);
 void set_gemv_debug_mode(int mode);
 void set_gemv_order(int force);
 void set_w8a8_deep(int d);          // W8A8 64 x 64 tile with 8 k-steps in flight: 0 the rule, 1 / 2 / 4 quartets forced, 9 off
+void set_w8a8_rows32(int r);        // W8A8 32 x 64 tiles (round 6): 0 the rule, 1 forced, 2 off
 void set_w8a8_big(int b);           // W8A8 128-row tiles: 0 the rule, 1 / 2 forced (128 / 64 columns), 9 off
 void set_lnq_stamps(void *p);
 void set_lnq_form(int f);           // 1: the workgroup-per-8-rows form of the LayerNormQ + W8A8 launch at every k
@@ -145,7 +146,6 @@ void set_gemm_pk256_auto(int on);  // 0: the dispatcher never picks the 256-row 
 void set_gemm_pk_wide_auto(int on);
 void set_gemm_pk_handoff_delta(int d);
 void set_gemm_pk_prio(int on);
-void set_gemm_pk_x2_any_group(int on);
 void set_gemm_pk_handoff(int on);    // 0: a two-run k cut exchanges through the last arriver (A/B), 1: run 0 hands its tile to run 1  // 1: the dispatcher may pick the wide forms (128 rows x 64 columns per wave)
 float gemm_pk_estimate_us(int M, int N, int K, int *form_out, bool has_scratch = false, int *split_out = nullptr, int group_size = 128, bool zero_point_8 = false);
 size_t gemm_pk_scratch_bytes();
