@@ -21,7 +21,7 @@ TESTKIT_LIB_PATH = os.path.join(LIB_DIR, "libtce_testkit.so")
 ADAPTER_TEST_PATH = os.path.join(LIB_DIR, "adapter_selftest")
 ADAPTER_BENCH_PATH = os.path.join(LIB_DIR, "adapter_bench")
 
-HIP_SOURCES = ["tce_capi.hip", "w4a16_gemv.hip", "w4a16_gemv_i8.hip", "w4a16_gemv_stream.hip", "w4a16_gemv_ovl.hip", "w4a16_gemm.hip", "w4a16_gemm_dma.hip", "w4a16_gemm_pk.hip", "w4a16_skinny.hip", "w4a16_awq.hip", "w8a8_gemm.hip", "w8a8_lnq_fused.hip", "glue.hip", "attention_ops.hip", "attention_fast.hip", "attention_prefill.hip", "opt_attention.hip", "comm.hip"]
+HIP_SOURCES = ["tce_capi.hip", "w4a16_gemv.hip", "w4a16_gemv_i8.hip", "w4a16_gemv_i8_token.hip", "w4a16_gemv_stream.hip", "w4a16_gemv_ovl.hip", "w4a16_gemm.hip", "w4a16_gemm_dma.hip", "w4a16_gemm_pk.hip", "w4a16_skinny.hip", "w4a16_awq.hip", "w8a8_gemm.hip", "w8a8_lnq_fused.hip", "glue.hip", "attention_ops.hip", "attention_fast.hip", "attention_prefill.hip", "opt_attention.hip", "comm.hip"]
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
     "-ffp-contract=off",  # the int8 epilogue and the fp16-accumulate entry point need every rounding
@@ -33,6 +33,7 @@ EXTRA_FLAGS: dict[str, list[str]] = {}  # (-fno-slp-vectorize on the GEMM: no pa
 # makes the compiler wait for all of them at the spill (measured: the OPT-6.7B layer 94 -> 103 us, found only by accident).  The build fails instead.
 NO_VGPR_SPILL: dict[str, list[str]] = {"w8a8_lnq_fused.hip": ["lnq_w8a8_wide_kernel"],
                                         "w4a16_gemv_stream.hip": ["w4a16_gemv_token_kernel"],
+                                        "w4a16_gemv_i8_token.hip": ["w4a16_gemv_i8_token_kernel"],
                                         # round 5: EVERY instantiation of the decode kernel, the general-zero-point forms included (round 4 let four of them spill 3-19 registers: each
                                         # spilled scale / zero-point load became load -> wait -> scratch store, i.e. the wave's requests went out one at a time)
                                         "w4a16_gemv_i8.hip": ["w4a16_gemv_i8_kernel"],

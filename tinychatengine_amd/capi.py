@@ -318,9 +318,9 @@ class Plan:
         self._h = C.c_void_p()
         check(lib().tce_plan_create_ex(self._descs, self._groups, len(launches), (TCE_PLAN_TAGGED if tagged else 0) | (TCE_PLAN_CHAINED if chained else 0) | (TCE_PLAN_OVERLAPPED if overlapped else 0) | (TCE_PLAN_TUNED if tuned else 0), C.byref(self._h)))
         self.n_launches = len(launches)
-        self.kind = int(lib().tce_plan_is_chained(self._h))  # 0 stream-ordered, 2 token kernel, 3 overlapped launches
+        self.kind = int(lib().tce_plan_is_chained(self._h))  # 0 stream-ordered, 2 token kernel (fp16 body), 3 overlapped launches, 4 token kernel on the int8-contraction body (round 6)
         self.chained = self.kind != 0
-        self.tagged = self.kind == 2
+        self.tagged = self.kind in (2, 4)
         self.overlapped = self.kind == 3
 
     def launch(self, stream: int | None) -> None:

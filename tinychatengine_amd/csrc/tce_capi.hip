@@ -172,7 +172,7 @@ int tce_w4a16_set_debug_mode(int mode) {
         return TCE_OK;
     }
     // (round 6, ADVICE r5: the three GEMM mode families below sit INSIDE this range and were shadowed by it since they were added -- they are matched further down)
-    const bool pk_mode_in_attention_range = (mode >= 6950 && mode <= 6958) || (mode >= 6972 && mode <= 6974);
+    const bool pk_mode_in_attention_range = (mode >= 6950 && mode <= 6958) || (mode >= 6972 && mode <= 6974) || (mode >= 7700 && mode <= 7710 + 512);
     if (mode >= 3000 && mode <= 3000 + 8192 && !pk_mode_in_attention_range) {  // fast attention step: workgroups the key range is cut for (3000: the fitted rule, the default)
         tce::set_attention_fast_target(mode - 3000);
         return TCE_OK;
@@ -191,6 +191,20 @@ int tce_w4a16_set_debug_mode(int mode) {
     }
     if ((mode >= 75 && mode <= 78) || mode == 176 || mode == 177) {  // W8A8, the 128-row tiles: 75 the rule, 76 / 77 forced with 128 / 64 columns, 176 / 177 the same with two quartets per tile, 78 off
         tce::set_w8a8_big(mode == 78 ? 9 : (mode >= 176 ? mode - 173 : mode - 75));
+        return TCE_OK;
+    }
+    if (mode >= 7710 && mode <= 7710 + 512) {  // ... a stage with more than (mode - 7710) units per workgroup ends the prefix the kernel takes (7710: the default, 512)
+        tce::set_i8_token_max_units(mode - 7710);
+        return TCE_OK;
+    }
+    if (mode >= 7700 && mode <= 7703) {  // TCE_PLAN_TAGGED on packed copies (round 6): 7700 the int8-contraction token kernel where the list allows (default), 7701 never (round 2's kernel);
+                                         // 7702 / 7703: plans built from now on record per-stage wall-clock stamps in the debug buffer (tce_w4a16_set_debug_buffer) / stop
+        if (mode <= 7701) tce::set_i8_token_mode(mode - 7700);
+        else tce::set_i8_token_stamps(mode == 7702 ? g_dbg_buf_capi : nullptr);
+        return TCE_OK;
+    }
+    if (mode == 7704 || mode == 7705) {  // ... 7704 (default): every wave requests its first unit's weights at the stage's head; 7705: units go to the non-converting waves first and the converting waves poll with an empty queue (A/B: slower)
+        tce::set_i8_token_order(mode - 7704);
         return TCE_OK;
     }
     if (mode >= 190 && mode <= 192) {  // W8A8, 32 x 64 tiles (round 6): 190 the rule, 191 forced wherever the 64 x 64 kernel would run, 192 off
@@ -1147,6 +1161,8 @@ struct tce_plan {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     tce::TokenPlan *token = nullptr;  // chained plans: the device-side launch list of the token kernel
+    tce::I8TokenPlan *token_i8 = nullptr;  // tagged plans on packed copies (round 6): the first `token_i8_taken` launches as one persistent int8-contraction kernel
+    int token_i8_taken = 0;
     std::vector<TunedGeometry> tuned;   // TCE_PLAN_TUNED: per launch, the geometry that won the timing (rows == 0: the dispatcher's choice)
 };
 
@@ -1155,6 +1171,7 @@ static void plan_free(tce_plan *p) {
     if (p->exec) (void)hipGraphExecDestroy(p->exec);
     if (p->graph) (void)hipGraphDestroy(p->graph);
     tce::token_plan_destroy(p->token);
+    tce::i8_token_plan_destroy(p->token_i8);
     delete p;
 }
 
@@ -1338,6 +1355,17 @@ int tce_plan_create_ex(const tce_w4a16_desc *descs, const int32_t *group_sizes, 
                 chained = false;
         }
     hipError_t he = hipSuccess;
+    if (chained && (flags & TCE_PLAN_TAGGED) && !(flags & TCE_PLAN_OVERLAPPED)) {
+        // round 6: the list's longest prefix the int8-contraction token kernel takes (packed copies, zero point 8, M = 1, groups of 128); what is left of the list
+        // follows the kernel as ordinary launches in the same graph
+        const int rc = tce::i8_token_plan_create(p->descs.data(), p->groups.data(), n_launches, &p->token_i8, &p->token_i8_taken, &he);
+        if (rc == TCE_ERR_HIP) {
+            plan_free(p);
+            return hip_fail(he, "int8 token plan");
+        }
+        if (rc != TCE_OK) p->token_i8 = nullptr;
+        else chained = false;
+    }
     if (chained) {
         const int rc = tce::token_plan_create(p->descs.data(), p->groups.data(), n_launches, &p->token, &he, (flags & TCE_PLAN_OVERLAPPED) ? 1 : 0);
         if (rc == TCE_ERR_HIP) {
@@ -1347,7 +1375,7 @@ int tce_plan_create_ex(const tce_w4a16_desc *descs, const int32_t *group_sizes, 
         if (rc != TCE_OK) p->token = nullptr;  // a launch the token kernel does not take: stream-ordered plan
     }
 
-    if ((flags & TCE_PLAN_TUNED) && !p->token && g_gemv_kernel == 0) (void)tune_plan_launches(p->descs, p->groups, p->tuned);
+    if ((flags & TCE_PLAN_TUNED) && !p->token && !p->token_i8 && g_gemv_kernel == 0) (void)tune_plan_launches(p->descs, p->groups, p->tuned);
     hipStream_t cap = nullptr;
     hipError_t e = hipStreamCreateWithFlags(&cap, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -1364,7 +1392,9 @@ int tce_plan_create_ex(const tce_w4a16_desc *descs, const int32_t *group_sizes, 
     if (p->token) {
         rc = tce::token_plan_enqueue(p->token, cap, &he);
     } else {
+        if (p->token_i8) rc = tce::i8_token_plan_enqueue(p->token_i8, cap, &he);
         for (int i = 0, off = 0; i < n_launches && rc == TCE_OK; off += p->groups[i], ++i) {
+            if (i < p->token_i8_taken) continue;  // (inside the token kernel)
             const bool forced = i < (int)p->tuned.size() && p->tuned[i].rows != 0;
             if (forced) (void)tce_w4a16_set_gemv_config(p->tuned[i].rows, p->tuned[i].wn, p->tuned[i].wk, p->tuned[i].depth);
             if (i < (int)p->tuned.size()) {
@@ -1400,9 +1430,19 @@ int tce_plan_create(const tce_w4a16_desc *descs, const int32_t *group_sizes, int
     return tce_plan_create_ex(descs, group_sizes, n_launches, 0, out);
 }
 
-int tce_plan_is_chained(const tce_plan *plan) { return plan && plan->token ? (tce::token_plan_mode(plan->token) == 1 ? 3 : 2) : 0; }
+int tce_plan_is_chained(const tce_plan *plan) {
+    if (plan && plan->token_i8) return 4;
+    return plan && plan->token ? (tce::token_plan_mode(plan->token) == 1 ? 3 : 2) : 0;
+}
 
 int tce_plan_geometry(const tce_plan *plan, int *rows, int *depth, int *waves, int *workgroups) {
+    if (plan && plan->token_i8 && rows && depth && waves && workgroups) {  // the int8 token kernel: rows = launches inside the kernel, depth = 1 unit in flight per wave
+        *rows = plan->token_i8_taken;
+        *depth = 1;
+        *waves = 16;
+        *workgroups = tce::i8_token_plan_blocks(plan->token_i8);
+        return TCE_OK;
+    }
     if (!plan || !plan->token || !rows || !depth || !waves || !workgroups) return fail(TCE_ERR_BAD_ARG, "not a chained plan");
     tce::token_plan_geometry(plan->token, rows, depth, waves, workgroups);
     return TCE_OK;
@@ -1422,6 +1462,11 @@ int tce_plan_status(tce_plan *plan) {
     if (!plan) return fail(TCE_ERR_BAD_ARG, "null plan");
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) return hip_fail(e, "hipDeviceSynchronize");
+    if (plan->token_i8) {
+        unsigned st8 = 0;
+        if (tce::i8_token_plan_status(plan->token_i8, &st8, &e) != TCE_OK) return hip_fail(e, "hipMemcpy");
+        return st8 == 0 ? TCE_OK : fail(TCE_ERR_HIP, "tagged plan: a wait for activations timed out");
+    }
     if (!plan->token) return TCE_OK;
     unsigned status = 0;
     if (tce::token_plan_status(plan->token, &status, &e) != TCE_OK) return hip_fail(e, "hipMemcpy");
@@ -1430,7 +1475,7 @@ int tce_plan_status(tce_plan *plan) {
 
 int tce_plan_launch(tce_plan *plan, void *stream) {
     if (!plan || !plan->exec) return fail(TCE_ERR_BAD_ARG, "null plan");
-    if (g_plan_eager && !plan->token) {
+    if (g_plan_eager && !plan->token && !plan->token_i8) {
         int rc = TCE_OK;
         const int n_launches = (int)plan->groups.size();
         for (int i = 0, off = 0; i < n_launches && rc == TCE_OK; off += plan->groups[i], ++i)

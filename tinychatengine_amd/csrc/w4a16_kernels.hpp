@@ -117,6 +117,19 @@ struct AttnDeferred;
 int launch_w4a16_gemv_i8(const tce_w4a16_desc *descs, int count, hipStream_t stream, hipError_t *hip_err, const float *gamma = nullptr, float eps = 0.f, const I8ResidualNorm *rn = nullptr,
                          const AttnDeferred *comb = nullptr, const int *comb_pos_dev = nullptr, int comb_pos = 0);
 
+// w4a16_gemv_i8_token.hip (round 6): a prefix of a launch list as ONE persistent kernel on the int8-contraction body, the data flow ordered by tagged output words
+struct I8TokenPlan;
+int i8_token_plan_create(const tce_w4a16_desc *descs, const int32_t *groups, int n_launches, I8TokenPlan **out, int *n_taken, hipError_t *hip_err);
+int i8_token_plan_enqueue(I8TokenPlan *tp, hipStream_t stream, hipError_t *hip_err);
+int i8_token_plan_status(I8TokenPlan *tp, unsigned *status, hipError_t *hip_err);
+int i8_token_plan_stages(const I8TokenPlan *tp);
+int i8_token_plan_blocks(const I8TokenPlan *tp);
+void i8_token_plan_destroy(I8TokenPlan *tp);
+void set_i8_token_stamps(void *buf);  // non-null: plans built from now on record [workgroup][stage][8] wall-clock stamps there (scripts/token_timeline.py)
+void set_i8_token_order(int o);       // 0 (default): every wave requests its first unit's weights at the stage's head; 1: units to the non-converting waves first, converting waves poll with an empty queue (measured slower)
+void set_i8_token_max_units(int u);   // a stage with more units (16-row tile x 1024-k chunk) per workgroup ends the prefix the kernel takes (default 512)
+void set_i8_token_mode(int mode);     // 0: tagged plans take this kernel where the list allows (default), 1: never (round 2's token kernel on the fp16 body)
+
 // MFMA GEMM on the q4_6 layout (prefill).  m_tiles x n_tiles 16x16 MFMA tiles per wave, 4 waves along N.
 #define TCE_GEMM_VARIANTS(X) \
     X(8, 1)                  \
