@@ -1081,6 +1081,8 @@ def main():
                     tplan.status()
                     variants = {"hipGraph of 129 launches (stream order)": {"ms_per_token": round(ms_g, 4), "tokens_per_s": round(1e3 / ms_g, 1)},
                                 "token kernel (TCE_PLAN_TAGGED)": {"ms_per_token": round(ms_t, 4), "tokens_per_s": round(1e3 / ms_t, 1), "geometry": tplan.geometry(),
+                                                                    "body": ("int8 contraction on the packed copies (csrc/w4a16_gemv_i8_token.hip, round 6: profiles/r6/i8_token_kernel.md)" if tplan.kind == 4
+                                                                             else "fp16 unpack (csrc/w4a16_gemv_stream.hip, round 2)"),
                                                                     "verified": "all outputs of the token bit-identical to the stream-ordered plan, 3 replays"}}
                     if args.issue == "token" or ms_t < ms_g:
                         step = tstep

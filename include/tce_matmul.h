@@ -410,7 +410,11 @@ TCE_API int tce_plan_create(const tce_w4a16_desc *descs, const int32_t *group_si
  * tiles are requested before it starts to wait.  A launch whose activations come from outside the plan reads them at once.
  * What is ordered is therefore the plan's DATA FLOW (and, transitively, everything in front of it), not the launch list as
  * such: launches that do not feed each other may overlap.  Outputs are bit-identical to the stream-ordered plan.
- * Not taken (the plan is then built stream-ordered; tce_plan_is_chained tells: 0 stream-ordered, 2 token kernel): a launch that
+ * Round 6: when the linears carry packed copies (tce_w4a16_prepack) and TCE_W4_ZERO_POINT_IS_8, the walk runs on the int8-contraction body of the decode GEMV
+ * (csrc/w4a16_gemv_i8_token.hip; tce_plan_is_chained = 4): the list's longest prefix of M = 1, group-128, K <= 15360 launches goes into ONE kernel, what is left (e.g. a
+ * linear with general zero points) follows it as ordinary launches of the same graph.  Bit-identical to the stream-ordered plan; measured level with it (0.976 vs 0.962 ms
+ * per Llama-3-8B token, profiles/r6/i8_token_kernel.md) -- opt-in.
+ * Not taken (the plan is then built stream-ordered; tce_plan_is_chained tells: 0 stream-ordered, 2 token kernel on the fp16 body, 4 on the int8 body): a launch that
  * is not an M = 1 GEMV the persistent kernel takes; an activation vector that straddles two outputs or starts at an odd
  * 16-byte offset; a launch list in which a launch overwrites memory that an earlier launch reads un-tagged (activations from
  * outside the plan, the old value of TCE_W4_ADD_TO_C) or also writes WITHOUT being downstream of that launch in the data
@@ -566,6 +570,8 @@ TCE_API int tce_w4a16_set_gemv_i8(int mode, int tiles_per_wave);
  *   694 / 695, 6950+d                   a k range cut in two runs: both meet at the counter (694) / run 0 hands its tile to run 1 (695, the default); run 0 shorter by d k-blocks (default 2)
  *   696 / 697 / 698, 6972..6974         the two waves of a SIMD at different priorities: off / on / the launcher's rule (default); level 3 / 1 / chosen by slot parity
  *   2600+a, 26000+a                     the 256-row / wide form with parts of the loop switched off (as 600+a; 128 / 256: where the refill is issued); outputs meaningless
+ *   7700 / 7701, 7702 / 7703, 7710+u    TCE_PLAN_TAGGED on packed copies: the int8 token kernel where the list allows (7700, default) / never (7701); plans built from now on record per-stage
+ *                                       wall-clock stamps in the debug buffer (7702) / stop (7703); a stage with more than u units per workgroup ends the prefix the kernel takes (7710: 512)
  *   (6262 / 6263 of round 5 are gone: the two-quartet forms are offered for every group size again -- isa_lint.py RULE 1, profiles/r6/pk_lost_lanes_rule.md)
  *   170..179, 180..188                  W8A8: the 64 x 64 tile with 8 k-steps in flight (quartets forced / off); a tile's k-steps cut across workgroups (180 the rule, 181 off, 182.. runs)
  *   2700..2899, 2950..2968, 2930 / 2931 prefill attention: block pairing, waves x row tiles; fast attention step without its combine (2931: timing only, the output is NOT written)

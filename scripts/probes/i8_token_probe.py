@@ -14,8 +14,6 @@ ap.add_argument("--stamps", action="store_true")
 ap.add_argument("--max-units", type=int, default=0)
 ap.add_argument("--layers", type=int, default=None)
 ap.add_argument("--reps", type=int, default=200)
-ap.add_argument("--order", type=int, default=0)
-ap.add_argument("--form", type=int, default=1)
 args = ap.parse_args()
 dev = torch.device("cuda:0"); L = capi.lib()
 shape = SHAPES[args.workload]
@@ -24,8 +22,6 @@ stream = torch.cuda.current_stream().cuda_stream
 plan = dl.make_plan()
 n = plan.n_launches
 stamps = None
-capi.check(L.tce_w4a16_set_debug_mode(7704 + args.order))
-capi.check(L.tce_w4a16_set_debug_mode(7706 + args.form))
 if args.max_units: capi.check(L.tce_w4a16_set_debug_mode(7710 + args.max_units))
 if args.stamps:
     stamps = torch.zeros(256 * n * 8, dtype=torch.int64, device=dev)
@@ -56,7 +52,7 @@ def rate(fn, k):
 ms_g = min(rate(lambda: plan.launch(stream), args.reps) for _ in range(3))
 ms_t = min(rate(lambda: tplan.launch(stream), args.reps) for _ in range(3))
 tplan.status()
-res = {"workload": args.workload, "order": args.order, "form": args.form, "launches": n, "plan_kind": tplan.kind, "geometry": geo, "mismatch": bad, "graph_ms": round(ms_g, 4), "token_ms": round(ms_t, 4),
+res = {"workload": args.workload, "launches": n, "plan_kind": tplan.kind, "geometry": geo, "mismatch": bad, "graph_ms": round(ms_g, 4), "token_ms": round(ms_t, 4),
        "graph_tok_s": round(1e3 / ms_g, 1), "token_tok_s": round(1e3 / ms_t, 1)}
 if stamps is not None and tplan.kind == 4:
     ns = geo["rows"]

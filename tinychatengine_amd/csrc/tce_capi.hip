@@ -203,14 +203,6 @@ int tce_w4a16_set_debug_mode(int mode) {
         else tce::set_i8_token_stamps(mode == 7702 ? g_dbg_buf_capi : nullptr);
         return TCE_OK;
     }
-    if (mode == 7706 || mode == 7707) {  // ... 7707 (default): the barrier-free token kernel; 7706: the kernel with one conversion per workgroup between two barriers (A/B)
-        tce::set_i8_token_form(mode - 7706);
-        return TCE_OK;
-    }
-    if (mode == 7704 || mode == 7705) {  // ... 7704 (default): every wave requests its first unit's weights at the stage's head; 7705: units go to the non-converting waves first and the converting waves poll with an empty queue (A/B: slower)
-        tce::set_i8_token_order(mode - 7704);
-        return TCE_OK;
-    }
     if (mode >= 190 && mode <= 192) {  // W8A8, 32 x 64 tiles (round 6): 190 the rule, 191 forced wherever the 64 x 64 kernel would run, 192 off
         tce::set_w8a8_rows32(mode - 190);
         return TCE_OK;

@@ -35,9 +35,8 @@ namespace {
 
 constexpr int kTokWaves = 16;
 constexpr int kTokMaxChunks = 15;   // planes of 15 chunks (60 KiB) beside the partial rows
-constexpr int kTokMaxUnits = 512;   // per workgroup and stage: 32 KiB of partial rows (twice in the barrier-free kernel)
+constexpr int kTokMaxUnits = 512;   // per workgroup and stage: 32 KiB of partial rows
 constexpr int kTokMaxTiles = 128;   // per workgroup and stage
-constexpr int kTokPollSleep = 8;    // s_sleep between two probes of a waiting wave (x 64 cycles)
 
 struct TokSeg {
     const void *words;      // u32 [NT16][U][64][4]
@@ -53,8 +52,6 @@ struct TokStage {
     int K, U, nch, nseg, ntiles, pad;
     TokSeg seg[TCE_MAX_GROUP];
 };
-typedef const __attribute__((address_space(4))) TokStage CTokStage;
-typedef const __attribute__((address_space(4))) TokSeg CTokSeg;
 constexpr int kRecWords = sizeof(TokStage) / 4;
 static_assert(sizeof(TokStage) % 8 == 0 && kRecWords <= 128, "a record is fetched by one wave, 8 bytes per lane");
 
@@ -73,13 +70,6 @@ constexpr int kShOff = kRecOff + 3 * (int)sizeof(TokStage);         // int sh[16
 constexpr int kCntOff = kShOff + 128;                               // unsigned tile_cnt[kTokMaxTiles]
 constexpr int kRedOff = kCntOff + kTokMaxTiles * 4;                 // float red[kTokMaxUnits][16]
 constexpr int kLdsBytes = kRedOff + kTokMaxUnits * 64;
-// the barrier-free kernel: [16 waves' images][TokStage[3]][stage_done[4]][tile_cnt[2][kTokMaxTiles]][red[2][kTokMaxUnits][16]]
-constexpr int kFreeRecOff = kTokWaves * 4096;
-constexpr int kFreeDoneOff = kFreeRecOff + 3 * (int)sizeof(TokStage);
-constexpr int kFreeCntOff = kFreeDoneOff + 16;
-constexpr int kFreeRedOff = kFreeCntOff + 2 * kTokMaxTiles * 4;
-constexpr int kFreeLdsBytes = kFreeRedOff + 2 * kTokMaxUnits * 64;
-static_assert(kFreeLdsBytes <= 160 * 1024 && 2 * kTokMaxTiles <= 64 * kTokWaves, "LDS of one workgroup per CU");
 
 template <int DPP_CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ unsigned tok_dpp_max_u32(unsigned v) {
@@ -103,11 +93,13 @@ __device__ __forceinline__ T *sgpr_ptr(T *p) {
     return reinterpret_cast<T *>(((unsigned long long)hi << 32) | lo);
 }
 
-// ORDER 0: every wave requests its first unit's weights at the stage's head, the converting waves poll behind them.
-// ORDER 1: units go to the waves that do NOT convert first (wave w's first unit: (w - nch) mod 16); a converting wave polls with nothing in front of the poll in its
-//          vector-memory queue (results return in order: behind 8 KiB of weights -- 32 MiB over the chip when every wave asks at once -- the activations came back 2-5 us
-//          after they were there) and requests its unit's weights the moment the activations are in registers, in front of the conversion.
-template <bool STAMPS, int ORDER>
+// Two other forms were built on this body, measured and removed (profiles/r6/i8_token_kernel.md; both bit-identical, the code is in commit 2cfe49f):
+//   * units dealt to the non-converting waves first, the converting waves polling IN FRONT of their own requests (a poll's answer otherwise queues behind the wave's 8 KiB
+//     of weights: results return in order) -- 1.09 ms per Llama-3-8B token against 0.976: the answer still queues behind the chip's 32 MiB of requests in the memory system,
+//     the converting waves' own units start a memory latency late, and waves that sweep flat out take bandwidth from the producers;
+//   * no barriers: every wave polls and converts the chunk of ITS unit (the stream-ordered kernel's structure inside one launch) -- 1.139 ms: sixteen waves per CU convert
+//     and poll where four did.
+template <bool STAMPS>
 __global__ __launch_bounds__(64 * kTokWaves) void w4a16_gemv_i8_token_kernel(const TokArgs args) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -177,13 +169,9 @@ __global__ __launch_bounds__(64 * kTokWaves) void w4a16_gemv_i8_token_kernel(con
             for (int tt = 0; tt < 8; ++tt)
                 wq[tt] = __builtin_amdgcn_raw_buffer_load_b128(u0 + tt < U ? rs_w : rs_none, lane * 16, (tl * U + u0 + tt) * 1024, /*nt*/ 2);
         };
-        // (ORDER 1 where at most half of the waves convert: with K = 14336 -- 14 converting waves -- the stage's whole stream would start behind the hand-off)
-        const bool poll_first = ORDER == 1 && nch <= kTokWaves / 2;
-        int u_cur = !poll_first ? w : (w >= nch ? w - nch : w + kTokWaves - nch);
+        int u_cur = w;
         const int u_first = u_cur;
-        if (!poll_first || w >= nch) {
-            if (u_cur < nunits) request(u_cur);
-        }
+        if (u_cur < nunits) request(u_cur);
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- the activations of chunk w (waves 0 .. nch - 1) ----
@@ -195,7 +183,6 @@ __global__ __launch_bounds__(64 * kTokWaves) void w4a16_gemv_i8_token_kernel(con
                 const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(sgpr_ptr(R->A)), 0, K * 2, 0x00020000);
 #pragma unroll
                 for (int c = 0; c < 2; ++c) xv[c] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, w * 2048 + (lane + 64 * c) * 16, 0, 0);
-                if (poll_first) asm volatile("" : "+v"(xv[0]), "+v"(xv[1]));
             } else {
                 const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(A_tag), 0, K * 4, 0x00020000);
                 bool need[2];
@@ -206,24 +193,6 @@ __global__ __launch_bounds__(64 * kTokWaves) void w4a16_gemv_i8_token_kernel(con
                     lo[c] = hi[c] = uint4_t{tag, tag, tag, tag};
                 }
                 int tries = 0;
-                // phase 1: ONE 16-byte piece per lane (every other piece of the chunk's first half) until all 64 are tagged -- a quarter of the sweep's traffic while the
-                // producers are still streaming (waiting waves that sweep flat out take bandwidth from the waves they wait for: measured, gate + up 10.5 -> 21.8 us with
-                // the next stage's 14 converting waves per workgroup sweeping beside it)
-                if (poll_first && need[0]) {  // (behind its own weight requests -- ORDER 0 -- a wave's first sweep returns when the weights have landed: it polls rarely anyway)
-                    for (;;) {
-                        const uint4_t probe = __builtin_amdgcn_raw_buffer_load_b128(rs_t, w * 4096 + lane * 32, 0, /*sc0|sc1*/ 17);
-                        const unsigned badp = ((probe.x ^ tag) | (probe.y ^ tag) | (probe.z ^ tag) | (probe.w ^ tag)) >> 16;
-                        if (!__builtin_amdgcn_ballot_w64(badp != 0u)) break;
-                        __builtin_amdgcn_s_sleep(kTokPollSleep);
-                        if ((++tries & 255) == 0) {
-                            if (__hip_atomic_load(args.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-                            if (tries > (1 << 18)) {
-                                __hip_atomic_store(args.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                break;
-                            }
-                        }
-                    }
-                }
                 for (;;) {
 #pragma unroll
                     for (int c = 0; c < 2; ++c)
@@ -260,9 +229,6 @@ __global__ __launch_bounds__(64 * kTokWaves) void w4a16_gemv_i8_token_kernel(con
             // the next stage's head (this block taken, the conversion block below not) and puts s_waitcnt vmcnt(0) THERE -- in front of the next stage's weight requests,
             // behind this stage's write-through stores (1-2 us to their acknowledgement): measured as workgroups entering a stage 2-3 us after the previous one's end.
             asm volatile("" : "+v"(xv[0]), "+v"(xv[1]));
-            if (poll_first) {
-                if (u_cur < nunits) request(u_cur);
-            }
         }
         stamp(s, 1);
         lds_barrier();  // A: every wave of the workgroup is through the previous stage (its planes, its partial rows)
@@ -472,334 +438,6 @@ __global__ __launch_bounds__(64 * kTokWaves) void w4a16_gemv_i8_token_kernel(con
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------------------------------------------
-// The same token without workgroup barriers (w4a16_gemv_i8_free_kernel).  In the kernel above a stage's activations are converted once per workgroup (wave c converts
-// chunk c) between two barriers: every wave waits for the workgroup's slowest converting wave, then all sixteen contract at once.  Here a wave is on its own, as the
-// workgroups of the stream-ordered kernel are: it requests its unit's weights, polls for the 1024 activations of ITS unit's chunk, converts them into its own 4 KiB of
-// LDS (once per stage where its units share a chunk: K = 4096 -> chunk = wave % 4), contracts, counts its partial row in.  What is shared between waves -- a tile's
-// partial rows and arrival counter -- lives in two sets by the stage's parity, the counter is zeroed by the wave that finishes the tile, and a wave does not enter stage
-// s before every wave of the workgroup has left stage s - 2 (a count per stage in LDS; in practice it never waits).
-template <bool STAMPS>
-__global__ __launch_bounds__(64 * kTokWaves) void w4a16_gemv_i8_free_kernel(const TokArgs args) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kq = lane >> 4, j16 = lane & 15;
-    const int p_l = j16 & 3, uu_l = j16 >> 2;
-    const int P = gridDim.x, b = blockIdx.x;
-    const int n = args.n_stages;
-    unsigned *const planes = reinterpret_cast<unsigned *>(smem) + w * 1024;  // this wave's own image
-    unsigned *const stage_done = reinterpret_cast<unsigned *>(smem + kFreeDoneOff);  // [4]: waves that have left a stage = s mod 4, counted up over the whole token
-    unsigned *const tile_cnt_all = reinterpret_cast<unsigned *>(smem + kFreeCntOff);  // [2][kTokMaxTiles]
-    float *const red_all = reinterpret_cast<float *>(smem + kFreeRedOff);             // [2][kTokMaxUnits][16]
-    const unsigned tag = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(args.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) << 16;
-    unsigned long long *const stamps = STAMPS && args.dbg ? args.dbg + (size_t)b * n * 8 : nullptr;
-    auto stamp = [&](int s, int i) {
-        if constexpr (STAMPS) {
-            if (stamps && tid == 0) stamps[s * 8 + i] = wall_clock64();
-        }
-    };
-
-    if (tid < 4) stage_done[tid] = 0u;
-    if (tid < 2 * kTokMaxTiles) tile_cnt_all[tid] = 0u;
-    __syncthreads();
-
-    uint4_t wq[8];
-    uint2_t sc[2];
-    const int4_t zero4 = int4_t{0, 0, 0, 0};
-
-    for (int s = 0; s < n; ++s) {
-        // the stage's record, read through the CONSTANT address space: scalar loads (their own counter: a record fetched with vector loads -- the kernel above stages it
-        // through LDS -- ties the fetch into the in-order vector-memory queue, between the weights and the write-through stores)
-        const CTokStage *R = (const CTokStage *)(unsigned long long)(args.stages + s);
-        const int K = sgpr(R->K), U = sgpr(R->U), nch = sgpr(R->nch), nseg = sgpr(R->nseg), ntiles = sgpr(R->ntiles);
-        const int ntw = b < ntiles ? (ntiles - 1 - b) / P + 1 : 0;
-        const int nunits = ntw * nch;
-        unsigned *const tile_cnt = tile_cnt_all + (s & 1) * kTokMaxTiles;
-        float *const red = red_all + (size_t)(s & 1) * kTokMaxUnits * 16;
-        stamp(s, 0);
-
-        auto seg_of = [&](int t) {
-            int si = 0;
-            for (int q = 1; q < nseg; ++q)
-                if (t >= sgpr(R->seg[q].tile_begin)) si = q;
-            return si;
-        };
-        auto request = [&](int u) {
-            const int i = u / nch, c = u - i * nch;
-            const int t = b + i * P;
-            const CTokSeg *S = &R->seg[seg_of(t)];
-            const int tl = t - sgpr(S->tile_begin);
-            const int u0 = c * 8;
-            const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(sgpr_ptr(S->words)), 0, sgpr(S->bytes_w), 0x00020000);
-            const __amdgpu_buffer_rsrc_t rs_none = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(sgpr_ptr(S->words)), 0, 0, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(sgpr_ptr(S->dscales)), 0, sgpr(S->bytes_s), 0x00020000);
-#pragma unroll
-            for (int ps = 0; ps < 2; ++ps) {
-                const int ga = tl * U + u0 + ps * 4 + uu_l;
-                sc[ps] = __builtin_bit_cast(uint2_t, __builtin_amdgcn_raw_buffer_load_b64(rs_s, (ga * 16 + 4 * kq) * 2, 0, 0));
-            }
-#pragma unroll
-            for (int tt = 0; tt < 8; ++tt)
-                wq[tt] = __builtin_amdgcn_raw_buffer_load_b128(u0 + tt < U ? rs_w : rs_none, lane * 16, (tl * U + u0 + tt) * 1024, /*nt*/ 2);
-        };
-        // ONE request site, at the top of the unit loop (a second one behind the contraction made hipcc copy the requested scale registers at the loop's back edge, behind
-        // s_waitcnt vmcnt(0): a wait for the next unit's weights AND for the acknowledgement of the tile's write-through stores, once per unit)
-        int u_cur = w;
-        // the next stage's record into the scalar cache (one word per 64-byte line; the wait hides behind the weights' latency)
-        auto touch_next_record = [&]() {
-            const CTokStage *Rn = (const CTokStage *)(unsigned long long)(args.stages + (s + 1 < n ? s + 1 : s));
-            const __attribute__((address_space(4))) int *wn = (const __attribute__((address_space(4))) int *)Rn;
-            int t0 = 0;
-#pragma unroll
-            for (int l = 0; l < (int)sizeof(TokStage); l += 64) t0 |= wn[l / 4];
-            asm volatile("" ::"s"(t0));
-        };
-        if (u_cur >= nunits) touch_next_record();  // (a wave without units in this stage)
-        int cur_c = -1, sh_c = 0;
-        bool bad_c = false;
-        while (u_cur < nunits) {
-            request(u_cur);
-            if (u_cur == w) {
-                touch_next_record();
-                // nobody of this workgroup is still in stage s - 2 (whose partial rows and counters this stage's overwrite)
-                if (s >= 2) {
-                    const unsigned want = (unsigned)kTokWaves * (unsigned)(((s - 2) >> 2) + 1);
-                    int spins = 0;
-                    while (sgpr((int)__hip_atomic_load(stage_done + ((s - 2) & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < (int)want) {
-                        __builtin_amdgcn_s_sleep(1);
-                        if (++spins > (1 << 22)) {
-                            __hip_atomic_store(args.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            break;
-                        }
-                    }
-                    asm volatile("" ::: "memory");
-                }
-            }
-            const int i = u_cur / nch, c = u_cur - i * nch;
-            if (c != cur_c) {
-                // ---- the activations of this unit's chunk: polled (or read), converted into the wave's own image ----
-                uint4_t xv[2];
-                const unsigned *A_tag = sgpr_ptr(R->A_tag);
-                if (A_tag == nullptr) {
-                    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(sgpr_ptr(R->A)), 0, K * 2, 0x00020000);
-#pragma unroll
-                    for (int cc = 0; cc < 2; ++cc) xv[cc] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, c * 2048 + (lane + 64 * cc) * 16, 0, 0);
-                } else {
-                    const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(A_tag), 0, K * 4, 0x00020000);
-                    bool need[2];
-                    uint4_t lo[2], hi[2];
-#pragma unroll
-                    for (int cc = 0; cc < 2; ++cc) {
-                        need[cc] = c * 1024 + (lane + 64 * cc) * 8 < K;
-                        lo[cc] = hi[cc] = uint4_t{tag, tag, tag, tag};
-                    }
-                    int tries = 0;
-                    for (;;) {
-#pragma unroll
-                        for (int cc = 0; cc < 2; ++cc)
-                            if (need[cc]) {
-                                lo[cc] = __builtin_amdgcn_raw_buffer_load_b128(rs_t, c * 4096 + (lane + 64 * cc) * 32, 0, /*sc0|sc1*/ 17);
-                                hi[cc] = __builtin_amdgcn_raw_buffer_load_b128(rs_t, c * 4096 + (lane + 64 * cc) * 32 + 16, 0, /*sc0|sc1*/ 17);
-                            }
-                        bool again = false;
-#pragma unroll
-                        for (int cc = 0; cc < 2; ++cc)
-                            if (need[cc]) {
-                                const unsigned bad = ((lo[cc].x ^ tag) | (lo[cc].y ^ tag) | (lo[cc].z ^ tag) | (lo[cc].w ^ tag) | (hi[cc].x ^ tag) | (hi[cc].y ^ tag) |
-                                                      (hi[cc].z ^ tag) | (hi[cc].w ^ tag)) >> 16;
-                                need[cc] = bad != 0u;
-                                again |= need[cc];
-                            }
-                        if (!__builtin_amdgcn_ballot_w64(again)) break;
-                        __builtin_amdgcn_s_sleep(2);
-                        if ((++tries & 255) == 0) {
-                            if (__hip_atomic_load(args.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-                            if (tries > (1 << 18)) {
-                                __hip_atomic_store(args.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                break;
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int cc = 0; cc < 2; ++cc)
-                        xv[cc] = uint4_t{(lo[cc].x & 0xFFFFu) | (lo[cc].y << 16), (lo[cc].z & 0xFFFFu) | (lo[cc].w << 16), (hi[cc].x & 0xFFFFu) | (hi[cc].y << 16),
-                                         (hi[cc].z & 0xFFFFu) | (hi[cc].w << 16)};
-                }
-                if (u_cur == w) stamp(s, 1);
-                unsigned mx = 0;
-#pragma unroll
-                for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const unsigned v = xv[cc][q] & 0x7FFF7FFFu;
-                        const unsigned v2 = v << 16;
-                        const unsigned m2 = v > v2 ? v : v2;
-                        mx = mx > m2 ? mx : m2;
-                    }
-                mx = tok_dpp_max_u32<0x111>(mx);
-                mx = tok_dpp_max_u32<0x112>(mx);
-                mx = tok_dpp_max_u32<0x114>(mx);
-                mx = tok_dpp_max_u32<0x118>(mx);
-                mx = tok_dpp_max_u32<0x142, 0xA>(mx);
-                mx = tok_dpp_max_u32<0x143, 0xC>(mx);
-                const int E = (int)((unsigned)__builtin_amdgcn_readlane((int)mx, 63) >> 26);
-                sh_c = 44 - E;
-                bad_c = E == 31;
-                const float scale = __builtin_bit_cast(float, (unsigned)(127 + sh_c) << 23);
-#pragma unroll
-                for (int cc = 0; cc < 2; ++cc) {
-                    unsigned d[8];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const half_t lo = __builtin_bit_cast(half_t, (unsigned short)(xv[cc][q] & 0xFFFFu));
-                        const half_t hi = __builtin_bit_cast(half_t, (unsigned short)(xv[cc][q] >> 16));
-                        d[2 * q] = ((unsigned)(int)__builtin_fmaf((float)lo, scale, 0.0f) + 0x00808080u) ^ 0x00808080u;
-                        d[2 * q + 1] = ((unsigned)(int)__builtin_fmaf((float)hi, scale, 0.0f) + 0x00808080u) ^ 0x00808080u;
-                    }
-                    const int pc = lane + 64 * cc;
-                    const int tu = pc >> 4, sw = (pc >> 2) & 3, q4 = pc & 3;
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const unsigned a0 = d[2 * h], a1 = d[2 * h + 4], a2 = d[2 * h + 1], a3 = d[2 * h + 5];
-                        const unsigned t0 = __builtin_amdgcn_perm(a1, a0, 0x05010400u);
-                        const unsigned t1 = __builtin_amdgcn_perm(a1, a0, 0x07030602u);
-                        const unsigned t2 = __builtin_amdgcn_perm(a3, a2, 0x05010400u);
-                        const unsigned t3 = __builtin_amdgcn_perm(a3, a2, 0x07030602u);
-                        const int base = (((tu * 2 + h) * 4) * 4 + q4) * 4 + sw;
-                        planes[base + 0] = __builtin_amdgcn_perm(t2, t0, 0x05040100u);
-                        planes[base + 16] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
-                        planes[base + 32] = __builtin_amdgcn_perm(t3, t1, 0x05040100u);
-                        planes[base + 48] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                cur_c = c;
-                if (u_cur == w) stamp(s, 3);
-            }
-            // ---- contraction (w4a16_gemv_i8_kernel<1, 1, 1, 8, true>'s) ----
-            int4_t B[4][2];
-#pragma unroll
-            for (int uu = 0; uu < 4; ++uu) B[uu][0] = B[uu][1] = zero4;
-            auto read_b = [&](int ps) {
-#pragma unroll
-                for (int uu = 0; uu < 4; ++uu)
-                    if (uu_l == uu) {
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const unsigned *src = planes + (((((ps * 4 + uu) * 2 + h) * 4 + p_l) * 4 + kq) * 4);
-                            B[uu][h] = __builtin_bit_cast(int4_t, *reinterpret_cast<const uint4_t *>(src));
-                        }
-                    }
-            };
-            read_b(0);
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ps = 0; ps < 2; ++ps) {
-                int4_t dd0 = zero4, dd1 = zero4;
-#pragma unroll
-                for (int uu = 0; uu < 4; ++uu) {
-                    const int t = ps * 4 + uu;
-                    int4_t alo, ahi;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const unsigned x = wq[t][q];
-                        ahi[q] = (int)((x & 0xF0F0F0F0u) ^ 0x80808080u);
-                        alo[q] = (int)(((x << 4) & 0xF0F0F0F0u) ^ 0x80808080u);
-                    }
-                    dd0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(alo, B[uu][0], dd0, 0, 0, 0);
-                    dd1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(ahi, B[uu][1], dd1, 0, 0, 0);
-                }
-                const half_t s0 = __builtin_bit_cast(half_t, (unsigned short)(sc[ps][0] & 0xFFFFu));
-                const half_t s1 = __builtin_bit_cast(half_t, (unsigned short)(sc[ps][0] >> 16));
-                const half_t s2 = __builtin_bit_cast(half_t, (unsigned short)(sc[ps][1] & 0xFFFFu));
-                const half_t s3 = __builtin_bit_cast(half_t, (unsigned short)(sc[ps][1] >> 16));
-                const int4_t tot = dd0 + dd1;
-                acc[0] = __builtin_fmaf((float)tot[0], (float)s0, acc[0]);
-                acc[1] = __builtin_fmaf((float)tot[1], (float)s1, acc[1]);
-                acc[2] = __builtin_fmaf((float)tot[2], (float)s2, acc[2]);
-                acc[3] = __builtin_fmaf((float)tot[3], (float)s3, acc[3]);
-                if (ps == 0) read_b(1);
-            }
-            const float cj = bad_c ? __builtin_nanf("") : __builtin_bit_cast(float, (unsigned)(127 + 8 * p_l - sh_c - 4) << 23);
-            float *slot = red + (size_t)u_cur * 16;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float v = acc[q] * cj;
-                v = tok_dpp_add_f32<0xB1>(v);
-                v = tok_dpp_add_f32<0x4E>(v);
-                v = tok_dpp_add_f32<0x128>(v);
-                v = tok_dpp_add_f32<0x124>(v);
-                if (j16 == 0) slot[kq * 4 + q] = v;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            unsigned old = 0;
-            if (lane == 0) old = __hip_atomic_fetch_add(tile_cnt + i, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            asm volatile("" ::: "memory");
-            const bool last = (unsigned)__builtin_amdgcn_readfirstlane((int)old) == (unsigned)(nch - 1);
-            const int t = b + i * P;
-            if (last) {
-                if constexpr (STAMPS) {
-                    if (stamps && lane == 0) stamps[s * 8 + 4] = wall_clock64();
-                }
-                if (lane == 0) tile_cnt[i] = 0u;  // for stage s + 2 (nobody else touches this tile's counter any more)
-                const CTokSeg *S = &R->seg[seg_of(t)];
-                const int tl = t - sgpr(S->tile_begin);
-                const int N = sgpr(S->N), epi = sgpr(S->epilogue);
-                half_t *C = sgpr_ptr(S->C);
-                unsigned *C_tag = sgpr_ptr(S->C_tag);
-                const float *parts = red + (size_t)(i * nch) * 16 + (lane & 15);
-                float v = 0.f;
-                for (int k2 = 0; k2 < nch; ++k2) v += parts[k2 * 16];
-                const int row = tl * 16 + (lane & 15);
-                half_t y = (half_t)v;
-                const half_t y_other = __builtin_bit_cast(half_t, (unsigned short)tok_dpp_u32<0xB1>((unsigned)__builtin_bit_cast(unsigned short, y)));
-                int idx = row;
-                bool live = lane < 16 && row < N;
-                if (epi & TCE_W4_SILU_MUL_PAIRS) {
-                    y = silu_mul_half(y, y_other);
-                    idx = row >> 1;
-                    live = live && (lane & 1) == 0;
-                } else if (epi & TCE_W4_ADD_TO_C) {
-                    unsigned short oldc = 0;
-                    if (live) oldc = __hip_atomic_load(reinterpret_cast<unsigned short *>(C) + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    y = __builtin_bit_cast(half_t, oldc) + y;
-                }
-                const unsigned short bits = __builtin_bit_cast(unsigned short, y);
-                if (live) {
-                    if (epi & TCE_W4_ADD_TO_C) __hip_atomic_store(reinterpret_cast<unsigned short *>(C) + idx, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    else C[idx] = y;
-                }
-                if (C_tag) {
-                    const unsigned word = tag | bits;
-                    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(C_tag, 0, 0x7FFFFFF0, 0x00020000);
-                    if (epi & TCE_W4_SILU_MUL_PAIRS) {
-                        const unsigned w1 = tok_dpp_u32<0x102>(word), w2 = tok_dpp_u32<0x104>(word), w3 = tok_dpp_u32<0x106>(word);
-                        if (lane < 16 && (lane & 7) == 0 && row + 7 < N) {
-                            __builtin_amdgcn_raw_buffer_store_b128(uint4_t{word, w1, w2, w3}, rs_c, idx * 4, 0, /*sc0|sc1: write-through*/ 17);
-                        } else if (lane < 16 && row < N && (lane & 1) == 0 && !(((row & ~7) + 7) < N)) {
-                            __hip_atomic_store(C_tag + idx, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                    } else {
-                        const unsigned w1 = tok_dpp_u32<0x101>(word), w2 = tok_dpp_u32<0x102>(word), w3 = tok_dpp_u32<0x103>(word);
-                        if (lane < 16 && (lane & 3) == 0 && row + 3 < N) {
-                            __builtin_amdgcn_raw_buffer_store_b128(uint4_t{word, w1, w2, w3}, rs_c, idx * 4, 0, /*sc0|sc1: write-through*/ 17);
-                        } else if (lane < 16 && row < N && !(((row & ~3) + 3) < N)) {
-                            __hip_atomic_store(C_tag + idx, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                    }
-                }
-            }
-            u_cur += kTokWaves;
-        }
-        // this wave has left stage s (its LDS reads and writes of the stage are done)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(stage_done + (s & 3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-}
-
 __global__ void i8_token_epoch_kernel(unsigned *epoch) { *epoch = *epoch % 65535u + 1u; }
 
 int tok_num_cus() {
@@ -811,8 +449,6 @@ int tok_num_cus() {
 
 thread_local unsigned long long *g_tok_stamps = nullptr;
 thread_local int g_tok_mode = 0;  // 0: tagged plans take this kernel where the list allows; 1: never (round 2's token kernel instead)
-thread_local int g_tok_free = 1;  // 1: the barrier-free kernel (default), 0: the kernel with one conversion per workgroup between two barriers (A/B: tce_w4a16_set_debug_mode(7706 / 7707))
-thread_local int g_tok_order = 0;  // the kernel's ORDER (A/B: tce_w4a16_set_debug_mode(7704 / 7705)); 0 measured faster (profiles/r6/i8_token_kernel.md)
 thread_local int g_tok_max_units = kTokMaxUnits;  // a stage with more units per workgroup ends the prefix the kernel takes (A/B: lm_head inside / behind the kernel)
 
 }  // namespace
@@ -821,14 +457,12 @@ struct I8TokenPlan {
     TokStage *stages = nullptr;  // device
     unsigned *sync = nullptr;    // device: [0] status, [1] the token's tag
     unsigned *shadow = nullptr;  // device: the outputs as tagged words
-    int n = 0, blocks = 0, order = 0, free_form = 1;
+    int n = 0, blocks = 0;
     unsigned long long *stamps = nullptr;
 };
 
 void set_i8_token_stamps(void *buf) { g_tok_stamps = static_cast<unsigned long long *>(buf); }
 void set_i8_token_mode(int mode) { g_tok_mode = mode == 1 ? 1 : 0; }
-void set_i8_token_form(int f) { g_tok_free = f ? 1 : 0; }
-void set_i8_token_order(int o) { g_tok_order = o == 0 ? 0 : 1; }
 void set_i8_token_max_units(int u) { g_tok_max_units = u >= 1 && u <= kTokMaxUnits ? u : kTokMaxUnits; }
 
 void i8_token_plan_destroy(I8TokenPlan *tp) {
@@ -848,14 +482,10 @@ int i8_token_plan_create(const tce_w4a16_desc *descs, const int32_t *groups, int
     if (g_tok_mode == 1) return TCE_ERR_UNSUPPORTED_SHAPE;
     const int cus = tok_num_cus();
     if (cus == 0) return TCE_ERR_HIP;
-    const void *kfn = nullptr;
-    if (g_tok_free) kfn = g_tok_stamps ? reinterpret_cast<const void *>(w4a16_gemv_i8_free_kernel<true>) : reinterpret_cast<const void *>(w4a16_gemv_i8_free_kernel<false>);
-    else kfn = g_tok_stamps ? (g_tok_order ? reinterpret_cast<const void *>(w4a16_gemv_i8_token_kernel<true, 1>) : reinterpret_cast<const void *>(w4a16_gemv_i8_token_kernel<true, 0>))
-                            : (g_tok_order ? reinterpret_cast<const void *>(w4a16_gemv_i8_token_kernel<false, 1>) : reinterpret_cast<const void *>(w4a16_gemv_i8_token_kernel<false, 0>));
-    const int lds_bytes = g_tok_free ? kFreeLdsBytes : kLdsBytes;
-    hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    const void *kfn = g_tok_stamps ? reinterpret_cast<const void *>(w4a16_gemv_i8_token_kernel<true>) : reinterpret_cast<const void *>(w4a16_gemv_i8_token_kernel<false>);
+    hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     int per_cu = 0;
-    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 64 * kTokWaves, lds_bytes);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 64 * kTokWaves, kLdsBytes);
     if (e != hipSuccess) {
         if (hip_err) *hip_err = e;
         return TCE_ERR_HIP;
@@ -914,8 +544,6 @@ int i8_token_plan_create(const tce_w4a16_desc *descs, const int32_t *groups, int
     tp->n = n;
     tp->blocks = P;
     tp->stamps = g_tok_stamps;
-    tp->order = g_tok_order;
-    tp->free_form = g_tok_free;
     auto n_out_of = [&](const TokStage &L, int i) { return (L.seg[i].epilogue & TCE_W4_SILU_MUL_PAIRS) ? L.seg[i].N / 2 : L.seg[i].N; };
     // the shadow vectors: one per linear of every stage (buffers reused from layer to layer must not alias)
     size_t words = 0;
@@ -1015,12 +643,8 @@ int i8_token_plan_enqueue(I8TokenPlan *tp, hipStream_t stream, hipError_t *hip_e
     a.epoch = tp->sync + 1;
     a.dbg = tp->stamps;
     const dim3 grid(tp->blocks), block(64 * kTokWaves);
-    if (tp->free_form && tp->stamps) hipLaunchKernelGGL(w4a16_gemv_i8_free_kernel<true>, grid, block, kFreeLdsBytes, stream, a);
-    else if (tp->free_form) hipLaunchKernelGGL(w4a16_gemv_i8_free_kernel<false>, grid, block, kFreeLdsBytes, stream, a);
-    else if (tp->stamps && tp->order) hipLaunchKernelGGL((w4a16_gemv_i8_token_kernel<true, 1>), grid, block, kLdsBytes, stream, a);
-    else if (tp->stamps) hipLaunchKernelGGL((w4a16_gemv_i8_token_kernel<true, 0>), grid, block, kLdsBytes, stream, a);
-    else if (tp->order) hipLaunchKernelGGL((w4a16_gemv_i8_token_kernel<false, 1>), grid, block, kLdsBytes, stream, a);
-    else hipLaunchKernelGGL((w4a16_gemv_i8_token_kernel<false, 0>), grid, block, kLdsBytes, stream, a);
+    if (tp->stamps) hipLaunchKernelGGL(w4a16_gemv_i8_token_kernel<true>, grid, block, kLdsBytes, stream, a);
+    else hipLaunchKernelGGL(w4a16_gemv_i8_token_kernel<false>, grid, block, kLdsBytes, stream, a);
     hipLaunchKernelGGL(i8_token_epoch_kernel, dim3(1), dim3(1), 0, stream, tp->sync + 1);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

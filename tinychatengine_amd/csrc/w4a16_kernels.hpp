@@ -126,8 +126,6 @@ int i8_token_plan_stages(const I8TokenPlan *tp);
 int i8_token_plan_blocks(const I8TokenPlan *tp);
 void i8_token_plan_destroy(I8TokenPlan *tp);
 void set_i8_token_stamps(void *buf);  // non-null: plans built from now on record [workgroup][stage][8] wall-clock stamps there (scripts/token_timeline.py)
-void set_i8_token_order(int o);       // 0 (default): every wave requests its first unit's weights at the stage's head; 1: units to the non-converting waves first, converting waves poll with an empty queue (measured slower)
-void set_i8_token_form(int f);        // 1 (default): the barrier-free kernel (every wave converts its own chunk), 0: one conversion per workgroup between two barriers
 void set_i8_token_max_units(int u);   // a stage with more units (16-row tile x 1024-k chunk) per workgroup ends the prefix the kernel takes (default 512)
 void set_i8_token_mode(int mode);     // 0: tagged plans take this kernel where the list allows (default), 1: never (round 2's token kernel on the fp16 body)
 
