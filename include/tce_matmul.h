@@ -47,7 +47,7 @@ extern "C" {
 
 #define TCE_API __attribute__((visibility("default")))
 
-#define TCE_VERSION 110 /* 0.1.10: tce_attention_decode_step_deferred_f16 + tce_w4a16_forward_deferred_attention (the attention combine in o_proj's prologue); size-prefixed descriptors (tce_w4a16_desc_v2 / tce_w8a8_desc_v2 + the *_v2 entry points; the plain ones stay), TCE_ERR_RCCL, the tuning setters act on the CALLING THREAD only; 0.1.9: tce_w4a16_check_zero_point_8_async, tce_host_alloc / tce_host_free (the adapter no longer synchronises); 0.1.8: per-family tuning setters (tce_attention_set_tuning, tce_w8a8_set_tuning); 0.1.7: decode on the pre-packed copy (int8 contraction), tce_w4a16_set_gemv_i8; 0.1.6: TCE_PLAN_TUNED; 0.1.5: tce_opt_attention_decode; 0.1.4: tce_attention_prefill_f16 (0.1.3: tce_attention_decode_step_gqa_f16, TCE_PLAN_OVERLAPPED; 0.1.2: tce_w4a16_desc.scratch; 0.1.1: .prepacked, tce_w4a16_prepack*) */
+#define TCE_VERSION 111 /* 0.1.11: tce_w4a16_gemm_scratch_faults (a k-cut exchange that gives up stores NaN and poisons its counter: loud, sticky), TCE_PLAN_TAGGED on packed copies runs the int8-contraction token kernel (tce_plan_is_chained = 4), TCE_DESC_V2_MAX_BYTES; 0.1.10: tce_attention_decode_step_deferred_f16 + tce_w4a16_forward_deferred_attention (the attention combine in o_proj's prologue); size-prefixed descriptors (tce_w4a16_desc_v2 / tce_w8a8_desc_v2 + the *_v2 entry points; the plain ones stay), TCE_ERR_RCCL, the tuning setters act on the CALLING THREAD only; 0.1.9: tce_w4a16_check_zero_point_8_async, tce_host_alloc / tce_host_free (the adapter no longer synchronises); 0.1.8: per-family tuning setters (tce_attention_set_tuning, tce_w8a8_set_tuning); 0.1.7: decode on the pre-packed copy (int8 contraction), tce_w4a16_set_gemv_i8; 0.1.6: TCE_PLAN_TUNED; 0.1.5: tce_opt_attention_decode; 0.1.4: tce_attention_prefill_f16 (0.1.3: tce_attention_decode_step_gqa_f16, TCE_PLAN_OVERLAPPED; 0.1.2: tce_w4a16_desc.scratch; 0.1.1: .prepacked, tce_w4a16_prepack*) */
 
 /* error codes (return values) */
 #define TCE_OK 0
@@ -99,8 +99,10 @@ typedef struct tce_w4a16_desc {
                                              and add the partial tiles in a fixed order.  One scratch area per stream that runs such
                                              calls concurrently; calls on one stream may share it.  (0.1.10: a range cut in TWO runs is a
                                              directed hand-off -- run 1 waits, for a bounded number of polls, for the tile of run 0, which is
-                                             dispatched before it on the same XCD's queue; the last word of the first 4096 bytes counts waits
-                                             that ran out.  It has never been seen other than zero, and a caller that wants to know reads it.) */
+                                             dispatched before it on the same XCD's queue.  A wait that runs out -- never seen -- is LOUD since
+                                             0.1.11: the tile is stored as NaN, the tile's counter word is poisoned so that every later call
+                                             meeting it stores NaN too, and the last word of the first 4096 bytes counts the faults:
+                                             tce_w4a16_gemm_scratch_faults() reads it; zeroing the first 4096 bytes recovers the area.) */
 } tce_w4a16_desc;
 
 /* flags */
@@ -291,6 +293,10 @@ TCE_API int tce_w4a16_check_zero_point_8_async(const void *zeros, long long n_wo
  * MFMA kernel (csrc/w4a16_gemm_pk.hip) for M > 128 (where its cost model beats the 64-row kernel's); results stay within the W4A16 tolerance of every other path. */
 TCE_API size_t tce_w4a16_prepack_bytes(int N, int K, int group_size);
 TCE_API size_t tce_w4a16_gemm_scratch_bytes(void); /* size of tce_w4a16_desc.scratch (32 MiB + 4 KiB) */
+/* (0.1.11) Exchanges between workgroups on `scratch` that gave up waiting, counted since the area was last zeroed: synchronises `stream`, copies one word.  0 is the only
+ * value ever observed; non-zero means some outputs computed with this area since hold NaN (never a plausible wrong number) and the area stays poisoned until its first
+ * 4096 bytes are zeroed again.  A host that keeps a scratch area for a long time calls this where it synchronises anyway (the adapter: at teardown and on request). */
+TCE_API int tce_w4a16_gemm_scratch_faults(const void *scratch, void *stream, uint32_t *faults);
 TCE_API int tce_w4a16_prepack(const tce_w4a16_desc *d, void *packed, void *stream);
 
 /* count (<= TCE_MAX_GROUP) linears with identical M, K, group_size and A/lda, one launch (GEMV path only). */

@@ -64,7 +64,7 @@ def test_cpp_adapter_selftest(oracle, tmp_path):
     r = subprocess.run([B.ADAPTER_TEST_PATH, str(path)], capture_output=True, text=True, timeout=300)
     print(r.stdout, r.stderr)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("Passed!") == 4 and "Fail!" not in r.stdout
+    assert r.stdout.count("Passed!") == 5 and "Fail!" not in r.stdout  # (round 6: + the GEMM scratch fault count)
 
 
 def test_adapter_bench_tiny_runs_every_leg():

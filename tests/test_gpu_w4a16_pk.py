@@ -380,3 +380,57 @@ def test_two_run_k_cut_as_a_directed_hand_off(dev, oracle):
         finally:
             L.tce_w4a16_set_debug_mode(695)
             L.tce_w4a16_set_debug_mode(60)
+
+
+@pytest.mark.parametrize("mode,what", [(65, "two runs, directed hand-off"), (694, "two runs through the last arriver")])
+def test_a_failed_exchange_is_loud_and_sticky(dev, oracle, mode, what):
+    """Round 6: a k-cut exchange that gives up must not return a plausible number.  The state such a fault leaves behind -- the tile's counter word
+    poisoned -- is planted by hand (the wait itself has never been seen to run out): every launch that meets it stores NaN for that tile, counts a fault
+    (tce_w4a16_gemm_scratch_faults), and keeps doing so until the host zeroes the area's first 4096 bytes; the other tiles and, after the clearing, all tiles are the
+    uncut kernel's."""
+    import ctypes as C
+    from tinychatengine_amd import capi
+    from tinychatengine_amd.linear import Linear_half_int4, gemm_scratch
+    L = capi.lib()
+    M, N, K = 512, 4096, 4096
+    g = torch.Generator(device=dev).manual_seed(77)
+    lin = Linear_half_int4.from_float(torch.empty(N, K, device=dev).normal_(0, 0.02, generator=g), 128).prepack()
+    x = torch.empty(M, K, device=dev).normal_(0, 1, generator=g).to(torch.float16)
+    scratch = gemm_scratch(dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def faults():
+        n = C.c_uint32(0)
+        capi.check(L.tce_w4a16_gemm_scratch_faults(C.c_void_p(scratch.data_ptr()), C.c_void_p(st), C.byref(n)))
+        return n.value
+
+    def run():
+        y = torch.full((M, N), 7.0, dtype=torch.float16, device=dev)
+        capi.check(capi.w4a16_forward(lin.desc(x, y), st))
+        torch.cuda.synchronize()
+        return y
+    try:
+        if mode == 694:
+            capi.check(L.tce_w4a16_set_debug_mode(694))
+        assert "ksplit=2" in capi.describe_dispatch(lin.desc(x, torch.empty((M, N), dtype=torch.float16, device=dev)))
+        assert faults() == 0
+        good = run()
+        assert not torch.isnan(good.float()).any() and faults() == 0
+        words = scratch[:4096].view(torch.int32)
+        words[3] = -2147483648  # 0x80000000: the poison a run 1 leaves when its wait runs out
+        torch.cuda.synchronize()
+        for rep in range(2):
+            bad = run()
+            nan = torch.isnan(bad.float())
+            assert nan.any(), f"{what}: a poisoned counter must not yield a finite tile"
+            rows, cols = nan.any(dim=1).nonzero().flatten(), nan.any(dim=0).nonzero().flatten()
+            assert rows.numel() == 128 and cols.numel() == 128 and bool(nan[rows[0]:rows[-1] + 1, cols[0]:cols[-1] + 1].all()), "exactly one 128 x 128 tile"
+            assert torch.equal(bad[~nan], good[~nan]), "the other tiles are untouched"
+            assert faults() >= rep + 1
+        words.zero_()  # the host's recovery
+        torch.cuda.synchronize()
+        assert torch.equal(run(), good) and faults() == 0
+    finally:
+        scratch[:4096].zero_()
+        L.tce_w4a16_set_debug_mode(695)
+        torch.cuda.synchronize()

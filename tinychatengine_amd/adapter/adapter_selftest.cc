@@ -234,5 +234,7 @@ int main(int argc, char **argv) {
 
     // ---- layout: this build's matmul_params must be the reference's (416 bytes, kernels/matmul.h:78-92) ----
     all_ok &= report("matmul_params layout", tce_adapter_layout(0) == 416);
+    // ---- no k-cut exchange of the prefill calls above gave up (a fault would have stored NaN and poisoned the scratch area: library header, 0.1.11) ----
+    all_ok &= report("GEMM scratch faults == 0", tce_adapter_gemm_faults() == 0);
     return all_ok ? 0 : 1;
 }

@@ -428,6 +428,16 @@ extern "C" long long tce_adapter_prepare(const void *qweight, const void *scales
 }
 
 // Bytes of device memory the adapter holds beyond the model's own tensors (packed copies + AWQ re-layouts).
+// Exchanges between workgroups on the adapter's GEMM scratch area that gave up waiting (tce_w4a16_gemm_scratch_faults: synchronises; 0 is the only value ever
+// observed; non-zero = some prefill outputs since hold NaN and the area is poisoned until tce_adapter_forget_all() is followed by a new area -- a host checks where it
+// synchronises anyway, e.g. once per generated sequence).  -1: the call failed; 0 also when no area was ever allocated.
+extern "C" long tce_adapter_gemm_faults(void) {
+    void *area = gemm_scratch();
+    if (!area) return 0;
+    uint32_t n = 0;
+    return tce_w4a16_gemm_scratch_faults(area, nullptr, &n) == TCE_OK ? (long)n : -1;
+}
+
 extern "C" long long tce_adapter_device_bytes(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     long long n = 0;

@@ -104,6 +104,8 @@ extern "C" long tce_adapter_cache_entries(void);
 // device memory the adapter holds beyond the model's own tensors.
 extern "C" long long tce_adapter_prepare(const void *qweight, const void *scales, const void *zeros, int N, int K, int group_size);
 extern "C" long long tce_adapter_device_bytes(void);
+// faults of the k-cut exchanges on the adapter's GEMM scratch area since start (synchronises the null stream; never seen other than 0; non-zero: NaN outputs, see the library header)
+extern "C" long tce_adapter_gemm_faults(void);
 
 // Layout probe used by the tests: index -> value (0 sizeof(matmul_params), 1 sizeof(matrix), 2.. offsets).
 extern "C" long tce_adapter_layout(int idx);

@@ -670,6 +670,15 @@ size_t tce_w4a16_prepack_bytes(int N, int K, int G) { return tce::prepack_bytes(
 
 size_t tce_w4a16_gemm_scratch_bytes(void) { return tce::gemm_pk_scratch_bytes(); }
 
+int tce_w4a16_gemm_scratch_faults(const void *scratch, void *stream, uint32_t *faults) {
+    if (!scratch || !faults) return fail(TCE_ERR_BAD_ARG, "tce_w4a16_gemm_scratch_faults: null argument");
+    hipError_t e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
+    e = hipMemcpy(faults, static_cast<const unsigned char *>(scratch) + 4096 - 4, sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpy");
+    return TCE_OK;
+}
+
 int tce_w4a16_prepack(const tce_w4a16_desc *d, void *packed, void *stream) {
     if (!d || !packed) return fail(TCE_ERR_BAD_ARG, "tce_w4a16_prepack: null argument");
     if (!d->qweight || !d->scales || !d->zeros || d->N <= 0 || d->K <= 0) return fail(TCE_ERR_BAD_ARG, "tce_w4a16_prepack: null weights / non-positive N, K");

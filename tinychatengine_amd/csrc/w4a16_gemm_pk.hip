@@ -134,6 +134,7 @@ __global__ __launch_bounds__(64) void prepack_decode_kernel(const PrepackArgs a)
 // ------------------------------------------------------------------------------------------------------------------------
 typedef float float2_t __attribute__((ext_vector_type(2)));
 constexpr int kPkFaultWord = 1023;  // last word of the scratch area's counter page
+constexpr unsigned kPkPoison = 0x80000000u;  // a tile counter whose hand-off ran out of patience (sticky until the host clears the page)
 struct PkGemmArgs {
     const half_t *A;
     const uint4_t *words;   // [NT16][NKB][64]
@@ -846,19 +847,37 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
             // alone rather than hanging a queue; it has never been seen to happen), take the counter back to zero for the next launch
             unsigned *flag = reinterpret_cast<unsigned *>(smem);
             __syncthreads();
+            // Round 6: a wait that runs out must be LOUD and must not reach into later launches.  The counter word is 0 (idle), 1 (run 0's tile is there) or
+            // kPkPoison: a run 1 whose wait runs out poisons the word (compare-and-swap 0 -> poison; if run 0 published in that instant the swap fails and all is well),
+            // counts the fault and stores NaN for the whole tile; run 0 publishes with compare-and-swap 0 -> 1, so a late run 0 cannot un-poison the word; every later
+            // launch that meets the poisoned word stores NaN and counts a fault as well -- until the host clears the scratch area's first 4096 bytes
+            // (tce_w4a16_gemm_scratch_faults reports the count).  Round 5 stored the tile with this run's k range alone, returned TCE_OK and zeroed the word, which the late
+            // run 0 then left at 1 for the next launch to trip over.
+            // (Visibility: run 0 stores its partial tile write-through (sc0 sc1), waits for the acknowledgement and only then publishes; the reads below are sc0 sc1 loads
+            //  of those lines -- the pairing MI355X_MICROARCH.md lists as valid without a separate acquire.)
             if (tid == 0) {
                 unsigned v = 0;
                 for (int n = 0; n < (1 << 20) && !v; ++n) {
                     v = __hip_atomic_load(g.counters + tile_lin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (!v) __builtin_amdgcn_s_sleep(2);
                 }
-                __hip_atomic_store(g.counters + tile_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (!v) __hip_atomic_fetch_add(g.counters + kPkFaultWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                *flag = v;
+                if (v == 0u) {  // out of patience
+                    unsigned expect = 0u;
+                    if (!__hip_atomic_compare_exchange_strong(g.counters + tile_lin, &expect, kPkPoison, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) v = expect;
+                }
+                if (v == 1u) __hip_atomic_store(g.counters + tile_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+                else __hip_atomic_fetch_add(g.counters + kPkFaultWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *flag = v == 1u ? 1u : 2u;
             }
             __syncthreads();
-            const bool have = *flag != 0u;
+            const bool have = *flag == 1u;
             __syncthreads();  // (the flag word is part of the output tile's LDS image below)
+            if (!have) {
+#pragma unroll
+                for (int i = 0; i < kMT; ++i)
+#pragma unroll
+                    for (int j = 0; j < kNT; ++j) acc[i][j] = float4_t{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+            }
             if (have) {  // run order: run 0's partial first, then this run's (the same sum the last-arriver form computes)
                 uint4_t t4[kMT * kNT];
 #pragma unroll
@@ -882,19 +901,33 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         unsigned *flag = reinterpret_cast<unsigned *>(smem);
         __syncthreads();
-        if (handoff) {  // run 0 of a hand-off: its tile is acknowledged; raise the counter and leave
-            if (tid == 0) __hip_atomic_store(g.counters + tile_lin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (handoff) {  // run 0 of a hand-off: its tile is acknowledged; raise the counter (0 -> 1 only: a poisoned word stays poisoned) and leave
+            if (tid == 0) {
+                unsigned expect = 0u;
+                (void)__hip_atomic_compare_exchange_strong(g.counters + tile_lin, &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             return;
         }
         if (tid == 0) {
             const unsigned old = __hip_atomic_fetch_add(g.counters + tile_lin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned last = old == (unsigned)split - 1 ? 1u : 0u;
+            unsigned last = old == (unsigned)split - 1 ? 1u : 0u;
             if (last) __hip_atomic_store(g.counters + tile_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+            if (old >= (unsigned)split) {  // a word an earlier launch's fault left poisoned: nobody would ever be last -- run 0 stores NaN for the tile, the fault is counted
+                __hip_atomic_fetch_add(g.counters + kPkFaultWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = part == 0 ? 2u : 0u;
+            }
             *flag = last;
         }
         __syncthreads();
-        if (*flag == 0u) return;
+        const unsigned role = *flag;
+        if (role == 0u) return;
         __syncthreads();  // (the flag word is part of the output tile's LDS image below)
+        if (role == 2u) {
+#pragma unroll
+            for (int i = 0; i < kMT; ++i)
+#pragma unroll
+                for (int j = 0; j < kNT; ++j) acc[i][j] = float4_t{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+        } else
         // the sum in run order 0, 1, ..., split_s - 1 whoever computes it
         if constexpr (kMT * kNT > 16) {
             // 256-row and wide tiles: 128 accumulator registers leave no room for a second copy -- every run's partial (this one's included: the same values it stored) is

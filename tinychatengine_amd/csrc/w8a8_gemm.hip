@@ -800,8 +800,10 @@ int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err,
             else hipLaunchKernelGGL((w8a8_mfma_deep_kernel<1, 8>), grid, dim3(256), dl, stream, a);
         } else
         // round 6: few 64 x 64 tiles with a long chain -- 512 x 768 x 3072 is 96 workgroups on 256 CUs -- run on 32 x 64 tiles instead (twice the
-        // workgroups, the same chain per quartet; each CU pulls half the rows through its L1).  The rule: at most 128 tiles of 64 x 64, at least two 32-row tiles, >= 24 k-steps.
-        if ((g_w8a8_rows32 == 1 || (g_w8a8_rows32 == 0 && tiles <= 128 && d.K / 64 >= 24)) && d.M > 32) {
+        // workgroups, the same chain per quartet; each CU pulls half the rows through its L1).  The rule: at most 128 tiles of 64 x 64, at least two 32-row tiles, >= 12 k-steps.
+        // MEASURED (profiles/r6/w8a8_rows32_ab.jsonl, weights from HBM): 512 x 768 x 3072 13.19 -> 10.16 us (bench harness, weights in L2: 10.85 -> 8.16), 512 x 768 x 768
+        // 6.26 -> 5.04 (hence >= 12 k-steps, not 24); 108 x 768 x 3072 a tie (13.6: the cut across workgroups above serves it); two quartets = four.
+        if ((g_w8a8_rows32 == 1 || (g_w8a8_rows32 == 0 && tiles <= 128 && d.K / 64 >= 12)) && d.M > 32) {
             const dim3 g32(grid.x, (d.M + 31) / 32, d.batch);
             const long tiles32 = (long)g32.x * g32.y * g32.z;
             int ks32 = g_w8a8_ks == 3 ? 0 : g_w8a8_ks;
