@@ -7,6 +7,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
+from tinychatengine_amd import lab; lab.use_lab()  # (loop parts switched off: the diagnostics build)
 from tinychatengine_amd import capi
 from tinychatengine_amd.linear import Linear_half_int4
 

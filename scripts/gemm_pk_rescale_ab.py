@@ -6,6 +6,7 @@ Boxes differ by 4-8 % on MFMA work, so only numbers taken in one process compare
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from tinychatengine_amd import lab; lab.use_lab()  # (the scalar-rescale instantiation: the diagnostics build)
 from tinychatengine_amd import capi
 from tinychatengine_amd.linear import Linear_half_int4
 

@@ -6,6 +6,7 @@ usage: gemm_pkw_sweep.py [--abl] [MxNxK ...]"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from tinychatengine_amd import lab; lab.use_lab()  # (loop parts switched off: the diagnostics build)
 from tinychatengine_amd import capi
 from tinychatengine_amd.linear import Linear_half_int4
 dev = torch.device("cuda:0"); L = capi.lib(); st = torch.cuda.current_stream().cuda_stream

@@ -5,6 +5,7 @@ verifies every output bit-identical, then times both, for a list of (branches, w
 import ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+from tinychatengine_amd import lab; lab.use_lab()  # (per-launch stamps: the diagnostics build)
 from tinychatengine_amd import capi
 from tinychatengine_amd.decode import SHAPES, DecodeLinears
 

@@ -5,6 +5,8 @@ the hipGraph of stream-ordered launches -- outputs compared bit for bit, both ti
 import argparse, ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
+if "--stamps" in sys.argv:
+    from tinychatengine_amd import lab; lab.use_lab()  # (the token kernel with wall-clock stamps: the diagnostics build)
 from tinychatengine_amd import capi
 from tinychatengine_amd.decode import SHAPES, DecodeLinears
 

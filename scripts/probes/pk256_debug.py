@@ -1,6 +1,7 @@
 import sys, os, json
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch
+from tinychatengine_amd import lab; lab.use_lab()  # (loop parts switched off: the diagnostics build)
 from tinychatengine_amd import capi
 from tinychatengine_amd.linear import Linear_half_int4
 dev = torch.device("cuda:0"); L = capi.lib(); st = torch.cuda.current_stream().cuda_stream

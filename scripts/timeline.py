@@ -3,6 +3,7 @@
 import ctypes as C, json, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tinychatengine_amd import lab; lab.use_lab()  # (the decode kernel's timestamp form: the diagnostics build)
 from tinychatengine_amd import capi, quantize
 dev = torch.device("cuda:0")
 L = capi.lib()

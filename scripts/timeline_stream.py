@@ -3,6 +3,8 @@
 import ctypes as C, json, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tinychatengine_amd import lab; lab.use_lab()  # (the persistent kernel's timestamp form: the diagnostics build)
 from overlap_exp import mk, timeit, L, capi
 def main():
     for (segs, K) in [([11008, 11008], 4096), ([128256], 4096)]:

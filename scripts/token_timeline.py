@@ -4,6 +4,7 @@ while the tagged plan is built).  Prints one JSON line per launch shape (average
 import ctypes as C, json, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+from tinychatengine_amd import lab; lab.use_lab()  # (per-launch stamps: the diagnostics build)
 from tinychatengine_amd import capi
 from tinychatengine_amd.decode import SHAPES, DecodeLinears
 

@@ -26,7 +26,7 @@ def built():
 
 
 def _declared_symbols():
-    src = open(os.path.join(REPO, "include", "tce_matmul.h")).read()
+    src = open(os.path.join(REPO, "include", "tce_matmul.h")).read() + open(os.path.join(REPO, "include", "tce_tuning.h")).read()  # (round 6: the tuning entry points have their own header)
     return sorted(set(re.findall(r"TCE_API\s+[\w\s\*]+?\b(tce_\w+)\s*\(", src)))
 
 
@@ -211,3 +211,40 @@ def test_missing_library_fails_loudly(built, monkeypatch):
     monkeypatch.setattr(capi, "LIB_PATH", "/nonexistent/libtce_hip.so")
     with pytest.raises(RuntimeError, match="no CPU or PyTorch fallback"):
         capi.lib()
+
+
+def test_the_product_library_holds_no_diagnostic_instantiation(built):
+    """Round 6: libtce_hip.so is built without -DTCE_LAB -- the kernels with parts of a loop switched off (outputs meaningless), the stream-only /
+    timestamp / arithmetic-only forms of the decode kernels and the token kernel's stamped form exist in libtce_hip_lab.so only (python -m tinychatengine_amd.build
+    --lab).  The build writes the product's kernel list next to the library; held here: the list is what the objects hold, none of its entries is a diagnostic
+    instantiation, and the modes that select one are refused by the product library."""
+    import re
+    from tinychatengine_amd import build as B
+    path = B.LIB_PATH + ".kernels.txt"
+    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(B.LIB_PATH):
+        objs = [os.path.join(B.LIB_DIR, s.replace(".hip", ".o")) for s in B.HIP_SOURCES]
+        B.write_kernel_list(objs, B.LIB_PATH)
+    lines = [ln.strip() for ln in open(path) if ln.strip() and not ln.startswith("#")]
+    assert len(lines) > 300
+    bad = []
+    for ln in lines:
+        name = ln.split(": ", 1)[1]
+        m = re.match(r"void w4a16_gemm_pk\w*_kernel<(.*?)>\(", name)
+        if m:  # <KS, LG, ABL, NS> or <LG, ABL>: ABL = loop parts switched off
+            args = [a.strip() for a in m.group(1).split(",")]
+            abl = args[2] if name.startswith("void w4a16_gemm_pk_kernel<") else args[1]
+            if abl != "0":
+                bad.append(ln)
+        m = re.match(r"void w4a16_gemv_kernel<(.*?)>\(", name)
+        if m and m.group(1).split(",")[6].strip() in ("1", "2", "4"):  # MODE: 1 stream only, 2 timestamps, 4 arithmetic only
+            bad.append(ln)
+        m = re.match(r"void w4a16_gemv_stream_kernel<(.*?)>\(", name)
+        if m and m.group(1).split(",")[3].strip() != "0":
+            bad.append(ln)
+        if name.startswith("void w4a16_gemv_i8_token_kernel<true>"):
+            bad.append(ln)
+    assert not bad, "diagnostic instantiations in the product library:\n" + "\n".join(bad[:10])
+    L = built.lib()
+    for mode in (601, 655, 2607, 26001, 1, 2, 4, 7702):
+        assert L.tce_w4a16_set_debug_mode(mode) == -1 and b"lab build" in L.tce_last_error(), mode
+    assert L.tce_w4a16_set_debug_mode(600) == 0 and L.tce_w4a16_set_debug_mode(0) == 0

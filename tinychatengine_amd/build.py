@@ -17,6 +17,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libtce_hip.so")
 ADAPTER_LIB_PATH = os.path.join(LIB_DIR, "libtce_matmul_operator.so")
+LAB_LIB_PATH = os.path.join(LIB_DIR, "libtce_hip_lab.so")
 TESTKIT_LIB_PATH = os.path.join(LIB_DIR, "libtce_testkit.so")
 ADAPTER_TEST_PATH = os.path.join(LIB_DIR, "adapter_selftest")
 ADAPTER_BENCH_PATH = os.path.join(LIB_DIR, "adapter_bench")
@@ -33,7 +34,7 @@ EXTRA_FLAGS: dict[str, list[str]] = {}  # (-fno-slp-vectorize on the GEMM: no pa
 # makes the compiler wait for all of them at the spill (measured: the OPT-6.7B layer 94 -> 103 us, found only by accident).  The build fails instead.
 NO_VGPR_SPILL: dict[str, list[str]] = {"w8a8_lnq_fused.hip": ["lnq_w8a8_wide_kernel"],
                                         "w4a16_gemv_stream.hip": ["w4a16_gemv_token_kernel"],
-                                        "w4a16_gemv_i8_token.hip": ["w4a16_gemv_i8_token_kernel"],
+                                        "w4a16_gemv_i8_token.hip": ["w4a16_gemv_i8_token_kernelILb0E"],  # (ILb1E: the lab build's instantiation with wall-clock stamps)
                                         # round 5: EVERY instantiation of the decode kernel, the general-zero-point forms included (round 4 let four of them spill 3-19 registers: each
                                         # spilled scale / zero-point load became load -> wait -> scratch store, i.e. the wave's requests went out one at a time)
                                         "w4a16_gemv_i8.hip": ["w4a16_gemv_i8_kernel"],
@@ -65,6 +66,21 @@ def _check_spills(src: str, stderr_text: str) -> None:
                 raise RuntimeError(f"{src}: kernel {name} spills {n} vector registers (see NO_VGPR_SPILL in build.py)")
 
 
+def write_kernel_list(objs: list[str], lib_path: str) -> str:
+    """<library>.kernels.txt: every device kernel of the library, demangled, one per line (what tests/test_boundary.py holds the product library to: no diagnostic
+    instantiation in it), with the library's size in the first line."""
+    from . import isa_lint
+    names = []
+    for o in objs:
+        ks = isa_lint.kernels(isa_lint.disassemble(o))
+        names += [f"{os.path.basename(o)[:-2]}: {n}" for n in isa_lint.demangle(list(ks.keys()))]
+    path = lib_path + ".kernels.txt"
+    with open(path, "w") as f:
+        f.write(f"# {os.path.basename(lib_path)}: {os.path.getsize(lib_path)} bytes, {len(names)} kernels\n")
+        f.write("\n".join(sorted(names)) + "\n")
+    return path
+
+
 def _hipcc() -> str:
     for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -79,17 +95,23 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, lab: bool = False) -> str:
+    """lab = False: libtce_hip.so, the product -- the kernels the dispatcher (and the forced-form settings the parity tests use) can reach.
+    lab = True: libtce_hip_lab.so from the same sources with -DTCE_LAB: additionally the diagnostic instantiations (parts of a loop switched off, stream-only /
+    timestamp / arithmetic-only forms, the token kernel's stamps) that scripts/ use for timelines and ablations; objects under lib/lab/.  TCE_LIB_PATH selects it."""
     os.makedirs(LIB_DIR, exist_ok=True)
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + [os.path.join(REPO_DIR, "include", "tce_matmul.h")]
+    obj_dir = os.path.join(LIB_DIR, "lab") if lab else LIB_DIR
+    os.makedirs(obj_dir, exist_ok=True)
+    lib_path = LAB_LIB_PATH if lab else LIB_PATH
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + [os.path.join(REPO_DIR, "include", "tce_matmul.h"), os.path.join(REPO_DIR, "include", "tce_tuning.h")]
     objs, jobs = [], []
     hipcc = _hipcc()
     for src in HIP_SOURCES:
         sp = os.path.join(CSRC, src)
-        op = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
+        op = os.path.join(obj_dir, src.replace(".hip", ".o"))
         if force or _stale(op, [sp] + headers):
             check = ["-Rpass-analysis=kernel-resource-usage"] if src in NO_VGPR_SPILL else []
-            jobs.append([hipcc, *HIPCC_FLAGS, *EXTRA_FLAGS.get(src, []), *check, "-I", os.path.join(REPO_DIR, "include"), "-I", CSRC, "-c", sp, "-o", op])
+            jobs.append([hipcc, *HIPCC_FLAGS, *(["-DTCE_LAB"] if lab else []), *EXTRA_FLAGS.get(src, []), *check, "-I", os.path.join(REPO_DIR, "include"), "-I", CSRC, "-c", sp, "-o", op])
         objs.append(op)
     if jobs:  # the translation units are independent: compile them side by side
         from concurrent.futures import ThreadPoolExecutor
@@ -125,11 +147,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
             list(pool.map(run, jobs))
-    if force or _stale(LIB_PATH, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs]
+    if force or _stale(lib_path, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path, *objs]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        write_kernel_list(objs, lib_path)
+    if lab:
+        return lib_path
     # test infrastructure (tests/, scripts/probes/ only): a launch that fills every CU's registers and LDS with NaNs (csrc/testkit_poison.hip)
     tk_src = os.path.join(CSRC, "testkit_poison.hip")
     if force or _stale(TESTKIT_LIB_PATH, [tk_src]):
@@ -174,5 +199,11 @@ def build_adapter(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
+    if "--lab" in sys.argv:  # the diagnostics build only (scripts/: timelines, ablations); the product is what every other invocation builds
+        print(build(force="--force" in sys.argv, verbose=True, lab=True))
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_adapter(force="--force" in sys.argv, verbose=True))
+    for p_ in (LIB_PATH, LAB_LIB_PATH):
+        if os.path.exists(p_ + ".kernels.txt"):
+            print(open(p_ + ".kernels.txt").readline().strip())

@@ -200,7 +200,12 @@ int tce_w4a16_set_debug_mode(int mode) {
     if (mode >= 7700 && mode <= 7703) {  // TCE_PLAN_TAGGED on packed copies (round 6): 7700 the int8-contraction token kernel where the list allows (default), 7701 never (round 2's kernel);
                                          // 7702 / 7703: plans built from now on record per-stage wall-clock stamps in the debug buffer (tce_w4a16_set_debug_buffer) / stop
         if (mode <= 7701) tce::set_i8_token_mode(mode - 7700);
-        else tce::set_i8_token_stamps(mode == 7702 ? g_dbg_buf_capi : nullptr);
+        else {
+#ifndef TCE_LAB
+            if (mode == 7702) return fail(TCE_ERR_BAD_ARG, "debug mode 7702 (per-stage stamps of the token kernel) needs the lab build (python -m tinychatengine_amd.build --lab, TCE_LIB_PATH)");
+#endif
+            tce::set_i8_token_stamps(mode == 7702 ? g_dbg_buf_capi : nullptr);
+        }
         return TCE_OK;
     }
     if (mode >= 190 && mode <= 192) {  // W8A8, 32 x 64 tiles (round 6): 190 the rule, 191 forced wherever the 64 x 64 kernel would run, 192 off
@@ -230,6 +235,13 @@ int tce_w4a16_set_debug_mode(int mode) {
         tce::set_gemm_pk_split(mode - 640);
         return TCE_OK;
     }
+#ifndef TCE_LAB
+    // Round 6: the instantiations with parts of a loop switched off (600+a, 2600+a, 26000+a: outputs meaningless), the decode kernels' stream-only / timestamp /
+    // arithmetic-only forms (1, 2, 4) and the token kernel's stamps (7702) are compiled into libtce_hip_lab.so only (python -m tinychatengine_amd.build --lab;
+    // TCE_LIB_PATH selects it): the product library holds kernels the dispatcher can reach.
+    if ((mode > 2600 && mode <= 2664) || (mode > 600 && mode <= 664) || (mode > 26000 && mode <= 26256) || mode == 1 || mode == 2 || mode == 4 || mode == 7702)
+        return fail(TCE_ERR_BAD_ARG, "debug mode %d selects a diagnostic instantiation that only the lab build holds (python -m tinychatengine_amd.build --lab, TCE_LIB_PATH)", mode);
+#endif
     if (mode >= 2600 && mode <= 2664) {  // the same switches on the 256-row form (round 5)
         g_pk_mode = mode == 2600 ? 0 : 6;
         tce::set_gemm_pk_mode(mode == 2600 ? 0 : 6, 0);

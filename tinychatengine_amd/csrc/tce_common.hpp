@@ -6,6 +6,7 @@
 #include <type_traits>
 
 #include "tce_matmul.h"
+#include "tce_tuning.h"
 
 namespace tce {
 

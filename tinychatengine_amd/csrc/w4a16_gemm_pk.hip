@@ -1176,7 +1176,11 @@ hipError_t launch_pk256(PkGemmArgs &g, hipStream_t stream) {
 
 }  // namespace
 
+#ifdef TCE_LAB
 void set_gemm_pk_ablation(int abl) { g_pk_abl = abl; }
+#else
+void set_gemm_pk_ablation(int) { g_pk_abl = 0; }  // (the loop-parts-switched-off instantiations exist in the lab build only: build.py --lab)
+#endif
 void set_gemm_pk256_auto(int on) { g_pk256_auto = on ? 1 : 0; }
 void set_gemm_pk_wide_auto(int on) { g_pk_wide_auto = on ? 1 : 0; }
 void set_gemm_pk_handoff(int on) { g_pk_handoff = on ? 1 : 0; }
@@ -1445,6 +1449,7 @@ int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_
     const int ks = form;
     hipError_t e;
     const int lg = d.group_size == 128 ? 7 : (d.group_size == 64 ? 6 : 5);
+#ifdef TCE_LAB
     if (wide && lg == 7 && g_pk_abl && !widex2 && !wide3 && !wide512) {  // timing experiments on the wide form (results meaningless)
         switch (g_pk_abl) {
 #define TCE_ABL(X) case X: e = launch_pkw<7, X>(g, stream); break;
@@ -1458,6 +1463,8 @@ int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_
         }
         return TCE_OK;
     }
+#endif
+#ifdef TCE_LAB
     if (g_pk_abl && lg == 7 && !rows256 && !wide) {
         switch (g_pk_abl) {
 #define TCE_ABL(X) case X: e = launch_pk<1, 7, X>(g, stream); break;
@@ -1471,11 +1478,13 @@ int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_
         }
         return TCE_OK;
     }
+#endif
     if (wide512) e = launch_pkw512(g, stream);
     else if (wide3) e = form == 14 ? launch_pkw3<2>(g, stream) : launch_pkw3<1>(g, stream);
     else if (wide) e = widex2 ? launch_pkwx2<7>(g, stream) : launch_pkw<7>(g, stream);
     else if (rows256w) e = launch_pk256w<7>(g, stream);
     else if (rows256x2) e = launch_pk256x2<7>(g, stream);
+#ifdef TCE_LAB
     else if (rows256 && g_pk_abl) {  // timing experiments on the 256-row form (results meaningless): tce_w4a16_set_debug_mode(66), then 600 + bits as for the 128-row form
         switch (g_pk_abl) {
 #define TCE_ABL(X) case X: e = launch_pk256<7, X>(g, stream); break;
@@ -1484,6 +1493,7 @@ int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_
             default: return TCE_ERR_BAD_ARG;
         }
     } else if (rows256) e = launch_pk256<7>(g, stream);  // (groups of 128 only: gemm_pk_estimate_us offers forms 6 / 7 for no other group size)
+#endif
     else if (ks == 3) e = lg == 7 ? launch_pk<1, 7, 0, 2>(g, stream) : (lg == 6 ? launch_pk<1, 6, 0, 2>(g, stream) : launch_pk<1, 5, 0, 2>(g, stream));
     else if (ks == 2) e = lg == 7 ? launch_pk<2, 7>(g, stream) : (lg == 6 ? launch_pk<2, 6>(g, stream) : launch_pk<2, 5>(g, stream));
     else e = lg == 7 ? launch_pk<1, 7>(g, stream) : (lg == 6 ? launch_pk<1, 6>(g, stream) : launch_pk<1, 5>(g, stream));

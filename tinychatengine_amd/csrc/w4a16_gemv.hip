@@ -508,10 +508,12 @@ hipError_t launch_variant(const GemvArgs &a, int total_blocks, int m_blocks, hip
                                      : launch_one<1, ROWS, WN, WK, DEPTH, 2, 0, false, true>(a, total_blocks, m_blocks, stream);
                 }
             }
+#ifdef TCE_LAB  // (diagnostic instantiations -- stream only / timestamps / arithmetic only --: the lab build, build.py --lab)
             if (g_debug_mode == 1) return launch_one<1, ROWS, WN, WK, DEPTH, 8, 1>(a, total_blocks, m_blocks, stream);
             if (g_debug_mode == 2) return launch_one<1, ROWS, WN, WK, DEPTH, 2, 2>(a, total_blocks, m_blocks, stream);
-            if (g_debug_mode == 3) return launch_one<1, ROWS, WN, WK, DEPTH, 2, 3>(a, total_blocks, m_blocks, stream);
             if (g_debug_mode == 4) return launch_one<1, ROWS, WN, WK, DEPTH, 2, 4>(a, total_blocks, m_blocks, stream);
+#endif
+            if (g_debug_mode == 3) return launch_one<1, ROWS, WN, WK, DEPTH, 2, 3>(a, total_blocks, m_blocks, stream);
         }
         // MODE 3 = "x first": the workgroup stages x completely before it issues its first weight load.  When the whole
         // grid is resident at once (one generation of workgroups) this keeps the x loads from queueing behind HBM-bound

@@ -482,7 +482,11 @@ int i8_token_plan_create(const tce_w4a16_desc *descs, const int32_t *groups, int
     if (g_tok_mode == 1) return TCE_ERR_UNSUPPORTED_SHAPE;
     const int cus = tok_num_cus();
     if (cus == 0) return TCE_ERR_HIP;
+#ifdef TCE_LAB
     const void *kfn = g_tok_stamps ? reinterpret_cast<const void *>(w4a16_gemv_i8_token_kernel<true>) : reinterpret_cast<const void *>(w4a16_gemv_i8_token_kernel<false>);
+#else
+    const void *kfn = reinterpret_cast<const void *>(w4a16_gemv_i8_token_kernel<false>);  // (the instantiation with wall-clock stamps: the lab build, build.py --lab)
+#endif
     hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     int per_cu = 0;
     if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 64 * kTokWaves, kLdsBytes);
@@ -543,7 +547,9 @@ int i8_token_plan_create(const tce_w4a16_desc *descs, const int32_t *groups, int
     if (!tp) return TCE_ERR_BAD_ARG;
     tp->n = n;
     tp->blocks = P;
+#ifdef TCE_LAB
     tp->stamps = g_tok_stamps;
+#endif
     auto n_out_of = [&](const TokStage &L, int i) { return (L.seg[i].epilogue & TCE_W4_SILU_MUL_PAIRS) ? L.seg[i].N / 2 : L.seg[i].N; };
     // the shadow vectors: one per linear of every stage (buffers reused from layer to layer must not alias)
     size_t words = 0;
@@ -643,8 +649,11 @@ int i8_token_plan_enqueue(I8TokenPlan *tp, hipStream_t stream, hipError_t *hip_e
     a.epoch = tp->sync + 1;
     a.dbg = tp->stamps;
     const dim3 grid(tp->blocks), block(64 * kTokWaves);
+#ifdef TCE_LAB
     if (tp->stamps) hipLaunchKernelGGL(w4a16_gemv_i8_token_kernel<true>, grid, block, kLdsBytes, stream, a);
-    else hipLaunchKernelGGL(w4a16_gemv_i8_token_kernel<false>, grid, block, kLdsBytes, stream, a);
+    else
+#endif
+    hipLaunchKernelGGL(w4a16_gemv_i8_token_kernel<false>, grid, block, kLdsBytes, stream, a);
     hipLaunchKernelGGL(i8_token_epoch_kernel, dim3(1), dim3(1), 0, stream, tp->sync + 1);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -691,12 +691,15 @@ int launch_w4a16_gemv_stream(const tce_w4a16_desc *descs, int count, hipStream_t
 
     hipError_t e = hipSuccess;
     bool found = true;
+#ifdef TCE_LAB  // (diagnostic instantiations -- stream only / timestamps / arithmetic only --: the lab build, build.py --lab)
     if (g_stream_mode != 0) {
         const int md = g_stream_mode;
         if (rows == 2 && depth == 2) e = md == 1 ? launch_stream<2, 2, false, 1>(a, blocks, nw, stream) : (md == 4 ? launch_stream<2, 2, false, 4>(a, blocks, nw, stream) : launch_stream<2, 2, false, 2>(a, blocks, nw, stream));
         else if (rows == 4 && depth == 2) e = md == 1 ? launch_stream<4, 2, false, 1>(a, blocks, nw, stream) : (md == 4 ? launch_stream<4, 2, false, 4>(a, blocks, nw, stream) : launch_stream<4, 2, false, 2>(a, blocks, nw, stream));
         else return TCE_ERR_BAD_ARG;
-    } else {
+    } else
+#endif
+    {
 #define TCE_S(R_, D_) \
     if (rows == R_ && depth == D_) e = z8 ? launch_stream<R_, D_, true>(a, blocks, nw, stream) : launch_stream<R_, D_, false>(a, blocks, nw, stream); else
         TCE_S(1, 2) TCE_S(1, 3) TCE_S(2, 2) TCE_S(2, 3) TCE_S(4, 2)
