@@ -61,8 +61,9 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true", help="N > 1: issue the token eagerly instead of capturing GEMVs + gathers into one graph")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (gloo + TCE_BENCH_SINGLE_DEVICE=1: exercise the multi-rank orchestration on one GPU)")
     ap.add_argument("--selftest-emit", default="", help=argparse.SUPPRESS)
-    ap.add_argument("--cpu-worker", default="", choices=["", "avx", "ref"], help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-worker", default="", choices=["", "avx", "avx_cold", "ref", "parity"], help=argparse.SUPPRESS)
     ap.add_argument("--threads", type=int, default=8, help=argparse.SUPPRESS)
+    ap.add_argument("--parity-dir", default="", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -116,6 +117,12 @@ def compact_line(full: dict, details_file: str | None = None, budget: int = LINE
         if isinstance(cpu.get("sample"), str):
             cc["sample"] = cpu["sample"][:160]
         out["cpu_baseline"] = cc
+        if "value_weights_from_dram" in cpu:
+            cc["value_weights_from_dram"] = cpu["value_weights_from_dram"]
+    par = full.get("parity")
+    if isinstance(par, dict):
+        opt(0, "parity", {k: par[k] for k in ("worst_err_over_tol", "max_share_passing_only_through_the_floor", "max_share_failing_with_floor_rms_over_256", "error") if k in par}
+            | ({"linears_checked": len(par["rows"])} if isinstance(par.get("rows"), list) else {}))
     rn = full.get("cpu_baseline_ref_naive")
     if isinstance(rn, dict):
         opt(1, "cpu_baseline_ref_naive", {"value": rn.get("value"), "unit": rn.get("unit"), "cores": rn.get("cores"), "kind": rn.get("kind"), "sample": str(rn.get("sample", ""))[:90]})
@@ -830,6 +837,8 @@ def cpu_baseline_worker(args):
     from tinychatengine_amd.decode import SHAPES
     shape = SHAPES[args.workload]
     kind, threads = args.cpu_worker, args.threads
+    if kind == "parity":
+        return parity_worker(args)
     h, f = shape.hidden, shape.ffn
     block = [(n, h) for n in shape.qkv] + [(h, h), (f, h), (f, h), (h, f)]
     head = (shape.vocab, h)
@@ -838,9 +847,20 @@ def cpu_baseline_worker(args):
     for (n, k) in block + [head]:
         codes = rng.integers(0, 16, (n, k), dtype=np.uint8)  # timing does not depend on the code values
         a = rng.standard_normal((1, k)).astype(np.float16).astype(np.float32)
-        if kind == "avx":
+        if kind in ("avx", "avx_cold"):
             d = (rng.random((n, k // 32), dtype=np.float32) * 0.01 + 0.001)
-            call = O.ReferenceAVX(num_thread=threads).make_timed_call(a, O.ReferenceAVX.pack_q4_3(codes), d, 1, n, k)
+            packed = O.ReferenceAVX.pack_q4_3(codes)
+            ref_avx = O.ReferenceAVX(num_thread=threads)
+            if kind == "avx":  # ten repetitions on ONE copy: a linear's 8-30 MB of W4A8 weights stay in this host's L3
+                call = ref_avx.make_timed_call(a, packed, d, 1, n, k)
+            else:  # (round 6) the weights from DRAM, as the GPU leg's come from HBM: copies in rotation, > 768 MB between two uses of one
+                ncopy = max(2, min(32, int(768e6 // packed.nbytes) + 1))
+                calls = [ref_avx.make_timed_call(a, packed.copy(), d.copy(), 1, n, k) for _ in range(ncopy)]
+                it = [0]
+
+                def call(calls=calls, it=it):
+                    calls[it[0] % len(calls)]()
+                    it[0] += 1
             warm, reps = 3, 10
         else:
             ref = O.Reference()
@@ -859,6 +879,65 @@ def cpu_baseline_worker(args):
         else:
             t_block += dt
     print(json.dumps({"tokens_per_s": 1.0 / (t_block * shape.layers + t_head), "block_ms": t_block * 1e3, "lm_head_ms": t_head * 1e3}))
+
+
+def parity_worker(args):
+    """Child process (the CHECKER, not the thing measured): the outputs the GPU produced for full-size linears of the headline workload (written to a scratch directory by
+    parity_leg) against the oracle's restatement of the reference arithmetic -- per linear the worst error over the tests' tolerance 1e-3 * max(|ref|, rms / 64), the share of
+    outputs that pass only through the rms / 64 floor, and what a floor of rms / 256 would fail."""
+    import numpy as np
+    from oracle.oracle import Oracle
+    orc = Oracle()
+    rows = []
+    for name in sorted(os.listdir(args.parity_dir)):
+        if not name.endswith(".npz"):
+            continue
+        z = np.load(os.path.join(args.parity_dir, name))
+        n, k = int(z["n"]), int(z["k"])
+        ref = orc.w4a16_gemv_q4_6_mt(z["x"], z["qweight"].view(np.uint32), z["scales"], z["zeros"].view(np.uint32), 1, n, k, 128).astype(np.float64).ravel()
+        got = z["y"].astype(np.float64).ravel()
+        rms = float(np.sqrt(np.mean(ref * ref)))
+        err = np.abs(got - ref)
+        tol64, tol256 = 1e-3 * np.maximum(np.abs(ref), rms / 64.0), 1e-3 * np.maximum(np.abs(ref), rms / 256.0)
+        rows.append({"linear": name[:-4], "N": n, "K": k, "worst_err_over_tol": round(float((err / tol64).max()), 3),
+                     "share_passing_only_through_the_floor": round(float((err > 1e-3 * np.abs(ref)).mean()), 6),
+                     "share_failing_with_floor_rms_over_256": round(float((err > tol256).mean()), 6),
+                     "worst_err_over_tol_with_floor_rms_over_256": round(float((err / tol256).max()), 3),
+                     "err_rms_over_ref_rms": float(f"{np.sqrt(np.mean(err * err)) / rms:.3e}")})
+    print(json.dumps({"rows": rows}))
+
+
+def parity_leg(dl, torch, workload: str):
+    """Tolerance evidence in the driver's own record: block 0's linears and lm_head of the headline workload, FULL size, M = 1 -- computed by the
+    product path here, checked by the oracle in a child process (the cpu_baseline leg's checker; nothing of oracle/ is imported into this process)."""
+    import shutil
+    import subprocess
+    import tempfile
+    import numpy as np
+    d = tempfile.mkdtemp(prefix="tce_parity_")
+    try:
+        b = dl.blocks[0]
+        gx = torch.Generator(device=dl.device).manual_seed(777)
+        named = [(f"{i}_{nm}", l) for i, (nm, l) in enumerate([*[(f"qkv{j}", l) for j, l in enumerate(b["qkv"])], ("o", b["o"]), ("gate", b["gate"]), ("up", b["up"]), ("down", b["down"]),
+                                                              ("lm_head", dl.lm_head)])]
+        for nm, l in named:
+            x = torch.empty((1, l.in_features), dtype=torch.float32, device=dl.device).normal_(0, 1, generator=gx).to(torch.float16)
+            y = l.forward(x)
+            torch.cuda.synchronize()
+            np.savez(os.path.join(d, nm + ".npz"), n=l.out_features, k=l.in_features, x=x.cpu().numpy(), y=y.cpu().numpy(), qweight=l.weight.cpu().numpy(),
+                     scales=l.scale.cpu().numpy(), zeros=l.zero_point.cpu().numpy())
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", "parity", "--parity-dir", d, "--workload", workload]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+        if r.returncode != 0:
+            return {"error": f"exit {r.returncode}: {r.stderr.strip()[-300:]}"}
+        rows = json.loads(r.stdout.strip().splitlines()[-1])["rows"]
+        return {"tolerance": "|gpu - oracle| <= 1e-3 * max(|oracle|, rms(oracle) / 64) per output (tests/conftest.py w4a16_close); every output of every listed linear checked",
+                "worst_err_over_tol": max(x["worst_err_over_tol"] for x in rows), "max_share_passing_only_through_the_floor": max(x["share_passing_only_through_the_floor"] for x in rows),
+                "max_share_failing_with_floor_rms_over_256": max(x["share_failing_with_floor_rms_over_256"] for x in rows), "rows": rows}
+    except Exception as e:  # noqa: BLE001 -- evidence, never the reason a bench line is missing
+        return {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def cpu_baseline_leg(workload: str, shape):
@@ -893,8 +972,11 @@ def cpu_baseline_leg(workload: str, shape):
             if "tokens_per_s" in r and (best is None or r["tokens_per_s"] > best[1]):
                 best = (th, r["tokens_per_s"])
         if best:
+            cold = run("avx_cold", best[0])
+            res[f"avx_cold_{best[0]}t"] = cold
             res["avx"] = {"value": round(best[1], 3), "unit": "tokens/s", "cores": best[0], "kind": "reference",
-                          "sample": f"kernels/avx mat_mul_accelerator_int8_int4_fast_no_offset (W4A8, group 32, {best[0]} threads; best of 8 / {min(ncpu, 64)} threads), {sample}, 10 reps each"}
+                          "sample": f"kernels/avx mat_mul_accelerator_int8_int4_fast_no_offset (W4A8, group 32, {best[0]} threads; best of 8 / {min(ncpu, 64)} threads), {sample}, 10 reps each ON ONE COPY of a linear's weights (8-30 MB: resident in this host's L3)",
+                          **({"value_weights_from_dram": round(cold["tokens_per_s"], 3), "weights_from_dram": "the same call over copies in rotation (> 768 MB between two uses of a copy), as the GPU leg's weights come from HBM"} if "tokens_per_s" in cold else {})}
     if O.have_ref():
         r = run("ref", 1)
         res["ref_1t"] = r
@@ -1394,11 +1476,14 @@ def main():
             adapter = {"error": f"{type(e).__name__}: {e}"}
 
     cpu = None
+    parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             cpu = cpu_baseline_leg(args.workload, shape)
         except Exception as e:  # noqa: BLE001 -- the baseline must never take the GPU number down with it
             cpu = {"error": f"{type(e).__name__}: {e}"}
+        if prepack and not args.layers:
+            parity = parity_leg(dl, torch, args.workload)
 
     if rank == 0:
         out = {
@@ -1453,6 +1538,8 @@ def main():
             out["llama2_13b"] = llama13  # BASELINE config 5, column-sharded over the run's eight ranks
         if adapter is not None:
             out["adapter_path"] = adapter
+        if parity is not None:
+            out["parity"] = parity
         if cpu is not None:
             main_cpu = cpu.get("avx") or cpu.get("ref")
             if main_cpu:

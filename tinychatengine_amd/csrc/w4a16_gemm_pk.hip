@@ -1492,8 +1492,9 @@ int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_
 #undef TCE_ABL
             default: return TCE_ERR_BAD_ARG;
         }
-    } else if (rows256) e = launch_pk256<7>(g, stream);  // (groups of 128 only: gemm_pk_estimate_us offers forms 6 / 7 for no other group size)
+    }
 #endif
+    else if (rows256) e = launch_pk256<7>(g, stream);  // (groups of 128 only: gemm_pk_estimate_us offers forms 6 / 7 for no other group size)
     else if (ks == 3) e = lg == 7 ? launch_pk<1, 7, 0, 2>(g, stream) : (lg == 6 ? launch_pk<1, 6, 0, 2>(g, stream) : launch_pk<1, 5, 0, 2>(g, stream));
     else if (ks == 2) e = lg == 7 ? launch_pk<2, 7>(g, stream) : (lg == 6 ? launch_pk<2, 6>(g, stream) : launch_pk<2, 5>(g, stream));
     else e = lg == 7 ? launch_pk<1, 7>(g, stream) : (lg == 6 ? launch_pk<1, 6>(g, stream) : launch_pk<1, 5>(g, stream));
