@@ -86,7 +86,7 @@ def compact_line(full: dict, details_file: str | None = None, budget: int = LINE
             c[k] = c[k][:197] + "..."
     gv = cfg.get("gather_variants")
     if isinstance(gv, dict):
-        c["gather_variants"] = {("peer" if k.startswith("peer") else "rccl" if k.startswith("RCCL") else k[:8]) + ("_4" if ", 4 gather" in k else "_1" if ", 1 gather" in k else ""):
+        c["gather_variants"] = {("peer" if k.startswith("peer") else "rccl" if k.startswith("RCCL") else k[:8]) + ("_4" if ", 4 gather" in k else "_1" if ", 1 gather" in k else "") + ("x1" if "one launch per block" in k else ""):
                                 (v.get("tokens_per_s", "rejected") if isinstance(v, dict) else v) for k, v in gv.items()}
     for k in ("ranks", "rccl_ranks", "gather_path"):
         if k in cfg:
@@ -658,8 +658,22 @@ def projected_scaling_leg(torch, dev, G, prepack=True):
                 n1, n4 = shape.layers + 1, shape.layers * (3 + len(shape.qkv)) + 1  # exchanges per token: 1 per block + logits; qkv slices, o, gate, up, down per block + logits
                 row = {"shard_compute_ms_per_token": round(ms, 4), "shard_weight_bytes": dlp.token_bytes(), "launches": plan.n_launches}
                 if P > 1:
+                    # the one-gather-per-block form: a rank's linears of a block are ONE launch (round 6, tce_w4a16_forward_independent) -- MEASURED here like the four-launch form
+                    plan1 = dlp.make_plan(one_launch_per_block=True)
+                    for _ in range(5):
+                        plan1.launch(st)
+                    torch.cuda.synchronize()
+                    a.record()
+                    for _ in range(30):
+                        plan1.launch(st)
+                    b.record()
+                    torch.cuda.synchronize()
+                    ms1 = a.elapsed_time(b) / 30
+                    row["shard_compute_ms_per_token_one_launch_per_block"] = round(ms1, 4)
+                    row["launches_one_launch_per_block"] = plan1.n_launches
+                    del plan1
                     for gname, gus in assumed.items():
-                        row[f"projected_tokens_per_s_1_gather_per_block_{gname[:-10]}"] = round(1e3 / (ms + n1 * gus * 1e-3), 1)
+                        row[f"projected_tokens_per_s_1_gather_per_block_{gname[:-10]}"] = round(1e3 / (min(ms, ms1) + n1 * gus * 1e-3), 1)
                         row[f"projected_tokens_per_s_4_gathers_per_block_{gname[:-10]}"] = round(1e3 / (ms + n4 * gus * 1e-3), 1)
                 else:
                     row["tokens_per_s"] = round(1e3 / ms, 1)
@@ -1250,8 +1264,9 @@ def main():
     else:
         n_launches = dl.n_layers * 4 + 1
 
-        def build_dist_step(gpb, gather, dl=dl):
-            """The distributed token (gpb gathers per block, joined by `gather`) as a callable + how it is issued."""
+        def build_dist_step(gpb, gather, dl=dl, block_launch="four"):
+            """The distributed token (gpb gathers per block, joined by `gather`; block_launch "one": a rank's linears of a block as ONE launch, gpb = 1 only) as a
+            callable + how it is issued."""
             graph = None
             try:  # capture GEMVs + RCCL all-gathers of one token into one graph; fall back to eager issue if capture fails
                 if args.no_graph or (args.backend != "nccl" and gather != "peer"):
@@ -1261,11 +1276,11 @@ def main():
                 dist.barrier()
                 torch.cuda.synchronize()
                 for _ in range(3):
-                    dl.run_token_distributed(gpb, gather=gather)
+                    dl.run_token_distributed(gpb, gather=gather, block_launch=block_launch)
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):  # the RCCL watchdog thread may call HIP APIs meanwhile
-                    dl.run_token_distributed(gpb, gather=gather)
+                    dl.run_token_distributed(gpb, gather=gather, block_launch=block_launch)
                 step = graph.replay
                 mode = f"one graph replay per token (GEMVs + {'peer-write' if gather == 'peer' else 'RCCL'} all-gathers captured)"
             except Exception as e:  # noqa: BLE001
@@ -1278,7 +1293,7 @@ def main():
                 torch.cuda.set_stream(torch.cuda.default_stream())
                 capi.lib().tce_reset_last_error()
                 torch.cuda.synchronize()
-                step = lambda: dl.run_token_distributed(gpb, gather=gather)
+                step = lambda: dl.run_token_distributed(gpb, gather=gather, block_launch=block_launch)
                 mode = "eager issue per token"
             return step, mode
 
@@ -1313,11 +1328,12 @@ def main():
         gathers = [g for g in (("peer", "rccl") if args.gather == "all" else (args.gather,)) if g != "peer" or getattr(dl, "comm", None) is not None]
         gpbs = (1, 4) if args.gathers_per_block == 0 else (args.gathers_per_block,)
         gather_variants, runs = {}, []
-        for gpb in gpbs:
+        for gpb, blk in [(g, b) for g in gpbs for b in ((("one", "four") if g == 1 else ("four",)))]:
             for gth in gathers:
-                name = f"{'peer-write kernel (tce_allgather_f16)' if gth == 'peer' else 'RCCL all_gather_into_tensor'}, {gpb} gather{'s' if gpb > 1 else ''} per block"
+                name = f"{'peer-write kernel (tce_allgather_f16)' if gth == 'peer' else 'RCCL all_gather_into_tensor'}, {gpb} gather{'s' if gpb > 1 else ''} per block" + \
+                       (", one launch per block (tce_w4a16_forward_independent)" if blk == "one" else "")
                 try:
-                    step_v, mode_v = build_dist_step(gpb, gth, dl)
+                    step_v, mode_v = build_dist_step(gpb, gth, dl, blk)
                     wall_v, ev_v = timed_run(step_v)
                     ok = True
                     if gth == "peer":
@@ -1334,7 +1350,7 @@ def main():
                     gather_variants[name] = ({"ms_per_token": round(wall_v * 1e3 / args.steps, 4), "tokens_per_s": round(args.steps / wall_v, 1), "issue": mode_v} if ok
                                              else {"rejected": "tce_comm_status != 0 on some rank: a peer-write gather timed out"})
                     if ok:
-                        runs.append((gpb, gth, wall_v, ev_v, mode_v, name))
+                        runs.append((gpb, gth, wall_v, ev_v, mode_v, name, blk))
                 except Exception as e:  # noqa: BLE001 -- one variant never takes the others down with it
                     gather_variants[name] = {"rejected": f"{type(e).__name__}: {e}"}
                     try:
@@ -1357,8 +1373,9 @@ def main():
         if not runs:
             raise SystemExit("no gather variant completed: " + json.dumps(gather_variants))
         one = [r for r in runs if r[0] == min(g for g, *_ in runs)]
-        gpb_h, gth_h, wall, ev_ms_total, mode, name_h = min(one, key=lambda r: r[2])
+        gpb_h, gth_h, wall, ev_ms_total, mode, name_h, blk_h = min(one, key=lambda r: r[2])
         args.gathers_per_block, args.gather = gpb_h, gth_h
+        n_launches = dl.n_layers * (1 if blk_h == "one" else 4) + 1  # (the gather kernels / collectives are not counted)
         gather_variants["headline"] = name_h
         # BASELINE config 5 (Llama-2-13B column-sharded 8 ways) beside the headline workload when the run has its eight ranks (VERDICT r4 item 7 ii): same
         # variants, same timing; never takes the headline down with it
@@ -1604,6 +1621,7 @@ def selftest_emit(args):
         out["n_gpus"] = world
         if world > 1:
             names = [f"{g}, {n} gather{'s' if n > 1 else ''} per block" for n in (1, 4) for g in ("peer-write kernel (tce_allgather_f16)", "RCCL all_gather_into_tensor")]
+            names = [nm + ", one launch per block (tce_w4a16_forward_independent)" for nm in names[:2]] + names
             out["config"]["gather_variants"] = dict({nm: {"ms_per_token": 1.0, "tokens_per_s": 1000.0, "issue": "x" * 120} for nm in names}, headline=names[0])
             out["config"]["ranks"] = [{"rank": r, "device": r, "pci_bus_id": "0000:00:00.0"} for r in range(world)]
     print(f"[bench] rank {rank}: selftest noise on stdout before the line")

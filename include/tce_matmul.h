@@ -47,7 +47,7 @@ extern "C" {
 
 #define TCE_API __attribute__((visibility("default")))
 
-#define TCE_VERSION 111 /* 0.1.11: tce_w4a16_gemm_scratch_faults (a k-cut exchange that gives up stores NaN and poisons its counter: loud, sticky), TCE_PLAN_TAGGED on packed copies runs the int8-contraction token kernel (tce_plan_is_chained = 4), TCE_DESC_V2_MAX_BYTES; 0.1.10: tce_attention_decode_step_deferred_f16 + tce_w4a16_forward_deferred_attention (the attention combine in o_proj's prologue); size-prefixed descriptors (tce_w4a16_desc_v2 / tce_w8a8_desc_v2 + the *_v2 entry points; the plain ones stay), TCE_ERR_RCCL, the tuning setters act on the CALLING THREAD only; 0.1.9: tce_w4a16_check_zero_point_8_async, tce_host_alloc / tce_host_free (the adapter no longer synchronises); 0.1.8: per-family tuning setters (tce_attention_set_tuning, tce_w8a8_set_tuning); 0.1.7: decode on the pre-packed copy (int8 contraction), tce_w4a16_set_gemv_i8; 0.1.6: TCE_PLAN_TUNED; 0.1.5: tce_opt_attention_decode; 0.1.4: tce_attention_prefill_f16 (0.1.3: tce_attention_decode_step_gqa_f16, TCE_PLAN_OVERLAPPED; 0.1.2: tce_w4a16_desc.scratch; 0.1.1: .prepacked, tce_w4a16_prepack*) */
+#define TCE_VERSION 112 /* 0.1.12: tce_w4a16_forward_independent (up to TCE_MAX_INDEPENDENT decode linears with their own activations and K as one launch: the sharded block); 0.1.11: tce_w4a16_gemm_scratch_faults (a k-cut exchange that gives up stores NaN and poisons its counter: loud, sticky), TCE_PLAN_TAGGED on packed copies runs the int8-contraction token kernel (tce_plan_is_chained = 4), TCE_DESC_V2_MAX_BYTES; 0.1.10: tce_attention_decode_step_deferred_f16 + tce_w4a16_forward_deferred_attention (the attention combine in o_proj's prologue); size-prefixed descriptors (tce_w4a16_desc_v2 / tce_w8a8_desc_v2 + the *_v2 entry points; the plain ones stay), TCE_ERR_RCCL, the tuning setters act on the CALLING THREAD only; 0.1.9: tce_w4a16_check_zero_point_8_async, tce_host_alloc / tce_host_free (the adapter no longer synchronises); 0.1.8: per-family tuning setters (tce_attention_set_tuning, tce_w8a8_set_tuning); 0.1.7: decode on the pre-packed copy (int8 contraction), tce_w4a16_set_gemv_i8; 0.1.6: TCE_PLAN_TUNED; 0.1.5: tce_opt_attention_decode; 0.1.4: tce_attention_prefill_f16 (0.1.3: tce_attention_decode_step_gqa_f16, TCE_PLAN_OVERLAPPED; 0.1.2: tce_w4a16_desc.scratch; 0.1.1: .prepacked, tce_w4a16_prepack*) */
 
 /* error codes (return values) */
 #define TCE_OK 0
@@ -302,6 +302,17 @@ TCE_API int tce_w4a16_prepack(const tce_w4a16_desc *d, void *packed, void *strea
 /* count (<= TCE_MAX_GROUP) linears with identical M, K, group_size and A/lda, one launch (GEMV path only). */
 #define TCE_MAX_GROUP 4
 TCE_API int tce_w4a16_forward_group(const tce_w4a16_desc *descs, int count, void *stream);
+/* (0.1.12) count (<= TCE_MAX_INDEPENDENT) decode linears that share NOTHING -- each its own activation, K, N, epilogue flags -- as ONE launch.  For the column-sharded
+ * model (the one-gather-per-block form): a rank's q / k / v / o / gate / up / down shards of a block read replicated inputs and do not depend on each
+ * other; one by one they are launches of 1-6 MB at 8 ranks, each paying a full launch boundary.  No ordering among the linears of the call is implied or provided (a
+ * linear that reads another one's output belongs in a later call).  Every output is bit-identical to the same descriptor through tce_w4a16_forward.
+ * One launch when every linear has M = 1, group_size 128, K <= 16384, a packed copy (`prepacked`) and no RMSNorm prologue (csrc/w4a16_gemv_i8.hip, the mixed launch);
+ * otherwise the linears are issued one after the other on `stream` -- same results.  *launches (may be null) receives the number of kernel launches made. */
+#define TCE_MAX_INDEPENDENT 8
+TCE_API int tce_w4a16_forward_independent(const tce_w4a16_desc *descs, int count, int *launches, void *stream);
+/* How tce_w4a16_forward_independent would run `descs` (no launch, no HIP call): "gemv-i8-mixed waves=<per workgroup> workgroups=<n>" -- one launch -- or
+ * "one-by-one launches=<count>". */
+TCE_API int tce_w4a16_describe_independent(const tce_w4a16_desc *descs, int count, char *buf, int buf_len);
 
 /*
  * AWQ "CUDA GEMM" (q4_5) layout -- quantize_methods.py:299-368, kernels/cuda/matmul_int4.cu:19-39:
@@ -444,6 +455,10 @@ TCE_API int tce_plan_create(const tce_w4a16_desc *descs, const int32_t *group_si
  * only if the whole plan gets 0.7 % faster; outputs are redirected to a scratch buffer (the caller's buffers are not written).  Costs a second or two, once; results are bit-identical to the
  * untuned plan's (only geometries that keep every row's summation order are candidates). */
 #define TCE_PLAN_TUNED 8
+/* (0.1.12) TCE_PLAN_INDEPENDENT: every group of the list is a set of linears that share NOTHING (tce_w4a16_forward_independent: group sizes up to
+ * TCE_MAX_INDEPENDENT, own activation / K / N / flags per linear) -- a rank's shards of one transformer block in the one-gather-per-block form.  Stream-ordered plan;
+ * not combinable with the other flags. */
+#define TCE_PLAN_INDEPENDENT 16
 TCE_API int tce_plan_create_ex(const tce_w4a16_desc *descs, const int32_t *group_sizes, int n_launches, int flags, tce_plan **out);
 TCE_API int tce_plan_is_chained(const tce_plan *plan);
 TCE_API int tce_plan_geometry(const tce_plan *plan, int *rows, int *depth, int *waves, int *workgroups);

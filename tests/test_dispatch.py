@@ -111,3 +111,27 @@ def test_packed_prefill_dispatch_rules_of_round_5():
             s = d(_pk(M, N, K, G=G))
             assert s.startswith("gemm-pk") and f"quartets={q}" in s and f"group={G}" in s, s
     assert "quartets=2" in d(_pk(1024, 4096, 4096, z8=False))
+
+
+def test_independent_linears_dispatch():
+    """tce_w4a16_forward_independent (round 6): one launch for decode rows on packed copies whatever their K; the workgroup is as wide as the longest K needs and a
+    shorter K packs floor(waves / own waves) tiles into it.  No GPU needed (tce_w4a16_describe_independent)."""
+    def d(N, K, M=1, G=128, packed=256, flags=0):
+        x = _desc(M, N, K, G, flags)
+        x.prepacked = packed
+        return x
+    # a rank's shards of a Llama-3-8B block at 8 ranks: q, k, v, o, gate, up (K = 4096: 4 waves a tile, 3 tiles per 14-wave workgroup) and down (K = 14336: 14 waves)
+    shards = [d(512, 4096), d(128, 4096), d(128, 4096), d(512, 4096), d(1792, 4096), d(1792, 4096), d(512, 14336)]
+    tiles = [32, 8, 8, 32, 112, 112]
+    assert capi.describe_independent(shards) == f"gemv-i8-mixed waves=14 workgroups={sum(-(-t // 3) for t in tiles) + 32}"
+    assert capi.describe_independent([d(256, 4096), d(100, 4096)]) == "gemv-i8-mixed waves=4 workgroups=23"
+    assert capi.describe_independent([d(16, 128), d(16, 1408)]) == "gemv-i8-mixed waves=2 workgroups=2"   # 1408 = 11 units: two waves; the 128-wide linear packs two tiles per workgroup
+    # what the one-launch form does not take goes linear by linear
+    assert capi.describe_independent([d(256, 4096)]) == "one-by-one launches=1"
+    assert capi.describe_independent([d(256, 4096), d(64, 4096, packed=0)]) == "one-by-one launches=2"
+    assert capi.describe_independent([d(256, 4096), d(64, 4096, M=2)]) == "one-by-one launches=2"
+    assert capi.describe_independent([d(256, 4096), d(64, 4096, G=64)]) == "one-by-one launches=2"
+    assert capi.describe_independent([d(256, 4096), d(64, 28672)]) == "one-by-one launches=2"
+    assert capi.describe_independent([d(256, 4096), d(64, 4096, flags=capi.TCE_W4_FORCE_GEMM)]) == "one-by-one launches=2"
+    with pytest.raises(capi.TceError):
+        capi.describe_independent([d(16, 1024)] * 9)

@@ -116,7 +116,10 @@ def test_sharded_linears_gathered_by_peer_writes_equal_the_unsharded_linear(worl
     lins = [Linear_half_int4.from_float(torch.empty(n, k, device=dev).normal_(0, 0.02, generator=g), 128) for n, k in shapes]
     comms = [capi.Comm(r, world, 16384, slots=3) for r in range(world)]
     capi.Comm.connect_local(comms)
-    streams = [torch.cuda.Stream() for _ in range(world)]
+    # the two in-process ranks wait for each other INSIDE their kernels: their streams must sit on different hardware queues.  Streams of one priority share a pool of
+    # queues by creation order -- which streams the tests that ran earlier in the process took decides whether two of them collide (seen: this test failing with a
+    # timed-out gather when another test file ran first) -- streams of different priorities never share a queue
+    streams = [torch.cuda.Stream(priority=0 if r % 2 == 0 else -1) for r in range(world)]
     try:
         capi.set_gemv_config(2, 4, 1, 2)  # one geometry for shards and whole: bit-identical rows (tests/test_gpu_w4a16.py)
         for round_ in range(5):  # epochs 1..5 on every slot: both buffer parities, flags from earlier rounds still in the windows
@@ -269,7 +272,7 @@ def test_allgather_rows_two_ranks_peer_regime():
     world, M, N = 2, 6, 1024
     comms = [capi.Comm(r, world, M * N, slots=2) for r in range(world)]
     capi.Comm.connect_local(comms)
-    streams = [torch.cuda.Stream() for _ in range(world)]
+    streams = [torch.cuda.Stream(priority=0 if r % 2 == 0 else -1) for r in range(world)]  # (different priorities: never one hardware queue, see above)
     ws = [torch.empty(M * N, dtype=torch.float16, device=dev) for _ in range(world)]
     try:
         for it in range(4):
@@ -297,7 +300,7 @@ def test_allgather_rows_beyond_64k_slices_without_rccl_uses_the_window():
     world, M, N = 2, 64, 4096
     comms = [capi.Comm(r, world, M * N, slots=2) for r in range(world)]
     capi.Comm.connect_local(comms)
-    streams = [torch.cuda.Stream() for _ in range(world)]
+    streams = [torch.cuda.Stream(priority=0 if r % 2 == 0 else -1) for r in range(world)]  # (different priorities: never one hardware queue, see above)
     ws = [torch.empty(M * N, dtype=torch.float16, device=dev) for _ in range(world)]
     try:
         for it in range(3):

@@ -22,16 +22,17 @@ TCE_W4_SILU_MUL_PAIRS = 8
 TCE_W4_ADD_TO_C = 16
 TCE_PLAN_CHAINED = 1
 TCE_PLAN_TAGGED = 2
-TCE_ABI_VERSION = 111  # include/tce_matmul.h TCE_VERSION: the struct layouts mirrored below
+TCE_ABI_VERSION = 112  # include/tce_matmul.h TCE_VERSION: the struct layouts mirrored below
 TCE_PLAN_OVERLAPPED = 4
 TCE_PLAN_TUNED = 8
+TCE_PLAN_INDEPENDENT = 16
 TCE_W4_ZERO_POINT_IS_8 = 4
 TCE_BIAS_NONE, TCE_BIAS_INT8, TCE_BIAS_FP32 = 0, 1, 2
 TCE_OUT_INT8, TCE_OUT_FP32 = 0, 1
 
 # every symbol include/tce_matmul.h declares (tests/test_boundary.py checks the .so exports exactly these)
 EXPORTS = [
-    "tce_w4a16_forward", "tce_w4a16_residual_rmsnorm_workspace_bytes", "tce_w4a16_forward_residual_rmsnorm", "tce_w4a16_prepack_bytes", "tce_w4a16_prepack", "tce_w4a16_gemm_scratch_bytes", "tce_w4a16_gemm_scratch_faults", "tce_w4a16_describe_dispatch", "tce_reset_last_error", "tce_bmm_f16t", "tce_rope_half", "tce_softmax_half", "tce_attention_decode_f16", "tce_attention_decode_workspace_bytes", "tce_attention_decode_describe", "tce_attention_decode_step_f16", "tce_attention_decode_step_gqa_f16", "tce_attention_decode_describe_gqa", "tce_attention_decode_step_pos_f16", "tce_attention_prefill_f16", "tce_attention_prefill_workspace_bytes", "tce_opt_attention_decode", "tce_prefetch", "tce_add_half", "tce_silu_mul_half", "tce_rmsnorm_half", "tce_w4a16_forward_group_rmsnorm", "tce_w4a16_forward_group", "tce_w4a16_check_zero_point_8", "tce_w4a16_awq_fp16acc", "tce_w4a16_awq_workspace_bytes",
+    "tce_w4a16_forward", "tce_w4a16_residual_rmsnorm_workspace_bytes", "tce_w4a16_forward_residual_rmsnorm", "tce_w4a16_prepack_bytes", "tce_w4a16_prepack", "tce_w4a16_gemm_scratch_bytes", "tce_w4a16_gemm_scratch_faults", "tce_w4a16_describe_dispatch", "tce_reset_last_error", "tce_bmm_f16t", "tce_rope_half", "tce_softmax_half", "tce_attention_decode_f16", "tce_attention_decode_workspace_bytes", "tce_attention_decode_describe", "tce_attention_decode_step_f16", "tce_attention_decode_step_gqa_f16", "tce_attention_decode_describe_gqa", "tce_attention_decode_step_pos_f16", "tce_attention_prefill_f16", "tce_attention_prefill_workspace_bytes", "tce_opt_attention_decode", "tce_prefetch", "tce_add_half", "tce_silu_mul_half", "tce_rmsnorm_half", "tce_w4a16_forward_group_rmsnorm", "tce_w4a16_forward_group", "tce_w4a16_forward_independent", "tce_w4a16_describe_independent", "tce_w4a16_check_zero_point_8", "tce_w4a16_awq_fp16acc", "tce_w4a16_awq_workspace_bytes",
     "tce_w4a16_gemm_awq", "tce_w4a16_shard", "tce_comm_create", "tce_comm_export", "tce_comm_connect", "tce_comm_connect_local", "tce_allgather_f16", "tce_comm_rccl_unique_id", "tce_comm_rccl_init", "tce_allgather_rows_workspace_bytes", "tce_allgather_rows_f16", "tce_comm_status", "tce_comm_set_timeout_ms", "tce_comm_reset", "tce_comm_device", "tce_comm_destroy", "tce_w8a8_matmul", "tce_opt_softmax_q", "tce_opt_kv_append", "tce_layernorm_q", "tce_layernorm_q_w8a8_group", "tce_plan_create", "tce_plan_create_ex", "tce_plan_is_chained", "tce_plan_geometry", "tce_plan_status", "tce_plan_launch_geometry", "tce_plan_launch", "tce_plan_n_launches",
     "tce_w4a16_forward_v2", "tce_w8a8_matmul_v2", "tce_w8a8_scratch_bytes", "tce_attention_decode_step_deferred_f16", "tce_w4a16_forward_deferred_attention", "tce_plan_destroy", "tce_version", "tce_last_error", "tce_build_info", "tce_w4a16_set_gemv_config", "tce_w4a16_set_gemv_i8",
     "tce_w4a16_set_gemm_config", "tce_w4a16_algorithmic_bytes", "tce_w4a16_gemv_variant", "tce_w4a16_gemm_variant",
@@ -140,6 +141,8 @@ def lib() -> C.CDLL:
         L.tce_build_info.restype = C.c_char_p
         L.tce_w4a16_forward.argtypes = [C.POINTER(W4A16Desc), C.c_void_p]
         L.tce_w4a16_forward_group.argtypes = [C.POINTER(W4A16Desc), C.c_int, C.c_void_p]
+        L.tce_w4a16_forward_independent.argtypes = [C.POINTER(W4A16Desc), C.c_int, C.POINTER(C.c_int), C.c_void_p]
+        L.tce_w4a16_describe_independent.argtypes = [C.POINTER(W4A16Desc), C.c_int, C.c_char_p, C.c_int]
         L.tce_w4a16_prepack_bytes.argtypes = [C.c_int] * 3
         L.tce_w4a16_prepack_bytes.restype = C.c_size_t
         L.tce_w4a16_gemm_scratch_bytes.argtypes = []
@@ -255,6 +258,25 @@ def w4a16_forward_group(descs: list[W4A16Desc], stream: int | None) -> int:
     return lib().tce_w4a16_forward_group(arr, len(descs), C.c_void_p(stream or 0))
 
 
+TCE_MAX_INDEPENDENT = 8
+
+
+def w4a16_forward_independent(descs: list[W4A16Desc], stream: int | None) -> int:
+    """tce_w4a16_forward_independent: linears that share nothing, one launch where the library has one.  Returns the number of kernel launches made (raises on error)."""
+    arr = (W4A16Desc * len(descs))(*descs)
+    n = C.c_int(0)
+    check(lib().tce_w4a16_forward_independent(arr, len(descs), C.byref(n), C.c_void_p(stream or 0)))
+    return n.value
+
+
+def describe_independent(descs: list[W4A16Desc]) -> str:
+    """tce_w4a16_describe_independent: how the library would run these linears through tce_w4a16_forward_independent (no GPU needed)."""
+    arr = (W4A16Desc * len(descs))(*descs)
+    buf = C.create_string_buffer(128)
+    check(lib().tce_w4a16_describe_independent(arr, len(descs), buf, len(buf)))
+    return buf.value.decode()
+
+
 def w8a8_matmul(desc: W8A8Desc, stream: int | None) -> int:
     return lib().tce_w8a8_matmul(C.byref(desc), C.c_void_p(stream or 0))
 
@@ -308,15 +330,16 @@ def gemm_variants() -> list[tuple[int, int]]:
 class Plan:
     """tce_plan: a fixed sequence of W4A16 launches captured into one hipGraph (one decode token's linears)."""
 
-    def __init__(self, launches: list[list[W4A16Desc]], chained: bool = False, tagged: bool = False, overlapped: bool = False, tuned: bool = False):
+    def __init__(self, launches: list[list[W4A16Desc]], chained: bool = False, tagged: bool = False, overlapped: bool = False, tuned: bool = False, independent: bool = False):
         """tagged (chained: accepted synonym): TCE_PLAN_TAGGED -- one persistent kernel walks the list, the plan's data flow
         ordered by polling tagged output words (include/tce_matmul.h).  self.tagged tells whether that form was built.
-        tuned: TCE_PLAN_TUNED -- the decode launches' geometries are timed on this device at creation (stream-ordered plans)."""
+        tuned: TCE_PLAN_TUNED -- the decode launches' geometries are timed on this device at creation (stream-ordered plans).
+        independent: TCE_PLAN_INDEPENDENT -- every group is a set of linears that share nothing (up to TCE_MAX_INDEPENDENT; tce_w4a16_forward_independent)."""
         flat = [d for g in launches for d in g]
         self._descs = (W4A16Desc * len(flat))(*flat)
         self._groups = (C.c_int32 * len(launches))(*[len(g) for g in launches])
         self._h = C.c_void_p()
-        check(lib().tce_plan_create_ex(self._descs, self._groups, len(launches), (TCE_PLAN_TAGGED if tagged else 0) | (TCE_PLAN_CHAINED if chained else 0) | (TCE_PLAN_OVERLAPPED if overlapped else 0) | (TCE_PLAN_TUNED if tuned else 0), C.byref(self._h)))
+        check(lib().tce_plan_create_ex(self._descs, self._groups, len(launches), (TCE_PLAN_TAGGED if tagged else 0) | (TCE_PLAN_CHAINED if chained else 0) | (TCE_PLAN_OVERLAPPED if overlapped else 0) | (TCE_PLAN_TUNED if tuned else 0) | (TCE_PLAN_INDEPENDENT if independent else 0), C.byref(self._h)))
         self.n_launches = len(launches)
         self.kind = int(lib().tce_plan_is_chained(self._h))  # 0 stream-ordered, 2 token kernel (fp16 body), 3 overlapped launches, 4 token kernel on the int8-contraction body (round 6)
         self.chained = self.kind != 0

@@ -556,6 +556,48 @@ int tce_w4a16_forward_group(const tce_w4a16_desc *descs, int count, void *stream
     return TCE_OK;
 }
 
+int tce_w4a16_forward_independent(const tce_w4a16_desc *descs, int count, int *launches, void *stream) {
+    if (launches) *launches = 0;
+    if (!descs || count < 1 || count > TCE_MAX_INDEPENDENT) return fail(TCE_ERR_BAD_ARG, "tce_w4a16_forward_independent: count %d not in 1..%d", count, TCE_MAX_INDEPENDENT);
+    for (int i = 0; i < count; ++i) {
+        const int rc = check_w4a16(&descs[i]);
+        if (rc != TCE_OK) return rc;
+    }
+    // one launch: decode rows on packed copies (csrc/w4a16_gemv_i8.hip, the mixed launch).  A forced GEMV geometry / a diagnostic mode keeps the kernels it names
+    if (count > 1 && g_gemv_kernel == 0 && g_debug_mode_capi == 0 && tce::gemv_i8_mixed_supports(descs, count)) {
+        hipError_t he = hipSuccess;
+        const int rc = tce::launch_w4a16_gemv_i8_mixed(descs, count, static_cast<hipStream_t>(stream), &he);
+        if (rc == TCE_ERR_HIP) return hip_fail(he, "w4a16 gemv (int8 contraction, mixed) launch");
+        if (rc == TCE_OK) {
+            if (launches) *launches = 1;
+            return TCE_OK;
+        }
+        if (rc != TCE_ERR_UNSUPPORTED_SHAPE) return fail(rc, "w4a16 gemv (int8 contraction, mixed): unsupported configuration");
+    }
+    for (int i = 0; i < count; ++i) {  // anything else: one after the other, whatever tce_w4a16_forward would run -- the same results
+        const int rc = tce_w4a16_forward(&descs[i], stream);
+        if (rc != TCE_OK) return rc;
+        if (launches) *launches += 1;
+    }
+    return TCE_OK;
+}
+
+int tce_w4a16_describe_independent(const tce_w4a16_desc *descs, int count, char *buf, int buf_len) {
+    if (!descs || !buf || buf_len < 64 || count < 1 || count > TCE_MAX_INDEPENDENT) return fail(TCE_ERR_BAD_ARG, "tce_w4a16_describe_independent: bad argument (count 1..%d, 64 bytes of buffer)", TCE_MAX_INDEPENDENT);
+    for (int i = 0; i < count; ++i) {
+        const int rc = check_w4a16(&descs[i]);
+        if (rc != TCE_OK) return rc;
+    }
+    if (count > 1 && g_gemv_kernel == 0 && g_debug_mode_capi == 0 && tce::gemv_i8_mixed_supports(descs, count)) {
+        int waves = 0, wgs = 0;
+        tce::gemv_i8_mixed_geometry(descs, count, &waves, &wgs);
+        std::snprintf(buf, (size_t)buf_len, "gemv-i8-mixed waves=%d workgroups=%d", waves, wgs);
+    } else {
+        std::snprintf(buf, (size_t)buf_len, "one-by-one launches=%d", count);
+    }
+    return TCE_OK;
+}
+
 size_t tce_w4a16_residual_rmsnorm_workspace_bytes(void) { return 2048 * sizeof(float) + 256; }
 
 int tce_w4a16_forward_residual_rmsnorm(const tce_w4a16_desc *d, const float *gamma, float eps, void *xn_out, void *workspace, void *stream) {
@@ -1346,14 +1388,17 @@ static int tune_plan_launches(const std::vector<tce_w4a16_desc> &descs, const st
 
 int tce_plan_create_ex(const tce_w4a16_desc *descs, const int32_t *group_sizes, int n_launches, int flags, tce_plan **out) {
     if (!descs || !group_sizes || n_launches < 1 || !out) return fail(TCE_ERR_BAD_ARG, "bad argument");
-    if (flags & ~(TCE_PLAN_CHAINED | TCE_PLAN_TAGGED | TCE_PLAN_OVERLAPPED | TCE_PLAN_TUNED)) return fail(TCE_ERR_BAD_ARG, "unknown plan flags 0x%x", flags);
+    if (flags & ~(TCE_PLAN_CHAINED | TCE_PLAN_TAGGED | TCE_PLAN_OVERLAPPED | TCE_PLAN_TUNED | TCE_PLAN_INDEPENDENT)) return fail(TCE_ERR_BAD_ARG, "unknown plan flags 0x%x", flags);
+    const bool independent = (flags & TCE_PLAN_INDEPENDENT) != 0;
+    if (independent && flags != TCE_PLAN_INDEPENDENT) return fail(TCE_ERR_BAD_ARG, "TCE_PLAN_INDEPENDENT does not combine with other plan flags (0x%x)", flags);
+    const int max_group = independent ? TCE_MAX_INDEPENDENT : TCE_MAX_GROUP;
     tce_plan *p = new (std::nothrow) tce_plan();
     if (!p) return fail(TCE_ERR_BAD_ARG, "out of host memory");
     int total = 0;
     for (int i = 0; i < n_launches; ++i) {
-        if (group_sizes[i] < 1 || group_sizes[i] > TCE_MAX_GROUP) {
+        if (group_sizes[i] < 1 || group_sizes[i] > max_group) {
             delete p;
-            return fail(TCE_ERR_BAD_ARG, "group size %d not in 1..%d", group_sizes[i], TCE_MAX_GROUP);
+            return fail(TCE_ERR_BAD_ARG, "group size %d not in 1..%d", group_sizes[i], max_group);
         }
         total += group_sizes[i];
     }
@@ -1418,7 +1463,8 @@ int tce_plan_create_ex(const tce_w4a16_desc *descs, const int32_t *group_sizes, 
                 tce::set_gemv_shared_xsum(p->tuned[i].shared_xsum);
                 tce::set_gemv_order(p->tuned[i].order);
             }
-            rc = p->groups[i] == 1 ? tce_w4a16_forward(&p->descs[off], cap) : tce_w4a16_forward_group(&p->descs[off], p->groups[i], cap);
+            if (independent) rc = tce_w4a16_forward_independent(&p->descs[off], p->groups[i], nullptr, cap);
+            else rc = p->groups[i] == 1 ? tce_w4a16_forward(&p->descs[off], cap) : tce_w4a16_forward_group(&p->descs[off], p->groups[i], cap);
             tce::set_gemv_order(0);
             tce::set_gemv_shared_xsum(0);
             if (forced) (void)tce_w4a16_set_gemv_config(0, 0, 0, 0);

@@ -60,6 +60,34 @@ struct I8Args {
     I8Seg seg[TCE_MAX_GROUP];
 };
 
+// ---- the MIXED launch (round 6): up to kI8MixMax decode linears that share NOTHING -- own activation, own K -- as one launch.
+// What it is for: with the linears sharded over P ranks and the activations replicated (north_star's one-gather-per-block form) a rank's five linears of a block read
+// independent inputs; issued one by one they are 4 launches of 2-6 MB at P = 8, each paying the same ~2.5 us of boundary and ramp as a 60 MB launch.
+// Geometry: the workgroup has as many waves as the LONGEST K needs (K / 1024, e.g. 14 for down_proj of Llama-3-8B); a linear with a shorter K packs floor(waves / its own
+// waves) tiles into one workgroup -- wave groups of ITS K-split width, each with its own LDS region, running the unchanged body.  A row's bits are therefore exactly those
+// of the ordinary launch (same waves per tile, same order of every sum).  The workgroup barrier of the K reduction is shared by the wave groups (each reaches it once);
+// waves that belong to no group end at once (a barrier counts the surviving waves only).
+constexpr int kI8MixMax = 8;
+struct I8MixSeg {
+    const half_t *A;
+    int lda, K;
+    I8Seg seg;  // block_begin: first blockIdx.x of this linear
+};
+struct I8MixArgs {
+    int nseg, M;
+    // (what the body reads from I8Args whatever the form; the prologues / epilogues that use them are not compiled into the mixed form)
+    const float *gamma = nullptr;
+    float eps = 0.f;
+    const float *out_gamma = nullptr;
+    float out_eps = 0.f;
+    half_t *xn_out = nullptr;
+    float *ws = nullptr;
+    const float *comb_part = nullptr;
+    const int *comb_pos_dev = nullptr;
+    int comb_pos = 0, comb_slots = 0, comb_chunk = 0, comb_stride = 0, comb_heads = 0;
+    I8MixSeg s[kI8MixMax];
+};
+
 template <int DPP_CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ unsigned dpp_max_u32(unsigned v) {
     const unsigned t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, DPP_CTRL, ROW_MASK, 0xF, false);
@@ -85,8 +113,11 @@ __device__ __forceinline__ float dpp_add_f32(float v) {
 // gate/up launches; the next launch is then the plain kernel).  Bits: C as TCE_W4_ADD_TO_C, xn as tce_rmsnorm_half on the updated row.
 // MEASURED (round 4): correct and SLOWER than the prologue it replaces -- the write-through stores must be acknowledged before a workgroup may count itself in and the last
 // workgroup's pass is serial: +3.8 us per producer launch, a whole token 1.65 against 1.41 ms.  Kept as an entry point (tests pin its bits); DecoderBlock.step does not use it.
-template <int MB, int GPU, int ROWS, int UW, bool Z8, int MAXT, bool NORM = false, bool RNORM = false, int COMB = 0>
-__global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const I8Args args) {
+// ARGS = I8MixArgs: the mixed launch (above) -- the linear, its activation and k range per WORKGROUP, the tile per wave group
+template <int MB, int GPU, int ROWS, int UW, bool Z8, int MAXT, bool NORM = false, bool RNORM = false, int COMB = 0, typename ARGS = I8Args>
+__global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const ARGS args) {
+    constexpr bool MIX = std::is_same<ARGS, I8MixArgs>::value;
+    static_assert(!MIX || (MB == 1 && GPU == 1 && ROWS == 1 && UW == 8 && !NORM && !RNORM && !COMB), "the mixed launch: one decode row, groups of 128, one tile per wave group");
     static_assert(!COMB || (MB == 1 && ROWS == 1 && GPU == 1 && UW == 8 && !NORM && !RNORM), "the deferred-attention prologue: one decode row, groups of 128, K a multiple of 1024");
     static_assert(MB * GPU <= 4, "sixteen output columns: rows x groups-per-unit x 4 planes");
     static_assert(!RNORM || (MB == 1 && ROWS == 1 && !NORM), "the residual + next-norm epilogue: one decode row, one tile per workgroup");
@@ -96,22 +127,49 @@ __global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const I8Args args) 
     constexpr int NP = UW / UPP;         // passes
     constexpr int XC = UW / 4;           // 8-element activation chunks per lane and row (64 lanes x 8 = 4 units)
     constexpr int SPG = 4 / GPU;         // dwords of a lane's B operand that belong to one group
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_wg[];
+    unsigned char *smem = smem_wg;
+    int tid = threadIdx.x;
+    int WK = blockDim.x >> 6;
+    int U, NG, K_, lda_, tile0;
+    const half_t *A_;
+    I8Seg seg;
+    if constexpr (MIX) {
+        int si = 0;
+#pragma unroll
+        for (int s = 1; s < kI8MixMax; ++s)
+            if (s < args.nseg && (int)blockIdx.x >= args.s[s].seg.block_begin) si = s;
+        A_ = args.s[si].A;
+        lda_ = args.s[si].lda;
+        K_ = args.s[si].K;
+        seg = args.s[si].seg;
+        U = NG = K_ >> 7;
+        const int wl = WK;                               // waves of the launch's workgroups
+        WK = (U + UW - 1) / UW;                          // waves that split THIS linear's K
+        const int nsub = wl / WK;                        // its tiles per workgroup
+        const int sub = __builtin_amdgcn_readfirstlane(tid >> 6) / WK;
+        tile0 = ((int)blockIdx.x - seg.block_begin) * nsub + sub;
+        if (sub >= nsub || tile0 >= ((seg.N + 15) >> 4)) return;  // (whole wave groups: the barrier below counts the surviving waves)
+        tid -= sub * WK * 64;
+        smem += (size_t)sub * ((size_t)WK * UW * 512 + (size_t)WK * 16 * sizeof(float));
+    } else {
+        U = args.U;
+        NG = args.NG;
+        K_ = args.K;
+        lda_ = args.lda;
+        A_ = args.A;
+        int si = 0;
+#pragma unroll
+        for (int s = 1; s < TCE_MAX_GROUP; ++s)
+            if (s < args.nseg && (int)blockIdx.x >= args.seg[s].block_begin) si = s;
+        seg = args.seg[si];
+        tile0 = ((int)blockIdx.x - seg.block_begin) * ROWS;
+    }
     const int lane = tid & 63;
     const int wk = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int WK = blockDim.x >> 6;
     const int u0 = wk * UW;
     const int kq = lane >> 4, j = lane & 15;
-    const int U = args.U, NG = args.NG;
     const int m0 = blockIdx.y * MB;
-
-    int si = 0;
-#pragma unroll
-    for (int s = 1; s < TCE_MAX_GROUP; ++s)
-        if (s < args.nseg && (int)blockIdx.x >= args.seg[s].block_begin) si = s;
-    const I8Seg seg = args.seg[si];
-    const int tile0 = ((int)blockIdx.x - seg.block_begin) * ROWS;
     const int ntiles = (seg.N + 15) >> 4;
     auto tile_of = [&](int r) { return tile0 + r < ntiles ? tile0 + r : ntiles - 1; };  // a surplus tile of the last workgroup re-reads the last one; its stores are masked
 
@@ -164,7 +222,7 @@ __global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const I8Args args) 
         int mrow = m0 + m;
         mrow = mrow < args.M ? mrow : args.M - 1;
         // a descriptor per row, K halves long: chunks past K (a ragged last wave) read as zeros
-        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(args.A + (size_t)mrow * args.lda), 0, args.K * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t *>(A_ + (size_t)mrow * lda_), 0, K_ * 2, 0x00020000);
 #pragma unroll
         for (int c = 0; c < XC; ++c) xv[m][c] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, u0 * 256 + (lane + 64 * c) * 16, 0, 0);  // (the scalar offset of a buffer load is NOT range-checked: everything that may run past K sits in the vector offset)
     }
@@ -180,7 +238,7 @@ __global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const I8Args args) 
     }
     float4_t gm[NORM ? XC : 1][2];  // gamma of the lane's 8 columns per chunk
     if constexpr (NORM) {
-        const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(args.gamma), 0, args.K * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(args.gamma), 0, K_ * 4, 0x00020000);
 #pragma unroll
         for (int c = 0; c < XC; ++c) {
             gm[c][0] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_g, u0 * 512 + (lane + 64 * c) * 32, 0, 0));
@@ -250,7 +308,7 @@ __global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const I8Args args) 
         // slot[p] = the sum of squares of the row's p-th 16-byte piece (fmaf chain over its 8 values); K <= 16384: at most two pieces per slot of the
         // 1024-slot order, and a two-term sum does not depend on which wave wrote which
         float *slots = reinterpret_cast<float *>(smem + (size_t)WK * UW * MB * 512 + (size_t)WK * ROWS * MB * 16 * sizeof(float));  // [2048]
-        const int pieces = args.K >> 3;
+        const int pieces = K_ >> 3;
 #pragma unroll
         for (int c = 0; c < XC; ++c) {
             const int p = u0 * 16 + lane + 64 * c;
@@ -276,7 +334,7 @@ __global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const I8Args args) 
         }
         tot = wave_sum_dpp_lane63(tot);
         tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), 63));
-        const float rs = 1.0f / sqrtf(tot / (float)args.K + args.eps);
+        const float rs = 1.0f / sqrtf(tot / (float)K_ + args.eps);
 #pragma unroll
         for (int c = 0; c < XC; ++c) {
             const half8_t v = __builtin_bit_cast(half8_t, xv[0][c]);
@@ -716,6 +774,84 @@ int launch_w4a16_gemv_i8(const tce_w4a16_desc *descs, int count, hipStream_t str
     TCE_I8(1, 4, 1, 8, 1024)
     return TCE_ERR_UNSUPPORTED_SHAPE;
 #undef TCE_I8
+    if (e != hipSuccess) {
+        if (hip_err) *hip_err = e;
+        return TCE_ERR_HIP;
+    }
+    return TCE_OK;
+}
+
+// ---- the mixed launch: up to TCE_MAX_INDEPENDENT decode linears with their own activations and K as ONE launch (the kernel with ARGS = I8MixArgs) ----
+static_assert(kI8MixMax == TCE_MAX_INDEPENDENT, "include/tce_matmul.h");
+
+bool gemv_i8_mixed_supports(const tce_w4a16_desc *descs, int count) {
+    if (g_i8_mode == 1 || count < 1 || count > kI8MixMax) return false;
+    for (int i = 0; i < count; ++i) {
+        const tce_w4a16_desc &d = descs[i];
+        // one decode row, groups of 128, eight units per wave (K <= 16384), no prologue: the <1, 1, 1, 8> body
+        if (d.M != 1 || d.group_size != 128 || d.K % 128 != 0 || d.K > 16384 || d.rmsnorm_gamma) return false;
+        if (!d.prepacked || (reinterpret_cast<uintptr_t>(d.prepacked) & 255)) return false;
+        if ((long long)pk::nt16(d.N) * (d.K / 2) * 16 >= (1LL << 31)) return false;
+        if (d.flags & TCE_W4_FORCE_GEMM) return false;
+    }
+    return true;
+}
+
+// workgroups of the mixed launch and the waves of each (what tce_w4a16_forward_independent reports through describe; ONE rule with the launcher)
+void gemv_i8_mixed_geometry(const tce_w4a16_desc *descs, int count, int *waves, int *workgroups) {
+    int wl = 1, blocks = 0;
+    for (int i = 0; i < count; ++i) wl = wl > (descs[i].K / 128 + 7) / 8 ? wl : (descs[i].K / 128 + 7) / 8;
+    for (int i = 0; i < count; ++i) {
+        const int nsub = wl / ((descs[i].K / 128 + 7) / 8);
+        blocks += (pk::nt16(descs[i].N) + nsub - 1) / nsub;
+    }
+    *waves = wl;
+    *workgroups = blocks;
+}
+
+int launch_w4a16_gemv_i8_mixed(const tce_w4a16_desc *descs, int count, hipStream_t stream, hipError_t *hip_err) {
+    if (!gemv_i8_mixed_supports(descs, count)) return TCE_ERR_UNSUPPORTED_SHAPE;
+    I8MixArgs a{};
+    a.nseg = count;
+    a.M = 1;
+    int wl = 1, total = 0;
+    gemv_i8_mixed_geometry(descs, count, &wl, &total);
+    bool z8 = true;
+    int blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        const tce_w4a16_desc &d = descs[i];
+        z8 = z8 && (d.flags & TCE_W4_ZERO_POINT_IS_8);
+        I8MixSeg &m = a.s[i];
+        m.A = static_cast<const half_t *>(d.A);
+        m.lda = d.lda ? d.lda : d.K;
+        m.K = d.K;
+        I8Seg &s = m.seg;
+        const unsigned char *base = static_cast<const unsigned char *>(d.prepacked);
+        s.words = base;
+        s.dscales = reinterpret_cast<const half_t *>(base + pk::dscales_offset(d.N, d.K, d.group_size));
+        s.dzeros = reinterpret_cast<const unsigned *>(base + pk::dzeros_offset(d.N, d.K, d.group_size));
+        s.C = static_cast<half_t *>(d.C);
+        s.N = d.N;
+        s.epilogue = d.flags & (TCE_W4_SILU_MUL_PAIRS | TCE_W4_ADD_TO_C);
+        s.ldc = d.ldc ? d.ldc : ((s.epilogue & TCE_W4_SILU_MUL_PAIRS) ? d.N / 2 : d.N);
+        s.bytes_w = (int)pk::words_bytes(d.N, d.K);
+        s.bytes_s = (int)pk::dscales_bytes(d.N, d.K, d.group_size);
+        s.bytes_z = (int)pk::dzeros_bytes(d.N, d.K, d.group_size);
+        s.block_begin = blocks;
+        const int nsub = wl / ((d.K / 128 + 7) / 8);
+        blocks += (pk::nt16(d.N) + nsub - 1) / nsub;
+    }
+    for (int i = count; i < kI8MixMax; ++i) a.s[i] = a.s[0];
+    const size_t lds = (size_t)wl * 8 * 512 + (size_t)wl * 16 * sizeof(float);  // the wave groups' regions side by side: never more than `wl` waves' worth
+    auto launch = [&](auto kfn) -> hipError_t {
+        if (lds > 64 * 1024) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kfn, dim3(blocks, 1, 1), dim3(64 * wl, 1, 1), lds, stream, a);
+        return hipGetLastError();
+    };
+    const hipError_t e = z8 ? launch(w4a16_gemv_i8_kernel<1, 1, 1, 8, true, 1024, false, false, 0, I8MixArgs>) : launch(w4a16_gemv_i8_kernel<1, 1, 1, 8, false, 1024, false, false, 0, I8MixArgs>);
     if (e != hipSuccess) {
         if (hip_err) *hip_err = e;
         return TCE_ERR_HIP;

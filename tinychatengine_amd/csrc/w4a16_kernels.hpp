@@ -117,6 +117,10 @@ struct AttnDeferred;
 int launch_w4a16_gemv_i8(const tce_w4a16_desc *descs, int count, hipStream_t stream, hipError_t *hip_err, const float *gamma = nullptr, float eps = 0.f, const I8ResidualNorm *rn = nullptr,
                          const AttnDeferred *comb = nullptr, const int *comb_pos_dev = nullptr, int comb_pos = 0);
 
+// the mixed launch (round 6): up to TCE_MAX_INDEPENDENT decode linears with their own activations and K, one launch; bit-identical to the linears issued one by one
+bool gemv_i8_mixed_supports(const tce_w4a16_desc *descs, int count);
+void gemv_i8_mixed_geometry(const tce_w4a16_desc *descs, int count, int *waves, int *workgroups);
+int launch_w4a16_gemv_i8_mixed(const tce_w4a16_desc *descs, int count, hipStream_t stream, hipError_t *hip_err);
 // w4a16_gemv_i8_token.hip (round 6): a prefix of a launch list as ONE persistent kernel on the int8-contraction body, the data flow ordered by tagged output words
 struct I8TokenPlan;
 int i8_token_plan_create(const tce_w4a16_desc *descs, const int32_t *groups, int n_launches, I8TokenPlan **out, int *n_taken, hipError_t *hip_err);

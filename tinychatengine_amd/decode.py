@@ -150,7 +150,17 @@ class DecodeLinears:
         """Algorithmic HBM bytes of one token on THIS rank (SURVEY §8d formula, summed over its linears)."""
         return sum(capi.algorithmic_bytes(self.m, l.out_features, l.in_features, self.group_size) for l in self.all_linears())
 
-    def make_plan(self, grouped: bool = True, tagged: bool = False, overlapped: bool = False, tuned: bool = False) -> capi.Plan:
+    def token_launches_one_per_block(self) -> list[list[capi.W4A16Desc]]:
+        """The one-gather-per-block form's launch list (replicated inputs: nothing inside a block depends on anything inside it): a rank's linears of a
+        block as ONE group of linears that share nothing (tce_w4a16_forward_independent / TCE_PLAN_INDEPENDENT) -- layers + 1 launches per token instead of 4 x layers + 1."""
+        if self.dataflow:
+            raise ValueError("the data-flow wiring orders the linears of a block: they are not independent")
+        return [[d for g in self.block_launches(li) for d in g] for li in range(self.n_layers)] + \
+               [[self.lm_head.desc(self.x, self.logits, allow_host=self._host_ok)]]
+
+    def make_plan(self, grouped: bool = True, tagged: bool = False, overlapped: bool = False, tuned: bool = False, one_launch_per_block: bool = False) -> capi.Plan:
+        if one_launch_per_block:
+            return capi.Plan(self.token_launches_one_per_block(), independent=True)
         return capi.Plan(self.token_launches(grouped), tagged=tagged, overlapped=overlapped, tuned=tuned)
 
     # ---- eager issue (used inside torch graph capture for world > 1, and by tests) ----
@@ -158,6 +168,10 @@ class DecodeLinears:
     def _hip_launch(group: list[capi.W4A16Desc]) -> None:
         st = _stream()
         capi.check(capi.w4a16_forward_group(group, st) if len(group) > 1 else capi.w4a16_forward(group[0], st))
+
+    @staticmethod
+    def _hip_launch_independent(group: list[capi.W4A16Desc]) -> None:
+        capi.w4a16_forward_independent(group, _stream())
 
     def run_block(self, li: int, launch=None) -> None:
         launch = launch or self._hip_launch
@@ -191,12 +205,15 @@ class DecodeLinears:
         if getattr(self, "comm", None) is not None and self.comm.status() != 0:
             raise RuntimeError(f"rank {self.rank}: a peer-write all-gather timed out (tce_comm_status != 0); the token's outputs are void")
 
-    def run_token_distributed(self, gathers_per_block: int = 1, launch=None, gather: str = "rccl", check: bool = False) -> None:
+    def run_token_distributed(self, gathers_per_block: int = 1, launch=None, gather: str = "rccl", check: bool = False, block_launch: str = "one") -> None:
         """world > 1: per block, the rank-local GEMVs on N/P shards, then the all-gather(s) of the fp16 output slices --
         gather="rccl": torch.distributed (backend 'nccl' == RCCL over xGMI on the GPU box; 'gloo' in the CPU tests, where
         `launch` is a CPU stand-in for the kernel launch); gather="peer": tce_allgather_f16, one peer-write kernel per
         exchange (attach_peer_comm first).  gathers_per_block = 1 is the north-star definition (all five linears of a block
-        from replicated inputs, one gather of the block output); 4 is the dependency-faithful variant."""
+        from replicated inputs, one gather of the block output); 4 is the dependency-faithful variant.
+        block_launch (gathers_per_block = 1 only; round 6): "one" -- the rank's linears of a block are ONE launch (tce_w4a16_forward_independent: they share nothing and
+        depend on nothing inside the block); "four" -- q/k/v grouped, o, gate/up grouped, down, as through round 5.  Same outputs, bit for bit."""
+        launch_ind = launch or self._hip_launch_independent  # (a CPU stand-in handles any list of descriptors)
         launch = launch or self._hip_launch
         m = self.m
         if gather == "peer":
@@ -223,8 +240,11 @@ class DecodeLinears:
         for li in range(self.n_layers):
             lch = self.block_launches(li)
             if gathers_per_block == 1:
-                for g in lch:
-                    launch(g)
+                if block_launch == "one":
+                    launch_ind([d for g in lch for d in g])
+                else:
+                    for g in lch:
+                        launch(g)
                 ag(self.g_down, self.out_down)
             else:
                 launch(lch[0])
