@@ -86,7 +86,7 @@ def compact_line(full: dict, details_file: str | None = None, budget: int = LINE
             c[k] = c[k][:197] + "..."
     gv = cfg.get("gather_variants")
     if isinstance(gv, dict):
-        c["gather_variants"] = {("peer" if k.startswith("peer") else "rccl" if k.startswith("RCCL") else k[:8]) + ("_4" if ", 4 gather" in k else "_1" if ", 1 gather" in k else "") + ("x1" if "one launch per block" in k else ""):
+        c["gather_variants"] = {("peer" if k.startswith("peer") else "rccl" if k.startswith("RCCL") else k[:8]) + ("_4" if ", 4 gather" in k else "_1" if ", 1 gather" in k else "") + ("x1" if "one launch per block" in k else "f" if "inside the block" in k else ""):
                                 (v.get("tokens_per_s", "rejected") if isinstance(v, dict) else v) for k, v in gv.items()}
     for k in ("ranks", "rccl_ranks", "gather_path"):
         if k in cfg:
@@ -1328,10 +1328,14 @@ def main():
         gathers = [g for g in (("peer", "rccl") if args.gather == "all" else (args.gather,)) if g != "peer" or getattr(dl, "comm", None) is not None]
         gpbs = (1, 4) if args.gathers_per_block == 0 else (args.gathers_per_block,)
         gather_variants, runs = {}, []
-        for gpb, blk in [(g, b) for g in gpbs for b in ((("one", "four") if g == 1 else ("four",)))]:
+        for gpb, blk in [(g, b) for g in gpbs for b in ((("fused", "one", "four") if g == 1 else ("four",)))]:
             for gth in gathers:
+                if blk == "fused" and gth != "peer":
+                    continue
                 name = f"{'peer-write kernel (tce_allgather_f16)' if gth == 'peer' else 'RCCL all_gather_into_tensor'}, {gpb} gather{'s' if gpb > 1 else ''} per block" + \
                        (", one launch per block (tce_w4a16_forward_independent)" if blk == "one" else "")
+                if blk == "fused":
+                    name = "peer-write exchange inside the block's one launch (tce_w4a16_forward_independent_gather), 1 gather per block"
                 try:
                     step_v, mode_v = build_dist_step(gpb, gth, dl, blk)
                     wall_v, ev_v = timed_run(step_v)
@@ -1375,7 +1379,7 @@ def main():
         one = [r for r in runs if r[0] == min(g for g, *_ in runs)]
         gpb_h, gth_h, wall, ev_ms_total, mode, name_h, blk_h = min(one, key=lambda r: r[2])
         args.gathers_per_block, args.gather = gpb_h, gth_h
-        n_launches = dl.n_layers * (1 if blk_h == "one" else 4) + 1  # (the gather kernels / collectives are not counted)
+        n_launches = dl.n_layers * (4 if blk_h == "four" else 1) + 1  # (the gather kernels / collectives are not counted; "fused": there are none but the logits')
         gather_variants["headline"] = name_h
         # BASELINE config 5 (Llama-2-13B column-sharded 8 ways) beside the headline workload when the run has its eight ranks (VERDICT r4 item 7 ii): same
         # variants, same timing; never takes the headline down with it
@@ -1621,7 +1625,8 @@ def selftest_emit(args):
         out["n_gpus"] = world
         if world > 1:
             names = [f"{g}, {n} gather{'s' if n > 1 else ''} per block" for n in (1, 4) for g in ("peer-write kernel (tce_allgather_f16)", "RCCL all_gather_into_tensor")]
-            names = [nm + ", one launch per block (tce_w4a16_forward_independent)" for nm in names[:2]] + names
+            names = ["peer-write exchange inside the block's one launch (tce_w4a16_forward_independent_gather), 1 gather per block"] + \
+                    [nm + ", one launch per block (tce_w4a16_forward_independent)" for nm in names[:2]] + names
             out["config"]["gather_variants"] = dict({nm: {"ms_per_token": 1.0, "tokens_per_s": 1000.0, "issue": "x" * 120} for nm in names}, headline=names[0])
             out["config"]["ranks"] = [{"rank": r, "device": r, "pci_bus_id": "0000:00:00.0"} for r in range(world)]
     print(f"[bench] rank {rank}: selftest noise on stdout before the line")

@@ -504,6 +504,15 @@ TCE_API int tce_comm_export(tce_comm *comm, void *handle_out /* 64 bytes */);
 TCE_API int tce_comm_connect(tce_comm *comm, const void *handles /* [world][64], rank order */);
 TCE_API int tce_comm_connect_local(tce_comm *comm, tce_comm *const *all_ranks /* [world] */);
 TCE_API int tce_allgather_f16(tce_comm *comm, int slot, const void *src_slice, void *dst_full, int n_total, void *stream);
+/* (0.1.12) tce_w4a16_forward_independent with the all-gather of ONE of its linears INSIDE the launch (the one-gather-per-block form as one launch per block:
+ * layers + 1 launches per token).  Linear `gathered` of the call is this rank's slice (its N rows; M = 1) of a vector of N * world halves: besides storing the slice at
+ * its own C, the tiles that compute it write their 16 values straight into every rank's window, the tile that arrives last publishes this rank's flag, waits for the
+ * other ranks' flags and copies the complete vector to `dst_full` -- tce_allgather_f16's protocol, window, buffers, flags and epochs (the two calls may alternate on one
+ * slot), without its launch.  Same contract: every rank issues the same sequence of exchanges per slot; a rank that never arrives flags the communicator after the bound
+ * (tce_comm_status).  The other linears of the call are not delayed by the exchange (one wave of the launch waits).
+ * One launch under tce_w4a16_forward_independent's conditions (+ the gathered linear has no SiLU-mul-pair epilogue, N * world % 8 == 0 and <= 16384, the vector fits the window);
+ * otherwise tce_w4a16_forward_independent followed by tce_allgather_f16 -- same results.  *launches (may be null): kernel launches made. */
+TCE_API int tce_w4a16_forward_independent_gather(const tce_w4a16_desc *descs, int count, int gathered, tce_comm *comm, int slot, void *dst_full, int *launches, void *stream);
 /* Round 4: RCCL behind the same communicator, for exchanges beyond the latency regime (north star: "a single RCCL all-gather over xGMI per transformer block";
  * SURVEY 8e sizes a prompt's exchange at 0.65-1.97 MB per rank).  librccl is opened on first use (dlopen); the communicator is built from an opaque
  * TCE_RCCL_ID_BYTES blob that rank 0 obtains (tce_comm_rccl_unique_id) and the host hands to every rank exactly like the IPC handles (tce_comm_rccl_init is

@@ -370,3 +370,167 @@ def test_one_process_two_devices_through_connect_local():
     finally:
         for c in comms:
             c.close()
+
+
+# ---- round 6: the exchange INSIDE the block's one launch (tce_w4a16_forward_independent_gather) ----
+
+def _block_shards(T, capi, dev, g, world, hidden=1024, ffn=3584):
+    """The linears of a small sharded block: (full linears, per rank [shards]) -- q, o, gate of K = hidden, down of K = ffn (the gathered one, last)."""
+    from tinychatengine_amd.linear import Linear_half_int4
+    fulls = [Linear_half_int4.from_float(T.empty(n, k, device=dev).normal_(0, 0.02, generator=g), 128).prepack()
+             for n, k in ((hidden, hidden), (hidden, hidden), (ffn, hidden), (hidden, ffn))]
+    return fulls, [[f.shard(r, world).prepack() for f in fulls] for r in range(world)]
+
+
+@gpu
+def test_exchange_inside_the_block_launch_two_ranks_in_one_process():
+    """Two ranks in one process (streams of different priorities): per round every rank issues ONE call -- its four shards, the last one's slice exchanged inside the
+    launch -- and ends with the complete down output, bit-identical to the unsharded linear, the other shards bit-identical to the rows of theirs.  Rounds alternate with
+    the plain gather kernel on the SAME slot (one protocol), cover both buffer parities, and a residual-add epilogue on the gathered linear."""
+    from tinychatengine_amd import capi
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda:0")
+    world = 2
+    g = torch.Generator(device=dev).manual_seed(11)
+    fulls, shards = _block_shards(torch, capi, dev, g, world)
+    comms = [capi.Comm(r, world, 4096, slots=2) for r in range(world)]
+    capi.Comm.connect_local(comms)
+    streams = [torch.cuda.Stream(priority=0 if r % 2 == 0 else -1) for r in range(world)]
+    try:
+        for round_ in range(6):
+            xs = [torch.empty(1, f.in_features, device=dev).normal_(0, 1, generator=g).to(torch.float16) for f in fulls]
+            add = round_ % 3 == 2  # the gathered linear adds to its slice buffer (o_proj / down_proj + residual): the exchanged values are the sums
+            resid = torch.empty(1, fulls[3].out_features, device=dev).normal_(0, 1, generator=g).to(torch.float16)
+            wants = [f.forward(x) for f, x in zip(fulls, xs)]
+            if add:
+                wants[3] = fulls[3].forward_add(xs[3], resid.clone())
+            torch.cuda.synchronize()
+            outs = [[torch.full((1, s.out_features), float("nan"), dtype=torch.float16, device=dev) for s in shards[r]] for r in range(world)]
+            full_down = [torch.full((1, fulls[3].out_features), float("nan"), dtype=torch.float16, device=dev) for _ in range(world)]
+            n_launches = []
+            for r in range(world):
+                n_loc = shards[r][3].out_features
+                if add:
+                    outs[r][3].copy_(resid[:, r * n_loc:(r + 1) * n_loc])
+                with torch.cuda.stream(streams[r]):
+                    descs = [s.desc(x, o, flags=(capi.TCE_W4_ADD_TO_C if add and i == 3 else 0)) for i, (s, x, o) in enumerate(zip(shards[r], xs, outs[r]))]
+                    if round_ % 3 == 1:  # the two-call form on the same slot
+                        capi.w4a16_forward_independent(descs, streams[r].cuda_stream)
+                        comms[r].allgather(0, outs[r][3].data_ptr(), full_down[r].data_ptr(), fulls[3].out_features, streams[r].cuda_stream)
+                    else:
+                        n_launches.append(comms[r].forward_independent_gather(descs, 3, 0, full_down[r].data_ptr(), streams[r].cuda_stream))
+            torch.cuda.synchronize()
+            assert all(n == 1 for n in n_launches), n_launches
+            for r in range(world):
+                assert comms[r].status() == 0
+                assert torch.equal(full_down[r].view(torch.int16), wants[3].view(torch.int16)), f"round {round_} rank {r}: gathered vector"
+                for i in range(4):
+                    n_loc = shards[r][i].out_features
+                    assert torch.equal(outs[r][i].view(torch.int16), wants[i][:, r * n_loc:(r + 1) * n_loc].view(torch.int16)), f"round {round_} rank {r} linear {i}"
+    finally:
+        for c in comms:
+            c.close()
+
+
+@gpu
+def test_exchange_inside_the_launch_single_rank_and_fallbacks():
+    """world = 1: the exchange is a copy through the window.  A vector beyond 16384 halves, or a gathered linear the one-launch form does not take, goes through
+    tce_w4a16_forward_independent + the gather kernel: same result, the launch count says so.  Bad arguments are refused by name."""
+    from tinychatengine_amd import capi
+    from tinychatengine_amd.linear import Linear_half_int4
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(3)
+    st = torch.cuda.current_stream().cuda_stream
+    comm = capi.Comm(0, 1, 32768, slots=2)
+    capi.Comm.connect_local([comm])
+    try:
+        for n, k, prepack, expect in ((256, 1024, True, 1), (20480, 1024, True, 2), (256, 1024, False, 2)):
+            lin = Linear_half_int4.from_float(torch.empty(n, k, device=dev).normal_(0, 0.02, generator=g), 128)
+            if prepack:
+                lin.prepack()
+            x = torch.empty(1, k, device=dev).normal_(0, 1, generator=g).to(torch.float16)
+            want = lin.forward(x)
+            for it in range(3):
+                part = torch.full((1, n), float("nan"), dtype=torch.float16, device=dev)
+                full = torch.full((1, n), float("nan"), dtype=torch.float16, device=dev)
+                assert comm.forward_independent_gather([lin.desc(x, part)], 0, 1, full.data_ptr(), st) == expect
+                torch.cuda.synchronize()
+                assert comm.status() == 0 and torch.equal(part, want) and torch.equal(full, want), (n, k, prepack, it)
+        with pytest.raises(capi.TceError):
+            comm.forward_independent_gather([lin.desc(x, part)], 1, 0, full.data_ptr(), st)  # gathered: not an index of the call
+        with pytest.raises(capi.TceError):
+            comm.forward_independent_gather([lin.desc(x, part)], 0, 5, full.data_ptr(), st)  # slot out of range
+        capi.lib().tce_reset_last_error()
+    finally:
+        comm.close()
+
+
+def _ipc_rank_fused(rank, world, conn, seed, use_graph):
+    """Child process: a rank of the sharded block, the block output exchanged inside the block's one launch."""
+    sys.path.insert(0, REPO)
+    import torch as T
+    from tinychatengine_amd import capi
+    dev = T.device("cuda:0")
+    g = T.Generator(device=dev).manual_seed(seed)  # same seed everywhere: identical weights and inputs
+    fulls, shards = _block_shards(T, capi, dev, g, world)
+    mine = shards[rank]
+    comm = capi.Comm(rank, world, 4096, slots=2)
+    conn.send(comm.export())
+    comm.connect(conn.recv())
+    ok = True
+    xs = [T.zeros(1, f.in_features, dtype=T.float16, device=dev) for f in fulls]
+    outs = [T.zeros(1, s.out_features, dtype=T.float16, device=dev) for s in mine]
+    got = T.zeros(1, fulls[3].out_features, dtype=T.float16, device=dev)
+    descs = [s.desc(x, o) for s, x, o in zip(mine, xs, outs)]
+    cs = T.cuda.Stream()
+    gr = None
+    if use_graph:
+        gr = T.cuda.CUDAGraph()
+        with T.cuda.stream(cs):
+            with T.cuda.graph(gr, stream=cs, capture_error_mode="thread_local"):
+                comm.forward_independent_gather(descs, 3, 1, got.data_ptr(), cs.cuda_stream)
+    for it in range(8):
+        for x in xs:
+            x.copy_(T.empty(1, x.shape[1], device=dev).normal_(0, 1, generator=g).to(T.float16))
+        want = fulls[3].forward(xs[3])
+        got.fill_(float("nan"))
+        T.cuda.synchronize()
+        if gr is not None:
+            gr.replay()
+        else:
+            ok = ok and comm.forward_independent_gather(descs, 3, 1, got.data_ptr(), cs.cuda_stream) == 1
+        T.cuda.synchronize()
+        ok = ok and comm.status() == 0 and bool(T.equal(got.view(T.int16), want.view(T.int16)))
+    conn.send(ok)
+    conn.recv()
+    comm.close()
+
+
+@gpu
+@pytest.mark.parametrize("world,use_graph", [(2, False), (4, False), (2, True)])
+def test_processes_exchange_inside_the_block_launch(world, use_graph):
+    """One process per rank on the one GPU (IPC windows), the block's one launch carrying the exchange: every rank's complete vector bit-identical to the unsharded linear,
+    eagerly and as a replayed hipGraph (the epoch and the arrival counter live on the device)."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    pipes = [ctx.Pipe() for _ in range(world)]
+    procs = [ctx.Process(target=_ipc_rank_fused, args=(r, world, pipes[r][1], 91, use_graph)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        handles = [pipes[r][0].recv() for r in range(world)] if all(pipes[r][0].poll(300) for r in range(world)) else None
+        assert handles is not None, "a rank did not come up"
+        for r in range(world):
+            pipes[r][0].send(handles)
+        results = []
+        for r in range(world):
+            assert pipes[r][0].poll(300), f"rank {r} did not finish"
+            results.append(pipes[r][0].recv())
+        for r in range(world):
+            pipes[r][0].send(True)
+        assert all(results), results
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()

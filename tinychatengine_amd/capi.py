@@ -32,7 +32,7 @@ TCE_OUT_INT8, TCE_OUT_FP32 = 0, 1
 
 # every symbol include/tce_matmul.h declares (tests/test_boundary.py checks the .so exports exactly these)
 EXPORTS = [
-    "tce_w4a16_forward", "tce_w4a16_residual_rmsnorm_workspace_bytes", "tce_w4a16_forward_residual_rmsnorm", "tce_w4a16_prepack_bytes", "tce_w4a16_prepack", "tce_w4a16_gemm_scratch_bytes", "tce_w4a16_gemm_scratch_faults", "tce_w4a16_describe_dispatch", "tce_reset_last_error", "tce_bmm_f16t", "tce_rope_half", "tce_softmax_half", "tce_attention_decode_f16", "tce_attention_decode_workspace_bytes", "tce_attention_decode_describe", "tce_attention_decode_step_f16", "tce_attention_decode_step_gqa_f16", "tce_attention_decode_describe_gqa", "tce_attention_decode_step_pos_f16", "tce_attention_prefill_f16", "tce_attention_prefill_workspace_bytes", "tce_opt_attention_decode", "tce_prefetch", "tce_add_half", "tce_silu_mul_half", "tce_rmsnorm_half", "tce_w4a16_forward_group_rmsnorm", "tce_w4a16_forward_group", "tce_w4a16_forward_independent", "tce_w4a16_describe_independent", "tce_w4a16_check_zero_point_8", "tce_w4a16_awq_fp16acc", "tce_w4a16_awq_workspace_bytes",
+    "tce_w4a16_forward", "tce_w4a16_residual_rmsnorm_workspace_bytes", "tce_w4a16_forward_residual_rmsnorm", "tce_w4a16_prepack_bytes", "tce_w4a16_prepack", "tce_w4a16_gemm_scratch_bytes", "tce_w4a16_gemm_scratch_faults", "tce_w4a16_describe_dispatch", "tce_reset_last_error", "tce_bmm_f16t", "tce_rope_half", "tce_softmax_half", "tce_attention_decode_f16", "tce_attention_decode_workspace_bytes", "tce_attention_decode_describe", "tce_attention_decode_step_f16", "tce_attention_decode_step_gqa_f16", "tce_attention_decode_describe_gqa", "tce_attention_decode_step_pos_f16", "tce_attention_prefill_f16", "tce_attention_prefill_workspace_bytes", "tce_opt_attention_decode", "tce_prefetch", "tce_add_half", "tce_silu_mul_half", "tce_rmsnorm_half", "tce_w4a16_forward_group_rmsnorm", "tce_w4a16_forward_group", "tce_w4a16_forward_independent", "tce_w4a16_describe_independent", "tce_w4a16_forward_independent_gather", "tce_w4a16_check_zero_point_8", "tce_w4a16_awq_fp16acc", "tce_w4a16_awq_workspace_bytes",
     "tce_w4a16_gemm_awq", "tce_w4a16_shard", "tce_comm_create", "tce_comm_export", "tce_comm_connect", "tce_comm_connect_local", "tce_allgather_f16", "tce_comm_rccl_unique_id", "tce_comm_rccl_init", "tce_allgather_rows_workspace_bytes", "tce_allgather_rows_f16", "tce_comm_status", "tce_comm_set_timeout_ms", "tce_comm_reset", "tce_comm_device", "tce_comm_destroy", "tce_w8a8_matmul", "tce_opt_softmax_q", "tce_opt_kv_append", "tce_layernorm_q", "tce_layernorm_q_w8a8_group", "tce_plan_create", "tce_plan_create_ex", "tce_plan_is_chained", "tce_plan_geometry", "tce_plan_status", "tce_plan_launch_geometry", "tce_plan_launch", "tce_plan_n_launches",
     "tce_w4a16_forward_v2", "tce_w8a8_matmul_v2", "tce_w8a8_scratch_bytes", "tce_attention_decode_step_deferred_f16", "tce_w4a16_forward_deferred_attention", "tce_plan_destroy", "tce_version", "tce_last_error", "tce_build_info", "tce_w4a16_set_gemv_config", "tce_w4a16_set_gemv_i8",
     "tce_w4a16_set_gemm_config", "tce_w4a16_algorithmic_bytes", "tce_w4a16_gemv_variant", "tce_w4a16_gemm_variant",
@@ -143,6 +143,7 @@ def lib() -> C.CDLL:
         L.tce_w4a16_forward_group.argtypes = [C.POINTER(W4A16Desc), C.c_int, C.c_void_p]
         L.tce_w4a16_forward_independent.argtypes = [C.POINTER(W4A16Desc), C.c_int, C.POINTER(C.c_int), C.c_void_p]
         L.tce_w4a16_describe_independent.argtypes = [C.POINTER(W4A16Desc), C.c_int, C.c_char_p, C.c_int]
+        L.tce_w4a16_forward_independent_gather.argtypes = [C.POINTER(W4A16Desc), C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
         L.tce_w4a16_prepack_bytes.argtypes = [C.c_int] * 3
         L.tce_w4a16_prepack_bytes.restype = C.c_size_t
         L.tce_w4a16_gemm_scratch_bytes.argtypes = []
@@ -406,6 +407,14 @@ class Comm:
 
     def allgather(self, slot: int, src_ptr: int, dst_ptr: int, n_total: int, stream: int | None) -> None:
         check(lib().tce_allgather_f16(self.handle, slot, C.c_void_p(src_ptr), C.c_void_p(dst_ptr), n_total, C.c_void_p(stream or 0)))
+
+    def forward_independent_gather(self, descs: list, gathered: int, slot: int, dst_ptr: int, stream: int | None) -> int:
+        """tce_w4a16_forward_independent_gather: the linears of `descs` as one launch, linear `gathered`'s slice exchanged with the other ranks inside it (the complete
+        vector lands at dst_ptr).  Returns the number of kernel launches made."""
+        arr = (W4A16Desc * len(descs))(*descs)
+        n = C.c_int(0)
+        check(lib().tce_w4a16_forward_independent_gather(arr, len(descs), gathered, self.handle, slot, C.c_void_p(dst_ptr), C.byref(n), C.c_void_p(stream or 0)))
+        return n.value
 
     @staticmethod
     def rccl_unique_id() -> bytes:

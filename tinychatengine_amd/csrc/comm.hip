@@ -35,6 +35,7 @@ namespace tce {
 
 constexpr int kMaxRanks = 8;
 constexpr int kFlagStride = 16;  // words between flags (their own 64-byte lines)
+static_assert(kMaxRanks == kCommMaxRanks && kFlagStride == kCommFlagStride, "w4a16_kernels.hpp: the in-launch exchange addresses the same flag table");
 
 struct Comm {
     int rank = 0, world = 1, slots = 0;
@@ -135,8 +136,9 @@ int comm_create(int rank, int world, int max_vector_elems, int slots, Comm **out
         e = hipMalloc(&p, c->window_bytes);  // single-device setups (tests): coherence within the device is all that is needed
     }
     if (e == hipSuccess) e = hipMemset(p, 0, c->window_bytes);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->epochs), (size_t)(slots + 1) * 4);
-    if (e == hipSuccess) e = hipMemset(c->epochs, 0, (size_t)(slots + 1) * 4);
+    // [slots] epochs, the status word, [slots] arrival counters of the exchanges that run inside a linear's launch (PeerGatherEpi)
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->epochs), (size_t)(2 * slots + 1) * 4);
+    if (e == hipSuccess) e = hipMemset(c->epochs, 0, (size_t)(2 * slots + 1) * 4);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         if (p) (void)hipFree(p);
@@ -247,7 +249,7 @@ int comm_set_timeout_ms(Comm *c, int ms) {
 int comm_reset(Comm *c, hipError_t *he) {
     DeviceGuard guard(c->device);
     hipError_t e = hipDeviceSynchronize();
-    if (e == hipSuccess) e = hipMemset(c->epochs + c->slots, 0, 4);
+    if (e == hipSuccess) e = hipMemset(c->epochs + c->slots, 0, (size_t)(c->slots + 1) * 4);  // the status word and the arrival counters (a launch that was cut short may have left one)
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         if (he) *he = e;
@@ -317,6 +319,29 @@ int launch_allgather_f16(Comm *c, int slot, const void *src_slice, void *dst_ful
     return TCE_OK;
 }
 
+
+int comm_peer_gather_epi(Comm *c, int slot, void *dst_full, int n_total, PeerGatherEpi *out) {
+    if (slot < 0 || slot >= c->slots || n_total <= 0 || n_total % c->world || !dst_full) return TCE_ERR_BAD_ARG;
+    // 16-byte pieces of the complete vector; the slices themselves are written element by element by the tiles that computed them
+    if (n_total % 8 || (size_t)n_total * 2 > c->vec_bytes || (reinterpret_cast<uintptr_t>(dst_full) & 15)) return TCE_ERR_UNSUPPORTED_SHAPE;
+    PeerGatherEpi g{};
+    for (int p = 0; p < c->world; ++p) {
+        if (!c->peer[p]) return TCE_ERR_BAD_ARG;  // not connected
+        g.peer[p] = c->peer[p];
+    }
+    g.epochs = c->epochs;
+    g.dst = dst_full;
+    g.rank = c->rank;
+    g.world = c->world;
+    g.slot = slot;
+    g.slots = c->slots;
+    g.slice_elems = (unsigned)(n_total / c->world);
+    g.vec_bytes = c->vec_bytes;
+    g.flags_off = data_bytes(*c);
+    g.timeout_ticks = c->timeout_ticks;
+    *out = g;
+    return TCE_OK;
+}
 
 // ---- RCCL behind the same communicator (round 4): exchanges beyond the latency regime ----
 // A decode exchange is 1-4 KB per rank: one peer-write kernel.  A prompt's exchange (0.65-1.97 MB per rank at M = 512) is a bandwidth problem, and

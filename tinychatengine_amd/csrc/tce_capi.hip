@@ -1031,6 +1031,44 @@ int tce_allgather_f16(tce_comm *comm, int slot, const void *src_slice, void *dst
     if (rc != TCE_OK) return fail(rc, "tce_allgather_f16: slot out of range, group not connected, n_total %% world != 0, slices not multiples of 16 bytes, or vector larger than the window (and no RCCL communicator: tce_comm_rccl_init)");
     return TCE_OK;
 }
+int tce_w4a16_forward_independent_gather(const tce_w4a16_desc *descs, int count, int gathered, tce_comm *comm, int slot, void *dst_full, int *launches, void *stream) {
+    if (launches) *launches = 0;
+    if (!descs || count < 1 || count > TCE_MAX_INDEPENDENT || gathered < 0 || gathered >= count || !comm || !dst_full)
+        return fail(TCE_ERR_BAD_ARG, "tce_w4a16_forward_independent_gather: bad argument (count 1..%d, gathered an index of the call, comm and dst_full non-null)", TCE_MAX_INDEPENDENT);
+    for (int i = 0; i < count; ++i) {
+        const int rc = check_w4a16(&descs[i]);
+        if (rc != TCE_OK) return rc;
+    }
+    tce::Comm *c = reinterpret_cast<tce::Comm *>(comm);
+    const tce_w4a16_desc &dg = descs[gathered];
+    if (dg.M != 1) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_w4a16_forward_independent_gather: the gathered linear is a decode row (M = 1; a prompt's rows: tce_allgather_rows_f16)");
+    const long long n_total = (long long)dg.N * tce::comm_world_of(c);
+    if (n_total > 0x7FFFFFFF) return fail(TCE_ERR_UNSUPPORTED_SHAPE, "tce_w4a16_forward_independent_gather: vector too long");
+    // (ONE wave finishes the exchange inside the launch: vectors of up to 16384 halves -- a hidden state or an FFN row; longer ones, the logits, keep the gather kernel's
+    //  1024 threads)
+    if (g_gemv_kernel == 0 && g_debug_mode_capi == 0 && n_total <= 16384 && tce::gemv_i8_mixed_supports(descs, count) && !(dg.flags & TCE_W4_SILU_MUL_PAIRS)) {
+        tce::PeerGatherEpi g{};
+        const int rcg = tce::comm_peer_gather_epi(c, slot, dst_full, (int)n_total, &g);
+        if (rcg == TCE_ERR_BAD_ARG) return fail(rcg, "tce_w4a16_forward_independent_gather: slot out of range or group not connected");
+        if (rcg == TCE_OK) {
+            hipError_t he = hipSuccess;
+            const int rc = tce::launch_w4a16_gemv_i8_mixed(descs, count, static_cast<hipStream_t>(stream), &he, &g, gathered);
+            if (rc == TCE_ERR_HIP) return hip_fail(he, "w4a16 gemv (int8 contraction, mixed, exchange inside) launch");
+            if (rc == TCE_OK) {
+                if (launches) *launches = 1;
+                return TCE_OK;
+            }
+            if (rc != TCE_ERR_UNSUPPORTED_SHAPE) return fail(rc, "w4a16 gemv (int8 contraction, mixed, exchange inside): unsupported configuration");
+        }
+    }
+    int n = 0;
+    int rc = tce_w4a16_forward_independent(descs, count, &n, stream);
+    if (rc != TCE_OK) return rc;
+    rc = tce_allgather_f16(comm, slot, dg.C, dst_full, (int)n_total, stream);
+    if (rc != TCE_OK) return rc;
+    if (launches) *launches = n + 1;
+    return TCE_OK;
+}
 int tce_comm_rccl_unique_id(void *id_out) {
     if (!id_out) return fail(TCE_ERR_BAD_ARG, "tce_comm_rccl_unique_id: null");
     const int rc = tce::comm_rccl_unique_id(id_out);

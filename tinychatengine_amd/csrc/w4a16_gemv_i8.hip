@@ -85,6 +85,11 @@ struct I8MixArgs {
     const float *comb_part = nullptr;
     const int *comb_pos_dev = nullptr;
     int comb_pos = 0, comb_slots = 0, comb_chunk = 0, comb_stride = 0, comb_heads = 0;
+    // the exchange of ONE linear's output slice with the other ranks inside this launch (tce_w4a16_forward_independent_gather): linear g_seg (-1: none), its g_tiles
+    // 16-row tiles count themselves in on the slot's arrival counter
+    int g_seg = -1;
+    unsigned g_tiles = 0;
+    PeerGatherEpi g;
     I8MixSeg s[kI8MixMax];
 };
 
@@ -134,6 +139,8 @@ __global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const ARGS args) {
     int U, NG, K_, lda_, tile0;
     const half_t *A_;
     I8Seg seg;
+    bool gathers = false;   // MIX: this workgroup's linear is the one whose slice is exchanged inside the launch
+    unsigned g_epoch = 0;   // the exchange's epoch: the slot's count of completed exchanges + 1 (the same on every rank: they all run the same sequence per slot)
     if constexpr (MIX) {
         int si = 0;
 #pragma unroll
@@ -152,6 +159,9 @@ __global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const ARGS args) {
         if (sub >= nsub || tile0 >= ((seg.N + 15) >> 4)) return;  // (whole wave groups: the barrier below counts the surviving waves)
         tid -= sub * WK * 64;
         smem += (size_t)sub * ((size_t)WK * UW * 512 + (size_t)WK * 16 * sizeof(float));
+        gathers = si == args.g_seg;
+        // (read before any tile of this launch can have counted itself in: the word changes only after ALL of them have)
+        if (gathers) g_epoch = __hip_atomic_load(args.g.epochs + args.g.slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     } else {
         U = args.U;
         NG = args.NG;
@@ -540,6 +550,17 @@ __global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const ARGS args) {
             } else {
                 crow[row] = y;
             }
+            if constexpr (MIX) {
+                if (gathers) {
+                    // (a) the tile's 16 values into EVERY rank's window -- buffer (slot, parity of the epoch), this rank's slice -- past every cache (comm.hip's protocol)
+                    const half_t outv = (seg.epilogue & TCE_W4_ADD_TO_C) ? (half_t)(c_old + y) : y;
+                    const size_t off = ((size_t)args.g.slot * 2 + (g_epoch & 1u)) * args.g.vec_bytes + ((size_t)args.g.rank * args.g.slice_elems + (size_t)row) * 2;
+#pragma unroll
+                    for (int p = 0; p < kCommMaxRanks; ++p)
+                        if (p < args.g.world)
+                            __hip_atomic_store(reinterpret_cast<unsigned short *>(args.g.peer[p] + off), __builtin_bit_cast(unsigned short, outv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
         }
         if constexpr (RNORM) {
             // the tile's 16 updated values -> memory, past every cache (the last workgroup reads them from another XCD); their two piece sums likewise
@@ -554,6 +575,59 @@ __global__ __launch_bounds__(MAXT) void w4a16_gemv_i8_kernel(const ARGS args) {
                 s1 = __builtin_fmaf(v1, v1, s1);
             }
             if (tid < 2) __hip_atomic_store(args.ws + 2 * tile0 + tid, tid == 0 ? s0 : s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if constexpr (MIX) {
+        if (gathers && tid < 64) {  // (the tile's first wave: the one that stored)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores above have been acknowledged before the tile counts itself in
+            unsigned *const counter = args.g.epochs + args.g.slots + 1 + args.g.slot;
+            unsigned last = 0;
+            if (tid == 0) last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == args.g_tiles - 1u ? 1u : 0u;
+            last = (unsigned)__builtin_amdgcn_readfirstlane((int)last);
+            if (last) {
+                // ---- the last tile of the slice: flags out, the other ranks' flags in, the complete vector to the consumer's buffer (allgather_peer_kernel's b, c, d) ----
+                const unsigned e = g_epoch, par = e & 1u;
+                __threadfence_system();
+                if (tid < args.g.world) {
+                    unsigned *flag = reinterpret_cast<unsigned *>(args.g.peer[tid] + args.g.flags_off) + (((size_t)args.g.slot * 2 + par) * kCommMaxRanks + args.g.rank) * kCommFlagStride;
+                    __hip_atomic_store(flag, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                if (tid < args.g.world) {
+                    const unsigned *flag = reinterpret_cast<const unsigned *>(args.g.peer[args.g.rank] + args.g.flags_off) + (((size_t)args.g.slot * 2 + par) * kCommMaxRanks + tid) * kCommFlagStride;
+                    const unsigned long long t0 = wall_clock64();
+                    const bool dead = __hip_atomic_load(args.g.epochs + args.g.slots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+                    while (!dead && (int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
+                        __builtin_amdgcn_s_sleep(8);
+                        if (wall_clock64() - t0 > args.g.timeout_ticks) {  // a rank that never arrives: give up, flag the communicator (tce_comm_status; tce_comm_reset re-arms)
+                            __hip_atomic_store(args.g.epochs + args.g.slots, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                __threadfence_system();  // acquire: the peers' data behind their flags
+                const unsigned char *full = args.g.peer[args.g.rank] + ((size_t)args.g.slot * 2 + par) * args.g.vec_bytes;
+                const unsigned total16 = args.g.slice_elems * (unsigned)args.g.world / 8u;
+                for (unsigned base = 0; base < total16; base += 64 * 8) {
+                    uint4_t v[8];  // eight pieces per lane in flight (one wave carries the whole vector: 8 KiB at 4096 halves)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const unsigned i = base + q * 64 + tid;
+                        const unsigned ic = i < total16 ? i : total16 - 1;
+                        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[q]) : "v"(full + (size_t)ic * 16) : "memory");
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const unsigned i = base + q * 64 + tid;
+                        if (i < total16) reinterpret_cast<uint4_t *>(args.g.dst)[i] = v[q];
+                    }
+                }
+                if (tid == 0) {
+                    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next exchange on this slot (ordered by the kernel boundary)
+                    __hip_atomic_store(args.g.epochs + args.g.slot, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
     }
     if constexpr (RNORM) {
@@ -809,11 +883,19 @@ void gemv_i8_mixed_geometry(const tce_w4a16_desc *descs, int count, int *waves, 
     *workgroups = blocks;
 }
 
-int launch_w4a16_gemv_i8_mixed(const tce_w4a16_desc *descs, int count, hipStream_t stream, hipError_t *hip_err) {
+int launch_w4a16_gemv_i8_mixed(const tce_w4a16_desc *descs, int count, hipStream_t stream, hipError_t *hip_err, const PeerGatherEpi *gather, int gathered) {
     if (!gemv_i8_mixed_supports(descs, count)) return TCE_ERR_UNSUPPORTED_SHAPE;
     I8MixArgs a{};
     a.nseg = count;
     a.M = 1;
+    if (gather) {  // linear `gathered`'s slice is exchanged inside the launch: plain or residual-add store (the pair epilogue halves the row index), the slice is the whole linear
+        if (gathered < 0 || gathered >= count) return TCE_ERR_BAD_ARG;
+        const tce_w4a16_desc &dg = descs[gathered];
+        if ((dg.flags & TCE_W4_SILU_MUL_PAIRS) || (unsigned)dg.N != gather->slice_elems) return TCE_ERR_UNSUPPORTED_SHAPE;
+        a.g = *gather;
+        a.g_seg = gathered;
+        a.g_tiles = (unsigned)pk::nt16(dg.N);
+    }
     int wl = 1, total = 0;
     gemv_i8_mixed_geometry(descs, count, &wl, &total);
     bool z8 = true;

@@ -118,9 +118,10 @@ int launch_w4a16_gemv_i8(const tce_w4a16_desc *descs, int count, hipStream_t str
                          const AttnDeferred *comb = nullptr, const int *comb_pos_dev = nullptr, int comb_pos = 0);
 
 // the mixed launch (round 6): up to TCE_MAX_INDEPENDENT decode linears with their own activations and K, one launch; bit-identical to the linears issued one by one
+struct PeerGatherEpi;  // (below, with the communicator)
 bool gemv_i8_mixed_supports(const tce_w4a16_desc *descs, int count);
 void gemv_i8_mixed_geometry(const tce_w4a16_desc *descs, int count, int *waves, int *workgroups);
-int launch_w4a16_gemv_i8_mixed(const tce_w4a16_desc *descs, int count, hipStream_t stream, hipError_t *hip_err);
+int launch_w4a16_gemv_i8_mixed(const tce_w4a16_desc *descs, int count, hipStream_t stream, hipError_t *hip_err, const PeerGatherEpi *gather = nullptr, int gathered = -1);
 // w4a16_gemv_i8_token.hip (round 6): a prefix of a launch list as ONE persistent kernel on the int8-contraction body, the data flow ordered by tagged output words
 struct I8TokenPlan;
 int i8_token_plan_create(const tce_w4a16_desc *descs, const int32_t *groups, int n_launches, I8TokenPlan **out, int *n_taken, hipError_t *hip_err);
@@ -209,6 +210,19 @@ int comm_status(Comm *c, hipError_t *he);
 void comm_destroy(Comm *c);
 int launch_allgather_f16(Comm *c, int slot, const void *src_slice, void *dst_full, int n_total, hipStream_t stream, hipError_t *he);
 int comm_world_of(const Comm *c);
+// the peer-write exchange of ONE linear's output slice inside the launch that computes it (w4a16_gemv_i8.hip, the mixed launch; round 6): what that kernel's epilogue
+// needs of the communicator -- same window, buffers, flags and epochs as allgather_peer_kernel, so the two forms can alternate on one slot
+constexpr int kCommMaxRanks = 8, kCommFlagStride = 16;  // the flag table of a window: [slots][2 parities][kCommMaxRanks] words, kCommFlagStride words apart (comm.hip)
+struct PeerGatherEpi {
+    unsigned char *peer[8];  // every rank's window as mapped here
+    unsigned *epochs;        // [slots] exchanges completed per slot, the status word at [slots], the arrival counters at [slots + 1 + slot]
+    void *dst;               // the complete vector on this rank
+    int rank, world, slot, slots;
+    unsigned slice_elems;    // halves per rank
+    size_t vec_bytes, flags_off;
+    unsigned long long timeout_ticks;
+};
+int comm_peer_gather_epi(Comm *c, int slot, void *dst_full, int n_total, PeerGatherEpi *out);  // the checks of launch_allgather_f16, no launch
 int comm_rccl_unique_id(void *id128);
 int comm_rccl_init(Comm *c, const void *id128);
 bool comm_has_rccl(const Comm *c);

@@ -212,7 +212,11 @@ class DecodeLinears:
         exchange (attach_peer_comm first).  gathers_per_block = 1 is the north-star definition (all five linears of a block
         from replicated inputs, one gather of the block output); 4 is the dependency-faithful variant.
         block_launch (gathers_per_block = 1 only; round 6): "one" -- the rank's linears of a block are ONE launch (tce_w4a16_forward_independent: they share nothing and
-        depend on nothing inside the block); "four" -- q/k/v grouped, o, gate/up grouped, down, as through round 5.  Same outputs, bit for bit."""
+        depend on nothing inside the block); "four" -- q/k/v grouped, o, gate/up grouped, down, as through round 5; "fused" (gather="peer" only) -- one launch per
+        block WITH the exchange of the block output inside it (tce_w4a16_forward_independent_gather): layers + 1 launches per token and nothing else.  Same outputs, bit
+        for bit."""
+        if block_launch == "fused" and (gather != "peer" or gathers_per_block != 1 or self.m != 1):
+            raise ValueError("block_launch='fused': the peer-write exchange, one gather per block, decode rows")
         launch_ind = launch or self._hip_launch_independent  # (a CPU stand-in handles any list of descriptors)
         launch = launch or self._hip_launch
         m = self.m
@@ -240,6 +244,10 @@ class DecodeLinears:
         for li in range(self.n_layers):
             lch = self.block_launches(li)
             if gathers_per_block == 1:
+                if block_launch == "fused":  # the exchange inside the block's one launch (tce_w4a16_forward_independent_gather): layers + 1 launches per token
+                    flat = [d for g in lch for d in g]
+                    self.comm.forward_independent_gather(flat, len(flat) - 1, slot_of.setdefault(self.g_down.data_ptr(), len(slot_of)), self.g_down.data_ptr(), st)
+                    continue
                 if block_launch == "one":
                     launch_ind([d for g in lch for d in g])
                 else:
@@ -253,7 +261,11 @@ class DecodeLinears:
                 launch(lch[1]); ag(self.g_o, self.out_o)
                 launch(lch[2]); ag(self.g_gate, self.out_gate); ag(self.g_up, self.out_up)
                 launch(lch[3]); ag(self.g_down, self.out_down)
-        launch([self.lm_head.desc(self.x, self.logits, allow_host=self._host_ok)])
-        ag(self.g_logits, self.logits)
+        if gathers_per_block == 1 and block_launch == "fused":
+            self.comm.forward_independent_gather([self.lm_head.desc(self.x, self.logits, allow_host=self._host_ok)], 0, slot_of.setdefault(self.g_logits.data_ptr(), len(slot_of)),
+                                                 self.g_logits.data_ptr(), st)
+        else:
+            launch([self.lm_head.desc(self.x, self.logits, allow_host=self._host_ok)])
+            ag(self.g_logits, self.logits)
         if check and gather == "peer":  # (synchronises: not for a timed loop or a graph capture)
             self.check_comm()
