@@ -17,7 +17,8 @@ side = torch.cuda.Stream()
 big_a = torch.empty(256 << 20, dtype=torch.uint8, device=dev); big_b = torch.empty_like(big_a)
 small = [torch.randn(1 << 16, device=dev) for _ in range(8)]
 CASES = [(192, 200, 512, 32, [61, 62, 63, 64, 60]), (700, 392, 3072, 32, [61, 62, 63, 64, 60]), (260, 300, 1408, 64, [61, 62, 63, 64, 60]),
-         (513, 2100, 256, 128, [61, 62, 63, 64, 66, 67, 68, 2670, 2671, 2673, 2674, 2675, 60]), (384, 520, 2048, 128, [61, 62, 63, 64, 66, 67, 672, 68, 2669, 2670, 2671, 2672, 2683, 2673, 2674, 2675, 60])]
+         (513, 2100, 256, 128, [61, 62, 63, 64, 66, 67, 68, 2670, 2671, 2673, 2674, 2675, 60]), (384, 520, 2048, 128, [61, 62, 63, 64, 66, 67, 672, 68, 2669, 2670, 2671, 2672, 2683, 2673, 2674, 2675, 60]),
+         (260, 300, 1408, 128, [2676, 64, 60])]  # (round 6: form 16 -- two quartets per tile and the k range handed off between two workgroups)
 if os.environ.get("STRESS_CASES"): CASES = [CASES[int(i)] for i in os.environ["STRESS_CASES"].split(",")]
 if os.environ.get("STRESS_MODES"): CASES = [(M, N, K, G, [int(v) for v in os.environ["STRESS_MODES"].split(",")]) for (M, N, K, G, _) in CASES]
 for (M, N, K, G, modes) in CASES:

@@ -7,6 +7,8 @@
   w8a8  -- tce_w8a8_matmul on the three OPT-125M shapes at M = 512 and the 128-row tile's 512 x 4096 x 4096
   attn  -- the fast decode attention step at 512 and 2048 keys (32 heads x 128; the grouped-query form 32 / 8)
   token -- one whole decode token through 32 decoder layers, eagerly (the fused-norm GEMV launches, the attention step, the residual epilogues)
+  shard -- (round 6) rank 0's share of a token of the column-sharded model at 8 and 2 ranks (this GPU playing rank 0; no exchange): a block's seven shards as ONE launch
+           (tce_w4a16_forward_independent) and as the four launches of rounds 1-5
 Every family uses distinct shapes per case, so (kernel name, grid size) identifies a case in the profiler's tables (summarize_prof.py with TCE_PROF_KEY_GRID=1)."""
 import ctypes as C
 import os
@@ -95,3 +97,19 @@ if "token" in fams:
     torch.cuda.synchronize()
     print("token finite", bool(torch.isfinite(hid.float()).all().item()))
 print("families done:", fams)
+
+
+if "shard" in fams:
+    from tinychatengine_amd.decode import SHAPES, DecodeLinears
+    st_ = torch.cuda.current_stream().cuda_stream
+    for P in (8, 2):
+        dlp = DecodeLinears(SHAPES["llama3-8b"], device=dev, rank=0, world=P, prepack=True)
+        for rep in range(max(1, REPS // 4)):
+            for li in range(dlp.n_layers):   # one launch per block
+                capi.w4a16_forward_independent([d for g_ in dlp.block_launches(li) for d in g_], st_)
+            torch.cuda.synchronize()
+            for li in range(dlp.n_layers):   # four launches per block
+                dlp.run_block(li)
+            torch.cuda.synchronize()
+        del dlp
+        torch.cuda.empty_cache()

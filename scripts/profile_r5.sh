@@ -6,7 +6,7 @@
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"
 TAG=${1:-r5}
 shift
-FAMS="${@:-gemm w8a8 attn token}"
+FAMS="${@:-gemm w8a8 attn token shard}"
 OUT=$REPO/gpurun_out/prof_${TAG}_families
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -26,6 +26,7 @@ summ gemm_pk "w4a16_gemm_pk"
 summ w8a8 "w8a8_"
 summ attention_step "attn_|attention"
 summ decode_token_launches "w4a16_gemv|rmsnorm|glue|add_half|silu"
+summ sharded_block_launches "w4a16_gemv_i8"
 summ all ""
 find $OUT -name "*.csv" -size +2M -delete
 tail -5 $OUT/kt.log; wc -l $OUT/rocprofv3_summary_*.txt

@@ -93,8 +93,15 @@ def test_packed_prefill_dispatch_rules_of_round_5():
     """The cost model's choices the GPU tests also see (tests/test_gpu_w4a16_pk.py), held here without a GPU: which form of the packed prefill GEMM a shape is sent to."""
     d = capi.describe_dispatch
     # few tiles: the k range of every 128 x 128 tile cut across workgroups -- two runs (a directed hand-off) at K = 4096, four through the last arriver at K = 11008
-    assert "tile=128x128 quartets=1 ksplit=2 " in d(_pk(512, 4096, 4096)), d(_pk(512, 4096, 4096))
-    assert "tile=128x128 quartets=1 ksplit=4 " in d(_pk(512, 4096, 11008)), d(_pk(512, 4096, 11008))
+    # (round 6: with at most 128 tiles the two runs are walked by TWO quartets each -- form 16, two waves per SIMD on every CU: 512 x 4096 x 4096 27.3 -> 26.1 us,
+    #  x 11008 53.6 -> 50.9-53.8; very long k ranges and launches of 64 tiles keep four runs of one quartet; other group sizes keep the one-quartet runs)
+    assert "tile=128x128 quartets=2 ksplit=2 " in d(_pk(512, 4096, 4096)), d(_pk(512, 4096, 4096))
+    assert "tile=128x128 quartets=2 ksplit=2 " in d(_pk(512, 4096, 11008)), d(_pk(512, 4096, 11008))
+    assert "tile=128x128 quartets=2 ksplit=2 " in d(_pk(384, 4096, 4096)), d(_pk(384, 4096, 4096))
+    assert "tile=128x128 quartets=1 ksplit=4 " in d(_pk(512, 4096, 14336)), d(_pk(512, 4096, 14336))
+    assert "tile=128x128 quartets=1 ksplit=4 " in d(_pk(512, 2048, 8192)), d(_pk(512, 2048, 8192))
+    assert "tile=128x128 quartets=1 ksplit=2 " in d(_pk(512, 4096, 4096, G=64)), d(_pk(512, 4096, 4096, G=64))
+    assert "ksplit" not in d(_pk(1024, 4096, 4096))  # 256 tiles: whole tiles
     assert "ksplit" not in d(_pk(512, 4096, 4096, scratch=False))  # no scratch area, no cut
     # the wide forms (128 rows x 64 / 48 columns per wave): linears whose zero points are all 8, groups of 128
     assert "tile=128x192 wave=128x48 quartets=2" in d(_pk(512, 11008, 4096))

@@ -89,6 +89,7 @@ PK_SHAPES = [
     (256, 256, 512, 128), (200, 136, 384, 128), (513, 2100, 256, 128), (128, 128, 128, 128), (300, 264, 1024, 64), (192, 200, 512, 32),
     (384, 520, 1408 + 128 * 5, 128),
     (260, 300, 1408, 64), (700, 392, 3072, 32),  # uneven runs when the k range is cut across workgroups (11 k-blocks in 2; 24 in 3 / 4), groups of 64 / 32
+    (260, 300, 1408, 128), (200, 136, 1152, 128), (130, 520, 1024, 128),  # round 6, form 16 (mode 2676): 11 / 9 / 8 k-blocks handed off between two workgroups of two quartets each
 ]
 
 
@@ -106,7 +107,7 @@ def test_pk_gemm_matches_oracle(dev, oracle, M, N, K, G):
         lin = _lin(dev, qw, sc, zp, G).prepack()
         x = torch.from_numpy(a).to(dev)
         try:
-            for mode in (61, 62, 63, 64, 66, 67, 672, 68, 2669, 2670, 2671, 2672, 2683, 2673, 2674, 2675, 60):  # 64: the k range cut across workgroups (needs the scratch area desc() attaches); 66 / 67 / 672 / 68 / 2669: the 256-row wave tiles (round 5; groups of 128 -- other group sizes run form 1 under these modes): whole tiles / k range cut / two quartets alternating a tile's k-blocks (even counts; odd: one quartet) / two quartets side by side on 256 x 256
+            for mode in (61, 62, 63, 64, 66, 67, 672, 68, 2669, 2670, 2671, 2672, 2683, 2673, 2674, 2675, 2676, 60):  # 2676 (round 6): form 16 -- two quartets alternating a run's k-blocks, the k range handed off between two workgroups (8+ k-blocks, groups of 128; otherwise form 2);  64: the k range cut across workgroups (needs the scratch area desc() attaches); 66 / 67 / 672 / 68 / 2669: the 256-row wave tiles (round 5; groups of 128 -- other group sizes run form 1 under these modes): whole tiles / k range cut / two quartets alternating a tile's k-blocks (even counts; odd: one quartet) / two quartets side by side on 256 x 256
                 capi.check(L.tce_w4a16_set_debug_mode(mode))
                 out = torch.full((M, N), float("nan"), dtype=torch.float16, device=dev)
                 d = lin.desc(x, out)
@@ -114,6 +115,8 @@ def test_pk_gemm_matches_oracle(dev, oracle, M, N, K, G):
                     assert capi.describe_dispatch(d).startswith("gemm-pk"), capi.describe_dispatch(d)
                 if mode in (2670, 2671, 2672, 2683, 2675) and not rz and G == 128 and M > 128:  # round 5: 128 rows x 64 columns per wave
                     assert "wave=128x64" in capi.describe_dispatch(d), capi.describe_dispatch(d)
+                if mode == 2676 and G == 128 and K >= 1024:
+                    assert "quartets=2 ksplit=2" in capi.describe_dispatch(d), capi.describe_dispatch(d)
                 if mode in (2673, 2674) and not rz and G == 128 and M > 128:  # the same on 128 x 192 tiles
                     assert "wave=128x48" in capi.describe_dispatch(d), capi.describe_dispatch(d)
                 capi.check(capi.w4a16_forward(d, torch.cuda.current_stream().cuda_stream))
@@ -260,6 +263,8 @@ def test_pk_dispatch_rules(dev, oracle):
     d.M, d.N, d.K, d.lda, d.ldc = 512, 4096, 4096, 4096, 4096
     assert d.scratch and "ksplit=2" in capi.describe_dispatch(d), capi.describe_dispatch(d)
     d.K = d.lda = 11008
+    assert "quartets=2 ksplit=2" in capi.describe_dispatch(d), capi.describe_dispatch(d)  # (round 6, form 16: two runs of two quartets each, 50.9-53.8 us against four one-quartet runs' 53.1-54.1)
+    d.K = d.lda = 14336
     assert "ksplit=4" in capi.describe_dispatch(d), capi.describe_dispatch(d)  # (round 4: the scratch area holds 512 units; four runs per tile win on the long k range -- also against round 5's two handed-off runs once the weights come from HBM: 53.5 against 54.55 us)
     d.scratch = None
     assert capi.describe_dispatch(d).startswith("gemm-dma")
@@ -282,7 +287,7 @@ def test_full_size_prefill_on_the_packed_kernel(dev, oracle, N, K):
     what = capi.describe_dispatch(lin.desc(x, y))
     # N = 4096: 128 tiles, every tile's k range cut in two (K = 4096) or four (K = 11008: round 4); N = 11008: 344 tiles, the 88 past the first 256 cut in two (one run per CU at most)
     # N = 11008 (round 5): 128 x 192 tiles -- 232 of them for the 256 CUs --, two quartets alternating a tile's k-blocks (until then: 344 tiles of 128 x 128, the 88 past the first 256 cut in two)
-    assert what.startswith("gemm-pk") and ((("ksplit=2 " if K == 4096 else "ksplit=4 ") in what) if N == 4096 else "tile=128x192 wave=128x48 quartets=2" in what), what
+    assert what.startswith("gemm-pk") and (("quartets=2 ksplit=2 " in what) if N == 4096 else "tile=128x192 wave=128x48 quartets=2" in what), what
     for rep in range(3):  # (the scratch counters must be back to zero after every call)
         y.fill_(float("nan"))
         lin.forward(x, y)

@@ -69,7 +69,8 @@ def repeat_under_load(dev, launch, results, seconds=SECONDS):
 
 PK_CASES = [  # M, N, K, G, forced forms (60 = the dispatcher's choice)
     (192, 200, 512, 32, [61, 62, 63, 64, 60]), (700, 392, 3072, 32, [61, 64, 60]), (260, 300, 1408, 64, [61, 62, 63, 64, 60]),
-    (513, 2100, 256, 128, [61, 62, 63, 64, 66, 67, 68, 2670, 2671, 2673, 2674, 2675, 60]), (384, 520, 2048, 128, [61, 62, 63, 64, 66, 67, 672, 68, 2669, 2670, 2671, 2672, 2683, 2673, 2674, 2675, 60]),
+    (513, 2100, 256, 128, [61, 62, 63, 64, 66, 67, 68, 2670, 2671, 2673, 2674, 2675, 60]), (384, 520, 2048, 128, [61, 62, 63, 64, 66, 67, 672, 68, 2669, 2670, 2671, 2672, 2683, 2673, 2674, 2675, 2676, 60]),
+    (260, 300, 1408, 128, [2676, 64, 60]),  # round 6, form 16 (two quartets per tile AND the k range handed off between two workgroups) on an odd number of k-blocks
 ]
 
 

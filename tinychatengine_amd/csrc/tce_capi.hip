@@ -172,7 +172,7 @@ int tce_w4a16_set_debug_mode(int mode) {
         return TCE_OK;
     }
     // (round 6, ADVICE r5: the three GEMM mode families below sit INSIDE this range and were shadowed by it since they were added -- they are matched further down)
-    const bool pk_mode_in_attention_range = (mode >= 6950 && mode <= 6958) || (mode >= 6972 && mode <= 6974) || (mode >= 7700 && mode <= 7710 + 512);
+    const bool pk_mode_in_attention_range = (mode >= 6950 && mode <= 6958) || (mode >= 6972 && mode <= 6974) || (mode >= 7700 && mode <= 7710 + 512) || mode == 6916 || mode == 6917;
     if (mode >= 3000 && mode <= 3000 + 8192 && !pk_mode_in_attention_range) {  // fast attention step: workgroups the key range is cut for (3000: the fitted rule, the default)
         tce::set_attention_fast_target(mode - 3000);
         return TCE_OK;
@@ -252,6 +252,17 @@ int tce_w4a16_set_debug_mode(int mode) {
         g_pk_mode = mode == 600 ? 0 : 1;
         tce::set_gemm_pk_mode(mode == 600 ? 0 : 1, 0);
         tce::set_gemm_pk_ablation(mode - 600);
+        return TCE_OK;
+    }
+    if (mode == 2676) {  // (round 6) 128 x 128 tiles, two quartets alternating a run's k-blocks, every tile's k range handed off between two workgroups (form 16)
+        g_pk_mode = 8;
+        tce::set_gemm_pk_ablation(0);
+        tce::set_gemm_pk_split(0);
+        tce::set_gemm_pk_mode(16, 0);
+        return TCE_OK;
+    }
+    if (mode == 6916 || mode == 6917) {  // form 16 offered to the dispatcher (6917, the default) or not (6916)
+        tce::set_gemm_pk_form16_auto(mode - 6916);
         return TCE_OK;
     }
     if (mode == 2675) {  // the wide form on 128 x 512 tiles (two quartets side by side on one activation ring)
@@ -687,6 +698,7 @@ int tce_w4a16_describe_dispatch(const tce_w4a16_desc *d, char *buf, int buf_len)
         else if (form == 11) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=128x256 wave=128x64 quartets=2 group=%d", d->group_size);
         else if (form == 12) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=128x256 wave=128x64 quartets=1 ksplit=%d group=%d", split, d->group_size);
         else if (form == 4) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=128x128 quartets=1 ksplit=%d group=%d", split, d->group_size);
+        else if (form == 16) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=128x128 quartets=2 ksplit=2 group=%d", d->group_size);
         else if (form == 5) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=128x128 quartets=1 ksplit=%d-of-the-tiles-past-256 group=%d", split, d->group_size);
         else if (form == 6) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=256x128 quartets=1 group=%d", d->group_size);
         else if (form == 7) std::snprintf(buf, (size_t)buf_len, "gemm-pk tile=256x128 quartets=1 ksplit=%d group=%d", split, d->group_size);

@@ -220,8 +220,11 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
     // Which tiles are cut: those in slots >= full_slots, i.e. the ones whose first runs are dispatched LAST -- a launch of 344 tiles
     // runs 256 whole tiles (one per CU) and the k-blocks of the other 88 as 3 x 88 short runs beside them, instead of two whole tiles
     // on 88 CUs and one on the rest.
+    // the forms whose tiles' k range may be cut across workgroups: one quartet per tile (any tile shape), and -- round 6, form 16 -- the 128 x 128 tile whose k-blocks
+    // alternate between two quartets: each RUN alternates between them, the quartets join through LDS as always, quartet 0 carries the exchange between the runs
+    constexpr bool CUT = NS == 1 && (KS == 1 || (KS == 2 && kMT == 8 && kNT == 2));
     int bid = blockIdx.x, part = 0;
-    if (KS == 1 && NS == 1 && g.split_s > 1) {
+    if (CUT && g.split_s > 1) {
         const int per = 8 * g.m_per * g.n_per;
         if (bid >= per) {
             const int tail_wgs = per - 8 * g.full_slots, e = bid - per;
@@ -250,9 +253,9 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
     const int n16 = lane & 15, q = lane >> 4;
     const int m_base = m_blk * ROWS, nb0 = n_blk * BN;
     const int nkb = g.K >> 7;
-    const int split = (KS == 1 && NS == 1 && g.split_s > 1 && slot >= g.full_slots) ? g.split_s : 1;
+    const int split = (CUT && g.split_s > 1 && slot >= g.full_slots) ? g.split_s : 1;
     // this workgroup's run of k-blocks (the hand-off form: run 0 is two k-blocks shorter than run 1 -- about the time its write-through takes to become visible)
-    const bool handoff = KS == 1 && NS == 1 && kMT == 8 && kNT == 2 && split == 2 && g.handoff != 0;
+    const bool handoff = CUT && kMT == 8 && kNT == 2 && split == 2 && g.handoff != 0;
     // (g.handoff = 1 + the k-blocks run 0 is shorter by; never fewer than two k-blocks for run 0 -- ADVICE r5: an unclamped delta of 8 at K = 1024 left run 0 without a k-block)
     const int n0_raw = nkb >= 8 ? (nkb - (g.handoff - 1)) / 2 : nkb / 2;
     const int n0_h = n0_raw >= 2 ? n0_raw : (nkb >= 4 ? 2 : nkb / 2);
@@ -834,7 +837,8 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
         __syncthreads();
     }
 
-    if (KS == 1 && NS == 1 && split > 1) {
+    if (CUT && split > 1) {
+        // (KS == 2: the joined tile sits in quartet 0's registers -- `grp == 0` moves the partials; everything that synchronises or decides is done by all 512 threads)
         // ---- K split across workgroups: the run's partial tile (true units, fp32) goes to the scratch area with write-through stores;
         //      the workgroup that arrives LAST at the tile's counter adds the split_s partials in run order -- so the sum does not
         //      depend on who was last -- and stores the tile.  (Same visibility
@@ -878,7 +882,7 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
 #pragma unroll
                     for (int j = 0; j < kNT; ++j) acc[i][j] = float4_t{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
             }
-            if (have) {  // run order: run 0's partial first, then this run's (the same sum the last-arriver form computes)
+            if (have && grp == 0) {  // run order: run 0's partial first, then this run's (the same sum the last-arriver form computes)
                 uint4_t t4[kMT * kNT];
 #pragma unroll
                 for (int r = 0; r < kMT * kNT; ++r) t4[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_p, (r * 256 + tid) * 16, 0, /*sc0|sc1*/ 17);
@@ -893,11 +897,13 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
                     }
             }
         } else {
+        if (grp == 0) {
 #pragma unroll
         for (int i = 0; i < kMT; ++i)
 #pragma unroll
             for (int j = 0; j < kNT; ++j)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, acc[i][j]), rs_p, ((part * kMT * kNT + i * kNT + j) * 256 + tid) * 16, 0, /*sc0|sc1*/ 17);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         unsigned *flag = reinterpret_cast<unsigned *>(smem);
         __syncthreads();
@@ -936,7 +942,7 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
             for (int i = 0; i < kMT; ++i)
 #pragma unroll
                 for (int j = 0; j < kNT; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
-            for (int p = 0; p < split; ++p) {
+            for (int p = 0; p < split && grp == 0; ++p) {
 #pragma unroll
                 for (int c0 = 0; c0 < kMT * kNT; c0 += 8) {
                     uint4_t t4[8];
@@ -956,7 +962,7 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
                 own[i][j] = acc[i][j];
                 acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
             }
-        for (int p = 0; p < split; ++p) {
+        for (int p = 0; p < split && grp == 0; ++p) {
             if (p == part) {  // workgroup-uniform
 #pragma unroll
                 for (int i = 0; i < kMT; ++i)
@@ -1064,6 +1070,10 @@ thread_local int g_pk_handoff_delta = 2;   // k-blocks run 0 of a hand-off is sh
 thread_local int g_pk_prio = -1;  // -1: the rule below (the wide form with one quartet per tile); 0 .. 4 forced (tce_w4a16_set_debug_mode(696 / 697 / 6972 .. 6974; 698: the rule))
 thread_local int g_pk_handoff = 1;         // 1: a k range cut in two runs is a directed hand-off (tce_w4a16_set_debug_mode(694): the last-arriver exchange, for the A/B)
 constexpr float kPkHandoffUs = 5.0f;       // run 1's read of run 0's tile + what is left of run 0's write-through when run 1 arrives; fitted with the weights coming from HBM (scripts/probes/gemm_pk_handoff_cold_ab.py: 512 x 4096 x 4096 26.15 -> 24.85 us; at K = 11008 two handed-off runs take 54.55, four runs through the last arriver 53.5 -- the model keeps four there)
+thread_local int g_pk_form16_auto = 1;                   // 1: the dispatcher may pick form 16 by itself (tce_w4a16_set_debug_mode(6916): never)
+// fitted to profiles/r6/gemm_pk_form16_ab.jsonl (same process, weights in rotation): 512 x 4096 x 4096 27.3 -> 26.1 us, x 11008 53.1-54.1 -> 50.9-53.8, 384 x 4096 x 4096 24.8-25.5 -> 24.0-24.5;
+// ties or losses where the model keeps the other forms (x 14336: four runs 64.7 against 63.6-67.6; 512 x 2048 x 8192, 64 tiles: four runs 29.4 against 36.5)
+constexpr float kPk16ExtraUs = -2.0f;
 thread_local int g_pk_wide_auto = 1;                    // 1: the dispatcher may pick the wide forms 10 / 11 / 12 by itself (tce_w4a16_set_debug_mode(692): never)
 // fitted to profiles/r5/gemm_pkw_sweep.jsonl: 2048 x 4096 x 4096 (256 tiles, one per CU) 68.1 us; 4096 x 4096 x 4096 (512 tiles, two per CU) 112.8 us; two quartets on one tile 62.7 / 147.0 us at K = 4096 / 11008
 constexpr float kPkWideAloneUs = 2.02f;    // wide form: one quartet alone on its CU walking a k-block (128 MFMAs per wave)
@@ -1183,13 +1193,14 @@ void set_gemm_pk_ablation(int) { g_pk_abl = 0; }  // (the loop-parts-switched-of
 #endif
 void set_gemm_pk256_auto(int on) { g_pk256_auto = on ? 1 : 0; }
 void set_gemm_pk_wide_auto(int on) { g_pk_wide_auto = on ? 1 : 0; }
+void set_gemm_pk_form16_auto(int on) { g_pk_form16_auto = on ? 1 : 0; }
 void set_gemm_pk_handoff(int on) { g_pk_handoff = on ? 1 : 0; }
 void set_gemm_pk_prio(int on) { g_pk_prio = on >= 0 && on <= 4 ? on : -1; }
 void set_gemm_pk_handoff_delta(int d) { g_pk_handoff_delta = d >= 0 && d <= 8 ? d : 2; }
 void set_gemm_pk_split(int s) { g_pk_split_force = s >= 2 && s <= 4 ? s : 0; }
 
 void set_gemm_pk_mode(int form, int xm) {
-    g_pk_ks = (form >= 1 && form <= 15) ? form : 0;  // 15: the wide form on 128 x 512 tiles (two quartets side by side on one activation ring)  // 13 / 14: the wide form on 128 x 192 tiles, one quartet per tile / two alternating its k-blocks  // 10 / 11 / 12: the wide form (one quartet per 128 x 256 tile; two quartets alternating its k-blocks; every tile's k range cut across workgroups)  // 9: 256 x 256 tiles, two quartets side by side (debug mode 2669)  // 6: 256-row wave tiles, whole tiles; 7: the same with every tile's k range cut across workgroups
+    g_pk_ks = (form >= 1 && form <= 16) ? form : 0;  // 16 (round 6): 128 x 128 tiles, two quartets alternating the k-blocks of a RUN, every tile's k range handed off between two workgroups  // 15: the wide form on 128 x 512 tiles (two quartets side by side on one activation ring)  // 13 / 14: the wide form on 128 x 192 tiles, one quartet per tile / two alternating its k-blocks  // 10 / 11 / 12: the wide form (one quartet per 128 x 256 tile; two quartets alternating its k-blocks; every tile's k range cut across workgroups)  // 9: 256 x 256 tiles, two quartets side by side (debug mode 2669)  // 6: 256-row wave tiles, whole tiles; 7: the same with every tile's k range cut across workgroups
     g_pk_xm = (xm == 1 || xm == 2 || xm == 4 || xm == 8) ? xm : 0;
 }
 
@@ -1367,22 +1378,31 @@ float gemm_pk_estimate_us(int M, int N, int K, int *form_out, bool has_scratch, 
         if (cost11 < best) best = cost11, form = 11;
         if (cost12 < best) best = cost12, form = 12;
     }
+    // form 16 (round 6): form 2's tile -- two quartets alternating its k-blocks, two waves per SIMD -- with every tile's k range handed off between TWO workgroups: for the
+    // launches whose 128 x 128 tiles are at most half the CUs (M = 512 at N = 4096: 128 tiles), where form 4 leaves one wave per SIMD and form 2 half the chip idle.
+    // A run is ceil(nkb / 2) (+ 1: run 1 is the longer one) k-blocks, walked in pairs at form 2's rate
+    float cost16 = 1e30f;
+    if (has_scratch && tiles1 * 2 <= 256 && nkb >= 8.f && g_pk_handoff && group_size == 128)  // (measured with groups of 128 only)
+        cost16 = (float)(((int)nkb / 2 + 1 + 1) / 2) * (1.7f + 0.4f * load(tiles1 * 2 * 8)) + 3.0f + kPkHandoffUs + kPk16ExtraUs;
+    if (g_pk_form16_auto && cost16 < best) best = cost16, form = 16;
     if (g_pk_ks) {
         form = g_pk_ks;
+        if (form == 16 && cost16 > 1e29f) form = 2;
         if (form == 4 && split == 1) form = split5 > 1 ? 5 : 1;  // "cut the k range": whichever of the two cut forms applies
         if (form == 7 && split7 == 1) form = 6;
         if ((form >= 6 && form <= 9) && (M <= 128 || group_size != 128)) form = 1;
         if (form == 8 && (nkb < 2.f || ((int)nkb & 1))) form = 6;
-        if (form >= 10 && (M <= 128 || group_size != 128 || !zero_point_8)) form = 1;
+        if (form >= 10 && form <= 15 && (M <= 128 || group_size != 128 || !zero_point_8)) form = 1;
         if (form == 11 && (nkb < 2.f || ((int)nkb & 1))) form = 10;
         if (form == 12 && split12 == 1) form = 10;
         if (form == 14 && (nkb < 2.f || ((int)nkb & 1))) form = 13;
-        if (form >= 10) best = form == 10 ? cost10 : (form == 11 ? cost11 : (form == 12 ? cost12 : (form == 13 ? cost13 : (form == 14 ? cost14 : cost15))));
+        if (form == 16) best = cost16;
+        else if (form >= 10) best = form == 10 ? cost10 : (form == 11 ? cost11 : (form == 12 ? cost12 : (form == 13 ? cost13 : (form == 14 ? cost14 : cost15))));
         else
         best = form == 1 ? cost1 : (form == 2 ? cost2 : (form == 3 ? cost3 : (form == 4 ? cost4 : (form == 5 ? cost5 : (form == 6 ? cost6 : (form == 7 ? cost7 : (form == 8 ? cost8 : cost9)))))));
     }
     if (form_out) *form_out = form;
-    if (split_out) *split_out = form == 4 ? split : (form == 5 ? split5 : (form == 7 ? split7 : (form == 12 ? split12 : 1)));
+    if (split_out) *split_out = form == 4 ? split : (form == 5 ? split5 : (form == 7 ? split7 : (form == 12 ? split12 : (form == 16 ? 2 : 1))));
     return best;
 }
 
@@ -1411,14 +1431,15 @@ int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_
     const bool cut_tail_only = form == 5;
     const bool rows256 = form >= 6 && form <= 9;
     const bool rows256x2 = form == 8, rows256w = form == 9;
+    const bool two_quartets_cut = form == 16;
     const bool wide = form >= 10 && form <= 15, widex2 = form == 11, wide3 = form == 13 || form == 14, wide512 = form == 15;
-    const bool handoff_form = form == 4 && split == 2 && g_pk_handoff;
+    const bool handoff_form = (form == 4 || form == 16) && split == 2 && g_pk_handoff;
     // Two workgroups of the one-quartet wide form share a CU, a wave of each on every SIMD, with nothing tying their progress: half of them (a CU's first dispatch round) run at
     // s_setprio 2 for the whole kernel -- 2048 x 11008 x 4096 162 -> 156 us, 3072 rows 260.4 -> 255.9, 4096 x 14336 x 4096 384-391 -> 379 (profiles/r5/gemm_pk_prio_ab.jsonl: whichever half,
     // whichever level); nothing for the forms whose two quartets share barriers, nothing for the narrow forms.  Priorities do not touch the arithmetic.
     g.prio = g_pk_prio >= 0 ? g_pk_prio : ((form == 10 || form == 12) ? 1 : 0);
-    if (form == 4 || form == 5 || form == 7 || form == 12) {
-        form = 1;
+    if (form == 4 || form == 5 || form == 7 || form == 12 || form == 16) {
+        form = two_quartets_cut ? 2 : 1;
         g.split_s = split;
         g.handoff = handoff_form ? 1 + g_pk_handoff_delta : 0;
         g.counters = static_cast<unsigned *>(d.scratch);

@@ -161,6 +161,7 @@ int launch_w4a16_prepack(const tce_w4a16_desc &d, void *out, hipStream_t stream,
 int launch_w4a16_gemm_pk(const tce_w4a16_desc &d, const void *packed, hipStream_t stream, hipError_t *hip_err);
 void set_gemm_pk256_auto(int on);  // 0: the dispatcher never picks the 256-row forms by itself
 void set_gemm_pk_wide_auto(int on);
+void set_gemm_pk_form16_auto(int on);
 void set_gemm_pk_handoff_delta(int d);
 void set_gemm_pk_prio(int on);
 void set_gemm_pk_handoff(int on);    // 0: a two-run k cut exchanges through the last arriver (A/B), 1: run 0 hands its tile to run 1  // 1: the dispatcher may pick the wide forms (128 rows x 64 columns per wave)
