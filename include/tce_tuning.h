@@ -46,6 +46,7 @@ TCE_API int tce_w4a16_set_gemv_i8(int mode, int tiles_per_wave);
  *   3000+g   fast attention step: workgroups the key range is cut for (3000: the fitted per-context rule, the default)
  * Round 5 (the full list is the dispatch in csrc/tce_capi.hip, one commented `if` per range):
  *   66..69, 672..674, 2669, 690 / 691   pre-packed GEMM, 256-row wave tiles: whole tiles / k range cut / the tile shared by two quartets / 256 x 256 tiles; the dispatcher may pick them (691) or not (690)
+ *   51000..51016                        the mixed decode launch (tce_w4a16_forward_independent): waves per workgroup forced (51000: the rule -- the width that launches the fewest waves)
  *   2676, 6916 / 6917                   pre-packed GEMM, 128 x 128 tiles with two quartets AND the k range handed off between two workgroups (round 6, form 16): forced; offered or not
  *   2670..2675, 2682..2684, 692 / 693   pre-packed GEMM, the wide forms (128 rows x 64 / 48 columns per wave) on 128 x 256 / 192 / 512 tiles, their k range cut in 2 / 3 / 4; offered (693) or not (692)
  *   694 / 695, 6950+d                   a k range cut in two runs: both meet at the counter (694) / run 0 hands its tile to run 1 (695, the default); run 0 shorter by d k-blocks (default 2)

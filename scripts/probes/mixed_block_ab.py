@@ -55,7 +55,16 @@ def main():
             o.fill_(float("nan"))
         g1.replay(); torch.cuda.synchronize()
         same = all(torch.equal(a.view(torch.int16), b.view(torch.int16)) for a, b in zip(want, outs))
-        row = {"shape": shape_name, "P": P, "block_shard_MB": round(blk_bytes / 1e6, 2), "four_launches_us_per_block": round(t4, 2), "one_launch_us_per_block": round(t1, 2),
+        sweep = {}
+        if os.environ.get("WAVES_SWEEP", "1") == "1":  # the mixed launch's workgroup width (tuning mode 51000 + w; below what the longest K needs: the rule stays)
+            need = max(-(-(l.in_features // 128) // 8) for l in [*dl.blocks[0]["qkv"], dl.blocks[0]["o"], dl.blocks[0]["gate"], dl.blocks[0]["up"], dl.blocks[0]["down"]])
+            for w in range(need, 17):
+                capi.check(capi.lib().tce_w4a16_set_debug_mode(51000 + w))
+                gw = graph_of(one, s)
+                sweep[w] = round(min(rate(gw) for _ in range(3)) * 1e3 / L, 2)
+                del gw
+            capi.check(capi.lib().tce_w4a16_set_debug_mode(51000))
+        row = {"shape": shape_name, "P": P, "one_launch_us_by_waves_per_workgroup": sweep, "rule": capi.describe_independent([d for g in dl.block_launches(0) for d in g]), "block_shard_MB": round(blk_bytes / 1e6, 2), "four_launches_us_per_block": round(t4, 2), "one_launch_us_per_block": round(t1, 2),
                "launches_reported": n_one, "same_bits": same, "one_launch_frac_of_8TBs": round(blk_bytes / (t1 * 1e-6) / 8e12, 3)}
         print(json.dumps(row), flush=True)
         rows.append(row)

@@ -261,6 +261,10 @@ int tce_w4a16_set_debug_mode(int mode) {
         tce::set_gemm_pk_mode(16, 0);
         return TCE_OK;
     }
+    if (mode >= 51000 && mode <= 51016) {  // the mixed decode launch (tce_w4a16_forward_independent): waves per workgroup forced (51000: the rule)
+        tce::set_gemv_i8_mixed_waves(mode - 51000);
+        return TCE_OK;
+    }
     if (mode == 6916 || mode == 6917) {  // form 16 offered to the dispatcher (6917, the default) or not (6916)
         tce::set_gemm_pk_form16_auto(mode - 6916);
         return TCE_OK;

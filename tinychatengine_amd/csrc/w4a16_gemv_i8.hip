@@ -872,15 +872,45 @@ bool gemv_i8_mixed_supports(const tce_w4a16_desc *descs, int count) {
 }
 
 // workgroups of the mixed launch and the waves of each (what tce_w4a16_forward_independent reports through describe; ONE rule with the launcher)
+thread_local int g_i8_mix_waves = 0;  // tuning: waves per workgroup of the mixed launch forced (>= what the longest K needs; 0: the rule)
+void set_gemv_i8_mixed_waves(int w) { g_i8_mix_waves = w >= 1 && w <= 16 ? w : 0; }
+
 void gemv_i8_mixed_geometry(const tce_w4a16_desc *descs, int count, int *waves, int *workgroups) {
-    int wl = 1, blocks = 0;
-    for (int i = 0; i < count; ++i) wl = wl > (descs[i].K / 128 + 7) / 8 ? wl : (descs[i].K / 128 + 7) / 8;
-    for (int i = 0; i < count; ++i) {
-        const int nsub = wl / ((descs[i].K / 128 + 7) / 8);
-        blocks += (pk::nt16(descs[i].N) + nsub - 1) / nsub;
-    }
+    int need = 1;
+    for (int i = 0; i < count; ++i) need = need > (descs[i].K / 128 + 7) / 8 ? need : (descs[i].K / 128 + 7) / 8;
+    auto blocks_at = [&](int wl) {
+        int blocks = 0;
+        for (int i = 0; i < count; ++i) {
+            const int nsub = wl / ((descs[i].K / 128 + 7) / 8);
+            blocks += (pk::nt16(descs[i].N) + nsub - 1) / nsub;
+        }
+        return blocks;
+    };
+    // The workgroup is at least as wide as the longest K needs and at most 16 waves.  What a width costs is the most loaded CU -- workgroups go to the 256 CUs in
+    // index order, a workgroup's bytes are its live waves' 8 KiB each -- and, between widths that load it alike (within 5 %), the number of workgroups.  Fitted to
+    // profiles/r6/mixed_block_waves_sweep.jsonl (a Llama-3-8B block's shards at 8 / 4 / 2 / 1 ranks: 14 waves 6.29 / 11.08 / 16.45 / 26.26 us, 16 waves 6.66 / 7.89 / 13.73 /
+    // 24.71; Llama-2-13B: 14 waves 7.01 / 11.4 / 20.07 / 36.3, 15 waves 6.98 / 12.0 / 18.03 / 33.4): the rule picks the faster (or a tie) in all eight.
+    auto max_load = [&](int wl) {
+        int load[256] = {0};
+        int b = 0, worst = 0;
+        for (int i = 0; i < count; ++i) {
+            const int wk = (descs[i].K / 128 + 7) / 8, nsub = wl / wk, tiles = pk::nt16(descs[i].N);
+            for (int t = 0; t < tiles; t += nsub, ++b) {
+                load[b & 255] += (tiles - t < nsub ? tiles - t : nsub) * wk;
+                worst = worst > load[b & 255] ? worst : load[b & 255];
+            }
+        }
+        return worst;
+    };
+    int best_load = 1 << 30;
+    for (int w = need; w <= 16; ++w) best_load = best_load < max_load(w) ? best_load : max_load(w);
+    int wl = need;
+    long best_blocks = 1L << 40;
+    for (int w = need; w <= 16; ++w)
+        if (max_load(w) * 20 <= best_load * 21 && blocks_at(w) < best_blocks) best_blocks = blocks_at(w), wl = w;
+    if (g_i8_mix_waves >= need) wl = g_i8_mix_waves;
     *waves = wl;
-    *workgroups = blocks;
+    *workgroups = blocks_at(wl);
 }
 
 int launch_w4a16_gemv_i8_mixed(const tce_w4a16_desc *descs, int count, hipStream_t stream, hipError_t *hip_err, const PeerGatherEpi *gather, int gathered) {

@@ -121,6 +121,7 @@ int launch_w4a16_gemv_i8(const tce_w4a16_desc *descs, int count, hipStream_t str
 struct PeerGatherEpi;  // (below, with the communicator)
 bool gemv_i8_mixed_supports(const tce_w4a16_desc *descs, int count);
 void gemv_i8_mixed_geometry(const tce_w4a16_desc *descs, int count, int *waves, int *workgroups);
+void set_gemv_i8_mixed_waves(int w);  // tuning: 0 the rule
 int launch_w4a16_gemv_i8_mixed(const tce_w4a16_desc *descs, int count, hipStream_t stream, hipError_t *hip_err, const PeerGatherEpi *gather = nullptr, int gathered = -1);
 // w4a16_gemv_i8_token.hip (round 6): a prefix of a launch list as ONE persistent kernel on the int8-contraction body, the data flow ordered by tagged output words
 struct I8TokenPlan;
