@@ -142,3 +142,31 @@ def test_independent_linears_dispatch():
     assert capi.describe_independent([d(256, 4096), d(64, 4096, flags=capi.TCE_W4_FORCE_GEMM)]) == "one-by-one launches=2"
     with pytest.raises(capi.TceError):
         capi.describe_independent([d(16, 1024)] * 9)
+
+    # the width rule, restated workgroup by workgroup (the library computes a CU's load in closed form per linear and keeps the last answer per thread): the most loaded of
+    # 256 CUs in index order, widths within 5 % of the best compared by their workgroup count, the narrowest on ties
+    def rule(shapes):
+        wk = [-(-(K // 128) // 8) for _, K in shapes]
+        tiles = [-(-N // 16) for N, _ in shapes]
+        need = max(wk)
+        def blocks(w):
+            return sum(-(-t // (w // k)) for t, k in zip(tiles, wk))
+        def worst(w):
+            load, b = [0] * 256, 0
+            for t, k in zip(tiles, wk):
+                nsub = w // k
+                for t0 in range(0, t, nsub):
+                    load[b % 256] += min(nsub, t - t0) * k
+                    b += 1
+            return max(load)
+        best = min(worst(w) for w in range(need, 17))
+        ok = [w for w in range(need, 17) if worst(w) * 20 <= best * 21]
+        w = min(ok, key=lambda w: (blocks(w), w))
+        return f"gemv-i8-mixed waves={w} workgroups={blocks(w)}"
+    import random
+    rng = random.Random(6)
+    for _ in range(200):
+        shapes = [(rng.choice((16, 48, 100, 128, 512, 1792, 3584, 5120, 14336, 40000)), 128 * rng.choice((1, 8, 11, 32, 40, 86, 108, 112, 128)))
+                  for _ in range(rng.randint(2, 8))]
+        assert capi.describe_independent([d(N, K) for N, K in shapes]) == rule(shapes), shapes
+        assert capi.describe_independent([d(N, K) for N, K in shapes]) == rule(shapes)  # (the remembered answer)
