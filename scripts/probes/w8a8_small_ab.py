@@ -13,9 +13,9 @@ rows = []
 for m_ in os.environ.get("W8A8_MODES", "").split(","):
     if m_: capi.check(L.tce_w4a16_set_debug_mode(int(m_)))  # e.g. 171 / 172 / 174: the deep-pipeline 64 x 64 kernel forced with 1 / 2 / 4 quartets; 179 off
 shapes = [tuple(int(v) for v in x.split("x")) for x in os.environ["W8A8_SHAPES"].split(",")] if os.environ.get("W8A8_SHAPES") else None
-for M in (512, 108, 16):
-    for N, K in ((768, 768), (3072, 768), (768, 3072), (2048, 2048), (8192, 2048), (2048, 8192)):
-        if shapes and (M, N, K) not in shapes: continue
+default = [(M, N, K) for M in (512, 108, 16) for N, K in ((768, 768), (3072, 768), (768, 3072), (2048, 2048), (8192, 2048), (2048, 8192))]
+for M, N, K in (shapes or default):
+    if True:
         nsets = max(2, min(64, int(3e8 // (N * K))))
         A = ri(M, K)
         sets = []

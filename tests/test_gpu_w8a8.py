@@ -273,6 +273,36 @@ def test_32_row_tiles_are_bit_exact(dev, oracle, M, N, K):
         L.tce_w4a16_set_debug_mode(190)
 
 
+KSLICE_FORMS = (304, 404, 904)
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 768, 3072), (108, 768, 3072), (65, 130, 208), (33, 65, 128), (70, 33, 1136), (40, 16, 64), (300, 768, 1552), (512, 768, 768), (97, 200, 16)])
+def test_whole_tile_per_wave_is_bit_exact(dev, oracle, M, N, K):
+    """Round 6: w8a8_kslice_kernel -- every wave of the workgroup contracts the WHOLE (32 | 64) x (48 | 64) tile on its own run of k-steps (each operand byte through the CU's
+    L1 once per workgroup), the waves' int32 tiles added through LDS -- every form forced (debug mode 19000 + form) and the rule: int8 and fp32 outputs, ragged last row /
+    column tiles, a K tail, fewer k-steps than waves (waves without a step), K < 64 (the tail only): the oracle's bytes every time."""
+    from tinychatengine_amd import capi
+    from tinychatengine_amd.matmul import MatmulOperator
+    op = MatmulOperator()
+    L = capi.lib()
+    A, B, b8, bf = _data(M, N, K, seed=K + M + 11)
+    exp = oracle.int8_matmul_bias_i8(A, B, b8, ALPHA, BETA, -128, 127, M, N, K)
+    exp32 = oracle.int8_matmul_bias_f32(A, B, bf, ALPHA, M, N, K)
+    try:
+        for form in KSLICE_FORMS + (0,):
+            capi.check(L.tce_w4a16_set_debug_mode(19000 + form))
+            p, out = _params(dev, A, B, torch.int8, b8)
+            op.mat_mul_accelerator_int8_fast_2x2_32unroll(p)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), exp), f"form {form}: {(out.cpu().numpy() != exp).sum()} mismatches"
+            p, out = _params(dev, A, B, torch.float32, bf)
+            op.mat_mul_accelerator_int8_fast_2x2_32unroll_bfp32_ofp32(p)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy().view(np.uint32), exp32.view(np.uint32)), f"form {form}, fp32 output"
+    finally:
+        L.tce_w4a16_set_debug_mode(19000)
+
+
 @pytest.mark.parametrize("M,N,K", [(64, 64, 64), (65, 100, 1024), (512, 768, 3072), (108, 2048, 8192), (16, 136, 1600), (9, 64, 192), (130, 70, 4160)])
 def test_deep_pipeline_tile_is_bit_exact(dev, oracle, M, N, K):
     """The 64x64 tile with eight k-steps in flight (w8a8_mfma_deep_kernel; the rule takes it for chains of 64+ steps on few tiles) forced with 1 / 2 / 4 wave quartets

@@ -208,6 +208,10 @@ int tce_w4a16_set_debug_mode(int mode) {
         }
         return TCE_OK;
     }
+    if (mode >= 19000 && mode <= 19999) {  // W8A8, the whole tile in every wave (round 6): 19000 the rule, 19001 off, 19304 / 19404 / 19904 the 32 x 48 / 32 x 64 / 64 x 64 tile forced wherever the 64 x 64 kernel would run
+        tce::set_w8a8_kslice(mode - 19000);
+        return TCE_OK;
+    }
     if (mode >= 190 && mode <= 192) {  // W8A8, 32 x 64 tiles (round 6): 190 the rule, 191 forced wherever the 64 x 64 kernel would run, 192 off
         tce::set_w8a8_rows32(mode - 190);
         return TCE_OK;

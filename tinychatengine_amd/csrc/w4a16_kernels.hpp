@@ -52,6 +52,7 @@ void set_gemv_debug_mode(int mode);
 void set_gemv_order(int force);
 void set_w8a8_deep(int d);          // W8A8 64 x 64 tile with 8 k-steps in flight: 0 the rule, 1 / 2 / 4 quartets forced, 9 off
 void set_w8a8_rows32(int r);        // W8A8 32 x 64 tiles (round 6): 0 the rule, 1 forced, 2 off
+void set_w8a8_kslice(int code);    // W8A8, the whole tile in every wave (round 6): 0 the rule, 1 off, else a forced form (w8a8_gemm.hip)
 void set_w8a8_big(int b);           // W8A8 128-row tiles: 0 the rule, 1 / 2 forced (128 / 64 columns), 9 off
 void set_lnq_stamps(void *p);
 void set_lnq_form(int f);           // 1: the workgroup-per-8-rows form of the LayerNormQ + W8A8 launch at every k

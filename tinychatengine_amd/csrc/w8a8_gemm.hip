@@ -272,6 +272,128 @@ __global__ __launch_bounds__(256 * KS) void w8a8_mfma_kernel(const W8A8Args a) {
         }
 }
 
+// Round 6, second form for few tiles with a long chain: the WHOLE tile in every wave, the k-steps dealt to the waves.  In the kernel above a quartet's waves sit 2 x 2 on
+// the tile, so every operand row is fetched by two waves: a 32 x 64 tile's k-step pulls 12 KiB through the CU's L1 for 6 KiB of operands, and 512 x 768 x 3072 (192
+// workgroups x 48 steps) is bound by that path, not by the matrix pipe or the chain (two and four quartets tie).  Here a wave owns a run of k-steps and contracts the full
+// (16 TM16) x (16 TN16) tile on them -- TM16 + TN16 fragments requested for TM16 x TN16 MFMAs, every operand byte through L1 ONCE per workgroup, the same per-wave LDS
+// transposition, no barrier in the loop -- and the W waves' int32 tiles are added through LDS at the end (any order: integers, the same epilogue: bit-exact).  A 32 x 48
+// tile gives 512 x 768 x 3072 exactly 256 workgroups; four waves (a wave walks its run three steps at a time) measured level with eight and sixteen.
+template <int TM16, int TN16, int W>
+__global__ __launch_bounds__(64 * W) void w8a8_kslice_kernel(const W8A8Args a) {
+    constexpr int NF = TM16 + TN16;          // fragments of a k-step: A row tiles, then B column tiles
+    constexpr int TILE4 = TM16 * TN16 * 64;  // the tile as int4 positions: [MFMA tile][lane]
+    constexpr int D = 3;                     // k-steps requested at once
+    constexpr int NP = (TILE4 + 64 * W - 1) / (64 * W);  // positions a thread finishes
+    extern __shared__ __attribute__((aligned(16))) int4_t lds_ks[];  // [W waves][NF fragments][64 slots]; afterwards the sums' [W][TILE4]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int4_t(*lds_t)[64] = reinterpret_cast<int4_t(*)[64]>(lds_ks + (size_t)wave * NF * 64);
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int lrow = lane >> 2, lchunk = lane & 3;
+    const int wslot = lrow * 4 + (lchunk ^ ((lrow >> 2) & 3));
+    const int rslot = r16 * 4 + (kq ^ ((r16 >> 2) & 3));
+    const int batch = blockIdx.z;
+    const int8_t *A = a.A + (size_t)batch * a.strideA;
+    const int8_t *B = a.B + (size_t)batch * a.strideB;
+    const size_t c_off = (size_t)batch * a.strideC;
+    void *Cb = a.out_kind == TCE_OUT_INT8 ? static_cast<void *>(static_cast<int8_t *>(a.C) + c_off)
+                                          : static_cast<void *>(static_cast<float *>(a.C) + c_off);
+    const int m_base = blockIdx.y * (16 * TM16), n_base = blockIdx.x * (16 * TN16);
+
+    const int8_t *p[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        if (f < TM16) {
+            int m = m_base + f * 16 + lrow;
+            m = m < a.M ? m : a.M - 1;
+            p[f] = A + (size_t)m * a.lda + lchunk * 16;
+        } else {
+            int n = n_base + (f - TM16) * 16 + lrow;
+            n = n < a.N ? n : a.N - 1;
+            p[f] = B + (size_t)n * a.ldb + lchunk * 16;
+        }
+    }
+    // the additive terms of the positions this thread finishes, requested now
+    float bterm[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int pos = tid + q * 64 * W;
+        const int n = n_base + ((pos >> 6) % TN16) * 16 + (pos & 15);
+        bterm[q] = pos < TILE4 ? bias_term(a, n < a.N ? n : a.N - 1) : 0.0f;
+    }
+    int4_t acc[TM16][TN16];
+#pragma unroll
+    for (int i = 0; i < TM16; ++i)
+#pragma unroll
+        for (int j = 0; j < TN16; ++j) acc[i][j] = int4_t{0, 0, 0, 0};
+
+    auto contract = [&](const int4_t (&raw)[NF]) {
+        int4_t fr[NF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) lds_t[f][wslot] = raw[f];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) fr[f] = lds_t[f][rslot];
+#pragma unroll
+        for (int i = 0; i < TM16; ++i)
+#pragma unroll
+            for (int j = 0; j < TN16; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fr[i], fr[TM16 + j], acc[i][j], 0, 0, 0);
+    };
+
+    const int nfull = a.K >> 6;
+    const int s_begin = wave * nfull / W, s_end = (wave + 1) * nfull / W;  // this wave's k-steps (none when there are fewer steps than waves)
+    for (int s = s_begin; s < s_end; s += D) {
+        int4_t raw[D][NF];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int k0 = (s + d < s_end ? s + d : s_end - 1) * 64;  // (past the run: a clamped re-read, not contracted)
+#pragma unroll
+            for (int f = 0; f < NF; ++f) raw[d][f] = *reinterpret_cast<const int4_t *>(p[f] + k0);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // (every request of the D steps is out before the first fragment goes through LDS: the scheduler otherwise sinks the loads to their uses)
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (s + d < s_end) contract(raw[d]);
+    }
+    if ((nfull << 6) < a.K && wave == W - 1) {  // K % 64 in {16, 32, 48}: chunks past the end contribute zeros (K % 16 == 0 is guaranteed)
+        const bool live = (nfull << 6) + lchunk * 16 < a.K;
+        int4_t raw[NF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            raw[f] = *reinterpret_cast<const int4_t *>(p[f] + (live ? (nfull << 6) : 0));  // dead chunks re-read a valid address and are zeroed
+            if (!live) raw[f] = int4_t{0, 0, 0, 0};
+        }
+        contract(raw);
+    }
+
+    __syncthreads();  // every wave is done with its transposition slots
+#pragma unroll
+    for (int i = 0; i < TM16; ++i)
+#pragma unroll
+        for (int j = 0; j < TN16; ++j) lds_ks[(size_t)wave * TILE4 + (i * TN16 + j) * 64 + lane] = acc[i][j];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int pos = tid + q * 64 * W;
+        if (pos >= TILE4) break;
+        int4_t sum = lds_ks[pos];
+#pragma unroll
+        for (int w = 1; w < W; ++w) {
+            const int4_t o = lds_ks[(size_t)w * TILE4 + pos];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sum[r] += o[r];
+        }
+        // position = [MFMA tile i * TN16 + j][lane]: D[row = 4 * (lane >> 4) + r][col = lane & 15]
+        const int t = pos >> 6, l = pos & 63;
+        const int n = n_base + (t % TN16) * 16 + (l & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m_base + (t / TN16) * 16 + (l >> 4) * 4 + r;
+            if (m < a.M && n < a.N) epilogue_store(a, Cb, m, n, sum[r], bterm[q]);
+        }
+    }
+}
+
 // The same 64 x 64 tile for launches whose k chain is long and whose tiles are few (OPT-125M's 512 x 768 x 3072 is 96 tiles of 48 k-steps): the kernel above keeps ONE
 // k-step of loads in flight per wave, and a step is 4 MFMAs -- 64 cycles of work against a memory round trip of ~1500 -- so the chain runs at memory LATENCY
 // (0.3 us per step).  Here a quartet stages its panels cooperatively (a k-step is 64 + 64 rows of 64 bytes = ONE 16-byte piece of A and one of B per thread, half
@@ -685,6 +807,8 @@ thread_local int g_w8a8_deep = 0;  // the 64 x 64 tile with 8 k-steps in flight:
 thread_local int g_w8a8_big = 0;  // the 128-row tiles: 0 the rule, 1 / 2 forced with 128 / 64 columns (one quartet), 3 / 4 the same with two quartets, 9 off (A/B)
 thread_local int g_w8a8_rows32 = 0;  // the 32 x 64 tiles: 0 the rule, 1 forced wherever the 64 x 64 kernel would run, 2 off (A/B)
 void set_w8a8_rows32(int r) { g_w8a8_rows32 = (r >= 0 && r <= 2) ? r : 0; }
+thread_local int g_w8a8_kslice = 0;  // the whole tile in every wave (w8a8_kslice_kernel): 0 the rule, 1 off, else forced: 304 / 404 / 904 = the 32 x 48 / 32 x 64 / 64 x 64 tile
+void set_w8a8_kslice(int c) { g_w8a8_kslice = (c == 1 || c == 304 || c == 404 || c == 904) ? c : 0; }
 void set_w8a8_big(int b) { g_w8a8_big = b; }
 void set_w8a8_deep(int d) { g_w8a8_deep = d; }
 
@@ -784,6 +908,31 @@ int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err,
                 xs = g_w8a8_xs;
             }
         }
+        // round 6: the whole tile in every wave, the k-steps dealt to the waves (w8a8_kslice_kernel), four waves per workgroup.  Chains of >= 12 k-steps; the smallest of
+        // 32 x 48 / 32 x 64 / 64 x 64 whose workgroups are at most one per CU (what bounds these launches is what ONE CU pulls through its L1: (rows + columns) x K per
+        // workgroup), or 32 x 48 at two per CU.  MEASURED (profiles/r6/w8a8_kslice_ab.jsonl, weights rotating through HBM, 28 launches from 16 x 768 x 768 to
+        // 512 x 2048 x 8192 against every form): 512 x 768 x 3072 10.24 -> 7.40 us, 512 x 768 x 768 5.07 -> 4.26, 108 x 768 x 3072 13.66 -> 6.70, 16 x 768 x 3072 10.90 -> 6.44,
+        // 16 x 4096 x 16384 41.4 -> 27.6, 512 x 1024 x 4096 14.69 -> 9.80 (32 x 64), 512 x 2048 x 8192 30.5 -> 24.1 (64 x 64); never behind the other kernels where the rule
+        // takes it, 2 % behind the best form over the set (eight and sixteen waves per workgroup: within 5 % of four everywhere, not kept).
+        int kslice = g_w8a8_kslice > 1 ? g_w8a8_kslice : 0;
+        if (g_w8a8_kslice == 0 && d.K / 64 >= 12 && g_w8a8_ks == 0 && g_w8a8_deep == 0 && g_w8a8_xs == 0 && g_w8a8_rows32 == 0) {  // (a forced form of another family: that family)
+            const long r32 = (d.M + 31) / 32, w48 = r32 * ((d.N + 47) / 48) * d.batch, w64 = r32 * ((d.N + 63) / 64) * d.batch;
+            if (w48 <= 256 || (w48 >= 448 && w48 <= 512)) kslice = 304;
+            else if (w64 <= 256) kslice = 404;
+            else if (tiles <= 256) kslice = 904;
+        }
+        if (kslice) {
+            const int tm16 = kslice >= 500 ? 4 : 2, tn16 = (kslice % 500) / 100, w = kslice % 100;
+            const dim3 gk((d.N + 16 * tn16 - 1) / (16 * tn16), (d.M + 16 * tm16 - 1) / (16 * tm16), d.batch);
+            const size_t slots = (size_t)w * (tm16 + tn16) * 64 * 16, sums = (size_t)w * tm16 * tn16 * 64 * 16;
+            const size_t ldk = slots > sums ? slots : sums;  // (<= 64 KiB for every form kept)
+            switch (kslice) {
+                case 304: hipLaunchKernelGGL((w8a8_kslice_kernel<2, 3, 4>), gk, dim3(64 * w), ldk, stream, a); break;
+                case 404: hipLaunchKernelGGL((w8a8_kslice_kernel<2, 4, 4>), gk, dim3(64 * w), ldk, stream, a); break;
+                case 904: hipLaunchKernelGGL((w8a8_kslice_kernel<4, 4, 4>), gk, dim3(64 * w), ldk, stream, a); break;
+                default: return TCE_ERR_BAD_ARG;
+            }
+        } else
         if (xs > 1) {
             a.xs = xs;
             a.xcnt = static_cast<unsigned *>(scratch);
