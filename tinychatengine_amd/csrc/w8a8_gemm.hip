@@ -47,20 +47,27 @@ __device__ __forceinline__ float bias_term(const W8A8Args &a, int n) {
     return 0.0f;
 }
 
+// the int8 output of one accumulator (`u` = bias_term of its column)
+__device__ __forceinline__ int8_t epilogue_i8(const W8A8Args &a, int acc, float u) {
+    const float f = (float)acc;  // v_cvt_f32_i32: round-to-nearest-even, like the host cast
+    float v = __fmul_rn(f, a.alpha);
+    if (a.bias_kind == TCE_BIAS_INT8) v = __fadd_rn(v, u);
+    float r = roundf(v);  // half away from zero (std::round)
+    // the reference narrows to int32 first and clamps the integer (matmul_ref_int8.cc:32-34); clamping the rounded float and
+    // narrowing afterwards gives the same int8 for every |v| < 2^31 -- beyond that the reference's float -> int32 cast is UB
+    r = fmaxf(r, (float)a.q_min);
+    r = fminf(r, (float)a.q_max);
+    return (int8_t)(int)r;
+}
+
 // `u` = bias_term(a, n), loaded by the caller once per column (the MFMA kernel's 16 outputs per lane share two columns:
 // a bias load per element put 16 dependent memory round trips, ~10 us, behind a ~1 us contraction).
 __device__ __forceinline__ void epilogue_store(const W8A8Args &a, void *Cb, int m, int n, int acc, float u) {
-    const float f = (float)acc;  // v_cvt_f32_i32: round-to-nearest-even, like the host cast
-    float v = __fmul_rn(f, a.alpha);
     if (a.out_kind == TCE_OUT_INT8) {
-        if (a.bias_kind == TCE_BIAS_INT8) v = __fadd_rn(v, u);
-        float r = roundf(v);  // half away from zero (std::round)
-        // the reference narrows to int32 first and clamps the integer (matmul_ref_int8.cc:32-34); clamping the rounded float and
-        // narrowing afterwards gives the same int8 for every |v| < 2^31 -- beyond that the reference's float -> int32 cast is UB
-        r = fmaxf(r, (float)a.q_min);
-        r = fminf(r, (float)a.q_max);
-        static_cast<int8_t *>(Cb)[(size_t)m * a.ldc + n] = (int8_t)(int)r;
+        static_cast<int8_t *>(Cb)[(size_t)m * a.ldc + n] = epilogue_i8(a, acc, u);
     } else {
+        const float f = (float)acc;
+        float v = __fmul_rn(f, a.alpha);
         if (a.bias_kind == TCE_BIAS_FP32) v = __fadd_rn(v, u);
         float *dst = static_cast<float *>(Cb) + (size_t)m * a.ldc + n;
         if (a.accumulate) v = __fadd_rn(*dst, v);  // add(a, b, c): c = a + b, one rounding (Int8OPTDecoderLayer.cc:14-22)
@@ -258,6 +265,28 @@ __global__ __launch_bounds__(256 * KS) void w8a8_mfma_kernel(const W8A8Args a) {
         }
     }
 
+    // int8 outputs of a full-width tile leave through LDS as 16-byte row pieces (round 6): the accumulator layout gives a lane ONE column of four rows -- sixteen byte
+    // stores per lane, 16 bytes contiguous per row and instruction; staged, a row's 64 bytes leave as four lanes' dwordx4 (512 x 3072 x 768 writes 1.5 MB that way)
+    if constexpr (!XS) {
+        const bool packed_ok = a.out_kind == TCE_OUT_INT8 && (a.ldc & 15) == 0 && (reinterpret_cast<uintptr_t>(Cb) & 15) == 0 && (int)(blockIdx.x * 64 + 64) <= a.N;  // workgroup-uniform
+        if (packed_ok) {
+            __syncthreads();  // (every wave of the quartet is done with its transposition slots; quartets 1.. have left)
+            int8_t *tile = reinterpret_cast<int8_t *>(lds_dyn);  // [32 * MT][64]
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        tile[(wm * (16 * MT) + i * 16 + kq * 4 + r) * 64 + wn * 32 + j * 16 + r16] = epilogue_i8(a, acc[i][j][r], bterm[j]);
+            __syncthreads();
+            const int row = tid >> 2, piece = tid & 3;
+            const int m = blockIdx.y * (32 * MT) + row;
+            if (row < 32 * MT && m < a.M)
+                *reinterpret_cast<int4_t *>(static_cast<int8_t *>(Cb) + (size_t)m * a.ldc + blockIdx.x * 64 + piece * 16) = *reinterpret_cast<const int4_t *>(tile + row * 64 + piece * 16);
+            return;
+        }
+    }
     // D[row = 4*(lane>>4) + r][col = lane & 15]
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -372,24 +401,53 @@ __global__ __launch_bounds__(64 * W) void w8a8_kslice_kernel(const W8A8Args a) {
 #pragma unroll
         for (int j = 0; j < TN16; ++j) lds_ks[(size_t)wave * TILE4 + (i * TN16 + j) * 64 + lane] = acc[i][j];
     __syncthreads();
+    int4_t sum[NP];
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
         const int pos = tid + q * 64 * W;
+        sum[q] = int4_t{0, 0, 0, 0};
         if (pos >= TILE4) break;
-        int4_t sum = lds_ks[pos];
+        sum[q] = lds_ks[pos];
 #pragma unroll
         for (int w = 1; w < W; ++w) {
             const int4_t o = lds_ks[(size_t)w * TILE4 + pos];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sum[r] += o[r];
+            for (int r = 0; r < 4; ++r) sum[q][r] += o[r];
         }
-        // position = [MFMA tile i * TN16 + j][lane]: D[row = 4 * (lane >> 4) + r][col = lane & 15]
+    }
+    // position = [MFMA tile i * TN16 + j][lane]: D[row = 4 * (lane >> 4) + r][col = lane & 15]
+    // int8 outputs of a full-width tile leave through LDS as 16-byte row pieces (as in w8a8_mfma_kernel)
+    constexpr int TNB = 16 * TN16;
+    const bool packed_ok = a.out_kind == TCE_OUT_INT8 && (a.ldc & 15) == 0 && (reinterpret_cast<uintptr_t>(Cb) & 15) == 0 && n_base + TNB <= a.N && m_base + 16 < a.M;  // workgroup-uniform (a tile of at most 16 live rows: the two extra barriers cost more than the stores save -- 16 x 768 x 3072 6.47 -> 6.65 us)
+    if (packed_ok) {
+        __syncthreads();  // every thread has taken its sums
+        int8_t *tile = reinterpret_cast<int8_t *>(lds_ks);  // [16 TM16][TNB]
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int pos = tid + q * 64 * W;
+            if (pos >= TILE4) break;
+            const int t = pos >> 6, l = pos & 63;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tile[((t / TN16) * 16 + (l >> 4) * 4 + r) * TNB + (t % TN16) * 16 + (l & 15)] = epilogue_i8(a, sum[q][r], bterm[q]);
+        }
+        __syncthreads();
+        for (int e = tid; e < 16 * TM16 * TN16; e += 64 * W) {
+            const int row = e / TN16, piece = e % TN16;
+            if (m_base + row < a.M)
+                *reinterpret_cast<int4_t *>(static_cast<int8_t *>(Cb) + (size_t)(m_base + row) * a.ldc + n_base + piece * 16) = *reinterpret_cast<const int4_t *>(tile + row * TNB + piece * 16);
+        }
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int pos = tid + q * 64 * W;
+        if (pos >= TILE4) break;
         const int t = pos >> 6, l = pos & 63;
         const int n = n_base + (t % TN16) * 16 + (l & 15);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = m_base + (t / TN16) * 16 + (l >> 4) * 4 + r;
-            if (m < a.M && n < a.N) epilogue_store(a, Cb, m, n, sum[r], bterm[q]);
+            if (m < a.M && n < a.N) epilogue_store(a, Cb, m, n, sum[q][r], bterm[q]);
         }
     }
 }
