@@ -56,6 +56,8 @@ TCE_API int tce_w4a16_set_gemv_i8(int mode, int tiles_per_wave);
  *                                       wall-clock stamps in the debug buffer (7702) / stop (7703); a stage with more than u units per workgroup ends the prefix the kernel takes (7710: 512)
  *   (6262 / 6263 of round 5 are gone: the two-quartet forms are offered for every group size again -- isa_lint.py RULE 1, profiles/r6/pk_lost_lanes_rule.md)
  *   170..179, 180..188                  W8A8: the 64 x 64 tile with 8 k-steps in flight (quartets forced / off); a tile's k-steps cut across workgroups (180 the rule, 181 off, 182.. runs)
+ *   190..192, 19000 / 19001 / 19304..   W8A8: 32 x 64 tiles (190 the rule, 191 forced, 192 off); the whole tile in every wave, the k-steps dealt to the waves (round 6: 19000 the rule,
+ *                                       19001 off, 19304 / 19404 / 19904 the 32 x 48 / 32 x 64 / 64 x 64 tile forced wherever the 64 x 64 kernel would run)
  *   2700..2899, 2950..2968, 2930 / 2931 prefill attention: block pairing, waves x row tiles; fast attention step without its combine (2931: timing only, the output is NOT written)
  *   15000 / 15001, 50000+..             plans: graph replay / eager issue of a stream-ordered plan; overlapped plans' branches and ring slots
  * Every setting computes correct results except GEMV modes 1, 3, 4, the "switched off" ablations (600+a, 2600+a, 26000+a), 83 and 2931. */
