@@ -493,7 +493,13 @@ def test_opt_decoder_layer_against_the_oracle_composition(dev, oracle, embed, he
                                                           (200, 260, 320, 77, 384, 448, 300, 2),
                                                           # two wave quartets per tile, each on half of K (176 / 177: 128 / 64 columns), odd numbers of k-steps
                                                           (129, 65, 256, 176, 0, 0, 0, 1), (300, 2100, 1024, 177, 0, 0, 0, 1), (200, 260, 320, 176, 384, 448, 300, 2),
-                                                          (512, 4096, 4096, 75, 0, 0, 0, 1), (130, 200, 576, 177, 0, 0, 0, 1)])
+                                                          (512, 4096, 4096, 75, 0, 0, 0, 1), (130, 200, 576, 177, 0, 0, 0, 1),
+                                                          # round 6, the whole tile in every wave (19304 / 19404 / 19904) and the staged int8 stores under leading dimensions, a
+                                                          # batch, `accumulate`: ldc a multiple of 16 (row pieces of 16 bytes) and not (byte stores), N ragged against the 48 / 64-wide tiles
+                                                          (200, 260, 832, 19304, 896, 960, 304, 2), (200, 260, 832, 19404, 896, 960, 300, 2), (200, 260, 832, 19904, 896, 960, 304, 3),
+                                                          (70, 192, 1024, 19304, 0, 0, 208, 1), (70, 192, 1024, 19404, 0, 0, 0, 2), (40, 64, 1024, 19000, 1040, 0, 768, 12),
+                                                          # the 64 x 64 quartet kernel's staged stores (19001: the k-slice forms off)
+                                                          (200, 260, 832, 19001, 896, 960, 304, 2), (512, 768, 768, 19001, 0, 0, 0, 1)])
 def test_w8a8_large_tiles_bit_exact(dev, oracle, M, N, K, mode, lda, ldb, ldc, batch):
     """The prefill-sized int8 kernel (w8a8_mfma_big_kernel: 128 x 128 / 128 x 64 tiles, operand panels through a three-stage LDS ring) against the oracle: the
     int8-out form with an int8 bias (clamp at 0: the ReLU linear) and the fp32-out form with an fp32 bias accumulating into C -- every element, ragged edges,
@@ -524,6 +530,7 @@ def test_w8a8_large_tiles_bit_exact(dev, oracle, M, N, K, mode, lda, ldb, ldc, b
         torch.cuda.synchronize()
     finally:
         capi.check(L.tce_w4a16_set_debug_mode(75))
+        capi.check(L.tce_w4a16_set_debug_mode(19000))
     got8, gotf = out8.cpu().numpy(), tC.cpu().numpy()
     for bi in range(batch):
         Ab, Bb = np.ascontiguousarray(A[bi, :, :K]), np.ascontiguousarray(B[bi, :, :K])
