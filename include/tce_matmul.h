@@ -47,7 +47,7 @@ extern "C" {
 
 #define TCE_API __attribute__((visibility("default")))
 
-#define TCE_VERSION 112 /* 0.1.12: tce_w4a16_forward_independent (up to TCE_MAX_INDEPENDENT decode linears with their own activations and K as one launch: the sharded block); 0.1.11: tce_w4a16_gemm_scratch_faults (a k-cut exchange that gives up stores NaN and poisons its counter: loud, sticky), TCE_PLAN_TAGGED on packed copies runs the int8-contraction token kernel (tce_plan_is_chained = 4), TCE_DESC_V2_MAX_BYTES; 0.1.10: tce_attention_decode_step_deferred_f16 + tce_w4a16_forward_deferred_attention (the attention combine in o_proj's prologue); size-prefixed descriptors (tce_w4a16_desc_v2 / tce_w8a8_desc_v2 + the *_v2 entry points; the plain ones stay), TCE_ERR_RCCL, the tuning setters act on the CALLING THREAD only; 0.1.9: tce_w4a16_check_zero_point_8_async, tce_host_alloc / tce_host_free (the adapter no longer synchronises); 0.1.8: per-family tuning setters (tce_attention_set_tuning, tce_w8a8_set_tuning); 0.1.7: decode on the pre-packed copy (int8 contraction), tce_w4a16_set_gemv_i8; 0.1.6: TCE_PLAN_TUNED; 0.1.5: tce_opt_attention_decode; 0.1.4: tce_attention_prefill_f16 (0.1.3: tce_attention_decode_step_gqa_f16, TCE_PLAN_OVERLAPPED; 0.1.2: tce_w4a16_desc.scratch; 0.1.1: .prepacked, tce_w4a16_prepack*) */
+#define TCE_VERSION 113 /* 0.1.13: tce_w8a8_describe_dispatch; 0.1.12: tce_w4a16_forward_independent (up to TCE_MAX_INDEPENDENT decode linears with their own activations and K as one launch: the sharded block); 0.1.11: tce_w4a16_gemm_scratch_faults (a k-cut exchange that gives up stores NaN and poisons its counter: loud, sticky), TCE_PLAN_TAGGED on packed copies runs the int8-contraction token kernel (tce_plan_is_chained = 4), TCE_DESC_V2_MAX_BYTES; 0.1.10: tce_attention_decode_step_deferred_f16 + tce_w4a16_forward_deferred_attention (the attention combine in o_proj's prologue); size-prefixed descriptors (tce_w4a16_desc_v2 / tce_w8a8_desc_v2 + the *_v2 entry points; the plain ones stay), TCE_ERR_RCCL, the tuning setters act on the CALLING THREAD only; 0.1.9: tce_w4a16_check_zero_point_8_async, tce_host_alloc / tce_host_free (the adapter no longer synchronises); 0.1.8: per-family tuning setters (tce_attention_set_tuning, tce_w8a8_set_tuning); 0.1.7: decode on the pre-packed copy (int8 contraction), tce_w4a16_set_gemv_i8; 0.1.6: TCE_PLAN_TUNED; 0.1.5: tce_opt_attention_decode; 0.1.4: tce_attention_prefill_f16 (0.1.3: tce_attention_decode_step_gqa_f16, TCE_PLAN_OVERLAPPED; 0.1.2: tce_w4a16_desc.scratch; 0.1.1: .prepacked, tce_w4a16_prepack*) */
 
 /* error codes (return values) */
 #define TCE_OK 0
@@ -562,6 +562,11 @@ TCE_API int tce_reset_last_error(void);
  * "gemm-dma tile=RxC quartets=Q group=G" | "gemm tile=RxC".  Launches nothing and
  * makes no HIP call (works without a GPU); a shape the chosen GEMM form cannot hold in LDS still falls back at launch time. */
 TCE_API int tce_w4a16_describe_dispatch(const tce_w4a16_desc *d, char *buf, int buf_len);
+/* (0.1.13) The same for tce_w8a8_matmul / tce_w8a8_matmul_v2 (with_scratch != 0: as if tce_w8a8_desc_v2.scratch were given): "w8a8 wave-per-column rows=M" |
+ * "w8a8 wave-per-output (a B per row of A)" | "w8a8 tile=128xC quartets=Q" | "w8a8 k-slice tile=RxC waves=W workgroups=G" (the whole tile in every wave, the k-steps
+ * dealt to the waves) | "w8a8 tile=64x64 deep-pipeline quartets=Q" | "w8a8 tile=64x64 quartets=Q [kcut=S]" | "w8a8 tile=32x64 quartets=Q" | "w8a8 generic ...".
+ * Operand pointers enter through their 16-byte alignment only (null pointers: aligned).  Launches nothing, makes no HIP call. */
+TCE_API int tce_w8a8_describe_dispatch(const tce_w8a8_desc *d, int with_scratch, char *buf, int buf_len);
 /* Tuning and diagnostics entry points (forced kernel forms for parity tests and sweeps, per-family setters, the debug buffer): include/tce_tuning.h -- exported by
  * this library, never needed by a host, not part of the operator boundary. */
 /* Algorithmic HBM bytes of one tce_w4a16_forward call: N*K/2 + 2*N*K/G + N*K/(2G) + 2*M*K + 2*M*N. */

@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(built):
     lib = built.lib()
     for s in declared:
         assert hasattr(lib, s)
-    assert lib.tce_version() == 112
+    assert lib.tce_version() == 113
     assert b"gfx950" in lib.tce_build_info()
 
 

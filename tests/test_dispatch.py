@@ -170,3 +170,44 @@ def test_independent_linears_dispatch():
                   for _ in range(rng.randint(2, 8))]
         assert capi.describe_independent([d(N, K) for N, K in shapes]) == rule(shapes), shapes
         assert capi.describe_independent([d(N, K) for N, K in shapes]) == rule(shapes)  # (the remembered answer)
+
+
+def test_w8a8_dispatch_rules():
+    """tce_w8a8_describe_dispatch (ABI 0.1.13): the form tce_w8a8_matmul would run, without a GPU -- BASELINE config 4's OPT-125M launches and the rules round 6 fitted
+    (the whole tile in every wave for chains of >= 12 k-steps: the smallest of 32 x 48 / 32 x 64 / 64 x 64 whose workgroups are at most one per CU, 32 x 48 also at two)."""
+    def d(M, N, K, batch=1, **kw):
+        return capi.W8A8Desc(M=M, N=N, K=K, batch=batch, alpha=1.0, q_min=-128, q_max=127, bias_kind=capi.TCE_BIAS_NONE, out_kind=capi.TCE_OUT_INT8, **kw)
+    f = capi.describe_w8a8_dispatch
+    assert f(d(1, 768, 768)) == "w8a8 wave-per-column rows=1" and f(d(1, 768, 3072)) == "w8a8 wave-per-column rows=1"
+    assert f(d(512, 768, 3072)) == "w8a8 k-slice tile=32x48 waves=4 workgroups=256"
+    assert f(d(512, 768, 768)) == "w8a8 k-slice tile=32x48 waves=4 workgroups=256"
+    assert f(d(108, 768, 3072)) == "w8a8 k-slice tile=32x48 waves=4 workgroups=64"
+    assert f(d(108, 768, 3072), with_scratch=True) == "w8a8 k-slice tile=32x48 waves=4 workgroups=64"  # (the cut across workgroups no longer takes it)
+    assert f(d(108, 3072, 768)) == "w8a8 k-slice tile=32x48 waves=4 workgroups=256"
+    assert f(d(1024, 768, 768)) == "w8a8 k-slice tile=32x48 waves=4 workgroups=512"   # two per CU
+    assert f(d(512, 1024, 4096)) == "w8a8 k-slice tile=32x64 waves=4 workgroups=256"
+    assert f(d(512, 2048, 8192)) == "w8a8 k-slice tile=64x64 waves=4 workgroups=256"
+    assert f(d(512, 3072, 768)) == "w8a8 tile=64x64 quartets=1"                         # 384 tiles of 64 x 64: the quartet kernel
+    assert f(d(2048, 768, 3072)) == "w8a8 tile=64x64 deep-pipeline quartets=1"
+    assert f(d(512, 4096, 4096)) == "w8a8 tile=64x64 deep-pipeline quartets=1"          # OPT-6.7B widths at 512 rows: 512 tiles x 64 k-steps (round 4's rule)
+    assert f(d(2048, 4096, 4096)) == "w8a8 tile=128x128 quartets=1" and f(d(512, 16384, 4096)) == "w8a8 tile=128x128 quartets=1"  # the 128-row tiles
+    assert f(d(512, 512, 64, batch=12)) == "w8a8 tile=64x64 quartets=1"                # the attention BMMs: one k-step
+    assert f(d(512, 64, 512, batch=12)).startswith("w8a8 tile=64x64 quartets=")        # eight k-steps: under the k-slice rule's twelve
+    assert f(d(40, 33, 50)) == "w8a8 generic (one output per thread)"                   # K % 16 != 0
+    L = capi.lib()
+    try:  # a forced form of one family switches the other families' rules off, never the other way round
+        capi.check(L.tce_w4a16_set_debug_mode(19001))
+        assert f(d(512, 768, 3072)) == "w8a8 tile=32x64 quartets=2"                    # (round 6's first step, reached only like this now)
+        capi.check(L.tce_w4a16_set_debug_mode(19904))
+        assert f(d(512, 768, 3072)) == "w8a8 k-slice tile=64x64 waves=4 workgroups=96"
+        capi.check(L.tce_w4a16_set_debug_mode(19000))
+        capi.check(L.tce_w4a16_set_debug_mode(72))
+        assert f(d(512, 768, 3072)) == "w8a8 tile=32x64 quartets=2"
+        capi.check(L.tce_w4a16_set_debug_mode(70))
+        capi.check(L.tce_w4a16_set_debug_mode(184))
+        assert f(d(108, 768, 3072), with_scratch=True) == "w8a8 tile=64x64 quartets=2 kcut=4"
+    finally:
+        for m in (19000, 70, 180, 190, 170, 75):
+            L.tce_w4a16_set_debug_mode(m)
+    with pytest.raises(capi.TceError):
+        f(d(0, 16, 64))

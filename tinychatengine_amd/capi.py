@@ -22,7 +22,7 @@ TCE_W4_SILU_MUL_PAIRS = 8
 TCE_W4_ADD_TO_C = 16
 TCE_PLAN_CHAINED = 1
 TCE_PLAN_TAGGED = 2
-TCE_ABI_VERSION = 112  # include/tce_matmul.h TCE_VERSION: the struct layouts mirrored below
+TCE_ABI_VERSION = 113  # include/tce_matmul.h TCE_VERSION: the struct layouts mirrored below
 TCE_PLAN_OVERLAPPED = 4
 TCE_PLAN_TUNED = 8
 TCE_PLAN_INDEPENDENT = 16
@@ -32,7 +32,7 @@ TCE_OUT_INT8, TCE_OUT_FP32 = 0, 1
 
 # every symbol include/tce_matmul.h declares (tests/test_boundary.py checks the .so exports exactly these)
 EXPORTS = [
-    "tce_w4a16_forward", "tce_w4a16_residual_rmsnorm_workspace_bytes", "tce_w4a16_forward_residual_rmsnorm", "tce_w4a16_prepack_bytes", "tce_w4a16_prepack", "tce_w4a16_gemm_scratch_bytes", "tce_w4a16_gemm_scratch_faults", "tce_w4a16_describe_dispatch", "tce_reset_last_error", "tce_bmm_f16t", "tce_rope_half", "tce_softmax_half", "tce_attention_decode_f16", "tce_attention_decode_workspace_bytes", "tce_attention_decode_describe", "tce_attention_decode_step_f16", "tce_attention_decode_step_gqa_f16", "tce_attention_decode_describe_gqa", "tce_attention_decode_step_pos_f16", "tce_attention_prefill_f16", "tce_attention_prefill_workspace_bytes", "tce_opt_attention_decode", "tce_prefetch", "tce_add_half", "tce_silu_mul_half", "tce_rmsnorm_half", "tce_w4a16_forward_group_rmsnorm", "tce_w4a16_forward_group", "tce_w4a16_forward_independent", "tce_w4a16_describe_independent", "tce_w4a16_forward_independent_gather", "tce_w4a16_check_zero_point_8", "tce_w4a16_awq_fp16acc", "tce_w4a16_awq_workspace_bytes",
+    "tce_w4a16_forward", "tce_w4a16_residual_rmsnorm_workspace_bytes", "tce_w4a16_forward_residual_rmsnorm", "tce_w4a16_prepack_bytes", "tce_w4a16_prepack", "tce_w4a16_gemm_scratch_bytes", "tce_w4a16_gemm_scratch_faults", "tce_w4a16_describe_dispatch", "tce_w8a8_describe_dispatch", "tce_reset_last_error", "tce_bmm_f16t", "tce_rope_half", "tce_softmax_half", "tce_attention_decode_f16", "tce_attention_decode_workspace_bytes", "tce_attention_decode_describe", "tce_attention_decode_step_f16", "tce_attention_decode_step_gqa_f16", "tce_attention_decode_describe_gqa", "tce_attention_decode_step_pos_f16", "tce_attention_prefill_f16", "tce_attention_prefill_workspace_bytes", "tce_opt_attention_decode", "tce_prefetch", "tce_add_half", "tce_silu_mul_half", "tce_rmsnorm_half", "tce_w4a16_forward_group_rmsnorm", "tce_w4a16_forward_group", "tce_w4a16_forward_independent", "tce_w4a16_describe_independent", "tce_w4a16_forward_independent_gather", "tce_w4a16_check_zero_point_8", "tce_w4a16_awq_fp16acc", "tce_w4a16_awq_workspace_bytes",
     "tce_w4a16_gemm_awq", "tce_w4a16_shard", "tce_comm_create", "tce_comm_export", "tce_comm_connect", "tce_comm_connect_local", "tce_allgather_f16", "tce_comm_rccl_unique_id", "tce_comm_rccl_init", "tce_allgather_rows_workspace_bytes", "tce_allgather_rows_f16", "tce_comm_status", "tce_comm_set_timeout_ms", "tce_comm_reset", "tce_comm_device", "tce_comm_destroy", "tce_w8a8_matmul", "tce_opt_softmax_q", "tce_opt_kv_append", "tce_layernorm_q", "tce_layernorm_q_w8a8_group", "tce_plan_create", "tce_plan_create_ex", "tce_plan_is_chained", "tce_plan_geometry", "tce_plan_status", "tce_plan_launch_geometry", "tce_plan_launch", "tce_plan_n_launches",
     "tce_w4a16_forward_v2", "tce_w8a8_matmul_v2", "tce_w8a8_scratch_bytes", "tce_attention_decode_step_deferred_f16", "tce_w4a16_forward_deferred_attention", "tce_plan_destroy", "tce_version", "tce_last_error", "tce_build_info", "tce_w4a16_set_gemv_config", "tce_w4a16_set_gemv_i8",
     "tce_w4a16_set_gemm_config", "tce_w4a16_algorithmic_bytes", "tce_w4a16_gemv_variant", "tce_w4a16_gemm_variant",
@@ -268,6 +268,15 @@ def w4a16_forward_independent(descs: list[W4A16Desc], stream: int | None) -> int
     n = C.c_int(0)
     check(lib().tce_w4a16_forward_independent(arr, len(descs), C.byref(n), C.c_void_p(stream or 0)))
     return n.value
+
+
+def describe_w8a8_dispatch(desc: W8A8Desc, with_scratch: bool = False) -> str:
+    """tce_w8a8_describe_dispatch: the kernel form tce_w8a8_matmul would run for this descriptor (no GPU needed)."""
+    buf = C.create_string_buffer(128)
+    L = lib()
+    L.tce_w8a8_describe_dispatch.argtypes = [C.POINTER(W8A8Desc), C.c_int, C.c_char_p, C.c_int]
+    check(L.tce_w8a8_describe_dispatch(C.byref(desc), 1 if with_scratch else 0, buf, 128))
+    return buf.value.decode()
 
 
 def describe_independent(descs: list[W4A16Desc]) -> str:

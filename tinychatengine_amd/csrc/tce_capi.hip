@@ -15,7 +15,7 @@
 #include "w4a16_kernels.hpp"
 
 namespace tce {
-int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err, void *scratch = nullptr);
+int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err, void *scratch = nullptr, char *describe = nullptr, int describe_len = 0);
 size_t w8a8_scratch_bytes();
 void set_w8a8_xsplit(int xs);
 }
@@ -973,6 +973,14 @@ int tce_w8a8_matmul_v2(const tce_w8a8_desc_v2 *d, void *stream) {
     return rc != TCE_OK ? rc : w8a8_matmul_impl(&local.desc, local.scratch, stream);
 }
 size_t tce_w8a8_scratch_bytes(void) { return tce::w8a8_scratch_bytes(); }
+int tce_w8a8_describe_dispatch(const tce_w8a8_desc *d, int with_scratch, char *buf, int buf_len) {
+    if (!d || !buf || buf_len <= 0) return fail(TCE_ERR_BAD_ARG, "tce_w8a8_describe_dispatch: null descriptor or no buffer");
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0) return fail(TCE_ERR_BAD_ARG, "tce_w8a8_describe_dispatch: M, N, K, batch must be positive");
+    alignas(256) static unsigned char stand_in_for_a_scratch_area[256];  // (only its presence and alignment enter the rules; never touched)
+    hipError_t he = hipSuccess;
+    const int rc = tce::launch_w8a8(*d, nullptr, &he, with_scratch ? stand_in_for_a_scratch_area : nullptr, buf, buf_len);
+    return rc == TCE_OK ? rc : fail(rc, "tce_w8a8_describe_dispatch: the descriptor would be refused (leading dimensions / kind)");
+}
 
 // ---- multi-GPU (csrc/comm.hip): tce_comm is tce::Comm ----
 int tce_w4a16_shard(const tce_w4a16_desc *full, int rank, int world, tce_w4a16_desc *shard) {

@@ -872,7 +872,14 @@ void set_w8a8_deep(int d) { g_w8a8_deep = d; }
 
 size_t w8a8_scratch_bytes() { return 4096 + (size_t)1024 * 16384; }  // [1024 tile counters][1024 partial tiles of 64 x 64 int32]
 
-int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err, void *scratch) {
+// describe != nullptr: nothing is launched and no HIP call is made -- the form the rules below pick is written there as text (tce_w8a8_describe_dispatch; `scratch` then only
+// says whether the caller would hand one over).  ONE decision path with the launch: every branch below names its form through TCE_W8A8_FORM in front of its launch.
+#define TCE_W8A8_FORM(...)                                        \
+    if (describe) {                                               \
+        std::snprintf(describe, (size_t)describe_len, __VA_ARGS__); \
+        return TCE_OK;                                            \
+    }
+int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err, void *scratch, char *describe, int describe_len) {
     W8A8Args a{};
     a.A = static_cast<const int8_t *>(d.A);
     a.B = static_cast<const int8_t *>(d.B);
@@ -909,9 +916,11 @@ int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err,
     // 1 x 768 x 3072: 3.4 against 9.4 -- scratch measurements of round 3); from 3 rows on only up to 4096 columns (round 4, scripts/probes/w8a8_rowdot_ab.py: a wave per
     // column walks all M rows -- 8 x 16384 x 4096: 30.5 us against the MFMA tiles' 15.6; 5 x 8192 x 2048: 10.4 against 9.2)
     if (rowdot_ok && !d.b_per_row && d.M <= kRowdotMaxM && (d.M <= 2 || (d.N <= 4096 && (d.M <= 4 || d.K >= 2048))) && d.K >= 64 && (size_t)d.M * d.K <= 64 * 1024) {
+        TCE_W8A8_FORM("w8a8 wave-per-column rows=%d", d.M)
         hipLaunchKernelGGL(w8a8_rowdot_kernel<0>, dim3((d.N + 3) / 4, 1, d.batch), dim3(256), (size_t)d.M * d.K, stream, a);
     } else if (rowdot_ok && d.b_per_row && d.batch == 1 && d.K >= 256) {
         const long long outs = (long long)d.M * d.N;
+        TCE_W8A8_FORM("w8a8 wave-per-output (a B per row of A)")
         hipLaunchKernelGGL(w8a8_rowdot_kernel<1>, dim3((unsigned)((outs + 3) / 4), 1, d.batch), dim3(256), 0, stream, a);
     } else if (!d.b_per_row && aligned && d.K % 64 == 0 && d.K >= 256 && g_w8a8_big != 9 &&
                ((g_w8a8_big >= 1 && g_w8a8_big <= 4) || (long)((d.M + 127) / 128) * ((d.N + 63) / 64) * d.batch >= 512 ||
@@ -933,6 +942,7 @@ int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err,
             if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(kfn, grid, dim3(threads), lds, stream, a);
         };
+        TCE_W8A8_FORM("w8a8 tile=128x%d quartets=%d", wide ? 128 : 64, split ? 2 : 1)
         if (wide && split) launch(w8a8_mfma_big_kernel<128, 2>, 512);
         else if (wide) launch(w8a8_mfma_big_kernel<128, 1>, 256);
         else if (split) launch(w8a8_mfma_big_kernel<64, 2>, 512);
@@ -984,6 +994,8 @@ int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err,
             const dim3 gk((d.N + 16 * tn16 - 1) / (16 * tn16), (d.M + 16 * tm16 - 1) / (16 * tm16), d.batch);
             const size_t slots = (size_t)w * (tm16 + tn16) * 64 * 16, sums = (size_t)w * tm16 * tn16 * 64 * 16;
             const size_t ldk = slots > sums ? slots : sums;  // (<= 64 KiB for every form kept)
+            if (kslice != 304 && kslice != 404 && kslice != 904) return TCE_ERR_BAD_ARG;
+            TCE_W8A8_FORM("w8a8 k-slice tile=%dx%d waves=%d workgroups=%ld", 16 * tm16, 16 * tn16, w, (long)gk.x * gk.y * gk.z)
             switch (kslice) {
                 case 304: hipLaunchKernelGGL((w8a8_kslice_kernel<2, 3, 4>), gk, dim3(64 * w), ldk, stream, a); break;
                 case 404: hipLaunchKernelGGL((w8a8_kslice_kernel<2, 4, 4>), gk, dim3(64 * w), ldk, stream, a); break;
@@ -996,12 +1008,14 @@ int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err,
             a.xcnt = static_cast<unsigned *>(scratch);
             a.xpart = reinterpret_cast<int4_t *>(static_cast<unsigned char *>(scratch) + 4096);
             const dim3 gx(grid.x, grid.y, xs);
+            TCE_W8A8_FORM("w8a8 tile=64x64 quartets=%d kcut=%d", d.K / 64 / xs >= 4 ? 2 : 1, xs)
             if (d.K / 64 / xs >= 4) hipLaunchKernelGGL((w8a8_mfma_kernel<2, true>), gx, dim3(512), (size_t)2 * 4 * 4 * 64 * 16, stream, a);
             else hipLaunchKernelGGL((w8a8_mfma_kernel<1, true>), gx, dim3(256), (size_t)4 * 4 * 64 * 16, stream, a);
         } else
         if (deep) {
             const int dks = g_w8a8_deep == 1 || g_w8a8_deep == 2 || g_w8a8_deep == 4 ? g_w8a8_deep : (tiles <= 256 || (tiles <= 512 && d.K / 64 >= 128) ? 2 : 1);
             const size_t dl = (size_t)dks * 2 * 512 * 16;  // (>= the reduction's (dks - 1) * 16 KiB)
+            TCE_W8A8_FORM("w8a8 tile=64x64 deep-pipeline quartets=%d", dks)
             if (dks == 4) hipLaunchKernelGGL((w8a8_mfma_deep_kernel<4, 8>), grid, dim3(1024), dl, stream, a);
             else if (dks == 2) hipLaunchKernelGGL((w8a8_mfma_deep_kernel<2, 8>), grid, dim3(512), dl, stream, a);
             else hipLaunchKernelGGL((w8a8_mfma_deep_kernel<1, 8>), grid, dim3(256), dl, stream, a);
@@ -1016,16 +1030,20 @@ int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err,
             int ks32 = g_w8a8_ks == 3 ? 0 : g_w8a8_ks;
             if (ks32 == 0) ks32 = (tiles32 <= 256 && d.K / 64 >= 4) ? 2 : 1;
             const size_t lds32 = (size_t)ks32 * 4 * 4 * 64 * 16;
+            TCE_W8A8_FORM("w8a8 tile=32x64 quartets=%d", ks32)
             if (ks32 == 4) hipLaunchKernelGGL((w8a8_mfma_kernel<4, false, 1>), g32, dim3(1024), lds32, stream, a);
             else if (ks32 == 2) hipLaunchKernelGGL((w8a8_mfma_kernel<2, false, 1>), g32, dim3(512), lds32, stream, a);
             else hipLaunchKernelGGL((w8a8_mfma_kernel<1, false, 1>), g32, dim3(256), lds32, stream, a);
-        } else
-        if (ks == 4) hipLaunchKernelGGL(w8a8_mfma_kernel<4>, grid, dim3(1024), lds, stream, a);
-        else if (ks == 2) hipLaunchKernelGGL(w8a8_mfma_kernel<2>, grid, dim3(512), lds, stream, a);
-        else hipLaunchKernelGGL(w8a8_mfma_kernel<1>, grid, dim3(256), lds, stream, a);
+        } else {
+            TCE_W8A8_FORM("w8a8 tile=64x64 quartets=%d", ks)
+            if (ks == 4) hipLaunchKernelGGL(w8a8_mfma_kernel<4>, grid, dim3(1024), lds, stream, a);
+            else if (ks == 2) hipLaunchKernelGGL(w8a8_mfma_kernel<2>, grid, dim3(512), lds, stream, a);
+            else hipLaunchKernelGGL(w8a8_mfma_kernel<1>, grid, dim3(256), lds, stream, a);
+        }
     } else {
         const long long total = (long long)d.M * d.N;
         dim3 grid((unsigned)((total + 255) / 256), 1, d.batch);
+        TCE_W8A8_FORM("w8a8 generic (one output per thread)")
         hipLaunchKernelGGL(w8a8_generic_kernel, grid, dim3(256), 0, stream, a);
     }
     hipError_t e = hipGetLastError();
@@ -1035,5 +1053,6 @@ int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err,
     }
     return TCE_OK;
 }
+#undef TCE_W8A8_FORM
 
 }  // namespace tce
