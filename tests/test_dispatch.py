@@ -189,7 +189,8 @@ def test_w8a8_dispatch_rules():
     assert f(d(512, 2048, 8192)) == "w8a8 k-slice tile=64x64 waves=4 workgroups=256"
     assert f(d(512, 3072, 768)) == "w8a8 tile=64x64 quartets=1"                         # 384 tiles of 64 x 64: the quartet kernel
     assert f(d(2048, 768, 3072)) == "w8a8 tile=64x64 deep-pipeline quartets=1"
-    assert f(d(512, 4096, 4096)) == "w8a8 tile=64x64 deep-pipeline quartets=1"          # OPT-6.7B widths at 512 rows: 512 tiles x 64 k-steps (round 4's rule)
+    assert f(d(512, 4096, 4096)) == "w8a8 k-slice tile=64x64 waves=4 workgroups=512"    # OPT-6.7B widths at 512 rows: 512 tiles x 64 k-steps (until round 6 the deep-pipeline tile)
+    assert f(d(512, 4096, 2048)) == "w8a8 tile=128x64 quartets=2" and f(d(1024, 4096, 8192)) == "w8a8 tile=128x128 quartets=2"  # (the 128-row tiles keep what round 3 / 4 gave them)
     assert f(d(2048, 4096, 4096)) == "w8a8 tile=128x128 quartets=1" and f(d(512, 16384, 4096)) == "w8a8 tile=128x128 quartets=1"  # the 128-row tiles
     assert f(d(512, 512, 64, batch=12)) == "w8a8 tile=64x64 quartets=1"                # the attention BMMs: one k-step
     assert f(d(512, 64, 512, batch=12)).startswith("w8a8 tile=64x64 quartets=")        # eight k-steps: under the k-slice rule's twelve

@@ -988,6 +988,7 @@ int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err,
             if (w48 <= 256 || (w48 >= 448 && w48 <= 512)) kslice = 304;
             else if (w64 <= 256) kslice = 404;
             else if (tiles <= 256) kslice = 904;
+            else if (tiles <= 512 && d.K / 64 >= 64) kslice = 904;  // (two per CU on long chains, against the deep-pipeline tile: 512 x 4096 x 4096 29.5 -> 28.2 us, x 16384 79.5 -> 74.7)
         }
         if (kslice) {
             const int tm16 = kslice >= 500 ? 4 : 2, tn16 = (kslice % 500) / 100, w = kslice % 100;
