@@ -265,7 +265,7 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
 
     // ---- DMA sources of a half-stage: instruction ii of this wave fills 8 rows; the lane fetches the piece that belongs at its position ----
     // (uniform 64-bit base + 32-bit lane offset: the address arithmetic of a refill is scalar; launch_w4a16_gemm_pk refuses M * lda * 2 >= 4 GiB)
-    constexpr bool BUFDMA = kMT == 16 || WIDE;  // the activation DMAs through a buffer descriptor (one lane offset, everything else scalar)
+    constexpr bool BUFDMA = true;  // the activation DMAs through a buffer descriptor (one lane offset, everything else scalar) -- the 256-row and wide forms since round 5, every form since round 6 (the narrow forms' per-piece 64-bit address adds were 12 of a k-block's 151 vector instructions: 512 x 4096 x 4096 26.2 -> 26.1 us, 384 rows 25.05 -> 24.56, x 11008 54.0 -> 53.35; two builds alternating)
     unsigned a_voff[BUFDMA ? 1 : DPW];
 #pragma unroll
     for (int ii = 0; ii < (BUFDMA ? 0 : DPW); ++ii) {
