@@ -559,6 +559,23 @@ __global__ __launch_bounds__(256 * KS) void w8a8_mfma_deep_kernel(const W8A8Args
         const int nn = n_base + j * 16 + r16;
         bterm[j] = bias_term(a, nn < a.N ? nn : a.N - 1);
     }
+    // int8 outputs of a full-width tile leave through LDS as 16-byte row pieces (as in w8a8_mfma_kernel)
+    const bool packed_ok = a.out_kind == TCE_OUT_INT8 && (a.ldc & 15) == 0 && (reinterpret_cast<uintptr_t>(Cb) & 15) == 0 && n_tile + 64 <= a.N;  // workgroup-uniform
+    if (packed_ok) {
+        lds_barrier();  // (every wave of the quartet is done with the stages / the exchange; quartets 1.. have left)
+        int8_t *tile = reinterpret_cast<int8_t *>(lds_deep);  // [64][64]
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tile[(wm * 32 + i * 16 + kq * 4 + r) * 64 + wn * 32 + j * 16 + r16] = epilogue_i8(a, acc[i][j][r], bterm[j]);
+        lds_barrier();
+        const int row = tid >> 2, piece = tid & 3;
+        if (m_tile + row < a.M)
+            *reinterpret_cast<int4_t *>(static_cast<int8_t *>(Cb) + (size_t)(m_tile + row) * a.ldc + n_tile + piece * 16) = *reinterpret_cast<const int4_t *>(tile + row * 64 + piece * 16);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -699,6 +716,27 @@ __global__ __launch_bounds__(256 * KS) void w8a8_mfma_big_kernel(const W8A8Args 
     for (int j = 0; j < NJ; ++j) {
         const int n = n_base + j * 16 + r16;
         bterm[j] = bias_term(a, n < a.N ? n : a.N - 1);
+    }
+    // int8 outputs of a full-width tile leave through LDS as 16-byte row pieces (as in w8a8_mfma_kernel: the accumulator layout gives a lane one column of four rows)
+    const bool packed_ok = a.out_kind == TCE_OUT_INT8 && (a.ldc & 15) == 0 && (reinterpret_cast<uintptr_t>(Cb) & 15) == 0 && n_tile + TN <= a.N;  // workgroup-uniform
+    if (packed_ok) {
+        lds_barrier();  // (every wave of the quartet is done with the ring / the exchange; quartets 1.. have left)
+        int8_t *tile = reinterpret_cast<int8_t *>(lds_all);  // [TM][TN]
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    tile[(wm * 64 + i * 16 + kq * 4 + r) * TN + wn * (TN / 2) + j * 16 + r16] = epilogue_i8(a, acc[i][j][r], bterm[j]);
+        lds_barrier();
+        constexpr int PPR = TN / 16;  // 16-byte pieces per row
+        for (int e = tid; e < TM * PPR; e += 256) {
+            const int row = e / PPR, piece = e % PPR;
+            if (m_tile + row < a.M)
+                *reinterpret_cast<int4_t *>(static_cast<int8_t *>(Cb) + (size_t)(m_tile + row) * a.ldc + n_tile + piece * 16) = *reinterpret_cast<const int4_t *>(tile + row * TN + piece * 16);
+        }
+        return;
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
