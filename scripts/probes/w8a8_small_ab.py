@@ -20,11 +20,16 @@ for M, N, K in (shapes or default):
         A = ri(M, K)
         sets = []
         for _ in range(nsets):
-            W, b, o = ri(N, K), ri(N), torch.empty(M, N, dtype=torch.int8, device=dev)
-            d = capi.W8A8Desc(M=M, N=N, K=K, batch=1, A=A.data_ptr(), B=W.data_ptr(), bias=b.data_ptr(), C=o.data_ptr(), alpha=0.0005, beta=0.02, q_min=-128, q_max=127,
-                              bias_kind=capi.TCE_BIAS_INT8, out_kind=capi.TCE_OUT_INT8)
+            if os.environ.get("W8A8_OUT", "int8") == "fp32":  # the fp32-output form with an fp32 bias accumulating into C (out_proj / fc2 of the OPT layers)
+                W, b, o = ri(N, K), torch.randn(N, device=dev, generator=g), torch.zeros(M, N, dtype=torch.float32, device=dev)
+                d = capi.W8A8Desc(M=M, N=N, K=K, batch=1, A=A.data_ptr(), B=W.data_ptr(), bias=b.data_ptr(), C=o.data_ptr(), alpha=0.0005, q_min=-128, q_max=127,
+                                  bias_kind=capi.TCE_BIAS_FP32, out_kind=capi.TCE_OUT_FP32, accumulate=1)
+            else:
+                W, b, o = ri(N, K), ri(N), torch.empty(M, N, dtype=torch.int8, device=dev)
+                d = capi.W8A8Desc(M=M, N=N, K=K, batch=1, A=A.data_ptr(), B=W.data_ptr(), bias=b.data_ptr(), C=o.data_ptr(), alpha=0.0005, beta=0.02, q_min=-128, q_max=127,
+                                  bias_kind=capi.TCE_BIAS_INT8, out_kind=capi.TCE_OUT_INT8)
             sets.append((d, W, b, o))
         us = min(time_graph(lambda i, sp: capi.check(L.tce_w8a8_matmul(C.byref(sets[i % nsets][0]), sp)), 32) for _ in range(3))
         rows.append(f"{M}x{N}x{K}: {us:.2f}")
         del sets
-print(json.dumps({"lib": os.environ.get("TCE_LIB_PATH", "in-tree"), "modes": os.environ.get("W8A8_MODES", ""), "us": rows}), flush=True)
+print(json.dumps({"lib": os.environ.get("TCE_LIB_PATH", "in-tree"), "modes": os.environ.get("W8A8_MODES", ""), "out": os.environ.get("W8A8_OUT", "int8"), "us": rows}), flush=True)

@@ -60,6 +60,39 @@ __device__ __forceinline__ int8_t epilogue_i8(const W8A8Args &a, int acc, float 
     return (int8_t)(int)r;
 }
 
+// the fp32 output of one accumulator BEFORE `accumulate` (`u` = bias_term of its column)
+__device__ __forceinline__ float epilogue_f32(const W8A8Args &a, int acc, float u) {
+    float v = __fmul_rn((float)acc, a.alpha);
+    if (a.bias_kind == TCE_BIAS_FP32) v = __fadd_rn(v, u);
+    return v;
+}
+// Staged outputs (round 6): a full-width tile [rows][TN] of int8_t or float outputs, written to LDS by the lanes that hold the accumulators, leaves as 16-byte row pieces --
+// the accumulator layout gives a lane ONE column of four rows, i.e. 16 .. 64 one-element stores (and, with `accumulate`, as many dependent one-element loads) per lane.
+// fp32 with `accumulate`: C = fadd_rn(C, result), one rounding, as epilogue_store.  staged_ok: the launch-uniform part of the condition.
+__device__ __forceinline__ bool staged_ok(const W8A8Args &a, const void *Cb) {
+    return (reinterpret_cast<uintptr_t>(Cb) & 15) == 0 && (a.out_kind == TCE_OUT_INT8 ? (a.ldc & 15) == 0 : (a.ldc & 3) == 0);
+}
+template <int TN, typename T>
+__device__ __forceinline__ void flush_tile(const W8A8Args &a, void *Cb, const T *tile, int rows, int m0, int n0, int tid, int nthreads) {
+    constexpr int EPP = 16 / (int)sizeof(T), PPR = TN / EPP;  // elements per piece, pieces per row
+    for (int e = tid; e < rows * PPR; e += nthreads) {
+        const int row = e / PPR, piece = e % PPR;
+        if (m0 + row >= a.M) continue;
+        T *dst = static_cast<T *>(Cb) + (size_t)(m0 + row) * a.ldc + n0 + piece * EPP;
+        if constexpr (sizeof(T) == 4) {
+            float4_t v = *reinterpret_cast<const float4_t *>(tile + row * TN + piece * EPP);
+            if (a.accumulate) {
+                const float4_t old = *reinterpret_cast<const float4_t *>(dst);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = __fadd_rn(old[r], v[r]);
+            }
+            *reinterpret_cast<float4_t *>(dst) = v;
+        } else {
+            *reinterpret_cast<int4_t *>(dst) = *reinterpret_cast<const int4_t *>(tile + row * TN + piece * EPP);
+        }
+    }
+}
+
 // `u` = bias_term(a, n), loaded by the caller once per column (the MFMA kernel's 16 outputs per lane share two columns:
 // a bias load per element put 16 dependent memory round trips, ~10 us, behind a ~1 us contraction).
 __device__ __forceinline__ void epilogue_store(const W8A8Args &a, void *Cb, int m, int n, int acc, float u) {
@@ -265,25 +298,32 @@ __global__ __launch_bounds__(256 * KS) void w8a8_mfma_kernel(const W8A8Args a) {
         }
     }
 
-    // int8 outputs of a full-width tile leave through LDS as 16-byte row pieces (round 6): the accumulator layout gives a lane ONE column of four rows -- sixteen byte
-    // stores per lane, 16 bytes contiguous per row and instruction; staged, a row's 64 bytes leave as four lanes' dwordx4 (512 x 3072 x 768 writes 1.5 MB that way)
+    // the outputs of a full-width tile leave through LDS as 16-byte row pieces (flush_tile above; 512 x 3072 x 768 writes 1.5 MB of int8 that way)
     if constexpr (!XS) {
-        const bool packed_ok = a.out_kind == TCE_OUT_INT8 && (a.ldc & 15) == 0 && (reinterpret_cast<uintptr_t>(Cb) & 15) == 0 && (int)(blockIdx.x * 64 + 64) <= a.N;  // workgroup-uniform
-        if (packed_ok) {
+        if (staged_ok(a, Cb) && (int)(blockIdx.x * 64 + 64) <= a.N) {  // workgroup-uniform
             __syncthreads();  // (every wave of the quartet is done with its transposition slots; quartets 1.. have left)
-            int8_t *tile = reinterpret_cast<int8_t *>(lds_dyn);  // [32 * MT][64]
+            const int trow = wm * (16 * MT) + kq * 4, tcol = wn * 32 + r16;
+            if (a.out_kind == TCE_OUT_INT8) {
+                int8_t *tile = reinterpret_cast<int8_t *>(lds_dyn);  // [32 * MT][64]
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        tile[(wm * (16 * MT) + i * 16 + kq * 4 + r) * 64 + wn * 32 + j * 16 + r16] = epilogue_i8(a, acc[i][j][r], bterm[j]);
-            __syncthreads();
-            const int row = tid >> 2, piece = tid & 3;
-            const int m = blockIdx.y * (32 * MT) + row;
-            if (row < 32 * MT && m < a.M)
-                *reinterpret_cast<int4_t *>(static_cast<int8_t *>(Cb) + (size_t)m * a.ldc + blockIdx.x * 64 + piece * 16) = *reinterpret_cast<const int4_t *>(tile + row * 64 + piece * 16);
+                        for (int r = 0; r < 4; ++r) tile[(trow + i * 16 + r) * 64 + tcol + j * 16] = epilogue_i8(a, acc[i][j][r], bterm[j]);
+                __syncthreads();
+                flush_tile<64>(a, Cb, tile, 32 * MT, (int)blockIdx.y * (32 * MT), (int)blockIdx.x * 64, tid & 255, 256);
+            } else {
+                float *tile = reinterpret_cast<float *>(lds_dyn);  // [32 * MT][64]: 16 KiB, the first quartet's slots
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) tile[(trow + i * 16 + r) * 64 + tcol + j * 16] = epilogue_f32(a, acc[i][j][r], bterm[j]);
+                __syncthreads();
+                flush_tile<64>(a, Cb, tile, 32 * MT, (int)blockIdx.y * (32 * MT), (int)blockIdx.x * 64, tid & 255, 256);
+            }
             return;
         }
     }
@@ -418,23 +458,32 @@ __global__ __launch_bounds__(64 * W) void w8a8_kslice_kernel(const W8A8Args a) {
     // position = [MFMA tile i * TN16 + j][lane]: D[row = 4 * (lane >> 4) + r][col = lane & 15]
     // int8 outputs of a full-width tile leave through LDS as 16-byte row pieces (as in w8a8_mfma_kernel)
     constexpr int TNB = 16 * TN16;
-    const bool packed_ok = a.out_kind == TCE_OUT_INT8 && (a.ldc & 15) == 0 && (reinterpret_cast<uintptr_t>(Cb) & 15) == 0 && n_base + TNB <= a.N && m_base + 16 < a.M;  // workgroup-uniform (a tile of at most 16 live rows: the two extra barriers cost more than the stores save -- 16 x 768 x 3072 6.47 -> 6.65 us)
-    if (packed_ok) {
+    if (staged_ok(a, Cb) && n_base + TNB <= a.N && m_base + 16 < a.M) {  // workgroup-uniform (a tile of at most 16 live rows: the two extra barriers cost more than the stores save -- 16 x 768 x 3072 6.47 -> 6.65 us)
         __syncthreads();  // every thread has taken its sums
-        int8_t *tile = reinterpret_cast<int8_t *>(lds_ks);  // [16 TM16][TNB]
+        if (a.out_kind == TCE_OUT_INT8) {
+            int8_t *tile = reinterpret_cast<int8_t *>(lds_ks);  // [16 TM16][TNB]
 #pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            const int pos = tid + q * 64 * W;
-            if (pos >= TILE4) break;
-            const int t = pos >> 6, l = pos & 63;
+            for (int q = 0; q < NP; ++q) {
+                const int pos = tid + q * 64 * W;
+                if (pos >= TILE4) break;
+                const int t = pos >> 6, l = pos & 63;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) tile[((t / TN16) * 16 + (l >> 4) * 4 + r) * TNB + (t % TN16) * 16 + (l & 15)] = epilogue_i8(a, sum[q][r], bterm[q]);
-        }
-        __syncthreads();
-        for (int e = tid; e < 16 * TM16 * TN16; e += 64 * W) {
-            const int row = e / TN16, piece = e % TN16;
-            if (m_base + row < a.M)
-                *reinterpret_cast<int4_t *>(static_cast<int8_t *>(Cb) + (size_t)(m_base + row) * a.ldc + n_base + piece * 16) = *reinterpret_cast<const int4_t *>(tile + row * TNB + piece * 16);
+                for (int r = 0; r < 4; ++r) tile[((t / TN16) * 16 + (l >> 4) * 4 + r) * TNB + (t % TN16) * 16 + (l & 15)] = epilogue_i8(a, sum[q][r], bterm[q]);
+            }
+            __syncthreads();
+            flush_tile<TNB>(a, Cb, tile, 16 * TM16, m_base, n_base, tid, 64 * W);
+        } else {
+            float *tile = reinterpret_cast<float *>(lds_ks);  // [16 TM16][TNB]: at most 16 KiB
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const int pos = tid + q * 64 * W;
+                if (pos >= TILE4) break;
+                const int t = pos >> 6, l = pos & 63;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tile[((t / TN16) * 16 + (l >> 4) * 4 + r) * TNB + (t % TN16) * 16 + (l & 15)] = epilogue_f32(a, sum[q][r], bterm[q]);
+            }
+            __syncthreads();
+            flush_tile<TNB>(a, Cb, tile, 16 * TM16, m_base, n_base, tid, 64 * W);
         }
         return;
     }
@@ -560,20 +609,30 @@ __global__ __launch_bounds__(256 * KS) void w8a8_mfma_deep_kernel(const W8A8Args
         bterm[j] = bias_term(a, nn < a.N ? nn : a.N - 1);
     }
     // int8 outputs of a full-width tile leave through LDS as 16-byte row pieces (as in w8a8_mfma_kernel)
-    const bool packed_ok = a.out_kind == TCE_OUT_INT8 && (a.ldc & 15) == 0 && (reinterpret_cast<uintptr_t>(Cb) & 15) == 0 && n_tile + 64 <= a.N;  // workgroup-uniform
-    if (packed_ok) {
+    if (staged_ok(a, Cb) && n_tile + 64 <= a.N) {  // workgroup-uniform
         lds_barrier();  // (every wave of the quartet is done with the stages / the exchange; quartets 1.. have left)
-        int8_t *tile = reinterpret_cast<int8_t *>(lds_deep);  // [64][64]
+        const int trow = wm * 32 + kq * 4, tcol = wn * 32 + r16;
+        if (a.out_kind == TCE_OUT_INT8) {
+            int8_t *tile = reinterpret_cast<int8_t *>(lds_deep);  // [64][64]
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) tile[(wm * 32 + i * 16 + kq * 4 + r) * 64 + wn * 32 + j * 16 + r16] = epilogue_i8(a, acc[i][j][r], bterm[j]);
-        lds_barrier();
-        const int row = tid >> 2, piece = tid & 3;
-        if (m_tile + row < a.M)
-            *reinterpret_cast<int4_t *>(static_cast<int8_t *>(Cb) + (size_t)(m_tile + row) * a.ldc + n_tile + piece * 16) = *reinterpret_cast<const int4_t *>(tile + row * 64 + piece * 16);
+                    for (int r = 0; r < 4; ++r) tile[(trow + i * 16 + r) * 64 + tcol + j * 16] = epilogue_i8(a, acc[i][j][r], bterm[j]);
+            lds_barrier();
+            flush_tile<64>(a, Cb, tile, 64, m_tile, n_tile, tid, 256);
+        } else {
+            float *tile = reinterpret_cast<float *>(lds_deep);  // [64][64]: 16 KiB, one quartet's stages
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tile[(trow + i * 16 + r) * 64 + tcol + j * 16] = epilogue_f32(a, acc[i][j][r], bterm[j]);
+            lds_barrier();
+            flush_tile<64>(a, Cb, tile, 64, m_tile, n_tile, tid, 256);
+        }
         return;
     }
 #pragma unroll
@@ -718,23 +777,36 @@ __global__ __launch_bounds__(256 * KS) void w8a8_mfma_big_kernel(const W8A8Args 
         bterm[j] = bias_term(a, n < a.N ? n : a.N - 1);
     }
     // int8 outputs of a full-width tile leave through LDS as 16-byte row pieces (as in w8a8_mfma_kernel: the accumulator layout gives a lane one column of four rows)
-    const bool packed_ok = a.out_kind == TCE_OUT_INT8 && (a.ldc & 15) == 0 && (reinterpret_cast<uintptr_t>(Cb) & 15) == 0 && n_tile + TN <= a.N;  // workgroup-uniform
-    if (packed_ok) {
+    if (staged_ok(a, Cb) && n_tile + TN <= a.N) {  // workgroup-uniform
         lds_barrier();  // (every wave of the quartet is done with the ring / the exchange; quartets 1.. have left)
-        int8_t *tile = reinterpret_cast<int8_t *>(lds_all);  // [TM][TN]
+        const int tcol = wn * (TN / 2) + r16;
+        if (a.out_kind == TCE_OUT_INT8) {
+            int8_t *tile = reinterpret_cast<int8_t *>(lds_all);  // [TM][TN]
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    tile[(wm * 64 + i * 16 + kq * 4 + r) * TN + wn * (TN / 2) + j * 16 + r16] = epilogue_i8(a, acc[i][j][r], bterm[j]);
-        lds_barrier();
-        constexpr int PPR = TN / 16;  // 16-byte pieces per row
-        for (int e = tid; e < TM * PPR; e += 256) {
-            const int row = e / PPR, piece = e % PPR;
-            if (m_tile + row < a.M)
-                *reinterpret_cast<int4_t *>(static_cast<int8_t *>(Cb) + (size_t)(m_tile + row) * a.ldc + n_tile + piece * 16) = *reinterpret_cast<const int4_t *>(tile + row * TN + piece * 16);
+                    for (int r = 0; r < 4; ++r) tile[(wm * 64 + i * 16 + kq * 4 + r) * TN + tcol + j * 16] = epilogue_i8(a, acc[i][j][r], bterm[j]);
+            lds_barrier();
+            flush_tile<TN>(a, Cb, tile, TM, m_tile, n_tile, tid, 256);
+        } else {
+            // fp32: the tile's two 64-row halves one after the other (64 x TN floats: 32 KiB of the ring's 48)
+            float *tile = reinterpret_cast<float *>(lds_all);  // [64][TN]
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (h) lds_barrier();  // the first half has been read
+                if (wm == h) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) tile[(i * 16 + kq * 4 + r) * TN + tcol + j * 16] = epilogue_f32(a, acc[i][j][r], bterm[j]);
+                }
+                lds_barrier();
+                flush_tile<TN>(a, Cb, tile, 64, m_tile + 64 * h, n_tile, tid, 256);
+            }
         }
         return;
     }
