@@ -23,8 +23,10 @@ for (M, N, K) in SHAPES:
     nset = max(3, int(400e6 // (N * K // 2)))
     lins = [Linear_half_int4.from_float(torch.empty(N, K, device=dev).normal_(0, 0.02, generator=g), 128).prepack() for _ in range(nset)]
     x = torch.empty(M, K, device=dev).normal_(0, 1, generator=g).to(torch.float16)
-    out = torch.empty(M, N, dtype=torch.float16, device=dev)
-    descs = [l.desc(x, out, flags=capi.TCE_W4_ZERO_POINT_IS_8) if os.environ.get("PK_Z8", "1") == "1" else l.desc(x, out) for l in lins]; it = [0]
+    pairs = os.environ.get("PK_PAIRS", "0") == "1"  # the gate / up rows interleaved, SiLU * mul in the epilogue: C is [M][N / 2]
+    out = torch.empty(M, N // 2 if pairs else N, dtype=torch.float16, device=dev)
+    fl = (capi.TCE_W4_ZERO_POINT_IS_8 if os.environ.get("PK_Z8", "1") == "1" else 0) | (capi.TCE_W4_SILU_MUL_PAIRS if pairs else 0)
+    descs = [l.desc(x, out, flags=fl) for l in lins]; it = [0]
     def run():
         capi.check(capi.w4a16_forward(descs[it[0] % nset], st)); it[0] += 1
     us = timed(run)

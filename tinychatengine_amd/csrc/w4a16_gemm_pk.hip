@@ -1002,6 +1002,10 @@ __device__ __forceinline__ void w4a16_gemm_pk_body(const PkGemmArgs &g) {
         const half8_t v = *reinterpret_cast<const half8_t *>(lds_c + row * BN + pc * 8);
         if (g.pairs) {  // interleaved gate / up columns: the fp16 values the two linears would have stored, then SiLuMul_half (Int4llamaDecoderLayer.cu:20-30, 96-102)
             half_t *c2 = g.C + (size_t)m * g.ldc + (n >> 1);
+            if (n + 8 <= g.N && (g.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 7) == 0) {  // one 8-byte store for the piece's four outputs (round 6: four 2-byte stores until now)
+                *reinterpret_cast<half4_t *>(c2) = half4_t{silu_mul_half(v[0], v[1]), silu_mul_half(v[2], v[3]), silu_mul_half(v[4], v[5]), silu_mul_half(v[6], v[7])};
+                continue;
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if (n + 2 * u + 1 < g.N) c2[u] = silu_mul_half(v[2 * u], v[2 * u + 1]);
