@@ -192,6 +192,10 @@ def test_w8a8_dispatch_rules():
     assert f(d(512, 4096, 4096)) == "w8a8 k-slice tile=64x64 waves=4 workgroups=512"    # OPT-6.7B widths at 512 rows: 512 tiles x 64 k-steps (until round 6 the deep-pipeline tile)
     assert f(d(512, 4096, 2048)) == "w8a8 tile=128x64 quartets=2" and f(d(1024, 4096, 8192)) == "w8a8 tile=128x128 quartets=2"  # (the 128-row tiles keep what round 3 / 4 gave them)
     assert f(d(2048, 4096, 4096)) == "w8a8 tile=128x128 quartets=1" and f(d(512, 16384, 4096)) == "w8a8 tile=128x128 quartets=1"  # the 128-row tiles
+    # 128 x 64 tiles from 384 of them on (round 6: 1024 x 3072 x 768 12.1 -> 9.7 us); one quartet under 32 k-steps, two from there on while they are fewer than 512
+    assert f(d(1024, 3072, 768)) == "w8a8 tile=128x64 quartets=1" and f(d(640, 5120, 1280)) == "w8a8 tile=128x64 quartets=1"
+    assert f(d(768, 4096, 4096)) == "w8a8 tile=128x64 quartets=2" and f(d(1024, 3072, 8192)) == "w8a8 tile=128x64 quartets=2"
+    assert f(d(512, 8192, 2048)) == "w8a8 tile=128x64 quartets=1"                       # 512 tiles: one quartet, as before
     assert f(d(512, 512, 64, batch=12)) == "w8a8 tile=64x64 quartets=1"                # the attention BMMs: one k-step
     assert f(d(512, 64, 512, batch=12)).startswith("w8a8 tile=64x64 quartets=")        # eight k-steps: under the k-slice rule's twelve
     assert f(d(40, 33, 50)) == "w8a8 generic (one output per thread)"                   # K % 16 != 0

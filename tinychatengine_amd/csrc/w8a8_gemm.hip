@@ -1034,7 +1034,8 @@ int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err,
         hipLaunchKernelGGL(w8a8_rowdot_kernel<1>, dim3((unsigned)((outs + 3) / 4), 1, d.batch), dim3(256), 0, stream, a);
     } else if (!d.b_per_row && aligned && d.K % 64 == 0 && d.K >= 256 && g_w8a8_big != 9 &&
                ((g_w8a8_big >= 1 && g_w8a8_big <= 4) || (long)((d.M + 127) / 128) * ((d.N + 63) / 64) * d.batch >= 512 ||
-                ((long)((d.M + 127) / 128) * ((d.N + 63) / 64) * d.batch >= 256 && d.K >= 2048 && d.K < 4096))) {  // (round 4: from 64 k-steps on the 64 x 64 deep-pipeline kernel is level or ahead at one tile per CU -- 512 x 4096 x 16384: 83 -> 78 us -- and far ahead where M leaves most of a 128-row tile empty: 16 x 16384 x 4096 23.2 -> 16.6)
+                ((long)((d.M + 127) / 128) * ((d.N + 63) / 64) * d.batch >= 256 && d.K >= 2048 && d.K < 4096) ||
+                (long)((d.M + 127) / 128) * ((d.N + 63) / 64) * d.batch >= 384)) {  // (round 6: from 384 tiles of 128 x 64 on -- 1024 x 3072 x 768 12.1 -> 9.7 us, 640 x 5120 x 1280 19.6 -> 13.7, 1024 x 3584 x 1024 15.4 -> 11.0, 768 x 4096 x 4096 36.5 -> 32.2; never behind the 64 x 64 kernels on nine launches: profiles/r6/w8a8_kslice_ab.jsonl)  // (round 4: from 64 k-steps on the 64 x 64 deep-pipeline kernel is level or ahead at one tile per CU -- 512 x 4096 x 16384: 83 -> 78 us -- and far ahead where M leaves most of a 128-row tile empty: 16 x 16384 x 4096 23.2 -> 16.6)
         // prefill-sized (scripts/w8a8_gemm_sizes.py, profiles/r3/w8a8_gemm_sizes.jsonl; never slower than the 64 x 64 kernel on the 18 shapes measured):
         // 128 x 128 tiles from two per CU on (512 x 16384 x 4096: 149 -> 57 us; 2048 x 4096 x 4096: 131 -> 56), 128 x 64 tiles from two per CU on
         // (512 x 8192 x 2048: 32 -> 24), from one per CU on with TWO quartets per tile when K is long (512 x 4096 x 4096: 38 -> 29; 512 x 4096 x 16384: 124 -> 85),
@@ -1044,7 +1045,7 @@ int launch_w8a8(const tce_w8a8_desc &d, hipStream_t stream, hipError_t *hip_err,
         // (round 4: one 128 x 128 tile per CU with two quartets on half of K each beats the 128 x 64 tiles when K is long -- 2048 x 2048 x 8192: 71.8 -> 64.4 us)
         const bool long_k_one_per_cu = g_w8a8_big == 0 && t128 >= 256 && t128 < 512 && d.K >= 8192;
         const bool wide = g_w8a8_big == 1 || g_w8a8_big == 3 || (g_w8a8_big == 0 && t128 >= 512) || long_k_one_per_cu;
-        const bool split = g_w8a8_big == 3 || g_w8a8_big == 4 || (g_w8a8_big == 0 && !wide && t64 < 512) || long_k_one_per_cu;
+        const bool split = g_w8a8_big == 3 || g_w8a8_big == 4 || (g_w8a8_big == 0 && !wide && t64 < 512 && d.K >= 2048) || long_k_one_per_cu;  // (chains under 32 k-steps: one quartet -- 1024 x 3072 x 768 9.7 us against 10.9 with two)
         const size_t ring = (size_t)3 * (128 + (wide ? 128 : 64)) * 4 * 16;
         const size_t lds = split ? ((2 * ring > (size_t)(wide ? 16 : 8) * 256 * 16) ? 2 * ring : (size_t)(wide ? 16 : 8) * 256 * 16) : ring;
         const dim3 grid((d.N + (wide ? 127 : 63)) / (wide ? 128 : 64), (d.M + 127) / 128, d.batch);
