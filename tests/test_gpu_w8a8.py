@@ -498,6 +498,8 @@ def test_opt_decoder_layer_against_the_oracle_composition(dev, oracle, embed, he
                                                           # batch, `accumulate`: ldc a multiple of 16 (row pieces of 16 bytes) and not (byte stores), N ragged against the 48 / 64-wide tiles
                                                           (200, 260, 832, 19304, 896, 960, 304, 2), (200, 260, 832, 19404, 896, 960, 300, 2), (200, 260, 832, 19904, 896, 960, 304, 3),
                                                           (70, 192, 1024, 19304, 0, 0, 208, 1), (70, 192, 1024, 19404, 0, 0, 0, 2), (40, 64, 1024, 19000, 1040, 0, 768, 12),
+                                                          # a row pitch no 16-byte piece fits (301: both output kinds take the one-element stores), every family
+                                                          (200, 260, 832, 19304, 896, 960, 301, 2), (200, 260, 832, 19001, 896, 960, 301, 2), (300, 2100, 1024, 76, 0, 0, 2101, 1),
                                                           # the 64 x 64 quartet kernel's staged stores (19001: the k-slice forms off)
                                                           (200, 260, 832, 19001, 896, 960, 304, 2), (512, 768, 768, 19001, 0, 0, 0, 1)])
 def test_w8a8_large_tiles_bit_exact(dev, oracle, M, N, K, mode, lda, ldb, ldc, batch):
